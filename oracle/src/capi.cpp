@@ -1,0 +1,271 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see types.hpp header).
+//
+// Flat C API over the oracle so tests (ctypes) and bench.py's cpu_baseline leg
+// can drive it.  Nothing in fidget_amd/ links or loads this library.
+#include <chrono>
+
+#include "render.hpp"
+
+namespace orc {
+thread_local uint64_t g_invalid_intervals = 0;
+}
+using namespace orc;
+
+struct OrcShape {
+    VmDataP d;
+};
+
+extern "C" {
+
+// ---- Context -------------------------------------------------------------
+void* orc_ctx_new() { return new Context(); }
+void orc_ctx_free(void* c) { delete (Context*)c; }
+uint32_t orc_ctx_len(void* c) { return (uint32_t)((Context*)c)->len(); }
+uint32_t orc_ctx_x(void* c) { return ((Context*)c)->x(); }
+uint32_t orc_ctx_y(void* c) { return ((Context*)c)->y(); }
+uint32_t orc_ctx_z(void* c) { return ((Context*)c)->z(); }
+uint32_t orc_ctx_var(void* c, uint64_t index) { return ((Context*)c)->var(Var{3, index}); }
+uint32_t orc_ctx_constant(void* c, float f) { return ((Context*)c)->constant(f); }
+// opcode numbering = UnaryOpcode / BinaryOpcode declaration order (context/op.rs)
+uint32_t orc_ctx_unary(void* c, int op, uint32_t a) {
+    Context* x = (Context*)c;
+    switch ((UnaryOpcode)op) {
+        case U_NEG: return x->neg(a);
+        case U_ABS: return x->abs(a);
+        case U_RECIP: return x->recip(a);
+        case U_SQRT: return x->sqrt(a);
+        case U_SQUARE: return x->square(a);
+        case U_FLOOR: return x->floor(a);
+        case U_CEIL: return x->ceil(a);
+        case U_ROUND: return x->round(a);
+        case U_SIN: return x->sin(a);
+        case U_COS: return x->cos(a);
+        case U_TAN: return x->tan(a);
+        case U_ASIN: return x->asin(a);
+        case U_ACOS: return x->acos(a);
+        case U_ATAN: return x->atan(a);
+        case U_EXP: return x->exp(a);
+        case U_LN: return x->ln(a);
+        case U_NOT: return x->not_(a);
+        case U_RAND: return x->rand(a);
+    }
+    return BAD_NODE;
+}
+uint32_t orc_ctx_binary(void* c, int op, uint32_t a, uint32_t b) {
+    Context* x = (Context*)c;
+    switch ((BinaryOpcode)op) {
+        case B_ADD: return x->add(a, b);
+        case B_SUB: return x->sub(a, b);
+        case B_MUL: return x->mul(a, b);
+        case B_DIV: return x->div(a, b);
+        case B_ATAN: return x->atan2(a, b);
+        case B_MIN: return x->min(a, b);
+        case B_MAX: return x->max(a, b);
+        case B_COMPARE: return x->compare(a, b);
+        case B_MOD: return x->modulo(a, b);
+        case B_AND: return x->and_(a, b);
+        case B_OR: return x->or_(a, b);
+        case B_MIX: return x->mix(a, b);
+    }
+    return BAD_NODE;
+}
+uint32_t orc_ctx_less_than(void* c, uint32_t a, uint32_t b) { return ((Context*)c)->less_than(a, b); }
+uint32_t orc_ctx_less_than_or_equal(void* c, uint32_t a, uint32_t b) { return ((Context*)c)->less_than_or_equal(a, b); }
+uint32_t orc_ctx_if_nonzero_else(void* c, uint32_t q, uint32_t a, uint32_t b) { return ((Context*)c)->if_nonzero_else(q, a, b); }
+// Returns the root node or 0xFFFFFFFF on a parse error
+uint32_t orc_ctx_from_text(void* c, const char* text) {
+    try {
+        return Context::from_text(*(Context*)c, std::string(text));
+    } catch (const std::exception& e) {
+        fprintf(stderr, "oracle: from_text: %s\n", e.what());
+        return BAD_NODE;
+    }
+}
+// Context::eval_xyz-like scalar evaluation (context/mod.rs:798-856)
+float orc_ctx_eval_xyz(void* c, uint32_t root, float x, float y, float z) {
+    Context* ctx = (Context*)c;
+    std::vector<float> cache(ctx->len(), 0.0f);
+    std::vector<uint8_t> done(ctx->len(), 0);
+    // nodes are created children-first, so a forward sweep is a valid order
+    for (uint32_t i = 0; i <= root && i < ctx->len(); i++) {
+        const NodeOp& o = ctx->ops[i];
+        switch (o.kind) {
+            case N_INPUT: cache[i] = o.var.kind == 0 ? x : o.var.kind == 1 ? y : o.var.kind == 2 ? z : NANF; break;
+            case N_CONST: cache[i] = o.c; break;
+            case N_UNARY: cache[i] = eval_unary((UnaryOpcode)o.opcode, cache[o.a]); break;
+            case N_BINARY: cache[i] = eval_binary((BinaryOpcode)o.opcode, cache[o.a], cache[o.b]); break;
+        }
+    }
+    return cache[root];
+}
+
+// ---- Shapes (VmData) -------------------------------------------------------
+void* orc_shape_new(void* c, const uint32_t* roots, int n_roots, uint32_t n_regs) {
+    std::vector<Node> r(roots, roots + n_roots);
+    VmDataP d = vmdata_new(*(Context*)c, r, n_regs);
+    if (!d) return nullptr;
+    return new OrcShape{d};
+}
+void orc_shape_free(void* s) { delete (OrcShape*)s; }
+uint32_t orc_shape_len(void* s) { return (uint32_t)((OrcShape*)s)->d->len(); }
+uint32_t orc_shape_ssa_len(void* s) { return (uint32_t)((OrcShape*)s)->d->ssa.tape.size(); }
+uint32_t orc_shape_choice_count(void* s) { return (uint32_t)((OrcShape*)s)->d->choice_count(); }
+uint32_t orc_shape_output_count(void* s) { return (uint32_t)((OrcShape*)s)->d->output_count(); }
+uint32_t orc_shape_slot_count(void* s) { return (uint32_t)((OrcShape*)s)->d->slot_count(); }
+uint32_t orc_shape_var_count(void* s) { return (uint32_t)((OrcShape*)s)->d->vars->len(); }
+// index of X/Y/Z (axis 0..2) in the variable list, or -1
+int orc_shape_axis_index(void* s, int axis) {
+    const VarMap& v = *((OrcShape*)s)->d->vars;
+    return axis == 0 ? v.x : axis == 1 ? v.y : v.z;
+}
+int orc_shape_var_index(void* s, uint64_t index) { return ((OrcShape*)s)->d->vars->get(Var{3, index}); }
+
+// Dump a tape as 6 x u32 records: {op, form, out, a, b, idx} + imm bits in a
+// parallel array.  which = 0: SSA tape (root first); 1: register tape in
+// evaluation order (iter_asm).
+uint32_t orc_shape_dump(void* s, int which, uint32_t* rec, uint32_t* imm, uint32_t cap) {
+    const VmData& d = *((OrcShape*)s)->d;
+    const std::vector<TOp>& t = which == 0 ? d.ssa.tape : d.asm_.tape;
+    uint32_t n = (uint32_t)t.size();
+    for (uint32_t i = 0; i < n && i < cap; i++) {
+        const TOp& o = which == 0 ? t[i] : t[n - 1 - i];
+        rec[i * 6 + 0] = o.op; rec[i * 6 + 1] = o.form; rec[i * 6 + 2] = o.out;
+        rec[i * 6 + 3] = o.a; rec[i * 6 + 4] = o.b; rec[i * 6 + 5] = o.idx;
+        imm[i] = f2u(o.imm);
+    }
+    return n;
+}
+
+void* orc_shape_simplify(void* s, const uint8_t* choices, uint32_t n, uint32_t n_regs) {
+    VmDataP d = vmdata_simplify(*((OrcShape*)s)->d, choices, n, n_regs);
+    if (!d) return nullptr;  // BadChoiceSlice
+    return new OrcShape{d};
+}
+
+// Bytecode::new; returns number of words (call with cap=0 to size)
+uint32_t orc_shape_bytecode(void* s, uint32_t* words, uint32_t cap, uint32_t* reg_count, uint32_t* mem_count) {
+    Bytecode bc = bytecode_new(*((OrcShape*)s)->d);
+    if (bc.reserved_register) return 0;
+    if (reg_count) *reg_count = bc.reg_count;
+    if (mem_count) *mem_count = bc.mem_count;
+    for (uint32_t i = 0; i < bc.data.size() && i < cap; i++) words[i] = bc.data[i];
+    return (uint32_t)bc.data.size();
+}
+
+// ---- Evaluators ------------------------------------------------------------
+// Interval tracing eval: vars = nvars x {lo,hi}; out = output_count x {lo,hi};
+// choices = choice_count bytes.  Returns 1 if a trace is reported, 0 if not,
+// -1 on BadVarSlice.
+int orc_eval_interval(void* s, const float* vars, uint32_t nvars, float* out, uint8_t* choices) {
+    const VmData& d = *((OrcShape*)s)->d;
+    TracingEval<Interval> e;
+    std::vector<Interval> v(nvars);
+    for (uint32_t i = 0; i < nvars; i++) { v[i].lo = vars[2 * i]; v[i].hi = vars[2 * i + 1]; }
+    int r = e.eval(d, v.data(), nvars);
+    if (r < 0) return r;
+    for (size_t i = 0; i < e.out.size(); i++) { out[2 * i] = e.out[i].lo; out[2 * i + 1] = e.out[i].hi; }
+    if (choices) std::memcpy(choices, e.choices.data(), e.choices.size());
+    return r;
+}
+int orc_eval_point(void* s, const float* vars, uint32_t nvars, float* out, uint8_t* choices) {
+    const VmData& d = *((OrcShape*)s)->d;
+    TracingEval<float> e;
+    int r = e.eval(d, vars, nvars);
+    if (r < 0) return r;
+    for (size_t i = 0; i < e.out.size(); i++) out[i] = e.out[i];
+    if (choices) std::memcpy(choices, e.choices.data(), e.choices.size());
+    return r;
+}
+// Bulk f32: vars[i] -> n floats; out = output_count x n (output-major).
+// Returns -1 BadVarSlice.
+int orc_eval_float_slice(void* s, const float* const* vars, uint32_t nvars, uint32_t n, float* out) {
+    const VmData& d = *((OrcShape*)s)->d;
+    BulkEval<float> e;
+    int r = e.eval(d, vars, nvars, n);
+    if (r < 0) return r;
+    for (size_t o = 0; o < e.out.size(); o++) std::memcpy(out + o * n, e.out[o].data(), n * 4);
+    return 0;
+}
+// Bulk grad: vars[i] -> n x {v,dx,dy,dz}
+int orc_eval_grad_slice(void* s, const float* const* vars, uint32_t nvars, uint32_t n, float* out) {
+    const VmData& d = *((OrcShape*)s)->d;
+    BulkEval<Grad> e;
+    std::vector<const Grad*> v(nvars);
+    for (uint32_t i = 0; i < nvars; i++) v[i] = (const Grad*)vars[i];
+    int r = e.eval(d, v.data(), nvars, n);
+    if (r < 0) return r;
+    for (size_t o = 0; o < e.out.size(); o++) std::memcpy(out + o * n * 4, e.out[o].data(), n * 16);
+    return 0;
+}
+uint64_t orc_invalid_intervals() { return g_invalid_intervals; }
+void orc_reset_invalid_intervals() { g_invalid_intervals = 0; }
+
+// ---- Geometry ----------------------------------------------------------------
+// screen_to_world for 2D (3x3, size = {w,h}) or 3D (4x4, size = {w,h,d})
+void orc_screen_to_world(const uint32_t* size, int n, float* out) { screen_to_world(size, n, out); }
+void orc_mat_mul(const float* a, const float* b, int dim, float* out) { mat_mul(a, b, dim, out); }
+void orc_transform_point(const float* mat4, float x, float y, float z, float* out) {
+    Mat4 m;
+    std::memcpy(m.m, mat4, 64);
+    transform_f32(m, x, y, z, out, out + 1, out + 2);
+}
+void orc_transform_interval(const float* mat4, const float* xyz /*3x{lo,hi}*/, float* out /*3x{lo,hi}*/) {
+    Mat4 m;
+    std::memcpy(m.m, mat4, 64);
+    Interval o[3];
+    transform_interval(m, Interval(xyz[0], xyz[1]), Interval(xyz[2], xyz[3]), Interval(xyz[4], xyz[5]), o);
+    for (int i = 0; i < 3; i++) { out[2 * i] = o[i].lo; out[2 * i + 1] = o[i].hi; }
+}
+
+// ---- Renders -----------------------------------------------------------------
+// stats: array of sizeof(RenderStats)/8 uint64 (see orc_stats_names)
+static const char* STATS_NAMES =
+    "interval_evals,interval_ops,interval_choices,simplify_calls,simplify_in,simplify_out,simplify_kept,"
+    "tiles_full,tiles_empty,tiles_ambiguous,tiles_skipped,float_evals,float_points,float_lane_ops,"
+    "float_wave_ops,grad_evals,grad_points,grad_lane_ops,grad_tape_ops,invalid_intervals";
+const char* orc_stats_names() { return STATS_NAMES; }
+uint32_t orc_stats_count() { return (uint32_t)(sizeof(RenderStats) / 8); }
+
+// world_to_model: row-major 3x3 (may be NULL = identity).  Returns 0 ok, -1 unbound vars.
+int orc_render2d(void* s, const float* world_to_model, uint32_t w, uint32_t h, float z, int pixel_perfect,
+                 const uint32_t* tiles, uint32_t n_tiles, int mode, int threads, float* out, uint64_t* stats,
+                 double* seconds) {
+    uint32_t size[2] = {w, h};
+    float s2w[9], mat[9];
+    screen_to_world(size, 2, s2w);
+    if (world_to_model) mat_mul(world_to_model, s2w, 3, mat);
+    else {
+        const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        mat_mul(I, s2w, 3, mat);
+    }
+    std::vector<uint32_t> ts(tiles, tiles + n_tiles);
+    auto t0 = std::chrono::steady_clock::now();
+    RenderResult r = render_2d(((OrcShape*)s)->d, mat, w, h, z, pixel_perfect != 0, ts, mode, threads, out);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));
+    return r.ok ? 0 : -1;
+}
+// world_to_model: row-major 4x4 (may be NULL).  out = w*h GeometryPixel {f32 normal[3]; u32 depth}
+int orc_render3d(void* s, const float* world_to_model, uint32_t w, uint32_t h, uint32_t d, const uint32_t* tiles,
+                 uint32_t n_tiles, int mode, int threads, void* out, uint64_t* stats, double* seconds) {
+    uint32_t size[3] = {w, h, d};
+    float s2w[16], mat[16];
+    screen_to_world(size, 3, s2w);
+    if (world_to_model) mat_mul(world_to_model, s2w, 4, mat);
+    else {
+        const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        mat_mul(I, s2w, 4, mat);
+    }
+    std::vector<uint32_t> ts(tiles, tiles + n_tiles);
+    auto t0 = std::chrono::steady_clock::now();
+    RenderResult r = render_3d(((OrcShape*)s)->d, mat, w, h, d, ts, mode, threads, (GeometryPixel*)out);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));
+    return r.ok ? 0 : -1;
+}
+
+int orc_max_threads() { return omp_get_max_threads(); }
+
+}  // extern "C"
