@@ -96,8 +96,8 @@ def lib():
             "orc_transform_interval": (None, [vp, vp, vp]),
             "orc_stats_names": (C.c_char_p, []),
             "orc_stats_count": (u32, []),
-            "orc_render2d": (i32, [vp, vp, u32, u32, f32, i32, vp, u32, i32, i32, vp, vp, vp]),
-            "orc_render3d": (i32, [vp, vp, u32, u32, u32, vp, u32, i32, i32, vp, vp, vp]),
+            "orc_render2d": (i32, [vp, vp, u32, u32, f32, i32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
+            "orc_render3d": (i32, [vp, vp, u32, u32, u32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_max_threads": (i32, []),
         }
         for name, (res, args) in sig.items():
@@ -298,6 +298,15 @@ class Shape:
         out, tr = self.eval_interval_raw(vs)
         return (float(out[0][0]), float(out[0][1])), tr
 
+    def eval_interval_batch(self, batch):
+        """batch: list of per-variable (lo, hi) lists (None = [0,0]).  Returns [((lo,hi), trace|None)]."""
+        out = []
+        for vs in batch:
+            vs = [(0.0, 0.0) if v is None else v for v in vs]
+            o, tr = self.eval_interval_raw(vs)
+            out.append(((float(o[0][0]), float(o[0][1])), tr))
+        return out
+
     def eval_point_raw(self, vars_):
         v = np.array(vars_, dtype=np.float32)
         out = np.zeros(max(self.output_count(), 1), dtype=np.float32)
@@ -403,8 +412,15 @@ def lift_2d(m3):
     return m
 
 
+def _vars(vars_):
+    vars_ = vars_ or {}
+    k = np.array(list(vars_.keys()), dtype=np.uint64)
+    v = np.array(list(vars_.values()), dtype=np.float32)
+    return k, v
+
+
 def render2d(shape, width, height=None, z=0.0, pixel_perfect=False, world_to_model=None,
-             tile_sizes=None, mode=SIMPLIFY_REFERENCE, threads=0):
+             tile_sizes=None, mode=SIMPLIFY_REFERENCE, threads=0, vars=None):
     """``fidget_raster::pixel::render``.  Returns (float32 image [h,w] of raw pixels, stats dict, seconds)."""
     height = width if height is None else height
     ts = np.array(tile_sizes or VM_TILES_2D, dtype=np.uint32)
@@ -412,8 +428,9 @@ def render2d(shape, width, height=None, z=0.0, pixel_perfect=False, world_to_mod
     stats = np.zeros(lib().orc_stats_count(), dtype=np.uint64)
     secs = C.c_double(0)
     w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    vk, vv = _vars(vars)
     r = lib().orc_render2d(shape._h, _p(w2m), width, height, z, int(pixel_perfect), _p(ts), len(ts), mode, threads,
-                           _p(out), _p(stats), C.byref(secs))
+                           _p(out), _p(stats), C.byref(secs), _p(vk), _p(vv), len(vk))
     if r != 0:
         raise ValueError("MissingVar")
     return out, dict(zip(stats_names(), (int(s) for s in stats))), secs.value
@@ -423,7 +440,7 @@ GEOMETRY_PIXEL = np.dtype([("normal", np.float32, 3), ("depth", np.uint32)])
 
 
 def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_sizes=None,
-             mode=SIMPLIFY_REFERENCE, threads=0):
+             mode=SIMPLIFY_REFERENCE, threads=0, vars=None):
     """``fidget_raster::voxel::render``.  Returns (GeometryPixel image [h,w], stats, seconds)."""
     height = width if height is None else height
     depth = width if depth is None else depth
@@ -432,8 +449,9 @@ def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_si
     stats = np.zeros(lib().orc_stats_count(), dtype=np.uint64)
     secs = C.c_double(0)
     w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    vk, vv = _vars(vars)
     r = lib().orc_render3d(shape._h, _p(w2m), width, height, depth, _p(ts), len(ts), mode, threads, _p(out),
-                           _p(stats), C.byref(secs))
+                           _p(stats), C.byref(secs), _p(vk), _p(vv), len(vk))
     if r != 0:
         raise ValueError("MissingVar")
     return out, dict(zip(stats_names(), (int(s) for s in stats))), secs.value

@@ -229,7 +229,7 @@ uint32_t orc_stats_count() { return (uint32_t)(sizeof(RenderStats) / 8); }
 // world_to_model: row-major 3x3 (may be NULL = identity).  Returns 0 ok, -1 unbound vars.
 int orc_render2d(void* s, const float* world_to_model, uint32_t w, uint32_t h, float z, int pixel_perfect,
                  const uint32_t* tiles, uint32_t n_tiles, int mode, int threads, float* out, uint64_t* stats,
-                 double* seconds) {
+                 double* seconds, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars) {
     uint32_t size[2] = {w, h};
     float s2w[9], mat[9];
     screen_to_world(size, 2, s2w);
@@ -240,7 +240,8 @@ int orc_render2d(void* s, const float* world_to_model, uint32_t w, uint32_t h, f
     }
     std::vector<uint32_t> ts(tiles, tiles + n_tiles);
     auto t0 = std::chrono::steady_clock::now();
-    RenderResult r = render_2d(((OrcShape*)s)->d, mat, w, h, z, pixel_perfect != 0, ts, mode, threads, out);
+    RenderResult r = render_2d(((OrcShape*)s)->d, mat, w, h, z, pixel_perfect != 0, ts, mode, threads, out, var_keys,
+                               var_vals, n_vars);
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));
@@ -248,7 +249,8 @@ int orc_render2d(void* s, const float* world_to_model, uint32_t w, uint32_t h, f
 }
 // world_to_model: row-major 4x4 (may be NULL).  out = w*h GeometryPixel {f32 normal[3]; u32 depth}
 int orc_render3d(void* s, const float* world_to_model, uint32_t w, uint32_t h, uint32_t d, const uint32_t* tiles,
-                 uint32_t n_tiles, int mode, int threads, void* out, uint64_t* stats, double* seconds) {
+                 uint32_t n_tiles, int mode, int threads, void* out, uint64_t* stats, double* seconds,
+                 const uint64_t* var_keys, const float* var_vals, uint32_t n_vars) {
     uint32_t size[3] = {w, h, d};
     float s2w[16], mat[16];
     screen_to_world(size, 3, s2w);
@@ -259,7 +261,8 @@ int orc_render3d(void* s, const float* world_to_model, uint32_t w, uint32_t h, u
     }
     std::vector<uint32_t> ts(tiles, tiles + n_tiles);
     auto t0 = std::chrono::steady_clock::now();
-    RenderResult r = render_3d(((OrcShape*)s)->d, mat, w, h, d, ts, mode, threads, (GeometryPixel*)out);
+    RenderResult r = render_3d(((OrcShape*)s)->d, mat, w, h, d, ts, mode, threads, (GeometryPixel*)out, var_keys,
+                               var_vals, n_vars);
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));

@@ -176,8 +176,19 @@ static inline std::vector<uint32_t> tile_sizes_ref(const std::vector<uint32_t>& 
 // Map X/Y/Z onto the tape's variable slots (shape/mod.rs:518-532, 764-774).
 struct Axes {
     int ix, iy, iz, n;
+    std::vector<std::pair<int, float>> bound;  // (slot, value) for Var::V entries (ShapeVars<f32>)
     explicit Axes(const VarMap& v) : ix(v.x), iy(v.y), iz(v.z), n(v.len()) {}
 };
+// BoundShape::new (shape/mod.rs:848-857): every Var::V must have a value
+static inline bool bind_vars(const VarMap& vm, const uint64_t* keys, const float* vals, size_t n, Axes& axes) {
+    for (auto& kv : vm.v) {
+        bool found = false;
+        for (size_t i = 0; i < n; i++)
+            if (keys[i] == kv.first) { axes.bound.push_back({kv.second, vals[i]}); found = true; break; }
+        if (!found) return false;
+    }
+    return true;
+}
 
 // ---------------------------------------------------------------------------
 // 2D (pixel.rs)
@@ -201,8 +212,10 @@ struct Worker2D {
     RenderStats st;
     std::vector<Interval> ivars;
 
-    Worker2D(const std::vector<uint32_t>& ts_, const Mat4& t, float z_, bool pp, int mode_, const VarMap& vm)
-        : ts(ts_), transform(t), z(z_), pixel_perfect(pp), mode(mode_), axes(vm) {
+    std::vector<std::vector<float>> bound_arrays;
+    Worker2D(const std::vector<uint32_t>& ts_, const Mat4& t, float z_, bool pp, int mode_, const Axes& ax)
+        : ts(ts_), transform(t), z(z_), pixel_perfect(pp), mode(mode_), axes(ax) {
+        for (auto& b : axes.bound) bound_arrays.push_back(std::vector<float>((size_t)ts.back() * ts.back(), b.second));
         size_t n = (size_t)ts.back() * ts.back();
         sx.resize(n); sy.resize(n); sz.resize(n);
         ivars.resize(std::max(axes.n, 1));
@@ -224,6 +237,7 @@ struct Worker2D {
         if (axes.ix >= 0) ivars[axes.ix] = tr[0];
         if (axes.iy >= 0) ivars[axes.iy] = tr[1];
         if (axes.iz >= 0) ivars[axes.iz] = tr[2];
+        for (auto& b : axes.bound) ivars[b.first] = Interval(b.second);
         int simplify = eval_interval.eval(*shape->shape, ivars.data(), ivars.size());
         Interval i = eval_interval.out[0];
         st.interval_evals++;
@@ -272,6 +286,7 @@ struct Worker2D {
         if (axes.ix >= 0) vars[axes.ix] = sx.data();
         if (axes.iy >= 0) vars[axes.iy] = sy.data();
         if (axes.iz >= 0) vars[axes.iz] = sz.data();
+        for (size_t q = 0; q < axes.bound.size(); q++) vars[axes.bound[q].first] = bound_arrays[q].data();
         eval_float.eval(*shape->shape, vars, nv, index);
         st.float_evals++;
         st.float_points += index;
@@ -295,9 +310,11 @@ struct RenderResult {
 // already combined by the caller (row-major 3x3).  out = width*height floats.
 static inline RenderResult render_2d(const VmDataP& shape, const float* mat3, uint32_t width, uint32_t height, float z,
                                      bool pixel_perfect, const std::vector<uint32_t>& tile_sizes, int mode,
-                                     int threads, float* out) {
+                                     int threads, float* out, const uint64_t* var_keys = nullptr,
+                                     const float* var_vals = nullptr, size_t n_vars = 0) {
     RenderResult res;
-    if (shape->vars->v.size() > 0) { res.ok = false; return res; }  // unbound Var::V
+    Axes axes(*shape->vars);
+    if (!bind_vars(*shape->vars, var_keys, var_vals, n_vars, axes)) { res.ok = false; return res; }  // MissingVar
     std::vector<uint32_t> ts = tile_sizes_ref(tile_sizes, std::max(width, height));
     const uint32_t t0 = ts[0];
     std::vector<std::pair<uint32_t, uint32_t>> tiles;
@@ -309,7 +326,7 @@ static inline RenderResult render_2d(const VmDataP& shape, const float* mat3, ui
     RenderStats total;
 #pragma omp parallel num_threads(threads)
     {
-        Worker2D w(ts, transform, z, pixel_perfect, mode, *shape->vars);
+        Worker2D w(ts, transform, z, pixel_perfect, mode, axes);
         RenderHandle rh(shape);
         g_invalid_intervals = 0;
 #pragma omp for schedule(dynamic, 1)
@@ -356,9 +373,15 @@ struct Worker3D {
     std::vector<Interval> ivars;
     RenderStats st;
 
-    Worker3D(const std::vector<uint32_t>& ts_, const Mat4& t, uint32_t depth, int mode_, const VarMap& vm)
-        : ts(ts_), transform(t), image_depth(depth), mode(mode_), axes(vm) {
+    std::vector<std::vector<float>> bound_arrays;
+    std::vector<std::vector<Grad>> bound_grads;
+    Worker3D(const std::vector<uint32_t>& ts_, const Mat4& t, uint32_t depth, int mode_, const Axes& ax)
+        : ts(ts_), transform(t), image_depth(depth), mode(mode_), axes(ax) {
         size_t b = ts.back();
+        for (auto& bv : axes.bound) {
+            bound_arrays.push_back(std::vector<float>(b * b * b, bv.second));
+            bound_grads.push_back(std::vector<Grad>(b * b, Grad(bv.second)));
+        }
         sx.resize(b * b * b); sy.resize(b * b * b); sz.resize(b * b * b); zeros.assign(b * b * b, 0.0f);
         gx.resize(b * b); gy.resize(b * b); gz.resize(b * b); gzeros.assign(b * b, Grad(0.0f));
         ivars.resize(std::max(axes.n, 1));
@@ -394,6 +417,7 @@ struct Worker3D {
         if (axes.ix >= 0) ivars[axes.ix] = tr[0];
         if (axes.iy >= 0) ivars[axes.iy] = tr[1];
         if (axes.iz >= 0) ivars[axes.iz] = tr[2];
+        for (auto& b : axes.bound) ivars[b.first] = Interval(b.second);
         int simplify = eval_interval.eval(*shape->shape, ivars.data(), ivars.size());
         Interval i = eval_interval.out[0];
         st.interval_evals++;
@@ -450,6 +474,7 @@ struct Worker3D {
         if (axes.ix >= 0) vars[axes.ix] = sx.data();
         if (axes.iy >= 0) vars[axes.iy] = sy.data();
         if (axes.iz >= 0) vars[axes.iz] = sz.data();
+        for (size_t q = 0; q < axes.bound.size(); q++) vars[axes.bound[q].first] = bound_arrays[q].data();
         eval_float.eval(*shape->shape, vars, nv, size);
         st.float_evals++;
         st.float_points += size;
@@ -484,6 +509,7 @@ struct Worker3D {
             if (axes.ix >= 0) gv[axes.ix] = gx.data();
             if (axes.iy >= 0) gv[axes.iy] = gy.data();
             if (axes.iz >= 0) gv[axes.iz] = gz.data();
+            for (size_t q = 0; q < axes.bound.size(); q++) gv[axes.bound[q].first] = bound_grads[q].data();
             eval_grad.eval(*shape->shape, gv, nv, grad);
             st.grad_evals++;
             st.grad_points += grad;
@@ -501,9 +527,11 @@ struct Worker3D {
 // voxel.rs:500-553.  `mat4` = world_to_model * screen_to_world (row-major).
 static inline RenderResult render_3d(const VmDataP& shape, const float* mat4, uint32_t width, uint32_t height,
                                      uint32_t depth, const std::vector<uint32_t>& tile_sizes, int mode, int threads,
-                                     GeometryPixel* image) {
+                                     GeometryPixel* image, const uint64_t* var_keys = nullptr,
+                                     const float* var_vals = nullptr, size_t n_vars = 0) {
     RenderResult res;
-    if (shape->vars->v.size() > 0) { res.ok = false; return res; }
+    Axes axes(*shape->vars);
+    if (!bind_vars(*shape->vars, var_keys, var_vals, n_vars, axes)) { res.ok = false; return res; }
     std::vector<uint32_t> ts = tile_sizes_ref(tile_sizes, std::max(width, height));
     const uint32_t t0 = ts[0];
     std::vector<std::pair<uint32_t, uint32_t>> tiles;
@@ -516,7 +544,7 @@ static inline RenderResult render_3d(const VmDataP& shape, const float* mat4, ui
     RenderStats total;
 #pragma omp parallel num_threads(threads)
     {
-        Worker3D w(ts, transform, depth, mode, *shape->vars);
+        Worker3D w(ts, transform, depth, mode, axes);
         RenderHandle rh(shape);
         g_invalid_intervals = 0;
 #pragma omp for schedule(dynamic, 1)

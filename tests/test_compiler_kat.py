@@ -1,0 +1,154 @@
+"""Tape-construction known-answer tests from the reference's compiler unit tests:
+  fidget-core/src/compiler/ssa_tape.rs:427-463   (tape lengths 9 / 3 / 2)
+  fidget-core/src/vm/data.rs:415-436             (spill counts when N changes 3 -> 2 -> 3)
+  fidget-bytecode/src/lib.rs:351-451             (word-exact bytecode, 255 and 2 registers)
+  fidget-core/src/vm/data.rs doc-test 47-58      (x + y register tape)
+  fidget-core/src/context/mod.rs doc-tests       (constructor identities)
+"""
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import model_path
+
+# BytecodeOp numbering, fidget-bytecode/src/lib.rs:69-104
+BC = {n: i for i, n in enumerate(
+    ["Output", "Input", "Copy", "Neg", "Abs", "Recip", "Sqrt", "Square", "Floor", "Ceil", "Round", "Not", "Rand",
+     "Sin", "Cos", "Tan", "Asin", "Acos", "Atan", "Exp", "Ln", "Add", "Sub", "Mul", "Div", "Atan2", "Compare",
+     "Mix", "Mod", "Min", "Max", "And", "Or", "Mem"])}
+
+
+def word(*b):
+    return struct.unpack("<I", bytes(b))[0]
+
+
+def test_ring(be):  # ssa_tape.rs:427-444
+    ctx = be.Context()
+    c0 = ctx.constant(0.5)
+    x, y = ctx.x(), ctx.y()
+    r = ctx.add(ctx.square(x), ctx.square(y))
+    c6 = ctx.sub(r, c0)
+    c8 = ctx.sub(ctx.constant(0.25), r)
+    c9 = ctx.max(c8, c6)
+    s = be.Shape(ctx, c9)
+    assert s.ssa_len() == 9
+    assert s.var_count() == 2
+
+
+def test_dupe(be):  # ssa_tape.rs:446-454
+    ctx = be.Context()
+    x = ctx.x()
+    s = be.Shape(ctx, ctx.mul(x, x))
+    assert s.ssa_len() == 3  # x, square, output
+    assert s.var_count() == 1
+
+
+def test_constant_tape(be):  # ssa_tape.rs:456-462
+    ctx = be.Context()
+    s = be.Shape(ctx, ctx.constant(1.5))
+    assert s.ssa_len() == 2  # CopyImm, output
+    assert s.var_count() == 0
+
+
+def test_simplify_reg_count_change(be):  # vm/data.rs:415-436
+    ctx = be.Context()
+    x, y, z = ctx.x(), ctx.y(), ctx.z()  # node creation order matters (commutative operand sort)
+    xyz = ctx.add(ctx.add(x, y), z)
+    d = be.Shape(ctx, xyz, n_regs=3)
+    assert d.size() == 6  # 3x input, 2x add, 1x output
+    assert d.simplify([], n_regs=2).size() == 8  # extra load + store
+    d = be.Shape(ctx, xyz, n_regs=2)
+    assert d.size() == 8
+    assert d.simplify([], n_regs=3).size() == 6
+
+
+def test_vmdata_doc_example(be):  # vm/data.rs:47-58
+    ctx = be.Context()
+    s = be.Shape(ctx, ctx.add(ctx.x(), ctx.y()))
+    assert s.size() == 4
+    ops = s.asm_ops()
+    ix, iy = s.axis_index(0), s.axis_index(1)
+    assert ops[0][:3] == ("Input", "", 0) and ops[0][5] == ix
+    assert ops[1][:3] == ("Input", "", 1) and ops[1][5] == iy
+    assert ops[2][:5] == ("Add", "RegReg", 0, 0, 1)
+
+
+def test_simple_bytecode(be):  # fidget-bytecode/src/lib.rs:351-378
+    ctx = be.Context()
+    s = be.Shape(ctx, ctx.add(ctx.x(), ctx.constant(1.0)))
+    w, regs, mem = s.bytecode()
+    assert list(w) == [
+        0xFFFFFFFF, 0,
+        word(BC["Input"], 0, 0xFF, 0xFF), 0,
+        word(BC["Add"], 0, 0, 0xFF), struct.unpack("<I", struct.pack("<f", 1.0))[0],
+        word(BC["Output"], 0, 0xFF, 0xFF), 0,
+        0xFFFFFFFF, 0xFFFFFFFF,
+    ]
+
+
+def test_load_store_bytecode(be):  # fidget-bytecode/src/lib.rs:380-451
+    ctx = be.Context()
+    x, y, z = ctx.x(), ctx.y(), ctx.z()
+    out = ctx.max(ctx.max(x, y), z)
+    s = be.Shape(ctx, out, n_regs=2)
+    w, regs, mem = s.bytecode()
+    assert regs == 2 and mem == 1
+    assert list(w) == [
+        0xFFFFFFFF, 0,
+        word(BC["Input"], 1, 0xFF, 0xFF), 2,      # Z
+        word(BC["Mem"], 0xFF, 1, 0xFF), 0,        # reg[1] -> mem[0]
+        word(BC["Input"], 1, 0xFF, 0xFF), 1,
+        word(BC["Input"], 0, 0xFF, 0xFF), 0,
+        word(BC["Max"], 1, 1, 0), 0xFF000000,
+        word(BC["Mem"], 0, 0xFF, 0xFF), 0,        # mem[0] -> reg[0]
+        word(BC["Max"], 0, 0, 1), 0xFF000000,
+        word(BC["Output"], 0, 0xFF, 0xFF), 0,
+        0xFFFFFFFF, 0xFFFFFFFF,
+    ]
+
+
+def test_context_identities(be):  # context/mod.rs:234-322, 344-400, 586-623 (+ doc-tests)
+    ctx = be.Context()
+    x, y = ctx.x(), ctx.y()
+    assert len(ctx) == 2
+    assert ctx.x() == x  # dedup
+    assert ctx.add(x, 0.0) == x and ctx.add(0.0, x) == x
+    assert ctx.mul(x, 1.0) == x and ctx.mul(1.0, x) == x
+    zero = ctx.constant(0.0)
+    assert ctx.mul(x, 0.0) == zero and ctx.mul(0.0, x) == zero
+    assert ctx.min(x, x) == x and ctx.max(x, x) == x
+    assert ctx.sub(x, 0.0) == x
+    assert ctx.sub(0.0, x) == ctx.neg(x)
+    assert ctx.div(x, 1.0) == x and ctx.div(0.0, x) == zero
+    assert ctx.mul(x, x) == ctx.square(x)
+    assert ctx.add(x, x) == ctx.mul(x, 2.0)
+    assert ctx.add(x, y) == ctx.add(y, x)  # commutative operands are sorted
+    assert ctx.min(x, y) == ctx.min(y, x)
+    assert ctx.and_(0.0, x) == zero and ctx.and_(2.0, x) == x
+    assert ctx.or_(2.0, x) == ctx.constant(2.0) and ctx.or_(0.0, x) == x and ctx.or_(x, 0.0) == x
+    assert ctx.add(ctx.constant(1.0), ctx.constant(2.0)) == ctx.constant(3.0)  # constant folding
+    assert ctx.constant(-0.0) == zero  # OrderedFloat: -0 == +0
+
+
+def test_from_text_circle(be):  # context/mod.rs:858-874
+    txt = """
+# This is a comment!
+0x600000b90000 var-x
+0x600000b900a0 square 0x600000b90000
+0x600000b90050 var-y
+0x600000b900f0 square 0x600000b90050
+0x600000b90140 add 0x600000b900a0 0x600000b900f0
+0x600000b90190 sqrt 0x600000b90140
+0x600000b901e0 const 1
+"""
+    ctx, _node = be.Context.from_text(txt)
+    assert len(ctx) == 7
+
+
+@pytest.mark.parametrize("name,ops,choices", [("prospero.vm", 6363, 2878), ("hi.vm", 46, 18)])
+def test_model_sizes(be, name, ops, choices):
+    # prospero = 6362 SSA ops + 1 Output, 2878 choice ops, vars {X,Y}
+    s = be.Shape.from_vm(model_path(name))
+    assert s.ssa_len() == ops and s.choice_count() == choices
+    assert s.axis_index(2) == -1 and s.var_count() == 2
