@@ -1,0 +1,623 @@
+"""fidget_amd — Python binding of libfidget_hip.so (the MI355X / gfx950 backend).
+
+Host-side mirror of the reference's user-facing surface for the evaluation hot path:
+
+    reference (Rust)                                this module
+    ---------------------------------------------   ------------------------------
+    fidget_core::Context (+ from_text)              Context
+    Shape<F> / F: Function + MathFunction           Shape (one device tape; simplify())
+    TracingEvaluator / BulkEvaluator impls          Shape.eval_interval / eval_point /
+                                                    eval_float_slice / eval_grad_slice
+    fidget_raster::pixel::render / voxel::render    render2d / render3d
+
+Everything that computes goes through the C ABI in include/fidget_hip.h (ctypes);
+there is NO CPU fallback: importing works without a GPU (so the build and symbol
+checks run anywhere), but creating a context without a HIP device raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
+_SOURCES = ["capi.hip", "kernels.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h"]
+
+UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
+         "asin", "acos", "atan", "exp", "ln", "not", "rand"]          # context/op.rs:11-30
+BINARY = ["add", "sub", "mul", "div", "atan2", "min", "max", "compare", "mod", "and", "or", "mix"]  # op.rs:35-48
+
+FH_OPS = (["Output", "Input", "CopyReg", "CopyImm"] + [u.capitalize() for u in UNARY]
+          + [b.capitalize() + "RR" for b in ["add", "sub", "mul", "div", "atan2", "compare", "mix", "mod", "min", "max", "and", "or"]]
+          + [b.capitalize() + "RI" for b in ["add", "sub", "mul", "div", "atan2", "compare", "mix", "mod", "min", "max", "and", "or"]]
+          + [b.capitalize() + "IR" for b in ["sub", "div", "atan2", "compare", "mix", "mod"]])
+
+STATUS = {1: "BadVarSlice", 2: "MismatchedSlices", 3: "BadChoiceSlice", 4: "MissingVar", 5: "BadTape",
+          6: "Unsupported", 7: "HipError", 8: "Cancelled", 9: "ParseError", 10: "Overflow"}
+
+VM_TILES_3D = [128, 64, 32, 16, 8]
+VM_TILES_2D = [128, 32, 8]
+GEOMETRY_PIXEL = np.dtype([("normal", np.float32, 3), ("depth", np.uint32)])
+
+EXPORTS = [
+    "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
+    "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
+    "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard",
+    "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
+    "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
+    "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
+    "fhip_screen_to_world",
+]
+
+
+class FidgetHipError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+
+
+def build(force=False, verbose=False):
+    """Compile libfidget_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-o", LIB_PATH, os.path.join(_CSRC, "capi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class _Cfg2D(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("world_to_model", C.c_void_p), ("z", C.c_float),
+                ("pixel_perfect", C.c_int), ("tile_sizes", C.c_void_p), ("n_tile_sizes", C.c_uint32),
+                ("var_keys", C.c_void_p), ("var_values", C.c_void_p), ("n_vars", C.c_uint32),
+                ("axis_slots", C.c_void_p)]
+
+
+class _Cfg3D(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_uint32), ("world_to_model", C.c_void_p),
+                ("tile_sizes", C.c_void_p), ("n_tile_sizes", C.c_uint32), ("var_keys", C.c_void_p),
+                ("var_values", C.c_void_p), ("n_vars", C.c_uint32), ("axis_slots", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32, f32, u64 = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint64
+        sig = {
+            "fhip_ctx_create": (i32, [i32, vp, C.POINTER(vp)]), "fhip_ctx_destroy": (None, [vp]),
+            "fhip_last_error": (C.c_char_p, [vp]), "fhip_ctx_sync": (i32, [vp]),
+            "fhip_cancel": (None, [vp]), "fhip_cancel_reset": (None, [vp]),
+            "fhip_tape_from_bytecode": (i32, [vp, vp, C.c_size_t, C.POINTER(vp)]), "fhip_tape_free": (None, [vp]),
+            "fhip_tape_len": (u32, [vp]), "fhip_tape_choice_count": (u32, [vp]), "fhip_tape_reg_count": (u32, [vp]),
+            "fhip_tape_var_count": (u32, [vp]), "fhip_tape_output_count": (u32, [vp]),
+            "fhip_tape_ops": (u32, [vp, vp, u32]),
+            "fhip_simplify": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
+            "fhip_interval_eval": (i32, [vp, vp, vp, u32, u32, vp, vp, vp]),
+            "fhip_point_eval": (i32, [vp, vp, vp, u32, u32, vp, vp, vp]),
+            "fhip_float_eval": (i32, [vp, vp, vp, vp, u32, vp]),
+            "fhip_grad_eval": (i32, [vp, vp, vp, vp, u32, vp]),
+            "fhip_render2d": (i32, [vp, vp, C.POINTER(_Cfg2D), vp, i32]),
+            "fhip_render3d": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32]),
+            "fhip_render3d_shard": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, u32]),
+            "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]),
+            "fhip_render_counters": (i32, [vp, vp]),
+            "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
+            "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
+            "fhip_graph_unary": (u32, [vp, i32, u32]), "fhip_graph_binary": (u32, [vp, i32, u32, u32]),
+            "fhip_graph_from_text": (u32, [vp, C.c_char_p]),
+            "fhip_tape_from_graph": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
+            "fhip_tape_axis_slot": (i32, [vp, i32]), "fhip_tape_var_slot": (i32, [vp, u64]),
+            "fhip_screen_to_world": (None, [vp, i32, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class HipContext:
+    """fhip_ctx: one device + stream.  `stream` may be a raw hipStream_t (e.g. torch's)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        st = lib().fhip_ctx_create(device, C.c_void_p(stream or 0), C.byref(h))
+        if st != 0:
+            raise FidgetHipError(st, "no usable HIP device: fidget_amd has no CPU fallback")
+        self._h = h
+
+    def __del__(self):
+        try:
+            lib().fhip_ctx_destroy(self._h)
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != 0:
+            raise FidgetHipError(st, (lib().fhip_last_error(self._h) or b"").decode())
+
+    def sync(self):
+        self.check(lib().fhip_ctx_sync(self._h))
+
+    def cancel(self):
+        lib().fhip_cancel(self._h)
+
+    def cancel_reset(self):
+        lib().fhip_cancel_reset(self._h)
+
+    def profile(self, on):
+        lib().fhip_profile_enable(self._h, int(on))
+
+    def profile_read(self):
+        ms = np.zeros(4, np.float64)
+        n = np.zeros(4, np.uint32)
+        self.check(lib().fhip_profile_read(self._h, _p(ms), _p(n)))
+        names = ["tiles", "points", "normals", "other"]
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+    def counters(self):
+        c = np.zeros(8, np.uint64)
+        self.check(lib().fhip_render_counters(self._h, _p(c)))
+        return {"arena_ops": int(c[0]), "arena_overflow": int(c[1]), "leaves_last_slab": int(c[2]),
+                "queue_overflow": int(c[3]), "groups_last_slab": [int(v) for v in c[4:8]]}
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("FHIP_USE_LOCAL_RANK") else 0)
+    return _default_ctx
+
+
+BAD_NODE = 0xFFFFFFFF
+
+
+class BadNode(Exception):
+    pass
+
+
+class Node(int):
+    pass
+
+
+class Context:
+    """Host mirror of fidget_core::Context (constructor identities, dedup, .vm text)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib().fhip_graph_new())
+
+    def __del__(self):
+        try:
+            lib().fhip_graph_free(self._h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().fhip_graph_len(self._h)
+
+    def _node(self, v):
+        if isinstance(v, (float, int)) and not isinstance(v, Node):
+            return self.constant(float(v))
+        return v
+
+    def x(self): return Node(lib().fhip_graph_var(self._h, 0, 0))
+    def y(self): return Node(lib().fhip_graph_var(self._h, 1, 0))
+    def z(self): return Node(lib().fhip_graph_var(self._h, 2, 0))
+    def var(self, index): return Node(lib().fhip_graph_var(self._h, 3, int(index)))
+    def constant(self, f): return Node(lib().fhip_graph_constant(self._h, float(f)))
+
+    def _un(self, name, a):
+        r = lib().fhip_graph_unary(self._h, UNARY.index(name), int(self._node(a)))
+        if r == BAD_NODE:
+            raise BadNode()
+        return Node(r)
+
+    def _bin(self, name, a, b):
+        r = lib().fhip_graph_binary(self._h, BINARY.index(name), int(self._node(a)), int(self._node(b)))
+        if r == BAD_NODE:
+            raise BadNode()
+        return Node(r)
+
+    # derived constructors (context/mod.rs:701-780)
+    def less_than(self, lhs, rhs):
+        return self.max(self._bin("compare", rhs, lhs), 0.0)
+
+    def less_than_or_equal(self, lhs, rhs):
+        return self.min(self.add(self._bin("compare", rhs, lhs), 1.0), 1.0)
+
+    def if_nonzero_else(self, cond, a, b):
+        cond, a, b = self._node(cond), self._node(a), self._node(b)
+        lhs = self.and_(cond, a)
+        rhs = self.and_(self.not_(cond), b)
+        return self.or_(lhs, rhs)
+
+    @staticmethod
+    def from_text(text):
+        ctx = Context()
+        if isinstance(text, str):
+            text = text.encode()
+        r = lib().fhip_graph_from_text(ctx._h, text)
+        if r == BAD_NODE:
+            raise ValueError("parse error")
+        return ctx, Node(r)
+
+
+def _mk_un(name):
+    def f(self, a):
+        return self._un(name, a)
+    return f
+
+
+def _mk_bin(name):
+    def f(self, a, b):
+        return self._bin(name, a, b)
+    return f
+
+
+for _n in UNARY:
+    setattr(Context, {"not": "not_"}.get(_n, _n), _mk_un(_n))
+for _n in BINARY:
+    setattr(Context, {"and": "and_", "or": "or_", "mod": "modulo"}.get(_n, _n), _mk_bin(_n))
+
+
+class Shape:
+    """One function compiled to a device tape (the role of `Shape<HipFunction>`)."""
+
+    def __init__(self, ctx=None, node=None, n_regs=255, _h=None, roots=None, hip=None, _vars=None):
+        # n_regs is accepted for signature parity with GenericVmFunction<N>; device tapes
+        # always use dense renumbering over up to 256 registers (no spills).
+        self._hip = hip  # created lazily: tape construction and simplify are host-only
+        self.n_regs = n_regs
+        if _h is not None:
+            self._h = _h
+            self._vars = _vars
+            return
+        if roots is None:
+            roots = [node]
+        r = np.array([int(n) for n in roots], dtype=np.uint32)
+        h = C.c_void_p()
+        st = lib().fhip_tape_from_graph(None, ctx._h, _p(r), len(r), C.byref(h))
+        if st != 0:
+            raise FidgetHipError(st, "tape construction failed")
+        self._h = h
+        self._vars = None
+
+    @property
+    def hip(self):
+        if self._hip is None:
+            self._hip = default_context()
+        return self._hip
+
+    def __del__(self):
+        try:
+            lib().fhip_tape_free(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def from_vm(path_or_text, n_regs=255, hip=None):
+        text = open(path_or_text).read() if os.path.exists(path_or_text) else path_or_text
+        ctx, root = Context.from_text(text)
+        return Shape(ctx, root, n_regs, hip=hip)
+
+    @staticmethod
+    def from_bytecode(words, axis_slots=(0, 1, 2), hip=None):
+        """The reference wire format (fidget_bytecode::Bytecode::data()); axis_slots = VarMap slots of X, Y, Z."""
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        h = C.c_void_p()
+        st = lib().fhip_tape_from_bytecode(None, _p(w), len(w), C.byref(h))
+        if st != 0:
+            raise FidgetHipError(st, "bad bytecode")
+        return Shape(_h=h, hip=hip, _vars=tuple(axis_slots))
+
+    # sizes ---------------------------------------------------------------
+    def size(self): return lib().fhip_tape_len(self._h)
+    __len__ = size
+    def ssa_len(self): return self.size()  # device tapes carry no load/store: one op per SSA op
+    def choice_count(self): return lib().fhip_tape_choice_count(self._h)
+    def output_count(self): return lib().fhip_tape_output_count(self._h)
+    def slot_count(self): return lib().fhip_tape_reg_count(self._h)
+    def var_count(self): return lib().fhip_tape_var_count(self._h)
+
+    def axis_index(self, axis):
+        if self._vars is not None:
+            return self._vars[axis]
+        return lib().fhip_tape_axis_slot(self._h, axis)
+
+    def var_index(self, index): return lib().fhip_tape_var_slot(self._h, int(index))
+
+    def ops(self):
+        """Device tape as (name, out, a, b, imm_bits) tuples in evaluation order."""
+        n = self.size()
+        w = np.zeros(max(n, 1), dtype=np.uint64)
+        lib().fhip_tape_ops(self._h, _p(w), n)
+        out = []
+        for v in w[:n]:
+            v = int(v)
+            out.append((FH_OPS[v & 0xFF], (v >> 8) & 0xFFF, (v >> 20) & 0xFFF, v >> 32, v >> 32))  # (name, out, a, b|imm, imm)
+        return out
+
+    def simplify(self, choices, n_regs=None):
+        c = np.ascontiguousarray(choices, dtype=np.uint8)
+        h = C.c_void_p()
+        st = lib().fhip_simplify(None, self._h, _p(c), len(c), C.byref(h))
+        if st != 0:
+            raise ValueError(STATUS.get(st, str(st)))
+        return Shape(_h=h, hip=self._hip, _vars=self._vars if self._vars is not None else tuple(self.axis_index(a) for a in range(3)),
+                     n_regs=self.n_regs)._with_named(self)
+
+    def _with_named(self, parent):
+        self._named_parent = parent  # children keep the parent's Var::V slots
+        return self
+
+    def _named_slot(self, index):
+        p = self
+        while getattr(p, "_named_parent", None) is not None:
+            p = p._named_parent
+        return lib().fhip_tape_var_slot(p._h, int(index))
+
+    # evaluators ------------------------------------------------------------
+    def _xyz_vars(self, x, y, z, extra=None):
+        n = max(self.var_count(), 1)
+        vs = [None] * n
+        for axis, v in enumerate((x, y, z)):
+            i = self.axis_index(axis)
+            if 0 <= i < n:
+                vs[i] = v
+        for k, v in (extra or {}).items():
+            i = self._named_slot(k)
+            if 0 <= i < n:
+                vs[i] = v
+        return vs
+
+    def _tracing(self, fn, v, comp):
+        n, nv = v.shape[0], v.shape[1]
+        no, nc = self.output_count(), self.choice_count()
+        out = np.zeros((n, max(no, 1)) + ((2,) if comp == 2 else ()), dtype=np.float32)
+        ch = np.zeros((n, max(nc, 1)), dtype=np.uint8)
+        simp = np.zeros(n, dtype=np.uint8)
+        st = fn(self.hip._h, self._h, _p(v), nv, n, _p(out), _p(ch), _p(simp))
+        if st in (1, 2, 3):
+            raise ValueError(STATUS[st])
+        self.hip.check(st)
+        return out[:, :no], ch[:, :nc], simp
+
+    def eval_interval_batch(self, batch):
+        """batch: list of per-variable (lo, hi) lists (None = [0,0]).  Returns [((lo,hi), trace|None)]."""
+        v = np.array([[(0.0, 0.0) if a is None else a for a in vs] for vs in batch], dtype=np.float32)
+        if v.ndim != 3:
+            v = v.reshape(len(batch), -1, 2)
+        out, ch, simp = self._tracing(lib().fhip_interval_eval, np.ascontiguousarray(v), 2)
+        return [((float(out[i, 0, 0]), float(out[i, 0, 1])), (ch[i].copy() if simp[i] else None)) for i in range(len(batch))]
+
+    def eval_interval_raw(self, vars_):
+        v = np.array(vars_, dtype=np.float32).reshape(1, -1, 2)
+        out, ch, simp = self._tracing(lib().fhip_interval_eval, v, 2)
+        return out[0], (ch[0].copy() if simp[0] else None)
+
+    def eval_interval(self, x, y, z, extra=None):
+        vs = self._xyz_vars(x, y, z, extra)
+        vs = [(0.0, 0.0) if v is None else ((v, v) if np.isscalar(v) else tuple(v)) for v in vs]
+        out, tr = self.eval_interval_raw(vs)
+        return (float(out[0][0]), float(out[0][1])), tr
+
+    def eval_point_raw(self, vars_):
+        v = np.array(vars_, dtype=np.float32).reshape(1, -1)
+        out, ch, simp = self._tracing(lib().fhip_point_eval, v, 1)
+        return out[0], (ch[0].copy() if simp[0] else None)
+
+    def eval_point(self, x, y, z, extra=None):
+        vs = [0.0 if v is None else v for v in self._xyz_vars(x, y, z, extra)]
+        out, tr = self.eval_point_raw(vs)
+        return float(out[0]), tr
+
+    def _bulk(self, fn, arrs, comp):
+        n = len(arrs[0]) // comp if arrs else 0
+        lens = np.array([len(a) // comp for a in arrs], dtype=np.uint32)
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        no = self.output_count()
+        outs = [np.zeros(n * comp, dtype=np.float32) for _ in range(no)]
+        optrs = (C.c_void_p * max(no, 1))(*[o.ctypes.data for o in outs])
+        st = fn(self.hip._h, self._h, ptrs, _p(lens), len(arrs), optrs)
+        if st in (1, 2, 3):
+            raise ValueError(STATUS[st])
+        self.hip.check(st)
+        return outs
+
+    def eval_float_slice_raw(self, arrays):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in arrays]
+        outs = self._bulk(lib().fhip_float_eval, arrs, 1)
+        n = len(arrs[0]) if arrs else 0
+        return np.array(outs, dtype=np.float32).reshape(self.output_count(), n)
+
+    def eval_float_slice(self, x, y, z, extra=None):
+        x, y, z = (np.asarray(a, dtype=np.float32) for a in (x, y, z))
+        n = len(x)
+        vs = self._xyz_vars(x, y, z, extra)
+        vs = [np.zeros(n, np.float32) if v is None else (np.full(n, v, np.float32) if np.isscalar(v) else v) for v in vs]
+        return self.eval_float_slice_raw(vs)[0]
+
+    def eval_grad_slice_raw(self, arrays):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in arrays]
+        outs = self._bulk(lib().fhip_grad_eval, arrs, 4)
+        n = len(arrs[0]) // 4 if arrs else 0
+        return np.array(outs, dtype=np.float32).reshape(self.output_count(), n, 4)
+
+    def eval_grad_slice(self, x, y, z, extra=None):
+        x, y, z = (np.asarray(a, dtype=np.float32) for a in (x, y, z))
+        n = len(x)
+
+        def seed(v, k):
+            g = np.zeros((n, 4), np.float32)
+            g[:, 0] = v
+            g[:, 1 + k] = 1.0
+            return g
+        vs = self._xyz_vars(seed(x, 0), seed(y, 1), seed(z, 2), extra)
+        out = []
+        for v in vs:
+            if v is None:
+                out.append(np.zeros((n, 4), np.float32))
+            elif np.isscalar(v):
+                g = np.zeros((n, 4), np.float32)
+                g[:, 0] = v
+                out.append(g)
+            else:
+                out.append(v)
+        return self.eval_grad_slice_raw(out)[0]
+
+
+# ---- geometry helpers (host f32, same operation order as the C++ driver) --------------
+def screen_to_world(size):
+    n = len(size)
+    s = np.array(size, dtype=np.uint32)
+    out = np.zeros((n + 1, n + 1), dtype=np.float32)
+    lib().fhip_screen_to_world(_p(s), n, _p(out))
+    return out
+
+
+def mat_mul(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    d = a.shape[0]
+    out = np.zeros((d, d), np.float32)
+    for col in range(d):
+        for row in range(d):
+            acc = np.float32(a[row, 0] * b[0, col])
+            for k in range(1, d):
+                acc = np.float32(np.float32(a[row, k] * b[k, col]) + acc)
+            out[row, col] = acc
+    return out
+
+
+def lift_2d(m3):
+    m3 = np.asarray(m3, np.float32)
+    m = np.zeros((4, 4), np.float32)
+    m[0, :2] = m3[0, :2]; m[0, 3] = m3[0, 2]
+    m[1, :2] = m3[1, :2]; m[1, 3] = m3[1, 2]
+    m[2, 2] = 1.0
+    m[3, :2] = m3[2, :2]; m[3, 3] = m3[2, 2]
+    return m
+
+
+def transform_point(mat4, x, y, z):
+    m = np.asarray(mat4, np.float32)
+    x, y, z = np.float32(x), np.float32(y), np.float32(z)
+    r = [np.float32(np.float32(np.float32(m[i, 0] * x) + np.float32(m[i, 1] * y)) + np.float32(m[i, 2] * z)) + m[i, 3]
+         for i in range(4)]
+    r = [np.float32(v) for v in r]
+    if r[3] != 0:
+        return np.array([r[0] / r[3], r[1] / r[3], r[2] / r[3]], np.float32)
+    return np.array(r[:3], np.float32)
+
+
+def _var_arrays(shape, vars_):
+    vars_ = vars_ or {}
+    k = np.array(list(vars_.keys()), dtype=np.uint64)
+    v = np.array(list(vars_.values()), dtype=np.float32)
+    return k, v
+
+
+def _dev_ptr(out):
+    """Accept a torch CUDA tensor (device pointer) or None."""
+    if out is None:
+        return None
+    return C.c_void_p(out.data_ptr())
+
+
+def render2d(shape, width, height=None, z=0.0, pixel_perfect=False, world_to_model=None, tile_sizes=None,
+             vars=None, out=None, mode=None, threads=None):
+    """fidget_raster::pixel::render on the GPU.  Returns (float32 [h,w] RawDistancePixel image, stats, seconds);
+    with `out` (a torch CUDA float32 tensor) the call is asynchronous and returns (out, None, None)."""
+    height = width if height is None else height
+    hip = shape.hip
+    ts = np.array(tile_sizes, dtype=np.uint32) if tile_sizes else None
+    w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    vk, vv = _var_arrays(shape, vars)
+    ax = None
+    if shape._vars is not None:
+        ax = np.array(shape._vars, dtype=np.int32)
+        vk = np.array([shape._named_slot(k) for k in (vars or {})], dtype=np.uint64)
+    cfg = _Cfg2D(width, height, _p(w2m), z, int(pixel_perfect), _p(ts), 0 if ts is None else len(ts), _p(vk), _p(vv),
+                 len(vk), _p(ax))
+    if out is not None:
+        st = lib().fhip_render2d(hip._h, shape._h, C.byref(cfg), _dev_ptr(out), 1)
+        if st == 4:
+            raise ValueError("MissingVar")
+        hip.check(st)
+        return out, None, None
+    img = np.zeros((height, width), dtype=np.float32)
+    import time
+    t0 = time.perf_counter()
+    st = lib().fhip_render2d(hip._h, shape._h, C.byref(cfg), _p(img), 0)
+    dt = time.perf_counter() - t0
+    if st == 4:
+        raise ValueError("MissingVar")
+    hip.check(st)
+    return img, {}, dt
+
+
+def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_sizes=None, vars=None, out=None,
+             shard=0, n_shards=1, mode=None, threads=None):
+    """fidget_raster::voxel::render on the GPU.  Returns (GeometryPixel [h,w] image, stats, seconds)."""
+    height = width if height is None else height
+    depth = width if depth is None else depth
+    hip = shape.hip
+    ts = np.array(tile_sizes, dtype=np.uint32) if tile_sizes else None
+    w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    vk, vv = _var_arrays(shape, vars)
+    ax = None
+    if shape._vars is not None:
+        ax = np.array(shape._vars, dtype=np.int32)
+        vk = np.array([shape._named_slot(k) for k in (vars or {})], dtype=np.uint64)
+    cfg = _Cfg3D(width, height, depth, _p(w2m), _p(ts), 0 if ts is None else len(ts), _p(vk), _p(vv), len(vk), _p(ax))
+    if out is not None:
+        st = lib().fhip_render3d_shard(hip._h, shape._h, C.byref(cfg), _dev_ptr(out), 1, shard, n_shards)
+        if st == 4:
+            raise ValueError("MissingVar")
+        hip.check(st)
+        return out, None, None
+    img = np.zeros((height, width), dtype=GEOMETRY_PIXEL)
+    import time
+    t0 = time.perf_counter()
+    st = lib().fhip_render3d_shard(hip._h, shape._h, C.byref(cfg), _p(img), 0, shard, n_shards)
+    dt = time.perf_counter() - t0
+    if st == 4:
+        raise ValueError("MissingVar")
+    hip.check(st)
+    return img, {}, dt
+
+
+def pixel_inside(img):
+    """RawDistancePixel::inside (fidget-raster/src/pixel.rs:187-193)."""
+    img = np.asarray(img, np.float32)
+    bits = img.view(np.uint32)
+    is_fill = np.isnan(img) & ((bits & (0xFF << 9)) == (0xF6 << 9))
+    return np.where(is_fill, (bits & 1) == 1, img < 0.0)
+
+
+def pixel_fill_depth(img):
+    img = np.asarray(img, np.float32)
+    bits = img.view(np.uint32)
+    is_fill = np.isnan(img) & ((bits & (0xFF << 9)) == (0xF6 << 9))
+    return np.where(is_fill, ((bits >> 1) & 0xFF).astype(np.int32), -1)

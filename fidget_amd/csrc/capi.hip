@@ -1,0 +1,660 @@
+// libfidget_hip.so: C ABI (include/fidget_hip.h) + host driver of the render pipeline.
+// Single translation unit: the kernels are included so that one `hipcc -shared` builds
+// everything for gfx950.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "../../include/fidget_hip.h"
+#include "host_graph.hpp"
+#include "kernels.hip"
+
+#define FH_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
+
+// ----------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct fhip_tape {
+    fh::HostTape t;
+    mutable uint64_t* d_ops = nullptr;  // uploaded on first device use (tape construction is host-only)
+};
+struct fhip_graph {
+    fh::Graph g;
+};
+
+struct fhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    std::string err;
+    std::atomic<int> cancelled{0};
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e;
+    DevBuf queue[FH_MAX_LEVELS];
+    size_t arena_bytes = (size_t)1 << 30;
+    bool profiling = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    FhRenderState last_state;
+    bool have_last_state = false;
+};
+
+static fhip_status fail(fhip_ctx* ctx, fhip_status s, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return s;
+}
+#define HIP_TRY(ctx, call)                                                                                       \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+template <class F>
+static void launch(fhip_ctx* ctx, int klass, F&& f) {
+    if (ctx->profiling) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, ctx->stream);
+        f();
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->prof_events.push_back({klass, {a, b}});
+    } else {
+        f();
+    }
+}
+
+extern "C" {
+
+// ---- context ---------------------------------------------------------------------------
+fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
+    if (!out) return FHIP_ERR_BAD_TAPE;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return FHIP_ERR_HIP;
+    fhip_ctx* c = new fhip_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (const char* mb = getenv("FHIP_ARENA_MB")) c->arena_bytes = (size_t)atol(mb) << 20;
+    // allow the full 160 KiB of LDS for the interpreters' register files
+    const void* fns[] = {(const void*)k_eval_f32<false>, (const void*)k_eval_interval<false>, (const void*)k_eval_grad<false>,
+                         (const void*)k_tiles<false>, (const void*)k_tiles<true>, (const void*)k_pixels2d,
+                         (const void*)k_columns3d, (const void*)k_normals3d};
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    *out = c;
+    return FHIP_OK;
+}
+void fhip_ctx_destroy(fhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
+                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& q : c->queue) q.release();
+    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    delete c;
+}
+const char* fhip_last_error(const fhip_ctx* c) { return c ? c->err.c_str() : "no context"; }
+fhip_status fhip_ctx_sync(fhip_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FHIP_OK;
+}
+void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
+void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
+
+// ---- tapes -----------------------------------------------------------------------------
+static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** out) {
+    std::string err;
+    fhip_tape* t = new fhip_tape();
+    if (!fh::allocate(prog, t->t, err)) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, err); }
+    if (t->t.n_vars > FH_MAX_INPUTS) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 16 input variables"); }
+    *out = t;
+    return FHIP_OK;
+}
+static fhip_status tape_to_device(fhip_ctx* ctx, const fhip_tape* t) {
+    if (t->d_ops) return FHIP_OK;
+    size_t bytes = std::max<size_t>(t->t.ops.size(), 1) * 8;
+    HIP_TRY(ctx, hipMalloc((void**)&t->d_ops, bytes));
+    HIP_TRY(ctx, hipMemcpy(t->d_ops, t->t.ops.data(), t->t.ops.size() * 8, hipMemcpyHostToDevice));
+    return FHIP_OK;
+}
+fhip_status fhip_tape_from_bytecode(fhip_ctx* ctx, const uint32_t* words, size_t n_words, fhip_tape** out) {
+    fh::SsaProgram prog;
+    std::string err;
+    if (!fh::from_bytecode(words, n_words, prog, err)) return fail(ctx, FHIP_ERR_BAD_TAPE, err);
+    return finish_tape(ctx, prog, out);
+}
+fhip_status fhip_tape_from_graph(fhip_ctx* ctx, const fhip_graph* g, const uint32_t* roots, uint32_t n_roots,
+                                 fhip_tape** out) {
+    fh::SsaProgram prog;
+    std::string err;
+    std::vector<fh::NodeId> r(roots, roots + n_roots);
+    if (!fh::flatten(g->g, r, prog, err)) return fail(ctx, FHIP_ERR_BAD_TAPE, err);
+    return finish_tape(ctx, prog, out);
+}
+void fhip_tape_free(fhip_tape* t) {
+    if (!t) return;
+    if (t->d_ops) (void)hipFree(t->d_ops);
+    delete t;
+}
+uint32_t fhip_tape_len(const fhip_tape* t) { return (uint32_t)t->t.ops.size(); }
+uint32_t fhip_tape_choice_count(const fhip_tape* t) { return t->t.n_choices; }
+uint32_t fhip_tape_reg_count(const fhip_tape* t) { return t->t.n_regs; }
+uint32_t fhip_tape_var_count(const fhip_tape* t) { return t->t.n_vars; }
+uint32_t fhip_tape_output_count(const fhip_tape* t) { return t->t.n_outputs; }
+uint32_t fhip_tape_ops(const fhip_tape* t, uint64_t* ops, uint32_t cap) {
+    for (uint32_t i = 0; i < t->t.ops.size() && i < cap; i++) ops[i] = t->t.ops[i];
+    return (uint32_t)t->t.ops.size();
+}
+int fhip_tape_axis_slot(const fhip_tape* t, int axis) { return (axis >= 0 && axis < 3) ? t->t.vars.axis[axis] : -1; }
+int fhip_tape_var_slot(const fhip_tape* t, uint64_t index) { return t->t.vars.slot_of(3, index); }
+
+// Host form of the device prune sweep (kernels.hip: prune_sweep<true>), same algorithm.
+fhip_status fhip_simplify(fhip_ctx* ctx, const fhip_tape* tape, const uint8_t* choices, uint32_t n_choices,
+                          fhip_tape** child) {
+    const fh::HostTape& p = tape->t;
+    if (n_choices != p.n_choices) return fail(ctx, FHIP_ERR_BAD_CHOICE_SLICE, "choice slice length mismatch");
+    std::vector<int> map(FH_MAX_REGS, -1);
+    fh::RegPool pool;
+    std::vector<uint64_t> rev;
+    uint32_t ci = n_choices, kept = 0;
+    auto use = [&](uint32_t r) { if (map[r] < 0) map[r] = pool.take(); return (uint32_t)map[r]; };
+    for (size_t k = p.ops.size(); k-- > 0;) {
+        const uint64_t w = p.ops[k];
+        const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+        const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
+        const bool is_choice = fh_is_choice(op);
+        uint32_t c = FH_CHOICE_BOTH;
+        if (is_choice) {
+            c = choices[--ci];
+            if (c == FH_CHOICE_UNKNOWN) return fail(ctx, FHIP_ERR_BAD_CHOICE_SLICE, "Choice::Unknown in trace");
+        }
+        if (op == FH_OUTPUT) { rev.push_back(fh_pack(op, 0, use(ra), 0, w1)); continue; }
+        const int no = map[ro];
+        if (no < 0) continue;
+        map[ro] = -1;
+        int alias = -1;
+        bool copy_imm = false;
+        if (op == FH_COPY_REG) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_LEFT) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_RIGHT) { if (fh_is_rr(op)) alias = (int)rb; else copy_imm = true; }
+        if (alias >= 0) {
+            if (map[alias] < 0) { map[alias] = no; continue; }
+            pool.give(no);
+            rev.push_back(fh_pack(FH_COPY_REG, no, map[alias], 0, 0));
+            continue;
+        }
+        pool.give(no);
+        if (copy_imm) { rev.push_back(fh_pack(FH_COPY_IMM, no, 0, 0, w1)); continue; }
+        uint32_t na = 0, nb = 0;
+        if (op != FH_INPUT && op != FH_COPY_IMM) na = use(ra);
+        if (fh_is_rr(op)) nb = use(rb);
+        if (is_choice) kept++;
+        rev.push_back(fh_pack(op, no, na, nb, w1));
+    }
+    fhip_tape* t = new fhip_tape();
+    t->t.ops.assign(rev.rbegin(), rev.rend());
+    t->t.n_regs = pool.high;
+    t->t.n_choices = kept;
+    t->t.n_outputs = p.n_outputs;
+    t->t.n_vars = p.n_vars;  // children keep the parent's variable slots (vm/data.rs:316)
+    t->t.vars = p.vars;
+    *child = t;
+    return FHIP_OK;
+}
+
+// ---- evaluators ------------------------------------------------------------------------
+static fhip_status tracing_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* vars, uint32_t n_vars, uint32_t n,
+                                float* out, uint8_t* choices, uint8_t* simplify, bool interval) {
+    const fh::HostTape& t = tape->t;
+    if (n_vars < t.n_vars) return fail(ctx, FHIP_ERR_BAD_VAR_SLICE, "too few variables");
+    if (n == 0) return FHIP_OK;
+    { fhip_status ts_ = tape_to_device(ctx, tape); if (ts_) return ts_; }
+    const uint32_t comp = interval ? 2 : 1;
+    const size_t nv = std::max<uint32_t>(n_vars, 1);
+    std::vector<float> hv((size_t)n * nv * comp, 0.0f);
+    if (interval) {
+        if (n_vars) memcpy(hv.data(), vars, (size_t)n * n_vars * 8);
+    } else {
+        for (uint32_t i = 0; i < n; i++)
+            for (uint32_t v = 0; v < n_vars; v++) hv[(size_t)v * n + i] = vars[(size_t)i * n_vars + v];  // -> [var][n]
+    }
+    const size_t out_elems = (size_t)n * t.n_outputs * comp;
+    const size_t ch_bytes = (size_t)n * std::max<uint32_t>(t.n_choices, 1);
+    HIP_TRY(ctx, ctx->io_a.ensure(hv.size() * 4));
+    HIP_TRY(ctx, ctx->io_b.ensure(std::max<size_t>(out_elems, 1) * 4));
+    HIP_TRY(ctx, ctx->io_c.ensure(ch_bytes));
+    HIP_TRY(ctx, ctx->io_d.ensure(n));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0xFF, std::max<size_t>(out_elems, 1) * 4, ctx->stream));  // NaN prefill (vm/mod.rs:314-319)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_c.p, 0, ch_bytes, ctx->stream));
+    const uint32_t grid = (n + WAVE - 1) / WAVE;
+    const uint32_t nr = std::max<uint32_t>(t.n_regs, 1);
+    const size_t lds = (size_t)nr * WAVE * 4 * comp;
+    const bool g = lds > FH_LDS_MAX;  // register file too large for LDS: global scratch slab
+    if (g) HIP_TRY(ctx, ctx->io_e.ensure(lds * grid));
+    if (interval) {
+        if (g) hipLaunchKernelGGL(k_eval_interval<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float2*)ctx->io_a.p, (uint32_t)nv, n, (float2*)ctx->io_b.p, t.n_outputs,
+                           (uint8_t*)ctx->io_c.p, (uint8_t*)ctx->io_d.p, t.n_choices, (IV*)ctx->io_e.p, nr);
+        else hipLaunchKernelGGL(k_eval_interval<false>, dim3(grid), dim3(WAVE), lds, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float2*)ctx->io_a.p, (uint32_t)nv, n, (float2*)ctx->io_b.p, t.n_outputs,
+                           (uint8_t*)ctx->io_c.p, (uint8_t*)ctx->io_d.p, t.n_choices, (IV*)nullptr, nr);
+    } else {
+        if (g) hipLaunchKernelGGL(k_eval_f32<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)ctx->io_c.p,
+                           (uint8_t*)ctx->io_d.p, t.n_choices, (float*)ctx->io_e.p, nr);
+        else hipLaunchKernelGGL(k_eval_f32<false>, dim3(grid), dim3(WAVE), lds, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)ctx->io_c.p,
+                           (uint8_t*)ctx->io_d.p, t.n_choices, (float*)nullptr, nr);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> ho(std::max<size_t>(out_elems, 1));
+    HIP_TRY(ctx, hipMemcpyAsync(ho.data(), ctx->io_b.p, out_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (choices && t.n_choices)
+        HIP_TRY(ctx, hipMemcpyAsync(choices, ctx->io_c.p, (size_t)n * t.n_choices, hipMemcpyDeviceToHost, ctx->stream));
+    if (simplify) HIP_TRY(ctx, hipMemcpyAsync(simplify, ctx->io_d.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (interval) memcpy(out, ho.data(), out_elems * 4);
+    else
+        for (uint32_t i = 0; i < n; i++)
+            for (uint32_t o = 0; o < t.n_outputs; o++) out[(size_t)i * t.n_outputs + o] = ho[(size_t)o * n + i];
+    return FHIP_OK;
+}
+fhip_status fhip_interval_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* vars, uint32_t n_vars, uint32_t n,
+                               float* out, uint8_t* choices, uint8_t* simplify) {
+    return tracing_eval(ctx, tape, vars, n_vars, n, out, choices, simplify, true);
+}
+fhip_status fhip_point_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* vars, uint32_t n_vars, uint32_t n,
+                            float* out, uint8_t* choices, uint8_t* simplify) {
+    return tracing_eval(ctx, tape, vars, n_vars, n, out, choices, simplify, false);
+}
+
+static fhip_status bulk_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* const* vars, const uint32_t* lens,
+                             uint32_t n_vars, float* const* out, uint32_t comp) {
+    const fh::HostTape& t = tape->t;
+    if (n_vars < t.n_vars) return fail(ctx, FHIP_ERR_BAD_VAR_SLICE, "too few variable slices");
+    const uint32_t n = n_vars ? lens[0] : 0;  // vm/mod.rs:808
+    for (uint32_t v = 1; v < n_vars; v++)
+        if (lens[v] != n) return fail(ctx, FHIP_ERR_MISMATCHED_SLICES, "variable slices differ in length");
+    if (n == 0) return FHIP_OK;
+    { fhip_status ts_ = tape_to_device(ctx, tape); if (ts_) return ts_; }
+    const size_t row = (size_t)n * comp;
+    HIP_TRY(ctx, ctx->io_a.ensure(row * 4 * n_vars));
+    HIP_TRY(ctx, ctx->io_b.ensure(row * 4 * std::max<uint32_t>(t.n_outputs, 1)));
+    for (uint32_t v = 0; v < n_vars; v++)
+        HIP_TRY(ctx, hipMemcpyAsync((float*)ctx->io_a.p + v * row, vars[v], row * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0xFF, row * 4 * std::max<uint32_t>(t.n_outputs, 1), ctx->stream));
+    const uint32_t grid = (n + WAVE - 1) / WAVE;
+    const uint32_t nr = std::max<uint32_t>(t.n_regs, 1);
+    const size_t lds = (size_t)nr * WAVE * 4 * comp;
+    const bool g = lds > FH_LDS_MAX;
+    if (g) HIP_TRY(ctx, ctx->io_e.ensure(lds * grid));
+    if (comp == 1) {
+        if (g) hipLaunchKernelGGL(k_eval_f32<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)nullptr, (uint8_t*)nullptr, 0u, (float*)ctx->io_e.p, nr);
+        else hipLaunchKernelGGL(k_eval_f32<false>, dim3(grid), dim3(WAVE), lds, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)nullptr, (uint8_t*)nullptr, 0u, (float*)nullptr, nr);
+    } else {
+        if (g) hipLaunchKernelGGL(k_eval_grad<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float4*)ctx->io_a.p, n, (float4*)ctx->io_b.p, (GR*)ctx->io_e.p, nr);
+        else hipLaunchKernelGGL(k_eval_grad<false>, dim3(grid), dim3(WAVE), lds, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
+                           (const float4*)ctx->io_a.p, n, (float4*)ctx->io_b.p, (GR*)nullptr, nr);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    for (uint32_t o = 0; o < t.n_outputs; o++)
+        HIP_TRY(ctx, hipMemcpyAsync(out[o], (float*)ctx->io_b.p + o * row, row * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FHIP_OK;
+}
+fhip_status fhip_float_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* const* vars, const uint32_t* lens,
+                            uint32_t n_vars, float* const* out) {
+    return bulk_eval(ctx, tape, vars, lens, n_vars, out, 1);
+}
+fhip_status fhip_grad_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* const* vars, const uint32_t* lens,
+                           uint32_t n_vars, float* const* out) {
+    return bulk_eval(ctx, tape, vars, lens, n_vars, out, 4);
+}
+
+// ---- geometry --------------------------------------------------------------------------
+// RegionSize::screen_to_world (render/region.rs:87-108): identity, then nalgebra's
+// append_translation_mut(-center) and append_nonuniform_scaling_mut(scale, -scale, ..)
+void fhip_screen_to_world(const uint32_t* size, int n, float* out) {
+    const int d = n + 1;
+    float center[3] = {0, 0, 0};
+    uint32_t smallest = size[0];
+    for (int i = 0; i < n; i++) { center[i] = (float)size[i] / 2.0f; smallest = std::min(smallest, size[i]); }
+    center[1] -= 1.0f;
+    const float scale = 2.0f / (float)smallest;
+    for (int i = 0; i < d * d; i++) out[i] = (i / d == i % d) ? 1.0f : 0.0f;
+    for (int col = 0; col < d; col++)
+        for (int row = 0; row < n; row++) out[row * d + col] += (-center[row]) * out[n * d + col];
+    for (int row = 0; row < n; row++) {
+        float s = scale;
+        if (row == 1) s *= -1.0f;
+        for (int col = 0; col < d; col++) out[row * d + col] *= s;
+    }
+}
+// nalgebra's small-matrix product: per output column, accumulate a[:,k] * b[k][col] for k = 0..d-1
+static void mat_product(const float* a, const float* b, int d, float* out) {
+    for (int col = 0; col < d; col++)
+        for (int row = 0; row < d; row++) {
+            float acc = a[row * d] * b[col];
+            for (int k = 1; k < d; k++) acc = a[row * d + k] * b[k * d + col] + acc;
+            out[row * d + col] = acc;
+        }
+}
+
+// ---- renders ---------------------------------------------------------------------------
+static const uint32_t VM_TILES_2D[] = {128, 32, 8};        // fidget-core/src/vm/mod.rs:255-257
+static const uint32_t VM_TILES_3D[] = {128, 64, 32, 16, 8};  // fidget-core/src/vm/mod.rs:251-253
+
+struct RenderSetup {
+    FhRenderState S;
+    std::vector<FhGroup> roots;
+    uint32_t n_slabs = 1;
+    size_t lds_tiles = 0, lds_points = 0, lds_normals = 0;
+    uint32_t table_words = 0;
+};
+
+static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
+                               const float* vals, uint32_t n, FhRender& P) {
+    const fh::HostTape& t = tape->t;
+    std::vector<char> bound(FH_MAX_INPUTS, 0);
+    for (uint32_t s = 0; s < FH_MAX_INPUTS; s++) { P.in_kind[s] = 3; P.in_value[s] = 0.0f; }
+    for (int a = 0; a < 3; a++) {
+        const int s = axis_slots ? axis_slots[a] : t.vars.axis[a];
+        if (s >= 0 && s < FH_MAX_INPUTS) { P.in_kind[s] = (uint32_t)a; bound[s] = 1; }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        // graph-built tapes: keys are Var::V indices; bytecode tapes (axis_slots given): keys are slots
+        const int s = axis_slots ? (int)keys[i] : t.vars.slot_of(3, keys[i]);
+        if (s >= 0 && s < FH_MAX_INPUTS) { P.in_value[s] = vals[i]; bound[s] = 1; }
+    }
+    for (uint32_t s = 0; s < t.n_vars; s++)
+        if (!bound[s]) return fail(ctx, FHIP_ERR_MISSING_VAR, "a variable of the shape has no value");
+    return FHIP_OK;
+}
+
+// fidget-raster/src/lib.rs:59-66
+static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint32_t max_size) {
+    uint32_t i = n;
+    for (uint32_t k = 0; k < n; k++) if (tiles[k] < max_size) { i = k; break; }
+    i = i ? i - 1 : 0;
+    return std::vector<uint32_t>(tiles + i, tiles + n);
+}
+
+static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
+                           uint32_t shard, uint32_t n_shards, RenderSetup& R) {
+    FhRenderState& S = R.S;
+    FhRender& P = S.P;
+    const fh::HostTape& t = tape->t;
+    if (t.n_outputs != 1) return fail(ctx, FHIP_ERR_BAD_TAPE, "shape tapes have exactly one output");
+    if (ts.empty() || ts.size() > FH_MAX_LEVELS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "1..8 tile levels supported");
+    P.n_levels = (uint32_t)ts.size();
+    for (size_t i = 0; i < ts.size(); i++) {
+        P.tiles[i] = ts[i];
+        if (i) {
+            if (ts[i - 1] <= ts[i] || ts[i - 1] % ts[i]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad tile size list");
+            const uint32_t n = ts[i - 1] / ts[i];
+            if ((is3d ? n * n * n : n * n) > TL) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 16 children");
+        }
+    }
+    if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
+    if (t.n_regs > 256) return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 256 registers");
+    P.max_regs = std::max<uint32_t>(t.n_regs, 1);
+    P.max_choices = t.n_choices;
+    P.roots_x = (P.width + ts[0] - 1) / ts[0];
+    P.roots_y = (P.height + ts[0] - 1) / ts[0];
+    R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
+
+    // LDS budgets (bounded by the root tape; children never need more)
+    R.lds_tiles = (size_t)P.max_regs * TL * 8 + (size_t)((P.max_choices + 15) / 16) * TL * 4 + (size_t)P.max_regs * TL;
+    R.lds_tiles = (R.lds_tiles + 15) & ~(size_t)15;
+    R.lds_points = (size_t)P.max_regs * WAVE * 4;
+    R.lds_normals = (size_t)P.max_regs * WAVE * 16;
+    if (R.lds_tiles > FH_LDS_MAX || R.lds_normals > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
+
+    // root groups: runs of <= 16 root tiles of this shard
+    std::vector<uint32_t> mine;
+    for (uint32_t ri = shard; ri < P.roots_x * P.roots_y; ri += n_shards) mine.push_back(ri);
+    FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
+    for (size_t i = 0; i < mine.size(); i += TL) {
+        FhGroup g{};
+        g.tape = root;
+        g.first = mine[i];
+        g.n = (uint32_t)std::min<size_t>(TL, mine.size() - i);
+        g.stride = n_shards;
+        R.roots.push_back(g);
+    }
+
+    // capacities (exact upper bounds per slab)
+    uint32_t qcap = std::max<uint32_t>((uint32_t)R.roots.size(), 1);
+    for (size_t l = 1; l < ts.size(); l++) {
+        const uint64_t tp = ts[l - 1];
+        uint64_t c = (uint64_t)((P.width + tp - 1) / tp) * ((P.height + tp - 1) / tp) * (is3d ? ts[0] / tp : 1);
+        qcap = (uint32_t)std::max<uint64_t>(qcap, c);
+    }
+    const uint64_t tl = ts.back();
+    const uint64_t fw = (P.width + tl - 1) / tl, fhh = (P.height + tl - 1) / tl;
+    const uint64_t leaf_cap = fw * fhh * (is3d ? ts[0] / tl : 1);
+    R.table_words = is3d ? (uint32_t)leaf_cap : 0;
+
+    HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
+    HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes));
+    for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcap * sizeof(FhGroup)));
+    HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
+    if (is3d) {
+        HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
+        HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
+        HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
+    }
+    S.arena = (uint64_t*)ctx->arena.p;
+    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8, 0xFFFFFFF0u);
+    S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
+    S.arena_overflow = 0;
+    for (int l = 0; l < FH_MAX_LEVELS; l++) { S.queue[l] = (FhGroup*)ctx->queue[l].p; S.count[l] = 0; S.cursor[l] = 0; }
+    S.count[0] = (uint32_t)R.roots.size();
+    S.queue_cap = qcap;
+    S.queue_overflow = 0;
+    S.leaves = (FhLeaf*)ctx->leaves.p;
+    S.leaf_cap = (uint32_t)leaf_cap;
+    S.n_leaves = S.leaf_cursor = S.normal_cursor = 0;
+    S.leaf_table = (uint32_t*)ctx->leaf_table.p;
+    S.zbuf = (uint64_t*)ctx->zbuf.p;
+    S.normals = (float*)ctx->normals.p;
+    S.image2d = nullptr;
+    memset(S.stat, 0, sizeof(S.stat));
+    if ((size_t)t.ops.size() * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
+    return FHIP_OK;
+}
+
+static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu) {
+    int per_cu = lds ? (int)std::min<size_t>((size_t)max_per_cu, FH_LDS_MAX / std::max<size_t>(lds, 1)) : max_per_cu;
+    per_cu = std::max(per_cu, 1);
+    return ctx->n_cu * per_cu;
+}
+
+static fhip_status finish_render(fhip_ctx* ctx) {
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state, ctx->state.p, sizeof(FhRenderState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_last_state = true;
+    if (ctx->last_state.queue_overflow) return fail(ctx, FHIP_ERR_OVERFLOW, "device work queue overflow");
+    return FHIP_OK;
+}
+
+fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
+                          int out_is_device) {
+    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    RenderSetup R;
+    memset(&R.S, 0, sizeof(R.S));
+    FhRender& P = R.S.P;
+    P.width = cfg->width; P.height = cfg->height; P.depth = 0; P.z = cfg->z; P.pixel_perfect = cfg->pixel_perfect ? 1 : 0;
+    fhip_status st = bind_inputs(ctx, tape, cfg->axis_slots, cfg->var_keys, cfg->var_values, cfg->n_vars, P);
+    if (st) return st;
+    // mat = world_to_model * screen_to_world, lifted to 4x4 preserving Z (pixel.rs:122-124, 281-285)
+    const uint32_t size[2] = {cfg->width, cfg->height};
+    float s2w[9], m3[9];
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    fhip_screen_to_world(size, 2, s2w);
+    mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 3, m3);
+    const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
+    memcpy(P.mat, m4, sizeof(m4));
+    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                                     : trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height));
+    st = prepare(ctx, tape, false, ts, 0, 1, R);
+    if (st) return st;
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    float* d_out = out;
+    if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * 4)); d_out = (float*)ctx->tmp_out.p; }
+    R.S.image2d = d_out;
+    FhRenderState* dS = (FhRenderState*)ctx->state.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dS, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->queue[0].p, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
+    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->prof_events.clear();
+    for (uint32_t l = 0; l < P.n_levels; l++) {
+        if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+        launch(ctx, FHIP_K_TILES, [&] {
+            hipLaunchKernelGGL(k_tiles<false>, dim3(blocks_for(ctx, R.lds_tiles, 8)), dim3(WAVE), R.lds_tiles, ctx->stream, dS, (int)l);
+        });
+    }
+    launch(ctx, FHIP_K_POINTS, [&] {
+        hipLaunchKernelGGL(k_pixels2d, dim3(blocks_for(ctx, R.lds_points, 16)), dim3(WAVE), R.lds_points, ctx->stream, dS);
+    });
+    HIP_TRY(ctx, hipGetLastError());
+    if (!out_is_device) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        return finish_render(ctx);
+    }
+    return FHIP_OK;
+}
+
+fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t shard, uint32_t n_shards) {
+    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad shard");
+    RenderSetup R;
+    memset(&R.S, 0, sizeof(R.S));
+    FhRender& P = R.S.P;
+    P.width = cfg->width; P.height = cfg->height; P.depth = cfg->depth; P.z = 0; P.pixel_perfect = 0;
+    fhip_status st = bind_inputs(ctx, tape, cfg->axis_slots, cfg->var_keys, cfg->var_values, cfg->n_vars, P);
+    if (st) return st;
+    const uint32_t size[3] = {cfg->width, cfg->height, cfg->depth};
+    float s2w[16];
+    const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    fhip_screen_to_world(size, 3, s2w);
+    mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
+    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                                     : trim_tiles(VM_TILES_3D, 5, std::max(cfg->width, cfg->height));
+    st = prepare(ctx, tape, true, ts, shard, n_shards, R);
+    if (st) return st;
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    FhGeometryPixel* d_out = (FhGeometryPixel*)out;
+    if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
+    FhRenderState* dS = (FhRenderState*)ctx->state.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dS, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!R.roots.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->queue[0].p, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, 0, npix * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
+    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->prof_events.clear();
+    const uint32_t n_groups = (uint32_t)R.roots.size();
+    const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
+    for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
+        if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+        launch(ctx, FHIP_K_OTHER, [&] {
+            hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k * ts[0], n_groups);
+        });
+        for (uint32_t l = 0; l < P.n_levels; l++)
+            launch(ctx, FHIP_K_TILES, [&] {
+                hipLaunchKernelGGL(k_tiles<true>, dim3(blocks_for(ctx, R.lds_tiles, 8)), dim3(WAVE), R.lds_tiles, ctx->stream, dS, (int)l);
+            });
+        launch(ctx, FHIP_K_POINTS, [&] {
+            hipLaunchKernelGGL(k_columns3d, dim3(blocks_for(ctx, R.lds_points, 16)), dim3(WAVE), R.lds_points, ctx->stream, dS);
+        });
+        launch(ctx, FHIP_K_NORMALS, [&] {
+            hipLaunchKernelGGL(k_normals3d, dim3(blocks_for(ctx, R.lds_normals, 8)), dim3(WAVE), R.lds_normals, ctx->stream, dS);
+        });
+    }
+    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS, d_out); });
+    HIP_TRY(ctx, hipGetLastError());
+    if (!out_is_device) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
+        return finish_render(ctx);
+    }
+    return FHIP_OK;
+}
+fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                          int out_is_device) {
+    return fhip_render3d_shard(ctx, tape, cfg, out, out_is_device, 0, 1);
+}
+
+// ---- profiling -------------------------------------------------------------------------
+void fhip_profile_enable(fhip_ctx* ctx, int on) { ctx->profiling = on != 0; }
+fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4]) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; i++) { ms[i] = 0; launches[i] = 0; }
+    for (auto& e : ctx->prof_events) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, e.second.first, e.second.second) == hipSuccess) { ms[e.first] += t; launches[e.first]++; }
+    }
+    return FHIP_OK;
+}
+fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]) {
+    fhip_status st = finish_render(ctx);
+    if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
+    const FhRenderState& S = ctx->last_state;
+    out[0] = S.arena_head; out[1] = S.arena_overflow; out[2] = S.n_leaves; out[3] = S.queue_overflow;
+    for (int i = 0; i < 4; i++) out[4 + i] = S.count[i + 1];
+    return FHIP_OK;
+}
+
+// ---- host graph ------------------------------------------------------------------------
+static const int UNARY_MAP[] = {FH_NEG, FH_ABS, FH_RECIP, FH_SQRT, FH_SQUARE, FH_FLOOR, FH_CEIL, FH_ROUND, FH_SIN,
+                                FH_COS, FH_TAN, FH_ASIN, FH_ACOS, FH_ATAN, FH_EXP, FH_LN, FH_NOT, FH_RAND};
+// BinaryOpcode order (context/op.rs:35-48): Add Sub Mul Div Atan Min Max Compare Mod And Or Mix
+static const int BINARY_MAP[] = {FH_ADD_RR, FH_SUB_RR, FH_MUL_RR, FH_DIV_RR, FH_ATAN2_RR, FH_MIN_RR, FH_MAX_RR,
+                                 FH_COMPARE_RR, FH_MOD_RR, FH_AND_RR, FH_OR_RR, FH_MIX_RR};
+fhip_graph* fhip_graph_new(void) { return new fhip_graph(); }
+void fhip_graph_free(fhip_graph* g) { delete g; }
+uint32_t fhip_graph_len(const fhip_graph* g) { return (uint32_t)g->g.nodes.size(); }
+uint32_t fhip_graph_var(fhip_graph* g, int kind, uint64_t index) { return g->g.var((uint8_t)kind, kind < 3 ? 0 : index); }
+uint32_t fhip_graph_constant(fhip_graph* g, float v) { return g->g.constant(v); }
+uint32_t fhip_graph_unary(fhip_graph* g, int opcode, uint32_t a) {
+    if (opcode < 0 || opcode >= 18) return fh::NO_NODE;
+    return g->g.unary(UNARY_MAP[opcode], a);
+}
+uint32_t fhip_graph_binary(fhip_graph* g, int opcode, uint32_t a, uint32_t b) {
+    if (opcode < 0 || opcode >= 12) return fh::NO_NODE;
+    return g->g.binary(BINARY_MAP[opcode], a, b);
+}
+uint32_t fhip_graph_from_text(fhip_graph* g, const char* text) {
+    std::string err;
+    return g->g.parse(text, err);
+}
+
+}  // extern "C"

@@ -1,0 +1,634 @@
+// fidget-hip: CDNA4 (gfx950) kernels for tape evaluation and tile rendering.
+//
+// Execution model (MI355X-first, not a port of the reference's CPU recursion):
+//   * a tape is a read-only array of 8-byte ops in HBM; every lane of a wave
+//     walks the SAME tape, so op words are fetched wave-uniformly (scalar loads)
+//     and decoded once per wave;
+//   * the per-lane register file of the interpreter lives in LDS,
+//     regs[reg][lane]  (bank = lane -> conflict free);
+//   * interval evaluation maps one TILE per lane, lanes of a wave = sibling
+//     tiles that share the parent's tape; the wave then prunes the tape for
+//     each child (two reverse sweeps: count, then emit with dense register
+//     renumbering) into a bump-allocated HBM arena;
+//   * point evaluation maps one voxel / pixel per lane, one 8x8 footprint per
+//     wave; 3D columns are walked front-to-back inside the wave so occluded
+//     voxels are never evaluated;
+//   * work flows level by level through device-side queues consumed by
+//     persistent workgroups (no host round trips inside a frame).
+//
+// Results are order independent: the 3D depth buffer is a 64-bit atomicMax of
+// (depth << 32 | leaf id), which reproduces the reference's sequential
+// front-to-back "first writer wins" semantics (fidget-raster/src/voxel.rs:275-484).
+#include <hip/hip_runtime.h>
+
+#include "dev_ops.hpp"
+#include "render_state.h"
+
+using namespace fhd;
+
+#define WAVE 64
+
+FH_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+FH_DEV uint64_t ballot(bool p) { return __ballot(p); }
+
+// --------------------------------------------------------------------------------------
+// LDS register file access.  LANES is the lane stride (64 for point kernels, 16 for
+// the tile kernel where at most 16 sibling tiles share a wave).
+template <class T, int LANES>
+struct Regs {
+    T* base;
+    int lane;
+    FH_DEV T get(uint32_t r) const { return base[r * LANES + lane]; }
+    FH_DEV void set(uint32_t r, T v) const { base[r * LANES + lane] = v; }
+};
+
+// One interpreter step shared by every kernel.  `in` supplies input slots, `on_out`
+// receives outputs, `on_choice` receives the Choice of min/max/and/or ops.
+template <class D, int LANES, class InFn, class OutFn, class ChoiceFn>
+FH_DEV void step(uint64_t w, const Regs<typename D::V, LANES>& R, InFn in, OutFn on_out, ChoiceFn on_choice) {
+    typedef typename D::V V;
+    const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
+    if (op >= FH_ADD_RR) {
+        V a, b;
+        int base;
+        bool swap_mul = false;
+        if (op < FH_ADD_RI) { base = op - FH_ADD_RR; a = R.get(ra); b = R.get(rb); }
+        else if (op < FH_SUB_IR) {
+            base = op - FH_ADD_RI; a = R.get(ra); b = D::imm(u2f(w1));
+            swap_mul = (base == 2);
+        } else {
+            // imm,reg forms: sub div atan2 compare mix mod -> bases 1 3 4 5 6 7
+            const int irb = op - FH_SUB_IR;
+            base = irb == 0 ? 1 : irb + 2;
+            a = D::imm(u2f(w1)); b = R.get(ra);
+        }
+        int c = FH_CHOICE_BOTH;
+        V r = swap_mul ? D::mul_imm(a, u2f(w1)) : D::binary(base, a, b, c);
+        R.set(ro, r);
+        if (base >= 8) on_choice(c);
+    } else if (op >= FH_NEG) {
+        R.set(ro, D::unary(op, R.get(ra)));
+    } else if (op == FH_INPUT) {
+        R.set(ro, in(w1));
+    } else if (op == FH_COPY_REG) {
+        R.set(ro, R.get(ra));
+    } else if (op == FH_COPY_IMM) {
+        R.set(ro, D::imm(u2f(w1)));
+    } else {
+        on_out(w1, R.get(ra));
+    }
+}
+
+// ======================================================================================
+// Trait-surface kernels (fhip_float_eval / fhip_point_eval / fhip_interval_eval /
+// fhip_grad_eval): one sample per lane, one wave per workgroup.
+// ======================================================================================
+// vars: [n_vars][n] f32; out: [n_out][n]; choices (optional): [n][n_choices] bytes,
+// simplify (optional): [n] bytes  (vm/mod.rs:543-760 / 794-1086)
+// GREGS: the register file of tapes too large for LDS lives in a global scratch slab
+// (one [n_regs][64] block per workgroup); only the trait-surface kernels need this.
+template <bool GREGS>
+__global__ void __launch_bounds__(WAVE)
+k_eval_f32(const uint64_t* __restrict__ tape, uint32_t len, const float* __restrict__ vars, uint32_t n,
+           float* __restrict__ out, uint8_t* __restrict__ choices, uint8_t* __restrict__ simplify, uint32_t n_choices,
+           float* gregs, uint32_t n_regs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * WAVE + lane;
+    const bool act = i < n;
+    const uint32_t ii = act ? i : 0;
+    Regs<float, WAVE> R{GREGS ? gregs + (size_t)blockIdx.x * n_regs * WAVE : (float*)smem, lane};
+    uint32_t ci = 0;
+    bool simp = false;
+    for (uint32_t k = 0; k < len; k++) {
+        const uint64_t w = tape[k];
+        step<F32, WAVE>(
+            w, R, [&](uint32_t slot) { return vars[(size_t)slot * n + ii]; },
+            [&](uint32_t slot, float v) { if (act) out[(size_t)slot * n + ii] = v; },
+            [&](int c) {
+                if (choices && act) choices[(size_t)ii * n_choices + ci] = (uint8_t)c;
+                simp |= (c != FH_CHOICE_BOTH);
+                ci++;
+            });
+    }
+    if (simplify && act) simplify[ii] = simp ? 1 : 0;
+}
+
+// vars: [n][n_vars] {lo,hi}; out: [n][n_out] {lo,hi}   (vm/mod.rs:325-538)
+template <bool GREGS>
+__global__ void __launch_bounds__(WAVE)
+k_eval_interval(const uint64_t* __restrict__ tape, uint32_t len, const float2* __restrict__ vars, uint32_t n_vars,
+                uint32_t n, float2* __restrict__ out, uint32_t n_out, uint8_t* __restrict__ choices,
+                uint8_t* __restrict__ simplify, uint32_t n_choices, IV* gregs, uint32_t n_regs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * WAVE + lane;
+    const bool act = i < n;
+    const uint32_t ii = act ? i : 0;
+    Regs<IV, WAVE> R{GREGS ? gregs + (size_t)blockIdx.x * n_regs * WAVE : (IV*)smem, lane};
+    uint32_t ci = 0;
+    bool simp = false;
+    for (uint32_t k = 0; k < len; k++) {
+        const uint64_t w = tape[k];
+        step<IVAL, WAVE>(
+            w, R,
+            [&](uint32_t slot) { float2 v = vars[(size_t)ii * n_vars + slot]; return iv(v.x, v.y); },
+            [&](uint32_t slot, IV v) { if (act) out[(size_t)ii * n_out + slot] = make_float2(v.lo, v.hi); },
+            [&](int c) {
+                if (choices && act) choices[(size_t)ii * n_choices + ci] = (uint8_t)c;
+                simp |= (c != FH_CHOICE_BOTH);
+                ci++;
+            });
+    }
+    if (simplify && act) simplify[ii] = simp ? 1 : 0;
+}
+
+// vars: [n_vars][n] {v,dx,dy,dz}; out: [n_out][n]   (vm/mod.rs:1091-1397)
+template <bool GREGS>
+__global__ void __launch_bounds__(WAVE)
+k_eval_grad(const uint64_t* __restrict__ tape, uint32_t len, const float4* __restrict__ vars, uint32_t n,
+            float4* __restrict__ out, GR* gregs, uint32_t n_regs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * WAVE + lane;
+    const bool act = i < n;
+    const uint32_t ii = act ? i : 0;
+    Regs<GR, WAVE> R{GREGS ? gregs + (size_t)blockIdx.x * n_regs * WAVE : (GR*)smem, lane};
+    for (uint32_t k = 0; k < len; k++) {
+        const uint64_t w = tape[k];
+        step<GRAD, WAVE>(
+            w, R,
+            [&](uint32_t slot) { float4 v = vars[(size_t)slot * n + ii]; return gr(v.x, v.y, v.z, v.w); },
+            [&](uint32_t slot, GR v) { if (act) out[(size_t)slot * n + ii] = make_float4(v.v, v.dx, v.dy, v.dz); },
+            [&](int) {});
+    }
+}
+
+// ======================================================================================
+// Rendering
+// ======================================================================================
+FH_DEV float input_value_f(const FhRender& P, uint32_t slot, float x, float y, float z) {
+    const uint32_t k = P.in_kind[slot];
+    return k == 0 ? x : (k == 1 ? y : (k == 2 ? z : P.in_value[slot]));
+}
+
+// Wave-wide exclusive prefix sum over lanes (and total) of a per-lane count
+FH_DEV uint32_t wave_excl_sum(uint32_t v, uint32_t& total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, WAVE);
+        if ((int)(threadIdx.x & 63) >= d) x += y;
+    }
+    total = __shfl(x, WAVE - 1, WAVE);
+    return x - v;
+}
+FH_DEV uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, WAVE));
+    return v;
+}
+
+// 256-bit free-register pool held in VGPRs (lowest free first)
+struct Pool {
+    uint64_t f0, f1, f2, f3;
+    int high;
+    FH_DEV void init() { f0 = f1 = f2 = f3 = ~0ull; high = 0; }
+    FH_DEV int take() {
+        int r;
+        if (f0) { r = __builtin_ctzll(f0); f0 &= f0 - 1; }
+        else if (f1) { r = 64 + __builtin_ctzll(f1); f1 &= f1 - 1; }
+        else if (f2) { r = 128 + __builtin_ctzll(f2); f2 &= f2 - 1; }
+        else { r = 192 + __builtin_ctzll(f3); f3 &= f3 - 1; }
+        high = max(high, r + 1);
+        return r;
+    }
+    FH_DEV void give(int r) {
+        const uint64_t b = 1ull << (r & 63);
+        const int w = r >> 6;
+        if (w == 0) f0 |= b; else if (w == 1) f1 |= b; else if (w == 2) f2 |= b; else f3 |= b;
+    }
+};
+
+#define TL 16  // lane stride of the tile kernel (<= 16 sibling tiles per wave)
+#define DEAD 0xFFu
+
+// Reverse sweep over the parent tape for one child tile (one lane):
+//   EMIT = false: count surviving ops
+//   EMIT = true : write them (back to front) with densely renumbered registers
+// This is the device form of VmData::simplify (fidget-core/src/vm/data.rs:123-318):
+// ops whose value is never used are dropped, a min/max/and/or whose trace says
+// Left/Right is replaced by its surviving operand (aliased when that operand is
+// not otherwise live yet, copied when it is).
+template <bool EMIT>
+FH_DEV void prune_sweep(const uint64_t* __restrict__ tape, uint32_t len, uint32_t n_choices, const uint32_t* chbits,
+                        uint8_t* map, int lane16, bool act, uint64_t* dst /*one past the last op*/, uint32_t& out_len,
+                        uint32_t& out_regs, uint32_t& out_choices) {
+    Pool pool;
+    pool.init();
+    uint32_t ci = n_choices;
+    uint32_t cw = 0;
+    uint32_t count = 0, kept_choices = 0;
+    auto M = [&](uint32_t r) -> uint8_t& { return map[r * TL + lane16]; };
+    auto use = [&](uint32_t r) -> uint32_t {  // register holding old value r before this op
+        uint32_t m = M(r);
+        if (m == DEAD) { m = EMIT ? (uint32_t)pool.take() : 0u; M(r) = (uint8_t)m; }
+        return m;
+    };
+    for (uint32_t k = len; k-- > 0;) {
+        const uint64_t w = tape[k];
+        const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+        const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
+        const bool is_choice = fh_is_choice(op);
+        uint32_t c = FH_CHOICE_BOTH;
+        if (is_choice) {
+            ci--;
+            if ((ci & 15) == 15 || ci == n_choices - 1) cw = chbits[(ci >> 4) * TL + lane16];
+            c = (cw >> ((ci & 15) * 2)) & 3;
+        }
+        if (!act) continue;
+        if (op == FH_OUTPUT) {
+            const uint32_t na = use(ra);
+            if (EMIT) *--dst = fh_pack(op, 0, na, 0, w1);
+            count++;
+            continue;
+        }
+        const uint32_t no = M(ro);
+        if (no == DEAD) continue;  // value never used
+        M(ro) = DEAD;
+        // which operand survives a decided choice
+        int alias = -1;  // old register aliased by `out`, or -1
+        bool copy_imm = false;
+        if (op == FH_COPY_REG) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_LEFT) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_RIGHT) {
+            if (fh_is_rr(op)) alias = (int)rb; else copy_imm = true;
+        }
+        if (alias >= 0) {
+            if (M(alias) == DEAD) { M(alias) = (uint8_t)no; continue; }  // hand the register over, no op
+            if (EMIT) { pool.give(no); *--dst = fh_pack(FH_COPY_REG, no, M(alias), 0, 0); }
+            count++;
+            continue;
+        }
+        if (EMIT) pool.give(no);
+        if (copy_imm) {
+            if (EMIT) *--dst = fh_pack(FH_COPY_IMM, no, 0, 0, w1);
+            count++;
+            continue;
+        }
+        uint32_t na = 0, nb = 0;
+        if (op != FH_INPUT && op != FH_COPY_IMM) na = use(ra);
+        if (fh_is_rr(op)) nb = use(rb);
+        if (is_choice) kept_choices++;
+        if (EMIT) *--dst = fh_pack(op, no, na, nb, w1);
+        count++;
+    }
+    out_len = count;
+    out_regs = (uint32_t)pool.high;
+    out_choices = kept_choices;
+}
+
+// Pixel footprint occlusion test (voxel.rs:283-289): true when every in-image pixel of
+// the T x T footprint already has depth >= fill_z.  All 64 lanes cooperate.
+FH_DEV bool footprint_occluded(const FhRender& P, const uint64_t* zbuf, uint32_t cx, uint32_t cy, uint32_t T, uint32_t fill_z) {
+    uint32_t mn = 0xFFFFFFFFu;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t p = lane; p < T * T; p += WAVE) {
+        const uint32_t x = cx + (p % T), y = cy + (p / T);
+        if (x < P.width && y < P.height) mn = min(mn, (uint32_t)(zbuf[(size_t)y * P.width + x] >> 32));
+    }
+    return wave_min(mn) >= fill_z;
+}
+
+// The tile kernel: interval-evaluate the children of one parent tile per wave, classify
+// them, fill / discard the decided ones and emit pruned tapes + next-level work for the
+// ambiguous ones.  Persistent workgroups pull parents from queue[level].
+template <bool IS3D>
+__global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FhRender& P = S->P;
+    const int lane = threadIdx.x;
+    const int lane16 = lane & (TL - 1);
+    IV* regs = (IV*)smem;                                            // [max_regs][TL]
+    uint32_t* chbits = (uint32_t*)(smem + (size_t)P.max_regs * TL * sizeof(IV));   // [(max_choices+15)/16][TL]
+    uint8_t* map = (uint8_t*)(chbits + (size_t)((P.max_choices + 15) / 16) * TL);  // [max_regs][TL]
+    const uint64_t* arena = S->arena;
+    const uint32_t T = P.tiles[level];
+    const bool last_level = (level + 1 == (int)P.n_levels);
+
+    for (;;) {
+        uint32_t gi = 0;
+        if (lane == 0) gi = atomicAdd(&S->cursor[level], 1u);
+        gi = uni(gi);
+        if (gi >= S->count[level]) break;
+        const FhGroup g = S->queue[level][gi];
+        const uint64_t* tape = arena + g.tape.off;
+        const uint32_t len = g.tape.len, n_choices = g.tape.n_choices, n_regs = g.tape.n_regs;
+
+        // ---- enumerate children ------------------------------------------------
+        uint32_t nchild, cx, cy, cz;
+        if (level == 0) {
+            nchild = g.n;
+            const uint32_t ri = g.first + lane16 * g.stride;  // root index, x-major (lib.rs:116-123)
+            cx = (ri / P.roots_y) * T; cy = (ri % P.roots_y) * T; cz = g.z;
+        } else {
+            const uint32_t n = P.tiles[level - 1] / T;
+            nchild = IS3D ? n * n * n : n * n;
+            const uint32_t ci = lane16 % n, cj = (lane16 / n) % n, ck = IS3D ? lane16 / (n * n) : 0;
+            cx = g.x + ci * T; cy = g.y + cj * T; cz = g.z + ck * T;
+        }
+        bool act = lane < (int)nchild;
+        const uint32_t fill_z = cz + T + 1;
+
+        // ---- occlusion (3D only; never changes results, only skips work) -------------
+        if (IS3D) {
+            uint32_t occ = 0;
+            for (uint32_t c = 0; c < nchild; c++) {
+                const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE), cfz = __shfl(fill_z, c, WAVE);
+                if (footprint_occluded(P, S->zbuf, ccx, ccy, T, cfz)) occ |= 1u << c;
+            }
+            if (act && ((occ >> lane) & 1)) act = false;
+            if (ballot(act) == 0) continue;
+        }
+
+        // ---- forward interval pass, trace packed 2 bits per choice ------------------
+        IV X, Y, Z;
+        {
+            const IV sx = iv((float)cx, (float)cx + (float)T), sy = iv((float)cy, (float)cy + (float)T);
+            const IV sz = IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z);
+            xf_interval(*(const Mat4*)P.mat, sx, sy, sz, X, Y, Z);
+        }
+        Regs<IV, TL> R{regs, lane16};
+        IV result = iv_nan();
+        uint32_t ci = 0, cw = 0;
+        bool any_decided = false;
+        if (lane < TL) {
+            for (uint32_t k = 0; k < len; k++) {
+                const uint64_t w = tape[k];
+                step<IVAL, TL>(
+                    w, R,
+                    [&](uint32_t slot) {
+                        const uint32_t kd = P.in_kind[slot];
+                        return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot])));
+                    },
+                    [&](uint32_t, IV v) { result = v; },
+                    [&](int c) {
+                        cw |= (uint32_t)c << ((ci & 15) * 2);
+                        any_decided |= (c != FH_CHOICE_BOTH);
+                        if ((ci & 15) == 15) { chbits[(ci >> 4) * TL + lane16] = cw; cw = 0; }
+                        ci++;
+                    });
+            }
+            if (ci & 15) chbits[(ci >> 4) * TL + lane16] = cw;
+        }
+
+        // ---- classify (voxel.rs:310-320, pixel.rs:345-368) -----------------------------
+        const bool full = act && (IS3D || !P.pixel_perfect) && result.hi < 0.0f;
+        const bool empty = act && (IS3D || !P.pixel_perfect) && !full && result.lo > 0.0f;
+        const bool amb = act && !full && !empty;
+
+        // fills, cooperatively over the 64 lanes
+        {
+            uint64_t fm = ballot(full) | (IS3D ? 0ull : ballot(empty));
+            while (fm) {
+                const int c = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
+                if (IS3D) {
+                    const uint64_t v = (uint64_t)__shfl(fill_z, c, WAVE) << 32;
+                    for (uint32_t p = lane; p < T * T; p += WAVE) {
+                        const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                        if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
+                    }
+                } else {
+                    const bool inside = (ballot(full) >> c) & 1;
+                    const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (inside ? 1u : 0u) | (0xF6u << 9));
+                    for (uint32_t p = lane; p < T * T; p += WAVE) {
+                        const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                        if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;
+                    }
+                }
+            }
+        }
+        if (ballot(amb) == 0) continue;
+
+        // ---- prune the tape for every ambiguous child whose trace decided something ----
+        const bool prune = amb && any_decided;
+        FhTapeRef child = g.tape;
+        if (ballot(prune)) {
+            uint32_t clen = 0, cregs = 0, cch = 0;
+            if (lane < TL) {
+                for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
+                prune_sweep<false>(tape, len, n_choices, chbits, map, lane16, prune, nullptr, clen, cregs, cch);
+            }
+            uint32_t total;
+            const uint32_t my = prune ? clen : 0;
+            const uint32_t excl = wave_excl_sum(my, total);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&S->arena_head, total);
+            base = uni(base);
+            if (base + total <= S->arena_cap) {
+                if (lane < TL) {
+                    for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
+                    uint64_t* dst = S->arena + base + excl + clen;
+                    prune_sweep<true>(tape, len, n_choices, chbits, map, lane16, prune, dst, clen, cregs, cch);
+                }
+                if (prune) {
+                    child.off = base + excl; child.len = clen;
+                    child.n_regs = (uint16_t)cregs; child.n_choices = (uint16_t)cch;
+                }
+            } else if (lane == 0) {
+                atomicAdd(&S->arena_overflow, 1u);  // children fall back to the parent tape
+            }
+        }
+
+        // ---- hand ambiguous children to the next stage ------------------------------------
+        uint32_t namb;
+        const uint32_t slot = wave_excl_sum(amb ? 1u : 0u, namb);
+        if (!last_level) {
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&S->count[level + 1], namb);
+            qb = uni(qb);
+            if (amb && qb + slot < S->queue_cap) {
+                FhGroup o;
+                o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = 0; o.stride = 0;
+                S->queue[level + 1][qb + slot] = o;
+            } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+        } else {
+            uint32_t lb = 0;
+            if (lane == 0) lb = atomicAdd(&S->n_leaves, namb);
+            lb = uni(lb);
+            if (amb && lb + slot < S->leaf_cap) {
+                FhLeaf lf;
+                lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
+                S->leaves[lb + slot] = lf;
+                if (IS3D) {
+                    const uint32_t fw = (P.width + T - 1) / T;
+                    const uint32_t layers = P.tiles[0] / T;
+                    S->leaf_table[((size_t)(cy / T) * fw + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
+                }
+            } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+        }
+    }
+}
+
+// 2D leaves: one 8x8 (T x T, T*T <= 64) pixel tile per wave (pixel.rs:400-441)
+__global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FhRender& P = S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[P.n_levels - 1];
+    Regs<float, WAVE> R{(float*)smem, lane};
+    for (;;) {
+        uint32_t li = 0;
+        if (lane == 0) li = atomicAdd(&S->leaf_cursor, 1u);
+        li = uni(li);
+        if (li >= min(S->n_leaves, S->leaf_cap)) break;
+        const FhLeaf lf = S->leaves[li];
+        const uint64_t* tape = S->arena + lf.tape.off;
+        for (uint32_t p0 = 0; p0 < T * T; p0 += WAVE) {
+            const uint32_t p = p0 + lane;
+            const uint32_t px = lf.x + (p % T), py = lf.y + (p / T);
+            float x, y, z, res = 0.0f;
+            xf_point(*(const Mat4*)P.mat, (float)px, (float)py, P.z, x, y, z);
+            for (uint32_t k = 0; k < lf.tape.len; k++) {
+                const uint64_t w = tape[k];
+                step<F32, WAVE>(
+                    w, R, [&](uint32_t slot) { return input_value_f(P, slot, x, y, z); },
+                    [&](uint32_t, float v) { res = v; }, [&](int) {});
+            }
+            if (p < T * T && px < P.width && py < P.height)
+                S->image2d[(size_t)py * P.width + px] = isnan_(res) ? u2f(0x7FC00000u) : res;  // pixel.rs:235-241
+        }
+    }
+}
+
+// 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
+// each leaf front to back in z, lanes dropping out once their column has been hit or is
+// occluded (voxel.rs:359-463).  Only the winning hit of a column is ever evaluated.
+__global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FhRender& P = S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[P.n_levels - 1];  // T*T == 64 lanes
+    const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
+    const uint32_t layers = P.tiles[0] / T;
+    Regs<float, WAVE> R{(float*)smem, lane};
+    for (;;) {
+        uint32_t fi = 0;
+        if (lane == 0) fi = atomicAdd(&S->leaf_cursor, 1u);
+        fi = uni(fi);
+        if (fi >= fw * fh) break;
+        const uint32_t* col = S->leaf_table + (size_t)fi * layers;
+        const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
+        const bool inimg = px < P.width && py < P.height;
+        const size_t pix = (size_t)py * P.width + px;
+        uint32_t depth = inimg ? (uint32_t)(S->zbuf[pix] >> 32) : 0xFFFFFFFFu;
+        uint32_t hit_leaf = 0;
+        for (int zl = (int)layers - 1; zl >= 0; zl--) {
+            const uint32_t id = col[zl];
+            if (id == 0) continue;
+            const FhLeaf lf = S->leaves[id - 1];
+            const uint32_t zmax = lf.z + T;
+            bool pending = depth < zmax;  // voxel.rs:377-381
+            if (ballot(pending) == 0) break;  // everything behind is occluded as well
+            const uint64_t* tape = S->arena + lf.tape.off;
+            for (int k = (int)T - 1; k >= 0; k--) {
+                float x, y, z, res = 0.0f;
+                xf_point(*(const Mat4*)P.mat, (float)px, (float)py, (float)(lf.z + k), x, y, z);
+                for (uint32_t q = 0; q < lf.tape.len; q++) {
+                    const uint64_t w = tape[q];
+                    step<F32, WAVE>(
+                        w, R, [&](uint32_t slot) { return input_value_f(P, slot, x, y, z); },
+                        [&](uint32_t, float v) { res = v; }, [&](int) {});
+                }
+                if (pending && res < 0.0f) {  // first voxel inside, front to back
+                    depth = lf.z + k + 1;
+                    hit_leaf = id;
+                    pending = false;
+                }
+                if (ballot(pending) == 0) break;
+            }
+        }
+        if (hit_leaf) S->zbuf[pix] = ((uint64_t)depth << 32) | hit_leaf;
+    }
+}
+
+// Normals for the hits of this slab: gradient of the winning leaf's tape at the voxel one
+// above the hit (voxel.rs:447-482).  Lanes of a footprint may have been hit in different
+// leaves; the wave loops over the distinct ones.
+__global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FhRender& P = S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[P.n_levels - 1];
+    const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
+    Regs<GR, WAVE> R{(GR*)smem, lane};
+    for (;;) {
+        uint32_t fi = 0;
+        if (lane == 0) fi = atomicAdd(&S->normal_cursor, 1u);
+        fi = uni(fi);
+        if (fi >= fw * fh) break;
+        const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
+        const bool inimg = px < P.width && py < P.height;
+        const size_t pix = (size_t)py * P.width + px;
+        const uint64_t zb = inimg ? S->zbuf[pix] : 0;
+        uint32_t id = (uint32_t)zb;
+        const uint32_t depth = (uint32_t)(zb >> 32);
+        uint64_t todo = ballot(id != 0);
+        while (todo) {
+            const uint32_t cur = __shfl(id, __builtin_ctzll(todo), WAVE);
+            const bool mine = (id == cur);
+            const FhLeaf lf = S->leaves[cur - 1];
+            const uint64_t* tape = S->arena + lf.tape.off;
+            GR gx, gy, gz, res = gr1(0.0f);
+            xf_grad(*(const Mat4*)P.mat, gr((float)px, 1, 0, 0), gr((float)py, 0, 1, 0), gr((float)(depth - 1), 0, 0, 1), gx, gy, gz);
+            for (uint32_t q = 0; q < lf.tape.len; q++) {
+                const uint64_t w = tape[q];
+                step<GRAD, WAVE>(
+                    w, R,
+                    [&](uint32_t slot) {
+                        const uint32_t kd = P.in_kind[slot];
+                        return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot])));
+                    },
+                    [&](uint32_t, GR v) { res = v; }, [&](int) {});
+            }
+            if (mine) {
+                S->normals[pix * 3 + 0] = res.dx; S->normals[pix * 3 + 1] = res.dy; S->normals[pix * 3 + 2] = res.dz;
+                S->zbuf[pix] = zb & 0xFFFFFFFF00000000ull;  // normal done
+                id = 0;
+            }
+            todo &= ~ballot(mine);
+        }
+    }
+}
+
+// Per-slab reset of the work queues, leaf table and tape arena (root tape stays)
+__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab_z, uint32_t n_root_groups) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
+    if (i == 0) {
+        for (int l = 0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; }
+        S->count[0] = n_root_groups;
+        S->n_leaves = 0; S->leaf_cursor = 0; S->normal_cursor = 0;
+        S->arena_head = S->arena_root_end;
+    }
+    if (i < n_root_groups) S->queue[0][i].z = slab_z;
+}
+
+// Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
+__global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
+    const FhRender& P = S->P;
+    const size_t n = (size_t)P.width * P.height;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t d = (uint32_t)(S->zbuf[i] >> 32);
+        FhGeometryPixel o;
+        if (d >= P.depth - 1) { o.normal[0] = 0.0f; o.normal[1] = 0.0f; o.normal[2] = 1.0f; o.depth = P.depth; }
+        else { o.normal[0] = S->normals[i * 3]; o.normal[1] = S->normals[i * 3 + 1]; o.normal[2] = S->normals[i * 3 + 2]; o.depth = d; }
+        out[i] = o;
+    }
+}
+
+template __global__ void k_tiles<false>(FhRenderState*, int);
+template __global__ void k_tiles<true>(FhRenderState*, int);

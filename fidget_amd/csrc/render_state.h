@@ -1,0 +1,65 @@
+// Device-resident state of one render, shared by the host driver (capi.hip) and the
+// kernels.  Plain C structs; all device pointers.
+#pragma once
+#include <stdint.h>
+
+#include "tape_format.h"
+
+#define FH_MAX_LEVELS 8
+#define FH_MAX_INPUTS 16
+
+// One wave's worth of interval work: a parent tile (or, at level 0, a run of root tiles)
+// together with the tape that evaluates its children.
+struct FhGroup {
+    FhTapeRef tape;
+    uint32_t x, y, z;     // parent corner in pixels / voxels (levels >= 1); z also used at level 0
+    uint32_t first, n;    // level 0 only: first root-tile index (x-major) and how many (<= 16)
+    uint32_t stride;      // level 0 only: index step between the group's root tiles (multi-GPU shards)
+};
+
+// An ambiguous smallest tile: evaluated point by point
+struct FhLeaf {
+    FhTapeRef tape;
+    uint32_t x, y, z;
+};
+
+// fidget_raster::voxel::GeometryPixel (fidget-raster/src/voxel.rs:122-134)
+struct FhGeometryPixel {
+    float normal[3];
+    uint32_t depth;
+};
+
+// Per-render constants
+struct FhRender {
+    float mat[16];                   // screen -> model, row major (voxel.rs:107-109 / pixel.rs:281-285)
+    uint32_t width, height, depth;   // depth = 0 for 2D
+    float z;                         // 2D slice height
+    uint32_t pixel_perfect;
+    uint32_t n_levels;
+    uint32_t tiles[FH_MAX_LEVELS];   // tile sizes, largest first (after TileSizesRef trimming)
+    uint32_t roots_x, roots_y;       // root tile grid
+    uint32_t max_regs, max_choices;  // of the root tape: bounds for every tape of the frame
+    uint32_t in_kind[FH_MAX_INPUTS]; // per input slot: 0 x, 1 y, 2 z, 3 bound constant
+    float in_value[FH_MAX_INPUTS];
+};
+
+struct FhRenderState {
+    FhRender P;
+    // tape arena (8-byte ops)
+    uint64_t* arena;
+    uint32_t arena_cap, arena_head, arena_root_end, arena_overflow;
+    // level queues
+    FhGroup* queue[FH_MAX_LEVELS];
+    uint32_t count[FH_MAX_LEVELS], cursor[FH_MAX_LEVELS];
+    uint32_t queue_cap, queue_overflow;
+    // leaves
+    FhLeaf* leaves;
+    uint32_t leaf_cap, n_leaves, leaf_cursor, normal_cursor;
+    uint32_t* leaf_table;   // 3D: [footprint][layer] -> leaf id + 1
+    // images
+    uint64_t* zbuf;         // 3D: depth << 32 | leaf id (+1) of a hit whose normal is pending
+    float* normals;         // 3D: 3 floats per pixel
+    float* image2d;         // 2D: RawDistancePixel bits
+    // statistics (optional, for bench / roofline accounting)
+    unsigned long long stat[8];
+};

@@ -1,0 +1,165 @@
+/* fidget_hip.h — C ABI of libfidget_hip.so: the MI355X (gfx950) backend for Fidget's
+ * evaluation hot path.
+ *
+ * This is the drop-in boundary.  A Rust crate `fidget-hip` binds these symbols
+ *  and implements fidget_core::eval::{Function, MathFunction,
+ * Tape, TracingEvaluator, BulkEvaluator} + render::RenderHints on top of them, the
+ * same way `fidget-jit` wraps `VmData` and replaces only tapes and evaluators
+ * (/root/reference/fidget-jit/src/lib.rs:872-998).  Every entry point names the
+ * reference interface it replaces.
+ *
+ * Conventions: plain C, no unwinding; every call returns an fhip_status; all
+ * `const T*` / `T*` arguments are CALLER-OWNED HOST buffers unless a parameter is
+ * documented as a device pointer; one fhip_ctx per host thread / HIP stream
+ * (evaluators in the reference are per-thread too, fidget-raster/src/lib.rs:129-133).
+ */
+#ifndef FIDGET_HIP_H
+#define FIDGET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fhip_status {
+    FHIP_OK = 0,
+    FHIP_ERR_BAD_VAR_SLICE = 1,     /* var/mod.rs:151-165  TracingArgError / BulkArgError::BadVarSlice */
+    FHIP_ERR_MISMATCHED_SLICES = 2, /* var/mod.rs:167-197  BulkArgError::MismatchedSlices */
+    FHIP_ERR_BAD_CHOICE_SLICE = 3,  /* vm/data.rs:129-134  BadTrace(BadChoiceSlice) */
+    FHIP_ERR_MISSING_VAR = 4,       /* shape/mod.rs:391-396 MissingVar */
+    FHIP_ERR_BAD_TAPE = 5,          /* malformed bytecode / bad node (context BadNode) */
+    FHIP_ERR_UNSUPPORTED = 6,       /* e.g. > 256 live registers, tile fan-out > 16 */
+    FHIP_ERR_HIP = 7,               /* a HIP runtime call failed; see fhip_last_error */
+    FHIP_ERR_CANCELLED = 8,         /* render/config.rs:38-80 CancelToken */
+    FHIP_ERR_PARSE = 9,             /* context/mod.rs ParseError */
+    FHIP_ERR_OVERFLOW = 10          /* a device work queue overflowed (sizes are bounds; should not happen) */
+} fhip_status;
+
+typedef struct fhip_ctx fhip_ctx;     /* device, stream, scratch pools        */
+typedef struct fhip_tape fhip_tape;   /* one compiled function (host + device) */
+typedef struct fhip_graph fhip_graph; /* host mirror of fidget_core::Context   */
+
+/* ---- context ------------------------------------------------------------------------ */
+/* `stream` is a hipStream_t (NULL = the default stream), e.g. torch's current stream. */
+fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out);
+void fhip_ctx_destroy(fhip_ctx* ctx);
+const char* fhip_last_error(const fhip_ctx* ctx);
+fhip_status fhip_ctx_sync(fhip_ctx* ctx);
+/* render/config.rs:38-80: cooperative cancellation, honoured between kernel waves */
+void fhip_cancel(fhip_ctx* ctx);
+void fhip_cancel_reset(fhip_ctx* ctx);
+
+/* ---- tapes -------------------------------------------------------------------------- */
+/* The wire format produced by fidget_bytecode::Bytecode::new(&VmData)
+ * (fidget-bytecode/src/lib.rs:11-42, 203-332).  Replaces JitFunction's
+ * `point_tape/interval_tape/float_slice_tape/grad_slice_tape` compilation
+ * (fidget-jit/src/lib.rs:875-908): one device tape serves all four evaluators.
+ * Variable slots are the reference's VarMap indices. */
+fhip_status fhip_tape_from_bytecode(fhip_ctx* ctx, const uint32_t* words, size_t n_words, fhip_tape** out);
+void fhip_tape_free(fhip_tape* tape);
+uint32_t fhip_tape_len(const fhip_tape* tape);          /* Function::size      eval/mod.rs:171 */
+uint32_t fhip_tape_choice_count(const fhip_tape* tape); /* Function::can_simplify != 0 */
+uint32_t fhip_tape_reg_count(const fhip_tape* tape);
+uint32_t fhip_tape_var_count(const fhip_tape* tape);    /* Tape::vars().len()  eval/mod.rs:41 */
+uint32_t fhip_tape_output_count(const fhip_tape* tape); /* Tape::output_count  eval/mod.rs:47 */
+/* Copy the device-format ops (8 bytes each, evaluation order) to `ops`; returns the length */
+uint32_t fhip_tape_ops(const fhip_tape* tape, uint64_t* ops, uint32_t cap);
+
+/* Function::simplify (eval/mod.rs:147-160; VmData::simplify vm/data.rs:123-318).
+ * `choices` is one byte per choice op in evaluation order, values 1/2/3 = Left/Right/Both. */
+fhip_status fhip_simplify(fhip_ctx* ctx, const fhip_tape* tape, const uint8_t* choices, uint32_t n_choices,
+                          fhip_tape** child);
+
+/* ---- evaluators (trait surface; batched over n samples) ----------------------------- */
+/* TracingEvaluator<Data = Interval>::eval (eval/tracing.rs:26-64, vm/mod.rs:325-538).
+ * vars: [n][n_vars][2] (lo,hi); out: [n][n_outputs][2]; choices: [n][choice_count] or NULL;
+ * simplify: [n] (1 = a trace would be returned) or NULL.  n_vars may exceed the tape's. */
+fhip_status fhip_interval_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* vars, uint32_t n_vars, uint32_t n,
+                               float* out, uint8_t* choices, uint8_t* simplify);
+/* TracingEvaluator<Data = f32>::eval (vm/mod.rs:543-760).  vars: [n][n_vars]; out: [n][n_outputs] */
+fhip_status fhip_point_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* vars, uint32_t n_vars, uint32_t n,
+                            float* out, uint8_t* choices, uint8_t* simplify);
+/* BulkEvaluator<Data = f32>::eval (eval/bulk.rs:23-58, vm/mod.rs:794-1086).
+ * vars[i] -> lens[i] floats (all lens must be equal, else MISMATCHED_SLICES);
+ * out[o] -> n floats for each of the tape's outputs. */
+fhip_status fhip_float_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* const* vars, const uint32_t* lens,
+                            uint32_t n_vars, float* const* out);
+/* BulkEvaluator<Data = Grad>::eval (vm/mod.rs:1091-1397).  Grad = {v,dx,dy,dz} (types/grad.rs:4-13) */
+fhip_status fhip_grad_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* const* vars, const uint32_t* lens,
+                           uint32_t n_vars, float* const* out);
+
+/* ---- batched renders (the throughput path) ------------------------------------------ */
+/* fidget_raster::pixel::{RenderConfig, EvalConfig} (fidget-raster/src/pixel.rs:27-57) */
+typedef struct fhip_render2d_config {
+    uint32_t width, height;
+    const float* world_to_model;   /* row-major 3x3, NULL = identity */
+    float z;
+    int pixel_perfect;
+    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_2d() of the VM: {128,32,8} */
+    uint32_t n_tile_sizes;
+    const uint64_t* var_keys;      /* ShapeVars<f32>: Var::V index -> value */
+    const float* var_values;
+    uint32_t n_vars;
+    const int32_t* axis_slots;     /* VarMap slot of X, Y, Z (-1 = absent); NULL = use the tape's own map */
+} fhip_render2d_config;
+/* fidget_raster::voxel::{RenderConfig, EvalConfig} (fidget-raster/src/voxel.rs:25-54) */
+typedef struct fhip_render3d_config {
+    uint32_t width, height, depth;
+    const float* world_to_model;   /* row-major 4x4, NULL = identity */
+    const uint32_t* tile_sizes;    /* NULL = {128,64,32,16,8} */
+    uint32_t n_tile_sizes;
+    const uint64_t* var_keys;
+    const float* var_values;
+    uint32_t n_vars;
+    const int32_t* axis_slots;
+} fhip_render3d_config;
+
+/* fidget_raster::pixel::render (pixel.rs:452-492).  out: width*height RawDistancePixel (f32
+ * bit patterns, pixel.rs:159-241); a device pointer when out_is_device != 0, in which case
+ * the call is asynchronous on the context's stream. */
+fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
+                          int out_is_device);
+/* fidget_raster::voxel::render (voxel.rs:500-553).  out: width*height GeometryPixel
+ * {f32 normal[3]; u32 depth} (voxel.rs:122-134). */
+fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                          int out_is_device);
+/* Multi-GPU 3D: render only root-tile columns whose index (x-major, lib.rs:116-123)
+ * satisfies index % n_shards == shard; other pixels are left {0,0,0,0} so that the partial
+ * images combine with an element-wise max on depth (no pixel is produced twice). */
+fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t shard, uint32_t n_shards);
+
+/* ---- profiling ----------------------------------------------------------------------- */
+/* When enabled, every kernel launch of a render is bracketed by HIP events on the context's
+ * stream; fhip_profile_read returns per-kernel-class totals of the last render. */
+enum { FHIP_K_TILES = 0, FHIP_K_POINTS = 1, FHIP_K_NORMALS = 2, FHIP_K_OTHER = 3, FHIP_K_COUNT = 4 };
+void fhip_profile_enable(fhip_ctx* ctx, int on);
+fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4]);
+/* Device-side counters of the last render: arena ops used (peak), arena overflows, leaves */
+fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
+
+/* ---- host mirror of fidget_core::Context (no Rust toolchain here; tests + demos) ------ */
+/* Opcode numbers = declaration order of UnaryOpcode / BinaryOpcode (context/op.rs:11-48). */
+fhip_graph* fhip_graph_new(void);
+void fhip_graph_free(fhip_graph* g);
+uint32_t fhip_graph_len(const fhip_graph* g);
+uint32_t fhip_graph_var(fhip_graph* g, int axis_or_3, uint64_t index); /* 0 X, 1 Y, 2 Z, 3 Var::V(index) */
+uint32_t fhip_graph_constant(fhip_graph* g, float v);
+uint32_t fhip_graph_unary(fhip_graph* g, int opcode, uint32_t a);              /* 0xFFFFFFFF = BadNode */
+uint32_t fhip_graph_binary(fhip_graph* g, int opcode, uint32_t a, uint32_t b);
+uint32_t fhip_graph_from_text(fhip_graph* g, const char* text);               /* Context::from_text */
+/* MathFunction::new (eval/mod.rs:203-208) */
+fhip_status fhip_tape_from_graph(fhip_ctx* ctx, const fhip_graph* g, const uint32_t* roots, uint32_t n_roots,
+                                 fhip_tape** out);
+/* VarMap of a graph-built tape: slot of X/Y/Z (axis 0..2) or of Var::V(index); -1 if absent */
+int fhip_tape_axis_slot(const fhip_tape* tape, int axis);
+int fhip_tape_var_slot(const fhip_tape* tape, uint64_t index);
+
+/* RegionSize::screen_to_world (render/region.rs:87-108); n = 2 -> 3x3, n = 3 -> 4x4, row major */
+void fhip_screen_to_world(const uint32_t* size, int n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
