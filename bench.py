@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of fidget-hip on MI355X.
+
+Metric (BASELINE.json): Mvoxel/s of the heightmap+normals render (interval + point
+evaluation) of prospero.vm at 1024^3, nominal volume / wall time
+(W*H*D / t / 1e6, the convention of the reference's README.md:152-156).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 through torch.distributed.run).  A step is
+one full frame.  With N > 1 the frame is sharded by root-tile column (index % N == rank,
+no data-path collective inside the render) and the 16 MiB partial images are combined on
+rank 0 by ONE RCCL reduce over xGMI (integer SUM of the raw pixel words: every pixel is
+produced by exactly one rank, the others hold zeros, so the sum is bit-exact).  Total work
+is fixed as N grows -> "strong" scaling.
+
+Prints ONE JSON line on rank 0, including
+  roofline     — for the dominant kernel (k_columns3d, the point interpreter): algorithmic
+                 bytes (8 B per tape word per wavefront pass, exact because pruning
+                 is deterministic; taken from the oracle's counters) / kernel time measured
+                 with HIP events on the render stream, vs the 8 TB/s HBM peak;
+  cpu_baseline — the C++ oracle (restatement of the reference's VmShape path, OpenMP over
+                 root tiles like render_tiles' rayon pool) on this box's host cores, same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--model", default="prospero.vm")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import fidget_amd as F
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.size
+    stream = torch.cuda.current_stream(dev)
+    hip = F.HipContext(local, stream.cuda_stream)
+    shape = F.Shape.from_vm(os.path.join(ROOT, "models", args.model), hip=hip)
+    out = torch.zeros((n, n, 4), dtype=torch.int32, device=dev)  # GeometryPixel = 4 x 32-bit words
+
+    def step():
+        F.render3d(shape, n, out=out, shard=rank, n_shards=world)
+        if world > 1:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    hip.sync()
+    counters = hip.counters()
+
+    # ---- per-kernel timing with HIP events on the render stream (separate, profiled frames) ----
+    hip.profile(True)
+    prof = {"tiles": [0.0, 0], "points": [0.0, 0], "normals": [0.0, 0], "other": [0.0, 0]}
+    PROF_FRAMES = 3
+    for _ in range(PROF_FRAMES):
+        F.render3d(shape, n, out=out, shard=rank, n_shards=world)
+        for k, (ms, cnt) in hip.profile_read().items():
+            prof[k][0] += ms
+            prof[k][1] += cnt
+    hip.profile(False)
+    if world > 1:
+        step()  # leave `out` holding the combined image on rank 0
+        fence()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = (n ** 3) * args.steps / dt / 1e6
+    result = {
+        "metric": "Mvoxel/s (interval+point eval) on prospero.vm 1024^3",
+        "value": value, "unit": "Mvoxel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, tiles [128,64,32,16,8], world_to_model=I",
+                   "sharding": "root-tile columns round-robin, 1 RCCL reduce" if world > 1 else "single GPU"},
+        "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in prof.items()},
+        "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in prof.items()},
+        "arena_ops_last_slab": counters["arena_ops"], "arena_overflow": counters["arena_overflow"],
+    }
+
+    # ---- cpu_baseline + parity + algorithmic bytes (oracle; rank 0, N = 1 only) -----------------
+    if not args.no_cpu and world == 1:
+        import oracle as O
+        oshape = O.Shape.from_vm(os.path.join(ROOT, "models", args.model))
+        ref, st, secs = O.render3d(oshape, n)
+        got = out.cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        want = ref.view(np.uint32).reshape(n, n, 4)
+        result["parity"] = {"depth_equal": bool((got[..., 3] == want[..., 3]).all()),
+                            "normals_equal": bool((got[..., :3].view(np.float32) == want[..., :3].view(np.float32)).all())}
+        cores = O.max_threads()
+        result["cpu_baseline"] = {"value": (n ** 3) / secs / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+                                  "sample": f"one full {n}^3 frame ({secs:.2f} s wall on {cores} threads); C++ restatement of "
+                                            "the reference VmShape interpreter path, not the Rust JIT (published JIT/VM ratio "
+                                            "on M1 Max: 61.7/23.6 = 2.6x, README.md:154)"}
+        # leaf stage = 8 B per tape word per wavefront pass; + the W*H*16 B image written once
+        alg_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
+        k_ms = result["kernel_ms_per_frame"]["points"]
+        launches = max(result["kernel_launches_per_frame"]["points"], 1)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        result["roofline"] = {"bound": "hbm", "kernel": "k_columns3d", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes_per_launch": alg_bytes / launches,
+                              "avg_launch_ms": k_ms / launches, "launches_per_frame": launches,
+                              "note": "tape words are wave-uniform scalar loads served by K$/L2, so HBM traffic is far "
+                                      "below the algorithmic bytes: the kernel is LDS/VALU bound, not HBM bound"}
+        result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
+                                                         "float_lane_ops", "float_wave_ops", "grad_points")}
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -338,7 +338,9 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             const uint32_t ci = lane16 % n, cj = (lane16 / n) % n, ck = IS3D ? lane16 / (n * n) : 0;
             cx = g.x + ci * T; cy = g.y + cj * T; cz = g.z + ck * T;
         }
-        bool act = lane < (int)nchild;
+        // tiles entirely outside the image never reach the output (the reference evaluates them
+        // into its root-tile scratch and clips at the end, pixel.rs:478-490 / voxel.rs:529-533)
+        bool act = lane < (int)nchild && cx < P.width && cy < P.height;
         const uint32_t fill_z = cz + T + 1;
 
         // ---- occlusion (3D only; never changes results, only skips work) -------------
