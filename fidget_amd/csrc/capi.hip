@@ -45,7 +45,7 @@ struct fhip_ctx {
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind;
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)1 << 30;
     bool profiling = false;
@@ -97,8 +97,11 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (const char* mb = getenv("FHIP_ARENA_MB")) c->arena_bytes = (size_t)atol(mb) << 20;
     // allow the full 160 KiB of LDS for the interpreters' register files
     const void* fns[] = {(const void*)k_eval_f32<false>, (const void*)k_eval_interval<false>, (const void*)k_eval_grad<false>,
-                         (const void*)k_tiles<false>, (const void*)k_tiles<true>, (const void*)k_pixels2d,
-                         (const void*)k_columns3d, (const void*)k_normals3d};
+                         (const void*)k_tiles<false, false, true>, (const void*)k_tiles<false, true, true>,
+                         (const void*)k_tiles<true, false, true>, (const void*)k_tiles<true, true, true>,
+                         (const void*)k_pixels2d<0, false>, (const void*)k_pixels2d<0, true>,
+                         (const void*)k_columns3d<2, 0, 1, false>, (const void*)k_columns3d<2, 0, 1, true>,
+                         (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     *out = c;
     return FHIP_OK;
@@ -108,7 +111,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
-                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e};
+                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
@@ -373,8 +376,9 @@ struct RenderSetup {
     FhRenderState S;
     std::vector<FhGroup> roots;
     uint32_t n_slabs = 1;
-    size_t lds_tiles = 0, lds_points = 0, lds_normals = 0;
-    uint32_t table_words = 0;
+    size_t lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
+    uint32_t table_words = 0, n_footprints = 0;
+    bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -404,6 +408,21 @@ static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint3
     return std::vector<uint32_t>(tiles + i, tiles + n);
 }
 
+static bool tape_is_full(const fh::HostTape& t) {
+    for (uint64_t w : t.ops) {
+        const uint32_t op = FH_W_OP((uint32_t)w);
+        if ((op >= FH_SIN && op <= FH_LN) || op == FH_ATAN2_RR || op == FH_ATAN2_RI || op == FH_ATAN2_IR ||
+            op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR)
+            return true;
+    }
+    return false;
+}
+
+static size_t tiles_lds(uint32_t regs, uint32_t choices) {
+    size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL;
+    return (b + 15) & ~(size_t)15;
+}
+
 static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
                            uint32_t shard, uint32_t n_shards, RenderSetup& R) {
     FhRenderState& S = R.S;
@@ -421,19 +440,21 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         }
     }
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
-    if (t.n_regs > 256) return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 256 registers");
+    if (t.n_regs > 256) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 256 registers");
     P.max_regs = std::max<uint32_t>(t.n_regs, 1);
     P.max_choices = t.n_choices;
     P.roots_x = (P.width + ts[0] - 1) / ts[0];
     P.roots_y = (P.height + ts[0] - 1) / ts[0];
     R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
+    R.full = tape_is_full(t);
 
-    // LDS budgets (bounded by the root tape; children never need more)
-    R.lds_tiles = (size_t)P.max_regs * TL * 8 + (size_t)((P.max_choices + 15) / 16) * TL * 4 + (size_t)P.max_regs * TL;
-    R.lds_tiles = (R.lds_tiles + 15) & ~(size_t)15;
-    R.lds_points = (size_t)P.max_regs * WAVE * 4;
-    R.lds_normals = (size_t)P.max_regs * WAVE * 16;
-    if (R.lds_tiles > FH_LDS_MAX || R.lds_normals > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
+    // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
+    R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices);
+    R.lds_tiles_small = tiles_lds(SMALL_REGS, SMALL_CHOICES);
+    R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
+    R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
+    R.lds_normals_small = (size_t)32 * WAVE * 16;
+    if (R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
 
     // root groups: runs of <= 16 root tiles of this shard
     std::vector<uint32_t> mine;
@@ -459,6 +480,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     const uint64_t fw = (P.width + tl - 1) / tl, fhh = (P.height + tl - 1) / tl;
     const uint64_t leaf_cap = fw * fhh * (is3d ? ts[0] / tl : 1);
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
+    R.n_footprints = (uint32_t)(fw * fhh);
 
     HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
     HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes));
@@ -468,24 +490,41 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
         HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
+        HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
+        size_t mind_words = 0;
+        for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
+        HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->mind.p, 0, mind_words * 4, ctx->stream));  // empty image: nothing occluded
+        uint32_t* mp = (uint32_t*)ctx->mind.p;
+        for (size_t l = 0; l < ts.size(); l++) {
+            S.mind[l] = mp;
+            mp += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
+        }
+        for (int c = 0; c < 3; c++) S.fp_list[c] = (uint32_t*)ctx->fp_lists.p + (size_t)c * R.n_footprints;
     }
     S.arena = (uint64_t*)ctx->arena.p;
-    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8, 0xFFFFFFF0u);
+    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 16, 0xFFFFFFF0u);  // slack: 4-op prefetch reads past a tape's end
     S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
     S.arena_overflow = 0;
-    for (int l = 0; l < FH_MAX_LEVELS; l++) { S.queue[l] = (FhGroup*)ctx->queue[l].p; S.count[l] = 0; S.cursor[l] = 0; }
-    S.count[0] = (uint32_t)R.roots.size();
+    for (int l = 0; l < FH_MAX_LEVELS; l++) {
+        S.queue[l] = (FhGroup*)ctx->queue[l].p;
+        S.count[l] = S.cursor[l] = S.count_big[l] = S.cursor_big[l] = 0;
+    }
+    S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     S.queue_cap = qcap;
     S.queue_overflow = 0;
     S.leaves = (FhLeaf*)ctx->leaves.p;
     S.leaf_cap = (uint32_t)leaf_cap;
-    S.n_leaves = S.leaf_cursor = S.normal_cursor = 0;
+    S.n_leaves = S.leaf_cursor = S.leaf_cursor_big = S.normal_cursor = S.normal_cursor_big = 0;
     S.leaf_table = (uint32_t*)ctx->leaf_table.p;
+    for (int c = 0; c < 3; c++) S.fp_count[c] = S.fp_cursor[c] = 0;
     S.zbuf = (uint64_t*)ctx->zbuf.p;
     S.normals = (float*)ctx->normals.p;
     S.image2d = nullptr;
     memset(S.stat, 0, sizeof(S.stat));
-    if ((size_t)t.ops.size() * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
+    if (((size_t)t.ops.size() + 64) * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
+    // level-0 groups sit at the back of queue[0] (the "big" half), in reverse order
+    std::reverse(R.roots.begin(), R.roots.end());
     return FHIP_OK;
 }
 
@@ -501,6 +540,35 @@ static fhip_status finish_render(fhip_ctx* ctx) {
     ctx->have_last_state = true;
     if (ctx->last_state.queue_overflow) return fail(ctx, FHIP_ERR_OVERFLOW, "device work queue overflow");
     return FHIP_OK;
+}
+
+static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!R.roots.empty()) {
+        FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.queue_cap - R.roots.size());
+        HIP_TRY(ctx, hipMemcpyAsync(back, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->prof_events.clear();
+    return FHIP_OK;
+}
+
+// One level of the tile hierarchy: the small-LDS variant for the bulk of the groups and the
+// root-sized variant for the few large tapes (both always launched; empty queues exit at once).
+#define FH_LAUNCH_TILES(IS3D, FULL, BIG, grid, lds) \
+    hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level)
+static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
+    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(true, false, true, gb, R.lds_tiles_big); }
+        else { if (R.full) FH_LAUNCH_TILES(false, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(false, false, true, gb, R.lds_tiles_big); }
+    });
+    if (level > 0)
+        launch(ctx, FHIP_K_TILES, [&] {
+            if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, false, gs, R.lds_tiles_small); else FH_LAUNCH_TILES(true, false, false, gs, R.lds_tiles_small); }
+            else { if (R.full) FH_LAUNCH_TILES(false, true, false, gs, R.lds_tiles_small); else FH_LAUNCH_TILES(false, false, false, gs, R.lds_tiles_small); }
+        });
 }
 
 fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
@@ -529,20 +597,22 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * 4)); d_out = (float*)ctx->tmp_out.p; }
     R.S.image2d = d_out;
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
-    HIP_TRY(ctx, hipMemcpyAsync(dS, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->queue[0].p, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
-    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
-    ctx->prof_events.clear();
+    st = upload_frame(ctx, tape, R);
+    if (st) return st;
     for (uint32_t l = 0; l < P.n_levels; l++) {
         if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
-        launch(ctx, FHIP_K_TILES, [&] {
-            hipLaunchKernelGGL(k_tiles<false>, dim3(blocks_for(ctx, R.lds_tiles, 8)), dim3(WAVE), R.lds_tiles, ctx->stream, dS, (int)l);
-        });
+        launch_tiles(ctx, R, dS, (int)l, false);
     }
     launch(ctx, FHIP_K_POINTS, [&] {
-        hipLaunchKernelGGL(k_pixels2d, dim3(blocks_for(ctx, R.lds_points, 16)), dim3(WAVE), R.lds_points, ctx->stream, dS);
+        if (R.full) hipLaunchKernelGGL((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+        else hipLaunchKernelGGL((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
     });
+    if (P.max_regs > 32)
+        launch(ctx, FHIP_K_POINTS, [&] {
+            const int g = blocks_for(ctx, R.lds_points_big, 16);
+            if (R.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+            else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+        });
     HIP_TRY(ctx, hipGetLastError());
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -574,30 +644,45 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
-    HIP_TRY(ctx, hipMemcpyAsync(dS, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (!R.roots.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->queue[0].p, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
+    st = upload_frame(ctx, tape, R);
+    if (st) return st;
     HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, 0, npix * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
-    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
-    ctx->prof_events.clear();
     const uint32_t n_groups = (uint32_t)R.roots.size();
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
+    const int class_blocks = (int)((R.n_footprints + 255) / 256);
     for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
         launch(ctx, FHIP_K_OTHER, [&] {
             hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k * ts[0], n_groups);
+            if (k != (int)R.n_slabs - 1)  // the first slab sees an empty image (pyramid pre-zeroed)
+                hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
         });
-        for (uint32_t l = 0; l < P.n_levels; l++)
-            launch(ctx, FHIP_K_TILES, [&] {
-                hipLaunchKernelGGL(k_tiles<true>, dim3(blocks_for(ctx, R.lds_tiles, 8)), dim3(WAVE), R.lds_tiles, ctx->stream, dS, (int)l);
-            });
+        for (uint32_t l = 0; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS); });
         launch(ctx, FHIP_K_POINTS, [&] {
-            hipLaunchKernelGGL(k_columns3d, dim3(blocks_for(ctx, R.lds_points, 16)), dim3(WAVE), R.lds_points, ctx->stream, dS);
+            // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
+            if (R.full) {
+                hipLaunchKernelGGL((k_columns3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_columns3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+            } else {
+                hipLaunchKernelGGL((k_columns3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_columns3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+            }
+            if (P.max_regs > 32) {
+                const int g = blocks_for(ctx, R.lds_points_big, 16);
+                if (R.full) hipLaunchKernelGGL((k_columns3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                else hipLaunchKernelGGL((k_columns3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+            }
         });
         launch(ctx, FHIP_K_NORMALS, [&] {
-            hipLaunchKernelGGL(k_normals3d, dim3(blocks_for(ctx, R.lds_normals, 8)), dim3(WAVE), R.lds_normals, ctx->stream, dS);
+            const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_for(ctx, R.lds_normals_big, 8);
+            if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS);
+            else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS);
+            if (P.max_regs > 32) {
+                if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS);
+                else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS);
+            }
         });
     }
     launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS, d_out); });

@@ -90,6 +90,9 @@ FH_DEV float f_or(float a, float b, int& c) {
 struct F32 {
     typedef float V;
     static FH_DEV V imm(float f) { return f; }
+    // FULL = false drops the transcendental / modulo cases (and their f64 code and register
+    // pressure) from kernels built for tapes that contain none of them.
+    template <bool FULL>
     static FH_DEV V unary(int op, V a) {
         switch (op) {
             case FH_NEG: return -a;
@@ -100,29 +103,38 @@ struct F32 {
             case FH_FLOOR: return floorf(a);
             case FH_CEIL: return ceilf(a);
             case FH_ROUND: return roundf(a);
-            case FH_SIN: return t_sin(a);
-            case FH_COS: return t_cos(a);
-            case FH_TAN: return t_tan(a);
-            case FH_ASIN: return t_asin(a);
-            case FH_ACOS: return t_acos(a);
-            case FH_ATAN: return t_atan(a);
-            case FH_EXP: return t_exp(a);
-            case FH_LN: return t_ln(a);
             case FH_NOT: return a == 0.0f ? 1.0f : 0.0f;
-            default: return f_rand(a);
+            case FH_RAND: return f_rand(a);
+            default: break;
         }
+        if constexpr (FULL) {
+            switch (op) {
+                case FH_SIN: return t_sin(a);
+                case FH_COS: return t_cos(a);
+                case FH_TAN: return t_tan(a);
+                case FH_ASIN: return t_asin(a);
+                case FH_ACOS: return t_acos(a);
+                case FH_ATAN: return t_atan(a);
+                case FH_EXP: return t_exp(a);
+                default: return t_ln(a);
+            }
+        }
+        return a;
     }
     // base = op - FH_ADD_RR (0 add .. 11 or)
+    template <bool FULL>
     static FH_DEV V binary(int base, V a, V b, int& c) {
+        if constexpr (FULL) {
+            if (base == 4) return t_atan2(a, b);
+            if (base == 7) return rem_euclid(a, b);
+        }
         switch (base) {
             case 0: return a + b;
             case 1: return a - b;
             case 2: return a * b;
             case 3: return a / b;
-            case 4: return t_atan2(a, b);
             case 5: return f_compare(a, b);
             case 6: return f_mix(a, b);
-            case 7: return rem_euclid(a, b);
             case 8: return f_min(a, b, c);
             case 9: return f_max(a, b, c);
             case 10: return f_and(a, b, c);
@@ -309,6 +321,7 @@ FH_DEV IV iv_or(IV a, IV b, int& c) {                                       // 4
 struct IVAL {
     typedef IV V;
     static FH_DEV V imm(float f) { return iv1(f); }
+    template <bool FULL>
     static FH_DEV V unary(int op, V a) {
         switch (op) {
             case FH_NEG: return iv_neg(a);
@@ -319,28 +332,37 @@ struct IVAL {
             case FH_FLOOR: return iv_floor(a);
             case FH_CEIL: return iv_ceil(a);
             case FH_ROUND: return iv_round(a);
-            case FH_SIN: return iv_sincos<true>(a);
-            case FH_COS: return iv_sincos<false>(a);
-            case FH_TAN: return iv_tan(a);
-            case FH_ASIN: return iv_asin(a);
-            case FH_ACOS: return iv_acos(a);
-            case FH_ATAN: return iv_atan(a);
-            case FH_EXP: return iv_exp(a);
-            case FH_LN: return iv_ln(a);
             case FH_NOT: return iv_not(a);
-            default: return iv_rand(a);
+            case FH_RAND: return iv_rand(a);
+            default: break;
         }
+        if constexpr (FULL) {
+            switch (op) {
+                case FH_SIN: return iv_sincos<true>(a);
+                case FH_COS: return iv_sincos<false>(a);
+                case FH_TAN: return iv_tan(a);
+                case FH_ASIN: return iv_asin(a);
+                case FH_ACOS: return iv_acos(a);
+                case FH_ATAN: return iv_atan(a);
+                case FH_EXP: return iv_exp(a);
+                default: return iv_ln(a);
+            }
+        }
+        return a;
     }
+    template <bool FULL>
     static FH_DEV V binary(int base, V a, V b, int& c) {
+        if constexpr (FULL) {
+            if (base == 4) return iv_atan2(a, b);
+            if (base == 7) return iv_rem_euclid(a, b);
+        }
         switch (base) {
             case 0: return iv_add(a, b);
             case 1: return iv_sub(a, b);
             case 2: return iv_mul(a, b);
             case 3: return iv_div(a, b);
-            case 4: return iv_atan2(a, b);
             case 5: return iv_compare(a, b);
             case 6: return iv_mix(a, b);
-            case 7: return iv_rem_euclid(a, b);
             case 8: return iv_min(a, b, c);
             case 9: return iv_max(a, b, c);
             case 10: return iv_and(a, b, c);
@@ -374,7 +396,11 @@ FH_DEV GR gr_scale_div(GR a, float v, float r) { return gr(v, a.dx / r, a.dy / r
 struct GRAD {
     typedef GR V;
     static FH_DEV V imm(float f) { return gr1(f); }
+    template <bool FULL>
     static FH_DEV V unary(int op, V a) {
+        if constexpr (!FULL) {
+            if (op >= FH_SIN && op <= FH_LN) return a;
+        }
         switch (op) {
             case FH_NEG: return gr_neg(a);
             case FH_ABS: return a.v < 0.0f ? gr_neg(a) : a;                 // 44-55
@@ -396,8 +422,12 @@ struct GRAD {
             default: return gr1(f_rand(a.v));
         }
     }
+    template <bool FULL>
     static FH_DEV V binary(int base, V a, V b, int& c) {
         (void)c;
+        if constexpr (!FULL) {
+            if (base == 4 || base == 7) return a;
+        }
         switch (base) {
             case 0: return gr_add(a, b);
             case 1: return gr_sub(a, b);

@@ -1,24 +1,28 @@
 // fidget-hip: CDNA4 (gfx950) kernels for tape evaluation and tile rendering.
 //
 // Execution model (MI355X-first, not a port of the reference's CPU recursion):
-//   * a tape is a read-only array of 8-byte ops in HBM; every lane of a wave
-//     walks the SAME tape, so op words are fetched wave-uniformly (scalar loads)
-//     and decoded once per wave;
-//   * the per-lane register file of the interpreter lives in LDS,
-//     regs[reg][lane]  (bank = lane -> conflict free);
-//   * interval evaluation maps one TILE per lane, lanes of a wave = sibling
-//     tiles that share the parent's tape; the wave then prunes the tape for
-//     each child (two reverse sweeps: count, then emit with dense register
-//     renumbering) into a bump-allocated HBM arena;
-//   * point evaluation maps one voxel / pixel per lane, one 8x8 footprint per
-//     wave; 3D columns are walked front-to-back inside the wave so occluded
-//     voxels are never evaluated;
-//   * work flows level by level through device-side queues consumed by
-//     persistent workgroups (no host round trips inside a frame).
+//   * a tape is a read-only array of 8-byte ops in HBM; every lane of a wave walks the
+//     SAME tape, so op words are fetched wave-uniformly with scalar loads (s_load through
+//     the constant address space, 4 ops = 32 B per request, double buffered) and decoded
+//     once per wave on the scalar unit;
+//   * the interpreter's per-lane register file lives in VGPRs for the tapes that dominate
+//     the run time (<= 32 registers after pruning; uniform dynamic indexing lowers to
+//     s_set_gpr_idx_on + v_mov, no memory traffic at all) and in LDS, regs[reg][lane],
+//     for larger tapes (bank == lane, conflict free);
+//   * interval evaluation maps one TILE per lane; the lanes of a wave are the sibling tiles
+//     that share their parent's tape.  The wave then prunes the tape for each child (two
+//     reverse sweeps: count, then emit with dense register renumbering) into a bump
+//     allocated HBM arena.  Wave ballots / prefix sums allocate arena and queue space with
+//     one atomic per wave;
+//   * point evaluation maps voxels to lanes, one 8x8 pixel footprint per wave and ZB
+//     consecutive z per lane; the leaves of a footprint are walked front to back inside
+//     the wave so occluded voxels are never evaluated;
+//   * work flows level by level through device-side queues consumed by persistent
+//     workgroups; there is no host round trip inside a frame.
 //
 // Results are order independent: the 3D depth buffer is a 64-bit atomicMax of
-// (depth << 32 | leaf id), which reproduces the reference's sequential
-// front-to-back "first writer wins" semantics (fidget-raster/src/voxel.rs:275-484).
+// (depth << 32 | leaf id), which reproduces the reference's sequential front-to-back
+// "first writer wins" semantics (fidget-raster/src/voxel.rs:275-484).
 #include <hip/hip_runtime.h>
 
 #include "dev_ops.hpp"
@@ -27,13 +31,21 @@
 using namespace fhd;
 
 #define WAVE 64
+#define AS4 __attribute__((address_space(4)))
+typedef const AS4 uint64_t* ctape_t;  // constant address space => scalar (SMEM) loads
 
 FH_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 FH_DEV uint64_t ballot(bool p) { return __ballot(p); }
 
+// Is `op` outside the "basic" arithmetic set?  Kernels are built twice: BASIC variants keep
+// the f64 transcendental code out of the register budget (prospero, colonnade, hi use none).
+FH_DEV bool op_is_heavy(uint32_t op) {
+    return (op >= FH_SIN && op <= FH_LN) || op == FH_ATAN2_RR || op == FH_ATAN2_RI || op == FH_ATAN2_IR ||
+           op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR;
+}
+
 // --------------------------------------------------------------------------------------
-// LDS register file access.  LANES is the lane stride (64 for point kernels, 16 for
-// the tile kernel where at most 16 sibling tiles share a wave).
+// LDS register file.  LANES is the lane stride (64 for point kernels, 16 for the tile kernel).
 template <class T, int LANES>
 struct Regs {
     T* base;
@@ -42,9 +54,8 @@ struct Regs {
     FH_DEV void set(uint32_t r, T v) const { base[r * LANES + lane] = v; }
 };
 
-// One interpreter step shared by every kernel.  `in` supplies input slots, `on_out`
-// receives outputs, `on_choice` receives the Choice of min/max/and/or ops.
-template <class D, int LANES, class InFn, class OutFn, class ChoiceFn>
+// One interpreter step (scalar domains F32 / IVAL / GRAD, LDS or global register file).
+template <class D, int LANES, bool FULL, class InFn, class OutFn, class ChoiceFn>
 FH_DEV void step(uint64_t w, const Regs<typename D::V, LANES>& R, InFn in, OutFn on_out, ChoiceFn on_choice) {
     typedef typename D::V V;
     const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
@@ -64,11 +75,11 @@ FH_DEV void step(uint64_t w, const Regs<typename D::V, LANES>& R, InFn in, OutFn
             a = D::imm(u2f(w1)); b = R.get(ra);
         }
         int c = FH_CHOICE_BOTH;
-        V r = swap_mul ? D::mul_imm(a, u2f(w1)) : D::binary(base, a, b, c);
+        V r = swap_mul ? D::mul_imm(a, u2f(w1)) : D::template binary<FULL>(base, a, b, c);
         R.set(ro, r);
         if (base >= 8) on_choice(c);
     } else if (op >= FH_NEG) {
-        R.set(ro, D::unary(op, R.get(ra)));
+        R.set(ro, D::template unary<FULL>(op, R.get(ra)));
     } else if (op == FH_INPUT) {
         R.set(ro, in(w1));
     } else if (op == FH_COPY_REG) {
@@ -83,17 +94,15 @@ FH_DEV void step(uint64_t w, const Regs<typename D::V, LANES>& R, InFn in, OutFn
 // ======================================================================================
 // Trait-surface kernels (fhip_float_eval / fhip_point_eval / fhip_interval_eval /
 // fhip_grad_eval): one sample per lane, one wave per workgroup.
+// GREGS: the register file of tapes too large for LDS lives in a global scratch slab.
 // ======================================================================================
-// vars: [n_vars][n] f32; out: [n_out][n]; choices (optional): [n][n_choices] bytes,
-// simplify (optional): [n] bytes  (vm/mod.rs:543-760 / 794-1086)
-// GREGS: the register file of tapes too large for LDS lives in a global scratch slab
-// (one [n_regs][64] block per workgroup); only the trait-surface kernels need this.
 template <bool GREGS>
 __global__ void __launch_bounds__(WAVE)
-k_eval_f32(const uint64_t* __restrict__ tape, uint32_t len, const float* __restrict__ vars, uint32_t n,
+k_eval_f32(const uint64_t* __restrict__ tape_g, uint32_t len, const float* __restrict__ vars, uint32_t n,
            float* __restrict__ out, uint8_t* __restrict__ choices, uint8_t* __restrict__ simplify, uint32_t n_choices,
            float* gregs, uint32_t n_regs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ctape_t tape = (ctape_t)tape_g;
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.x * WAVE + lane;
     const bool act = i < n;
@@ -103,7 +112,7 @@ k_eval_f32(const uint64_t* __restrict__ tape, uint32_t len, const float* __restr
     bool simp = false;
     for (uint32_t k = 0; k < len; k++) {
         const uint64_t w = tape[k];
-        step<F32, WAVE>(
+        step<F32, WAVE, true>(
             w, R, [&](uint32_t slot) { return vars[(size_t)slot * n + ii]; },
             [&](uint32_t slot, float v) { if (act) out[(size_t)slot * n + ii] = v; },
             [&](int c) {
@@ -115,13 +124,13 @@ k_eval_f32(const uint64_t* __restrict__ tape, uint32_t len, const float* __restr
     if (simplify && act) simplify[ii] = simp ? 1 : 0;
 }
 
-// vars: [n][n_vars] {lo,hi}; out: [n][n_out] {lo,hi}   (vm/mod.rs:325-538)
 template <bool GREGS>
 __global__ void __launch_bounds__(WAVE)
-k_eval_interval(const uint64_t* __restrict__ tape, uint32_t len, const float2* __restrict__ vars, uint32_t n_vars,
+k_eval_interval(const uint64_t* __restrict__ tape_g, uint32_t len, const float2* __restrict__ vars, uint32_t n_vars,
                 uint32_t n, float2* __restrict__ out, uint32_t n_out, uint8_t* __restrict__ choices,
                 uint8_t* __restrict__ simplify, uint32_t n_choices, IV* gregs, uint32_t n_regs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ctape_t tape = (ctape_t)tape_g;
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.x * WAVE + lane;
     const bool act = i < n;
@@ -131,7 +140,7 @@ k_eval_interval(const uint64_t* __restrict__ tape, uint32_t len, const float2* _
     bool simp = false;
     for (uint32_t k = 0; k < len; k++) {
         const uint64_t w = tape[k];
-        step<IVAL, WAVE>(
+        step<IVAL, WAVE, true>(
             w, R,
             [&](uint32_t slot) { float2 v = vars[(size_t)ii * n_vars + slot]; return iv(v.x, v.y); },
             [&](uint32_t slot, IV v) { if (act) out[(size_t)ii * n_out + slot] = make_float2(v.lo, v.hi); },
@@ -144,12 +153,12 @@ k_eval_interval(const uint64_t* __restrict__ tape, uint32_t len, const float2* _
     if (simplify && act) simplify[ii] = simp ? 1 : 0;
 }
 
-// vars: [n_vars][n] {v,dx,dy,dz}; out: [n_out][n]   (vm/mod.rs:1091-1397)
 template <bool GREGS>
 __global__ void __launch_bounds__(WAVE)
-k_eval_grad(const uint64_t* __restrict__ tape, uint32_t len, const float4* __restrict__ vars, uint32_t n,
+k_eval_grad(const uint64_t* __restrict__ tape_g, uint32_t len, const float4* __restrict__ vars, uint32_t n,
             float4* __restrict__ out, GR* gregs, uint32_t n_regs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ctape_t tape = (ctape_t)tape_g;
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.x * WAVE + lane;
     const bool act = i < n;
@@ -157,7 +166,7 @@ k_eval_grad(const uint64_t* __restrict__ tape, uint32_t len, const float4* __res
     Regs<GR, WAVE> R{GREGS ? gregs + (size_t)blockIdx.x * n_regs * WAVE : (GR*)smem, lane};
     for (uint32_t k = 0; k < len; k++) {
         const uint64_t w = tape[k];
-        step<GRAD, WAVE>(
+        step<GRAD, WAVE, true>(
             w, R,
             [&](uint32_t slot) { float4 v = vars[(size_t)slot * n + ii]; return gr(v.x, v.y, v.z, v.w); },
             [&](uint32_t slot, GR v) { if (act) out[(size_t)slot * n + ii] = make_float4(v.v, v.dx, v.dy, v.dz); },
@@ -166,13 +175,8 @@ k_eval_grad(const uint64_t* __restrict__ tape, uint32_t len, const float4* __res
 }
 
 // ======================================================================================
-// Rendering
+// Rendering: shared helpers
 // ======================================================================================
-FH_DEV float input_value_f(const FhRender& P, uint32_t slot, float x, float y, float z) {
-    const uint32_t k = P.in_kind[slot];
-    return k == 0 ? x : (k == 1 ? y : (k == 2 ? z : P.in_value[slot]));
-}
-
 // Wave-wide exclusive prefix sum over lanes (and total) of a per-lane count
 FH_DEV uint32_t wave_excl_sum(uint32_t v, uint32_t& total) {
     uint32_t x = v;
@@ -183,11 +187,6 @@ FH_DEV uint32_t wave_excl_sum(uint32_t v, uint32_t& total) {
     }
     total = __shfl(x, WAVE - 1, WAVE);
     return x - v;
-}
-FH_DEV uint32_t wave_min(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, WAVE));
-    return v;
 }
 
 // 256-bit free-register pool held in VGPRs (lowest free first)
@@ -222,8 +221,8 @@ struct Pool {
 // Left/Right is replaced by its surviving operand (aliased when that operand is
 // not otherwise live yet, copied when it is).
 template <bool EMIT>
-FH_DEV void prune_sweep(const uint64_t* __restrict__ tape, uint32_t len, uint32_t n_choices, const uint32_t* chbits,
-                        uint8_t* map, int lane16, bool act, uint64_t* dst /*one past the last op*/, uint32_t& out_len,
+FH_DEV void prune_sweep(ctape_t tape, uint32_t len, uint32_t n_choices, const uint32_t* chbits, uint8_t* map,
+                        int lane16, bool act, uint64_t* dst /*one past the last op*/, uint32_t& out_len,
                         uint32_t& out_regs, uint32_t& out_choices) {
     Pool pool;
     pool.init();
@@ -289,41 +288,43 @@ FH_DEV void prune_sweep(const uint64_t* __restrict__ tape, uint32_t len, uint32_
     out_choices = kept_choices;
 }
 
-// Pixel footprint occlusion test (voxel.rs:283-289): true when every in-image pixel of
-// the T x T footprint already has depth >= fill_z.  All 64 lanes cooperate.
-FH_DEV bool footprint_occluded(const FhRender& P, const uint64_t* zbuf, uint32_t cx, uint32_t cy, uint32_t T, uint32_t fill_z) {
-    uint32_t mn = 0xFFFFFFFFu;
-    const int lane = threadIdx.x & 63;
-    for (uint32_t p = lane; p < T * T; p += WAVE) {
-        const uint32_t x = cx + (p % T), y = cy + (p / T);
-        if (x < P.width && y < P.height) mn = min(mn, (uint32_t)(zbuf[(size_t)y * P.width + x] >> 32));
-    }
-    return wave_min(mn) >= fill_z;
-}
+// Small tapes (the overwhelming majority below the root levels) run with a small LDS
+// budget so that many waves fit per CU; the rest use the root tape's bounds.
+#define SMALL_REGS 32u
+#define SMALL_CHOICES 256u
+FH_DEV bool tape_is_small(const FhTapeRef& t) { return t.n_regs <= SMALL_REGS && t.n_choices <= SMALL_CHOICES; }
 
 // The tile kernel: interval-evaluate the children of one parent tile per wave, classify
 // them, fill / discard the decided ones and emit pruned tapes + next-level work for the
-// ambiguous ones.  Persistent workgroups pull parents from queue[level].
-template <bool IS3D>
+// ambiguous ones.  Persistent workgroups pull parents from queue[level]; BIG selects the
+// half of the queue whose tapes need the large LDS layout.
+template <bool IS3D, bool FULL, bool BIG>
 __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FhRender& P = S->P;
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const int lane16 = lane & (TL - 1);
-    IV* regs = (IV*)smem;                                            // [max_regs][TL]
-    uint32_t* chbits = (uint32_t*)(smem + (size_t)P.max_regs * TL * sizeof(IV));   // [(max_choices+15)/16][TL]
-    uint8_t* map = (uint8_t*)(chbits + (size_t)((P.max_choices + 15) / 16) * TL);  // [max_regs][TL]
-    const uint64_t* arena = S->arena;
+    const uint32_t max_regs = BIG ? P.max_regs : SMALL_REGS;
+    const uint32_t max_choices = BIG ? P.max_choices : SMALL_CHOICES;
+    IV* regs = (IV*)smem;                                                       // [max_regs][TL]
+    uint32_t* chbits = (uint32_t*)(smem + (size_t)max_regs * TL * sizeof(IV)); // [(max_choices+15)/16][TL]
+    uint8_t* map = (uint8_t*)(chbits + (size_t)((max_choices + 15) / 16) * TL);  // [max_regs][TL]
     const uint32_t T = P.tiles[level];
     const bool last_level = (level + 1 == (int)P.n_levels);
+    const uint32_t ntx = (P.width + T - 1) / T;
+    const uint32_t* mind = S->mind[level];
+    Mat4 mat;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
 
     for (;;) {
         uint32_t gi = 0;
-        if (lane == 0) gi = atomicAdd(&S->cursor[level], 1u);
+        if (lane == 0) gi = atomicAdd(BIG ? &S->cursor_big[level] : &S->cursor[level], 1u);
         gi = uni(gi);
-        if (gi >= S->count[level]) break;
-        const FhGroup g = S->queue[level][gi];
-        const uint64_t* tape = arena + g.tape.off;
+        if (gi >= (BIG ? S->count_big[level] : S->count[level])) break;
+        // small groups fill the queue from the front, big ones from the back
+        const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][BIG ? S->queue_cap - 1 - gi : gi];
+        const ctape_t tape = (ctape_t)(S->arena + g.tape.off);
         const uint32_t len = g.tape.len, n_choices = g.tape.n_choices, n_regs = g.tape.n_regs;
 
         // ---- enumerate children ------------------------------------------------
@@ -343,23 +344,17 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         bool act = lane < (int)nchild && cx < P.width && cy < P.height;
         const uint32_t fill_z = cz + T + 1;
 
-        // ---- occlusion (3D only; never changes results, only skips work) -------------
-        if (IS3D) {
-            uint32_t occ = 0;
-            for (uint32_t c = 0; c < nchild; c++) {
-                const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE), cfz = __shfl(fill_z, c, WAVE);
-                if (footprint_occluded(P, S->zbuf, ccx, ccy, T, cfz)) occ |= 1u << c;
-            }
-            if (act && ((occ >> lane) & 1)) act = false;
-            if (ballot(act) == 0) continue;
-        }
+        // ---- occlusion (voxel.rs:283-289; never changes results, only skips work): the
+        // min-depth pyramid holds, per tile footprint, the smallest depth as of the last slab
+        if (IS3D && act && mind[(cy / T) * ntx + cx / T] >= fill_z) act = false;
+        if (ballot(act) == 0) continue;
 
         // ---- forward interval pass, trace packed 2 bits per choice ------------------
         IV X, Y, Z;
         {
             const IV sx = iv((float)cx, (float)cx + (float)T), sy = iv((float)cy, (float)cy + (float)T);
             const IV sz = IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z);
-            xf_interval(*(const Mat4*)P.mat, sx, sy, sz, X, Y, Z);
+            xf_interval(mat, sx, sy, sz, X, Y, Z);
         }
         Regs<IV, TL> R{regs, lane16};
         IV result = iv_nan();
@@ -368,7 +363,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         if (lane < TL) {
             for (uint32_t k = 0; k < len; k++) {
                 const uint64_t w = tape[k];
-                step<IVAL, TL>(
+                step<IVAL, TL, FULL>(
                     w, R,
                     [&](uint32_t slot) {
                         const uint32_t kd = P.in_kind[slot];
@@ -392,7 +387,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
 
         // fills, cooperatively over the 64 lanes
         {
-            uint64_t fm = ballot(full) | (IS3D ? 0ull : ballot(empty));
+            const uint64_t fullm = ballot(full);
+            uint64_t fm = fullm | (IS3D ? 0ull : ballot(empty));
             while (fm) {
                 const int c = __builtin_ctzll(fm);
                 fm &= fm - 1;
@@ -404,7 +400,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                         if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
                     }
                 } else {
-                    const bool inside = (ballot(full) >> c) & 1;
+                    const bool inside = (fullm >> c) & 1;
                     const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (inside ? 1u : 0u) | (0xF6u << 9));
                     for (uint32_t p = lane; p < T * T; p += WAVE) {
                         const uint32_t x = ccx + (p % T), y = ccy + (p / T);
@@ -417,7 +413,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
 
         // ---- prune the tape for every ambiguous child whose trace decided something ----
         const bool prune = amb && any_decided;
-        FhTapeRef child = g.tape;
+        FhTapeRef child;
+        child.off = g.tape.off; child.len = len; child.n_regs = (uint16_t)n_regs; child.n_choices = (uint16_t)n_choices;
         if (ballot(prune)) {
             uint32_t clen = 0, cregs = 0, cch = 0;
             if (lane < TL) {
@@ -446,18 +443,27 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         }
 
         // ---- hand ambiguous children to the next stage ------------------------------------
-        uint32_t namb;
-        const uint32_t slot = wave_excl_sum(amb ? 1u : 0u, namb);
+        const bool small = tape_is_small(child);
         if (!last_level) {
-            uint32_t qb = 0;
-            if (lane == 0) qb = atomicAdd(&S->count[level + 1], namb);
-            qb = uni(qb);
-            if (amb && qb + slot < S->queue_cap) {
+            uint32_t ns, nb;
+            const uint32_t slot_s = wave_excl_sum((amb && small) ? 1u : 0u, ns);
+            const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
+            uint32_t qs = 0, qb = 0;
+            if (lane == 0) {
+                if (ns) qs = atomicAdd(&S->count[level + 1], ns);
+                if (nb) qb = atomicAdd(&S->count_big[level + 1], nb);
+            }
+            qs = uni(qs); qb = uni(qb);
+            if (amb) {
                 FhGroup o;
                 o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = 0; o.stride = 0;
-                S->queue[level + 1][qb + slot] = o;
-            } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+                // the two halves cannot collide: their total is bounded by queue_cap
+                if (small) S->queue[level + 1][qs + slot_s] = o;
+                else S->queue[level + 1][S->queue_cap - 1 - (qb + slot_b)] = o;
+            }
         } else {
+            uint32_t namb;
+            const uint32_t slot = wave_excl_sum(amb ? 1u : 0u, namb);
             uint32_t lb = 0;
             if (lane == 0) lb = atomicAdd(&S->n_leaves, namb);
             lb = uni(lb);
@@ -466,63 +472,197 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
                 if (IS3D) {
-                    const uint32_t fw = (P.width + T - 1) / T;
                     const uint32_t layers = P.tiles[0] / T;
-                    S->leaf_table[((size_t)(cy / T) * fw + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
+                    S->leaf_table[((size_t)(cy / T) * ntx + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
                 }
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
     }
 }
 
-// 2D leaves: one 8x8 (T x T, T*T <= 64) pixel tile per wave (pixel.rs:400-441)
+// ======================================================================================
+// Point evaluation with a VGPR register file: NR registers x ZB values per lane.
+// One array per z so that each stays within the 32-dword limit of uniform dynamic VGPR
+// indexing (s_set_gpr_idx_on); larger tapes take the LDS path below.
+// ======================================================================================
+#define FOR_Z for (int j = 0; j < ZB; j++)
+
+// Evaluate `tape` at ZB points per lane; x/y/z are model-space coordinates.
+template <int NR, int ZB, bool FULL>
+FH_DEV void run_points(ctape_t tape, uint32_t len, const AS4 FhRender& P, const float (&x)[ZB], const float (&y)[ZB],
+                       const float (&z)[ZB], float (&res)[ZB]) {
+    // one array per z: each must stay within 32 dwords to be kept in VGPRs
+    float r0[NR], r1[ZB > 1 ? NR : 1], r2[ZB > 2 ? NR : 1], r3[ZB > 2 ? NR : 1];
+#define RGET(i, v) do { v[0] = r0[i]; if (ZB > 1) v[1] = r1[i]; if (ZB > 2) { v[2] = r2[i]; v[3] = r3[i]; } } while (0)
+#define RSET(i, v) do { r0[i] = v[0]; if (ZB > 1) r1[i] = v[1]; if (ZB > 2) { r2[i] = v[2]; r3[i] = v[3]; } } while (0)
+    typedef unsigned long long Q4 __attribute__((ext_vector_type(4), aligned(8)));  // 4 ops = one s_load_dwordx8
+    const AS4 Q4* q = (const AS4 Q4*)tape;
+    Q4 cur = q[0];
+    for (uint32_t k0 = 0; k0 < len; k0 += 4) {
+        const Q4 nxt = q[(k0 >> 2) + 1];  // the arena keeps 8 ops of slack past its last tape
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k0 + u >= len) break;
+            const uint64_t w = cur[u];
+            const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+            const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0);
+            float a[ZB], b[ZB], c[ZB];
+            if (op >= FH_ADD_RR) {
+                int base;
+                if (op < FH_ADD_RI) { base = op - FH_ADD_RR; RGET(ra, a); RGET(w1, b); }
+                else if (op < FH_SUB_IR) { base = op - FH_ADD_RI; RGET(ra, a); FOR_Z b[j] = u2f(w1); }
+                else { const int irb = op - FH_SUB_IR; base = irb == 0 ? 1 : irb + 2; FOR_Z a[j] = u2f(w1); RGET(ra, b); }
+                int ch;
+                switch (base) {
+                    case 0: FOR_Z c[j] = a[j] + b[j]; break;
+                    case 1: FOR_Z c[j] = a[j] - b[j]; break;
+                    case 2: FOR_Z c[j] = a[j] * b[j]; break;
+                    case 3: FOR_Z c[j] = a[j] / b[j]; break;
+                    case 4: if (FULL) { FOR_Z c[j] = t_atan2(a[j], b[j]); } break;
+                    case 5: FOR_Z c[j] = f_compare(a[j], b[j]); break;
+                    case 6: FOR_Z c[j] = f_mix(a[j], b[j]); break;
+                    case 7: if (FULL) { FOR_Z c[j] = rem_euclid(a[j], b[j]); } break;
+                    case 8: FOR_Z c[j] = f_min(a[j], b[j], ch); break;
+                    case 9: FOR_Z c[j] = f_max(a[j], b[j], ch); break;
+                    case 10: FOR_Z c[j] = f_and(a[j], b[j], ch); break;
+                    default: FOR_Z c[j] = f_or(a[j], b[j], ch); break;
+                }
+                RSET(ro, c);
+            } else if (op >= FH_NEG) {
+                RGET(ra, a);
+                switch (op) {
+                    case FH_NEG: FOR_Z c[j] = -a[j]; break;
+                    case FH_ABS: FOR_Z c[j] = fabsf(a[j]); break;
+                    case FH_RECIP: FOR_Z c[j] = 1.0f / a[j]; break;
+                    case FH_SQRT: FOR_Z c[j] = sqrtf(a[j]); break;
+                    case FH_SQUARE: FOR_Z c[j] = a[j] * a[j]; break;
+                    case FH_FLOOR: FOR_Z c[j] = floorf(a[j]); break;
+                    case FH_CEIL: FOR_Z c[j] = ceilf(a[j]); break;
+                    case FH_ROUND: FOR_Z c[j] = roundf(a[j]); break;
+                    case FH_NOT: FOR_Z c[j] = a[j] == 0.0f ? 1.0f : 0.0f; break;
+                    case FH_RAND: FOR_Z c[j] = f_rand(a[j]); break;
+                    default:
+                        if (FULL) { FOR_Z c[j] = F32::unary<true>((int)op, a[j]); }
+                        break;
+                }
+                RSET(ro, c);
+            } else if (op == FH_INPUT) {
+                const uint32_t kd = P.in_kind[w1];
+                if (kd == 0) { FOR_Z c[j] = x[j]; } else if (kd == 1) { FOR_Z c[j] = y[j]; }
+                else if (kd == 2) { FOR_Z c[j] = z[j]; } else { const float v = P.in_value[w1]; FOR_Z c[j] = v; }
+                RSET(ro, c);
+            } else if (op == FH_COPY_REG) {
+                RGET(ra, a);
+                RSET(ro, a);
+            } else if (op == FH_COPY_IMM) {
+                FOR_Z c[j] = u2f(w1);
+                RSET(ro, c);
+            } else {
+                RGET(ra, a);
+                FOR_Z res[j] = a[j];
+            }
+        }
+        cur = nxt;
+    }
+}
+#undef RGET
+#undef RSET
+
+// Same, LDS register file, one value per lane (tapes with more than 32 registers)
+template <bool FULL>
+FH_DEV float run_points_lds(ctape_t tape, uint32_t len, const AS4 FhRender& P, float* lds, int lane, float x, float y, float z) {
+    Regs<float, WAVE> R{lds, lane};
+    float res = 0.0f;
+    for (uint32_t k = 0; k < len; k++) {
+        const uint64_t w = tape[k];
+        step<F32, WAVE, FULL>(
+            w, R,
+            [&](uint32_t slot) {
+                const uint32_t kd = P.in_kind[slot];
+                return kd == 0 ? x : (kd == 1 ? y : (kd == 2 ? z : (float)P.in_value[slot]));
+            },
+            [&](uint32_t, float v) { res = v; }, [&](int) {});
+    }
+    return res;
+}
+
+// 2D leaves: one T x T pixel tile (T*T <= 64) per wave (pixel.rs:400-441).
+// NR == 0 selects the LDS register file (big tapes, queued from the back of `leaves`).
+template <int NR, bool FULL>
 __global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FhRender& P = S->P;
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[P.n_levels - 1];
-    Regs<float, WAVE> R{(float*)smem, lane};
+    Mat4 mat;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
+    const uint32_t n_leaves = min(S->n_leaves, S->leaf_cap);
     for (;;) {
         uint32_t li = 0;
-        if (lane == 0) li = atomicAdd(&S->leaf_cursor, 1u);
+        if (lane == 0) li = atomicAdd(NR ? &S->leaf_cursor : &S->leaf_cursor_big, 1u);
         li = uni(li);
-        if (li >= min(S->n_leaves, S->leaf_cap)) break;
-        const FhLeaf lf = S->leaves[li];
-        const uint64_t* tape = S->arena + lf.tape.off;
+        if (li >= n_leaves) break;
+        const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
+        const bool fits = lf.tape.n_regs <= 32;
+        if (NR ? !fits : fits) continue;  // the other variant renders this leaf
+        const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
         for (uint32_t p0 = 0; p0 < T * T; p0 += WAVE) {
             const uint32_t p = p0 + lane;
             const uint32_t px = lf.x + (p % T), py = lf.y + (p / T);
-            float x, y, z, res = 0.0f;
-            xf_point(*(const Mat4*)P.mat, (float)px, (float)py, P.z, x, y, z);
-            for (uint32_t k = 0; k < lf.tape.len; k++) {
-                const uint64_t w = tape[k];
-                step<F32, WAVE>(
-                    w, R, [&](uint32_t slot) { return input_value_f(P, slot, x, y, z); },
-                    [&](uint32_t, float v) { res = v; }, [&](int) {});
-            }
+            float x[1], y[1], z[1], res[1] = {0.0f};
+            xf_point(mat, (float)px, (float)py, P.z, x[0], y[0], z[0]);
+            if (NR) run_points<(NR ? NR : 1), 1, FULL>(tape, lf.tape.len, P, x, y, z, res);
+            else res[0] = run_points_lds<FULL>(tape, lf.tape.len, P, (float*)smem, lane, x[0], y[0], z[0]);
             if (p < T * T && px < P.width && py < P.height)
-                S->image2d[(size_t)py * P.width + px] = isnan_(res) ? u2f(0x7FC00000u) : res;  // pixel.rs:235-241
+                S->image2d[(size_t)py * P.width + px] = isnan_(res[0]) ? u2f(0x7FC00000u) : res[0];  // pixel.rs:235-241
         }
     }
 }
 
-// 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
-// each leaf front to back in z, lanes dropping out once their column has been hit or is
-// occluded (voxel.rs:359-463).  Only the winning hit of a column is ever evaluated.
-__global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FhRender& P = S->P;
-    const int lane = threadIdx.x;
-    const uint32_t T = P.tiles[P.n_levels - 1];  // T*T == 64 lanes
+// Footprint classification for the 3D column kernels: a footprint goes to the variant that
+// fits the largest register count among its leaves (class 0: <= 16, 1: <= 32, 2: LDS).
+__global__ void k_classify3d(FhRenderState* S) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.tiles[0] / T;
-    Regs<float, WAVE> R{(float*)smem, lane};
+    const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= fw * fh) return;
+    const uint32_t* col = S->leaf_table + (size_t)fi * layers;
+    uint32_t mx = 0;
+    bool any = false;
+    for (uint32_t l = 0; l < layers; l++) {
+        const uint32_t id = col[l];
+        if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
+    }
+    if (!any) return;
+    const int cls = mx <= 16 ? 0 : (mx <= 32 ? 1 : 2);
+    S->fp_list[cls][atomicAdd(&S->fp_count[cls], 1u)] = fi;
+}
+
+// 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
+// each leaf front to back in z (ZB voxels per lane at a time), lanes dropping out once their
+// column has been hit or is occluded (voxel.rs:359-463).
+template <int CLS, int NR, int ZB, bool FULL>
+__global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[P.n_levels - 1];  // T*T == 64 lanes
+    const uint32_t fw = (P.width + T - 1) / T;
+    const uint32_t layers = P.tiles[0] / T;
+    Mat4 mat;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
+    const uint32_t n_fp = S->fp_count[CLS];
     for (;;) {
-        uint32_t fi = 0;
-        if (lane == 0) fi = atomicAdd(&S->leaf_cursor, 1u);
-        fi = uni(fi);
-        if (fi >= fw * fh) break;
-        const uint32_t* col = S->leaf_table + (size_t)fi * layers;
+        uint32_t wi = 0;
+        if (lane == 0) wi = atomicAdd(&S->fp_cursor[CLS], 1u);
+        wi = uni(wi);
+        if (wi >= n_fp) break;
+        const uint32_t fi = uni(S->fp_list[CLS][wi]);
+        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)fi * layers);
         const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
@@ -531,24 +671,23 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
         for (int zl = (int)layers - 1; zl >= 0; zl--) {
             const uint32_t id = col[zl];
             if (id == 0) continue;
-            const FhLeaf lf = S->leaves[id - 1];
-            const uint32_t zmax = lf.z + T;
-            bool pending = depth < zmax;  // voxel.rs:377-381
+            const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[id - 1];
+            const uint32_t lz = lf.z;
+            bool pending = depth < lz + T;  // voxel.rs:377-381
             if (ballot(pending) == 0) break;  // everything behind is occluded as well
-            const uint64_t* tape = S->arena + lf.tape.off;
-            for (int k = (int)T - 1; k >= 0; k--) {
-                float x, y, z, res = 0.0f;
-                xf_point(*(const Mat4*)P.mat, (float)px, (float)py, (float)(lf.z + k), x, y, z);
-                for (uint32_t q = 0; q < lf.tape.len; q++) {
-                    const uint64_t w = tape[q];
-                    step<F32, WAVE>(
-                        w, R, [&](uint32_t slot) { return input_value_f(P, slot, x, y, z); },
-                        [&](uint32_t, float v) { res = v; }, [&](int) {});
-                }
-                if (pending && res < 0.0f) {  // first voxel inside, front to back
-                    depth = lf.z + k + 1;
-                    hit_leaf = id;
-                    pending = false;
+            const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
+            const uint32_t len = lf.tape.len;
+            for (int k = (int)T - 1; k >= 0; k -= ZB) {
+                float x[ZB], y[ZB], z[ZB], res[ZB];
+                FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
+                if (NR) run_points<(NR ? NR : 1), ZB, FULL>(tape, len, P, x, y, z, res);
+                else res[0] = run_points_lds<FULL>(tape, len, P, (float*)smem, lane, x[0], y[0], z[0]);
+                FOR_Z {
+                    if (pending && res[j] < 0.0f) {  // first voxel inside, front to back
+                        depth = lz + (uint32_t)(k - j) + 1;
+                        hit_leaf = id;
+                        pending = false;
+                    }
                 }
                 if (ballot(pending) == 0) break;
             }
@@ -560,18 +699,30 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
 // Normals for the hits of this slab: gradient of the winning leaf's tape at the voxel one
 // above the hit (voxel.rs:447-482).  Lanes of a footprint may have been hit in different
 // leaves; the wave loops over the distinct ones.
+// BIG: footprints of class 2 (LDS sized by the root tape); otherwise classes 0 and 1
+// (<= 32 registers, small LDS so that many waves fit).
+template <bool FULL, bool BIG>
 __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FhRender& P = S->P;
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[P.n_levels - 1];
-    const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
+    const uint32_t fw = (P.width + T - 1) / T;
     Regs<GR, WAVE> R{(GR*)smem, lane};
+    Mat4 mat;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
+    const uint32_t n_all = BIG ? S->fp_count[2] : S->fp_count[0] + S->fp_count[1];
     for (;;) {
-        uint32_t fi = 0;
-        if (lane == 0) fi = atomicAdd(&S->normal_cursor, 1u);
+        uint32_t wi = 0;
+        if (lane == 0) wi = atomicAdd(BIG ? &S->normal_cursor_big : &S->normal_cursor, 1u);
+        wi = uni(wi);
+        if (wi >= n_all) break;
+        uint32_t fi;
+        if (BIG) fi = S->fp_list[2][wi];
+        else if (wi < S->fp_count[0]) fi = S->fp_list[0][wi];
+        else fi = S->fp_list[1][wi - S->fp_count[0]];
         fi = uni(fi);
-        if (fi >= fw * fh) break;
         const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
@@ -580,15 +731,16 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
         const uint32_t depth = (uint32_t)(zb >> 32);
         uint64_t todo = ballot(id != 0);
         while (todo) {
-            const uint32_t cur = __shfl(id, __builtin_ctzll(todo), WAVE);
+            const uint32_t cur = uni(__shfl(id, __builtin_ctzll(todo), WAVE));
             const bool mine = (id == cur);
-            const FhLeaf lf = S->leaves[cur - 1];
-            const uint64_t* tape = S->arena + lf.tape.off;
+            const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[cur - 1];
+            const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
+            const uint32_t len = lf.tape.len;
             GR gx, gy, gz, res = gr1(0.0f);
-            xf_grad(*(const Mat4*)P.mat, gr((float)px, 1, 0, 0), gr((float)py, 0, 1, 0), gr((float)(depth - 1), 0, 0, 1), gx, gy, gz);
-            for (uint32_t q = 0; q < lf.tape.len; q++) {
+            xf_grad(mat, gr((float)px, 1, 0, 0), gr((float)py, 0, 1, 0), gr((float)(depth - 1), 0, 0, 1), gx, gy, gz);
+            for (uint32_t q = 0; q < len; q++) {
                 const uint64_t w = tape[q];
-                step<GRAD, WAVE>(
+                step<GRAD, WAVE, FULL>(
                     w, R,
                     [&](uint32_t slot) {
                         const uint32_t kd = P.in_kind[slot];
@@ -611,17 +763,49 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
     if (i == 0) {
-        for (int l = 0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; }
-        S->count[0] = n_root_groups;
-        S->n_leaves = 0; S->leaf_cursor = 0; S->normal_cursor = 0;
+        for (int l = 0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0; }
+        S->count_big[0] = n_root_groups;  // the root tape uses the large LDS layout
+        S->n_leaves = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
+        for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
         S->arena_head = S->arena_root_end;
     }
-    if (i < n_root_groups) S->queue[0][i].z = slab_z;
+    if (i < n_root_groups) S->queue[0][S->queue_cap - 1 - i].z = slab_z;
+}
+
+// Min-depth pyramid of the z-buffer, one workgroup per root tile: mind[l][tile] = smallest
+// depth over the tile's in-image pixels.  Feeds the occlusion test of k_tiles.
+__global__ void __launch_bounds__(256) k_minpyramid(FhRenderState* S) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const uint32_t T0 = P.tiles[0];
+    const uint32_t x0 = (blockIdx.x / P.roots_y) * T0, y0 = (blockIdx.x % P.roots_y) * T0;
+    for (int l = (int)P.n_levels - 1; l >= 0; l--) {
+        const uint32_t T = P.tiles[l], n = T0 / T, ntx = (P.width + T - 1) / T;
+        for (uint32_t t = threadIdx.x; t < n * n; t += blockDim.x) {
+            const uint32_t tx = x0 / T + t % n, ty = y0 / T + t / n;
+            if (tx * T >= P.width || ty * T >= P.height) continue;
+            uint32_t mn = 0xFFFFFFFFu;
+            if (l == (int)P.n_levels - 1) {
+                for (uint32_t p = 0; p < T * T; p++) {
+                    const uint32_t x = tx * T + p % T, y = ty * T + p / T;
+                    if (x < P.width && y < P.height) mn = min(mn, (uint32_t)(S->zbuf[(size_t)y * P.width + x] >> 32));
+                }
+            } else {
+                const uint32_t Tc = P.tiles[l + 1], c = T / Tc, ncx = (P.width + Tc - 1) / Tc;
+                for (uint32_t q = 0; q < c * c; q++) {
+                    const uint32_t sx = tx * c + q % c, sy = ty * c + q / c;
+                    if (sx * Tc < P.width && sy * Tc < P.height) mn = min(mn, S->mind[l + 1][sy * ncx + sx]);
+                }
+            }
+            S->mind[l][ty * ntx + tx] = mn;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
 __global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
-    const FhRender& P = S->P;
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const size_t n = (size_t)P.width * P.height;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t d = (uint32_t)(S->zbuf[i] >> 32);
@@ -631,6 +815,3 @@ __global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
         out[i] = o;
     }
 }
-
-template __global__ void k_tiles<false>(FhRenderState*, int);
-template __global__ void k_tiles<true>(FhRenderState*, int);

@@ -48,14 +48,21 @@ struct FhRenderState {
     // tape arena (8-byte ops)
     uint64_t* arena;
     uint32_t arena_cap, arena_head, arena_root_end, arena_overflow;
-    // level queues
+    // level queues: groups whose tape fits the small LDS layout grow from the front
+    // (count / cursor), the others from the back (count_big / cursor_big)
     FhGroup* queue[FH_MAX_LEVELS];
     uint32_t count[FH_MAX_LEVELS], cursor[FH_MAX_LEVELS];
+    uint32_t count_big[FH_MAX_LEVELS], cursor_big[FH_MAX_LEVELS];
     uint32_t queue_cap, queue_overflow;
     // leaves
     FhLeaf* leaves;
-    uint32_t leaf_cap, n_leaves, leaf_cursor, normal_cursor;
+    uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
     uint32_t* leaf_table;   // 3D: [footprint][layer] -> leaf id + 1
+    // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
+    uint32_t* fp_list[3];
+    uint32_t fp_count[3], fp_cursor[3];
+    // 3D: min-depth pyramid, one array per tile level
+    uint32_t* mind[FH_MAX_LEVELS];
     // images
     uint64_t* zbuf;         // 3D: depth << 32 | leaf id (+1) of a hit whose normal is pending
     float* normals;         // 3D: 3 floats per pixel
