@@ -718,6 +718,38 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]) {
     return FHIP_OK;
 }
 
+// Diagnostics: time `reps` passes of the point interpreter over `tape` in `n_waves` waves.
+// variant: 0 = VGPR file 16 regs x 4, 1 = VGPR 32 x 2, 2 = LDS file, 3 = VGPR 32 x 1
+fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_waves, uint32_t reps, int variant, double* ms) {
+    fhip_status st = tape_to_device(ctx, tape);
+    if (st) return st;
+    HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
+    FhRenderState S;
+    memset(&S, 0, sizeof(S));
+    for (int i = 0; i < FH_MAX_INPUTS; i++) S.P.in_kind[i] = i % 3;
+    HIP_TRY(ctx, hipMemcpy(ctx->state.p, &S, sizeof(S), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->io_a.ensure((size_t)n_waves * WAVE * 4));
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    HIP_TRY(ctx, hipEventCreate(&b));
+    const uint32_t len = (uint32_t)tape->t.ops.size();
+    FhRenderState* dS = (FhRenderState*)ctx->state.p;
+    for (int it = 0; it < 2; it++) {
+        HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+        if (variant == 0) hipLaunchKernelGGL((k_bench_points<16, 4>), dim3(n_waves), dim3(WAVE), 0, ctx->stream, dS, tape->d_ops, len, reps, (float*)ctx->io_a.p);
+        else if (variant == 1) hipLaunchKernelGGL((k_bench_points<32, 2>), dim3(n_waves), dim3(WAVE), 0, ctx->stream, dS, tape->d_ops, len, reps, (float*)ctx->io_a.p);
+        else if (variant == 3) hipLaunchKernelGGL((k_bench_points<32, 1>), dim3(n_waves), dim3(WAVE), 0, ctx->stream, dS, tape->d_ops, len, reps, (float*)ctx->io_a.p);
+        else hipLaunchKernelGGL((k_bench_points<0, 1>), dim3(n_waves), dim3(WAVE), (size_t)std::max<uint32_t>(tape->t.n_regs, 1) * WAVE * 4, ctx->stream, dS, tape->d_ops, len, reps, (float*)ctx->io_a.p);
+        HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(b));
+    }
+    float t = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&t, a, b));
+    *ms = t;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return FHIP_OK;
+}
+
 // ---- host graph ------------------------------------------------------------------------
 static const int UNARY_MAP[] = {FH_NEG, FH_ABS, FH_RECIP, FH_SQRT, FH_SQUARE, FH_FLOOR, FH_CEIL, FH_ROUND, FH_SIN,
                                 FH_COS, FH_TAN, FH_ASIN, FH_ACOS, FH_ATAN, FH_EXP, FH_LN, FH_NOT, FH_RAND};

@@ -34,6 +34,10 @@ using namespace fhd;
 #define AS4 __attribute__((address_space(4)))
 typedef const AS4 uint64_t* ctape_t;  // constant address space => scalar (SMEM) loads
 
+// 4 tape ops (32 B) per scalar load request; the arena keeps slack past its last tape
+typedef unsigned long long Q4 __attribute__((ext_vector_type(4), aligned(8)));
+FH_DEV uint64_t q4_pick(Q4 q, int u) { return u == 0 ? q.x : (u == 1 ? q.y : (u == 2 ? q.z : q.w)); }
+
 FH_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 FH_DEV uint64_t ballot(bool p) { return __ballot(p); }
 
@@ -235,8 +239,11 @@ FH_DEV void prune_sweep(ctape_t tape, uint32_t len, uint32_t n_choices, const ui
         if (m == DEAD) { m = EMIT ? (uint32_t)pool.take() : 0u; M(r) = (uint8_t)m; }
         return m;
     };
+    const AS4 Q4* q = (const AS4 Q4*)tape;
+    Q4 cur = q[(len - 1) >> 2];
     for (uint32_t k = len; k-- > 0;) {
-        const uint64_t w = tape[k];
+        const uint64_t w = q4_pick(cur, (int)(k & 3));
+        if ((k & 3) == 0 && k) cur = q[(k >> 2) - 1];
         const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
         const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
         const bool is_choice = fh_is_choice(op);
@@ -361,8 +368,11 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         uint32_t ci = 0, cw = 0;
         bool any_decided = false;
         if (lane < TL) {
+            const AS4 Q4* q = (const AS4 Q4*)tape;
+            Q4 cur = q[0];
             for (uint32_t k = 0; k < len; k++) {
-                const uint64_t w = tape[k];
+                const uint64_t w = q4_pick(cur, (int)(k & 3));
+                if ((k & 3) == 3) cur = q[(k >> 2) + 1];
                 step<IVAL, TL, FULL>(
                     w, R,
                     [&](uint32_t slot) {
@@ -416,25 +426,23 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         FhTapeRef child;
         child.off = g.tape.off; child.len = len; child.n_regs = (uint16_t)n_regs; child.n_choices = (uint16_t)n_choices;
         if (ballot(prune)) {
+            // One reverse sweep: every pruned child reserves a slot as long as its parent and
+            // writes its ops back to front from the slot's end, so no counting pass is needed
+            // (the unused head of the slot is arena slack, recycled at the next slab).
             uint32_t clen = 0, cregs = 0, cch = 0;
-            if (lane < TL) {
-                for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
-                prune_sweep<false>(tape, len, n_choices, chbits, map, lane16, prune, nullptr, clen, cregs, cch);
-            }
-            uint32_t total;
-            const uint32_t my = prune ? clen : 0;
-            const uint32_t excl = wave_excl_sum(my, total);
+            const uint32_t nprune = (uint32_t)__popcll(ballot(prune));
+            const uint32_t rank = (uint32_t)__popcll(ballot(prune) & ((1ull << lane) - 1));
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&S->arena_head, total);
+            if (lane == 0) base = atomicAdd(&S->arena_head, nprune * len);
             base = uni(base);
-            if (base + total <= S->arena_cap) {
+            if (base + nprune * len <= S->arena_cap) {
                 if (lane < TL) {
                     for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
-                    uint64_t* dst = S->arena + base + excl + clen;
+                    uint64_t* dst = S->arena + base + (rank + 1) * len;
                     prune_sweep<true>(tape, len, n_choices, chbits, map, lane16, prune, dst, clen, cregs, cch);
                 }
                 if (prune) {
-                    child.off = base + excl; child.len = clen;
+                    child.off = base + (rank + 1) * len - clen; child.len = clen;
                     child.n_regs = (uint16_t)cregs; child.n_choices = (uint16_t)cch;
                 }
             } else if (lane == 0) {
@@ -495,7 +503,6 @@ FH_DEV void run_points(ctape_t tape, uint32_t len, const AS4 FhRender& P, const 
     float r0[NR], r1[ZB > 1 ? NR : 1], r2[ZB > 2 ? NR : 1], r3[ZB > 2 ? NR : 1];
 #define RGET(i, v) do { v[0] = r0[i]; if (ZB > 1) v[1] = r1[i]; if (ZB > 2) { v[2] = r2[i]; v[3] = r3[i]; } } while (0)
 #define RSET(i, v) do { r0[i] = v[0]; if (ZB > 1) r1[i] = v[1]; if (ZB > 2) { r2[i] = v[2]; r3[i] = v[3]; } } while (0)
-    typedef unsigned long long Q4 __attribute__((ext_vector_type(4), aligned(8)));  // 4 ops = one s_load_dwordx8
     const AS4 Q4* q = (const AS4 Q4*)tape;
     Q4 cur = q[0];
     for (uint32_t k0 = 0; k0 < len; k0 += 4) {
@@ -814,4 +821,20 @@ __global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
         else { o.normal[0] = S->normals[i * 3]; o.normal[1] = S->normals[i * 3 + 1]; o.normal[2] = S->normals[i * 3 + 2]; o.depth = d; }
         out[i] = o;
     }
+}
+
+// ---- micro-benchmark of the point interpreter (diagnostics only; fhip_debug_bench) -----------
+template <int NR, int ZB>
+__global__ void __launch_bounds__(WAVE) k_bench_points(FhRenderState* S, const uint64_t* tape_g, uint32_t len, uint32_t reps, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const ctape_t tape = (ctape_t)tape_g;
+    float x[ZB], y[ZB], z[ZB], res[ZB], acc = 0.0f;
+    FOR_Z { x[j] = (float)threadIdx.x * 0.01f + j; y[j] = (float)blockIdx.x * 0.001f; z[j] = 0.5f * j; res[j] = 0.0f; }
+    for (uint32_t r = 0; r < reps; r++) {
+        if (NR) run_points<(NR ? NR : 1), ZB, false>(tape, len, P, x, y, z, res);
+        else res[0] = run_points_lds<false>(tape, len, P, (float*)smem, threadIdx.x, x[0], y[0], z[0]);
+        FOR_Z { acc += res[j]; x[j] += 1e-3f; }
+    }
+    out[blockIdx.x * WAVE + threadIdx.x] = acc;
 }
