@@ -45,7 +45,7 @@ struct fhip_ctx {
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue;
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)1 << 30;
     bool profiling = false;
@@ -111,7 +111,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
-                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind};
+                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
@@ -377,7 +377,7 @@ struct RenderSetup {
     std::vector<FhGroup> roots;
     uint32_t n_slabs = 1;
     size_t lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
-    uint32_t table_words = 0, n_footprints = 0;
+    uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
 };
 
@@ -456,25 +456,36 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.lds_normals_small = (size_t)32 * WAVE * 16;
     if (R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
 
-    // root groups: runs of <= 16 root tiles of this shard
+    // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
+    S.n_slabs = R.n_slabs;
+    S.pre_levels = (is3d && ts.size() >= 3 && R.n_slabs <= FH_MAX_SLABS) ? 2 : 0;
+    const uint32_t slabs_in_q0 = S.pre_levels ? R.n_slabs : 1;
+
+    // root groups: runs of <= 16 root tiles of this shard (one set per slab in pre-pass mode)
     std::vector<uint32_t> mine;
     for (uint32_t ri = shard; ri < P.roots_x * P.roots_y; ri += n_shards) mine.push_back(ri);
     FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
-    for (size_t i = 0; i < mine.size(); i += TL) {
-        FhGroup g{};
-        g.tape = root;
-        g.first = mine[i];
-        g.n = (uint32_t)std::min<size_t>(TL, mine.size() - i);
-        g.stride = n_shards;
-        R.roots.push_back(g);
-    }
+    for (uint32_t k = 0; k < slabs_in_q0; k++)
+        for (size_t i = 0; i < mine.size(); i += TL) {
+            FhGroup g{};
+            g.tape = root;
+            g.first = mine[i];
+            g.n = (uint32_t)std::min<size_t>(TL, mine.size() - i);
+            g.stride = n_shards;
+            g.z = (R.n_slabs - 1 - k) * ts[0];  // front slabs first
+            R.roots.push_back(g);
+        }
+    R.groups_per_slab = (uint32_t)(R.roots.size() / slabs_in_q0);
 
-    // capacities (exact upper bounds per slab)
-    uint32_t qcap = std::max<uint32_t>((uint32_t)R.roots.size(), 1);
+    // capacities (exact upper bounds): queue[l] holds the tiles of size ts[l-1] that can be
+    // ambiguous, per slab for the per-slab levels and for the whole volume for pre-pass levels
+    uint32_t qcaps[FH_MAX_LEVELS] = {0};
+    qcaps[0] = std::max<uint32_t>((uint32_t)R.roots.size(), 1);
     for (size_t l = 1; l < ts.size(); l++) {
         const uint64_t tp = ts[l - 1];
         uint64_t c = (uint64_t)((P.width + tp - 1) / tp) * ((P.height + tp - 1) / tp) * (is3d ? ts[0] / tp : 1);
-        qcap = (uint32_t)std::max<uint64_t>(qcap, c);
+        if (l < S.pre_levels) c *= R.n_slabs;
+        qcaps[l] = (uint32_t)std::max<uint64_t>(c, 1);
     }
     const uint64_t tl = ts.back();
     const uint64_t fw = (P.width + tl - 1) / tl, fhh = (P.height + tl - 1) / tl;
@@ -484,7 +495,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
 
     HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
     HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes));
-    for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcap * sizeof(FhGroup)));
+    for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
+    if (S.pre_levels) HIP_TRY(ctx, ctx->squeue.ensure((size_t)qcaps[S.pre_levels] * R.n_slabs * sizeof(FhGroup)));
     HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
         HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
@@ -511,7 +523,11 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         S.count[l] = S.cursor[l] = S.count_big[l] = S.cursor_big[l] = 0;
     }
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
-    S.queue_cap = qcap;
+    for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
+    S.squeue = (FhGroup*)ctx->squeue.p;
+    S.squeue_cap = qcaps[S.pre_levels];
+    S.arena_frame_end = S.arena_root_end;
+    for (int k = 0; k < FH_MAX_SLABS; k++) S.scount[k] = S.scount_big[k] = 0;
     S.queue_overflow = 0;
     S.leaves = (FhLeaf*)ctx->leaves.p;
     S.leaf_cap = (uint32_t)leaf_cap;
@@ -546,7 +562,7 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (!R.roots.empty()) {
-        FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.queue_cap - R.roots.size());
+        FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size());
         HIP_TRY(ctx, hipMemcpyAsync(back, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
     }
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
@@ -648,17 +664,22 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     if (st) return st;
     HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, 0, npix * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
-    const uint32_t n_groups = (uint32_t)R.roots.size();
+    const uint32_t n_groups = R.groups_per_slab;
+    const uint32_t pre = R.S.pre_levels;
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
     const int class_blocks = (int)((R.n_footprints + 255) / 256);
+    if (pre && n_groups) {  // coarse levels of every slab in one go
+        for (uint32_t l = 0; l < pre; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
+    }
     for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
         launch(ctx, FHIP_K_OTHER, [&] {
-            hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k * ts[0], n_groups);
+            hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups);
             if (k != (int)R.n_slabs - 1)  // the first slab sees an empty image (pyramid pre-zeroed)
                 hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
         });
-        for (uint32_t l = 0; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS); });
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file

@@ -330,9 +330,15 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         gi = uni(gi);
         if (gi >= (BIG ? S->count_big[level] : S->count[level])) break;
         // small groups fill the queue from the front, big ones from the back
-        const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][BIG ? S->queue_cap - 1 - gi : gi];
+        const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][BIG ? S->qcap[level] - 1 - gi : gi];
         const ctape_t tape = (ctape_t)(S->arena + g.tape.off);
         const uint32_t len = g.tape.len, n_choices = g.tape.n_choices, n_regs = g.tape.n_regs;
+
+        // the whole parent may have been occluded since it was queued (pre-pass levels)
+        if (IS3D && level > 0) {
+            const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
+            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + Tp + 1) continue;
+        }
 
         // ---- enumerate children ------------------------------------------------
         uint32_t nchild, cx, cy, cz;
@@ -456,18 +462,23 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             uint32_t ns, nb;
             const uint32_t slot_s = wave_excl_sum((amb && small) ? 1u : 0u, ns);
             const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
+            // the last pre-pass level parks its output in the queue of the children's z-slab
+            const bool park = IS3D && S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
+            const uint32_t slab = park ? g.z / P.tiles[0] : 0;
+            FhGroup* const qdst = park ? S->squeue + (size_t)slab * S->squeue_cap : S->queue[level + 1];
+            const uint32_t qcap = park ? S->squeue_cap : S->qcap[level + 1];
             uint32_t qs = 0, qb = 0;
             if (lane == 0) {
-                if (ns) qs = atomicAdd(&S->count[level + 1], ns);
-                if (nb) qb = atomicAdd(&S->count_big[level + 1], nb);
+                if (ns) qs = atomicAdd(park ? &S->scount[slab] : &S->count[level + 1], ns);
+                if (nb) qb = atomicAdd(park ? &S->scount_big[slab] : &S->count_big[level + 1], nb);
             }
             qs = uni(qs); qb = uni(qb);
             if (amb) {
                 FhGroup o;
                 o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = 0; o.stride = 0;
-                // the two halves cannot collide: their total is bounded by queue_cap
-                if (small) S->queue[level + 1][qs + slot_s] = o;
-                else S->queue[level + 1][S->queue_cap - 1 - (qb + slot_b)] = o;
+                // the two halves cannot collide: their total is bounded by the capacity
+                if (small) qdst[qs + slot_s] = o;
+                else qdst[qcap - 1 - (qb + slot_b)] = o;
             }
         } else {
             uint32_t namb;
@@ -765,19 +776,29 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
     }
 }
 
-// Per-slab reset of the work queues, leaf table and tape arena (root tape stays)
-__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab_z, uint32_t n_root_groups) {
+// Per-slab reset of the work queues, leaf table and tape arena (frame-persistent tapes stay)
+__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
+    const uint32_t P0 = S->pre_levels;
     if (i == 0) {
-        for (int l = 0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0; }
-        S->count_big[0] = n_root_groups;  // the root tape uses the large LDS layout
+        for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0; }
+        if (P0 == 0) {
+            S->count_big[0] = n_root_groups;  // the root tape uses the large LDS layout
+            S->arena_head = S->arena_root_end;
+        } else {
+            S->queue[P0] = S->squeue + (size_t)slab * S->squeue_cap;
+            S->count[P0] = S->scount[slab];
+            S->count_big[P0] = S->scount_big[slab];
+            S->arena_head = S->arena_frame_end;
+        }
         S->n_leaves = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
-        S->arena_head = S->arena_root_end;
     }
-    if (i < n_root_groups) S->queue[0][S->queue_cap - 1 - i].z = slab_z;
+    if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.tiles[0];
 }
+// End of the pre-pass: everything allocated so far lives for the whole frame
+__global__ void k_mark_frame(FhRenderState* S) { S->arena_frame_end = S->arena_head; }
 
 // Min-depth pyramid of the z-buffer, one workgroup per root tile: mind[l][tile] = smallest
 // depth over the tile's in-image pixels.  Feeds the occlusion test of k_tiles.

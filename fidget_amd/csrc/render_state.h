@@ -7,6 +7,7 @@
 
 #define FH_MAX_LEVELS 8
 #define FH_MAX_INPUTS 16
+#define FH_MAX_SLABS 64
 
 // One wave's worth of interval work: a parent tile (or, at level 0, a run of root tiles)
 // together with the tape that evaluates its children.
@@ -53,7 +54,15 @@ struct FhRenderState {
     FhGroup* queue[FH_MAX_LEVELS];
     uint32_t count[FH_MAX_LEVELS], cursor[FH_MAX_LEVELS];
     uint32_t count_big[FH_MAX_LEVELS], cursor_big[FH_MAX_LEVELS];
-    uint32_t queue_cap, queue_overflow;
+    uint32_t qcap[FH_MAX_LEVELS];   // capacity of queue[l]
+    uint32_t queue_overflow;
+    // 3D: the first `pre_levels` tile levels are evaluated for ALL z-slabs in one go at the start
+    // of the frame (their cost is latency, not throughput); their output, the level-`pre_levels`
+    // work, is parked per slab in squeue[slab * squeue_cap ..] and their tapes stay in the arena
+    // below arena_frame_end for the whole frame.
+    uint32_t pre_levels, n_slabs, squeue_cap, arena_frame_end;
+    FhGroup* squeue;
+    uint32_t scount[FH_MAX_SLABS], scount_big[FH_MAX_SLABS];
     // leaves
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
