@@ -17,13 +17,15 @@ checks run anywhere), but creating a context without a HIP device raises.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "kernels.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h"]
+_SOURCES = ["capi.hip", "kernels.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
+            "gen_interp.py", "offsets.cpp"]
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
          "asin", "acos", "atan", "exp", "ln", "not", "rand"]          # context/op.rs:11-30
@@ -49,7 +51,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world",
+    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench",
 ]
 
 
@@ -60,15 +62,32 @@ class FidgetHipError(RuntimeError):
 
 
 def build(force=False, verbose=False):
-    """Compile libfidget_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile libfidget_hip.so for gfx950 (cross-compiles without a GPU): the assembly
+    interpreters (gen_interp.py -> .s -> code object, embedded in the library) and the HIP
+    kernels + C ABI (capi.hip)."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(_CSRC, "capi.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    gen = os.path.join(_CSRC, "_gen")
+    os.makedirs(gen, exist_ok=True)
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    co = os.path.join(gen, "interp_gfx950.co")
+
+    def run(cmd, **kw):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, **kw)
+
+    run(["g++", "-std=c++17", "-I", _CSRC, os.path.join(_CSRC, "offsets.cpp"), "-o", os.path.join(gen, "offsets")])
+    with open(os.path.join(gen, "offsets.json"), "w") as f:
+        subprocess.check_call([os.path.join(gen, "offsets")], stdout=f)
+    run([sys.executable, os.path.join(_CSRC, "gen_interp.py"), os.path.join(gen, "offsets.json"),
+         os.path.join(gen, "interp_gfx950.s")])
+    run([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
+         os.path.join(gen, "interp_gfx950.s"), "-o", os.path.join(gen, "interp_gfx950.o")])
+    run([os.path.join(llvm, "ld.lld"), "-shared", os.path.join(gen, "interp_gfx950.o"), "-o", co])
+    run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         f'-DFH_INTERP_CO="{co}"', "-o", LIB_PATH, os.path.join(_CSRC, "capi.hip")])
     return LIB_PATH
 
 
@@ -114,6 +133,8 @@ def lib():
             "fhip_render3d_shard": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, u32]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
+            "fhip_debug_stats": (i32, [vp, vp]),
+            "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
             "fhip_graph_unary": (u32, [vp, i32, u32]), "fhip_graph_binary": (u32, [vp, i32, u32, u32]),
@@ -178,6 +199,15 @@ class HipContext:
         self.check(lib().fhip_render_counters(self._h, _p(c)))
         return {"arena_ops": int(c[0]), "arena_overflow": int(c[1]), "leaves_last_slab": int(c[2]),
                 "queue_overflow": int(c[3]), "groups_last_slab": [int(v) for v in c[4:8]]}
+
+    def wave_stats(self):
+        """Per kernel kind: mean / max busy microseconds of the waves that found work, their
+        number and the units of work they pulled (frame totals)."""
+        c = np.zeros(32, np.uint64)
+        self.check(lib().fhip_debug_stats(self._h, _p(c)))
+        names = ["tiles_l0", "tiles_l1", "tiles_l2", "tiles_l3", "tiles_l4", "columns_c0", "columns_c12", "tiles_2d"]
+        return {k: {"busy_us_sum": int(c[4 * i]) / 100.0, "busy_us_max": int(c[4 * i + 1]) / 100.0,
+                    "waves": int(c[4 * i + 2]), "units": int(c[4 * i + 3])} for i, k in enumerate(names) if c[4 * i + 2]}
 
 
 _default_ctx = None

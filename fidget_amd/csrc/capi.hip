@@ -39,7 +39,18 @@ struct fhip_graph {
     fh::Graph g;
 };
 
+// The assembly interpreters (gen_interp.py -> interp_gfx950.co), embedded at build time
+#ifndef __HIP_DEVICE_COMPILE__
+__asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
+#endif
+extern "C" const char fh_interp_co[];
+enum { FH_ASM_COLUMNS_16x4 = 0, FH_ASM_COLUMNS_32x2, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns_16x4", "fh_columns_32x2", "fh_float_eval_16x4", "fh_float_eval_32x2"};
+
 struct fhip_ctx {
+    hipModule_t asm_mod = nullptr;
+    hipFunction_t asm_fn[FH_ASM_COUNT] = {};
+    bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -103,6 +114,10 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
                          (const void*)k_columns3d<2, 0, 1, false>, (const void*)k_columns3d<2, 0, 1, true>,
                          (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    if (hipModuleLoadData(&c->asm_mod, fh_interp_co) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    for (int i = 0; i < FH_ASM_COUNT; i++)
+        if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    if (const char* e = getenv("FHIP_NO_ASM")) c->use_asm = atoi(e) == 0;
     *out = c;
     return FHIP_OK;
 }
@@ -114,6 +129,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
                       &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
+    if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     delete c;
 }
@@ -134,10 +150,29 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     *out = t;
     return FHIP_OK;
 }
+// Launch one of the assembly kernels: `waves` single-wave workgroups, raw kernarg block
+static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes) {
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(ctx->asm_fn[which], waves, 1, 1, WAVE, 1, 1, 0, ctx->stream, nullptr, extra);
+}
+// The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
+static bool tape_asm_ok(const fh::HostTape& t) {
+    for (uint64_t w : t.ops) {
+        const uint32_t op = FH_W_OP((uint32_t)w);
+        if ((op >= FH_SIN && op <= FH_LN) || op == FH_RAND) return false;
+        if (op >= FH_ADD_RR) {
+            const int base = op >= FH_SUB_IR ? (int[]){1, 3, 4, 5, 6, 7}[op - FH_SUB_IR] : (int)((op - FH_ADD_RR) % 12);
+            if (base == 4 || base == 6 || base == 7) return false;  // atan2, mix, mod
+        }
+    }
+    return true;
+}
+
 static fhip_status tape_to_device(fhip_ctx* ctx, const fhip_tape* t) {
     if (t->d_ops) return FHIP_OK;
-    size_t bytes = std::max<size_t>(t->t.ops.size(), 1) * 8;
+    size_t bytes = (t->t.ops.size() + 16) * 8;  // slack: the interpreters prefetch up to 12 ops past the end
     HIP_TRY(ctx, hipMalloc((void**)&t->d_ops, bytes));
+    HIP_TRY(ctx, hipMemset(t->d_ops, 0, bytes));
     HIP_TRY(ctx, hipMemcpy(t->d_ops, t->t.ops.data(), t->t.ops.size() * 8, hipMemcpyHostToDevice));
     return FHIP_OK;
 }
@@ -313,7 +348,13 @@ static fhip_status bulk_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* 
     const size_t lds = (size_t)nr * WAVE * 4 * comp;
     const bool g = lds > FH_LDS_MAX;
     if (g) HIP_TRY(ctx, ctx->io_e.ensure(lds * grid));
-    if (comp == 1) {
+    if (comp == 1 && ctx->use_asm && nr <= 32 && tape_asm_ok(t)) {
+        // 64 * ZB samples per wave, register file in VGPRs (gen_interp.py)
+        struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } ka = {
+            tape->d_ops, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (uint32_t)t.ops.size(), n};
+        const uint32_t per = nr <= 16 ? 256 : 128;
+        HIP_TRY(ctx, launch_asm(ctx, nr <= 16 ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_32x2, (n + per - 1) / per, &ka, sizeof(ka)));
+    } else if (comp == 1) {
         if (g) hipLaunchKernelGGL(k_eval_f32<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
                            (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)nullptr, (uint8_t*)nullptr, 0u, (float*)ctx->io_e.p, nr);
         else hipLaunchKernelGGL(k_eval_f32<false>, dim3(grid), dim3(WAVE), lds, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
@@ -379,6 +420,7 @@ struct RenderSetup {
     size_t lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
+    bool asm_points = false;  // leaf stage on the assembly interpreters
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -447,6 +489,9 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     P.roots_y = (P.height + ts[0] - 1) / ts[0];
     R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
     R.full = tape_is_full(t);
+    // assembly leaf kernels: supported opcodes only and an affine screen-to-model matrix
+    R.asm_points = ctx->use_asm && is3d && tape_asm_ok(t) && P.mat[12] == 0.0f && P.mat[13] == 0.0f && P.mat[14] == 0.0f &&
+                   P.mat[15] == 1.0f;
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices);
@@ -515,7 +560,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         for (int c = 0; c < 3; c++) S.fp_list[c] = (uint32_t*)ctx->fp_lists.p + (size_t)c * R.n_footprints;
     }
     S.arena = (uint64_t*)ctx->arena.p;
-    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 16, 0xFFFFFFF0u);  // slack: 4-op prefetch reads past a tape's end
+    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 32, 0xFFFFFFE0u);  // slack: the interpreters prefetch up to 12 ops past a tape's end
     S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
     S.arena_overflow = 0;
     for (int l = 0; l < FH_MAX_LEVELS; l++) {
@@ -683,7 +728,11 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS); });
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
-            if (R.full) {
+            if (R.asm_points) {
+                void* ka = dS;
+                (void)launch_asm(ctx, FH_ASM_COLUMNS_16x4, ctx->n_cu * 16, &ka, sizeof(ka));
+                (void)launch_asm(ctx, FH_ASM_COLUMNS_32x2, ctx->n_cu * 16, &ka, sizeof(ka));
+            } else if (R.full) {
                 hipLaunchKernelGGL((k_columns3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_columns3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
             } else {
@@ -736,6 +785,14 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]) {
     const FhRenderState& S = ctx->last_state;
     out[0] = S.arena_head; out[1] = S.arena_overflow; out[2] = S.n_leaves; out[3] = S.queue_overflow;
     for (int i = 0; i < 4; i++) out[4 + i] = S.count[i + 1];
+    return FHIP_OK;
+}
+
+// Diagnostics: per-kernel-kind wave busy statistics of the last render (see WaveProbe)
+fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[32]) {
+    fhip_status st = finish_render(ctx);
+    if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
+    for (int i = 0; i < 32; i++) out[i] = ctx->last_state.stat[i];
     return FHIP_OK;
 }
 

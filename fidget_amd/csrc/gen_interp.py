@@ -1,0 +1,851 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 (CDNA4) assembly interpreters of fidget-hip.
+
+Why assembly: a tape interpreter is one indirect jump per operation.  The AMDGPU backend of
+clang has neither jump tables nor computed goto, so a C++ `switch` becomes a compare/branch
+tree (~20 taken branches per tape op) and every dynamically indexed write to a register-file
+array in VGPRs is preceded by a copy of the whole array.  Here the dispatch is one
+`s_setpc_b64` into a table of fixed-size handlers and the register file is addressed in place
+with `s_set_gpr_idx_on` (M0-relative VGPR operands).
+
+Kernels emitted (f32 point evaluation of a tape, fidget-core/src/vm/mod.rs:788-1049 semantics,
+bit-exact with the C++ kernels in kernels.hip which they replace on their fast path):
+
+  fh_columns_{NR}x{ZB}     3D leaf stage: one 8x8 pixel footprint per wave, leaves front to
+                           back, ZB voxels per lane per pass (same algorithm as k_columns3d)
+  fh_float_eval_{NR}x{ZB}  BulkEvaluator<f32>: 64*ZB samples per wave
+
+NR = registers of the VGPR register file, ZB = samples per lane.  The file occupies
+v[FILE .. FILE+NR*ZB): register r of sample slot j is v[FILE + j*NR + r].
+
+Tape format: tape_format.h (8 bytes per op: opcode | out<<8 | a<<20, then b / imm / slot).
+Tapes with transcendental, modulo or rng ops, more than 32 registers, or a projective
+screen-to-model matrix stay on the C++ kernels.
+
+usage: gen_interp.py offsets.json out.s
+"""
+import json
+import sys
+
+# ---- opcodes (tape_format.h) ---------------------------------------------------------------
+OPS = ["OUTPUT", "INPUT", "COPY_REG", "COPY_IMM",
+       "NEG", "ABS", "RECIP", "SQRT", "SQUARE", "FLOOR", "CEIL", "ROUND", "SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN",
+       "EXP", "LN", "NOT", "RAND"]
+BIN = ["ADD", "SUB", "MUL", "DIV", "ATAN2", "COMPARE", "MIX", "MOD", "MIN", "MAX", "AND", "OR"]
+OPS += [b + "_RR" for b in BIN] + [b + "_RI" for b in BIN] + [b + "_IR" for b in ("SUB", "DIV", "ATAN2", "COMPARE", "MIX", "MOD")]
+assert len(OPS) == 52
+UNSUPPORTED = {"SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "EXP", "LN", "RAND", "ATAN2", "MIX", "MOD"}
+
+HSTRIDE_LOG2 = 7  # handler slots of 128 bytes
+
+# ---- fixed SGPRs ---------------------------------------------------------------------------
+S_KERNARG = "s[0:1]"
+S_WG = "s2"
+S_STATE = "s[4:5]"
+S_MAT = 8               # s[8:23]    screen -> model matrix, row major
+S_WIDTH, S_HEIGHT = "s24", "s25"
+S_LAYERS, S_FW = "s26", "s27"
+S_SIGN = "s28"          # 0x80000000
+S_ABSM = "s29"          # 0x7fffffff
+S_ARENA = "s[30:31]"
+S_LEAVES = "s[32:33]"
+S_TABLE = "s[34:35]"
+S_ZBUF = "s[36:37]"
+S_FPLIST = "s[38:39]"
+S_NFP = "s40"
+S_WI = "s41"
+S_HBASE = "s[42:43]"    # address of handler 0
+S_TAPE = "s[44:45]"     # interpreter argument: first op
+S_LEN = "s46"           # interpreter argument: ops left
+S_LEN0 = "s47"
+S_QA = 48               # s[48:55]  current batch of 4 ops
+S_QB = 56               # s[56:63]  next batch
+S_W0, S_W1 = "s64", "s65"
+S_CUR = "s[64:65]"
+S_T0 = "s66"
+S_OUT = "s67"
+S_A = "s68"
+S_T1 = "s69"
+S_BATCH = "s70"
+S_FETCH = "s[72:73]"
+S_RET = "s[74:75]"
+S_FX, S_FY = "s76", "s77"
+S_ID = "s78"
+S_LZ = "s79"
+S_LAYMASK = "s[80:81]"
+S_PEND = "s[82:83]"
+S_TBASE = "s[84:85]"
+S_PC = "s[86:87]"
+S_SAVE = "s[88:89]"
+S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]   # per-slot lane masks s[90:97]
+S_K = "s98"
+S_ZL = "s99"
+S_N = "s6"              # bulk: number of samples
+S_ACT = [f"s[{8 + 2 * j}:{9 + 2 * j}]" for j in range(4)]  # bulk: lanes of slot j holding a sample
+S_VARS = "s[30:31]"     # bulk
+S_OUTP = "s[32:33]"     # bulk
+
+# ---- fixed VGPRs ---------------------------------------------------------------------------
+V_LANE = "v0"
+V_PXF, V_PYF = "v1", "v6"
+V_PIX = "v[2:3]"
+V_HIT, V_DEPTH = "v4", "v5"     # stored together as the 64-bit z-buffer word
+V_IDS = "v7"
+V_AX, V_AY, V_AZ = "v8", "v9", "v57"
+VX = [f"v{10 + j}" for j in range(4)]
+VY = [f"v{14 + j}" for j in range(4)]
+VZ = [f"v{18 + j}" for j in range(4)]
+VRES = [f"v{22 + j}" for j in range(4)]
+VT = [f"v{26 + j}" for j in range(4)]
+VU = [f"v{30 + j}" for j in range(4)]
+VW = [f"v{34 + j}" for j in range(4)]
+VD = [f"v{38 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
+V_QNAN = "v48"
+V_SQRTC = "v49"
+V_LX, V_LY = "v50", "v51"
+V_S0, V_S1, V_S2, V_S3 = "v52", "v53", "v54", "v55"
+V_IDV = "v56"
+VOFF = [f"v{58 + j}" for j in range(4)]  # bulk: byte offset of sample j
+FILE = 64
+
+SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.uid = 0
+
+    def __call__(self, s=""):
+        for ln in s.strip("\n").split("\n"):
+            self.lines.append(ln.rstrip())
+
+    def label(self, stem):
+        self.uid += 1
+        return f".L{stem}_{self.uid}"
+
+    def text(self):
+        return "\n".join(self.lines) + "\n"
+
+
+def hexf(x):
+    import struct
+    return "0x%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+class Interp:
+    """One interpreter instance (dispatch loop + handlers) for a given NR x ZB and I/O kind."""
+
+    def __init__(self, a, name, nr, zb, kind, off):
+        self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
+        self.next = f".L{name}_next"
+        self.ool = []  # out-of-line handler bodies: (label, callable)
+
+    def F(self, j):
+        return f"v{FILE + j * self.nr}"
+
+    # -- small helpers ---------------------------------------------------------------------
+    def idx_on(self, sreg, mode):
+        self.a(f"\ts_set_gpr_idx_on {sreg}, {mode}")
+
+    def idx_idx(self, sreg):
+        self.a(f"\ts_set_gpr_idx_idx {sreg}")
+
+    def idx_off(self):
+        self.a("\ts_set_gpr_idx_off")
+
+    def read_a(self, dst):
+        """dst[j] = file[a]; leaves SRC0-relative mode on."""
+        self.idx_on(S_A, SRC0)
+        for j in range(self.zb):
+            self.a(f"\tv_mov_b32 {dst[j]}, {self.F(j)}")
+
+    def read_b(self, dst, already_on=True):
+        if already_on:
+            self.idx_idx(S_W1)
+        else:
+            self.idx_on(S_W1, SRC0)
+        for j in range(self.zb):
+            self.a(f"\tv_mov_b32 {dst[j]}, {self.F(j)}")
+
+    def imm_b(self, dst):
+        for j in range(self.zb):
+            self.a(f"\tv_mov_b32 {dst[j]}, {S_W1}")
+
+    def write_out(self, src, done=True):
+        """file[out] = src[j]; ends the handler."""
+        self.idx_on(S_OUT, DST)
+        for j in range(self.zb):
+            self.a(f"\tv_mov_b32 {self.F(j)}, {src[j]}")
+        self.idx_off()
+        if done:
+            self.a(f"\ts_branch {self.next}")
+
+    def mask_gap(self):
+        """VALU-written SGPR read as a lane mask by a VALU op needs 2 wait states (gfx940+)."""
+        if self.zb < 3:
+            self.a(f"\ts_nop {2 - self.zb}")
+
+    # -- arithmetic on plain VGPR operands (index mode off) ------------------------------------
+    def f_minmax(self, is_min, A, B, R):
+        # min: a < b ? a : b, max: a > b ? a : b; either NaN -> NaN  (dev_ops.hpp f_min / f_max)
+        cmp = "v_cmp_lt_f32_e64" if is_min else "v_cmp_gt_f32_e64"
+        for j in range(self.zb):
+            self.a(f"\t{cmp} {S_M[j]}, {A[j]}, {B[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {S_M[j]}")
+        for j in range(self.zb):
+            self.a(f"\tv_cmp_u_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {S_M[j]}")
+
+    def f_andor(self, is_and, A, B, R):
+        # and: a == 0 ? a : b ; or: a != 0 ? a : b
+        cmp = "v_cmp_eq_f32_e64" if is_and else "v_cmp_neq_f32_e64"
+        for j in range(self.zb):
+            self.a(f"\t{cmp} {S_M[j]}, 0, {A[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {S_M[j]}")
+
+    def f_compare(self, A, B, R):
+        # a < b ? -1 : (a == b ? 0 : (a > b ? 1 : NaN))
+        for j in range(self.zb):
+            self.a(f"\tv_cmp_gt_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {V_QNAN}, 1.0, {S_M[j]}")
+        for j in range(self.zb):
+            self.a(f"\tv_cmp_eq_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, 0, {S_M[j]}")
+        for j in range(self.zb):
+            self.a(f"\tv_cmp_lt_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
+        self.mask_gap()
+        for j in range(self.zb):
+            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, -1.0, {S_M[j]}")
+
+    def f_div(self, A, B, R):
+        # IEEE-correct a / b: the div_scale / rcp / fma / div_fmas / div_fixup sequence
+        d = VD
+        for j in range(self.zb):
+            a, b = A[j], B[j]
+            self.a(f"""
+	v_div_scale_f32 {d[0]}, {S_SAVE}, {b}, {b}, {a}
+	v_rcp_f32 {d[1]}, {d[0]}
+	v_div_scale_f32 {d[2]}, vcc, {a}, {b}, {a}
+	v_fma_f32 {d[3]}, -{d[0]}, {d[1]}, 1.0
+	v_fmac_f32 {d[1]}, {d[3]}, {d[1]}
+	v_mul_f32 {d[3]}, {d[2]}, {d[1]}
+	v_fma_f32 {d[4]}, -{d[0]}, {d[3]}, {d[2]}
+	v_fmac_f32 {d[3]}, {d[4]}, {d[1]}
+	v_fma_f32 {d[0]}, -{d[0]}, {d[3]}, {d[2]}
+	v_div_fmas_f32 {d[0]}, {d[0]}, {d[1]}, {d[3]}
+	v_div_fixup_f32 {R[j]}, {d[0]}, {b}, {a}""")
+
+    def f_sqrt(self, A, R):
+        # correctly rounded sqrtf: scale denormals, v_sqrt_f32, one ulp fix-up either way
+        d = VD
+        for j in range(self.zb):
+            a = A[j]
+            self.a(f"""
+	v_mul_f32 {d[0]}, 0x4f800000, {a}
+	v_cmp_gt_f32 vcc, {V_SQRTC}, {a}
+	s_nop 1
+	v_cndmask_b32 {d[1]}, {a}, {d[0]}, vcc
+	v_sqrt_f32 {d[0]}, {d[1]}
+	s_nop 0
+	v_add_u32 {d[2]}, -1, {d[0]}
+	v_add_u32 {d[3]}, 1, {d[0]}
+	v_fma_f32 {d[4]}, -{d[2]}, {d[0]}, {d[1]}
+	v_fma_f32 {d[5]}, -{d[3]}, {d[0]}, {d[1]}
+	v_cmp_ge_f32_e64 {S_M[0]}, 0, {d[4]}
+	s_nop 1
+	v_cndmask_b32_e64 {d[0]}, {d[0]}, {d[2]}, {S_M[0]}
+	v_cmp_lt_f32_e64 {S_M[0]}, 0, {d[5]}
+	s_nop 1
+	v_cndmask_b32_e64 {d[0]}, {d[0]}, {d[3]}, {S_M[0]}
+	v_mul_f32 {d[2]}, 0x37800000, {d[0]}
+	v_cndmask_b32 {d[0]}, {d[0]}, {d[2]}, vcc
+	v_mov_b32 {d[3]}, 0x260
+	v_cmp_class_f32 vcc, {d[1]}, {d[3]}
+	s_nop 1
+	v_cndmask_b32 {R[j]}, {d[0]}, {d[1]}, vcc""")
+
+    def f_round(self, A, R):
+        # roundf: half away from zero
+        d = VD
+        for j in range(self.zb):
+            a = A[j]
+            self.a(f"""
+	v_trunc_f32 {d[0]}, {a}
+	v_sub_f32 {d[1]}, {a}, {d[0]}
+	v_cmp_ge_f32_e64 {S_M[0]}, |{d[1]}|, 0.5
+	s_nop 1
+	v_cndmask_b32_e64 {d[1]}, 0, 1.0, {S_M[0]}
+	v_bfi_b32 {d[1]}, {S_ABSM}, {d[1]}, {a}
+	v_add_f32 {R[j]}, {d[0]}, {d[1]}""")
+
+    # -- handlers ------------------------------------------------------------------------------
+    def out_of_line(self, stem, fn):
+        lab = f".L{self.name}_{stem}"
+        self.ool.append((lab, fn))
+        self.a(f"\ts_branch {lab}")
+
+    def handler(self, op):
+        a, zb, F = self.a, self.zb, self.F
+        Z = range(zb)
+        if op == "OUTPUT":
+            return self.h_output()
+        if op == "INPUT":
+            return self.out_of_line("input", self.h_input)
+        if op == "COPY_REG":
+            self.read_a(VT)
+            return self.write_out(VT)
+        if op == "COPY_IMM":
+            self.idx_on(S_OUT, DST)
+            for j in Z:
+                a(f"\tv_mov_b32 {F(j)}, {S_W1}")
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
+        if op in ("NEG", "ABS", "FLOOR", "CEIL"):
+            self.idx_on(S_A, SRC1 if op in ("NEG", "ABS") else SRC0)
+            for j in Z:
+                if op == "NEG":
+                    a(f"\tv_xor_b32 {VT[j]}, {S_SIGN}, {F(j)}")
+                elif op == "ABS":
+                    a(f"\tv_and_b32 {VT[j]}, {S_ABSM}, {F(j)}")
+                elif op == "FLOOR":
+                    a(f"\tv_floor_f32 {VT[j]}, {F(j)}")
+                else:
+                    a(f"\tv_ceil_f32 {VT[j]}, {F(j)}")
+            return self.write_out(VT)
+        if op == "SQUARE":
+            self.idx_on(S_A, SRC0 | SRC1)
+            for j in Z:
+                a(f"\tv_mul_f32 {VT[j]}, {F(j)}, {F(j)}")
+            return self.write_out(VT)
+        if op == "NOT":
+            self.read_a(VT)
+            self.idx_off()
+            for j in Z:
+                a(f"\tv_cmp_eq_f32_e64 {S_M[j]}, 0, {VT[j]}")
+            self.mask_gap()
+            for j in Z:
+                a(f"\tv_cndmask_b32_e64 {VU[j]}, 0, 1.0, {S_M[j]}")
+            return self.write_out(VU)
+        if op in ("RECIP", "SQRT", "ROUND"):
+            def body(op=op):
+                self.read_a(VT)
+                self.idx_off()
+                if op == "RECIP":
+                    one = ["1.0"] * 4
+                    self.f_div(one, VT, VU)
+                elif op == "SQRT":
+                    self.f_sqrt(VT, VU)
+                else:
+                    self.f_round(VT, VU)
+                self.write_out(VU)
+            return self.out_of_line(op.lower(), body)
+        base, form = op.rsplit("_", 1)
+        if base in ("ADD", "SUB", "MUL"):
+            if form == "RR":
+                self.read_a(VT)
+                self.idx_idx(S_W1)
+                ins = {"ADD": "v_add_f32", "SUB": "v_subrev_f32", "MUL": "v_mul_f32"}[base]
+                for j in Z:
+                    a(f"\t{ins} {VT[j]}, {F(j)}, {VT[j]}")       # subrev: D = S1 - S0 = a - b
+            else:
+                # a (register, relative SRC1) with the immediate as SRC0
+                ins = {("ADD", "RI"): "v_add_f32", ("MUL", "RI"): "v_mul_f32", ("SUB", "RI"): "v_subrev_f32",
+                       ("SUB", "IR"): "v_sub_f32"}[(base, form)]
+                self.idx_on(S_A, SRC1)
+                for j in Z:
+                    a(f"\t{ins} {VT[j]}, {S_W1}, {F(j)}")
+            return self.write_out(VT)
+        # two plain operands A, B in VT / VU, result in VW
+        def body(base=base, form=form):
+            self.read_a(VT)
+            if form == "RR":
+                self.read_b(VU)
+            self.idx_off()
+            if form != "RR":
+                self.imm_b(VU)
+            A, B = (VT, VU) if form != "IR" else (VU, VT)
+            if base == "DIV":
+                self.f_div(A, B, VW)
+            elif base == "COMPARE":
+                self.f_compare(A, B, VW)
+            elif base in ("MIN", "MAX"):
+                self.f_minmax(base == "MIN", A, B, VW)
+            else:
+                self.f_andor(base == "AND", A, B, VW)
+            self.write_out(VW)
+        if base in ("MIN", "MAX", "AND", "OR") and zb * (8 if base in ("MIN", "MAX") else 5) + 12 <= 30:
+            return body()
+        return self.out_of_line(op.lower(), body)
+
+    def h_output(self):
+        a = self.a
+        if self.kind == "columns":
+            self.read_a(VRES)
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
+        self.out_of_line("output", self.h_output_bulk)
+
+    def h_output_bulk(self):
+        a = self.a
+        self.read_a(VT)
+        self.idx_off()
+        # out + (slot * n) * 4, 64-bit
+        a(f"""
+	s_mul_hi_u32 s77, {S_W1}, {S_N}
+	s_mul_i32 s76, {S_W1}, {S_N}
+	s_lshl_b64 {S_PC}, s[76:77], 2
+	s_add_u32 s86, s86, s32
+	s_addc_u32 s87, s87, s33
+	s_mov_b64 {S_SAVE}, exec""")
+        for j in range(self.zb):
+            a(f"""
+	s_mov_b64 exec, {S_ACT[j]}
+	global_store_dword {VOFF[j]}, {VT[j]}, {S_PC}""")
+        a(f"""
+	s_mov_b64 exec, {S_SAVE}
+	s_branch {self.next}""")
+
+    def h_input(self):
+        a = self.a
+        if self.kind == "bulk":
+            a(f"""
+	s_mul_hi_u32 s77, {S_W1}, {S_N}
+	s_mul_i32 s76, {S_W1}, {S_N}
+	s_lshl_b64 {S_PC}, s[76:77], 2
+	s_add_u32 s86, s86, s30
+	s_addc_u32 s87, s87, s31""")
+            for j in range(self.zb):
+                a(f"\tglobal_load_dword {VT[j]}, {VOFF[j]}, {S_PC}")
+            a("\ts_waitcnt vmcnt(0)")
+            return self.write_out(VT)
+        # columns: the slot is bound to x, y, z or a constant (FhRender::in_kind / in_value)
+        lx, ly, lz, done = (a.label("in_x"), a.label("in_y"), a.label("in_z"), a.label("in_done"))
+        a(f"""
+	s_lshl_b32 {S_T0}, {S_W1}, 2
+	s_add_u32 s86, s4, {S_T0}
+	s_addc_u32 s87, s5, 0
+	s_load_dword {S_T0}, {S_PC}, {self.off['P.in_kind']}
+	s_load_dword {S_T1}, {S_PC}, {self.off['P.in_value']}
+	s_waitcnt lgkmcnt(0)
+	s_cmp_eq_u32 {S_T0}, 0
+	s_cbranch_scc1 {lx}
+	s_cmp_eq_u32 {S_T0}, 1
+	s_cbranch_scc1 {ly}
+	s_cmp_eq_u32 {S_T0}, 2
+	s_cbranch_scc1 {lz}""")
+        self.idx_on(S_OUT, DST)
+        for j in range(self.zb):
+            a(f"\tv_mov_b32 {self.F(j)}, {S_T1}")
+        a(f"\ts_branch {done}")
+        for lab, src in ((lx, VX), (ly, VY), (lz, VZ)):
+            a(f"{lab}:")
+            self.idx_on(S_OUT, DST)
+            for j in range(self.zb):
+                a(f"\tv_mov_b32 {self.F(j)}, {src[j]}")
+            if lab != lz:
+                a(f"\ts_branch {done}")
+        a(f"{done}:")
+        self.idx_off()
+        a(f"\ts_branch {self.next}")
+
+    # -- the interpreter -------------------------------------------------------------------
+    def emit(self):
+        a, n = self.a, self.name
+        qa, qb = S_QA, S_QB
+        a(f"""
+; ---- interpreter {n}: in {S_TAPE} = first op, {S_LEN} = ops; returns to {S_RET} -----------
+.L{n}_run:
+	s_load_dwordx8 s[{qa}:{qa + 7}], {S_TAPE}, 0x0
+	s_load_dwordx8 s[{qb}:{qb + 7}], {S_TAPE}, 0x20
+	s_add_u32 s72, s44, 0x40
+	s_addc_u32 s73, s45, 0
+	s_mov_b32 {S_BATCH}, 4
+	s_waitcnt lgkmcnt(0)
+{self.next}:
+	s_sub_u32 {S_LEN}, {S_LEN}, 1
+	s_cbranch_scc1 .L{n}_done
+	s_sub_u32 {S_BATCH}, {S_BATCH}, 1
+	s_cbranch_scc1 .L{n}_refill
+.L{n}_decode:
+	s_mov_b64 {S_CUR}, s[{qa}:{qa + 1}]
+	s_mov_b64 s[{qa}:{qa + 1}], s[{qa + 2}:{qa + 3}]
+	s_mov_b64 s[{qa + 2}:{qa + 3}], s[{qa + 4}:{qa + 5}]
+	s_mov_b64 s[{qa + 4}:{qa + 5}], s[{qa + 6}:{qa + 7}]
+	s_lshl_b32 {S_T0}, {S_W0}, {HSTRIDE_LOG2}
+	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << HSTRIDE_LOG2)}
+	s_add_u32 s86, s42, {S_T0}
+	s_addc_u32 s87, s43, 0
+	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
+	s_lshr_b32 {S_A}, {S_W0}, 20
+	s_setpc_b64 {S_PC}
+.L{n}_refill:
+	s_waitcnt lgkmcnt(0)
+	s_mov_b64 s[{qa}:{qa + 1}], s[{qb}:{qb + 1}]
+	s_mov_b64 s[{qa + 2}:{qa + 3}], s[{qb + 2}:{qb + 3}]
+	s_mov_b64 s[{qa + 4}:{qa + 5}], s[{qb + 4}:{qb + 5}]
+	s_mov_b64 s[{qa + 6}:{qa + 7}], s[{qb + 6}:{qb + 7}]
+	s_load_dwordx8 s[{qb}:{qb + 7}], {S_FETCH}, 0x0
+	s_add_u32 s72, s72, 0x20
+	s_addc_u32 s73, s73, 0
+	s_mov_b32 {S_BATCH}, 3
+	s_branch .L{n}_decode
+.L{n}_done:
+	s_waitcnt lgkmcnt(0)
+	s_setpc_b64 {S_RET}
+	.p2align {HSTRIDE_LOG2}
+.L{n}_handlers:""")
+        for i, op in enumerate(OPS):
+            a(f"\t.p2align {HSTRIDE_LOG2}")
+            a(f".L{n}_h{i}:  ; {op}")
+            start = len(a.lines)
+            base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
+            if base in UNSUPPORTED:
+                a(f"\ts_branch {self.next}")   # never emitted for tapes routed here (host checks)
+            else:
+                self.handler(op)
+            # size check is done by the assembler: the next .p2align would silently grow the
+            # slot, so emit an explicit assertion on the slot size
+            a(f"\t.if (. - .L{n}_h{i}) > {1 << HSTRIDE_LOG2}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
+        a(f"\t.p2align {HSTRIDE_LOG2}")
+        for lab, fn in self.ool:
+            a(f"{lab}:")
+            fn()
+
+
+def call_interp(a, it):
+    """Call the interpreter `it` as a subroutine."""
+    ret = a.label("ret")
+    here = a.label("pc")
+    a(f"""
+	s_getpc_b64 {S_RET}
+{here}:
+	s_add_u32 s74, s74, {ret} - {here}
+	s_addc_u32 s75, s75, 0
+	s_branch .L{it.name}_run
+{ret}:""")
+
+
+def kernel_header(a, name, kernarg, next_vgpr, lds=0, wg_id=False):
+    a(f"""
+	.text
+	.protected {name}
+	.globl {name}
+	.p2align 8
+	.type {name},@function
+{name}:""")
+
+
+def kernel_footer(a, name, kernarg, next_vgpr, next_sgpr, wg_id):
+    a(f"""
+	s_endpgm
+.L{name}_end:
+	.size {name}, .L{name}_end - {name}
+	.rodata
+	.p2align 6
+	.amdhsa_kernel {name}
+		.amdhsa_group_segment_fixed_size 0
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_kernarg_size {kernarg}
+		.amdhsa_user_sgpr_count 2
+		.amdhsa_user_sgpr_kernarg_segment_ptr 1
+		.amdhsa_system_sgpr_workgroup_id_x {1 if wg_id else 0}
+		.amdhsa_system_sgpr_workgroup_id_y 0
+		.amdhsa_system_sgpr_workgroup_id_z 0
+		.amdhsa_system_vgpr_workitem_id 0
+		.amdhsa_next_free_vgpr {next_vgpr}
+		.amdhsa_next_free_sgpr {next_sgpr}
+		.amdhsa_accum_offset {(next_vgpr + 3) // 4 * 4}
+		.amdhsa_reserve_vcc 1
+		.amdhsa_float_round_mode_32 0
+		.amdhsa_float_round_mode_16_64 0
+		.amdhsa_float_denorm_mode_32 3
+		.amdhsa_float_denorm_mode_16_64 3
+		.amdhsa_dx10_clamp 1
+		.amdhsa_ieee_mode 1
+	.end_amdhsa_kernel
+	.text""")
+
+
+def common_consts(a):
+    a(f"""
+	v_mov_b32 {V_QNAN}, 0x7fc00000
+	v_mov_b32 {V_SQRTC}, 0xf800000
+	s_mov_b32 {S_SIGN}, 0x80000000
+	s_mov_b32 {S_ABSM}, 0x7fffffff""")
+
+
+def handler_base(a, it):
+    here = a.label("pc")
+    a(f"""
+	s_getpc_b64 {S_HBASE}
+{here}:
+	s_add_u32 s42, s42, .L{it.name}_handlers - {here}
+	s_addc_u32 s43, s43, 0""")
+
+
+def gen_columns(a, nr, zb, cls, off):
+    name = f"fh_columns_{nr}x{zb}"
+    it = Interp(a, name, nr, zb, "columns", off)
+    o = off
+    kernel_header(a, name, 8, FILE + nr * zb)
+    m = S_MAT
+    a(f"""
+	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0""")
+    common_consts(a)
+    a(f"""
+	s_waitcnt lgkmcnt(0)
+	s_load_dwordx16 s[{m}:{m + 15}], {S_STATE}, {o['P.mat']}
+	s_load_dwordx2 s[24:25], {S_STATE}, {o['P.width']}
+	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.tiles']}
+	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
+	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
+	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
+	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
+	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list'] + 8 * cls}
+	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count'] + 4 * cls}""")
+    handler_base(a, it)
+    a(f"""
+	v_and_b32 {V_LX}, 7, {V_LANE}
+	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
+	s_waitcnt lgkmcnt(0)
+	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
+	s_add_u32 {S_FW}, {S_WIDTH}, 7
+	s_lshr_b32 {S_FW}, {S_FW}, 3
+.L{name}_outer:
+	; ---- next footprint: wi = atomicAdd(&fp_cursor[cls], 1) ------------------------------
+	v_cmp_eq_u32 vcc, 0, {V_LANE}
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	v_mov_b32 {V_S0}, 1
+	v_mov_b32 {V_S1}, 0
+	global_atomic_add {V_S2}, {V_S1}, {V_S0}, {S_STATE} offset:{o['fp_cursor'] + 4 * cls} sc0
+	s_waitcnt vmcnt(0)
+	s_mov_b64 exec, {S_SAVE}
+	s_nop 0
+	v_readfirstlane_b32 {S_WI}, {V_S2}
+	s_nop 3
+	s_cmp_ge_u32 {S_WI}, {S_NFP}
+	s_cbranch_scc1 .L{name}_exit
+	s_lshl_b32 {S_T0}, {S_WI}, 2
+	s_add_u32 s86, s38, {S_T0}
+	s_addc_u32 s87, s39, 0
+	s_load_dword {S_T0}, {S_PC}, 0x0
+	s_waitcnt lgkmcnt(0)
+	s_and_b32 {S_FX}, {S_T0}, 0xffff
+	s_lshr_b32 {S_FY}, {S_T0}, 16
+	; column of leaf ids: leaf_table + ((fy * fw + fx) * layers) * 4, one layer per lane
+	s_mul_i32 {S_T0}, {S_FY}, {S_FW}
+	s_add_u32 {S_T0}, {S_T0}, {S_FX}
+	s_mul_i32 {S_T0}, {S_T0}, {S_LAYERS}
+	s_lshl_b32 {S_T0}, {S_T0}, 2
+	s_add_u32 s86, s34, {S_T0}
+	s_addc_u32 s87, s35, 0
+	v_lshlrev_b32 {V_S0}, 2, {V_LANE}
+	v_mov_b32 {V_IDS}, 0
+	v_cmp_gt_u32 vcc, {S_LAYERS}, {V_LANE}
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	global_load_dword {V_IDS}, {V_S0}, {S_PC}
+	s_mov_b64 exec, {S_SAVE}
+	; pixel of this lane
+	s_lshl_b32 {S_FX}, {S_FX}, 3
+	s_lshl_b32 {S_FY}, {S_FY}, 3
+	v_add_u32 {V_S0}, {S_FX}, {V_LX}
+	v_add_u32 {V_S1}, {S_FY}, {V_LY}
+	v_cvt_f32_u32 {V_PXF}, {V_S0}
+	v_cvt_f32_u32 {V_PYF}, {V_S1}
+	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_S0}
+	v_cmp_gt_u32_e64 {S_M[1]}, {S_HEIGHT}, {V_S1}
+	v_mul_lo_u32 {V_S2}, {V_S1}, {S_WIDTH}
+	v_add_u32 {V_S2}, {V_S2}, {V_S0}
+	v_mov_b32 {V_S3}, 0
+	v_lshlrev_b64 {V_PIX}, 3, v[{V_S2[1:]}:{V_S3[1:]}]
+	v_mov_b32 {V_S3}, s37
+	v_add_co_u32 v2, vcc, s36, v2
+	v_addc_co_u32 v3, vcc, {V_S3}, v3, vcc
+	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
+	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
+	v_add_f32 {V_AX}, {V_AX}, {V_S0}
+	v_mul_f32 {V_AY}, s{m + 4}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 5}, {V_PYF}
+	v_add_f32 {V_AY}, {V_AY}, {V_S0}
+	v_mul_f32 {V_AZ}, s{m + 8}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
+	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
+	; depth so far (pixels outside the image never become pending)
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	v_mov_b32 {V_DEPTH}, -1
+	v_mov_b32 {V_HIT}, 0
+	s_mov_b64 {S_SAVE}, exec
+	s_mov_b64 exec, {S_M[0]}
+	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
+	s_mov_b64 exec, {S_SAVE}
+	s_waitcnt vmcnt(0)
+	v_cmp_ne_u32 vcc, 0, {V_IDS}
+	s_nop 3
+	s_mov_b64 {S_LAYMASK}, vcc
+.L{name}_layer:
+	s_cmp_eq_u64 {S_LAYMASK}, 0
+	s_cbranch_scc1 .L{name}_column_done
+	s_flbit_i32_b64 {S_T0}, {S_LAYMASK}
+	s_sub_u32 {S_ZL}, 63, {S_T0}
+	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
+	s_nop 0
+	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
+	s_nop 3
+	s_sub_u32 {S_T0}, {S_ID}, 1
+	s_mul_i32 {S_T0}, {S_T0}, 24
+	s_add_u32 s86, s32, {S_T0}
+	s_addc_u32 s87, s33, 0
+	s_load_dwordx2 {S_TBASE}, {S_PC}, 0x0
+	s_load_dword {S_LZ}, {S_PC}, 0x14
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 {S_LEN0}, s85
+	s_mov_b32 s85, 0
+	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
+	s_add_u32 s84, s84, s30
+	s_addc_u32 s85, s85, s31
+	; pending = depth < lz + 8  (voxel.rs:377-381); nothing pending: the rest is occluded too
+	s_add_u32 {S_T0}, {S_LZ}, 8
+	v_cmp_gt_u32 vcc, {S_T0}, {V_DEPTH}
+	v_mov_b32 {V_IDV}, {S_ID}
+	s_nop 3
+	s_mov_b64 {S_PEND}, vcc
+	s_cmp_eq_u64 {S_PEND}, 0
+	s_cbranch_scc1 .L{name}_column_done
+	s_mov_b32 {S_K}, 7
+.L{name}_chunk:""")
+    for j in range(zb):
+        a(f"""
+	s_add_u32 {S_T0}, {S_LZ}, {S_K}
+	s_sub_u32 {S_T0}, {S_T0}, {j}
+	v_cvt_f32_u32 {V_S0}, {S_T0}
+	v_mul_f32 {V_S1}, s{m + 2}, {V_S0}
+	v_add_f32 {V_S1}, {V_AX}, {V_S1}
+	v_add_f32 {VX[j]}, s{m + 3}, {V_S1}
+	v_mul_f32 {V_S1}, s{m + 6}, {V_S0}
+	v_add_f32 {V_S1}, {V_AY}, {V_S1}
+	v_add_f32 {VY[j]}, s{m + 7}, {V_S1}
+	v_mul_f32 {V_S1}, s{m + 10}, {V_S0}
+	v_add_f32 {V_S1}, {V_AZ}, {V_S1}
+	v_add_f32 {VZ[j]}, s{m + 11}, {V_S1}
+	v_mov_b32 {VRES[j]}, 0""")
+    a(f"""
+	s_mov_b64 {S_TAPE}, {S_TBASE}
+	s_mov_b32 {S_LEN}, {S_LEN0}""")
+    call_interp(a, it)
+    for j in range(zb):
+        # first voxel inside, front to back: depth = lz + (k - j) + 1
+        a(f"""
+	v_cmp_gt_f32 vcc, 0, {VRES[j]}
+	s_add_u32 {S_T0}, {S_LZ}, {S_K}
+	s_add_u32 {S_T0}, {S_T0}, {1 - j}
+	v_mov_b32 {V_S0}, {S_T0}
+	s_and_b64 {S_M[0]}, vcc, {S_PEND}
+	s_andn2_b64 {S_PEND}, {S_PEND}, {S_M[0]}
+	v_cndmask_b32_e64 {V_DEPTH}, {V_DEPTH}, {V_S0}, {S_M[0]}
+	v_cndmask_b32_e64 {V_HIT}, {V_HIT}, {V_IDV}, {S_M[0]}""")
+    a(f"""
+	s_cmp_eq_u64 {S_PEND}, 0
+	s_cbranch_scc1 .L{name}_layer
+	s_sub_u32 {S_K}, {S_K}, {zb}
+	s_cbranch_scc0 .L{name}_chunk
+	s_branch .L{name}_layer
+.L{name}_column_done:
+	v_cmp_ne_u32 vcc, 0, {V_HIT}
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	global_store_dwordx2 {V_PIX}, v[4:5], off
+	s_mov_b64 exec, {S_SAVE}
+	s_nop 1
+	s_branch .L{name}_outer
+.L{name}_exit:""")
+    kernel_footer(a, name, 8, FILE + nr * zb, 100, False)
+    it.emit()
+    return name
+
+
+def gen_bulk(a, nr, zb, off):
+    """fh_float_eval: kernarg = {tape*, vars*, out*, len u32, n u32}; vars / out are [slot][n]."""
+    name = f"fh_float_eval_{nr}x{zb}"
+    it = Interp(a, name, nr, zb, "bulk", off)
+    kernel_header(a, name, 32, FILE + nr * zb)
+    a(f"""
+	s_load_dwordx2 {S_TAPE}, {S_KERNARG}, 0x0
+	s_load_dwordx2 {S_VARS}, {S_KERNARG}, 0x8
+	s_load_dwordx2 {S_OUTP}, {S_KERNARG}, 0x10
+	s_load_dwordx2 s[46:47], {S_KERNARG}, 0x18""")
+    common_consts(a)
+    handler_base(a, it)
+    a(f"""
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 {S_N}, s47
+	s_mul_i32 {S_T0}, {S_WG}, {64 * zb}""")
+    for j in range(zb):
+        # sample index of slot j; inactive lanes read sample 0 and store nothing
+        a(f"""
+	v_add_u32 {VOFF[j]}, {S_T0}, {V_LANE}
+	v_add_u32 {VOFF[j]}, {64 * j}, {VOFF[j]}
+	v_cmp_gt_u32_e64 {S_ACT[j]}, {S_N}, {VOFF[j]}
+	s_nop 1
+	v_cndmask_b32_e64 {VOFF[j]}, 0, {VOFF[j]}, {S_ACT[j]}
+	v_lshlrev_b32 {VOFF[j]}, 2, {VOFF[j]}""")
+    call_interp(a, it)
+    kernel_footer(a, name, 32, FILE + nr * zb, 100, True)
+    it.emit()
+    return name
+
+
+def metadata(a, kernels):
+    a("\t.amdgpu_metadata\n---\namdhsa.kernels:")
+    for name, kernarg, vgprs, args in kernels:
+        a("  - .agpr_count:     0\n    .args:")
+        offp = 0
+        for size, kind in args:
+            if kind == "global_buffer":
+                a(f"      - .address_space:  global\n        .offset:         {offp}\n        .size:           {size}\n        .value_kind:     global_buffer")
+            else:
+                a(f"      - .offset:         {offp}\n        .size:           {size}\n        .value_kind:     by_value")
+            offp += size
+        a(f"""    .group_segment_fixed_size: 0
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {kernarg}
+    .max_flat_workgroup_size: 64
+    .name:           {name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     106
+    .sgpr_spill_count: 0
+    .symbol:         {name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     {vgprs}
+    .vgpr_spill_count: 0
+    .wavefront_size: 64""")
+    a("amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\t.end_amdgpu_metadata")
+
+
+def main():
+    off = json.load(open(sys.argv[1]))
+    a = Asm()
+    a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
+    ks = []
+    for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
+        n = gen_columns(a, nr, zb, cls, off)
+        ks.append((n, 8, FILE + nr * zb, [(8, "global_buffer")]))
+        n = gen_bulk(a, nr, zb, off)
+        ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
+    metadata(a, ks)
+    open(sys.argv[2], "w").write(a.text())
+
+
+if __name__ == "__main__":
+    main()

@@ -305,6 +305,24 @@ FH_DEV bool tape_is_small(const FhTapeRef& t) { return t.n_regs <= SMALL_REGS &&
 // them, fill / discard the decided ones and emit pruned tapes + next-level work for the
 // ambiguous ones.  Persistent workgroups pull parents from queue[level]; BIG selects the
 // half of the queue whose tapes need the large LDS layout.
+// Diagnostics: busy time of each wave (100 MHz wall clock) and units of work, per kernel kind
+// k: stat[4k] = sum of busy ticks, [4k+1] = max, [4k+2] = waves that found work, [4k+3] = work units
+struct WaveProbe {
+    FhRenderState* S;
+    int k;
+    uint64_t t0;
+    uint32_t units = 0;
+    __device__ WaveProbe(FhRenderState* S_, int k_) : S(S_), k(k_), t0(wall_clock64()) {}
+    __device__ void done(int lane) {
+        if (lane != 0 || units == 0) return;
+        const unsigned long long dt = wall_clock64() - t0;
+        atomicAdd(&S->stat[4 * k], dt);
+        atomicMax(&S->stat[4 * k + 1], dt);
+        atomicAdd(&S->stat[4 * k + 2], 1ull);
+        atomicAdd(&S->stat[4 * k + 3], (unsigned long long)units);
+    }
+};
+
 template <bool IS3D, bool FULL, bool BIG>
 __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,12 +341,14 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     Mat4 mat;
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
+    WaveProbe probe(S, IS3D ? level : 7);
 
     for (;;) {
         uint32_t gi = 0;
         if (lane == 0) gi = atomicAdd(BIG ? &S->cursor_big[level] : &S->cursor[level], 1u);
         gi = uni(gi);
         if (gi >= (BIG ? S->count_big[level] : S->count[level])) break;
+        probe.units++;
         // small groups fill the queue from the front, big ones from the back
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][BIG ? S->qcap[level] - 1 - gi : gi];
         const ctape_t tape = (ctape_t)(S->arena + g.tape.off);
@@ -497,6 +517,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
     }
+    probe.done(lane);
 }
 
 // ======================================================================================
@@ -656,7 +677,7 @@ __global__ void k_classify3d(FhRenderState* S) {
     }
     if (!any) return;
     const int cls = mx <= 16 ? 0 : (mx <= 32 ? 1 : 2);
-    S->fp_list[cls][atomicAdd(&S->fp_count[cls], 1u)] = fi;
+    S->fp_list[cls][atomicAdd(&S->fp_count[cls], 1u)] = ((fi / fw) << 16) | (fi % fw);  // fy, fx
 }
 
 // 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
@@ -674,14 +695,16 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     const uint32_t n_fp = S->fp_count[CLS];
+    WaveProbe probe(S, 5 + (CLS ? 1 : 0));
     for (;;) {
         uint32_t wi = 0;
         if (lane == 0) wi = atomicAdd(&S->fp_cursor[CLS], 1u);
         wi = uni(wi);
         if (wi >= n_fp) break;
-        const uint32_t fi = uni(S->fp_list[CLS][wi]);
-        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)fi * layers);
-        const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
+        const uint32_t fxy = uni(S->fp_list[CLS][wi]);
+        const uint32_t fx = fxy & 0xFFFFu, fy = fxy >> 16;
+        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)(fy * fw + fx) * layers);
+        const uint32_t px = fx * T + (lane % T), py = fy * T + (lane / T);
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
         uint32_t depth = inimg ? (uint32_t)(S->zbuf[pix] >> 32) : 0xFFFFFFFFu;
@@ -695,6 +718,7 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
             if (ballot(pending) == 0) break;  // everything behind is occluded as well
             const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
             const uint32_t len = lf.tape.len;
+            probe.units++;
             for (int k = (int)T - 1; k >= 0; k -= ZB) {
                 float x[ZB], y[ZB], z[ZB], res[ZB];
                 FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
@@ -712,6 +736,7 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
         }
         if (hit_leaf) S->zbuf[pix] = ((uint64_t)depth << 32) | hit_leaf;
     }
+    probe.done(lane);
 }
 
 // Normals for the hits of this slab: gradient of the winning leaf's tape at the voxel one
@@ -741,7 +766,7 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
         else if (wi < S->fp_count[0]) fi = S->fp_list[0][wi];
         else fi = S->fp_list[1][wi - S->fp_count[0]];
         fi = uni(fi);
-        const uint32_t px = (fi % fw) * T + (lane % T), py = (fi / fw) * T + (lane / T);
+        const uint32_t px = (fi & 0xFFFFu) * T + (lane % T), py = (fi >> 16) * T + (lane / T);
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
         const uint64_t zb = inimg ? S->zbuf[pix] : 0;

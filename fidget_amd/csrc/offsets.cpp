@@ -1,0 +1,17 @@
+// Prints the byte offsets of the FhRenderState fields used by the assembly kernels
+// (gen_interp.py); host and device layouts are identical (plain C, 64-bit pointers).
+#include <cstddef>
+#include <cstdio>
+
+#include "render_state.h"
+
+int main() {
+#define O(name, expr) printf("%s\"%s\": %zu", first ? "{" : ", ", name, (size_t)offsetof(FhRenderState, expr)), first = false
+    bool first = true;
+    O("P.mat", P.mat); O("P.width", P.width); O("P.height", P.height); O("P.tiles", P.tiles);
+    O("P.in_kind", P.in_kind); O("P.in_value", P.in_value);
+    O("arena", arena); O("leaves", leaves); O("leaf_table", leaf_table); O("zbuf", zbuf);
+    O("fp_list", fp_list); O("fp_count", fp_count); O("fp_cursor", fp_cursor); O("stat", stat);
+    printf("}\n");
+    return 0;
+}

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Render one frame and print the per-kernel-kind wave busy statistics (GPU box)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import fidget_amd as F
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+model = sys.argv[2] if len(sys.argv) > 2 else "prospero.vm"
+hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+shape = F.Shape.from_vm(os.path.join(ROOT, "models", model), hip=hip)
+out = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+for _ in range(2):
+    F.render3d(shape, n, out=out)
+hip.sync()
+for k, v in hip.wave_stats().items():
+    v["busy_us_mean"] = v["busy_us_sum"] / max(v["waves"], 1)
+    print(k, json.dumps(v))
+print(hip.counters())
