@@ -58,7 +58,7 @@ struct fhip_ctx {
     std::atomic<int> cancelled{0};
     DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue;
     DevBuf queue[FH_MAX_LEVELS];
-    size_t arena_bytes = (size_t)1 << 30;
+    size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     FhRenderState last_state;
@@ -108,8 +108,10 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (const char* mb = getenv("FHIP_ARENA_MB")) c->arena_bytes = (size_t)atol(mb) << 20;
     // allow the full 160 KiB of LDS for the interpreters' register files
     const void* fns[] = {(const void*)k_eval_f32<false>, (const void*)k_eval_interval<false>, (const void*)k_eval_grad<false>,
-                         (const void*)k_tiles<false, false, true>, (const void*)k_tiles<false, true, true>,
-                         (const void*)k_tiles<true, false, true>, (const void*)k_tiles<true, true, true>,
+                         (const void*)k_tiles<false, false, true, 16>, (const void*)k_tiles<false, true, true, 16>,
+                         (const void*)k_tiles<true, false, true, 16>, (const void*)k_tiles<true, true, true, 16>,
+                         (const void*)k_tiles<false, false, true, 64>, (const void*)k_tiles<false, true, true, 64>,
+                         (const void*)k_tiles<true, false, true, 64>, (const void*)k_tiles<true, true, true, 64>,
                          (const void*)k_pixels2d<0, false>, (const void*)k_pixels2d<0, true>,
                          (const void*)k_columns3d<2, 0, 1, false>, (const void*)k_columns3d<2, 0, 1, true>,
                          (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
@@ -412,6 +414,11 @@ static void mat_product(const float* a, const float* b, int d, float* out) {
 // ---- renders ---------------------------------------------------------------------------
 static const uint32_t VM_TILES_2D[] = {128, 32, 8};        // fidget-core/src/vm/mod.rs:255-257
 static const uint32_t VM_TILES_3D[] = {128, 64, 32, 16, 8};  // fidget-core/src/vm/mod.rs:251-253
+// RenderHints of the HIP shape (the reference lets every shape type pick its own, shape.rs RenderHints):
+// a fan-out of 4^3 = 64 children fills a wavefront
+// (128 -> 32 -> 8).  The root tile stays the one the reference's VmShape hints give for the image
+// size, so that exactly the same voxels are covered (a root tile overhanging the image in z is
+// evaluated there by the reference too).
 
 struct RenderSetup {
     FhRenderState S;
@@ -419,6 +426,7 @@ struct RenderSetup {
     uint32_t n_slabs = 1;
     size_t lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
+    uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
     bool asm_points = false;  // leaf stage on the assembly interpreters
 };
@@ -450,6 +458,14 @@ static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint3
     return std::vector<uint32_t>(tiles + i, tiles + n);
 }
 
+static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size) {
+    std::vector<uint32_t> v = trim_tiles(VM_TILES_3D, 5, max_size);
+    if (getenv("FHIP_VM_TILES")) return v;  // diagnostics: the reference's own subdivision
+    std::vector<uint32_t> out{v[0]};
+    for (uint32_t t = v[0]; t > 8;) { t = std::max<uint32_t>(t / 4, 8); out.push_back(t); }
+    return out;
+}
+
 static bool tape_is_full(const fh::HostTape& t) {
     for (uint64_t w : t.ops) {
         const uint32_t op = FH_W_OP((uint32_t)w);
@@ -460,7 +476,7 @@ static bool tape_is_full(const fh::HostTape& t) {
     return false;
 }
 
-static size_t tiles_lds(uint32_t regs, uint32_t choices) {
+static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {
     size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL;
     return (b + 15) & ~(size_t)15;
 }
@@ -473,14 +489,17 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     if (t.n_outputs != 1) return fail(ctx, FHIP_ERR_BAD_TAPE, "shape tapes have exactly one output");
     if (ts.empty() || ts.size() > FH_MAX_LEVELS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "1..8 tile levels supported");
     P.n_levels = (uint32_t)ts.size();
+    uint32_t fanout = 1;
     for (size_t i = 0; i < ts.size(); i++) {
         P.tiles[i] = ts[i];
         if (i) {
             if (ts[i - 1] <= ts[i] || ts[i - 1] % ts[i]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad tile size list");
             const uint32_t n = ts[i - 1] / ts[i];
-            if ((is3d ? n * n * n : n * n) > TL) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 16 children");
+            fanout = std::max(fanout, is3d ? n * n * n : n * n);
         }
     }
+    if (fanout > 64) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 64 children");
+    const uint32_t TL = R.tl = fanout > 16 ? 64 : 16;
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
     if (t.n_regs > 256) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 256 registers");
     P.max_regs = std::max<uint32_t>(t.n_regs, 1);
@@ -494,8 +513,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                    P.mat[15] == 1.0f;
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
-    R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices);
-    R.lds_tiles_small = tiles_lds(SMALL_REGS, SMALL_CHOICES);
+    R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
+    R.lds_tiles_small = tiles_lds(SMALL_REGS, SMALL_CHOICES, TL);
     R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
     R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
     R.lds_normals_small = (size_t)32 * WAVE * 16;
@@ -617,8 +636,11 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
 
 // One level of the tile hierarchy: the small-LDS variant for the bulk of the groups and the
 // root-sized variant for the few large tapes (both always launched; empty queues exit at once).
-#define FH_LAUNCH_TILES(IS3D, FULL, BIG, grid, lds) \
-    hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level)
+#define FH_LAUNCH_TILES(IS3D, FULL, BIG, grid, lds)                                                                  \
+    do {                                                                                                            \
+        if (R.tl == 64) hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 64>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level); \
+        else hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
+    } while (0)
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
     const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
     launch(ctx, FHIP_K_TILES, [&] {
@@ -698,7 +720,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     fhip_screen_to_world(size, 3, s2w);
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : trim_tiles(VM_TILES_3D, 5, std::max(cfg->width, cfg->height));
+                                                     : hip_tiles_3d(std::max(cfg->width, cfg->height));
     st = prepare(ctx, tape, true, ts, shard, n_shards, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
@@ -789,10 +811,10 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]) {
 }
 
 // Diagnostics: per-kernel-kind wave busy statistics of the last render (see WaveProbe)
-fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[32]) {
+fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
     fhip_status st = finish_render(ctx);
     if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
-    for (int i = 0; i < 32; i++) out[i] = ctx->last_state.stat[i];
+    for (int i = 0; i < 64; i++) out[i] = ctx->last_state.stat[i];
     return FHIP_OK;
 }
 

@@ -214,7 +214,7 @@ struct Pool {
     }
 };
 
-#define TL 16  // lane stride of the tile kernel (<= 16 sibling tiles per wave)
+// TL = lane stride of the tile kernel: sibling tiles per wave (16 or 64, template parameter)
 #define DEAD 0xFFu
 
 // Reverse sweep over the parent tape for one child tile (one lane):
@@ -224,7 +224,7 @@ struct Pool {
 // ops whose value is never used are dropped, a min/max/and/or whose trace says
 // Left/Right is replaced by its surviving operand (aliased when that operand is
 // not otherwise live yet, copied when it is).
-template <bool EMIT>
+template <bool EMIT, int TL>
 FH_DEV void prune_sweep(ctape_t tape, uint32_t len, uint32_t n_choices, const uint32_t* chbits, uint8_t* map,
                         int lane16, bool act, uint64_t* dst /*one past the last op*/, uint32_t& out_len,
                         uint32_t& out_regs, uint32_t& out_choices) {
@@ -323,7 +323,7 @@ struct WaveProbe {
     }
 };
 
-template <bool IS3D, bool FULL, bool BIG>
+template <bool IS3D, bool FULL, bool BIG, int TL>
 __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         }
         Regs<IV, TL> R{regs, lane16};
         IV result = iv_nan();
+        const uint64_t t_fwd0 = wall_clock64();
         uint32_t ci = 0, cw = 0;
         bool any_decided = false;
         if (lane < TL) {
@@ -416,6 +417,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             if (ci & 15) chbits[(ci >> 4) * TL + lane16] = cw;
         }
 
+        if (IS3D && lane == 0) { atomicAdd(&S->stat[32 + level], (unsigned long long)(wall_clock64() - t_fwd0)); atomicAdd(&S->stat[48 + level], (unsigned long long)len); }
+        const uint64_t t_prune0 = wall_clock64();
         // ---- classify (voxel.rs:310-320, pixel.rs:345-368) -----------------------------
         const bool full = act && (IS3D || !P.pixel_perfect) && result.hi < 0.0f;
         const bool empty = act && (IS3D || !P.pixel_perfect) && !full && result.lo > 0.0f;
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 if (lane < TL) {
                     for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
                     uint64_t* dst = S->arena + base + (rank + 1) * len;
-                    prune_sweep<true>(tape, len, n_choices, chbits, map, lane16, prune, dst, clen, cregs, cch);
+                    prune_sweep<true, TL>(tape, len, n_choices, chbits, map, lane16, prune, dst, clen, cregs, cch);
                 }
                 if (prune) {
                     child.off = base + (rank + 1) * len - clen; child.len = clen;
@@ -475,6 +478,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 atomicAdd(&S->arena_overflow, 1u);  // children fall back to the parent tape
             }
         }
+
+        if (IS3D && lane == 0) atomicAdd(&S->stat[40 + level], (unsigned long long)(wall_clock64() - t_prune0));
 
         // ---- hand ambiguous children to the next stage ------------------------------------
         const bool small = tape_is_small(child);

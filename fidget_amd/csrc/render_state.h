@@ -77,5 +77,5 @@ struct FhRenderState {
     float* normals;         // 3D: 3 floats per pixel
     float* image2d;         // 2D: RawDistancePixel bits
     // statistics (optional, for bench / roofline accounting)
-    unsigned long long stat[32];
+    unsigned long long stat[64];
 };

@@ -142,8 +142,9 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
 /* ---- diagnostics (not part of the reference surface) --------------------------------- */
 /* Wave busy-time statistics of the last render, 4 words per kernel kind (3D tile levels 0-4,
  * columns class 0, columns classes 1-2, 2D tiles): sum and max of per-wave busy ticks
- * (100 MHz), waves that found work, work units. */
-fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[32]);
+ * (100 MHz), waves that found work, work units; then per 3D tile level: [32+l] ticks in the
+ * forward interval pass, [40+l] ticks in classify + prune, [48+l] tape ops evaluated. */
+fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
 /* Times `reps` passes of the point interpreter over `tape` in `n_waves` waves
  * (variant 0: 16 registers x 4 voxels, 1: 32 x 2, 2: LDS register file, 3: 32 x 1). */
 fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_waves, uint32_t reps, int variant,

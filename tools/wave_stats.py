@@ -16,4 +16,5 @@ hip.sync()
 for k, v in hip.wave_stats().items():
     v["busy_us_mean"] = v["busy_us_sum"] / max(v["waves"], 1)
     print(k, json.dumps(v))
+print(hip.tile_phases)
 print(hip.counters())
