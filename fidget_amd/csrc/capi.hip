@@ -44,8 +44,8 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS_16x4 = 0, FH_ASM_COLUMNS_32x2, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_COUNT };
-static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns_16x4", "fh_columns_32x2", "fh_float_eval_16x4", "fh_float_eval_32x2"};
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2"};
 
 struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
@@ -752,8 +752,8 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
                 void* ka = dS;
-                (void)launch_asm(ctx, FH_ASM_COLUMNS_16x4, ctx->n_cu * 16, &ka, sizeof(ka));
-                (void)launch_asm(ctx, FH_ASM_COLUMNS_32x2, ctx->n_cu * 16, &ka, sizeof(ka));
+                // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
+                (void)launch_asm(ctx, FH_ASM_COLUMNS, ctx->n_cu * 16, &ka, sizeof(ka));
             } else if (R.full) {
                 hipLaunchKernelGGL((k_columns3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_columns3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);

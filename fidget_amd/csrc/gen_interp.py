@@ -80,6 +80,7 @@ S_SAVE = "s[88:89]"
 S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]   # per-slot lane masks s[90:97]
 S_K = "s98"
 S_ZL = "s99"
+S_VDONE = "s100"
 S_N = "s6"              # bulk: number of samples
 S_ACT = [f"s[{8 + 2 * j}:{9 + 2 * j}]" for j in range(4)]  # bulk: lanes of slot j holding a sample
 S_VARS = "s[30:31]"     # bulk
@@ -594,12 +595,14 @@ def handler_base(a, it):
 	s_addc_u32 s43, s43, 0""")
 
 
-def gen_columns(a, nr, zb, cls, off):
-    name = f"fh_columns_{nr}x{zb}"
-    it = Interp(a, name, nr, zb, "columns", off)
+def gen_columns(a, variants, off):
+    """One kernel for all register-file classes: even workgroups start with the first variant,
+    odd ones with the second, and a wave whose list has run dry moves on to the other list."""
+    kname = "fh_columns"
     o = off
-    kernel_header(a, name, 8, FILE + nr * zb)
     m = S_MAT
+    nvg = FILE + max(nr * zb for nr, zb, _ in variants)
+    kernel_header(a, kname, 8, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0""")
     common_consts(a)
@@ -612,16 +615,38 @@ def gen_columns(a, nr, zb, cls, off):
 	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
 	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
-	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list'] + 8 * cls}
-	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count'] + 4 * cls}""")
-    handler_base(a, it)
-    a(f"""
 	v_and_b32 {V_LX}, 7, {V_LANE}
 	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
+	s_mov_b32 {S_VDONE}, 0
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
 	s_add_u32 {S_FW}, {S_WIDTH}, 7
 	s_lshr_b32 {S_FW}, {S_FW}, 3
+	s_bitcmp1_b32 {S_WG}, 0
+	s_cbranch_scc1 .Lfh_columns_{variants[1][0]}x{variants[1][1]}_enter""")
+    its = []
+    for vi, (nr, zb, cls) in enumerate(variants):
+        its.append(gen_columns_variant(a, nr, zb, cls, off, vi, variants))
+    a(".Lfh_columns_exit:")
+    kernel_footer(a, kname, 8, nvg, 102, True)
+    for it in its:
+        it.emit()
+    return kname, nvg
+
+
+def gen_columns_variant(a, nr, zb, cls, off, vi, variants):
+    name = f"fh_columns_{nr}x{zb}"
+    it = Interp(a, name, nr, zb, "columns", off)
+    o = off
+    m = S_MAT
+    other = variants[1 - vi]
+    a(f"""
+.L{name}_enter:
+	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list'] + 8 * cls}
+	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count'] + 4 * cls}""")
+    handler_base(a, it)
+    a(f"""
+	s_waitcnt lgkmcnt(0)
 .L{name}_outer:
 	; ---- next footprint: wi = atomicAdd(&fp_cursor[cls], 1) ------------------------------
 	v_cmp_eq_u32 vcc, 0, {V_LANE}
@@ -768,10 +793,13 @@ def gen_columns(a, nr, zb, cls, off):
 	s_mov_b64 exec, {S_SAVE}
 	s_nop 1
 	s_branch .L{name}_outer
-.L{name}_exit:""")
-    kernel_footer(a, name, 8, FILE + nr * zb, 100, False)
-    it.emit()
-    return name
+.L{name}_exit:
+	; this list is exhausted: go on with the other one, once
+	s_bitset1_b32 {S_VDONE}, {vi}
+	s_bitcmp1_b32 {S_VDONE}, {1 - vi}
+	s_cbranch_scc0 .Lfh_columns_{other[0]}x{other[1]}_enter
+	s_branch .Lfh_columns_exit""")
+    return it
 
 
 def gen_bulk(a, nr, zb, off):
@@ -838,9 +866,9 @@ def main():
     a = Asm()
     a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
     ks = []
+    n, nvg = gen_columns(a, ((16, 4, 0), (32, 2, 1)), off)
+    ks.append((n, 8, nvg, [(8, "global_buffer")]))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
-        n = gen_columns(a, nr, zb, cls, off)
-        ks.append((n, 8, FILE + nr * zb, [(8, "global_buffer")]))
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
     metadata(a, ks)
