@@ -29,7 +29,7 @@ typedef enum fhip_status {
     FHIP_ERR_BAD_CHOICE_SLICE = 3,  /* vm/data.rs:129-134  BadTrace(BadChoiceSlice) */
     FHIP_ERR_MISSING_VAR = 4,       /* shape/mod.rs:391-396 MissingVar */
     FHIP_ERR_BAD_TAPE = 5,          /* malformed bytecode / bad node (context BadNode) */
-    FHIP_ERR_UNSUPPORTED = 6,       /* e.g. > 256 live registers, tile fan-out > 16 */
+    FHIP_ERR_UNSUPPORTED = 6,       /* e.g. > 256 live registers, tile fan-out > 64 */
     FHIP_ERR_HIP = 7,               /* a HIP runtime call failed; see fhip_last_error */
     FHIP_ERR_CANCELLED = 8,         /* render/config.rs:38-80 CancelToken */
     FHIP_ERR_PARSE = 9,             /* context/mod.rs ParseError */
@@ -107,7 +107,8 @@ typedef struct fhip_render2d_config {
 typedef struct fhip_render3d_config {
     uint32_t width, height, depth;
     const float* world_to_model;   /* row-major 4x4, NULL = identity */
-    const uint32_t* tile_sizes;    /* NULL = {128,64,32,16,8} */
+    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_3d() of the HIP shape: the root tile the
+                                    * VmShape hints give for this image size, then fan-out 4^3: {128,32,8} */
     uint32_t n_tile_sizes;
     const uint64_t* var_keys;
     const float* var_values;
