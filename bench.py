@@ -104,6 +104,8 @@ def main():
             prof[k][0] += ms
             prof[k][1] += cnt
     hip.profile(False)
+    hip.wave_stats()
+    tile_phases = hip.tile_phases  # device counters of the last frame: tape ops read / written per tile level
     if world > 1:
         step()  # leave `out` holding the combined image on rank 0
         fence()
@@ -141,17 +143,41 @@ def main():
                                   "sample": f"one full {n}^3 frame ({secs:.2f} s wall on {cores} threads); C++ restatement of "
                                             "the reference VmShape interpreter path, not the Rust JIT (published JIT/VM ratio "
                                             "on M1 Max: 61.7/23.6 = 2.6x, README.md:154)"}
-        # leaf stage = 8 B per tape word per wavefront pass; + the W*H*16 B image written once
-        alg_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
-        k_ms = result["kernel_ms_per_frame"]["points"]
-        launches = max(result["kernel_launches_per_frame"]["points"], 1)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        result["roofline"] = {"bound": "hbm", "kernel": "k_columns3d", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                              "algorithmic_bytes_per_launch": alg_bytes / launches,
-                              "avg_launch_ms": k_ms / launches, "launches_per_frame": launches,
-                              "note": "tape words are wave-uniform scalar loads served by K$/L2, so HBM traffic is far "
-                                      "below the algorithmic bytes: the kernel is LDS/VALU bound, not HBM bound"}
+        # ---- roofline ---------------------------------------------------------------
+        # Algorithmic bytes: 8 B per tape word read per wavefront pass + 8 B per tape word written
+        # + 2 bit per recorded choice + the W*H*16 B image once.  The tile stage's op counts come
+        # from the device's own counters (its subdivision 128/32/8 differs from the oracle's
+        # 128/64/32/16/8 schedule; pruning is deterministic, so they are exact for this frame);
+        # the leaf stage's from the oracle (same leaves, same pruned tapes).
+        # HBM traffic per launch: rocprofv3 PMC passes, committed under profiles/ (counters cannot
+        # be collected inside the timed run); FETCH_SIZE doubled per MI355X_MICROARCH.md.
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
+
+        def roof(kernel, alg_bytes, k_ms, launches, note):
+            achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            t = traffic.get(kernel)
+            tb = None
+            if t:
+                tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
+            return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
+                    "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1), "avg_launch_ms": k_ms / max(launches, 1),
+                    "launches_per_frame": launches, "note": note}
+
+        kms, kl = result["kernel_ms_per_frame"], result["kernel_launches_per_frame"]
+        ops_in = sum(v["ops"] for v in tile_phases.values())
+        ops_out = sum(v["ops_written"] for v in tile_phases.values())
+        tile_bytes = 8.0 * (ops_in + ops_out) + st["interval_choices"] / 4.0
+        result["roofline"] = roof("k_tiles", tile_bytes, kms["tiles"], kl["tiles"],
+                                  "dominant kernel by time; bound by the latency of the dependent op chain "
+                                  "(scalar decode + LDS round trip per tape op), far from any HBM limit")
+        leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
+        result["roofline_leaf"] = roof("fh_columns", leaf_bytes, kms["points"], kl["points"],
+                                       "tape words are wave-uniform scalar loads served by the scalar cache / L2: "
+                                       "the leaf kernel is bound by VALU issue, not by HBM")
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
     print(json.dumps(result))

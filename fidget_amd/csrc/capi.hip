@@ -44,19 +44,20 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_COUNT };
-static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2"};
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles"};
 
 struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
     bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
+    bool use_split = true;  // FHIP_NO_SPLIT=1: monolithic k_tiles for the 3D tile stage (diagnostics)
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2];
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -120,6 +121,13 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     for (int i = 0; i < FH_ASM_COUNT; i++)
         if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     if (const char* e = getenv("FHIP_NO_ASM")) c->use_asm = atoi(e) == 0;
+    (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    (void)hipGetLastError();
+    if (const char* e = getenv("FHIP_NO_SPLIT")) c->use_split = atoi(e) == 0;
+    {
+        const void* fb[] = {(const void*)k_teval3d<false, true>, (const void*)k_teval3d<true, true>};
+        for (const void* f : fb) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    }
     *out = c;
     return FHIP_OK;
 }
@@ -128,7 +136,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
-                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue};
+                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1]};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
@@ -153,9 +161,11 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     return FHIP_OK;
 }
 // Launch one of the assembly kernels: `waves` single-wave workgroups, raw kernarg block
-static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes) {
+static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(ctx->asm_fn[which], waves, 1, 1, WAVE, 1, 1, 0, ctx->stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, 1, 1, WAVE, 1, 1, (unsigned)lds, ctx->stream, nullptr, extra);
+    if (e != hipSuccess && ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
+    return e;
 }
 // The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
 static bool tape_asm_ok(const fh::HostTape& t) {
@@ -429,6 +439,8 @@ struct RenderSetup {
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
     bool asm_points = false;  // leaf stage on the assembly interpreters
+    bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
+    bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -477,7 +489,7 @@ static bool tape_is_full(const fh::HostTape& t) {
 }
 
 static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {
-    size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL;
+    size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL + 256;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -588,6 +600,17 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
+    R.split = ctx->use_split && is3d && R.tl == 64;
+    R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
+    if (R.split) {
+        uint32_t cap = 1;
+        for (size_t l = 0; l < ts.size(); l++) cap = std::max(cap, qcaps[l]);
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx, ctx->slots[k].ensure((size_t)cap * sizeof(FhSlot)));
+            S.slots[k] = (FhSlot*)ctx->slots[k].p;
+            S.slot_cap[k] = cap;
+        }
+    }
     S.squeue = (FhGroup*)ctx->squeue.p;
     S.squeue_cap = qcaps[S.pre_levels];
     S.arena_frame_end = S.arena_root_end;
@@ -641,7 +664,35 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         if (R.tl == 64) hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 64>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level); \
         else hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
     } while (0)
+// 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
+static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level) {
+    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
+    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
+    if (R.asm_tiles) {
+        launch(ctx, FHIP_K_TILES, [&] {
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, pad; } ka;
+            ka.S = dS; ka.level = (uint32_t)level; ka.pad = 0;
+            if (level > 0) {
+                ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
+                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
+            }
+            ka.big = 1; ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
+            (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
+        });
+    } else
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (level > 0) {
+            if (R.full) hipLaunchKernelGGL((k_teval3d<true, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+            else hipLaunchKernelGGL((k_teval3d<false, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+        }
+        if (R.full) hipLaunchKernelGGL((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+        else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+    });
+    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
+}
+
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
+    if (is3d && R.split) return launch_tiles_split(ctx, R, dS, level);
     const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(true, false, true, gb, R.lds_tiles_big); }
@@ -751,8 +802,9 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
-                void* ka = dS;
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
+                // (waves pull footprints with an atomic cursor: measured faster than a static round robin)
+                void* ka = dS;
                 (void)launch_asm(ctx, FH_ASM_COLUMNS, ctx->n_cu * 16, &ka, sizeof(ka));
             } else if (R.full) {
                 hipLaunchKernelGGL((k_columns3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);

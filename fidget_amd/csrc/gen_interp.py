@@ -871,6 +871,8 @@ def main():
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
+    from gen_tiles import gen_tiles
+    ks.append(gen_tiles(a, off))
     metadata(a, ks)
     open(sys.argv[2], "w").write(a.text())
 

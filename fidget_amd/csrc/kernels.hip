@@ -474,6 +474,11 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                     child.off = base + (rank + 1) * len - clen; child.len = clen;
                     child.n_regs = (uint16_t)cregs; child.n_choices = (uint16_t)cch;
                 }
+                if (IS3D) {  // ops written, for the algorithmic-bytes accounting
+                    uint32_t wsum;
+                    wave_excl_sum(prune ? clen : 0u, wsum);
+                    if (lane == 0) atomicAdd(&S->stat[56 + level], (unsigned long long)wsum);
+                }
             } else if (lane == 0) {
                 atomicAdd(&S->arena_overflow, 1u);  // children fall back to the parent tape
             }
@@ -523,6 +528,206 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
         }
     }
     probe.done(lane);
+}
+
+// ======================================================================================
+// Split 3D tile stage (64 children per parent): k_tsetup3d -> evaluate + prune (fh_tiles in
+// assembly, or k_teval3d below for tapes outside its opcode set) -> k_tpush3d.  Same
+// algorithm as k_tiles; the parent travels between the kernels in an FhSlot.
+// ======================================================================================
+__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[level];
+    const uint32_t ntx = (P.width + T - 1) / T;
+    const uint32_t* mind = S->mind[level];
+    Mat4 mat;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
+    // Parents map to slots one to one and waves to parents round robin: no atomic cursors (they
+    // serialise in L2 and cost more than this kernel's work)
+    const uint32_t ns = min(S->count[level], S->slot_cap[0]), nb = min(S->count_big[level], S->slot_cap[1]);
+    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns; S->n_slots[1][level] = nb; }
+    for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
+        const bool big = gi >= ns;
+        const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
+        FhSlot& sl = S->slots[big ? 1 : 0][big ? gi - ns : gi];
+        if (level > 0) {  // the whole parent may have been occluded since it was queued
+            const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
+            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
+        }
+        uint32_t nchild, cx, cy, cz;
+        if (level == 0) {
+            nchild = g.n;
+            const uint32_t ri = g.first + lane * g.stride;  // root index, x-major (lib.rs:116-123)
+            cx = (ri / P.roots_y) * T; cy = (ri % P.roots_y) * T; cz = g.z;
+        } else {
+            const uint32_t n = P.tiles[level - 1] / T;
+            nchild = n * n * n;
+            cx = g.x + (lane % n) * T; cy = g.y + ((lane / n) % n) * T; cz = g.z + (lane / (n * n)) * T;
+        }
+        bool act = lane < (int)nchild && cx < P.width && cy < P.height;
+        if (act && mind[(cy / T) * ntx + cx / T] >= cz + T + 1) act = false;  // voxel.rs:283-289
+        const uint64_t actm = ballot(act);
+        if (actm == 0) { if (lane == 0) sl.act = 0; continue; }
+        IV X, Y, Z;
+        xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
+                    iv((float)cz, (float)cz + (float)T), X, Y, Z);
+        if (lane == 0) {
+            sl.tape.off = g.tape.off; sl.tape.len = g.tape.len; sl.tape.n_regs = g.tape.n_regs; sl.tape.n_choices = g.tape.n_choices;
+            sl.level = (uint32_t)level; sl.act = actm; sl.base = 0; sl.overflow = 0;
+        }
+        sl.xyz[0][lane] = X.lo; sl.xyz[1][lane] = X.hi; sl.xyz[2][lane] = Y.lo; sl.xyz[3][lane] = Y.hi;
+        sl.xyz[4][lane] = Z.lo; sl.xyz[5][lane] = Z.hi;
+        sl.corner[0][lane] = cx; sl.corner[1][lane] = cy; sl.corner[2][lane] = cz;
+    }
+}
+
+// Step 2 in C++ (reference implementation of fh_tiles; used for tapes outside the assembly
+// opcode set): forward interval pass, then one reverse prune sweep per ambiguous child.
+template <bool FULL, bool BIG>
+__global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
+    constexpr int TL = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x;
+    const uint32_t max_regs = BIG ? P.max_regs : SMALL_REGS;
+    const uint32_t max_choices = BIG ? P.max_choices : SMALL_CHOICES;
+    IV* regs = (IV*)smem;
+    uint32_t* chbits = (uint32_t*)(smem + (size_t)max_regs * TL * sizeof(IV));
+    uint8_t* map = (uint8_t*)(chbits + (size_t)((max_choices + 15) / 16) * TL);
+    const uint32_t n_slots = S->n_slots[BIG ? 1 : 0][level];
+    for (uint32_t si = blockIdx.x; si < n_slots; si += gridDim.x) {
+        FhSlot& sl = S->slots[BIG ? 1 : 0][si];
+        if (uni((uint32_t)(sl.act != 0)) == 0) continue;
+        const uint32_t off = uni(sl.tape.off), len = uni(sl.tape.len);
+        const uint32_t n_choices = uni((uint32_t)sl.tape.n_choices), n_regs = uni((uint32_t)sl.tape.n_regs);
+        const ctape_t tape = (ctape_t)(S->arena + off);
+        const bool act = (sl.act >> lane) & 1;
+        const IV X = iv(sl.xyz[0][lane], sl.xyz[1][lane]), Y = iv(sl.xyz[2][lane], sl.xyz[3][lane]),
+                 Z = iv(sl.xyz[4][lane], sl.xyz[5][lane]);
+        Regs<IV, TL> R{regs, lane};
+        IV result = iv_nan();
+        uint32_t ci = 0, cw = 0;
+        bool any_decided = false;
+        {
+            const AS4 Q4* q = (const AS4 Q4*)tape;
+            Q4 cur = q[0];
+            for (uint32_t k = 0; k < len; k++) {
+                const uint64_t w = q4_pick(cur, (int)(k & 3));
+                if ((k & 3) == 3) cur = q[(k >> 2) + 1];
+                step<IVAL, TL, FULL>(
+                    w, R,
+                    [&](uint32_t slot) {
+                        const uint32_t kd = P.in_kind[slot];
+                        return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot])));
+                    },
+                    [&](uint32_t, IV v) { result = v; },
+                    [&](int c) {
+                        cw |= (uint32_t)c << ((ci & 15) * 2);
+                        any_decided |= (c != FH_CHOICE_BOTH);
+                        if ((ci & 15) == 15) { chbits[(ci >> 4) * TL + lane] = cw; cw = 0; }
+                        ci++;
+                    });
+            }
+            if (ci & 15) chbits[(ci >> 4) * TL + lane] = cw;
+        }
+        sl.res[0][lane] = result.lo; sl.res[1][lane] = result.hi;
+        const bool full = act && result.hi < 0.0f, empty = act && !full && result.lo > 0.0f;
+        const bool amb = act && !full && !empty;
+        const bool prune = amb && any_decided;
+        uint32_t coff = off, clen = len, cregs = n_regs, cch = n_choices;
+        const uint64_t pm = ballot(prune);
+        if (pm) {
+            const uint32_t nprune = (uint32_t)__popcll(pm);
+            const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1));
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&S->arena_head, nprune * len);
+            base = uni(base);
+            if (base + nprune * len <= S->arena_cap) {
+                for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane] = DEAD;
+                uint32_t l2 = 0, r2 = 0, c2 = 0;
+                prune_sweep<true, TL>(tape, len, n_choices, chbits, map, lane, prune, S->arena + base + (rank + 1) * len, l2, r2, c2);
+                if (prune) { coff = base + (rank + 1) * len - l2; clen = l2; cregs = r2; cch = c2; }
+                if (lane == 0) sl.base = base;
+            } else if (lane == 0) {
+                sl.overflow = 1;
+                atomicAdd(&S->arena_overflow, 1u);  // children fall back to the parent tape
+            }
+        }
+        sl.c_off[lane] = coff; sl.c_len[lane] = clen; sl.c_rc[lane] = cregs | (cch << 16);
+    }
+}
+
+// Step 3: fills of the decided children, queue / leaf entries for the ambiguous ones
+__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[level];
+    const uint32_t ntx = (P.width + T - 1) / T;
+    const bool last_level = (level + 1 == (int)P.n_levels);
+    const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    for (uint32_t si = blockIdx.x; si < n0 + n1; si += gridDim.x) {
+        const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
+        if (uni((uint32_t)(sl.act != 0)) == 0) continue;
+        const bool act = (sl.act >> lane) & 1;
+        const float lo = sl.res[0][lane], hi = sl.res[1][lane];
+        const uint32_t cx = sl.corner[0][lane], cy = sl.corner[1][lane], cz = sl.corner[2][lane];
+        const bool full = act && hi < 0.0f, empty = act && !full && lo > 0.0f;  // voxel.rs:310-320
+        const bool amb = act && !full && !empty;
+        uint64_t fm = ballot(full);
+        while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317)
+            const int c = __builtin_ctzll(fm);
+            fm &= fm - 1;
+            const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
+            const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + T + 1) << 32;
+            for (uint32_t p = lane; p < T * T; p += WAVE) {
+                const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
+            }
+        }
+        const uint64_t am = ballot(amb);
+        if (am == 0) continue;
+        FhTapeRef child;
+        child.off = sl.c_off[lane]; child.len = sl.c_len[lane];
+        child.n_regs = (uint16_t)(sl.c_rc[lane] & 0xFFFFu); child.n_choices = (uint16_t)(sl.c_rc[lane] >> 16);
+        const bool small = tape_is_small(child);
+        if (!last_level) {
+            uint32_t ns, nb;
+            const uint32_t slot_s = wave_excl_sum((amb && small) ? 1u : 0u, ns);
+            const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
+            // the last pre-pass level parks its output in the queue of the children's z-slab
+            const bool park = S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
+            const uint32_t slab = park ? uni(__shfl(cz, __builtin_ctzll(am), WAVE)) / P.tiles[0] : 0;
+            FhGroup* const qdst = park ? S->squeue + (size_t)slab * S->squeue_cap : S->queue[level + 1];
+            const uint32_t qcap = park ? S->squeue_cap : S->qcap[level + 1];
+            uint32_t qs = 0, qb = 0;
+            if (lane == 0) {
+                if (ns) qs = atomicAdd(park ? &S->scount[slab] : &S->count[level + 1], ns);
+                if (nb) qb = atomicAdd(park ? &S->scount_big[slab] : &S->count_big[level + 1], nb);
+            }
+            qs = uni(qs); qb = uni(qb);
+            if (amb) {
+                FhGroup o;
+                o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = 0; o.stride = 0;
+                if (small) qdst[qs + slot_s] = o;
+                else qdst[qcap - 1 - (qb + slot_b)] = o;
+            }
+        } else {
+            uint32_t namb;
+            const uint32_t slot = wave_excl_sum(amb ? 1u : 0u, namb);
+            uint32_t lb = 0;
+            if (lane == 0) lb = atomicAdd(&S->n_leaves, namb);
+            lb = uni(lb);
+            if (amb && lb + slot < S->leaf_cap) {
+                FhLeaf lf;
+                lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
+                S->leaves[lb + slot] = lf;
+                const uint32_t layers = P.tiles[0] / T;
+                S->leaf_table[((size_t)(cy / T) * ntx + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
+            } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+        }
+    }
 }
 
 // ======================================================================================
@@ -672,17 +877,24 @@ __global__ void k_classify3d(FhRenderState* S) {
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.tiles[0] / T;
     const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (fi >= fw * fh) return;
     const uint32_t* col = S->leaf_table + (size_t)fi * layers;
     uint32_t mx = 0;
     bool any = false;
-    for (uint32_t l = 0; l < layers; l++) {
+    for (uint32_t l = 0; l < layers && fi < fw * fh; l++) {
         const uint32_t id = col[l];
         if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
     }
-    if (!any) return;
-    const int cls = mx <= 16 ? 0 : (mx <= 32 ? 1 : 2);
-    S->fp_list[cls][atomicAdd(&S->fp_count[cls], 1u)] = ((fi / fw) << 16) | (fi % fw);  // fy, fx
+    // one atomic per wave and class instead of one per footprint
+    const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= 32 ? 1 : 2));
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int c = 0; c < 3; c++) {
+        const uint64_t m = ballot(cls == c);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&S->fp_count[c], (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), WAVE);
+        if (cls == c) S->fp_list[c][base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = ((fi / fw) << 16) | (fi % fw);  // fy, fx
+    }
 }
 
 // 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
@@ -812,7 +1024,11 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
     for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
     const uint32_t P0 = S->pre_levels;
     if (i == 0) {
-        for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) { S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0; }
+        for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) {
+            S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0;
+            S->setup_cur[l] = 0; S->push_cur[l] = 0;
+            S->n_slots[0][l] = 0; S->n_slots[1][l] = 0; S->eval_cur[0][l] = 0; S->eval_cur[1][l] = 0;
+        }
         if (P0 == 0) {
             S->count_big[0] = n_root_groups;  // the root tape uses the large LDS layout
             S->arena_head = S->arena_root_end;

@@ -18,6 +18,23 @@ struct FhGroup {
     uint32_t stride;      // level 0 only: index step between the group's root tiles (multi-GPU shards)
 };
 
+// A parent tile in flight between the kernels of the split 3D tile stage (setup -> evaluate +
+// prune -> push); one entry per lane = per child tile.  SoA so that every access is coalesced.
+#define FH_SLOT_LANES 64
+struct FhSlot {
+    FhTapeRef tape;                 // parent tape
+    uint32_t level;
+    uint64_t act;                   // in : children to evaluate (inside the image, not occluded)
+    uint32_t base, overflow;        // out: arena reservation of the pruned tapes / arena full
+    uint32_t pad[2];
+    float xyz[6][FH_SLOT_LANES];    // in : x.lo x.hi y.lo y.hi z.lo z.hi (model space)
+    uint32_t corner[3][FH_SLOT_LANES];  // in : child corner (voxels)
+    float res[2][FH_SLOT_LANES];    // out: interval result
+    uint32_t c_off[FH_SLOT_LANES];  // out: child tape (the parent's when nothing was pruned)
+    uint32_t c_len[FH_SLOT_LANES];
+    uint32_t c_rc[FH_SLOT_LANES];   //      n_regs | n_choices << 16
+};
+
 // An ambiguous smallest tile: evaluated point by point
 struct FhLeaf {
     FhTapeRef tape;
@@ -63,6 +80,11 @@ struct FhRenderState {
     uint32_t pre_levels, n_slabs, squeue_cap, arena_frame_end;
     FhGroup* squeue;
     uint32_t scount[FH_MAX_SLABS], scount_big[FH_MAX_SLABS];
+    // split 3D tile stage: slots[0] = tapes that fit the small LDS layout, slots[1] = the others
+    FhSlot* slots[2];
+    uint32_t slot_cap[2];
+    uint32_t setup_cur[FH_MAX_LEVELS];
+    uint32_t n_slots[2][FH_MAX_LEVELS], eval_cur[2][FH_MAX_LEVELS], push_cur[FH_MAX_LEVELS];
     // leaves
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;

@@ -144,7 +144,7 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
 /* Wave busy-time statistics of the last render, 4 words per kernel kind (3D tile levels 0-4,
  * columns class 0, columns classes 1-2, 2D tiles): sum and max of per-wave busy ticks
  * (100 MHz), waves that found work, work units; then per 3D tile level: [32+l] ticks in the
- * forward interval pass, [40+l] ticks in classify + prune, [48+l] tape ops evaluated. */
+ * forward interval pass, [40+l] ticks in classify + prune, [48+l] tape ops evaluated, [56+l] ops of pruned tapes written. */
 fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
 /* Times `reps` passes of the point interpreter over `tape` in `n_waves` waves
  * (variant 0: 16 registers x 4 voxels, 1: 32 x 2, 2: LDS register file, 3: 32 x 1). */
