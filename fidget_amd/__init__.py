@@ -207,7 +207,7 @@ class HipContext:
         self.check(lib().fhip_debug_stats(self._h, _p(c)))
         names = ["tiles_l0", "tiles_l1", "tiles_l2", "tiles_l3", "tiles_l4", "columns_c0", "columns_c12", "tiles_2d"]
         self.tile_phases = {f"l{l}": {"fwd_us": int(c[32 + l]) / 100.0, "prune_us": int(c[40 + l]) / 100.0,
-                                      "ops": int(c[48 + l]), "ops_written": int(c[56 + l])} for l in range(8) if c[48 + l]}
+                                      "ops": int(c[48 + l]), "ops_written": int(c[56 + l]), "fwd_shader_clocks": int(c[16 + l])} for l in range(8) if c[48 + l]}
         return {k: {"busy_us_sum": int(c[4 * i]) / 100.0, "busy_us_max": int(c[4 * i + 1]) / 100.0,
                     "waves": int(c[4 * i + 2]), "units": int(c[4 * i + 3])} for i, k in enumerate(names) if c[4 * i + 2]}
 

@@ -51,13 +51,21 @@ struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
     bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
+    bool probe = false;     // FHIP_PROBE=1: per-phase clocks in fh_tiles (slows it down; tools/wave_stats.py)
     bool use_split = true;  // FHIP_NO_SPLIT=1: monolithic k_tiles for the 3D tile stage (diagnostics)
+    // 3D: the tile stage of slab k+1 runs on a second stream while slab k's leaves are evaluated
+    bool use_pipeline = true;  // FHIP_NO_PIPELINE=1 serialises the slabs on one stream (diagnostics)
+    hipStream_t stream2 = nullptr;
+    std::vector<hipEvent_t> ev_tiles, ev_leaves;
+    hipEvent_t ev_fork = nullptr;
+    FhRenderState last_state_b;
+    bool forked = false;
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2];
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b;
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -124,6 +132,15 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     (void)hipGetLastError();
     if (const char* e = getenv("FHIP_NO_SPLIT")) c->use_split = atoi(e) == 0;
+    if (const char* e = getenv("FHIP_PROBE")) c->probe = atoi(e) != 0;
+    if (const char* e = getenv("FHIP_NO_PIPELINE")) c->use_pipeline = atoi(e) == 0;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS);
+    for (int i = 0; i < FH_MAX_SLABS; i++) {
+        (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_leaves[i], hipEventDisableTiming);
+    }
     {
         const void* fb[] = {(const void*)k_teval3d<false, true>, (const void*)k_teval3d<true, true>};
         for (const void* f : fb) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
@@ -136,10 +153,15 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
-                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1]};
+                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1],
+                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_tiles) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_leaves) (void)hipEventDestroy(e);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     delete c;
 }
@@ -569,16 +591,19 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
     R.n_footprints = (uint32_t)(fw * fhh);
 
-    HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
+    HIP_TRY(ctx, ctx->state.ensure(2 * sizeof(FhRenderState)));
     HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes));
     for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
     if (S.pre_levels) HIP_TRY(ctx, ctx->squeue.ensure((size_t)qcaps[S.pre_levels] * R.n_slabs * sizeof(FhGroup)));
     HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
+    if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
         HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
+        HIP_TRY(ctx, ctx->leaf_table_b.ensure(leaf_cap * 4));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
         HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
         HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
+        HIP_TRY(ctx, ctx->fp_lists_b.ensure((size_t)R.n_footprints * 4 * 3));
         size_t mind_words = 0;
         for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
         HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
@@ -639,7 +664,15 @@ static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu) {
 
 static fhip_status finish_render(fhip_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state, ctx->state.p, sizeof(FhRenderState), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->forked)
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state_b, (char*)ctx->state.p + sizeof(FhRenderState), sizeof(FhRenderState),
+                                    hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->forked) {  // the second slab context keeps its own counters
+        ctx->last_state.queue_overflow += ctx->last_state_b.queue_overflow;
+        ctx->last_state.arena_overflow += ctx->last_state_b.arena_overflow;
+        for (int i = 0; i < 64; i++) ctx->last_state.stat[i] += ctx->last_state_b.stat[i];
+    }
     ctx->have_last_state = true;
     if (ctx->last_state.queue_overflow) return fail(ctx, FHIP_ERR_OVERFLOW, "device work queue overflow");
     return FHIP_OK;
@@ -670,8 +703,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
     if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {
-            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, pad; } ka;
-            ka.S = dS; ka.level = (uint32_t)level; ka.pad = 0;
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, probe; } ka;
+            ka.S = dS; ka.level = (uint32_t)level; ka.probe = ctx->probe ? 1 : 0;
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
@@ -790,14 +823,40 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
         for (uint32_t l = 0; l < pre; l++) launch_tiles(ctx, R, dS, (int)l, true);
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
     }
+    // Two-stream pipeline over the z-slabs: the tile stage of a slab runs on the side stream while
+    // the leaves of the slab in front of it are evaluated on the caller's stream.  The occlusion
+    // pyramid is then one slab stale, which is still exact (depths only grow).  Two slab contexts
+    // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
+    FhRenderState* const dS0 = dS;
+    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.n_slabs > 1 && n_groups > 0;
+    hipStream_t const main_stream = ctx->stream;
+    ctx->forked = pipe;
+    if (pipe) {
+        uint32_t* fpb = (uint32_t*)ctx->fp_lists_b.p;
+        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, main_stream, dS0, dS0 + 1, (FhLeaf*)ctx->leaves_b.p,
+                           (uint32_t*)ctx->leaf_table_b.p, fpb, fpb + R.n_footprints, fpb + 2 * (size_t)R.n_footprints);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
     for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
-        if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+        if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
+        const int idx = (int)R.n_slabs - 1 - k;
+        dS = pipe && (idx & 1) ? dS0 + 1 : dS0;
+        if (pipe) {
+            ctx->stream = ctx->stream2;
+            if (idx >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_leaves[idx - 2], 0));  // context free again
+        }
         launch(ctx, FHIP_K_OTHER, [&] {
             hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups);
             if (k != (int)R.n_slabs - 1)  // the first slab sees an empty image (pyramid pre-zeroed)
                 hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
         });
         for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        if (pipe) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], ctx->stream2));
+            ctx->stream = main_stream;
+            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
+        }
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS); });
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
@@ -828,8 +887,9 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS);
             }
         });
+        if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
     }
-    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS, d_out); });
+    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out); });
     HIP_TRY(ctx, hipGetLastError());
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
@@ -875,7 +935,7 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
 fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_waves, uint32_t reps, int variant, double* ms) {
     fhip_status st = tape_to_device(ctx, tape);
     if (st) return st;
-    HIP_TRY(ctx, ctx->state.ensure(sizeof(FhRenderState)));
+    HIP_TRY(ctx, ctx->state.ensure(2 * sizeof(FhRenderState)));
     FhRenderState S;
     memset(&S, 0, sizeof(S));
     for (int i = 0; i < FH_MAX_INPUTS; i++) S.P.in_kind[i] = i % 3;

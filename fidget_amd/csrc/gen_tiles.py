@@ -13,7 +13,7 @@ Per FhSlot (one parent tile, one child per lane), exactly what k_teval3d (kernel
 Dispatch is threaded (`s_setpc_b64` into 128-byte handler slots); the tape is fetched through
 the scalar cache, 4 ops per load, double buffered.  Emitted by gen_interp.py.
 
-kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 pad }
+kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 probe }
 LDS    : regs [max_regs][64] x 8 B | choice words [(max_choices+15)/16][64] x 4 B | map [max_regs][64] x 1 B
 Limits : <= 128 registers (pool of 4 x 32 bits), opcodes of the assembly set (no transcendental / modulo / rng)
 """
@@ -57,7 +57,9 @@ S_SAVE = "s[88:89]"
 S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]
 S_T2, S_T3 = "s98", "s99"
 S_STAGED = "s13"
-S_SI, S_NWG = "s100", "s101"   # slot index of this wave, waves in the launch
+S_RR = "s3"
+S_PROBE = "s101"           # kernarg `probe`
+S_SI, S_NWG = "s2", "s100"   # slot index of this wave, waves in the launch
 
 # ---- VGPRs -----------------------------------------------------------------------------------
 V_LANE, V_L8, V_L4 = "v0", "v1", "v2"
@@ -83,7 +85,9 @@ V_COFF, V_CLEN, V_CRC = "v64", "v65", "v66"
 V_DEAD = "v67"
 V_ZERO = "v76"                              # v[68:75]: tape batch in flight
 V_PW = "v[78:79]"                           # prune: prefetched op
-N_VGPR = 80
+V_AOUT, V_AA, V_AB, V_AAL = "v80", "v81", "v82", "v83"   # prune: LDS addresses of map[out], map[a], map[b], alias
+V_MBV, V_AV = "v55", "v45"                  # prune: map[b], value of the aliased entry
+N_VGPR = 84
 
 SLOT_SIZE = 40 + 64 * 4 * 14
 SL_ACT, SL_XYZ, SL_CORNER, SL_RES, SL_COFF, SL_CLEN, SL_CRC = 16, 40, 40 + 6 * 256, 40 + 9 * 256, 40 + 11 * 256, 40 + 12 * 256, 40 + 13 * 256
@@ -572,11 +576,19 @@ class Tiles:
             a(f"{lab}:")
             fn()
 
-    # ---- pool of free registers (4 x 32 bits, 1 = free) ------------------------------------------
-    def pool_take(self, out):
+    # ---- pool of free registers (W x 32 bits, 1 = free) ------------------------------------------
+    def pool_take(self, out, W):
         """out = lowest free register, marked used; for the lanes in exec"""
         a = self.a
         u = V_U
+        if W == 1:
+            a(f"""
+	v_ffbl_b32 {out}, {P[0]}
+	v_lshlrev_b32 {u[0]}, {out}, {V_ONE}
+	v_add_u32 {u[1]}, 1, {out}
+	v_xor_b32 {P[0]}, {P[0]}, {u[0]}
+	v_max_u32 {V_HIGH}, {V_HIGH}, {u[1]}""")
+            return
         a(f"""
 	v_ffbl_b32 {u[0]}, {P[0]}
 	v_ffbl_b32 {u[1]}, {P[1]}
@@ -592,27 +604,23 @@ class Tiles:
 	v_add_u32 {u[2]}, 1, {out}
 	v_max_u32 {V_HIGH}, {V_HIGH}, {u[2]}""")
         for w in range(4):
-            a(f"""
-	v_cmp_eq_u32_e64 {S_M[w]}, {w}, {u[1]}""")
+            a(f"\tv_cmp_eq_u32_e64 {S_M[w]}, {w}, {u[1]}")
         a("\ts_nop 0")
         for w in range(4):
-            a(f"""
-	v_cndmask_b32_e64 {u[2]}, 0, {u[0]}, {S_M[w]}
-	v_xor_b32 {P[w]}, {P[w]}, {u[2]}""")
+            a(f"\tv_cndmask_b32_e64 {u[2]}, 0, {u[0]}, {S_M[w]}\n\tv_xor_b32 {P[w]}, {P[w]}, {u[2]}")
 
-    def pool_give(self, reg):
+    def pool_give(self, reg, W):
         a = self.a
         u = V_U
-        a(f"""
-	v_lshlrev_b32 {u[0]}, {reg}, {V_ONE}
-	v_lshrrev_b32 {u[1]}, 5, {reg}""")
+        if W == 1:
+            a(f"\tv_lshlrev_b32 {u[0]}, {reg}, {V_ONE}\n\tv_or_b32 {P[0]}, {P[0]}, {u[0]}")
+            return
+        a(f"\tv_lshlrev_b32 {u[0]}, {reg}, {V_ONE}\n\tv_lshrrev_b32 {u[1]}, 5, {reg}")
         for w in range(4):
             a(f"\tv_cmp_eq_u32_e64 {S_M[w]}, {w}, {u[1]}")
         a("\ts_nop 0")
         for w in range(4):
-            a(f"""
-	v_cndmask_b32_e64 {u[2]}, 0, {u[0]}, {S_M[w]}
-	v_or_b32 {P[w]}, {P[w]}, {u[2]}""")
+            a(f"\tv_cndmask_b32_e64 {u[2]}, 0, {u[0]}, {S_M[w]}\n\tv_or_b32 {P[w]}, {P[w]}, {u[2]}")
 
     def map_addr(self, dst, sreg):
         """LDS address of map[sreg][lane]"""
@@ -621,82 +629,76 @@ class Tiles:
 	s_add_u32 {S_T2}, {S_T2}, {S_MAPBASE}
 	v_add_u32 {dst}, {S_T2}, {V_LANE}""")
 
-    def use(self, sreg, out):
-        """out = map[sreg], allocating a register where the value is not live yet (lanes in exec)"""
+    def alloc_where_dead(self, val, addr, within, W, lab):
+        """lanes of `within` whose map value `val` is DEAD get a fresh register (written back)"""
         a = self.a
-        skip = a.label("use_skip")
-        self.map_addr(V_U[5], sreg)
         a(f"""
-	ds_read_u8 {out}, {V_U[5]}
-	s_waitcnt lgkmcnt(0)
-	s_mov_b64 {S_T64}, exec
-	v_cmp_eq_u32 vcc, {V_DEAD}, {out}
-	s_and_b64 vcc, vcc, exec
-	s_cbranch_scc0 {skip}
+	v_cmp_eq_u32 vcc, {V_DEAD}, {val}
+	s_and_b64 vcc, vcc, {within}
+	s_cbranch_scc0 {lab}
 	s_mov_b64 exec, vcc""")
-        self.pool_take(out)
+        self.pool_take(val, W)
         a(f"""
-	ds_write_b8 {V_U[5]}, {out}
-	s_mov_b64 exec, {S_T64}
-{skip}:""")
+	ds_write_b8 {addr}, {val}
+	s_mov_b64 exec, {within}
+{lab}:""")
 
     def emit_op(self, mask):
-        """store {V_EW0, V_EW1} one op below dst for the lanes in `mask`"""
+        """store {V_EW0, V_EW1} one op below dst for the lanes in `mask` (exec is left = mask)"""
         self.a(f"""
 	s_mov_b64 exec, {mask}
 	v_add_co_u32 v46, vcc, -8, v46
 	v_addc_co_u32 v47, vcc, -1, v47, vcc
 	v_add_u32 {V_COUNT}, 1, {V_COUNT}
-	global_store_dwordx2 {V_DST}, v[56:57], off
-	s_mov_b64 exec, -1""")
+	global_store_dwordx2 {V_DST}, v[56:57], off""")
 
     # ---- prune sweep -------------------------------------------------------------------------
-    def emit_prune(self):
-        """Reverse sweep for the lanes in S_PRUNE (vm/data.rs:123-318 as in prune_sweep, kernels.hip)."""
+    def emit_prune(self, W):
+        """Reverse sweep for the lanes in S_PRUNE (vm/data.rs:123-318 as in prune_sweep, kernels.hip);
+        W = words of the free-register pool (1: tapes of <= 32 registers, 4: <= 128)."""
         a = self.a
-        o = self.off
+        L = lambda n: f".Lfh_tiles_p{W}_{n}"
         a(f"""
-; ---- prune sweep: ops {S_LEN}-1 .. 0 of the tape at {S_TAPE}; lanes {S_PRUNE} -----------------
-.Lfh_tiles_prune:
+; ---- prune sweep ({32 * W} registers): ops {S_LEN}-1 .. 0 of the tape at {S_TAPE}; lanes {S_PRUNE} --------
+.Lfh_tiles_prune{W}:
 	s_mov_b32 {S_K}, {S_LEN}
 	s_mov_b32 {S_CI}, {S_NCH}
 	v_mov_b32 {V_COUNT}, 0
 	v_mov_b32 {V_KEPT}, 0
-	v_mov_b32 {V_HIGH}, 0
-	v_mov_b32 {P[0]}, -1
-	v_mov_b32 {P[1]}, -1
-	v_mov_b32 {P[2]}, -1
-	v_mov_b32 {P[3]}, -1
+	v_mov_b32 {V_HIGH}, 0""")
+        for w in range(W):
+            a(f"\tv_mov_b32 {P[w]}, -1")
+        a(f"""
 	; stage the tape in LDS, in the (now dead) interval register file, when it fits: a scalar
 	; load per op would cost its full latency every step
 	s_lshl_b32 {S_T0}, {S_LEN}, 3
 	s_mov_b32 {S_STAGED}, 0
 	s_cmp_le_u32 {S_T0}, {S_CHBASE}
-	s_cbranch_scc0 .Lfh_tiles_pnext
+	s_cbranch_scc0 {L('next')}
 	s_mov_b32 {S_STAGED}, 1
 	v_lshlrev_b32 {V_U[0]}, 4, {V_LANE}
-.Lfh_tiles_stage:
+{L('stage')}:
 	v_cmp_gt_u32 vcc, {S_T0}, {V_U[0]}
 	s_and_saveexec_b64 {S_SAVE}, vcc
-	s_cbranch_execz .Lfh_tiles_staged
+	s_cbranch_execz {L('staged')}
 	global_load_dwordx4 v[68:71], {V_U[0]}, {S_TAPE}
 	s_waitcnt vmcnt(0)
 	ds_write_b128 {V_U[0]}, v[68:71]
 	s_mov_b64 exec, {S_SAVE}
 	v_add_u32 {V_U[0]}, 0x400, {V_U[0]}
-	s_branch .Lfh_tiles_stage
-.Lfh_tiles_staged:
+	s_branch {L('stage')}
+{L('staged')}:
 	s_mov_b64 exec, -1
 	s_waitcnt lgkmcnt(0)
-	; prefetch the last op
 	s_sub_u32 {S_T0}, {S_T0}, 8
 	v_mov_b32 {V_U[0]}, {S_T0}
 	ds_read_b64 {V_PW}, {V_U[0]}
-.Lfh_tiles_pnext:
+{L('next')}:
+	s_mov_b64 exec, -1
 	s_sub_u32 {S_K}, {S_K}, 1
-	s_cbranch_scc1 .Lfh_tiles_pdone
+	s_cbranch_scc1 {L('done')}
 	s_cmp_eq_u32 {S_STAGED}, 0
-	s_cbranch_scc1 .Lfh_tiles_pslow
+	s_cbranch_scc1 {L('slow')}
 	s_waitcnt lgkmcnt(0)
 	v_readfirstlane_b32 {S_W0}, v78
 	v_readfirstlane_b32 {S_W1}, v79
@@ -705,21 +707,21 @@ class Tiles:
 	s_sub_u32 {S_T0}, {S_T0}, 8
 	v_mov_b32 {V_U[0]}, {S_T0}
 	ds_read_b64 {V_PW}, {V_U[0]}
-	s_branch .Lfh_tiles_phaveop
-.Lfh_tiles_pslow:
+	s_branch {L('haveop')}
+{L('slow')}:
 	s_lshl_b32 {S_T0}, {S_K}, 3
 	s_add_u32 s76, s44, {S_T0}
 	s_addc_u32 s77, s45, 0
 	s_load_dwordx2 {S_CUR}, {S_T64}, 0x0
 	s_waitcnt lgkmcnt(0)
-.Lfh_tiles_phaveop:
+{L('haveop')}:
 	s_and_b32 {S_OP}, {S_W0}, 0xff
 	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
 	s_lshr_b32 {S_A}, {S_W0}, 20
 	; choice of this op per lane (choice ops only): c in {V_C}
 	s_mov_b32 {S_T3}, 0
 	s_cmp_ge_u32 {S_OP}, 30
-	s_cbranch_scc0 .Lfh_tiles_pnochoice
+	s_cbranch_scc0 {L('nochoice')}
 	s_cmp_lt_u32 {S_OP}, 34
 	s_cselect_b32 {S_T3}, 1, 0
 	s_cmp_ge_u32 {S_OP}, 42
@@ -730,7 +732,7 @@ class Tiles:
 	s_lshl_b32 {S_T0}, {S_T0}, 1
 	s_or_b32 {S_T3}, {S_T3}, {S_T0}
 	s_cmp_eq_u32 {S_T3}, 0
-	s_cbranch_scc1 .Lfh_tiles_pnochoice
+	s_cbranch_scc1 {L('nochoice')}
 	; {S_T3}: 1 = choice op reg,reg  2 = choice op reg,imm
 	s_sub_u32 {S_CI}, {S_CI}, 1
 	s_and_b32 {S_T0}, {S_CI}, 15
@@ -741,145 +743,155 @@ class Tiles:
 	s_cselect_b32 {S_T2}, 1, 0
 	s_or_b32 {S_T1}, {S_T1}, {S_T2}
 	s_cmp_eq_u32 {S_T1}, 0
-	s_cbranch_scc1 .Lfh_tiles_phaveword
+	s_cbranch_scc1 {L('haveword')}
 	s_lshr_b32 {S_T1}, {S_CI}, 4
 	s_lshl_b32 {S_T1}, {S_T1}, 8
 	s_add_u32 {S_T1}, {S_T1}, {S_CHBASE}
 	v_add_u32 {V_TADDR}, {S_T1}, {V_L4}
 	ds_read_b32 {V_CWP}, {V_TADDR}
 	s_waitcnt lgkmcnt(0)
-.Lfh_tiles_phaveword:
+{L('haveword')}:
 	s_lshl_b32 {S_T0}, {S_T0}, 1
 	v_bfe_u32 {V_C}, {V_CWP}, {S_T0}, 2
-.Lfh_tiles_pnochoice:
+{L('nochoice')}:
 	s_cmp_eq_u32 {S_OP}, 0
-	s_cbranch_scc1 .Lfh_tiles_poutput
-	; ---- live lanes: map[out] != DEAD ------------------------------------------------------
-""")
-        self.map_addr(V_U[4], S_OUT)
+	s_cbranch_scc1 {L('output')}
+	; ---- all map traffic of this op in ONE LDS round trip: read map[out], kill it (a no-op for
+	; lanes where it is dead already), then read the operands' entries (LDS keeps the order)""")
+        self.map_addr(V_AOUT, S_OUT)
         a(f"""
-	ds_read_u8 {V_NO}, {V_U[4]}
+	ds_read_u8 {V_NO}, {V_AOUT}
+	s_mov_b64 exec, {S_PRUNE}
+	ds_write_b8 {V_AOUT}, {V_DEAD}
+	s_mov_b64 exec, -1
+	v_mov_b32 {V_MAV}, 0
+	; operand a: every op except INPUT (1) and COPY_IMM (3)
+	s_cmp_eq_u32 {S_OP}, 1
+	s_cbranch_scc1 {L('noa')}
+	s_cmp_eq_u32 {S_OP}, 3
+	s_cbranch_scc1 {L('noa')}""")
+        self.map_addr(V_AA, S_A)
+        a(f"""
+	ds_read_u8 {V_MAV}, {V_AA}
+{L('noa')}:
+	; operand b: reg,reg forms (22..33)
+	s_mov_b32 {S_RR}, 0
+	s_cmp_ge_u32 {S_OP}, 22
+	s_cbranch_scc0 {L('nob')}
+	s_cmp_lt_u32 {S_OP}, 34
+	s_cbranch_scc0 {L('nob')}
+	s_mov_b32 {S_RR}, 1""")
+        self.map_addr(V_AB, S_W1)
+        a(f"""
+	ds_read_u8 {V_MBV}, {V_AB}
+{L('nob')}:
 	s_waitcnt lgkmcnt(0)
 	v_cmp_ne_u32 vcc, {V_DEAD}, {V_NO}
 	s_and_b64 {S_LIVE}, vcc, {S_PRUNE}
-	s_cbranch_scc0 .Lfh_tiles_pnext
-	s_mov_b64 exec, {S_LIVE}
-	ds_write_b8 {V_U[4]}, {V_DEAD}
-	s_mov_b64 exec, -1
+	s_cbranch_scc0 {L('next')}
 	; ---- decided choices / copies alias `out` with the surviving operand ---------------------
 	s_mov_b64 {S_ALIAS}, 0
 	s_mov_b64 {S_CIMM}, 0
 	s_cmp_eq_u32 {S_OP}, 2
-	s_cbranch_scc0 .Lfh_tiles_pnotcopy
+	s_cbranch_scc0 {L('notcopy')}
 	s_mov_b64 {S_ALIAS}, {S_LIVE}
-	s_lshl_b32 {S_T0}, {S_A}, 6
-	v_mov_b32 {V_U[3]}, {S_T0}
-	s_branch .Lfh_tiles_palias
-.Lfh_tiles_pnotcopy:
+	v_mov_b32 {V_AV}, {V_MAV}
+	v_mov_b32 {V_AAL}, {V_AA}
+	s_branch {L('alias')}
+{L('notcopy')}:
 	s_cmp_eq_u32 {S_T3}, 0
-	s_cbranch_scc1 .Lfh_tiles_pkeep
+	s_cbranch_scc1 {L('keep')}
 	v_cmp_eq_u32_e64 {S_MA}, 1, {V_C}
 	v_cmp_eq_u32_e64 {S_MB}, 2, {V_C}
-	s_lshl_b32 {S_T0}, {S_A}, 6
-	s_lshl_b32 {S_T1}, {S_W1}, 6
-	v_mov_b32 {V_U[3]}, {S_T0}
-	v_mov_b32 {V_U[2]}, {S_T1}
+	v_mov_b32 {V_AV}, {V_MAV}
+	v_mov_b32 {V_AAL}, {V_AA}
 	s_and_b64 {S_MA}, {S_MA}, {S_LIVE}
 	s_and_b64 {S_MB}, {S_MB}, {S_LIVE}
-	v_cndmask_b32_e64 {V_U[3]}, {V_U[3]}, {V_U[2]}, {S_MB}
 	s_cmp_eq_u32 {S_T3}, 1
-	s_cbranch_scc0 .Lfh_tiles_primm
+	s_cbranch_scc0 {L('rimm')}
+	v_cndmask_b32_e64 {V_AV}, {V_AV}, {V_MBV}, {S_MB}
+	v_cndmask_b32_e64 {V_AAL}, {V_AAL}, {V_AB}, {S_MB}
 	s_or_b64 {S_ALIAS}, {S_MA}, {S_MB}
-	s_branch .Lfh_tiles_palias
-.Lfh_tiles_primm:
+	s_branch {L('alias')}
+{L('rimm')}:
 	s_mov_b64 {S_ALIAS}, {S_MA}
 	s_mov_b64 {S_CIMM}, {S_MB}
-.Lfh_tiles_palias:
+{L('alias')}:
 	s_cmp_eq_u64 {S_ALIAS}, 0
-	s_cbranch_scc1 .Lfh_tiles_pcimm
-	; per lane: {V_U[3]} = 64 * aliased register
-	v_add_u32 {V_U[3]}, {S_MAPBASE}, {V_U[3]}
-	v_add_u32 {V_U[3]}, {V_U[3]}, {V_LANE}
-	s_mov_b64 exec, {S_ALIAS}
-	ds_read_u8 {V_MAV}, {V_U[3]}
-	s_waitcnt lgkmcnt(0)
-	v_cmp_eq_u32 vcc, {V_DEAD}, {V_MAV}
-	s_and_b64 {S_MA}, vcc, exec
-	s_andn2_b64 {S_MB}, exec, vcc
+	s_cbranch_scc1 {L('cimm')}
+	v_cmp_eq_u32 vcc, {V_DEAD}, {V_AV}
+	s_and_b64 {S_MA}, vcc, {S_ALIAS}
+	s_andn2_b64 {S_MB}, {S_ALIAS}, vcc
 	; operand not live yet: it takes over the register, nothing is emitted
 	s_mov_b64 exec, {S_MA}
-	ds_write_b8 {V_U[3]}, {V_NO}
-	s_mov_b64 exec, -1
+	ds_write_b8 {V_AAL}, {V_NO}
 	s_cmp_eq_u64 {S_MB}, 0
-	s_cbranch_scc1 .Lfh_tiles_pcimm
+	s_cbranch_scc1 {L('cimm')}
 	; operand already live: COPY_REG no <- map[alias]; the register of `out` is free before it
 	s_mov_b64 exec, {S_MB}""")
-        self.pool_give(V_NO)
+        self.pool_give(V_NO, W)
         a(f"""
 	v_lshlrev_b32 {V_EW0}, 8, {V_NO}
-	v_lshl_or_b32 {V_EW0}, {V_MAV}, 20, {V_EW0}
+	v_lshl_or_b32 {V_EW0}, {V_AV}, 20, {V_EW0}
 	v_or_b32 {V_EW0}, 2, {V_EW0}
 	v_mov_b32 {V_EW1}, 0""")
         self.emit_op(S_MB)
         a(f"""
-.Lfh_tiles_pcimm:
+{L('cimm')}:
 	s_cmp_eq_u64 {S_CIMM}, 0
-	s_cbranch_scc1 .Lfh_tiles_pkeep
+	s_cbranch_scc1 {L('keep')}
 	s_mov_b64 exec, {S_CIMM}""")
-        self.pool_give(V_NO)
+        self.pool_give(V_NO, W)
         a(f"""
 	v_lshlrev_b32 {V_EW0}, 8, {V_NO}
 	v_or_b32 {V_EW0}, 3, {V_EW0}
 	v_mov_b32 {V_EW1}, {S_W1}""")
         self.emit_op(S_CIMM)
         a(f"""
-.Lfh_tiles_pkeep:
+{L('keep')}:
 	s_andn2_b64 {S_KEEP}, {S_LIVE}, {S_ALIAS}
 	s_andn2_b64 {S_KEEP}, {S_KEEP}, {S_CIMM}
 	s_cmp_eq_u64 {S_KEEP}, 0
-	s_cbranch_scc1 .Lfh_tiles_pnext
+	s_cbranch_scc1 {L('next')}
 	s_mov_b64 exec, {S_KEEP}""")
-        self.pool_give(V_NO)
+        self.pool_give(V_NO, W)
+        a(f"\tv_mov_b32 {V_EW1}, {S_W1}")
+        # operand a (V_MAV = 0 and never DEAD when the op has none)
+        self.alloc_where_dead(V_MAV, V_AA, S_KEEP, W, L('a_ok'))
         a(f"""
-	v_mov_b32 {V_NA}, 0
-	v_mov_b32 {V_EW1}, {S_W1}
-	; operand a: every op except INPUT (1) and COPY_IMM (3)
-	s_cmp_eq_u32 {S_OP}, 1
-	s_cbranch_scc1 .Lfh_tiles_pnoa
-	s_cmp_eq_u32 {S_OP}, 3
-	s_cbranch_scc1 .Lfh_tiles_pnoa""")
-        self.use(S_A, V_NA)
+	s_cmp_eq_u32 {S_RR}, 0
+	s_cbranch_scc1 {L('b_ok')}
+	v_mov_b32 {V_EW1}, {V_MAV}
+	s_cmp_eq_u32 {S_A}, {S_W1}
+	s_cbranch_scc1 {L('b_ok')}""")
+        self.alloc_where_dead(V_MBV, V_AB, S_KEEP, W, L('b_alloc'))
         a(f"""
-.Lfh_tiles_pnoa:
-	; operand b: reg,reg forms (22..33)
-	s_cmp_ge_u32 {S_OP}, 22
-	s_cbranch_scc0 .Lfh_tiles_pnob
-	s_cmp_lt_u32 {S_OP}, 34
-	s_cbranch_scc0 .Lfh_tiles_pnob""")
-        self.use(S_W1, V_NB)
-        a(f"""
-	v_mov_b32 {V_EW1}, {V_NB}
-.Lfh_tiles_pnob:
+	v_mov_b32 {V_EW1}, {V_MBV}
+{L('b_ok')}:
 	s_cmp_eq_u32 {S_T3}, 0
-	s_cbranch_scc1 .Lfh_tiles_pnokept
+	s_cbranch_scc1 {L('nokept')}
 	v_add_u32 {V_KEPT}, 1, {V_KEPT}
-.Lfh_tiles_pnokept:
+{L('nokept')}:
 	v_lshlrev_b32 {V_EW0}, 8, {V_NO}
-	v_lshl_or_b32 {V_EW0}, {V_NA}, 20, {V_EW0}
+	v_lshl_or_b32 {V_EW0}, {V_MAV}, 20, {V_EW0}
 	v_or_b32 {V_EW0}, {S_OP}, {V_EW0}""")
         self.emit_op(S_KEEP)
         a(f"""
-	s_branch .Lfh_tiles_pnext
-.Lfh_tiles_poutput:
-	s_mov_b64 exec, {S_PRUNE}""")
-        self.use(S_A, V_NA)
+	s_branch {L('next')}
+{L('output')}:""")
+        self.map_addr(V_AA, S_A)
         a(f"""
-	v_lshlrev_b32 {V_EW0}, 20, {V_NA}
+	ds_read_u8 {V_MAV}, {V_AA}
+	s_waitcnt lgkmcnt(0)
+	s_mov_b64 exec, {S_PRUNE}""")
+        self.alloc_where_dead(V_MAV, V_AA, S_PRUNE, W, L('o_ok'))
+        a(f"""
+	v_lshlrev_b32 {V_EW0}, 20, {V_MAV}
 	v_mov_b32 {V_EW1}, {S_W1}""")
         self.emit_op(S_PRUNE)
         a(f"""
-	s_branch .Lfh_tiles_pnext
-.Lfh_tiles_pdone:
+	s_branch {L('next')}
+{L('done')}:
 	s_mov_b64 exec, -1
 	s_waitcnt vmcnt(0) lgkmcnt(0)
 	s_setpc_b64 {S_RET}""")
@@ -898,8 +910,7 @@ class Tiles:
 {name}:
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
 	s_load_dwordx4 s[8:11], {S_KERNARG}, 0x8
-	s_load_dword {S_NWG}, {S_KERNARG}, 0x18
-	s_mov_b32 {S_SI}, s2
+	s_load_dwordx2 s[100:101], {S_KERNARG}, 0x18
 	v_mov_b32 {V_QNAN}, 0x7fc00000
 	v_mov_b32 {V_SQRTC}, 0xf800000
 	v_mov_b32 {V_ONE}, 1
@@ -958,7 +969,9 @@ class Tiles:
 	s_load_dwordx2 {S_ACT}, {S_SLOT}, {SL_ACT}
 	s_waitcnt lgkmcnt(0)
 	s_cmp_eq_u64 {S_ACT}, 0
-	s_cbranch_scc1 .Lfh_tiles_outer""")
+	s_cbranch_scc1 .Lfh_tiles_outer
+	s_memrealtime s[56:57]
+	s_memtime s[62:63]""")
         for k, r in enumerate((VX[0], VX[1], VY[0], VY[1], VZ[0], VZ[1])):
             a(f"\tglobal_load_dword {r}, {V_L4}, {S_SLOT} offset:{SL_XYZ + 256 * k}")
         a(f"""
@@ -983,6 +996,11 @@ class Tiles:
 	s_addc_u32 s75, s75, 0
 	s_branch .Lfh_tiles_run
 .Lfh_tiles_ret1:
+	s_memrealtime s[58:59]
+	s_memtime s[90:91]
+	s_waitcnt lgkmcnt(0)
+	s_sub_u32 s62, s90, s62
+	s_subb_u32 s63, s91, s63
 	; ---- flush the last partial choice word ----------------------------------------------------
 	s_and_b32 {S_T0}, {S_CI}, 15
 	s_cmp_eq_u32 {S_T0}, 0
@@ -1050,7 +1068,9 @@ class Tiles:
 .Lfh_tiles_pc2:
 	s_add_u32 s74, s74, .Lfh_tiles_ret2 - .Lfh_tiles_pc2
 	s_addc_u32 s75, s75, 0
-	s_branch .Lfh_tiles_prune
+	s_cmp_le_u32 {S_NREGS}, 32
+	s_cbranch_scc1 .Lfh_tiles_prune1
+	s_branch .Lfh_tiles_prune4
 .Lfh_tiles_ret2:
 	; child = {{ base + (rank+1)*len - count, count, high | kept << 16 }} for the pruned lanes
 	v_sub_u32 {T[4]}, {T[4]}, {V_COUNT}
@@ -1068,6 +1088,31 @@ class Tiles:
 	global_atomic_add {T[1]}, {T[0]}, {S_STATE} offset:{o['arena_overflow']}
 	s_mov_b64 exec, {S_SAVE}
 .Lfh_tiles_store:
+	; diagnostics (kernarg `probe`; the atomics serialise, so never in production runs): ticks
+	; (100 MHz) spent in the forward pass / in classify + prune, per level
+	s_cmp_eq_u32 {S_PROBE}, 0
+	s_cbranch_scc1 .Lfh_tiles_noprobe
+	s_memrealtime s[60:61]
+	s_waitcnt lgkmcnt(0)
+	s_sub_u32 s60, s60, s58
+	s_subb_u32 s61, s61, s59
+	s_sub_u32 s58, s58, s56
+	s_subb_u32 s59, s59, s57
+	s_lshl_b32 {S_T0}, {S_LEVEL}, 3
+	v_cmp_eq_u32 vcc, 0, {V_LANE}
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	v_mov_b32 {T[2]}, {S_T0}
+	v_mov_b32 {T[0]}, s58
+	v_mov_b32 {T[1]}, s59
+	global_atomic_add_x2 {T[2]}, v[16:17], {S_STATE} offset:{o['stat'] + 8 * 32}
+	v_mov_b32 {T[0]}, s60
+	v_mov_b32 {T[1]}, s61
+	global_atomic_add_x2 {T[2]}, v[16:17], {S_STATE} offset:{o['stat'] + 8 * 40}
+	v_mov_b32 {T[0]}, s62
+	v_mov_b32 {T[1]}, s63
+	global_atomic_add_x2 {T[2]}, v[16:17], {S_STATE} offset:{o['stat'] + 8 * 16}
+	s_mov_b64 exec, {S_SAVE}
+.Lfh_tiles_noprobe:
 	global_store_dword {V_L4}, {V_COFF}, {S_SLOT} offset:{SL_COFF}
 	global_store_dword {V_L4}, {V_CLEN}, {S_SLOT} offset:{SL_CLEN}
 	global_store_dword {V_L4}, {V_CRC}, {S_SLOT} offset:{SL_CRC}
@@ -1101,7 +1146,8 @@ class Tiles:
 	.end_amdhsa_kernel
 	.text""")
         self.emit_forward()
-        self.emit_prune()
+        self.emit_prune(1)
+        self.emit_prune(4)
 
 
 def gen_tiles(a, off):

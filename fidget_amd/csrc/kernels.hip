@@ -686,6 +686,11 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
             }
         }
+        {   // algorithmic-bytes accounting: tape ops read by this parent, ops of pruned tapes written
+            uint32_t wsum;
+            wave_excl_sum((amb && sl.c_off[lane] != sl.tape.off) ? sl.c_len[lane] : 0u, wsum);
+            if (lane == 0) { atomicAdd(&S->stat[48 + level], (unsigned long long)sl.tape.len); atomicAdd(&S->stat[56 + level], (unsigned long long)wsum); }
+        }
         const uint64_t am = ballot(amb);
         if (am == 0) continue;
         FhTapeRef child;
@@ -1042,6 +1047,18 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
     }
     if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.tiles[0];
+}
+// Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
+// pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
+__global__ void k_fork_state(FhRenderState* A, FhRenderState* B, FhLeaf* leaves, uint32_t* leaf_table, uint32_t* fp0,
+                             uint32_t* fp1, uint32_t* fp2) {
+    *B = *A;
+    B->leaves = leaves; B->leaf_table = leaf_table;
+    B->fp_list[0] = fp0; B->fp_list[1] = fp1; B->fp_list[2] = fp2;
+    const uint32_t lo = A->pre_levels ? A->arena_frame_end : A->arena_root_end;
+    const uint32_t mid = lo + (A->arena_cap - lo) / 2;
+    A->arena_cap = mid;
+    B->arena_frame_end = mid; B->arena_root_end = mid;
 }
 // End of the pre-pass: everything allocated so far lives for the whole frame
 __global__ void k_mark_frame(FhRenderState* S) { S->arena_frame_end = S->arena_head; }

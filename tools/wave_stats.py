@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Render one frame and print the per-kernel-kind wave busy statistics (GPU box)."""
 import os, sys, json
+os.environ.setdefault("FHIP_PROBE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
