@@ -44,8 +44,8 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_COUNT };
-static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles"};
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1"};
 
 struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
@@ -65,7 +65,7 @@ struct fhip_ctx {
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2];
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -154,7 +154,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
                       &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1],
-                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b};
+                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b, &c->chw[0], &c->chw[1]};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
@@ -463,6 +463,7 @@ struct RenderSetup {
     bool asm_points = false;  // leaf stage on the assembly interpreters
     bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
     bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
+    bool prune1 = false;      // ... and, on the pre-pass levels, the prune as one wave per child (fh_prune1)
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -627,6 +628,16 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
     R.split = ctx->use_split && is3d && R.tl == 64;
     R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
+    R.prune1 = R.asm_tiles && S.pre_levels > 0 && !getenv("FHIP_NO_PRUNE1");
+    if (R.prune1) {  // choice words of the pre-pass levels' forward passes: [slot][word][lane]
+        uint32_t cap = 1;
+        for (uint32_t l = 0; l < S.pre_levels; l++) cap = std::max(cap, qcaps[l]);
+        const size_t words[2] = {(SMALL_CHOICES + 15) / 16, ((size_t)P.max_choices + 15) / 16};
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx, ctx->chw[k].ensure(std::max<size_t>(cap * words[k] * 256, 256)));
+            S.chw[k] = (uint32_t*)ctx->chw[k].p;
+        }
+    }
     if (R.split) {
         uint32_t cap = 1;
         for (size_t l = 0; l < ts.size(); l++) cap = std::max(cap, qcaps[l]);
@@ -703,14 +714,24 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
     if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {
-            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, probe; } ka;
-            ka.S = dS; ka.level = (uint32_t)level; ka.probe = ctx->probe ? 1 : 0;
+            // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
+            // the prune runs as one wave per child (fh_prune1)
+            const bool exp = R.prune1 && (uint32_t)level < R.S.pre_levels;
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags; } ka;
+            ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
             }
             ka.big = 1; ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
+            if (exp) {
+                struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
+                const uint32_t bound = R.S.qcap[level] * 64;  // 64 waves per possible parent; unmarked children exit at once
+                if (level > 0) (void)launch_asm(ctx, FH_ASM_PRUNE1, bound, &kp, sizeof(kp));
+                kp.big = 1; kp.max_choices = R.S.P.max_choices;
+                (void)launch_asm(ctx, FH_ASM_PRUNE1, bound, &kp, sizeof(kp));
+            }
         });
     } else
     launch(ctx, FHIP_K_TILES, [&] {

@@ -873,6 +873,8 @@ def main():
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
     from gen_tiles import gen_tiles
     ks.append(gen_tiles(a, off))
+    from gen_prune import gen_prune1
+    ks.append(gen_prune1(a, off))
     metadata(a, ks)
     open(sys.argv[2], "w").write(a.text())
 

@@ -13,7 +13,9 @@ Per FhSlot (one parent tile, one child per lane), exactly what k_teval3d (kernel
 Dispatch is threaded (`s_setpc_b64` into 128-byte handler slots); the tape is fetched through
 the scalar cache, 4 ops per load, double buffered.  Emitted by gen_interp.py.
 
-kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 probe }
+kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 flags }
+         flags bit 0: phase probes; bit 1: export mode for the long tapes of the pre-pass levels (choice words go
+         to S->chw[big][slot][word][lane], pruned lanes are only marked, fh_prune1 sweeps them one per wave)
 LDS    : regs [max_regs][64] x 8 B | choice words [(max_choices+15)/16][64] x 4 B | map [max_regs][64] x 1 B
 Limits : <= 128 registers (pool of 4 x 32 bits), opcodes of the assembly set (no transcendental / modulo / rng)
 """
@@ -58,7 +60,8 @@ S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]
 S_T2, S_T3 = "s98", "s99"
 S_STAGED = "s13"
 S_RR = "s3"
-S_PROBE = "s101"           # kernarg `probe`
+S_FLAGS = "s101"           # kernarg `flags`: bit 0 = probes, bit 1 = export (choices to HBM, no prune here)
+S_CHW, S_CHWSLOT, S_CHWTMP = "s[78:79]", "s[80:81]", "s[82:83]"   # export mode (the prune registers are free then)
 S_SI, S_NWG = "s2", "s100"   # slot index of this wave, waves in the launch
 
 # ---- VGPRs -----------------------------------------------------------------------------------
@@ -555,9 +558,18 @@ class Tiles:
 	s_lshr_b32 {S_T0}, {S_CI}, 4
 	s_sub_u32 {S_T0}, {S_T0}, 1
 	s_lshl_b32 {S_T0}, {S_T0}, 8
+	s_bitcmp1_b32 {S_FLAGS}, 1
+	s_cbranch_scc1 .Lfh_tiles_choice_export
 	s_add_u32 {S_T0}, {S_T0}, {S_CHBASE}
 	v_add_u32 {V_TADDR}, {S_T0}, {V_L4}
 	ds_write_b32 {V_TADDR}, {V_CW}
+	v_mov_b32 {V_CW}, 0
+	s_branch {self.next}
+.Lfh_tiles_choice_export:
+	s_add_u32 s82, s80, {S_T0}
+	s_addc_u32 s83, s81, 0
+	global_store_dword {V_L4}, {V_CW}, {S_CHWTMP}
+	s_nop 0
 	v_mov_b32 {V_CW}, 0
 	s_branch {self.next}
 	.p2align {HSTRIDE_LOG2}
@@ -947,6 +959,10 @@ class Tiles:
 	s_add_u32 s76, s4, {S_T0}
 	s_addc_u32 s77, s5, 0
 	s_load_dword {S_NSLOTS}, {S_T64}, {o['n_slots']}
+	s_lshl_b32 {S_T0}, {S_BIG}, 3
+	s_add_u32 s76, s4, {S_T0}
+	s_addc_u32 s77, s5, 0
+	s_load_dwordx2 {S_CHW}, {S_T64}, {o['chw']}
 	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
 	s_load_dword {S_ARENACAP}, {S_STATE}, {o['arena_cap']}
 	s_getpc_b64 {S_HBASE}
@@ -961,6 +977,12 @@ class Tiles:
 	s_cbranch_scc1 .Lfh_tiles_exit
 	s_mov_b32 {S_T0}, {S_SI}
 	s_add_u32 {S_SI}, {S_SI}, {S_NWG}
+	; export mode: this slot's choice words at chw[big] + si * (words * 256 B)
+	s_sub_u32 {S_T2}, {S_MAPBASE}, {S_CHBASE}
+	s_mul_hi_u32 {S_T3}, {S_T0}, {S_T2}
+	s_mul_i32 {S_T2}, {S_T0}, {S_T2}
+	s_add_u32 s80, s78, {S_T2}
+	s_addc_u32 s81, s79, {S_T3}
 	s_mul_i32 {S_T1}, {S_T0}, {SLOT_SIZE}
 	s_mul_hi_u32 {S_T0}, {S_T0}, {SLOT_SIZE}
 	s_add_u32 s20, s14, {S_T1}
@@ -1007,9 +1029,16 @@ class Tiles:
 	s_cbranch_scc1 .Lfh_tiles_noflush
 	s_lshr_b32 {S_T0}, {S_CI}, 4
 	s_lshl_b32 {S_T0}, {S_T0}, 8
+	s_bitcmp1_b32 {S_FLAGS}, 1
+	s_cbranch_scc1 .Lfh_tiles_flush_export
 	s_add_u32 {S_T0}, {S_T0}, {S_CHBASE}
 	v_add_u32 {V_TADDR}, {S_T0}, {V_L4}
 	ds_write_b32 {V_TADDR}, {V_CW}
+	s_branch .Lfh_tiles_noflush
+.Lfh_tiles_flush_export:
+	s_add_u32 s82, s80, {S_T0}
+	s_addc_u32 s83, s81, 0
+	global_store_dword {V_L4}, {V_CW}, {S_CHWTMP}
 .Lfh_tiles_noflush:
 	global_store_dword {V_L4}, {V_RESL}, {S_SLOT} offset:{SL_RES}
 	global_store_dword {V_L4}, {V_RESH}, {S_SLOT} offset:{SL_RES + 256}
@@ -1043,6 +1072,17 @@ class Tiles:
 	s_cbranch_scc1 .Lfh_tiles_overflow
 	s_cmp_le_u32 {S_T0}, {S_ARENACAP}
 	s_cbranch_scc0 .Lfh_tiles_overflow
+	s_bitcmp1_b32 {S_FLAGS}, 1
+	s_cbranch_scc0 .Lfh_tiles_sweep_here
+	; export mode: mark the lanes to prune (c_len = ~0) and leave the end of their arena slot in c_off
+	v_add_u32 {T[0]}, 1, {V_RANK}
+	v_mul_lo_u32 {T[0]}, {T[0]}, {S_LEN}
+	v_add_u32 {T[0]}, {S_BASE}, {T[0]}
+	v_mov_b32 {T[1]}, -1
+	v_cndmask_b32_e64 {V_COFF}, {V_COFF}, {T[0]}, {S_PRUNE}
+	v_cndmask_b32_e64 {V_CLEN}, {V_CLEN}, {T[1]}, {S_PRUNE}
+	s_branch .Lfh_tiles_store
+.Lfh_tiles_sweep_here:
 	; map[r][lane] = DEAD for r < n_regs: n_regs * 64 bytes written as dwords
 	s_lshl_b32 {S_T0}, {S_NREGS}, 6
 	v_add_u32 {V_TADDR}, {S_MAPBASE}, {V_L4}
@@ -1090,8 +1130,8 @@ class Tiles:
 .Lfh_tiles_store:
 	; diagnostics (kernarg `probe`; the atomics serialise, so never in production runs): ticks
 	; (100 MHz) spent in the forward pass / in classify + prune, per level
-	s_cmp_eq_u32 {S_PROBE}, 0
-	s_cbranch_scc1 .Lfh_tiles_noprobe
+	s_bitcmp1_b32 {S_FLAGS}, 0
+	s_cbranch_scc0 .Lfh_tiles_noprobe
 	s_memrealtime s[60:61]
 	s_waitcnt lgkmcnt(0)
 	s_sub_u32 s60, s60, s58

@@ -83,6 +83,9 @@ struct FhRenderState {
     // split 3D tile stage: slots[0] = tapes that fit the small LDS layout, slots[1] = the others
     FhSlot* slots[2];
     uint32_t slot_cap[2];
+    // pre-pass levels: choice words [slot][word][lane] of the forward pass, read by the
+    // one-wave-per-child prune (fh_prune1); [0] small-LDS list (16 words per slot), [1] the other
+    uint32_t* chw[2];
     uint32_t setup_cur[FH_MAX_LEVELS];
     uint32_t n_slots[2][FH_MAX_LEVELS], eval_cur[2][FH_MAX_LEVELS], push_cur[FH_MAX_LEVELS];
     // leaves
