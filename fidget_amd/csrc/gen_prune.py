@@ -31,6 +31,7 @@ S_CHWP = "s[18:19]"                            # address of this child's word 0
 S_DST = "s[20:21]"
 S_K, S_CI, S_CW = "s22", "s23", "s24"
 S_HAVEW = "s25"
+S_CWN, S_PREF = "s34", "s35"                  # prefetched choice word, prefetch in flight
 S_POOLA, S_POOLB = "s[26:27]", "s[28:29]"
 S_HIGH, S_COUNT, S_KEPT = "s30", "s31", "s32"
 S_END = "s33"                                  # end of the arena slot, in ops
@@ -218,6 +219,7 @@ class Prune1:
 	s_mov_b32 {S_K}, {S_LEN}
 	s_mov_b32 {S_CI}, {S_NCH}
 	s_mov_b32 {S_HAVEW}, 0
+	s_mov_b32 {S_PREF}, 0
 	; first batch: the 8-op block holding op len-1, and the one below it
 	s_sub_u32 {S_T0}, {S_LEN}, 1
 	s_and_b32 {S_QBASE}, {S_T0}, -8
@@ -271,13 +273,28 @@ class Prune1:
 	s_cselect_b32 {S_T1}, 0, {S_HAVEW}
 	s_cmp_eq_u32 {S_T1}, 0
 	s_cbranch_scc0 .Lfh_prune1_haveword
+	; a new word of 16 choices: the prefetched one, or (first time) a direct load
 	s_lshr_b32 {S_T1}, {S_CI}, 4
-	s_lshl_b32 {S_T1}, {S_T1}, 8
-	s_add_u32 s82, s18, {S_T1}
+	s_lshl_b32 {S_T2}, {S_T1}, 8
+	s_add_u32 s82, s18, {S_T2}
 	s_addc_u32 s83, s19, 0
-	s_load_dword {S_CW}, {S_T64}, 0x0
-	s_mov_b32 {S_HAVEW}, 1
+	s_cmp_eq_u32 {S_PREF}, 0
+	s_cbranch_scc1 .Lfh_prune1_wdirect
 	s_waitcnt lgkmcnt(0)
+	s_mov_b32 {S_CW}, {S_CWN}
+	s_branch .Lfh_prune1_wnext
+.Lfh_prune1_wdirect:
+	s_load_dword {S_CW}, {S_T64}, 0x0
+	s_waitcnt lgkmcnt(0)
+.Lfh_prune1_wnext:
+	s_mov_b32 {S_HAVEW}, 1
+	s_mov_b32 {S_PREF}, 0
+	s_cmp_eq_u32 {S_T1}, 0
+	s_cbranch_scc1 .Lfh_prune1_haveword
+	s_sub_u32 s82, s82, 0x100
+	s_subb_u32 s83, s83, 0
+	s_load_dword {S_CWN}, {S_T64}, 0x0             ; the word below, needed 16 choices from now
+	s_mov_b32 {S_PREF}, 1
 .Lfh_prune1_haveword:
 	s_lshl_b32 {S_T0}, {S_T0}, 1
 	s_lshr_b32 {S_CH}, {S_CW}, {S_T0}
