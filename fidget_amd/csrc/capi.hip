@@ -851,21 +851,22 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     FhRenderState* const dS0 = dS;
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.n_slabs > 1 && n_groups > 0;
     hipStream_t const main_stream = ctx->stream;
+    hipStream_t const side_stream = getenv("FHIP_PIPE_SERIAL") ? main_stream : ctx->stream2;  // diagnostics
     ctx->forked = pipe;
     if (pipe) {
         uint32_t* fpb = (uint32_t*)ctx->fp_lists_b.p;
         hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, main_stream, dS0, dS0 + 1, (FhLeaf*)ctx->leaves_b.p,
                            (uint32_t*)ctx->leaf_table_b.p, fpb, fpb + R.n_footprints, fpb + 2 * (size_t)R.n_footprints);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
     for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
         const int idx = (int)R.n_slabs - 1 - k;
         dS = pipe && (idx & 1) ? dS0 + 1 : dS0;
         if (pipe) {
-            ctx->stream = ctx->stream2;
-            if (idx >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_leaves[idx - 2], 0));  // context free again
+            ctx->stream = side_stream;
+            if (idx >= 2) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_leaves[idx - 2], 0));  // context free again
         }
         launch(ctx, FHIP_K_OTHER, [&] {
             hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups);
@@ -874,7 +875,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
         });
         for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
         if (pipe) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], ctx->stream2));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], side_stream));
             ctx->stream = main_stream;
             HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }

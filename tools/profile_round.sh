@@ -23,7 +23,7 @@ for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != c: continue
     k = re.sub(r"\(.*", "", r["Kernel_Name"])
     tot[k] += float(r["Counter_Value"]); n[k] += 1
-print(f"# {c}: sum over dispatches of the whole run (6 frames), as reported by rocprofv3 (no correction applied)")
+print(f"# {c}: sum over dispatches of the whole run (1 warm-up + 5 timed + 3 profiled frames = 9), KB as reported by rocprofv3 (no correction applied)")
 for k in sorted(tot, key=lambda k: -tot[k]):
     print(f"{tot[k]:16.0f}  dispatches {n[k]:6d}  per-dispatch {tot[k]/n[k]:14.1f}  {k}")
 PY
