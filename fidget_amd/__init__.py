@@ -51,7 +51,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench",
+    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves",
 ]
 
 
@@ -134,6 +134,7 @@ def lib():
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
+            "fhip_debug_leaves": (u32, [vp, vp, u32]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
@@ -199,6 +200,14 @@ class HipContext:
         self.check(lib().fhip_render_counters(self._h, _p(c)))
         return {"arena_ops": int(c[0]), "arena_overflow": int(c[1]), "leaves_last_slab": int(c[2]),
                 "queue_overflow": int(c[3]), "groups_last_slab": [int(v) for v in c[4:8]]}
+
+    def last_leaves(self, cap=1 << 20):
+        """Leaf records of the last slab of the last 3D frame: structured array (off, len, regs, choices, x, y, z)."""
+        dt = np.dtype([("off", np.uint32), ("len", np.uint32), ("regs", np.uint16), ("choices", np.uint16),
+                       ("x", np.uint32), ("y", np.uint32), ("z", np.uint32)])
+        buf = np.zeros(cap, dt)
+        n = lib().fhip_debug_leaves(self._h, _p(buf), cap)
+        return buf[:n]
 
     def wave_stats(self):
         """Per kernel kind: mean / max busy microseconds of the waves that found work, their

@@ -879,7 +879,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             ctx->stream = main_stream;
             HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }
-        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS); });
+        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
@@ -950,6 +950,14 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
     if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
     for (int i = 0; i < 64; i++) out[i] = ctx->last_state.stat[i];
     return FHIP_OK;
+}
+
+// Diagnostics: the leaves (24-byte FhLeaf records) of the last slab of the last 3D frame
+uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap) {
+    if (finish_render(ctx) != FHIP_OK) return 0;
+    const uint32_t n = std::min(std::min(ctx->last_state.n_leaves, ctx->last_state.leaf_cap), cap);
+    if (hipMemcpy(out, ctx->last_state.leaves, (size_t)n * sizeof(FhLeaf), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 // Diagnostics: time `reps` passes of the point interpreter over `tape` in `n_waves` waves.

@@ -80,33 +80,32 @@ S_SAVE = "s[88:89]"
 S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]   # per-slot lane masks s[90:97]
 S_K = "s98"
 S_ZL = "s99"
-S_VDONE = "s100"
+S_HB = "s[100:101]"       # columns: handler table of the leaf's register class
+S_SLOTX, S_SLOTY, S_SLOTZ, S_RC = "s0", "s1", "s3", "s2"   # columns: input slots of x, y, z; regs | choices << 16
 S_N = "s6"              # bulk: number of samples
 S_ACT = [f"s[{8 + 2 * j}:{9 + 2 * j}]" for j in range(4)]  # bulk: lanes of slot j holding a sample
 S_VARS = "s[30:31]"     # bulk
 S_OUTP = "s[32:33]"     # bulk
 
-# ---- fixed VGPRs ---------------------------------------------------------------------------
+# ---- fixed VGPRs (ZB <= 8) ------------------------------------------------------------------
 V_LANE = "v0"
 V_PXF, V_PYF = "v1", "v6"
 V_PIX = "v[2:3]"
 V_HIT, V_DEPTH = "v4", "v5"     # stored together as the 64-bit z-buffer word
 V_IDS = "v7"
-V_AX, V_AY, V_AZ = "v8", "v9", "v57"
-VX = [f"v{10 + j}" for j in range(4)]
-VY = [f"v{14 + j}" for j in range(4)]
-VZ = [f"v{18 + j}" for j in range(4)]
-VRES = [f"v{22 + j}" for j in range(4)]
-VT = [f"v{26 + j}" for j in range(4)]
-VU = [f"v{30 + j}" for j in range(4)]
-VW = [f"v{34 + j}" for j in range(4)]
-VD = [f"v{38 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
-V_QNAN = "v48"
-V_SQRTC = "v49"
-V_LX, V_LY = "v50", "v51"
-V_S0, V_S1, V_S2, V_S3 = "v52", "v53", "v54", "v55"
-V_IDV = "v56"
-VOFF = [f"v{58 + j}" for j in range(4)]  # bulk: byte offset of sample j
+V_AX, V_AY, V_AZ = "v8", "v9", "v59"
+VRES = [f"v{10 + j}" for j in range(8)]
+VT = [f"v{18 + j}" for j in range(8)]
+VU = [f"v{26 + j}" for j in range(8)]
+VW = [f"v{34 + j}" for j in range(8)]
+VD = [f"v{42 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
+V_QNAN = "v50"
+V_SQRTC = "v51"
+V_LX, V_LY = "v52", "v53"
+V_S0, V_S1, V_S2, V_S3 = "v54", "v55", "v56", "v57"
+V_IDV = "v58"
+VOFF = [f"v{60 + j}" for j in range(4)]  # bulk: byte offset of sample j
+V_ROFF, V_RLEN, V_RRC, V_RZ = "v60", "v61", "v62", "v63"   # columns: leaf records of the column, lane = layer
 FILE = 64
 
 SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
@@ -188,46 +187,33 @@ class Interp:
             self.a(f"\ts_nop {2 - self.zb}")
 
     # -- arithmetic on plain VGPR operands (index mode off) ------------------------------------
+    def mask_pass(self, cmp, sel):
+        """per sample: a compare into a lane mask, then a select on it; 4 masks at a time"""
+        z = list(range(self.zb))
+        for g in (z[i:i + 4] for i in range(0, len(z), 4)):
+            for j in g:
+                self.a("\t" + cmp(j, S_M[j % 4]))
+            if len(g) < 3:
+                self.a(f"\ts_nop {2 - len(g)}")   # VALU-written mask -> VALU read: 2 wait states
+            for j in g:
+                self.a("\t" + sel(j, S_M[j % 4]))
+
     def f_minmax(self, is_min, A, B, R):
         # min: a < b ? a : b, max: a > b ? a : b; either NaN -> NaN  (dev_ops.hpp f_min / f_max)
         cmp = "v_cmp_lt_f32_e64" if is_min else "v_cmp_gt_f32_e64"
-        for j in range(self.zb):
-            self.a(f"\t{cmp} {S_M[j]}, {A[j]}, {B[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {S_M[j]}")
-        for j in range(self.zb):
-            self.a(f"\tv_cmp_u_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {S_M[j]}")
+        self.mask_pass(lambda j, m: f"{cmp} {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {m}")
+        self.mask_pass(lambda j, m: f"v_cmp_u_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {m}")
 
     def f_andor(self, is_and, A, B, R):
         # and: a == 0 ? a : b ; or: a != 0 ? a : b
         cmp = "v_cmp_eq_f32_e64" if is_and else "v_cmp_neq_f32_e64"
-        for j in range(self.zb):
-            self.a(f"\t{cmp} {S_M[j]}, 0, {A[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {S_M[j]}")
+        self.mask_pass(lambda j, m: f"{cmp} {m}, 0, {A[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {m}")
 
     def f_compare(self, A, B, R):
         # a < b ? -1 : (a == b ? 0 : (a > b ? 1 : NaN))
-        for j in range(self.zb):
-            self.a(f"\tv_cmp_gt_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {V_QNAN}, 1.0, {S_M[j]}")
-        for j in range(self.zb):
-            self.a(f"\tv_cmp_eq_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, 0, {S_M[j]}")
-        for j in range(self.zb):
-            self.a(f"\tv_cmp_lt_f32_e64 {S_M[j]}, {A[j]}, {B[j]}")
-        self.mask_gap()
-        for j in range(self.zb):
-            self.a(f"\tv_cndmask_b32_e64 {R[j]}, {R[j]}, -1.0, {S_M[j]}")
+        self.mask_pass(lambda j, m: f"v_cmp_gt_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {V_QNAN}, 1.0, {m}")
+        self.mask_pass(lambda j, m: f"v_cmp_eq_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, 0, {m}")
+        self.mask_pass(lambda j, m: f"v_cmp_lt_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, -1.0, {m}")
 
     def f_div(self, A, B, R):
         # IEEE-correct a / b: the div_scale / rcp / fma / div_fmas / div_fixup sequence
@@ -330,20 +316,18 @@ class Interp:
                 a(f"\tv_mul_f32 {VT[j]}, {F(j)}, {F(j)}")
             return self.write_out(VT)
         if op == "NOT":
-            self.read_a(VT)
-            self.idx_off()
-            for j in Z:
-                a(f"\tv_cmp_eq_f32_e64 {S_M[j]}, 0, {VT[j]}")
-            self.mask_gap()
-            for j in Z:
-                a(f"\tv_cndmask_b32_e64 {VU[j]}, 0, 1.0, {S_M[j]}")
-            return self.write_out(VU)
+            def body():
+                self.read_a(VT)
+                self.idx_off()
+                self.mask_pass(lambda j, m: f"v_cmp_eq_f32_e64 {m}, 0, {VT[j]}", lambda j, m: f"v_cndmask_b32_e64 {VU[j]}, 0, 1.0, {m}")
+                self.write_out(VU)
+            return body() if zb <= 4 else self.out_of_line("not", body)
         if op in ("RECIP", "SQRT", "ROUND"):
             def body(op=op):
                 self.read_a(VT)
                 self.idx_off()
                 if op == "RECIP":
-                    one = ["1.0"] * 4
+                    one = ["1.0"] * 8
                     self.f_div(one, VT, VU)
                 elif op == "SQRT":
                     self.f_sqrt(VT, VU)
@@ -430,33 +414,42 @@ class Interp:
                 a(f"\tglobal_load_dword {VT[j]}, {VOFF[j]}, {S_PC}")
             a("\ts_waitcnt vmcnt(0)")
             return self.write_out(VT)
-        # columns: the slot is bound to x, y, z or a constant (FhRender::in_kind / in_value)
-        lx, ly, lz, done = (a.label("in_x"), a.label("in_y"), a.label("in_z"), a.label("in_done"))
+        # columns: the slot is x, y or z (model coordinates of the ZB voxels of this pass, computed
+        # here: ((m[4r] x + m[4r+1] y) + m[4r+2] z) + m[4r+3], dev_ops.hpp xf_point) or a bound constant
+        lab = {k: a.label("in_" + k) for k in ("x", "y", "z", "done")}
+        m = S_MAT
         a(f"""
+	s_cmp_eq_u32 {S_W1}, {S_SLOTX}
+	s_cbranch_scc1 {lab['x']}
+	s_cmp_eq_u32 {S_W1}, {S_SLOTY}
+	s_cbranch_scc1 {lab['y']}
+	s_cmp_eq_u32 {S_W1}, {S_SLOTZ}
+	s_cbranch_scc1 {lab['z']}
 	s_lshl_b32 {S_T0}, {S_W1}, 2
 	s_add_u32 s86, s4, {S_T0}
 	s_addc_u32 s87, s5, 0
-	s_load_dword {S_T0}, {S_PC}, {self.off['P.in_kind']}
 	s_load_dword {S_T1}, {S_PC}, {self.off['P.in_value']}
-	s_waitcnt lgkmcnt(0)
-	s_cmp_eq_u32 {S_T0}, 0
-	s_cbranch_scc1 {lx}
-	s_cmp_eq_u32 {S_T0}, 1
-	s_cbranch_scc1 {ly}
-	s_cmp_eq_u32 {S_T0}, 2
-	s_cbranch_scc1 {lz}""")
+	s_waitcnt lgkmcnt(0)""")
         self.idx_on(S_OUT, DST)
         for j in range(self.zb):
             a(f"\tv_mov_b32 {self.F(j)}, {S_T1}")
-        a(f"\ts_branch {done}")
-        for lab, src in ((lx, VX), (ly, VY), (lz, VZ)):
-            a(f"{lab}:")
+        a(f"\ts_branch {lab['done']}")
+        for axis, (row, acc) in (("x", (0, V_AX)), ("y", (1, V_AY)), ("z", (2, V_AZ))):
+            a(f"{lab[axis]}:")
+            for j in range(self.zb):      # z of sample j = lz + k - j
+                a(f"""
+	s_add_u32 {S_T0}, {S_LZ}, {S_K}
+	s_sub_u32 {S_T0}, {S_T0}, {j}
+	v_cvt_f32_u32 {VT[j]}, {S_T0}
+	v_mul_f32 {VT[j]}, s{m + 4 * row + 2}, {VT[j]}
+	v_add_f32 {VT[j]}, {acc}, {VT[j]}
+	v_add_f32 {VT[j]}, s{m + 4 * row + 3}, {VT[j]}""")
             self.idx_on(S_OUT, DST)
             for j in range(self.zb):
-                a(f"\tv_mov_b32 {self.F(j)}, {src[j]}")
-            if lab != lz:
-                a(f"\ts_branch {done}")
-        a(f"{done}:")
+                a(f"\tv_mov_b32 {self.F(j)}, {VT[j]}")
+            if axis != "z":
+                a(f"\ts_branch {lab['done']}")
+        a(f"{lab['done']}:")
         self.idx_off()
         a(f"\ts_branch {self.next}")
 
@@ -469,6 +462,7 @@ class Interp:
 .L{n}_run:
 	s_load_dwordx8 s[{qa}:{qa + 7}], {S_TAPE}, 0x0
 	s_load_dwordx8 s[{qb}:{qb + 7}], {S_TAPE}, 0x20
+.L{n}_go:                                ; entry for callers that have requested the tape head themselves
 	s_add_u32 s72, s44, 0x40
 	s_addc_u32 s73, s45, 0
 	s_mov_b32 {S_BATCH}, 4
@@ -526,6 +520,9 @@ class Interp:
 
 def call_interp(a, it):
     """Call the interpreter `it` as a subroutine."""
+    import os
+    if os.environ.get("FH_EXP") == "nointerp" and it.kind == "columns":   # experiment: set-up cost only
+        return
     ret = a.label("ret")
     here = a.label("pc")
     a(f"""
@@ -596,12 +593,14 @@ def handler_base(a, it):
 
 
 def gen_columns(a, variants, off):
-    """One kernel for all register-file classes: even workgroups start with the first variant,
-    odd ones with the second, and a wave whose list has run dry moves on to the other list."""
+    """fh_columns: one 8x8 pixel footprint per wave, its leaves front to back.  The register-file
+    shape is chosen per LEAF (variants = [(NR, ZB)], smallest NR first: 8 registers x 8 voxels,
+    16 x 4, 32 x 2 - all 64 VGPRs), so 80 % of the leaves take a single pass over their 8 voxels."""
     kname = "fh_columns"
     o = off
     m = S_MAT
-    nvg = FILE + max(nr * zb for nr, zb, _ in variants)
+    nvg = FILE + 64
+    its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
     kernel_header(a, kname, 8, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0""")
@@ -615,52 +614,42 @@ def gen_columns(a, variants, off):
 	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
 	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
+	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list']}
+	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count']}
+	s_load_dwordx16 s[48:63], {S_STATE}, {o['P.in_kind']}
 	v_and_b32 {V_LX}, 7, {V_LANE}
 	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
-	s_mov_b32 {S_VDONE}, 0
-	s_waitcnt lgkmcnt(0)
+	s_mov_b32 {S_SLOTX}, -1
+	s_mov_b32 {S_SLOTY}, -1
+	s_mov_b32 {S_SLOTZ}, -1
+	s_waitcnt lgkmcnt(0)""")
+    for i in range(16):   # input slot of each axis (in_kind: 0 x, 1 y, 2 z, 3 bound constant)
+        a(f"""
+	s_cmp_eq_u32 s{48 + i}, 0
+	s_cselect_b32 {S_SLOTX}, {i}, {S_SLOTX}
+	s_cmp_eq_u32 s{48 + i}, 1
+	s_cselect_b32 {S_SLOTY}, {i}, {S_SLOTY}
+	s_cmp_eq_u32 s{48 + i}, 2
+	s_cselect_b32 {S_SLOTZ}, {i}, {S_SLOTZ}""")
+    handler_base(a, its[0])
+    a(f"""
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
 	s_add_u32 {S_FW}, {S_WIDTH}, 7
 	s_lshr_b32 {S_FW}, {S_FW}, 3
-	s_bitcmp1_b32 {S_WG}, 0
-	s_cbranch_scc1 .Lfh_columns_{variants[1][0]}x{variants[1][1]}_enter""")
-    its = []
-    for vi, (nr, zb, cls) in enumerate(variants):
-        its.append(gen_columns_variant(a, nr, zb, cls, off, vi, variants))
-    a(".Lfh_columns_exit:")
-    kernel_footer(a, kname, 8, nvg, 102, True)
-    for it in its:
-        it.emit()
-    return kname, nvg
-
-
-def gen_columns_variant(a, nr, zb, cls, off, vi, variants):
-    name = f"fh_columns_{nr}x{zb}"
-    it = Interp(a, name, nr, zb, "columns", off)
-    o = off
-    m = S_MAT
-    other = variants[1 - vi]
-    a(f"""
-.L{name}_enter:
-	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list'] + 8 * cls}
-	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count'] + 4 * cls}""")
-    handler_base(a, it)
-    a(f"""
-	s_waitcnt lgkmcnt(0)
-.L{name}_outer:
-	; ---- next footprint: wi = atomicAdd(&fp_cursor[cls], 1) ------------------------------
+.Lfh_columns_outer:
+	; ---- next footprint: wi = atomicAdd(&fp_cursor[0], 1) ----------------------------------
 	v_cmp_eq_u32 vcc, 0, {V_LANE}
 	s_and_saveexec_b64 {S_SAVE}, vcc
 	v_mov_b32 {V_S0}, 1
 	v_mov_b32 {V_S1}, 0
-	global_atomic_add {V_S2}, {V_S1}, {V_S0}, {S_STATE} offset:{o['fp_cursor'] + 4 * cls} sc0
+	global_atomic_add {V_S2}, {V_S1}, {V_S0}, {S_STATE} offset:{o['fp_cursor']} sc0
 	s_waitcnt vmcnt(0)
 	s_mov_b64 exec, {S_SAVE}
 	s_nop 0
 	v_readfirstlane_b32 {S_WI}, {V_S2}
 	s_nop 3
 	s_cmp_ge_u32 {S_WI}, {S_NFP}
-	s_cbranch_scc1 .L{name}_exit
+	s_cbranch_scc1 .Lfh_columns_exit
 	s_lshl_b32 {S_T0}, {S_WI}, 2
 	s_add_u32 s86, s38, {S_T0}
 	s_addc_u32 s87, s39, 0
@@ -716,62 +705,84 @@ def gen_columns_variant(a, nr, zb, cls, off, vi, variants):
 	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
 	s_mov_b64 exec, {S_SAVE}
 	s_waitcnt vmcnt(0)
+	; the leaf records of the whole column in one round trip: lane = layer
 	v_cmp_ne_u32 vcc, 0, {V_IDS}
-	s_nop 3
+	v_add_u32 {V_S0}, -1, {V_IDS}
+	v_mov_b32 {V_S2}, 24
+	v_mul_lo_u32 {V_S0}, {V_S0}, {V_S2}
+	s_nop 1
 	s_mov_b64 {S_LAYMASK}, vcc
-.L{name}_layer:
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	global_load_dwordx3 v[60:62], {V_S0}, {S_LEAVES}
+	global_load_dword {V_RZ}, {V_S0}, {S_LEAVES} offset:20
+	s_mov_b64 exec, {S_SAVE}
+	s_waitcnt vmcnt(0)
+.Lfh_columns_layer:
 	s_cmp_eq_u64 {S_LAYMASK}, 0
-	s_cbranch_scc1 .L{name}_column_done
+	s_cbranch_scc1 .Lfh_columns_column_done
 	s_flbit_i32_b64 {S_T0}, {S_LAYMASK}
 	s_sub_u32 {S_ZL}, 63, {S_T0}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
 	s_nop 0
 	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
+	v_readlane_b32 s84, {V_ROFF}, {S_ZL}
+	v_readlane_b32 {S_LEN0}, {V_RLEN}, {S_ZL}
+	v_readlane_b32 {S_RC}, {V_RRC}, {S_ZL}
+	v_readlane_b32 {S_LZ}, {V_RZ}, {S_ZL}
 	s_nop 3
-	s_sub_u32 {S_T0}, {S_ID}, 1
-	s_mul_i32 {S_T0}, {S_T0}, 24
-	s_add_u32 s86, s32, {S_T0}
-	s_addc_u32 s87, s33, 0
-	s_load_dwordx2 {S_TBASE}, {S_PC}, 0x0
-	s_load_dword {S_LZ}, {S_PC}, 0x14
-	s_waitcnt lgkmcnt(0)
-	s_mov_b32 {S_LEN0}, s85
 	s_mov_b32 s85, 0
 	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
 	s_add_u32 s84, s84, s30
 	s_addc_u32 s85, s85, s31
+	; the head of the tape is requested now and arrives while the pass is set up
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20
 	; pending = depth < lz + 8  (voxel.rs:377-381); nothing pending: the rest is occluded too
 	s_add_u32 {S_T0}, {S_LZ}, 8
 	v_cmp_gt_u32 vcc, {S_T0}, {V_DEPTH}
 	v_mov_b32 {V_IDV}, {S_ID}
-	s_nop 3
+	s_and_b32 {S_RC}, {S_RC}, 0xffff
+	s_nop 2
 	s_mov_b64 {S_PEND}, vcc
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .L{name}_column_done
-	s_mov_b32 {S_K}, 7
-.L{name}_chunk:""")
-    for j in range(zb):
+	s_cbranch_scc1 .Lfh_columns_column_done_drain
+	s_mov_b32 {S_K}, 7""")
+    # register class of this leaf -> interpreter variant
+    for vi, it in enumerate(its[:-1]):
+        a(f"\ts_cmp_le_u32 {S_RC}, {it.nr}\n\ts_cbranch_scc1 .L{it.name}_chunk")
+    a(f"\ts_branch .L{its[-1].name}_chunk")
+    for it in its:
+        name, zb = it.name, it.zb
         a(f"""
-	s_add_u32 {S_T0}, {S_LZ}, {S_K}
-	s_sub_u32 {S_T0}, {S_T0}, {j}
-	v_cvt_f32_u32 {V_S0}, {S_T0}
-	v_mul_f32 {V_S1}, s{m + 2}, {V_S0}
-	v_add_f32 {V_S1}, {V_AX}, {V_S1}
-	v_add_f32 {VX[j]}, s{m + 3}, {V_S1}
-	v_mul_f32 {V_S1}, s{m + 6}, {V_S0}
-	v_add_f32 {V_S1}, {V_AY}, {V_S1}
-	v_add_f32 {VY[j]}, s{m + 7}, {V_S1}
-	v_mul_f32 {V_S1}, s{m + 10}, {V_S0}
-	v_add_f32 {V_S1}, {V_AZ}, {V_S1}
-	v_add_f32 {VZ[j]}, s{m + 11}, {V_S1}
-	v_mov_b32 {VRES[j]}, 0""")
-    a(f"""
+.L{name}_chunk:
+	s_getpc_b64 {S_HBASE}
+.L{name}_hb:
+	s_add_u32 s42, s42, .L{name}_handlers - .L{name}_hb
+	s_addc_u32 s43, s43, 0""")
+        for j in range(zb):
+            a(f"\tv_mov_b32 {VRES[j]}, 0")
+        a(f"""
 	s_mov_b64 {S_TAPE}, {S_TBASE}
 	s_mov_b32 {S_LEN}, {S_LEN0}""")
-    call_interp(a, it)
-    for j in range(zb):
-        # first voxel inside, front to back: depth = lz + (k - j) + 1
+        ret, here = a.label("ret"), a.label("pc")
         a(f"""
+	s_getpc_b64 {S_RET}
+{here}:
+	s_add_u32 s74, s74, {ret} - {here}
+	s_addc_u32 s75, s75, 0
+	s_branch .L{name}_go
+{ret}:""")
+        import os
+        if os.environ.get("FH_EXP") == "nointerp":   # experiment: set-up cost only
+            a.lines[-2] = f"\ts_waitcnt lgkmcnt(0)"
+        if zb < 8:
+            # the next pass (if any) needs the head of the tape again: ask for it before the hit test
+            a(f"""
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20""")
+        for j in range(zb):
+            # first voxel inside, front to back: depth = lz + (k - j) + 1
+            a(f"""
 	v_cmp_gt_f32 vcc, 0, {VRES[j]}
 	s_add_u32 {S_T0}, {S_LZ}, {S_K}
 	s_add_u32 {S_T0}, {S_T0}, {1 - j}
@@ -780,26 +791,33 @@ def gen_columns_variant(a, nr, zb, cls, off, vi, variants):
 	s_andn2_b64 {S_PEND}, {S_PEND}, {S_M[0]}
 	v_cndmask_b32_e64 {V_DEPTH}, {V_DEPTH}, {V_S0}, {S_M[0]}
 	v_cndmask_b32_e64 {V_HIT}, {V_HIT}, {V_IDV}, {S_M[0]}""")
-    a(f"""
+        if zb < 8:
+            a(f"""
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .L{name}_layer
+	s_cbranch_scc1 .Lfh_columns_layer_drain
 	s_sub_u32 {S_K}, {S_K}, {zb}
 	s_cbranch_scc0 .L{name}_chunk
-	s_branch .L{name}_layer
-.L{name}_column_done:
+	s_branch .Lfh_columns_layer_drain""")
+        else:
+            a("\ts_branch .Lfh_columns_layer")
+    a(f"""
+.Lfh_columns_layer_drain:
+	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
+	s_branch .Lfh_columns_layer
+.Lfh_columns_column_done_drain:
+	s_waitcnt lgkmcnt(0)
+.Lfh_columns_column_done:
 	v_cmp_ne_u32 vcc, 0, {V_HIT}
 	s_and_saveexec_b64 {S_SAVE}, vcc
 	global_store_dwordx2 {V_PIX}, v[4:5], off
 	s_mov_b64 exec, {S_SAVE}
 	s_nop 1
-	s_branch .L{name}_outer
-.L{name}_exit:
-	; this list is exhausted: go on with the other one, once
-	s_bitset1_b32 {S_VDONE}, {vi}
-	s_bitcmp1_b32 {S_VDONE}, {1 - vi}
-	s_cbranch_scc0 .Lfh_columns_{other[0]}x{other[1]}_enter
-	s_branch .Lfh_columns_exit""")
-    return it
+	s_branch .Lfh_columns_outer
+.Lfh_columns_exit:""")
+    kernel_footer(a, kname, 8, nvg, 102, True)
+    for it in its:
+        it.emit()
+    return kname, nvg
 
 
 def gen_bulk(a, nr, zb, off):
@@ -866,7 +884,7 @@ def main():
     a = Asm()
     a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
     ks = []
-    n, nvg = gen_columns(a, ((16, 4, 0), (32, 2, 1)), off)
+    n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
     ks.append((n, 8, nvg, [(8, "global_buffer")]))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)

@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
 
 // Footprint classification for the 3D column kernels: a footprint goes to the variant that
 // fits the largest register count among its leaves (class 0: <= 16, 1: <= 32, 2: LDS).
-__global__ void k_classify3d(FhRenderState* S) {
+__global__ void k_classify3d(FhRenderState* S, int merge01) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
@@ -890,7 +890,8 @@ __global__ void k_classify3d(FhRenderState* S) {
         if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
     }
     // one atomic per wave and class instead of one per footprint
-    const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= 32 ? 1 : 2));
+    // merge01: the assembly leaf kernel picks the register-file shape per leaf, one list for <= 32 registers
+    const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= 32 ? (merge01 ? 0 : 1) : 2));
     const int lane = threadIdx.x & (WAVE - 1);
     for (int c = 0; c < 3; c++) {
         const uint64_t m = ballot(cls == c);

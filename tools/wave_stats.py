@@ -19,3 +19,9 @@ for k, v in hip.wave_stats().items():
     print(k, json.dumps(v))
 print(hip.tile_phases)
 print(hip.counters())
+lv = hip.last_leaves()
+import numpy as np
+print("leaves of the last slab:", len(lv), "mean len", lv["len"].mean(), "mean regs", lv["regs"].mean())
+for q in (4, 6, 8, 12, 16, 24, 32):
+    print(f"  regs <= {q}: {(lv['regs'] <= q).mean() * 100:.1f} %   len <= {q}: {(lv['len'] <= q).mean() * 100:.1f} %")
+print("  len percentiles 50/90/99/max:", np.percentile(lv["len"], [50, 90, 99, 100]))
