@@ -593,17 +593,26 @@ def handler_base(a, it):
 
 
 def gen_columns(a, variants, off):
-    """fh_columns: one 8x8 pixel footprint per wave, its leaves front to back.  The register-file
-    shape is chosen per LEAF (variants = [(NR, ZB)], smallest NR first: 8 registers x 8 voxels,
-    16 x 4, 32 x 2 - all 64 VGPRs), so 80 % of the leaves take a single pass over their 8 voxels."""
+    """fh_columns: ONE leaf (8x8x8 voxels, one pixel column per lane) per wave pass.  Waves walk the
+    leaf table [layer][footprint] front layer first, 64 footprints at a time, round robin without atomics;
+    hits go to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so any interleaving of the
+    waves gives the same image, and leaves behind a hit usually find it and retire after one load.
+    The register-file shape is chosen per leaf (variants = [(NR, ZB)], smallest NR first: 8 registers
+    x 8 voxels, 16 x 4, 32 x 2 - all 64 VGPRs): 80 % of prospero's leaves take a single pass.
+    kernarg: { FhRenderState* S; u32 n_waves; u32 pad }"""
     kname = "fh_columns"
     o = off
     m = S_MAT
     nvg = FILE + 64
     its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
-    kernel_header(a, kname, 8, nvg)
+    S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
+    BLKL = 2            # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast)
+    BLK = 1 << BLKL
+    kernel_header(a, kname, 16, nvg)
     a(f"""
-	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0""")
+	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
+	s_load_dword {S_NWG}, {S_KERNARG}, 0x8
+	s_mov_b32 {S_WGID}, s2""")
     common_consts(a)
     a(f"""
 	s_waitcnt lgkmcnt(0)
@@ -612,10 +621,8 @@ def gen_columns(a, variants, off):
 	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.tiles']}
 	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
 	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
-	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
-	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list']}
-	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count']}
+	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
 	s_load_dwordx16 s[48:63], {S_STATE}, {o['P.in_kind']}
 	v_and_b32 {V_LX}, 7, {V_LANE}
 	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
@@ -631,48 +638,92 @@ def gen_columns(a, variants, off):
 	s_cselect_b32 {S_SLOTY}, {i}, {S_SLOTY}
 	s_cmp_eq_u32 s{48 + i}, 2
 	s_cselect_b32 {S_SLOTZ}, {i}, {S_SLOTZ}""")
-    handler_base(a, its[0])
     a(f"""
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
-	s_add_u32 {S_FW}, {S_WIDTH}, 7
-	s_lshr_b32 {S_FW}, {S_FW}, 3
-.Lfh_columns_outer:
-	; ---- next footprint: wi = atomicAdd(&fp_cursor[0], 1) ----------------------------------
-	v_cmp_eq_u32 vcc, 0, {V_LANE}
-	s_and_saveexec_b64 {S_SAVE}, vcc
-	v_mov_b32 {V_S0}, 1
-	v_mov_b32 {V_S1}, 0
-	global_atomic_add {V_S2}, {V_S1}, {V_S0}, {S_STATE} offset:{o['fp_cursor']} sc0
-	s_waitcnt vmcnt(0)
-	s_mov_b64 exec, {S_SAVE}
-	s_nop 0
-	v_readfirstlane_b32 {S_WI}, {V_S2}
-	s_nop 3
-	s_cmp_ge_u32 {S_WI}, {S_NFP}
+	s_mov_b32 {S_L}, {S_LAYERS}
+	; footprints per layer, blocks of {BLK} of them
+	s_add_u32 {S_T0}, {S_WIDTH}, 7
+	s_lshr_b32 {S_T0}, {S_T0}, 3
+	s_add_u32 {S_T1}, {S_HEIGHT}, 7
+	s_lshr_b32 {S_T1}, {S_T1}, 3
+	s_mul_i32 {S_NFPL}, {S_T0}, {S_T1}
+	s_add_u32 {S_CNT}, {S_NFPL}, {BLK - 1}
+	s_lshr_b32 {S_CNT}, {S_CNT}, {BLKL}
+	; work items = (layer, block), front layer first; wave w takes items w, w + n_waves, ...
+	s_sub_u32 {S_L}, {S_L}, 1
+	s_mov_b32 {S_I}, {S_WGID}
+.Lfh_columns_block:
+	; ---- next block of {BLK} footprints (lane = footprint) --------------------------------------
+	s_cmp_ge_u32 {S_I}, {S_CNT}
+	s_cbranch_scc0 .Lfh_columns_haveblock
+	s_sub_u32 {S_I}, {S_I}, {S_CNT}
+	s_sub_u32 {S_L}, {S_L}, 1
 	s_cbranch_scc1 .Lfh_columns_exit
-	s_lshl_b32 {S_T0}, {S_WI}, 2
-	s_add_u32 s86, s38, {S_T0}
-	s_addc_u32 s87, s39, 0
-	s_load_dword {S_T0}, {S_PC}, 0x0
-	s_waitcnt lgkmcnt(0)
-	s_and_b32 {S_FX}, {S_T0}, 0xffff
-	s_lshr_b32 {S_FY}, {S_T0}, 16
-	; column of leaf ids: leaf_table + ((fy * fw + fx) * layers) * 4, one layer per lane
-	s_mul_i32 {S_T0}, {S_FY}, {S_FW}
-	s_add_u32 {S_T0}, {S_T0}, {S_FX}
-	s_mul_i32 {S_T0}, {S_T0}, {S_LAYERS}
-	s_lshl_b32 {S_T0}, {S_T0}, 2
-	s_add_u32 s86, s34, {S_T0}
+	s_branch .Lfh_columns_block
+.Lfh_columns_haveblock:
+	; rotate the block index by a per-layer offset: with a round-robin stride equal to the number of
+	; blocks a wave would otherwise own the same footprints in every layer (no balance at all)
+	s_mul_i32 {S_T0}, {S_L}, 1237
+	s_add_u32 {S_T0}, {S_T0}, {S_I}
+.Lfh_columns_rot:
+	s_cmp_ge_u32 {S_T0}, {S_CNT}
+	s_cbranch_scc0 .Lfh_columns_rotated
+	s_sub_u32 {S_T0}, {S_T0}, {S_CNT}
+	s_branch .Lfh_columns_rot
+.Lfh_columns_rotated:
+	s_lshl_b32 {S_T0}, {S_T0}, {BLKL}
+	s_add_u32 {S_I}, {S_I}, {S_NWG}
+	v_add_u32 {V_S0}, {S_T0}, {V_LANE}
+	v_cmp_gt_u32 vcc, {S_NFPL}, {V_S0}
+	v_cmp_gt_u32_e64 {S_M[0]}, {BLK}, {V_LANE}
+	s_nop 3
+	s_and_b64 vcc, vcc, {S_M[0]}
+	s_mul_i32 {S_T1}, {S_L}, {S_NFPL}
+	s_add_u32 {S_T1}, {S_T1}, {S_T0}
+	s_lshl_b32 {S_T1}, {S_T1}, 2
+	s_add_u32 s86, s34, {S_T1}
 	s_addc_u32 s87, s35, 0
 	v_lshlrev_b32 {V_S0}, 2, {V_LANE}
 	v_mov_b32 {V_IDS}, 0
-	v_cmp_gt_u32 vcc, {S_LAYERS}, {V_LANE}
 	s_and_saveexec_b64 {S_SAVE}, vcc
 	global_load_dword {V_IDS}, {V_S0}, {S_PC}
 	s_mov_b64 exec, {S_SAVE}
-	; pixel of this lane
-	s_lshl_b32 {S_FX}, {S_FX}, 3
-	s_lshl_b32 {S_FY}, {S_FY}, 3
+	s_waitcnt vmcnt(0)
+	v_cmp_ne_u32 vcc, 0, {V_IDS}
+	s_nop 3
+	s_mov_b64 {S_LAYMASK}, vcc
+.Lfh_columns_leaf:
+	; ---- next leaf of the block ---------------------------------------------------------------
+	s_cmp_eq_u64 {S_LAYMASK}, 0
+	s_cbranch_scc1 .Lfh_columns_block
+	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
+	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
+	s_nop 0
+	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
+	s_nop 3
+	s_sub_u32 {S_T0}, {S_ID}, 1
+	s_mul_i32 {S_T0}, {S_T0}, 24
+	s_add_u32 s86, s32, {S_T0}
+	s_addc_u32 s87, s33, 0
+	s_load_dwordx4 s[64:67], {S_PC}, 0x0            ; tape offset, length, regs | choices << 16, x
+	s_load_dwordx2 s[68:69], {S_PC}, 0x10           ; y, z
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 s84, s64
+	s_mov_b32 s85, 0
+	s_mov_b32 {S_LEN0}, s65
+	s_and_b32 {S_RC}, s66, 0xffff
+	s_mov_b32 {S_FX}, s67
+	s_mov_b32 {S_FY}, s68
+	s_mov_b32 {S_LZ}, s69
+	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_columns3d<2>
+	s_cbranch_scc1 .Lfh_columns_leaf
+	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
+	s_add_u32 s84, s84, s30
+	s_addc_u32 s85, s85, s31
+	; the head of the tape is requested now and arrives while the pass is set up
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20
+	; pixel of this lane, its z-buffer word
 	v_add_u32 {V_S0}, {S_FX}, {V_LX}
 	v_add_u32 {V_S1}, {S_FY}, {V_LY}
 	v_cvt_f32_u32 {V_PXF}, {V_S0}
@@ -686,6 +737,13 @@ def gen_columns(a, variants, off):
 	v_mov_b32 {V_S3}, s37
 	v_add_co_u32 v2, vcc, s36, v2
 	v_addc_co_u32 v3, vcc, {V_S3}, v3, vcc
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	v_mov_b32 {V_DEPTH}, -1                         ; pixels outside the image never become pending
+	v_mov_b32 {V_HIT}, 0
+	s_mov_b64 {S_SAVE}, exec
+	s_mov_b64 exec, {S_M[0]}
+	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
+	s_mov_b64 exec, {S_SAVE}
 	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
 	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
 	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
@@ -696,59 +754,17 @@ def gen_columns(a, variants, off):
 	v_mul_f32 {V_AZ}, s{m + 8}, {V_PXF}
 	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
 	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
-	; depth so far (pixels outside the image never become pending)
-	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
-	v_mov_b32 {V_DEPTH}, -1
-	v_mov_b32 {V_HIT}, 0
-	s_mov_b64 {S_SAVE}, exec
-	s_mov_b64 exec, {S_M[0]}
-	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
-	s_mov_b64 exec, {S_SAVE}
+	v_mov_b32 {V_IDV}, {S_ID}
 	s_waitcnt vmcnt(0)
-	; the leaf records of the whole column in one round trip: lane = layer
-	v_cmp_ne_u32 vcc, 0, {V_IDS}
-	v_add_u32 {V_S0}, -1, {V_IDS}
-	v_mov_b32 {V_S2}, 24
-	v_mul_lo_u32 {V_S0}, {V_S0}, {V_S2}
-	s_nop 1
-	s_mov_b64 {S_LAYMASK}, vcc
-	s_and_saveexec_b64 {S_SAVE}, vcc
-	global_load_dwordx3 v[60:62], {V_S0}, {S_LEAVES}
-	global_load_dword {V_RZ}, {V_S0}, {S_LEAVES} offset:20
-	s_mov_b64 exec, {S_SAVE}
-	s_waitcnt vmcnt(0)
-.Lfh_columns_layer:
-	s_cmp_eq_u64 {S_LAYMASK}, 0
-	s_cbranch_scc1 .Lfh_columns_column_done
-	s_flbit_i32_b64 {S_T0}, {S_LAYMASK}
-	s_sub_u32 {S_ZL}, 63, {S_T0}
-	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
-	s_nop 0
-	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
-	v_readlane_b32 s84, {V_ROFF}, {S_ZL}
-	v_readlane_b32 {S_LEN0}, {V_RLEN}, {S_ZL}
-	v_readlane_b32 {S_RC}, {V_RRC}, {S_ZL}
-	v_readlane_b32 {S_LZ}, {V_RZ}, {S_ZL}
-	s_nop 3
-	s_mov_b32 s85, 0
-	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
-	s_add_u32 s84, s84, s30
-	s_addc_u32 s85, s85, s31
-	; the head of the tape is requested now and arrives while the pass is set up
-	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
-	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20
-	; pending = depth < lz + 8  (voxel.rs:377-381); nothing pending: the rest is occluded too
+	; pending = depth < lz + 8  (voxel.rs:377-381)
 	s_add_u32 {S_T0}, {S_LZ}, 8
 	v_cmp_gt_u32 vcc, {S_T0}, {V_DEPTH}
-	v_mov_b32 {V_IDV}, {S_ID}
-	s_and_b32 {S_RC}, {S_RC}, 0xffff
-	s_nop 2
+	s_nop 3
 	s_mov_b64 {S_PEND}, vcc
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .Lfh_columns_column_done_drain
+	s_cbranch_scc1 .Lfh_columns_leaf_drain
 	s_mov_b32 {S_K}, 7""")
-    # register class of this leaf -> interpreter variant
-    for vi, it in enumerate(its[:-1]):
+    for it in its[:-1]:
         a(f"\ts_cmp_le_u32 {S_RC}, {it.nr}\n\ts_cbranch_scc1 .L{it.name}_chunk")
     a(f"\ts_branch .L{its[-1].name}_chunk")
     for it in its:
@@ -772,9 +788,6 @@ def gen_columns(a, variants, off):
 	s_addc_u32 s75, s75, 0
 	s_branch .L{name}_go
 {ret}:""")
-        import os
-        if os.environ.get("FH_EXP") == "nointerp":   # experiment: set-up cost only
-            a.lines[-2] = f"\ts_waitcnt lgkmcnt(0)"
         if zb < 8:
             # the next pass (if any) needs the head of the tape again: ask for it before the hit test
             a(f"""
@@ -794,27 +807,24 @@ def gen_columns(a, variants, off):
         if zb < 8:
             a(f"""
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .Lfh_columns_layer_drain
+	s_cbranch_scc1 .Lfh_columns_leaf_done
 	s_sub_u32 {S_K}, {S_K}, {zb}
 	s_cbranch_scc0 .L{name}_chunk
-	s_branch .Lfh_columns_layer_drain""")
+	s_branch .Lfh_columns_leaf_done""")
         else:
-            a("\ts_branch .Lfh_columns_layer")
+            a("\ts_branch .Lfh_columns_leaf_done")
     a(f"""
-.Lfh_columns_layer_drain:
-	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
-	s_branch .Lfh_columns_layer
-.Lfh_columns_column_done_drain:
-	s_waitcnt lgkmcnt(0)
-.Lfh_columns_column_done:
+.Lfh_columns_leaf_done:
+	; z-buffer word = max(word, depth << 32 | leaf) for the lanes that were hit
 	v_cmp_ne_u32 vcc, 0, {V_HIT}
 	s_and_saveexec_b64 {S_SAVE}, vcc
-	global_store_dwordx2 {V_PIX}, v[4:5], off
+	global_atomic_umax_x2 {V_PIX}, v[4:5], off
 	s_mov_b64 exec, {S_SAVE}
-	s_nop 1
-	s_branch .Lfh_columns_outer
+.Lfh_columns_leaf_drain:
+	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
+	s_branch .Lfh_columns_leaf
 .Lfh_columns_exit:""")
-    kernel_footer(a, kname, 8, nvg, 102, True)
+    kernel_footer(a, kname, 16, nvg, 102, True)
     for it in its:
         it.emit()
     return kname, nvg
@@ -885,7 +895,7 @@ def main():
     a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
     ks = []
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
-    ks.append((n, 8, nvg, [(8, "global_buffer")]))
+    ks.append((n, 16, nvg, [(8, "global_buffer"), (4, "by_value"), (4, "by_value")]))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))

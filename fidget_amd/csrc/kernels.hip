@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 S->leaves[lb + slot] = lf;
                 if (IS3D) {
                     const uint32_t layers = P.tiles[0] / T;
-                    S->leaf_table[((size_t)(cy / T) * ntx + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
+                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
                 }
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
                 const uint32_t layers = P.tiles[0] / T;
-                S->leaf_table[((size_t)(cy / T) * ntx + cx / T) * layers + (cz % P.tiles[0]) / T] = lb + slot + 1;
+                S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
     }
@@ -882,11 +882,11 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.tiles[0] / T;
     const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t* col = S->leaf_table + (size_t)fi * layers;
+    const uint32_t* col = S->leaf_table + fi;  // [layer][footprint]
     uint32_t mx = 0;
     bool any = false;
     for (uint32_t l = 0; l < layers && fi < fw * fh; l++) {
-        const uint32_t id = col[l];
+        const uint32_t id = col[(size_t)l * fw * fh];
         if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
     }
     // one atomic per wave and class instead of one per footprint
@@ -926,14 +926,15 @@ __global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
         if (wi >= n_fp) break;
         const uint32_t fxy = uni(S->fp_list[CLS][wi]);
         const uint32_t fx = fxy & 0xFFFFu, fy = fxy >> 16;
-        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)(fy * fw + fx) * layers);
+        const uint32_t fhh = (P.height + T - 1) / T;
+        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)(fy * fw + fx));  // [layer][footprint]
         const uint32_t px = fx * T + (lane % T), py = fy * T + (lane / T);
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
         uint32_t depth = inimg ? (uint32_t)(S->zbuf[pix] >> 32) : 0xFFFFFFFFu;
         uint32_t hit_leaf = 0;
         for (int zl = (int)layers - 1; zl >= 0; zl--) {
-            const uint32_t id = col[zl];
+            const uint32_t id = col[(size_t)zl * fw * fhh];
             if (id == 0) continue;
             const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[id - 1];
             const uint32_t lz = lf.z;

@@ -91,7 +91,7 @@ struct FhRenderState {
     // leaves
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
-    uint32_t* leaf_table;   // 3D: [footprint][layer] -> leaf id + 1
+    uint32_t* leaf_table;   // 3D: [layer][footprint] -> leaf id + 1 (layer = 8-voxel layer of the slab)
     // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
     uint32_t* fp_list[3];
     uint32_t fp_count[3], fp_cursor[3];
