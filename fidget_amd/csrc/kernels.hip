@@ -980,11 +980,9 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     const uint32_t n_all = BIG ? S->fp_count[2] : S->fp_count[0] + S->fp_count[1];
-    for (;;) {
-        uint32_t wi = 0;
-        if (lane == 0) wi = atomicAdd(BIG ? &S->normal_cursor_big : &S->normal_cursor, 1u);
-        wi = uni(wi);
-        if (wi >= n_all) break;
+    // static round robin: an atomic cursor per footprint would cost more than the work (most
+    // footprints have no pending hit)
+    for (uint32_t wi = blockIdx.x; wi < n_all; wi += gridDim.x) {
         uint32_t fi;
         if (BIG) fi = S->fp_list[2][wi];
         else if (wi < S->fp_count[0]) fi = S->fp_list[0][wi];
