@@ -716,7 +716,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         launch(ctx, FHIP_K_TILES, [&] {
             // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
             // the prune runs as one wave per child (fh_prune1)
-            const bool exp = R.prune1 && (uint32_t)level < R.S.pre_levels;
+            static const uint32_t p1_levels = getenv("FHIP_PRUNE1_LEVELS") ? (uint32_t)atoi(getenv("FHIP_PRUNE1_LEVELS")) : 1u;  // level 0 only: 8 parents, 6363-op tape (measured)
+            const bool exp = R.prune1 && (uint32_t)level < std::min(R.S.pre_levels, p1_levels);
             struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags; } ka;
             ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
             if (level > 0) {
