@@ -122,7 +122,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
                          (const void*)k_tiles<false, false, true, 64>, (const void*)k_tiles<false, true, true, 64>,
                          (const void*)k_tiles<true, false, true, 64>, (const void*)k_tiles<true, true, true, 64>,
                          (const void*)k_pixels2d<0, false>, (const void*)k_pixels2d<0, true>,
-                         (const void*)k_columns3d<2, 0, 1, false>, (const void*)k_columns3d<2, 0, 1, true>,
+                         (const void*)k_leaves3d<2, 0, 1, false>, (const void*)k_leaves3d<2, 0, 1, true>,
                          (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     if (hipModuleLoadData(&c->asm_mod, fh_interp_co) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
@@ -889,16 +889,16 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * 16, 0};
                 (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
             } else if (R.full) {
-                hipLaunchKernelGGL((k_columns3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
-                hipLaunchKernelGGL((k_columns3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
             } else {
-                hipLaunchKernelGGL((k_columns3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
-                hipLaunchKernelGGL((k_columns3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
             if (P.max_regs > 32) {
                 const int g = blocks_for(ctx, R.lds_points_big, 16);
-                if (R.full) hipLaunchKernelGGL((k_columns3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-                else hipLaunchKernelGGL((k_columns3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
             }
         });
         launch(ctx, FHIP_K_NORMALS, [&] {

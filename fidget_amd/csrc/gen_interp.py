@@ -12,7 +12,7 @@ Kernels emitted (f32 point evaluation of a tape, fidget-core/src/vm/mod.rs:788-1
 bit-exact with the C++ kernels in kernels.hip which they replace on their fast path):
 
   fh_columns_{NR}x{ZB}     3D leaf stage: one 8x8 pixel footprint per wave, leaves front to
-                           back, ZB voxels per lane per pass (same algorithm as k_columns3d)
+                           back, ZB voxels per lane per pass (same algorithm as k_leaves3d)
   fh_float_eval_{NR}x{ZB}  BulkEvaluator<f32>: 64*ZB samples per wave
 
 NR = registers of the VGPR register file, ZB = samples per lane.  The file occupies
@@ -715,7 +715,7 @@ def gen_columns(a, variants, off):
 	s_mov_b32 {S_FX}, s67
 	s_mov_b32 {S_FY}, s68
 	s_mov_b32 {S_LZ}, s69
-	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_columns3d<2>
+	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_leaves3d<2>
 	s_cbranch_scc1 .Lfh_columns_leaf
 	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
 	s_add_u32 s84, s84, s30

@@ -897,64 +897,51 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
     }
 }
 
-// 3D leaves: one 8x8 pixel footprint per wave; its leaf tiles are visited front to back and
-// each leaf front to back in z (ZB voxels per lane at a time), lanes dropping out once their
-// column has been hit or is occluded (voxel.rs:359-463).
+// 3D leaves in HIP (tapes outside the assembly opcode set, or needing the LDS register file): ONE
+// leaf (8x8x8 voxels, one pixel column per lane) per wave pass, static round robin over the slab's
+// leaves; the voxels of a column front to back, ZB per lane at a time (voxel.rs:359-463).  Hits go
+// to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so the order in which waves reach
+// the leaves of one column does not matter; a leaf whose pixels are all hit in front of it retires
+// after one load.  CLS: leaves of <= 16 registers, 17..32, more (LDS register file).
 template <int CLS, int NR, int ZB, bool FULL>
-__global__ void __launch_bounds__(WAVE) k_columns3d(FhRenderState* S) {
+__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[P.n_levels - 1];  // T*T == 64 lanes
-    const uint32_t fw = (P.width + T - 1) / T;
-    const uint32_t layers = P.tiles[0] / T;
     Mat4 mat;
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
-    const uint32_t n_fp = S->fp_count[CLS];
-    WaveProbe probe(S, 5 + (CLS ? 1 : 0));
-    for (;;) {
-        uint32_t wi = 0;
-        if (lane == 0) wi = atomicAdd(&S->fp_cursor[CLS], 1u);
-        wi = uni(wi);
-        if (wi >= n_fp) break;
-        const uint32_t fxy = uni(S->fp_list[CLS][wi]);
-        const uint32_t fx = fxy & 0xFFFFu, fy = fxy >> 16;
-        const uint32_t fhh = (P.height + T - 1) / T;
-        const AS4 uint32_t* col = (const AS4 uint32_t*)(S->leaf_table + (size_t)(fy * fw + fx));  // [layer][footprint]
-        const uint32_t px = fx * T + (lane % T), py = fy * T + (lane / T);
+    const uint32_t n_leaves = min(S->n_leaves, S->leaf_cap);
+    for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
+        const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
+        const uint32_t regs = lf.tape.n_regs;
+        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= 32)) continue;
+        const uint32_t px = lf.x + (lane % T), py = lf.y + (lane / T), lz = lf.z;
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
         uint32_t depth = inimg ? (uint32_t)(S->zbuf[pix] >> 32) : 0xFFFFFFFFu;
-        uint32_t hit_leaf = 0;
-        for (int zl = (int)layers - 1; zl >= 0; zl--) {
-            const uint32_t id = col[(size_t)zl * fw * fhh];
-            if (id == 0) continue;
-            const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[id - 1];
-            const uint32_t lz = lf.z;
-            bool pending = depth < lz + T;  // voxel.rs:377-381
-            if (ballot(pending) == 0) break;  // everything behind is occluded as well
-            const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
-            const uint32_t len = lf.tape.len;
-            probe.units++;
-            for (int k = (int)T - 1; k >= 0; k -= ZB) {
-                float x[ZB], y[ZB], z[ZB], res[ZB];
-                FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
-                if (NR) run_points<(NR ? NR : 1), ZB, FULL>(tape, len, P, x, y, z, res);
-                else res[0] = run_points_lds<FULL>(tape, len, P, (float*)smem, lane, x[0], y[0], z[0]);
-                FOR_Z {
-                    if (pending && res[j] < 0.0f) {  // first voxel inside, front to back
-                        depth = lz + (uint32_t)(k - j) + 1;
-                        hit_leaf = id;
-                        pending = false;
-                    }
+        bool pending = depth < lz + T;  // voxel.rs:377-381
+        if (ballot(pending) == 0) continue;
+        const ctape_t tape = (ctape_t)(S->arena + lf.tape.off);
+        const uint32_t len = lf.tape.len;
+        bool hit = false;
+        for (int k = (int)T - 1; k >= 0; k -= ZB) {
+            float x[ZB], y[ZB], z[ZB], res[ZB];
+            FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
+            if (NR) run_points<(NR ? NR : 1), ZB, FULL>(tape, len, P, x, y, z, res);
+            else res[0] = run_points_lds<FULL>(tape, len, P, (float*)smem, lane, x[0], y[0], z[0]);
+            FOR_Z {
+                if (pending && res[j] < 0.0f) {  // first voxel inside, front to back
+                    depth = lz + (uint32_t)(k - j) + 1;
+                    hit = true;
+                    pending = false;
                 }
-                if (ballot(pending) == 0) break;
             }
+            if (ballot(pending) == 0) break;
         }
-        if (hit_leaf) S->zbuf[pix] = ((uint64_t)depth << 32) | hit_leaf;
+        if (hit) atomicMax((unsigned long long*)&S->zbuf[pix], ((unsigned long long)depth << 32) | (li + 1));
     }
-    probe.done(lane);
 }
 
 // Normals for the hits of this slab: gradient of the winning leaf's tape at the voxel one
