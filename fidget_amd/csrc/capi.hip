@@ -456,7 +456,7 @@ struct RenderSetup {
     FhRenderState S;
     std::vector<FhGroup> roots;
     uint32_t n_slabs = 1;
-    size_t lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
+    size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
@@ -511,6 +511,8 @@ static bool tape_is_full(const fh::HostTape& t) {
     return false;
 }
 
+// medium LDS layout of the tile stage (pre-pass levels below the root): 48 KB, three waves per CU
+static const uint32_t MID_REGS = 64, MID_CHOICES = 768;
 static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {
     size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL + 256;
     return (b + 15) & ~(size_t)15;
@@ -550,6 +552,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
     R.lds_tiles_small = tiles_lds(SMALL_REGS, SMALL_CHOICES, TL);
+    R.lds_tiles_mid = tiles_lds(MID_REGS, MID_CHOICES, TL);
     R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
     R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
     R.lds_normals_small = (size_t)32 * WAVE * 16;
@@ -718,13 +721,25 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // the prune runs as one wave per child (fh_prune1)
             static const uint32_t p1_levels = getenv("FHIP_PRUNE1_LEVELS") ? (uint32_t)atoi(getenv("FHIP_PRUNE1_LEVELS")) : 1u;  // level 0 only: 8 parents, 6363-op tape (measured)
             const bool exp = R.prune1 && (uint32_t)level < std::min(R.S.pre_levels, p1_levels);
-            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags; } ka;
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
             ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
+            ka.skip_regs = ka.skip_choices = 0;
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
             }
-            ka.big = 1; ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
+            ka.big = 1;
+            // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
+            // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
+            // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
+            const bool mid = level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !getenv("FHIP_NO_MID");
+            if (mid) {
+                const int gm = blocks_for(ctx, R.lds_tiles_mid, 8);
+                ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
+                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid);
+                ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
+            }
+            ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};

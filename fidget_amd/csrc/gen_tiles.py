@@ -13,7 +13,9 @@ Per FhSlot (one parent tile, one child per lane), exactly what k_teval3d (kernel
 Dispatch is threaded (`s_setpc_b64` into 128-byte handler slots); the tape is fetched through
 the scalar cache, 4 ops per load, double buffered.  Emitted by gen_interp.py.
 
-kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 flags }
+kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 flags;
+           u32 skip_regs; u32 skip_choices }   slots whose tape exceeds (max_regs, max_choices) or fits
+         (skip_regs, skip_choices) are left to the launch with the matching LDS layout
          flags bit 0: phase probes; bit 1: export mode for the long tapes of the pre-pass levels (choice words go
          to S->chw[big][slot][word][lane], pruned lanes are only marked, fh_prune1 sweeps them one per wave)
 LDS    : regs [max_regs][64] x 8 B | choice words [(max_choices+15)/16][64] x 4 B | map [max_regs][64] x 1 B
@@ -59,6 +61,7 @@ S_SAVE = "s[88:89]"
 S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]
 S_T2, S_T3 = "s98", "s99"
 S_STAGED = "s13"
+S_SKIPR, S_SKIPC = "s7", "s19"   # (s7 = `big` is dead after the prologue)
 S_RR = "s3"
 S_FLAGS = "s101"           # kernarg `flags`: bit 0 = probes, bit 1 = export (choices to HBM, no prune here)
 S_CHW, S_CHWSLOT, S_CHWTMP = "s[78:79]", "s[80:81]", "s[82:83]"   # export mode (the prune registers are free then)
@@ -971,6 +974,10 @@ class Tiles:
 	s_addc_u32 s43, s43, 0
 	s_waitcnt lgkmcnt(0)
 	s_min_u32 {S_NSLOTS}, {S_NSLOTS}, {S_T2}
+	s_load_dwordx2 s[76:77], {S_KERNARG}, 0x20
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 {S_SKIPR}, s76
+	s_mov_b32 {S_SKIPC}, s77
 .Lfh_tiles_outer:
 	; ---- next slot: round robin over the waves ----------------------------------------------------
 	s_cmp_ge_u32 {S_SI}, {S_NSLOTS}
@@ -1000,6 +1007,18 @@ class Tiles:
 	s_waitcnt lgkmcnt(0)
 	s_and_b32 {S_NREGS}, {S_RC}, 0xffff
 	s_lshr_b32 {S_NCH}, {S_RC}, 16
+	; is this slot for this launch's LDS layout?
+	s_cmp_gt_u32 {S_NREGS}, {S_MAXREGS}
+	s_cbranch_scc1 .Lfh_tiles_outer_drain
+	s_cmp_gt_u32 {S_NCH}, {S_MAXCH}
+	s_cbranch_scc1 .Lfh_tiles_outer_drain
+	s_cmp_le_u32 {S_NREGS}, {S_SKIPR}
+	s_cselect_b32 {S_T0}, 1, 0
+	s_cmp_le_u32 {S_NCH}, {S_SKIPC}
+	s_cselect_b32 {S_T1}, 1, 0
+	s_and_b32 {S_T0}, {S_T0}, {S_T1}
+	s_cmp_eq_u32 {S_T0}, 1
+	s_cbranch_scc1 .Lfh_tiles_outer_drain
 	s_mov_b32 s44, {S_OFF}
 	s_mov_b32 s45, 0
 	s_lshl_b64 {S_TAPE}, {S_TAPE}, 3
@@ -1157,6 +1176,9 @@ class Tiles:
 	global_store_dword {V_L4}, {V_CLEN}, {S_SLOT} offset:{SL_CLEN}
 	global_store_dword {V_L4}, {V_CRC}, {S_SLOT} offset:{SL_CRC}
 	s_branch .Lfh_tiles_outer
+.Lfh_tiles_outer_drain:
+	s_waitcnt vmcnt(0)                              ; the per-lane interval loads of the skipped slot
+	s_branch .Lfh_tiles_outer
 .Lfh_tiles_exit:
 	s_endpgm
 .Lfh_tiles_end:
@@ -1166,7 +1188,7 @@ class Tiles:
 	.amdhsa_kernel {name}
 		.amdhsa_group_segment_fixed_size 0
 		.amdhsa_private_segment_fixed_size 0
-		.amdhsa_kernarg_size 32
+		.amdhsa_kernarg_size 40
 		.amdhsa_user_sgpr_count 2
 		.amdhsa_user_sgpr_kernarg_segment_ptr 1
 		.amdhsa_system_sgpr_workgroup_id_x 1
@@ -1193,4 +1215,4 @@ class Tiles:
 def gen_tiles(a, off):
     t = Tiles(a, off)
     t.emit_kernel()
-    return t.name, 32, N_VGPR, [(8, "global_buffer")] + [(4, "by_value")] * 6
+    return t.name, 40, N_VGPR, [(8, "global_buffer")] + [(4, "by_value")] * 8
