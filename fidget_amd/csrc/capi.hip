@@ -901,7 +901,8 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             if (R.asm_points) {
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
                 // (waves pull footprints with an atomic cursor: measured faster than a static round robin)
-                struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * 16, 0};
+                static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 16u;  // per CU
+                struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
                 (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
