@@ -518,6 +518,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
+                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     const uint32_t layers = P.tiles[0] / T;
                     S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
@@ -726,6 +727,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
+                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 const uint32_t layers = P.tiles[0] / T;
                 S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
@@ -913,6 +915,7 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     const uint32_t n_leaves = min(S->n_leaves, S->leaf_cap);
+    if (CLS == 2 && S->n_leaves_lds == 0) return;
     for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
         const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
         const uint32_t regs = lf.tape.n_regs;
@@ -1024,7 +1027,7 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
             S->count_big[P0] = S->scount_big[slab];
             S->arena_head = S->arena_frame_end;
         }
-        S->n_leaves = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
+        S->n_leaves = 0; S->n_leaves_lds = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
     }
     if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.tiles[0];

@@ -91,6 +91,7 @@ struct FhRenderState {
     // leaves
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
+    uint32_t n_leaves_lds;  // 3D: leaves of this slab that need the LDS register file (> 32 registers)
     uint32_t* leaf_table;   // 3D: [layer][footprint] -> leaf id + 1 (layer = 8-voxel layer of the slab)
     // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
     uint32_t* fp_list[3];
