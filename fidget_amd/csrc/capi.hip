@@ -183,9 +183,9 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     return FHIP_OK;
 }
 // Launch one of the assembly kernels: `waves` single-wave workgroups, raw kernarg block
-static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0) {
+static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0, uint32_t grid_y = 1) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, 1, 1, WAVE, 1, 1, (unsigned)lds, ctx->stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, ctx->stream, nullptr, extra);
     if (e != hipSuccess && ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
     return e;
 }
@@ -901,9 +901,12 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             if (R.asm_points) {
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
                 // (waves pull footprints with an atomic cursor: measured faster than a static round robin)
-                static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 16u;  // per CU
+                // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
+                // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
+                static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
                 struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
-                (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
+                if (col_waves) (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
+                else (void)launch_asm(ctx, FH_ASM_COLUMNS, (R.n_footprints + 3) / 4, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16));
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);

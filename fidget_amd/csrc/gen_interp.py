@@ -544,7 +544,7 @@ def kernel_header(a, name, kernarg, next_vgpr, lds=0, wg_id=False):
 {name}:""")
 
 
-def kernel_footer(a, name, kernarg, next_vgpr, next_sgpr, wg_id):
+def kernel_footer(a, name, kernarg, next_vgpr, next_sgpr, wg_id, wg_y=False):
     a(f"""
 	s_endpgm
 .L{name}_end:
@@ -558,7 +558,7 @@ def kernel_footer(a, name, kernarg, next_vgpr, next_sgpr, wg_id):
 		.amdhsa_user_sgpr_count 2
 		.amdhsa_user_sgpr_kernarg_segment_ptr 1
 		.amdhsa_system_sgpr_workgroup_id_x {1 if wg_id else 0}
-		.amdhsa_system_sgpr_workgroup_id_y 0
+		.amdhsa_system_sgpr_workgroup_id_y {1 if wg_y else 0}
 		.amdhsa_system_sgpr_workgroup_id_z 0
 		.amdhsa_system_vgpr_workitem_id 0
 		.amdhsa_next_free_vgpr {next_vgpr}
@@ -606,13 +606,15 @@ def gen_columns(a, variants, off):
     nvg = FILE + 64
     its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
     S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
+    S_ONE, S_WGY = "s100", "s101"
     BLKL = 2            # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast)
     BLK = 1 << BLKL
     kernel_header(a, kname, 16, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
 	s_load_dword {S_NWG}, {S_KERNARG}, 0x8
-	s_mov_b32 {S_WGID}, s2""")
+	s_mov_b32 {S_WGID}, s2
+	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
     a(f"""
 	s_waitcnt lgkmcnt(0)
@@ -649,11 +651,23 @@ def gen_columns(a, variants, off):
 	s_mul_i32 {S_NFPL}, {S_T0}, {S_T1}
 	s_add_u32 {S_CNT}, {S_NFPL}, {BLK - 1}
 	s_lshr_b32 {S_CNT}, {S_CNT}, {BLKL}
-	; work items = (layer, block), front layer first; wave w takes items w, w + n_waves, ...
+	; work items = (layer, block), front layer first.  n_waves != 0: persistent waves, wave w takes
+	; items w, w + n_waves, ...; n_waves == 0: one item per workgroup of a (blocks, layers) grid -
+	; short workgroups let the hardware balance them and let the tile stage of the next slab
+	; (other stream) slip in between
 	s_sub_u32 {S_L}, {S_L}, 1
 	s_mov_b32 {S_I}, {S_WGID}
+	s_mov_b32 {S_ONE}, 0
+	s_cmp_eq_u32 {S_NWG}, 0
+	s_cbranch_scc0 .Lfh_columns_block
+	s_mov_b32 {S_ONE}, 1
+	s_sub_u32 {S_L}, {S_L}, {S_WGY}
+	s_cbranch_scc1 .Lfh_columns_exit
 .Lfh_columns_block:
 	; ---- next block of {BLK} footprints (lane = footprint) --------------------------------------
+	s_cmp_ge_u32 {S_ONE}, 2
+	s_cbranch_scc1 .Lfh_columns_exit
+	s_add_u32 {S_ONE}, {S_ONE}, {S_ONE}
 	s_cmp_ge_u32 {S_I}, {S_CNT}
 	s_cbranch_scc0 .Lfh_columns_haveblock
 	s_sub_u32 {S_I}, {S_I}, {S_CNT}
@@ -824,7 +838,7 @@ def gen_columns(a, variants, off):
 	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
 	s_branch .Lfh_columns_leaf
 .Lfh_columns_exit:""")
-    kernel_footer(a, kname, 16, nvg, 102, True)
+    kernel_footer(a, kname, 16, nvg, 102, True, wg_y=True)
     for it in its:
         it.emit()
     return kname, nvg
