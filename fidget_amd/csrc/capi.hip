@@ -134,7 +134,11 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (const char* e = getenv("FHIP_NO_SPLIT")) c->use_split = atoi(e) == 0;
     if (const char* e = getenv("FHIP_PROBE")) c->probe = atoi(e) != 0;
     if (const char* e = getenv("FHIP_NO_PIPELINE")) c->use_pipeline = atoi(e) == 0;
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
@@ -713,8 +717,14 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     } while (0)
 // 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
 static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level) {
-    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
-    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
+    // Persistent waves with a static round robin over the parents.  (FHIP_ONE_EACH_TILES=1: one short
+    // workgroup per parent instead - measured slower in the pipelined frame: the tile stage then
+    // takes more of the machine from the leaf kernel it overlaps with.)
+    const uint32_t one_each = getenv("FHIP_ONE_EACH_TILES") ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
+    const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
+    const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
+    const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
+    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
     if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {
             // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
@@ -734,7 +744,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
             const bool mid = level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !getenv("FHIP_NO_MID");
             if (mid) {
-                const int gm = blocks_for(ctx, R.lds_tiles_mid, 8);
+                const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
                 (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid);
                 ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
@@ -758,7 +768,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         if (R.full) hipLaunchKernelGGL((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
         else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
-    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, level); });
+    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
 }
 
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
