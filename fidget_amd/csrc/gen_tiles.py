@@ -999,26 +999,26 @@ class Tiles:
 	s_waitcnt lgkmcnt(0)
 	s_cmp_eq_u64 {S_ACT}, 0
 	s_cbranch_scc1 .Lfh_tiles_outer
-	s_memrealtime s[56:57]
-	s_memtime s[62:63]""")
-        for k, r in enumerate((VX[0], VX[1], VY[0], VY[1], VZ[0], VZ[1])):
-            a(f"\tglobal_load_dword {r}, {V_L4}, {S_SLOT} offset:{SL_XYZ + 256 * k}")
-        a(f"""
-	s_waitcnt lgkmcnt(0)
 	s_and_b32 {S_NREGS}, {S_RC}, 0xffff
 	s_lshr_b32 {S_NCH}, {S_RC}, 16
 	; is this slot for this launch's LDS layout?
 	s_cmp_gt_u32 {S_NREGS}, {S_MAXREGS}
-	s_cbranch_scc1 .Lfh_tiles_outer_drain
+	s_cbranch_scc1 .Lfh_tiles_outer
 	s_cmp_gt_u32 {S_NCH}, {S_MAXCH}
-	s_cbranch_scc1 .Lfh_tiles_outer_drain
+	s_cbranch_scc1 .Lfh_tiles_outer
 	s_cmp_le_u32 {S_NREGS}, {S_SKIPR}
 	s_cselect_b32 {S_T0}, 1, 0
 	s_cmp_le_u32 {S_NCH}, {S_SKIPC}
 	s_cselect_b32 {S_T1}, 1, 0
 	s_and_b32 {S_T0}, {S_T0}, {S_T1}
 	s_cmp_eq_u32 {S_T0}, 1
-	s_cbranch_scc1 .Lfh_tiles_outer_drain
+	s_cbranch_scc1 .Lfh_tiles_outer
+	s_memrealtime s[56:57]
+	s_memtime s[62:63]""")
+        for k, r in enumerate((VX[0], VX[1], VY[0], VY[1], VZ[0], VZ[1])):
+            a(f"\tglobal_load_dword {r}, {V_L4}, {S_SLOT} offset:{SL_XYZ + 256 * k}")
+        a(f"""
+	s_waitcnt lgkmcnt(0)
 	s_mov_b32 s44, {S_OFF}
 	s_mov_b32 s45, 0
 	s_lshl_b64 {S_TAPE}, {S_TAPE}, 3
