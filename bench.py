@@ -15,7 +15,8 @@ produced by exactly one rank, the others hold zeros, so the sum is bit-exact).  
 is fixed as N grows -> "strong" scaling.
 
 Prints ONE JSON line on rank 0, including
-  roofline     — for the dominant kernel (fh_columns, the assembly point interpreter): algorithmic
+  roofline     — for the dominant kernel (fh_tiles, the assembly tile-stage interpreter; a second
+                 object covers fh_columns, the leaf interpreter): algorithmic
                  bytes (8 B per tape word per wavefront pass, exact because pruning
                  is deterministic; taken from the oracle's counters) / kernel time measured
                  with HIP events on the render stream, vs the 8 TB/s HBM peak;
@@ -168,18 +169,19 @@ def main():
                     "launches_per_frame": launches, "note": note}
 
         kms, kl = result["kernel_ms_per_frame"], result["kernel_launches_per_frame"]
-        # dominant kernel by total time (profiles/: rocprofv3 --stats): the leaf kernel fh_columns
-        leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
-        leaf_launches = traffic.get("fh_columns", {}).get("launches_per_frame", 8)
-        result["roofline"] = roof("fh_columns", leaf_bytes, kms["points"], leaf_launches,
-                                  "tape words are wave-uniform loads served by the scalar cache / L2 (traffic < "
-                                  "algorithmic bytes): the kernel is bound by instruction issue, not by HBM")
+        # dominant kernel by total time (profiles/: rocprofv3 --stats): fh_tiles, the tile stage's
+        # forward-interval + prune interpreter (its time below includes fh_prune1 and the set-up /
+        # push kernels of the stage, all measured together with HIP events on the render stream)
         ops_in = sum(v["ops"] for v in tile_phases.values())
         ops_out = sum(v["ops_written"] for v in tile_phases.values())
         tile_bytes = 8.0 * (ops_in + ops_out) + st["interval_choices"] / 4.0
-        result["roofline_tiles"] = roof("fh_tiles", tile_bytes, kms["tiles"], traffic.get("fh_tiles", {}).get("launches_per_frame", 19),
-                                        "tile stage (fh_tiles + fh_prune1 + setup / push): bound by the latency of the "
-                                        "dependent op chain of the long pre-pass tapes, far from any HBM limit")
+        result["roofline"] = roof("fh_tiles", tile_bytes, kms["tiles"], traffic.get("fh_tiles", {}).get("launches_per_frame", 20),
+                                  "bound by the latency of dependent tape ops (the root tape is a 6363-op chain walked "
+                                  "by 8 waves), far from any HBM limit: see DESIGN.md section 6")
+        leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
+        result["roofline_leaf"] = roof("fh_columns", leaf_bytes, kms["points"], traffic.get("fh_columns", {}).get("launches_per_frame", 8),
+                                       "tape words are wave-uniform loads served by the scalar cache / L2: the leaf kernel "
+                                       "is bound by instruction issue, not by HBM")
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
     print(json.dumps(result))
