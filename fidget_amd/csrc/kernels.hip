@@ -1039,13 +1039,14 @@ __global__ void k_fork_state(FhRenderState* A, FhRenderState* B, FhLeaf* leaves,
     *B = *A;
     B->leaves = leaves; B->leaf_table = leaf_table;
     B->fp_list[0] = fp0; B->fp_list[1] = fp1; B->fp_list[2] = fp2;
-    const uint32_t lo = A->pre_levels ? A->arena_frame_end : A->arena_root_end;
+    const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
     const uint32_t mid = lo + (A->arena_cap - lo) / 2;
     A->arena_cap = mid;
     B->arena_frame_end = mid; B->arena_root_end = mid;
 }
 // End of the pre-pass: everything allocated so far lives for the whole frame
-__global__ void k_mark_frame(FhRenderState* S) { S->arena_frame_end = S->arena_head; }
+// (arena_head runs past arena_cap when reservations failed: failed ones are never used)
+__global__ void k_mark_frame(FhRenderState* S) { S->arena_frame_end = min(S->arena_head, S->arena_cap); }
 
 // Min-depth pyramid of the z-buffer, one workgroup per root tile: mind[l][tile] = smallest
 // depth over the tile's in-image pixels.  Feeds the occlusion test of k_tiles.

@@ -8,7 +8,7 @@ import pytest
 
 import fidget_amd as F
 import oracle as O
-from conftest import model_path
+from conftest import model_path, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -61,3 +61,25 @@ def test_render3d_bear(size):
     assert nd == 0, f"{nd} depths differ"
     err = np.abs(a["normal"] - b["normal"])
     assert err.max() <= 1e-4 * max(1.0, np.abs(b["normal"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arena_mb", [2, 8])
+def test_render3d_survives_a_full_tape_arena(arena_mb):
+    """When the tape arena runs out the children keep their parent's tape (no pruning): slower, same
+    image.  Runs in a fresh process because the arena size is read when the context is created."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        os.environ["FHIP_ARENA_MB"] = "{arena_mb}"
+        import numpy as np, fidget_amd as F, oracle as O
+        m = os.path.join({ROOT!r}, "models", "prospero.vm")
+        a = F.render3d(F.Shape.from_vm(m), 256)[0]
+        b = O.render3d(O.Shape.from_vm(m), 256)[0]
+        assert (a["depth"] == b["depth"]).all() and (a["normal"].view(np.uint32) == b["normal"].view(np.uint32)).all()
+        c = F._default_ctx.counters() if F._default_ctx else None
+        print("overflows", c["arena_overflow"] if c else "?")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
