@@ -83,3 +83,33 @@ def test_render3d_survives_a_full_tape_arena(arena_mb):
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cancel_token():
+    """render/config.rs:38-80 CancelToken: a cancelled context refuses to render (the reference returns
+    None), and renders again once reset; non-rectangular volumes and larger-than-slab counts still work."""
+    hip = F.HipContext(0)
+    s = F.Shape.from_vm(model_path("hi.vm"), hip=hip)
+    hip.cancel()
+    with pytest.raises(F.FidgetHipError) as e:
+        F.render3d(s, 64)
+    assert "cancel" in str(e.value).lower()
+    with pytest.raises(F.FidgetHipError):
+        F.render2d(s, 64)
+    hip.cancel_reset()
+    a = F.render3d(s, 64)[0]
+    b = O.render3d(O.Shape.from_vm(model_path("hi.vm")), 64)[0]
+    assert (a["depth"] == b["depth"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("whd", [(200, 120, 300), (96, 256, 64), (33, 47, 129)])
+def test_render3d_non_cubic(whd):
+    w, h, d = whd
+    p, o = both("colonnade.vm")
+    a = F.render3d(p, w, h, d)[0]
+    b = O.render3d(o, w, h, d)[0]
+    assert a.shape == b.shape == (h, w)
+    assert (a["depth"] == b["depth"]).all(), f"{(a['depth'] != b['depth']).sum()} depths differ"
+    assert same_bits_f32(a["normal"], b["normal"])
