@@ -51,7 +51,8 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves",
+    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_tape_group",
 ]
 
 
@@ -134,6 +135,8 @@ def lib():
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
+            "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
+            "fhip_tape_group": (i32, [vp, vp, u32, vp]),
             "fhip_debug_leaves": (u32, [vp, vp, u32]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
@@ -355,6 +358,20 @@ class Shape:
             lib().fhip_tape_free(self._h)
         except Exception:
             pass
+
+    def groups(self):
+        """Tape parallelism: (combining op name, [Shape of each independent sub-tape]); ('', []) if the
+        root of the function is not a min / max of many parts."""
+        n = lib().fhip_tape_group_count(self._h)
+        out = []
+        for g in range(n):
+            h = C.c_void_p()
+            st = lib().fhip_tape_group(None, self._h, g, C.byref(h))
+            if st != 0:
+                raise FidgetHipError(st, "tape group")
+            out.append(Shape(_h=h, hip=self._hip, _vars=self._vars))
+        op = lib().fhip_tape_group_op(self._h)
+        return ({30: "min", 31: "max"}.get(op, ""), out)
 
     @staticmethod
     def from_vm(path_or_text, n_regs=255, hip=None):

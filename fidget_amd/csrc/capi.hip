@@ -34,6 +34,10 @@ struct DevBuf {
 struct fhip_tape {
     fh::HostTape t;
     mutable uint64_t* d_ops = nullptr;  // uploaded on first device use (tape construction is host-only)
+    // tape parallelism (host_graph.hpp split_root): when the root is a min / max of many parts, the
+    // same function as `groups.size()` independent tapes whose outputs combine with `group_op`
+    std::vector<fh::HostTape> groups;
+    int group_op = -1;
 };
 struct fhip_graph {
     fh::Graph g;
@@ -183,6 +187,25 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     fhip_tape* t = new fhip_tape();
     if (!fh::allocate(prog, t->t, err)) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, err); }
     if (t->t.n_vars > FH_MAX_INPUTS) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 16 input variables"); }
+    if (t->t.ops.size() >= 1024 && !getenv("FHIP_NO_GROUPS")) {
+        std::vector<fh::SsaProgram> gp;
+        const int op = fh::split_root(prog, FH_MAX_GROUPS, 2 * FH_MAX_GROUPS, gp);
+        if (op >= 0) {
+            t->groups.resize(gp.size());
+            bool ok = true;
+            for (size_t g = 0; g < gp.size() && ok; g++) ok = fh::allocate(gp[g], t->groups[g], err);
+            if (ok) t->group_op = op; else t->groups.clear();
+        }
+    }
+    *out = t;
+    return FHIP_OK;
+}
+uint32_t fhip_tape_group_count(const fhip_tape* tape) { return (uint32_t)tape->groups.size(); }
+int fhip_tape_group_op(const fhip_tape* tape) { return tape->group_op; }
+fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fhip_tape** out) {
+    if (g >= tape->groups.size()) return fail(ctx, FHIP_ERR_BAD_TAPE, "no such tape group");
+    fhip_tape* t = new fhip_tape();
+    t->t = tape->groups[g];
     *out = t;
     return FHIP_OK;
 }

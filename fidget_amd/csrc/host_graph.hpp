@@ -519,4 +519,102 @@ static inline void drop_dead(SsaProgram& p) {
     p.n_choices = choices;
 }
 
+// ---- tape parallelism: split a program at its root min / max tree ------------------------------
+// Many shapes are a union (min) or intersection (max) of hundreds of small parts (prospero.vm:
+// a min of 665 terms of <= 80 ops).  Evaluated as one tape that is a single dependency chain;
+// split into `want` contiguous runs of terms it is `want` independent tapes whose outputs
+// combine with the same op, in the same order - which keeps every tie (f32 min returns its
+// second operand on a tie, types/float.rs:93-108) and every NaN exactly as in the original tree.
+// Shared subexpressions are recomputed by each group that needs them.
+// Returns the combining opcode (FH_MIN_RR / FH_MAX_RR) or -1 when the root does not split.
+static inline int split_root(const SsaProgram& p, uint32_t want, uint32_t min_terms, std::vector<SsaProgram>& groups) {
+    groups.clear();
+    if (p.n_outputs != 1 || p.ops.empty() || p.ops[0].op != FH_OUTPUT || want < 2) return -1;
+    std::vector<int> def(p.n_values, -1);
+    for (size_t i = 0; i < p.ops.size(); i++)
+        if (p.ops[i].op != FH_OUTPUT) def[p.ops[i].out] = (int)i;
+    const uint32_t root = p.ops[0].a;
+    if (def[root] < 0) return -1;
+    const int rop = p.ops[def[root]].op;
+    int rr, ri;
+    if (rop == FH_MIN_RR || rop == FH_MIN_RI) { rr = FH_MIN_RR; ri = FH_MIN_RI; }
+    else if (rop == FH_MAX_RR || rop == FH_MAX_RI) { rr = FH_MAX_RR; ri = FH_MAX_RI; }
+    else return -1;
+    // in-order terms of the maximal tree of that op hanging off the root
+    struct Term { bool is_const; uint32_t v; };  // value id, or immediate bits
+    std::vector<Term> terms;
+    std::vector<std::pair<uint32_t, int>> stack{{root, 0}};  // (value, state); consts pushed as state 2
+    while (!stack.empty()) {
+        auto [v, st] = stack.back();
+        stack.pop_back();
+        if (st == 2) { terms.push_back({true, v}); continue; }
+        const SsaOp& o = p.ops[def[v]];
+        if (o.op == rr) { stack.push_back({o.b, 0}); stack.push_back({o.a, 0}); }        // a first, then b
+        else if (o.op == ri) { stack.push_back({o.imm, 2}); stack.push_back({o.a, 0}); }  // a first, then the constant
+        else terms.push_back({false, v});
+    }
+    if (terms.size() < min_terms) return -1;
+    // weight of a term = ops it reaches (what its group will have to evaluate, roughly)
+    std::vector<uint32_t> weight(terms.size(), 1);
+    std::vector<uint32_t> mark(p.n_values, 0), work;
+    uint64_t total = 0;
+    for (size_t t = 0; t < terms.size(); t++) {
+        if (terms[t].is_const) { total += 1; continue; }
+        uint32_t n = 0;
+        work.assign(1, terms[t].v);
+        while (!work.empty()) {
+            const uint32_t v = work.back();
+            work.pop_back();
+            if (mark[v] == t + 1) continue;
+            mark[v] = (uint32_t)t + 1;
+            n++;
+            const SsaOp& o = p.ops[def[v]];
+            if (o.op != FH_INPUT && o.op != FH_COPY_IMM) work.push_back(o.a);
+            if (fh_is_rr(o.op)) work.push_back(o.b);
+        }
+        weight[t] = n;
+        total += n;
+    }
+    // contiguous runs of about total / want ops
+    const uint64_t per = (total + want - 1) / want;
+    std::vector<std::pair<size_t, size_t>> runs;  // [first, last)
+    size_t first = 0;
+    uint64_t acc = 0;
+    for (size_t t = 0; t < terms.size(); t++) {
+        acc += weight[t];
+        if (acc >= per && runs.size() + 1 < want) { runs.push_back({first, t + 1}); first = t + 1; acc = 0; }
+    }
+    if (first < terms.size()) runs.push_back({first, terms.size()});
+    if (runs.size() < 2) return -1;
+    for (auto& run : runs) {
+        SsaProgram g;
+        g.n_values = p.n_values;
+        g.n_outputs = 1;
+        g.vars = p.vars;
+        // the chain acc = op(op(op(t0, t1), t2), ...) in evaluation order, stored root first
+        std::vector<SsaOp> chain;
+        uint32_t accv = 0;
+        bool have = false;
+        for (size_t t = run.first; t < run.second; t++) {
+            const Term& tm = terms[t];
+            if (!have) {
+                if (tm.is_const) { accv = g.n_values++; chain.push_back(SsaOp{FH_COPY_IMM, accv, 0, 0, tm.v}); }
+                else accv = tm.v;
+                have = true;
+                continue;
+            }
+            const uint32_t nv = g.n_values++;
+            if (tm.is_const) chain.push_back(SsaOp{(uint8_t)ri, nv, accv, 0, tm.v});
+            else chain.push_back(SsaOp{(uint8_t)rr, nv, accv, tm.v, 0});
+            accv = nv;
+        }
+        g.ops.push_back(SsaOp{FH_OUTPUT, 0, accv, 0, 0});
+        for (size_t i = chain.size(); i-- > 0;) g.ops.push_back(chain[i]);
+        for (size_t i = 1; i < p.ops.size(); i++) g.ops.push_back(p.ops[i]);  // what is not reached is dropped below
+        drop_dead(g);
+        groups.push_back(std::move(g));
+    }
+    return rr;
+}
+
 }  // namespace fh

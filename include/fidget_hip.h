@@ -66,6 +66,14 @@ uint32_t fhip_tape_output_count(const fhip_tape* tape); /* Tape::output_count  e
 /* Copy the device-format ops (8 bytes each, evaluation order) to `ops`; returns the length */
 uint32_t fhip_tape_ops(const fhip_tape* tape, uint64_t* ops, uint32_t cap);
 
+/* Tape parallelism (no counterpart in the reference): when the root of the function is a min / max
+ * of many parts, the same function as `count` independent tapes whose outputs combine, in order,
+ * with FH_MIN_RR (30) / FH_MAX_RR (31).  The renderers evaluate the root level that way; exposed
+ * for tests.  0 groups = the tape does not split. */
+uint32_t fhip_tape_group_count(const fhip_tape* tape);
+int fhip_tape_group_op(const fhip_tape* tape);
+fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fhip_tape** out);
+
 /* Function::simplify (eval/mod.rs:147-160; VmData::simplify vm/data.rs:123-318).
  * `choices` is one byte per choice op in evaluation order, values 1/2/3 = Left/Right/Both. */
 fhip_status fhip_simplify(fhip_ctx* ctx, const fhip_tape* tape, const uint8_t* choices, uint32_t n_choices,
