@@ -490,6 +490,9 @@ struct RenderSetup {
     bool asm_points = false;  // leaf stage on the assembly interpreters
     bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
     bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
+    uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
+    size_t lds_tiles_group = 0;
+    bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
     bool prune1 = false;      // ... and, on the pre-pass levels, the prune as one wave per child (fh_prune1)
 };
 
@@ -659,9 +662,46 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.split = ctx->use_split && is3d && R.tl == 64;
     R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
     R.prune1 = R.asm_tiles && S.pre_levels > 0 && !getenv("FHIP_NO_PRUNE1");
+    // tape parallelism: level 0 walks the tape's independent groups on different waves
+    // (experimental, FHIP_TAPE_GROUPS=1: the forward pass of level 0 drops from 0.9 to 0.07 ms, but the
+    // children's tapes come out ~15 % longer (shared subexpressions are duplicated per group) and the
+    // one-wave-per-child prune still walks every needed group in turn; the frame is slower for now)
+    R.groups = R.prune1 && !tape->groups.empty() && getenv("FHIP_TAPE_GROUPS");
+    S.n_tgroups = 0;
+    if (R.groups) {
+        uint32_t off = (uint32_t)t.ops.size() + 16, mr = 1, mc = 0;
+        for (size_t g = 0; g < tape->groups.size(); g++) {
+            const fh::HostTape& gt = tape->groups[g];
+            S.tgroup[g] = FhTapeRef{off, (uint32_t)gt.ops.size(), (uint16_t)gt.n_regs, (uint16_t)gt.n_choices};
+            off += (uint32_t)gt.ops.size() + 16;  // slack: the interpreters prefetch past a tape's end
+            mr = std::max(mr, gt.n_regs); mc = std::max(mc, gt.n_choices);
+        }
+        S.n_tgroups = (uint32_t)tape->groups.size();
+        S.tgroup_op = (uint32_t)tape->group_op;
+        S.arena_head = S.arena_root_end = off;
+        R.group_regs = mr; R.group_choices = mc;
+        // a child's tape is now a concatenation of (pruned) groups: shared subexpressions are
+        // duplicated, so the frame-wide bounds are those of the concatenation, not of the root tape
+        uint32_t sum_choices = 0;
+        for (auto& gt : tape->groups) sum_choices += gt.n_choices + 1;
+        P.max_choices = std::max(P.max_choices, sum_choices);
+        P.max_regs = std::max(P.max_regs, mr + 2);
+        R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
+        R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
+        R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
+        if (R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX) mr = 1000;  // does not fit: no groups (below)
+        R.lds_tiles_group = tiles_lds(mr, mc, TL);
+        if (mr > 112 || (size_t)off * 8 + 4096 > ctx->arena_bytes) {
+            R.groups = false; S.n_tgroups = 0; S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
+            P.max_regs = std::max<uint32_t>(t.n_regs, 1); P.max_choices = t.n_choices;
+            R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
+            R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
+            R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
+        }
+    }
     if (R.prune1) {  // choice words of the pre-pass levels' forward passes: [slot][word][lane]
         uint32_t cap = 1;
-        for (uint32_t l = 0; l < S.pre_levels; l++) cap = std::max(cap, qcaps[l]);
+        for (uint32_t l = 0; l < S.pre_levels; l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
         const size_t words[2] = {(SMALL_CHOICES + 15) / 16, ((size_t)P.max_choices + 15) / 16};
         for (int k = 0; k < 2; k++) {
             HIP_TRY(ctx, ctx->chw[k].ensure(std::max<size_t>(cap * words[k] * 256, 256)));
@@ -670,7 +710,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     if (R.split) {
         uint32_t cap = 1;
-        for (size_t l = 0; l < ts.size(); l++) cap = std::max(cap, qcaps[l]);
+        for (size_t l = 0; l < ts.size(); l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
         for (int k = 0; k < 2; k++) {
             HIP_TRY(ctx, ctx->slots[k].ensure((size_t)cap * sizeof(FhSlot)));
             S.slots[k] = (FhSlot*)ctx->slots[k].p;
@@ -722,6 +762,9 @@ static fhip_status finish_render(fhip_ctx* ctx) {
 static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t g = 0; g < R.S.n_tgroups; g++)  // the group tapes follow the root tape
+        HIP_TRY(ctx, hipMemcpyAsync((uint64_t*)ctx->arena.p + R.S.tgroup[g].off, tape->groups[g].ops.data(),
+                                    tape->groups[g].ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (!R.roots.empty()) {
         FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size());
         HIP_TRY(ctx, hipMemcpyAsync(back, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
@@ -748,7 +791,21 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
-    if (R.asm_tiles) {
+    if (R.groups && level == 0) {
+        // Tape parallelism: the root tape as its independent groups, one wave per (block of root tiles,
+        // group): forward passes -> combine (which groups does each child need?) -> one wave per child
+        // writes its tape from the groups it needs -> push.
+        launch(ctx, FHIP_K_TILES, [&] {
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
+            const int gg = blocks_for(ctx, R.lds_tiles_group, 8);
+            ka.S = dS; ka.level = 0; ka.big = 1; ka.max_regs = R.group_regs; ka.max_choices = R.group_choices;
+            ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u; ka.skip_regs = ka.skip_choices = 0;
+            (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
+            hipLaunchKernelGGL(k_tcombine3d, dim3(std::min<uint32_t>(R.S.qcap[0], (uint32_t)ctx->n_cu * 4)), dim3(WAVE), 0, ctx->stream, dS);
+            struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.group_choices, 1};
+            (void)launch_asm(ctx, FH_ASM_PRUNE1, R.S.qcap[0] * 64, &kp, sizeof(kp));
+        });
+    } else if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {
             // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
             // the prune runs as one wave per child (fh_prune1)

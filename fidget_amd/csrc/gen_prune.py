@@ -12,11 +12,13 @@ v_writelane with a scalar index), free-register pool as two 64-bit SGPR masks, t
 choices from S->chw (written by fh_tiles in export mode), the tape through the scalar cache
 (8 ops per load, double buffered, walked backwards).
 
-kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_choices; u32 pad }
+kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_choices; u32 mode }
+         mode 1 (tape groups, level 0): the wave walks the child's needed groups last to first and writes
+         ONE tape: group after group, each result folded into r0 right away (r0 = op(r0, r1))
 grid   : 64 workgroups (of one wave) per slot; workgroup = slot * 64 + child lane
 Limits : <= 128 registers
 """
-from gen_tiles import SLOT_SIZE, SL_COFF, SL_CLEN, SL_CRC
+from gen_tiles import SLOT_SIZE, SL_COFF, SL_CLEN, SL_CRC, SL_XYZ
 
 S_KERNARG = "s[0:1]"
 S_WG = "s2"
@@ -30,7 +32,8 @@ S_TAPE = "s[16:17]"
 S_CHWP = "s[18:19]"                            # address of this child's word 0
 S_DST = "s[20:21]"
 S_K, S_CI, S_CW = "s22", "s23", "s24"
-S_HAVEW = "s25"
+S_HAVEW = "s7"                                  # (s7 = `big` is dead after the prologue)
+S_MODE, S_LIVEG, S_RANK, S_SLOTI, S_NLIVE, S_NG, S_GOP, S_GI = "s87", "s97", "s100", "s101", "s88", "s89", "s15", "s25"
 S_CWN, S_PREF = "s34", "s35"                  # prefetched choice word, prefetch in flight
 S_POOLA, S_POOLB = "s[26:27]", "s[28:29]"
 S_HIGH, S_COUNT, S_KEPT = "s30", "s31", "s32"
@@ -149,8 +152,10 @@ class Prune1:
 	s_mov_b32 {S_LEVEL}, s8
 	s_mov_b32 {S_BIG}, s9
 	s_mov_b32 {S_MAXCH}, s10
-	s_lshr_b32 {S_T0}, {S_WG}, 6                  ; slot
+	s_mov_b32 {S_MODE}, s11
+	s_lshr_b32 {S_T0}, {S_WG}, 6                  ; slot (mode 1: block of root tiles)
 	s_and_b32 {S_C}, {S_WG}, 63                   ; child lane
+	s_load_dword {S_NG}, {S_STATE}, {o['n_tgroups']}
 	; n_slots[big][level], slots[big], chw[big]
 	s_lshl_b32 {S_T1}, {S_BIG}, 3
 	s_add_u32 {S_T1}, {S_T1}, {S_LEVEL}
@@ -165,6 +170,11 @@ class Prune1:
 	s_load_dwordx2 {S_CHWP}, {S_T64}, {o['chw']}
 	s_load_dwordx2 {S_TAPE}, {S_STATE}, {o['arena']}
 	s_waitcnt lgkmcnt(0)
+	s_cmp_eq_u32 {S_MODE}, 0
+	s_cbranch_scc1 .Lfh_prune1_slotok
+	s_mul_i32 {S_T0}, {S_T0}, {S_NG}               ; the block's primary slot
+.Lfh_prune1_slotok:
+	s_mov_b32 {S_SLOTI}, {S_T0}
 	s_cmp_ge_u32 {S_T0}, {S_T2}
 	s_cbranch_scc1 .Lfh_prune1_exit
 	; slot = slots + si * sizeof(FhSlot); chw column of this child
@@ -191,19 +201,13 @@ class Prune1:
 	s_waitcnt lgkmcnt(0)
 	s_cmp_eq_u32 {S_T2}, -1
 	s_cbranch_scc0 .Lfh_prune1_exit
-	s_lshr_b32 {S_NCH}, {S_RC}, 16
-	; tape = arena + 8 * off ; dst = arena + 8 * end
+	; dst = arena + 8 * end
 	s_mov_b64 {S_T64}, {S_TAPE}
 	s_mov_b32 {S_T0}, {S_END}
 	s_mov_b32 {S_T1}, 0
 	s_lshl_b64 s[78:79], s[78:79], 3
 	s_add_u32 s20, s82, {S_T0}
 	s_addc_u32 s21, s83, {S_T1}
-	s_mov_b32 {S_T0}, {S_OFF}
-	s_mov_b32 {S_T1}, 0
-	s_lshl_b64 s[78:79], s[78:79], 3
-	s_add_u32 s16, s82, {S_T0}
-	s_addc_u32 s17, s83, {S_T1}
 	; opcode sets: choice reg,reg 30..33 ; choice reg,imm 42..45 ; no operand a: INPUT (1), COPY_IMM (3)
 	s_mov_b32 s90, 0xc0000000
 	s_mov_b32 s91, 0x3
@@ -211,11 +215,22 @@ class Prune1:
 	s_mov_b32 s93, 0x3c00
 	s_mov_b32 s94, 0xa
 	s_mov_b32 s95, 0
-	s_mov_b64 {S_POOLA}, -1
-	s_mov_b64 {S_POOLB}, -1
 	s_mov_b32 {S_HIGH}, 0
 	s_mov_b32 {S_COUNT}, 0
 	s_mov_b32 {S_KEPT}, 0
+	s_mov_b32 {S_NLIVE}, 0
+	s_cmp_eq_u32 {S_MODE}, 0
+	s_cbranch_scc0 .Lfh_prune1_ginit
+	s_mov_b64 {S_POOLA}, -1
+	s_mov_b64 {S_POOLB}, -1
+.Lfh_prune1_tape:
+	; tape = arena + 8 * off
+	s_lshr_b32 {S_NCH}, {S_RC}, 16
+	s_mov_b32 {S_T0}, {S_OFF}
+	s_mov_b32 {S_T1}, 0
+	s_lshl_b64 s[78:79], s[78:79], 3
+	s_add_u32 s16, s82, {S_T0}
+	s_addc_u32 s17, s83, {S_T1}
 	s_mov_b32 {S_K}, {S_LEN}
 	s_mov_b32 {S_CI}, {S_NCH}
 	s_mov_b32 {S_HAVEW}, 0
@@ -383,11 +398,85 @@ class Prune1:
         self.use(S_MA, S_A)
         a(f"""
 	s_lshl_b32 {S_E0}, {S_MA}, 20
-	s_mov_b32 {S_E1}, {S_W1}""")
+	s_mov_b32 {S_E1}, {S_W1}
+	s_cmp_eq_u32 {S_MODE}, 0
+	s_cbranch_scc1 .Lfh_prune1_outemit
+	; tape groups: the group's result goes to register `rank` (COPY_REG) instead of the output
+	s_min_u32 {S_T0}, {S_RANK}, 1
+	s_lshl_b32 {S_T0}, {S_T0}, 8
+	s_or_b32 {S_E0}, {S_E0}, {S_T0}
+	s_or_b32 {S_E0}, {S_E0}, 2
+	s_mov_b32 {S_E1}, 0
+.Lfh_prune1_outemit:""")
         self.emit_op()
         a(f"""
 	s_branch {nxt}
+; ---- tape groups (mode 1) ------------------------------------------------------------------
+.Lfh_prune1_ginit:
+	s_lshl_b32 {S_T1}, {S_C}, 2
+	s_add_u32 s82, s8, {S_T1}
+	s_addc_u32 s83, s9, 0
+	s_load_dword {S_LIVEG}, {S_T64}, {SL_XYZ}        ; groups this child needs (k_tcombine3d)
+	s_load_dword {S_GOP}, {S_STATE}, {o['tgroup_op']}
+	s_waitcnt lgkmcnt(0)
+	s_bcnt1_i32_b32 {S_NLIVE}, {S_LIVEG}
+	s_min_u32 {S_HIGH}, {S_NLIVE}, 2
+	; Written back to front: OUTPUT r0; then, last needed group first: [r0 = op(r0, r1)] after the
+	; group's ops, whose result is copied to r1 (to r0 for the first group).  Only r0 and r1 are
+	; reserved, so the tape needs no more registers than its largest group + 2.
+	s_mov_b32 {S_E0}, 0
+	s_mov_b32 {S_E1}, 0""")
+        self.emit_op()
+        a(f"""
+	s_mov_b32 {S_RANK}, {S_NLIVE}
+.Lfh_prune1_gnext:
+	s_waitcnt lgkmcnt(0)                            ; prefetches of the group just finished
+	s_cmp_eq_u32 {S_LIVEG}, 0
+	s_cbranch_scc1 .Lfh_prune1_finish
+	s_flbit_i32_b32 {S_T0}, {S_LIVEG}
+	s_sub_u32 {S_GI}, 31, {S_T0}
+	s_bitset0_b32 {S_LIVEG}, {S_GI}
+	s_sub_u32 {S_RANK}, {S_RANK}, 1
+	s_cmp_eq_u32 {S_RANK}, 0
+	s_cbranch_scc1 .Lfh_prune1_gfirst
+	s_lshl_b32 {S_E0}, {S_GOP}, 0                   ; r0 = op(r0, r1): out 0, a 0, b 1
+	s_mov_b32 {S_E1}, 1""")
+        self.emit_op()
+        a(f"""
+	s_add_u32 {S_KEPT}, {S_KEPT}, 1
+.Lfh_prune1_gfirst:
+	s_mul_i32 {S_T0}, {S_GI}, 12
+	s_add_u32 s82, s4, {S_T0}
+	s_addc_u32 s83, s5, 0
+	s_load_dwordx2 s[12:13], {S_T64}, {o['tgroup']}
+	s_load_dword s14, {S_T64}, {o['tgroup'] + 8}
+	s_load_dwordx2 {S_CHWP}, {S_STATE}, {o['chw'] + 8}
+	s_load_dwordx2 {S_T64}, {S_STATE}, {o['arena']}
+	; this group's choice words: chw[1] + (primary slot + g) * bytes per slot + lane * 4
+	s_add_u32 {S_T1}, {S_MAXCH}, 15
+	s_lshr_b32 {S_T1}, {S_T1}, 4
+	s_lshl_b32 {S_T1}, {S_T1}, 8
+	s_add_u32 {S_T0}, {S_SLOTI}, {S_GI}
+	s_mul_hi_u32 {S_T2}, {S_T0}, {S_T1}
+	s_mul_i32 {S_T1}, {S_T0}, {S_T1}
+	s_waitcnt lgkmcnt(0)
+	s_add_u32 s18, s18, {S_T1}
+	s_addc_u32 s19, s19, {S_T2}
+	s_lshl_b32 {S_T1}, {S_C}, 2
+	s_add_u32 s18, s18, {S_T1}
+	s_addc_u32 s19, s19, 0
+	; fresh register map; registers 0 .. n_live-1 hold the groups' results and are never handed out
+	s_mov_b64 exec, -1
+	v_mov_b32 {V_MAPA}, {DEAD}
+	v_mov_b32 {V_MAPB}, {DEAD}
+	s_mov_b64 exec, 1
+	s_mov_b64 {S_POOLA}, -4                        ; r0, r1 are taken
+	s_mov_b64 {S_POOLB}, -1
+	s_branch .Lfh_prune1_tape
 .Lfh_prune1_done:
+	s_cmp_eq_u32 {S_MODE}, 0
+	s_cbranch_scc0 .Lfh_prune1_gnext
+.Lfh_prune1_finish:
 	; child = {{ end - count, count, high | kept << 16 }}
 	s_sub_u32 {S_T0}, {S_END}, {S_COUNT}
 	s_lshl_b32 {S_T1}, {S_KEPT}, 16

@@ -16,7 +16,8 @@ the scalar cache, 4 ops per load, double buffered.  Emitted by gen_interp.py.
 kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 flags;
            u32 skip_regs; u32 skip_choices }   slots whose tape exceeds (max_regs, max_choices) or fits
          (skip_regs, skip_choices) are left to the launch with the matching LDS layout
-         flags bit 0: phase probes; bit 1: export mode for the long tapes of the pre-pass levels (choice words go
+         flags bit 0: phase probes; bit 2: forward pass only (results + exported choices, nothing else);
+         bit 1: export mode for the long tapes of the pre-pass levels (choice words go
          to S->chw[big][slot][word][lane], pruned lanes are only marked, fh_prune1 sweeps them one per wave)
 LDS    : regs [max_regs][64] x 8 B | choice words [(max_choices+15)/16][64] x 4 B | map [max_regs][64] x 1 B
 Limits : <= 128 registers (pool of 4 x 32 bits), opcodes of the assembly set (no transcendental / modulo / rng)
@@ -1061,6 +1062,8 @@ class Tiles:
 .Lfh_tiles_noflush:
 	global_store_dword {V_L4}, {V_RESL}, {S_SLOT} offset:{SL_RES}
 	global_store_dword {V_L4}, {V_RESH}, {S_SLOT} offset:{SL_RES + 256}
+	s_bitcmp1_b32 {S_FLAGS}, 2                       ; forward pass only (tape groups: k_tcombine3d goes on)
+	s_cbranch_scc1 .Lfh_tiles_outer
 	; ---- classify: ambiguous = act && !(hi < 0) && !(lo > 0); prune those whose trace decided --
 	v_cmp_gt_f32_e64 {S_M[0]}, 0, {V_RESH}
 	v_cmp_gt_f32_e64 {S_M[1]}, {V_RESL}, 0

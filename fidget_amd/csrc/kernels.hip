@@ -545,12 +545,16 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     // Parents map to slots one to one and waves to parents round robin: no atomic cursors (they
     // serialise in L2 and cost more than this kernel's work)
-    const uint32_t ns = min(S->count[level], S->slot_cap[0]), nb = min(S->count_big[level], S->slot_cap[1]);
-    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns; S->n_slots[1][level] = nb; }
+    // Tape parallelism at level 0: every block of root tiles gets one slot per independent tape
+    // group (slots g0 .. g0 + G - 1, same children, different tapes); k_tcombine3d merges them.
+    const uint32_t G = (level == 0 && S->n_tgroups) ? S->n_tgroups : 1;
+    const uint32_t ns = min(S->count[level], S->slot_cap[0]), nb = min(S->count_big[level], S->slot_cap[1] / G);
+    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns; S->n_slots[1][level] = nb * G; }
     for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
         const bool big = gi >= ns;
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
-        FhSlot& sl = S->slots[big ? 1 : 0][big ? gi - ns : gi];
+        FhSlot* const slg = &S->slots[big ? 1 : 0][big ? (gi - ns) * G : gi];
+        FhSlot& sl = *slg;
         if (level > 0) {  // the whole parent may have been occluded since it was queued
             const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
             if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
@@ -568,17 +572,73 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
         bool act = lane < (int)nchild && cx < P.width && cy < P.height;
         if (act && mind[(cy / T) * ntx + cx / T] >= cz + T + 1) act = false;  // voxel.rs:283-289
         const uint64_t actm = ballot(act);
-        if (actm == 0) { if (lane == 0) sl.act = 0; continue; }
+        if (actm == 0) { if (lane < (int)G) slg[lane].act = 0; continue; }
         IV X, Y, Z;
         xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
                     iv((float)cz, (float)cz + (float)T), X, Y, Z);
-        if (lane == 0) {
-            sl.tape.off = g.tape.off; sl.tape.len = g.tape.len; sl.tape.n_regs = g.tape.n_regs; sl.tape.n_choices = g.tape.n_choices;
-            sl.level = (uint32_t)level; sl.act = actm; sl.base = 0; sl.overflow = 0;
+        for (uint32_t k = 0; k < G; k++) {
+            FhSlot& so = slg[k];
+            if (lane == 0) {
+                const FhTapeRef tr = (G > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
+                so.tape = tr;
+                so.level = (uint32_t)level; so.act = actm; so.base = 0; so.overflow = 0;
+            }
+            so.xyz[0][lane] = X.lo; so.xyz[1][lane] = X.hi; so.xyz[2][lane] = Y.lo; so.xyz[3][lane] = Y.hi;
+            so.xyz[4][lane] = Z.lo; so.xyz[5][lane] = Z.hi;
+            so.corner[0][lane] = cx; so.corner[1][lane] = cy; so.corner[2][lane] = cz;
         }
-        sl.xyz[0][lane] = X.lo; sl.xyz[1][lane] = X.hi; sl.xyz[2][lane] = Y.lo; sl.xyz[3][lane] = Y.hi;
-        sl.xyz[4][lane] = Z.lo; sl.xyz[5][lane] = Z.hi;
-        sl.corner[0][lane] = cx; sl.corner[1][lane] = cy; sl.corner[2][lane] = cz;
+    }
+}
+
+// Tape parallelism at level 0, after the forward passes of the groups: the children's intervals
+// are the running min / max of the groups' results, in order - with the Choice each step of that
+// chain would record (vm/mod.rs:436-471): a group whose interval is dominated is not needed by that
+// child at all.  For every ambiguous child this reserves arena space for its pruned tape and leaves
+// the list of groups it needs; fh_prune1 (group mode) writes the tape, k_tpush3d queues it.
+__global__ void __launch_bounds__(WAVE) k_tcombine3d(FhRenderState* S) {
+    const int lane = threadIdx.x;
+    const uint32_t G = S->n_tgroups;
+    const bool is_min = S->tgroup_op == FH_MIN_RR;
+    const uint32_t nblk = S->n_slots[1][0] / G;
+    const FhTapeRef root = FhTapeRef{0, S->tgroup[0].off - 16, (uint16_t)S->P.max_regs, (uint16_t)S->P.max_choices};
+    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        FhSlot* const slg = &S->slots[1][(size_t)b * G];
+        const uint64_t actm = slg[0].act;
+        if (actm == 0) continue;
+        const bool act = (actm >> lane) & 1;
+        IV acc = iv(slg[0].res[0][lane], slg[0].res[1][lane]);
+        uint32_t live = 1;
+        for (uint32_t k = 1; k < G; k++) {
+            const IV m = iv(slg[k].res[0][lane], slg[k].res[1][lane]);
+            if (iv_has_nan(acc) || iv_has_nan(m)) { acc = iv_nan(); live |= 1u << k; continue; }  // Both
+            const bool left = is_min ? acc.hi < m.lo : acc.lo > m.hi;    // the chain so far wins: group k is not needed
+            const bool right = is_min ? m.hi < acc.lo : m.lo > acc.hi;   // group k alone wins
+            acc = is_min ? iv(rmin(acc.lo, m.lo), rmin(acc.hi, m.hi)) : iv(rmax(acc.lo, m.lo), rmax(acc.hi, m.hi));
+            if (left) continue;
+            live = right ? (1u << k) : (live | (1u << k));
+        }
+        const bool full = act && acc.hi < 0.0f, empty = act && !full && acc.lo > 0.0f;
+        const bool amb = act && !full && !empty;
+        // arena: the groups' pruned tapes back to back + one copy and one combining op per group
+        uint32_t need = 0;
+        if (amb) {
+            for (uint32_t k = 0; k < G; k++) if ((live >> k) & 1) need += S->tgroup[k].len + 2;
+        }
+        uint32_t total;
+        const uint32_t before = wave_excl_sum(need, total);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(&S->arena_head, total);
+        base = uni(base);
+        const bool ok = total && base + total <= S->arena_cap;
+        if (total && !ok && lane == 0) atomicAdd(&S->arena_overflow, 1u);  // the children keep the root tape
+        FhSlot& p = slg[0];  // the primary slot carries the block from here on
+        p.res[0][lane] = acc.lo; p.res[1][lane] = acc.hi;
+        p.c_off[lane] = (amb && ok) ? base + before + need : root.off;      // end of this child's tape space
+        p.c_len[lane] = (amb && ok) ? 0xFFFFFFFFu : root.len;               // ~0: to be written by fh_prune1
+        p.c_rc[lane] = (uint32_t)root.n_regs | ((uint32_t)root.n_choices << 16);
+        ((uint32_t*)p.xyz[0])[lane] = live;                                 // groups this child needs
+        if (lane == 0) { p.tape = root; }
+        if (lane >= 1 && lane < (int)G) slg[lane].act = 0;                  // only the primary slot is pushed
     }
 }
 

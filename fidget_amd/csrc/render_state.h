@@ -84,6 +84,10 @@ struct FhRenderState {
     // split 3D tile stage: slots[0] = tapes that fit the small LDS layout, slots[1] = the others
     FhSlot* slots[2];
     uint32_t slot_cap[2];
+    // tape parallelism at level 0 (host_graph.hpp split_root): n_tgroups independent tapes (in the
+    // arena right after the root tape) whose outputs combine, in order, with tgroup_op
+    FhTapeRef tgroup[FH_MAX_GROUPS];
+    uint32_t n_tgroups, tgroup_op;
     // pre-pass levels: choice words [slot][word][lane] of the forward pass, read by the
     // one-wave-per-child prune (fh_prune1); [0] small-LDS list (16 words per slot), [1] the other
     uint32_t* chw[2];

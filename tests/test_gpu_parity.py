@@ -113,3 +113,22 @@ def test_render3d_non_cubic(whd):
     assert a.shape == b.shape == (h, w)
     assert (a["depth"] == b["depth"]).all(), f"{(a['depth'] != b['depth']).sum()} depths differ"
     assert same_bits_f32(a["normal"], b["normal"])
+
+
+@pytest.mark.gpu
+def test_render3d_with_tape_groups():
+    """Experimental tape parallelism at the root level (FHIP_TAPE_GROUPS=1): same image."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        os.environ["FHIP_TAPE_GROUPS"] = "1"
+        import numpy as np, fidget_amd as F, oracle as O
+        m = os.path.join({ROOT!r}, "models", "prospero.vm")
+        for n in (128, 256):
+            a = F.render3d(F.Shape.from_vm(m), n)[0]
+            b = O.render3d(O.Shape.from_vm(m), n)[0]
+            assert (a["depth"] == b["depth"]).all() and (a["normal"].view(np.uint32) == b["normal"].view(np.uint32)).all(), n
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
