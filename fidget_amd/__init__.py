@@ -52,7 +52,7 @@ EXPORTS = [
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
     "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_tape_group_count", "fhip_tape_group_op",
-    "fhip_tape_group",
+    "fhip_tape_group", "fhip_tape_term_plan",
 ]
 
 
@@ -136,7 +136,7 @@ def lib():
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
-            "fhip_tape_group": (i32, [vp, vp, u32, vp]),
+            "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]),
             "fhip_debug_leaves": (u32, [vp, vp, u32]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
@@ -372,6 +372,12 @@ class Shape:
             out.append(Shape(_h=h, hip=self._hip, _vars=self._vars))
         op = lib().fhip_tape_group_op(self._h)
         return ({30: "min", 31: "max"}.get(op, ""), out)
+
+    def term_plan(self):
+        """The renderer's root-level split: dict(groups, terms, tree_ops, tree_regs, choices); groups = 0 if none."""
+        info = (C.c_uint32 * 4)()
+        n = lib().fhip_tape_term_plan(self._h, info)
+        return dict(groups=n, terms=info[0], tree_ops=info[1], tree_regs=info[2], choices=info[3])
 
     @staticmethod
     def from_vm(path_or_text, n_regs=255, hip=None):

@@ -38,6 +38,12 @@ struct fhip_tape {
     // same function as `groups.size()` independent tapes whose outputs combine with `group_op`
     std::vector<fh::HostTape> groups;
     int group_op = -1;
+    // ... and the renderer's form of it (plan_terms): groups that output the root tree's terms, the
+    // tree as a small program over them, and where every choice of the full tape is recorded
+    fh::TermPlan plan;
+    std::vector<fh::HostTape> tgroups;
+    mutable FhTopOp* d_top = nullptr;
+    mutable uint32_t* d_chsrc = nullptr;
 };
 struct fhip_graph {
     fh::Graph g;
@@ -69,7 +75,7 @@ struct fhip_ctx {
     int n_cu = 256;
     std::string err;
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2];
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr;
     DevBuf queue[FH_MAX_LEVELS];
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -162,7 +168,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
                       &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1],
-                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b, &c->chw[0], &c->chw[1]};
+                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b, &c->chw[0], &c->chw[1], &c->tvals, &c->topch, &c->chwr};
     for (DevBuf* b : bufs) b->release();
     for (auto& q : c->queue) q.release();
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
@@ -187,14 +193,24 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     fhip_tape* t = new fhip_tape();
     if (!fh::allocate(prog, t->t, err)) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, err); }
     if (t->t.n_vars > FH_MAX_INPUTS) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 16 input variables"); }
-    if (t->t.ops.size() >= 1024 && !getenv("FHIP_NO_GROUPS")) {
+    // (FHIP_GROUPS_MIN_OPS / FHIP_GROUPS_MIN_TERMS: tests lower the thresholds to send small shapes down this path)
+    const size_t min_ops = getenv("FHIP_GROUPS_MIN_OPS") ? (size_t)atol(getenv("FHIP_GROUPS_MIN_OPS")) : 1024;
+    const uint32_t min_terms = getenv("FHIP_GROUPS_MIN_TERMS") ? (uint32_t)atol(getenv("FHIP_GROUPS_MIN_TERMS")) : 2 * FH_MAX_GROUPS;
+    if (t->t.ops.size() >= min_ops && !getenv("FHIP_NO_GROUPS")) {
         std::vector<fh::SsaProgram> gp;
-        const int op = fh::split_root(prog, FH_MAX_GROUPS, 2 * FH_MAX_GROUPS, gp);
+        const int op = fh::split_root(prog, FH_MAX_GROUPS, min_terms, gp);
         if (op >= 0) {
             t->groups.resize(gp.size());
             bool ok = true;
             for (size_t g = 0; g < gp.size() && ok; g++) ok = fh::allocate(gp[g], t->groups[g], err);
             if (ok) t->group_op = op; else t->groups.clear();
+        }
+        if (fh::plan_terms(prog, FH_MAX_GROUPS, min_terms, 16, t->plan)) {
+            t->tgroups.resize(t->plan.groups.size());
+            bool ok = true;
+            for (size_t g = 0; g < t->tgroups.size() && ok; g++) ok = fh::allocate(t->plan.groups[g], t->tgroups[g], err);
+            if (!ok) t->tgroups.clear();
+            t->plan.groups.clear();
         }
     }
     *out = t;
@@ -208,6 +224,11 @@ fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fh
     t->t = tape->groups[g];
     *out = t;
     return FHIP_OK;
+}
+uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]) {
+    info[0] = tape->plan.n_terms; info[1] = (uint32_t)tape->plan.top.size(); info[2] = tape->plan.top_regs;
+    info[3] = (uint32_t)tape->plan.choice_src.size();
+    return (uint32_t)tape->tgroups.size();
 }
 // Launch one of the assembly kernels: `waves` single-wave workgroups, raw kernarg block
 static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0, uint32_t grid_y = 1) {
@@ -254,6 +275,8 @@ fhip_status fhip_tape_from_graph(fhip_ctx* ctx, const fhip_graph* g, const uint3
 void fhip_tape_free(fhip_tape* t) {
     if (!t) return;
     if (t->d_ops) (void)hipFree(t->d_ops);
+    if (t->d_top) (void)hipFree(t->d_top);
+    if (t->d_chsrc) (void)hipFree(t->d_chsrc);
     delete t;
 }
 uint32_t fhip_tape_len(const fhip_tape* t) { return (uint32_t)t->t.ops.size(); }
@@ -662,42 +685,39 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.split = ctx->use_split && is3d && R.tl == 64;
     R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
     R.prune1 = R.asm_tiles && S.pre_levels > 0 && !getenv("FHIP_NO_PRUNE1");
-    // tape parallelism: level 0 walks the tape's independent groups on different waves
-    // (experimental, FHIP_TAPE_GROUPS=1: the forward pass of level 0 drops from 0.9 to 0.07 ms, but the
-    // children's tapes come out ~15 % longer (shared subexpressions are duplicated per group) and the
-    // one-wave-per-child prune still walks every needed group in turn; the frame is slower for now)
-    R.groups = R.prune1 && !tape->groups.empty() && getenv("FHIP_TAPE_GROUPS");
+    // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
+    // waves, then the tree itself; the prune sees the root tape with its usual choices
+    R.groups = R.prune1 && !tape->tgroups.empty() && !getenv("FHIP_NO_TAPE_GROUPS");
     S.n_tgroups = 0;
     if (R.groups) {
         uint32_t off = (uint32_t)t.ops.size() + 16, mr = 1, mc = 0;
-        for (size_t g = 0; g < tape->groups.size(); g++) {
-            const fh::HostTape& gt = tape->groups[g];
+        for (size_t g = 0; g < tape->tgroups.size(); g++) {
+            const fh::HostTape& gt = tape->tgroups[g];
             S.tgroup[g] = FhTapeRef{off, (uint32_t)gt.ops.size(), (uint16_t)gt.n_regs, (uint16_t)gt.n_choices};
             off += (uint32_t)gt.ops.size() + 16;  // slack: the interpreters prefetch past a tape's end
             mr = std::max(mr, gt.n_regs); mc = std::max(mc, gt.n_choices);
         }
-        S.n_tgroups = (uint32_t)tape->groups.size();
-        S.tgroup_op = (uint32_t)tape->group_op;
-        S.arena_head = S.arena_root_end = off;
         R.group_regs = mr; R.group_choices = mc;
-        // a child's tape is now a concatenation of (pruned) groups: shared subexpressions are
-        // duplicated, so the frame-wide bounds are those of the concatenation, not of the root tape
-        uint32_t sum_choices = 0;
-        for (auto& gt : tape->groups) sum_choices += gt.n_choices + 1;
-        P.max_choices = std::max(P.max_choices, sum_choices);
-        P.max_regs = std::max(P.max_regs, mr + 2);
-        R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
-        R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
-        R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
-        if (R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX) mr = 1000;  // does not fit: no groups (below)
         R.lds_tiles_group = tiles_lds(mr, mc, TL);
-        if (mr > 112 || (size_t)off * 8 + 4096 > ctx->arena_bytes) {
-            R.groups = false; S.n_tgroups = 0; S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
-            P.max_regs = std::max<uint32_t>(t.n_regs, 1); P.max_choices = t.n_choices;
-            R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
-            R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
-            R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
-        }
+        if (mr <= 128 && R.lds_tiles_group <= FH_LDS_MAX && (size_t)off * 8 + 4096 <= ctx->arena_bytes) {
+            S.n_tgroups = (uint32_t)tape->tgroups.size();
+            S.n_terms = tape->plan.n_terms; S.n_top = (uint32_t)tape->plan.top.size(); S.top_chain = tape->plan.chain ? 1 : 0;
+            S.troot_len = (uint32_t)t.ops.size(); S.troot_choices = t.n_choices; S.troot_regs = std::max<uint32_t>(t.n_regs, 1);
+            S.arena_head = S.arena_root_end = off;
+            if (!tape->d_top) {
+                static_assert(sizeof(FhTopOp) == sizeof(fh::TopOp), "top op layout");
+                HIP_TRY(ctx, hipMalloc((void**)&tape->d_top, tape->plan.top.size() * sizeof(FhTopOp)));
+                HIP_TRY(ctx, hipMemcpy(tape->d_top, tape->plan.top.data(), tape->plan.top.size() * sizeof(FhTopOp), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMalloc((void**)&tape->d_chsrc, std::max<size_t>(tape->plan.choice_src.size(), 1) * 4));
+                HIP_TRY(ctx, hipMemcpy(tape->d_chsrc, tape->plan.choice_src.data(), tape->plan.choice_src.size() * 4, hipMemcpyHostToDevice));
+            }
+            S.ttop = tape->d_top; S.chsrc = tape->d_chsrc;
+            const size_t blocks = qcaps[0];
+            HIP_TRY(ctx, ctx->tvals.ensure(blocks * S.n_terms * WAVE * 8));
+            HIP_TRY(ctx, ctx->topch.ensure(blocks * S.n_top * WAVE));
+            HIP_TRY(ctx, ctx->chwr.ensure(blocks * S.n_tgroups * ((t.n_choices + 15) / 16) * WAVE * 4 + 256));
+            S.tvals = (float*)ctx->tvals.p; S.topch = (uint8_t*)ctx->topch.p; S.chwr = (uint32_t*)ctx->chwr.p;
+        } else R.groups = false;
     }
     if (R.prune1) {  // choice words of the pre-pass levels' forward passes: [slot][word][lane]
         uint32_t cap = 1;
@@ -763,8 +783,8 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     for (uint32_t g = 0; g < R.S.n_tgroups; g++)  // the group tapes follow the root tape
-        HIP_TRY(ctx, hipMemcpyAsync((uint64_t*)ctx->arena.p + R.S.tgroup[g].off, tape->groups[g].ops.data(),
-                                    tape->groups[g].ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync((uint64_t*)ctx->arena.p + R.S.tgroup[g].off, tape->tgroups[g].ops.data(),
+                                    tape->tgroups[g].ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (!R.roots.empty()) {
         FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size());
         HIP_TRY(ctx, hipMemcpyAsync(back, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
@@ -792,18 +812,22 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
     if (R.groups && level == 0) {
-        // Tape parallelism: the root tape as its independent groups, one wave per (block of root tiles,
-        // group): forward passes -> combine (which groups does each child need?) -> one wave per child
-        // writes its tape from the groups it needs -> push.
+        // Tape parallelism: the root tree's terms by independent groups, one wave per (block of root
+        // tiles, group) -> the tree over the terms (result, marks, arena) -> the root tape's choice words
+        // gathered from both -> one wave per ambiguous child prunes the root tape -> push.
         launch(ctx, FHIP_K_TILES, [&] {
             struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
             const int gg = blocks_for(ctx, R.lds_tiles_group, 8);
             ka.S = dS; ka.level = 0; ka.big = 1; ka.max_regs = R.group_regs; ka.max_choices = R.group_choices;
-            ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u; ka.skip_regs = ka.skip_choices = 0;
+            ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u | 8u; ka.skip_regs = ka.skip_choices = 0;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
-            hipLaunchKernelGGL(k_tcombine3d, dim3(std::min<uint32_t>(R.S.qcap[0], (uint32_t)ctx->n_cu * 4)), dim3(WAVE), 0, ctx->stream, dS);
-            struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.group_choices, 1};
-            (void)launch_asm(ctx, FH_ASM_PRUNE1, R.S.qcap[0] * 64, &kp, sizeof(kp));
+            const uint32_t blocks = R.S.qcap[0], root_words = (R.S.troot_choices + 15) / 16, group_words = (R.group_choices + 15) / 16;
+            if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (root_words) hipLaunchKernelGGL(k_tscatter3d, dim3(root_words, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
+            struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
+            (void)launch_asm(ctx, FH_ASM_PRUNE1, blocks * 64, &kp, sizeof(kp));
         });
     } else if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {

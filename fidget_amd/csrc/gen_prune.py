@@ -13,8 +13,8 @@ choices from S->chw (written by fh_tiles in export mode), the tape through the s
 (8 ops per load, double buffered, walked backwards).
 
 kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_choices; u32 mode }
-         mode 1 (tape groups, level 0): the wave walks the child's needed groups last to first and writes
-         ONE tape: group after group, each result folded into r0 right away (r0 = op(r0, r1))
+         mode 2 (tape groups, level 0): 64 workgroups per block of root tiles, slot = block * n_tgroups; the choice
+         words come from S->chwr (k_tscatter3d) instead of chw[big]
 grid   : 64 workgroups (of one wave) per slot; workgroup = slot * 64 + child lane
 Limits : <= 128 registers
 """
@@ -31,14 +31,16 @@ S_C = "s11"                                    # child lane
 S_TAPE = "s[16:17]"
 S_CHWP = "s[18:19]"                            # address of this child's word 0
 S_DST = "s[20:21]"
-S_K, S_CI, S_CW = "s22", "s23", "s24"
-S_HAVEW = "s7"                                  # (s7 = `big` is dead after the prologue)
-S_MODE, S_LIVEG, S_RANK, S_SLOTI, S_NLIVE, S_NG, S_GOP, S_GI = "s87", "s97", "s100", "s101", "s88", "s89", "s15", "s25"
-S_CWN, S_PREF = "s34", "s35"                  # prefetched choice word, prefetch in flight
+S_B, S_CITOP, S_NNB, S_EL = "s22", "s23", "s24", "s7"   # current batch, lowest choice index decoded so far, batch in flight, emit lane
+S_MODE = "s87"
 S_POOLA, S_POOLB = "s[26:27]", "s[28:29]"
 S_HIGH, S_COUNT, S_KEPT = "s30", "s31", "s32"
 S_END = "s33"                                  # end of the arena slot, in ops
-S_QA, S_QB = 36, 52                            # s[36:51] current 8 ops, s[52:67] next 8 ops
+S_LIVEA, S_LIVEB = "s[36:37]", "s[38:39]"      # old registers with a mapping (= map[r] != DEAD)
+S_CAND, S_FORCE, S_LT64 = "s[40:41]", "s[42:43]", "s[44:45]"   # batch lanes still to visit; OUTPUT ops; out < 64
+S_M, S_M2 = "s[48:49]", "s[62:63]"
+S_VCUR, S_VNXT, S_VNN = "s[50:51]", "s[52:53]", "s[54:55]"     # valid lanes of the three batches in the pipeline
+S_LOADP, S_CHUNKP = "s[58:59]", "s[60:61]"
 S_W0, S_W1, S_W = "s68", "s69", "s[68:69]"
 S_OP, S_OUT, S_A = "s70", "s71", "s72"
 S_NO, S_MA, S_MB = "s73", "s74", "s75"
@@ -49,9 +51,10 @@ S_E0, S_E1 = "s84", "s85"
 S_ALIAS = "s86"
 S_RET = "s[88:89]"
 S_MRR, S_MRI, S_MNOA = "s[90:91]", "s[92:93]", "s[94:95]"   # opcode-set bit masks
-S_QBASE = "s96"                                # index of the first op of the current batch
-S_FETCH = "s[98:99]"
-V_LANE, V_MAPA, V_MAPB, V_E0, V_E1, V_ZERO, V_T = "v0", "v1", "v2", "v4", "v5", "v6", "v7"
+V_LANE, V_MAPA, V_MAPB, V_L8, V_E0, V_E1, V_ZERO, V_T = "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7"
+V_CW0, V_CW1, V_CCH, V_COUT = "v8", "v9", "v10", "v11"         # current batch: op words, choice, out & 63
+V_NW0, V_NW1, V_NCI, V_NCHW = "v12", "v13", "v14", "v15"       # next batch: op words, choice index, choice word (in flight)
+V_NN = "v[16:17]"                                              # the batch below, in flight
 DEAD = 0xFF
 
 
@@ -72,16 +75,19 @@ class Prune1:
 	s_cmp_lt_u32 {reg}, 64
 	s_cselect_b32 {dst}, {dst}, {S_T3}""")
 
-    def map_write(self, reg, val):
+    def map_write(self, reg, val, live):
         hi, done = self.lab("mw_hi"), self.lab("mw_done")
+        bit = "s_bitset1_b64" if live else "s_bitset0_b64"
         self.a(f"""
 	s_mov_b32 m0, {reg}
 	s_cmp_lt_u32 {reg}, 64
 	s_cbranch_scc0 {hi}
 	v_writelane_b32 {V_MAPA}, {val}, m0
+	{bit} {S_LIVEA}, {reg}
 	s_branch {done}
 {hi}:
 	v_writelane_b32 {V_MAPB}, {val}, m0
+	{bit} {S_LIVEB}, {reg}
 {done}:
 	s_nop 0""")
 
@@ -118,18 +124,84 @@ class Prune1:
         self.map_read(dst, reg)
         self.a(f"\ts_cmp_eq_u32 {dst}, {DEAD}\n\ts_cbranch_scc0 {ok}")
         self.take(dst)
-        self.map_write(reg, dst)
+        self.map_write(reg, dst, True)
         self.a(f"{ok}:")
 
     def emit_op(self):
-        """append {S_E0, S_E1} below dst (lane 0 stores)"""
+        """append {S_E0, S_E1} below what was written so far: op n of the child's tape (counted from its
+        end) sits in lane 63 - n % 64 of v[4:5]; a full buffer goes out as one 512-byte store"""
+        skip = self.lab("emit_skip")
         self.a(f"""
-	v_mov_b32 {V_E0}, {S_E0}
-	v_mov_b32 {V_E1}, {S_E1}
-	s_add_u32 s20, s20, -8
-	s_addc_u32 s21, s21, -1
+	s_mov_b32 m0, {S_EL}
 	s_add_u32 {S_COUNT}, {S_COUNT}, 1
-	global_store_dwordx2 {V_ZERO}, v[4:5], {S_DST}""")
+	v_writelane_b32 {V_E0}, {S_E0}, m0
+	v_writelane_b32 {V_E1}, {S_E1}, m0
+	s_sub_u32 {S_EL}, {S_EL}, 1
+	s_cbranch_scc0 {skip}
+	s_lshr_b32 {S_T3}, {S_COUNT}, 6
+	s_lshl_b32 {S_T3}, {S_T3}, 9
+	s_sub_u32 s60, s20, {S_T3}
+	s_subb_u32 s61, s21, 0
+	s_mov_b64 exec, -1
+	global_store_dwordx2 {V_L8}, v[4:5], {S_CHUNKP}
+	s_mov_b64 exec, 1
+	s_mov_b32 {S_EL}, 63
+{skip}:""")
+
+    def advance(self):
+        """one step of the three-deep batch pipeline: current <- next <- in flight; decode the new `next`
+        (choice indices per lane, its choice words requested); request the batch below"""
+        a = self.a
+        noload, loaded = self.lab("adv_noload"), self.lab("adv_loaded")
+        a(f"""
+	s_waitcnt vmcnt(0)
+	s_mov_b64 exec, -1
+	v_mov_b32 {V_CW0}, {V_NW0}
+	v_mov_b32 {V_CW1}, {V_NW1}
+	v_and_b32 {V_T}, 15, {V_NCI}
+	v_lshlrev_b32 {V_T}, 1, {V_T}
+	v_lshrrev_b32 {V_CCH}, {V_T}, {V_NCHW}
+	v_and_b32 {V_CCH}, 3, {V_CCH}
+	s_mov_b64 {S_VCUR}, {S_VNXT}
+	s_mov_b64 {S_VNXT}, {S_VNN}
+	v_and_b32 {V_T}, 0xff, {V_CW0}
+	v_cmp_eq_u32_e64 {S_FORCE}, 0, {V_T}
+	v_bfe_u32 {V_COUT}, {V_CW0}, 8, 12
+	v_cmp_gt_u32_e64 {S_LT64}, 64, {V_COUT}
+	v_and_b32 {V_COUT}, 63, {V_COUT}
+	s_and_b64 {S_FORCE}, {S_FORCE}, {S_VCUR}
+	s_mov_b64 {S_CAND}, {S_VCUR}
+	v_mov_b32 {V_NW0}, v16
+	v_mov_b32 {V_NW1}, v17
+	v_and_b32 {V_T}, 0xff, {V_NW0}
+	v_subrev_u32 v18, 30, {V_T}
+	v_cmp_gt_u32_e64 {S_M}, 4, v18
+	v_subrev_u32 v18, 42, {V_T}
+	v_cmp_gt_u32_e64 {S_M2}, 4, v18
+	s_or_b64 {S_M}, {S_M}, {S_M2}
+	s_and_b64 {S_M}, {S_M}, {S_VNXT}
+	s_bcnt1_i32_b64 {S_T0}, {S_M}
+	s_sub_u32 {S_CITOP}, {S_CITOP}, {S_T0}
+	v_mbcnt_lo_u32_b32 {V_NCI}, s48, 0
+	v_mbcnt_hi_u32_b32 {V_NCI}, s49, {V_NCI}
+	v_add_u32 {V_NCI}, {S_CITOP}, {V_NCI}
+	v_lshrrev_b32 v22, 4, {V_NCI}
+	v_lshlrev_b32 v22, 8, v22
+	s_mov_b64 exec, {S_M}
+	global_load_dword {V_NCHW}, v22, {S_CHWP}
+	s_sub_u32 {S_NNB}, {S_NNB}, 1
+	s_cmp_lt_i32 {S_NNB}, 0
+	s_cbranch_scc1 {noload}
+	s_mov_b64 {S_VNN}, -1
+	s_sub_u32 s58, s58, 0x200
+	s_subb_u32 s59, s59, 0
+	s_mov_b64 exec, -1
+	global_load_dwordx2 {V_NN}, {V_L8}, {S_LOADP}
+	s_branch {loaded}
+{noload}:
+	s_mov_b64 {S_VNN}, 0
+{loaded}:
+	s_mov_b64 exec, 1""")
 
     def emit(self):
         a, o = self.a, self.off
@@ -147,6 +219,7 @@ class Prune1:
 	v_mov_b32 {V_MAPA}, {DEAD}
 	v_mov_b32 {V_MAPB}, {DEAD}
 	v_mov_b32 {V_ZERO}, 0
+	v_lshlrev_b32 {V_L8}, 3, {V_LANE}
 	s_mov_b64 exec, 1
 	s_waitcnt lgkmcnt(0)
 	s_mov_b32 {S_LEVEL}, s8
@@ -155,7 +228,6 @@ class Prune1:
 	s_mov_b32 {S_MODE}, s11
 	s_lshr_b32 {S_T0}, {S_WG}, 6                  ; slot (mode 1: block of root tiles)
 	s_and_b32 {S_C}, {S_WG}, 63                   ; child lane
-	s_load_dword {S_NG}, {S_STATE}, {o['n_tgroups']}
 	; n_slots[big][level], slots[big], chw[big]
 	s_lshl_b32 {S_T1}, {S_BIG}, 3
 	s_add_u32 {S_T1}, {S_T1}, {S_LEVEL}
@@ -169,12 +241,15 @@ class Prune1:
 	s_load_dwordx2 {S_SLOT}, {S_T64}, {o['slots']}
 	s_load_dwordx2 {S_CHWP}, {S_T64}, {o['chw']}
 	s_load_dwordx2 {S_TAPE}, {S_STATE}, {o['arena']}
+	s_cmp_eq_u32 {S_MODE}, 2
+	s_cbranch_scc0 .Lfh_prune1_chwok
 	s_waitcnt lgkmcnt(0)
-	s_cmp_eq_u32 {S_MODE}, 0
-	s_cbranch_scc1 .Lfh_prune1_slotok
-	s_mul_i32 {S_T0}, {S_T0}, {S_NG}               ; the block's primary slot
-.Lfh_prune1_slotok:
-	s_mov_b32 {S_SLOTI}, {S_T0}
+	s_load_dwordx2 {S_CHWP}, {S_STATE}, {o['chwr']}
+	s_load_dword {S_T1}, {S_STATE}, {o['n_tgroups']}
+	s_waitcnt lgkmcnt(0)
+	s_mul_i32 {S_T0}, {S_T0}, {S_T1}                ; the block's primary slot
+.Lfh_prune1_chwok:
+	s_waitcnt lgkmcnt(0)
 	s_cmp_ge_u32 {S_T0}, {S_T2}
 	s_cbranch_scc1 .Lfh_prune1_exit
 	; slot = slots + si * sizeof(FhSlot); chw column of this child
@@ -218,9 +293,9 @@ class Prune1:
 	s_mov_b32 {S_HIGH}, 0
 	s_mov_b32 {S_COUNT}, 0
 	s_mov_b32 {S_KEPT}, 0
-	s_mov_b32 {S_NLIVE}, 0
-	s_cmp_eq_u32 {S_MODE}, 0
-	s_cbranch_scc0 .Lfh_prune1_ginit
+	s_mov_b32 {S_EL}, 63
+	s_mov_b64 {S_LIVEA}, 0
+	s_mov_b64 {S_LIVEB}, 0
 	s_mov_b64 {S_POOLA}, -1
 	s_mov_b64 {S_POOLB}, -1
 .Lfh_prune1_tape:
@@ -231,90 +306,64 @@ class Prune1:
 	s_lshl_b64 s[78:79], s[78:79], 3
 	s_add_u32 s16, s82, {S_T0}
 	s_addc_u32 s17, s83, {S_T1}
-	s_mov_b32 {S_K}, {S_LEN}
-	s_mov_b32 {S_CI}, {S_NCH}
-	s_mov_b32 {S_HAVEW}, 0
-	s_mov_b32 {S_PREF}, 0
-	; first batch: the 8-op block holding op len-1, and the one below it
-	s_sub_u32 {S_T0}, {S_LEN}, 1
-	s_and_b32 {S_QBASE}, {S_T0}, -8
-	s_lshl_b32 {S_T0}, {S_QBASE}, 3
-	s_add_u32 s98, s16, {S_T0}
-	s_addc_u32 s99, s17, 0
-	s_load_dwordx16 s[{S_QA}:{S_QA + 15}], {S_FETCH}, 0x0
-	s_sub_u32 s98, s98, 0x40
-	s_subb_u32 s99, s99, 0
-	s_cmp_eq_u32 {S_QBASE}, 0
-	s_cbranch_scc1 .Lfh_prune1_first
-	s_load_dwordx16 s[{S_QB}:{S_QB + 15}], {S_FETCH}, 0x0
-.Lfh_prune1_first:
-	s_waitcnt lgkmcnt(0)
-{nxt}:
-	s_sub_u32 {S_K}, {S_K}, 1
+	s_cmp_eq_u32 {S_LEN}, 0
 	s_cbranch_scc1 .Lfh_prune1_done
-	s_cmp_ge_u32 {S_K}, {S_QBASE}
-	s_cbranch_scc1 .Lfh_prune1_haveq
-	; next lower block of 8 ops; prefetch the one below it
-	s_waitcnt lgkmcnt(0)""")
-        for i in range(0, 16, 2):
-            a(f"\ts_mov_b64 s[{S_QA + i}:{S_QA + i + 1}], s[{S_QB + i}:{S_QB + i + 1}]")
+	; batches of 64 ops, last first: lane = op index % 64.  Top batch: lanes 0 .. (len-1) % 64
+	s_sub_u32 {S_T0}, {S_LEN}, 1
+	s_lshr_b32 {S_B}, {S_T0}, 6
+	s_and_b32 {S_T0}, {S_T0}, 63
+	s_sub_u32 {S_T0}, 63, {S_T0}
+	s_lshr_b64 {S_VNN}, -1, {S_T0}
+	s_mov_b64 {S_VNXT}, 0
+	s_mov_b64 {S_VCUR}, 0
+	s_mov_b32 {S_NNB}, {S_B}
+	s_mov_b32 {S_CITOP}, {S_NCH}
+	s_lshl_b32 {S_T0}, {S_B}, 9
+	s_add_u32 s58, s16, {S_T0}
+	s_addc_u32 s59, s17, 0
+	s_mov_b64 exec, {S_VNN}
+	global_load_dwordx2 {V_NN}, {V_L8}, {S_LOADP}
+	s_mov_b64 exec, 1""")
+        self.advance()
+        self.advance()
         a(f"""
-	s_sub_u32 {S_QBASE}, {S_QBASE}, 8
-	s_sub_u32 s98, s98, 0x40
-	s_subb_u32 s99, s99, 0
-	s_cmp_eq_u32 {S_QBASE}, 0
-	s_cbranch_scc1 .Lfh_prune1_haveq
-	s_load_dwordx16 s[{S_QB}:{S_QB + 15}], {S_FETCH}, 0x0
-.Lfh_prune1_haveq:
-	s_sub_u32 {S_T0}, {S_K}, {S_QBASE}
-	s_lshl_b32 {S_T0}, {S_T0}, 1
-	s_mov_b32 m0, {S_T0}
-	s_nop 0
-	s_movrels_b64 {S_W}, s[{S_QA}:{S_QA + 1}]
+{nxt}:
+	; which ops of the batch, below the last one handled, write a register that is wanted now?
+	s_mov_b64 exec, -1
+	v_lshrrev_b64 v[18:19], {V_COUT}, {S_LIVEA}
+	v_lshrrev_b64 v[20:21], {V_COUT}, {S_LIVEB}
+	v_cndmask_b32_e64 v18, v20, v18, {S_LT64}
+	v_and_b32 v18, 1, v18
+	v_cmp_ne_u32_e64 {S_M}, 0, v18
+	s_mov_b64 exec, 1
+	{"s_mov_b64 s[48:49], 0" if __import__("os").environ.get("FH_EXP") == "prune_nolive" else ""}
+	s_or_b64 {S_M}, {S_M}, {S_FORCE}
+	s_and_b64 {S_M}, {S_M}, {S_CAND}
+	s_cbranch_scc1 .Lfh_prune1_live
+	; nothing else in this batch: the next one down
+	s_cmp_eq_u32 {S_B}, 0
+	s_cbranch_scc1 .Lfh_prune1_done
+	s_sub_u32 {S_B}, {S_B}, 1""")
+        self.advance()
+        a(f"""
+	s_branch {nxt}
+.Lfh_prune1_live:
+	; the highest such op: everything above it is dead and leaves the state alone
+	s_flbit_i32_b64 {S_T0}, {S_M}
+	s_sub_u32 {S_T0}, 63, {S_T0}
+	s_bfm_b64 {S_M2}, {S_T0}, 0
+	s_and_b64 {S_CAND}, {S_CAND}, {S_M2}
+	v_readlane_b32 {S_W0}, {V_CW0}, {S_T0}
+	v_readlane_b32 {S_W1}, {V_CW1}, {S_T0}
+	v_readlane_b32 {S_CH}, {V_CCH}, {S_T0}
 	s_and_b32 {S_OP}, {S_W0}, 0xff
 	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
 	s_lshr_b32 {S_A}, {S_W0}, 20
-	; ---- choice of this op (min / max / and / or), consumed back to front ---------------------
 	s_mov_b32 {S_CLS}, 0
 	s_bitcmp1_b64 {S_MRR}, {S_OP}
 	s_cselect_b32 {S_CLS}, 1, 0
 	s_bitcmp1_b64 {S_MRI}, {S_OP}
 	s_cselect_b32 {S_CLS}, 2, {S_CLS}
-	s_cmp_eq_u32 {S_CLS}, 0
-	s_cbranch_scc1 .Lfh_prune1_nochoice
-	s_sub_u32 {S_CI}, {S_CI}, 1
-	s_and_b32 {S_T0}, {S_CI}, 15
-	s_cmp_eq_u32 {S_T0}, 15
-	s_cselect_b32 {S_T1}, 0, {S_HAVEW}
-	s_cmp_eq_u32 {S_T1}, 0
-	s_cbranch_scc0 .Lfh_prune1_haveword
-	; a new word of 16 choices: the prefetched one, or (first time) a direct load
-	s_lshr_b32 {S_T1}, {S_CI}, 4
-	s_lshl_b32 {S_T2}, {S_T1}, 8
-	s_add_u32 s82, s18, {S_T2}
-	s_addc_u32 s83, s19, 0
-	s_cmp_eq_u32 {S_PREF}, 0
-	s_cbranch_scc1 .Lfh_prune1_wdirect
-	s_waitcnt lgkmcnt(0)
-	s_mov_b32 {S_CW}, {S_CWN}
-	s_branch .Lfh_prune1_wnext
-.Lfh_prune1_wdirect:
-	s_load_dword {S_CW}, {S_T64}, 0x0
-	s_waitcnt lgkmcnt(0)
-.Lfh_prune1_wnext:
-	s_mov_b32 {S_HAVEW}, 1
-	s_mov_b32 {S_PREF}, 0
-	s_cmp_eq_u32 {S_T1}, 0
-	s_cbranch_scc1 .Lfh_prune1_haveword
-	s_sub_u32 s82, s82, 0x100
-	s_subb_u32 s83, s83, 0
-	s_load_dword {S_CWN}, {S_T64}, 0x0             ; the word below, needed 16 choices from now
-	s_mov_b32 {S_PREF}, 1
-.Lfh_prune1_haveword:
-	s_lshl_b32 {S_T0}, {S_T0}, 1
-	s_lshr_b32 {S_CH}, {S_CW}, {S_T0}
-	s_and_b32 {S_CH}, {S_CH}, 3
-.Lfh_prune1_nochoice:
 	s_cmp_eq_u32 {S_OP}, 0
 	s_cbranch_scc1 .Lfh_prune1_output""")
         self.map_read(S_NO, S_OUT)
@@ -322,7 +371,7 @@ class Prune1:
 	s_cmp_eq_u32 {S_NO}, {DEAD}
 	s_cbranch_scc1 {nxt}                          ; value never used
 	s_mov_b32 {S_T0}, {DEAD}""")
-        self.map_write(S_OUT, S_T0)
+        self.map_write(S_OUT, S_T0, False)
         a(f"""
 	; ---- decided choices / copies alias `out` with the surviving operand ---------------------
 	s_mov_b32 {S_ALIAS}, -1
@@ -344,7 +393,7 @@ class Prune1:
         a(f"""
 	s_cmp_eq_u32 {S_MA}, {DEAD}
 	s_cbranch_scc0 .Lfh_prune1_copyreg""")
-        self.map_write(S_ALIAS, S_NO)       # the operand takes the register over, nothing is emitted
+        self.map_write(S_ALIAS, S_NO, True)       # the operand takes the register over, nothing is emitted
         a(f"""
 	s_branch {nxt}
 .Lfh_prune1_copyreg:""")
@@ -399,84 +448,25 @@ class Prune1:
         a(f"""
 	s_lshl_b32 {S_E0}, {S_MA}, 20
 	s_mov_b32 {S_E1}, {S_W1}
-	s_cmp_eq_u32 {S_MODE}, 0
-	s_cbranch_scc1 .Lfh_prune1_outemit
-	; tape groups: the group's result goes to register `rank` (COPY_REG) instead of the output
-	s_min_u32 {S_T0}, {S_RANK}, 1
-	s_lshl_b32 {S_T0}, {S_T0}, 8
-	s_or_b32 {S_E0}, {S_E0}, {S_T0}
-	s_or_b32 {S_E0}, {S_E0}, 2
-	s_mov_b32 {S_E1}, 0
-.Lfh_prune1_outemit:""")
+""")
         self.emit_op()
         a(f"""
 	s_branch {nxt}
-; ---- tape groups (mode 1) ------------------------------------------------------------------
-.Lfh_prune1_ginit:
-	s_lshl_b32 {S_T1}, {S_C}, 2
-	s_add_u32 s82, s8, {S_T1}
-	s_addc_u32 s83, s9, 0
-	s_load_dword {S_LIVEG}, {S_T64}, {SL_XYZ}        ; groups this child needs (k_tcombine3d)
-	s_load_dword {S_GOP}, {S_STATE}, {o['tgroup_op']}
-	s_waitcnt lgkmcnt(0)
-	s_bcnt1_i32_b32 {S_NLIVE}, {S_LIVEG}
-	s_min_u32 {S_HIGH}, {S_NLIVE}, 2
-	; Written back to front: OUTPUT r0; then, last needed group first: [r0 = op(r0, r1)] after the
-	; group's ops, whose result is copied to r1 (to r0 for the first group).  Only r0 and r1 are
-	; reserved, so the tape needs no more registers than its largest group + 2.
-	s_mov_b32 {S_E0}, 0
-	s_mov_b32 {S_E1}, 0""")
-        self.emit_op()
-        a(f"""
-	s_mov_b32 {S_RANK}, {S_NLIVE}
-.Lfh_prune1_gnext:
-	s_waitcnt lgkmcnt(0)                            ; prefetches of the group just finished
-	s_cmp_eq_u32 {S_LIVEG}, 0
-	s_cbranch_scc1 .Lfh_prune1_finish
-	s_flbit_i32_b32 {S_T0}, {S_LIVEG}
-	s_sub_u32 {S_GI}, 31, {S_T0}
-	s_bitset0_b32 {S_LIVEG}, {S_GI}
-	s_sub_u32 {S_RANK}, {S_RANK}, 1
-	s_cmp_eq_u32 {S_RANK}, 0
-	s_cbranch_scc1 .Lfh_prune1_gfirst
-	s_lshl_b32 {S_E0}, {S_GOP}, 0                   ; r0 = op(r0, r1): out 0, a 0, b 1
-	s_mov_b32 {S_E1}, 1""")
-        self.emit_op()
-        a(f"""
-	s_add_u32 {S_KEPT}, {S_KEPT}, 1
-.Lfh_prune1_gfirst:
-	s_mul_i32 {S_T0}, {S_GI}, 12
-	s_add_u32 s82, s4, {S_T0}
-	s_addc_u32 s83, s5, 0
-	s_load_dwordx2 s[12:13], {S_T64}, {o['tgroup']}
-	s_load_dword s14, {S_T64}, {o['tgroup'] + 8}
-	s_load_dwordx2 {S_CHWP}, {S_STATE}, {o['chw'] + 8}
-	s_load_dwordx2 {S_T64}, {S_STATE}, {o['arena']}
-	; this group's choice words: chw[1] + (primary slot + g) * bytes per slot + lane * 4
-	s_add_u32 {S_T1}, {S_MAXCH}, 15
-	s_lshr_b32 {S_T1}, {S_T1}, 4
-	s_lshl_b32 {S_T1}, {S_T1}, 8
-	s_add_u32 {S_T0}, {S_SLOTI}, {S_GI}
-	s_mul_hi_u32 {S_T2}, {S_T0}, {S_T1}
-	s_mul_i32 {S_T1}, {S_T0}, {S_T1}
-	s_waitcnt lgkmcnt(0)
-	s_add_u32 s18, s18, {S_T1}
-	s_addc_u32 s19, s19, {S_T2}
-	s_lshl_b32 {S_T1}, {S_C}, 2
-	s_add_u32 s18, s18, {S_T1}
-	s_addc_u32 s19, s19, 0
-	; fresh register map; registers 0 .. n_live-1 hold the groups' results and are never handed out
-	s_mov_b64 exec, -1
-	v_mov_b32 {V_MAPA}, {DEAD}
-	v_mov_b32 {V_MAPB}, {DEAD}
-	s_mov_b64 exec, 1
-	s_mov_b64 {S_POOLA}, -4                        ; r0, r1 are taken
-	s_mov_b64 {S_POOLB}, -1
-	s_branch .Lfh_prune1_tape
 .Lfh_prune1_done:
-	s_cmp_eq_u32 {S_MODE}, 0
-	s_cbranch_scc0 .Lfh_prune1_gnext
-.Lfh_prune1_finish:
+	; the ops still in the buffer: lanes 64 - n .. 63
+	s_and_b32 {S_T0}, {S_COUNT}, 63
+	s_cbranch_scc0 .Lfh_prune1_flushed
+	s_sub_u32 {S_T1}, 64, {S_T0}
+	s_bfm_b64 {S_M2}, {S_T0}, {S_T1}
+	s_lshr_b32 {S_T3}, {S_COUNT}, 6
+	s_add_u32 {S_T3}, {S_T3}, 1
+	s_lshl_b32 {S_T3}, {S_T3}, 9
+	s_sub_u32 s60, s20, {S_T3}
+	s_subb_u32 s61, s21, 0
+	s_mov_b64 exec, {S_M2}
+	global_store_dwordx2 {V_L8}, v[4:5], {S_CHUNKP}
+	s_mov_b64 exec, 1
+.Lfh_prune1_flushed:
 	; child = {{ end - count, count, high | kept << 16 }}
 	s_sub_u32 {S_T0}, {S_END}, {S_COUNT}
 	s_lshl_b32 {S_T1}, {S_KEPT}, 16
@@ -484,11 +474,11 @@ class Prune1:
 	s_lshl_b32 {S_T2}, {S_C}, 2
 	s_add_u32 s82, s8, {S_T2}
 	s_addc_u32 s83, s9, 0
-	v_mov_b32 {V_E0}, {S_T0}
-	v_mov_b32 {V_E1}, {S_COUNT}
+	v_mov_b32 v18, {S_T0}
+	v_mov_b32 v19, {S_COUNT}
 	v_mov_b32 {V_T}, {S_T1}
-	global_store_dword {V_ZERO}, {V_E0}, {S_T64} offset:{SL_COFF}
-	global_store_dword {V_ZERO}, {V_E1}, {S_T64} offset:{SL_CLEN}
+	global_store_dword {V_ZERO}, v18, {S_T64} offset:{SL_COFF}
+	global_store_dword {V_ZERO}, v19, {S_T64} offset:{SL_CLEN}
 	global_store_dword {V_ZERO}, {V_T}, {S_T64} offset:{SL_CRC}
 .Lfh_prune1_exit:
 	s_endpgm
@@ -506,9 +496,9 @@ class Prune1:
 		.amdhsa_system_sgpr_workgroup_id_y 0
 		.amdhsa_system_sgpr_workgroup_id_z 0
 		.amdhsa_system_vgpr_workitem_id 0
-		.amdhsa_next_free_vgpr 8
+		.amdhsa_next_free_vgpr 24
 		.amdhsa_next_free_sgpr 102
-		.amdhsa_accum_offset 8
+		.amdhsa_accum_offset 24
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
 		.amdhsa_float_round_mode_16_64 0
@@ -522,4 +512,4 @@ class Prune1:
 
 def gen_prune1(a, off):
     Prune1(a, off).emit()
-    return "fh_prune1", 24, 8, [(8, "global_buffer")] + [(4, "by_value")] * 4
+    return "fh_prune1", 24, 24, [(8, "global_buffer")] + [(4, "by_value")] * 4

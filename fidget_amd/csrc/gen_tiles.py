@@ -17,6 +17,7 @@ kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; 
            u32 skip_regs; u32 skip_choices }   slots whose tape exceeds (max_regs, max_choices) or fits
          (skip_regs, skip_choices) are left to the launch with the matching LDS layout
          flags bit 0: phase probes; bit 2: forward pass only (results + exported choices, nothing else);
+         bit 3: every OUTPUT stores its interval to FhSlot::tvals[output index][lane] (tape groups);
          bit 1: export mode for the long tapes of the pre-pass levels (choice words go
          to S->chw[big][slot][word][lane], pruned lanes are only marked, fh_prune1 sweeps them one per wave)
 LDS    : regs [max_regs][64] x 8 B | choice words [(max_choices+15)/16][64] x 4 B | map [max_regs][64] x 1 B
@@ -66,6 +67,7 @@ S_SKIPR, S_SKIPC = "s7", "s19"   # (s7 = `big` is dead after the prologue)
 S_RR = "s3"
 S_FLAGS = "s101"           # kernarg `flags`: bit 0 = probes, bit 1 = export (choices to HBM, no prune here)
 S_CHW, S_CHWSLOT, S_CHWTMP = "s[78:79]", "s[80:81]", "s[82:83]"   # export mode (the prune registers are free then)
+S_TV = "s[84:85]"          # tape groups (forward only): FhSlot::tvals
 S_SI, S_NWG = "s2", "s100"   # slot index of this wave, waves in the launch
 
 # ---- VGPRs -----------------------------------------------------------------------------------
@@ -416,7 +418,18 @@ class Tiles:
     def handler(self, op):
         a = self.a
         if op == "OUTPUT":
-            a(f"\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32 {V_RESL}, {AL}\n\tv_mov_b32 {V_RESH}, {AH}\n\ts_branch {self.next}")
+            # flags bit 3 (tape groups): the tape's outputs are terms of the root tree, word 1 = term index;
+            # their intervals go to the block's tvals[term][lane]
+            a(f"""
+	s_waitcnt lgkmcnt(0)
+	v_mov_b32 {V_RESL}, {AL}
+	v_mov_b32 {V_RESH}, {AH}
+	s_bitcmp1_b32 {S_FLAGS}, 3
+	s_cbranch_scc0 {self.next}
+	s_lshl_b32 {S_T1}, {S_W1}, 9
+	v_add_u32 {V_TADDR}, {S_T1}, {V_L8}
+	global_store_dwordx2 {V_TADDR}, v[10:11], {S_TV}
+	s_branch {self.next}""")
             return
         if op == "INPUT":
             return self.ool_body("input", self.h_input)
@@ -997,6 +1010,7 @@ class Tiles:
 	s_addc_u32 s21, s15, {S_T0}
 	s_load_dwordx4 s[24:27], {S_SLOT}, 0x0
 	s_load_dwordx2 {S_ACT}, {S_SLOT}, {SL_ACT}
+	s_load_dwordx2 {S_TV}, {S_SLOT}, 0x20
 	s_waitcnt lgkmcnt(0)
 	s_cmp_eq_u64 {S_ACT}, 0
 	s_cbranch_scc1 .Lfh_tiles_outer
@@ -1062,7 +1076,7 @@ class Tiles:
 .Lfh_tiles_noflush:
 	global_store_dword {V_L4}, {V_RESL}, {S_SLOT} offset:{SL_RES}
 	global_store_dword {V_L4}, {V_RESH}, {S_SLOT} offset:{SL_RES + 256}
-	s_bitcmp1_b32 {S_FLAGS}, 2                       ; forward pass only (tape groups: k_tcombine3d goes on)
+	s_bitcmp1_b32 {S_FLAGS}, 2                       ; forward pass only (tape groups: k_ttop3d goes on)
 	s_cbranch_scc1 .Lfh_tiles_outer
 	; ---- classify: ambiguous = act && !(hi < 0) && !(lo > 0); prune those whose trace decided --
 	v_cmp_gt_f32_e64 {S_M[0]}, 0, {V_RESH}

@@ -617,4 +617,182 @@ static inline int split_root(const SsaProgram& p, uint32_t want, uint32_t min_te
     return rr;
 }
 
+// ---- tape parallelism for the renderer: terms of the root tree as separate outputs ------------------
+// split_root's groups recompute shared subexpressions and their pruned tapes cannot simply be glued
+// back together (the duplicates would stay).  For the renderer the split is therefore only used to
+// EVALUATE: the groups hold the tree's terms as outputs (no combining chain), the tree itself - a
+// few hundred min / max ops - becomes a small "top" program over those outputs, and every choice of
+// the full tape is found either in a group's trace or in the top program's (`choice_src`).  The
+// choices of the full tape are then exactly those its own forward pass would have recorded, and the
+// prune works on the full tape as if nothing had been split.
+struct TopOp {
+    uint8_t op;              // FH_MIN_RR / FH_MAX_RR (b_kind 0, 1) or their reg,imm forms (b_kind 2)
+    uint8_t out;             // top register
+    uint8_t a_kind, b_kind;  // 0 top register, 1 term (group output), 2 immediate bits
+    uint32_t a, b;
+};
+struct TermPlan {
+    int op = -1;
+    uint32_t n_terms = 0, top_regs = 0;
+    bool chain = false;                // acc = op(acc, term or constant) all the way, starting from a term
+    std::vector<SsaProgram> groups;    // OUTPUT imm = term index
+    std::vector<TopOp> top;            // evaluation order; the last op writes the root
+    std::vector<uint32_t> choice_src;  // per choice of the full tape, tape order: group << 24 | index; group 255: top op
+};
+static inline bool plan_terms(const SsaProgram& p, uint32_t want, uint32_t min_terms, uint32_t max_top_regs, TermPlan& plan) {
+    plan = TermPlan();
+    if (p.n_outputs != 1 || p.ops.empty() || p.ops[0].op != FH_OUTPUT || want < 2) return false;
+    std::vector<int> def(p.n_values, -1);
+    for (size_t i = 1; i < p.ops.size(); i++) {
+        if (p.ops[i].op == FH_OUTPUT) return false;
+        def[p.ops[i].out] = (int)i;
+    }
+    const uint32_t root = p.ops[0].a;
+    if (def[root] < 0) return false;
+    const int rop = p.ops[def[root]].op;
+    int rr, ri;
+    if (rop == FH_MIN_RR || rop == FH_MIN_RI) { rr = FH_MIN_RR; ri = FH_MIN_RI; }
+    else if (rop == FH_MAX_RR || rop == FH_MAX_RI) { rr = FH_MAX_RR; ri = FH_MAX_RI; }
+    else return false;
+    // tree nodes and, in order of first appearance, the values hanging off the tree
+    std::vector<char> is_node(p.n_values, 0);
+    std::vector<int> term_of(p.n_values, -1);
+    std::vector<uint32_t> terms;
+    std::vector<uint32_t> stack{root};
+    while (!stack.empty()) {
+        const uint32_t v = stack.back();
+        stack.pop_back();
+        const SsaOp& o = p.ops[def[v]];
+        if (o.op == rr || o.op == ri) {
+            if (is_node[v]) continue;
+            is_node[v] = 1;
+            if (o.op == rr) stack.push_back(o.b);
+            stack.push_back(o.a);
+        } else if (term_of[v] < 0) {
+            term_of[v] = (int)terms.size();
+            terms.push_back(v);
+        }
+    }
+    if (terms.size() < min_terms || terms.size() >= (1u << 20)) return false;
+    // a tree node may also be used from inside a term; then it is a term as well (its value must be
+    // an output of some group), evaluated a second time by the top program - same inputs, same result
+    // the top program: the tree's ops in evaluation order (p.ops is root first)
+    std::vector<int> top_index(p.n_values, -1), last_use(p.n_values, -1);
+    std::vector<uint32_t> order;
+    for (size_t i = p.ops.size(); i-- > 1;)
+        if (is_node[p.ops[i].out]) { top_index[p.ops[i].out] = (int)order.size(); order.push_back((uint32_t)i); }
+    for (size_t k = 0; k < order.size(); k++) {
+        const SsaOp& o = p.ops[order[k]];
+        if (is_node[o.a]) last_use[o.a] = (int)k;
+        if (o.op == rr && is_node[o.b]) last_use[o.b] = (int)k;
+    }
+    std::vector<int> treg(p.n_values, -1);
+    std::vector<int> free_regs;
+    uint32_t high = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+        const SsaOp& o = p.ops[order[k]];
+        TopOp t{};
+        t.op = o.op;
+        auto operand = [&](uint32_t v, uint8_t& kind, uint32_t& ref) -> bool {
+            if (is_node[v]) { if (treg[v] < 0) return false; kind = 0; ref = (uint32_t)treg[v]; }
+            else { kind = 1; ref = (uint32_t)term_of[v]; }
+            return true;
+        };
+        if (!operand(o.a, t.a_kind, t.a)) return false;
+        if (o.op == rr) { if (!operand(o.b, t.b_kind, t.b)) return false; }
+        else { t.b_kind = 2; t.b = o.imm; }
+        // operands die here (a value used twice by the same op is released once)
+        if (is_node[o.a] && last_use[o.a] == (int)k) { free_regs.push_back(treg[o.a]); }
+        if (o.op == rr && is_node[o.b] && o.b != o.a && last_use[o.b] == (int)k) { free_regs.push_back(treg[o.b]); }
+        int r;
+        if (!free_regs.empty()) { r = free_regs.back(); free_regs.pop_back(); }
+        else r = (int)high++;
+        if (high > max_top_regs || r > 255) return false;
+        treg[o.out] = r;
+        t.out = (uint8_t)r;
+        plan.top.push_back(t);
+    }
+    if (plan.top.empty() || p.ops[order.back()].out != root) return false;
+    plan.top_regs = high;
+    plan.chain = plan.top[0].a_kind == 1 && plan.top[0].b_kind != 0;
+    for (size_t k = 1; k < plan.top.size() && plan.chain; k++) plan.chain = plan.top[k].a_kind == 0 && plan.top[k].b_kind != 0;
+    plan.n_terms = (uint32_t)terms.size();
+    plan.op = rr;
+    // groups: contiguous runs of terms of about equal weight (ops a term reaches)
+    std::vector<uint32_t> weight(terms.size(), 1), mark(p.n_values, 0), work;
+    uint64_t total = 0;
+    for (size_t t = 0; t < terms.size(); t++) {
+        uint32_t n = 0;
+        work.assign(1, terms[t]);
+        while (!work.empty()) {
+            const uint32_t v = work.back();
+            work.pop_back();
+            if (mark[v] == t + 1) continue;
+            mark[v] = (uint32_t)t + 1;
+            n++;
+            const SsaOp& o = p.ops[def[v]];
+            if (o.op != FH_INPUT && o.op != FH_COPY_IMM) work.push_back(o.a);
+            if (fh_is_rr(o.op)) work.push_back(o.b);
+        }
+        weight[t] = n;
+        total += n;
+    }
+    const uint64_t per = (total + want - 1) / want;
+    std::vector<std::pair<size_t, size_t>> runs;
+    size_t first = 0;
+    uint64_t acc = 0;
+    for (size_t t = 0; t < terms.size(); t++) {
+        acc += weight[t];
+        if (acc >= per && runs.size() + 1 < want) { runs.push_back({first, t + 1}); first = t + 1; acc = 0; }
+    }
+    if (first < terms.size()) runs.push_back({first, terms.size()});
+    if (runs.size() < 2) return false;
+    // per group: each term's OUTPUT right after (in evaluation order) the op that defines it, so that
+    // a term's register is free again as soon as it is stored
+    std::vector<std::vector<int>> local_choice(runs.size());
+    for (size_t g = 0; g < runs.size(); g++) {
+        SsaProgram gp;
+        gp.n_values = p.n_values;
+        gp.n_outputs = plan.n_terms;
+        gp.vars = p.vars;
+        std::vector<int> out_term(p.n_values, -1);
+        for (size_t t = runs[g].first; t < runs[g].second; t++) out_term[terms[t]] = (int)t;
+        for (size_t i = 1; i < p.ops.size(); i++) {
+            const SsaOp& o = p.ops[i];
+            if (out_term[o.out] >= 0) gp.ops.push_back(SsaOp{FH_OUTPUT, 0, o.out, 0, (uint32_t)out_term[o.out]});
+            gp.ops.push_back(o);
+        }
+        drop_dead(gp);
+        // choice index, in this group's tape order, of every choice op it holds
+        local_choice[g].assign(p.n_values, -1);
+        int rank = 0;
+        for (size_t i = gp.ops.size(); i-- > 0;)
+            if (gp.ops[i].op != FH_OUTPUT && fh_is_choice(gp.ops[i].op)) local_choice[g][gp.ops[i].out] = rank++;
+        plan.groups.push_back(std::move(gp));
+    }
+    // where each choice of the full tape is recorded
+    std::vector<char> live(p.n_values, 0);  // (same liveness rule as allocate / drop_dead)
+    live[root] = 1;
+    std::vector<char> live_op(p.ops.size(), 0);
+    for (size_t i = 1; i < p.ops.size(); i++) {
+        const SsaOp& o = p.ops[i];
+        if (!live[o.out]) continue;
+        live_op[i] = 1;
+        if (o.op != FH_INPUT && o.op != FH_COPY_IMM) live[o.a] = 1;
+        if (fh_is_rr(o.op)) live[o.b] = 1;
+    }
+    for (size_t i = p.ops.size(); i-- > 1;) {
+        const SsaOp& o = p.ops[i];
+        if (!live_op[i] || !fh_is_choice(o.op)) continue;
+        uint32_t src = 0xFFFFFFFFu;
+        if (is_node[o.out]) src = (255u << 24) | (uint32_t)top_index[o.out];
+        else
+            for (size_t g = 0; g < runs.size(); g++)
+                if (local_choice[g][o.out] >= 0) { src = ((uint32_t)g << 24) | (uint32_t)local_choice[g][o.out]; break; }
+        if (src == 0xFFFFFFFFu) return false;
+        plan.choice_src.push_back(src);
+    }
+    return plan.choice_src.size() == p.n_choices;
+}
+
 }  // namespace fh

@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
     // Parents map to slots one to one and waves to parents round robin: no atomic cursors (they
     // serialise in L2 and cost more than this kernel's work)
     // Tape parallelism at level 0: every block of root tiles gets one slot per independent tape
-    // group (slots g0 .. g0 + G - 1, same children, different tapes); k_tcombine3d merges them.
+    // group (slots g0 .. g0 + G - 1, same children, different tapes); k_ttop3d merges them.
     const uint32_t G = (level == 0 && S->n_tgroups) ? S->n_tgroups : 1;
     const uint32_t ns = min(S->count[level], S->slot_cap[0]), nb = min(S->count_big[level], S->slot_cap[1] / G);
     if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns; S->n_slots[1][level] = nb * G; }
@@ -582,6 +582,7 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
                 const FhTapeRef tr = (G > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
                 so.tape = tr;
                 so.level = (uint32_t)level; so.act = actm; so.base = 0; so.overflow = 0;
+                so.tvals = (G > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : nullptr;
             }
             so.xyz[0][lane] = X.lo; so.xyz[1][lane] = X.hi; so.xyz[2][lane] = Y.lo; so.xyz[3][lane] = Y.hi;
             so.xyz[4][lane] = Z.lo; so.xyz[5][lane] = Z.hi;
@@ -590,56 +591,144 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
     }
 }
 
-// Tape parallelism at level 0, after the forward passes of the groups: the children's intervals
-// are the running min / max of the groups' results, in order - with the Choice each step of that
-// chain would record (vm/mod.rs:436-471): a group whose interval is dominated is not needed by that
-// child at all.  For every ambiguous child this reserves arena space for its pruned tape and leaves
-// the list of groups it needs; fh_prune1 (group mode) writes the tape, k_tpush3d queues it.
-__global__ void __launch_bounds__(WAVE) k_tcombine3d(FhRenderState* S) {
+// Tape parallelism at level 0 (host_graph.hpp plan_terms), after the groups' forward passes left the
+// terms' intervals in S->tvals: the root min / max tree over those terms, with the Choice every op
+// of the tree records (vm/mod.rs:436-471 via iv_min / iv_max) in topch[block][child][op].
+//
+// The usual tree is a chain, acc = op(acc, term): its accumulator is a prefix min / max of the terms
+// (associative and exact, NaN absorbing), so one wave per child scans 64 ops at a time.
+// grid (64 children, blocks), lane = op within the chunk.
+FH_DEV IV top_comb(bool is_min, IV a, IV b) {
+    if (iv_has_nan(a) || iv_has_nan(b)) return iv_nan();
+    return is_min ? iv(rmin(a.lo, b.lo), rmin(a.hi, b.hi)) : iv(rmax(a.lo, b.lo), rmax(a.hi, b.hi));
+}
+__global__ void __launch_bounds__(WAVE) k_tchain3d(FhRenderState* S) {
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x, b = blockIdx.y, G = S->n_tgroups, n_top = S->n_top;
+    if (b >= S->n_slots[1][0] / G) return;
+    FhSlot& p = S->slots[1][(size_t)b * G];
+    if (((p.act >> c) & 1) == 0) return;
+    const IV* const tv = (const IV*)S->tvals + (size_t)b * S->n_terms * WAVE;
+    uint8_t* const tc = S->topch + ((size_t)b * WAVE + c) * n_top;
+    const uint32_t* const top = (const uint32_t*)S->ttop;
+    const bool is_min = (top[0] & 0xFF) == FH_MIN_RR || (top[0] & 0xFF) == FH_MIN_RI;
+    const float ident = is_min ? u2f(0x7f800000u) : u2f(0xff800000u);
+    IV carry = tv[(size_t)top[1] * WAVE + c];   // the chain starts from the first op's `a`, a term
+    for (uint32_t j0 = 0; j0 < n_top; j0 += WAVE) {
+        const uint32_t j = j0 + lane;
+        const bool valid = j < n_top;
+        IV e = iv(ident, ident);
+        if (valid) {
+            const uint32_t bk = top[3 * j] >> 24, bv = top[3 * j + 2];
+            e = bk == 1 ? tv[(size_t)bv * WAVE + c] : iv1(u2f(bv));
+        }
+        IV incl = e;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const IV o = iv(__shfl_up(incl.lo, d, WAVE), __shfl_up(incl.hi, d, WAVE));
+            if (lane >= d) incl = top_comb(is_min, o, incl);
+        }
+        IV before = iv(__shfl_up(incl.lo, 1, WAVE), __shfl_up(incl.hi, 1, WAVE));
+        before = lane == 0 ? carry : top_comb(is_min, carry, before);
+        int ch;
+        if (is_min) (void)iv_min(before, e, ch); else (void)iv_max(before, e, ch);
+        if (valid) tc[j] = (uint8_t)ch;
+        carry = top_comb(is_min, carry, iv(__shfl(incl.lo, WAVE - 1, WAVE), __shfl(incl.hi, WAVE - 1, WAVE)));
+    }
+    if (lane == 0) { p.res[0][c] = carry.lo; p.res[1][c] = carry.hi; }
+}
+
+// Any other tree: op by op, one child per lane (registers of the tree in LDS).
+#define FH_TOP_REGS 16
+__global__ void __launch_bounds__(WAVE) k_ttop3d(FhRenderState* S) {
+    __shared__ IV regs[FH_TOP_REGS][WAVE];
+    const int lane = threadIdx.x;
+    const uint32_t G = S->n_tgroups, n_top = S->n_top, n_terms = S->n_terms;
+    const uint32_t nblk = S->n_slots[1][0] / G;
+    const AS4 uint32_t* const top = (const AS4 uint32_t*)S->ttop;   // 3 words per op
+    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        FhSlot& p = S->slots[1][(size_t)b * G];
+        if (p.act == 0) continue;
+        const IV* const tv = (const IV*)S->tvals + (size_t)b * n_terms * WAVE;
+        uint8_t* const tc = S->topch + ((size_t)b * WAVE + lane) * n_top;
+        IV r = iv_nan();
+        for (uint32_t j0 = 0; j0 < n_top; j0 += 8) {  // the terms of 8 ops are fetched together (independent loads)
+            FhTopOp o[8];
+            IV ta[8], tb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t j = min(j0 + u, n_top - 1), w0 = top[3 * j];
+                o[u].op = (uint8_t)w0; o[u].out = (uint8_t)(w0 >> 8); o[u].a_kind = (uint8_t)(w0 >> 16); o[u].b_kind = (uint8_t)(w0 >> 24);
+                o[u].a = top[3 * j + 1]; o[u].b = top[3 * j + 2];
+                ta[u] = o[u].a_kind == 1 ? tv[(size_t)o[u].a * WAVE + lane] : iv_nan();
+                tb[u] = o[u].b_kind == 1 ? tv[(size_t)o[u].b * WAVE + lane] : iv1(__uint_as_float(o[u].b));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (j0 + u >= n_top) break;
+                const IV a = o[u].a_kind == 0 ? regs[o[u].a][lane] : ta[u];
+                const IV bb = o[u].b_kind == 0 ? regs[o[u].b][lane] : tb[u];
+                int c;
+                r = (o[u].op == FH_MIN_RR || o[u].op == FH_MIN_RI) ? iv_min(a, bb, c) : iv_max(a, bb, c);
+                regs[o[u].out][lane] = r;
+                tc[j0 + u] = (uint8_t)c;
+            }
+        }
+        p.res[0][lane] = r.lo; p.res[1][lane] = r.hi;
+    }
+}
+
+// The tree's result is the root tape's result: ambiguous children reserve arena space for their
+// pruned tape and are marked for fh_prune1, exactly as fh_tiles does in export mode.
+__global__ void __launch_bounds__(WAVE) k_tmark3d(FhRenderState* S) {
     const int lane = threadIdx.x;
     const uint32_t G = S->n_tgroups;
-    const bool is_min = S->tgroup_op == FH_MIN_RR;
     const uint32_t nblk = S->n_slots[1][0] / G;
-    const FhTapeRef root = FhTapeRef{0, S->tgroup[0].off - 16, (uint16_t)S->P.max_regs, (uint16_t)S->P.max_choices};
+    const FhTapeRef root = FhTapeRef{0, S->troot_len, (uint16_t)S->troot_regs, (uint16_t)S->troot_choices};
     for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
         FhSlot* const slg = &S->slots[1][(size_t)b * G];
         const uint64_t actm = slg[0].act;
+        if (lane >= 1 && lane < (int)G) slg[lane].act = 0;   // only the primary slot is pushed
         if (actm == 0) continue;
         const bool act = (actm >> lane) & 1;
-        IV acc = iv(slg[0].res[0][lane], slg[0].res[1][lane]);
-        uint32_t live = 1;
-        for (uint32_t k = 1; k < G; k++) {
-            const IV m = iv(slg[k].res[0][lane], slg[k].res[1][lane]);
-            if (iv_has_nan(acc) || iv_has_nan(m)) { acc = iv_nan(); live |= 1u << k; continue; }  // Both
-            const bool left = is_min ? acc.hi < m.lo : acc.lo > m.hi;    // the chain so far wins: group k is not needed
-            const bool right = is_min ? m.hi < acc.lo : m.lo > acc.hi;   // group k alone wins
-            acc = is_min ? iv(rmin(acc.lo, m.lo), rmin(acc.hi, m.hi)) : iv(rmax(acc.lo, m.lo), rmax(acc.hi, m.hi));
-            if (left) continue;
-            live = right ? (1u << k) : (live | (1u << k));
-        }
-        const bool full = act && acc.hi < 0.0f, empty = act && !full && acc.lo > 0.0f;
+        FhSlot& p = slg[0];
+        const IV r = iv(p.res[0][lane], p.res[1][lane]);
+        const bool full = act && r.hi < 0.0f, empty = act && !full && r.lo > 0.0f;
         const bool amb = act && !full && !empty;
-        // arena: the groups' pruned tapes back to back + one copy and one combining op per group
-        uint32_t need = 0;
-        if (amb) {
-            for (uint32_t k = 0; k < G; k++) if ((live >> k) & 1) need += S->tgroup[k].len + 2;
-        }
-        uint32_t total;
-        const uint32_t before = wave_excl_sum(need, total);
+        const uint64_t am = ballot(amb);
+        const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1));
         uint32_t base = 0;
-        if (lane == 0 && total) base = atomicAdd(&S->arena_head, total);
+        if (lane == 0 && n) base = atomicAdd(&S->arena_head, n * root.len);
         base = uni(base);
-        const bool ok = total && base + total <= S->arena_cap;
-        if (total && !ok && lane == 0) atomicAdd(&S->arena_overflow, 1u);  // the children keep the root tape
-        FhSlot& p = slg[0];  // the primary slot carries the block from here on
-        p.res[0][lane] = acc.lo; p.res[1][lane] = acc.hi;
-        p.c_off[lane] = (amb && ok) ? base + before + need : root.off;      // end of this child's tape space
-        p.c_len[lane] = (amb && ok) ? 0xFFFFFFFFu : root.len;               // ~0: to be written by fh_prune1
+        const bool ok = n && base + n * root.len <= S->arena_cap;
+        if (n && !ok && lane == 0) atomicAdd(&S->arena_overflow, 1u);  // the children keep the root tape
+        p.c_off[lane] = (amb && ok) ? base + (rank + 1) * root.len : root.off;   // end of this child's arena slot
+        p.c_len[lane] = (amb && ok) ? 0xFFFFFFFFu : root.len;                    // ~0: to be written by fh_prune1
         p.c_rc[lane] = (uint32_t)root.n_regs | ((uint32_t)root.n_choices << 16);
-        ((uint32_t*)p.xyz[0])[lane] = live;                                 // groups this child needs
-        if (lane == 0) { p.tape = root; }
-        if (lane >= 1 && lane < (int)G) slg[lane].act = 0;                  // only the primary slot is pushed
+        if (lane == 0) { p.tape = root; if (ok) p.base = base; else if (n) p.overflow = 1; }
     }
+}
+
+// ... and the choice words of the root tape, gathered from the groups' traces and the tree's:
+// grid (word, block), lane = child.
+__global__ void __launch_bounds__(WAVE) k_tscatter3d(FhRenderState* S, uint32_t group_words, uint32_t root_words) {
+    const int lane = threadIdx.x;
+    const uint32_t w = blockIdx.x, b = blockIdx.y, G = S->n_tgroups;
+    if (b >= S->n_slots[1][0] / G) return;
+    if (S->slots[1][(size_t)b * G].act == 0) return;
+    const uint32_t nch = S->troot_choices;
+    const AS4 uint32_t* const src = (const AS4 uint32_t*)S->chsrc;
+    const uint8_t* const tc = S->topch + ((size_t)b * WAVE + lane) * S->n_top;
+    const uint32_t* const gw = S->chw[1] + (size_t)b * G * group_words * WAVE;
+    uint32_t out = 0;
+    for (uint32_t i = 0; i < 16 && w * 16 + i < nch; i++) {
+        const uint32_t e = src[w * 16 + i], g = e >> 24, j = e & 0xFFFFFFu;
+        uint32_t c;
+        if (g == 255) c = tc[j];
+        else c = (gw[((size_t)g * group_words + (j >> 4)) * WAVE + lane] >> ((j & 15) * 2)) & 3u;
+        out |= c << (2 * i);
+    }
+    S->chwr[((size_t)b * G * root_words + w) * WAVE + lane] = out;
 }
 
 // Step 2 in C++ (reference implementation of fh_tiles; used for tapes outside the assembly

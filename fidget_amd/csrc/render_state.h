@@ -22,12 +22,18 @@ struct FhGroup {
 // A parent tile in flight between the kernels of the split 3D tile stage (setup -> evaluate +
 // prune -> push); one entry per lane = per child tile.  SoA so that every access is coalesced.
 #define FH_SLOT_LANES 64
+// One op of the root tree over the terms (host_graph.hpp TopOp)
+struct FhTopOp {
+    uint8_t op, out, a_kind, b_kind;   // kinds: 0 top register, 1 term, 2 immediate
+    uint32_t a, b;
+};
+
 struct FhSlot {
     FhTapeRef tape;                 // parent tape
     uint32_t level;
     uint64_t act;                   // in : children to evaluate (inside the image, not occluded)
     uint32_t base, overflow;        // out: arena reservation of the pruned tapes / arena full
-    uint32_t pad[2];
+    float* tvals;                   // in : tape groups: where this block's term intervals go ([term][lane])
     float xyz[6][FH_SLOT_LANES];    // in : x.lo x.hi y.lo y.hi z.lo z.hi (model space)
     uint32_t corner[3][FH_SLOT_LANES];  // in : child corner (voxels)
     float res[2][FH_SLOT_LANES];    // out: interval result
@@ -84,10 +90,18 @@ struct FhRenderState {
     // split 3D tile stage: slots[0] = tapes that fit the small LDS layout, slots[1] = the others
     FhSlot* slots[2];
     uint32_t slot_cap[2];
-    // tape parallelism at level 0 (host_graph.hpp split_root): n_tgroups independent tapes (in the
-    // arena right after the root tape) whose outputs combine, in order, with tgroup_op
+    // tape parallelism at level 0 (host_graph.hpp plan_terms): the root min / max tree's terms are
+    // evaluated by n_tgroups independent tapes (in the arena right after the root tape) into
+    // tvals[block][term][lane]; the tree itself (ttop, n_top ops) runs over those values; chsrc tells
+    // for every choice of the root tape where it was recorded; chwr[slot][word][lane] then holds the
+    // choice words of the root tape as its own forward pass would have written them.
     FhTapeRef tgroup[FH_MAX_GROUPS];
-    uint32_t n_tgroups, tgroup_op;
+    uint32_t n_tgroups, n_terms, n_top, top_chain, troot_len, troot_choices, troot_regs;
+    const FhTopOp* ttop;
+    const uint32_t* chsrc;
+    float* tvals;        // [block][term][lane] x {lo, hi}
+    uint8_t* topch;      // [block][child][top op]
+    uint32_t* chwr;
     // pre-pass levels: choice words [slot][word][lane] of the forward pass, read by the
     // one-wave-per-child prune (fh_prune1); [0] small-LDS list (16 words per slot), [1] the other
     uint32_t* chw[2];

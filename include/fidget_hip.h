@@ -73,6 +73,11 @@ uint32_t fhip_tape_ops(const fhip_tape* tape, uint64_t* ops, uint32_t cap);
 uint32_t fhip_tape_group_count(const fhip_tape* tape);
 int fhip_tape_group_op(const fhip_tape* tape);
 fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fhip_tape** out);
+/* The form of that split the 3D renderer uses at its root level: groups that output the terms of the
+ * root min / max tree, the tree as a small program over them, and a table saying where each choice of
+ * the full tape is recorded.  Returns the number of groups (0: not split);
+ * info = { terms, tree ops, tree registers, choices covered (= fhip_tape_choice_count) }. */
+uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]);
 
 /* Function::simplify (eval/mod.rs:147-160; VmData::simplify vm/data.rs:123-318).
  * `choices` is one byte per choice op in evaluation order, values 1/2/3 = Left/Right/Both. */

@@ -116,13 +116,13 @@ def test_render3d_non_cubic(whd):
 
 
 @pytest.mark.gpu
-def test_render3d_with_tape_groups():
-    """Experimental tape parallelism at the root level (FHIP_TAPE_GROUPS=1): same image."""
+def test_render3d_without_tape_groups():
+    """The root level as one tape (FHIP_NO_TAPE_GROUPS=1; the default splits it, see test_groups.py): same image."""
     import subprocess, sys, textwrap
     code = textwrap.dedent(f"""
         import os, sys
         sys.path.insert(0, {ROOT!r})
-        os.environ["FHIP_TAPE_GROUPS"] = "1"
+        os.environ["FHIP_NO_TAPE_GROUPS"] = "1"
         import numpy as np, fidget_amd as F, oracle as O
         m = os.path.join({ROOT!r}, "models", "prospero.vm")
         for n in (128, 256):
