@@ -231,9 +231,10 @@ uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]) {
     return (uint32_t)tape->tgroups.size();
 }
 // Launch one of the assembly kernels: `waves` single-wave workgroups, raw kernarg block
-static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0, uint32_t grid_y = 1) {
+static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0, uint32_t grid_y = 1,
+                             hipStream_t stream = nullptr) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, ctx->stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, stream ? stream : ctx->stream, nullptr, extra);
     if (e != hipSuccess && ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
     return e;
 }
@@ -751,6 +752,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     S.normals = (float*)ctx->normals.p;
     S.image2d = nullptr;
     memset(S.stat, 0, sizeof(S.stat));
+    S.want_stats = (ctx->profiling || ctx->probe || getenv("FHIP_STATS")) ? 1 : 0;
     if (((size_t)t.ops.size() + 64) * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
     // level-0 groups sit at the back of queue[0] (the "big" half), in reverse order
     std::reverse(R.roots.begin(), R.roots.end());
@@ -838,11 +840,21 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
             ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
             ka.skip_regs = ka.skip_choices = 0;
+            // Pre-pass levels below the root: the small-layout parents and the others are different slot lists;
+            // their launches run side by side (second stream) instead of one after the other.
+            const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && ctx->stream2 &&
+                              ctx->stream != ctx->stream2 && !getenv("FHIP_PIPE_SERIAL");
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
-                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
+                if (side) {
+                    (void)hipEventRecord(ctx->ev_fork, ctx->stream);
+                    (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+                }
+                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small, 1, side ? ctx->stream2 : nullptr);
+                if (side) (void)hipEventRecord(ctx->ev_tiles[0], ctx->stream2);
             }
             ka.big = 1;
+            if (exp) ka.flags |= ((R.S.P.max_choices + 15) / 16) << 16;  // one stride in chw[1] for the medium and the large layout
             // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
             // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
             // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
@@ -855,6 +867,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             }
             ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
+            if (side) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_tiles[0], 0);
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
                 const uint32_t bound = R.S.qcap[level] * 64;  // 64 waves per possible parent; unmarked children exit at once
@@ -872,7 +885,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         if (R.full) hipLaunchKernelGGL((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
         else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
-    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
+    // (last level: fewer waves, several parents each - one leaf reservation per wave)
+    static const int push_mul = getenv("FHIP_PUSH_WAVES") ? atoi(getenv("FHIP_PUSH_WAVES")) : 2;
+    const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
+    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level); });
 }
 
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {

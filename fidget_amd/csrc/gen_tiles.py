@@ -17,6 +17,7 @@ kernarg: { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; 
            u32 skip_regs; u32 skip_choices }   slots whose tape exceeds (max_regs, max_choices) or fits
          (skip_regs, skip_choices) are left to the launch with the matching LDS layout
          flags bit 0: phase probes; bit 2: forward pass only (results + exported choices, nothing else);
+         bits 31:16: export mode: choice words per slot in S->chw (0: as in the LDS layout);
          bit 3: every OUTPUT stores its interval to FhSlot::tvals[output index][lane] (tape groups);
          bit 1: export mode for the long tapes of the pre-pass levels (choice words go
          to S->chw[big][slot][word][lane], pruned lanes are only marked, fh_prune1 sweeps them one per wave)
@@ -998,8 +999,13 @@ class Tiles:
 	s_cbranch_scc1 .Lfh_tiles_exit
 	s_mov_b32 {S_T0}, {S_SI}
 	s_add_u32 {S_SI}, {S_SI}, {S_NWG}
-	; export mode: this slot's choice words at chw[big] + si * (words * 256 B)
+	; export mode: this slot's choice words at chw[big] + si * (words * 256 B); words = flags[31:16], or
+	; (0) those of this launch's LDS layout
 	s_sub_u32 {S_T2}, {S_MAPBASE}, {S_CHBASE}
+	s_lshr_b32 {S_T3}, {S_FLAGS}, 16
+	s_lshl_b32 {S_T3}, {S_T3}, 8
+	s_cmp_eq_u32 {S_T3}, 0
+	s_cselect_b32 {S_T2}, {S_T2}, {S_T3}
 	s_mul_hi_u32 {S_T3}, {S_T0}, {S_T2}
 	s_mul_i32 {S_T2}, {S_T0}, {S_T2}
 	s_add_u32 s80, s78, {S_T2}

@@ -815,6 +815,22 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
     const uint32_t ntx = (P.width + T - 1) / T;
     const bool last_level = (level + 1 == (int)P.n_levels);
     const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    // Leaves: ONE reservation per wave for all its parents (a first pass counts them).  One atomic per
+    // parent on the same counter serialises in L2, ~15 ns each: with thousands of parents that was
+    // nearly all of this kernel's time.
+    uint32_t leaf_base = 0;
+    if (last_level) {
+        uint32_t mine = 0;
+        for (uint32_t si = blockIdx.x; si < n0 + n1; si += gridDim.x) {
+            const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
+            const uint64_t actm = sl.act;
+            if (uni((uint32_t)(actm != 0)) == 0) continue;
+            const float lo = sl.res[0][lane], hi = sl.res[1][lane];
+            mine += (uint32_t)__popcll(ballot(((actm >> lane) & 1) && !(hi < 0.0f) && !(lo > 0.0f)));
+        }
+        if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
+        leaf_base = uni(leaf_base);
+    }
     for (uint32_t si = blockIdx.x; si < n0 + n1; si += gridDim.x) {
         const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
         if (uni((uint32_t)(sl.act != 0)) == 0) continue;
@@ -834,7 +850,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
             }
         }
-        {   // algorithmic-bytes accounting: tape ops read by this parent, ops of pruned tapes written
+        if (S->want_stats) {   // algorithmic-bytes accounting: tape ops read by this parent, ops of pruned tapes written
             uint32_t wsum;
             wave_excl_sum((amb && sl.c_off[lane] != sl.tape.off) ? sl.c_len[lane] : 0u, wsum);
             if (lane == 0) { atomicAdd(&S->stat[48 + level], (unsigned long long)sl.tape.len); atomicAdd(&S->stat[56 + level], (unsigned long long)wsum); }
@@ -867,11 +883,9 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 else qdst[qcap - 1 - (qb + slot_b)] = o;
             }
         } else {
-            uint32_t namb;
-            const uint32_t slot = wave_excl_sum(amb ? 1u : 0u, namb);
-            uint32_t lb = 0;
-            if (lane == 0) lb = atomicAdd(&S->n_leaves, namb);
-            lb = uni(lb);
+            const uint32_t namb = (uint32_t)__popcll(am), slot = (uint32_t)__popcll(am & ((1ull << lane) - 1));
+            const uint32_t lb = leaf_base;
+            leaf_base += namb;
             if (amb && lb + slot < S->leaf_cap) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;

@@ -121,6 +121,8 @@ struct FhRenderState {
     uint64_t* zbuf;         // 3D: depth << 32 | leaf id (+1) of a hit whose normal is pending
     float* normals;         // 3D: 3 floats per pixel
     float* image2d;         // 2D: RawDistancePixel bits
-    // statistics (optional, for bench / roofline accounting)
+    // statistics (optional, for bench / roofline accounting); want_stats: count tape ops per level (two
+    // same-address atomics per parent tile: only in profiled frames)
+    uint32_t want_stats, pad_stats;
     unsigned long long stat[64];
 };

@@ -1,8 +1,3 @@
-R=$PWD
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -4
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tr; FHIP_NO_PIPELINE=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2>&1
-python $R/tools/trace_summary.py /tmp/tr 130 | grep -A14 "fillBufferAligned" | tail -16
-cd $R
-timeout 100 python bench.py --steps 40 --warmup 3 --no-cpu 2>/dev/null | python -c "
-import json,sys,os;d=json.loads(sys.stdin.read());print(d['ms_per_step'], d['kernel_ms_per_frame'])"
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_groups.py -m gpu -q -x 2>&1 | tail -3
+for i in 1 2; do timeout 100 python bench.py --steps 40 --warmup 3 --no-cpu 2>/dev/null | python -c "
+import json,sys,os;d=json.loads(sys.stdin.read());print(d['ms_per_step'], d['kernel_ms_per_frame'])"; done
