@@ -62,6 +62,7 @@ class Prune1:
     def __init__(self, a, off):
         self.a, self.off = a, off
         self.n = 0
+        self.ool = []     # rare paths (registers >= 64), kept out of the fall-through code: a taken branch costs far more than an instruction
 
     def lab(self, stem):
         self.n += 1
@@ -84,12 +85,12 @@ class Prune1:
 	s_cbranch_scc0 {hi}
 	v_writelane_b32 {V_MAPA}, {val}, m0
 	{bit} {S_LIVEA}, {reg}
-	s_branch {done}
+{done}:""")
+        self.ool.append(f"""
 {hi}:
 	v_writelane_b32 {V_MAPB}, {val}, m0
 	{bit} {S_LIVEB}, {reg}
-{done}:
-	s_nop 0""")
+	s_branch {done}""")
 
     def give(self, reg):
         hi, done = self.lab("gv_hi"), self.lab("gv_done")
@@ -97,10 +98,11 @@ class Prune1:
 	s_cmp_lt_u32 {reg}, 64
 	s_cbranch_scc0 {hi}
 	s_bitset1_b64 {S_POOLA}, {reg}
-	s_branch {done}
+{done}:""")
+        self.ool.append(f"""
 {hi}:
 	s_bitset1_b64 {S_POOLB}, {reg}
-{done}:""")
+	s_branch {done}""")
 
     def take(self, dst):
         hi, done = self.lab("tk_hi"), self.lab("tk_done")
@@ -109,14 +111,15 @@ class Prune1:
 	s_cmp_eq_i32 {dst}, -1
 	s_cbranch_scc1 {hi}
 	s_bitset0_b64 {S_POOLA}, {dst}
-	s_branch {done}
+{done}:
+	s_add_u32 {S_T3}, {dst}, 1
+	s_max_u32 {S_HIGH}, {S_HIGH}, {S_T3}""")
+        self.ool.append(f"""
 {hi}:
 	s_ff1_i32_b64 {dst}, {S_POOLB}
 	s_bitset0_b64 {S_POOLB}, {dst}
 	s_add_u32 {dst}, {dst}, 64
-{done}:
-	s_add_u32 {S_T3}, {dst}, 1
-	s_max_u32 {S_HIGH}, {S_HIGH}, {S_T3}""")
+	s_branch {done}""")
 
     def use(self, dst, reg):
         """dst = new register of old value `reg`, allocated on first (i.e. last) use"""
@@ -170,7 +173,27 @@ class Prune1:
 	v_cmp_gt_u32_e64 {S_LT64}, 64, {V_COUT}
 	v_and_b32 {V_COUT}, 63, {V_COUT}
 	s_and_b64 {S_FORCE}, {S_FORCE}, {S_VCUR}
-	s_mov_b64 {S_CAND}, {S_VCUR}
+	; ops that hand their own register on (a decided choice or a copy whose surviving operand IS the
+	; output register - the accumulator of a min / max chain) change nothing: never candidates
+	v_bfe_u32 v18, {V_CW0}, 8, 12
+	v_lshrrev_b32 v19, 20, {V_CW0}
+	v_subrev_u32 v20, 30, {V_T}
+	v_cmp_gt_u32_e64 {S_M}, 4, v20                    ; choice, reg,reg
+	v_subrev_u32 v20, 42, {V_T}
+	v_cmp_gt_u32_e64 {S_M2}, 4, v20                   ; choice, reg,imm
+	v_cmp_eq_u32_e64 s[64:65], v19, v18               ; a == out
+	v_cmp_eq_u32_e64 s[66:67], 1, {V_CCH}             ; Left
+	s_or_b64 {S_M2}, {S_M2}, {S_M}
+	s_and_b64 {S_M2}, {S_M2}, s[66:67]
+	v_cmp_eq_u32_e64 s[66:67], 2, {V_T}               ; COPY_REG
+	s_or_b64 {S_M2}, {S_M2}, s[66:67]
+	s_and_b64 {S_M2}, {S_M2}, s[64:65]
+	v_cmp_eq_u32_e64 s[64:65], {V_CW1}, v18           ; b == out
+	v_cmp_eq_u32_e64 s[66:67], 2, {V_CCH}             ; Right
+	s_and_b64 {S_M}, {S_M}, s[64:65]
+	s_and_b64 {S_M}, {S_M}, s[66:67]
+	s_or_b64 {S_M2}, {S_M2}, {S_M}
+	s_andn2_b64 {S_CAND}, {S_VCUR}, {S_M2}
 	v_mov_b32 {V_NW0}, v16
 	v_mov_b32 {V_NW1}, v17
 	v_and_b32 {V_T}, 0xff, {V_NW0}
@@ -339,15 +362,7 @@ class Prune1:
 	{"s_mov_b64 s[48:49], 0" if __import__("os").environ.get("FH_EXP") == "prune_nolive" else ""}
 	s_or_b64 {S_M}, {S_M}, {S_FORCE}
 	s_and_b64 {S_M}, {S_M}, {S_CAND}
-	s_cbranch_scc1 .Lfh_prune1_live
-	; nothing else in this batch: the next one down
-	s_cmp_eq_u32 {S_B}, 0
-	s_cbranch_scc1 .Lfh_prune1_done
-	s_sub_u32 {S_B}, {S_B}, 1""")
-        self.advance()
-        a(f"""
-	s_branch {nxt}
-.Lfh_prune1_live:
+	s_cbranch_scc0 .Lfh_prune1_bdone
 	; the highest such op: everything above it is dead and leaves the state alone
 	s_flbit_i32_b64 {S_T0}, {S_M}
 	s_sub_u32 {S_T0}, 63, {S_T0}
@@ -452,6 +467,17 @@ class Prune1:
         self.emit_op()
         a(f"""
 	s_branch {nxt}
+.Lfh_prune1_bdone:
+	; nothing else in this batch: the next one down
+	s_cmp_eq_u32 {S_B}, 0
+	s_cbranch_scc1 .Lfh_prune1_done
+	s_sub_u32 {S_B}, {S_B}, 1""")
+        self.advance()
+        a(f"""
+	s_branch {nxt}""")
+        for code in self.ool:
+            a(code)
+        a(f"""
 .Lfh_prune1_done:
 	; the ops still in the buffer: lanes 64 - n .. 63
 	s_and_b32 {S_T0}, {S_COUNT}, 63
