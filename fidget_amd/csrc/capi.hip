@@ -1025,6 +1025,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             ctx->stream = main_stream;
             HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }
+        // (on the tile chain this kernel, cheap as it is, was measured to cost the frame 0.8 ms)
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
@@ -1044,10 +1045,11 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
+            const uint32_t len_cap = 0;
             if (P.max_regs > 32) {
                 const int g = blocks_for(ctx, R.lds_points_big, 16);
-                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS, len_cap);
+                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS, len_cap);
             }
         });
         launch(ctx, FHIP_K_NORMALS, [&] {
@@ -1107,6 +1109,13 @@ uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap) {
     if (finish_render(ctx) != FHIP_OK) return 0;
     const uint32_t n = std::min(std::min(ctx->last_state.n_leaves, ctx->last_state.leaf_cap), cap);
     if (hipMemcpy(out, ctx->last_state.leaves, (size_t)n * sizeof(FhLeaf), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+// Diagnostics: `n` ops of the tape arena starting at op `off` (the tapes the last frame left there)
+uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out) {
+    if ((size_t)(off + (size_t)n) * 8 > ctx->arena_bytes) return 0;
+    if (hipMemcpy(out, (const uint64_t*)ctx->arena.p + off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
 

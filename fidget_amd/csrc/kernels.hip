@@ -1068,8 +1068,10 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
 // to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so the order in which waves reach
 // the leaves of one column does not matter; a leaf whose pixels are all hit in front of it retires
 // after one load.  CLS: leaves of <= 16 registers, 17..32, more (LDS register file).
+// len_cap (CLS 2 only): with fh_columns as the leaf kernel, leaves whose tape is longer than its LDS
+// staging area come here as well.
 template <int CLS, int NR, int ZB, bool FULL>
-__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
+__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S, uint32_t len_cap = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
@@ -1082,7 +1084,7 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
     for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
         const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
         const uint32_t regs = lf.tape.n_regs;
-        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= 32)) continue;
+        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : (regs <= 32 && !(len_cap && lf.tape.len > len_cap)))) continue;
         const uint32_t px = lf.x + (lane % T), py = lf.y + (lane / T), lz = lf.z;
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;
