@@ -51,7 +51,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan",
 ]
 
@@ -137,7 +137,7 @@ def lib():
             "fhip_debug_stats": (i32, [vp, vp]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
             "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]),
-            "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]),
+            "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]), "fhip_debug_probe": (i32, [vp, vp]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),

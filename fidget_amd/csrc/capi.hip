@@ -54,8 +54,8 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_COUNT };
-static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1"};
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_PROBE, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_probe"};
 
 struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
@@ -1110,6 +1110,16 @@ uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap) {
     const uint32_t n = std::min(std::min(ctx->last_state.n_leaves, ctx->last_state.leaf_cap), cap);
     if (hipMemcpy(out, ctx->last_state.leaves, (size_t)n * sizeof(FhLeaf), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
+}
+
+// Diagnostics: the ISA probe kernel (gen_interp.py gen_probe): 9 rows of 64 floats
+fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out) {
+    HIP_TRY(ctx, ctx->io_a.ensure(9 * 256));
+    struct { void* p; } ka = {ctx->io_a.p};
+    if (launch_asm(ctx, FH_ASM_PROBE, 1, &ka, sizeof(ka)) != hipSuccess) return FHIP_ERR_HIP;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->io_a.p, 9 * 256, hipMemcpyDeviceToHost));
+    return FHIP_OK;
 }
 
 // Diagnostics: `n` ops of the tape arena starting at op `off` (the tapes the last frame left there)

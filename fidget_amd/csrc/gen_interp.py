@@ -16,7 +16,11 @@ bit-exact with the C++ kernels in kernels.hip which they replace on their fast p
   fh_float_eval_{NR}x{ZB}  BulkEvaluator<f32>: 64*ZB samples per wave
 
 NR = registers of the VGPR register file, ZB = samples per lane.  The file occupies
-v[FILE .. FILE+NR*ZB): register r of sample slot j is v[FILE + j*NR + r].
+v[FILE .. FILE+NR*ZB): register r of sample slot j is v[FILE + r*ZB + j] - the ZB samples of a
+register are consecutive, so that copies and add / sub / mul take them two at a time
+(v_pk_mov_b32, v_pk_add_f32, v_pk_mul_f32: 64-bit operands, M0-relative like any other), and an
+op whose output register is one of its operands (more than half of a pruned tape's ops) works on
+the file in place, with no copy at all.
 
 Tape format: tape_format.h (8 bytes per op: opcode | out<<8 | a<<20, then b / imm / slot).
 Tapes with transcendental, modulo or rng ops, more than 32 registers, or a projective
@@ -138,11 +142,21 @@ class Interp:
 
     def __init__(self, a, name, nr, zb, kind, off):
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
+        self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.next = f".L{name}_next"
         self.ool = []  # out-of-line handler bodies: (label, callable)
 
     def F(self, j):
-        return f"v{FILE + j * self.nr}"
+        """sample j of the register selected by the index (M0 = register * ZB)"""
+        return f"v{FILE + j}"
+
+    def FP(self, k):
+        return f"v[{FILE + 2 * k}:{FILE + 2 * k + 1}]"
+
+    @staticmethod
+    def P(regs, k):
+        n = int(regs[2 * k][1:])
+        return f"v[{n}:{n + 1}]"
 
     # -- small helpers ---------------------------------------------------------------------
     def idx_on(self, sreg, mode):
@@ -154,29 +168,37 @@ class Interp:
     def idx_off(self):
         self.a("\ts_set_gpr_idx_off")
 
+    def b_index(self):
+        """S_T1 = file index of the register named by word 1"""
+        self.a(f"\ts_lshl_b32 {S_T1}, {S_W1}, {self.lg}")
+
+    def pk_mov(self, dst, src):
+        self.a(f"\tv_pk_mov_b32 {dst}, {src}, {src} op_sel:[0,1]")
+
     def read_a(self, dst):
-        """dst[j] = file[a]; leaves SRC0-relative mode on."""
-        self.idx_on(S_A, SRC0)
-        for j in range(self.zb):
-            self.a(f"\tv_mov_b32 {dst[j]}, {self.F(j)}")
+        """dst = file[a]; leaves the index mode on (SRC0 | SRC1 relative)."""
+        self.idx_on(S_A, SRC0 | SRC1)
+        for k in range(self.zb // 2):
+            self.pk_mov(self.P(dst, k), self.FP(k))
 
     def read_b(self, dst, already_on=True):
+        self.b_index()
         if already_on:
-            self.idx_idx(S_W1)
+            self.idx_idx(S_T1)
         else:
-            self.idx_on(S_W1, SRC0)
-        for j in range(self.zb):
-            self.a(f"\tv_mov_b32 {dst[j]}, {self.F(j)}")
+            self.idx_on(S_T1, SRC0 | SRC1)
+        for k in range(self.zb // 2):
+            self.pk_mov(self.P(dst, k), self.FP(k))
 
     def imm_b(self, dst):
         for j in range(self.zb):
             self.a(f"\tv_mov_b32 {dst[j]}, {S_W1}")
 
     def write_out(self, src, done=True):
-        """file[out] = src[j]; ends the handler."""
+        """file[out] = src; ends the handler."""
         self.idx_on(S_OUT, DST)
-        for j in range(self.zb):
-            self.a(f"\tv_mov_b32 {self.F(j)}, {src[j]}")
+        for k in range(self.zb // 2):
+            self.pk_mov(self.FP(k), self.P(src, k))
         self.idx_off()
         if done:
             self.a(f"\ts_branch {self.next}")
@@ -282,6 +304,12 @@ class Interp:
         self.ool.append((lab, fn))
         self.a(f"\ts_branch {lab}")
 
+    def ool_label(self, stem, fn):
+        """register an out-of-line body, return its label (the caller branches)"""
+        lab = f".L{self.name}_{stem}"
+        self.ool.append((lab, fn))
+        return lab
+
     def handler(self, op):
         a, zb, F = self.a, self.zb, self.F
         Z = range(zb)
@@ -289,6 +317,7 @@ class Interp:
             return self.h_output()
         if op == "INPUT":
             return self.out_of_line("input", self.h_input)
+        PZ = range(zb // 2)
         if op == "COPY_REG":
             self.read_a(VT)
             return self.write_out(VT)
@@ -299,29 +328,41 @@ class Interp:
             self.idx_off()
             return a(f"\ts_branch {self.next}")
         if op in ("NEG", "ABS", "FLOOR", "CEIL"):
-            self.idx_on(S_A, SRC1 if op in ("NEG", "ABS") else SRC0)
+            ins = {"NEG": f"v_xor_b32 {{d}}, {S_SIGN}, {{s}}", "ABS": f"v_and_b32 {{d}}, {S_ABSM}, {{s}}",
+                   "FLOOR": "v_floor_f32 {d}, {s}", "CEIL": "v_ceil_f32 {d}, {s}"}[op]
+            src = SRC1 if op in ("NEG", "ABS") else SRC0
+            def general(ins=ins, src=src):
+                self.idx_on(S_A, src)
+                for j in Z:
+                    a("\t" + ins.format(d=VT[j], s=F(j)))
+                self.write_out(VT)
+            gl = self.ool_label(op.lower() + "_g", general)
+            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
+            self.idx_on(S_A, src | DST)
             for j in Z:
-                if op == "NEG":
-                    a(f"\tv_xor_b32 {VT[j]}, {S_SIGN}, {F(j)}")
-                elif op == "ABS":
-                    a(f"\tv_and_b32 {VT[j]}, {S_ABSM}, {F(j)}")
-                elif op == "FLOOR":
-                    a(f"\tv_floor_f32 {VT[j]}, {F(j)}")
-                else:
-                    a(f"\tv_ceil_f32 {VT[j]}, {F(j)}")
-            return self.write_out(VT)
+                a("\t" + ins.format(d=F(j), s=F(j)))
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
         if op == "SQUARE":
-            self.idx_on(S_A, SRC0 | SRC1)
-            for j in Z:
-                a(f"\tv_mul_f32 {VT[j]}, {F(j)}, {F(j)}")
-            return self.write_out(VT)
+            def general():
+                self.idx_on(S_A, SRC0 | SRC1)
+                for k in PZ:
+                    a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.FP(k)}, {self.FP(k)}")
+                self.write_out(VT)
+            gl = self.ool_label("square_g", general)
+            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
+            self.idx_on(S_A, SRC0 | SRC1 | DST)
+            for k in PZ:
+                a(f"\tv_pk_mul_f32 {self.FP(k)}, {self.FP(k)}, {self.FP(k)}")
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
         if op == "NOT":
             def body():
                 self.read_a(VT)
                 self.idx_off()
                 self.mask_pass(lambda j, m: f"v_cmp_eq_f32_e64 {m}, 0, {VT[j]}", lambda j, m: f"v_cndmask_b32_e64 {VU[j]}, 0, 1.0, {m}")
                 self.write_out(VU)
-            return body() if zb <= 4 else self.out_of_line("not", body)
+            return self.out_of_line("not", body)
         if op in ("RECIP", "SQRT", "ROUND"):
             def body(op=op):
                 self.read_a(VT)
@@ -336,21 +377,70 @@ class Interp:
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         base, form = op.rsplit("_", 1)
+        if base in ("ADD", "SUB", "MUL") and form != "RR":
+            # register (op) immediate, two samples per instruction; the immediate sits in an aligned SGPR pair
+            # whose low half serves both samples.  a - imm = a + (-imm) and imm - a = (-a) + imm, exactly.
+            ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
+            mod = {("SUB", "RI"): " neg_lo:[0,1] neg_hi:[0,1]", ("SUB", "IR"): " neg_lo:[1,0] neg_hi:[1,0]"}.get((base, form), "")
+            def general(ins=ins, mod=mod):
+                a(f"\ts_mov_b32 s96, {S_W1}")
+                self.idx_on(S_A, SRC0)
+                for k in PZ:
+                    a(f"\t{ins} {self.P(VT, k)}, {self.FP(k)}, s[96:97] op_sel_hi:[1,0]{mod}")
+                self.write_out(VT)
+            gl = self.ool_label(op.lower() + "_g", general)
+            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
+            a(f"\ts_mov_b32 s96, {S_W1}")
+            self.idx_on(S_A, SRC0 | DST)
+            for k in PZ:
+                a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, s[96:97] op_sel_hi:[1,0]{mod}")
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
         if base in ("ADD", "SUB", "MUL"):
-            if form == "RR":
+            ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
+            negb = " neg_lo:[0,1] neg_hi:[0,1]" if base == "SUB" else ""
+            def general(ins=ins, negb=negb):
+                self.read_a(VT)                      # a in VT; then VT = VT (op) file[b]
+                self.b_index()
+                self.idx_on(S_T1, SRC1)
+                for k in PZ:
+                    a(f"\t{ins} {self.P(VT, k)}, {self.P(VT, k)}, {self.FP(k)}{negb}")
+                self.write_out(VT)
+            gl = self.ool_label(op.lower() + "_g", general)
+            # out == a: file[a] = file[a] (op) b, b through VU
+            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
+            self.read_b(VU, already_on=False)
+            self.idx_on(S_A, SRC0 | DST)
+            for k in PZ:
+                a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, {self.P(VU, k)}{negb}")
+            self.idx_off()
+            return a(f"\ts_branch {self.next}")
+        if base in ("MIN", "MAX") and form == "RR":
+            # out == a (nearly always: the accumulator of a union / intersection): the file entry is updated in
+            # place.  a < b ? a : b written as !(a < b) ? b : a so that `a`, the relative operand, stays SRC0.
+            ncmp = "v_cmp_nlt_f32_e64" if base == "MIN" else "v_cmp_ngt_f32_e64"
+            def general(base=base):
                 self.read_a(VT)
-                self.idx_idx(S_W1)
-                ins = {"ADD": "v_add_f32", "SUB": "v_subrev_f32", "MUL": "v_mul_f32"}[base]
-                for j in Z:
-                    a(f"\t{ins} {VT[j]}, {F(j)}, {VT[j]}")       # subrev: D = S1 - S0 = a - b
-            else:
-                # a (register, relative SRC1) with the immediate as SRC0
-                ins = {("ADD", "RI"): "v_add_f32", ("MUL", "RI"): "v_mul_f32", ("SUB", "RI"): "v_subrev_f32",
-                       ("SUB", "IR"): "v_sub_f32"}[(base, form)]
-                self.idx_on(S_A, SRC1)
-                for j in Z:
-                    a(f"\t{ins} {VT[j]}, {S_W1}, {F(j)}")
-            return self.write_out(VT)
+                self.read_b(VU)
+                self.idx_off()
+                self.f_minmax(base == "MIN", VT, VU, VW)
+                self.write_out(VW)
+            gl = self.ool_label(op.lower() + "_g", general)
+            def inplace(ncmp=ncmp):
+                self.read_b(VU, already_on=False)
+                self.idx_on(S_A, SRC0 | DST)
+                for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
+                    for q in (0, 1):
+                        a(f"\t{ncmp} {S_M[2 * q]}, {F(j + q)}, {VU[j + q]}")
+                        a(f"\tv_cmp_u_f32_e64 {S_M[2 * q + 1]}, {F(j + q)}, {VU[j + q]}")
+                    for q in (0, 1):
+                        a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {VU[j + q]}, {S_M[2 * q]}")
+                        a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {V_QNAN}, {S_M[2 * q + 1]}")
+                self.idx_off()
+                a(f"\ts_branch {self.next}")
+            il = self.ool_label(op.lower() + "_i", inplace)
+            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc1 {il}\n\ts_branch {gl}")
+            return
         # two plain operands A, B in VT / VU, result in VW
         def body(base=base, form=form):
             self.read_a(VT)
@@ -369,8 +459,6 @@ class Interp:
             else:
                 self.f_andor(base == "AND", A, B, VW)
             self.write_out(VW)
-        if base in ("MIN", "MAX", "AND", "OR") and zb * (8 if base in ("MIN", "MAX") else 5) + 12 <= 30:
-            return body()
         return self.out_of_line(op.lower(), body)
 
     def h_output(self):
@@ -436,17 +524,20 @@ class Interp:
         a(f"\ts_branch {lab['done']}")
         for axis, (row, acc) in (("x", (0, V_AX)), ("y", (1, V_AY)), ("z", (2, V_AZ))):
             a(f"{lab[axis]}:")
+            a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
             for j in range(self.zb):      # z of sample j = lz + k - j
-                a(f"""
-	s_add_u32 {S_T0}, {S_LZ}, {S_K}
-	s_sub_u32 {S_T0}, {S_T0}, {j}
-	v_cvt_f32_u32 {VT[j]}, {S_T0}
-	v_mul_f32 {VT[j]}, s{m + 4 * row + 2}, {VT[j]}
-	v_add_f32 {VT[j]}, {acc}, {VT[j]}
-	v_add_f32 {VT[j]}, s{m + 4 * row + 3}, {VT[j]}""")
+                a(f"\tv_cvt_f32_u32 {VT[j]}, {S_T0}")
+                if j + 1 < self.zb:
+                    a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
+            a(f"\ts_mov_b32 s96, s{m + 4 * row + 2}\n\ts_mov_b32 s97, s{m + 4 * row + 3}")
+            a(f"\tv_mov_b32 {VU[0]}, {acc}")       # (an aligned pair for the packed add; its low half serves both samples)
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel_hi:[1,0]")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, {self.P(VU, 0)} op_sel_hi:[1,0]")
             self.idx_on(S_OUT, DST)
-            for j in range(self.zb):
-                a(f"\tv_mov_b32 {self.F(j)}, {VT[j]}")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_add_f32 {self.FP(k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
             if axis != "z":
                 a(f"\ts_branch {lab['done']}")
         a(f"{lab['done']}:")
@@ -481,8 +572,10 @@ class Interp:
 	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << HSTRIDE_LOG2)}
 	s_add_u32 s86, s42, {S_T0}
 	s_addc_u32 s87, s43, 0
-	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
-	s_lshr_b32 {S_A}, {S_W0}, 20
+	s_lshr_b32 {S_OUT}, {S_W0}, {8 - self.lg}
+	s_lshr_b32 {S_A}, {S_W0}, {20 - self.lg}
+	s_and_b32 {S_OUT}, {S_OUT}, {hex(0xfff << self.lg)}     ; file index = register * ZB
+	s_andn2_b32 {S_A}, {S_A}, {(1 << self.lg) - 1}
 	s_setpc_b64 {S_PC}
 .L{n}_refill:
 	s_waitcnt lgkmcnt(0)
@@ -875,6 +968,54 @@ def gen_bulk(a, nr, zb, off):
     return name
 
 
+def gen_probe(a):
+    """fh_probe: does M0-relative VGPR addressing apply to packed (VOP3P) operands?  out[0..7] (diagnostics)."""
+    name = "fh_probe"
+    kernel_header(a, name, 8, 40)
+    a(f"""
+	s_load_dwordx2 s[4:5], s[0:1], 0x0
+	v_mov_b32 v10, 1.0
+	v_mov_b32 v11, 2.0
+	v_mov_b32 v12, 4.0
+	v_mov_b32 v13, 8.0
+	v_mov_b32 v20, 16.0
+	v_mov_b32 v21, 32.0
+	v_mov_b32 v30, 0
+	v_mov_b32 v31, 0
+	v_mov_b32 v32, 0
+	v_mov_b32 v33, 0
+	v_mov_b32 v34, 0
+	v_mov_b32 v35, 0
+	v_mov_b32 v36, 0
+	v_mov_b32 v37, 0
+	s_mov_b32 s10, 2
+	s_mov_b32 s12, 0x40400000
+	s_mov_b32 s13, 0x40a00000
+	s_set_gpr_idx_on s10, {SRC0}
+	v_pk_add_f32 v[30:31], v[10:11], v[20:21]          ; src0 relative: (4 + 16, 8 + 32) = (20, 40); not: (17, 34)
+	s_set_gpr_idx_off
+	s_set_gpr_idx_on s10, {DST}
+	v_pk_mul_f32 v[32:33], v[10:11], v[20:21]          ; dst relative: lands in v[34:35] = (16, 64)
+	s_set_gpr_idx_off
+	s_set_gpr_idx_on s10, {SRC0 | DST}
+	v_pk_mul_f32 v[10:11], v[10:11], s[12:13] op_sel_hi:[1,0]   ; in place on v[12:13] with a broadcast scalar: (12, 24)
+	s_set_gpr_idx_off
+	v_pk_mov_b32 v[36:37], v[12:13], v[12:13] op_sel:[0,1]
+	v_lshlrev_b32 v1, 2, v0
+	s_waitcnt lgkmcnt(0)
+	global_store_dword v1, v30, s[4:5]
+	global_store_dword v1, v31, s[4:5] offset:256
+	global_store_dword v1, v32, s[4:5] offset:512
+	global_store_dword v1, v34, s[4:5] offset:768
+	global_store_dword v1, v35, s[4:5] offset:1024
+	global_store_dword v1, v12, s[4:5] offset:1280
+	global_store_dword v1, v13, s[4:5] offset:1536
+	global_store_dword v1, v36, s[4:5] offset:1792
+	global_store_dword v1, v37, s[4:5] offset:2048""")
+    kernel_footer(a, name, 8, 40, 24, True)
+    return name, 8, 40, [(8, "global_buffer")]
+
+
 def metadata(a, kernels):
     a("\t.amdgpu_metadata\n---\namdhsa.kernels:")
     for name, kernarg, vgprs, args in kernels:
@@ -917,6 +1058,7 @@ def main():
     ks.append(gen_tiles(a, off))
     from gen_prune import gen_prune1
     ks.append(gen_prune1(a, off))
+    ks.append(gen_probe(a))
     metadata(a, ks)
     open(sys.argv[2], "w").write(a.text())
 

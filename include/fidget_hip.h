@@ -162,6 +162,7 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
 /* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
+fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_interp.py gen_probe), 9 x 64 floats */
 uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out);  /* ops of the tape arena after a frame */
 /* Times `reps` passes of the point interpreter over `tape` in `n_waves` waves
  * (variant 0: 16 registers x 4 voxels, 1: 32 x 2, 2: LDS register file, 3: 32 x 1). */
