@@ -70,7 +70,8 @@ S_T0 = "s66"
 S_OUT = "s67"
 S_A = "s68"
 S_T1 = "s69"
-S_BATCH = "s70"
+S_NEXT = "s[70:71]"      # address of the decode copy of the next op
+S_JMP = "s[44:45]"       # handler address (the interpreter's tape argument is consumed by then)
 S_FETCH = "s[72:73]"
 S_RET = "s[74:75]"
 S_FX, S_FY = "s76", "s77"
@@ -201,7 +202,7 @@ class Interp:
             self.pk_mov(self.FP(k), self.P(src, k))
         self.idx_off()
         if done:
-            self.a(f"\ts_branch {self.next}")
+            self.self.ret()
 
     def mask_gap(self):
         """VALU-written SGPR read as a lane mask by a VALU op needs 2 wait states (gfx940+)."""
@@ -310,14 +311,18 @@ class Interp:
         self.ool.append((lab, fn))
         return lab
 
-    def handler(self, op):
+    INPLACE = {"NEG", "ABS", "FLOOR", "CEIL", "SQUARE", "ADD_RI", "SUB_RI", "MUL_RI", "SUB_IR", "ADD_RR", "SUB_RR", "MUL_RR",
+               "MIN_RR", "MAX_RR"}
+
+    def handler(self, op, inplace=False):
+        """One handler slot.  `inplace`: the decode found out == a (slots 64 + opcode, ops of INPLACE only): the
+        op then works on the file entry itself."""
         a, zb, F = self.a, self.zb, self.F
-        Z = range(zb)
+        Z, PZ = range(zb), range(zb // 2)
         if op == "OUTPUT":
             return self.h_output()
         if op == "INPUT":
             return self.out_of_line("input", self.h_input)
-        PZ = range(zb // 2)
         if op == "COPY_REG":
             self.read_a(VT)
             return self.write_out(VT)
@@ -325,37 +330,20 @@ class Interp:
             self.idx_on(S_OUT, DST)
             for j in Z:
                 a(f"\tv_mov_b32 {F(j)}, {S_W1}")
-            self.idx_off()
-            return a(f"\ts_branch {self.next}")
+            return self.ret()
         if op in ("NEG", "ABS", "FLOOR", "CEIL"):
             ins = {"NEG": f"v_xor_b32 {{d}}, {S_SIGN}, {{s}}", "ABS": f"v_and_b32 {{d}}, {S_ABSM}, {{s}}",
                    "FLOOR": "v_floor_f32 {d}, {s}", "CEIL": "v_ceil_f32 {d}, {s}"}[op]
             src = SRC1 if op in ("NEG", "ABS") else SRC0
-            def general(ins=ins, src=src):
-                self.idx_on(S_A, src)
-                for j in Z:
-                    a("\t" + ins.format(d=VT[j], s=F(j)))
-                self.write_out(VT)
-            gl = self.ool_label(op.lower() + "_g", general)
-            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
-            self.idx_on(S_A, src | DST)
+            self.idx_on(S_A, src | (DST if inplace else 0))
             for j in Z:
-                a("\t" + ins.format(d=F(j), s=F(j)))
-            self.idx_off()
-            return a(f"\ts_branch {self.next}")
+                a("\t" + ins.format(d=F(j) if inplace else VT[j], s=F(j)))
+            return self.ret() if inplace else self.write_out(VT)
         if op == "SQUARE":
-            def general():
-                self.idx_on(S_A, SRC0 | SRC1)
-                for k in PZ:
-                    a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.FP(k)}, {self.FP(k)}")
-                self.write_out(VT)
-            gl = self.ool_label("square_g", general)
-            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
-            self.idx_on(S_A, SRC0 | SRC1 | DST)
+            self.idx_on(S_A, SRC0 | SRC1 | (DST if inplace else 0))
             for k in PZ:
-                a(f"\tv_pk_mul_f32 {self.FP(k)}, {self.FP(k)}, {self.FP(k)}")
-            self.idx_off()
-            return a(f"\ts_branch {self.next}")
+                a(f"\tv_pk_mul_f32 {self.FP(k) if inplace else self.P(VT, k)}, {self.FP(k)}, {self.FP(k)}")
+            return self.ret() if inplace else self.write_out(VT)
         if op == "NOT":
             def body():
                 self.read_a(VT)
@@ -378,55 +366,34 @@ class Interp:
             return self.out_of_line(op.lower(), body)
         base, form = op.rsplit("_", 1)
         if base in ("ADD", "SUB", "MUL") and form != "RR":
-            # register (op) immediate, two samples per instruction; the immediate sits in an aligned SGPR pair
-            # whose low half serves both samples.  a - imm = a + (-imm) and imm - a = (-a) + imm, exactly.
+            # register (op) immediate, two samples per instruction: the immediate is the high half of the op's
+            # SGPR pair, selected for both samples.  a - imm = a + (-imm) and imm - a = (-a) + imm, exactly.
             ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
             mod = {("SUB", "RI"): " neg_lo:[0,1] neg_hi:[0,1]", ("SUB", "IR"): " neg_lo:[1,0] neg_hi:[1,0]"}.get((base, form), "")
-            def general(ins=ins, mod=mod):
-                a(f"\ts_mov_b32 s96, {S_W1}")
-                self.idx_on(S_A, SRC0)
-                for k in PZ:
-                    a(f"\t{ins} {self.P(VT, k)}, {self.FP(k)}, s[96:97] op_sel_hi:[1,0]{mod}")
-                self.write_out(VT)
-            gl = self.ool_label(op.lower() + "_g", general)
-            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
-            a(f"\ts_mov_b32 s96, {S_W1}")
-            self.idx_on(S_A, SRC0 | DST)
+            self.idx_on(S_A, SRC0 | (DST if inplace else 0))
             for k in PZ:
-                a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, s[96:97] op_sel_hi:[1,0]{mod}")
-            self.idx_off()
-            return a(f"\ts_branch {self.next}")
+                a(f"\t{ins} {self.FP(k) if inplace else self.P(VT, k)}, {self.FP(k)}, {S_CUR} op_sel:[0,1] op_sel_hi:[1,1]{mod}")
+            return self.ret() if inplace else self.write_out(VT)
         if base in ("ADD", "SUB", "MUL"):
             ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
             negb = " neg_lo:[0,1] neg_hi:[0,1]" if base == "SUB" else ""
-            def general(ins=ins, negb=negb):
-                self.read_a(VT)                      # a in VT; then VT = VT (op) file[b]
-                self.b_index()
-                self.idx_on(S_T1, SRC1)
+            if inplace:                              # file[a] = file[a] (op) b, b through VU
+                self.read_b(VU, already_on=False)
+                self.idx_on(S_A, SRC0 | DST)
                 for k in PZ:
-                    a(f"\t{ins} {self.P(VT, k)}, {self.P(VT, k)}, {self.FP(k)}{negb}")
-                self.write_out(VT)
-            gl = self.ool_label(op.lower() + "_g", general)
-            # out == a: file[a] = file[a] (op) b, b through VU
-            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc0 {gl}")
-            self.read_b(VU, already_on=False)
-            self.idx_on(S_A, SRC0 | DST)
+                    a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, {self.P(VU, k)}{negb}")
+                return self.ret()
+            self.read_a(VT)                          # a in VT; then VT = VT (op) file[b]
+            self.b_index()
+            self.idx_on(S_T1, SRC1)
             for k in PZ:
-                a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, {self.P(VU, k)}{negb}")
-            self.idx_off()
-            return a(f"\ts_branch {self.next}")
-        if base in ("MIN", "MAX") and form == "RR":
+                a(f"\t{ins} {self.P(VT, k)}, {self.P(VT, k)}, {self.FP(k)}{negb}")
+            return self.write_out(VT)
+        if base in ("MIN", "MAX") and form == "RR" and inplace:
             # out == a (nearly always: the accumulator of a union / intersection): the file entry is updated in
             # place.  a < b ? a : b written as !(a < b) ? b : a so that `a`, the relative operand, stays SRC0.
             ncmp = "v_cmp_nlt_f32_e64" if base == "MIN" else "v_cmp_ngt_f32_e64"
-            def general(base=base):
-                self.read_a(VT)
-                self.read_b(VU)
-                self.idx_off()
-                self.f_minmax(base == "MIN", VT, VU, VW)
-                self.write_out(VW)
-            gl = self.ool_label(op.lower() + "_g", general)
-            def inplace(ncmp=ncmp):
+            def body(ncmp=ncmp):
                 self.read_b(VU, already_on=False)
                 self.idx_on(S_A, SRC0 | DST)
                 for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
@@ -436,11 +403,8 @@ class Interp:
                     for q in (0, 1):
                         a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {VU[j + q]}, {S_M[2 * q]}")
                         a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {V_QNAN}, {S_M[2 * q + 1]}")
-                self.idx_off()
-                a(f"\ts_branch {self.next}")
-            il = self.ool_label(op.lower() + "_i", inplace)
-            a(f"\ts_cmp_eq_u32 {S_OUT}, {S_A}\n\ts_cbranch_scc1 {il}\n\ts_branch {gl}")
-            return
+                self.ret()
+            return self.out_of_line(op.lower() + "_i", body)
         # two plain operands A, B in VT / VU, result in VW
         def body(base=base, form=form):
             self.read_a(VT)
@@ -464,9 +428,10 @@ class Interp:
     def h_output(self):
         a = self.a
         if self.kind == "columns":
+            # the one output of a shape tape is its last op: back to the caller
             self.read_a(VRES)
             self.idx_off()
-            return a(f"\ts_branch {self.next}")
+            return a(f"\ts_waitcnt lgkmcnt(0)\n\ts_setpc_b64 {S_RET}")
         self.out_of_line("output", self.h_output_bulk)
 
     def h_output_bulk(self):
@@ -486,11 +451,12 @@ class Interp:
 	s_mov_b64 exec, {S_ACT[j]}
 	global_store_dword {VOFF[j]}, {VT[j]}, {S_PC}""")
         a(f"""
-	s_mov_b64 exec, {S_SAVE}
-	s_branch {self.next}""")
+	s_mov_b64 exec, {S_SAVE}""")
+        self.ret()
 
     def h_input(self):
         a = self.a
+        self.idx_off()      # (plain vector code below; the previous handler may have left the index mode on)
         if self.kind == "bulk":
             a(f"""
 	s_mul_hi_u32 s77, {S_W1}, {S_N}
@@ -542,69 +508,84 @@ class Interp:
                 a(f"\ts_branch {lab['done']}")
         a(f"{lab['done']}:")
         self.idx_off()
-        a(f"\ts_branch {self.next}")
+        self.ret()
 
     # -- the interpreter -------------------------------------------------------------------
     def emit(self):
-        a, n = self.a, self.name
+        a, n, lg = self.a, self.name, self.lg
         qa, qb = S_QA, S_QB
+        COPY = 128
         a(f"""
-; ---- interpreter {n}: in {S_TAPE} = first op, {S_LEN} = ops; returns to {S_RET} -----------
+; ---- interpreter {n}: in {S_TAPE} = first op, {S_LEN} = ops (bulk); returns to {S_RET} -----------
+; The tape comes through the scalar cache 4 ops at a time into two SGPR batches; the decode code
+; exists 8 times, copy i for the op in slot i of the batches, so that nothing is shifted or counted:
+; a handler ends with a jump to {S_NEXT}, which every copy advances to the copy after it.
 .L{n}_run:
 	s_load_dwordx8 s[{qa}:{qa + 7}], {S_TAPE}, 0x0
-	s_load_dwordx8 s[{qb}:{qb + 7}], {S_TAPE}, 0x20
-.L{n}_go:                                ; entry for callers that have requested the tape head themselves
-	s_add_u32 s72, s44, 0x40
+.L{n}_go:                                ; entry for callers that have requested the first 4 ops themselves
+	s_add_u32 s72, s44, 0x20
 	s_addc_u32 s73, s45, 0
-	s_mov_b32 {S_BATCH}, 4
+	s_getpc_b64 {S_NEXT}
+.L{n}_gopc:
+	s_add_u32 s70, s70, .L{n}_d0 - .L{n}_gopc
+	s_addc_u32 s71, s71, 0
+	s_setpc_b64 {S_NEXT}
+	.p2align 7""")
+        for i in range(8):
+            q = (qa if i < 4 else qb) + 2 * (i % 4)
+            a(f".L{n}_d{i}:")
+            if i % 4 == 0:
+                other = qb if i == 0 else qa
+                a(f"""
 	s_waitcnt lgkmcnt(0)
-{self.next}:
-	s_sub_u32 {S_LEN}, {S_LEN}, 1
-	s_cbranch_scc1 .L{n}_done
-	s_sub_u32 {S_BATCH}, {S_BATCH}, 1
-	s_cbranch_scc1 .L{n}_refill
-.L{n}_decode:
-	s_mov_b64 {S_CUR}, s[{qa}:{qa + 1}]
-	s_mov_b64 s[{qa}:{qa + 1}], s[{qa + 2}:{qa + 3}]
-	s_mov_b64 s[{qa + 2}:{qa + 3}], s[{qa + 4}:{qa + 5}]
-	s_mov_b64 s[{qa + 4}:{qa + 5}], s[{qa + 6}:{qa + 7}]
-	s_lshl_b32 {S_T0}, {S_W0}, {HSTRIDE_LOG2}
-	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << HSTRIDE_LOG2)}
-	s_add_u32 s86, s42, {S_T0}
-	s_addc_u32 s87, s43, 0
-	s_lshr_b32 {S_OUT}, {S_W0}, {8 - self.lg}
-	s_lshr_b32 {S_A}, {S_W0}, {20 - self.lg}
-	s_and_b32 {S_OUT}, {S_OUT}, {hex(0xfff << self.lg)}     ; file index = register * ZB
-	s_andn2_b32 {S_A}, {S_A}, {(1 << self.lg) - 1}
-	s_setpc_b64 {S_PC}
-.L{n}_refill:
-	s_waitcnt lgkmcnt(0)
-	s_mov_b64 s[{qa}:{qa + 1}], s[{qb}:{qb + 1}]
-	s_mov_b64 s[{qa + 2}:{qa + 3}], s[{qb + 2}:{qb + 3}]
-	s_mov_b64 s[{qa + 4}:{qa + 5}], s[{qb + 4}:{qb + 5}]
-	s_mov_b64 s[{qa + 6}:{qa + 7}], s[{qb + 6}:{qb + 7}]
-	s_load_dwordx8 s[{qb}:{qb + 7}], {S_FETCH}, 0x0
+	s_load_dwordx8 s[{other}:{other + 7}], {S_FETCH}, 0x0
 	s_add_u32 s72, s72, 0x20
-	s_addc_u32 s73, s73, 0
-	s_mov_b32 {S_BATCH}, 3
-	s_branch .L{n}_decode
+	s_addc_u32 s73, s73, 0""")
+            if self.kind == "bulk":
+                a(f"""
+	s_sub_u32 {S_LEN}, {S_LEN}, 1
+	s_cbranch_scc1 .L{n}_done""")
+            a(f"""
+	s_mov_b64 {S_CUR}, s[{q}:{q + 1}]
+	{f"s_add_u32 s70, s70, {COPY}" if i < 7 else f"s_sub_u32 s70, s70, {7 * COPY}"}
+	s_lshl_b32 {S_T0}, {S_W0}, {HSTRIDE_LOG2}
+	s_lshr_b32 {S_OUT}, {S_W0}, {8 - lg}
+	s_lshr_b32 {S_A}, {S_W0}, {20 - lg}
+	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << HSTRIDE_LOG2)}
+	s_and_b32 {S_OUT}, {S_OUT}, {hex(0xfff << lg)}     ; file index = register * ZB
+	s_andn2_b32 {S_A}, {S_A}, {(1 << lg) - 1}
+	s_cmp_eq_u32 {S_OUT}, {S_A}
+	s_cselect_b32 {S_T1}, {hex(64 << HSTRIDE_LOG2)}, 0   ; out == a: the in-place handlers
+	s_or_b32 {S_T0}, {S_T0}, {S_T1}
+	s_add_u32 s44, s42, {S_T0}
+	s_addc_u32 s45, s43, 0
+	s_setpc_b64 {S_JMP}
+	.if (. - .L{n}_d{i}) > {COPY}
+	.error "decode copy of {n} exceeds its slot"
+	.endif
+	.p2align 7""")
+        a(f"""
 .L{n}_done:
 	s_waitcnt lgkmcnt(0)
+	s_set_gpr_idx_off
 	s_setpc_b64 {S_RET}
 	.p2align {HSTRIDE_LOG2}
 .L{n}_handlers:""")
-        for i, op in enumerate(OPS):
-            a(f"\t.p2align {HSTRIDE_LOG2}")
-            a(f".L{n}_h{i}:  ; {op}")
-            start = len(a.lines)
-            base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-            if base in UNSUPPORTED:
-                a(f"\ts_branch {self.next}")   # never emitted for tapes routed here (host checks)
-            else:
-                self.handler(op)
-            # size check is done by the assembler: the next .p2align would silently grow the
-            # slot, so emit an explicit assertion on the slot size
-            a(f"\t.if (. - .L{n}_h{i}) > {1 << HSTRIDE_LOG2}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
+        for inplace in (False, True):
+            for i in range(64):
+                a(f"\t.p2align {HSTRIDE_LOG2}")
+                lab = f".L{n}_{'i' if inplace else 'h'}{i}"
+                op = OPS[i] if i < len(OPS) else None
+                a(f"{lab}:  ; {op}{' (in place)' if inplace else ''}")
+                base = op.rsplit("_", 1)[0] if op and "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
+                if op is None or base in UNSUPPORTED:
+                    self.ret()             # never reached for tapes routed here (host checks)
+                elif inplace and op not in self.INPLACE:
+                    a(f"\ts_branch .L{n}_h{i}")
+                else:
+                    self.handler(op, inplace)
+                # the next .p2align would silently grow the slot: an explicit assertion on its size
+                a(f"\t.if (. - {lab}) > {1 << HSTRIDE_LOG2}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
         a(f"\t.p2align {HSTRIDE_LOG2}")
         for lab, fn in self.ool:
             a(f"{lab}:")
@@ -829,7 +810,6 @@ def gen_columns(a, variants, off):
 	s_addc_u32 s85, s85, s31
 	; the head of the tape is requested now and arrives while the pass is set up
 	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
-	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20
 	; pixel of this lane, its z-buffer word
 	v_add_u32 {V_S0}, {S_FX}, {V_LX}
 	v_add_u32 {V_S1}, {S_FY}, {V_LY}
@@ -898,8 +878,7 @@ def gen_columns(a, variants, off):
         if zb < 8:
             # the next pass (if any) needs the head of the tape again: ask for it before the hit test
             a(f"""
-	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
-	s_load_dwordx8 s[{S_QB}:{S_QB + 7}], {S_TBASE}, 0x20""")
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0""")
         for j in range(zb):
             # first voxel inside, front to back: depth = lz + (k - j) + 1
             a(f"""
