@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > 32 || child.len > FH_COL_TAPE_CAP) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     const uint32_t layers = P.tiles[0] / T;
                     S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > 32 || child.len > FH_COL_TAPE_CAP) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 const uint32_t layers = P.tiles[0] / T;
                 S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
