@@ -1036,9 +1036,8 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
                 struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
-                const size_t col_lds = 4 * FH_COL_TAPE_CAP * 16 + 4 * 256;  // decoded tapes (16 B per op) and depths of a block's 4 leaves
-                if (col_waves) (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka), col_lds);
-                else (void)launch_asm(ctx, FH_ASM_COLUMNS, (R.n_footprints + 3) / 4, &ka, sizeof(ka), col_lds, std::min<uint32_t>(P.tiles[0] / 8, 16));
+                if (col_waves) (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
+                else (void)launch_asm(ctx, FH_ASM_COLUMNS, (R.n_footprints + 3) / 4, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16));
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
@@ -1046,11 +1045,10 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
-            const uint32_t len_cap = R.asm_points ? FH_COL_TAPE_CAP : 0u;
-            if (P.max_regs > 32 || (len_cap && tape->t.ops.size() > len_cap)) {
+            if (P.max_regs > 32) {
                 const int g = blocks_for(ctx, R.lds_points_big, 16);
-                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS, len_cap);
-                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS, len_cap);
+                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
             }
         });
         launch(ctx, FHIP_K_NORMALS, [&] {

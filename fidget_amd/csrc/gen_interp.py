@@ -41,7 +41,6 @@ assert len(OPS) == 52
 UNSUPPORTED = {"SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "EXP", "LN", "RAND", "ATAN2", "MIX", "MOD"}
 
 HSTRIDE_LOG2 = 7  # handler slots of 128 bytes
-EXP = __import__("os").environ.get("FH_EXP", "")   # timing experiments (wrong results): noidx, novalu, nointerp
 
 # ---- fixed SGPRs ---------------------------------------------------------------------------
 S_KERNARG = "s[0:1]"
@@ -111,11 +110,7 @@ V_LX, V_LY = "v52", "v53"
 V_S0, V_S1, V_S2, V_S3 = "v54", "v55", "v56", "v57"
 V_IDV = "v58"
 VOFF = [f"v{60 + j}" for j in range(4)]  # bulk: byte offset of sample j
-V_OP, V_OPA = "v[60:63]", "v7"   # columns: decoded op in flight from LDS, its LDS address (v7: the table ids, dead by then)
-COL_TAPE_CAP = 96       # columns: ops of a leaf tape staged in LDS (longer tapes: k_leaves3d<2>, with the > 32 register ones)
-COL_OP_BYTES = 16       # ... decoded: handler address, out index, a index, b index / immediate / slot
-COL_LEAF_LDS = COL_TAPE_CAP * COL_OP_BYTES
-COL_LDS = 4 * COL_LEAF_LDS + 4 * 256
+V_ROFF, V_RLEN, V_RRC, V_RZ = "v60", "v61", "v62", "v63"   # columns: leaf records of the column, lane = layer
 FILE = 64
 
 SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
@@ -149,7 +144,6 @@ class Interp:
     def __init__(self, a, name, nr, zb, kind, off):
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
-        self.breg = S_W1 if kind == "columns" else S_T1
         self.next = f".L{name}_next"
         self.ool = []  # out-of-line handler bodies: (label, callable)
 
@@ -167,21 +161,17 @@ class Interp:
 
     # -- small helpers ---------------------------------------------------------------------
     def idx_on(self, sreg, mode):
-        if EXP != "noidx":
-            self.a(f"\ts_set_gpr_idx_on {sreg}, {mode}")
+        self.a(f"\ts_set_gpr_idx_on {sreg}, {mode}")
 
     def idx_idx(self, sreg):
-        if EXP != "noidx":
-            self.a(f"\ts_set_gpr_idx_idx {sreg}")
+        self.a(f"\ts_set_gpr_idx_idx {sreg}")
 
     def idx_off(self):
-        if EXP != "noidx":
-            self.a("\ts_set_gpr_idx_off")
+        self.a("\ts_set_gpr_idx_off")
 
     def b_index(self):
-        """self.breg = file index of the register named by word 1 (the leaf kernel decodes it ahead of time)"""
-        if self.kind != "columns":
-            self.a(f"\ts_lshl_b32 {S_T1}, {S_W1}, {self.lg}")
+        """S_T1 = file index of the register named by word 1"""
+        self.a(f"\ts_lshl_b32 {S_T1}, {S_W1}, {self.lg}")
 
     def pk_mov(self, dst, src):
         self.a(f"\tv_pk_mov_b32 {dst}, {src}, {src} op_sel:[0,1]")
@@ -195,9 +185,9 @@ class Interp:
     def read_b(self, dst, already_on=True):
         self.b_index()
         if already_on:
-            self.idx_idx(self.breg)
+            self.idx_idx(S_T1)
         else:
-            self.idx_on(self.breg, SRC0 | SRC1)
+            self.idx_on(S_T1, SRC0 | SRC1)
         for k in range(self.zb // 2):
             self.pk_mov(self.P(dst, k), self.FP(k))
 
@@ -206,9 +196,6 @@ class Interp:
             self.a(f"\tv_mov_b32 {dst[j]}, {S_W1}")
 
     def ret(self):
-        """end of a handler: on to the decode of the next op.  The index mode may stay on: every handler
-        (re)sets the mode before its first vector instruction, and the decode code that has vector
-        instructions (leaf kernel) switches it off first."""
         self.a(f"\ts_setpc_b64 {S_NEXT}")
 
     def write_out(self, src, done=True):
@@ -400,7 +387,7 @@ class Interp:
                 return self.ret()
             self.read_a(VT)                          # a in VT; then VT = VT (op) file[b]
             self.b_index()
-            self.idx_on(self.breg, SRC1)
+            self.idx_on(S_T1, SRC1)
             for k in PZ:
                 a(f"\t{ins} {self.P(VT, k)}, {self.P(VT, k)}, {self.FP(k)}{negb}")
             return self.write_out(VT)
@@ -530,8 +517,6 @@ class Interp:
         a, n, lg = self.a, self.name, self.lg
         qa, qb = S_QA, S_QB
         COPY = 128
-        if self.kind == "columns":
-            return self.emit_columns()
         a(f"""
 ; ---- interpreter {n}: in {S_TAPE} = first op, {S_LEN} = ops (bulk); returns to {S_RET} -----------
 ; The tape comes through the scalar cache 4 ops at a time into two SGPR batches; the decode code
@@ -585,38 +570,7 @@ class Interp:
 .L{n}_done:
 	s_waitcnt lgkmcnt(0)
 	s_set_gpr_idx_off
-	s_setpc_b64 {S_RET}""")
-        self.emit_handlers()
-
-    def emit_columns(self):
-        """The leaf kernel decodes a leaf's whole tape with vector code (lane = op) into LDS: handler address,
-        file indices of out / a / b.  What is left per op is a 16-byte LDS read one op ahead, four
-        v_readfirstlane and the jump: the scalar unit, which every wave of a CU shares and which was what
-        bounded this kernel, sees 3 instructions per op here instead of ~17."""
-        a, n = self.a, self.name
-        a(f"""
-; ---- interpreter {n}: first op requested into {V_OP} from LDS address {V_OPA}; returns to {S_RET} at the OUTPUT
-.L{n}_go:
-	s_getpc_b64 {S_NEXT}
-.L{n}_gopc:
-	s_add_u32 s70, s70, .L{n}_d0 - .L{n}_gopc
-	s_addc_u32 s71, s71, 0
-	s_mov_b32 s45, s43
-.L{n}_d0:
-	s_set_gpr_idx_off                               ; (the handlers leave their index mode on)
-	s_waitcnt lgkmcnt(0)
-	v_readfirstlane_b32 s44, v60
-	v_readfirstlane_b32 {S_OUT}, v61
-	v_readfirstlane_b32 {S_A}, v62
-	v_readfirstlane_b32 {S_W1}, v63
-	v_add_u32 {V_OPA}, {COL_OP_BYTES}, {V_OPA}
-	ds_read_b128 {V_OP}, {V_OPA}
-	s_setpc_b64 {S_JMP}""")
-        self.emit_handlers()
-
-    def emit_handlers(self):
-        a, n = self.a, self.name
-        a(f"""
+	s_setpc_b64 {S_RET}
 	.p2align {HSTRIDE_LOG2}
 .L{n}_handlers:""")
         for inplace in (False, True):
@@ -628,8 +582,6 @@ class Interp:
                 base = op.rsplit("_", 1)[0] if op and "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
                 if op is None or base in UNSUPPORTED:
                     self.ret()             # never reached for tapes routed here (host checks)
-                elif EXP == "novalu" and op != "OUTPUT":
-                    self.ret()
                 elif inplace and op not in self.INPLACE:
                     a(f"\ts_branch .L{n}_h{i}")
                 else:
@@ -731,8 +683,6 @@ def gen_columns(a, variants, off):
     its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
     S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
     S_ONE, S_WGY = "s100", "s101"
-    S_LDSB = "s73"      # LDS address of the current leaf's tape
-    S_HB = ["s39", "s46", "s47"]   # handler tables of the register classes (low halves; s43 = the high half)
     BLKL = 2            # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast)
     BLK = 1 << BLKL
     kernel_header(a, kname, 16, nvg)
@@ -753,15 +703,7 @@ def gen_columns(a, variants, off):
 	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
 	s_load_dwordx16 s[48:63], {S_STATE}, {o['P.in_kind']}
 	v_and_b32 {V_LX}, 7, {V_LANE}
-	v_lshrrev_b32 {V_LY}, 3, {V_LANE}""")
-    for q, it in enumerate(its):
-        here = a.label("hb")
-        a(f"""
-	s_getpc_b64 {S_HBASE}
-{here}:
-	s_add_u32 {S_HB[q]}, s42, .L{it.name}_handlers - {here}
-	s_addc_u32 s43, s43, 0""")
-    a(f"""
+	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
 	s_mov_b32 {S_SLOTX}, -1
 	s_mov_b32 {S_SLOTY}, -1
 	s_mov_b32 {S_SLOTZ}, -1
@@ -840,151 +782,43 @@ def gen_columns(a, variants, off):
 	v_cmp_ne_u32 vcc, 0, {V_IDS}
 	s_nop 3
 	s_mov_b64 {S_LAYMASK}, vcc
-	{"s_endpgm" if __import__("os").environ.get("FH_EXP") == "noleaf" else ""}
-	s_cmp_eq_u64 {S_LAYMASK}, 0
-	s_cbranch_scc1 .Lfh_columns_block
-	; ---- everything the leaves of this block need, requested together: a leaf is a chain of dependent
-	; loads (table -> record -> tape, depths); taken one leaf at a time that chain, not the arithmetic,
-	; was the kernel's time.  Records: lane = footprint.
-	v_subrev_u32 {V_S0}, 1, {V_IDS}
-	v_mul_lo_u32 {V_S0}, {V_S0}, 24
-	s_mov_b64 exec, {S_LAYMASK}
-	global_load_dwordx4 v[18:21], {V_S0}, {S_LEAVES}             ; tape offset, length, regs | choices << 16, x
-	global_load_dwordx2 v[22:23], {V_S0}, {S_LEAVES} offset:16   ; y, z
-	s_mov_b64 exec, -1
-	s_waitcnt vmcnt(0)
-	v_and_b32 {V_S1}, 0xffff, v20
-	v_cmp_ge_u32 vcc, 32, {V_S1}                                  ; more registers / a longer tape: left to k_leaves3d<2>
-	s_movk_i32 {S_T0}, {COL_TAPE_CAP}
-	v_cmp_ge_u32_e64 {S_M[0]}, {S_T0}, v19
-	v_lshl_or_b32 v24, {V_S1}, 16, v19                            ; length | regs << 16
-	v_lshl_or_b32 v25, v22, 16, v21                               ; x | y << 16
-	s_and_b64 vcc, vcc, {S_M[0]}
-	s_and_b64 {S_LAYMASK}, {S_LAYMASK}, vcc
-	s_cbranch_scc0 .Lfh_columns_block""")
-    inplace_mask = 0
-    for k, op in enumerate(OPS):
-        if op in Interp.INPLACE:
-            inplace_mask |= 1 << k
-    V_LN8, V_LN16, V_LN4 = VD[4], VD[5], VD[6]
-    a(f"""
-	v_lshlrev_b32 {V_LN8}, 3, {V_LANE}
-	v_lshlrev_b32 {V_LN16}, 4, {V_LANE}
-	v_lshlrev_b32 {V_LN4}, 2, {V_LANE}""")
-    for i in range(BLK):
-        skip, one = a.label("req_skip"), a.label("req_one")
-        a(f"""
-	s_bitcmp1_b64 {S_LAYMASK}, {i}
-	s_cbranch_scc0 {skip}
-	v_readlane_b32 s84, v18, {i}
-	v_readlane_b32 s{48 + 4 * i}, v24, {i}
-	v_readlane_b32 s{49 + 4 * i}, v25, {i}
-	v_readlane_b32 s{50 + 4 * i}, v23, {i}
-	v_readlane_b32 s{51 + 4 * i}, {V_IDS}, {i}
-	s_mov_b32 s85, 0
-	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
-	s_add_u32 s84, s84, s30
-	s_addc_u32 s85, s85, s31
-	; the tape: lane = op (two requests when it is longer than 64)
-	s_and_b32 {S_T1}, s{48 + 4 * i}, 0xffff
-	s_min_u32 {S_T0}, {S_T1}, 64
-	s_sub_u32 {S_T0}, 64, {S_T0}
-	s_lshr_b64 exec, -1, {S_T0}
-	global_load_dwordx2 v[{26 + 2 * i}:{27 + 2 * i}], {V_LN8}, {S_TBASE}
-	s_cmp_gt_u32 {S_T1}, 64
-	s_cbranch_scc0 {one}
-	s_sub_u32 {S_T0}, 128, {S_T1}
-	s_lshr_b64 exec, -1, {S_T0}
-	global_load_dwordx2 v[{34 + 2 * i}:{35 + 2 * i}], {V_LN8}, {S_TBASE} offset:512
-{one}:
-	s_mov_b64 exec, -1
-	; the depths under the leaf: lane = pixel
-	s_and_b32 {S_T0}, s{49 + 4 * i}, 0xffff
-	s_lshr_b32 {S_T1}, s{49 + 4 * i}, 16
-	v_add_u32 {V_S0}, {S_T0}, {V_LX}
-	v_add_u32 {V_S1}, {S_T1}, {V_LY}
-	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_S0}
-	v_cmp_gt_u32_e64 {S_M[1]}, {S_HEIGHT}, {V_S1}
-	v_mul_lo_u32 {V_S2}, {V_S1}, {S_WIDTH}
-	v_add_u32 {V_S2}, {V_S2}, {V_S0}
-	v_lshlrev_b32 {V_S2}, 3, {V_S2}
-	v_mov_b32 {VD[i]}, -1                              ; pixels outside the image never become pending
-	s_and_b64 exec, {S_M[0]}, {S_M[1]}
-	global_load_dword {VD[i]}, {V_S2}, {S_ZBUF} offset:4
-	s_mov_b64 exec, -1
-{skip}:""")
-    a(f"""
-	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}         ; ops with an in-place handler
-	s_mov_b32 s97, {hex(inplace_mask >> 32)}
-	s_waitcnt vmcnt(0)""")
-    for i in range(BLK):
-        skip = a.label("dec_skip")
-        # the leaf's register class: shift of its file indices, handler table
-        a(f"""
-	s_bitcmp1_b64 {S_LAYMASK}, {i}
-	s_cbranch_scc0 {skip}
-	s_lshr_b32 {S_T0}, s{48 + 4 * i}, 16
-	s_mov_b32 {S_T1}, {its[-1].lg}
-	s_mov_b32 s84, {S_HB[len(its) - 1]}""")
-        for q in range(len(its) - 2, -1, -1):
-            a(f"""
-	s_cmp_le_u32 {S_T0}, {its[q].nr}
-	s_cselect_b32 {S_T1}, {its[q].lg}, {S_T1}
-	s_cselect_b32 s84, {S_HB[q]}, s84""")
-        for c, raw in ((0, 26 + 2 * i), (1, 34 + 2 * i)):
-            w0, w1 = f"v{raw}", f"v{raw + 1}"
-            a(f"""
-	v_and_b32 v10, 0xff, {w0}                          ; opcode
-	v_bfe_u32 v11, {w0}, 8, 12                         ; out
-	v_lshrrev_b32 v12, 20, {w0}                        ; a
-	v_cmp_eq_u32 vcc, v11, v12
-	v_lshrrev_b64 v[14:15], v10, s[96:97]
-	v_subrev_u32 v13, 22, v10
-	v_and_b32 v14, 1, v14
-	v_cndmask_b32 v14, 0, v14, vcc                     ; out == a and the op has an in-place handler
-	v_cmp_gt_u32 vcc, 12, v13                          ; reg,reg form: word 1 is a register
-	v_lshl_or_b32 v14, v14, 6, v10
-	v_lshlrev_b32 v15, {S_T1}, {w1}
-	v_lshlrev_b32 v14, {HSTRIDE_LOG2}, v14
-	v_lshlrev_b32 v19, {S_T1}, v11
-	v_lshlrev_b32 v20, {S_T1}, v12
-	v_add_u32 v18, s84, v14                            ; handler address (low half; the tables share the high one)
-	v_cndmask_b32 v21, {w1}, v15, vcc
-	{"s_mov_b32 exec_hi, 0" if c else ""}
-	ds_write_b128 {V_LN16}, v[18:21] offset:{i * COL_LEAF_LDS + c * 1024}
-	{"s_mov_b32 exec_hi, -1" if c else ""}""")
-        a(f"""
-	ds_write_b32 {V_LN4}, {VD[i]} offset:{4 * COL_LEAF_LDS + 256 * i}
-{skip}:""")
-    a(f"""
 .Lfh_columns_leaf:
 	; ---- next leaf of the block ---------------------------------------------------------------
 	s_cmp_eq_u64 {S_LAYMASK}, 0
 	s_cbranch_scc1 .Lfh_columns_block
 	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
-	s_lshl_b32 {S_T0}, {S_ZL}, 2
-	s_mov_b32 m0, {S_T0}
-	s_mul_i32 {S_LDSB}, {S_ZL}, {COL_LEAF_LDS}
-	s_movrels_b64 s[64:65], s[48:49]
-	s_movrels_b64 s[66:67], s[50:51]
-	; its first op and the depths, from LDS
-	v_mov_b32 {V_OPA}, {S_LDSB}
-	s_lshl_b32 {S_T1}, {S_ZL}, 8
-	v_lshlrev_b32 {V_S3}, 2, {V_LANE}
-	ds_read_b128 {V_OP}, {V_OPA}
-	v_add_u32 {V_S3}, {S_T1}, {V_S3}
-	ds_read_b32 {V_DEPTH}, {V_S3} offset:{4 * COL_LEAF_LDS}
-	s_lshr_b32 {S_RC}, s64, 16
-	s_and_b32 {S_FX}, s65, 0xffff
-	s_lshr_b32 {S_FY}, s65, 16
-	s_mov_b32 {S_LZ}, s66
-	s_mov_b32 {S_ID}, s67
+	s_nop 0
+	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
+	s_nop 3
+	s_sub_u32 {S_T0}, {S_ID}, 1
+	s_mul_i32 {S_T0}, {S_T0}, 24
+	s_add_u32 s86, s32, {S_T0}
+	s_addc_u32 s87, s33, 0
+	s_load_dwordx4 s[64:67], {S_PC}, 0x0            ; tape offset, length, regs | choices << 16, x
+	s_load_dwordx2 s[68:69], {S_PC}, 0x10           ; y, z
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 s84, s64
+	s_mov_b32 s85, 0
+	s_mov_b32 {S_LEN0}, s65
+	s_and_b32 {S_RC}, s66, 0xffff
+	s_mov_b32 {S_FX}, s67
+	s_mov_b32 {S_FY}, s68
+	s_mov_b32 {S_LZ}, s69
+	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_leaves3d<2>
+	s_cbranch_scc1 .Lfh_columns_leaf
+	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
+	s_add_u32 s84, s84, s30
+	s_addc_u32 s85, s85, s31
+	; the head of the tape is requested now and arrives while the pass is set up
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
 	; pixel of this lane, its z-buffer word
 	v_add_u32 {V_S0}, {S_FX}, {V_LX}
 	v_add_u32 {V_S1}, {S_FY}, {V_LY}
 	v_cvt_f32_u32 {V_PXF}, {V_S0}
 	v_cvt_f32_u32 {V_PYF}, {V_S1}
+	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_S0}
+	v_cmp_gt_u32_e64 {S_M[1]}, {S_HEIGHT}, {V_S1}
 	v_mul_lo_u32 {V_S2}, {V_S1}, {S_WIDTH}
 	v_add_u32 {V_S2}, {V_S2}, {V_S0}
 	v_mov_b32 {V_S3}, 0
@@ -992,7 +826,13 @@ def gen_columns(a, variants, off):
 	v_mov_b32 {V_S3}, s37
 	v_add_co_u32 v2, vcc, s36, v2
 	v_addc_co_u32 v3, vcc, {V_S3}, v3, vcc
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	v_mov_b32 {V_DEPTH}, -1                         ; pixels outside the image never become pending
 	v_mov_b32 {V_HIT}, 0
+	s_mov_b64 {S_SAVE}, exec
+	s_mov_b64 exec, {S_M[0]}
+	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
+	s_mov_b64 exec, {S_SAVE}
 	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
 	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
 	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
@@ -1004,14 +844,14 @@ def gen_columns(a, variants, off):
 	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
 	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
 	v_mov_b32 {V_IDV}, {S_ID}
-	s_waitcnt lgkmcnt(0)
+	s_waitcnt vmcnt(0)
 	; pending = depth < lz + 8  (voxel.rs:377-381)
 	s_add_u32 {S_T0}, {S_LZ}, 8
 	v_cmp_gt_u32 vcc, {S_T0}, {V_DEPTH}
 	s_nop 3
 	s_mov_b64 {S_PEND}, vcc
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .Lfh_columns_leaf
+	s_cbranch_scc1 .Lfh_columns_leaf_drain
 	s_mov_b32 {S_K}, 7""")
     for it in its[:-1]:
         a(f"\ts_cmp_le_u32 {S_RC}, {it.nr}\n\ts_cbranch_scc1 .L{it.name}_chunk")
@@ -1026,20 +866,21 @@ def gen_columns(a, variants, off):
 	s_addc_u32 s43, s43, 0""")
         for j in range(zb):
             a(f"\tv_mov_b32 {VRES[j]}, 0")
+        a(f"""
+	s_mov_b64 {S_TAPE}, {S_TBASE}
+	s_mov_b32 {S_LEN}, {S_LEN0}""")
         ret, here = a.label("ret"), a.label("pc")
         a(f"""
 	s_getpc_b64 {S_RET}
 {here}:
 	s_add_u32 s74, s74, {ret} - {here}
 	s_addc_u32 s75, s75, 0
-	{"s_waitcnt lgkmcnt(0)" if __import__("os").environ.get("FH_EXP") == "nointerp" else "s_branch .L" + name + "_go"}
+	s_branch .L{name}_go
 {ret}:""")
         if zb < 8:
-            # the next pass (if any) needs the first op again: ask for it before the hit test
+            # the next pass (if any) needs the head of the tape again: ask for it before the hit test
             a(f"""
-	v_mov_b32 {V_OPA}, {S_LDSB}
-	s_nop 0
-	ds_read_b128 {V_OP}, {V_OPA}""")
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0""")
         for j in range(zb):
             # first voxel inside, front to back: depth = lz + (k - j) + 1
             a(f"""
@@ -1068,7 +909,7 @@ def gen_columns(a, variants, off):
 	global_atomic_umax_x2 {V_PIX}, v[4:5], off
 	s_mov_b64 exec, {S_SAVE}
 .Lfh_columns_leaf_drain:
-	s_waitcnt lgkmcnt(0)                            ; an unused op request may still be in flight
+	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
 	s_branch .Lfh_columns_leaf
 .Lfh_columns_exit:""")
     kernel_footer(a, kname, 16, nvg, 102, True, wg_y=True)

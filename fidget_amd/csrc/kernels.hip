@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32 || child.len > FH_COL_TAPE_CAP) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     const uint32_t layers = P.tiles[0] / T;
                     S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32 || child.len > FH_COL_TAPE_CAP) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 const uint32_t layers = P.tiles[0] / T;
                 S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
@@ -1068,10 +1068,8 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
 // to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so the order in which waves reach
 // the leaves of one column does not matter; a leaf whose pixels are all hit in front of it retires
 // after one load.  CLS: leaves of <= 16 registers, 17..32, more (LDS register file).
-// len_cap (CLS 2 only): with fh_columns as the leaf kernel, leaves whose tape is longer than its LDS
-// staging area come here as well.
 template <int CLS, int NR, int ZB, bool FULL>
-__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S, uint32_t len_cap = 0) {
+__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
@@ -1084,7 +1082,7 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S, uint32_t le
     for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
         const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
         const uint32_t regs = lf.tape.n_regs;
-        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : (regs <= 32 && !(len_cap && lf.tape.len > len_cap)))) continue;
+        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= 32)) continue;
         const uint32_t px = lf.x + (lane % T), py = lf.y + (lane / T), lz = lf.z;
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;

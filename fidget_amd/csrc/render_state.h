@@ -8,7 +8,6 @@
 #define FH_MAX_LEVELS 8
 #define FH_MAX_INPUTS 16
 #define FH_MAX_SLABS 64
-#define FH_COL_TAPE_CAP 96   // fh_columns stages leaf tapes of up to this many ops in LDS (gen_interp.py COL_TAPE_CAP)
 #define FH_MAX_GROUPS 16  // independent sub-tapes of a root min / max (tape parallelism at level 0)
 
 // One wave's worth of interval work: a parent tile (or, at level 0, a run of root tiles)
