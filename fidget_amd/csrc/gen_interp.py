@@ -110,7 +110,7 @@ V_LX, V_LY = "v52", "v53"
 V_S0, V_S1, V_S2, V_S3 = "v54", "v55", "v56", "v57"
 V_IDV = "v58"
 VOFF = [f"v{60 + j}" for j in range(4)]  # bulk: byte offset of sample j
-V_ROFF, V_RLEN, V_RRC, V_RZ = "v60", "v61", "v62", "v63"   # columns: leaf records of the column, lane = layer
+V_DEC = ["v60", "v61", "v62", "v63"]   # columns: the leaf's tape decoded, lane = op: handler address, out index, a index, word 1
 FILE = 64
 
 SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
@@ -566,6 +566,24 @@ class Interp:
 	.error "decode copy of {n} exceeds its slot"
 	.endif
 	.p2align 7""")
+        if self.kind == "columns":
+            a(f"""
+; ---- ... and for tapes the caller has decoded into {V_DEC[0]}..{V_DEC[3]} (lane = op): one copy, four v_readlane
+.L{n}_gov:
+	s_getpc_b64 {S_NEXT}
+.L{n}_govpc:
+	s_add_u32 s70, s70, .L{n}_dv - .L{n}_govpc
+	s_addc_u32 s71, s71, 0
+	s_mov_b32 s45, s43
+	s_mov_b32 {S_LEN}, 0
+.L{n}_dv:
+	s_set_gpr_idx_off                               ; (the handlers leave their index mode on)
+	v_readlane_b32 s44, {V_DEC[0]}, {S_LEN}
+	v_readlane_b32 {S_OUT}, {V_DEC[1]}, {S_LEN}
+	v_readlane_b32 {S_A}, {V_DEC[2]}, {S_LEN}
+	v_readlane_b32 {S_W1}, {V_DEC[3]}, {S_LEN}
+	s_add_u32 {S_LEN}, {S_LEN}, 1
+	s_setpc_b64 {S_JMP}""")
         a(f"""
 .L{n}_done:
 	s_waitcnt lgkmcnt(0)
@@ -681,6 +699,10 @@ def gen_columns(a, variants, off):
     m = S_MAT
     nvg = FILE + 64
     its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
+    inplace_mask = 0
+    for k, op in enumerate(OPS):
+        if op in Interp.INPLACE:
+            inplace_mask |= 1 << k
     S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
     S_ONE, S_WGY = "s100", "s101"
     BLKL = 2            # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast)
@@ -810,8 +832,20 @@ def gen_columns(a, variants, off):
 	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
 	s_add_u32 s84, s84, s30
 	s_addc_u32 s85, s85, s31
-	; the head of the tape is requested now and arrives while the pass is set up
+	; The tape is requested now and arrives while the pass is set up.  Up to 64 ops: one vector load,
+	; lane = op, decoded below by vector code; the scalar unit, which all waves of a CU share and which
+	; bounds this kernel, then only jumps.  Longer tapes (1 % of prospero's leaves) keep the scalar fetch.
+	s_cmp_gt_u32 {S_LEN0}, 64
+	s_cbranch_scc1 .Lfh_columns_longtape
+	v_lshlrev_b32 {V_S3}, 3, {V_LANE}
+	s_sub_u32 {S_T0}, 64, {S_LEN0}
+	s_lshr_b64 exec, -1, {S_T0}
+	global_load_dwordx2 v[60:61], {V_S3}, {S_TBASE}
+	s_mov_b64 exec, -1
+	s_branch .Lfh_columns_taperequested
+.Lfh_columns_longtape:
 	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+.Lfh_columns_taperequested:
 	; pixel of this lane, its z-buffer word
 	v_add_u32 {V_S0}, {S_FX}, {V_LX}
 	v_add_u32 {V_S1}, {S_FY}, {V_LY}
@@ -864,23 +898,49 @@ def gen_columns(a, variants, off):
 .L{name}_hb:
 	s_add_u32 s42, s42, .L{name}_handlers - .L{name}_hb
 	s_addc_u32 s43, s43, 0""")
+        a(f"""
+	s_cmp_gt_u32 {S_LEN0}, 64
+	s_cbranch_scc1 .L{name}_pass
+	; decode the tape, lane = op: handler address (in-place variant when out == a and the op has one), file
+	; indices of out and a; word 1 stays as it is
+	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
+	s_mov_b32 s97, {hex(inplace_mask >> 32)}
+	v_and_b32 v18, 0xff, v60
+	v_bfe_u32 v19, v60, 8, 12
+	v_lshrrev_b32 v20, 20, v60
+	v_cmp_eq_u32 vcc, v19, v20
+	v_lshrrev_b64 v[22:23], v18, s[96:97]
+	v_mov_b32 v63, v61
+	v_and_b32 v22, 1, v22
+	v_cndmask_b32 v22, 0, v22, vcc
+	v_lshlrev_b32 v61, {it.lg}, v19
+	v_lshl_or_b32 v22, v22, 6, v18
+	v_lshlrev_b32 v62, {it.lg}, v20
+	v_lshlrev_b32 v22, {HSTRIDE_LOG2}, v22
+	v_add_u32 v60, s42, v22
+.L{name}_pass:""")
         for j in range(zb):
             a(f"\tv_mov_b32 {VRES[j]}, 0")
         a(f"""
-	s_mov_b64 {S_TAPE}, {S_TBASE}
-	s_mov_b32 {S_LEN}, {S_LEN0}""")
+	s_mov_b64 {S_TAPE}, {S_TBASE}""")
         ret, here = a.label("ret"), a.label("pc")
         a(f"""
 	s_getpc_b64 {S_RET}
 {here}:
 	s_add_u32 s74, s74, {ret} - {here}
 	s_addc_u32 s75, s75, 0
+	s_cmp_gt_u32 {S_LEN0}, 64
+	s_cbranch_scc0 .L{name}_gov
 	s_branch .L{name}_go
 {ret}:""")
         if zb < 8:
-            # the next pass (if any) needs the head of the tape again: ask for it before the hit test
+            # the next pass (if any) of a long tape needs its head again: ask for it before the hit test
+            skip = a.label("nohead")
             a(f"""
-	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0""")
+	s_cmp_gt_u32 {S_LEN0}, 64
+	s_cbranch_scc0 {skip}
+	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+{skip}:""")
         for j in range(zb):
             # first voxel inside, front to back: depth = lz + (k - j) + 1
             a(f"""
@@ -897,7 +957,7 @@ def gen_columns(a, variants, off):
 	s_cmp_eq_u64 {S_PEND}, 0
 	s_cbranch_scc1 .Lfh_columns_leaf_done
 	s_sub_u32 {S_K}, {S_K}, {zb}
-	s_cbranch_scc0 .L{name}_chunk
+	s_cbranch_scc0 .L{name}_pass
 	s_branch .Lfh_columns_leaf_done""")
         else:
             a("\ts_branch .Lfh_columns_leaf_done")
