@@ -176,8 +176,8 @@ def main():
         ops_out = sum(v["ops_written"] for v in tile_phases.values())
         tile_bytes = 8.0 * (ops_in + ops_out) + st["interval_choices"] / 4.0
         result["roofline"] = roof("fh_tiles", tile_bytes, kms["tiles"], traffic.get("fh_tiles", {}).get("launches_per_frame", 20),
-                                  "bound by the latency of dependent tape ops (the root tape is a 6363-op chain walked "
-                                  "by 8 waves), far from any HBM limit: see DESIGN.md section 6")
+                                  "bound by the latency of dependent tape ops and by scalar instruction issue (one interval op "
+                                  "per ~340 cycles per wave), far from any HBM limit: see DESIGN.md sections 4 and 6")
         leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
         result["roofline_leaf"] = roof("fh_columns", leaf_bytes, kms["points"], traffic.get("fh_columns", {}).get("launches_per_frame", 8),
                                        "tape words are wave-uniform loads served by the scalar cache / L2: the leaf kernel "

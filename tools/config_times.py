@@ -33,4 +33,12 @@ g = out3.cpu().numpy().view(np.uint32); r, _, secs = O.render3d(O.Shape.from_vm(
 rn = r["normal"]; gn = g[..., :3].view(np.float32)
 res["C3 bear 3D 512^3"].update(oracle_ms=secs * 1e3, depth_exact=bool((g[..., 3] == r["depth"]).all()),
                                normal_max_abs_err=float(np.abs(gn - rn).max()))
+m = os.path.join(ROOT, "models", "prospero.vm")
+s = F.Shape.from_vm(m, hip=hip)
+n = 2048
+out4 = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+ms = timed(lambda: F.render3d(s, n, out=out4), 5)
+g = out4.cpu().numpy().view(np.uint32); r, _, secs = O.render3d(O.Shape.from_vm(m), n)
+res["prospero 3D 2048^3 (beyond BASELINE)"] = {"gpu_ms": ms, "mvoxel_per_s": n ** 3 / ms / 1e3, "oracle_ms": secs * 1e3,
+    "bit_exact": bool((g[..., 3] == r["depth"]).all() and (g[..., :3].view(np.float32).view(np.uint32) == r["normal"].view(np.uint32)).all())}
 print(json.dumps(res, indent=1))
