@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
 }
 
 // Per-slab reset of the work queues, leaf table and tape arena (frame-persistent tapes stay)
-__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups) {
+__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
     const uint32_t P0 = S->pre_levels;
@@ -1194,6 +1194,11 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
     }
     if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.tiles[0];
+    // the coarse levels of the min-depth pyramid are rebuilt by k_minpyramid (not for the first slab: empty image)
+    if (reset_root_mind) {
+        const uint32_t T = S->P.tiles[0], n = ((S->P.width + T - 1) / T) * ((S->P.height + T - 1) / T);
+        for (uint32_t k = i; k < n; k += gridDim.x * blockDim.x) S->mind[0][k] = 0xFFFFFFFFu;
+    }
 }
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
@@ -1239,6 +1244,35 @@ __global__ void __launch_bounds__(256) k_minpyramid(FhRenderState* S) {
         }
         __threadfence_block();
         __syncthreads();
+    }
+}
+
+// The same for the usual shape of the pyramid (three levels, each 4 x 4 of the next, 8 x 8 leaf tiles): one
+// block per tile of the middle level, one wave per leaf tile in it, lane = pixel (coalesced rows); the
+// root level, reset to ~0 by k_reset_slab, takes 16 atomics per word.  (The kernel above, one thread
+// walking each leaf tile, took 30 us of every slab's tile chain.)
+__global__ void __launch_bounds__(1024) k_minpyramid3(FhRenderState* S) {
+    __shared__ uint32_t part[16];
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t T2 = P.tiles[2], T1 = P.tiles[1], T0 = P.tiles[0];
+    const uint32_t n1x = (P.width + T1 - 1) / T1, n2x = (P.width + T2 - 1) / T2, n0x = (P.width + T0 - 1) / T0;
+    const uint32_t bx = blockIdx.x % n1x, by = blockIdx.x / n1x;
+    const uint32_t tx = bx * 4 + (w & 3), ty = by * 4 + (w >> 2);
+    const uint32_t x = tx * T2 + (lane & 7), y = ty * T2 + (lane >> 3);
+    uint32_t mn = (x < P.width && y < P.height) ? (uint32_t)(S->zbuf[(size_t)y * P.width + x] >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, WAVE));
+    if (lane == 0) {
+        part[w] = mn;
+        if (tx * T2 < P.width && ty * T2 < P.height) S->mind[2][ty * n2x + tx] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = part[0];
+        for (int k = 1; k < 16; k++) m = min(m, part[k]);
+        S->mind[1][by * n1x + bx] = m;
+        atomicMin(&S->mind[0][(by * T1 / T0) * n0x + bx * T1 / T0], m);
     }
 }
 
