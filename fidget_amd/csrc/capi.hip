@@ -67,8 +67,8 @@ struct fhip_ctx {
     bool use_split = true;  // FHIP_NO_SPLIT=1: monolithic k_tiles for the 3D tile stage (diagnostics)
     // 3D: the tile stage of slab k+1 runs on a second stream while slab k's leaves are evaluated
     bool use_pipeline = true;  // FHIP_NO_PIPELINE=1 serialises the slabs on one stream (diagnostics)
-    hipStream_t stream2 = nullptr;
-    std::vector<hipEvent_t> ev_tiles, ev_leaves;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
     hipEvent_t ev_fork = nullptr;
     FhRenderState last_state_b;
     bool forked = false;
@@ -154,10 +154,12 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
         if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS);
+    if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
         (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_leaves[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming);
     }
     {
         const void* fb[] = {(const void*)k_teval3d<false, true>, (const void*)k_teval3d<true, true>};
@@ -177,6 +179,8 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     for (auto& q : c->queue) q.release();
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+    for (hipEvent_t e : c->ev_aux) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->ev_tiles) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_leaves) (void)hipEventDestroy(e);
@@ -1044,7 +1048,27 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }
         // (on the tile chain this kernel, cheap as it is, was measured to cost the frame 0.8 ms)
-        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
+        // The footprint lists (needed by the normals only) and the leaves of the LDS class (any order with
+        // the others: atomic-max z-buffer) go beside the leaf kernel on a third stream: off the chain
+        // whose length is the slab's period.
+        // (measured: 0.75 ms SLOWER per frame - the three queues get in each other's way; off unless FHIP_AUX_STREAM=1)
+        const bool aux = pipe && ctx->stream3 && getenv("FHIP_AUX_STREAM");
+        auto aux_work = [&] {
+            launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
+            if (P.max_regs > 32)
+                launch(ctx, FHIP_K_POINTS, [&] {
+                    const int g = blocks_for(ctx, R.lds_points_big, 16);
+                    if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                    else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                });
+        };
+        if (aux) {
+            ctx->stream = ctx->stream3;
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_tiles[idx], 0));
+            aux_work();
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], ctx->stream3));
+            ctx->stream = main_stream;
+        } else aux_work();
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
@@ -1063,12 +1087,8 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
-            if (P.max_regs > 32) {
-                const int g = blocks_for(ctx, R.lds_points_big, 16);
-                if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-                else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-            }
         });
+        if (aux) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_aux[idx], 0));
         launch(ctx, FHIP_K_NORMALS, [&] {
             const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_for(ctx, R.lds_normals_big, 8);
             if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS);
