@@ -1075,7 +1075,6 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
-                // (waves pull footprints with an atomic cursor: measured faster than a static round robin)
                 // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
                 // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;

@@ -22,6 +22,16 @@ register are consecutive, so that copies and add / sub / mul take them two at a 
 op whose output register is one of its operands (more than half of a pruned tape's ops) works on
 the file in place, with no copy at all.
 
+Dispatch.  What bounds these kernels is the scalar unit, which all the waves of a CU share
+(PMC: 36 scalar instructions per tape op in the first version): the vector work of an op is issued
+beside it for free.  So the decode exists in eight copies, one per slot of the two 4-op SGPR
+batches the tape comes in by (no queue shifting, no counters; a handler ends with a jump to the
+next copy), the handler table has an "in place" half that the decode selects when out == a, and
+the leaf kernel, whose tapes are short, takes a whole tape of up to 64 ops with ONE vector load,
+lane = op, decodes it with vector code into four VGPRs (handler address, file indices of out and
+a, word 1) and dispatches with four v_readlane and a jump.  Shape tapes have one output and it is
+their last op: the OUTPUT handler of the leaf kernel returns to the caller, nothing is counted.
+
 Tape format: tape_format.h (8 bytes per op: opcode | out<<8 | a<<20, then b / imm / slot).
 Tapes with transcendental, modulo or rng ops, more than 32 registers, or a projective
 screen-to-model matrix stay on the C++ kernels.
