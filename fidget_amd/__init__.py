@@ -52,7 +52,7 @@ EXPORTS = [
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
     "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
-    "fhip_tape_group", "fhip_tape_term_plan",
+    "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
 
@@ -136,7 +136,8 @@ def lib():
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
-            "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]),
+            "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]), "fhip_tape_term_group": (i32, [vp, vp, u32, vp]),
+            "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
             "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]), "fhip_debug_probe": (i32, [vp, vp]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
@@ -378,6 +379,22 @@ class Shape:
             out.append(Shape(_h=h, hip=self._hip, _vars=self._vars))
         op = lib().fhip_tape_group_op(self._h)
         return ({30: "min", 31: "max"}.get(op, ""), out)
+
+    def term_parts(self):
+        """(group Shapes, tree ops as an (n, 3) u32 array, choice sources as a u32 array) of term_plan()."""
+        n = self.term_plan()
+        gs = []
+        for g in range(n["groups"]):
+            h = C.c_void_p()
+            st = lib().fhip_tape_term_group(None, self._h, g, C.byref(h))
+            if st != 0:
+                raise FidgetHipError(st, "term group")
+            gs.append(Shape(_h=h, hip=self._hip, _vars=self._vars))
+        tree = np.zeros((max(n["tree_ops"], 1), 3), np.uint32)
+        lib().fhip_tape_term_tree(self._h, _p(tree), n["tree_ops"])
+        src = np.zeros(max(n["choices"], 1), np.uint32)
+        lib().fhip_tape_term_choice_src(self._h, _p(src), n["choices"])
+        return gs, tree[:n["tree_ops"]], src[:n["choices"]]
 
     def term_plan(self):
         """The renderer's root-level split: dict(groups, terms, tree_ops, tree_regs, choices); groups = 0 if none."""

@@ -233,6 +233,27 @@ fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fh
     *out = t;
     return FHIP_OK;
 }
+fhip_status fhip_tape_term_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fhip_tape** out) {
+    if (g >= tape->tgroups.size()) return fail(ctx, FHIP_ERR_BAD_TAPE, "no such term group");
+    fhip_tape* t = new fhip_tape();
+    t->t = tape->tgroups[g];
+    *out = t;
+    return FHIP_OK;
+}
+uint32_t fhip_tape_term_tree(const fhip_tape* tape, uint32_t* words, uint32_t cap_ops) {
+    const uint32_t n = (uint32_t)std::min<size_t>(tape->plan.top.size(), cap_ops);
+    for (uint32_t i = 0; i < n; i++) {
+        const fh::TopOp& o = tape->plan.top[i];
+        words[3 * i] = (uint32_t)o.op | ((uint32_t)o.out << 8) | ((uint32_t)o.a_kind << 16) | ((uint32_t)o.b_kind << 24);
+        words[3 * i + 1] = o.a; words[3 * i + 2] = o.b;
+    }
+    return (uint32_t)tape->plan.top.size();
+}
+uint32_t fhip_tape_term_choice_src(const fhip_tape* tape, uint32_t* src, uint32_t cap) {
+    const uint32_t n = (uint32_t)std::min<size_t>(tape->plan.choice_src.size(), cap);
+    for (uint32_t i = 0; i < n; i++) src[i] = tape->plan.choice_src[i];
+    return (uint32_t)tape->plan.choice_src.size();
+}
 uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]) {
     info[0] = tape->plan.n_terms; info[1] = (uint32_t)tape->plan.top.size(); info[2] = tape->plan.top_regs;
     info[3] = (uint32_t)tape->plan.choice_src.size();

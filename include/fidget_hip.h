@@ -78,6 +78,13 @@ fhip_status fhip_tape_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fh
  * the full tape is recorded.  Returns the number of groups (0: not split);
  * info = { terms, tree ops, tree registers, choices covered (= fhip_tape_choice_count) }. */
 uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]);
+/* ... its parts, for tests: group g as a tape of its own (its OUTPUT ops carry the term index);
+ * the tree, 3 words per op: op | out << 8 | a_kind << 16 | b_kind << 24 (kinds: 0 tree register, 1 term,
+ * 2 immediate bits), a, b (returns the number of ops); and per choice of the full tape, in tape order,
+ * where it is recorded: group << 24 | choice index there, group 255 = op index of the tree. */
+fhip_status fhip_tape_term_group(fhip_ctx* ctx, const fhip_tape* tape, uint32_t g, fhip_tape** out);
+uint32_t fhip_tape_term_tree(const fhip_tape* tape, uint32_t* words, uint32_t cap_ops);
+uint32_t fhip_tape_term_choice_src(const fhip_tape* tape, uint32_t* src, uint32_t cap);
 
 /* Function::simplify (eval/mod.rs:147-160; VmData::simplify vm/data.rs:123-318).
  * `choices` is one byte per choice op in evaluation order, values 1/2/3 = Left/Right/Both. */

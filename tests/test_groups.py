@@ -133,3 +133,86 @@ def test_render3d_small_trees_through_groups():
     from conftest import ROOT
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _SMALL_TREES], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- plan_terms on the CPU: a point interpreter of the device tape format in numpy f32 -------------------
+def _run_tape(ops, pts):
+    """Evaluate a device tape (Shape.ops()) at points pts[n, 3] (x, y, z in input slot order 0, 1, 2).
+    Returns ({output slot: f32[n]}, [choice arrays in tape order]); choices as the f32 evaluators record
+    them: 1 = left, 2 = right, 3 = both (tie or NaN).  Only the opcodes prospero uses."""
+    f = np.float32
+    r, outs, choices = {}, {}, []
+    def minmax(a, b, is_min):
+        lt = (a < b) if is_min else (a > b)
+        gt = (b < a) if is_min else (b > a)
+        nan = np.isnan(a) | np.isnan(b)
+        v = np.where(lt, a, np.where(gt, b, np.where(nan, f(np.nan), b))).astype(f)
+        choices.append(np.where(lt, 1, np.where(gt, 2, 3)).astype(np.uint8))
+        return v
+    with np.errstate(all="ignore"):
+        for name, out, a, b, imm in ops:
+            iv = np.full(len(pts), np.array([imm], np.uint32).view(f)[0], f)
+            if name == "Output": outs[imm] = r[a]
+            elif name == "Input": r[out] = pts[:, imm].astype(f)
+            elif name == "CopyReg": r[out] = r[a]
+            elif name == "CopyImm": r[out] = iv
+            elif name == "Neg": r[out] = -r[a]
+            elif name == "Abs": r[out] = np.abs(r[a])
+            elif name == "Square": r[out] = r[a] * r[a]
+            elif name == "Sqrt": r[out] = np.sqrt(r[a])
+            elif name == "AddRR": r[out] = r[a] + r[b]
+            elif name == "SubRR": r[out] = r[a] - r[b]
+            elif name == "MulRR": r[out] = r[a] * r[b]
+            elif name == "AddRI": r[out] = r[a] + iv
+            elif name == "SubRI": r[out] = r[a] - iv
+            elif name == "MulRI": r[out] = r[a] * iv
+            elif name == "SubIR": r[out] = iv - r[a]
+            elif name == "MinRR": r[out] = minmax(r[a], r[b], True)
+            elif name == "MaxRR": r[out] = minmax(r[a], r[b], False)
+            elif name == "MinRI": r[out] = minmax(r[a], iv, True)
+            elif name == "MaxRI": r[out] = minmax(r[a], iv, False)
+            else: raise NotImplementedError(name)
+    return outs, choices
+
+
+def test_term_plan_is_the_same_function_cpu():
+    """Without a GPU: the groups' terms folded by the tree are the root tape's value bit for bit, and every
+    choice of the root tape is found where the plan says it is recorded (point semantics, numpy f32)."""
+    import fidget_amd as F
+    s = F.Shape.from_vm(model_path("prospero.vm"))
+    groups, tree, src = s.term_parts()
+    assert len(groups) >= 2 and len(src) == s.choice_count()
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-1, 1, (48, 3)), [[0, 0, 0], [0.5, -0.25, 0.1], [-1, 1, 0]]]).astype(np.float32)
+    want, want_ch = _run_tape(s.ops(), pts)
+    assert len(want_ch) == len(src)
+    terms, group_ch = {}, []
+    for g in groups:
+        o, ch = _run_tape(g.ops(), pts)
+        assert not (set(o) & set(terms))           # a term belongs to one group
+        terms.update(o)
+        group_ch.append(ch)
+    assert sorted(terms) == list(range(s.term_plan()["terms"]))
+    # the tree over the terms
+    regs, tree_ch = {}, []
+    def operand(kind, ref):
+        if kind == 0: return regs[ref]
+        if kind == 1: return terms[ref]
+        return np.full(len(pts), np.array([ref], np.uint32).view(np.float32)[0], np.float32)
+    for w0, a, b in tree:
+        op, out, ak, bk = int(w0) & 0xFF, (int(w0) >> 8) & 0xFF, (int(w0) >> 16) & 0xFF, int(w0) >> 24
+        assert op in (30, 31, 42, 43)             # MIN / MAX, reg,reg or reg,imm
+        va, vb = operand(ak, int(a)), operand(bk, int(b))
+        is_min = op in (30, 42)
+        lt = (va < vb) if is_min else (va > vb)
+        gt = (vb < va) if is_min else (vb > va)
+        nan = np.isnan(va) | np.isnan(vb)
+        regs[out] = np.where(lt, va, np.where(gt, vb, np.where(nan, np.float32(np.nan), vb))).astype(np.float32)
+        tree_ch.append(np.where(lt, 1, np.where(gt, 2, 3)).astype(np.uint8))
+    root = regs[(int(tree[-1][0]) >> 8) & 0xFF]
+    assert (root.view(np.uint32) == want[0].view(np.uint32)).all()
+    # every choice of the full tape, from where the plan says it is recorded
+    for c, e in enumerate(src):
+        g, j = int(e) >> 24, int(e) & 0xFFFFFF
+        got = tree_ch[j] if g == 255 else group_ch[g][j]
+        assert (got == want_ch[c]).all(), (c, g, j)
