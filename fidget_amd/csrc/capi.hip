@@ -71,7 +71,8 @@ struct fhip_ctx {
     std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
     hipEvent_t ev_fork = nullptr;
     FhRenderState last_state_b;
-    bool forked = false;
+    uint32_t forked = 0;          // slab contexts of the last 3D frame (0: not pipelined)
+    uint32_t slab_contexts = 2;   // FHIP_SLAB_CONTEXTS (2 or 3): how far the tile chain may run ahead of the leaf chain
     uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
     uint32_t resident_groups = 0;
     int device = 0;
@@ -148,6 +149,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (const char* e = getenv("FHIP_NO_SPLIT")) c->use_split = atoi(e) == 0;
     if (const char* e = getenv("FHIP_PROBE")) c->probe = atoi(e) != 0;
     if (const char* e = getenv("FHIP_NO_PIPELINE")) c->use_pipeline = atoi(e) == 0;
+    if (const char* e = getenv("FHIP_SLAB_CONTEXTS")) c->slab_contexts = (uint32_t)std::min(4, std::max(2, atoi(e)));
     {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -678,19 +680,20 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
     R.n_footprints = (uint32_t)(fw * fhh);
 
-    HIP_TRY(ctx, ctx->state.ensure(2 * sizeof(FhRenderState)));
+    HIP_TRY(ctx, ctx->state.ensure(4 * sizeof(FhRenderState)));
     { void* const before = ctx->arena.p; HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes)); if (ctx->arena.p != before) ctx->resident_serial = 0; }
     for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
     if (S.pre_levels) HIP_TRY(ctx, ctx->squeue.ensure((size_t)qcaps[S.pre_levels] * R.n_slabs * sizeof(FhGroup)));
     HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
-    if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(leaf_cap * sizeof(FhLeaf)));
+    const size_t extra = ctx->slab_contexts - 1;
+    if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(extra * leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
         HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
-        HIP_TRY(ctx, ctx->leaf_table_b.ensure(leaf_cap * 4));
+        HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * 4));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
         HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
         HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
-        HIP_TRY(ctx, ctx->fp_lists_b.ensure((size_t)R.n_footprints * 4 * 3));
+        HIP_TRY(ctx, ctx->fp_lists_b.ensure(extra * (size_t)R.n_footprints * 4 * 3));
         size_t mind_words = 0;
         for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
         HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
@@ -796,11 +799,9 @@ static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu) {
 
 static fhip_status finish_render(fhip_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state, ctx->state.p, sizeof(FhRenderState), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->forked)
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state_b, (char*)ctx->state.p + sizeof(FhRenderState), sizeof(FhRenderState),
-                                    hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->forked) {  // the second slab context keeps its own counters
+    for (uint32_t k = 1; k < ctx->forked; k++) {  // the other slab contexts keep their own counters
+        HIP_TRY(ctx, hipMemcpy(&ctx->last_state_b, (char*)ctx->state.p + k * sizeof(FhRenderState), sizeof(FhRenderState), hipMemcpyDeviceToHost));
         ctx->last_state.queue_overflow += ctx->last_state_b.queue_overflow;
         ctx->last_state.arena_overflow += ctx->last_state_b.arena_overflow;
         for (int i = 0; i < 64; i++) ctx->last_state.stat[i] += ctx->last_state_b.stat[i];
@@ -1034,21 +1035,21 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.n_slabs > 1 && n_groups > 0;
     hipStream_t const main_stream = ctx->stream;
     hipStream_t const side_stream = getenv("FHIP_PIPE_SERIAL") ? main_stream : ctx->stream2;  // diagnostics
-    ctx->forked = pipe;
+    const uint32_t NC = pipe ? ctx->slab_contexts : 1;
+    ctx->forked = pipe ? NC : 0;
     if (pipe) {
-        uint32_t* fpb = (uint32_t*)ctx->fp_lists_b.p;
-        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, main_stream, dS0, dS0 + 1, (FhLeaf*)ctx->leaves_b.p,
-                           (uint32_t*)ctx->leaf_table_b.p, fpb, fpb + R.n_footprints, fpb + 2 * (size_t)R.n_footprints);
+        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, main_stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
+                           (uint32_t*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
     for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
         const int idx = (int)R.n_slabs - 1 - k;
-        dS = pipe && (idx & 1) ? dS0 + 1 : dS0;
+        dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
         if (pipe) {
             ctx->stream = side_stream;
-            if (idx >= 2) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_leaves[idx - 2], 0));  // context free again
+            if (idx >= (int)NC) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_leaves[idx - (int)NC], 0));  // context free again
         }
         launch(ctx, FHIP_K_OTHER, [&] {
             // the usual pyramid (three levels, 4 x 4 each, 8 x 8 leaf tiles) has a kernel of its own

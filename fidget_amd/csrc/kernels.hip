@@ -1202,15 +1202,21 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
 }
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
-__global__ void k_fork_state(FhRenderState* A, FhRenderState* B, FhLeaf* leaves, uint32_t* leaf_table, uint32_t* fp0,
-                             uint32_t* fp1, uint32_t* fp2) {
-    *B = *A;
-    B->leaves = leaves; B->leaf_table = leaf_table;
-    B->fp_list[0] = fp0; B->fp_list[1] = fp1; B->fp_list[2] = fp2;
+__global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, uint32_t* leaf_table, uint32_t* fp_lists,
+                             size_t leaf_cap, size_t n_footprints) {
+    // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
     const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
-    const uint32_t mid = lo + (A->arena_cap - lo) / 2;
-    A->arena_cap = mid;
-    B->arena_frame_end = mid; B->arena_root_end = mid;
+    const uint32_t part = (A->arena_cap - lo) / n;
+    for (uint32_t k = 1; k < n; k++) {
+        FhRenderState* B = A + k;
+        *B = *A;
+        B->leaves = leaves + (k - 1) * leaf_cap; B->leaf_table = leaf_table + (k - 1) * leaf_cap;
+        uint32_t* fp = fp_lists + (k - 1) * 3 * n_footprints;
+        B->fp_list[0] = fp; B->fp_list[1] = fp + n_footprints; B->fp_list[2] = fp + 2 * n_footprints;
+        B->arena_frame_end = lo + k * part; B->arena_root_end = lo + k * part;
+        B->arena_cap = lo + (k + 1) * part;
+    }
+    A->arena_cap = lo + part;
 }
 // End of the pre-pass: everything allocated so far lives for the whole frame
 // (arena_head runs past arena_cap when reservations failed: failed ones are never used)
