@@ -167,6 +167,22 @@ def _run_tape(ops, pts):
             elif name == "SubRI": r[out] = r[a] - iv
             elif name == "MulRI": r[out] = r[a] * iv
             elif name == "SubIR": r[out] = iv - r[a]
+            elif name == "Recip": r[out] = (f(1.0) / r[a]).astype(f)
+            elif name == "Floor": r[out] = np.floor(r[a])
+            elif name == "Ceil": r[out] = np.ceil(r[a])
+            elif name == "Round": r[out] = (np.trunc(r[a]) + np.where(np.abs(r[a] - np.trunc(r[a])) >= f(0.5), np.copysign(f(1), r[a]), f(0))).astype(f)
+            elif name == "Not": r[out] = np.where(r[a] == 0, f(1), f(0)).astype(f)
+            elif name in ("DivRR", "DivRI", "DivIR"):
+                x, y = (r[a], r[b]) if name == "DivRR" else ((r[a], iv) if name == "DivRI" else (iv, r[a]))
+                r[out] = (x / y).astype(f)
+            elif name in ("CompareRR", "CompareRI", "CompareIR"):
+                x, y = (r[a], r[b]) if name == "CompareRR" else ((r[a], iv) if name == "CompareRI" else (iv, r[a]))
+                r[out] = np.where(x < y, f(-1), np.where(x == y, f(0), np.where(x > y, f(1), f(np.nan)))).astype(f)
+            elif name in ("AndRR", "AndRI", "OrRR", "OrRI"):
+                y = r[b] if name.endswith("RR") else iv
+                first = (r[a] == 0) if name.startswith("And") else (r[a] != 0)
+                r[out] = np.where(first, r[a], y).astype(f)
+                choices.append(np.where(first, 1, 2).astype(np.uint8))
             elif name == "MinRR": r[out] = minmax(r[a], r[b], True)
             elif name == "MaxRR": r[out] = minmax(r[a], r[b], False)
             elif name == "MinRI": r[out] = minmax(r[a], iv, True)
@@ -175,14 +191,12 @@ def _run_tape(ops, pts):
     return outs, choices
 
 
-def test_term_plan_is_the_same_function_cpu():
-    """Without a GPU: the groups' terms folded by the tree are the root tape's value bit for bit, and every
-    choice of the root tape is found where the plan says it is recorded (point semantics, numpy f32)."""
-    import fidget_amd as F
-    s = F.Shape.from_vm(model_path("prospero.vm"))
+def _check_plan(s, seed=3):
+    """the groups' terms folded by the tree are the root tape's value bit for bit, and every choice of the
+    root tape is found where the plan says it is recorded (point semantics, numpy f32)"""
     groups, tree, src = s.term_parts()
     assert len(groups) >= 2 and len(src) == s.choice_count()
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(seed)
     pts = np.concatenate([rng.uniform(-1, 1, (48, 3)), [[0, 0, 0], [0.5, -0.25, 0.1], [-1, 1, 0]]]).astype(np.float32)
     want, want_ch = _run_tape(s.ops(), pts)
     assert len(want_ch) == len(src)
@@ -216,3 +230,43 @@ def test_term_plan_is_the_same_function_cpu():
         g, j = int(e) >> 24, int(e) & 0xFFFFFF
         got = tree_ch[j] if g == 255 else group_ch[g][j]
         assert (got == want_ch[c]).all(), (c, g, j)
+
+
+def test_term_plan_is_the_same_function_cpu():
+    """Without a GPU: plan_terms on prospero.vm (a chain of 665 terms)."""
+    import fidget_amd as F
+    _check_plan(F.Shape.from_vm(model_path("prospero.vm")))
+
+
+def test_term_plan_small_trees_cpu(monkeypatch):
+    """... and on small shapes sent down the same path: random CSG (min and max roots, reg,imm tree ops,
+    every opcode of the assembly set inside the terms) and a balanced tree with a shared part."""
+    import random
+    import fidget_amd as F
+    from test_render_random import build
+    monkeypatch.setenv("FHIP_GROUPS_MIN_OPS", "0")
+    monkeypatch.setenv("FHIP_GROUPS_MIN_TERMS", "2")
+    split = 0
+    for seed in range(12):
+        ctx = F.Context()
+        s = F.Shape(ctx, build(ctx, seed))
+        if s.term_plan()["groups"] >= 2:
+            split += 1
+            _check_plan(s, seed)
+    assert split >= 6
+    for op, n in (("min", 13), ("max", 9)):
+        ctx = F.Context()
+        rng = random.Random(5)
+        x, y, z = ctx.x(), ctx.y(), ctx.z()
+        def ball():
+            c = [rng.uniform(-0.7, 0.7) for _ in range(3)]
+            d = ctx.add(ctx.add(ctx.square(ctx.sub(x, c[0])), ctx.square(ctx.sub(y, c[1]))), ctx.square(ctx.sub(z, c[2])))
+            return ctx.sub(ctx.sqrt(d), rng.uniform(0.15, 0.4))
+        level = [ball() for _ in range(n)]
+        shared = level[1]
+        while len(level) > 1:
+            level = [getattr(ctx, op)(level[i], level[i + 1]) if i + 1 < len(level) else level[i] for i in range(0, len(level), 2)]
+        s = F.Shape(ctx, getattr(ctx, op)(level[0], ctx.add(shared, 0.05)))
+        p = s.term_plan()
+        assert p["groups"] >= 2 and p["tree_regs"] > 1
+        _check_plan(s)
