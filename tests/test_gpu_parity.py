@@ -51,6 +51,27 @@ def test_render3d_bit_exact(name, size):
     assert same_bits_f32(a["normal"], b["normal"])
 
 
+def test_render3d_headline_config_full_size():
+    """BASELINE.json's metric configuration itself: prospero.vm at 1024^3, bit for bit against the oracle
+    (0.7 s on the GPU box's host cores), plus what must hold at any size: the image does not change from
+    one frame to the next (resident tapes, recycled arena), saturated columns carry (D, [0, 0, 1])
+    (voxel.rs:536-542), and the two halves of a two-way shard are disjoint and sum to the image."""
+    n = 1024
+    p, o = both("prospero.vm")
+    a = F.render3d(p, n)[0]
+    b = O.render3d(o, n)[0]
+    assert (a["depth"] == b["depth"]).all(), f"{(a['depth'] != b['depth']).sum()} depths differ"
+    assert same_bits_f32(a["normal"], b["normal"])
+    again = F.render3d(p, n)[0]
+    assert (again["depth"] == a["depth"]).all() and same_bits_f32(again["normal"], a["normal"])
+    sat = a["depth"] == n
+    assert sat.any() and (a["normal"][sat] == np.array([0, 0, 1], np.float32)).all()
+    halves = [F.render3d(p, n, shard=r, n_shards=2)[0] for r in (0, 1)]
+    h0, h1 = (h.view(np.uint32).reshape(n, n, 4) for h in halves)
+    assert not ((h0 != 0).any(axis=2) & (h1 != 0).any(axis=2)).any()
+    assert ((h0 + h1) == a.view(np.uint32).reshape(n, n, 4)).all()
+
+
 @pytest.mark.parametrize("size", [64, 128, 256])
 def test_render3d_bear(size):
     # transcendentals (exp/ln/sin/cos): occupancy must match, normals within float noise of libm vs f64 device math
