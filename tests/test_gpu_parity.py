@@ -24,7 +24,8 @@ def same_bits_f32(a, b):
 
 
 @pytest.mark.parametrize("name,size", [("hi.vm", 256), ("prospero.vm", 256), ("prospero.vm", 1024), ("quarter.vm", 128),
-                                       ("prospero.vm", 100), ("colonnade.vm", 200)])
+                                       ("prospero.vm", 100), ("colonnade.vm", 200),
+                                       ("prospero.vm", 4096)])   # 4096: BASELINE.json configuration 2 at full size
 def test_render2d_bit_exact(name, size):
     p, o = both(name)
     a = F.render2d(p, size)[0]
@@ -72,7 +73,7 @@ def test_render3d_headline_config_full_size():
     assert ((h0 + h1) == a.view(np.uint32).reshape(n, n, 4)).all()
 
 
-@pytest.mark.parametrize("size", [64, 128, 256])
+@pytest.mark.parametrize("size", [64, 128, 256, 512])   # 512: BASELINE.json configuration 3 at full size
 def test_render3d_bear(size):
     # transcendentals (exp/ln/sin/cos): occupancy must match, normals within float noise of libm vs f64 device math
     p, o = both("bear.vm")
