@@ -48,7 +48,7 @@ EXPORTS = [
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
     "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard",
-    "fhip_profile_enable", "fhip_profile_read", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
+    "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
     "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
@@ -132,7 +132,7 @@ def lib():
             "fhip_render2d": (i32, [vp, vp, C.POINTER(_Cfg2D), vp, i32]),
             "fhip_render3d": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32]),
             "fhip_render3d_shard": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, u32]),
-            "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]),
+            "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
@@ -197,6 +197,14 @@ class HipContext:
         n = np.zeros(4, np.uint32)
         self.check(lib().fhip_profile_read(self._h, _p(ms), _p(n)))
         names = ["tiles", "points", "normals", "other"]
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+    def profile_read_kernels(self):
+        """(ms, launches) of the last profiled frame per assembly kernel, every launch timed on its own."""
+        ms = np.zeros(8, np.float64)
+        n = np.zeros(8, np.uint32)
+        self.check(lib().fhip_profile_read_kernels(self._h, _p(ms), _p(n)))
+        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def counters(self):

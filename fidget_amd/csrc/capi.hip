@@ -85,6 +85,7 @@ struct fhip_ctx {
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> asm_events;   // ... and per assembly kernel launch
     FhRenderState last_state;
     bool have_last_state = false;
 };
@@ -187,6 +188,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     for (hipEvent_t e : c->ev_tiles) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_leaves) (void)hipEventDestroy(e);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (auto& e : c->asm_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     delete c;
 }
 const char* fhip_last_error(const fhip_ctx* c) { return c ? c->err.c_str() : "no context"; }
@@ -265,7 +267,11 @@ uint32_t fhip_tape_term_plan(const fhip_tape* tape, uint32_t info[4]) {
 static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* args, size_t bytes, size_t lds = 0, uint32_t grid_y = 1,
                              hipStream_t stream = nullptr) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, stream ? stream : ctx->stream, nullptr, extra);
+    hipStream_t const st = stream ? stream : ctx->stream;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, st); }
+    const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, st, nullptr, extra);
+    if (ctx->profiling) { (void)hipEventRecord(eb, st); ctx->asm_events.push_back({which, {ea, eb}}); }
     if (e != hipSuccess && ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
     return e;
 }
@@ -830,6 +836,8 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     }
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     ctx->prof_events.clear();
+    for (auto& e : ctx->asm_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->asm_events.clear();
     return FHIP_OK;
 }
 
@@ -1144,6 +1152,15 @@ fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4])
     for (auto& e : ctx->prof_events) {
         float t = 0;
         if (hipEventElapsedTime(&t, e.second.first, e.second.second) == hipSuccess) { ms[e.first] += t; launches[e.first]++; }
+    }
+    return FHIP_OK;
+}
+fhip_status fhip_profile_read_kernels(fhip_ctx* ctx, double ms[8], uint32_t launches[8]) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; i++) { ms[i] = 0; launches[i] = 0; }
+    for (auto& e : ctx->asm_events) {
+        float t = 0;
+        if (e.first < 8 && hipEventElapsedTime(&t, e.second.first, e.second.second) == hipSuccess) { ms[e.first] += t; launches[e.first]++; }
     }
     return FHIP_OK;
 }

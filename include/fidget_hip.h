@@ -157,6 +157,9 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
 enum { FHIP_K_TILES = 0, FHIP_K_POINTS = 1, FHIP_K_NORMALS = 2, FHIP_K_OTHER = 3, FHIP_K_COUNT = 4 };
 void fhip_profile_enable(fhip_ctx* ctx, int on);
 fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4]);
+/* ... and per assembly kernel, each launch bracketed by its own pair of events:
+ * index 0 fh_columns, 1 / 2 fh_float_eval_{16x4, 32x2}, 3 fh_tiles, 4 fh_prune1 */
+fhip_status fhip_profile_read_kernels(fhip_ctx* ctx, double ms[8], uint32_t launches[8]);
 /* Device-side counters of the last render: arena ops used (peak), arena overflows, leaves */
 fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
 
