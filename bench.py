@@ -18,8 +18,9 @@ Prints ONE JSON line on rank 0, including
   roofline     — for the dominant kernel (fh_tiles, the assembly tile-stage interpreter; a second
                  object covers fh_columns, the leaf interpreter): algorithmic
                  bytes (8 B per tape word per wavefront pass, exact because pruning
-                 is deterministic; taken from the oracle's counters) / kernel time measured
-                 with HIP events on the render stream, vs the 8 TB/s HBM peak;
+                 is deterministic; taken from the oracle's / the device's counters) / the kernel's
+                 launches, each between its own pair of HIP events on the stream it is launched
+                 on (three extra, un-pipelined frames after the timed loop), vs the 8 TB/s HBM peak;
   cpu_baseline — the C++ oracle (restatement of the reference's VmShape path, OpenMP over
                  root tiles like render_tiles' rayon pool) on this box's host cores, same frame.
 """
