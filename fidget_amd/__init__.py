@@ -25,7 +25,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
 _SOURCES = ["capi.hip", "kernels.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
-            "gen_interp.py", "offsets.cpp"]
+            "gen_interp.py", "gen_tiles.py", "gen_prune.py", "offsets.cpp", "../../include/fidget_hip.h",
+            "../../include/fidget_hip_debug.h"]
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
          "asin", "acos", "atan", "exp", "ln", "not", "rand"]          # context/op.rs:11-30
@@ -51,7 +52,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -140,6 +141,7 @@ def lib():
             "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
             "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]), "fhip_debug_probe": (i32, [vp, vp]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
+            "fhip_debug_groups": (u32, [vp, i32, u32, vp, u32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
             "fhip_graph_unary": (u32, [vp, i32, u32]), "fhip_graph_binary": (u32, [vp, i32, u32, u32]),
@@ -220,6 +222,17 @@ class HipContext:
         buf = np.zeros(cap, dt)
         n = lib().fhip_debug_leaves(self._h, _p(buf), cap)
         return buf[:n]
+
+    def groups(self, kind, index, cap=1 << 20):
+        """Work-queue entries the last 3D frame left behind (kind 0: tile level `index`; 1: parked z-slab `index`):
+        (structured array (off, len, regs, choices, x, y, z, ...), (n_small_layout, n_other))."""
+        dt = np.dtype([("off", np.uint32), ("len", np.uint32), ("regs", np.uint16), ("choices", np.uint16),
+                       ("x", np.uint32), ("y", np.uint32), ("z", np.uint32), ("first", np.uint32), ("n", np.uint32), ("stride", np.uint32)])
+        assert dt.itemsize == 36  # sizeof(FhGroup)
+        buf = np.zeros(cap, dt)
+        cnt = np.zeros(2, np.uint32)
+        n = lib().fhip_debug_groups(self._h, kind, index, _p(buf), cap, _p(cnt))
+        return buf[:n], (int(cnt[0]), int(cnt[1]))
 
     def arena_ops(self, off, n):
         """`n` device-format ops of the tape arena from op `off` (diagnostics; see last_leaves)."""

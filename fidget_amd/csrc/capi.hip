@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/fidget_hip.h"
+#include "../../include/fidget_hip_debug.h"
 #include "host_graph.hpp"
 #include "kernels.hip"
 
@@ -1187,6 +1188,29 @@ uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap) {
     const uint32_t n = std::min(std::min(ctx->last_state.n_leaves, ctx->last_state.leaf_cap), cap);
     if (hipMemcpy(out, ctx->last_state.leaves, (size_t)n * sizeof(FhLeaf), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
+}
+
+// Diagnostics: the work-queue entries (36-byte FhGroup records) the last 3D frame left behind: kind 0 = queue of
+// tile level `index`, kind 1 = parked queue of z-slab `index`.  counts[0] = entries of the small-layout half (written
+// first), counts[1] = of the other half.  Returns the number of records written.
+uint32_t fhip_debug_groups(fhip_ctx* ctx, int kind, uint32_t index, void* out, uint32_t cap, uint32_t counts[2]) {
+    counts[0] = counts[1] = 0;
+    if (finish_render(ctx) != FHIP_OK) return 0;
+    const FhRenderState& S = ctx->last_state;
+    const FhGroup* base; uint32_t ns, nb, qcap;
+    if (kind == 0) {
+        if (index >= FH_MAX_LEVELS || !S.queue[index]) return 0;
+        base = S.queue[index]; ns = S.count[index]; nb = S.count_big[index]; qcap = S.qcap[index];
+    } else {
+        if (index >= FH_MAX_SLABS || !S.squeue) return 0;
+        base = S.squeue + (size_t)index * S.squeue_cap; ns = S.scount[index]; nb = S.scount_big[index]; qcap = S.squeue_cap;
+    }
+    ns = std::min(ns, qcap); nb = std::min(nb, qcap - ns);
+    const uint32_t n0 = std::min(ns, cap), n1 = std::min(nb, cap - n0);
+    if (n0 && hipMemcpy(out, base, (size_t)n0 * sizeof(FhGroup), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (n1 && hipMemcpy((FhGroup*)out + n0, base + (qcap - nb), (size_t)n1 * sizeof(FhGroup), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    counts[0] = n0; counts[1] = n1;
+    return n0 + n1;
 }
 
 // Diagnostics: the ISA probe kernel (gen_interp.py gen_probe): 9 rows of 64 floats

@@ -15,7 +15,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FH_HD __host__ __device__
 #else
 #define FH_HD

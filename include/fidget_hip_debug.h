@@ -1,0 +1,33 @@
+/* fidget_hip_debug.h - diagnostics of libfidget_hip.so (NOT part of the drop-in surface of fidget_hip.h).
+ * Used by tests/ and tools/ only: wave statistics, dumps of the device arena and queues, micro-benchmarks. */
+#ifndef FIDGET_HIP_DEBUG_H
+#define FIDGET_HIP_DEBUG_H
+#include "fidget_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Wave busy-time statistics of the last render, 4 words per kernel kind (3D tile levels 0-4,
+ * columns class 0, columns classes 1-2, 2D tiles): sum and max of per-wave busy ticks
+ * (100 MHz), waves that found work, work units; then per 3D tile level: [32+l] ticks in the
+ * forward interval pass, [40+l] ticks in classify + prune, [48+l] tape ops evaluated, [56+l] ops of pruned tapes written. */
+fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
+/* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
+ * last slab of the last 3D frame; returns their number. */
+uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
+fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_interp.py gen_probe), 9 x 64 floats */
+uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out);  /* ops of the tape arena after a frame */
+/* Times `reps` passes of the point interpreter over `tape` in `n_waves` waves
+ * (variant 0: 16 registers x 4 voxels, 1: 32 x 2, 2: LDS register file, 3: 32 x 1). */
+fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_waves, uint32_t reps, int variant,
+                             double* ms);
+
+/* Work-queue entries (36-byte FhGroup records: tape offset, length, registers | choices << 16, x, y, z, ...) the
+ * last 3D frame left behind.  kind 0: queue of tile level `index`; kind 1: parked queue of z-slab `index`.
+ * counts[0] = entries whose tape fits the small register-file layout (written first), counts[1] = the others. */
+uint32_t fhip_debug_groups(fhip_ctx* ctx, int kind, uint32_t index, void* out, uint32_t cap, uint32_t counts[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

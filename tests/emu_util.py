@@ -1,0 +1,390 @@
+"""Harness for running the assembled gfx950 kernels on the CPU emulator (tools/gfx950_emu.py) and numpy
+restatements of what they compute, on the device tape format (tape_format.h).
+
+TEST INFRASTRUCTURE ONLY.  The numpy evaluators follow fidget_amd/csrc/dev_ops.hpp (which cites
+fidget-core/src/types/{float,interval}.rs line by line) and kernels.hip prune_sweep (vm/data.rs:123-318)."""
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gfx950_emu as E  # noqa: E402
+
+F32 = np.float32
+U32 = np.uint32
+GEN = os.path.join(ROOT, "fidget_amd", "csrc", "_gen")
+
+OPS = ["OUTPUT", "INPUT", "COPY_REG", "COPY_IMM", "NEG", "ABS", "RECIP", "SQRT", "SQUARE", "FLOOR", "CEIL", "ROUND", "SIN", "COS", "TAN",
+       "ASIN", "ACOS", "ATAN", "EXP", "LN", "NOT", "RAND"]
+BIN = ["ADD", "SUB", "MUL", "DIV", "ATAN2", "COMPARE", "MIX", "MOD", "MIN", "MAX", "AND", "OR"]
+OPS += [b + "_RR" for b in BIN] + [b + "_RI" for b in BIN] + [b + "_IR" for b in ("SUB", "DIV", "ATAN2", "COMPARE", "MIX", "MOD")]
+OPN = {n: i for i, n in enumerate(OPS)}
+
+_prog = None
+
+
+def program():
+    global _prog
+    if _prog is None:
+        import fidget_amd
+        fidget_amd.build()
+        _prog = E.Program(os.path.join(GEN, "interp_gfx950.co"))
+    return _prog
+
+
+def offsets():
+    return json.load(open(os.path.join(GEN, "offsets.json")))
+
+
+def f2u(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def u2f(x):
+    return struct.unpack("<f", struct.pack("<I", x & 0xFFFFFFFF))[0]
+
+
+def decode(w):
+    w = int(w)
+    w0, w1 = w & 0xFFFFFFFF, w >> 32
+    return w0 & 0xFF, (w0 >> 8) & 0xFFF, w0 >> 20, w1
+
+
+def pack(op, out=0, a=0, w1=0):
+    return (op | (out << 8) | (a << 20)) | (w1 << 32)
+
+
+def is_choice(op):
+    return 30 <= op <= 33 or 42 <= op <= 45
+
+
+def is_rr(op):
+    return 22 <= op <= 33
+
+
+def split(op):
+    """(base index 0..11 or None, form)"""
+    if op >= 46:
+        return [1, 3, 4, 5, 6, 7][op - 46], "IR"
+    if op >= 34:
+        return op - 34, "RI"
+    if op >= 22:
+        return op - 22, "RR"
+    return None, None
+
+
+# ---- f32 ----------------------------------------------------------------------------------------
+def _round(x):
+    t = np.trunc(x)
+    d = x - t
+    return (t + np.copysign((np.abs(d) >= 0.5).astype(F32), x)).astype(F32)
+
+
+def _f_compare(a, b):
+    with np.errstate(all="ignore"):
+        return np.where(a < b, F32(-1), np.where(a == b, F32(0), np.where(a > b, F32(1), F32(np.nan)))).astype(F32)
+
+
+def ref_f32(tape, inputs, n):
+    """inputs: slot -> array[n]; returns {output slot: array}"""
+    regs = {}
+    out = {}
+    qn = F32(np.nan)
+    with np.errstate(all="ignore"):
+        for w in tape:
+            op, ro, ra, w1 = decode(w)
+            imm = F32(u2f(w1))
+            name = OPS[op]
+            if name == "OUTPUT":
+                out[w1] = regs[ra].copy()
+                continue
+            if name == "INPUT":
+                regs[ro] = np.asarray(inputs[w1], F32).copy()
+                continue
+            if name == "COPY_REG":
+                regs[ro] = regs[ra].copy()
+                continue
+            if name == "COPY_IMM":
+                regs[ro] = np.full(n, imm, F32)
+                continue
+            base, form = split(op)
+            if base is None:
+                a = regs[ra]
+                r = {"NEG": lambda: -a, "ABS": lambda: np.abs(a), "RECIP": lambda: F32(1) / a, "SQRT": lambda: np.sqrt(a),
+                     "SQUARE": lambda: a * a, "FLOOR": lambda: np.floor(a), "CEIL": lambda: np.ceil(a), "ROUND": lambda: _round(a),
+                     "NOT": lambda: (a == 0).astype(F32)}[name]()
+                regs[ro] = r.astype(F32)
+                continue
+            if form == "RR":
+                a, b = regs[ra], regs[w1]
+            elif form == "RI":
+                a, b = regs[ra], np.full(n, imm, F32)
+            else:
+                a, b = np.full(n, imm, F32), regs[ra]
+            bn = BIN[base]
+            un = np.isnan(a) | np.isnan(b)
+            if bn == "ADD":
+                r = a + b
+            elif bn == "SUB":
+                r = a - b
+            elif bn == "MUL":
+                r = a * b
+            elif bn == "DIV":
+                r = a / b
+            elif bn == "COMPARE":
+                r = _f_compare(a, b)
+            elif bn == "MIN":
+                r = np.where(a < b, a, np.where(b < a, b, np.where(un, qn, b)))
+            elif bn == "MAX":
+                r = np.where(a > b, a, np.where(b > a, b, np.where(un, qn, b)))
+            elif bn == "AND":
+                r = np.where(a == 0, a, b)
+            elif bn == "OR":
+                r = np.where(a != 0, a, b)
+            else:
+                raise NotImplementedError(bn)
+            regs[ro] = r.astype(F32)
+    return out
+
+
+# ---- intervals -----------------------------------------------------------------------------------
+def _rmin(a, b):
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.minimum(a, b))).astype(F32)
+
+
+def _rmax(a, b):
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.maximum(a, b))).astype(F32)
+
+
+def _nan(lo, hi):
+    return np.isnan(lo) | np.isnan(hi)
+
+
+def ref_interval(tape, inputs, n):
+    """inputs: slot -> (lo[n], hi[n]).  Returns (result lo, hi, choices [n_choice_ops][n] u8, {slot: (lo, hi)} of all outputs)."""
+    regs = {}
+    res = (np.full(n, np.nan, F32), np.full(n, np.nan, F32))
+    outs = {}
+    choices = []
+    NAN = F32(np.nan)
+    with np.errstate(all="ignore"):
+        for w in tape:
+            op, ro, ra, w1 = decode(w)
+            imm = F32(u2f(w1))
+            name = OPS[op]
+            if name == "OUTPUT":
+                res = (regs[ra][0].copy(), regs[ra][1].copy())
+                outs[w1] = res
+                continue
+            if name == "INPUT":
+                lo, hi = inputs[w1]
+                regs[ro] = (np.asarray(lo, F32).copy(), np.asarray(hi, F32).copy())
+                continue
+            if name == "COPY_REG":
+                regs[ro] = (regs[ra][0].copy(), regs[ra][1].copy())
+                continue
+            if name == "COPY_IMM":
+                regs[ro] = (np.full(n, imm, F32), np.full(n, imm, F32))
+                continue
+            base, form = split(op)
+            if base is None:
+                al, ah = regs[ra]
+                if name == "NEG":
+                    r = (-ah, -al)
+                elif name == "ABS":
+                    neg, pos = al < 0, ah > 0
+                    r = (np.where(neg, np.where(pos, F32(0), -ah), al), np.where(neg, np.where(pos, _rmax(ah, -al), -al), ah))
+                elif name == "RECIP":
+                    ok = (al > 0) | (ah < 0)
+                    r = (np.where(ok, F32(1) / ah, NAN), np.where(ok, F32(1) / al, NAN))
+                elif name == "SQRT":
+                    bad = al < 0
+                    r = (np.where(bad, NAN, np.sqrt(al)), np.where(bad, NAN, np.sqrt(ah)))
+                elif name == "SQUARE":
+                    m = _rmax(np.abs(al), np.abs(ah))
+                    lo = np.where(ah < 0, ah * ah, np.where(al > 0, al * al, np.where(_nan(al, ah), NAN, F32(0))))
+                    hi = np.where(ah < 0, al * al, np.where(al > 0, ah * ah, np.where(_nan(al, ah), NAN, m * m)))
+                    r = (lo, hi)
+                elif name in ("FLOOR", "CEIL", "ROUND"):
+                    f = {"FLOOR": np.floor, "CEIL": np.ceil, "ROUND": _round}[name]
+                    r = (f(al), f(ah))
+                elif name == "NOT":
+                    contains = (al <= 0) & (ah >= 0)
+                    zero = (al == 0) & (ah == 0)
+                    first = ~contains & ~_nan(al, ah)
+                    r = (np.where(first, F32(0), np.where(zero, F32(1), F32(0))), np.where(first, F32(0), F32(1)))
+                else:
+                    raise NotImplementedError(name)
+                regs[ro] = (r[0].astype(F32), r[1].astype(F32))
+                continue
+            if form == "RR":
+                (al, ah), (bl, bh) = regs[ra], regs[w1]
+            elif form == "RI":
+                (al, ah), (bl, bh) = regs[ra], (np.full(n, imm, F32), np.full(n, imm, F32))
+            else:
+                (al, ah), (bl, bh) = (np.full(n, imm, F32), np.full(n, imm, F32)), regs[ra]
+            bn = BIN[base]
+            nn = _nan(al, ah) | _nan(bl, bh)
+            c = None
+            if bn == "ADD":
+                r = (al + bl, ah + bh)
+            elif bn == "SUB":
+                r = (al - bh, ah - bl)
+            elif bn == "MUL" and form == "RI":
+                neg = imm < 0
+                bad = _nan(al, ah) | np.isnan(imm)
+                r = (np.where(bad, NAN, ah * imm if neg else al * imm), np.where(bad, NAN, al * imm if neg else ah * imm))
+            elif bn == "MUL":
+                p = [al * bl, al * bh, ah * bl, ah * bh]
+                lo = _rmin(_rmin(_rmin(p[0], p[1]), p[2]), p[3])
+                hi = _rmax(_rmax(_rmax(p[0], p[1]), p[2]), p[3])
+                r = (np.where(nn, NAN, lo), np.where(nn, NAN, hi))
+            elif bn == "DIV":
+                ok = ((bl > 0) | (bh < 0)) & ~_nan(al, ah)
+                q = [al / bl, al / bh, ah / bl, ah / bh]
+                lo = _rmin(_rmin(_rmin(q[0], q[1]), q[2]), q[3])
+                hi = _rmax(_rmax(_rmax(q[0], q[1]), q[2]), q[3])
+                r = (np.where(ok, lo, NAN), np.where(ok, hi, NAN))
+            elif bn == "COMPARE":
+                less, greater = ah < bl, al > bh
+                eq = (al == ah) & (bl == bh) & (al == bl)
+                lo = np.where(nn, NAN, np.where(less, F32(-1), np.where(greater, F32(1), np.where(eq, F32(0), F32(-1)))))
+                hi = np.where(nn, NAN, np.where(less, F32(-1), np.where(greater, F32(1), np.where(eq, F32(0), F32(1)))))
+                r = (lo, hi)
+            elif bn == "MIN":
+                c = np.where(nn, 3, np.where(ah < bl, 1, np.where(bh < al, 2, 3)))
+                r = (np.where(nn, NAN, _rmin(al, bl)), np.where(nn, NAN, _rmin(ah, bh)))
+            elif bn == "MAX":
+                c = np.where(nn, 3, np.where(al > bh, 1, np.where(bl > ah, 2, 3)))
+                r = (np.where(nn, NAN, _rmax(al, bl)), np.where(nn, NAN, _rmax(ah, bh)))
+            elif bn == "AND":
+                zero = (al == 0) & (ah == 0)
+                contains = (al <= 0) & (ah >= 0)
+                c = np.where(nn, 3, np.where(zero, 1, np.where(~contains, 2, 3)))
+                lo = np.where(nn, NAN, np.where(zero, F32(0), np.where(~contains, bl, _rmin(bl, F32(0)))))
+                hi = np.where(nn, NAN, np.where(zero, F32(0), np.where(~contains, bh, _rmax(bh, F32(0)))))
+                r = (lo, hi)
+            elif bn == "OR":
+                zero = (al == 0) & (ah == 0)
+                contains = (al <= 0) & (ah >= 0)
+                c = np.where(nn, 3, np.where(~contains, 1, np.where(zero, 2, 3)))
+                lo = np.where(nn, NAN, np.where(~contains, al, np.where(zero, bl, _rmin(al, bl))))
+                hi = np.where(nn, NAN, np.where(~contains, ah, np.where(zero, bh, _rmax(ah, bh))))
+                r = (lo, hi)
+            else:
+                raise NotImplementedError(bn)
+            regs[ro] = (np.asarray(r[0], F32), np.asarray(r[1], F32))
+            if c is not None:
+                choices.append(np.asarray(c, np.uint8))
+    ch = np.array(choices, dtype=np.uint8).reshape(len(choices), n)
+    return res[0], res[1], ch, outs
+
+
+# ---- prune (kernels.hip prune_sweep<true>) -----------------------------------------------------------
+def ref_prune(tape, choices):
+    """choices: one value per choice op, evaluation order.  Returns (ops list, n_regs, kept choices)."""
+    DEAD = -1
+    m = {}
+    free = []          # pool: lowest free first
+    high = [0]
+    used = set()
+
+    def take():
+        r = 0
+        while r in used:
+            r += 1
+        used.add(r)
+        high[0] = max(high[0], r + 1)
+        return r
+
+    def give(r):
+        used.discard(r)
+
+    def use(r):
+        if m.get(r, DEAD) == DEAD:
+            m[r] = take()
+        return m[r]
+
+    rev = []
+    ci = len(choices)
+    kept = 0
+    for w in reversed(list(tape)):
+        op, ro, ra, w1 = decode(w)
+        c = 3
+        if is_choice(op):
+            ci -= 1
+            c = int(choices[ci])
+        if op == 0:
+            rev.append(pack(0, 0, use(ra), w1))
+            continue
+        no = m.get(ro, DEAD)
+        if no == DEAD:
+            continue
+        m[ro] = DEAD
+        alias, copy_imm = None, False
+        if op == 2:
+            alias = ra
+        elif is_choice(op) and c == 1:
+            alias = ra
+        elif is_choice(op) and c == 2:
+            if is_rr(op):
+                alias = w1
+            else:
+                copy_imm = True
+        if alias is not None:
+            if m.get(alias, DEAD) == DEAD:
+                m[alias] = no
+                continue
+            give(no)
+            rev.append(pack(2, no, m[alias], 0))
+            continue
+        give(no)
+        if copy_imm:
+            rev.append(pack(3, no, 0, w1))
+            continue
+        na = nb = 0
+        if op not in (1, 3):
+            na = use(ra)
+        if is_rr(op):
+            nb = use(w1)
+        if is_choice(op):
+            kept += 1
+        rev.append(pack(op, no, na, nb if is_rr(op) else w1))
+    return rev[::-1], high[0], kept
+
+
+# ---- device state in emulator memory -------------------------------------------------------------------
+class Blob:
+    """a zeroed struct image with typed pokes at byte offsets"""
+
+    def __init__(self, size):
+        self.b = np.zeros(size, dtype=np.uint8)
+
+    def u32(self, off, v):
+        self.b[off:off + 4] = np.frombuffer(struct.pack("<I", int(v) & 0xFFFFFFFF), np.uint8)
+
+    def u64(self, off, v):
+        self.b[off:off + 8] = np.frombuffer(struct.pack("<Q", int(v)), np.uint8)
+
+    def f32(self, off, v):
+        self.b[off:off + 4] = np.frombuffer(struct.pack("<f", float(v)), np.uint8)
+
+    def arr(self, off, a):
+        a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        self.b[off:off + len(a)] = a
+
+    def get_u32(self, off, n=1):
+        return self.b[off:off + 4 * n].view(U32).copy()
+
+
+def shape_tape(shape):
+    """device-format ops (uint64 array) of a fidget_amd.Shape (host only, no GPU)"""
+    import fidget_amd as F
+    n = shape.size()
+    w = np.zeros(max(n, 1), dtype=np.uint64)
+    F.lib().fhip_tape_ops(shape._h, w.ctypes.data_as(F.C.c_void_p), n)
+    return w[:n]

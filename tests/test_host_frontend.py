@@ -26,7 +26,7 @@ MODELS = ["prospero.vm", "hi.vm", "bear.vm", "colonnade.vm", "quarter.vm", "tang
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "fidget_hip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "fidget_hip.h")).read() + open(os.path.join(ROOT, "include", "fidget_hip_debug.h")).read()
     declared = sorted(set(re.findall(r"\b(fhip_\w+)\s*\(", hdr)) - {"fhip_status"})
     assert len(declared) >= 35
     lib = ctypes.CDLL(F.LIB_PATH)
