@@ -24,8 +24,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "kernels.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
-            "gen_interp.py", "gen_tiles.py", "gen_prune.py", "offsets.cpp", "../../include/fidget_hip.h",
+_SOURCES = ["capi.hip", "kernels.hip", "effects.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
+            "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
@@ -48,11 +48,11 @@ EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
-    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -133,6 +133,11 @@ def lib():
             "fhip_render2d": (i32, [vp, vp, C.POINTER(_Cfg2D), vp, i32]),
             "fhip_render3d": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32]),
             "fhip_render3d_shard": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, u32]),
+            "fhip_denoise_normals": (i32, [vp, vp, u32, u32, vp, i32]),
+            "fhip_compute_ssao": (i32, [vp, vp, u32, u32, u32, vp, u32, vp, u32, vp, i32]),
+            "fhip_blur_ssao": (i32, [vp, vp, u32, u32, vp, i32]),
+            "fhip_apply_shading": (i32, [vp, vp, u32, u32, u32, vp, vp, i32]),
+            "fhip_to_rgba": (i32, [vp, vp, u32, u32, i32, vp, i32]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
@@ -142,6 +147,7 @@ def lib():
             "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]), "fhip_debug_probe": (i32, [vp, vp]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_debug_groups": (u32, [vp, i32, u32, vp, u32, vp]),
+            "fhip_debug_ubench": (i32, [vp, u32, u32, u32, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
             "fhip_graph_unary": (u32, [vp, i32, u32]), "fhip_graph_binary": (u32, [vp, i32, u32, u32]),
@@ -206,7 +212,7 @@ class HipContext:
         ms = np.zeros(8, np.float64)
         n = np.zeros(8, np.uint32)
         self.check(lib().fhip_profile_read_kernels(self._h, _p(ms), _p(n)))
-        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1"]
+        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_tiles_v32", "fh_tiles_v64"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def counters(self):
@@ -246,6 +252,8 @@ class HipContext:
         c = np.zeros(64, np.uint64)
         self.check(lib().fhip_debug_stats(self._h, _p(c)))
         names = ["tiles_l0", "tiles_l1", "tiles_l2", "tiles_l3", "tiles_l4", "columns_c0", "columns_c12", "tiles_2d"]
+        self.tile_v = {f"l{l}": {"slots": int(c[8 + l]), "fwd_clocks": int(c[16 + l]), "prune_clocks": int(c[24 + l]), "max_slot_clocks": int(c[l])}
+                       for l in range(8) if c[8 + l]}
         self.tile_phases = {f"l{l}": {"fwd_us": int(c[32 + l]) / 100.0, "prune_us": int(c[40 + l]) / 100.0,
                                       "ops": int(c[48 + l]), "ops_written": int(c[56 + l]), "fwd_shader_clocks": int(c[16 + l])} for l in range(8) if c[48 + l]}
         return {k: {"busy_us_sum": int(c[4 * i]) / 100.0, "busy_us_max": int(c[4 * i + 1]) / 100.0,
@@ -729,3 +737,60 @@ def pixel_fill_depth(img):
     bits = img.view(np.uint32)
     is_fill = np.isnan(img) & ((bits & (0xFF << 9)) == (0xF6 << 9))
     return np.where(is_fill, ((bits >> 1) & 0xFF).astype(np.int32), -1)
+
+
+# ---- fidget_raster::effects (fidget-raster/src/effects.rs), host arrays in / out -----------------------
+def denoise_normals(image, hip=None):
+    hip = hip or default_context()
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    out = np.zeros_like(image)
+    hip.check(lib().fhip_denoise_normals(hip._h, _p(image), image.shape[1], image.shape[0], _p(out), 0))
+    return out
+
+
+def compute_ssao(image, depth, kernel, noise, hip=None):
+    """kernel: 3 x n, noise: 2 x m (the matrices effects::ssao_kernel / ssao_noise return)"""
+    hip = hip or default_context()
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    k = np.ascontiguousarray(np.asarray(kernel, np.float32).T)
+    nz = np.ascontiguousarray(np.asarray(noise, np.float32).T)
+    out = np.zeros(image.shape, np.float32)
+    hip.check(lib().fhip_compute_ssao(hip._h, _p(image), image.shape[1], image.shape[0], depth, _p(k), len(k), _p(nz), len(nz), _p(out), 0))
+    return out
+
+
+def blur_ssao(ssao, hip=None):
+    hip = hip or default_context()
+    ssao = np.ascontiguousarray(ssao, np.float32)
+    out = np.zeros_like(ssao)
+    hip.check(lib().fhip_blur_ssao(hip._h, _p(ssao), ssao.shape[1], ssao.shape[0], _p(out), 0))
+    return out
+
+
+def apply_shading(image, depth, ssao=None, hip=None):
+    hip = hip or default_context()
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    s = None if ssao is None else np.ascontiguousarray(ssao, np.float32)
+    out = np.zeros(image.shape + (3,), np.uint8)
+    hip.check(lib().fhip_apply_shading(hip._h, _p(image), image.shape[1], image.shape[0], depth, _p(s), _p(out), 0))
+    return out
+
+
+def _to_rgba(image, mode, hip=None):
+    hip = hip or default_context()
+    image = np.ascontiguousarray(image, np.float32)
+    out = np.zeros(image.shape + (4,), np.uint8)
+    hip.check(lib().fhip_to_rgba(hip._h, _p(image), image.shape[1], image.shape[0], mode, _p(out), 0))
+    return out
+
+
+def to_rgba_bitmap(image, transparent=False, hip=None):
+    return _to_rgba(image, 1 if transparent else 0, hip)
+
+
+def to_debug_bitmap(image, hip=None):
+    return _to_rgba(image, 2, hip)
+
+
+def to_rgba_distance(image, hip=None):
+    return _to_rgba(image, 3, hip)

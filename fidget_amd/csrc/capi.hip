@@ -14,6 +14,7 @@
 #include "../../include/fidget_hip_debug.h"
 #include "host_graph.hpp"
 #include "kernels.hip"
+#include "effects.hip"
 
 #define FH_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
 
@@ -57,8 +58,11 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_PROBE, FH_ASM_COUNT };
-static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_probe"};
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench"};
+// register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
+static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
 struct fhip_ctx {
     hipModule_t asm_mod = nullptr;
@@ -890,21 +894,39 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // their launches run side by side (second stream) instead of one after the other.
             const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && ctx->stream2 &&
                               ctx->stream != ctx->stream2 && !getenv("FHIP_PIPE_SERIAL");
+            // Tapes of <= 32 registers / 256 choices (the small slot list: every parent of the leaf level) and, from the other
+            // list, those of <= 64 / 512 go to the kernels that keep the interval file, the choices and the prune's register
+            // map in VGPRs (fh_tiles_v32: 16 waves per CU, fh_tiles_v64: 8; no LDS); what is left takes the LDS layouts.
+            static const bool use_v = !getenv("FHIP_NO_TILES_V");
+            const bool vk = use_v && !exp;
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 if (side) {
                     (void)hipEventRecord(ctx->ev_fork, ctx->stream);
                     (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
                 }
-                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small, 1, side ? ctx->stream2 : nullptr);
+                if (vk) {
+                    static const int v32_waves = getenv("FHIP_V32_WAVES") ? atoi(getenv("FHIP_V32_WAVES")) : 16;
+                    ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
+                    (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka), 0, 1, side ? ctx->stream2 : nullptr);
+                } else
+                    (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small, 1, side ? ctx->stream2 : nullptr);
                 if (side) (void)hipEventRecord(ctx->ev_tiles[0], ctx->stream2);
             }
             ka.big = 1;
             if (exp) ka.flags |= ((R.S.P.max_choices + 15) / 16) << 16;  // one stride in chw[1] for the medium and the large layout
+            bool rest = true;   // anything left for the root-sized LDS layout?
+            if (vk && level > 0) {
+                static const int v64_waves = getenv("FHIP_V64_WAVES") ? atoi(getenv("FHIP_V64_WAVES")) : 8;
+                ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES; ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v64_waves);
+                (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka));
+                ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
+                rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
+            }
             // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
             // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
             // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
-            const bool mid = level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !getenv("FHIP_NO_MID");
+            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !getenv("FHIP_NO_MID");
             if (mid) {
                 const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
@@ -912,7 +934,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
             }
             ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
-            (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
+            if (rest) (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
             if (side) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_tiles[0], 0);
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
@@ -1145,6 +1167,98 @@ fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     return fhip_render3d_shard(ctx, tape, cfg, out, out_is_device, 0, 1);
 }
 
+// ---- effects (fidget-raster/src/effects.rs) ---------------------------------------------------
+// Inputs and outputs are device pointers when `on_device` != 0 (asynchronous on the context's stream: the
+// usual case, the image was just rendered there); otherwise host buffers, staged through the context.
+struct FxStage {
+    fhip_ctx* ctx;
+    int on_device;
+    std::vector<std::pair<void*, std::pair<void*, size_t>>> outs;   // host ptr <- device ptr, bytes
+    const void* in(DevBuf& b, const void* host, size_t bytes, hipError_t& e) {
+        if (on_device || !host) return host;
+        if ((e = b.ensure(bytes)) != hipSuccess) return nullptr;
+        e = hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        return b.p;
+    }
+    void* out(DevBuf& b, void* host, size_t bytes, hipError_t& e) {
+        if (on_device) return host;
+        if ((e = b.ensure(bytes)) != hipSuccess) return nullptr;
+        outs.push_back({host, {b.p, bytes}});
+        return b.p;
+    }
+    fhip_status finish() {
+        HIP_TRY(ctx, hipGetLastError());
+        for (auto& o : outs) HIP_TRY(ctx, hipMemcpyAsync(o.first, o.second.first, o.second.second, hipMemcpyDeviceToHost, ctx->stream));
+        if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return FHIP_OK;
+    }
+};
+static dim3 fx_grid(uint32_t w, uint32_t h) { return dim3((w + 15) / 16, (h + 15) / 16); }
+
+fhip_status fhip_denoise_normals(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, void* out, int on_device) {
+    if (!width || !height) return FHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    FxStage st{ctx, on_device, {}};
+    hipError_t e = hipSuccess;
+    const size_t bytes = (size_t)width * height * sizeof(FhGeometryPixel);
+    const void* di = st.in(ctx->io_a, image, bytes, e); HIP_TRY(ctx, e);
+    void* dout = st.out(ctx->io_b, out, bytes, e); HIP_TRY(ctx, e);
+    hipLaunchKernelGGL(fhfx::k_fx_denoise, fx_grid(width, height), dim3(16, 16), 0, ctx->stream, (const FhGeometryPixel*)di, (int)width, (int)height,
+                       (FhGeometryPixel*)dout);
+    return st.finish();
+}
+fhip_status fhip_compute_ssao(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t depth, const float* kernel,
+                              uint32_t n_kernel, const float* noise, uint32_t n_noise, float* out, int on_device) {
+    if (!width || !height) return FHIP_OK;
+    if (!n_kernel || !n_noise || !depth) return fail(ctx, FHIP_ERR_UNSUPPORTED, "empty SSAO kernel / noise or zero depth");
+    (void)hipSetDevice(ctx->device);
+    FxStage st{ctx, on_device, {}};
+    hipError_t e = hipSuccess;
+    const void* di = st.in(ctx->io_a, image, (size_t)width * height * sizeof(FhGeometryPixel), e); HIP_TRY(ctx, e);
+    const void* dk = st.in(ctx->io_c, kernel, (size_t)n_kernel * 12, e); HIP_TRY(ctx, e);
+    const void* dn = st.in(ctx->io_d, noise, (size_t)n_noise * 8, e); HIP_TRY(ctx, e);
+    void* dout = st.out(ctx->io_b, out, (size_t)width * height * 4, e); HIP_TRY(ctx, e);
+    hipLaunchKernelGGL(fhfx::k_fx_ssao, fx_grid(width, height), dim3(16, 16), 0, ctx->stream, (const FhGeometryPixel*)di, (int)width, (int)height,
+                       (int)depth, (const float*)dk, (int)n_kernel, (const float*)dn, (int)n_noise, (float*)dout);
+    return st.finish();
+}
+fhip_status fhip_blur_ssao(fhip_ctx* ctx, const float* ssao, uint32_t width, uint32_t height, float* out, int on_device) {
+    if (!width || !height) return FHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    FxStage st{ctx, on_device, {}};
+    hipError_t e = hipSuccess;
+    const void* di = st.in(ctx->io_a, ssao, (size_t)width * height * 4, e); HIP_TRY(ctx, e);
+    void* dout = st.out(ctx->io_b, out, (size_t)width * height * 4, e); HIP_TRY(ctx, e);
+    hipLaunchKernelGGL(fhfx::k_fx_blur, fx_grid(width, height), dim3(16, 16), 0, ctx->stream, (const float*)di, (int)width, (int)height, (float*)dout);
+    return st.finish();
+}
+fhip_status fhip_apply_shading(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t depth, const float* ssao,
+                               uint8_t* out_rgb, int on_device) {
+    if (!width || !height) return FHIP_OK;
+    if (!depth) return fail(ctx, FHIP_ERR_UNSUPPORTED, "zero depth");
+    (void)hipSetDevice(ctx->device);
+    FxStage st{ctx, on_device, {}};
+    hipError_t e = hipSuccess;
+    const void* di = st.in(ctx->io_a, image, (size_t)width * height * sizeof(FhGeometryPixel), e); HIP_TRY(ctx, e);
+    const void* ds = st.in(ctx->io_c, ssao, (size_t)width * height * 4, e); HIP_TRY(ctx, e);
+    void* dout = st.out(ctx->io_b, out_rgb, (size_t)width * height * 3, e); HIP_TRY(ctx, e);
+    hipLaunchKernelGGL(fhfx::k_fx_shade, fx_grid(width, height), dim3(16, 16), 0, ctx->stream, (const FhGeometryPixel*)di, (int)width, (int)height,
+                       (int)depth, (const float*)ds, (uint8_t*)dout);
+    return st.finish();
+}
+fhip_status fhip_to_rgba(fhip_ctx* ctx, const float* image, uint32_t width, uint32_t height, int mode, uint8_t* out_rgba, int on_device) {
+    if (mode < 0 || mode > 3) return fail(ctx, FHIP_ERR_UNSUPPORTED, "colour map 0..3");
+    const size_t n = (size_t)width * height;
+    if (!n) return FHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    FxStage st{ctx, on_device, {}};
+    hipError_t e = hipSuccess;
+    const void* di = st.in(ctx->io_a, image, n * 4, e); HIP_TRY(ctx, e);
+    void* dout = st.out(ctx->io_b, out_rgba, n * 4, e); HIP_TRY(ctx, e);
+    hipLaunchKernelGGL(fhfx::k_fx_rgba, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)di, n, mode, (uchar4*)dout);
+    return st.finish();
+}
+
 // ---- profiling -------------------------------------------------------------------------
 void fhip_profile_enable(fhip_ctx* ctx, int on) { ctx->profiling = on != 0; }
 fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4]) {
@@ -1213,13 +1327,25 @@ uint32_t fhip_debug_groups(fhip_ctx* ctx, int kind, uint32_t index, void* out, u
     return n0 + n1;
 }
 
-// Diagnostics: the ISA probe kernel (gen_interp.py gen_probe): 9 rows of 64 floats
+// Diagnostics: the ISA probe kernel (gen_interp.py gen_probe): 16 rows of 64 floats
 fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out) {
-    HIP_TRY(ctx, ctx->io_a.ensure(9 * 256));
+    HIP_TRY(ctx, ctx->io_a.ensure(16 * 256));
     struct { void* p; } ka = {ctx->io_a.p};
     if (launch_asm(ctx, FH_ASM_PROBE, 1, &ka, sizeof(ka)) != hipSuccess) return FHIP_ERR_HIP;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->io_a.p, 9 * 256, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->io_a.p, 16 * 256, hipMemcpyDeviceToHost));
+    return FHIP_OK;
+}
+
+// Diagnostics: instruction-cost micro-benchmark `test` (gen_ubench.py) on `n_waves` single-wave workgroups; out[w] = shader
+// clocks per pattern for wave w
+fhip_status fhip_debug_ubench(fhip_ctx* ctx, uint32_t test, uint32_t iters, uint32_t n_waves, float* out) {
+    HIP_TRY(ctx, ctx->io_a.ensure((size_t)n_waves * 4));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_a.p, 0, (size_t)n_waves * 4, ctx->stream));
+    struct { void* p; uint32_t test, iters; } ka = {ctx->io_a.p, test, iters};
+    if (launch_asm(ctx, FH_ASM_UBENCH, n_waves, &ka, sizeof(ka), 64) != hipSuccess) return FHIP_ERR_HIP;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->io_a.p, (size_t)n_waves * 4, hipMemcpyDeviceToHost));
     return FHIP_OK;
 }
 

@@ -1052,6 +1052,32 @@ def gen_probe(a):
 	v_pk_mul_f32 v[10:11], v[10:11], s[12:13] op_sel_hi:[1,0]   ; in place on v[12:13] with a broadcast scalar: (12, 24)
 	s_set_gpr_idx_off
 	v_pk_mov_b32 v[36:37], v[12:13], v[12:13] op_sel:[0,1]
+	; does the index mode reach v_readlane_b32?  rows 9 .. 12: (SRC0 relative) 64 = no, 128 = yes; (DST relative) value read,
+	; s17 (stays 0 unless the scalar destination was displaced); v_readfirstlane under SRC0 relative
+	v_mov_b32 v14, 0x42800000
+	v_mov_b32 v16, 0x43000000
+	s_mov_b32 s14, 0
+	s_mov_b32 s15, 0
+	s_mov_b32 s16, 0
+	s_mov_b32 s17, 0
+	s_mov_b32 s18, 0
+	s_mov_b32 s19, 0
+	s_mov_b32 s20, 0
+	s_nop 4
+	s_set_gpr_idx_on s10, {SRC0}
+	v_readlane_b32 s14, v14, 0
+	s_set_gpr_idx_off
+	s_set_gpr_idx_on s10, {DST}
+	v_readlane_b32 s15, v14, 0
+	s_set_gpr_idx_off
+	s_set_gpr_idx_on s10, {SRC0}
+	v_readfirstlane_b32 s18, v14
+	s_set_gpr_idx_off
+	s_nop 4
+	v_mov_b32 v22, s14
+	v_mov_b32 v23, s15
+	v_mov_b32 v24, s17
+	v_mov_b32 v25, s18
 	v_lshlrev_b32 v1, 2, v0
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v1, v30, s[4:5]
@@ -1062,7 +1088,11 @@ def gen_probe(a):
 	global_store_dword v1, v12, s[4:5] offset:1280
 	global_store_dword v1, v13, s[4:5] offset:1536
 	global_store_dword v1, v36, s[4:5] offset:1792
-	global_store_dword v1, v37, s[4:5] offset:2048""")
+	global_store_dword v1, v37, s[4:5] offset:2048
+	global_store_dword v1, v22, s[4:5] offset:2304
+	global_store_dword v1, v23, s[4:5] offset:2560
+	global_store_dword v1, v24, s[4:5] offset:2816
+	global_store_dword v1, v25, s[4:5] offset:3072""")
     kernel_footer(a, name, 8, 40, 24, True)
     return name, 8, 40, [(8, "global_buffer")]
 
@@ -1109,7 +1139,12 @@ def main():
     ks.append(gen_tiles(a, off))
     from gen_prune import gen_prune1
     ks.append(gen_prune1(a, off))
+    from gen_tilesv import gen_tilesv
+    ks.append(gen_tilesv(a, off, 32, 16))
+    ks.append(gen_tilesv(a, off, 64, 32))
     ks.append(gen_probe(a))
+    from gen_ubench import gen_ubench
+    ks.append(gen_ubench(a))
     metadata(a, ks)
     open(sys.argv[2], "w").write(a.text())
 

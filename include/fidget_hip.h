@@ -151,6 +151,26 @@ fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
 fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                 int out_is_device, uint32_t shard, uint32_t n_shards);
 
+/* ---- post-processing: fidget_raster::effects (fidget-raster/src/effects.rs) --------------------
+ * The step right after a render; images are width*height arrays as the renders produce them.  With on_device != 0
+ * every pointer is a device pointer and the call is asynchronous on the context's stream (the image a render just
+ * left in HBM is consumed in place); otherwise host buffers. */
+/* denoise_normals (effects.rs:17-36, denoise_pixel 252-326): GeometryPixel image -> GeometryPixel image */
+fhip_status fhip_denoise_normals(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, void* out, int on_device);
+/* compute_ssao (effects.rs:73-95, compute_pixel_ssao 156-250): out = width*height f32, NaN where depth == 0.  The
+ * reference draws the sampling kernel (3 x n_kernel, ssao_kernel 395-424) and the rotation noise (2 x n_noise,
+ * ssao_noise 430-448) from rand::rng(); here the caller passes them: kernel[i*3 + {0,1,2}], noise[i*2 + {0,1}]. */
+fhip_status fhip_compute_ssao(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t depth, const float* kernel,
+                              uint32_t n_kernel, const float* noise, uint32_t n_noise, float* out, int on_device);
+/* blur_ssao (effects.rs:98-115, compute_pixel_blur 329-392) */
+fhip_status fhip_blur_ssao(fhip_ctx* ctx, const float* ssao, uint32_t width, uint32_t height, float* out, int on_device);
+/* apply_shading (effects.rs:42-67, shade_pixel 118-153): ssao = blurred occlusion map or NULL; out = width*height*3 bytes */
+fhip_status fhip_apply_shading(fhip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t depth, const float* ssao,
+                               uint8_t* out_rgb, int on_device);
+/* RawDistancePixel image -> RGBA8: mode 0 to_rgba_bitmap (effects.rs:443-464), 1 the same with transparent = true,
+ * 2 to_debug_bitmap (467-496), 3 to_rgba_distance (506-547) */
+fhip_status fhip_to_rgba(fhip_ctx* ctx, const float* image, uint32_t width, uint32_t height, int mode, uint8_t* out_rgba, int on_device);
+
 /* ---- profiling ----------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a render is bracketed by HIP events on the context's
  * stream; fhip_profile_read returns per-kernel-class totals of the last render. */

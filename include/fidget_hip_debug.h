@@ -15,13 +15,15 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
 /* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
-fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_interp.py gen_probe), 9 x 64 floats */
+fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_interp.py gen_probe), 16 x 64 floats */
 uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out);  /* ops of the tape arena after a frame */
 /* Times `reps` passes of the point interpreter over `tape` in `n_waves` waves
  * (variant 0: 16 registers x 4 voxels, 1: 32 x 2, 2: LDS register file, 3: 32 x 1). */
 fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_waves, uint32_t reps, int variant,
                              double* ms);
 
+/* Instruction-cost micro-benchmark `test` of fh_ubench (fidget_amd/csrc/gen_ubench.py): shader clocks per pattern, per wave */
+fhip_status fhip_debug_ubench(fhip_ctx* ctx, uint32_t test, uint32_t iters, uint32_t n_waves, float* out);
 /* Work-queue entries (36-byte FhGroup records: tape offset, length, registers | choices << 16, x, y, z, ...) the
  * last 3D frame left behind.  kind 0: queue of tile level `index`; kind 1: parked queue of z-slab `index`.
  * counts[0] = entries whose tape fits the small register-file layout (written first), counts[1] = the others. */

@@ -99,6 +99,13 @@ def lib():
             "orc_render2d": (i32, [vp, vp, u32, u32, f32, i32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_render3d": (i32, [vp, vp, u32, u32, u32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_max_threads": (i32, []),
+            "orc_fx_denoise_normals": (None, [vp, i32, i32, vp]),
+            "orc_fx_compute_ssao": (None, [vp, i32, i32, i32, vp, i32, vp, i32, vp]),
+            "orc_fx_blur_ssao": (None, [vp, i32, i32, vp]),
+            "orc_fx_apply_shading": (None, [vp, i32, i32, i32, vp, vp]),
+            "orc_fx_to_rgba_bitmap": (None, [vp, C.c_uint64, i32, vp]),
+            "orc_fx_to_debug_bitmap": (None, [vp, C.c_uint64, vp]),
+            "orc_fx_to_rgba_distance": (None, [vp, C.c_uint64, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -477,3 +484,57 @@ def pixel_fill_depth(img):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+# ---- fidget_raster::effects (effects.rs) -------------------------------------------------------
+def denoise_normals(image):
+    """effects.rs:17-36: image = GEOMETRY_PIXEL array [h, w]"""
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    out = np.zeros_like(image)
+    lib().orc_fx_denoise_normals(_p(image), image.shape[1], image.shape[0], _p(out))
+    return out
+
+
+def compute_ssao(image, depth, kernel, noise):
+    """effects.rs:73-95 with the kernel (3 x n) and noise (2 x m) matrices given (the reference draws them from rand::rng())"""
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    k = np.ascontiguousarray(np.asarray(kernel, np.float32).T)   # column j = sample j -> [n][3]
+    nz = np.ascontiguousarray(np.asarray(noise, np.float32).T)
+    out = np.zeros(image.shape, np.float32)
+    lib().orc_fx_compute_ssao(_p(image), image.shape[1], image.shape[0], depth, _p(k), len(k), _p(nz), len(nz), _p(out))
+    return out
+
+
+def blur_ssao(ssao):
+    ssao = np.ascontiguousarray(ssao, np.float32)
+    out = np.zeros_like(ssao)
+    lib().orc_fx_blur_ssao(_p(ssao), ssao.shape[1], ssao.shape[0], _p(out))
+    return out
+
+
+def apply_shading(image, depth, ssao=None):
+    """effects.rs:42-67 (ssao = blurred occlusion map or None); returns uint8 [h, w, 3]"""
+    image = np.ascontiguousarray(image, GEOMETRY_PIXEL)
+    s = None if ssao is None else np.ascontiguousarray(ssao, np.float32)
+    out = np.zeros(image.shape + (3,), np.uint8)
+    lib().orc_fx_apply_shading(_p(image), image.shape[1], image.shape[0], depth, _p(s), _p(out))
+    return out
+
+
+def _rgba(fn, image, *args):
+    image = np.ascontiguousarray(image, np.float32)
+    out = np.zeros(image.shape + (4,), np.uint8)
+    fn(_p(image), image.size, *args, _p(out))
+    return out
+
+
+def to_rgba_bitmap(image, transparent=False):
+    return _rgba(lib().orc_fx_to_rgba_bitmap, image, int(transparent))
+
+
+def to_debug_bitmap(image):
+    return _rgba(lib().orc_fx_to_debug_bitmap, image)
+
+
+def to_rgba_distance(image):
+    return _rgba(lib().orc_fx_to_rgba_distance, image)

@@ -5,6 +5,7 @@
 #include <chrono>
 
 #include "render.hpp"
+#include "effects.hpp"
 
 namespace orc {
 thread_local uint64_t g_invalid_intervals = 0;
@@ -271,4 +272,17 @@ int orc_render3d(void* s, const float* world_to_model, uint32_t w, uint32_t h, u
 
 int orc_max_threads() { return omp_get_max_threads(); }
 
+
+// ---- effects (fidget-raster/src/effects.rs) ---------------------------------------------
+void orc_fx_denoise_normals(const void* img, int w, int h, void* out) { fx_denoise_normals((const GeomPx*)img, w, h, (GeomPx*)out); }
+void orc_fx_compute_ssao(const void* img, int w, int h, int d, const float* kernel, int nk, const float* noise, int nn, float* out) {
+    fx_compute_ssao((const GeomPx*)img, w, h, d, kernel, nk, noise, nn, out);
+}
+void orc_fx_blur_ssao(const float* ssao, int w, int h, float* out) { fx_blur_ssao(ssao, w, h, out); }
+void orc_fx_apply_shading(const void* img, int w, int h, int d, const float* ssao, uint8_t* out) {
+    fx_apply_shading((const GeomPx*)img, w, h, d, ssao, out);
+}
+void orc_fx_to_rgba_bitmap(const float* img, uint64_t n, int transparent, uint8_t* out) { fx_to_rgba_bitmap(img, n, transparent, out); }
+void orc_fx_to_debug_bitmap(const float* img, uint64_t n, uint8_t* out) { fx_to_debug_bitmap(img, n, out); }
+void orc_fx_to_rgba_distance(const float* img, uint64_t n, uint8_t* out) { fx_to_rgba_distance(img, n, out); }
 }  // extern "C"

@@ -1,0 +1,228 @@
+"""The assembly tile kernels (fh_tiles, fh_tiles_v32, fh_tiles_v64) executed instruction by instruction on the CPU
+emulator (tools/gfx950_emu.py: the assembled code object, hazard checks on) against the numpy restatement of the
+interval evaluator and of the prune sweep (tests/emu_util.py, following dev_ops.hpp / kernels.hip prune_sweep, i.e.
+fidget-core/src/vm/mod.rs:325-538 and vm/data.rs:123-318): interval results, and every pruned child tape, bit for bit.
+
+No GPU needed: this is how the assembly is developed and regression-tested in the build container."""
+import os
+
+import numpy as np
+import pytest
+
+import emu_util as U
+from emu_util import E, F32, U32
+from conftest import model_path
+from test_render_random import build
+
+N_VGPR = {"fh_tiles": 84, "fh_tiles_v32": 128, "fh_tiles_v64": 208}
+LIMITS = {"fh_tiles": (128, 4096), "fh_tiles_v32": (32, 256), "fh_tiles_v64": (64, 512)}
+ARENA_OPS = 1 << 17
+
+
+def run_tiles(kernel, tape, xyz, in_kind, n_regs, n_choices, act=(1 << 64) - 1, arena_cap=None, in_value=None, skip=(0, 0), limits=None):
+    """One FhSlot through `kernel`.  Returns dict(res, coff, clen, crc, arena, wave, head, overflow)."""
+    off = U.offsets()
+    mem = E.Memory()
+    n = len(tape)
+    arena = np.zeros(ARENA_OPS, np.uint64)
+    arena[16:16 + n] = tape
+    a_arena = mem.map(arena, "arena")
+    st, slot = U.Blob(off["sizeof_state"]), U.Blob(off["sizeof_slot"])
+    slot.u32(0, 16); slot.u32(4, n); slot.u32(8, n_regs | (n_choices << 16)); slot.u32(12, 2)
+    slot.u64(16, act)
+    for k in range(6):
+        slot.arr(40 + 256 * k, np.asarray(xyz[k], F32))
+    a_slot = mem.map(slot.b, "slot")
+    head0 = 16 + n + 16
+    st.u64(off["arena"], a_arena); st.u32(off["arena_cap"], arena_cap if arena_cap is not None else ARENA_OPS - 64); st.u32(off["arena_head"], head0)
+    st.u64(off["slots"], a_slot); st.u64(off["slots"] + 8, a_slot)
+    st.u32(off["slot_cap"], 1); st.u32(off["slot_cap"] + 4, 1)
+    level = 2
+    for big in (0, 1):
+        st.u32(off["n_slots"] + 4 * (big * 8 + level), 1)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
+        if in_value is not None and s < len(in_value):
+            st.f32(off["P.in_value"] + 4 * s, in_value[s])
+    a_st = mem.map(st.b, "state")
+    mr, mc = limits or LIMITS[kernel]
+    if kernel == "fh_tiles":
+        mr, mc = max(n_regs, 32), max(n_choices, 256)
+    ka = np.zeros(10, U32)
+    ka[0], ka[1] = a_st & 0xFFFFFFFF, a_st >> 32
+    ka[2:10] = [level, 0, mr, mc, 1, 0, skip[0], skip[1]]
+    lds = mr * 512 + ((mc + 15) // 16) * 256 + mr * 64 + 256 if kernel == "fh_tiles" else 0
+    w = E.launch(U.program(), mem, kernel, ka.tobytes(), 1, lds_bytes=max(lds, 16), n_vgpr=N_VGPR[kernel])[0]
+    g = lambda k: slot.b[40 + k * 256: 40 + (k + 1) * 256]
+    return dict(res=(g(9).view(F32).copy(), g(10).view(F32).copy()), coff=g(11).view(U32).copy(), clen=g(12).view(U32).copy(),
+                crc=g(13).view(U32).copy(), arena=arena, wave=w, head=int(st.get_u32(off["arena_head"])[0]), head0=head0,
+                overflow=int(st.get_u32(off["arena_overflow"])[0]))
+
+
+def children(center, half, n=4):
+    """x.lo x.hi y.lo y.hi z.lo z.hi of the n^3 (n = 4: 64) children of the cube center +- half, lane = x + n*y + n*n*z"""
+    lanes = np.arange(64)
+    idx = (lanes % n, (lanes // n) % n, lanes // (n * n))
+    step = 2.0 * half / n
+    out = []
+    for ax in range(3):
+        lo = (center[ax] - half + idx[ax] * step).astype(F32)
+        out += [lo, (lo + F32(step)).astype(F32)]
+    return out
+
+
+def check_slot(kernel, tape, xyz, in_kind, n_regs, n_choices, act=(1 << 64) - 1, **kw):
+    r = run_tiles(kernel, tape, xyz, in_kind, n_regs, n_choices, act=act, **kw)
+    inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(in_kind) if k < 3}
+    el, eh, ch, _ = U.ref_interval(tape, inputs, 64)
+    rl, rh = r["res"]
+    assert (el.view(U32) == rl.view(U32)).all() and (eh.view(U32) == rh.view(U32)).all(), "interval results differ"
+    actm = np.array([(act >> i) & 1 for i in range(64)], bool)
+    amb = actm & ~(eh < 0) & ~(el > 0)
+    decided = (ch != 3).any(axis=0) if len(ch) else np.zeros(64, bool)
+    pruned = amb & decided
+    kids = {}
+    for lane in range(64):
+        if pruned[lane]:
+            ops, regs, kept = U.ref_prune(tape, ch[:, lane])
+            got = r["arena"][r["coff"][lane]: r["coff"][lane] + r["clen"][lane]]
+            assert r["clen"][lane] == len(ops) and (got == np.array(ops, np.uint64)).all(), f"lane {lane}: pruned tape differs"
+            assert r["crc"][lane] == (regs | (kept << 16)), f"lane {lane}: regs / choices {r['crc'][lane]:#x} vs {regs}, {kept}"
+            assert r["coff"][lane] + r["clen"][lane] <= r["head"] and r["coff"][lane] >= r["head0"]
+            kids[lane] = (np.array(ops, np.uint64), regs, kept)
+        else:
+            assert r["coff"][lane] == 16 and r["clen"][lane] == len(tape) and r["crc"][lane] == (n_regs | (n_choices << 16))
+    assert r["head"] == r["head0"] + int(pruned.sum()) * len(tape)
+    return r, kids, (el, eh)
+
+
+def shape_of(seed):
+    import fidget_amd as F
+    ctx = F.Context()
+    sh = F.Shape(ctx, build(ctx, seed))
+    ik = [3] * 16
+    for a in range(3):
+        s = sh.axis_index(a)
+        if s >= 0:
+            ik[s] = a
+    return sh, U.shape_tape(sh), ik
+
+
+@pytest.mark.parametrize("kernel", ["fh_tiles", "fh_tiles_v32", "fh_tiles_v64"])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes(kernel, seed):
+    sh, tape, ik = shape_of(seed)
+    if sh.slot_count() > LIMITS[kernel][0] or sh.choice_count() > LIMITS[kernel][1]:
+        pytest.skip("tape outside this kernel's register file")
+    rng = np.random.default_rng(seed)
+    total = 0
+    for _ in range(2):
+        c, h = rng.uniform(-0.7, 0.7, 3), rng.uniform(0.1, 0.6)
+        _, kids, _ = check_slot(kernel, tape, children(c, h), ik, sh.slot_count(), sh.choice_count())
+        total += len(kids)
+    assert total >= 0
+
+
+def prospero_chain():
+    """root tape -> a level-1 parent tape (128^3 tile of a 1024^3 render) -> a level-2 parent tape (32^3 tile), by the reference"""
+    import fidget_amd as F
+    sh = F.Shape.from_vm(model_path("prospero.vm"))
+    tape = U.shape_tape(sh)
+    ik = [3] * 16
+    for a in range(3):
+        ik[sh.axis_index(a)] = a
+    # the 8^3 = 512 root tiles of 128^3 voxels in [-1, 1]^3: pick an ambiguous one with a long pruned tape
+    out = []
+    cur, regs, nch = tape, sh.slot_count(), sh.choice_count()
+    center, half = np.zeros(3), 1.0
+    for level in range(2):
+        n = 8 if level == 0 else 4
+        best = None
+        if level == 0:     # 8 x 8 x 8 children: evaluate them 64 at a time (z layers)
+            cands = []
+            for zl in range(8):
+                lanes = np.arange(64)
+                xs, ys = lanes % 8, lanes // 8
+                xyz = []
+                for idx in (xs, ys, np.full(64, zl)):
+                    lo = (-1.0 + idx * 0.25).astype(F32)
+                    xyz += [lo, (lo + F32(0.25)).astype(F32)]
+                inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(ik) if k < 3}
+                el, eh, ch, _ = U.ref_interval(cur, inputs, 64)
+                amb = ~(eh < 0) & ~(el > 0)
+                for lane in np.nonzero(amb)[0]:
+                    cands.append((zl, lane, ch[:, lane].copy(), [float(xyz[2 * a][lane]) for a in range(3)]))
+            # the child with the longest pruned tape
+            for zl, lane, c, lo in cands:
+                ops, r, k = U.ref_prune(cur, c)
+                if best is None or len(ops) > len(best[0]):
+                    best = (ops, r, k, lo, 0.125)
+        else:
+            xyz = children(center, half)
+            inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(ik) if k < 3}
+            el, eh, ch, _ = U.ref_interval(cur, inputs, 64)
+            amb = ~(eh < 0) & ~(el > 0)
+            for lane in np.nonzero(amb)[0]:
+                ops, r, k = U.ref_prune(cur, ch[:, lane])
+                if best is None or len(ops) > len(best[0]):
+                    best = (ops, r, k, [float(xyz[2 * a][lane]) for a in range(3)], half / 4)
+        ops, r, k, lo, h = best
+        cur, regs, nch = np.array(ops, np.uint64), r, k
+        center, half = np.array(lo) + h, h
+        out.append((cur, regs, nch, center.copy(), half))
+    return ik, out
+
+
+_chain = None
+
+
+def chain():
+    global _chain
+    if _chain is None:
+        _chain = prospero_chain()
+    return _chain
+
+
+def test_prospero_level1_parent_v64():
+    """a level-1 parent of prospero.vm (hundreds of ops, > 32 registers) through the 64-register kernel, and through fh_tiles"""
+    ik, ch = chain()
+    tape, regs, nch, center, half = ch[0]
+    assert 32 < regs <= 64 and nch <= 512 and len(tape) > 300
+    r, kids, _ = check_slot("fh_tiles_v64", tape, children(center, half), ik, regs, nch)
+    assert len(kids) > 8
+    # fh_tiles_v32 leaves the slot alone (tape outside its register file)
+    r32 = run_tiles("fh_tiles_v32", tape, children(center, half), ik, regs, nch)
+    assert (r32["clen"] == 0).all() and r32["head"] == r32["head0"]
+
+
+def test_prospero_level2_parent_v32():
+    ik, ch = chain()
+    tape, regs, nch, center, half = ch[1]
+    assert regs <= 32 and nch <= 256 and len(tape) > 64
+    for kernel in ("fh_tiles_v32", "fh_tiles_v64", "fh_tiles"):
+        r, kids, _ = check_slot(kernel, tape, children(center, half), ik, regs, nch)
+        assert len(kids) > 4
+    # static cost of the two designs on the same parent (instructions per tape op of the whole slot)
+    a = run_tiles("fh_tiles", tape, children(center, half), ik, regs, nch)["wave"]
+    b = run_tiles("fh_tiles_v32", tape, children(center, half), ik, regs, nch)["wave"]
+    assert b.counts.get("lds", 0) == 0 and b.n_inst < 0.7 * a.n_inst
+
+
+def test_partial_activity_and_skip_rules():
+    sh, tape, ik = shape_of(2)
+    xyz = children(np.array([0.1, -0.2, 0.0]), 0.5)
+    act = 0x0F0F_F0F0_1234_5678
+    check_slot("fh_tiles_v32", tape, xyz, ik, sh.slot_count(), sh.choice_count(), act=act)
+    # a slot that fits the (skip_regs, skip_choices) layout is left to the other launch
+    r = run_tiles("fh_tiles_v64", tape, xyz, ik, sh.slot_count(), sh.choice_count(), skip=(32, 256))
+    assert (r["clen"] == 0).all() and r["head"] == r["head0"]
+    # inactive slot
+    r = run_tiles("fh_tiles_v32", tape, xyz, ik, sh.slot_count(), sh.choice_count(), act=0)
+    assert (r["clen"] == 0).all()
+
+
+def test_arena_overflow_keeps_parent_tape():
+    sh, tape, ik = shape_of(0)
+    xyz = children(np.array([0.0, 0.0, 0.0]), 0.5)
+    r = run_tiles("fh_tiles_v32", tape, xyz, ik, sh.slot_count(), sh.choice_count(), arena_cap=16 + len(tape) + 20)
+    assert r["overflow"] == 1 and (r["coff"] == 16).all() and (r["clen"] == len(tape)).all()

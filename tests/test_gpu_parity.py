@@ -81,8 +81,12 @@ def test_render3d_bear(size):
     b = O.render3d(o, size)[0]
     nd = int((a["depth"] != b["depth"]).sum())
     assert nd == 0, f"{nd} depths differ"
+    # depth (every pruning / occupancy decision) is exact; the normal is a sum of products of sin / cos / exp / ln values that
+    # the device rounds once from f64 and glibc computes in f32 (<= 1 ulp apart each): the error bar is 4 ulp of the
+    # gradient's largest component per pixel (measured: 0.3 ulp, profiles/r01i/other_configs.json), not 1e-4
+    scale = np.abs(b["normal"]).max(axis=2, keepdims=True)
     err = np.abs(a["normal"] - b["normal"])
-    assert err.max() <= 1e-4 * max(1.0, np.abs(b["normal"]).max())
+    assert (err <= 4 * 2.0 ** -23 * np.maximum(scale, 2.0 ** -100)).all(), f"max error {err.max()} = {np.nanmax(err / np.maximum(scale, 1e-30)) * 2 ** 23:.2f} ulp"
 
 
 @pytest.mark.gpu

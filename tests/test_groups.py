@@ -105,7 +105,8 @@ def check(fa, fb, n, what):
     a = F.render3d(fa, n)[0]
     b = O.render3d(fb, n)[0]
     assert (a["depth"] == b["depth"]).all(), (what, n, int((a["depth"] != b["depth"]).sum()))
-    assert np.abs(a["normal"] - b["normal"]).max() <= 1e-5, (what, n)
+    same = (a["normal"] == b["normal"]) | (np.isnan(a["normal"]) & np.isnan(b["normal"]))   # add / square / sqrt only: bit-exact
+    assert same.all(), (what, n, int((~same).any(axis=2).sum()))
 
 split = 0
 for seed in range(12):

@@ -105,8 +105,11 @@ def test_random_shapes_3d(seed, size, oracle_mod):
     a = F.render3d(F.Shape(*_shape(F, seed)), size)[0]
     b = O.render3d(O.Shape(*_shape(O, seed)), size)[0]
     assert (a["depth"] == b["depth"]).all(), f"{(a['depth'] != b['depth']).sum()} depths differ"
-    # gradients go through sqrt / div chains: same formulas, but fused differently by the two compilers
-    assert np.abs(a["normal"] - b["normal"]).max() <= 1e-5
+    # no transcendental opcode in these shapes: the normals are bit-exact too (NaN == NaN, +0 == -0 by float equality).
+    # Round 1 allowed 1e-5 here; tools/bisect_normals.py (profiles/r02a) found no differing pixel at 64 / 128 / 200.
+    na, nb = a["normal"], b["normal"]
+    same = (na == nb) | (np.isnan(na) & np.isnan(nb))
+    assert same.all(), f"{(~same).any(axis=2).sum()} pixels with different normals"
 
 
 @pytest.mark.gpu
