@@ -8,11 +8,12 @@ evaluation) of prospero.vm at 1024^3, nominal volume / wall time
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (the driver launches N>1 through torch.distributed.run).  A step is
-one full frame.  With N > 1 the frame is sharded by root-tile column (index % N == rank,
-no data-path collective inside the render) and the 16 MiB partial images are combined on
-rank 0 by ONE RCCL reduce over xGMI (integer SUM of the raw pixel words: every pixel is
-produced by exactly one rank, the others hold zeros, so the sum is bit-exact).  Total work
-is fixed as N grows -> "strong" scaling.
+one full frame.  With N > 1 the frame is sharded (no collective inside the render) and BOTH
+partitions of fidget_amd/dist.py are timed, K steps each: "columns" (root-tile column index
+% N == rank at full depth; ONE RCCL SUM reduce of the partial images) and "blocks" (the north
+star's octants, 2 x 2 x 2 at N = 8: a gather of the ranks' own rectangles, then the
+front-to-back depth merge on rank 0).  `value` is the faster one (named in config.sharding),
+both are listed under "partitions".  Total work is fixed as N grows -> "strong" scaling.
 
 Prints ONE JSON line on rank 0, including
   roofline     — for the dominant kernel (fh_tiles, the assembly tile-stage interpreter; a second
@@ -51,7 +52,7 @@ def main():
     import torch
     import torch.distributed as dist
     import fidget_amd as F
-    from fidget_amd.dist import combine
+    from fidget_amd.dist import combine, gather_blocks, block_split
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,27 +73,53 @@ def main():
     shape = F.Shape.from_vm(os.path.join(ROOT, "models", args.model), hip=hip)
     out = torch.zeros((n, n, 4), dtype=torch.int32, device=dev)  # GeometryPixel = 4 x 32-bit words
 
-    def step():
+    split = block_split(world)
+
+    def step_columns():
         F.render3d(shape, n, out=out, shard=rank, n_shards=world)
-        combine(out, dst=0)  # one RCCL reduce of the 16 MiB partial images (no-op at N = 1)
+        combine(out, dst=0)  # one RCCL reduce of the partial images (no-op at N = 1)
+
+    def step_blocks():
+        F.render3d(shape, n, out=out, block=(rank, split))
+        gather_blocks(out, n, split, lambda a, b, d: F.merge_depth(a, b, d, hip=hip), dst=0)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    partitions = {}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # the stream of the context is torch's current stream: collectives and renders are ordered on it
+        dt_b = timed(step_blocks)
+        img_b = out.clone()
+        dt_c = timed(step_columns)
+        partitions = {"columns": {"ms_per_step": dt_c / args.steps * 1e3, "combine": "1 RCCL reduce (SUM) of the full image"},
+                      "blocks": {"ms_per_step": dt_b / args.steps * 1e3, "split": list(split),
+                                 "combine": "RCCL gather of each rank's rectangle + front-to-back depth merge on rank 0"}}
+        if rank == 0:
+            partitions["images_equal"] = bool(torch.equal(img_b, out))
+        dt, step = (dt_c, step_columns) if dt_c <= dt_b else (dt_b, step_blocks)
+        sharding = "root-tile columns round-robin, 1 RCCL reduce" if dt_c <= dt_b else f"blocks {split[0]}x{split[1]}x{split[2]} (octant split), RCCL gather + depth merge"
+    else:
+        step = step_columns
+        dt = timed(step)
+        sharding = "single GPU"
     hip.sync()
     counters = hip.counters()
 
@@ -130,12 +157,14 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
-                   "sharding": "root-tile columns round-robin, 1 RCCL reduce" if world > 1 else "single GPU"},
+                   "sharding": sharding},
         "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in prof.items()},
         "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in prof.items()},
         "asm_kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in kern.items() if v[1]},
         "arena_ops_last_slab": counters["arena_ops"], "arena_overflow": counters["arena_overflow"],
     }
+    if partitions:
+        result["partitions"] = partitions
 
     # ---- cpu_baseline + parity + algorithmic bytes (oracle; rank 0, N = 1 only) -----------------
     if not args.no_cpu and world == 1:

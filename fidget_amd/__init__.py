@@ -48,7 +48,7 @@ EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
-    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
@@ -133,6 +133,8 @@ def lib():
             "fhip_render2d": (i32, [vp, vp, C.POINTER(_Cfg2D), vp, i32]),
             "fhip_render3d": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32]),
             "fhip_render3d_shard": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, u32]),
+            "fhip_render3d_block": (i32, [vp, vp, C.POINTER(_Cfg3D), vp, i32, u32, vp]),
+            "fhip_merge_depth": (i32, [vp, vp, vp, u64, u32]),
             "fhip_denoise_normals": (i32, [vp, vp, u32, u32, vp, i32]),
             "fhip_compute_ssao": (i32, [vp, vp, u32, u32, u32, vp, u32, vp, u32, vp, i32]),
             "fhip_blur_ssao": (i32, [vp, vp, u32, u32, vp, i32]),
@@ -694,8 +696,10 @@ def render2d(shape, width, height=None, z=0.0, pixel_perfect=False, world_to_mod
 
 
 def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_sizes=None, vars=None, out=None,
-             shard=0, n_shards=1, mode=None, threads=None):
-    """fidget_raster::voxel::render on the GPU.  Returns (GeometryPixel [h,w] image, stats, seconds)."""
+             shard=0, n_shards=1, mode=None, threads=None, block=None):
+    """fidget_raster::voxel::render on the GPU.  Returns (GeometryPixel [h,w] image, stats, seconds).
+    Multi-GPU parts: (shard, n_shards) = root-tile columns round robin; block = (index, (nx, ny, nz)) = one block of an
+    nx x ny x nz split of the volume (fhip_render3d_block)."""
     height = width if height is None else height
     depth = width if depth is None else depth
     hip = shape.hip
@@ -707,8 +711,13 @@ def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_si
         ax = np.array(shape._vars, dtype=np.int32)
         vk = np.array([shape._named_slot(k) for k in (vars or {})], dtype=np.uint64)
     cfg = _Cfg3D(width, height, depth, _p(w2m), _p(ts), 0 if ts is None else len(ts), _p(vk), _p(vv), len(vk), _p(ax))
+    def call(ptr, dev):
+        if block is not None:
+            split = np.array(block[1], dtype=np.uint32)
+            return lib().fhip_render3d_block(hip._h, shape._h, C.byref(cfg), ptr, dev, int(block[0]), _p(split))
+        return lib().fhip_render3d_shard(hip._h, shape._h, C.byref(cfg), ptr, dev, shard, n_shards)
     if out is not None:
-        st = lib().fhip_render3d_shard(hip._h, shape._h, C.byref(cfg), _dev_ptr(out), 1, shard, n_shards)
+        st = call(_dev_ptr(out), 1)
         if st == 4:
             raise ValueError("MissingVar")
         hip.check(st)
@@ -716,12 +725,19 @@ def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_si
     img = np.zeros((height, width), dtype=GEOMETRY_PIXEL)
     import time
     t0 = time.perf_counter()
-    st = lib().fhip_render3d_shard(hip._h, shape._h, C.byref(cfg), _p(img), 0, shard, n_shards)
+    st = call(_p(img), 0)
     dt = time.perf_counter() - t0
     if st == 4:
         raise ValueError("MissingVar")
     hip.check(st)
     return img, {}, dt
+
+
+def merge_depth(front, back, image_depth, hip=None):
+    """fhip_merge_depth on torch CUDA tensors ([h, w, 4] int32 GeometryPixel words), in place on `front`."""
+    hip = hip or default_context()
+    hip.check(lib().fhip_merge_depth(hip._h, _dev_ptr(front), _dev_ptr(back), front.numel() // 4, int(image_depth)))
+    return front
 
 
 def pixel_inside(img):

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,12 @@ struct fhip_tape {
     std::vector<fh::HostTape> tgroups;
     mutable FhTopOp* d_top = nullptr;
     mutable uint32_t* d_chsrc = nullptr;
+    // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
+    // reference's workers): its lazily created device copies are made under this lock, on the device of the first
+    // context that needs them (HIP allocations are visible to every device of the process with peer access; a tape
+    // used from several devices should be built per device)
+    mutable std::mutex upload_lock;
+    mutable int device = -1;
 };
 struct fhip_graph {
     fh::Graph g;
@@ -84,6 +91,8 @@ struct fhip_ctx {
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::string err;
+    bool launch_failed = false;     // an assembly kernel launch of the current frame failed (reported when the frame has been queued)
+    bool async_pending = false;     // the last render left its result on the device: its overflow flags have not been read yet
     std::atomic<int> cancelled{0};
     DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr;
     DevBuf queue[FH_MAX_LEVELS];
@@ -95,6 +104,7 @@ struct fhip_ctx {
     bool have_last_state = false;
 };
 
+static fhip_status finish_render(fhip_ctx* ctx);
 static fhip_status fail(fhip_ctx* ctx, fhip_status s, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return s;
@@ -197,8 +207,16 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     delete c;
 }
 const char* fhip_last_error(const fhip_ctx* c) { return c ? c->err.c_str() : "no context"; }
+// Waits for everything queued on the context.  An asynchronous render (out_is_device) cannot report what only the
+// device knows when it returns: its queue-overflow flag (the queues are sized to exact upper bounds, so this would be
+// a bug, not a condition) is read here.
 fhip_status fhip_ctx_sync(fhip_ctx* c) {
+    (void)hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->async_pending) {
+        c->async_pending = false;
+        return finish_render(c);
+    }
     return FHIP_OK;
 }
 void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
@@ -277,7 +295,10 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
     if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, st); }
     const hipError_t e = hipModuleLaunchKernel(ctx->asm_fn[which], waves, grid_y, 1, WAVE, 1, 1, (unsigned)lds, st, nullptr, extra);
     if (ctx->profiling) { (void)hipEventRecord(eb, st); ctx->asm_events.push_back({which, {ea, eb}}); }
-    if (e != hipSuccess && ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
+    if (e != hipSuccess) {
+        ctx->launch_failed = true;
+        if (ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
+    }
     return e;
 }
 // The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
@@ -294,11 +315,16 @@ static bool tape_asm_ok(const fh::HostTape& t) {
 }
 
 static fhip_status tape_to_device(fhip_ctx* ctx, const fhip_tape* t) {
+    std::lock_guard<std::mutex> guard(t->upload_lock);
+    (void)hipSetDevice(ctx->device);
     if (t->d_ops) return FHIP_OK;
+    t->device = ctx->device;
     size_t bytes = (t->t.ops.size() + 16) * 8;  // slack: the interpreters prefetch up to 12 ops past the end
-    HIP_TRY(ctx, hipMalloc((void**)&t->d_ops, bytes));
-    HIP_TRY(ctx, hipMemset(t->d_ops, 0, bytes));
-    HIP_TRY(ctx, hipMemcpy(t->d_ops, t->t.ops.data(), t->t.ops.size() * 8, hipMemcpyHostToDevice));
+    uint64_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, bytes));
+    HIP_TRY(ctx, hipMemset(d, 0, bytes));
+    HIP_TRY(ctx, hipMemcpy(d, t->t.ops.data(), t->t.ops.size() * 8, hipMemcpyHostToDevice));
+    t->d_ops = d;   // published only when complete
     return FHIP_OK;
 }
 fhip_status fhip_tape_from_bytecode(fhip_ctx* ctx, const uint32_t* words, size_t n_words, fhip_tape** out) {
@@ -549,6 +575,7 @@ struct RenderSetup {
     FhRenderState S;
     std::vector<FhGroup> roots;
     uint32_t n_slabs = 1;
+    uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
     size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
@@ -614,8 +641,15 @@ static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {
     return (b + 15) & ~(size_t)15;
 }
 
+// Which part of the volume a render covers (multi-GPU): root-tile columns round robin (index % n_shards == shard, full
+// depth), or a block of an nx x ny x nz split of the root-tile grid and of the z-slabs (octants: 2 x 2 x 2)
+struct PartSpec {
+    uint32_t shard = 0, n_shards = 1;
+    uint32_t ix = 0, nx = 1, iy = 0, ny = 1, iz = 0, nz = 1;
+};
 static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
-                           uint32_t shard, uint32_t n_shards, RenderSetup& R) {
+                           const PartSpec& part, RenderSetup& R) {
+    const uint32_t shard = part.shard, n_shards = part.n_shards;
     FhRenderState& S = R.S;
     FhRender& P = S.P;
     const fh::HostTape& t = tape->t;
@@ -634,7 +668,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     if (fanout > 64) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 64 children");
     const uint32_t TL = R.tl = fanout > 16 ? 64 : 16;
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
-    if (t.n_regs > 256) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 256 registers");
+    // (the device prunes keep old -> new register maps in bytes with 0xFF = dead: 255 registers at most)
+    if (t.n_regs > 255) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 255 registers");
     P.max_regs = std::max<uint32_t>(t.n_regs, 1);
     P.max_choices = t.n_choices;
     P.roots_x = (P.width + ts[0] - 1) / ts[0];
@@ -657,23 +692,44 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
     S.n_slabs = R.n_slabs;
     S.pre_levels = (is3d && ts.size() >= 3 && R.n_slabs <= FH_MAX_SLABS) ? 2 : 0;
-    const uint32_t slabs_in_q0 = S.pre_levels ? R.n_slabs : 1;
+    const uint32_t slabs_in_q0 = S.pre_levels ? R.n_slabs : 1;   // (bound for the queue capacities; a z-split part uses fewer)
 
-    // root groups: runs of <= 16 root tiles of this shard (one set per slab in pre-pass mode)
-    std::vector<uint32_t> mine;
-    for (uint32_t ri = shard; ri < P.roots_x * P.roots_y; ri += n_shards) mine.push_back(ri);
+    // z-slabs of this part: slab k of the block split belongs to iz = k * nz / n_slabs (iz = nz - 1: the front)
+    R.slab_lo = 0; R.slab_hi = R.n_slabs;
+    if (part.nz > 1) {
+        R.slab_lo = R.n_slabs; R.slab_hi = 0;
+        for (uint32_t k = 0; k < R.n_slabs; k++)
+            if ((uint64_t)k * part.nz / R.n_slabs == part.iz) { R.slab_lo = std::min(R.slab_lo, k); R.slab_hi = std::max(R.slab_hi, k + 1); }
+        if (R.slab_lo >= R.slab_hi) R.slab_lo = R.slab_hi = 0;   // more parts than slabs: nothing to do
+    }
+    // root groups: runs of <= TL root tiles of this part, index = first + lane * stride (one set per slab in pre-pass mode)
+    struct Run { uint32_t first, n, stride; };
+    std::vector<Run> runs;
+    if (part.nx > 1 || part.ny > 1) {       // a block of root-tile columns: per x, the run of its y range (x-major numbering)
+        for (uint32_t tx = 0; tx < P.roots_x; tx++) {
+            if ((uint64_t)tx * part.nx / P.roots_x != part.ix) continue;
+            uint32_t y0 = P.roots_y, y1 = 0;
+            for (uint32_t ty = 0; ty < P.roots_y; ty++)
+                if ((uint64_t)ty * part.ny / P.roots_y == part.iy) { y0 = std::min(y0, ty); y1 = std::max(y1, ty + 1); }
+            for (uint32_t ty = y0; ty < y1; ty += TL) runs.push_back(Run{tx * P.roots_y + ty, std::min<uint32_t>(TL, y1 - ty), 1});
+        }
+    } else {
+        std::vector<uint32_t> mine;
+        for (uint32_t ri = shard; ri < P.roots_x * P.roots_y; ri += n_shards) mine.push_back(ri);
+        for (size_t i = 0; i < mine.size(); i += TL) runs.push_back(Run{mine[i], (uint32_t)std::min<size_t>(TL, mine.size() - i), n_shards});
+    }
     FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
-    for (uint32_t k = 0; k < slabs_in_q0; k++)
-        for (size_t i = 0; i < mine.size(); i += TL) {
+    const uint32_t q0_slabs = S.pre_levels ? R.slab_hi - R.slab_lo : 1;
+    for (uint32_t k = 0; k < q0_slabs; k++)
+        for (const Run& r : runs) {
             FhGroup g{};
             g.tape = root;
-            g.first = mine[i];
-            g.n = (uint32_t)std::min<size_t>(TL, mine.size() - i);
-            g.stride = n_shards;
-            g.z = (R.n_slabs - 1 - k) * ts[0];  // front slabs first
+            g.first = r.first; g.n = r.n; g.stride = r.stride;
+            g.z = (R.slab_hi - 1 - k) * ts[0];  // front slabs first
             R.roots.push_back(g);
         }
-    R.groups_per_slab = (uint32_t)(R.roots.size() / slabs_in_q0);
+    R.groups_per_slab = (uint32_t)(R.roots.size() / std::max<uint32_t>(q0_slabs, 1));
+    if (R.slab_lo >= R.slab_hi) { R.roots.clear(); R.groups_per_slab = 0; }
 
     // capacities (exact upper bounds): queue[l] holds the tiles of size ts[l-1] that can be
     // ambiguous, per slab for the per-slab levels and for the whole volume for pre-pass levels
@@ -717,7 +773,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         for (int c = 0; c < 3; c++) S.fp_list[c] = (uint32_t*)ctx->fp_lists.p + (size_t)c * R.n_footprints;
     }
     S.arena = (uint64_t*)ctx->arena.p;
-    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 32, 0xFFFFFFE0u);  // slack: the interpreters prefetch up to 12 ops past a tape's end
+    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 64, 0x7FFFFFE0u);  // slack: the interpreters prefetch up to 12 ops past a tape's end
     S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
     S.arena_overflow = 0;
     for (int l = 0; l < FH_MAX_LEVELS; l++) {
@@ -748,6 +804,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
             S.n_terms = tape->plan.n_terms; S.n_top = (uint32_t)tape->plan.top.size(); S.top_chain = tape->plan.chain ? 1 : 0;
             S.troot_len = (uint32_t)t.ops.size(); S.troot_choices = t.n_choices; S.troot_regs = std::max<uint32_t>(t.n_regs, 1);
             S.arena_head = S.arena_root_end = off;
+            std::lock_guard<std::mutex> guard(tape->upload_lock);
             if (!tape->d_top) {
                 static_assert(sizeof(FhTopOp) == sizeof(fh::TopOp), "top op layout");
                 HIP_TRY(ctx, hipMalloc((void**)&tape->d_top, tape->plan.top.size() * sizeof(FhTopOp)));
@@ -992,7 +1049,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     memcpy(P.mat, m4, sizeof(m4));
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
                                                      : trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height));
-    st = prepare(ctx, tape, false, ts, 0, 1, R);
+    st = prepare(ctx, tape, false, ts, PartSpec{}, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
     float* d_out = out;
@@ -1023,10 +1080,10 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     return FHIP_OK;
 }
 
-fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
-                                int out_is_device, uint32_t shard, uint32_t n_shards) {
+static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                 int out_is_device, const PartSpec& part) {
     if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
-    if (n_shards == 0 || shard >= n_shards) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad shard");
+    (void)hipSetDevice(ctx->device);
     RenderSetup R;
     memset(&R.S, 0, sizeof(R.S));
     FhRender& P = R.S.P;
@@ -1040,7 +1097,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
                                                      : hip_tiles_3d(std::max(cfg->width, cfg->height));
-    st = prepare(ctx, tape, true, ts, shard, n_shards, R);
+    st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
@@ -1063,7 +1120,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     // pyramid is then one slab stale, which is still exact (depths only grow).  Two slab contexts
     // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
     FhRenderState* const dS0 = dS;
-    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.n_slabs > 1 && n_groups > 0;
+    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
     hipStream_t const main_stream = ctx->stream;
     hipStream_t const side_stream = getenv("FHIP_PIPE_SERIAL") ? main_stream : ctx->stream2;  // diagnostics
     const uint32_t NC = pipe ? ctx->slab_contexts : 1;
@@ -1074,9 +1131,9 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
-    for (int k = (int)R.n_slabs - 1; k >= 0 && n_groups; k--) {  // front to back (voxel.rs:252-261)
+    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
-        const int idx = (int)R.n_slabs - 1 - k;
+        const int idx = (int)R.slab_hi - 1 - k;
         dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
         if (pipe) {
             ctx->stream = side_stream;
@@ -1087,7 +1144,7 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
             // (up to 1024 x 1024: at 2048 x 2048 it was measured SLOWER than the generic kernel - 11.2 vs 8.2 ms per frame)
             const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
                               ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !getenv("FHIP_OLD_PYR");
-            const bool rebuild = k != (int)R.n_slabs - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
+            const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
             hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
                                (pyr3 && rebuild) ? 1u : 0u);
             if (rebuild && pyr3) {
@@ -1156,6 +1213,8 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
     }
     launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out); });
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
+    ctx->async_pending = out_is_device != 0;
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);
@@ -1164,7 +1223,36 @@ fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip
 }
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                           int out_is_device) {
-    return fhip_render3d_shard(ctx, tape, cfg, out, out_is_device, 0, 1);
+    return render3d_part(ctx, tape, cfg, out, out_is_device, PartSpec{});
+}
+fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t shard, uint32_t n_shards) {
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad shard");
+    PartSpec p;
+    p.shard = shard; p.n_shards = n_shards;
+    return render3d_part(ctx, tape, cfg, out, out_is_device, p);
+}
+// Octant-style shards: block `index` = ix + nx * (iy + ny * iz) of an nx x ny x nz split of the volume (root-tile
+// columns in x and y, z-slabs in z; iz = nz - 1 is the front).  Pixels outside the block's columns stay {0,0,0,0}.
+fhip_status fhip_render3d_block(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t index, const uint32_t split[3]) {
+    if (!split || !split[0] || !split[1] || !split[2] || index >= split[0] * split[1] * split[2]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad block");
+    PartSpec p;
+    p.nx = split[0]; p.ny = split[1]; p.nz = split[2];
+    p.ix = index % p.nx; p.iy = (index / p.nx) % p.ny; p.iz = index / (p.nx * p.ny);
+    return render3d_part(ctx, tape, cfg, out, out_is_device, p);
+}
+// Merge of two partial images of the same pixels from different z ranges (the stitch rule of voxel.rs:527-550 applied
+// across shards): the larger depth wins, a tie goes to `front` (the range nearer the camera: a hit there carries the
+// normal, the other side's equal depth is a filled tile's z + T + 1 with no normal); then the clamp depth >= D - 1 ->
+// (D, [0, 0, 1]).  In place on `front`; device pointers; n pixels.
+fhip_status fhip_merge_depth(fhip_ctx* ctx, void* front, const void* back, uint64_t n_pixels, uint32_t image_depth) {
+    if (!n_pixels) return FHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    hipLaunchKernelGGL(k_merge_depth, dim3((unsigned)std::min<uint64_t>((n_pixels + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+                       (FhGeometryPixel*)front, (const FhGeometryPixel*)back, (size_t)n_pixels, image_depth);
+    HIP_TRY(ctx, hipGetLastError());
+    return FHIP_OK;
 }
 
 // ---- effects (fidget-raster/src/effects.rs) ---------------------------------------------------

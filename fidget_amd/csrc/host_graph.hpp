@@ -450,9 +450,11 @@ static inline bool from_bytecode(const uint32_t* w, size_t n_words, SsaProgram& 
         uint32_t a, b;
         if (op == 0) {  // Output
             if (!rd(r1, &a)) return false;
+            if (imm >= 256) { err = "output slot out of range"; return false; }   // (slot + 1 sizes the output buffers)
             fwd.push_back({FH_OUTPUT, 0, a, 0, imm});
             if (imm + 1 > n_out) n_out = imm + 1;
         } else if (op == 1) {  // Input
+            if (imm >= 16) { err = "input slot out of range (16 variables at most)"; return false; }   // FH_MAX_INPUTS
             cur[r1] = next;
             fwd.push_back({FH_INPUT, next++, 0, 0, imm});
             if (imm + 1 > max_in) max_in = imm + 1;

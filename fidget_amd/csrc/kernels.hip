@@ -39,6 +39,14 @@ typedef unsigned long long Q4 __attribute__((ext_vector_type(4), aligned(8)));
 FH_DEV uint64_t q4_pick(Q4 q, int u) { return u == 0 ? q.x : (u == 1 ? q.y : (u == 2 ? q.z : q.w)); }
 
 FH_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Arena reservation of `n` ops by one lane: the bump pointer moves back when the reservation does not fit, so that it
+// cannot creep past 2^32 and wrap under a long run of failures (arena_cap <= 2^31 ops, at most a few thousand waves in
+// flight add <= 2^18 ops each).  Returns ~0u on failure.
+FH_DEV uint32_t arena_reserve(FhRenderState* S, uint32_t n) {
+    const uint32_t base = atomicAdd(&S->arena_head, n);
+    if (base + n < base || base + n > S->arena_cap) { atomicSub(&S->arena_head, n); return 0xFFFFFFFFu; }
+    return base;
+}
 FH_DEV uint64_t ballot(bool p) { return __ballot(p); }
 
 // Is `op` outside the "basic" arithmetic set?  Kernels are built twice: BASIC variants keep
@@ -460,9 +468,9 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             const uint32_t nprune = (uint32_t)__popcll(ballot(prune));
             const uint32_t rank = (uint32_t)__popcll(ballot(prune) & ((1ull << lane) - 1));
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&S->arena_head, nprune * len);
+            if (lane == 0) base = arena_reserve(S, nprune * len);
             base = uni(base);
-            if (base + nprune * len <= S->arena_cap) {
+            if (base != 0xFFFFFFFFu) {
                 if (lane < TL) {
                     for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane16] = DEAD;
                     uint64_t* dst = S->arena + base + (rank + 1) * len;
@@ -698,9 +706,9 @@ __global__ void __launch_bounds__(WAVE) k_tmark3d(FhRenderState* S) {
         const uint64_t am = ballot(amb);
         const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1));
         uint32_t base = 0;
-        if (lane == 0 && n) base = atomicAdd(&S->arena_head, n * root.len);
+        if (lane == 0 && n) base = arena_reserve(S, n * root.len);
         base = uni(base);
-        const bool ok = n && base + n * root.len <= S->arena_cap;
+        const bool ok = n && base != 0xFFFFFFFFu;
         if (n && !ok && lane == 0) atomicAdd(&S->arena_overflow, 1u);  // the children keep the root tape
         p.c_off[lane] = (amb && ok) ? base + (rank + 1) * root.len : root.off;   // end of this child's arena slot
         p.c_len[lane] = (amb && ok) ? 0xFFFFFFFFu : root.len;                    // ~0: to be written by fh_prune1
@@ -790,9 +798,9 @@ __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
             const uint32_t nprune = (uint32_t)__popcll(pm);
             const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1));
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&S->arena_head, nprune * len);
+            if (lane == 0) base = arena_reserve(S, nprune * len);
             base = uni(base);
-            if (base + nprune * len <= S->arena_cap) {
+            if (base != 0xFFFFFFFFu) {
                 for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane] = DEAD;
                 uint32_t l2 = 0, r2 = 0, c2 = 0;
                 prune_sweep<true, TL>(tape, len, n_choices, chbits, map, lane, prune, S->arena + base + (rank + 1) * len, l2, r2, c2);
@@ -1219,7 +1227,6 @@ __global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, uint3
     A->arena_cap = lo + part;
 }
 // End of the pre-pass: everything allocated so far lives for the whole frame
-// (arena_head runs past arena_cap when reservations failed: failed ones are never used)
 __global__ void k_mark_frame(FhRenderState* S) { S->arena_frame_end = min(S->arena_head, S->arena_cap); }
 
 // Min-depth pyramid of the z-buffer, one workgroup per root tile: mind[l][tile] = smallest
@@ -1292,6 +1299,17 @@ __global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
         if (d >= P.depth - 1) { o.normal[0] = 0.0f; o.normal[1] = 0.0f; o.normal[2] = 1.0f; o.depth = P.depth; }
         else { o.normal[0] = S->normals[i * 3]; o.normal[1] = S->normals[i * 3 + 1]; o.normal[2] = S->normals[i * 3 + 2]; o.depth = d; }
         out[i] = o;
+    }
+}
+
+// Multi-GPU merge of partial images over the same pixels (z-split shards); see fhip_merge_depth
+__global__ void k_merge_depth(FhGeometryPixel* front, const FhGeometryPixel* back, size_t n, uint32_t D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        FhGeometryPixel a = front[i];
+        const FhGeometryPixel b = back[i];
+        if (b.depth > a.depth) a = b;     // ties: the front range keeps its pixel
+        if (D && a.depth >= D - 1) { a.depth = D; a.normal[0] = 0.0f; a.normal[1] = 0.0f; a.normal[2] = 1.0f; }   // voxel.rs:533-539
+        front[i] = a;
     }
 }
 

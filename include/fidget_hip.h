@@ -145,11 +145,21 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
  * {f32 normal[3]; u32 depth} (voxel.rs:122-134). */
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                           int out_is_device);
-/* Multi-GPU 3D: render only root-tile columns whose index (x-major, lib.rs:116-123)
- * satisfies index % n_shards == shard; other pixels are left {0,0,0,0} so that the partial
- * images combine with an element-wise max on depth (no pixel is produced twice). */
+/* Multi-GPU 3D, partition A: render only the root-tile columns whose index (x-major, lib.rs:116-123) satisfies
+ * index % n_shards == shard, at full depth (front-to-back culling intact).  Other pixels are left {0,0,0,0}: every pixel is
+ * produced by exactly one shard, so the partial images combine with an integer SUM of the raw words (or a gather). */
 fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                 int out_is_device, uint32_t shard, uint32_t n_shards);
+/* Multi-GPU 3D, partition B (the octant split): block `index` = ix + split[0] * (iy + split[1] * iz) of a
+ * split[0] x split[1] x split[2] division of the volume: blocks of root-tile columns in x and y, of z-slabs (root-tile
+ * layers) in z; iz = split[2] - 1 is nearest the camera.  Pixels outside the block's columns stay {0,0,0,0}.  Blocks
+ * that differ only in iz cover the same pixels and combine with fhip_merge_depth, front range first. */
+fhip_status fhip_render3d_block(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t index, const uint32_t split[3]);
+/* The stitch rule of voxel.rs:527-550 across z ranges, in place on `front` (device pointers, n_pixels GeometryPixel each):
+ * the larger depth wins, a tie keeps `front` (a hit there carries the normal; the equal depth on the other side is a
+ * filled tile's z + T + 1, which has none), then depth >= image_depth - 1 -> (image_depth, [0, 0, 1]). */
+fhip_status fhip_merge_depth(fhip_ctx* ctx, void* front, const void* back, uint64_t n_pixels, uint32_t image_depth);
 
 /* ---- post-processing: fidget_raster::effects (fidget-raster/src/effects.rs) --------------------
  * The step right after a render; images are width*height arrays as the renders produce them.  With on_device != 0

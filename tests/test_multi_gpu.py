@@ -1,8 +1,9 @@
-"""Multi-GPU path: root-tile-column shards combined by one SUM reduce.
+"""Multi-GPU path: A. root-tile-column shards combined by one SUM reduce; B. blocks of the volume (octants at
+8 ranks) gathered and merged front to back with the stitch rule of voxel.rs:527-550.
 
-CPU: the combine protocol at world size 2 over gloo, partial images cut from the oracle's frame
-with the same ownership rule the device uses.  GPU: the device's own shards are disjoint, zero
-elsewhere and sum to the single-GPU frame."""
+CPU: both protocols at world size 2 over gloo, partial images cut from the oracle's frame with the ownership rules the
+device uses (incl. equal depths on both sides of a z split: the front range keeps its pixel).  GPU: the device's own
+shards / blocks, rendered one after the other on one GPU, combine to the single-GPU frame bit for bit."""
 import os
 import socket
 import sys
@@ -78,3 +79,110 @@ def test_device_shards_sum_to_the_frame(world):
         assert np.array_equal(part, np.where((own == r)[..., None], full, 0)), f"shard {r} is not full * ownership mask"
         acc += part
     assert np.array_equal(acc, full)
+
+
+# ---- partition B: blocks (octants) ---------------------------------------------------------------------------------
+def test_block_split_and_rects():
+    assert [D.block_split(w) for w in (1, 2, 4, 8, 3, 6)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2), (3, 1, 1), (6, 1, 1)]
+    rects = [D.block_rect(1024, 1024, 128, (2, 2, 2), i) for i in range(8)]
+    assert rects[:4] == [(0, 512, 0, 512), (0, 512, 512, 1024), (512, 1024, 0, 512), (512, 1024, 512, 1024)] and rects[4:] == rects[:4]
+    # a non-divisible image: the rectangles tile it
+    cover = np.zeros((200, 300), int)
+    for i in range(4):
+        y0, y1, x0, x1 = D.block_rect(300, 200, 128, (2, 2, 1), i)
+        cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()
+
+
+def merge_ref(front, back, image_depth):
+    """the rule of fhip_merge_depth on CPU tensors (test double of the device kernel): in place on `front`"""
+    f, b = front.numpy(), back.numpy()
+    take = b[:, 3].astype(np.uint32) > f[:, 3].astype(np.uint32)
+    f[take] = b[take]
+    sat = f[:, 3].astype(np.uint32) >= image_depth - 1
+    f[sat] = np.array([0, 0, np.float32(1.0).view(np.int32), image_depth], np.int32)
+    return front
+
+
+def _parts_of(full, split, depth, rank, rng):
+    """what rank `rank` would hold: its rectangle, its z range only; pixels the nearer range already hit get an equal-depth,
+    normal-less entry on the far side now and then (a filled tile's z + T + 1 meeting a hit on the cut plane)"""
+    H, W = full.shape[:2]
+    ix, iy, iz = D.block_coords(rank, split)
+    y0, y1, x0, x1 = D.block_rect(W, H, D.root_tile(max(W, H)), split, rank)
+    d = full[..., 3].astype(np.int64)
+    zlo, zhi = depth * iz // split[2], depth * (iz + 1) // split[2]
+    mine = np.zeros_like(full)
+    inrect = np.zeros((H, W), bool)
+    inrect[y0:y1, x0:x1] = True
+    own = inrect & (d > zlo) & ((d <= zhi) | (iz == split[2] - 1))
+    mine[own] = full[own]
+    if iz < split[2] - 1:
+        tie = inrect & (d > zhi) & (rng.random((H, W)) < 0.05)
+        mine[tie, 3] = full[tie, 3]          # same depth, zero normal: must lose against the front range
+    return mine
+
+
+def _worker_blocks(rank, world, port, path, split, depth):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.load(path)
+    part = torch.from_numpy(_parts_of(full, split, depth, rank, np.random.default_rng(rank)))
+    out = D.gather_blocks(part, depth, split, merge_ref, dst=0)
+    ok = torch.tensor([1])
+    if rank == 0:
+        ok[0] = int(np.array_equal(out.numpy(), full))
+    dist.broadcast(ok, src=0)
+    dist.destroy_process_group()
+    assert ok.item() == 1
+
+
+@pytest.mark.parametrize("split", [(2, 1, 1), (1, 1, 2)])
+def test_gather_blocks_two_ranks_gloo(tmp_path, oracle_mod, split):
+    import torch.multiprocessing as mp
+    O = oracle_mod
+    img = O.render3d(O.Shape.from_vm(MODEL), SIZE)[0]
+    words = img.view(np.int32).reshape(SIZE, SIZE, 4)
+    assert (words[..., 3] > SIZE // 2).any() and ((words[..., 3] > 0) & (words[..., 3] <= SIZE // 2)).any()
+    path = str(tmp_path / "frame.npy")
+    np.save(path, words)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_blocks, args=(2, port, path, split, SIZE), nprocs=2, join=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [(2, 2, 2), (2, 1, 1), (1, 1, 2), (2, 2, 1), (1, 2, 4)])
+@pytest.mark.parametrize("model", ["colonnade.vm", "prospero.vm"])
+def test_device_blocks_merge_to_the_frame(split, model):
+    """every block of the split rendered on this GPU, then the rank-0 assembly with the device merge kernel"""
+    import torch
+    import fidget_amd as F
+    shape = F.Shape.from_vm(os.path.join(ROOT, "models", model))
+    n = SIZE
+    full = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+    F.render3d(shape, n, out=full)
+    world = split[0] * split[1] * split[2]
+    rects = [D.block_rect(n, n, D.root_tile(n), split, r) for r in range(world)]
+    area = max((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in rects)
+    parts = []
+    for r in range(world):
+        part = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+        F.render3d(shape, n, out=part, block=(r, split))
+        shape.hip.sync()
+        y0, y1, x0, x1 = rects[r]
+        outside = part.clone()
+        outside[y0:y1, x0:x1] = 0
+        assert not outside.any(), f"block {r} wrote outside its rectangle"
+        send = torch.zeros((area, 4), dtype=torch.int32, device="cuda")
+        send[:(y1 - y0) * (x1 - x0)] = part[y0:y1, x0:x1].reshape(-1, 4)
+        parts.append(send)
+    out = torch.zeros_like(full)
+    D.assemble_blocks(parts, out, rects, split, n, lambda a, b, d: F.merge_depth(a, b, d, hip=shape.hip))
+    shape.hip.sync()
+    assert torch.equal(out, full), f"{int((out != full).any(dim=2).sum())} pixels differ"
