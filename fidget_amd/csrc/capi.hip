@@ -676,9 +676,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     P.roots_y = (P.height + ts[0] - 1) / ts[0];
     R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
     R.full = tape_is_full(t);
-    // assembly leaf kernels: supported opcodes only and an affine screen-to-model matrix
-    R.asm_points = ctx->use_asm && is3d && tape_asm_ok(t) && P.mat[12] == 0.0f && P.mat[13] == 0.0f && P.mat[14] == 0.0f &&
-                   P.mat[15] == 1.0f;
+    // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
+    R.asm_points = ctx->use_asm && is3d && tape_asm_ok(t);
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);

@@ -96,6 +96,7 @@ S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]   # per-slot lane mask
 S_K = "s98"
 S_ZL = "s99"
 S_HB = "s[100:101]"       # columns: handler table of the leaf's register class
+S_PROJFLAG = "s101"       # columns: bit 16 = projective screen-to-model matrix (row 3 != 0 0 0 1); (low half: workgroup id y)
 S_SLOTX, S_SLOTY, S_SLOTZ, S_RC = "s0", "s1", "s3", "s2"   # columns: input slots of x, y, z; regs | choices << 16
 S_N = "s6"              # bulk: number of samples
 S_ACT = [f"s[{8 + 2 * j}:{9 + 2 * j}]" for j in range(4)]  # bulk: lanes of slot j holding a sample
@@ -119,6 +120,7 @@ V_SQRTC = "v51"
 V_LX, V_LY = "v52", "v53"
 V_S0, V_S1, V_S2, V_S3 = "v54", "v55", "v56", "v57"
 V_IDV = "v58"
+V_AW = "v56"             # columns: m[12] * x + m[13] * y of this lane's pixel (V_S2 is free once the pixel address is formed)
 VOFF = [f"v{60 + j}" for j in range(4)]  # bulk: byte offset of sample j
 V_DEC = ["v60", "v61", "v62", "v63"]   # columns: the leaf's tape decoded, lane = op: handler address, out index, a index, word 1
 FILE = 64
@@ -513,9 +515,33 @@ class Interp:
                 a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel_hi:[1,0]")
             for k in range(self.zb // 2):
                 a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, {self.P(VU, 0)} op_sel_hi:[1,0]")
+            proj = a.label("in_proj_" + axis)
+            a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, 16\n\ts_cbranch_scc1 {proj}")
             self.idx_on(S_OUT, DST)
             for k in range(self.zb // 2):
                 a(f"\tv_pk_add_f32 {self.FP(k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+            a(f"\ts_branch {lab['done']}")
+            # projective matrix (shape/mod.rs:906-916, nalgebra transform_point): the row value divided by
+            # w = ((m[12] x + m[13] y) + m[14] z) + m[15] wherever w != 0
+            a(f"{proj}:")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+            a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
+            for j in range(self.zb):
+                a(f"\tv_cvt_f32_u32 {VU[j]}, {S_T0}")
+                if j + 1 < self.zb:
+                    a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
+            a(f"\ts_mov_b32 s96, s{m + 14}\n\ts_mov_b32 s97, s{m + 15}")
+            a(f"\tv_mov_b32 {VW[0]}, {V_AW}")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_mul_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel_hi:[1,0]")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, {self.P(VW, 0)} op_sel_hi:[1,0]")
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+            self.f_div(VT, VU, VW)
+            self.mask_pass(lambda j, mk: f"v_cmp_neq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VT[j]}, {VT[j]}, {VW[j]}, {mk}")
+            self.write_out(VT, done=False)
             if axis != "z":
                 a(f"\ts_branch {lab['done']}")
         a(f"{lab['done']}:")
@@ -749,6 +775,15 @@ def gen_columns(a, variants, off):
 	s_cmp_eq_u32 s{48 + i}, 2
 	s_cselect_b32 {S_SLOTZ}, {i}, {S_SLOTZ}""")
     a(f"""
+	; projective matrix?  row 3 != (0, 0, 0, 1)
+	s_or_b32 {S_T0}, s{m + 12}, s{m + 13}
+	s_or_b32 {S_T0}, {S_T0}, s{m + 14}
+	s_and_b32 {S_T0}, {S_T0}, 0x7fffffff
+	s_xor_b32 {S_T1}, s{m + 15}, 0x3f800000
+	s_or_b32 {S_T0}, {S_T0}, {S_T1}
+	s_cmp_lg_u32 {S_T0}, 0
+	s_cselect_b32 {S_T0}, 0x10000, 0
+	s_or_b32 {S_WGY}, {S_WGY}, {S_T0}
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
 	s_mov_b32 {S_L}, {S_LAYERS}
 	; footprints per layer, blocks of {BLK} of them
@@ -769,7 +804,8 @@ def gen_columns(a, variants, off):
 	s_cmp_eq_u32 {S_NWG}, 0
 	s_cbranch_scc0 .Lfh_columns_block
 	s_mov_b32 {S_ONE}, 1
-	s_sub_u32 {S_L}, {S_L}, {S_WGY}
+	s_and_b32 {S_T0}, {S_WGY}, 0xffff
+	s_sub_u32 {S_L}, {S_L}, {S_T0}
 	s_cbranch_scc1 .Lfh_columns_exit
 .Lfh_columns_block:
 	; ---- next block of {BLK} footprints (lane = footprint) --------------------------------------
@@ -887,6 +923,9 @@ def gen_columns(a, variants, off):
 	v_mul_f32 {V_AZ}, s{m + 8}, {V_PXF}
 	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
 	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
+	v_mul_f32 {V_AW}, s{m + 12}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 13}, {V_PYF}
+	v_add_f32 {V_AW}, {V_AW}, {V_S0}
 	v_mov_b32 {V_IDV}, {S_ID}
 	s_waitcnt vmcnt(0)
 	; pending = depth < lz + 8  (voxel.rs:377-381)

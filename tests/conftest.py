@@ -9,6 +9,13 @@ import sys
 
 import pytest
 
+try:
+    # torch bundles its own ROCm runtime: it has to be loaded before libfidget_hip.so pulls in the system one, or
+    # torch.cuda finds "no HIP GPUs" later in the same process (tests that hand torch CUDA tensors to the library)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,89 @@
+"""fh_columns (the assembly leaf interpreter: f32 point evaluation of 8x8x8 voxel leaves, z-buffer by 64-bit atomic max) on
+the CPU emulator against a numpy evaluation of the same tape at the same voxels (tests/emu_util.py ref_f32, which follows
+fidget-core/src/vm/mod.rs:794-1086 via dev_ops.hpp; the voxel -> model transform is dev_ops.hpp xf_point, i.e. nalgebra's
+transform_point as shape/mod.rs:906-916 calls it): depth words bit for bit, affine AND projective matrices."""
+import numpy as np
+import pytest
+
+import emu_util as U
+from emu_util import E, F32, U32
+from test_emu_tiles import shape_of
+
+
+def xf_point(m, x, y, z):
+    m = m.astype(F32)
+    x, y, z = (np.asarray(v, F32) for v in (x, y, z))
+    rows = [((m[4 * r] * x + m[4 * r + 1] * y) + m[4 * r + 2] * z) + m[4 * r + 3] for r in range(4)]
+    with np.errstate(all="ignore"):
+        return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
+
+
+def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0):
+    off = U.offsets()
+    mem = E.Memory()
+    arena = np.zeros(4096, np.uint64)
+    arena[16:16 + len(tape)] = tape
+    a_arena = mem.map(arena)
+    nfp = (size // 8) ** 2
+    layers = size // 8
+    table = np.zeros(layers * nfp, U32)
+    leaves = np.zeros((4, 6), U32)
+    lx, ly, lz = leaf_xyz
+    leaves[0] = [16, len(tape), n_regs | (n_choices << 16), lx, ly, lz]
+    table[(lz % size) // 8 * nfp + (ly // 8) * (size // 8) + lx // 8] = 1
+    zbuf = np.zeros(size * size, np.uint64) if zbuf_init is None else zbuf_init.copy()
+    a_tab, a_leaves, a_z = mem.map(table), mem.map(leaves), mem.map(zbuf)
+    st = U.Blob(off["sizeof_state"])
+    st.arr(off["P.mat"], np.asarray(mat, F32))
+    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
+    st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
+    a_st = mem.map(st.b)
+    ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, 0], U32)
+    waves = E.launch(U.program(), mem, "fh_columns", ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=128)
+    return zbuf, waves
+
+
+def expect(tape, in_kind, mat, leaf_xyz, size, zbuf_init=None):
+    lx, ly, lz = leaf_xyz
+    z0 = np.zeros(size * size, np.uint64) if zbuf_init is None else zbuf_init.copy()
+    for py in range(ly, min(ly + 8, size)):
+        for px in range(lx, min(lx + 8, size)):
+            i = py * size + px
+            if (int(z0[i]) >> 32) >= lz + 8:
+                continue
+            zs = np.arange(lz + 7, lz - 1, -1)
+            X, Y, Z = xf_point(np.asarray(mat, F32), np.full(8, px), np.full(8, py), zs)
+            inputs = {s: (X, Y, Z)[k] for s, k in enumerate(in_kind) if k < 3}
+            v = U.ref_f32(tape, inputs, 8)[0]
+            hit = np.nonzero(v < 0)[0]
+            if len(hit):
+                z0[i] = max(int(z0[i]), ((int(zs[hit[0]]) + 1) << 32) | 1)
+    return z0
+
+
+AFFINE = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0, 0, 0, 1]                 # screen_to_world of a 16^3 volume
+ROTATED = [0.1, 0.05, 0.02, -1.1, -0.04, -0.11, 0.03, 0.9, 0.01, 0.02, 0.12, -0.95, 0, 0, 0, 1]
+PERSPECTIVE = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0.01, -0.005, 0.0375, 0.7]   # w = 0.7 + ... (never 0 here)
+W_ZERO = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0, 0, 0.125, -1.0]              # w = z/8 - 1: exactly 0 at z = 8
+
+
+@pytest.mark.parametrize("mat", [AFFINE, ROTATED, PERSPECTIVE, W_ZERO], ids=["affine", "rotated", "perspective", "w_zero"])
+@pytest.mark.parametrize("seed", [0, 2, 3, 5])
+def test_leaf_against_numpy(seed, mat):
+    sh, tape, ik = shape_of(seed)
+    if sh.slot_count() > 32:
+        pytest.skip("needs the LDS leaf kernel")
+    for leaf in ((0, 8, 0), (8, 0, 8)):
+        got, waves = run_columns(tape, sh.slot_count(), ik, mat, leaf)
+        want = expect(tape, ik, mat, leaf, 16)
+        assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+
+
+def test_occluded_pixels_are_left_alone():
+    sh, tape, ik = shape_of(0)
+    z = np.zeros(256, np.uint64)
+    z[0:128] = np.uint64((16 << 32) | 7)     # front rows already hit by a nearer leaf
+    got, _ = run_columns(tape, sh.slot_count(), ik, AFFINE, (0, 0, 0), zbuf_init=z)
+    assert (got == expect(tape, ik, AFFINE, (0, 0, 0), 16, z)).all()
