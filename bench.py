@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--model", default="prospero.vm")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
@@ -88,15 +88,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    frame_ms = []
+
     def timed(step):
         for _ in range(args.warmup):
             step()
         fence()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record(stream)
+        for i in range(args.steps):
             step()
+            marks[i + 1].record(stream)      # (an event record costs ~1 us on the stream; the frames still queue back to back)
         fence()
         dt = time.perf_counter() - t0
+        frame_ms[:] = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,7 +160,8 @@ def main():
     result = {
         "metric": "Mvoxel/s (interval+point eval) on prospero.vm 1024^3",
         "value": value, "unit": "Mvoxel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(frame_ms)), "ms_per_step_min": float(np.min(frame_ms)),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
                    "sharding": sharding},
@@ -170,28 +177,43 @@ def main():
     if not args.no_cpu and world == 1:
         import oracle as O
         oshape = O.Shape.from_vm(os.path.join(ROOT, "models", args.model))
-        ref, st, secs = O.render3d(oshape, n)
+        ref, st, _ = O.render3d(oshape, n)                     # warm-up frame (also the parity reference)
         got = out.cpu().numpy().view(np.uint32).reshape(n, n, 4)
         want = ref.view(np.uint32).reshape(n, n, 4)
         result["parity"] = {"depth_equal": bool((got[..., 3] == want[..., 3]).all()),
                             "normals_equal": bool((got[..., :3].view(np.float32) == want[..., :3].view(np.float32)).all())}
         cores = O.max_threads()
-        result["cpu_baseline"] = {"value": (n ** 3) / secs / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
-                                  "sample": f"one full {n}^3 frame ({secs:.2f} s wall on {cores} threads); C++ restatement of "
-                                            "the reference VmShape interpreter path, not the Rust JIT (published JIT/VM ratio "
-                                            "on M1 Max: 61.7/23.6 = 2.6x, README.md:154)"}
+        CPU_FRAMES = 10
+        secs = sorted(O.render3d(oshape, n)[2] for _ in range(CPU_FRAMES))
+        med = float(np.median(secs))
+        small = max(n // 4, 64)
+        O.render3d(oshape, small, threads=1)
+        one = float(np.median([O.render3d(oshape, small, threads=1)[2] for _ in range(3)]))
+        result["cpu_baseline"] = {"value": (n ** 3) / med / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+                                  "sample": f"median of {CPU_FRAMES} full {n}^3 frames after one warm-up frame ({med:.3f} s each, min {secs[0]:.3f}, "
+                                            f"on {cores} threads); C++ restatement of the reference VmShape interpreter path (OpenMP over root "
+                                            "tiles like render_tiles' rayon pool), not the Rust JIT (published JIT/VM ratio on M1 Max: "
+                                            "61.7/23.6 = 2.6x, README.md:154)",
+                                  "one_thread": {"value": (small ** 3) / one / 1e6, "unit": "Mvoxel/s", "cores": 1,
+                                                 "sample": f"median of 3 frames at {small}^3 (1/{(n // small) ** 3} of the volume), one thread"}}
         # ---- roofline ---------------------------------------------------------------
         # Algorithmic bytes: 8 B per tape word read per wavefront pass + 8 B per tape word written
         # + 2 bit per recorded choice + the W*H*16 B image once.  The tile stage's op counts come
         # from the device's own counters (its subdivision 128/32/8 differs from the oracle's
         # 128/64/32/16/8 schedule; pruning is deterministic, so they are exact for this frame);
         # the leaf stage's from the oracle (same leaves, same pruned tapes).
-        # HBM traffic per launch: rocprofv3 PMC passes, committed under profiles/ (counters cannot
-        # be collected inside the timed run); FETCH_SIZE doubled per MI355X_MICROARCH.md.
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        # HBM traffic per launch: rocprofv3 PMC passes of tools/profile_round.sh, committed under profiles/ (counters cannot
+        # be collected inside the timed run); the file names the hash of the device sources it was measured on and is
+        # ignored (traffic = null) when that is not this build.  FETCH_SIZE doubled per MI355X_MICROARCH.md.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from src_hash import source_hash
+        traffic, traffic_note = {}, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))
+            if traffic.get("source_hash") != source_hash():
+                traffic_note = f"profiles/traffic_r02.json was measured on sources {traffic.get('source_hash')}, this build is {source_hash()}: traffic not reported"
+                traffic = {}
 
         def roof(kernel, alg_bytes, k_ms, launches, note):
             # the kernel's own launches, each timed with HIP events on its stream (profiled frames); these
@@ -203,25 +225,33 @@ def main():
             tb = None
             if t:
                 tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
-            return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
-                    "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1), "avg_launch_ms": k_ms / max(launches, 1),
-                    "launches_per_frame": launches, "note": note}
+            r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
+                 "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1), "avg_launch_ms": k_ms / max(launches, 1),
+                 "launches_per_frame": launches, "note": note}
+            if t and "valu_per_launch" in t and k_ms > 0:
+                # the bound that actually holds: wave-instructions issued per SIMD per cycle against the ceiling the
+                # micro-benchmarks give for independent VALU work at 4 waves per SIMD (profiles/r02/ubench.json)
+                cycles = k_ms / max(launches, 1) * 1e-3 * t.get("clock_hz", 2.4e9)
+                ipc = (t["valu_per_launch"] + t["salu_per_launch"]) / (cycles * 1024)
+                r["issue"] = {"bound": "instruction issue", "achieved": ipc, "peak": 0.57, "unit": "wave-instructions / cycle / SIMD",
+                              "frac": ipc / 0.57, "valu_per_launch": t["valu_per_launch"], "salu_per_launch": t["salu_per_launch"]}
+            if traffic_note:
+                r["traffic_note"] = traffic_note
+            return r
 
         kms, kl = result["kernel_ms_per_frame"], result["kernel_launches_per_frame"]
-        # dominant kernel by total time (profiles/: rocprofv3 --stats): fh_tiles, the tile stage's
-        # forward-interval + prune interpreter (its time below includes fh_prune1 and the set-up /
-        # push kernels of the stage, all measured together with HIP events on the render stream)
-        ops_in = sum(v["ops"] for v in tile_phases.values())
-        ops_out = sum(v["ops_written"] for v in tile_phases.values())
-        tile_bytes = 8.0 * (ops_in + ops_out) + st["interval_choices"] / 4.0
-        result["roofline"] = roof("fh_tiles", tile_bytes, kms["tiles"], traffic.get("fh_tiles", {}).get("launches_per_frame", 20),
-                                  "bound by the latency of dependent tape ops and by scalar instruction issue (one interval op "
-                                  "per ~340 cycles per wave), far from any HBM limit: see DESIGN.md sections 4 and 6")
+        # dominant kernel by total time (profiles/: rocprofv3 --stats): fh_columns, the leaf interpreter, since the tile
+        # stage moved to the VGPR kernels; `roofline_tiles` covers fh_tiles_v32 (the per-slab tile stage)
         leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
-        result["roofline_leaf"] = roof("fh_columns", leaf_bytes, kms["points"], traffic.get("fh_columns", {}).get("launches_per_frame", 8),
-                                       "tape words are wave-uniform loads served by the scalar cache / L2: the leaf kernel "
-                                       "is bound by instruction issue, not by HBM")
+        result["roofline"] = roof("fh_columns", leaf_bytes, kms["points"], 8,
+                                  "tape words are wave-uniform loads served by L2: the leaf interpreter is bound by instruction "
+                                  "issue (see `issue`), not by HBM: DESIGN.md sections 4 and 6")
+        lv = [v for k, v in tile_phases.items() if int(k[1:]) >= 2]
+        tile_bytes = 8.0 * (sum(v["ops"] for v in lv) + sum(v["ops_written"] for v in lv))
+        result["roofline_tiles"] = roof("fh_tiles_v32", tile_bytes, kms["tiles"], 8,
+                                        "interval interpreter + lockstep prune with the register file in VGPRs: bound by the "
+                                        "latency of each parent's dependent op chain (one wave per parent)")
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
     print(json.dumps(result))

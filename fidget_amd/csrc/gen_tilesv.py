@@ -47,7 +47,12 @@ S_N = "s50"                # ops of the current chunk
 S_SENT = "s51"             # sentinel handler code of the current chunk
 S_PBASE = "s[52:53]"       # prune: jump table of the op classes
 S_JMP = "s[54:55]"         # dispatch target (s55 = s43: high half of the code address)
-S_CHUNK = "s56"            # prune: chunk index
+S_CHUNK = "s3"             # prune: chunk index
+S_OUTM = "s[56:57]"        # prune: lanes of the current chunk holding OUTPUT ops
+S_ANYLIVE = "s[72:73]"     # prune: old registers that are mapped (map[r] != DEAD) in at least one lane
+S_CBASE = "s17"            # prune: choice ops before the current chunk
+S_CWI = "s18"              # prune: index of the choice word held in V_CWP
+HL = 9                     # forward handler slots of 512 bytes: the hot bodies and a copy of the dispatcher sit inline
 S_M8 = "s[58:59]"          # -8 as a 64-bit integer
 S_BIDX = "s60"             # prune: register b (word 1 of reg,reg ops)
 S_AEQB = "s61"
@@ -59,6 +64,7 @@ V_DEAD = "v39"
 PW = ("v40", "v41")        # raw tape chunk in flight (lane = op)
 # prune (the forward pass' operands are dead by then)
 V_PH, V_PW0, V_PW1 = "v30", "v31", "v32"   # decoded chunk: class jump, word 0, word 1
+V_PO, V_PCI = "v42", "v43"                 # ... output register, index of the op's choice (choice ops before it)
 PO = ["v4", "v5"]          # free-register pool, 32 registers per word, 1 = free
 V_HIGH, V_COUNT, V_KEPT, V_NO = "v6", "v7", "v8", "v9"
 V_MAV, V_MBV, V_AV, V_CWP = "v10", "v11", "v12", "v13"
@@ -94,12 +100,42 @@ class TilesV(Tiles):
         return f"v[{self.FILE}:{self.FILE + 1}]"
 
     # ---- helpers -------------------------------------------------------------------------------------
+    def dispatch(self):
+        """fetch the next op of the decoded chunk and jump to its handler with A = file[a] loaded.  (Every handler leaves the
+        index mode off, destination- or src2-relative: v_readlane only honours SRC0-relative mode, tools/probe_isa.py.)
+        A copy sits at the end of every handler: one taken jump per op (21-31 cycles each, profiles/r02/ubench.json)."""
+        self.a(f"""
+	v_readlane_b32 s54, {DEC[0]}, {S_K}
+	v_readlane_b32 {S_OUT}, {DEC[1]}, {S_K}
+	v_readlane_b32 {S_A}, {DEC[2]}, {S_K}
+	v_readlane_b32 {S_W1}, {DEC[3]}, {S_K}
+	s_add_u32 {S_K}, {S_K}, 1
+	s_set_gpr_idx_on {S_A}, {SRC0 | SRC1}
+	v_pk_mov_b32 v[10:11], {self.F()}, {self.F()} op_sel:[0,1]
+	s_setpc_b64 {S_JMP}""")
+
     def done(self):
         """file[out] = R, next op"""
         self.a(f"""
 	s_set_gpr_idx_on {S_OUT}, {DST}
+	v_pk_mov_b32 {self.F()}, v[14:15], v[14:15] op_sel:[0,1]""")
+        self.dispatch()
+
+    def choice_done(self):
+        """file[out] = R; the choice in {V_C} (2 bits) goes straight into its word of the choice file (16 to a word, the file
+        is zeroed per slot); next op"""
+        self.a(f"""
+	v_cmp_ne_u32_e64 {S_MA}, 3, {V_C}
+	s_set_gpr_idx_on {S_OUT}, {DST}
 	v_pk_mov_b32 {self.F()}, v[14:15], v[14:15] op_sel:[0,1]
-	s_branch {self.next}""")
+	s_and_b32 {S_T0}, {S_CI}, 15
+	s_lshl_b32 {S_T1}, {S_T0}, 1
+	s_lshr_b32 {S_T2}, {S_CI}, 4
+	s_set_gpr_idx_on {S_T2}, {SRC2 | DST}
+	v_lshl_or_b32 v{self.CHF}, {V_C}, {S_T1}, v{self.CHF}
+	s_add_u32 {S_CI}, {S_CI}, 1
+	s_or_b64 {S_DECIDED}, {S_DECIDED}, {S_MA}""")
+        self.dispatch()
 
     def load_b(self):
         self.a(f"""
@@ -118,7 +154,12 @@ class TilesV(Tiles):
 	v_mov_b32 {AL}, {S_W1}
 	v_mov_b32 {AH}, {S_W1}""")
 
+    INLINE = {"abs", "square", "sqrt", "mul", "mulimm", "min", "max", "and", "or", "input"}
+
     def ool_body(self, stem, fn):
+        """the body of a handler: inline (hot ops: the slot is large enough) or out of line (one more taken branch)"""
+        if stem in self.INLINE:
+            return fn()
         lab = f"{self.p}_b_{stem}"
         if not any(l == lab for l, _ in self.ool):
             self.ool.append((lab, fn))
@@ -128,14 +169,14 @@ class TilesV(Tiles):
     def handler(self, op):
         a = self.a
         if op == "OUTPUT":
-            a(f"\ts_set_gpr_idx_off\n\tv_mov_b32 {V_RESL}, {AL}\n\tv_mov_b32 {V_RESH}, {AH}\n\ts_branch {self.next}")
-            return
+            a(f"\ts_set_gpr_idx_off\n\tv_mov_b32 {V_RESL}, {AL}\n\tv_mov_b32 {V_RESH}, {AH}")
+            return self.dispatch()
         if op == "INPUT":
             a("\ts_set_gpr_idx_off")
             return self.ool_body("input", self.h_input)
         if op == "COPY_REG":
-            a(f"\ts_set_gpr_idx_on {S_OUT}, {DST}\n\tv_pk_mov_b32 {self.F()}, v[10:11], v[10:11] op_sel:[0,1]\n\ts_branch {self.next}")
-            return
+            a(f"\ts_set_gpr_idx_on {S_OUT}, {DST}\n\tv_pk_mov_b32 {self.F()}, v[10:11], v[10:11] op_sel:[0,1]")
+            return self.dispatch()
         if op == "COPY_IMM":
             a(f"\ts_set_gpr_idx_off\n\tv_mov_b32 {RL}, {S_W1}\n\tv_mov_b32 {RH}, {S_W1}")
             return self.done()
@@ -189,10 +230,7 @@ class TilesV(Tiles):
                 self.b_minmax(base == "MIN")
             else:
                 self.b_andor(base == "AND")
-            a(f"""
-	s_set_gpr_idx_on {S_OUT}, {DST}
-	v_pk_mov_b32 {self.F()}, v[14:15], v[14:15] op_sel:[0,1]
-	s_branch {self.p}_choice""")
+            self.choice_done()
         return self.ool_body(base.lower(), cbody)
 
     # ---- fetch of a tape chunk: lanes 0 .. n-1 load op k of the chunk at S_CB --------------------------
@@ -236,7 +274,7 @@ class TilesV(Tiles):
 	v_lshlrev_b32 {DEC[2]}, 1, {T[2]}
 	v_subrev_u32 {T[3]}, 22, {T[0]}
 	v_cmp_gt_u32 vcc, 12, {T[3]}
-	v_lshlrev_b32 {T[0]}, {HSTRIDE_LOG2}, {T[0]}
+	v_lshlrev_b32 {T[0]}, {HL}, {T[0]}
 	v_add_u32 {DEC[0]}, s42, {T[0]}
 	v_cndmask_b32 {DEC[3]}, {PW[1]}, {T[4]}, vcc
 	s_cmp_eq_u32 {S_REM}, 0
@@ -248,57 +286,32 @@ class TilesV(Tiles):
         a(f"""
 {p}_nofetch:
 	s_mov_b32 {S_K}, 0
-{self.next}:
-	; (every handler leaves the index mode off or destination-relative, which v_readlane ignores: tools/probe_isa.py)
-	v_readlane_b32 s54, {DEC[0]}, {S_K}
-	v_readlane_b32 {S_OUT}, {DEC[1]}, {S_K}
-	v_readlane_b32 {S_A}, {DEC[2]}, {S_K}
-	v_readlane_b32 {S_W1}, {DEC[3]}, {S_K}
-	s_add_u32 {S_K}, {S_K}, 1
-	s_set_gpr_idx_on {S_A}, {SRC0 | SRC1}
-	v_pk_mov_b32 v[10:11], {self.F()}, {self.F()} op_sel:[0,1]
-	s_setpc_b64 {S_JMP}
+{self.next}:""")
+        self.dispatch()
+        a(f"""
 {p}_done:
 	s_set_gpr_idx_off
 	s_setpc_b64 {S_RET}
-; ---- record the choice in {V_C} (2 bits, 16 to a word; a full word goes to the choice file) ----------------
-{p}_choice:
-	s_set_gpr_idx_off
-	v_cmp_ne_u32_e64 {S_MA}, 3, {V_C}
-	s_and_b32 {S_T0}, {S_CI}, 15
-	s_lshl_b32 {S_T1}, {S_T0}, 1
-	v_lshl_or_b32 {V_CW}, {V_C}, {S_T1}, {V_CW}
-	s_add_u32 {S_CI}, {S_CI}, 1
-	s_or_b64 {S_DECIDED}, {S_DECIDED}, {S_MA}
-	s_cmp_eq_u32 {S_T0}, 15
-	s_cbranch_scc0 {self.next}
-	s_lshr_b32 {S_T0}, {S_CI}, 4
-	s_sub_u32 {S_T0}, {S_T0}, 1
-	s_set_gpr_idx_on {S_T0}, {DST}
-	v_mov_b32 v{self.CHF}, {V_CW}
-	s_set_gpr_idx_off
-	v_mov_b32 {V_CW}, 0
-	s_branch {self.next}
-	.p2align {HSTRIDE_LOG2}
+	.p2align {HL}
 {p}_handlers:""")
         for i in range(64):
-            a(f"\t.p2align {HSTRIDE_LOG2}")
+            a(f"\t.p2align {HL}")
             a(f"{p}_h{i}:")
             if i == CODE_REFILL:
                 a(f"\ts_branch {p}_refill")
             elif i == CODE_DONE:
                 a(f"\ts_branch {p}_done")
             elif i >= len(OPS):
-                a(f"\ts_branch {self.next}")
+                self.dispatch()
             else:
                 op = OPS[i]
                 base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
                 if base in UNSUPPORTED:
-                    a(f"\ts_branch {self.next}")
+                    self.dispatch()
                 else:
                     self.handler(op)
-            a(f"\t.if (. - {p}_h{i}) > {1 << HSTRIDE_LOG2}\n\t.error \"tile handler {i} of {self.name} exceeds its slot\"\n\t.endif")
-        a(f"\t.p2align {HSTRIDE_LOG2}")
+            a(f"\t.if (. - {p}_h{i}) > {1 << HL}\n\t.error \"tile handler {i} of {self.name} exceeds its slot\"\n\t.endif")
+        a(f"\t.p2align {HL}")
         for lab, fn in self.ool:
             a(f"{lab}:")
             fn()
@@ -347,9 +360,11 @@ class TilesV(Tiles):
         """dst = map[sreg] (leaves the index mode off)"""
         self.a(f"\ts_set_gpr_idx_on {sreg}, {SRC0}\n\tv_mov_b32 {dst}, v{self.FILE}\n\ts_set_gpr_idx_off")
 
-    def map_write(self, sreg, src):
-        """map[sreg] = src for the lanes in exec"""
-        self.a(f"\ts_set_gpr_idx_on {sreg}, {DST}\n\tv_mov_b32 v{self.FILE}, {src}\n\ts_set_gpr_idx_off")
+    def map_write(self, sreg, src, live=True):
+        """map[sreg] = src for the lanes in exec (non-empty).  live: src is a register number (some lane now maps sreg);
+        otherwise DEAD written to every lane that mapped it (nobody maps it any more)"""
+        bit = "s_bitset1_b64" if live else "s_bitset0_b64"
+        self.a(f"\ts_set_gpr_idx_on {sreg}, {DST}\n\tv_mov_b32 v{self.FILE}, {src}\n\ts_set_gpr_idx_off\n\t{bit} {S_ANYLIVE}, {sreg}")
 
     def alloc_where_dead(self, val, sreg, within):
         """lanes of `within` (= exec) whose map value `val` is DEAD take a fresh register (written back to map[sreg])"""
@@ -374,20 +389,19 @@ class TilesV(Tiles):
 	global_store_dwordx2 {V_DST}, v[14:15], off""")
 
     def head(self, has_choice):
-        """common head of the op classes: the choice (if any), no = map[out]; lanes where it is live -> exec, map[out] = DEAD"""
+        """common head of the op classes (exec = all lanes): the choice (if any), no = map[out]; the lanes where it is live
+        -> exec (never empty: only ops whose output some lane wants are visited), map[out] = DEAD there"""
         a, p = self.a, self.p
         if has_choice:
-            reload, have = self.lab("cw_reload"), self.lab("cw_have")
+            have = self.lab("cw_have")
             a(f"""
-	s_sub_u32 {S_CI}, {S_CI}, 1
-	s_and_b32 {S_T0}, {S_CI}, 15
-	s_cmp_eq_u32 {S_T0}, 15
-	s_cbranch_scc1 {reload}
-	s_add_u32 {S_T2}, {S_CI}, 1
-	s_cmp_eq_u32 {S_T2}, {S_NCH}
-	s_cbranch_scc0 {have}
-{reload}:
+	v_readlane_b32 {S_CI}, {V_PCI}, {S_K}
+	s_nop 0
 	s_lshr_b32 {S_T1}, {S_CI}, 4
+	s_and_b32 {S_T0}, {S_CI}, 15
+	s_cmp_eq_u32 {S_T1}, {S_CWI}
+	s_cbranch_scc1 {have}
+	s_mov_b32 {S_CWI}, {S_T1}
 	s_set_gpr_idx_on {S_T1}, {SRC0}
 	v_mov_b32 {V_CWP}, v{self.CHF}
 	s_set_gpr_idx_off
@@ -397,10 +411,9 @@ class TilesV(Tiles):
         self.map_read(V_NO, S_OUT)
         a(f"""
 	v_cmp_ne_u32_e64 {S_LIVE}, {V_DEAD}, {V_NO}
-	s_cmp_eq_u64 {S_LIVE}, 0
-	s_cbranch_scc1 {p}_pnext
+	s_nop 0
 	s_mov_b64 exec, {S_LIVE}""")
-        self.map_write(S_OUT, V_DEAD)
+        self.map_write(S_OUT, V_DEAD, live=False)
 
     def ew0(self, opcode, a_reg=None):
         """EW0 = opcode | no << 8 [| a_reg << 20]"""
@@ -474,21 +487,49 @@ class TilesV(Tiles):
         self.emit_op()
         a(f"{done}:")
 
+    def pnext(self):
+        """Next op of the sweep: the highest op below {S_K} in the current chunk whose output register is mapped in some lane
+        (or that is an OUTPUT).  Everything in between is dead in every lane and is never looked at: their outputs are not
+        wanted now, and nothing is visited in between that could make them wanted."""
+        a, p = self.a, self.p
+        a(f"""
+	s_mov_b64 exec, -1
+	v_lshrrev_b64 v[16:17], {V_PO}, {S_ANYLIVE}
+	s_bfm_b64 {S_SAVE}, {S_K}, 0
+	v_and_b32 v16, 1, v16
+	v_cmp_ne_u32_e64 {S_T64}, 0, v16
+	s_or_b64 {S_T64}, {S_T64}, {S_OUTM}
+	s_and_b64 {S_T64}, {S_T64}, {S_SAVE}
+	s_cbranch_scc0 {p}_pchunk
+	s_flbit_i32_b64 {S_K}, {S_T64}
+	s_sub_u32 {S_K}, 63, {S_K}
+	v_readlane_b32 {S_W0}, {V_PW0}, {S_K}
+	v_readlane_b32 {S_W1}, {V_PW1}, {S_K}
+	v_readlane_b32 s54, {V_PH}, {S_K}
+	s_and_b32 {S_OP}, {S_W0}, 0xff
+	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
+	s_lshr_b32 {S_A}, {S_W0}, 20
+	s_setpc_b64 {S_JMP}""")
+
     # ---- prune sweep -------------------------------------------------------------------------------------------
     def emit_prune(self):
         a, p = self.a, self.p
         a(f"""
 ; ---- prune sweep: ops {S_LEN}-1 .. 0 of the tape at {S_TAPE} for the lanes {S_PRUNE}; returns to {S_RET} --------------
 {p}_prune:
-	s_mov_b32 {S_CI}, {S_NCH}
+	s_mov_b32 s55, s53
 	v_mov_b32 {V_COUNT}, 0
 	v_mov_b32 {V_KEPT}, 0
 	v_mov_b32 {V_HIGH}, 0
-	v_mov_b32 {V_CWP}, 0""")
+	v_mov_b32 {V_CWP}, 0
+	s_mov_b32 {S_CWI}, -1
+	s_mov_b64 {S_ANYLIVE}, 0
+	s_mov_b32 {S_CBASE}, {S_NCH}""")
         for w in range(self.W):
             a(f"\tv_mov_b32 {PO[w]}, -1")
         for r in range(self.nr):          # the (dead) interval file becomes the register map
             a(f"\tv_mov_b32 v{self.FILE + r}, {V_DEAD}")
+        off = lambda k: f"{p}_k_{k} - {p}_classes"
         a(f"""
 	; last chunk first
 	s_add_u32 {S_T0}, {S_LEN}, {CHUNK - 1}
@@ -504,32 +545,46 @@ class TilesV(Tiles):
         self.fetch(S_N)
         a(f"""
 {p}_prefill:
-	; ---- decode the chunk that has arrived: class jump per op; ask for the chunk below it --------------------------
+	; ---- decode the chunk that has arrived (lane = op): class handler, output register, choice index; ask for the chunk below
 	s_waitcnt vmcnt(0)
 	v_and_b32 {T[0]}, 0xff, {PW[0]}
 	v_mov_b32 {V_PW0}, {PW[0]}
 	v_mov_b32 {V_PW1}, {PW[1]}
-	v_mov_b32 {T[1]}, 3                                   ; class 3: one register operand
-	v_cmp_eq_u32_e64 {S_M[0]}, 0, {T[0]}
-	v_cmp_eq_u32_e64 {S_M[1]}, 2, {T[0]}
+	v_bfe_u32 {V_PO}, {PW[0]}, 8, 12
+	v_cmp_gt_u32_e64 {S_SAVE}, {S_N}, {V_LANE}            ; lanes holding an op
+	v_cmp_eq_u32_e64 {S_M[0]}, 0, {T[0]}                  ; OUTPUT
+	v_mov_b32 {T[1]}, {off('a')}                          ; default class: one register operand
+	v_mov_b32 v27, {off('out')}
+	v_cmp_eq_u32_e64 {S_M[1]}, 2, {T[0]}                  ; COPY_REG
 	v_and_b32 {T[2]}, 0xfd, {T[0]}
-	v_subrev_u32 {T[3]}, 22, {T[0]}
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 0, {S_M[0]}          ; OUTPUT
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v27, {S_M[0]}
+	s_and_b64 {S_OUTM}, {S_M[0]}, {S_SAVE}
+	v_mov_b32 v27, {off('copy')}
 	v_cmp_eq_u32_e64 {S_M[2]}, 1, {T[2]}                  ; INPUT (1), COPY_IMM (3)
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 2, {S_M[1]}          ; COPY_REG
+	v_subrev_u32 {T[3]}, 22, {T[0]}
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v27, {S_M[1]}
+	v_mov_b32 v27, {off('none')}
 	v_cmp_gt_u32_e64 {S_M[0]}, 8, {T[3]}                  ; 22 .. 29: reg,reg, no choice
-	v_subrev_u32 v27, 30, {T[0]}
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 1, {S_M[2]}
-	v_cmp_gt_u32_e64 {S_M[1]}, 4, v27                     ; 30 .. 33: choice reg,reg
+	v_subrev_u32 v28, 30, {T[0]}
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v27, {S_M[2]}
+	v_mov_b32 v27, {off('rr')}
+	v_cmp_gt_u32_e64 {S_M[1]}, 4, v28                     ; 30 .. 33: choice reg,reg
 	v_subrev_u32 v28, 42, {T[0]}
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 4, {S_M[0]}
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v27, {S_M[0]}
+	v_mov_b32 v27, {off('crr')}
 	v_cmp_gt_u32_e64 {S_M[2]}, 4, v28                     ; 42 .. 45: choice reg,imm
-	s_nop 0
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 5, {S_M[1]}
-	s_nop 0
-	v_cndmask_b32_e64 {T[1]}, {T[1]}, 6, {S_M[2]}
-	v_lshlrev_b32 {T[1]}, 2, {T[1]}
+	v_mov_b32 v28, {off('cri')}
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v27, {S_M[1]}
+	s_or_b64 {S_T64}, {S_M[1]}, {S_M[2]}                  ; choice ops of the chunk
+	s_and_b64 {S_T64}, {S_T64}, {S_SAVE}
+	v_cndmask_b32_e64 {T[1]}, {T[1]}, v28, {S_M[2]}
 	v_add_u32 {V_PH}, s52, {T[1]}
+	; choice index of an op = choice ops before it in the tape: those below this chunk + those below it in the chunk
+	s_bcnt1_i32_b64 {S_T0}, {S_T64}
+	s_sub_u32 {S_CBASE}, {S_CBASE}, {S_T0}
+	v_mbcnt_lo_u32_b32 {V_PCI}, s76, 0
+	v_mbcnt_hi_u32_b32 {V_PCI}, s77, {V_PCI}
+	v_add_u32 {V_PCI}, {S_CBASE}, {V_PCI}
 	s_mov_b32 {S_K}, {S_N}
 	s_cmp_eq_u32 {S_CHUNK}, 0
 	s_cbranch_scc1 {p}_pnext
@@ -537,19 +592,9 @@ class TilesV(Tiles):
 	s_subb_u32 s49, s49, 0
 	s_mov_b32 {S_T3}, {CHUNK}""")
         self.fetch(S_T3)
+        a(f"{p}_pnext:")
+        self.pnext()
         a(f"""
-{p}_pnext:
-	s_mov_b64 exec, -1
-	s_sub_u32 {S_K}, {S_K}, 1
-	s_cbranch_scc1 {p}_pchunk
-	v_readlane_b32 {S_W0}, {V_PW0}, {S_K}
-	v_readlane_b32 {S_W1}, {V_PW1}, {S_K}
-	v_readlane_b32 s54, {V_PH}, {S_K}
-	s_and_b32 {S_OP}, {S_W0}, 0xff
-	s_bfe_u32 {S_OUT}, {S_W0}, 0xc0008
-	s_lshr_b32 {S_A}, {S_W0}, 20
-	s_mov_b32 s55, s53
-	s_setpc_b64 {S_JMP}
 {p}_pchunk:
 	s_sub_u32 {S_CHUNK}, {S_CHUNK}, 1
 	s_cbranch_scc1 {p}_pdone
@@ -560,13 +605,6 @@ class TilesV(Tiles):
 	s_setpc_b64 {S_RET}
 	.p2align 6
 {p}_classes:
-	s_branch {p}_k_out
-	s_branch {p}_k_none
-	s_branch {p}_k_copy
-	s_branch {p}_k_a
-	s_branch {p}_k_rr
-	s_branch {p}_k_crr
-	s_branch {p}_k_cri
 ; ---- class: OUTPUT.  every lane being pruned needs its operand -----------------------------------------------------
 {p}_k_out:
 	s_mov_b64 exec, {S_PRUNE}""")
@@ -576,27 +614,27 @@ class TilesV(Tiles):
 	v_lshlrev_b32 {V_EW0}, 20, {V_MAV}
 	v_mov_b32 {V_EW1}, {S_W1}""")
         self.emit_op()
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: no register operand (INPUT, COPY_IMM) ------------------------------------------------------------------\n{p}_k_none:")
         self.head(False)
         self.pool_give(V_NO)
         self.ew0(S_OP)
         a(f"\tv_mov_b32 {V_EW1}, {S_W1}")
         self.emit_op()
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: one register operand (unary, reg (op) imm, imm (op) reg) ----------------------------------------------\n{p}_k_a:")
         self.head(False)
         self.keep_path(S_LIVE, False, False)
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: two register operands ------------------------------------------------------------------------------------\n{p}_k_rr:")
         self.head(False)
         self.keep_path(S_LIVE, True, False)
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: COPY_REG: out is a ------------------------------------------------------------------------------------------\n{p}_k_copy:")
         self.head(False)
         a(f"\ts_mov_b64 {S_ALIAS}, {S_LIVE}")
         self.alias_path(S_LIVE, None)
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: min / max / and / or, reg,reg ---------------------------------------------------------------------------------\n{p}_k_crr:")
         self.head(True)
         nokeep, noalias = self.lab("crr_nokeep"), self.lab("crr_noalias")
@@ -616,7 +654,7 @@ class TilesV(Tiles):
 	s_cbranch_scc1 {p}_pnext
 	s_mov_b64 exec, {S_SAVE}""")
         self.keep_path(S_SAVE, True, True)
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
         a(f"; ---- class: min / max / and / or, reg,imm: Right = the immediate --------------------------------------------------------\n{p}_k_cri:")
         self.head(True)
         noalias, nocimm = self.lab("cri_noalias"), self.lab("cri_nocimm")
@@ -646,7 +684,7 @@ class TilesV(Tiles):
 	s_cbranch_scc1 {p}_pnext
 	s_mov_b64 exec, {S_SAVE}""")
         self.keep_path(S_SAVE, False, True)
-        a(f"\ts_branch {p}_pnext")
+        self.pnext()
 
     # ---- kernel ----------------------------------------------------------------------------------------------
     def emit_kernel(self):
@@ -748,8 +786,7 @@ class TilesV(Tiles):
 	s_addc_u32 s45, s45, s11
 	s_mov_b32 {S_CI}, 0
 	s_mov_b64 {S_DECIDED}, 0
-	v_mov_b32 {V_CW}, 0
-	v_mov_b32 {V_RESL}, {V_QNAN}
+""" + "".join(f"\tv_mov_b32 v{self.CHF + w}, 0\n" for w in range(self.ncw)) + f"""	v_mov_b32 {V_RESL}, {V_QNAN}
 	v_mov_b32 {V_RESH}, {V_QNAN}
 	s_getpc_b64 {S_RET}
 {p}_pc1:
@@ -758,15 +795,6 @@ class TilesV(Tiles):
 	s_branch {p}_run
 {p}_ret1:
 	s_memtime s[62:63]
-	; ---- flush the last partial choice word ---------------------------------------------------------------------------
-	s_and_b32 {S_T0}, {S_CI}, 15
-	s_cmp_eq_u32 {S_T0}, 0
-	s_cbranch_scc1 {p}_noflush
-	s_lshr_b32 {S_T0}, {S_CI}, 4
-	s_set_gpr_idx_on {S_T0}, {DST}
-	v_mov_b32 v{self.CHF}, {V_CW}
-	s_set_gpr_idx_off
-{p}_noflush:
 	global_store_dword {V_L4}, {V_RESL}, {S_SLOT} offset:{SL_RES}
 	global_store_dword {V_L4}, {V_RESH}, {S_SLOT} offset:{SL_RES + 256}
 	; ---- classify: ambiguous = act && !(hi < 0) && !(lo > 0); prune those whose trace decided something ------------

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round profile on the GPU box: rocprofv3 kernel stats of the bench command, then two separate
-# PMC passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) with --kernel-trace only.
-# usage: tools/profile_round.sh <tag>      (writes gpurun_out/prof_<tag>/)
+# Round profile on the GPU box: rocprofv3 kernel stats of the bench command, then separate PMC passes
+# (FETCH_SIZE, WRITE_SIZE, SQ instruction counters; they do not fit one pass) with --kernel-trace only.
+# usage: tools/profile_round.sh <tag>      (writes gpurun_out/prof_<tag>/, incl. traffic.json for bench.py's roofline)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -12,21 +12,41 @@ CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $CMD > $OUT/stats_run.log 2>&1
 cp /tmp/p_stats/s_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 grep '^{"metric"' $OUT/stats_run.log > $OUT/bench_under_rocprof.json
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $CMD > $OUT/pmc_$C.log 2>&1
-  F=$(find /tmp/p_$C -name "*counter_collection.csv" | head -1)
-  python - "$F" "$C" > $OUT/pmc_$C.txt <<'PY'
-import csv, sys, collections, re
-f, c = sys.argv[1], sys.argv[2]
-tot = collections.defaultdict(float); n = collections.defaultdict(int)
-for r in csv.DictReader(open(f)):
-    if r["Counter_Name"] != c: continue
-    k = re.sub(r"\(.*", "", r["Kernel_Name"])
-    tot[k] += float(r["Counter_Value"]); n[k] += 1
-print(f"# {c}: sum over dispatches of the whole run (1 warm-up + 5 timed + 3 profiled frames = 9), KB as reported by rocprofv3 (no correction applied)")
-for k in sorted(tot, key=lambda k: -tot[k]):
-    print(f"{tot[k]:16.0f}  dispatches {n[k]:6d}  per-dispatch {tot[k]/n[k]:14.1f}  {k}")
-PY
+for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SMEM"; do
+  N=$(echo $C | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$N -o c -- $CMD > $OUT/pmc_$N.log 2>&1
+  F=$(find /tmp/p_$N -name "*counter_collection.csv" | head -1)
+  cp "$F" $OUT/pmc_$N.csv 2>/dev/null
 done
 cd $R
+python - "$OUT" <<'PY'
+import csv, sys, collections, re, json, glob, os
+out = sys.argv[1]
+sys.path.insert(0, "tools")
+from src_hash import source_hash
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(os.path.join(out, "pmc_*.csv")):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").split("<")[0]
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+FRAMES = 1 + 5 + 3          # bench.py: warm-up + timed + profiled frames
+res = {"_comment": "per-kernel PMC totals of `bench.py --steps 5 --warmup 1 --no-cpu` under rocprofv3 --pmc (9 frames), one pass per counter group; "
+                   "FETCH_SIZE / WRITE_SIZE in KB as reported (bench.py doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950)",
+       "source_hash": source_hash(), "frames": FRAMES}
+lines = []
+for k in sorted(tot, key=lambda k: -tot[k].get("SQ_INSTS_VALU", 0)):
+    d = tot[k]; c = n[k]
+    launches = max(c.values())
+    e = {"launches_per_frame": launches / FRAMES}
+    if "FETCH_SIZE" in d: e["fetch_kb_per_frame"] = d["FETCH_SIZE"] / FRAMES
+    if "WRITE_SIZE" in d: e["write_kb_per_frame"] = d["WRITE_SIZE"] / FRAMES
+    for key, name in (("SQ_INSTS_VALU", "valu_per_launch"), ("SQ_INSTS_SALU", "salu_per_launch"), ("SQ_INSTS_SMEM", "smem_per_launch"),
+                      ("SQ_WAVES", "waves_per_launch"), ("SQ_WAVE_CYCLES", "wave_cycles_per_launch"), ("SQ_BUSY_CYCLES", "busy_cycles_per_launch")):
+        if key in d: e[name] = d[key] / max(c[key], 1)
+    res[k] = e
+    lines.append(f"{k:40s} " + "  ".join(f"{a}={b:.4g}" for a, b in e.items()))
+json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+open(os.path.join(out, "pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
 ls -la $OUT
