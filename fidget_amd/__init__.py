@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
 _SOURCES = ["capi.hip", "kernels.hip", "effects.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
-            "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "offsets.cpp", "../../include/fidget_hip.h",
+            "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
@@ -52,7 +52,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -83,8 +83,11 @@ def build(force=False, verbose=False):
     run(["g++", "-std=c++17", "-I", _CSRC, os.path.join(_CSRC, "offsets.cpp"), "-o", os.path.join(gen, "offsets")])
     with open(os.path.join(gen, "offsets.json"), "w") as f:
         subprocess.check_call([os.path.join(gen, "offsets")], stdout=f)
+    # the transcendental routines the assembly interpreters call: compiler output of trans_funcs.hip, embedded by gen_trans.py
+    run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", _CSRC,
+         "-o", os.path.join(gen, "trans_funcs.s"), os.path.join(_CSRC, "trans_funcs.hip")])
     run([sys.executable, os.path.join(_CSRC, "gen_interp.py"), os.path.join(gen, "offsets.json"),
-         os.path.join(gen, "interp_gfx950.s")])
+         os.path.join(gen, "interp_gfx950.s"), os.path.join(gen, "trans_funcs.s")])
     run([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
          os.path.join(gen, "interp_gfx950.s"), "-o", os.path.join(gen, "interp_gfx950.o")])
     run([os.path.join(llvm, "ld.lld"), "-shared", os.path.join(gen, "interp_gfx950.o"), "-o", co])
@@ -150,6 +153,7 @@ def lib():
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
             "fhip_debug_groups": (u32, [vp, i32, u32, vp, u32, vp]),
             "fhip_debug_ubench": (i32, [vp, u32, u32, u32, vp]),
+            "fhip_debug_math_sweep": (i32, [vp, i32, u32, u32, u64, vp, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
             "fhip_graph_unary": (u32, [vp, i32, u32]), "fhip_graph_binary": (u32, [vp, i32, u32, u32]),

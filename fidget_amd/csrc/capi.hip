@@ -65,9 +65,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -581,6 +581,7 @@ struct RenderSetup {
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
     bool asm_points = false;  // leaf stage on the assembly interpreters
+    bool asm_points_t = false;  // ... on fh_columns_t (tapes with transcendental / modulo / rng opcodes)
     bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
     bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
     uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
@@ -677,7 +678,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
     R.full = tape_is_full(t);
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
-    R.asm_points = ctx->use_asm && is3d && tape_asm_ok(t);
+    R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !getenv("FHIP_NO_COLUMNS_T"));
+    R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
@@ -1188,8 +1190,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
                 struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
-                if (col_waves) (void)launch_asm(ctx, FH_ASM_COLUMNS, ka.n_waves, &ka, sizeof(ka));
-                else (void)launch_asm(ctx, FH_ASM_COLUMNS, (R.n_footprints + 3) / 4, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16));
+                const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
+                if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka));
+                else {
+                    static const uint32_t blk = 1u << (getenv("FHIP_COL_BLKL") ? atoi(getenv("FHIP_COL_BLKL")) : 2);   // footprints per workgroup: gen_interp.py BLKL
+                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16));
+                }
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
@@ -1433,6 +1439,24 @@ fhip_status fhip_debug_ubench(fhip_ctx* ctx, uint32_t test, uint32_t iters, uint
     if (launch_asm(ctx, FH_ASM_UBENCH, n_waves, &ka, sizeof(ka), 64) != hipSuccess) return FHIP_ERR_HIP;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->io_a.p, (size_t)n_waves * 4, hipMemcpyDeviceToHost));
+    return FHIP_OK;
+}
+
+// Diagnostics: accuracy of transcendental opcode `op` (0 sin 1 cos 2 tan 3 asin 4 acos 5 atan 6 exp 7 ln) against `ref` (host
+// libm results for the floats with bit patterns first + i * stride): out = {max ulp, differing, > 1 ulp, input bits of the worst}
+fhip_status fhip_debug_math_sweep(fhip_ctx* ctx, int op, uint32_t first, uint32_t stride, uint64_t n, const float* ref, uint64_t out[4]) {
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, ctx->io_a.ensure(n * 4));
+    HIP_TRY(ctx, ctx->io_b.ensure(64));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, ref, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_math_sweep, dim3(ctx->n_cu * 16), dim3(256), 0, ctx->stream, op, first, stride, (size_t)n, (const float*)ctx->io_a.p,
+                       (unsigned long long*)ctx->io_b.p);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long r[4];
+    HIP_TRY(ctx, hipMemcpyAsync(r, ctx->io_b.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = r[0] >> 32; out[1] = r[1]; out[2] = r[2]; out[3] = r[0] & 0xFFFFFFFFull;
     return FHIP_OK;
 }
 

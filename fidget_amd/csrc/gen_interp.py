@@ -153,8 +153,9 @@ def hexf(x):
 class Interp:
     """One interpreter instance (dispatch loop + handlers) for a given NR x ZB and I/O kind."""
 
-    def __init__(self, a, name, nr, zb, kind, off):
+    def __init__(self, a, name, nr, zb, kind, off, trans=False):
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
+        self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.next = f".L{name}_next"
         self.ool = []  # out-of-line handler bodies: (label, callable)
@@ -209,6 +210,35 @@ class Interp:
 
     def ret(self):
         self.a(f"\ts_setpc_b64 {S_NEXT}")
+
+    def call(self, fn):
+        """call the embedded routine fh_t_<fn> (gen_trans.py): argument(s) v128 (, v129), result v128, return address s[96:97];
+        clobbers v128..v153, s86..s97 and vcc (the mask scratch of the handlers: nothing live)"""
+        here, ret = self.a.label("call"), self.a.label("ret")
+        self.a(f"""
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_branch fh_t_{fn}
+{ret}:""")
+
+    def pcg_consts(self):
+        self.a("\ts_mov_b32 s90, 747796405\n\ts_mov_b32 s91, 0xac564b05\n\ts_mov_b32 s92, 277803737")
+
+    def pcg(self, x, r):
+        """r = rng::hash(x) (rng/mod.rs:8-13, the PCG output permutation); r may be x; scratch {VD[0]}, {VD[1]}"""
+        t0, t1 = VD[0], VD[1]
+        self.a(f"""
+	v_mul_lo_u32 {t0}, {x}, s90
+	v_add_u32 {t0}, s91, {t0}
+	v_lshrrev_b32 {t1}, 28, {t0}
+	v_add_u32 {t1}, 4, {t1}
+	v_lshrrev_b32 {t1}, {t1}, {t0}
+	v_xor_b32 {t1}, {t1}, {t0}
+	v_mul_lo_u32 {t1}, {t1}, s92
+	v_lshrrev_b32 {t0}, 22, {t1}
+	v_xor_b32 {r}, {t0}, {t1}""")
 
     def write_out(self, src, done=True):
         """file[out] = src; ends the handler."""
@@ -378,7 +408,49 @@ class Interp:
                     self.f_round(VT, VU)
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
+        if op in ("SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "EXP", "LN"):
+            def body(fn=op.lower()):
+                self.read_a(VT)
+                self.idx_off()
+                for j in Z:
+                    a(f"\tv_mov_b32 v128, {VT[j]}")
+                    self.call(fn)
+                    a(f"\tv_mov_b32 {VU[j]}, v128")
+                self.write_out(VU)
+            return self.out_of_line(op.lower(), body)
+        if op == "RAND":
+            def body():
+                self.read_a(VT)
+                self.idx_off()
+                self.pcg_consts()
+                for j in Z:                       # rng::rand (rng/mod.rs:19-23): bits (hash >> 9) | 1.0, minus 1
+                    self.pcg(VT[j], VU[j])
+                    a(f"\tv_lshrrev_b32 {VU[j]}, 9, {VU[j]}\n\tv_or_b32 {VU[j]}, 0x3f800000, {VU[j]}\n\tv_add_f32 {VU[j]}, -1.0, {VU[j]}")
+                self.write_out(VU)
+            return self.out_of_line("rand", body)
         base, form = op.rsplit("_", 1)
+        if base in ("ATAN2", "MOD", "MIX"):
+            def body(base=base, form=form):
+                self.read_a(VT)
+                if form == "RR":
+                    self.read_b(VU)
+                self.idx_off()
+                if form != "RR":
+                    self.imm_b(VU)
+                A, B = (VT, VU) if form != "IR" else (VU, VT)
+                if base == "MIX":                 # rng::mix (rng/mod.rs:30-33): hash(a + hash(b)) on the bit patterns
+                    self.pcg_consts()
+                    for j in Z:
+                        self.pcg(B[j], VW[j])
+                        a(f"\tv_add_u32 {VW[j]}, {A[j]}, {VW[j]}")
+                        self.pcg(VW[j], VW[j])
+                else:
+                    for j in Z:
+                        a(f"\tv_mov_b32 v128, {A[j]}\n\tv_mov_b32 v129, {B[j]}")
+                        self.call(base.lower())
+                        a(f"\tv_mov_b32 {VW[j]}, v128")
+                self.write_out(VW)
+            return self.out_of_line(op.lower(), body)
         if base in ("ADD", "SUB", "MUL") and form != "RR":
             # register (op) immediate, two samples per instruction: the immediate is the high half of the op's
             # SGPR pair, selected for both samples.  a - imm = a + (-imm) and imm - a = (-a) + imm, exactly.
@@ -634,7 +706,7 @@ class Interp:
                 op = OPS[i] if i < len(OPS) else None
                 a(f"{lab}:  ; {op}{' (in place)' if inplace else ''}")
                 base = op.rsplit("_", 1)[0] if op and "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-                if op is None or base in UNSUPPORTED:
+                if op is None or (base in UNSUPPORTED and not self.trans):
                     self.ret()             # never reached for tapes routed here (host checks)
                 elif inplace and op not in self.INPLACE:
                     a(f"\ts_branch .L{n}_h{i}")
@@ -722,7 +794,7 @@ def handler_base(a, it):
 	s_addc_u32 s43, s43, 0""")
 
 
-def gen_columns(a, variants, off):
+def gen_columns(a, variants, off, trans=None):
     """fh_columns: ONE leaf (8x8x8 voxels, one pixel column per lane) per wave pass.  Waves walk the
     leaf table [layer][footprint] front layer first, 64 footprints at a time, round robin without atomics;
     hits go to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so any interleaving of the
@@ -730,18 +802,29 @@ def gen_columns(a, variants, off):
     The register-file shape is chosen per leaf (variants = [(NR, ZB)], smallest NR first: 8 registers
     x 8 voxels, 16 x 4, 32 x 2 - all 64 VGPRs): 80 % of prospero's leaves take a single pass.
     kernarg: { FhRenderState* S; u32 n_waves; u32 pad }"""
-    kname = "fh_columns"
+    kname = "fh_columns_t" if trans else "fh_columns"
+    if trans:   # same generator into a scratch buffer, labels renamed, the routines embedded next to the handlers (s_branch range)
+        b = Asm()
+        b.uid = a.uid + 100000
+        r = _gen_columns_body(b, variants, off, kname, trans)
+        a(b.text().replace(".Lfh_columns_", ".Lfh_columns_t_"))
+        return r
+    return _gen_columns_body(a, variants, off, kname, None)
+
+
+def _gen_columns_body(a, variants, off, kname, trans):
     o = off
     m = S_MAT
-    nvg = FILE + 64
-    its = [Interp(a, f"fh_columns_{nr}x{zb}", nr, zb, "columns", off) for nr, zb in variants]
+    nvg = 160 if trans else FILE + 64      # (the routines' register window v128..v153)
+    its = [Interp(a, f"{kname}_{nr}x{zb}", nr, zb, "columns", off, trans=bool(trans)) for nr, zb in variants]
     inplace_mask = 0
     for k, op in enumerate(OPS):
         if op in Interp.INPLACE:
             inplace_mask |= 1 << k
     S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
     S_ONE, S_WGY = "s100", "s101"
-    BLKL = 2            # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast)
+    import os
+    BLKL = int(os.environ.get("FH_BLKL", "2"))   # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast); capi.hip FH_COL_BLKL must agree
     BLK = 1 << BLKL
     kernel_header(a, kname, 16, nvg)
     a(f"""
@@ -1022,6 +1105,9 @@ def gen_columns(a, variants, off):
 	s_branch .Lfh_columns_leaf
 .Lfh_columns_exit:""")
     kernel_footer(a, kname, 16, nvg, 102, True, wg_y=True)
+    if trans:
+        import gen_trans
+        gen_trans.embed(a, trans)
     for it in its:
         it.emit()
     return kname, nvg
@@ -1171,6 +1257,9 @@ def main():
     ks = []
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
     ks.append((n, 16, nvg, [(8, "global_buffer"), (4, "by_value"), (4, "by_value")]))
+    if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
+        n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off, trans=sys.argv[3])
+        ks.append((n, 16, nvg, [(8, "global_buffer"), (4, "by_value"), (4, "by_value")]))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))

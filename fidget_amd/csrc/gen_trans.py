@@ -1,0 +1,63 @@
+"""Embeds the compiled transcendental routines (trans_funcs.hip -> hipcc -S) in the interpreters' code object.
+
+Each function body is taken from the compiler's assembly, its registers moved into the window the interpreters keep free
+while a handler runs (v0..v25 -> v128..v153, s0..s9 -> s86..s95, return address s[30:31] -> s[96:97]; vcc and exec are used
+as they are: exec is restored by the functions themselves), its local labels made unique.  Calling convention for the
+handlers: argument(s) in v128 (, v129), result in v128, `s_getpc / s_add / s_branch` with the return address in s[96:97]."""
+import re
+
+V_BASE, S_BASE, S_RET = 128, 86, 96
+FUNCS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod"]
+MAX_V, MAX_S = 26, 10
+
+
+def _rename(body, name):
+    def v1(m):
+        n = int(m.group(1))
+        assert n < MAX_V, (name, m.group(0))
+        return f"v{V_BASE + n}"
+
+    def v2(m):
+        a, b = int(m.group(1)), int(m.group(2))
+        assert b < MAX_V, (name, m.group(0))
+        return f"v[{V_BASE + a}:{V_BASE + b}]"
+
+    def smap(n):
+        if n in (30, 31):
+            return S_RET + (n - 30)
+        assert n < MAX_S, (name, n)
+        return S_BASE + n
+
+    def s1(m):
+        return f"s{smap(int(m.group(1)))}"
+
+    def s2(m):
+        a, b = int(m.group(1)), int(m.group(2))
+        assert smap(b) - smap(a) == b - a
+        return f"s[{smap(a)}:{smap(b)}]"
+
+    out = []
+    for line in body.split("\n"):
+        code = line.split(";")[0].rstrip()
+        if not code.strip() or code.strip().startswith("."):
+            if re.match(r"^\.LBB\d+_\d+:", code.strip()):
+                out.append(re.sub(r"\.LBB(\d+)_(\d+)", rf".Lfh_t_{name}_bb\2", code.strip()))
+            continue
+        code = re.sub(r"\.LBB(\d+)_(\d+)", rf".Lfh_t_{name}_bb\2", code)
+        code = re.sub(r"\bv\[(\d+):(\d+)\]", v2, code)
+        code = re.sub(r"\bv(\d+)\b", v1, code)
+        code = re.sub(r"\bs\[(\d+):(\d+)\]", s2, code)
+        code = re.sub(r"\bs(\d+)\b", s1, code)
+        for bad in ("scratch", "buffer_", "s_swappc", "s_getpc", "ds_", "global_", "flat_", "m0"):
+            assert bad not in code, (name, code)
+        out.append(code)
+    return "\n".join(out)
+
+
+def embed(a, path):
+    txt = open(path).read()
+    for f in FUNCS:
+        m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
+        assert m, f
+        a(f"\t.p2align 6\nfh_t_{f}:")
+        a(_rename(m.group(1), f))

@@ -1313,6 +1313,42 @@ __global__ void k_merge_depth(FhGeometryPixel* front, const FhGeometryPixel* bac
     }
 }
 
+// Accuracy sweep of the transcendental opcodes (diagnostics; tests/test_gpu_math.py): x_i = bits(first + i * stride),
+// y = the device's f32 result (f64 evaluation rounded once, dev_ops.hpp t_*), compared with ref[i] (the host libm's):
+// out[0] = max ulp distance, out[1] = results that differ, out[2] = results more than 1 ulp apart, out[3] = an input of the worst case
+__global__ void k_math_sweep(int op, uint32_t first, uint32_t stride, size_t n, const float* __restrict__ ref, unsigned long long* out) {
+    unsigned long long worst = 0, ndiff = 0, nbad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t xb = first + (uint32_t)i * stride;
+        const float x = u2f(xb);
+        float y;
+        switch (op) {
+            case 0: y = t_sin(x); break;
+            case 1: y = t_cos(x); break;
+            case 2: y = t_tan(x); break;
+            case 3: y = t_asin(x); break;
+            case 4: y = t_acos(x); break;
+            case 5: y = t_atan(x); break;
+            case 6: y = t_exp(x); break;
+            default: y = t_ln(x); break;
+        }
+        const float r = ref[i];
+        if (isnan_(y) && isnan_(r)) continue;
+        // distance in units in the last place: map the bit patterns to a monotonic integer line
+        const int32_t a = (int32_t)f2u(y), b = (int32_t)f2u(r);
+        const long long ka = a < 0 ? -(long long)(f2u(y) & 0x7fffffffu) : (long long)a;
+        const long long kb = b < 0 ? -(long long)(f2u(r) & 0x7fffffffu) : (long long)b;
+        unsigned long long d = (unsigned long long)(ka > kb ? ka - kb : kb - ka);
+        if (isnan_(y) != isnan_(r)) d = 0xFFFFFFFFull;
+        if (d) ndiff++;
+        if (d > 1) nbad++;
+        if (d > (worst >> 32)) worst = (d << 32) | xb;
+    }
+    if (ndiff) atomicAdd(&out[1], ndiff);
+    if (nbad) atomicAdd(&out[2], nbad);
+    if (worst) atomicMax(&out[0], worst);
+}
+
 // ---- micro-benchmark of the point interpreter (diagnostics only; fhip_debug_bench) -----------
 template <int NR, int ZB>
 __global__ void __launch_bounds__(WAVE) k_bench_points(FhRenderState* S, const uint64_t* tape_g, uint32_t len, uint32_t reps, float* out) {

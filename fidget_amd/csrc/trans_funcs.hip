@@ -1,0 +1,28 @@
+// Transcendental / modulo routines for the assembly interpreters, as out-of-line device functions.
+//
+// The reference evaluates sin, cos, ... with the platform libm; the device's definition of those opcodes is dev_ops.hpp
+// t_* (f64 evaluation, one rounding to f32) and the HIP kernels inline exactly these expressions.  The assembly
+// interpreters must return the same bits, so they CALL the same code: this file is compiled to gfx950 assembly
+// (hipcc -S; no scratch, no tables: ocml's argument reduction uses v_trig_preop_f64), gen_interp.py renames the registers
+// of each function into a window the interpreters keep free (v0.. -> v128.., s0.. -> s86.., return address
+// s[30:31] -> s[96:97]) and embeds the bodies in the interpreters' code object.
+#include <hip/hip_runtime.h>
+
+#include "dev_ops.hpp"
+
+#define FH_NI extern "C" __device__ __attribute__((noinline, used))
+FH_NI float fh_t_sin(float a) { return fhd::t_sin(a); }
+FH_NI float fh_t_cos(float a) { return fhd::t_cos(a); }
+FH_NI float fh_t_tan(float a) { return fhd::t_tan(a); }
+FH_NI float fh_t_asin(float a) { return fhd::t_asin(a); }
+FH_NI float fh_t_acos(float a) { return fhd::t_acos(a); }
+FH_NI float fh_t_atan(float a) { return fhd::t_atan(a); }
+FH_NI float fh_t_exp(float a) { return fhd::t_exp(a); }
+FH_NI float fh_t_ln(float a) { return fhd::t_ln(a); }
+FH_NI float fh_t_atan2(float y, float x) { return fhd::t_atan2(y, x); }
+FH_NI float fh_t_mod(float a, float b) { return fhd::rem_euclid(a, b); }
+// (a kernel that references them keeps the functions in the device image)
+__global__ void fh_trans_keep(float* p) {
+    p[0] = fh_t_sin(p[0]) + fh_t_cos(p[0]) + fh_t_tan(p[1]) + fh_t_asin(p[2]) + fh_t_acos(p[2]) + fh_t_atan(p[2]) + fh_t_exp(p[1]) + fh_t_ln(p[2]) +
+           fh_t_atan2(p[3], p[4]) + fh_t_mod(p[3], p[4]);
+}

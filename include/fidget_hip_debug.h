@@ -24,6 +24,10 @@ fhip_status fhip_debug_bench(fhip_ctx* ctx, const fhip_tape* tape, uint32_t n_wa
 
 /* Instruction-cost micro-benchmark `test` of fh_ubench (fidget_amd/csrc/gen_ubench.py): shader clocks per pattern, per wave */
 fhip_status fhip_debug_ubench(fhip_ctx* ctx, uint32_t test, uint32_t iters, uint32_t n_waves, float* out);
+/* Accuracy of transcendental opcode `op` (0 sin 1 cos 2 tan 3 asin 4 acos 5 atan 6 exp 7 ln) on the device against `ref` (the host
+ * libm's f32 results for the floats with bit patterns first + i * stride, i < n): out = {max ulp distance, results that differ,
+ * results more than 1 ulp apart, input bits of the worst case} */
+fhip_status fhip_debug_math_sweep(fhip_ctx* ctx, int op, uint32_t first, uint32_t stride, uint64_t n, const float* ref, uint64_t out[4]);
 /* Work-queue entries (36-byte FhGroup records: tape offset, length, registers | choices << 16, x, y, z, ...) the
  * last 3D frame left behind.  kind 0: queue of tile level `index`; kind 1: parked queue of z-slab `index`.
  * counts[0] = entries whose tape fits the small register-file layout (written first), counts[1] = the others. */

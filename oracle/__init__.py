@@ -99,6 +99,7 @@ def lib():
             "orc_render2d": (i32, [vp, vp, u32, u32, f32, i32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_render3d": (i32, [vp, vp, u32, u32, u32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_max_threads": (i32, []),
+            "orc_math_unary": (None, [i32, u32, u32, C.c_uint64, vp]),
             "orc_fx_denoise_normals": (None, [vp, i32, i32, vp]),
             "orc_fx_compute_ssao": (None, [vp, i32, i32, i32, vp, i32, vp, i32, vp]),
             "orc_fx_blur_ssao": (None, [vp, i32, i32, vp]),
@@ -538,3 +539,13 @@ def to_debug_bitmap(image):
 
 def to_rgba_distance(image):
     return _rgba(lib().orc_fx_to_rgba_distance, image)
+
+
+MATH_OPS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln"]
+
+
+def math_unary(op, first, stride, count):
+    """glibc f32 libm over the floats with bit patterns first + i * stride (the reference's transcendental opcodes)"""
+    out = np.zeros(count, np.float32)
+    lib().orc_math_unary(MATH_OPS.index(op), first & 0xFFFFFFFF, stride, count, _p(out))
+    return out

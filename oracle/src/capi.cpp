@@ -285,4 +285,25 @@ void orc_fx_apply_shading(const void* img, int w, int h, int d, const float* ssa
 void orc_fx_to_rgba_bitmap(const float* img, uint64_t n, int transparent, uint8_t* out) { fx_to_rgba_bitmap(img, n, transparent, out); }
 void orc_fx_to_debug_bitmap(const float* img, uint64_t n, uint8_t* out) { fx_to_debug_bitmap(img, n, out); }
 void orc_fx_to_rgba_distance(const float* img, uint64_t n, uint8_t* out) { fx_to_rgba_distance(img, n, out); }
+
+// ---- libm sweep: the reference's transcendental opcodes call the platform libm in f32 (glibc here) --------------------
+// out[i] = f(x_i), x_i = the float with bit pattern first + i * stride; op: 0 sin 1 cos 2 tan 3 asin 4 acos 5 atan 6 exp 7 ln
+void orc_math_unary(int op, uint32_t first, uint32_t stride, uint64_t count, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        const float x = u2f(first + (uint32_t)i * stride);
+        float y;
+        switch (op) {
+            case 0: y = sinf(x); break;
+            case 1: y = cosf(x); break;
+            case 2: y = tanf(x); break;
+            case 3: y = asinf(x); break;
+            case 4: y = acosf(x); break;
+            case 5: y = atanf(x); break;
+            case 6: y = expf(x); break;
+            default: y = logf(x); break;
+        }
+        out[i] = y;
+    }
+}
 }  // extern "C"

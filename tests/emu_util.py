@@ -89,6 +89,50 @@ def _f_compare(a, b):
         return np.where(a < b, F32(-1), np.where(a == b, F32(0), np.where(a > b, F32(1), F32(np.nan)))).astype(F32)
 
 
+def pcg(v):
+    """rng::hash (fidget-core/src/rng/mod.rs:8-13) on uint32 arrays"""
+    v = np.asarray(v, np.uint64)
+    s = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    w = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+    return (((w >> 22) ^ w) & 0xFFFFFFFF).astype(U32)
+
+
+def t64(fn, *a):
+    """the device's definition of a transcendental opcode: f64 evaluation, one rounding (dev_ops.hpp t_*)"""
+    with np.errstate(all="ignore"):
+        return fn(*[np.asarray(x, F32).astype(np.float64) for x in a]).astype(F32)
+
+
+def rem_euclid(a, b):
+    with np.errstate(all="ignore"):
+        r = np.fmod(np.asarray(a, F32), np.asarray(b, F32)).astype(F32)
+        return np.where(r < 0, (r + np.abs(b)).astype(F32), r).astype(F32)
+
+
+TRANS = {"SIN": np.sin, "COS": np.cos, "TAN": np.tan, "ASIN": np.arcsin, "ACOS": np.arccos, "ATAN": np.arctan, "EXP": np.exp, "LN": np.log}
+
+
+def trans_hooks(prog):
+    """native stand-ins for the compiled routines embedded by gen_trans.py (the emulator has no f64 ISA): argument(s) in v128 (,
+    v129), result in v128 for the lanes in exec, return to s[96:97]"""
+    def mk(fn, nargs):
+        def hook(w):
+            m = w._bits(w.exec)
+            args = [w.v[128 + k].view(F32).copy() for k in range(nargs)]
+            r = fn(*args).astype(F32).view(U32)
+            w.v[128][m] = r[m]
+            w.v[129:154] = 0xDEADBEEF            # the routines may clobber their whole register window
+            w.s[86:96] = 0xDEADBEEF
+            return int(w.s[96]) | (int(w.s[97]) << 32)
+        return hook
+    h = {}
+    for name, fn in TRANS.items():
+        h[prog.symbols["fh_t_" + name.lower()]] = mk(lambda x, fn=fn: t64(fn, x), 1)
+    h[prog.symbols["fh_t_atan2"]] = mk(lambda y, x: t64(np.arctan2, y, x), 2)
+    h[prog.symbols["fh_t_mod"]] = mk(rem_euclid, 2)
+    return h
+
+
 def ref_f32(tape, inputs, n):
     """inputs: slot -> array[n]; returns {output slot: array}"""
     regs = {}
@@ -112,6 +156,12 @@ def ref_f32(tape, inputs, n):
                 regs[ro] = np.full(n, imm, F32)
                 continue
             base, form = split(op)
+            if base is None and name in TRANS:
+                regs[ro] = t64(TRANS[name], regs[ra])
+                continue
+            if base is None and name == "RAND":
+                regs[ro] = (((pcg(regs[ra].view(U32)) >> U32(9)) | U32(0x3F800000)).view(F32) - F32(1)).astype(F32)
+                continue
             if base is None:
                 a = regs[ra]
                 r = {"NEG": lambda: -a, "ABS": lambda: np.abs(a), "RECIP": lambda: F32(1) / a, "SQRT": lambda: np.sqrt(a),
@@ -137,6 +187,12 @@ def ref_f32(tape, inputs, n):
                 r = a / b
             elif bn == "COMPARE":
                 r = _f_compare(a, b)
+            elif bn == "ATAN2":
+                r = t64(np.arctan2, a, b)
+            elif bn == "MOD":
+                r = rem_euclid(a, b)
+            elif bn == "MIX":
+                r = pcg((a.view(U32).astype(np.uint64) + pcg(b.view(U32)).astype(np.uint64)) & 0xFFFFFFFF).view(F32)
             elif bn == "MIN":
                 r = np.where(a < b, a, np.where(b < a, b, np.where(un, qn, b)))
             elif bn == "MAX":

@@ -18,7 +18,7 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
-def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0):
+def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns"):
     off = U.offsets()
     mem = E.Memory()
     arena = np.zeros(4096, np.uint64)
@@ -41,7 +41,9 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     a_st = mem.map(st.b)
     ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, 0], U32)
-    waves = E.launch(U.program(), mem, "fh_columns", ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=128)
+    trans = kernel == "fh_columns_t"
+    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=160 if trans else 128,
+                     hooks=U.trans_hooks(U.program()) if trans else None)
     return zbuf, waves
 
 
@@ -87,3 +89,48 @@ def test_occluded_pixels_are_left_alone():
     z[0:128] = np.uint64((16 << 32) | 7)     # front rows already hit by a nearer leaf
     got, _ = run_columns(tape, sh.slot_count(), ik, AFFINE, (0, 0, 0), zbuf_init=z)
     assert (got == expect(tape, ik, AFFINE, (0, 0, 0), 16, z)).all()
+
+
+def trans_shape(kind):
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    if kind == 0:      # unary transcendentals, every one of them
+        n = c.add(c.mul(c.sin(c.mul(x, 3.0)), c.cos(c.mul(y, 2.0))), c.sub(c.exp(c.mul(z, 0.5)), 1.2))
+        n = c.add(n, c.mul(c.tan(c.mul(x, 0.4)), 0.1))
+        n = c.add(n, c.mul(c.asin(c.mul(y, 0.5)), c.acos(c.mul(z, 0.5))))
+        n = c.sub(n, c.mul(c.atan(x), c.ln(c.add(c.abs(y), 0.3))))
+    elif kind == 1:    # atan2 / mod in the three operand forms
+        n = c.sub(c.atan2(y, x), c.mul(z, 2.0))
+        n = c.add(n, c.sub(c.modulo(c.mul(x, 3.0), 0.7), 0.3))
+        n = c.add(n, c.mul(c.modulo(2.5, c.add(c.abs(y), 0.4)), 0.2))
+        n = c.add(n, c.mul(c.atan2(0.3, z), c.atan2(x, -0.6)))
+        n = c.add(n, c.mul(c.modulo(c.add(x, 2.0), c.add(c.square(z), 0.5)), 0.1))
+    else:              # rng
+        n = c.sub(c.add(c.rand(c.mul(x, 7.0)), c.mix(y, z)), c.add(c.mix(x, 0.25), c.mix(1.5, z)))
+        n = c.sub(n, 0.2)
+    sh = F.Shape(c, n)
+    ik = [3] * 16
+    for a in range(3):
+        s = sh.axis_index(a)
+        if s >= 0:
+            ik[s] = a
+    return sh, U.shape_tape(sh), ik
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_transcendental_leaf_kernel(kind):
+    """fh_columns_t: the opcodes that call the compiled routines (stood in for natively in the emulator: what is tested is the
+    call sequence, the register window and the operand forms) and the rng opcodes (integer code, emulated exactly)"""
+    sh, tape, ik = trans_shape(kind)
+    assert sh.slot_count() <= 32
+    for mat in (AFFINE, PERSPECTIVE):
+        for leaf in ((0, 8, 0), (8, 0, 8)):
+            got, _ = run_columns(tape, sh.slot_count(), ik, mat, leaf, kernel="fh_columns_t")
+            want = expect(tape, ik, mat, leaf, 16)
+            assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+    # and a tape without such opcodes gives the same words through either kernel
+    sh2, tape2, ik2 = shape_of(2)
+    a, _ = run_columns(tape2, sh2.slot_count(), ik2, ROTATED, (0, 8, 0))
+    b, _ = run_columns(tape2, sh2.slot_count(), ik2, ROTATED, (0, 8, 0), kernel="fh_columns_t")
+    assert (a == b).all()

@@ -43,10 +43,10 @@ def _f2u(x):
 
 # ---- program -------------------------------------------------------------------------------
 class Inst:
-    __slots__ = ("addr", "size", "mn", "ops", "mods", "text")
+    __slots__ = ("addr", "size", "mn", "ops", "mods", "text", "word0")
 
-    def __init__(self, addr, size, mn, ops, mods, text):
-        self.addr, self.size, self.mn, self.ops, self.mods, self.text = addr, size, mn, ops, mods, text
+    def __init__(self, addr, size, mn, ops, mods, text, word0=0):
+        self.addr, self.size, self.mn, self.ops, self.mods, self.text, self.word0 = addr, size, mn, ops, mods, text, word0
 
 
 _MOD_RE = re.compile(r"\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([0-9,]+)\]|\boffset:(-?\d+)|\b(sc0|sc1|nt|glc|slc|clamp)\b")
@@ -99,7 +99,7 @@ class Program:
             for suf in ("_e32", "_e64"):
                 if mn.endswith(suf):
                     mn = mn[: -len(suf)]
-            self.insts[addr] = Inst(addr, 4 * len(words), mn, ops, mods, line.split("//")[0].strip())
+            self.insts[addr] = Inst(addr, 4 * len(words), mn, ops, mods, line.split("//")[0].strip(), int(words[0], 16))
 
 
 # ---- memory --------------------------------------------------------------------------------
@@ -170,6 +170,7 @@ class Wave:
         self.lanes = np.arange(LANES, dtype=U32)
         self.mn_counts = {}
         self.n_vgpr = 512     # launch() sets the kernel's allocation
+        self.hooks = {}       # address -> python function(wave): native stand-ins for embedded compiled routines
 
     # -- exec / masks -------------------------------------------------------------------------
     @staticmethod
@@ -437,6 +438,10 @@ class Wave:
         self.pc = entry
         self.done = False
         while not self.done:
+            h = self.hooks.get(self.pc)
+            if h is not None:
+                self.pc = h(self)
+                continue
             inst = self.p.insts.get(self.pc)
             if inst is None:
                 raise EmuError(f"pc {self.pc:#x} is not an instruction")
@@ -718,7 +723,7 @@ class Wave:
         self.scc = int({"eq": x == y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[op])
 
     def _branch(self, i, off):
-        o = int(off, 0)
+        o = i.word0 & 0xFFFF          # SOPP simm16 (the listing shows a symbol when the target has one)
         if o >= 0x8000:
             o -= 0x10000
         return i.addr + 4 + 4 * o
@@ -1287,8 +1292,9 @@ class Wave:
         osh = i.mods.get("op_sel_hi", [1] * n)
         nlo = i.mods.get("neg_lo", [0] * n)
         nhi = i.mods.get("neg_hi", [0] * n)
-        lo_in = [srcs[k][osl[k]].view(F32) * (F32(-1) if nlo[k] else F32(1)) for k in range(n)]
-        hi_in = [srcs[k][osh[k]].view(F32) * (F32(-1) if nhi[k] else F32(1)) for k in range(n)]
+        sgn = lambda x, neg: (x.view(U32) ^ U32(0x80000000)).view(F32) if neg else x.view(F32)   # (sign flip: exact, NaN-safe)
+        lo_in = [sgn(srcs[k][osl[k]], nlo[k]) for k in range(n)]
+        hi_in = [sgn(srcs[k][osh[k]], nhi[k]) for k in range(n)]
         # (negation by multiplication keeps NaN payloads irrelevant; -0 handled: -1 * 0 = -0)
         with np.errstate(all="ignore"):
             lo, hi = fn(*lo_in), fn(*hi_in)
@@ -1491,7 +1497,7 @@ class Wave:
 
 
 def launch(prog, mem, kernel, kernarg_bytes, n_workgroups=1, grid_y=1, lds_bytes=160 * 1024, check_hazards=True, wg_id_sgpr=2, wg_y_sgpr=3,
-           max_inst=50_000_000, trace=None, n_vgpr=512):
+           max_inst=50_000_000, trace=None, n_vgpr=512, hooks=None):
     """Run `kernel` for every single-wave workgroup of the grid, one after the other.
     Conventions of the interpreters: s[0:1] = kernarg segment, s2 = workgroup id x, s3 = workgroup id y (when enabled), v0 = lane id.
     Returns the list of waves (for their counters)."""
@@ -1506,6 +1512,7 @@ def launch(prog, mem, kernel, kernarg_bytes, n_workgroups=1, grid_y=1, lds_bytes
                 w.s[wg_y_sgpr] = y
             w.v[0] = np.arange(LANES, dtype=U32)
             w.trace = trace
+            w.hooks = hooks or {}
             w.n_vgpr = n_vgpr
             w.run(prog.symbols[kernel], max_inst)
             waves.append(w)
