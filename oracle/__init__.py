@@ -100,6 +100,11 @@ def lib():
             "orc_render3d": (i32, [vp, vp, u32, u32, u32, vp, u32, i32, i32, vp, vp, vp, vp, vp, u32]),
             "orc_max_threads": (i32, []),
             "orc_math_unary": (None, [i32, u32, u32, C.c_uint64, vp]),
+            "orc_mesh_build": (vp, [vp, vp, u32, i32, vp, vp, u32]), "orc_mesh_free": (None, [vp]),
+            "orc_mesh_counts": (None, [vp, vp]), "orc_mesh_verts": (None, [vp, vp]), "orc_mesh_cells": (None, [vp, vp]),
+            "orc_mesh_samples": (None, [vp, vp, vp, vp, vp, vp, vp]), "orc_mesh_walk_dual": (None, [vp, vp]),
+            "orc_mesh_dual_copy": (None, [vp, vp, vp]), "orc_mesh_table": (None, [i32, vp, vp]),
+            "orc_qef_solve": (None, [vp, vp, i32, vp, vp]),
             "orc_fx_denoise_normals": (None, [vp, i32, i32, vp]),
             "orc_fx_compute_ssao": (None, [vp, i32, i32, i32, vp, i32, vp, i32, vp]),
             "orc_fx_blur_ssao": (None, [vp, i32, i32, vp]),
@@ -549,3 +554,70 @@ def math_unary(op, first, stride, count):
     out = np.zeros(count, np.float32)
     lib().orc_math_unary(MATH_OPS.index(op), first & 0xFFFFFFFF, stride, count, _p(out))
     return out
+
+
+# ---- fidget-mesh ------------------------------------------------------------------------------------------------
+CELL_KINDS = ["Invalid", "Empty", "Full", "Branch", "Leaf"]
+
+
+class Octree:
+    """fidget_mesh::Octree::build (octree.rs:48-68, single-threaded path).  Attributes: root (kind, mask, index), cells
+    [n, 8, 3] (kind, mask, index), verts [n, 3]; samples: the leaf sampling data (bounds, mask, intersections as u16
+    positions and f32 points, gradients (dx, dy, dz, v), cell vertices) in evaluation order."""
+
+    def __init__(self, shape, depth, world_to_model=None, mode=SIMPLIFY_REFERENCE, vars=None):
+        w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+        vk, vv = _vars(vars)
+        self._h = lib().orc_mesh_build(shape._h, _p(w2m), depth, mode, _p(vk), _p(vv), len(vk))
+        if not self._h:
+            raise ValueError("MissingVar")
+        c = np.zeros(8, np.uint64)
+        lib().orc_mesh_counts(self._h, _p(c))
+        nc, nv, ns = int(c[0]), int(c[1]), int(c[2])
+        self.interval_evals = int(c[3])
+        self.root = (CELL_KINDS[int(c[4])], int(c[5]), int(c[6]))
+        self.verts = np.zeros((nv, 3), np.float32)
+        lib().orc_mesh_verts(self._h, _p(self.verts))
+        self.cells = np.zeros((nc, 8, 3), np.uint32)
+        lib().orc_mesh_cells(self._h, _p(self.cells))
+        self.samples = {"bounds": np.zeros((ns, 6), np.float32), "info": np.zeros((ns, 3), np.uint32), "inter": np.zeros((ns, 12, 3), np.uint16),
+                        "pos": np.zeros((ns, 12, 3), np.float32), "grad": np.zeros((ns, 12, 4), np.float32), "vert": np.zeros((ns, 4, 3), np.float32)}
+        s = self.samples
+        lib().orc_mesh_samples(self._h, _p(s["bounds"]), _p(s["info"]), _p(s["inter"]), _p(s["pos"]), _p(s["grad"]), _p(s["vert"]))
+
+    def __del__(self):
+        try:
+            lib().orc_mesh_free(self._h)
+        except Exception:
+            pass
+
+    def walk_dual(self):
+        """Octree::walk_dual (dc.rs): (triangles [n, 3] vertex indices, vertices [m, 3])"""
+        c = np.zeros(2, np.uint64)
+        lib().orc_mesh_walk_dual(self._h, _p(c))
+        tris = np.zeros((int(c[0]), 3), np.uint64)
+        verts = np.zeros((int(c[1]), 3), np.float32)
+        lib().orc_mesh_dual_copy(self._h, _p(tris), _p(verts))
+        return tris, verts
+
+
+def mdc_table(mask):
+    """(CELL_TO_VERT_TO_EDGES[mask] as a list of vertices = lists of (start, end), CELL_TO_EDGE_TO_VERT[mask] as [12] of (vert, edge) or None)"""
+    v = np.zeros(128, np.int32)
+    e = np.zeros((12, 2), np.int32)
+    lib().orc_mesh_table(mask, _p(v), _p(e))
+    out, k = [], 1
+    for _ in range(v[0]):
+        n = v[k]; k += 1
+        out.append([(int(v[k + 2 * i]), int(v[k + 2 * i + 1])) for i in range(n)])
+        k += 2 * n
+    return out, [None if a < 0 else (int(a), int(b)) for a, b in e]
+
+
+def qef_solve(points, grads):
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    g = np.ascontiguousarray(grads, np.float32).reshape(-1, 4)
+    pos = np.zeros(3, np.float32)
+    err = np.zeros(1, np.float32)
+    lib().orc_qef_solve(_p(p), _p(g), len(p), _p(pos), _p(err))
+    return pos, float(err[0])

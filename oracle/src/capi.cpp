@@ -6,6 +6,7 @@
 
 #include "render.hpp"
 #include "effects.hpp"
+#include "mesh.hpp"
 
 namespace orc {
 thread_local uint64_t g_invalid_intervals = 0;
@@ -305,5 +306,85 @@ void orc_math_unary(int op, uint32_t first, uint32_t stride, uint64_t count, flo
         }
         out[i] = y;
     }
+}
+
+// ---- fidget-mesh: Octree::build / walk_dual (octree.rs:48-68, 219-225) ------------------------------------
+struct OrcMesh {
+    mesh::Octree o;
+    mesh::MeshOut m;
+    bool walked = false;
+};
+// world_to_model: row-major 4x4 or NULL (= identity); returns NULL if a variable has no value
+void* orc_mesh_build(void* s, const float* world_to_model, uint32_t depth, int mode, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars) {
+    VmDataP shape = ((OrcShape*)s)->d;
+    Axes axes(*shape->vars);
+    if (!bind_vars(*shape->vars, var_keys, var_vals, n_vars, axes)) return nullptr;
+    Mat4 m;
+    bool ident = true;
+    if (world_to_model) {
+        for (int i = 0; i < 16; i++) { m.m[i] = world_to_model[i]; ident &= (world_to_model[i] == ((i % 5 == 0) ? 1.0f : 0.0f)); }
+    }
+    mesh::Builder b(depth, (world_to_model && !ident) ? &m : nullptr, axes, mode);
+    RenderHandle root(shape);
+    mesh::Hermite h;
+    b.recurse(&root, mesh::CellIndex(), &h);
+    OrcMesh* out = new OrcMesh();
+    out->o = std::move(b.o);
+    if (world_to_model && !ident) {      // octree.rs:58-65: vertices back to model space
+        for (auto& v : out->o.verts) transform_f32(m, v.x, v.y, v.z, &v.x, &v.y, &v.z);
+    }
+    return out;
+}
+void orc_mesh_free(void* h) { delete (OrcMesh*)h; }
+// counts: cells (groups of 8), verts, leaf samples, interval evaluations, root kind, root mask, root index
+void orc_mesh_counts(void* h, uint64_t out[8]) {
+    OrcMesh* m = (OrcMesh*)h;
+    out[0] = m->o.cells.size(); out[1] = m->o.verts.size(); out[2] = m->o.samples.size(); out[3] = m->o.interval_evals;
+    out[4] = m->o.root.kind; out[5] = m->o.root.mask; out[6] = m->o.root.index; out[7] = 0;
+}
+void orc_mesh_verts(void* h, float* out) { OrcMesh* m = (OrcMesh*)h; std::memcpy(out, m->o.verts.data(), m->o.verts.size() * 12); }
+// cells: per cell 3 x u32 (kind, mask, index), 8 per group
+void orc_mesh_cells(void* h, uint32_t* out) {
+    OrcMesh* m = (OrcMesh*)h;
+    size_t k = 0;
+    for (auto& g : m->o.cells) for (auto& c : g) { out[k++] = c.kind; out[k++] = c.mask; out[k++] = c.index; }
+}
+// leaf samples: bounds f32[6] (x.lo x.hi y.lo y.hi z.lo z.hi), u32 mask, n_edges, n_verts; u16 inter[12][3]; f32 pos[12][3]; f32 grad[12][4]
+// (dx dy dz v); f32 vert[4][3]
+void orc_mesh_samples(void* h, float* bounds, uint32_t* info, uint16_t* inter, float* pos, float* grad, float* vert) {
+    OrcMesh* m = (OrcMesh*)h;
+    size_t i = 0;
+    for (auto& s : m->o.samples) {
+        for (int k = 0; k < 3; k++) { bounds[i * 6 + 2 * k] = s.bounds.b[k].lo; bounds[i * 6 + 2 * k + 1] = s.bounds.b[k].hi; }
+        info[i * 3] = s.mask; info[i * 3 + 1] = s.n_edges; info[i * 3 + 2] = s.n_verts;
+        std::memcpy(inter + i * 36, s.inter, 72); std::memcpy(pos + i * 36, s.pos, 144); std::memcpy(grad + i * 48, s.grad, 192);
+        std::memcpy(vert + i * 12, s.vert, 48);
+        i++;
+    }
+}
+// walk_dual: returns (triangles, vertices) counts in out[0..1]; then copy with orc_mesh_dual_copy
+void orc_mesh_walk_dual(void* h, uint64_t out[2]) {
+    OrcMesh* m = (OrcMesh*)h;
+    if (!m->walked) { mesh::Walker w(m->o); w.cell(mesh::CellIndex()); m->m = std::move(w.out); m->walked = true; }
+    out[0] = m->m.triangles.size(); out[1] = m->m.vertices.size();
+}
+void orc_mesh_dual_copy(void* h, uint64_t* tris, float* verts) {
+    OrcMesh* m = (OrcMesh*)h;
+    std::memcpy(tris, m->m.triangles.data(), m->m.triangles.size() * 24);
+    std::memcpy(verts, m->m.vertices.data(), m->m.vertices.size() * 12);
+}
+// CELL_TO_VERT_TO_EDGES / CELL_TO_EDGE_TO_VERT (build.rs): for mask: out[0] = vertices, then per vertex: count, (start, end)...; e2v[12][2]
+void orc_mesh_table(int mask, int32_t* v2e, int32_t* e2v) {
+    const mesh::Tables& T = mesh::tables();
+    size_t k = 0;
+    v2e[k++] = (int32_t)T.v2e[mask].size();
+    for (auto& vs : T.v2e[mask]) { v2e[k++] = (int32_t)vs.size(); for (auto& e : vs) { v2e[k++] = e.first; v2e[k++] = e.second; } }
+    for (int e = 0; e < 12; e++) { e2v[2 * e] = T.e2v[mask][e][0]; e2v[2 * e + 1] = T.e2v[mask][e][1]; }
+}
+// QuadraticErrorSolver (qef.rs): n intersections (pos[3], grad[4]) -> solve
+void orc_qef_solve(const float* pos, const float* grad, int n, float* out_pos, float* out_err) {
+    mesh::Qef q;
+    for (int i = 0; i < n; i++) q.add_intersection(pos + 3 * i, grad + 4 * i);
+    q.solve(out_pos, out_err);
 }
 }  // extern "C"

@@ -1,0 +1,252 @@
+"""fidget-mesh (Manifold Dual Contouring): the oracle's restatement (oracle/src/mesh.hpp) pinned by the reference's own
+tests (fidget-mesh/src/octree.rs:1092-1560, qef.rs:128-169, fidget/tests/octree.rs:9-30), then the device leaf sampler
+against the oracle.  Vertex positions come out of a QEF solve whose SVD is not restated bit for bit: the tolerances are
+the reference's."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import model_path
+
+
+def sphere(c, center, r):
+    x, y, z = c.x(), c.y(), c.z()
+    d = c.add(c.add(c.square(c.sub(x, center[0])), c.square(c.sub(y, center[1]))), c.square(c.sub(z, center[2])))
+    return c.sub(c.sqrt(d), r)
+
+
+def cube(c, bx, by, bz):
+    x, y, z = c.x(), c.y(), c.z()
+    xb = c.max(c.sub(bx[0], x), c.sub(x, bx[1]))
+    yb = c.max(c.sub(by[0], y), c.sub(y, by[1]))
+    zb = c.max(c.sub(bz[0], z), c.sub(z, bz[1]))
+    return c.max(c.max(xb, yb), zb)
+
+
+def check_for_vertex_dupes(verts):            # octree.rs:1561-1570
+    v = verts.view(np.uint32).reshape(-1, 3)
+    assert len(np.unique(v, axis=0)) == len(v), "duplicate vertices"
+
+
+def check_for_edge_matching(tris):            # octree.rs:1572-1594
+    edges = {}
+    for t in tris.tolist():
+        assert t[0] != t[1] and t[1] != t[2] and t[0] != t[2], "triangle with duplicate edges"
+        for e in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            edges[e] = edges.get(e, 0) + 1
+    for (a, b), n in edges.items():
+        assert n == 1, f"duplicate edge ({a}, {b})"
+        assert (b, a) in edges, "unpaired edges"
+
+
+def test_tables_match_build_rs_properties(oracle_mod):
+    """build.rs: every inside -> outside corner pair along an axis appears once; vertices partition them by region"""
+    O = oracle_mod
+    for mask in range(256):
+        v2e, e2v = O.mdc_table(mask)
+        want = {(s, s ^ ax) for s in range(8) for ax in (1, 2, 4) if (mask >> s) & 1 and not (mask >> (s ^ ax)) & 1}
+        got = [e for vs in v2e for e in vs]
+        assert set(got) == want and len(got) == len(want)
+        assert len(v2e) <= 4
+        n = 0
+        for vi, vs in enumerate(v2e):
+            for s, e in vs:
+                t = s ^ e
+                u = 1 if t == 4 else t << 1
+                v = 1 if u == 4 else u << 1
+                edge = {1: 0, 2: 1, 4: 2}[t] * 4 + (1 if s & u else 0) + (2 if s & v else 0)
+                assert e2v[edge] == (vi, len(v2e) + n)
+                n += 1
+    assert O.mdc_table(0) == ([], [None] * 12) and O.mdc_table(255)[0] == []
+    # the cube corner: one vertex with three edges (Nielson's case 1)
+    assert O.mdc_table(1)[0] == [[(0, 1), (0, 2), (0, 4)]]
+    # two opposite corners: two separate vertices
+    assert len(O.mdc_table(0b10000001)[0]) == 2
+
+
+def test_mesh_basic(oracle_mod):              # octree.rs:1141-1176
+    O = oracle_mod
+    c = O.Context()
+    s = O.Shape(c, sphere(c, (0, 0, 0), 0.2))
+    o = O.Octree(s, 0)
+    assert len(o.cells) == 0 and o.root[0] == "Empty" and len(o.verts) == 0
+    t, v = o.walk_dual()
+    assert len(t) == 0 and len(v) == 0
+    o = O.Octree(s, 1)
+    assert len(o.cells) == 1 and o.root == ("Branch", 0, 0)
+    assert len(o.verts) == 6 * 4 + 8
+    for kind, mask, index in o.cells[0].tolist():
+        assert O.CELL_KINDS[kind] == "Leaf" and bin(mask).count("1") == 1 and index % 4 == 0
+    t, v = o.walk_dual()
+    assert len(v) > 1 and len(t) > 0
+
+
+def test_sphere_verts(oracle_mod):            # octree.rs:1178-1215
+    O = oracle_mod
+    c = O.Context()
+    o = O.Octree(O.Shape(c, sphere(c, (0, 0, 0), 0.2)), 1)
+    _, verts = o.walk_dual()
+    edge_count = 0
+    for v in verts:
+        nz = int((v != 0).sum())
+        assert nz in (1, 3)
+        if nz == 1:
+            assert abs(np.linalg.norm(v) - 0.2) < 2.0 / 65535
+            edge_count += 1
+        else:
+            assert np.linalg.norm(np.abs(v) - 0.2) < 2.0 / 65535, v
+    assert edge_count == 6
+
+
+def test_sphere_manifold(oracle_mod):         # octree.rs:1217-1232
+    O = oracle_mod
+    c = O.Context()
+    o = O.Octree(O.Shape(c, sphere(c, (0, 0, 0), 0.85)), 5)
+    t, v = o.walk_dual()
+    check_for_vertex_dupes(v)
+    check_for_edge_matching(t)
+
+
+def test_cube_verts(oracle_mod):              # octree.rs:1234-1276
+    O = oracle_mod
+    c = O.Context()
+    o = O.Octree(O.Shape(c, cube(c, (-0.1, 0.6), (-0.2, 0.75), (-0.3, 0.4))), 1)
+    _, verts = o.walk_dual()
+    eps = 2.0 / 65535
+    assert len(verts)
+    lim = [(-0.1, 0.6), (-0.2, 0.75), (-0.3, 0.4)]
+    for v in verts:
+        on = [bool(v[k] != 0) for k in range(3)]
+        near = [abs(v[k] - lim[k][0]) < eps or abs(v[k] - lim[k][1]) < eps for k in range(3)]
+        assert sum(on) in (1, 3)
+        if sum(on) == 1:
+            assert any(on[k] and near[k] for k in range(3)), v
+        else:
+            assert all(near), v
+
+
+def test_cube_edge(oracle_mod):               # octree.rs:1092-1107
+    O = oracle_mod
+    c = O.Context()
+    o = O.Octree(O.Shape(c, cube(c, (-2, 2), (-2, 0.3), (-2, 0.6))), 0)
+    assert len(o.verts) == 5
+    assert np.linalg.norm(o.verts[0] - np.array([0.0, 0.3, 0.6])) < 1e-3
+
+
+def test_plane_center(oracle_mod):            # octree.rs:1278-1312
+    O = oracle_mod
+    for dx, dy, off in itertools.product([0.0, 0.25, -0.25, 2.0, -2.0], [0.0, 0.25, -0.25, 2.0, -2.0], [0.0, -0.2, 0.2]):
+        c = O.Context()
+        f = c.add(c.add(c.add(c.mul(c.x(), dx), c.mul(c.y(), dy)), c.z()), off)
+        s = O.Shape(c, f)
+        o = O.Octree(s, 0)
+        assert len(o.cells) == 0
+        pos = o.verts[0]
+        mass = o.verts[1:].mean(axis=0)
+        assert np.linalg.norm(pos - mass) < 1e-3, (dx, dy, off, pos, mass)
+        for v in o.verts:
+            assert abs(s.eval_point(float(v[0]), float(v[1]), float(v[2]))[0]) < 1e-3
+
+
+def test_cone_vert(oracle_mod):               # octree.rs:1314-1343 (cone: 1109-1139)
+    O = oracle_mod
+    for tip in (np.array([0.2, 0.3, 0.4]), np.array([1.2, 1.3, 1.4])):
+        corner = np.array([-1.0, -1.0, -1.0])
+        d = (tip - corner).astype(np.float32)
+        length = float(np.linalg.norm(d))
+        d = d / np.float32(length)
+        c = O.Context()
+        p = [c.x(), c.y(), c.z()]
+        offs = [c.sub(p[k], float(corner[k])) for k in range(3)]
+        a = c.add(c.add(c.mul(offs[0], float(d[0])), c.mul(offs[1], float(d[1]))), c.mul(offs[2], float(d[2])))
+        apos = [c.add(float(corner[k]), c.mul(float(d[k]), a)) for k in range(3)]
+        o2 = [c.sub(p[k], apos[k]) for k in range(3)]
+        b = c.sqrt(c.add(c.add(c.square(o2[0]), c.square(o2[1])), c.square(o2[2])))
+        f = c.sub(b, c.mul(0.1, c.sub(1.0, c.div(a, length))))
+        s = O.Shape(c, f)
+        assert abs(s.eval_point(*[float(t) for t in tip])[0]) < 1e-6
+        assert s.eval_point(-1.0, -1.0, -1.0)[0] < 0
+        o = O.Octree(s, 0)
+        assert len(o.cells) == 0 and len(o.verts) == 4
+        assert np.linalg.norm(o.verts[0] - tip) < 1e-3, (o.verts[0], tip)
+
+
+def test_qef_rank2_and_near_planar(oracle_mod):     # qef.rs:133-168
+    O = oracle_mod
+    _, err = O.qef_solve([[-0.5, -0.75, -0.75], [-0.75, -1.0, -0.6], [-0.5, -1.0, -0.6]],
+                         [[0.24, 0.12, 0.0, 0.0], [0.0, 0.0, 0.31, 0.0], [0.0, 0.0, 0.31, 0.0]])
+    assert err == np.float32(1e-6)
+    pos, err = O.qef_solve([[-0.5, -0.25, 0.4999981], [-0.5, -0.25, 0.5], [-0.5, -0.25, 0.5]],
+                           [[-0.66666776, -0.33333388, 0.66666526, -1.2516975e-6], [-0.6666667, -0.33333334, 0.6666667, 0.0],
+                            [-0.6666667, -0.33333334, 0.6666667, 0.0]])
+    assert err == np.float32(1e-6)
+    assert np.linalg.norm(pos - np.array([-0.5, -0.25, 0.5])) < 1e-3
+
+
+@pytest.mark.parametrize("mask", list(range(0, 256, 5)) + [255])
+def test_mesh_manifold(mask, oracle_mod):     # octree.rs:1345-1391 (a fifth of the 256 masks: the CPU suite has a time budget)
+    O = oracle_mod
+    c = O.Context()
+    parts = [sphere(c, (0.5 if j & 1 else 0.0, 0.5 if j & 2 else 0.0, 0.5 if j & 4 else 0.0), 0.1) for j in range(8) if mask & (1 << j)]
+    if not parts:
+        return
+    node = parts.pop()
+    for p in parts:
+        node = c.min(node, p)
+    o = O.Octree(O.Shape(c, node), 2)
+    t, v = o.walk_dual()
+    if mask not in (0, 255):
+        assert len(v) and len(t)
+    check_for_vertex_dupes(v)
+    check_for_edge_matching(t)
+
+
+def test_colonnade_manifold_and_bounds(oracle_mod):   # octree.rs:1476-1500 (depth 5), 1502-1530 (bounds; depth 6 here, 8 there)
+    O = oracle_mod
+    s = O.Shape.from_vm(model_path("colonnade.vm"))
+    t, v = O.Octree(s, 5).walk_dual()
+    check_for_edge_matching(t)
+    _, v = O.Octree(s, 6).walk_dual()
+    assert (v[:, 0] < 1).all() and (v[:, 0] > -1).all() and (v[:, 1] < 1).all() and (v[:, 1] > -1).all() and (v[:, 2] < 1).all() and (v[:, 2] > -0.5).all()
+
+
+def test_bear_bounds(oracle_mod):             # octree.rs:1532-1559
+    O = oracle_mod
+    _, v = O.Octree(O.Shape.from_vm(model_path("bear.vm")), 5).walk_dual()
+    assert (v[:, 0] < 1).all() and (v[:, 0] > -0.75).all() and (v[:, 1] < 1).all() and (v[:, 1] > -0.75).all()
+    assert (v[:, 2] < 0.75).all() and (v[:, 2] > -0.75).all()
+
+
+def test_octree_camera(oracle_mod):           # fidget/tests/octree.rs:9-30: View3::from_center_and_scale(center, 0.5)
+    O = oracle_mod
+    c = O.Context()
+    s = O.Shape(c, sphere(c, (1.0, 1.0, 1.0), 0.25))
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] *= 0.5
+    m[:3, 3] = 1.0
+    _, v = O.Octree(s, 4, world_to_model=m).walk_dual()
+    n = np.linalg.norm(v - 1.0, axis=1)
+    assert len(v) and (n > 0.2).all() and (n < 0.3).all()
+
+
+def test_gyroid_sphere_model_and_leaf_samples(oracle_mod):
+    """models/gyroid-sphere.vm restates models/gyroid-sphere.rhai (BASELINE config 5); its leaf samples obey the invariants of
+    octree.rs:590-862: intersections lie on cell edges between an inside and an outside corner, |value| small there"""
+    O = oracle_mod
+    s = O.Shape.from_vm(model_path("gyroid-sphere.vm"))
+    x, y, z = 0.31, -0.22, 0.4
+    g = np.sin(30 * x) * np.cos(30 * y) + np.sin(30 * y) * np.cos(30 * z) + np.sin(30 * z) * np.cos(30 * x)
+    want = max(np.sqrt((30 * x) ** 2 + (30 * y) ** 2 + (30 * z) ** 2) - 25, abs(g) - 0.2)
+    assert abs(s.eval_point(x, y, z)[0] - want) < 1e-4
+    o = O.Octree(s, 5)
+    sm = o.samples
+    assert len(sm["info"]) > 100
+    for i in range(0, len(sm["info"]), 37):
+        mask, ne, nv = sm["info"][i]
+        v2e, _ = O.mdc_table(int(mask))
+        assert ne == sum(len(v) for v in v2e) and nv == len(v2e)
+        for e in range(ne):
+            on_edge = sorted(int(p in (0, 65535)) for p in sm["inter"][i, e])
+            assert on_edge == [0, 1, 1] or on_edge == [1, 1, 1]
+            assert abs(s.eval_point(*[float(t) for t in sm["pos"][i, e]])[0]) < 0.05
