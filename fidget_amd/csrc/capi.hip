@@ -16,6 +16,7 @@
 #include "host_graph.hpp"
 #include "kernels.hip"
 #include "effects.hip"
+#include "mesh.hip"
 
 #define FH_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
 
@@ -1351,6 +1352,152 @@ fhip_status fhip_to_rgba(fhip_ctx* ctx, const float* image, uint32_t width, uint
     hipLaunchKernelGGL(fhfx::k_fx_rgba, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)di, n, mode, (uchar4*)dout);
     return st.finish();
 }
+
+// ---- meshing: the evaluation side of fidget_mesh::Octree::build (fidget-mesh/src/octree.rs) --------------------------------
+// CELL_TO_VERT_TO_EDGES of fidget-mesh/build.rs:26-160: per corner mask, the inside -> outside edges grouped into cell vertices
+// by connected region (filled regions first, then empty ones, each in ascending order of their corner sets)
+static void build_mdc_table(FhMdcTable& T) {
+    auto next = [](int a) { return (a << 1) > 4 ? 1 : (a << 1); };
+    for (int i = 0; i < 256; i++) {
+        int region_of[2][8];
+        for (int pass = 0; pass < 2; pass++) {
+            int* r = region_of[pass];
+            for (int j = 0; j < 8; j++) r[j] = 1 << j;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int f = 0; f < 8; f++) {
+                    if ((((i >> f) & 1) != 0) != (pass == 0)) continue;
+                    for (int axis : {1, 2, 4}) {
+                        const int g = f ^ axis;
+                        if ((((i >> g) & 1) != 0) != (pass == 0)) continue;
+                        const int v = r[f] | r[g];
+                        if (r[f] != v || r[g] != v) { r[f] = v; r[g] = v; changed = true; }
+                    }
+                }
+            }
+        }
+        std::vector<int> fr, er;
+        for (int j = 0; j < 8; j++) ((i >> j) & 1 ? fr : er).push_back(region_of[(i >> j) & 1 ? 0 : 1][j]);
+        for (auto* v : {&fr, &er}) { std::sort(v->begin(), v->end()); v->erase(std::unique(v->begin(), v->end()), v->end()); }
+        int regions[8], ri = 0;
+        for (auto* rs : {&fr, &er})
+            for (int r : *rs) { for (int j = 0; j < 8; j++) if (r & (1 << j)) regions[j] = ri; ri++; }
+        std::vector<std::pair<int, std::vector<std::pair<int, int>>>> verts;
+        for (int rev = 0; rev < 2; rev++)
+            for (int t : {1, 2, 4}) {
+                const int u = next(t), v = next(u);
+                for (int b = 0; b < 2; b++)
+                    for (int a = 0; a < 2; a++) {
+                        int start = (a * u) | (b * v), end = start | t;
+                        if (rev) std::swap(start, end);
+                        if (!(((i >> start) & 1) && !((i >> end) & 1))) continue;
+                        auto it = std::find_if(verts.begin(), verts.end(), [&](auto& kv) { return kv.first == regions[start]; });
+                        if (it == verts.end()) { verts.push_back({regions[start], {}}); it = verts.end() - 1; }
+                        it->second.push_back({start, end});
+                    }
+            }
+        std::sort(verts.begin(), verts.end(), [](auto& a, auto& b) { return a.first < b.first; });
+        T.n_verts[i] = (uint8_t)verts.size();
+        int ne = 0;
+        for (int k = 0; k < 4; k++) T.per_vert[i][k] = 0;
+        for (size_t vi = 0; vi < verts.size(); vi++) {
+            T.per_vert[i][vi] = (uint8_t)verts[vi].second.size();
+            for (auto& e : verts[vi].second) { T.edge[i][ne][0] = (uint8_t)e.first; T.edge[i][ne][1] = (uint8_t)e.second; ne++; }
+        }
+        T.n_edges[i] = (uint8_t)ne;
+    }
+}
+struct fhip_mesh {
+    std::vector<FhMeshLeaf> leaves;
+    uint64_t cells_evaluated = 0, full = 0, empty = 0, ambiguous_leaves = 0;
+    std::vector<uint64_t> per_level;   // cells evaluated at each depth
+};
+fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
+    if (!out) return FHIP_ERR_BAD_TAPE;
+    *out = nullptr;
+    if (depth > 20) return fail(ctx, FHIP_ERR_UNSUPPORTED, "octree depth above 20");
+    const fh::HostTape& t = tape->t;
+    if (t.n_outputs != 1) return fail(ctx, FHIP_ERR_BAD_TAPE, "shape tapes have exactly one output");
+    (void)hipSetDevice(ctx->device);
+    { fhip_status ts_ = tape_to_device(ctx, tape); if (ts_) return ts_; }
+    FhRender R;
+    memset(&R, 0, sizeof(R));
+    fhip_status st = bind_inputs(ctx, tape, axis_slots, var_keys, var_values, n_vars, R);
+    if (st) return st;
+    FhMeshParams P;
+    memset(&P, 0, sizeof(P));
+    P.tape = tape->d_ops; P.len = (uint32_t)t.ops.size(); P.n_regs = std::max<uint32_t>(t.n_regs, 1);
+    bool ident = true;
+    if (world_to_model) for (int i = 0; i < 16; i++) { P.mat[i] = world_to_model[i]; ident &= world_to_model[i] == ((i % 5 == 0) ? 1.0f : 0.0f); }
+    P.has_mat = (world_to_model && !ident) ? 1 : 0;     // octree.rs:487-492: no transform at all for the identity
+    for (int s = 0; s < FH_MAX_INPUTS; s++) { P.in_kind[s] = R.in_kind[s]; P.in_value[s] = R.in_value[s]; }
+    const size_t lds_iv = (size_t)P.n_regs * WAVE * 8, lds_leaf = (size_t)P.n_regs * WAVE * 16;
+    if (lds_leaf + 1024 > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)fhm::k_mesh_cells, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+        (void)hipFuncSetAttribute((const void*)fhm::k_mesh_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX - 2048);
+        attr_done = true;
+    }
+    fhip_mesh* M = new fhip_mesh();
+    DevBuf bufs[2], counters, table, leaves;
+    auto cleanup = [&] { bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); };
+#define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+    MESH_TRY(counters.ensure(16));
+    FhMeshCell root;
+    for (int k = 0; k < 3; k++) { root.b[2 * k] = -1.0f; root.b[2 * k + 1] = 1.0f; }     // CellBounds::new (cell.rs:171-176)
+    root.path = 1;
+    MESH_TRY(bufs[0].ensure(sizeof(FhMeshCell)));
+    MESH_TRY(hipMemcpyAsync(bufs[0].p, &root, sizeof(root), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t n_in = 1;      // cells in bufs[cur] to evaluate (level 0) or whose 8 children to evaluate
+    int cur = 0;
+    uint32_t n_leaf_cells = 0;
+    for (uint32_t d = 0; d <= depth; d++) {
+        const uint64_t n64 = d == 0 ? 1 : (uint64_t)n_in * 8;
+        if (n64 > (1ull << 30)) { cleanup(); delete M; return fail(ctx, FHIP_ERR_OVERFLOW, "octree level above 2^30 cells"); }
+        const uint32_t n = (uint32_t)n64;
+        MESH_TRY(bufs[cur ^ 1].ensure((size_t)n * sizeof(FhMeshCell)));
+        MESH_TRY(hipMemsetAsync(counters.p, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(fhm::k_mesh_cells, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n, d == 0 ? 0 : 1,
+                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n);
+        MESH_TRY(hipGetLastError());
+        uint32_t c[4];
+        MESH_TRY(hipMemcpyAsync(c, counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        MESH_TRY(hipStreamSynchronize(ctx->stream));
+        M->cells_evaluated += n; M->full += c[1]; M->empty += c[2];
+        M->per_level.push_back(n);
+        cur ^= 1;
+        n_in = c[0];
+        if (d == depth) n_leaf_cells = c[0];
+        if (n_in == 0) break;
+    }
+    M->ambiguous_leaves = n_leaf_cells;
+    if (n_leaf_cells) {
+        FhMdcTable T;
+        build_mdc_table(T);
+        MESH_TRY(table.ensure(sizeof(T)));
+        MESH_TRY(hipMemcpyAsync(table.p, &T, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        MESH_TRY(leaves.ensure((size_t)n_leaf_cells * sizeof(FhMeshLeaf)));
+        hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(n_leaf_cells), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n_leaf_cells,
+                           (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p);
+        MESH_TRY(hipGetLastError());
+        M->leaves.resize(n_leaf_cells);
+        MESH_TRY(hipMemcpyAsync(M->leaves.data(), leaves.p, (size_t)n_leaf_cells * sizeof(FhMeshLeaf), hipMemcpyDeviceToHost, ctx->stream));
+        MESH_TRY(hipStreamSynchronize(ctx->stream));
+    }
+#undef MESH_TRY
+    cleanup();
+    *out = M;
+    return FHIP_OK;
+}
+void fhip_mesh_free(fhip_mesh* m) { delete m; }
+// out = {cells evaluated (= interval evaluations), Full, Empty, ambiguous cells at the leaf depth (= calls of leaf()), bytes per leaf record, levels}
+void fhip_mesh_counts(const fhip_mesh* m, uint64_t out[8]) {
+    out[0] = m->cells_evaluated; out[1] = m->full; out[2] = m->empty; out[3] = m->ambiguous_leaves; out[4] = sizeof(FhMeshLeaf);
+    out[5] = m->per_level.size(); out[6] = out[7] = 0;
+}
+void fhip_mesh_leaves(const fhip_mesh* m, void* out) { memcpy(out, m->leaves.data(), m->leaves.size() * sizeof(FhMeshLeaf)); }
 
 // ---- profiling -------------------------------------------------------------------------
 void fhip_profile_enable(fhip_ctx* ctx, int on) { ctx->profiling = on != 0; }

@@ -1,0 +1,308 @@
+// fidget-hip: the evaluation side of fidget-mesh's octree construction on the device (fidget-mesh/src/octree.rs).
+//
+//   k_mesh_cells  one lane per octree cell of a level: cell bounds (cell.rs:184-194 midpoint splitting), interval
+//                 evaluation of the shape's tape (octree.rs:521-544), classification Full / Empty / ambiguous; the ambiguous
+//                 cells are appended to the next level's list (or, at the last level, to the leaf list);
+//   k_mesh_leaf   one wavefront per ambiguous leaf cell (octree.rs:590-862): the 8 corners (bulk f32) -> corner mask ->
+//                 edges of the Manifold Dual Contouring table -> 4 rounds of 16-point search per edge (4 edges per 64-lane
+//                 pass) -> intersections (u16 cell coordinates) -> gradients there -> one QEF per cell vertex (qef.rs).
+//
+// Every cell is evaluated with the shape's own tape (values do not depend on tape simplification); pruning
+// the tape down the octree as the render's tile stage does is the next step for large tapes.  The octree bookkeeping
+// (cell collapse, the dual walk) has no evaluation in it and stays on the host side of the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_ops.hpp"
+// (included by capi.hip after kernels.hip: Regs, step, ballot, uni, ctape_t)
+
+struct FhMeshCell {
+    float b[6];        // x.lo x.hi y.lo y.hi z.lo z.hi
+    uint64_t path;     // 3 bits per level below the root (corner index), leading 1
+};
+struct FhMeshLeaf {
+    float b[6];
+    uint64_t path;
+    uint32_t mask, n_edges, n_verts, pad;
+    uint16_t inter[12][3];
+    uint16_t pad2[4];
+    float pos[12][3];
+    float grad[12][4];   // dx dy dz v
+    float vert[4][3];
+    float qef_err[4];
+};
+// CELL_TO_VERT_TO_EDGES (fidget-mesh/build.rs), flattened: per mask the edges in vertex order as (start, end), edges per vertex
+struct FhMdcTable {
+    uint8_t n_edges[256], n_verts[256];
+    uint8_t per_vert[256][4];
+    uint8_t edge[256][12][2];
+};
+struct FhMeshParams {
+    const uint64_t* tape;
+    uint32_t len, n_regs;
+    float mat[16];
+    uint32_t has_mat;
+    uint32_t in_kind[FH_MAX_INPUTS];
+    float in_value[FH_MAX_INPUTS];
+};
+
+namespace fhm {
+using namespace fhd;
+
+__device__ __forceinline__ float lerp_pos(float lo, float hi, uint32_t p) {   // cell.rs:208-217, Interval::lerp
+    const float f = (float)p / 65535.0f;
+    return lo * (1.0f - f) + hi * f;
+}
+
+// interval evaluation + classification of the cells of one level.  expand: cell i is child (i & 7) of in[i >> 3]
+__global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMeshCell* in, uint32_t n, int expand, FhMeshCell* out, uint32_t* counters /* amb, full, empty */,
+                                                      uint32_t out_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * WAVE + lane;
+    const bool act = i < n;
+    FhMeshCell c;
+    {
+        const FhMeshCell p = in[expand ? min(i, n - 1) >> 3 : min(i, n - 1)];
+        c = p;
+        if (expand) {
+            const int corner = i & 7;
+            for (int k = 0; k < 3; k++) {
+                const float mid = (p.b[2 * k] + p.b[2 * k + 1]) / 2.0f;
+                if (corner & (1 << k)) { c.b[2 * k] = mid; c.b[2 * k + 1] = p.b[2 * k + 1]; } else { c.b[2 * k] = p.b[2 * k]; c.b[2 * k + 1] = mid; }
+            }
+            c.path = (p.path << 3) | (uint64_t)corner;
+        }
+    }
+    IV X = iv(c.b[0], c.b[1]), Y = iv(c.b[2], c.b[3]), Z = iv(c.b[4], c.b[5]);
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m.m[k] = P.mat[k];
+        xf_interval(m, X, Y, Z, X, Y, Z);
+    }
+    Regs<IV, WAVE> R{(IV*)smem, lane};
+    IV result = iv_nan();
+    const ctape_t tape = (ctape_t)P.tape;
+    for (uint32_t k = 0; k < P.len; k++) {
+        step<IVAL, WAVE, true>(
+            tape[k], R,
+            [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); },
+            [&](uint32_t, IV v) { result = v; }, [&](int) {});
+    }
+    const bool full = act && result.hi < 0.0f, empty = act && !full && result.lo > 0.0f, amb = act && !full && !empty;
+    const uint64_t am = ballot(amb);
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (am) base = atomicAdd(&counters[0], (uint32_t)__popcll(am));
+        const uint32_t nf = (uint32_t)__popcll(ballot(full)), ne = (uint32_t)__popcll(ballot(empty));
+        if (nf) atomicAdd(&counters[1], nf);
+        if (ne) atomicAdd(&counters[2], ne);
+    }
+    base = uni(base);
+    if (amb) {
+        const uint32_t slot = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
+        if (slot < out_cap) out[slot] = c;
+    }
+}
+
+// the QEF of one cell vertex (qef.rs:45-126; SVD of the symmetric A^T A by cyclic Jacobi rotations in f64)
+struct Qef {
+    float ata[3][3], atb[3], btb, mass[4];
+    __device__ void init() {
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) ata[i][j] = 0.0f; atb[i] = 0.0f; }
+        btb = 0.0f;
+        for (int i = 0; i < 4; i++) mass[i] = 0.0f;
+    }
+    __device__ void add(const float* pos, const float* grad) {
+        mass[0] += pos[0]; mass[1] += pos[1]; mass[2] += pos[2]; mass[3] += 1.0f;
+        const float nn = sqrtf(0.0f + ((grad[0] * grad[0] + grad[1] * grad[1]) + grad[2] * grad[2]));
+        const float n[3] = {grad[0] / nn, grad[1] / nn, grad[2] / nn};
+        const float d = (n[0] * pos[0] + n[1] * pos[1]) + n[2] * pos[2];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) ata[i][j] += n[i] * n[j];
+            atb[i] += n[i] * d;
+        }
+        btb += d * d;
+    }
+    __device__ void solve(float* pos, float* err) const {
+        const float center[3] = {mass[0] / mass[3], mass[1] / mass[3], mass[2] / mass[3]};
+        float b[3];
+        for (int i = 0; i < 3; i++) b[i] = atb[i] - ((ata[i][0] * center[0] + ata[i][1] * center[1]) + ata[i][2] * center[2]);
+        double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = ata[i][j];
+        for (int sweep = 0; sweep < 32; sweep++) {
+            const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+            if (off < 1e-30) break;
+            for (int p = 0; p < 2; p++)
+                for (int q = p + 1; q < 3; q++) {
+                    if (fabs(a[p][q]) < 1e-300) continue;
+                    const double th = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                    const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                    for (int k = 0; k < 3; k++) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+                    for (int k = 0; k < 3; k++) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+                    for (int k = 0; k < 3; k++) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+                }
+        }
+        int order[3] = {0, 1, 2};
+        for (int i = 0; i < 2; i++)          // stable selection sort, descending |eigenvalue| (std::sort on 3 elements in the oracle)
+            for (int j = i + 1; j < 3; j++)
+                if (fabs(a[order[j]][order[j]]) > fabs(a[order[i]][order[i]])) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+        float sv[3];
+        for (int i = 0; i < 3; i++) sv[i] = (float)fabs(a[order[i]][order[i]]);
+        const float cutoff = fabsf(sv[0]) * 1e-3f;
+        int rank = 3;
+        for (int i = 0; i < 3; i++) if (fabsf(sv[i]) < cutoff) { rank = i; break; }
+        const float eps = rank < 3 ? sv[rank] : 0.0f;
+        double sol[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) {
+            const int e = order[k];
+            if (!((float)fabs(a[e][e]) > eps)) continue;
+            const double proj = (v[0][e] * b[0] + v[1][e] * b[1] + v[2][e] * b[2]) / a[e][e];
+            for (int i = 0; i < 3; i++) sol[i] += v[i][e] * proj;
+        }
+        for (int i = 0; i < 3; i++) pos[i] = (float)sol[i] + center[i];
+        float ap[3];
+        for (int i = 0; i < 3; i++) ap[i] = (ata[i][0] * pos[0] + ata[i][1] * pos[1]) + ata[i][2] * pos[2];
+        float e = ((pos[0] * ap[0] + pos[1] * ap[1]) + pos[2] * ap[2]) - 2.0f * ((pos[0] * atb[0] + pos[1] * atb[1]) + pos[2] * atb[2]);
+        e += btb;
+        *err = e > 1e-6f ? e : 1e-6f;
+    }
+};
+
+// f32 value of the tape at this lane's point (lanes evaluate different points of the same leaf)
+__device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<float, WAVE>& R, float x, float y, float z) {
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m.m[k] = P.mat[k];
+        xf_point(m, x, y, z, x, y, z);
+    }
+    float result = qnan();
+    const ctape_t tape = (ctape_t)P.tape;
+    for (uint32_t k = 0; k < P.len; k++) {
+        step<F32, WAVE, true>(
+            tape[k], R, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? x : (kd == 1 ? y : (kd == 2 ? z : P.in_value[slot])); },
+            [&](uint32_t, float v) { result = v; }, [&](int) {});
+    }
+    return result;
+}
+
+__global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMeshCell* cells, uint32_t n, const FhMdcTable* T, FhMeshLeaf* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint16_t s_start[12][3], s_end[12][3];
+    __shared__ float s_pos[12][3], s_grad[12][4];
+    const int lane = threadIdx.x;
+    const uint32_t li = blockIdx.x;
+    if (li >= n) return;
+    const FhMeshCell c = cells[li];
+    Regs<float, WAVE> R{(float*)smem, lane};
+    // corners (cell.rs:196-206): bit 0 x, 1 y, 2 z
+    const int cr = lane & 7;
+    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4]);
+    const uint32_t mask = (uint32_t)(ballot(v < 0.0f) & 0xFFull);
+    FhMeshLeaf* o = &out[li];
+    if (lane < 6) o->b[lane] = c.b[lane];
+    if (lane == 0) { o->path = c.path; o->mask = mask; o->n_edges = 0; o->n_verts = 0; o->pad = 0; }
+    if (mask == 0 || mask == 255) return;      // Cell::Empty / Cell::Full (octree.rs:633-637)
+    const uint32_t ne = T->n_edges[mask], nv = T->n_verts[mask];
+    if (lane < (int)ne) {
+        const int st = T->edge[mask][lane][0], en = T->edge[mask][lane][1];
+        const int axis = st ^ en, ai = axis == 1 ? 0 : (axis == 2 ? 1 : 2);
+        const uint16_t a = (en & axis) ? 0 : 65535, b = (en & axis) ? 65535 : 0;
+        uint16_t p[3] = {0, 0, 0};
+        const int i = (ai + 1) % 3, j = (ai + 2) % 3;
+        p[i] = (st & (1 << i)) ? 65535 : 0;
+        p[j] = (st & (1 << j)) ? 65535 : 0;
+        for (int k = 0; k < 3; k++) { s_start[lane][k] = p[k]; s_end[lane][k] = p[k]; }
+        s_start[lane][ai] = a; s_end[lane][ai] = b;
+    }
+    __syncthreads();
+    // N-ary search: 4 rounds of 16 points per edge, 4 edges per pass (octree.rs:697-768)
+    for (int round = 0; round < 4; round++) {
+        for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+            const uint32_t e = e0 + (lane >> 4), j = lane & 15;
+            const bool valid = e < ne;
+            const uint32_t ee = valid ? e : 0;
+            uint32_t p[3];
+            for (int k = 0; k < 3; k++) p[k] = ((uint32_t)s_start[ee][k] * (15u - j) + (uint32_t)s_end[ee][k] * j) / 15u;
+            const float r = eval_point(P, R, lerp_pos(c.b[0], c.b[1], p[0]), lerp_pos(c.b[2], c.b[3], p[1]), lerp_pos(c.b[4], c.b[5], p[2]));
+            const uint64_t nonneg = ballot(r >= 0.0f);
+            const uint32_t m16 = (uint32_t)(nonneg >> ((lane >> 4) * 16)) & 0xFFFFu;
+            uint32_t frac = m16 ? (uint32_t)__builtin_ctz(m16) : 16u;
+            if (frac == 0) frac = 1;
+            if (frac > 15) frac = 15;
+            __syncthreads();
+            if (valid && j == 0) {
+                uint16_t a[3], b[3];
+                for (int k = 0; k < 3; k++) {
+                    a[k] = (uint16_t)(((uint32_t)s_start[e][k] * (15u - (frac - 1)) + (uint32_t)s_end[e][k] * (frac - 1)) / 15u);
+                    b[k] = (uint16_t)(((uint32_t)s_start[e][k] * (15u - frac) + (uint32_t)s_end[e][k] * frac) / 15u);
+                }
+                for (int k = 0; k < 3; k++) { s_start[e][k] = a[k]; s_end[e][k] = b[k]; }
+            }
+            __syncthreads();
+        }
+    }
+    // intersections, gradients (octree.rs:771-803)
+    {
+        const uint32_t e = lane < (int)ne ? lane : 0;
+        uint16_t q[3];
+        for (int k = 0; k < 3; k++) q[k] = (uint16_t)(((uint32_t)s_start[e][k] + (uint32_t)s_end[e][k]) / 2u);
+        const float px = lerp_pos(c.b[0], c.b[1], q[0]), py = lerp_pos(c.b[2], c.b[3], q[1]), pz = lerp_pos(c.b[4], c.b[5], q[2]);
+        GR gx = gr(px, 1.0f, 0.0f, 0.0f), gy = gr(py, 0.0f, 1.0f, 0.0f), gz = gr(pz, 0.0f, 0.0f, 1.0f);
+        if (P.has_mat) {
+            Mat4 m;
+#pragma unroll
+            for (int k = 0; k < 16; k++) m.m[k] = P.mat[k];
+            xf_grad(m, gx, gy, gz, gx, gy, gz);
+        }
+        __syncthreads();
+        Regs<GR, WAVE> G{(GR*)smem, lane};
+        GR result = gr1(qnan());
+        const ctape_t tape = (ctape_t)P.tape;
+        for (uint32_t k = 0; k < P.len; k++) {
+            step<GRAD, WAVE, true>(
+                tape[k], G, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot]))); },
+                [&](uint32_t, GR v) { result = v; }, [&](int) {});
+        }
+        if (lane < (int)ne) {
+            for (int k = 0; k < 3; k++) o->inter[lane][k] = q[k];
+            o->pos[lane][0] = px; o->pos[lane][1] = py; o->pos[lane][2] = pz;
+            o->grad[lane][0] = result.dx; o->grad[lane][1] = result.dy; o->grad[lane][2] = result.dz; o->grad[lane][3] = result.v;
+            s_pos[lane][0] = px; s_pos[lane][1] = py; s_pos[lane][2] = pz;
+            s_grad[lane][0] = result.dx; s_grad[lane][1] = result.dy; s_grad[lane][2] = result.dz; s_grad[lane][3] = result.v;
+        }
+    }
+    __syncthreads();
+    // one QEF per cell vertex (octree.rs:805-848), vertices in order: a NaN gradient snaps the vertex to that intersection and
+    // stops its loop WITHOUT consuming the edge (the reference's `break` comes before `i += 1`), so the next vertex starts there
+    if (lane == 0) {
+        uint32_t i = 0;
+        for (uint32_t vtx = 0; vtx < nv; vtx++) {
+            Qef q;
+            q.init();
+            bool forced = false;
+            float pos[3] = {0, 0, 0}, err = -1.0f;
+            for (uint32_t k = 0; k < T->per_vert[mask][vtx]; k++) {
+                const uint32_t ii = i < 12 ? i : 11;
+                const float* g = s_grad[ii];
+                if (g[0] != g[0] || g[1] != g[1] || g[2] != g[2] || g[3] != g[3]) {
+                    forced = true;
+                    for (int a = 0; a < 3; a++) pos[a] = s_pos[ii][a];
+                    err = -2.0f;
+                    break;
+                }
+                q.add(s_pos[ii], g);
+                i++;
+            }
+            if (!forced) q.solve(pos, &err);
+            for (int a = 0; a < 3; a++) o->vert[vtx][a] = pos[a];
+            o->qef_err[vtx] = err;
+        }
+    }
+    if (lane == 0) { o->n_edges = ne; o->n_verts = nv; }
+}
+
+}  // namespace fhm

@@ -181,6 +181,22 @@ fhip_status fhip_apply_shading(fhip_ctx* ctx, const void* image, uint32_t width,
  * 2 to_debug_bitmap (467-496), 3 to_rgba_distance (506-547) */
 fhip_status fhip_to_rgba(fhip_ctx* ctx, const float* image, uint32_t width, uint32_t height, int mode, uint8_t* out_rgba, int on_device);
 
+/* ---- meshing: the evaluation side of fidget_mesh::Octree::build (fidget-mesh/src/octree.rs) -----------------
+ * Octree cells of [-1, 1]^3 to `depth` (Settings::depth), classified by interval evaluation (recurse, octree.rs:521-583), and
+ * every ambiguous cell of the last level sampled as leaf() does (octree.rs:590-862): corner mask, Manifold Dual Contouring
+ * edges, 4 x 16-point edge search, intersections, gradients, one QEF vertex per cell vertex.  What has no evaluation in it
+ * (cell collapse, the dual walk) stays with the caller.  Leaf record (fhip_mesh_counts out[4] bytes, 528): f32 bounds[6]
+ * (x.lo x.hi y.lo y.hi z.lo z.hi); u64 path (3 bits per level, leading 1); u32 mask, n_edges, n_verts, pad; u16 inter[12][3]
+ * (+ 4 u16 pad); f32 pos[12][3]; f32 grad[12][4] (dx dy dz v); f32 vert[4][3]; f32 qef_err[4].  mask 0 / 255: the cell turned
+ * out Empty / Full at its corners (n_edges = 0). */
+typedef struct fhip_mesh fhip_mesh;
+fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
+void fhip_mesh_free(fhip_mesh* mesh);
+/* out = {cells interval-evaluated, Full, Empty, ambiguous cells at the leaf depth, bytes per leaf record, levels visited, 0, 0} */
+void fhip_mesh_counts(const fhip_mesh* mesh, uint64_t out[8]);
+void fhip_mesh_leaves(const fhip_mesh* mesh, void* out);
+
 /* ---- profiling ----------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a render is bracketed by HIP events on the context's
  * stream; fhip_profile_read returns per-kernel-class totals of the last render. */

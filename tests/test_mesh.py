@@ -250,3 +250,83 @@ def test_gyroid_sphere_model_and_leaf_samples(oracle_mod):
             on_edge = sorted(int(p in (0, 65535)) for p in sm["inter"][i, e])
             assert on_edge == [0, 1, 1] or on_edge == [1, 1, 1]
             assert abs(s.eval_point(*[float(t) for t in sm["pos"][i, e]])[0]) < 0.05
+
+
+# ---- device leaf sampler against the oracle ---------------------------------------------------------------------------
+def _key(bounds):
+    return tuple(np.asarray(bounds, np.float32).view(np.uint32).tolist())
+
+
+def _compare(F, O, fshape, oshape, depth, w2m=None, transcendental=False):
+    leaves, counts = F.mesh_sample(fshape, depth, world_to_model=w2m)
+    o = O.Octree(oshape, depth, world_to_model=w2m)
+    # every cell the reference's recursion interval-evaluates, and no other
+    assert counts["cells"] == o.interval_evals, (counts, o.interval_evals)
+    sm = o.samples
+    want = {_key(sm["bounds"][i]): i for i in range(len(sm["info"]))}
+    sampled = leaves[(leaves["mask"] != 0) & (leaves["mask"] != 255)]
+    assert len(sampled) == len(want), (len(sampled), len(want))
+    nd = 0
+    for lf in sampled:
+        i = want[_key(lf["bounds"])]
+        mask, ne, nv = (int(v) for v in sm["info"][i])
+        assert (int(lf["mask"]), int(lf["n_edges"]), int(lf["n_verts"])) == (mask, ne, nv)
+        if transcendental:
+            # intersections come out of sign tests of values 1 ulp apart at most: identical except where the field is within an ulp
+            # of zero at a search point; positions then differ by one step of the last round
+            same = (lf["inter"][:ne] == sm["inter"][i, :ne]).all()
+            nd += 0 if same else 1
+            if same:
+                g, w = lf["grad"][:ne], sm["grad"][i, :ne]
+                scale = np.abs(w[:, :3]).max(axis=1, keepdims=True)
+                assert (np.abs(g[:, :3] - w[:, :3]) <= 64 * 2.0 ** -23 * np.maximum(scale, 1e-30)).all()
+            continue
+        assert (lf["inter"][:ne] == sm["inter"][i, :ne]).all(), "edge-search intersections differ"
+        assert (lf["pos"][:ne].view(np.uint32) == sm["pos"][i, :ne].view(np.uint32)).all()
+        g, w = lf["grad"][:ne], sm["grad"][i, :ne]
+        assert ((g == w) | (np.isnan(g) & np.isnan(w))).all(), "gradients differ"
+        v, wv = lf["vert"][:nv], sm["vert"][i, :nv]
+        assert ((v == wv) | (np.isnan(v) & np.isnan(wv))).all(), f"QEF vertices differ: {v} vs {wv}"
+    assert nd <= max(1, len(sampled) // 200)
+    return counts, len(sampled)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 1, 3, 5])
+def test_device_leaf_samples_sphere_and_cube(depth, oracle_mod):
+    import fidget_amd as F
+    O = oracle_mod
+    for build in (lambda c: sphere(c, (0.1, -0.05, 0.2), 0.6), lambda c: cube(c, (-0.1, 0.6), (-0.2, 0.75), (-0.3, 0.4))):
+        cf, co = F.Context(), O.Context()
+        _compare(F, O, F.Shape(cf, build(cf)), O.Shape(co, build(co)), depth)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("colonnade.vm", 6), ("prospero.vm", 5), ("tanglecube.vm", 6)])
+def test_device_leaf_samples_models(model, depth, oracle_mod):
+    import fidget_amd as F
+    O = oracle_mod
+    counts, n = _compare(F, O, F.Shape.from_vm(model_path(model)), O.Shape.from_vm(model_path(model)), depth)
+    assert n > 50
+
+
+@pytest.mark.gpu
+def test_device_leaf_samples_camera(oracle_mod):
+    import fidget_amd as F
+    O = oracle_mod
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] *= 0.5
+    m[:3, 3] = 1.0
+    cf, co = F.Context(), O.Context()
+    _compare(F, O, F.Shape(cf, sphere(cf, (1.0, 1.0, 1.0), 0.25)), O.Shape(co, sphere(co, (1.0, 1.0, 1.0), 0.25)), 4, w2m=m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 6), ("bear.vm", 5)])
+def test_device_leaf_samples_transcendental(model, depth, oracle_mod):
+    """BASELINE configuration 5's model (sin / cos): cell classification and corner masks exact, the rest within the ulp of the
+    transcendental opcodes"""
+    import fidget_amd as F
+    O = oracle_mod
+    counts, n = _compare(F, O, F.Shape.from_vm(model_path(model)), O.Shape.from_vm(model_path(model)), depth, transcendental=True)
+    assert n > 100
