@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "kernels.hip", "effects.hip", "mesh.hip", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
+_SOURCES = ["capi.hip", "kernels.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
             "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
@@ -48,7 +48,7 @@ EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
-    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
@@ -145,6 +145,8 @@ def lib():
             "fhip_to_rgba": (i32, [vp, vp, u32, u32, i32, vp, i32]),
             "fhip_mesh_sample": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(vp)]), "fhip_mesh_free": (None, [vp]),
             "fhip_mesh_counts": (None, [vp, vp]), "fhip_mesh_leaves": (None, [vp, vp]),
+            "fhip_mesh_build": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(vp)]),
+            "fhip_mesh_vertices": (None, [vp, vp]), "fhip_mesh_triangles": (None, [vp, vp]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
@@ -824,7 +826,12 @@ MESH_LEAF = np.dtype([("bounds", np.float32, 6), ("path", np.uint64), ("mask", n
                       ("grad", np.float32, (12, 4)), ("vert", np.float32, (4, 3)), ("qef_err", np.float32, 4)])
 
 
-def mesh_sample(shape, depth, world_to_model=None, vars=None):
+def mesh(shape, depth, world_to_model=None, vars=None):
+    """fidget_mesh::Octree::build(...).walk_dual(): (triangles [n, 3] uint64, vertices [m, 3] float32, counts)"""
+    return mesh_sample(shape, depth, world_to_model, vars, _build=True)
+
+
+def mesh_sample(shape, depth, world_to_model=None, vars=None, _build=False):
     """The evaluation side of fidget_mesh::Octree::build on the device (fhip_mesh_sample): returns (leaf records as a
     MESH_LEAF array, counts dict)."""
     hip = shape.hip
@@ -835,7 +842,8 @@ def mesh_sample(shape, depth, world_to_model=None, vars=None):
         ax = np.array(shape._vars, dtype=np.int32)
         vk = np.array([shape._named_slot(k) for k in (vars or {})], dtype=np.uint64)
     h = C.c_void_p()
-    st = lib().fhip_mesh_sample(hip._h, shape._h, depth, _p(w2m), _p(ax), _p(vk), _p(vv), len(vk), C.byref(h))
+    fn = lib().fhip_mesh_build if _build else lib().fhip_mesh_sample
+    st = fn(hip._h, shape._h, depth, _p(w2m), _p(ax), _p(vk), _p(vv), len(vk), C.byref(h))
     if st == 4:
         raise ValueError("MissingVar")
     hip.check(st)
@@ -843,6 +851,15 @@ def mesh_sample(shape, depth, world_to_model=None, vars=None):
         c = np.zeros(8, np.uint64)
         lib().fhip_mesh_counts(h, _p(c))
         assert int(c[4]) == MESH_LEAF.itemsize, (int(c[4]), MESH_LEAF.itemsize)
+        counts = {"cells": int(c[0]), "full": int(c[1]), "empty": int(c[2]), "leaf_cells": int(c[3]), "levels": int(c[5])}
+        if _build:
+            verts = np.zeros((int(c[6]), 3), np.float32)
+            tris = np.zeros((int(c[7]), 3), np.uint64)
+            if len(verts):
+                lib().fhip_mesh_vertices(h, _p(verts))
+            if len(tris):
+                lib().fhip_mesh_triangles(h, _p(tris))
+            return tris, verts, counts
         leaves = np.zeros(int(c[3]), MESH_LEAF)
         if len(leaves):
             lib().fhip_mesh_leaves(h, _p(leaves))

@@ -17,6 +17,7 @@
 #include "kernels.hip"
 #include "effects.hip"
 #include "mesh.hip"
+#include "host_mesh.hpp"
 
 #define FH_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
 
@@ -1411,9 +1412,67 @@ struct fhip_mesh {
     std::vector<FhMeshLeaf> leaves;
     uint64_t cells_evaluated = 0, full = 0, empty = 0, ambiguous_leaves = 0;
     std::vector<uint64_t> per_level;   // cells evaluated at each depth
+    // per level, per evaluated cell: class (1 empty 2 full 3 ambiguous) and, for ambiguous cells, their index among the level's
+    // ambiguous cells (= parent index of their children / leaf record index)
+    std::vector<std::vector<uint8_t>> cls;
+    std::vector<std::vector<uint32_t>> slot;
+    std::vector<float> vertices;          // fhip_mesh_build: Mesh::vertices (3 floats each)
+    std::vector<uint64_t> triangles;      // ... Mesh::triangles (3 indices each)
+    uint64_t octree_cells = 0, octree_verts = 0;
 };
-fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
-                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
+// Assembly of the octree from the device's results, as Octree::recurse unwinds (octree.rs:556-583), then Octree::walk_dual
+struct MeshAssembler {
+    const fhip_mesh& M;
+    uint32_t depth;
+    fhmesh::Octree o;
+    fhmesh::Cell build(uint32_t d, size_t i, const float* b, fhmesh::Hermite* hermite) {
+        fhmesh::Cell res;
+        const uint8_t c = M.cls[d][i];
+        if (c == 2) { res.kind = fhmesh::C_FULL; return res; }
+        if (c == 1) { res.kind = fhmesh::C_EMPTY; return res; }
+        const uint32_t s = M.slot[d][i];
+        if (d == depth) {       // leaf() (octree.rs:590-862) with the device's samples
+            const FhMeshLeaf& lf = M.leaves[s];
+            if (lf.mask == 0) { res.kind = fhmesh::C_EMPTY; return res; }
+            if (lf.mask == 255) { res.kind = fhmesh::C_FULL; return res; }
+            const fhmesh::Tables& T = fhmesh::tables();
+            uint32_t ii = 0, vi = 0;
+            for (auto& vs : T.v2e[lf.mask]) {
+                bool forced = false;
+                for (auto& e : vs) {
+                    const uint32_t k = std::min<uint32_t>(ii, 11);
+                    const float* g = lf.grad[k];
+                    if (g[0] != g[0] || g[1] != g[1] || g[2] != g[2] || g[3] != g[3]) { forced = true; hermite->qef_err = fhmesh::QEF_ERR_INVALID; break; }
+                    fhmesh::LeafIntersection& li = hermite->inter[fhmesh::to_undirected(e.first, e.second)];
+                    li.pos[0] = lf.pos[k][0]; li.pos[1] = lf.pos[k][1]; li.pos[2] = lf.pos[k][2]; li.pos[3] = 1.0f;
+                    for (int q = 0; q < 4; q++) li.grad[q] = g[q];
+                    ii++;
+                }
+                if (!forced) hermite->qef_err = lf.qef_err[vi];
+                vi++;
+            }
+            res.kind = fhmesh::C_LEAF; res.mask = (uint8_t)lf.mask; res.index = (uint32_t)o.verts.size();
+            for (uint32_t v = 0; v < lf.n_verts; v++) o.verts.push_back(fhmesh::V3{lf.vert[v][0], lf.vert[v][1], lf.vert[v][2]});
+            for (uint32_t e = 0; e < lf.n_edges; e++) o.verts.push_back(fhmesh::V3{lf.pos[e][0], lf.pos[e][1], lf.pos[e][2]});
+            return res;
+        }
+        const size_t index = o.cells.size();
+        o.cells.push_back(std::array<fhmesh::Cell, 8>());
+        fhmesh::Hermite hc[8];
+        for (int corner = 0; corner < 8; corner++) {
+            float cb[6];
+            for (int k = 0; k < 3; k++) {
+                const float mid = (b[2 * k] + b[2 * k + 1]) / 2.0f;        // cell.rs:184-194
+                if (corner & (1 << k)) { cb[2 * k] = mid; cb[2 * k + 1] = b[2 * k + 1]; } else { cb[2 * k] = b[2 * k]; cb[2 * k + 1] = mid; }
+            }
+            const fhmesh::Cell ch = build(d + 1, (size_t)s * 8 + corner, cb, &hc[corner]);
+            o.cells[index][corner] = ch;
+        }
+        return o.check_done(b, index, hc, hermite);
+    }
+};
+static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                            const uint64_t* var_keys, const float* var_values, uint32_t n_vars, bool assemble, fhip_mesh** out) {
     if (!out) return FHIP_ERR_BAD_TAPE;
     *out = nullptr;
     if (depth > 20) return fail(ctx, FHIP_ERR_UNSUPPORTED, "octree depth above 20");
@@ -1441,8 +1500,8 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
         attr_done = true;
     }
     fhip_mesh* M = new fhip_mesh();
-    DevBuf bufs[2], counters, table, leaves;
-    auto cleanup = [&] { bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); };
+    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot;
+    auto cleanup = [&] { bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release(); };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
     MESH_TRY(counters.ensure(16));
     FhMeshCell root;
@@ -1459,11 +1518,17 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
         const uint32_t n = (uint32_t)n64;
         MESH_TRY(bufs[cur ^ 1].ensure((size_t)n * sizeof(FhMeshCell)));
         MESH_TRY(hipMemsetAsync(counters.p, 0, 16, ctx->stream));
+        if (assemble) { MESH_TRY(d_cls.ensure(n)); MESH_TRY(d_slot.ensure((size_t)n * 4)); }
         hipLaunchKernelGGL(fhm::k_mesh_cells, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n, d == 0 ? 0 : 1,
-                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n);
+                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n, assemble ? (uint8_t*)d_cls.p : nullptr, assemble ? (uint32_t*)d_slot.p : nullptr);
         MESH_TRY(hipGetLastError());
         uint32_t c[4];
         MESH_TRY(hipMemcpyAsync(c, counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (assemble) {
+            M->cls.emplace_back(n); M->slot.emplace_back(n);
+            MESH_TRY(hipMemcpyAsync(M->cls.back().data(), d_cls.p, n, hipMemcpyDeviceToHost, ctx->stream));
+            MESH_TRY(hipMemcpyAsync(M->slot.back().data(), d_slot.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         MESH_TRY(hipStreamSynchronize(ctx->stream));
         M->cells_evaluated += n; M->full += c[1]; M->empty += c[2];
         M->per_level.push_back(n);
@@ -1488,14 +1553,50 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
     }
 #undef MESH_TRY
     cleanup();
+    if (assemble) {
+        MeshAssembler A{*M, depth, {}};
+        const float rb[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
+        fhmesh::Hermite h;
+        // (a level the recursion never reached - everything above it was decided - has no arrays: only levels 0 .. cls.size()-1 are indexed)
+        A.o.root = A.build(0, 0, rb, &h);
+        if (P.has_mat)       // octree.rs:58-65: vertices back to model space (nalgebra transform_point)
+            for (auto& v : A.o.verts) {
+                const float x = v.x, y = v.y, z = v.z;
+                const float n = ((P.mat[12] * x + P.mat[13] * y) + P.mat[14] * z) + P.mat[15];
+                float a = ((P.mat[0] * x + P.mat[1] * y) + P.mat[2] * z) + P.mat[3];
+                float b = ((P.mat[4] * x + P.mat[5] * y) + P.mat[6] * z) + P.mat[7];
+                float c = ((P.mat[8] * x + P.mat[9] * y) + P.mat[10] * z) + P.mat[11];
+                if (n != 0.0f) { a = a / n; b = b / n; c = c / n; }
+                v.x = a; v.y = b; v.z = c;
+            }
+        fhmesh::Walker W(A.o);
+        W.cell(fhmesh::CellRef());
+        M->octree_cells = A.o.cells.size(); M->octree_verts = A.o.verts.size();
+        M->vertices.reserve(W.vertices.size() * 3);
+        for (auto& v : W.vertices) { M->vertices.push_back(v.x); M->vertices.push_back(v.y); M->vertices.push_back(v.z); }
+        M->triangles.reserve(W.triangles.size() * 3);
+        for (auto& t : W.triangles) { M->triangles.push_back(t[0]); M->triangles.push_back(t[1]); M->triangles.push_back(t[2]); }
+    }
     *out = M;
     return FHIP_OK;
 }
+fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
+    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, false, out);
+}
+// Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225): fhip_mesh_sample, then the octree assembled from the device's
+// results (cell collapse included) and the dual walk on the host
+fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                            const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
+    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, true, out);
+}
+void fhip_mesh_vertices(const fhip_mesh* m, float* out) { memcpy(out, m->vertices.data(), m->vertices.size() * 4); }
+void fhip_mesh_triangles(const fhip_mesh* m, uint64_t* out) { memcpy(out, m->triangles.data(), m->triangles.size() * 8); }
 void fhip_mesh_free(fhip_mesh* m) { delete m; }
 // out = {cells evaluated (= interval evaluations), Full, Empty, ambiguous cells at the leaf depth (= calls of leaf()), bytes per leaf record, levels}
 void fhip_mesh_counts(const fhip_mesh* m, uint64_t out[8]) {
     out[0] = m->cells_evaluated; out[1] = m->full; out[2] = m->empty; out[3] = m->ambiguous_leaves; out[4] = sizeof(FhMeshLeaf);
-    out[5] = m->per_level.size(); out[6] = out[7] = 0;
+    out[5] = m->per_level.size(); out[6] = m->vertices.size() / 3; out[7] = m->triangles.size() / 3;
 }
 void fhip_mesh_leaves(const fhip_mesh* m, void* out) { memcpy(out, m->leaves.data(), m->leaves.size() * sizeof(FhMeshLeaf)); }
 

@@ -1,0 +1,342 @@
+// Host side of the meshing path: what fidget-mesh does with the evaluation results and has no evaluation in it.
+//
+//   * the Manifold Dual Contouring connectivity tables (fidget-mesh/build.rs:26-160);
+//   * assembly of the octree from the device's per-level cell classes and leaf records, bottom-up as Octree::recurse unwinds
+//     (octree.rs:556-583): eight children -> check_done / try_collapse / collapsible (octree.rs:256-470) with the merged Hermite
+//     data of LeafHermiteData (octree.rs:866-1035);
+//   * the dual walk that emits the triangles (dc.rs, builder.rs).
+//
+// Integer / topological code, plus the QEF of a collapsed cell (mesh_qef.hpp, the definition the device kernel uses too).
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "mesh_qef.hpp"
+
+namespace fhmesh {
+
+enum { AX = 1, AY = 2, AZ = 4 };
+static inline int axis_next(int a) { return (a << 1) > AZ ? AX : (a << 1); }   // types.rs Axis::next
+static inline int axis_index(int a) { return a == 1 ? 0 : (a == 2 ? 1 : 2); }
+
+struct Tables {
+    std::vector<std::vector<std::pair<uint8_t, uint8_t>>> v2e[256];   // CELL_TO_VERT_TO_EDGES
+    int e2v[256][12][2];                                              // CELL_TO_EDGE_TO_VERT: (vertex, intersection) offsets or -1
+};
+// build.rs:26-160
+static inline const Tables& tables() {
+    static Tables* T = nullptr;
+    if (T) return *T;
+    Tables* t = new Tables();
+    for (int i = 0; i < 256; i++) {
+        int region_of[2][8];
+        for (int pass = 0; pass < 2; pass++) {
+            int* r = region_of[pass];
+            for (int j = 0; j < 8; j++) r[j] = 1 << j;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int f = 0; f < 8; f++) {
+                    if ((((i >> f) & 1) != 0) != (pass == 0)) continue;
+                    for (int axis : {AX, AY, AZ}) {
+                        const int g = f ^ axis;
+                        if ((((i >> g) & 1) != 0) != (pass == 0)) continue;
+                        const int v = r[f] | r[g];
+                        if (r[f] != v || r[g] != v) { r[f] = v; r[g] = v; changed = true; }
+                    }
+                }
+            }
+        }
+        std::vector<int> fr, er;
+        for (int j = 0; j < 8; j++) ((i >> j) & 1 ? fr : er).push_back(region_of[(i >> j) & 1 ? 0 : 1][j]);
+        for (auto* v : {&fr, &er}) { std::sort(v->begin(), v->end()); v->erase(std::unique(v->begin(), v->end()), v->end()); }
+        int regions[8], ri = 0;
+        for (auto* rs : {&fr, &er})
+            for (int r : *rs) { for (int j = 0; j < 8; j++) if (r & (1 << j)) regions[j] = ri; ri++; }
+        std::vector<std::pair<int, std::vector<std::pair<uint8_t, uint8_t>>>> verts;
+        for (int rev = 0; rev < 2; rev++)
+            for (int tt : {AX, AY, AZ}) {
+                const int u = axis_next(tt), v = axis_next(u);
+                for (int b = 0; b < 2; b++)
+                    for (int a = 0; a < 2; a++) {
+                        int start = (a * u) | (b * v), end = start | tt;
+                        if (rev) std::swap(start, end);
+                        if (!(((i >> start) & 1) && !((i >> end) & 1))) continue;
+                        auto it = std::find_if(verts.begin(), verts.end(), [&](auto& kv) { return kv.first == regions[start]; });
+                        if (it == verts.end()) { verts.push_back({regions[start], {}}); it = verts.end() - 1; }
+                        it->second.push_back({(uint8_t)start, (uint8_t)end});
+                    }
+            }
+        std::sort(verts.begin(), verts.end(), [](auto& a, auto& b) { return a.first < b.first; });
+        for (int e = 0; e < 12; e++) t->e2v[i][e][0] = t->e2v[i][e][1] = -1;
+        const int vert_count = (int)verts.size();
+        int n = 0;
+        for (int vi = 0; vi < vert_count; vi++) {
+            t->v2e[i].push_back(verts[vi].second);
+            for (auto& se : verts[vi].second) {
+                const int tt = se.first ^ se.second, u = axis_next(tt), v = axis_next(u);
+                const int edge = axis_index(tt) * 4 + ((se.first & u) ? 1 : 0) + ((se.first & v) ? 2 : 0);
+                t->e2v[i][edge][0] = vi;
+                t->e2v[i][edge][1] = vert_count + n++;
+            }
+        }
+    }
+    T = t;
+    return *T;
+}
+static inline int to_undirected(int start, int end) {     // types.rs DirectedEdge::to_undirected
+    const int t = start ^ end, u = axis_next(t), v = axis_next(u);
+    return axis_index(t) * 4 + ((start & v) ? 2 : 0) + ((start & u) ? 1 : 0);
+}
+static inline void edge_corners(int e, int* start, int* end) {   // types.rs Edge::corners
+    static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}};
+    const int t = FR[e / 4][0], u = ((e % 4) % 2 != 0) ? FR[e / 4][1] : 0, v = ((e % 4) / 2 != 0) ? FR[e / 4][2] : 0;
+    *start = u | v; *end = t | u | v;
+}
+
+enum CellKind : uint8_t { C_INVALID = 0, C_EMPTY, C_FULL, C_BRANCH, C_LEAF };
+struct Cell {
+    uint8_t kind = C_INVALID, mask = 0;
+    uint32_t index = 0;
+    bool corner(int c) const { return kind == C_LEAF ? ((mask >> c) & 1) : kind == C_FULL; }
+};
+struct V3 { float x, y, z; };
+struct CellRef {       // CellIndex (cell.rs:87-110) without the bounds: where the cell is stored, how deep it is
+    int64_t ci = -1;
+    uint8_t cj = 0;
+    uint32_t depth = 0;
+};
+
+static const float QEF_ERR_EMPTY = -1.0f, QEF_ERR_INVALID = -2.0f;
+struct LeafIntersection { float pos[4] = {0, 0, 0, 0}, grad[4] = {0, 0, 0, 0}; };
+static inline fhq::Qef qef_zero() { fhq::Qef q; q.init(); return q; }
+static inline fhq::Qef qef_of(const LeafIntersection& i) { fhq::Qef q = qef_zero(); if (i.pos[3] != 0.0f) q.add(i.pos, i.grad); return q; }
+// LeafHermiteData (octree.rs:866-1035)
+struct Hermite {
+    LeafIntersection inter[12];
+    fhq::Qef face[6], center;
+    float qef_err = QEF_ERR_EMPTY;
+    Hermite() { for (auto& f : face) f.init(); center.init(); }
+    static bool merge(const Hermite* leafs, Hermite* out) {
+        *out = Hermite();
+        for (int i = 0; i < 8; i++) if (leafs[i].qef_err == QEF_ERR_INVALID) return false;
+        for (int t : {AX, AY, AZ}) {
+            const int u = axis_next(t), v = axis_next(u);
+            for (int edge = 0; edge < 4; edge++) {
+                int start = 0;
+                if (edge & 1) start |= u;
+                if (edge & 2) start |= v;
+                const int end = start | t, e = axis_index(t) * 4 + edge;
+                const LeafIntersection &a = leafs[start].inter[e], &b = leafs[end].inter[e];
+                if (a.pos[3] > 0.0f && !(b.pos[3] > 0.0f)) out->inter[e] = a;
+                else if (!(a.pos[3] > 0.0f) && b.pos[3] > 0.0f) out->inter[e] = b;
+            }
+        }
+        for (int t : {AX, AY, AZ}) {
+            const int u = axis_next(t), v = axis_next(t);   // (octree.rs:946-947: both are t.next())
+            for (int fc = 0; fc < 2; fc++) {
+                const int a = fc == 1 ? t : 0, b = a | u, c = a | v, d = a | u | v, f = axis_index(t) * 2 + fc;
+                for (int q : {a, b, c, d}) out->face[f].merge(leafs[q].face[f]);
+                const int ev = axis_index(v) * 4 + fc * 2 + 1;
+                out->face[f].merge(qef_of(leafs[a].inter[ev]));
+                out->face[f].merge(qef_of(leafs[b].inter[ev]));
+                out->face[f].merge(qef_of(leafs[a].inter[ev]));
+                out->face[f].merge(qef_of(leafs[c].inter[ev]));
+            }
+        }
+        for (int t : {AX, AY, AZ}) {
+            const int u = axis_next(t), v = axis_next(t);
+            const int a = 0, b = a | u, c = a | v, d = a | u | v;
+            for (int q : {a, b, c, d}) out->center.merge(leafs[q].face[axis_index(t) * 2 + 1]);
+            out->center.merge(qef_of(leafs[a].inter[axis_index(u) * 4 + 3]));
+            out->center.merge(qef_of(leafs[b].inter[axis_index(u) * 4 + 3]));
+        }
+        for (int i = 0; i < 8; i++) out->center.merge(leafs[i].center);
+        out->qef_err = INFINITY;
+        for (int i = 0; i < 8; i++) if (leafs[i].qef_err >= 0.0f) out->qef_err = fminf(out->qef_err, leafs[i].qef_err);
+        return true;
+    }
+    void solve(float* pos, float* err) const {
+        fhq::Qef q = center;
+        for (auto& i : inter) q.merge(qef_of(i));
+        for (auto& f : face) q.merge(f);
+        q.solve(pos, err);
+    }
+};
+
+struct Octree {
+    Cell root;
+    std::vector<std::array<Cell, 8>> cells;
+    std::vector<V3> verts;
+    Cell& at(const CellRef& c) { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
+    const Cell& at(const CellRef& c) const { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
+    bool is_leaf(const CellRef& c) const { const uint8_t k = at(c).kind; return k == C_LEAF || k == C_FULL || k == C_EMPTY; }
+    CellRef child(const CellRef& c, int i) const {
+        const Cell& x = at(c);
+        if (x.kind != C_BRANCH) return c;
+        CellRef r; r.ci = x.index; r.cj = (uint8_t)i; r.depth = c.depth + 1;
+        return r;
+    }
+    // octree.rs:389-470
+    bool collapsible(size_t rootc, uint8_t* out_mask) const {
+        const auto& cs = cells[rootc];
+        const Tables& T = tables();
+        int mask = 0;
+        for (int i = 0; i < 8; i++) {
+            int b;
+            if (cs[i].kind == C_LEAF) { if (T.v2e[cs[i].mask].size() > 1) return false; b = (cs[i].mask >> i) & 1; }
+            else if (cs[i].kind == C_EMPTY) b = 0;
+            else if (cs[i].kind == C_FULL) b = 1;
+            else return false;
+            mask |= b << i;
+        }
+        static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}};
+        for (auto& f : FR) {
+            const int t = f[0], u = f[1], v = f[2];
+            for (int i = 0; i < 4; i++) {
+                const int a = ((i & 1) ? u : 0) | ((i & 2) ? v : 0), b = a | t;
+                const bool center = cs[a].corner(b);
+                if ((((mask >> a) & 1) != 0) != center && (((mask >> b) & 1) != 0) != center) return false;
+            }
+            for (int i = 0; i < 2; i++) {
+                const int a = ((i & 1) == 0) ? t : 0, b = a | u, c = a | v, d = a | u | v;
+                const bool center = cs[a].corner(d);
+                bool all = true;
+                for (int q : {a, b, c, d}) all &= ((((mask >> q) & 1) != 0) != center);
+                if (all) return false;
+            }
+            const bool center = cs[0].corner(t | u | v);
+            bool all = true;
+            for (int q = 0; q < 8; q++) all &= ((((mask >> q) & 1) != 0) != center);
+            if (all) return false;
+        }
+        if (T.v2e[mask].size() == 1) { *out_mask = (uint8_t)mask; return true; }
+        return false;
+    }
+    // octree.rs:256-340; bounds = this cell's x.lo x.hi y.lo y.hi z.lo z.hi
+    Cell check_done(const float* bounds, size_t index, const Hermite* hd, Hermite* hermite) {
+        int full = 0, empty = 0;
+        for (int i = 0; i < 8; i++) {
+            const uint8_t k = cells[index][i].kind;
+            if (k == C_FULL) full++;
+            else if (k == C_EMPTY) empty++;
+            else if (k == C_BRANCH) { Cell c; c.kind = C_BRANCH; c.index = (uint32_t)index; return c; }
+        }
+        Cell out;
+        if (full == 8) out.kind = C_FULL;
+        else if (empty == 8) out.kind = C_EMPTY;
+        else {
+            uint8_t mask;
+            bool ok = collapsible(index, &mask) && Hermite::merge(hd, hermite);
+            float pos[3], err = 0;
+            if (ok) {
+                hermite->solve(pos, &err);
+                bool inside = true;
+                for (int k = 0; k < 3; k++) inside &= pos[k] >= bounds[2 * k] && pos[k] <= bounds[2 * k + 1];
+                if (err >= hermite->qef_err * 2.0f || !inside) ok = false;
+            }
+            if (ok) {
+                hermite->qef_err = err;
+                const size_t vi = verts.size();
+                verts.push_back(V3{pos[0], pos[1], pos[2]});
+                for (auto& e : tables().v2e[mask][0]) {
+                    const LeafIntersection& li = hermite->inter[to_undirected(e.first, e.second)];
+                    verts.push_back(V3{li.pos[0], li.pos[1], li.pos[2]});
+                }
+                out.kind = C_LEAF; out.mask = mask; out.index = (uint32_t)vi;
+            } else { out.kind = C_BRANCH; out.index = (uint32_t)index; }
+        }
+        if (out.kind != C_BRANCH) {
+            if (index == cells.size() - 1) cells.resize(index);
+            else cells[index] = std::array<Cell, 8>();
+        }
+        return out;
+    }
+};
+
+// dc.rs / builder.rs
+struct Walker {
+    const Octree& o;
+    std::vector<std::array<uint64_t, 3>> triangles;
+    std::vector<V3> vertices;
+    std::vector<size_t> map;
+    explicit Walker(const Octree& oc) : o(oc) {}
+    static void frame(int f, int* t, int* u, int* v) { static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}}; *t = FR[f][0]; *u = FR[f][1]; *v = FR[f][2]; }
+    size_t vertex(size_t v) {
+        if (v >= map.size()) map.resize(v + 1, (size_t)-1);
+        if (map[v] == (size_t)-1) { map[v] = vertices.size(); vertices.push_back(o.verts[v]); }
+        return map[v];
+    }
+    void cell(const CellRef& c) {
+        if (o.at(c).kind != C_BRANCH) return;
+        for (int i = 0; i < 8; i++) cell(o.child(c, i));
+        for (int f = 0; f < 3; f++) {
+            int t, u, v; frame(f, &t, &u, &v);
+            for (int k : {0, u, v, u | v}) face(f, o.child(c, k), o.child(c, k | t));
+        }
+        for (int i = 0; i < 2; i++) {
+            const int x = i ? AX : 0, y = i ? AY : 0, z = i ? AZ : 0;
+            edge(0, o.child(c, x), o.child(c, x | AY), o.child(c, x | AY | AZ), o.child(c, x | AZ));
+            edge(1, o.child(c, y), o.child(c, y | AZ), o.child(c, y | AX | AZ), o.child(c, y | AX));
+            edge(2, o.child(c, z), o.child(c, z | AX), o.child(c, z | AX | AY), o.child(c, z | AY));
+        }
+    }
+    void face(int f, const CellRef& lo, const CellRef& hi) {
+        if (o.is_leaf(lo) && o.is_leaf(hi)) return;
+        int t, u, v; frame(f, &t, &u, &v);
+        face(f, o.child(lo, t), o.child(hi, 0));
+        face(f, o.child(lo, t | u), o.child(hi, u));
+        face(f, o.child(lo, t | v), o.child(hi, v));
+        face(f, o.child(lo, t | u | v), o.child(hi, u | v));
+        for (int i = 0; i < 2; i++) {
+            const int ui = i ? u : 0, vi = i ? v : 0;
+            edge((f + 1) % 3, o.child(lo, ui | t), o.child(lo, ui | v | t), o.child(hi, ui | v), o.child(hi, ui));
+            edge((f + 2) % 3, o.child(lo, vi | t), o.child(hi, vi), o.child(hi, vi | u), o.child(lo, vi | u | t));
+        }
+    }
+    void edge(int f, const CellRef& a, const CellRef& b, const CellRef& c, const CellRef& d) {
+        const CellRef cs[4] = {a, b, c, d};
+        bool all_leaf = true;
+        for (auto& x : cs) all_leaf &= o.is_leaf(x);
+        int t, u, v; frame(f, &t, &u, &v);
+        if (!all_leaf) {
+            for (int i = 0; i < 2; i++) {
+                const int ti = i ? t : 0;
+                edge(f, o.child(a, ti | u | v), o.child(b, ti | v), o.child(c, ti), o.child(d, ti | u));
+            }
+            return;
+        }
+        Cell leafs[4];
+        for (int i = 0; i < 4; i++) { leafs[i] = o.at(cs[i]); if (leafs[i].kind != C_LEAF) return; }
+        int deepest = 0;     // Iterator::max_by_key: the last maximum
+        for (int i = 0; i < 4; i++) if (cs[i].depth >= cs[deepest].depth) deepest = i;
+        const int ti = axis_index(t);
+        const int edges[4] = {ti * 4 + 3, ti * 4 + 2, ti * 4 + 0, ti * 4 + 1};
+        int s0, e0;
+        edge_corners(edges[deepest], &s0, &e0);
+        const bool st = !((leafs[deepest].mask >> s0) & 1), en = !((leafs[deepest].mask >> e0) & 1);
+        if (st == en) return;
+        const Tables& T = tables();
+        int vv[4][2];
+        for (int i = 0; i < 4; i++) {
+            vv[i][0] = vv[i][1] = -1;
+            if (cs[i].depth == cs[deepest].depth) { vv[i][0] = T.e2v[leafs[i].mask][edges[i]][0]; vv[i][1] = T.e2v[leafs[i].mask][edges[i]][1]; }
+            else for (int j = 0; j < 12; j++) if (T.e2v[leafs[i].mask][j][0] >= 0) { vv[i][0] = T.e2v[leafs[i].mask][j][0]; vv[i][1] = T.e2v[leafs[i].mask][j][1]; break; }
+            if (vv[i][0] < 0) return;
+        }
+        const size_t iv = vertex(leafs[deepest].index + (size_t)vv[deepest][1]);
+        size_t vs[4];
+        for (int i = 0; i < 4; i++) vs[i] = vertex(leafs[i].index + (size_t)vv[i][0]);
+        const int winding = st ? 3 : 1;
+        for (int j = 0; j < 4; j++) {
+            const CellRef &p = cs[j], &q = cs[(j + winding) % 4];
+            if (p.ci != q.ci || p.cj != q.cj) triangles.push_back({vs[j], vs[(j + winding) % 4], iv});
+        }
+    }
+};
+
+}  // namespace fhmesh

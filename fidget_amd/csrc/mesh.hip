@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dev_ops.hpp"
+#include "mesh_qef.hpp"
 // (included by capi.hip after kernels.hip: Regs, step, ballot, uni, ctape_t)
 
 struct FhMeshCell {
@@ -56,7 +57,7 @@ __device__ __forceinline__ float lerp_pos(float lo, float hi, uint32_t p) {   //
 
 // interval evaluation + classification of the cells of one level.  expand: cell i is child (i & 7) of in[i >> 3]
 __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMeshCell* in, uint32_t n, int expand, FhMeshCell* out, uint32_t* counters /* amb, full, empty */,
-                                                      uint32_t out_cap) {
+                                                      uint32_t out_cap, uint8_t* cls /* per cell: 1 empty 2 full 3 ambiguous */, uint32_t* slot /* of an ambiguous cell in out */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.x * WAVE + lane;
@@ -100,76 +101,13 @@ __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMes
         if (ne) atomicAdd(&counters[2], ne);
     }
     base = uni(base);
+    uint32_t sl = 0xFFFFFFFFu;
     if (amb) {
-        const uint32_t slot = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
-        if (slot < out_cap) out[slot] = c;
+        sl = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
+        if (sl < out_cap) out[sl] = c;
     }
+    if (act && cls) { cls[i] = full ? 2 : (empty ? 1 : 3); slot[i] = sl; }
 }
-
-// the QEF of one cell vertex (qef.rs:45-126; SVD of the symmetric A^T A by cyclic Jacobi rotations in f64)
-struct Qef {
-    float ata[3][3], atb[3], btb, mass[4];
-    __device__ void init() {
-        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) ata[i][j] = 0.0f; atb[i] = 0.0f; }
-        btb = 0.0f;
-        for (int i = 0; i < 4; i++) mass[i] = 0.0f;
-    }
-    __device__ void add(const float* pos, const float* grad) {
-        mass[0] += pos[0]; mass[1] += pos[1]; mass[2] += pos[2]; mass[3] += 1.0f;
-        const float nn = sqrtf(0.0f + ((grad[0] * grad[0] + grad[1] * grad[1]) + grad[2] * grad[2]));
-        const float n[3] = {grad[0] / nn, grad[1] / nn, grad[2] / nn};
-        const float d = (n[0] * pos[0] + n[1] * pos[1]) + n[2] * pos[2];
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++) ata[i][j] += n[i] * n[j];
-            atb[i] += n[i] * d;
-        }
-        btb += d * d;
-    }
-    __device__ void solve(float* pos, float* err) const {
-        const float center[3] = {mass[0] / mass[3], mass[1] / mass[3], mass[2] / mass[3]};
-        float b[3];
-        for (int i = 0; i < 3; i++) b[i] = atb[i] - ((ata[i][0] * center[0] + ata[i][1] * center[1]) + ata[i][2] * center[2]);
-        double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = ata[i][j];
-        for (int sweep = 0; sweep < 32; sweep++) {
-            const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-            if (off < 1e-30) break;
-            for (int p = 0; p < 2; p++)
-                for (int q = p + 1; q < 3; q++) {
-                    if (fabs(a[p][q]) < 1e-300) continue;
-                    const double th = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                    const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                    const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-                    for (int k = 0; k < 3; k++) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
-                    for (int k = 0; k < 3; k++) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
-                    for (int k = 0; k < 3; k++) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
-                }
-        }
-        int order[3] = {0, 1, 2};
-        for (int i = 0; i < 2; i++)          // stable selection sort, descending |eigenvalue| (std::sort on 3 elements in the oracle)
-            for (int j = i + 1; j < 3; j++)
-                if (fabs(a[order[j]][order[j]]) > fabs(a[order[i]][order[i]])) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-        float sv[3];
-        for (int i = 0; i < 3; i++) sv[i] = (float)fabs(a[order[i]][order[i]]);
-        const float cutoff = fabsf(sv[0]) * 1e-3f;
-        int rank = 3;
-        for (int i = 0; i < 3; i++) if (fabsf(sv[i]) < cutoff) { rank = i; break; }
-        const float eps = rank < 3 ? sv[rank] : 0.0f;
-        double sol[3] = {0, 0, 0};
-        for (int k = 0; k < 3; k++) {
-            const int e = order[k];
-            if (!((float)fabs(a[e][e]) > eps)) continue;
-            const double proj = (v[0][e] * b[0] + v[1][e] * b[1] + v[2][e] * b[2]) / a[e][e];
-            for (int i = 0; i < 3; i++) sol[i] += v[i][e] * proj;
-        }
-        for (int i = 0; i < 3; i++) pos[i] = (float)sol[i] + center[i];
-        float ap[3];
-        for (int i = 0; i < 3; i++) ap[i] = (ata[i][0] * pos[0] + ata[i][1] * pos[1]) + ata[i][2] * pos[2];
-        float e = ((pos[0] * ap[0] + pos[1] * ap[1]) + pos[2] * ap[2]) - 2.0f * ((pos[0] * atb[0] + pos[1] * atb[1]) + pos[2] * atb[2]);
-        e += btb;
-        *err = e > 1e-6f ? e : 1e-6f;
-    }
-};
 
 // f32 value of the tape at this lane's point (lanes evaluate different points of the same leaf)
 __device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<float, WAVE>& R, float x, float y, float z) {
@@ -281,7 +219,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
     if (lane == 0) {
         uint32_t i = 0;
         for (uint32_t vtx = 0; vtx < nv; vtx++) {
-            Qef q;
+            fhq::Qef q;
             q.init();
             bool forced = false;
             float pos[3] = {0, 0, 0}, err = -1.0f;

@@ -192,8 +192,16 @@ fhip_status fhip_to_rgba(fhip_ctx* ctx, const float* image, uint32_t width, uint
 typedef struct fhip_mesh fhip_mesh;
 fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
+/* fidget_mesh::Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225; Settings: depth, world_to_model): fhip_mesh_sample, then
+ * the octree assembled from the device's results - cell collapse (check_done / try_collapse, octree.rs:256-385) with the merged
+ * Hermite data included - and the dual walk (dc.rs) on the host -> Mesh { vertices, triangles } (lib.rs:64-69). */
+fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                            const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
+void fhip_mesh_vertices(const fhip_mesh* mesh, float* out);        /* counts[6] x 3 floats */
+void fhip_mesh_triangles(const fhip_mesh* mesh, uint64_t* out);    /* counts[7] x 3 vertex indices */
 void fhip_mesh_free(fhip_mesh* mesh);
-/* out = {cells interval-evaluated, Full, Empty, ambiguous cells at the leaf depth, bytes per leaf record, levels visited, 0, 0} */
+/* out = {cells interval-evaluated, Full, Empty, ambiguous cells at the leaf depth, bytes per leaf record, levels visited,
+ *        mesh vertices, mesh triangles} */
 void fhip_mesh_counts(const fhip_mesh* mesh, uint64_t out[8]);
 void fhip_mesh_leaves(const fhip_mesh* mesh, void* out);
 

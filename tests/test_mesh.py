@@ -330,3 +330,66 @@ def test_device_leaf_samples_transcendental(model, depth, oracle_mod):
     O = oracle_mod
     counts, n = _compare(F, O, F.Shape.from_vm(model_path(model)), O.Shape.from_vm(model_path(model)), depth, transcendental=True)
     assert n > 100
+
+
+# ---- the whole mesher (device sampling + host assembly and dual walk) against the oracle -------------------------------------
+def _same_mesh(F, O, fshape, oshape, depth, w2m=None):
+    tris, verts, counts = F.mesh(fshape, depth, world_to_model=w2m)
+    t, v = O.Octree(oshape, depth, world_to_model=w2m).walk_dual()
+    t, v = np.asarray(t, np.uint64).reshape(-1, 3), np.asarray(v, np.float32).reshape(-1, 3)
+    assert tris.shape == t.shape and verts.shape == v.shape, (tris.shape, t.shape, verts.shape, v.shape)
+    assert (tris == t).all(), "triangles differ"
+    assert ((verts == v) | (np.isnan(verts) & np.isnan(v))).all(), "vertices differ"
+    return tris, verts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 1, 2, 4, 5])
+def test_device_mesh_sphere_and_cube(depth, oracle_mod):
+    """octree.rs:1141-1276's shapes: triangles and vertices identical to Octree::build(..).walk_dual(), collapsed cells included"""
+    import fidget_amd as F
+    O = oracle_mod
+    for build in (lambda c: sphere(c, (0.1, -0.05, 0.2), 0.6), lambda c: cube(c, (-0.1, 0.6), (-0.2, 0.75), (-0.3, 0.4)),
+                  lambda c: sphere(c, (0.0, 0.0, 0.0), 0.2)):
+        cf, co = F.Context(), O.Context()
+        tris, verts = _same_mesh(F, O, F.Shape(cf, build(cf)), O.Shape(co, build(co)), depth)
+        if depth >= 2:
+            assert len(tris) > 0
+            check_for_vertex_dupes(verts)
+            check_for_edge_matching(tris)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("colonnade.vm", 6), ("prospero.vm", 6), ("tanglecube.vm", 6)])
+def test_device_mesh_models(model, depth, oracle_mod):
+    import fidget_amd as F
+    O = oracle_mod
+    tris, verts = _same_mesh(F, O, F.Shape.from_vm(model_path(model)), O.Shape.from_vm(model_path(model)), depth)
+    assert len(tris) > 100
+    if model == "colonnade.vm":
+        check_for_edge_matching(tris)
+
+
+@pytest.mark.gpu
+def test_device_mesh_camera(oracle_mod):          # fidget/tests/octree.rs:9-30
+    import fidget_amd as F
+    O = oracle_mod
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] *= 0.5
+    m[:3, 3] = 1.0
+    cf, co = F.Context(), O.Context()
+    _, verts = _same_mesh(F, O, F.Shape(cf, sphere(cf, (1.0, 1.0, 1.0), 0.25)), O.Shape(co, sphere(co, (1.0, 1.0, 1.0), 0.25)), 4, w2m=m)
+    assert (np.abs(np.linalg.norm(verts - 1.0, axis=1) - 0.25) < 0.01).all()
+
+
+@pytest.mark.gpu
+def test_device_mesh_gyroid_sphere_manifold(oracle_mod):
+    """BASELINE configuration 5's model; transcendental opcodes are within 1 ulp of libm, so the mesh is checked through the
+    reference's own properties (octree.rs:1561-1594) and its size against the oracle's"""
+    import fidget_amd as F
+    O = oracle_mod
+    tris, verts, counts = F.mesh(F.Shape.from_vm(model_path("gyroid-sphere.vm")), 6)
+    t, v = O.Octree(O.Shape.from_vm(model_path("gyroid-sphere.vm")), 6).walk_dual()
+    check_for_edge_matching(tris)
+    assert abs(len(tris) - len(np.asarray(t).reshape(-1, 3))) <= max(4, len(tris) // 500)
+    assert np.isfinite(verts).all() and (np.abs(verts) <= 1.0).all()
