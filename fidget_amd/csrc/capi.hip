@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -73,7 +74,32 @@ static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_e
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
-struct fhip_ctx {
+// Everything one frame of a render owns on the device.  A context holds two sets: an asynchronous 3D render takes the set
+// the previous frame did not use, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
+// run on a stream of their own beside the previous frame's slabs (frame pipelining, FHIP_NO_FRAME_PIPELINE=1 turns it off).
+struct FrameBufs {
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr;
+    DevBuf queue[FH_MAX_LEVELS];
+    uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
+    uint32_t resident_groups = 0;
+    uint32_t forked = 0;            // slab contexts of the last 3D frame of this set (0: not pipelined)
+    bool async_pending = false;     // the last render of this set left its result on the device: its overflow flags have not been read yet
+    hipEvent_t ev_done = nullptr;   // recorded when the last frame of this set has been queued completely
+    bool ev_done_valid = false;
+    void release_all() {
+        DevBuf* bufs[] = {&state, &arena, &leaves, &leaf_table, &zbuf, &normals, &fp_lists, &mind, &squeue, &slots[0], &slots[1],
+                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr};
+        for (DevBuf* b : bufs) b->release();
+        for (auto& q : queue) q.release();
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        ev_done = nullptr;
+    }
+};
+struct fhip_ctx : FrameBufs {
+    FrameBufs other;                // the set of the frame before (or after) the current one
+    bool frame_pipeline = true;
+    hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
+    hipEvent_t ev_pre = nullptr;
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
     bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
@@ -85,19 +111,16 @@ struct fhip_ctx {
     std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
     hipEvent_t ev_fork = nullptr;
     FhRenderState last_state_b;
-    uint32_t forked = 0;          // slab contexts of the last 3D frame (0: not pipelined)
     uint32_t slab_contexts = 2;   // FHIP_SLAB_CONTEXTS (2 or 3): how far the tile chain may run ahead of the leaf chain
-    uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
-    uint32_t resident_groups = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::string err;
     bool launch_failed = false;     // an assembly kernel launch of the current frame failed (reported when the frame has been queued)
-    bool async_pending = false;     // the last render left its result on the device: its overflow flags have not been read yet
     std::atomic<int> cancelled{0};
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, tmp_out, io_a, io_b, io_c, io_d, io_e, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr;
-    DevBuf queue[FH_MAX_LEVELS];
+    DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
+    struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[4];   // pinned (upload_frame)
+    uint32_t staging_next = 0;
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -174,7 +197,12 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
         if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
+    if (const char* e = getenv("FHIP_NO_FRAME_PIPELINE")) c->frame_pipeline = atoi(e) == 0;
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
         (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
@@ -192,11 +220,16 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->state, &c->arena, &c->leaves, &c->leaf_table, &c->zbuf, &c->normals, &c->tmp_out,
-                      &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->fp_lists, &c->mind, &c->squeue, &c->slots[0], &c->slots[1],
-                      &c->leaves_b, &c->leaf_table_b, &c->fp_lists_b, &c->chw[0], &c->chw[1], &c->tvals, &c->topch, &c->chwr};
+    if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->tmp_out, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e};
     for (DevBuf* b : bufs) b->release();
-    for (auto& q : c->queue) q.release();
+    c->release_all();
+    c->other.release_all();
+    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
@@ -215,11 +248,19 @@ const char* fhip_last_error(const fhip_ctx* c) { return c ? c->err.c_str() : "no
 fhip_status fhip_ctx_sync(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fhip_status st = FHIP_OK;
+    if (c->other.async_pending) {      // the frame before the last one (frame pipelining): same check, then back to the last frame's set
+        std::swap(static_cast<FrameBufs&>(*c), c->other);
+        c->async_pending = false;
+        st = finish_render(c);
+        std::swap(static_cast<FrameBufs&>(*c), c->other);
+    }
     if (c->async_pending) {
         c->async_pending = false;
-        return finish_render(c);
+        const fhip_status s2 = finish_render(c);
+        if (st == FHIP_OK) st = s2;
     }
-    return FHIP_OK;
+    return st;
 }
 void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
 void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
@@ -883,7 +924,21 @@ static fhip_status finish_render(fhip_ctx* ctx) {
 }
 
 static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, &R.S, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
+    // The frame's state and root groups go through pinned staging slots (a ring of four, each guarded by an event): a copy from
+    // pageable memory would make the host wait for everything queued on the stream before it, i.e. for the previous frame.
+    const size_t roots_bytes = R.roots.size() * sizeof(FhGroup);
+    fhip_ctx::Staging& sg = ctx->staging[ctx->staging_next++ % 4];
+    if (sg.ev && sg.used) HIP_TRY(ctx, hipEventSynchronize(sg.ev));
+    if (!sg.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+    if (sg.cap < sizeof(FhRenderState) + roots_bytes) {
+        if (sg.p) (void)hipHostFree(sg.p);
+        sg.p = nullptr; sg.cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&sg.p, sizeof(FhRenderState) + roots_bytes + 4096, hipHostMallocDefault));
+        sg.cap = sizeof(FhRenderState) + roots_bytes + 4096;
+    }
+    memcpy(sg.p, &R.S, sizeof(FhRenderState));
+    if (roots_bytes) memcpy((char*)sg.p + sizeof(FhRenderState), R.roots.data(), roots_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, sg.p, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
     // The root tape and its groups sit below arena_root_end, where no frame writes: a shape rendered
     // again finds them there (17 small copies, 0.1 ms of a 4 ms frame, otherwise).
     if (ctx->resident_serial != tape->serial || ctx->resident_groups != R.S.n_tgroups) {
@@ -897,8 +952,10 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     }
     if (!R.roots.empty()) {
         FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size());
-        HIP_TRY(ctx, hipMemcpyAsync(back, R.roots.data(), R.roots.size() * sizeof(FhGroup), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(back, (char*)sg.p + sizeof(FhRenderState), roots_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
+    HIP_TRY(ctx, hipEventRecord(sg.ev, ctx->stream));
+    sg.used = true;
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     ctx->prof_events.clear();
     for (auto& e : ctx->asm_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
@@ -1100,6 +1157,18 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
                                                      : hip_tiles_3d(std::max(cfg->width, cfg->height));
+    // Frame pipelining (asynchronous renders): this frame takes the buffer set the previous frame did not use, and everything up
+    // to and including its coarse levels is queued on a stream of its own - it depends on nothing the previous frame does, so it
+    // runs beside that frame's slabs.  The slabs' tile chains follow on the side stream (after the previous frame's), the leaf
+    // chains and the final image on the caller's stream as before.
+    hipStream_t const main_stream = ctx->stream;
+    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !getenv("FHIP_PIPE_SERIAL");
+    struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    if (fpipe) {
+        std::swap(static_cast<FrameBufs&>(*ctx), ctx->other);
+        ctx->stream = ctx->stream_pre;
+        if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
+    }
     st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
@@ -1124,15 +1193,19 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
     FhRenderState* const dS0 = dS;
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
-    hipStream_t const main_stream = ctx->stream;
     hipStream_t const side_stream = getenv("FHIP_PIPE_SERIAL") ? main_stream : ctx->stream2;  // diagnostics
     const uint32_t NC = pipe ? ctx->slab_contexts : 1;
     ctx->forked = pipe ? NC : 0;
     if (pipe) {
-        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, main_stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
+        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
                            (uint32_t*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
+    }
+    if (fpipe) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream_pre));
+        HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
+        ctx->stream = main_stream;
     }
     for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
@@ -1222,6 +1295,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;
+    if (fpipe) { HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream)); ctx->ev_done_valid = true; }
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);
@@ -1500,6 +1574,10 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         attr_done = true;
     }
     fhip_mesh* M = new fhip_mesh();
+    const bool times = getenv("FHIP_MESH_TIMES") != nullptr;       // diagnostic: phase wall times on stderr
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    double t_cells = 0, t_leaf = 0, t_copy = 0;
     DevBuf bufs[2], counters, table, leaves, d_cls, d_slot;
     auto cleanup = [&] { bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release(); };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -1538,6 +1616,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         if (n_in == 0) break;
     }
     M->ambiguous_leaves = n_leaf_cells;
+    t_cells = now() - t_start;
     if (n_leaf_cells) {
         FhMdcTable T;
         build_mdc_table(T);
@@ -1547,12 +1626,15 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(n_leaf_cells), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n_leaf_cells,
                            (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p);
         MESH_TRY(hipGetLastError());
+        if (times) { MESH_TRY(hipStreamSynchronize(ctx->stream)); t_leaf = now() - t_start - t_cells; }
         M->leaves.resize(n_leaf_cells);
         MESH_TRY(hipMemcpyAsync(M->leaves.data(), leaves.p, (size_t)n_leaf_cells * sizeof(FhMeshLeaf), hipMemcpyDeviceToHost, ctx->stream));
         MESH_TRY(hipStreamSynchronize(ctx->stream));
     }
 #undef MESH_TRY
     cleanup();
+    t_copy = now() - t_start - t_cells - t_leaf;
+    double t_asm = 0, t_walk = 0;
     if (assemble) {
         MeshAssembler A{*M, depth, {}};
         const float rb[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
@@ -1569,14 +1651,19 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                 if (n != 0.0f) { a = a / n; b = b / n; c = c / n; }
                 v.x = a; v.y = b; v.z = c;
             }
+        t_asm = now() - t_start - t_cells - t_leaf - t_copy;
         fhmesh::Walker W(A.o);
         W.cell(fhmesh::CellRef());
+        t_walk = now() - t_start - t_cells - t_leaf - t_copy - t_asm;
         M->octree_cells = A.o.cells.size(); M->octree_verts = A.o.verts.size();
         M->vertices.reserve(W.vertices.size() * 3);
         for (auto& v : W.vertices) { M->vertices.push_back(v.x); M->vertices.push_back(v.y); M->vertices.push_back(v.z); }
         M->triangles.reserve(W.triangles.size() * 3);
         for (auto& t : W.triangles) { M->triangles.push_back(t[0]); M->triangles.push_back(t[1]); M->triangles.push_back(t[2]); }
     }
+    if (times)
+        fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
+                depth, t_cells, (unsigned long long)M->cells_evaluated, t_leaf, n_leaf_cells, t_copy, t_asm, t_walk, now() - t_start);
     *out = M;
     return FHIP_OK;
 }

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""GPU box: BASELINE config 5 (gyroid-sphere Manifold Dual Contouring) - wall time of fidget_amd.mesh per octree depth, with the
+phases the library reports (FHIP_MESH_TIMES=1), next to the CPU oracle where it finishes in seconds."""
+import os, sys, json, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["FHIP_MESH_TIMES"] = "1"
+import torch
+import numpy as np
+import fidget_amd as F
+hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+res = {}
+depths = [int(a) for a in sys.argv[1:]] or [6, 7, 8, 9]
+shape = F.Shape.from_vm(os.path.join(ROOT, "models", "gyroid-sphere.vm"), hip=hip)
+F.mesh(shape, 4)
+for depth in depths:
+    t0 = time.perf_counter()
+    tris, verts, counts = F.mesh(shape, depth)
+    dt = time.perf_counter() - t0
+    res[f"depth {depth}"] = {"s": dt, "triangles": len(tris), "vertices": len(verts), **counts}
+    print(depth, res[f"depth {depth}"], flush=True)
+    del tris, verts
+if "--oracle" in os.environ.get("MESH_TIMES_FLAGS", ""):
+    import oracle as O
+    for depth in [d for d in depths if d <= 8]:
+        t0 = time.perf_counter()
+        m = O.mesh(os.path.join(ROOT, "models", "gyroid-sphere.vm"), depth)
+        res[f"oracle depth {depth}"] = {"s": time.perf_counter() - t0}
+        print("oracle", depth, res[f"oracle depth {depth}"], flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "mesh_times.json"), "w"), indent=1)
