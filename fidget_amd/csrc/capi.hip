@@ -111,7 +111,7 @@ struct fhip_ctx : FrameBufs {
     std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
     hipEvent_t ev_fork = nullptr;
     FhRenderState last_state_b;
-    uint32_t slab_contexts = 2;   // FHIP_SLAB_CONTEXTS (2 or 3): how far the tile chain may run ahead of the leaf chain
+    uint32_t slab_contexts = 3;   // FHIP_SLAB_CONTEXTS (2 .. 4): how far the tile chain may run ahead of the leaf chain
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -202,7 +202,14 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
     if (const char* e = getenv("FHIP_NO_FRAME_PIPELINE")) c->frame_pipeline = atoi(e) == 0;
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int pp = getenv("FHIP_PRE_PRIORITY") ? atoi(getenv("FHIP_PRE_PRIORITY")) : 0;
+        const hipError_t e = pp == 0 ? hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking)
+                                     : hipStreamCreateWithPriority(&c->stream_pre, hipStreamNonBlocking, pp == 1 ? lo : hi);
+        if (e != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
         (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
@@ -1035,7 +1042,13 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             bool rest = true;   // anything left for the root-sized LDS layout?
             if (vk && level > 0) {
                 static const int v64_waves = getenv("FHIP_V64_WAVES") ? atoi(getenv("FHIP_V64_WAVES")) : 8;
-                ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES; ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v64_waves);
+                // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
+                // VGPRs each, queued behind the leaf kernel of the slab in front, was measured to hold the tile chain up for
+                // 130 us: a small persistent grid there)
+                static const int v64_slab_waves = getenv("FHIP_V64_SLAB_WAVES") ? atoi(getenv("FHIP_V64_SLAB_WAVES")) : 128;
+                const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
+                ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
+                ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
                 (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka));
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
@@ -1133,6 +1146,8 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
             else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
         });
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->stream));     // (a later pipelined 3D frame that takes this buffer set waits for it)
+    ctx->ev_done_valid = true;
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);
@@ -1207,6 +1222,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
         ctx->stream = main_stream;
     }
+    int last_tail_idx = -1;
     for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
         const int idx = (int)R.slab_hi - 1 - k;
@@ -1225,7 +1241,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                                (pyr3 && rebuild) ? 1u : 0u);
             if (rebuild && pyr3) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
-                hipLaunchKernelGGL(k_minpyramid3, dim3(n1), dim3(1024), 0, ctx->stream, dS);
+                hipLaunchKernelGGL(k_minpyramid3, dim3(n1), dim3(256), 0, ctx->stream, dS);
             } else if (rebuild)
                 hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
         });
@@ -1235,13 +1251,15 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             ctx->stream = main_stream;
             HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }
-        // (on the tile chain this kernel, cheap as it is, was measured to cost the frame 0.8 ms)
-        // The footprint lists (needed by the normals only) and the leaves of the LDS class (any order with
-        // the others: atomic-max z-buffer) go beside the leaf kernel on a third stream: off the chain
-        // whose length is the slab's period.
-        // (measured: 0.75 ms SLOWER per frame - the three queues get in each other's way; off unless FHIP_AUX_STREAM=1)
-        const bool aux = pipe && ctx->stream3 && getenv("FHIP_AUX_STREAM");
-        auto aux_work = [&] {
+        // The leaf kernel is the slab's critical chain.  What surrounds it - the footprint lists (needed by the normals and the
+        // LDS-class leaves only), those leaves (any order with the others: atomic-max z-buffer) and the normals of the slab's
+        // hits - are small launches that leave the machine mostly idle, so in the pipelined frame they run on a third stream
+        // beside the leaf kernel of the NEXT slab: the normals kernel only takes hits of its own slab's depth range, and a hit
+        // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
+        static const int tail_mode = getenv("FHIP_TAIL_STREAM") ? atoi(getenv("FHIP_TAIL_STREAM")) : 1;   // 0: off, 1: lists + normals, 2: normals only
+        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points;   // (the HIP leaf kernels walk the footprint lists)
+        const uint32_t z_lo = (uint32_t)k * P.tiles[0], z_hi = z_lo + P.tiles[0];
+        auto classify_work = [&] {
             launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
             if (P.max_regs > 32)
                 launch(ctx, FHIP_K_POINTS, [&] {
@@ -1250,13 +1268,23 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                     else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
                 });
         };
-        if (aux) {
+        auto normals_work = [&] {
+            launch(ctx, FHIP_K_NORMALS, [&] {
+                const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_for(ctx, R.lds_normals_big, 8);
+                if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                if (P.max_regs > 32) {
+                    if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                    else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                }
+            });
+        };
+        if (tail && tail_mode == 1) {
             ctx->stream = ctx->stream3;
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_tiles[idx], 0));
-            aux_work();
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], ctx->stream3));
+            classify_work();
             ctx->stream = main_stream;
-        } else aux_work();
+        } else classify_work();
         launch(ctx, FHIP_K_POINTS, [&] {
             // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
             if (R.asm_points) {
@@ -1279,23 +1307,26 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
         });
-        if (aux) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_aux[idx], 0));
-        launch(ctx, FHIP_K_NORMALS, [&] {
-            const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_for(ctx, R.lds_normals_big, 8);
-            if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS);
-            else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS);
-            if (P.max_regs > 32) {
-                if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS);
-                else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS);
-            }
-        });
+        if (tail) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], main_stream));          // the slab's leaf kernel is through
+            ctx->stream = ctx->stream3;
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_aux[idx], 0));
+            normals_work();
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], ctx->stream3));       // slab context free again; the last one: image complete
+            ctx->stream = main_stream;
+            last_tail_idx = idx;
+            continue;
+        }
+        normals_work();
         if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
     }
+    if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
     launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out); });
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;
-    if (fpipe) { HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream)); ctx->ev_done_valid = true; }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream));     // (a later pipelined frame that takes this set waits for it)
+    ctx->ev_done_valid = true;
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);

@@ -1123,8 +1123,10 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
 // leaves; the wave loops over the distinct ones.
 // BIG: footprints of class 2 (LDS sized by the root tape); otherwise classes 0 and 1
 // (<= 32 registers, small LDS so that many waves fit).
+// z_lo, z_hi: only hits of this slab (z_lo < depth <= z_hi) are this launch's - the leaf kernel of the slab behind may already
+// be running (its hits lie below z_lo and carry leaf numbers of the other slab context).
 template <bool FULL, bool BIG>
-__global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
+__global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
@@ -1149,6 +1151,7 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S) {
         const uint64_t zb = inimg ? S->zbuf[pix] : 0;
         uint32_t id = (uint32_t)zb;
         const uint32_t depth = (uint32_t)(zb >> 32);
+        if (depth <= z_lo || depth > z_hi) id = 0;
         uint64_t todo = ballot(id != 0);
         while (todo) {
             const uint32_t cur = uni(__shfl(id, __builtin_ctzll(todo), WAVE));
@@ -1264,26 +1267,36 @@ __global__ void __launch_bounds__(256) k_minpyramid(FhRenderState* S) {
 // block per tile of the middle level, one wave per leaf tile in it, lane = pixel (coalesced rows); the
 // root level, reset to ~0 by k_reset_slab, takes 16 atomics per word.  (The kernel above, one thread
 // walking each leaf tile, took 30 us of every slab's tile chain.)
-__global__ void __launch_bounds__(1024) k_minpyramid3(FhRenderState* S) {
-    __shared__ uint32_t part[16];
+__global__ void __launch_bounds__(256) k_minpyramid3(FhRenderState* S) {
+    // one block of four waves per middle-level tile, four leaf tiles per wave (a block of 16 waves finds no room on a CU
+    // while the leaf kernel of the slab in front keeps the machine full: 166 us instead of 10)
+    __shared__ uint32_t part[4];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t T2 = P.tiles[2], T1 = P.tiles[1], T0 = P.tiles[0];
     const uint32_t n1x = (P.width + T1 - 1) / T1, n2x = (P.width + T2 - 1) / T2, n0x = (P.width + T0 - 1) / T0;
     const uint32_t bx = blockIdx.x % n1x, by = blockIdx.x / n1x;
-    const uint32_t tx = bx * 4 + (w & 3), ty = by * 4 + (w >> 2);
-    const uint32_t x = tx * T2 + (lane & 7), y = ty * T2 + (lane >> 3);
-    uint32_t mn = (x < P.width && y < P.height) ? (uint32_t)(S->zbuf[(size_t)y * P.width + x] >> 32) : 0xFFFFFFFFu;
+    const uint32_t ty = by * 4 + w, y = ty * T2 + (lane >> 3);
+    uint32_t v[4];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, WAVE));
-    if (lane == 0) {
-        part[w] = mn;
-        if (tx * T2 < P.width && ty * T2 < P.height) S->mind[2][ty * n2x + tx] = mn;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t x = (bx * 4 + i) * T2 + (lane & 7);
+        v[i] = (x < P.width && y < P.height) ? (uint32_t)(S->zbuf[(size_t)y * P.width + x] >> 32) : 0xFFFFFFFFu;
     }
+    uint32_t row = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t mn = v[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, WAVE));
+        const uint32_t tx = bx * 4 + i;
+        if (lane == 0 && tx * T2 < P.width && ty * T2 < P.height) S->mind[2][ty * n2x + tx] = mn;
+        row = min(row, mn);
+    }
+    if (lane == 0) part[w] = row;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t m = part[0];
-        for (int k = 1; k < 16; k++) m = min(m, part[k]);
+        const uint32_t m = min(min(part[0], part[1]), min(part[2], part[3]));
         S->mind[1][by * n1x + bx] = m;
         atomicMin(&S->mind[0][(by * T1 / T0) * n0x + bx * T1 / T0], m);
     }

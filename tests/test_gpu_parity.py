@@ -200,3 +200,34 @@ def test_render3d_reference_bench_camera_full_size():
     b = O.render3d(o, 1024, world_to_model=m)[0]
     assert (a["depth"] == b["depth"]).all()
     assert ((a["normal"] == b["normal"]) | (np.isnan(a["normal"]) & np.isnan(b["normal"]))).all()
+
+
+@pytest.mark.gpu
+def test_render3d_frames_in_flight():
+    """Asynchronous renders are pipelined across frames (two buffer sets per context, the coarse levels of frame n + 1
+    beside the slabs of frame n): a queue of frames of different shapes, sizes and cameras, nothing waited for in between,
+    gives the images the oracle gives, every one of them; a synchronous render in the middle of the queue as well."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    jobs = [("prospero.vm", 512, None), ("colonnade.vm", 256, bench_camera(0.3)), ("prospero.vm", 512, None), ("tanglecube.vm", 128, None),
+            ("colonnade.vm", 512, None), ("prospero.vm", 256, bench_camera(0.15)), ("prospero.vm", 1024, None), ("prospero.vm", 1024, None),
+            ("colonnade.vm", 256, None)]
+    shapes = {m: F.Shape.from_vm(model_path(m), hip=hip) for m, _, _ in jobs}
+    outs = [torch.zeros((n, n, 4), dtype=torch.int32, device="cuda") for _, n, _ in jobs]
+    mid = None
+    for rep in range(2):           # the second round reuses both sets with every buffer already sized
+        for i, (m, n, cam) in enumerate(jobs):
+            F.render3d(shapes[m], n, world_to_model=cam, out=outs[i])
+            if rep == 1 and i == 4:
+                mid = F.render3d(shapes["tanglecube.vm"], 64)[0]       # host output: waits for its own frame only
+    torch.cuda.synchronize()
+    hip.sync()
+    oshape = {m: O.Shape.from_vm(model_path(m)) for m in shapes}
+    for i, (m, n, cam) in enumerate(jobs):
+        b = O.render3d(oshape[m], n, world_to_model=cam)[0]
+        a = outs[i].cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        assert (a[:, :, 3] == b["depth"]).all(), f"frame {i} ({m} {n}): {(a[:, :, 3] != b['depth']).sum()} depths differ"
+        an = a[:, :, :3].copy().view(np.float32)
+        assert ((an == b["normal"]) | (np.isnan(an) & np.isnan(b["normal"]))).all(), f"frame {i} ({m} {n}): normals differ"
+    b = O.render3d(oshape["tanglecube.vm"], 64)[0]
+    assert (mid["depth"] == b["depth"]).all() and same_bits_f32(mid["normal"], b["normal"])
