@@ -52,7 +52,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -155,6 +155,7 @@ def lib():
             "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
             "fhip_debug_leaves": (u32, [vp, vp, u32]), "fhip_debug_arena": (u32, [vp, u32, u32, vp]), "fhip_debug_probe": (i32, [vp, vp]),
             "fhip_debug_bench": (i32, [vp, vp, u32, u32, i32, vp]),
+            "fhip_debug_walk_dual": (None, [vp, u64, vp, vp, u64, i32, vp, vp, vp]),
             "fhip_debug_groups": (u32, [vp, i32, u32, vp, u32, vp]),
             "fhip_debug_ubench": (i32, [vp, u32, u32, u32, vp]),
             "fhip_debug_math_sweep": (i32, [vp, i32, u32, u32, u64, vp, vp]),
@@ -824,6 +825,19 @@ def to_rgba_distance(image, hip=None):
 MESH_LEAF = np.dtype([("bounds", np.float32, 6), ("path", np.uint64), ("mask", np.uint32), ("n_edges", np.uint32), ("n_verts", np.uint32),
                       ("pad", np.uint32), ("inter", np.uint16, (12, 3)), ("pad2", np.uint16, 4), ("pos", np.float32, (12, 3)),
                       ("grad", np.float32, (12, 4)), ("vert", np.float32, (4, 3)), ("qef_err", np.float32, 4)])
+
+
+def debug_walk_dual(cells, root, verts, parallel):
+    """Octree::walk_dual of the library's host side on a given octree (fhip_debug_walk_dual): (triangles, vertices)"""
+    cells = np.ascontiguousarray(cells, np.uint32)
+    root = np.ascontiguousarray(root, np.uint32)
+    verts = np.ascontiguousarray(verts, np.float32)
+    c = np.zeros(2, np.uint64)
+    lib().fhip_debug_walk_dual(_p(cells), len(cells), _p(root), _p(verts), len(verts), int(parallel), _p(c), None, None)
+    tris = np.zeros((int(c[0]), 3), np.uint64)
+    out = np.zeros((int(c[1]), 3), np.float32)
+    lib().fhip_debug_walk_dual(_p(cells), len(cells), _p(root), _p(verts), len(verts), int(parallel), _p(c), _p(tris), _p(out))
+    return tris, out
 
 
 def mesh(shape, depth, world_to_model=None, vars=None):

@@ -120,6 +120,8 @@ struct fhip_ctx : FrameBufs {
     std::atomic<int> cancelled{0};
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[4];   // pinned (upload_frame)
+    void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
+    size_t mesh_pinned_cap = 0;
     uint32_t staging_next = 0;
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -237,6 +239,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
+    if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
@@ -1514,15 +1517,24 @@ static void build_mdc_table(FhMdcTable& T) {
     }
 }
 struct fhip_mesh {
-    std::vector<FhMeshLeaf> leaves;
+    // leaf records, in pinned host memory (the device writes them there in chunks while the leaf kernel is still running)
+    struct PinnedLeaves {
+        FhMeshLeaf* p = nullptr;
+        size_t n = 0;
+        bool borrowed = false;      // the context's cached area (fhip_mesh_build): not kept with the mesh
+        const FhMeshLeaf& operator[](size_t i) const { return p[i]; }
+        const FhMeshLeaf* data() const { return p; }
+        size_t size() const { return n; }
+        ~PinnedLeaves() { if (p && !borrowed) (void)hipHostFree(p); }
+    } leaves;
     uint64_t cells_evaluated = 0, full = 0, empty = 0, ambiguous_leaves = 0;
     std::vector<uint64_t> per_level;   // cells evaluated at each depth
     // per level, per evaluated cell: class (1 empty 2 full 3 ambiguous) and, for ambiguous cells, their index among the level's
     // ambiguous cells (= parent index of their children / leaf record index)
     std::vector<std::vector<uint8_t>> cls;
     std::vector<std::vector<uint32_t>> slot;
-    std::vector<float> vertices;          // fhip_mesh_build: Mesh::vertices (3 floats each)
-    std::vector<uint64_t> triangles;      // ... Mesh::triangles (3 indices each)
+    std::vector<fhmesh::V3> vertices;                    // fhip_mesh_build: Mesh::vertices
+    std::vector<std::array<uint64_t, 3>> triangles;      // ... Mesh::triangles
     uint64_t octree_cells = 0, octree_verts = 0;
 };
 // Assembly of the octree from the device's results, as Octree::recurse unwinds (octree.rs:556-583), then Octree::walk_dual
@@ -1574,6 +1586,90 @@ struct MeshAssembler {
             o.cells[index][corner] = ch;
         }
         return o.check_done(b, index, hc, hermite);
+    }
+};
+// The same assembly by independent subtrees on the host's threads, with the sequential recursion's result cell for cell and
+// vertex for vertex (as Octree::build_inner_mt does with its thread pool, octree.rs:94-210, but spliced in recursion order):
+// the ambiguous cells of level L are built each into an octree of its own, then the levels above them are assembled
+// sequentially and take the subtrees in the order the recursion reaches them (cell / vertex indices shifted to where the
+// recursion would have put them - check_done's bookkeeping only ever looks at the end of the arrays, which a subtree owns).
+struct ParallelMeshAssembler {
+    const fhip_mesh& M;
+    uint32_t depth, L;
+    fhmesh::Octree o;
+    struct Task { size_t i; float b[6]; };
+    struct Sub { fhmesh::Octree o; fhmesh::Cell root; fhmesh::Hermite h; size_t co = 0, vo = 0; };
+    static fhmesh::Cell shift(fhmesh::Cell x, size_t co, size_t vo) {
+        if (x.kind == fhmesh::C_BRANCH) x.index += (uint32_t)co;
+        else if (x.kind == fhmesh::C_LEAF) x.index += (uint32_t)vo;
+        return x;
+    }
+    std::vector<Task> tasks;
+    std::vector<Sub> subs;
+    size_t next = 0;
+    static void child_bounds(const float* b, int corner, float* cb) {
+        for (int k = 0; k < 3; k++) {
+            const float mid = (b[2 * k] + b[2 * k + 1]) / 2.0f;        // cell.rs:184-194
+            if (corner & (1 << k)) { cb[2 * k] = mid; cb[2 * k + 1] = b[2 * k + 1]; } else { cb[2 * k] = b[2 * k]; cb[2 * k + 1] = mid; }
+        }
+    }
+    void plan(uint32_t d, size_t i, const float* b) {
+        if (M.cls[d][i] != 3) return;
+        if (d == L) { Task t; t.i = i; for (int k = 0; k < 6; k++) t.b[k] = b[k]; tasks.push_back(t); return; }
+        const uint32_t s = M.slot[d][i];
+        for (int corner = 0; corner < 8; corner++) { float cb[6]; child_bounds(b, corner, cb); plan(d + 1, (size_t)s * 8 + corner, cb); }
+    }
+    fhmesh::Cell top(uint32_t d, size_t i, const float* b, fhmesh::Hermite* hermite) {
+        fhmesh::Cell res;
+        const uint8_t c = M.cls[d][i];
+        if (c == 2) { res.kind = fhmesh::C_FULL; return res; }
+        if (c == 1) { res.kind = fhmesh::C_EMPTY; return res; }
+        if (d == L) {       // splice the subtree
+            Sub& S = subs[next++];
+            // (room now, contents later and in parallel: nothing above this level ever reads inside a subtree)
+            const size_t co = o.cells.size(), vo = o.verts.size();
+            S.co = co; S.vo = vo;
+            o.cells.resize(co + S.o.cells.size());
+            o.verts.resize(vo + S.o.verts.size());
+            *hermite = S.h;
+            return shift(S.root, co, vo);
+        }
+        const uint32_t s = M.slot[d][i];
+        const size_t index = o.cells.size();
+        o.cells.push_back(std::array<fhmesh::Cell, 8>());
+        fhmesh::Hermite hc[8];
+        for (int corner = 0; corner < 8; corner++) {
+            float cb[6];
+            child_bounds(b, corner, cb);
+            const fhmesh::Cell ch = top(d + 1, (size_t)s * 8 + corner, cb, &hc[corner]);
+            o.cells[index][corner] = ch;
+        }
+        return o.check_done(b, index, hc, hermite);
+    }
+    fhmesh::Cell run(const float* rb, fhmesh::Hermite* h) {
+        fhmesh::tables();
+        plan(0, 0, rb);
+        subs.resize(tasks.size());
+        fhmesh::parallel_for(tasks.size(), [&](size_t k) {
+            MeshAssembler A{M, depth, {}};
+            subs[k].root = A.build(L, tasks[k].i, tasks[k].b, &subs[k].h);
+            subs[k].o = std::move(A.o);
+        });
+        size_t total_c = 64, total_v = 64;
+        for (auto& S : subs) { total_c += S.o.cells.size() + 1; total_v += S.o.verts.size(); }
+        o.cells.reserve(total_c + 600 * tasks.size() / 512 + 4096);
+        o.verts.reserve(total_v + 4096);
+        const fhmesh::Cell root = top(0, 0, rb, h);
+        fhmesh::parallel_for(subs.size(), [&](size_t k) {
+            Sub& S = subs[k];
+            // (a top-level collapse may have cut the arrays back below this subtree: then it is unreachable and not copied)
+            if (S.co + S.o.cells.size() <= o.cells.size())
+                for (size_t i = 0; i < S.o.cells.size(); i++) for (int q = 0; q < 8; q++) o.cells[S.co + i][q] = shift(S.o.cells[i][q], S.co, S.vo);
+            if (S.vo + S.o.verts.size() <= o.verts.size() && !S.o.verts.empty())
+                memcpy(&o.verts[S.vo], S.o.verts.data(), S.o.verts.size() * sizeof(fhmesh::V3));
+            S.o = fhmesh::Octree();
+        });
+        return root;
     }
 };
 static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
@@ -1654,24 +1750,64 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         MESH_TRY(table.ensure(sizeof(T)));
         MESH_TRY(hipMemcpyAsync(table.p, &T, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         MESH_TRY(leaves.ensure((size_t)n_leaf_cells * sizeof(FhMeshLeaf)));
-        hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(n_leaf_cells), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n_leaf_cells,
-                           (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p);
-        MESH_TRY(hipGetLastError());
-        if (times) { MESH_TRY(hipStreamSynchronize(ctx->stream)); t_leaf = now() - t_start - t_cells; }
-        M->leaves.resize(n_leaf_cells);
-        MESH_TRY(hipMemcpyAsync(M->leaves.data(), leaves.p, (size_t)n_leaf_cells * sizeof(FhMeshLeaf), hipMemcpyDeviceToHost, ctx->stream));
-        MESH_TRY(hipStreamSynchronize(ctx->stream));
+        // in chunks: the records of chunk k travel to the host (second stream) while chunk k + 1 is sampled
+        const size_t leaf_bytes = (size_t)n_leaf_cells * sizeof(FhMeshLeaf);
+        if (assemble) {     // the records are only needed until the octree is assembled: the context's cached landing area
+            if (ctx->mesh_pinned_cap < leaf_bytes) {
+                if (ctx->mesh_pinned) (void)hipHostFree(ctx->mesh_pinned);
+                ctx->mesh_pinned = nullptr; ctx->mesh_pinned_cap = 0;
+                MESH_TRY(hipHostMalloc(&ctx->mesh_pinned, leaf_bytes + leaf_bytes / 8, hipHostMallocDefault));
+                ctx->mesh_pinned_cap = leaf_bytes + leaf_bytes / 8;
+            }
+            M->leaves.p = (FhMeshLeaf*)ctx->mesh_pinned;
+            M->leaves.borrowed = true;
+        } else
+            MESH_TRY(hipHostMalloc((void**)&M->leaves.p, leaf_bytes, hipHostMallocDefault));
+        M->leaves.n = n_leaf_cells;
+        const uint32_t CH = 1u << 19;
+        std::vector<hipEvent_t> evs;
+        hipStream_t const copy_stream = ctx->stream2 ? ctx->stream2 : ctx->stream;
+        bool ok = true;
+        hipError_t first_err = hipSuccess;
+        auto chk = [&](hipError_t e) { if (e != hipSuccess && ok) { ok = false; first_err = e; } };
+        for (uint32_t off = 0; off < n_leaf_cells && ok; off += CH) {
+            const uint32_t cnt = std::min<uint32_t>(CH, n_leaf_cells - off);
+            hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p + off, cnt,
+                               (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off);
+            chk(hipGetLastError());
+            hipEvent_t ev = nullptr;
+            chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            if (ev) evs.push_back(ev);
+            chk(hipEventRecord(ev, ctx->stream));
+            chk(hipStreamWaitEvent(copy_stream, ev, 0));
+            chk(hipMemcpyAsync(M->leaves.p + off, (FhMeshLeaf*)leaves.p + off, (size_t)cnt * sizeof(FhMeshLeaf), hipMemcpyDeviceToHost, copy_stream));
+        }
+        if (times) { chk(hipStreamSynchronize(ctx->stream)); t_leaf = now() - t_start - t_cells; }
+        chk(hipStreamSynchronize(ctx->stream));
+        chk(hipStreamSynchronize(copy_stream));
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        MESH_TRY(first_err);
     }
 #undef MESH_TRY
     cleanup();
     t_copy = now() - t_start - t_cells - t_leaf;
     double t_asm = 0, t_walk = 0;
     if (assemble) {
-        MeshAssembler A{*M, depth, {}};
         const float rb[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
         fhmesh::Hermite h;
         // (a level the recursion never reached - everything above it was decided - has no arrays: only levels 0 .. cls.size()-1 are indexed)
-        A.o.root = A.build(0, 0, rb, &h);
+        const uint32_t split = std::min<uint32_t>(depth, getenv("FHIP_MESH_SPLIT") ? (uint32_t)atoi(getenv("FHIP_MESH_SPLIT")) : 4u);
+        const bool par = split >= 1 && M->cls.size() > split && fhmesh::mesh_threads() > 1;
+        struct { fhmesh::Octree o; } A;
+        if (par) {
+            ParallelMeshAssembler PA{*M, depth, split, {}, {}, {}, 0};
+            PA.o.root = PA.run(rb, &h);
+            A.o = std::move(PA.o);
+        } else {
+            MeshAssembler SA{*M, depth, {}};
+            SA.o.root = SA.build(0, 0, rb, &h);
+            A.o = std::move(SA.o);
+        }
         if (P.has_mat)       // octree.rs:58-65: vertices back to model space (nalgebra transform_point)
             for (auto& v : A.o.verts) {
                 const float x = v.x, y = v.y, z = v.z;
@@ -1683,14 +1819,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                 v.x = a; v.y = b; v.z = c;
             }
         t_asm = now() - t_start - t_cells - t_leaf - t_copy;
-        fhmesh::Walker W(A.o);
-        W.cell(fhmesh::CellRef());
+        M->leaves.p = nullptr; M->leaves.n = 0;      // (borrowed from the context: gone with the assembly)
+        fhmesh::ParallelWalker W(A.o);
+        W.run();
         t_walk = now() - t_start - t_cells - t_leaf - t_copy - t_asm;
         M->octree_cells = A.o.cells.size(); M->octree_verts = A.o.verts.size();
-        M->vertices.reserve(W.vertices.size() * 3);
-        for (auto& v : W.vertices) { M->vertices.push_back(v.x); M->vertices.push_back(v.y); M->vertices.push_back(v.z); }
-        M->triangles.reserve(W.triangles.size() * 3);
-        for (auto& t : W.triangles) { M->triangles.push_back(t[0]); M->triangles.push_back(t[1]); M->triangles.push_back(t[2]); }
+        M->vertices.swap(W.vertices);
+        M->triangles.swap(W.triangles);
     }
     if (times)
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
@@ -1708,13 +1843,30 @@ fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
     return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, true, out);
 }
-void fhip_mesh_vertices(const fhip_mesh* m, float* out) { memcpy(out, m->vertices.data(), m->vertices.size() * 4); }
-void fhip_mesh_triangles(const fhip_mesh* m, uint64_t* out) { memcpy(out, m->triangles.data(), m->triangles.size() * 8); }
+void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_t* root, const float* verts, uint64_t n_verts, int parallel,
+                          uint64_t counts[2], uint64_t* tris, float* verts_out) {
+    fhmesh::Octree o;
+    auto cell = [](const uint32_t* w) { fhmesh::Cell c; c.kind = (uint8_t)w[0]; c.mask = (uint8_t)w[1]; c.index = w[2]; return c; };
+    o.root = cell(root);
+    o.cells.resize(n_cells);
+    for (uint64_t i = 0; i < n_cells; i++) for (int k = 0; k < 8; k++) o.cells[i][k] = cell(cells + (i * 8 + k) * 3);
+    o.verts.resize(n_verts);
+    for (uint64_t i = 0; i < n_verts; i++) o.verts[i] = fhmesh::V3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
+    std::vector<std::array<uint64_t, 3>> t;
+    std::vector<fhmesh::V3> v;
+    if (parallel) { fhmesh::ParallelWalker W(o); W.run(); t.swap(W.triangles); v.swap(W.vertices); }
+    else { fhmesh::Walker W(o); W.cell(fhmesh::CellRef()); t.swap(W.triangles); v.swap(W.vertices); }
+    counts[0] = t.size(); counts[1] = v.size();
+    if (tris) memcpy(tris, t.data(), t.size() * 24);
+    if (verts_out) memcpy(verts_out, v.data(), v.size() * 12);
+}
+void fhip_mesh_vertices(const fhip_mesh* m, float* out) { memcpy(out, m->vertices.data(), m->vertices.size() * 12); }
+void fhip_mesh_triangles(const fhip_mesh* m, uint64_t* out) { memcpy(out, m->triangles.data(), m->triangles.size() * 24); }
 void fhip_mesh_free(fhip_mesh* m) { delete m; }
 // out = {cells evaluated (= interval evaluations), Full, Empty, ambiguous cells at the leaf depth (= calls of leaf()), bytes per leaf record, levels}
 void fhip_mesh_counts(const fhip_mesh* m, uint64_t out[8]) {
     out[0] = m->cells_evaluated; out[1] = m->full; out[2] = m->empty; out[3] = m->ambiguous_leaves; out[4] = sizeof(FhMeshLeaf);
-    out[5] = m->per_level.size(); out[6] = m->vertices.size() / 3; out[7] = m->triangles.size() / 3;
+    out[5] = m->per_level.size(); out[6] = m->vertices.size(); out[7] = m->triangles.size();
 }
 void fhip_mesh_leaves(const fhip_mesh* m, void* out) { memcpy(out, m->leaves.data(), m->leaves.size() * sizeof(FhMeshLeaf)); }
 

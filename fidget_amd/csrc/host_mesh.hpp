@@ -9,10 +9,15 @@
 // Integer / topological code, plus the QEF of a collapsed cell (mesh_qef.hpp, the definition the device kernel uses too).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -168,10 +173,20 @@ struct Hermite {
     }
 };
 
+// (vector growth without value-initialisation: the parallel assembly makes room for a subtree's vertices first and fills it in
+// from another thread later - zeroing two gigabytes in between, page by page, was a third of its time)
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    default_init_allocator() = default;
+    template <class U> default_init_allocator(const default_init_allocator<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
 struct Octree {
     Cell root;
     std::vector<std::array<Cell, 8>> cells;
-    std::vector<V3> verts;
+    std::vector<V3, default_init_allocator<V3>> verts;
     Cell& at(const CellRef& c) { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
     const Cell& at(const CellRef& c) const { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
     bool is_leaf(const CellRef& c) const { const uint8_t k = at(c).kind; return k == C_LEAF || k == C_FULL || k == C_EMPTY; }
@@ -336,6 +351,165 @@ struct Walker {
             const CellRef &p = cs[j], &q = cs[(j + winding) % 4];
             if (p.ci != q.ci || p.cj != q.cj) triangles.push_back({vs[j], vs[(j + winding) % 4], iv});
         }
+    }
+};
+
+// ---- host threads ------------------------------------------------------------------------------------------------
+// (FHIP_MESH_THREADS overrides; the work items below are independent subtrees / sub-walks, taken from a shared counter)
+static inline unsigned mesh_threads() {
+    if (const char* e = getenv("FHIP_MESH_THREADS")) return (unsigned)std::max(1, atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hc ? hc : 1u, 128u));
+}
+static inline void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+    const unsigned nt = (unsigned)std::min<size_t>(mesh_threads(), n);
+    if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto& t : th) t.join();
+}
+
+// The dual walk split into independent pieces with the sequential walk's output, triangle for triangle.  The recursion
+// of Walker (cell -> cells, faces, edges; face -> faces, edges; edge -> edges) is unrolled breadth first, every call replaced
+// by its sub-calls IN THE ORDER THE RECURSION MAKES THEM, until there are enough calls to keep the threads busy; each
+// remaining call is then walked on its own and records what it would emit - per edge the five octree vertices in the order
+// Walker::edge asks MeshBuilder for them, and which of the four triangles exist; a final sequential pass over the records in
+// call order numbers the vertices by first use (builder.rs) and writes the triangles.
+struct ParallelWalker {
+    const Octree& o;
+    std::vector<std::array<uint64_t, 3>> triangles;
+    std::vector<V3> vertices;
+    explicit ParallelWalker(const Octree& oc) : o(oc) {}
+    struct Call { uint8_t kind, f; CellRef c[4]; };        // kind 0 cell(c0), 1 face(f, c0, c1), 2 edge(f, c0..c3)
+    struct Rec { uint64_t iv, vs[4]; uint8_t winding, push; };
+    static void frame(int f, int* t, int* u, int* v) { Walker::frame(f, t, u, v); }
+    // the sub-calls of one call, in order; false: the call emits (or does nothing) itself
+    struct CallBuf { Call c[26]; int n = 0; void push_back(const Call& k) { c[n++] = k; } };
+    bool expand(const Call& k, CallBuf& out) const {
+        auto cell = [&](const CellRef& a) { Call c{}; c.kind = 0; c.c[0] = a; out.push_back(c); };
+        auto face = [&](int f, const CellRef& lo, const CellRef& hi) { Call c{}; c.kind = 1; c.f = (uint8_t)f; c.c[0] = lo; c.c[1] = hi; out.push_back(c); };
+        auto edge = [&](int f, const CellRef& a, const CellRef& b, const CellRef& c2, const CellRef& d) {
+            Call c{}; c.kind = 2; c.f = (uint8_t)f; c.c[0] = a; c.c[1] = b; c.c[2] = c2; c.c[3] = d; out.push_back(c);
+        };
+        if (k.kind == 0) {
+            const CellRef& c = k.c[0];
+            if (o.at(c).kind != C_BRANCH) return true;     // nothing to do: expands to no calls
+            for (int i = 0; i < 8; i++) cell(o.child(c, i));
+            for (int f = 0; f < 3; f++) {
+                int t, u, v; frame(f, &t, &u, &v);
+                for (int q : {0, u, v, u | v}) face(f, o.child(c, q), o.child(c, q | t));
+            }
+            for (int i = 0; i < 2; i++) {
+                const int x = i ? AX : 0, y = i ? AY : 0, z = i ? AZ : 0;
+                edge(0, o.child(c, x), o.child(c, x | AY), o.child(c, x | AY | AZ), o.child(c, x | AZ));
+                edge(1, o.child(c, y), o.child(c, y | AZ), o.child(c, y | AX | AZ), o.child(c, y | AX));
+                edge(2, o.child(c, z), o.child(c, z | AX), o.child(c, z | AX | AY), o.child(c, z | AY));
+            }
+            return true;
+        }
+        if (k.kind == 1) {
+            const CellRef &lo = k.c[0], &hi = k.c[1];
+            if (o.is_leaf(lo) && o.is_leaf(hi)) return true;
+            const int f = k.f;
+            int t, u, v; frame(f, &t, &u, &v);
+            face(f, o.child(lo, t), o.child(hi, 0));
+            face(f, o.child(lo, t | u), o.child(hi, u));
+            face(f, o.child(lo, t | v), o.child(hi, v));
+            face(f, o.child(lo, t | u | v), o.child(hi, u | v));
+            for (int i = 0; i < 2; i++) {
+                const int ui = i ? u : 0, vi = i ? v : 0;
+                edge((f + 1) % 3, o.child(lo, ui | t), o.child(lo, ui | v | t), o.child(hi, ui | v), o.child(hi, ui));
+                edge((f + 2) % 3, o.child(lo, vi | t), o.child(hi, vi), o.child(hi, vi | u), o.child(lo, vi | u | t));
+            }
+            return true;
+        }
+        bool all_leaf = true;
+        for (int i = 0; i < 4; i++) all_leaf &= o.is_leaf(k.c[i]);
+        if (all_leaf) return false;
+        int t, u, v; frame(k.f, &t, &u, &v);
+        for (int i = 0; i < 2; i++) {
+            const int ti = i ? t : 0;
+            edge(k.f, o.child(k.c[0], ti | u | v), o.child(k.c[1], ti | v), o.child(k.c[2], ti), o.child(k.c[3], ti | u));
+        }
+        return true;
+    }
+    // Walker::edge on four leaves, recording instead of numbering
+    void emit(const Call& k, std::vector<Rec>& out) const {
+        const CellRef* cs = k.c;
+        Cell leafs[4];
+        for (int i = 0; i < 4; i++) { leafs[i] = o.at(cs[i]); if (leafs[i].kind != C_LEAF) return; }
+        int deepest = 0;
+        for (int i = 0; i < 4; i++) if (cs[i].depth >= cs[deepest].depth) deepest = i;
+        int t, u, v; frame(k.f, &t, &u, &v);
+        const int ti = axis_index(t);
+        const int edges[4] = {ti * 4 + 3, ti * 4 + 2, ti * 4 + 0, ti * 4 + 1};
+        int s0, e0;
+        edge_corners(edges[deepest], &s0, &e0);
+        const bool st = !((leafs[deepest].mask >> s0) & 1), en = !((leafs[deepest].mask >> e0) & 1);
+        if (st == en) return;
+        const Tables& T = tables();
+        int vv[4][2];
+        for (int i = 0; i < 4; i++) {
+            vv[i][0] = vv[i][1] = -1;
+            if (cs[i].depth == cs[deepest].depth) { vv[i][0] = T.e2v[leafs[i].mask][edges[i]][0]; vv[i][1] = T.e2v[leafs[i].mask][edges[i]][1]; }
+            else for (int j = 0; j < 12; j++) if (T.e2v[leafs[i].mask][j][0] >= 0) { vv[i][0] = T.e2v[leafs[i].mask][j][0]; vv[i][1] = T.e2v[leafs[i].mask][j][1]; break; }
+            if (vv[i][0] < 0) return;
+        }
+        Rec r;
+        r.iv = leafs[deepest].index + (uint64_t)vv[deepest][1];
+        for (int i = 0; i < 4; i++) r.vs[i] = leafs[i].index + (uint64_t)vv[i][0];
+        r.winding = st ? 3 : 1;
+        r.push = 0;
+        for (int j = 0; j < 4; j++) {
+            const CellRef &p = cs[j], &q = cs[(j + r.winding) % 4];
+            if (p.ci != q.ci || p.cj != q.cj) r.push |= (uint8_t)(1 << j);
+        }
+        out.push_back(r);
+    }
+    void walk(const Call& k, std::vector<Rec>& out) const {     // depth first from one call
+        CallBuf sub;
+        if (!expand(k, sub)) { emit(k, out); return; }
+        for (int i = 0; i < sub.n; i++) walk(sub.c[i], out);
+    }
+    void run() {
+        tables();
+        std::vector<Call> calls(1);
+        calls[0] = Call{};
+        const size_t want = (size_t)mesh_threads() * 64;
+        for (int round = 0; round < 8 && calls.size() < want && mesh_threads() > 1; round++) {
+            std::vector<Call> next;
+            next.reserve(calls.size() * 8);
+            for (const Call& k : calls) {
+                CallBuf sub;
+                if (expand(k, sub)) next.insert(next.end(), sub.c, sub.c + sub.n);
+                else next.push_back(k);
+            }
+            if (next.size() == calls.size()) break;
+            calls.swap(next);
+        }
+        std::vector<std::vector<Rec>> recs(calls.size());
+        parallel_for(calls.size(), [&](size_t i) { walk(calls[i], recs[i]); });
+        // octree vertex -> mesh vertex + 1 (0: not seen yet); calloc: only the pages that are touched cost anything
+        uint32_t* map = (uint32_t*)calloc(std::max<size_t>(o.verts.size(), 1), sizeof(uint32_t));
+        size_t nrec = 0;
+        for (auto& r : recs) nrec += r.size();
+        triangles.reserve(nrec * 4);
+        vertices.reserve(nrec * 2);
+        auto vertex = [&](uint64_t v) {
+            if (map[v] == 0) { vertices.push_back(o.verts[v]); map[v] = (uint32_t)vertices.size(); }
+            return (uint64_t)(map[v] - 1);
+        };
+        for (auto& rs : recs)
+            for (const Rec& r : rs) {
+                const uint64_t iv = vertex(r.iv);
+                uint64_t vs[4];
+                for (int i = 0; i < 4; i++) vs[i] = vertex(r.vs[i]);
+                for (int j = 0; j < 4; j++)
+                    if (r.push & (1 << j)) triangles.push_back({vs[j], vs[(j + r.winding) % 4], iv});
+            }
+        free(map);
     }
 };
 

@@ -542,7 +542,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
 // assembly, or k_teval3d below for tapes outside its opcode set) -> k_tpush3d.  Same
 // algorithm as k_tiles; the parent travels between the kernels in an FhSlot.
 // ======================================================================================
-__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) {
+template <bool IS3D>
+FH_DEV void tsetup_body(FhRenderState* S, int level) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
         FhSlot* const slg = &S->slots[big ? 1 : 0][big ? (gi - ns) * G : gi];
         FhSlot& sl = *slg;
-        if (level > 0) {  // the whole parent may have been occluded since it was queued
+        if (IS3D && level > 0) {  // the whole parent may have been occluded since it was queued
             const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
             if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
         }
@@ -574,16 +575,16 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
             cx = (ri / P.roots_y) * T; cy = (ri % P.roots_y) * T; cz = g.z;
         } else {
             const uint32_t n = P.tiles[level - 1] / T;
-            nchild = n * n * n;
-            cx = g.x + (lane % n) * T; cy = g.y + ((lane / n) % n) * T; cz = g.z + (lane / (n * n)) * T;
+            nchild = IS3D ? n * n * n : n * n;
+            cx = g.x + (lane % n) * T; cy = g.y + ((lane / n) % n) * T; cz = IS3D ? g.z + (lane / (n * n)) * T : 0u;
         }
         bool act = lane < (int)nchild && cx < P.width && cy < P.height;
-        if (act && mind[(cy / T) * ntx + cx / T] >= cz + T + 1) act = false;  // voxel.rs:283-289
+        if (IS3D && act && mind[(cy / T) * ntx + cx / T] >= cz + T + 1) act = false;  // voxel.rs:283-289
         const uint64_t actm = ballot(act);
         if (actm == 0) { if (lane < (int)G) slg[lane].act = 0; continue; }
         IV X, Y, Z;
         xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
-                    iv((float)cz, (float)cz + (float)T), X, Y, Z);
+                    IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z), X, Y, Z);     // (2D: pixel.rs:325-333)
         for (uint32_t k = 0; k < G; k++) {
             FhSlot& so = slg[k];
             if (lane == 0) {
@@ -598,6 +599,11 @@ __global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) 
         }
     }
 }
+
+__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) { tsetup_body<true>(S, level); }
+// ... and of the 2D renderer when its tile sizes give 64 children per parent (the 128 / 16 hint): same slots, same
+// evaluate + prune kernels; children are the n x n sub-tiles at the slice height z
+__global__ void __launch_bounds__(WAVE) k_tsetup2d(FhRenderState* S, int level) { tsetup_body<false>(S, level); }
 
 // Tape parallelism at level 0 (host_graph.hpp plan_terms), after the groups' forward passes left the
 // terms' intervals in S->tvals: the root min / max tree over those terms, with the Choice every op
@@ -816,7 +822,8 @@ __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
 }
 
 // Step 3: fills of the decided children, queue / leaf entries for the ambiguous ones
-__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
+template <bool IS3D>
+FH_DEV void tpush_body(FhRenderState* S, int level) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
@@ -834,7 +841,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
             const uint64_t actm = sl.act;
             if (uni((uint32_t)(actm != 0)) == 0) continue;
             const float lo = sl.res[0][lane], hi = sl.res[1][lane];
-            mine += (uint32_t)__popcll(ballot(((actm >> lane) & 1) && !(hi < 0.0f) && !(lo > 0.0f)));
+            mine += (uint32_t)__popcll(ballot(((actm >> lane) & 1) && ((!IS3D && P.pixel_perfect) || (!(hi < 0.0f) && !(lo > 0.0f)))));
         }
         if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
         leaf_base = uni(leaf_base);
@@ -845,17 +852,28 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
         const bool act = (sl.act >> lane) & 1;
         const float lo = sl.res[0][lane], hi = sl.res[1][lane];
         const uint32_t cx = sl.corner[0][lane], cy = sl.corner[1][lane], cz = sl.corner[2][lane];
-        const bool full = act && hi < 0.0f, empty = act && !full && lo > 0.0f;  // voxel.rs:310-320
+        const bool fills = IS3D || !P.pixel_perfect;                                       // pixel.rs:345-368
+        const bool full = act && fills && hi < 0.0f, empty = act && fills && !full && lo > 0.0f;  // voxel.rs:310-320
         const bool amb = act && !full && !empty;
-        uint64_t fm = ballot(full);
-        while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317)
+        const uint64_t fullm = ballot(full);
+        uint64_t fm = fullm | (IS3D ? 0ull : ballot(empty));
+        while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317); 2D: full and empty tiles, their level in the fill
             const int c = __builtin_ctzll(fm);
             fm &= fm - 1;
             const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
-            const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + T + 1) << 32;
-            for (uint32_t p = lane; p < T * T; p += WAVE) {
-                const uint32_t x = ccx + (p % T), y = ccy + (p / T);
-                if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
+            if (IS3D) {
+                const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + T + 1) << 32;
+                for (uint32_t p = lane; p < T * T; p += WAVE) {
+                    const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                    if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
+                }
+            } else {
+                const bool inside = (fullm >> c) & 1;
+                const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (inside ? 1u : 0u) | (0xF6u << 9));   // pixel.rs:225-229
+                for (uint32_t p = lane; p < T * T; p += WAVE) {
+                    const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                    if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;
+                }
             }
         }
         if (S->want_stats) {   // algorithmic-bytes accounting: tape ops read by this parent, ops of pruned tapes written
@@ -874,7 +892,7 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
             const uint32_t slot_s = wave_excl_sum((amb && small) ? 1u : 0u, ns);
             const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
             // the last pre-pass level parks its output in the queue of the children's z-slab
-            const bool park = S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
+            const bool park = IS3D && S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
             const uint32_t slab = park ? uni(__shfl(cz, __builtin_ctzll(am), WAVE)) / P.tiles[0] : 0;
             FhGroup* const qdst = park ? S->squeue + (size_t)slab * S->squeue_cap : S->queue[level + 1];
             const uint32_t qcap = park ? S->squeue_cap : S->qcap[level + 1];
@@ -899,12 +917,14 @@ __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
                 if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
-                const uint32_t layers = P.tiles[0] / T;
-                S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
+                if (IS3D)
+                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
     }
 }
+__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) { tpush_body<true>(S, level); }
+__global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level); }
 
 // ======================================================================================
 // Point evaluation with a VGPR register file: NR registers x ZB values per lane.

@@ -93,10 +93,10 @@ __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMes
     }
     const bool full = act && result.hi < 0.0f, empty = act && !full && result.lo > 0.0f, amb = act && !full && !empty;
     const uint64_t am = ballot(amb);
+    const uint32_t nf = (uint32_t)__popcll(ballot(full)), ne = (uint32_t)__popcll(ballot(empty));    // (every lane votes: outside the branch)
     uint32_t base = 0;
     if (lane == 0) {
         if (am) base = atomicAdd(&counters[0], (uint32_t)__popcll(am));
-        const uint32_t nf = (uint32_t)__popcll(ballot(full)), ne = (uint32_t)__popcll(ballot(empty));
         if (nf) atomicAdd(&counters[1], nf);
         if (ne) atomicAdd(&counters[2], ne);
     }

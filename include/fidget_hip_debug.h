@@ -33,6 +33,14 @@ fhip_status fhip_debug_math_sweep(fhip_ctx* ctx, int op, uint32_t first, uint32_
  * counts[0] = entries whose tape fits the small register-file layout (written first), counts[1] = the others. */
 uint32_t fhip_debug_groups(fhip_ctx* ctx, int kind, uint32_t index, void* out, uint32_t cap, uint32_t counts[2]);
 
+/* The host side of fhip_mesh_build on an octree given by the caller (no device involved): Octree::walk_dual over `cells`
+ * ([n_cells][8] x {kind (0 invalid 1 empty 2 full 3 branch 4 leaf), mask, index}, u32 each), `root` (same three words) and `verts`
+ * ([n_verts][3] floats), sequentially (parallel = 0: the recursion of dc.rs) or by independent sub-walks on the host's threads
+ * (parallel = 1: what fhip_mesh_build runs).  Call with tris = verts_out = NULL for the sizes (counts = {triangles, vertices}),
+ * then again with buffers of 3 u64 per triangle and 3 floats per vertex. */
+void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_t* root, const float* verts, uint64_t n_verts, int parallel,
+                          uint64_t counts[2], uint64_t* tris, float* verts_out);
+
 #ifdef __cplusplus
 }
 #endif

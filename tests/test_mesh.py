@@ -393,3 +393,22 @@ def test_device_mesh_gyroid_sphere_manifold(oracle_mod):
     check_for_edge_matching(tris)
     assert abs(len(tris) - len(np.asarray(t).reshape(-1, 3))) <= max(4, len(tris) // 500)
     assert np.isfinite(verts).all() and (np.abs(verts) <= 1.0).all()
+
+
+@pytest.mark.parametrize("model,depth,threads", [("gyroid-sphere.vm", 5, 4), ("bear.vm", 5, 3), ("colonnade.vm", 5, 8), ("prospero.vm", 4, 2)])
+def test_library_dual_walk_sequential_and_parallel(model, depth, threads, oracle_mod, monkeypatch):
+    """The host side of fhip_mesh_build walks the dual on the host's threads (independent sub-walks, vertices numbered by a
+    final sequential pass): on the oracle's octree it gives the triangles and vertices of the sequential recursion, which are
+    the oracle's own walk_dual, element for element - no device needed (fhip_debug_walk_dual)."""
+    import fidget_amd as F
+    O = oracle_mod
+    oc = O.Octree(O.Shape.from_vm(model_path(model)), depth)
+    ref_t, ref_v = oc.walk_dual()
+    kinds = {"Invalid": 0, "Empty": 1, "Full": 2, "Branch": 3, "Leaf": 4}
+    root = np.array([kinds[oc.root[0]], oc.root[1], oc.root[2]], np.uint32)
+    monkeypatch.setenv("FHIP_MESH_THREADS", str(threads))
+    for parallel in (0, 1):
+        t, v = F.debug_walk_dual(oc.cells, root, oc.verts, parallel)
+        assert len(ref_t) > 1000
+        assert (t == ref_t).all() and t.shape == ref_t.shape
+        assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
