@@ -43,6 +43,9 @@ STATUS = {1: "BadVarSlice", 2: "MismatchedSlices", 3: "BadChoiceSlice", 4: "Miss
 VM_TILES_3D = [128, 64, 32, 16, 8]
 VM_TILES_2D = [128, 32, 8]
 GEOMETRY_PIXEL = np.dtype([("normal", np.float32, 3), ("depth", np.uint32)])
+# RenderHints of the HIP shape (capi.hip): 2D 128 / 16 as fidget-jit, 3D 128 / 32 / 8; the VM shape's for comparison
+HIP_TILES_2D, HIP_TILES_3D = [128, 16], [128, 32, 8]
+VM_TILES_2D, VM_TILES_3D = [128, 32, 8], [128, 64, 32, 16, 8]
 
 EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",

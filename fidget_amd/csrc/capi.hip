@@ -640,7 +640,8 @@ struct RenderSetup {
     uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
     size_t lds_tiles_group = 0;
     bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
-    bool prune1 = false;      // ... and, on the pre-pass levels, the prune as one wave per child (fh_prune1)
+    bool prune1 = false;      // ... and, on the first exp_levels levels, the prune as one wave per child (fh_prune1)
+    uint32_t exp_levels = 0;
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -678,6 +679,9 @@ static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size) {
     return out;
 }
 
+// 2D hint of the HIP shape: 128 -> 16 with 16 x 16 pixel leaves - what fidget-jit uses (fidget-jit/src/lib.rs:984-986); a fan-out
+// of 64 children per parent fills a wavefront of the tile-stage kernels (the VM's 128 / 32 / 8 fans out by 16)
+static const uint32_t HIP_TILES_2D[] = {128, 16};
 static bool tape_is_full(const fh::HostTape& t) {
     for (uint64_t w : t.ops) {
         const uint32_t op = FH_W_OP((uint32_t)w);
@@ -836,9 +840,15 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
-    R.split = ctx->use_split && is3d && R.tl == 64;
+    R.split = ctx->use_split && R.tl == 64 && (is3d || !getenv("FHIP_NO_SPLIT_2D"));
     R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
-    R.prune1 = R.asm_tiles && S.pre_levels > 0 && !getenv("FHIP_NO_PRUNE1");
+    // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
+    // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
+    {
+        static const uint32_t p1_levels = getenv("FHIP_PRUNE1_LEVELS") ? (uint32_t)atoi(getenv("FHIP_PRUNE1_LEVELS")) : 1u;
+        R.exp_levels = is3d ? std::min(S.pre_levels, p1_levels) : std::min(1u, p1_levels);
+    }
+    R.prune1 = R.asm_tiles && R.exp_levels > 0 && !getenv("FHIP_NO_PRUNE1");
     // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
     // waves, then the tree itself; the prune sees the root tape with its usual choices
     R.groups = R.prune1 && !tape->tgroups.empty() && !getenv("FHIP_NO_TAPE_GROUPS");
@@ -876,7 +886,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     if (R.prune1) {  // choice words of the pre-pass levels' forward passes: [slot][word][lane]
         uint32_t cap = 1;
-        for (uint32_t l = 0; l < S.pre_levels; l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
+        for (uint32_t l = 0; l < std::max(S.pre_levels, R.exp_levels); l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
         const size_t words[2] = {(SMALL_CHOICES + 15) / 16, ((size_t)P.max_choices + 15) / 16};
         for (int k = 0; k < 2; k++) {
             HIP_TRY(ctx, ctx->chw[k].ensure(std::max<size_t>(cap * words[k] * 256, 256)));
@@ -981,7 +991,7 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         else hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
     } while (0)
 // 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
-static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level) {
+static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
     // Persistent waves with a static round robin over the parents.  (FHIP_ONE_EACH_TILES=1: one short
     // workgroup per parent instead - measured slower in the pipelined frame: the tile stage then
     // takes more of the machine from the leaf kernel it overlaps with.)
@@ -989,7 +999,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
     const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
-    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level); });
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+        else hipLaunchKernelGGL(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+    });
     if (R.groups && level == 0) {
         // Tape parallelism: the root tree's terms by independent groups, one wave per (block of root
         // tiles, group) -> the tree over the terms (result, marks, arena) -> the root tape's choice words
@@ -1012,8 +1025,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         launch(ctx, FHIP_K_TILES, [&] {
             // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
             // the prune runs as one wave per child (fh_prune1)
-            static const uint32_t p1_levels = getenv("FHIP_PRUNE1_LEVELS") ? (uint32_t)atoi(getenv("FHIP_PRUNE1_LEVELS")) : 1u;  // level 0 only: 8 parents, 6363-op tape (measured)
-            const bool exp = R.prune1 && (uint32_t)level < std::min(R.S.pre_levels, p1_levels);
+            const bool exp = R.prune1 && (uint32_t)level < R.exp_levels;      // level 0 only: 8 parents, 6363-op tape (measured)
             struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
             ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
             ka.skip_regs = ka.skip_choices = 0;
@@ -1089,11 +1101,14 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     // (last level: fewer waves, several parents each - one leaf reservation per wave)
     static const int push_mul = getenv("FHIP_PUSH_WAVES") ? atoi(getenv("FHIP_PUSH_WAVES")) : 2;
     const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
-    launch(ctx, FHIP_K_TILES, [&] { hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level); });
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+        else hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+    });
 }
 
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
-    if (is3d && R.split) return launch_tiles_split(ctx, R, dS, level);
+    if (R.split) return launch_tiles_split(ctx, R, dS, level, is3d);
     const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(true, false, true, gb, R.lds_tiles_big); }
@@ -1124,7 +1139,8 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
     memcpy(P.mat, m4, sizeof(m4));
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height));
+                                                     : (getenv("FHIP_VM_TILES") ? trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height))
+                                                                                : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height)));
     st = prepare(ctx, tape, false, ts, PartSpec{}, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;

@@ -27,19 +27,27 @@ def same_bits_f32(a, b):
                                        ("prospero.vm", 100), ("colonnade.vm", 200),
                                        ("prospero.vm", 4096)])   # 4096: BASELINE.json configuration 2 at full size
 def test_render2d_bit_exact(name, size):
+    """the HIP shape's own 2D hint (128 / 16, fidget-jit's: 64 children per parent, the split tile stage with the assembly
+    kernels) and the VM shape's (128 / 32 / 8: 16 children, the one-kernel tile stage), each against the oracle with the same
+    tile sizes - fills carry the level they were decided at"""
     p, o = both(name)
-    a = F.render2d(p, size)[0]
-    b = O.render2d(o, size)[0]
-    assert a.shape == b.shape
-    assert same_bits_f32(a, b), f"{(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
-    assert (F.pixel_fill_depth(a) == O.pixel_fill_depth(b)).all()
+    for ts in (None, F.VM_TILES_2D):
+        a = F.render2d(p, size, tile_sizes=ts)[0]
+        b = O.render2d(o, size, tile_sizes=ts or F.HIP_TILES_2D)[0]
+        assert a.shape == b.shape
+        assert same_bits_f32(a, b), f"{ts}: {(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
+        assert (F.pixel_fill_depth(a) == O.pixel_fill_depth(b)).all()
 
 
 def test_render2d_pixel_perfect_and_rect():
     p, o = both("prospero.vm")
-    a = F.render2d(p, 192, 128, pixel_perfect=True)[0]
-    b = O.render2d(o, 192, 128, pixel_perfect=True)[0]
-    assert same_bits_f32(a, b)
+    for ts in (None, F.VM_TILES_2D):
+        a = F.render2d(p, 192, 128, pixel_perfect=True, tile_sizes=ts)[0]
+        b = O.render2d(o, 192, 128, pixel_perfect=True, tile_sizes=ts or F.HIP_TILES_2D)[0]
+        assert same_bits_f32(a, b)
+        a = F.render2d(p, 200, 136, tile_sizes=ts)[0]
+        b = O.render2d(o, 200, 136, tile_sizes=ts or F.HIP_TILES_2D)[0]
+        assert same_bits_f32(a, b)
 
 
 @pytest.mark.parametrize("name,size", [("prospero.vm", 128), ("prospero.vm", 256), ("colonnade.vm", 128), ("colonnade.vm", 256),

@@ -118,5 +118,5 @@ def test_random_shapes_2d(seed, oracle_mod):
     import fidget_amd as F
     O = oracle_mod
     a = F.render2d(F.Shape(*_shape(F, seed)), 256, z=0.1)[0]
-    b = O.render2d(O.Shape(*_shape(O, seed)), 256, z=0.1)[0]
+    b = O.render2d(O.Shape(*_shape(O, seed)), 256, z=0.1, tile_sizes=F.HIP_TILES_2D)[0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all(), f"{(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
