@@ -1103,7 +1103,11 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
-        else hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+        else {
+            hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+            const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);
+            hipLaunchKernelGGL(k_tfill2d, dim3(64, slots_max), dim3(256), 0, ctx->stream, dS, level);
+        }
     });
 }
 

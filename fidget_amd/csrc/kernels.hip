@@ -856,8 +856,8 @@ FH_DEV void tpush_body(FhRenderState* S, int level) {
         const bool full = act && fills && hi < 0.0f, empty = act && fills && !full && lo > 0.0f;  // voxel.rs:310-320
         const bool amb = act && !full && !empty;
         const uint64_t fullm = ballot(full);
-        uint64_t fm = fullm | (IS3D ? 0ull : ballot(empty));
-        while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317); 2D: full and empty tiles, their level in the fill
+        uint64_t fm = IS3D ? fullm : 0ull;      // (2D: k_tfill2d, one workgroup per decided tile - the root level's 128 x 128 fills by 16 waves took 1.9 ms)
+        while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317)
             const int c = __builtin_ctzll(fm);
             fm &= fm - 1;
             const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
@@ -925,6 +925,26 @@ FH_DEV void tpush_body(FhRenderState* S, int level) {
 }
 __global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) { tpush_body<true>(S, level); }
 __global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level); }
+// 2D fills (pixel.rs:345-368, 225-229): a tile whose interval is decided becomes a NaN-boxed fill carrying the level it was
+// decided at and whether it is inside.  grid (64 children, slots of the level's upper bound), one workgroup per tile.
+__global__ void __launch_bounds__(256) k_tfill2d(FhRenderState* S, int level) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    if (P.pixel_perfect) return;
+    const uint32_t c = blockIdx.x, si = blockIdx.y;
+    const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    if (si >= n0 + n1) return;
+    const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
+    if (((sl.act >> c) & 1) == 0) return;
+    const float lo = sl.res[0][c], hi = sl.res[1][c];
+    const bool full = hi < 0.0f, empty = !full && lo > 0.0f;
+    if (!full && !empty) return;
+    const uint32_t T = P.tiles[level], cx = sl.corner[0][c], cy = sl.corner[1][c];
+    const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (full ? 1u : 0u) | (0xF6u << 9));
+    for (uint32_t p = threadIdx.x; p < T * T; p += blockDim.x) {
+        const uint32_t x = cx + (p % T), y = cy + (p / T);
+        if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;
+    }
+}
 
 // ======================================================================================
 // Point evaluation with a VGPR register file: NR registers x ZB values per lane.
