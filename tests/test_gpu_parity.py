@@ -239,3 +239,42 @@ def test_render3d_frames_in_flight():
         assert ((an == b["normal"]) | (np.isnan(an) & np.isnan(b["normal"]))).all(), f"frame {i} ({m} {n}): normals differ"
     b = O.render3d(oshape["tanglecube.vm"], 64)[0]
     assert (mid["depth"] == b["depth"]).all() and same_bits_f32(mid["normal"], b["normal"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_regs,size", [("colonnade.vm", 255, 256), ("colonnade.vm", 6, 128), ("prospero.vm", 24, 256)])
+def test_render_from_reference_bytecode(name, n_regs, size):
+    """The words a Rust `fidget-hip` shim hands over (fidget_bytecode::Bytecode of a VmData<N>; N < 255 gives tapes with Mem
+    load / store ops, which the import folds back into SSA form) rendered on the device: same image as the oracle's, 2D and 3D."""
+    o = O.Shape.from_vm(model_path(name), n_regs=n_regs)
+    words, regs, mem = o.bytecode()
+    p = F.Shape.from_bytecode(words, axis_slots=[o.axis_index(a) for a in range(3)])
+    a, b = F.render3d(p, size)[0], O.render3d(o, size)[0]
+    assert (a["depth"] == b["depth"]).all() and same_bits_f32(a["normal"], b["normal"])
+    a, b = F.render2d(p, size)[0], O.render2d(o, size, tile_sizes=F.HIP_TILES_2D)[0]
+    assert same_bits_f32(a, b)
+
+
+@pytest.mark.gpu
+def test_render3d_bound_variables():
+    """Var::V inputs bound at render time (ShapeVars, shape/mod.rs:372-400) through the whole 3D device path - tile stage,
+    assembly leaf kernel, normals: a blend of two shapes steered by two variables, several bindings, rotated camera."""
+    def build(be):
+        ctx = be.Context()
+        x, y, z = ctx.x(), ctx.y(), ctx.z()
+        r, k = ctx.var(7), ctx.var(0x1234)
+        sphere = ctx.sub(ctx.sqrt(ctx.add(ctx.add(ctx.square(x), ctx.square(y)), ctx.square(z))), r)
+        box = ctx.max(ctx.max(ctx.sub(ctx.abs(x), 0.6), ctx.sub(ctx.abs(y), k)), ctx.sub(ctx.abs(z), 0.4))
+        return be.Shape(ctx, ctx.min(sphere, ctx.add(box, ctx.mul(k, 0.1))))
+    p, o = build(F), build(O)
+    cam = bench_camera(0.2)
+    for vars in ({7: 0.5, 0x1234: 0.3}, {7: 0.8, 0x1234: 0.7}, {7: 0.1, 0x1234: 0.05}):
+        for w2m in (None, cam):
+            a = F.render3d(p, 192, world_to_model=w2m, vars=vars)[0]
+            b = O.render3d(o, 192, world_to_model=w2m, vars=vars)[0]
+            assert b["depth"].max() > 0
+            assert (a["depth"] == b["depth"]).all(), f"{vars}: {(a['depth'] != b['depth']).sum()} depths differ"
+            same = (a["normal"] == b["normal"]) | (np.isnan(a["normal"]) & np.isnan(b["normal"]))
+            assert same.all(), f"{vars}: {(~same).any(axis=2).sum()} normals differ"
+    with pytest.raises(ValueError):
+        F.render3d(p, 64, vars={7: 0.5})        # MissingVar, as the reference (shape/mod.rs:388-396)

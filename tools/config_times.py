@@ -47,14 +47,18 @@ try:
     res["colonnade.vm 3D 1024^3, identity ms"] = t3("colonnade.vm", 1024)
 except Exception as e:
     res["bench camera"] = repr(e)
-# C5 (mesh): the evaluation side of Octree::build for gyroid-sphere (leaf sampling; no dual walk on the device yet)
-for depth in (6, 7, 8):
-    shape = F.Shape.from_vm(os.path.join(ROOT, "models", "gyroid-sphere.vm"), hip=hip)
-    F.mesh_sample(shape, 4)
+# C5 (mesh): Octree::build + walk_dual of gyroid-sphere (device: cell recursion, leaf sampling, QEF; host threads: octree assembly with
+# cell collapse, dual walk).  Depth 10 = BASELINE.json's 1024^3; the second depth-10 call finds the pinned landing area of the leaf
+# records already there
+shape = F.Shape.from_vm(os.path.join(ROOT, "models", "gyroid-sphere.vm"), hip=hip)
+F.mesh(shape, 4)
+for tag, depth in (("", 8), ("", 9), (" (first call)", 10), (" (second call)", 10)):
     t0 = time.perf_counter()
-    leaves, counts = F.mesh_sample(shape, depth)
-    dt = (time.perf_counter() - t0) * 1e3
-    res[f"C5 gyroid-sphere.vm octree depth {depth} ({2 ** depth}^3): cells / leaf cells / ms (incl. {leaves.nbytes >> 20} MiB of leaf records to the host)"] = [counts["cells"], counts["leaf_cells"], dt]
+    tris, verts, counts = F.mesh(shape, depth)
+    dt = time.perf_counter() - t0
+    res[f"C5 gyroid-sphere.vm mesh, octree depth {depth} ({2 ** depth}^3){tag}: s / triangles / vertices / cells evaluated / leaf cells"] = [
+        dt, len(tris), len(verts), counts["cells"], counts["leaf_cells"]]
+    del tris, verts
 print(json.dumps(res, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "other_configs.json"), "w"), indent=1)
