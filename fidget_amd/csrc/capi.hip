@@ -99,6 +99,7 @@ struct fhip_ctx : FrameBufs {
     FrameBufs other;                // the set of the frame before (or after) the current one
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
+    hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
     hipEvent_t ev_pre = nullptr;
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
@@ -200,6 +201,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+    if (getenv("FHIP_LEAF_STREAMS") && atoi(getenv("FHIP_LEAF_STREAMS")) == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
     if (const char* e = getenv("FHIP_NO_FRAME_PIPELINE")) c->frame_pipeline = atoi(e) == 0;
@@ -237,6 +239,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     c->release_all();
     c->other.release_all();
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
+    if (c->stream_leaf2) { (void)hipStreamSynchronize(c->stream_leaf2); (void)hipStreamDestroy(c->stream_leaf2); }
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
@@ -1272,8 +1275,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         if (pipe) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], side_stream));
             ctx->stream = main_stream;
-            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_tiles[idx], 0));
         }
+        // (diagnostics, FHIP_LEAF_STREAMS=2: leaf kernels of consecutive slabs on two streams, so that the tail of one overlaps
+        // the head of the next - any interleaving gives the same image - at the price of lanes that no longer see the hits in front)
+        static const bool tail1 = !getenv("FHIP_TAIL_STREAM") || atoi(getenv("FHIP_TAIL_STREAM")) == 1;
+        hipStream_t const leaf_stream = (pipe && tail1 && R.asm_points && ctx->stream3 && ctx->stream_leaf2 && (idx & 1)) ? ctx->stream_leaf2 : main_stream;
+        if (pipe) HIP_TRY(ctx, hipStreamWaitEvent(leaf_stream, ctx->ev_tiles[idx], 0));
         // The leaf kernel is the slab's critical chain.  What surrounds it - the footprint lists (needed by the normals and the
         // LDS-class leaves only), those leaves (any order with the others: atomic-max z-buffer) and the normals of the slab's
         // hits - are small launches that leave the machine mostly idle, so in the pipelined frame they run on a third stream
@@ -1317,10 +1324,10 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
                 struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
-                if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka));
+                if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
                 else {
                     static const uint32_t blk = 1u << (getenv("FHIP_COL_BLKL") ? atoi(getenv("FHIP_COL_BLKL")) : 2);   // footprints per workgroup: gen_interp.py BLKL
-                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16));
+                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16), leaf_stream);
                 }
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
@@ -1331,7 +1338,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             }
         });
         if (tail) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], main_stream));          // the slab's leaf kernel is through
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], leaf_stream));          // the slab's leaf kernel is through
             ctx->stream = ctx->stream3;
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_aux[idx], 0));
             normals_work();

@@ -116,7 +116,9 @@ typedef struct fhip_render2d_config {
     const float* world_to_model;   /* row-major 3x3, NULL = identity */
     float z;
     int pixel_perfect;
-    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_2d() of the VM: {128,32,8} */
+    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_2d() of the HIP shape: {128,16}, as fidget-jit (fidget-jit/src/lib.rs:984-986):
+                                    * 64 children per parent.  Fills carry the level they were decided at (pixel.rs:225-229), so images
+                                    * compare bit for bit with the reference rendered with the same tile sizes */
     uint32_t n_tile_sizes;
     const uint64_t* var_keys;      /* ShapeVars<f32>: Var::V index -> value */
     const float* var_values;
@@ -142,7 +144,10 @@ typedef struct fhip_render3d_config {
 fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
                           int out_is_device);
 /* fidget_raster::voxel::render (voxel.rs:500-553).  out: width*height GeometryPixel
- * {f32 normal[3]; u32 depth} (voxel.rs:122-134). */
+ * {f32 normal[3]; u32 depth} (voxel.rs:122-134).
+ * Asynchronous renders (out_is_device) of one context are pipelined across frames: the context keeps two sets of device
+ * buffers, and the coarse tile levels of a frame run on an internal stream beside the slabs of the frame before it.  For the
+ * caller nothing changes: `out` is written on the context's stream, in call order; fhip_ctx_sync waits for every frame. */
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                           int out_is_device);
 /* Multi-GPU 3D, partition A: render only the root-tile columns whose index (x-major, lib.rs:116-123) satisfies
@@ -194,7 +199,10 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
 /* fidget_mesh::Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225; Settings: depth, world_to_model): fhip_mesh_sample, then
  * the octree assembled from the device's results - cell collapse (check_done / try_collapse, octree.rs:256-385) with the merged
- * Hermite data included - and the dual walk (dc.rs) on the host -> Mesh { vertices, triangles } (lib.rs:64-69). */
+ * Hermite data included - and the dual walk (dc.rs) on the host -> Mesh { vertices, triangles } (lib.rs:64-69).  Both host steps
+ * run on the host's threads (independent subtrees, as build_inner_mt octree.rs:94-210; independent sub-walks) and give the cells,
+ * vertices and triangles of the single-threaded recursion, in its order (FHIP_MESH_THREADS, default: all cores up to 128).  The
+ * leaf records are not kept with the mesh (fhip_mesh_leaves after a build copies nothing). */
 fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
 void fhip_mesh_vertices(const fhip_mesh* mesh, float* out);        /* counts[6] x 3 floats */
