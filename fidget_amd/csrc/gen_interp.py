@@ -95,6 +95,8 @@ S_SAVE = "s[88:89]"
 S_M = [f"s[{90 + 2 * j}:{91 + 2 * j}]" for j in range(4)]   # per-slot lane masks s[90:97]
 S_K = "s98"
 S_ZL = "s99"
+S_INV = "s99"            # columns: the leaf's tape reads no input that changes along a pixel column (S_ZL is dead by then)
+S_DEPMASK = "s39"        # columns: input slots that change along a pixel column
 S_HB = "s[100:101]"       # columns: handler table of the leaf's register class
 S_PROJFLAG = "s101"       # columns: bit 16 = projective screen-to-model matrix (row 3 != 0 0 0 1); (low half: workgroup id y)
 S_SLOTX, S_SLOTY, S_SLOTZ, S_RC = "s0", "s1", "s3", "s2"   # columns: input slots of x, y, z; regs | choices << 16
@@ -869,6 +871,37 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_or_b32 {S_WGY}, {S_WGY}, {S_T0}
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
 	s_mov_b32 {S_L}, {S_LAYERS}
+	; Input slots whose value changes along a pixel column: the axis' matrix row has a z coefficient (or the matrix is
+	; projective: w changes with z).  A leaf tape that reads none of them has ONE value per pixel for its 8 voxels, and
+	; is evaluated once per pixel (below) - a vertical wall, an extrusion, whatever pruning left independent of z.
+	s_mov_b32 {S_DEPMASK}, 0
+	s_and_b32 {S_T0}, s{m + 2}, 0x7fffffff
+	s_cmp_lg_u32 {S_T0}, 0
+	s_cselect_b32 {S_T0}, 1, 0
+	s_bitcmp1_b32 {S_WGY}, 16
+	s_cselect_b32 {S_T0}, 1, {S_T0}
+	s_cmp_lt_i32 {S_SLOTX}, 0
+	s_cselect_b32 {S_T0}, 0, {S_T0}
+	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTX}
+	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
+	s_and_b32 {S_T0}, s{m + 6}, 0x7fffffff
+	s_cmp_lg_u32 {S_T0}, 0
+	s_cselect_b32 {S_T0}, 1, 0
+	s_bitcmp1_b32 {S_WGY}, 16
+	s_cselect_b32 {S_T0}, 1, {S_T0}
+	s_cmp_lt_i32 {S_SLOTY}, 0
+	s_cselect_b32 {S_T0}, 0, {S_T0}
+	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTY}
+	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
+	s_and_b32 {S_T0}, s{m + 10}, 0x7fffffff
+	s_cmp_lg_u32 {S_T0}, 0
+	s_cselect_b32 {S_T0}, 1, 0
+	s_bitcmp1_b32 {S_WGY}, 16
+	s_cselect_b32 {S_T0}, 1, {S_T0}
+	s_cmp_lt_i32 {S_SLOTZ}, 0
+	s_cselect_b32 {S_T0}, 0, {S_T0}
+	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTZ}
+	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
 	; footprints per layer, blocks of {BLK} of them
 	s_add_u32 {S_T0}, {S_WIDTH}, 7
 	s_lshr_b32 {S_T0}, {S_T0}, 3
@@ -1018,7 +1051,26 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 {S_PEND}, vcc
 	s_cmp_eq_u64 {S_PEND}, 0
 	s_cbranch_scc1 .Lfh_columns_leaf_drain
-	s_mov_b32 {S_K}, 7""")
+	s_mov_b32 {S_K}, 7
+	; does the tape read an input that changes along the column?  (tapes of up to 64 ops: the words are in v[60:61], lane = op)
+	s_mov_b32 {S_INV}, 0
+	s_cmp_gt_u32 {S_LEN0}, 64
+	s_cbranch_scc1 .Lfh_columns_zdep
+	v_and_b32 v18, 0xff, v60
+	v_lshrrev_b32_e64 v19, v61, {S_DEPMASK}
+	v_and_b32 v19, 1, v19
+	v_cmp_eq_u32 vcc, {OPS.index("INPUT")}, v18
+	v_cmp_eq_u32_e64 {S_M[1]}, 1, v19
+	s_sub_u32 {S_T0}, 64, {S_LEN0}
+	s_lshr_b64 {S_M[2]}, -1, {S_T0}
+	s_nop 1
+	s_and_b64 {S_M[1]}, {S_M[1]}, vcc
+	s_and_b64 {S_M[1]}, {S_M[1]}, {S_M[2]}
+	s_cmp_eq_u64 {S_M[1]}, 0
+	s_cbranch_scc0 .Lfh_columns_zdep
+	s_mov_b32 {S_INV}, 1                          ; one pass of the two-sample class, its first sample is the column's value
+	s_branch .L{its[-1].name}_chunk
+.Lfh_columns_zdep:""")
     for it in its[:-1]:
         a(f"\ts_cmp_le_u32 {S_RC}, {it.nr}\n\ts_cbranch_scc1 .L{it.name}_chunk")
     a(f"\ts_branch .L{its[-1].name}_chunk")
@@ -1087,6 +1139,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
         if zb < 8:
             a(f"""
 	s_cmp_eq_u64 {S_PEND}, 0
+	s_cbranch_scc1 .Lfh_columns_leaf_done
+	s_cmp_lg_u32 {S_INV}, 0
 	s_cbranch_scc1 .Lfh_columns_leaf_done
 	s_sub_u32 {S_K}, {S_K}, {zb}
 	s_cbranch_scc0 .L{name}_pass

@@ -134,3 +134,44 @@ def test_transcendental_leaf_kernel(kind):
     a, _ = run_columns(tape2, sh2.slot_count(), ik2, ROTATED, (0, 8, 0))
     b, _ = run_columns(tape2, sh2.slot_count(), ik2, ROTATED, (0, 8, 0), kernel="fh_columns_t")
     assert (a == b).all()
+
+
+def column_shape(kind):
+    """kind 0: a function of x and y only (an extrusion); 1: the same plus a z term"""
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    n = c.sub(c.sqrt(c.add(c.square(c.sub(x, 0.2)), c.square(c.mul(y, 1.3)))), 0.55)
+    n = c.max(n, c.sub(0.25, c.abs(c.add(x, c.mul(y, 0.5)))))
+    n = c.min(n, c.sub(c.abs(c.sub(y, 0.4)), 0.1))
+    if kind == 1:
+        n = c.max(n, c.sub(c.abs(z), 0.6))
+    sh = F.Shape(c, n)
+    ik = [3] * 16
+    for a in range(3):
+        s = sh.axis_index(a)
+        if s >= 0:
+            ik[s] = a
+    return sh, U.shape_tape(sh), ik
+
+
+@pytest.mark.parametrize("mat", [AFFINE, ROTATED, PERSPECTIVE], ids=["affine", "rotated", "perspective"])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_column_invariant_leaves(kind, mat):
+    """A leaf tape that reads no input varying along the pixel column (no z under an axis-aligned camera) is evaluated once
+    per pixel instead of once per voxel; with a rotated or projective camera x and y vary with z and it is not.  Same words
+    either way, and the short cut really is taken (fewer instructions) exactly when it applies."""
+    sh, tape, ik = column_shape(kind)
+    counts = {}
+    for leaf in ((0, 8, 0), (8, 0, 8), (8, 8, 0)):
+        z = np.zeros(256, np.uint64)
+        z[5::7] = np.uint64((3 << 32) | 9)        # some pixels already hit further back: still pending
+        got, waves = run_columns(tape, sh.slot_count(), ik, mat, leaf, zbuf_init=z)
+        want = expect(tape, ik, mat, leaf, 16, z)
+        assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+        counts[leaf] = sum(w.counts.get("valu", 0) for w in waves)
+    if kind == 0:       # vector instructions of the same leaf under the axis-aligned camera (short cut) and the rotated one (none)
+        _, wa = run_columns(tape, sh.slot_count(), ik, AFFINE, (0, 8, 0))
+        _, wr = run_columns(tape, sh.slot_count(), ik, ROTATED, (0, 8, 0))
+        va, vr = (sum(w.counts.get("valu", 0) for w in ws) for ws in (wa, wr))
+        assert va < 0.6 * vr, (va, vr)
