@@ -1263,6 +1263,11 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
                               ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !getenv("FHIP_OLD_PYR");
             const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
+            if (rebuild && pyr3 && pre == 2 && !getenv("FHIP_NO_SLAB_BEGIN")) {
+                const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
+                hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
+                return;
+            }
             hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
                                (pyr3 && rebuild) ? 1u : 0u);
             if (rebuild && pyr3) {

@@ -748,9 +748,8 @@ __global__ void __launch_bounds__(WAVE) k_tscatter3d(FhRenderState* S, uint32_t 
 // Step 2 in C++ (reference implementation of fh_tiles; used for tapes outside the assembly
 // opcode set): forward interval pass, then one reverse prune sweep per ambiguous child.
 template <bool FULL, bool BIG>
-__global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
+FH_DEV void teval_slots(FhRenderState* S, int level, char* smem, uint32_t first, uint32_t stride) {
     constexpr int TL = 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t max_regs = BIG ? P.max_regs : SMALL_REGS;
@@ -759,7 +758,7 @@ __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
     uint32_t* chbits = (uint32_t*)(smem + (size_t)max_regs * TL * sizeof(IV));
     uint8_t* map = (uint8_t*)(chbits + (size_t)((max_choices + 15) / 16) * TL);
     const uint32_t n_slots = S->n_slots[BIG ? 1 : 0][level];
-    for (uint32_t si = blockIdx.x; si < n_slots; si += gridDim.x) {
+    for (uint32_t si = first; si < n_slots; si += stride) {
         FhSlot& sl = S->slots[BIG ? 1 : 0][si];
         if (uni((uint32_t)(sl.act != 0)) == 0) continue;
         const uint32_t off = uni(sl.tape.off), len = uni(sl.tape.len);
@@ -820,10 +819,15 @@ __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
         sl.c_off[lane] = coff; sl.c_len[lane] = clen; sl.c_rc[lane] = cregs | (cch << 16);
     }
 }
+template <bool FULL, bool BIG>
+__global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    teval_slots<FULL, BIG>(S, level, smem, blockIdx.x, gridDim.x);
+}
 
 // Step 3: fills of the decided children, queue / leaf entries for the ambiguous ones
 template <bool IS3D>
-FH_DEV void tpush_body(FhRenderState* S, int level) {
+FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t stride) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
@@ -836,7 +840,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level) {
     uint32_t leaf_base = 0;
     if (last_level) {
         uint32_t mine = 0;
-        for (uint32_t si = blockIdx.x; si < n0 + n1; si += gridDim.x) {
+        for (uint32_t si = first; si < n0 + n1; si += stride) {
             const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
             const uint64_t actm = sl.act;
             if (uni((uint32_t)(actm != 0)) == 0) continue;
@@ -846,7 +850,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level) {
         if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
         leaf_base = uni(leaf_base);
     }
-    for (uint32_t si = blockIdx.x; si < n0 + n1; si += gridDim.x) {
+    for (uint32_t si = first; si < n0 + n1; si += stride) {
         const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
         if (uni((uint32_t)(sl.act != 0)) == 0) continue;
         const bool act = (sl.act >> lane) & 1;
@@ -923,8 +927,8 @@ FH_DEV void tpush_body(FhRenderState* S, int level) {
         }
     }
 }
-__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) { tpush_body<true>(S, level); }
-__global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level); }
+__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) { tpush_body<true>(S, level, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level, blockIdx.x, gridDim.x); }
 // 2D fills (pixel.rs:345-368, 225-229): a tile whose interval is decided becomes a NaN-boxed fill carrying the level it was
 // decided at and whether it is inside.  grid (64 children, slots of the level's upper bound), one workgroup per tile.
 __global__ void __launch_bounds__(256) k_tfill2d(FhRenderState* S, int level) {
@@ -1222,9 +1226,8 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
 }
 
 // Per-slab reset of the work queues, leaf table and tape arena (frame-persistent tapes stay)
-__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t k = i; k < table_words; k += gridDim.x * blockDim.x) S->leaf_table[k] = 0;
+FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
+    for (uint32_t k = i; k < table_words; k += stride) S->leaf_table[k] = 0;
     const uint32_t P0 = S->pre_levels;
     if (i == 0) {
         for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) {
@@ -1248,8 +1251,11 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
     // the coarse levels of the min-depth pyramid are rebuilt by k_minpyramid (not for the first slab: empty image)
     if (reset_root_mind) {
         const uint32_t T = S->P.tiles[0], n = ((S->P.width + T - 1) / T) * ((S->P.height + T - 1) / T);
-        for (uint32_t k = i; k < n; k += gridDim.x * blockDim.x) S->mind[0][k] = 0xFFFFFFFFu;
+        for (uint32_t k = i; k < n; k += stride) S->mind[0][k] = 0xFFFFFFFFu;
     }
+}
+__global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
+    reset_slab_body(S, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, table_words, slab, n_root_groups, reset_root_mind);
 }
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
@@ -1307,7 +1313,8 @@ __global__ void __launch_bounds__(256) k_minpyramid(FhRenderState* S) {
 // block per tile of the middle level, one wave per leaf tile in it, lane = pixel (coalesced rows); the
 // root level, reset to ~0 by k_reset_slab, takes 16 atomics per word.  (The kernel above, one thread
 // walking each leaf tile, took 30 us of every slab's tile chain.)
-__global__ void __launch_bounds__(256) k_minpyramid3(FhRenderState* S) {
+template <bool ROOT>
+FH_DEV void minpyramid3_body(FhRenderState* S, uint32_t block) {
     // one block of four waves per middle-level tile, four leaf tiles per wave (a block of 16 waves finds no room on a CU
     // while the leaf kernel of the slab in front keeps the machine full: 166 us instead of 10)
     __shared__ uint32_t part[4];
@@ -1315,7 +1322,7 @@ __global__ void __launch_bounds__(256) k_minpyramid3(FhRenderState* S) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t T2 = P.tiles[2], T1 = P.tiles[1], T0 = P.tiles[0];
     const uint32_t n1x = (P.width + T1 - 1) / T1, n2x = (P.width + T2 - 1) / T2, n0x = (P.width + T0 - 1) / T0;
-    const uint32_t bx = blockIdx.x % n1x, by = blockIdx.x / n1x;
+    const uint32_t bx = block % n1x, by = block / n1x;
     const uint32_t ty = by * 4 + w, y = ty * T2 + (lane >> 3);
     uint32_t v[4];
 #pragma unroll
@@ -1338,8 +1345,17 @@ __global__ void __launch_bounds__(256) k_minpyramid3(FhRenderState* S) {
     if (threadIdx.x == 0) {
         const uint32_t m = min(min(part[0], part[1]), min(part[2], part[3]));
         S->mind[1][by * n1x + bx] = m;
-        atomicMin(&S->mind[0][(by * T1 / T0) * n0x + bx * T1 / T0], m);
+        if (ROOT) atomicMin(&S->mind[0][(by * T1 / T0) * n0x + bx * T1 / T0], m);
     }
+}
+__global__ void __launch_bounds__(256) k_minpyramid3(FhRenderState* S) { minpyramid3_body<true>(S, blockIdx.x); }
+// Start of a slab's tile chain in one launch (every kernel boundary on that chain costs ~10 us beside a full machine): the
+// first n1 blocks rebuild the two fine levels of the min-depth pyramid, the others reset the slab's queues and leaf table.
+// For the 128 / 32 / 8 pyramid with two pre-pass levels: the per-slab level only reads pyramid levels 1 and 2, so the root
+// level (which the reset would have to clear before the rebuild's atomic minima) is left alone.
+__global__ void __launch_bounds__(256) k_slab_begin3(FhRenderState* S, uint32_t n1, uint32_t table_words, uint32_t slab, uint32_t n_root_groups) {
+    if (blockIdx.x < n1) { minpyramid3_body<false>(S, blockIdx.x); return; }
+    reset_slab_body(S, (blockIdx.x - n1) * blockDim.x + threadIdx.x, (gridDim.x - n1) * blockDim.x, table_words, slab, n_root_groups, 0);
 }
 
 // Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
