@@ -816,8 +816,9 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     const size_t extra = ctx->slab_contexts - 1;
     if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(extra * leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
-        HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * 4));
-        HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * 4));
+        if (P.width > 65535 || P.height > 65535) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images up to 65535 x 65535");
+        HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * sizeof(FhLeafRef)));
+        HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * sizeof(FhLeafRef)));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
         HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
         HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
@@ -913,7 +914,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     S.leaves = (FhLeaf*)ctx->leaves.p;
     S.leaf_cap = (uint32_t)leaf_cap;
     S.n_leaves = S.leaf_cursor = S.leaf_cursor_big = S.normal_cursor = S.normal_cursor_big = 0;
-    S.leaf_table = (uint32_t*)ctx->leaf_table.p;
+    S.leaf_table = (FhLeafRef*)ctx->leaf_table.p;
     for (int c = 0; c < 3; c++) S.fp_count[c] = S.fp_cursor[c] = 0;
     S.zbuf = (uint64_t*)ctx->zbuf.p;
     S.normals = (float*)ctx->normals.p;
@@ -1218,7 +1219,9 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
     st = upload_frame(ctx, tape, R);
     if (st) return st;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, 0, npix * 8, ctx->stream));
+    // (FHIP_DEBUG_ZFILL, diagnostics: every pixel already at the far depth - the front slab's leaf kernel then finds all its
+    // leaves but nothing pending, which times its per-workgroup and per-leaf set-up without the interpretation)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, getenv("FHIP_DEBUG_ZFILL") ? 0xFF : 0, npix * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
     const uint32_t n_groups = R.groups_per_slab;
     const uint32_t pre = R.S.pre_levels;
@@ -1239,7 +1242,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     ctx->forked = pipe ? NC : 0;
     if (pipe) {
         hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
-                           (uint32_t*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
+                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
@@ -1327,7 +1330,23 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
                 // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
-                struct { FhRenderState* S; uint32_t n_waves, pad; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0};
+                // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
+                // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0, 0, 0, {0, 0}};
+                {
+                    uint32_t u[16];
+                    memcpy(u, P.mat, sizeof(u));
+                    const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
+                    int slot[3] = {-1, -1, -1};
+                    for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis, as the kernel's scan took it)
+                    ka.slots = 0;
+                    for (int ax = 0; ax < 3; ax++) {
+                        ka.slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
+                        const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
+                        if (dep && slot[ax] >= 0) ka.depmask |= 1u << slot[ax];
+                    }
+                    ka.flags = proj ? 0x10000u : 0u;
+                }
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
                 else {

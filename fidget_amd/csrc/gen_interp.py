@@ -62,7 +62,8 @@ S_LAYERS, S_FW = "s26", "s27"
 S_SIGN = "s28"          # 0x80000000
 S_ABSM = "s29"          # 0x7fffffff
 S_ARENA = "s[30:31]"
-S_LEAVES = "s[32:33]"
+S_NXTV = "s32"           # columns: the next leaf's tape is on its way into V_NXT
+S_SLABZ = "s26"          # columns: z of the slab's first voxel (S_LAYERS is dead after the prologue)
 S_TABLE = "s[34:35]"
 S_ZBUF = "s[36:37]"
 S_FPLIST = "s[38:39]"
@@ -110,7 +111,7 @@ V_LANE = "v0"
 V_PXF, V_PYF = "v1", "v6"
 V_PIX = "v[2:3]"
 V_HIT, V_DEPTH = "v4", "v5"     # stored together as the 64-bit z-buffer word
-V_IDS = "v7"
+V_IDS = "v54"            # (= V_ENT[0])
 V_AX, V_AY, V_AZ = "v8", "v9", "v59"
 VRES = [f"v{10 + j}" for j in range(8)]
 VT = [f"v{18 + j}" for j in range(8)]
@@ -119,10 +120,12 @@ VW = [f"v{34 + j}" for j in range(8)]
 VD = [f"v{42 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
 V_QNAN = "v50"
 V_SQRTC = "v51"
-V_LX, V_LY = "v52", "v53"
-V_S0, V_S1, V_S2, V_S3 = "v54", "v55", "v56", "v57"
+V_NXT = ("v52", "v53")   # columns: the NEXT leaf's tape words, requested while this leaf is interpreted
+V_S0, V_S1, V_S2, V_S3 = "v42", "v43", "v44", "v45"   # set-up temporaries (the division / sqrt scratch: dead between leaves)
+V_S4 = "v46"
+V_ENT = ("v54", "v55", "v56", "v57")   # columns: the block's leaf table entries, lane = footprint: id + 1, tape offset, length | regs << 24, x | y << 16
 V_IDV = "v58"
-V_AW = "v56"             # columns: m[12] * x + m[13] * y of this lane's pixel (V_S2 is free once the pixel address is formed)
+V_AW = "v7"              # columns: m[12] * x + m[13] * y of this lane's pixel
 VOFF = [f"v{60 + j}" for j in range(4)]  # bulk: byte offset of sample j
 V_DEC = ["v60", "v61", "v62", "v63"]   # columns: the leaf's tape decoded, lane = op: handler address, out index, a index, word 1
 FILE = 64
@@ -159,6 +162,7 @@ class Interp:
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
+        self.hl = HSTRIDE_LOG2
         self.next = f".L{name}_next"
         self.ool = []  # out-of-line handler bodies: (label, callable)
 
@@ -211,6 +215,8 @@ class Interp:
             self.a(f"\tv_mov_b32 {dst[j]}, {S_W1}")
 
     def ret(self):
+        # (a copy of the vector dispatcher here instead - one taken jump per op less - was measured: no change in the leaf
+        # kernel's time, which is set by the number of instructions issued per op, not by the jumps' latency)
         self.a(f"\ts_setpc_b64 {S_NEXT}")
 
     def call(self, fn):
@@ -660,14 +666,14 @@ class Interp:
             a(f"""
 	s_mov_b64 {S_CUR}, s[{q}:{q + 1}]
 	{f"s_add_u32 s70, s70, {COPY}" if i < 7 else f"s_sub_u32 s70, s70, {7 * COPY}"}
-	s_lshl_b32 {S_T0}, {S_W0}, {HSTRIDE_LOG2}
+	s_lshl_b32 {S_T0}, {S_W0}, {self.hl}
 	s_lshr_b32 {S_OUT}, {S_W0}, {8 - lg}
 	s_lshr_b32 {S_A}, {S_W0}, {20 - lg}
-	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << HSTRIDE_LOG2)}
+	s_and_b32 {S_T0}, {S_T0}, {hex(0xff << self.hl)}
 	s_and_b32 {S_OUT}, {S_OUT}, {hex(0xfff << lg)}     ; file index = register * ZB
 	s_andn2_b32 {S_A}, {S_A}, {(1 << lg) - 1}
 	s_cmp_eq_u32 {S_OUT}, {S_A}
-	s_cselect_b32 {S_T1}, {hex(64 << HSTRIDE_LOG2)}, 0   ; out == a: the in-place handlers
+	s_cselect_b32 {S_T1}, {hex(64 << self.hl)}, 0   ; out == a: the in-place handlers
 	s_or_b32 {S_T0}, {S_T0}, {S_T1}
 	s_add_u32 s44, s42, {S_T0}
 	s_addc_u32 s45, s43, 0
@@ -699,11 +705,11 @@ class Interp:
 	s_waitcnt lgkmcnt(0)
 	s_set_gpr_idx_off
 	s_setpc_b64 {S_RET}
-	.p2align {HSTRIDE_LOG2}
+	.p2align {self.hl}
 .L{n}_handlers:""")
         for inplace in (False, True):
             for i in range(64):
-                a(f"\t.p2align {HSTRIDE_LOG2}")
+                a(f"\t.p2align {self.hl}")
                 lab = f".L{n}_{'i' if inplace else 'h'}{i}"
                 op = OPS[i] if i < len(OPS) else None
                 a(f"{lab}:  ; {op}{' (in place)' if inplace else ''}")
@@ -715,8 +721,8 @@ class Interp:
                 else:
                     self.handler(op, inplace)
                 # the next .p2align would silently grow the slot: an explicit assertion on its size
-                a(f"\t.if (. - {lab}) > {1 << HSTRIDE_LOG2}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
-        a(f"\t.p2align {HSTRIDE_LOG2}")
+                a(f"\t.if (. - {lab}) > {1 << self.hl}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
+        a(f"\t.p2align {self.hl}")
         for lab, fn in self.ool:
             a(f"{lab}:")
             fn()
@@ -803,7 +809,7 @@ def gen_columns(a, variants, off, trans=None):
     waves gives the same image, and leaves behind a hit usually find it and retire after one load.
     The register-file shape is chosen per leaf (variants = [(NR, ZB)], smallest NR first: 8 registers
     x 8 voxels, 16 x 4, 32 x 2 - all 64 VGPRs): 80 % of prospero's leaves take a single pass.
-    kernarg: { FhRenderState* S; u32 n_waves; u32 pad }"""
+    kernarg: { FhRenderState* S; u32 n_waves; u32 axis slots; u32 inputs varying along a column; u32 flags; u32 pad[2] }"""
     kname = "fh_columns_t" if trans else "fh_columns"
     if trans:   # same generator into a scratch buffer, labels renamed, the routines embedded next to the handlers (s_branch range)
         b = Asm()
@@ -828,10 +834,13 @@ def _gen_columns_body(a, variants, off, kname, trans):
     import os
     BLKL = int(os.environ.get("FH_BLKL", "2"))   # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast); capi.hip FH_COL_BLKL must agree
     BLK = 1 << BLKL
-    kernel_header(a, kname, 16, nvg)
+    # kernarg: { FhRenderState* S; u32 n_waves; u32 axis slots x | y << 8 | z << 16 (0xFF: the tape has no such input);
+    #            u32 inputs that change along a pixel column (bit per input slot); u32 flags (bit 16: projective matrix) }
+    # - per frame constants the host works out once: 65 536 workgroups per launch each spent ~130 scalar instructions on them
+    kernel_header(a, kname, 32, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
-	s_load_dword {S_NWG}, {S_KERNARG}, 0x8
+	s_load_dwordx4 s[48:51], {S_KERNARG}, 0x8
 	s_mov_b32 {S_WGID}, s2
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
@@ -841,67 +850,22 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_load_dwordx2 s[24:25], {S_STATE}, {o['P.width']}
 	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.tiles']}
 	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
-	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
 	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
-	s_load_dwordx16 s[48:63], {S_STATE}, {o['P.in_kind']}
-	v_and_b32 {V_LX}, 7, {V_LANE}
-	v_lshrrev_b32 {V_LY}, 3, {V_LANE}
-	s_mov_b32 {S_SLOTX}, -1
-	s_mov_b32 {S_SLOTY}, -1
-	s_mov_b32 {S_SLOTZ}, -1
-	s_waitcnt lgkmcnt(0)""")
-    for i in range(16):   # input slot of each axis (in_kind: 0 x, 1 y, 2 z, 3 bound constant)
-        a(f"""
-	s_cmp_eq_u32 s{48 + i}, 0
-	s_cselect_b32 {S_SLOTX}, {i}, {S_SLOTX}
-	s_cmp_eq_u32 s{48 + i}, 1
-	s_cselect_b32 {S_SLOTY}, {i}, {S_SLOTY}
-	s_cmp_eq_u32 s{48 + i}, 2
-	s_cselect_b32 {S_SLOTZ}, {i}, {S_SLOTZ}""")
-    a(f"""
-	; projective matrix?  row 3 != (0, 0, 0, 1)
-	s_or_b32 {S_T0}, s{m + 12}, s{m + 13}
-	s_or_b32 {S_T0}, {S_T0}, s{m + 14}
-	s_and_b32 {S_T0}, {S_T0}, 0x7fffffff
-	s_xor_b32 {S_T1}, s{m + 15}, 0x3f800000
-	s_or_b32 {S_T0}, {S_T0}, {S_T1}
-	s_cmp_lg_u32 {S_T0}, 0
-	s_cselect_b32 {S_T0}, 0x10000, 0
-	s_or_b32 {S_WGY}, {S_WGY}, {S_T0}
+	s_mov_b32 {S_NWG}, s48
+	s_bfe_i32 {S_SLOTX}, s49, 0x80000               ; (s0 / s1 held the kernarg pointer until here)
+	s_bfe_i32 {S_SLOTY}, s49, 0x80008
+	s_bfe_i32 {S_SLOTZ}, s49, 0x80010
+	s_mov_b32 {S_DEPMASK}, s50
+	s_and_b32 s51, s51, 0x10000
+	s_or_b32 {S_WGY}, {S_WGY}, s51
+	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
 	s_mov_b32 {S_L}, {S_LAYERS}
-	; Input slots whose value changes along a pixel column: the axis' matrix row has a z coefficient (or the matrix is
-	; projective: w changes with z).  A leaf tape that reads none of them has ONE value per pixel for its 8 voxels, and
-	; is evaluated once per pixel (below) - a vertical wall, an extrusion, whatever pruning left independent of z.
-	s_mov_b32 {S_DEPMASK}, 0
-	s_and_b32 {S_T0}, s{m + 2}, 0x7fffffff
-	s_cmp_lg_u32 {S_T0}, 0
-	s_cselect_b32 {S_T0}, 1, 0
-	s_bitcmp1_b32 {S_WGY}, 16
-	s_cselect_b32 {S_T0}, 1, {S_T0}
-	s_cmp_lt_i32 {S_SLOTX}, 0
-	s_cselect_b32 {S_T0}, 0, {S_T0}
-	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTX}
-	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
-	s_and_b32 {S_T0}, s{m + 6}, 0x7fffffff
-	s_cmp_lg_u32 {S_T0}, 0
-	s_cselect_b32 {S_T0}, 1, 0
-	s_bitcmp1_b32 {S_WGY}, 16
-	s_cselect_b32 {S_T0}, 1, {S_T0}
-	s_cmp_lt_i32 {S_SLOTY}, 0
-	s_cselect_b32 {S_T0}, 0, {S_T0}
-	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTY}
-	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
-	s_and_b32 {S_T0}, s{m + 10}, 0x7fffffff
-	s_cmp_lg_u32 {S_T0}, 0
-	s_cselect_b32 {S_T0}, 1, 0
-	s_bitcmp1_b32 {S_WGY}, 16
-	s_cselect_b32 {S_T0}, 1, {S_T0}
-	s_cmp_lt_i32 {S_SLOTZ}, 0
-	s_cselect_b32 {S_T0}, 0, {S_T0}
-	s_lshl_b32 {S_T0}, {S_T0}, {S_SLOTZ}
-	s_or_b32 {S_DEPMASK}, {S_DEPMASK}, {S_T0}
+	s_load_dword {S_SLABZ}, {S_STATE}, {o['slab_z']}
+	; ({S_DEPMASK}, from the kernarg: the input slots whose value changes along a pixel column - the axis' matrix row has a z
+	; coefficient, or the matrix is projective.  A leaf tape that reads none of them has ONE value per pixel for its 8
+	; voxels and is evaluated once per pixel, below: a vertical wall, an extrusion, whatever pruning left independent of z.)
 	; footprints per layer, blocks of {BLK} of them
 	s_add_u32 {S_T0}, {S_WIDTH}, 7
 	s_lshr_b32 {S_T0}, {S_T0}, 3
@@ -954,49 +918,55 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_and_b64 vcc, vcc, {S_M[0]}
 	s_mul_i32 {S_T1}, {S_L}, {S_NFPL}
 	s_add_u32 {S_T1}, {S_T1}, {S_T0}
-	s_lshl_b32 {S_T1}, {S_T1}, 2
+	s_lshl_b32 {S_T1}, {S_T1}, 4                     ; 16-byte entries (FhLeafRef)
 	s_add_u32 s86, s34, {S_T1}
 	s_addc_u32 s87, s35, 0
-	v_lshlrev_b32 {V_S0}, 2, {V_LANE}
-	v_mov_b32 {V_IDS}, 0
+	v_lshlrev_b32 {V_S0}, 4, {V_LANE}
+	v_mov_b32 {V_ENT[0]}, 0
 	s_and_saveexec_b64 {S_SAVE}, vcc
-	global_load_dword {V_IDS}, {V_S0}, {S_PC}
+	global_load_dwordx4 v[{V_ENT[0][1:]}:{V_ENT[3][1:]}], {V_S0}, {S_PC}
 	s_mov_b64 exec, {S_SAVE}
-	s_waitcnt vmcnt(0)
-	v_cmp_ne_u32 vcc, 0, {V_IDS}
-	s_nop 3
+	s_lshl_b32 {S_LZ}, {S_L}, 3                      ; this layer's z: every leaf of the block has it
+	s_waitcnt vmcnt(0) lgkmcnt(0)
+	s_add_u32 {S_LZ}, {S_LZ}, {S_SLABZ}
+	v_cmp_ne_u32 vcc, 0, {V_ENT[0]}
+	s_mov_b32 {S_NXTV}, 0
+	s_nop 2
 	s_mov_b64 {S_LAYMASK}, vcc
 .Lfh_columns_leaf:
-	; ---- next leaf of the block ---------------------------------------------------------------
+	; ---- next leaf of the block: everything needed to start on it is in the entries (no load before the tape's) --------
 	s_cmp_eq_u64 {S_LAYMASK}, 0
 	s_cbranch_scc1 .Lfh_columns_block
 	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
 	s_nop 0
-	v_readlane_b32 {S_ID}, {V_IDS}, {S_ZL}
-	s_nop 3
-	s_sub_u32 {S_T0}, {S_ID}, 1
-	s_mul_i32 {S_T0}, {S_T0}, 24
-	s_add_u32 s86, s32, {S_T0}
-	s_addc_u32 s87, s33, 0
-	s_load_dwordx4 s[64:67], {S_PC}, 0x0            ; tape offset, length, regs | choices << 16, x
-	s_load_dwordx2 s[68:69], {S_PC}, 0x10           ; y, z
-	s_waitcnt lgkmcnt(0)
-	s_mov_b32 s84, s64
+	v_readlane_b32 {S_ID}, {V_ENT[0]}, {S_ZL}
+	v_readlane_b32 s84, {V_ENT[1]}, {S_ZL}
+	v_readlane_b32 {S_T0}, {V_ENT[2]}, {S_ZL}
+	v_readlane_b32 {S_T1}, {V_ENT[3]}, {S_ZL}
 	s_mov_b32 s85, 0
-	s_mov_b32 {S_LEN0}, s65
-	s_and_b32 {S_RC}, s66, 0xffff
-	s_mov_b32 {S_FX}, s67
-	s_mov_b32 {S_FY}, s68
-	s_mov_b32 {S_LZ}, s69
-	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_leaves3d<2>
+	s_nop 1
+	s_and_b32 {S_LEN0}, {S_T0}, 0xffffff
+	s_lshr_b32 {S_RC}, {S_T0}, 24
+	s_and_b32 {S_FX}, {S_T1}, 0xffff
+	s_lshr_b32 {S_FY}, {S_T1}, 16
+	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_leaves3d<2> (never requested ahead)
 	s_cbranch_scc1 .Lfh_columns_leaf
 	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
 	s_add_u32 s84, s84, s30
 	s_addc_u32 s85, s85, s31
-	; The tape is requested now and arrives while the pass is set up.  Up to 64 ops: one vector load,
-	; lane = op, decoded below by vector code; the scalar unit, which all waves of a CU share and which
-	; bounds this kernel, then only jumps.  Longer tapes (1 % of prospero's leaves) keep the scalar fetch.
+	; The tape: requested while the leaf before this one was interpreted (it is in V_NXT, or about to be), or requested now -
+	; up to 64 ops by one vector load, lane = op, decoded below by vector code (the scalar unit, which all waves of a CU
+	; share, then only jumps); longer tapes (1 % of prospero's leaves) keep the scalar fetch.
+	s_cmp_eq_u32 {S_NXTV}, 0
+	s_cbranch_scc1 .Lfh_columns_request
+	; (in flight: the requested tape and, if the last leaf had hits, its z-buffer atomic - loads and atomics complete in no
+	; particular order with each other, so both are waited for)
+	s_waitcnt vmcnt(0)
+	v_mov_b32 v60, {V_NXT[0]}
+	v_mov_b32 v61, {V_NXT[1]}
+	s_branch .Lfh_columns_taperequested
+.Lfh_columns_request:
 	s_cmp_gt_u32 {S_LEN0}, 64
 	s_cbranch_scc1 .Lfh_columns_longtape
 	v_lshlrev_b32 {V_S3}, 3, {V_LANE}
@@ -1009,8 +979,11 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
 .Lfh_columns_taperequested:
 	; pixel of this lane, its z-buffer word
-	v_add_u32 {V_S0}, {S_FX}, {V_LX}
-	v_add_u32 {V_S1}, {S_FY}, {V_LY}
+	s_mov_b32 {S_NXTV}, 0
+	v_and_b32 {V_S0}, 7, {V_LANE}
+	v_lshrrev_b32 {V_S1}, 3, {V_LANE}
+	v_add_u32 {V_S0}, {S_FX}, {V_S0}
+	v_add_u32 {V_S1}, {S_FY}, {V_S1}
 	v_cvt_f32_u32 {V_PXF}, {V_S0}
 	v_cvt_f32_u32 {V_PYF}, {V_S1}
 	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_S0}
@@ -1029,6 +1002,32 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 exec, {S_M[0]}
 	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
 	s_mov_b64 exec, {S_SAVE}
+	; the next leaf of the block: its tape (if it is one of up to 64 ops for this kernel) is requested now, behind this
+	; leaf's own loads, and arrives while this leaf is interpreted
+	s_cmp_eq_u64 {S_LAYMASK}, 0
+	s_cbranch_scc1 .Lfh_columns_noahead
+	s_ff1_i32_b64 {S_T0}, {S_LAYMASK}
+	s_nop 0
+	v_readlane_b32 {S_T1}, {V_ENT[2]}, {S_T0}
+	v_readlane_b32 s86, {V_ENT[1]}, {S_T0}
+	s_mov_b32 s87, 0
+	s_nop 1
+	s_lshr_b32 {S_T0}, {S_T1}, 24
+	s_and_b32 {S_T1}, {S_T1}, 0xffffff
+	s_cmp_gt_u32 {S_T0}, 32
+	s_cbranch_scc1 .Lfh_columns_noahead
+	s_cmp_gt_u32 {S_T1}, 64
+	s_cbranch_scc1 .Lfh_columns_noahead
+	s_lshl_b64 {S_PC}, {S_PC}, 3
+	s_add_u32 s86, s86, s30
+	s_addc_u32 s87, s87, s31
+	v_lshlrev_b32 {V_S4}, 3, {V_LANE}
+	s_sub_u32 {S_T0}, 64, {S_T1}
+	s_lshr_b64 exec, -1, {S_T0}
+	global_load_dwordx2 v[{V_NXT[0][1:]}:{V_NXT[1][1:]}], {V_S4}, {S_PC}
+	s_mov_b64 exec, -1
+	s_mov_b32 {S_NXTV}, 1
+.Lfh_columns_noahead:
 	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
 	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
 	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
@@ -1043,7 +1042,13 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	v_mul_f32 {V_S0}, s{m + 13}, {V_PYF}
 	v_add_f32 {V_AW}, {V_AW}, {V_S0}
 	v_mov_b32 {V_IDV}, {S_ID}
+	s_cmp_eq_u32 {S_NXTV}, 0
+	s_cbranch_scc1 .Lfh_columns_waitall
+	s_waitcnt vmcnt(1)                              ; (the request ahead is the youngest: it may stay in flight)
+	s_branch .Lfh_columns_have
+.Lfh_columns_waitall:
 	s_waitcnt vmcnt(0)
+.Lfh_columns_have:
 	; pending = depth < lz + 8  (voxel.rs:377-381)
 	s_add_u32 {S_T0}, {S_LZ}, 8
 	v_cmp_gt_u32 vcc, {S_T0}, {V_DEPTH}
@@ -1100,7 +1105,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	v_lshlrev_b32 v61, {it.lg}, v19
 	v_lshl_or_b32 v22, v22, 6, v18
 	v_lshlrev_b32 v62, {it.lg}, v20
-	v_lshlrev_b32 v22, {HSTRIDE_LOG2}, v22
+	v_lshlrev_b32 v22, {it.hl}, v22
 	v_add_u32 v60, s42, v22
 .L{name}_pass:""")
         for j in range(zb):
@@ -1158,7 +1163,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
 	s_branch .Lfh_columns_leaf
 .Lfh_columns_exit:""")
-    kernel_footer(a, kname, 16, nvg, 102, True, wg_y=True)
+    kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
     if trans:
         import gen_trans
         gen_trans.embed(a, trans)
@@ -1310,10 +1315,10 @@ def main():
     a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
     ks = []
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
-    ks.append((n, 16, nvg, [(8, "global_buffer"), (4, "by_value"), (4, "by_value")]))
+    ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
         n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off, trans=sys.argv[3])
-        ks.append((n, 16, nvg, [(8, "global_buffer"), (4, "by_value"), (4, "by_value")]))
+        ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))

@@ -529,7 +529,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     const uint32_t layers = P.tiles[0] / T;
-                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
+                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
+                        FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
                 }
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
@@ -922,7 +923,8 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                 S->leaves[lb + slot] = lf;
                 if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D)
-                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] = lb + slot + 1;  // [layer][footprint]
+                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
+                        FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
     }
@@ -1093,11 +1095,11 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.tiles[0] / T;
     const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t* col = S->leaf_table + fi;  // [layer][footprint]
+    const FhLeafRef* col = S->leaf_table + fi;  // [layer][footprint]
     uint32_t mx = 0;
     bool any = false;
     for (uint32_t l = 0; l < layers && fi < fw * fh; l++) {
-        const uint32_t id = col[(size_t)l * fw * fh];
+        const uint32_t id = col[(size_t)l * fw * fh].id;
         if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
     }
     // one atomic per wave and class instead of one per footprint
@@ -1227,9 +1229,10 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
 
 // Per-slab reset of the work queues, leaf table and tape arena (frame-persistent tapes stay)
 FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
-    for (uint32_t k = i; k < table_words; k += stride) S->leaf_table[k] = 0;
+    for (uint32_t k = i; k < table_words; k += stride) S->leaf_table[k] = FhLeafRef{0, 0, 0, 0};
     const uint32_t P0 = S->pre_levels;
     if (i == 0) {
+        S->slab_z = slab * S->P.tiles[0];
         for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) {
             S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0;
             S->setup_cur[l] = 0; S->push_cur[l] = 0;
@@ -1259,7 +1262,7 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
 }
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
-__global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, uint32_t* leaf_table, uint32_t* fp_lists,
+__global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, FhLeafRef* leaf_table, uint32_t* fp_lists,
                              size_t leaf_cap, size_t n_footprints) {
     // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
     const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);

@@ -48,6 +48,15 @@ struct FhLeaf {
     uint32_t x, y, z;
 };
 
+// Entry of the 3D leaf table: the leaf kernel finds everything it needs to start on a leaf here, one load for the up to four
+// leaves of a block of footprints, instead of one dependent load per leaf (the table entry, then the FhLeaf record)
+struct FhLeafRef {
+    uint32_t id;         // leaf index + 1 in `leaves` (what goes into the z-buffer word); 0 = no leaf
+    uint32_t off;        // tape offset in the arena
+    uint32_t len_regs;   // tape length | n_regs << 24
+    uint32_t xy;         // corner x | y << 16
+};
+
 // fidget_raster::voxel::GeometryPixel (fidget-raster/src/voxel.rs:122-134)
 struct FhGeometryPixel {
     float normal[3];
@@ -111,7 +120,8 @@ struct FhRenderState {
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
     uint32_t n_leaves_lds;  // 3D: leaves of this slab that need the LDS register file (> 32 registers)
-    uint32_t* leaf_table;   // 3D: [layer][footprint] -> leaf id + 1 (layer = 8-voxel layer of the slab)
+    FhLeafRef* leaf_table;  // 3D: [layer][footprint] -> leaf id + 1 and what the leaf kernel needs of the leaf (layer = 8-voxel layer of the slab)
+    uint32_t slab_z, pad_slab;   // 3D: z of the current slab's first voxel (a leaf's z = slab_z + 8 * layer)
     // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
     uint32_t* fp_list[3];
     uint32_t fp_count[3], fp_cursor[3];

@@ -18,6 +18,22 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
+def col_kernarg(a_st, in_kind, mat):
+    """the leaf kernel's kernarg as capi.hip builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags"""
+    u = np.asarray(mat, F32).view(U32)
+    proj = bool(((int(u[12]) | int(u[13]) | int(u[14])) & 0x7FFFFFFF) | (int(u[15]) ^ 0x3F800000))
+    slot = [-1, -1, -1]
+    for s_, k in enumerate(list(in_kind) + [3] * (16 - len(in_kind))):
+        if k < 3:
+            slot[k] = s_
+    slots = sum((0xFF if slot[ax] < 0 else slot[ax]) << (8 * ax) for ax in range(3))
+    dep = 0
+    for ax in range(3):
+        if slot[ax] >= 0 and (proj or (int(u[4 * ax + 2]) & 0x7FFFFFFF)):
+            dep |= 1 << slot[ax]
+    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, 0x10000 if proj else 0, 0, 0], U32)
+
+
 def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns"):
     off = U.offsets()
     mem = E.Memory()
@@ -26,11 +42,11 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     a_arena = mem.map(arena)
     nfp = (size // 8) ** 2
     layers = size // 8
-    table = np.zeros(layers * nfp, U32)
+    table = np.zeros((layers * nfp, 4), U32)       # FhLeafRef: id + 1, tape offset, length | regs << 24, x | y << 16
     leaves = np.zeros((4, 6), U32)
     lx, ly, lz = leaf_xyz
     leaves[0] = [16, len(tape), n_regs | (n_choices << 16), lx, ly, lz]
-    table[(lz % size) // 8 * nfp + (ly // 8) * (size // 8) + lx // 8] = 1
+    table[(lz % size) // 8 * nfp + (ly // 8) * (size // 8) + lx // 8] = [1, 16, len(tape) | (n_regs << 24), lx | (ly << 16)]
     zbuf = np.zeros(size * size, np.uint64) if zbuf_init is None else zbuf_init.copy()
     a_tab, a_leaves, a_z = mem.map(table), mem.map(leaves), mem.map(zbuf)
     st = U.Blob(off["sizeof_state"])
@@ -39,8 +55,9 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     for s in range(16):
         st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
+    st.u32(off["slab_z"], lz - lz % size)
     a_st = mem.map(st.b)
-    ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, 0], U32)
+    ka = col_kernarg(a_st, in_kind, mat)
     trans = kernel == "fh_columns_t"
     waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=160 if trans else 128,
                      hooks=U.trans_hooks(U.program()) if trans else None)
@@ -175,3 +192,74 @@ def test_column_invariant_leaves(kind, mat):
         _, wr = run_columns(tape, sh.slot_count(), ik, ROTATED, (0, 8, 0))
         va, vr = (sum(w.counts.get("valu", 0) for w in ws) for ws in (wa, wr))
         assert va < 0.6 * vr, (va, vr)
+
+
+def run_block(leaves_spec, in_kind, mat, size=16, zbuf_init=None, kernel="fh_columns"):
+    """several leaves in one block of footprints: leaves_spec = [(tape, n_regs, (x, y, z))], tapes laid out one after the other"""
+    off = U.offsets()
+    mem = E.Memory()
+    arena = np.zeros(8192, np.uint64)
+    nfp = (size // 8) ** 2
+    layers = size // 8
+    table = np.zeros((layers * nfp, 4), U32)
+    leaves = np.zeros((len(leaves_spec) + 1, 6), U32)
+    pos = 16
+    slab_z = None
+    for i, (tape, n_regs, (lx, ly, lz)) in enumerate(leaves_spec):
+        arena[pos:pos + len(tape)] = tape
+        leaves[i] = [pos, len(tape), n_regs, lx, ly, lz]
+        table[(lz % size) // 8 * nfp + (ly // 8) * (size // 8) + lx // 8] = [i + 1, pos, len(tape) | (n_regs << 24), lx | (ly << 16)]
+        pos += len(tape) + 24
+        slab_z = lz - lz % size
+    zbuf = np.zeros(size * size, np.uint64) if zbuf_init is None else zbuf_init.copy()
+    a_arena, a_tab, a_leaves, a_z = mem.map(arena), mem.map(table), mem.map(leaves), mem.map(zbuf)
+    st = U.Blob(off["sizeof_state"])
+    st.arr(off["P.mat"], np.asarray(mat, F32))
+    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
+    st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
+    st.u32(off["slab_z"], slab_z)
+    a_st = mem.map(st.b)
+    ka = col_kernarg(a_st, in_kind, mat)
+    E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=128)
+    return zbuf
+
+
+def test_block_of_leaves_with_tapes_requested_ahead():
+    """All four footprints of a layer hold a leaf (one block for one wave): short tapes are requested one leaf ahead, a tape of
+    more than 64 ops and a leaf of the LDS class (left to another kernel) sit in between; every pixel as if each leaf were alone."""
+    sh0, t0, ik = column_shape(1)
+    sh1, t1, _ = column_shape(0)
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    n = c.sub(c.add(c.square(x), c.add(c.square(y), c.square(z))), 0.5)
+    for k in range(30):                     # a long chain: more than 64 ops, few registers
+        n = c.min(c.add(n, 0.01), c.sub(c.add(c.mul(x, 0.1 * (k + 1)), c.mul(y, 0.03 * k)), c.mul(z, 0.2)))
+    shl = F.Shape(c, n)
+    tl = U.shape_tape(shl)
+    assert len(tl) > 64 and shl.slot_count() <= 32
+    assert all(shl.axis_index(a) == sh0.axis_index(a) for a in range(3))      # same input slots: one in_kind for the block
+    for mat in (AFFINE, ROTATED):
+        for order in ([t0, tl, t1, t0], [tl, t1, t0, tl], [t1, t0, t0, t1]):
+            regs = {id(t0): sh0.slot_count(), id(t1): sh1.slot_count(), id(tl): shl.slot_count()}
+            spec = [(t, regs[id(t)], (8 * (i % 2), 8 * (i // 2), 8)) for i, t in enumerate(order)]
+            got = run_block(spec, ik, mat)
+            want = np.zeros(256, np.uint64)
+            for i, (t, r, xyz) in enumerate(spec):
+                e = expect(t, ik, mat, xyz, 16)
+                hit = e != 0
+                want[hit] = (e[hit] & ~np.uint64(0xFFFFFFFF)) | np.uint64(i + 1)
+            assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+        # an LDS-class leaf (more than 32 registers) in the block is skipped, its neighbours are not disturbed
+        spec = [(t0, sh0.slot_count(), (0, 0, 0)), (t1, 40, (8, 0, 0)), (t1, sh1.slot_count(), (0, 8, 0)), (t0, sh0.slot_count(), (8, 8, 0))]
+        got = run_block(spec, ik, mat)
+        want = np.zeros(256, np.uint64)
+        for i, (t, r, xyz) in enumerate(spec):
+            if r > 32:
+                continue
+            e = expect(t, ik, mat, xyz, 16)
+            hit = e != 0
+            want[hit] = (e[hit] & ~np.uint64(0xFFFFFFFF)) | np.uint64(i + 1)
+        assert (got == want).all()

@@ -625,6 +625,16 @@ class Wave:
         self.ws32(d, r)
         self.scc = 1 if r else 0
 
+    def i_s_bfe_i32(self, i, d, a, b):
+        self.count("salu")
+        x, y = self.rs32(a), self.rs32(b)
+        off, w = y & 31, (y >> 16) & 0x7F
+        r = (x >> off) & ((1 << w) - 1) if w else 0
+        if w and w < 32 and (r >> (w - 1)) & 1:
+            r |= (0xFFFFFFFF << w) & 0xFFFFFFFF
+        self.ws32(d, r)
+        self.scc = 1 if r else 0
+
     def i_s_bfm_b64(self, i, d, a, b):
         self.count("salu")
         w, off = self.rs32(a) & 63, self.rs32(b) & 63
