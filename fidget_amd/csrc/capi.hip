@@ -100,6 +100,7 @@ struct fhip_ctx : FrameBufs {
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
     hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
+    hipEvent_t ev_rest_fork = nullptr, ev_rest_join = nullptr;
     hipEvent_t ev_pre = nullptr;
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
@@ -112,7 +113,7 @@ struct fhip_ctx : FrameBufs {
     std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
     hipEvent_t ev_fork = nullptr;
     FhRenderState last_state_b;
-    uint32_t slab_contexts = 3;   // FHIP_SLAB_CONTEXTS (2 .. 4): how far the tile chain may run ahead of the leaf chain
+    uint32_t slab_contexts = 4;   // FHIP_SLAB_CONTEXTS (2 .. 4): how far the tile chain may run ahead of the leaf chain (measured: 2.03 / 1.60 / 1.55 ms per frame with 2 / 3 / 4)
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -201,6 +202,8 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
     if (getenv("FHIP_LEAF_STREAMS") && atoi(getenv("FHIP_LEAF_STREAMS")) == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
@@ -240,6 +243,8 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     c->other.release_all();
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream_leaf2) { (void)hipStreamSynchronize(c->stream_leaf2); (void)hipStreamDestroy(c->stream_leaf2); }
+    if (c->ev_rest_fork) (void)hipEventDestroy(c->ev_rest_fork);
+    if (c->ev_rest_join) (void)hipEventDestroy(c->ev_rest_join);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
@@ -1035,8 +1040,15 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             ka.skip_regs = ka.skip_choices = 0;
             // Pre-pass levels below the root: the small-layout parents and the others are different slot lists;
             // their launches run side by side (second stream) instead of one after the other.
-            const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && ctx->stream2 &&
-                              ctx->stream != ctx->stream2 && !getenv("FHIP_PIPE_SERIAL");
+            // (Only for a frame alone, whose coarse levels are on the caller's stream: in a pipelined frame they are off the critical
+            // path, and the side stream carries the previous frame's tile chains, where this frame's level-1 kernel sat for 170 us
+            // of every frame - 1.64 -> 1.60 ms without the fork.  Forking to the tail stream instead: 2.0 ms; to streams of their
+            // own, also for the per-slab levels' nearly always empty big-list launches: 3.5 ms - streams beyond four share
+            // hardware queues (GPU_MAX_HW_QUEUES) and serialise against each other.)
+            hipStream_t const rest_stream = ctx->stream2;
+            const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && rest_stream &&
+                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !getenv("FHIP_PIPE_SERIAL") && is3d;
+            hipStream_t const big_stream = side ? rest_stream : nullptr;
             // Tapes of <= 32 registers / 256 choices (the small slot list: every parent of the leaf level) and, from the other
             // list, those of <= 64 / 512 go to the kernels that keep the interval file, the choices and the prune's register
             // map in VGPRs (fh_tiles_v32: 16 waves per CU, fh_tiles_v64: 8; no LDS); what is left takes the LDS layouts.
@@ -1045,16 +1057,15 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 if (side) {
-                    (void)hipEventRecord(ctx->ev_fork, ctx->stream);
-                    (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+                    (void)hipEventRecord(ctx->ev_rest_fork, ctx->stream);
+                    (void)hipStreamWaitEvent(rest_stream, ctx->ev_rest_fork, 0);
                 }
                 if (vk) {
                     static const int v32_waves = getenv("FHIP_V32_WAVES") ? atoi(getenv("FHIP_V32_WAVES")) : 16;
                     ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
-                    (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka), 0, 1, side ? ctx->stream2 : nullptr);
+                    (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
                 } else
-                    (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small, 1, side ? ctx->stream2 : nullptr);
-                if (side) (void)hipEventRecord(ctx->ev_tiles[0], ctx->stream2);
+                    (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
             }
             ka.big = 1;
             if (exp) ka.flags |= ((R.S.P.max_choices + 15) / 16) << 16;  // one stride in chw[1] for the medium and the large layout
@@ -1068,7 +1079,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
                 ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
                 ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
-                (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka));
+                (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
             }
@@ -1079,12 +1090,15 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (mid) {
                 const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
-                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid);
+                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid, 1, big_stream);
                 ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
             }
             ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
-            if (rest) (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big);
-            if (side) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_tiles[0], 0);
+            if (rest) (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big, 1, big_stream);
+            if (side) {
+                (void)hipEventRecord(ctx->ev_rest_join, rest_stream);
+                (void)hipStreamWaitEvent(ctx->stream, ctx->ev_rest_join, 0);
+            }
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
                 const uint32_t bound = R.S.qcap[level] * 64;  // 64 waves per possible parent; unmarked children exit at once
