@@ -650,6 +650,8 @@ struct RenderSetup {
     bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
     bool prune1 = false;      // ... and, on the first exp_levels levels, the prune as one wave per child (fh_prune1)
     uint32_t exp_levels = 0;
+    uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
+    bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -1227,6 +1229,22 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     }
     st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
+    {   // input slots of the axes, and which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix)
+        uint32_t u[16];
+        memcpy(u, P.mat, sizeof(u));
+        const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
+        int slot[3] = {-1, -1, -1};
+        for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis)
+        for (int ax = 0; ax < 3; ax++) {
+            R.col_slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
+            const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
+            if (dep && slot[ax] >= 0) R.col_depmask |= 1u << slot[ax];
+        }
+        R.col_flags = proj ? 0x10000u : 0u;
+        // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
+        const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
+        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !getenv("FHIP_NO_ZREP");
+    }
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
@@ -1242,7 +1260,11 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
     const int class_blocks = (int)((R.n_footprints + 255) / 256);
     if (pre && n_groups) {  // coarse levels of every slab in one go
-        for (uint32_t l = 0; l < pre; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        for (uint32_t l = 0; l < pre; l++) {
+            if (R.zrep && l > 0) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            launch_tiles(ctx, R, dS, (int)l, true);
+        }
+        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
     }
     // Two-stream pipeline over the z-slabs: the tile stage of a slab runs on the side stream while
@@ -1346,21 +1368,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
                 // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
                 // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
-                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, 0, 0, 0, {0, 0}};
-                {
-                    uint32_t u[16];
-                    memcpy(u, P.mat, sizeof(u));
-                    const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
-                    int slot[3] = {-1, -1, -1};
-                    for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis, as the kernel's scan took it)
-                    ka.slots = 0;
-                    for (int ax = 0; ax < 3; ax++) {
-                        ka.slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
-                        const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
-                        if (dep && slot[ax] >= 0) ka.depmask |= 1u << slot[ax];
-                    }
-                    ka.flags = proj ? 0x10000u : 0u;
-                }
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
                 else {

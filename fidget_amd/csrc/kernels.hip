@@ -538,6 +538,31 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     probe.done(lane);
 }
 
+// Which queued parents have a tape that reads no input changing along z (`depmask`: bit per input slot, from the camera
+// matrix - capi.hip)?  Their children repeat along z (tsetup_body / tpush_body).  One wave per queue entry, the tape scanned
+// 64 ops at a time; parked = 0: the queue of `level`; 1: the per-slab parking queues of the first per-slab level.
+__global__ void __launch_bounds__(WAVE) k_tape_flags(FhRenderState* S, int level, uint32_t depmask, int parked) {
+    const int lane = threadIdx.x;
+    const uint32_t nq = parked ? S->n_slabs : 1u;
+    for (uint32_t q = 0; q < nq; q++) {
+        FhGroup* const base = parked ? S->squeue + (size_t)q * S->squeue_cap : S->queue[level];
+        const uint32_t cap = parked ? S->squeue_cap : S->qcap[level];
+        const uint32_t ns = parked ? S->scount[q] : S->count[level], nb = parked ? S->scount_big[q] : S->count_big[level];
+        for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
+            FhGroup& g = base[gi < ns ? gi : cap - 1 - (gi - ns)];
+            const ctape_t tape = (ctape_t)(S->arena + g.tape.off);
+            const uint32_t len = uni(g.tape.len);
+            bool dep = false;
+            for (uint32_t k = lane; k < len; k += WAVE) {
+                const uint64_t w = tape[k];
+                if ((uint32_t)(w & 0xFFu) == FH_INPUT && ((depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) dep = true;
+            }
+            const bool any = ballot(dep) != 0;
+            if (lane == 0) g.stride = any ? 0u : 0x80000000u;
+        }
+    }
+}
+
 // ======================================================================================
 // Split 3D tile stage (64 children per parent): k_tsetup3d -> evaluate + prune (fh_tiles in
 // assembly, or k_teval3d below for tapes outside its opcode set) -> k_tpush3d.  Same
@@ -565,9 +590,16 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
         FhSlot* const slg = &S->slots[big ? 1 : 0][big ? (gi - ns) * G : gi];
         FhSlot& sl = *slg;
+        // Column-invariant parents (k_tape_flags: the tape reads no input that changes along z, axis-aligned camera): the
+        // children of a z-layer are those of every other layer, and the copies of the parent stacked along z (g.n tiles one
+        // tile apart, this one included: the push stage queued one entry for them) are the same tile again - only the first
+        // layer is evaluated, the push stage hands its results to all the instances.  Occlusion is tested for the instance
+        // nearest the camera.
+        const uint32_t zrep = (IS3D && level > 0 && g.n > 1) ? g.n : 1u;
+        const bool inv = IS3D && level > 0 && ((g.stride >> 31) != 0 || zrep > 1);   // (a copy-carrying entry's tape is invariant: pruning only removes ops)
         if (IS3D && level > 0) {  // the whole parent may have been occluded since it was queued
             const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
-            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
+            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
         }
         uint32_t nchild, cx, cy, cz;
         if (level == 0) {
@@ -580,7 +612,13 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
             cx = g.x + (lane % n) * T; cy = g.y + ((lane / n) % n) * T; cz = IS3D ? g.z + (lane / (n * n)) * T : 0u;
         }
         bool act = lane < (int)nchild && cx < P.width && cy < P.height;
-        if (IS3D && act && mind[(cy / T) * ntx + cx / T] >= cz + T + 1) act = false;  // voxel.rs:283-289
+        uint32_t cz_top = cz;       // z of the instance nearest the camera among those this lane stands for
+        if (inv) {
+            const uint32_t n = P.tiles[level - 1] / T;
+            if (lane / (n * n) != 0) act = false;
+            cz_top = g.z + (zrep - 1) * P.tiles[level - 1] + (n - 1) * T;
+        }
+        if (IS3D && act && mind[(cy / T) * ntx + cx / T] >= cz_top + T + 1) act = false;  // voxel.rs:283-289
         const uint64_t actm = ballot(act);
         if (actm == 0) { if (lane < (int)G) slg[lane].act = 0; continue; }
         IV X, Y, Z;
@@ -592,7 +630,8 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
                 const FhTapeRef tr = (G > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
                 so.tape = tr;
                 so.level = (uint32_t)level; so.act = actm; so.base = 0; so.overflow = 0;
-                so.tvals = (G > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : nullptr;
+                // (levels >= 1 have no term values: the field carries inv | zrep << 8 to the push stage)
+                so.tvals = (G > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : (float*)(uintptr_t)((inv ? 1u : 0u) | (zrep << 8));
             }
             so.xyz[0][lane] = X.lo; so.xyz[1][lane] = X.hi; so.xyz[2][lane] = Y.lo; so.xyz[3][lane] = Y.hi;
             so.xyz[4][lane] = Z.lo; so.xyz[5][lane] = Z.hi;
@@ -846,7 +885,9 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             const uint64_t actm = sl.act;
             if (uni((uint32_t)(actm != 0)) == 0) continue;
             const float lo = sl.res[0][lane], hi = sl.res[1][lane];
-            mine += (uint32_t)__popcll(ballot(((actm >> lane) & 1) && ((!IS3D && P.pixel_perfect) || (!(hi < 0.0f) && !(lo > 0.0f)))));
+            const uint32_t zi = (IS3D && level > 0) ? uni((uint32_t)(uintptr_t)sl.tvals) : 0u;
+            const uint32_t ninst = (zi & 1) ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u;
+            mine += ninst * (uint32_t)__popcll(ballot(((actm >> lane) & 1) && ((!IS3D && P.pixel_perfect) || (!(hi < 0.0f) && !(lo > 0.0f)))));
         }
         if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
         leaf_base = uni(leaf_base);
@@ -857,6 +898,10 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         const bool act = (sl.act >> lane) & 1;
         const float lo = sl.res[0][lane], hi = sl.res[1][lane];
         const uint32_t cx = sl.corner[0][lane], cy = sl.corner[1][lane], cz = sl.corner[2][lane];
+        // column-invariant parent (tsetup_body): every active lane stands for `ninst` tiles stacked along z, one T apart
+        const uint32_t zi = (IS3D && level > 0) ? uni((uint32_t)(uintptr_t)sl.tvals) : 0u;
+        const bool inv = (zi & 1) != 0;
+        const uint32_t ninst = inv ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u;
         const bool fills = IS3D || !P.pixel_perfect;                                       // pixel.rs:345-368
         const bool full = act && fills && hi < 0.0f, empty = act && fills && !full && lo > 0.0f;  // voxel.rs:310-320
         const bool amb = act && !full && !empty;
@@ -867,7 +912,8 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             fm &= fm - 1;
             const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
             if (IS3D) {
-                const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + T + 1) << 32;
+                // (of the instances stacked along z the nearest one's fill is the maximum)
+                const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + (ninst - 1) * T + T + 1) << 32;
                 for (uint32_t p = lane; p < T * T; p += WAVE) {
                     const uint32_t x = ccx + (p % T), y = ccy + (p / T);
                     if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
@@ -909,23 +955,27 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             qs = uni(qs); qb = uni(qb);
             if (amb) {
                 FhGroup o;
-                o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = 0; o.stride = 0;
+                // (a child of a column-invariant parent is queued once for its ninst instances, one T apart: as a parent it is the
+                // first of `n` copies one tile apart; stride: k_tape_flags)
+                o.tape = child; o.x = cx; o.y = cy; o.z = cz; o.first = 0; o.n = inv ? ninst : 0u; o.stride = 0;
                 if (small) qdst[qs + slot_s] = o;
                 else qdst[qcap - 1 - (qb + slot_b)] = o;
             }
         } else {
             const uint32_t namb = (uint32_t)__popcll(am), slot = (uint32_t)__popcll(am & ((1ull << lane) - 1));
-            const uint32_t lb = leaf_base;
-            leaf_base += namb;
-            if (amb && lb + slot < S->leaf_cap) {
-                FhLeaf lf;
-                lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
-                S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
-                if (IS3D)
-                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
-                        FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
-            } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+            for (uint32_t inst = 0; inst < ninst; inst++) {       // (one leaf per instance along z: same tape, its own layer)
+                const uint32_t lb = leaf_base, iz = cz + inst * T;
+                leaf_base += namb;
+                if (amb && lb + slot < S->leaf_cap) {
+                    FhLeaf lf;
+                    lf.tape = child; lf.x = cx; lf.y = cy; lf.z = iz;
+                    S->leaves[lb + slot] = lf;
+                    if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                    if (IS3D)
+                        S->leaf_table[(size_t)((iz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
+                            FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
+                } else if (amb) atomicAdd(&S->queue_overflow, 1u);
+            }
         }
     }
 }

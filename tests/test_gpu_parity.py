@@ -278,3 +278,26 @@ def test_render3d_bound_variables():
             assert same.all(), f"{vars}: {(~same).any(axis=2).sum()} normals differ"
     with pytest.raises(ValueError):
         F.render3d(p, 64, vars={7: 0.5})        # MissingVar, as the reference (shape/mod.rs:388-396)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("prospero.vm", 512), ("colonnade.vm", 256), ("colonnade.vm", 512), ("tanglecube.vm", 128)])
+def test_render3d_column_invariant_parents(name, size, monkeypatch):
+    """Tiles whose tape reads nothing that changes along z (an extrusion such as prospero.vm, the vertical shafts of
+    colonnade.vm once pruned) repeat along z: the tile stage evaluates one z-layer of their children and hands the results to
+    every instance (k_tape_flags, tsetup_body / tpush_body).  Same image as without the short cut, which is the oracle's;
+    under a rotated camera nothing is invariant and nothing changes either."""
+    p, o = both(name)
+    ref = O.render3d(o, size)[0]
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("FHIP_NO_ZREP", flag)
+        else:
+            monkeypatch.delenv("FHIP_NO_ZREP", raising=False)
+        a = F.render3d(p, size)[0]
+        assert (a["depth"] == ref["depth"]).all(), f"NO_ZREP={flag}: {(a['depth'] != ref['depth']).sum()} depths differ"
+        assert same_bits_f32(a["normal"], ref["normal"])
+    monkeypatch.delenv("FHIP_NO_ZREP", raising=False)
+    cam = bench_camera(0.0)
+    a, b = F.render3d(p, size, world_to_model=cam)[0], O.render3d(o, size, world_to_model=cam)[0]
+    assert (a["depth"] == b["depth"]).all()
