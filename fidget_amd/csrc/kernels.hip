@@ -885,9 +885,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             const uint64_t actm = sl.act;
             if (uni((uint32_t)(actm != 0)) == 0) continue;
             const float lo = sl.res[0][lane], hi = sl.res[1][lane];
-            const uint32_t zi = (IS3D && level > 0) ? uni((uint32_t)(uintptr_t)sl.tvals) : 0u;
-            const uint32_t ninst = (zi & 1) ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u;
-            mine += ninst * (uint32_t)__popcll(ballot(((actm >> lane) & 1) && ((!IS3D && P.pixel_perfect) || (!(hi < 0.0f) && !(lo > 0.0f)))));
+            mine += (uint32_t)__popcll(ballot(((actm >> lane) & 1) && ((!IS3D && P.pixel_perfect) || (!(hi < 0.0f) && !(lo > 0.0f)))));
         }
         if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
         leaf_base = uni(leaf_base);
@@ -963,8 +961,10 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             }
         } else {
             const uint32_t namb = (uint32_t)__popcll(am), slot = (uint32_t)__popcll(am & ((1ull << lane) - 1));
-            for (uint32_t inst = 0; inst < ninst; inst++) {       // (one leaf per instance along z: same tape, its own layer)
-                const uint32_t lb = leaf_base, iz = cz + inst * T;
+            // Leaves of a column-invariant parent: the ninst leaves stacked along z hold the same value in every voxel of a pixel's
+            // column, so a pixel is hit in the nearest of them or in none - ONE leaf, the nearest, stands for the stack.
+            {
+                const uint32_t lb = leaf_base, iz = cz + (ninst - 1) * T;
                 leaf_base += namb;
                 if (amb && lb + slot < S->leaf_cap) {
                     FhLeaf lf;
