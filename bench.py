@@ -127,6 +127,20 @@ def main():
         step = step_columns
         dt = timed(step)
         sharding = "single GPU"
+    # the same frames with the column-invariance short cuts off (FHIP_NO_COLUMN_INV: leaves evaluated once per voxel, every tile
+    # of a z-stack evaluated) - prospero.vm has no z, so every one of its tapes takes them; this is what a model with z in
+    # every tape gets from the same kernels
+    general = None
+    if world == 1:
+        os.environ["FHIP_NO_COLUMN_INV"] = "1"
+        saved = list(frame_ms)
+        dt_g = timed(step)
+        general = {"ms_per_step": dt_g / args.steps * 1e3, "ms_per_step_median": float(np.median(frame_ms)), "value": (n ** 3) * args.steps / dt_g / 1e6,
+                   "note": "FHIP_NO_COLUMN_INV=1: no tape treated as independent of z (same image)"}
+        frame_ms[:] = saved
+        del os.environ["FHIP_NO_COLUMN_INV"]
+        for _ in range(2):
+            step()
     # one frame alone (nothing in flight before it, waited for): asynchronous frames are pipelined - the coarse levels of
     # frame n + 1 run beside the slabs of frame n - so the throughput above is not 1 / latency
     lat = []
@@ -174,11 +188,15 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frame_latency_ms": float(np.median(lat)),
+        "without_column_invariance": general,
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
                    "sharding": sharding,
                    "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (two buffer "
                              "sets per context: the coarse levels of a frame run beside the previous frame's slabs), every frame does all of its "
-                             "work; frame_latency_ms is one frame alone"},
+                             "work; frame_latency_ms is one frame alone",
+                   "column_invariance": "tapes that read no input varying along z (under this camera: no z) are evaluated once per pixel "
+                                        "column / once per z-stack of tiles (DESIGN.md section 2); prospero.vm is an extrusion, so all of its "
+                                        "tapes qualify - `without_column_invariance` times the same frames with the short cuts off"},
         "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in prof.items()},
         "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in prof.items()},
         "asm_kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in kern.items() if v[1]},

@@ -1243,7 +1243,11 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         R.col_flags = proj ? 0x10000u : 0u;
         // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
         const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
-        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !getenv("FHIP_NO_ZREP");
+        // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying
+        // along z - which is what a model with z in every tape gets)
+        const bool no_inv = getenv("FHIP_NO_COLUMN_INV") != nullptr;
+        if (no_inv) R.col_depmask = 0xFFFFFFFFu;
+        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !no_inv && !getenv("FHIP_NO_ZREP");
     }
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
