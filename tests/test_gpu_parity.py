@@ -289,15 +289,16 @@ def test_render3d_column_invariant_parents(name, size, monkeypatch):
     under a rotated camera nothing is invariant and nothing changes either."""
     p, o = both(name)
     ref = O.render3d(o, size)[0]
-    for flag in (None, "1"):
-        if flag:
-            monkeypatch.setenv("FHIP_NO_ZREP", flag)
-        else:
-            monkeypatch.delenv("FHIP_NO_ZREP", raising=False)
+    for var in (None, "FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):       # everything on; the tile stage's short cut off; all of them off
+        for v in ("FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):
+            monkeypatch.delenv(v, raising=False)
+        if var:
+            monkeypatch.setenv(var, "1")
         a = F.render3d(p, size)[0]
-        assert (a["depth"] == ref["depth"]).all(), f"NO_ZREP={flag}: {(a['depth'] != ref['depth']).sum()} depths differ"
+        assert (a["depth"] == ref["depth"]).all(), f"{var}: {(a['depth'] != ref['depth']).sum()} depths differ"
         assert same_bits_f32(a["normal"], ref["normal"])
-    monkeypatch.delenv("FHIP_NO_ZREP", raising=False)
+    for v in ("FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):
+        monkeypatch.delenv(v, raising=False)
     cam = bench_camera(0.0)
     a, b = F.render3d(p, size, world_to_model=cam)[0], O.render3d(o, size, world_to_model=cam)[0]
     assert (a["depth"] == b["depth"]).all()

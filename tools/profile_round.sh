@@ -8,7 +8,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-general"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $CMD > $OUT/stats_run.log 2>&1
 cp /tmp/p_stats/s_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 grep '^{"metric"' $OUT/stats_run.log > $OUT/bench_under_rocprof.json
@@ -29,8 +29,8 @@ for f in glob.glob(os.path.join(out, "pmc_*.csv")):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").split("<")[0]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
-FRAMES = 1 + 5 + 3          # bench.py: warm-up + timed + profiled frames
-res = {"_comment": "per-kernel PMC totals of `bench.py --steps 5 --warmup 1 --no-cpu` under rocprofv3 --pmc (9 frames), one pass per counter group; "
+FRAMES = 1 + 5 + 5 + 3      # bench.py --no-general: warm-up + timed + one-at-a-time (latency) + profiled frames
+res = {"_comment": "per-kernel PMC totals of `bench.py --steps 5 --warmup 1 --no-cpu` under rocprofv3 --pmc (14 frames), one pass per counter group; "
                    "FETCH_SIZE / WRITE_SIZE in KB as reported (bench.py doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950)",
        "source_hash": source_hash(), "frames": FRAMES}
 lines = []
