@@ -170,13 +170,15 @@ def main():
             kern[k][1] += cnt
     # ... and one profiled frame with the column-invariance short cuts off: the leaf kernel then does all the work the
     # algorithmic byte count stands for (with them on it skips most of it, and its roofline fraction flatters it)
-    kern_general = {}
+    kern_general, tile_phases_general = {}, None
     if world == 1 and not args.no_general:
         os.environ["FHIP_NO_COLUMN_INV"] = "1"
         F.render3d(shape, n, out=out)
         hip.profile_read()
         for k, (ms, cnt) in hip.profile_read_kernels().items():
             kern_general[k] = (ms, cnt)
+        hip.wave_stats()
+        tile_phases_general = hip.tile_phases     # tape ops read / written per tile level when no tile is skipped as a copy along z
         del os.environ["FHIP_NO_COLUMN_INV"]
         hip.profile(False)
         F.render3d(shape, n, out=out)       # (leaves the default path's image in `out` and its counters in the context)
@@ -294,20 +296,29 @@ def main():
             return r
 
         kms, kl = result["kernel_ms_per_frame"], result["kernel_launches_per_frame"]
-        # dominant kernel by total time (profiles/: rocprofv3 --stats): fh_columns, the leaf interpreter, since the tile
-        # stage moved to the VGPR kernels; `roofline_tiles` covers fh_tiles_v32 (the per-slab tile stage)
+        # Two kernels carry the frame: fh_columns (leaf interpreter) and fh_tiles_v32 (tile stage of the per-slab level and part
+        # of level 1).  `roofline` is the one with more time per frame in this run (profiles/: rocprofv3 --stats agrees), the other
+        # follows as `roofline_leaf` / `roofline_tiles`.  ALGORITHMIC bytes: the leaf stage's from the oracle (every voxel of every
+        # leaf), the tile stage's from the device's op counters of a frame with the column-invariance short cuts off (every tile of
+        # the 128 / 32 / 8 subdivision) - prospero's tapes are column-invariant, so the default path evaluates one leaf per stack,
+        # once per pixel, and one z-layer of tiles: it touches far fewer bytes (`traffic`), and `without_column_invariance` gives
+        # the same figure with the short cuts off.
         leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
-        result["roofline"] = roof("fh_columns", leaf_bytes, kms["points"], 8,
-                                  "tape words are wave-uniform loads served by L2: the leaf interpreter is bound by instruction "
-                                  "issue (see `issue`), not by HBM: DESIGN.md sections 4 and 6.  `achieved` divides the ALGORITHMIC bytes "
-                                  "(the oracle's: every voxel of every leaf) by the kernel's time; prospero's tapes are column-invariant, so "
-                                  "the kernel evaluates one leaf per stack, once per pixel, and touches far fewer bytes (`traffic`): "
-                                  "`without_column_invariance` is the same figure with those short cuts off")
-        lv = [v for k, v in tile_phases.items() if int(k[1:]) >= 2]
+        r_leaf = roof("fh_columns", leaf_bytes, kms["points"], 8,
+                      "tape words are wave-uniform loads served by L2: the leaf interpreter is bound by instruction issue (see `issue`), "
+                      "not by HBM: DESIGN.md sections 4 and 6.  Algorithmic bytes are the oracle's (every voxel of every leaf); the "
+                      "column-invariance short cuts skip most of that work for prospero.vm - see `without_column_invariance`")
+        tp = tile_phases_general or tile_phases
+        lv = [v for k, v in tp.items() if int(k[1:]) >= 2]
         tile_bytes = 8.0 * (sum(v["ops"] for v in lv) + sum(v["ops_written"] for v in lv))
-        result["roofline_tiles"] = roof("fh_tiles_v32", tile_bytes, kms["tiles"], 8,
-                                        "interval interpreter + lockstep prune with the register file in VGPRs: bound by the "
-                                        "latency of each parent's dependent op chain (one wave per parent)")
+        r_tiles = roof("fh_tiles_v32", tile_bytes, kms["tiles"], 8,
+                       "interval interpreter + lockstep prune with the register file in VGPRs: bound by the latency of each parent's "
+                       "dependent op chain (one wave per parent) and by instruction issue; algorithmic bytes = tape ops read + written at "
+                       "the per-slab level with no tile skipped as a copy along z")
+        def per_frame(r):
+            return r["avg_launch_ms"] * r["launches_per_frame"]
+        result["roofline"] = r_tiles if per_frame(r_tiles) > per_frame(r_leaf) else r_leaf
+        result["roofline_leaf"], result["roofline_tiles"] = r_leaf, r_tiles
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
     print(json.dumps(result))
