@@ -738,6 +738,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
     // (the device prunes keep old -> new register maps in bytes with 0xFF = dead: 255 registers at most)
     if (t.n_regs > 255) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 255 registers");
+    if (t.ops.size() >= (1u << 24)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support tapes of up to 2^24 ops");   // (FhLeafRef packs length | registers << 24)
     P.max_regs = std::max<uint32_t>(t.n_regs, 1);
     P.max_choices = t.n_choices;
     P.roots_x = (P.width + ts[0] - 1) / ts[0];
@@ -1056,16 +1057,22 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // map in VGPRs (fh_tiles_v32: 16 waves per CU, fh_tiles_v64: 8; no LDS); what is left takes the LDS layouts.
             static const bool use_v = !getenv("FHIP_NO_TILES_V");
             const bool vk = use_v && !exp;
+            bool both_lists = false;
             if (level > 0) {
                 ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
                 if (side) {
                     (void)hipEventRecord(ctx->ev_rest_fork, ctx->stream);
                     (void)hipStreamWaitEvent(rest_stream, ctx->ev_rest_fork, 0);
                 }
-                if (vk) {
+                // (a pre-pass level has a few hundred parents in the two lists together: fh_tiles_v64 takes both in ONE launch
+                // below - the level's time is its slowest parent's either way, and a launch of its own for the small list put
+                // another 130 us on the coarse levels' chain)
+                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side && !getenv("FHIP_NO_BOTH_LISTS");
+                if (vk && !both_lists) {
                     static const int v32_waves = getenv("FHIP_V32_WAVES") ? atoi(getenv("FHIP_V32_WAVES")) : 16;
                     ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
                     (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
+                } else if (vk) {
                 } else
                     (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
             }
@@ -1081,7 +1088,9 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
                 ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
                 ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
+                if (both_lists) ka.flags |= 16u;
                 (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
+                ka.flags &= ~16u;
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
             }

@@ -716,6 +716,17 @@ class TilesV(Tiles):
 	s_mov_b32 {S_MAXREGS}, s10
 	s_min_u32 {S_MAXREGS}, {S_MAXREGS}, {self.nr}
 	s_min_u32 {S_MAXCH}, {S_MAXCH}, {self.ncw * 16}
+	; flags bit 4: both slot lists in this launch, `big` first then the other (a level of few parents, where two launches
+	; one after the other cost more than the waves: every wave walks its share of one list, then of the other)
+	; (s70, s86, s87 are the kernel's free SGPRs; {S_BIG}'s and {S_LEVEL}'s registers are reused once a list's state is loaded:
+	; s70 = other list still to do | big << 1 | level << 8, s86 = this wave's index)
+	s_mov_b32 s86, s2
+	s_bfe_u32 s70, s101, 0x10004
+	s_lshl_b32 s87, {S_BIG}, 1
+	s_or_b32 s70, s70, s87
+	s_lshl_b32 s87, {S_LEVEL}, 8
+	s_or_b32 s70, s70, s87
+{p}_list:
 	; per-list state: slots[big], slot_cap[big], n_slots[big][level]
 	s_lshl_b32 {S_T0}, {S_BIG}, 3
 	s_add_u32 s76, s4, {S_T0}
@@ -900,6 +911,15 @@ class TilesV(Tiles):
 	global_store_dword {V_L4}, {V_CRC}, {S_SLOT} offset:{SL_CRC}
 	s_branch {p}_outer
 {p}_exit:
+	s_bitcmp1_b32 s70, 0
+	s_cbranch_scc0 {p}_quit
+	s_and_b32 s70, s70, 0xfffffffe
+	s_bfe_u32 {S_BIG}, s70, 0x10001
+	s_xor_b32 {S_BIG}, {S_BIG}, 1
+	s_lshr_b32 {S_LEVEL}, s70, 8
+	s_mov_b32 {S_SI}, s86
+	s_branch {p}_list
+{p}_quit:
 	s_endpgm
 {p}_end:
 	.size {name}, {p}_end - {name}

@@ -226,3 +226,47 @@ def test_arena_overflow_keeps_parent_tape():
     xyz = children(np.array([0.0, 0.0, 0.0]), 0.5)
     r = run_tiles("fh_tiles_v32", tape, xyz, ik, sh.slot_count(), sh.choice_count(), arena_cap=16 + len(tape) + 20)
     assert r["overflow"] == 1 and (r["coff"] == 16).all() and (r["clen"] == len(tape)).all()
+
+
+@pytest.mark.parametrize("kernel", ["fh_tiles_v32", "fh_tiles_v64"])
+def test_both_slot_lists_in_one_launch(kernel):
+    """flags bit 4 (a pre-pass level's few hundred parents: one launch instead of two): the waves walk the `big` list, then the
+    other; each slot comes out as when it is the only one of its launch."""
+    off = U.offsets()
+    sh, tape, ik = shape_of(2)
+    n = len(tape)
+    boxes = [children((0.1, -0.2, 0.3), 0.5), children((-0.3, 0.25, 0.0), 0.45)]
+    alone = [run_tiles(kernel, tape, b, ik, sh.slot_count(), sh.choice_count()) for b in boxes]
+    mem = E.Memory()
+    arena = np.zeros(ARENA_OPS, np.uint64)
+    arena[16:16 + n] = tape
+    a_arena = mem.map(arena, "arena")
+    st = U.Blob(off["sizeof_state"])
+    slots = []
+    for b in boxes:
+        slot = U.Blob(off["sizeof_slot"])
+        slot.u32(0, 16); slot.u32(4, n); slot.u32(8, sh.slot_count() | (sh.choice_count() << 16)); slot.u32(12, 2)
+        slot.u64(16, (1 << 64) - 1)
+        for k in range(6):
+            slot.arr(40 + 256 * k, np.asarray(b[k], F32))
+        slots.append(slot)
+    a0, a1 = mem.map(slots[0].b, "slot0"), mem.map(slots[1].b, "slot1")
+    head0 = 16 + n + 16
+    st.u64(off["arena"], a_arena); st.u32(off["arena_cap"], ARENA_OPS - 64); st.u32(off["arena_head"], head0)
+    st.u64(off["slots"], a0); st.u64(off["slots"] + 8, a1)
+    st.u32(off["slot_cap"], 1); st.u32(off["slot_cap"] + 4, 1)
+    level = 2
+    for big in (0, 1):
+        st.u32(off["n_slots"] + 4 * (big * 8 + level), 1)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, ik[s] if s < len(ik) else 3)
+    a_st = mem.map(st.b, "state")
+    mr, mc = LIMITS[kernel]
+    ka = np.zeros(10, U32)
+    ka[0], ka[1] = a_st & 0xFFFFFFFF, a_st >> 32
+    ka[2:10] = [level, 1, mr, mc, 1, 16, 0, 0]
+    E.launch(U.program(), mem, kernel, ka.tobytes(), 1, lds_bytes=16, n_vgpr=N_VGPR[kernel])
+    for sl, ref in zip(slots, alone):
+        g = lambda k: sl.b[40 + k * 256: 40 + (k + 1) * 256]
+        assert (g(9).view(U32) == ref["res"][0].view(U32)).all() and (g(10).view(U32) == ref["res"][1].view(U32)).all()
+        assert (g(12).view(U32) == ref["clen"]).all() and (g(13).view(U32) == ref["crc"]).all()
