@@ -302,3 +302,38 @@ def test_render3d_column_invariant_parents(name, size, monkeypatch):
     cam = bench_camera(0.0)
     a, b = F.render3d(p, size, world_to_model=cam)[0], O.render3d(o, size, world_to_model=cam)[0]
     assert (a["depth"] == b["depth"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_render3d_partly_column_invariant_shapes(kind, monkeypatch):
+    """Shapes in which SOME tiles' tapes lose their z (an extruded profile joined with, cut by, or standing behind a body that
+    depends on z), so that column-invariant stacks and ordinary tiles meet in one frame - in front of each other, occluding
+    each other, sharing parents: depth and normals as the oracle's, cubic and not, plain and scaled (still axis-aligned) camera."""
+    def build(be):
+        c = be.Context()
+        x, y, z = c.x(), c.y(), c.z()
+        star = c.sub(c.add(c.abs(c.sub(x, 0.1)), c.mul(c.abs(c.add(y, 0.2)), 1.5)), 0.45)           # extruded diamond
+        ring = c.sub(c.abs(c.sub(c.sqrt(c.add(c.square(c.add(x, 0.3)), c.square(c.sub(y, 0.3)))), 0.35)), 0.06)   # extruded ring
+        ball = c.sub(c.sqrt(c.add(c.add(c.square(c.sub(x, 0.2)), c.square(y)), c.square(c.sub(z, 0.3)))), 0.5)
+        if kind == 0:
+            n = c.min(c.min(star, ring), ball)                      # union: stacks beside and behind a body with z
+        elif kind == 1:
+            n = c.max(c.min(star, ring), c.sub(c.abs(c.sub(z, 0.1)), 0.55))     # extrusions cut by two planes: z comes back near the cuts
+        else:
+            n = c.min(c.max(star, c.neg(ball)), c.max(ring, c.sub(z, -0.2)))    # a body carved out of one, the other cut off below
+        return be.Shape(c, n)
+    p, o = build(F), build(O)
+    scaled = np.diag([1.3, 0.9, 1.1, 1.0]).astype(np.float32)
+    for whd, cam in (((256, 256, 256), None), ((384, 256, 512), None), ((256, 256, 256), scaled)):
+        ref = O.render3d(o, *whd, world_to_model=cam)[0]
+        assert ref["depth"].max() > 0 and (ref["depth"] == 0).any()
+        for var in (None, "FHIP_NO_COLUMN_INV"):
+            monkeypatch.delenv("FHIP_NO_COLUMN_INV", raising=False)
+            if var:
+                monkeypatch.setenv(var, "1")
+            a = F.render3d(p, *whd, world_to_model=cam)[0]
+            assert (a["depth"] == ref["depth"]).all(), f"kind {kind} {whd} {var}: {(a['depth'] != ref['depth']).sum()} depths differ"
+            same = (a["normal"] == ref["normal"]) | (np.isnan(a["normal"]) & np.isnan(ref["normal"]))
+            assert same.all(), f"kind {kind} {whd} {var}: {(~same).any(axis=2).sum()} normals differ"
+    monkeypatch.delenv("FHIP_NO_COLUMN_INV", raising=False)
