@@ -51,10 +51,6 @@ def main():
     ap.add_argument("--no-general", action="store_true", help="skip the frames with the column-invariance short cuts off (profiling runs: per-kernel statistics of the default path only)")
     args = ap.parse_args()
 
-    # The library keeps four streams busy (caller's, side, tail, pre-pass); HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
-    # (default 4) and streams that share one serialise against each other.  RCCL and torch bring streams of their own in the
-    # multi-GPU runs, so leave headroom (measured at N = 1: no difference between 4 and 8; 2 costs 60 %).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     import fidget_amd as F

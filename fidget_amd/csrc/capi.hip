@@ -1048,6 +1048,9 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // of every frame - 1.64 -> 1.60 ms without the fork.  Forking to the tail stream instead: 2.0 ms; to streams of their
             // own, also for the per-slab levels' nearly always empty big-list launches: 3.5 ms - streams beyond four share
             // hardware queues (GPU_MAX_HW_QUEUES) and serialise against each other.)
+            // (A fifth stream for the per-slab levels' nearly always empty big-list launches, with GPU_MAX_HW_QUEUES=8 in the
+            // environment: 2.3 ms per frame instead of 1.03 - more than four streams in flight cost far more than two kernel
+            // boundaries per slab, whatever the number of hardware queues.)
             hipStream_t const rest_stream = ctx->stream2;
             const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && rest_stream &&
                               ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !getenv("FHIP_PIPE_SERIAL") && is3d;
