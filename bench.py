@@ -63,6 +63,11 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
             sys.exit(2)
+    if world > 1:
+        # RCCL brings a stream of its own; the library keeps four busy (caller's, side, tail, pre-pass), and a fifth stream in flight
+        # was measured to cost a single GPU a factor of two.  With a collective in the frame the slab's small
+        # kernels go back to the caller's stream (FHIP_TAIL_STREAM=0: three streams + RCCL's); not measurable on the one-GPU box.
+        os.environ.setdefault("FHIP_TAIL_STREAM", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
