@@ -63,16 +63,37 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
             sys.exit(2)
-    if world > 1:
-        # RCCL brings a stream of its own; the library keeps four busy (caller's, side, tail, pre-pass), and a fifth stream in flight
-        # was measured to cost a single GPU a factor of two.  With a collective in the frame the slab's small
-        # kernels go back to the caller's stream (FHIP_TAIL_STREAM=0: three streams + RCCL's); not measurable on the one-GPU box.
-        os.environ.setdefault("FHIP_TAIL_STREAM", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    direct_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # The frame's one collective goes through RCCL's C API ON THE RENDER'S STREAM (fidget_amd/dist.py DirectRccl):
+        # torch.distributed would run it on a stream of its own behind a cross-stream wait, and such a wait holds the next
+        # frame's coarse levels back (one GPU, stand-in tools/fifth_stream.py: the pipelined frame rate halves).  The process
+        # group stays for the barrier, the unique id and the timing reduction - and as the fallback if the library cannot be
+        # loaded on some rank (agreed on before any rank enters the communicator's collective initialisation).
+        from fidget_amd.dist import DirectRccl, use_direct_rccl
+        lib_ok = 1
+        if os.environ.get("FHIP_NO_DIRECT_RCCL"):
+            lib_ok = 0
+        else:
+            try:
+                DirectRccl.probe()
+            except Exception as e:      # noqa: BLE001
+                lib_ok, direct_note = 0, f"librccl not usable through ctypes ({e!r}): torch.distributed collectives"
+        flag = torch.tensor([lib_ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            def bcast(raw, src):
+                t = torch.tensor(list(raw), dtype=torch.uint8, device=dev) if rank == src else torch.zeros(len(raw), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, src=src)
+                return bytes(t.cpu().tolist())
+            use_direct_rccl(DirectRccl(rank, world, bcast))
+            direct_note = "RCCL C API on the render's stream (fidget_amd.dist.DirectRccl)"
+        elif direct_note is None:
+            direct_note = "torch.distributed collectives (FHIP_NO_DIRECT_RCCL or another rank could not load librccl)"
 
     n = args.size
     stream = torch.cuda.current_stream(dev)
@@ -227,6 +248,7 @@ def main():
     }
     if partitions:
         result["partitions"] = partitions
+        result["collectives"] = direct_note
 
     # ---- cpu_baseline + parity + algorithmic bytes (oracle; rank 0, N = 1 only) -----------------
     if not args.no_cpu and world == 1:

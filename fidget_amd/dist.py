@@ -38,10 +38,111 @@ def owner_map(width, height, root, world):
     return ((x * roots_y + y) % world).astype(np.int32)
 
 
+# ---- RCCL on the caller's stream ---------------------------------------------------------------------------------------
+class DirectRccl:
+    """An RCCL communicator driven through its C API, so that a collective is queued ON THE STREAM THE RENDER IS ON.
+
+    torch.distributed runs its collectives on a stream of its own that waits for an event on the caller's stream.  On
+    MI355X that wait - a barrier packet in whichever hardware queue the foreign stream shares with one of the library's
+    streams - holds the next frame's coarse levels back until this frame has finished: measured on one GPU with a stand-in
+    (tools/fifth_stream.py: a stream that only WAITS for the frame's end), the pipelined frame rate halves (1.02 -> 2.05 ms per
+    frame).  Queued on the render's own stream the collective orders itself after the frame without any cross-stream wait.
+
+    rank 0 creates the unique id; `bcast_bytes(b, src)` hands it to the other ranks (torch.distributed's broadcast of a byte
+    tensor in bench.py).  One communicator per process / device, like the torch process group beside it."""
+    INT32, SUM = 2, 0            # ncclInt32, ncclSum (rccl.h)
+
+    @staticmethod
+    def probe(lib_path=None):
+        """load the library and look the entry points up, nothing else (raises if that fails): what every rank checks before
+        any of them enters ncclCommInitRank, which is a collective"""
+        DirectRccl(0, 0, lib_path=lib_path)
+
+    def __init__(self, rank, world, bcast_bytes=None, lib_path=None):
+        import ctypes as C
+        import os
+        self.C = C
+        self.comm = None
+        cands = [lib_path] if lib_path else []
+        try:
+            import torch
+            cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))     # the one torch itself loaded
+        except Exception:
+            pass
+        cands += ["librccl.so", "/opt/rocm/lib/librccl.so"]
+        self.lib = None
+        for c in cands:
+            try:
+                self.lib = C.CDLL(c)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise OSError("librccl.so not found")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        L = self.lib
+        L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        L.ncclReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclGetErrorString.restype = C.c_char_p
+        for f in (L.ncclGetUniqueId, L.ncclCommInitRank, L.ncclReduce, L.ncclGather, L.ncclCommDestroy):
+            f.restype = C.c_int
+        if world == 0:          # probe()
+            return
+        uid = UniqueId()
+        if rank == 0:
+            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        raw = C.string_at(C.addressof(uid), 128)
+        if world > 1:
+            if bcast_bytes is None:
+                raise ValueError("a broadcast for the unique id is needed with more than one rank")
+            raw = bcast_bytes(raw, 0)
+            C.memmove(C.addressof(uid), raw, 128)
+        self.rank, self.world = rank, world
+        self.comm = C.c_void_p()
+        self._check(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+
+    def _check(self, r, what):
+        if r != 0:
+            raise RuntimeError(f"{what}: {self.lib.ncclGetErrorString(r).decode()}")
+
+    def reduce_sum(self, t, dst, stream):
+        """in-place integer SUM of the int32 tensor `t` onto rank dst, queued on `stream` (a raw hipStream_t)"""
+        self._check(self.lib.ncclReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.INT32, self.SUM, dst, self.comm, stream), "ncclReduce")
+
+    def gather(self, send, recv, dst, stream):
+        """every rank's `send` (int32, same size) into `recv` on rank dst ([world * send.numel()], None elsewhere), on `stream`"""
+        self._check(self.lib.ncclGather(send.data_ptr(), recv.data_ptr() if recv is not None else None, send.numel(), self.INT32, dst,
+                                        self.comm, stream), "ncclGather")
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+_direct = None
+
+
+def use_direct_rccl(comm):
+    """From here on combine / gather_blocks queue their collective through `comm` (a DirectRccl) on torch's current stream."""
+    global _direct
+    _direct = comm
+
+
 def combine(out, dst=0):
     """Partition A: sum the ranks' partial images (int32 view of GeometryPixel) onto rank `dst`.
     `out` is a torch tensor; a no-op for a single process."""
     import torch.distributed as dist
+    if _direct is not None and _direct.world > 1:
+        import torch
+        _direct.reduce_sum(out, dst, torch.cuda.current_stream(out.device).cuda_stream)
+        return out
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
     return out
@@ -99,7 +200,11 @@ def gather_blocks(out, image_depth, split, merge, dst=0):
     n_mine = (y1 - y0) * (x1 - x0)
     if n_mine:
         send[:n_mine] = out[y0:y1, x0:x1].reshape(n_mine, 4)
-    if world > 1:
+    if world > 1 and _direct is not None and _direct.world == world:
+        recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device) if rank == dst else None
+        _direct.gather(send, recv, dst, torch.cuda.current_stream(send.device).cuda_stream)
+        parts = [recv[r] for r in range(world)] if rank == dst else None
+    elif world > 1:
         parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
         dist.gather(send, parts, dst=dst)
     else:

@@ -186,3 +186,33 @@ def test_device_blocks_merge_to_the_frame(split, model):
     D.assemble_blocks(parts, out, rects, split, n, lambda a, b, d: F.merge_depth(a, b, d, hip=shape.hip))
     shape.hip.sync()
     assert torch.equal(out, full), f"{int((out != full).any(dim=2).sum())} pixels differ"
+
+
+def test_direct_rccl_library_loads():
+    """bench.py's ranks agree on this before any of them enters ncclCommInitRank (a collective): the library loads through
+    ctypes and exports the six entry points DirectRccl binds"""
+    D.DirectRccl.probe()
+
+
+@pytest.mark.gpu
+def test_direct_rccl_single_rank_on_the_callers_stream():
+    """The ctypes plumbing of DirectRccl (unique id by value, datatype / op codes, raw stream handle) on a communicator of
+    one rank: SUM-reduce and gather of int32 words queued on a non-default torch stream behind the kernel that produces them."""
+    import torch
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    comm = D.DirectRccl(0, 1)
+    try:
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            t = torch.arange(-5000, 5000, dtype=torch.int32, device=dev) * 200001        # wraps like the pixel words do
+            want = t.clone()
+            comm.reduce_sum(t, 0, torch.cuda.current_stream(dev).cuda_stream)
+            send = torch.arange(4 * 777, dtype=torch.int32, device=dev).reshape(777, 4)
+            recv = torch.full((1, 777, 4), -1, dtype=torch.int32, device=dev)
+            comm.gather(send, recv, 0, torch.cuda.current_stream(dev).cuda_stream)
+        s.synchronize()
+        assert torch.equal(t, want)
+        assert torch.equal(recv[0], send)
+    finally:
+        comm.close()
