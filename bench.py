@@ -90,8 +90,29 @@ def main():
                 t = torch.tensor(list(raw), dtype=torch.uint8, device=dev) if rank == src else torch.zeros(len(raw), dtype=torch.uint8, device=dev)
                 dist.broadcast(t, src=src)
                 return bytes(t.cpu().tolist())
-            use_direct_rccl(DirectRccl(rank, world, bcast))
-            direct_note = "RCCL C API on the render's stream (fidget_amd.dist.DirectRccl)"
+            # one trial of both collectives, checked, before the timed loops rely on them
+            try:
+                comm = DirectRccl(rank, world, bcast)
+                raw = torch.cuda.current_stream(dev).cuda_stream
+                t = torch.full((4096,), rank + 1, dtype=torch.int32, device=dev)
+                comm.reduce_sum(t, 0, raw)
+                send = torch.full((1024, 4), 7 * rank + 3, dtype=torch.int32, device=dev)
+                recv = torch.zeros((world, 1024, 4), dtype=torch.int32, device=dev) if rank == 0 else None
+                comm.gather(send, recv, 0, raw)
+                torch.cuda.synchronize(dev)
+                trial_ok = 1
+                if rank == 0:
+                    want = torch.arange(world, dtype=torch.int32, device=dev) * 7 + 3
+                    trial_ok = int(bool((t == world * (world + 1) // 2).all()) and bool((recv == want[:, None, None]).all()))
+            except Exception:       # noqa: BLE001
+                trial_ok = 0
+            flag = torch.tensor([trial_ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                use_direct_rccl(comm)
+                direct_note = "RCCL C API on the render's stream (fidget_amd.dist.DirectRccl)"
+            else:
+                direct_note = "torch.distributed collectives (the trial of the direct RCCL communicator failed)"
         elif direct_note is None:
             direct_note = "torch.distributed collectives (FHIP_NO_DIRECT_RCCL or another rank could not load librccl)"
 
