@@ -214,6 +214,23 @@ def gather_blocks(out, image_depth, split, merge, dst=0):
     return assemble_blocks(parts, out, rects, split, image_depth, merge)
 
 
+def gather_frames(out, recv, dst=0):
+    """Partition C (frame-level sharding of a SEQUENCE of frames): every rank has rendered a whole frame of its own into `out`
+    ([H, W, 4] int32); rank `dst` collects them into `recv` ([world, H, W, 4], None elsewhere) - frame r of the group of
+    `world` consecutive frames comes from rank r.  No merge rule: the frames are independent."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if world > 1 and _direct is not None and _direct.world == world:
+        import torch
+        _direct.gather(out, recv if rank == dst else None, dst, torch.cuda.current_stream(out.device).cuda_stream)
+    elif world > 1:
+        dist.gather(out, [recv[r] for r in range(world)] if rank == dst else None, dst=dst)
+    elif recv is not None:
+        recv[0].copy_(out)
+    return recv
+
+
 def assemble_blocks(parts, out, rects, split, image_depth, merge):
     """rank-0 half of gather_blocks: parts[r] = block r's rectangle as [area, 4] words (padded), rects[r] its pixel range"""
     world = len(parts)

@@ -156,6 +156,42 @@ def test_gather_blocks_two_ranks_gloo(tmp_path, oracle_mod, split):
     mp.spawn(_worker_blocks, args=(2, port, path, split, SIZE), nprocs=2, join=True)
 
 
+def _worker_frames(rank, world, port):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = (torch.arange(40 * 24 * 4, dtype=torch.int32).reshape(40, 24, 4) * (rank + 3)) ^ (rank << 20)
+    recv = torch.full((world, 40, 24, 4), -1, dtype=torch.int32) if rank == 0 else None
+    D.gather_frames(mine, recv, dst=0)
+    ok = torch.tensor([1])
+    if rank == 0:
+        want = torch.stack([(torch.arange(40 * 24 * 4, dtype=torch.int32).reshape(40, 24, 4) * (r + 3)) ^ (r << 20) for r in range(world)])
+        ok[0] = int(torch.equal(recv, want))
+    dist.broadcast(ok, src=0)
+    dist.destroy_process_group()
+    assert ok.item() == 1
+
+
+def test_gather_frames_two_ranks_gloo():
+    """partition C: whole frames, one per rank, collected on rank 0 in rank order"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_frames, args=(2, port), nprocs=2, join=True)
+
+
+def test_gather_frames_single_process():
+    import torch
+    mine = torch.arange(6 * 5 * 4, dtype=torch.int32).reshape(6, 5, 4)
+    recv = torch.zeros((1, 6, 5, 4), dtype=torch.int32)
+    D.gather_frames(mine, recv)
+    assert torch.equal(recv[0], mine)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("split", [(2, 2, 2), (2, 1, 1), (1, 1, 2), (2, 2, 1), (1, 2, 4)])
 @pytest.mark.parametrize("model", ["colonnade.vm", "prospero.vm"])
