@@ -51,7 +51,7 @@ EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
-    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
@@ -150,6 +150,9 @@ def lib():
             "fhip_mesh_counts": (None, [vp, vp]), "fhip_mesh_leaves": (None, [vp, vp]),
             "fhip_mesh_build": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(vp)]),
             "fhip_mesh_vertices": (None, [vp, vp]), "fhip_mesh_triangles": (None, [vp, vp]),
+            "fhip_mesh_sample_part": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp)]),
+            "fhip_mesh_part_bytes": (C.c_uint64, [vp]), "fhip_mesh_part_export": (None, [vp, vp]),
+            "fhip_mesh_merge": (i32, [vp, vp, vp, u32, vp, C.POINTER(vp)]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
             "fhip_debug_stats": (i32, [vp, vp]),
@@ -846,6 +849,59 @@ def debug_walk_dual(cells, root, verts, parallel):
 def mesh(shape, depth, world_to_model=None, vars=None):
     """fidget_mesh::Octree::build(...).walk_dual(): (triangles [n, 3] uint64, vertices [m, 3] float32, counts)"""
     return mesh_sample(shape, depth, world_to_model, vars, _build=True)
+
+
+def mesh_part(shape, depth, part, n_parts, world_to_model=None, vars=None, alloc=None):
+    """The device side of a mesh build for part `part` of `n_parts` (the root's octants o with o * n_parts // 8 == part;
+    fhip_mesh_sample_part), as the flat uint8 buffer fhip_mesh_part_export writes: what a rank sends to the merging rank.
+    `alloc(nbytes)` -> writable uint8 array to export into (shared memory, say); default: a fresh numpy array."""
+    hip = shape.hip
+    w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    vk, vv = _var_arrays(shape, vars)
+    ax = None
+    if shape._vars is not None:
+        ax = np.array(shape._vars, dtype=np.int32)
+        vk = np.array([shape._named_slot(k) for k in (vars or {})], dtype=np.uint64)
+    h = C.c_void_p()
+    st = lib().fhip_mesh_sample_part(hip._h, shape._h, depth, _p(w2m), _p(ax), _p(vk), _p(vv), len(vk), part, n_parts, C.byref(h))
+    if st == 4:
+        raise ValueError("MissingVar")
+    hip.check(st)
+    try:
+        n = int(lib().fhip_mesh_part_bytes(h))
+        buf = np.zeros(n, np.uint8) if alloc is None else alloc(n)
+        assert buf.dtype == np.uint8 and buf.size == n and buf.flags.c_contiguous
+        lib().fhip_mesh_part_export(h, buf.ctypes.data_as(C.c_void_p))
+    finally:
+        lib().fhip_mesh_free(h)
+    return buf
+
+
+def mesh_merge(parts, world_to_model=None, hip=None):
+    """fhip_mesh_merge: the buffers of all parts (parts[k] = mesh_part(.., k, len(parts))) -> (triangles, vertices, counts),
+    the mesh of `mesh()` on one GPU.  `hip`: a context for the error text only (no device work)."""
+    parts = [np.ascontiguousarray(b, np.uint8) for b in parts]
+    w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
+    ptrs = (C.c_void_p * len(parts))(*[b.ctypes.data for b in parts])
+    sizes = np.array([b.size for b in parts], np.uint64)
+    h = C.c_void_p()
+    st = lib().fhip_mesh_merge(hip._h if hip is not None else None, ptrs, _p(sizes), len(parts), _p(w2m), C.byref(h))
+    if st:
+        if hip is not None:
+            hip.check(st)
+        raise RuntimeError(f"fhip_mesh_merge: status {st}")
+    try:
+        c = np.zeros(8, np.uint64)
+        lib().fhip_mesh_counts(h, _p(c))
+        verts = np.zeros((int(c[6]), 3), np.float32)
+        tris = np.zeros((int(c[7]), 3), np.uint64)
+        if len(verts):
+            lib().fhip_mesh_vertices(h, _p(verts))
+        if len(tris):
+            lib().fhip_mesh_triangles(h, _p(tris))
+    finally:
+        lib().fhip_mesh_free(h)
+    return tris, verts, {"cells": int(c[0]), "full": int(c[1]), "empty": int(c[2]), "leaf_cells": int(c[3]), "levels": int(c[5])}
 
 
 def mesh_sample(shape, depth, world_to_model=None, vars=None, _build=False):

@@ -1613,7 +1613,15 @@ struct fhip_mesh {
         FhMeshLeaf* p = nullptr;
         size_t n = 0;
         bool borrowed = false;      // the context's cached area (fhip_mesh_build): not kept with the mesh
-        const FhMeshLeaf& operator[](size_t i) const { return p[i]; }
+        // fhip_mesh_merge: the records stay where the parts' buffers hold them; segment k covers records seg_start[k] .. seg_start[k + 1] - 1
+        std::vector<const FhMeshLeaf*> seg_p;
+        std::vector<size_t> seg_start;
+        const FhMeshLeaf& operator[](size_t i) const {
+            if (seg_p.empty()) return p[i];
+            size_t k = 0;
+            while (k + 1 < seg_p.size() && i >= seg_start[k + 1]) k++;
+            return seg_p[k][i - seg_start[k]];
+        }
         const FhMeshLeaf* data() const { return p; }
         size_t size() const { return n; }
         ~PinnedLeaves() { if (p && !borrowed) (void)hipHostFree(p); }
@@ -1627,6 +1635,7 @@ struct fhip_mesh {
     std::vector<fhmesh::V3> vertices;                    // fhip_mesh_build: Mesh::vertices
     std::vector<std::array<uint64_t, 3>> triangles;      // ... Mesh::triangles
     uint64_t octree_cells = 0, octree_verts = 0;
+    uint32_t depth = 0, part = 0, n_parts = 1;           // fhip_mesh_sample_part: which of the root's octants this one covers
 };
 // Assembly of the octree from the device's results, as Octree::recurse unwinds (octree.rs:556-583), then Octree::walk_dual
 struct MeshAssembler {
@@ -1763,11 +1772,23 @@ struct ParallelMeshAssembler {
         return root;
     }
 };
+// the root's octants part `part` of `n_parts` evaluates: octant o belongs to part o * n_parts / 8 (8 parts: one octant each, as
+// Octree::build_inner_mt hands the root's children to its workers, octree.rs:109-123; 2 parts: the z halves)
+static uint32_t mesh_part_mask(uint32_t part, uint32_t n_parts) {
+    uint32_t m = 0;
+    for (uint32_t o = 0; o < 8; o++) if (o * n_parts / 8 == part) m |= 1u << o;
+    return m;
+}
+struct MeshTimes { bool on; double t_start, t_cells, t_leaf, t_copy; uint32_t n_leaf_cells; };
+static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T);
+enum MeshMode { MESH_SAMPLE, MESH_BUILD, MESH_PART };
 static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
-                            const uint64_t* var_keys, const float* var_values, uint32_t n_vars, bool assemble, fhip_mesh** out) {
+                            const uint64_t* var_keys, const float* var_values, uint32_t n_vars, MeshMode mode, uint32_t part, uint32_t n_parts, fhip_mesh** out) {
     if (!out) return FHIP_ERR_BAD_TAPE;
     *out = nullptr;
+    const bool assemble = mode == MESH_BUILD, keep = mode != MESH_SAMPLE;
     if (depth > 20) return fail(ctx, FHIP_ERR_UNSUPPORTED, "octree depth above 20");
+    if (n_parts < 1 || n_parts > 8 || part >= n_parts) return fail(ctx, FHIP_ERR_UNSUPPORTED, "mesh parts: 1..8, part < n_parts");
     const fh::HostTape& t = tape->t;
     if (t.n_outputs != 1) return fail(ctx, FHIP_ERR_BAD_TAPE, "shape tapes have exactly one output");
     (void)hipSetDevice(ctx->device);
@@ -1792,6 +1813,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         attr_done = true;
     }
     fhip_mesh* M = new fhip_mesh();
+    M->depth = depth; M->part = part; M->n_parts = n_parts;
     const bool times = getenv("FHIP_MESH_TIMES") != nullptr;       // diagnostic: phase wall times on stderr
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
@@ -1814,20 +1836,22 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         const uint32_t n = (uint32_t)n64;
         MESH_TRY(bufs[cur ^ 1].ensure((size_t)n * sizeof(FhMeshCell)));
         MESH_TRY(hipMemsetAsync(counters.p, 0, 16, ctx->stream));
-        if (assemble) { MESH_TRY(d_cls.ensure(n)); MESH_TRY(d_slot.ensure((size_t)n * 4)); }
+        if (keep) { MESH_TRY(d_cls.ensure(n)); MESH_TRY(d_slot.ensure((size_t)n * 4)); }
+        const uint32_t child_mask = (d == 1 && n_parts > 1) ? mesh_part_mask(part, n_parts) : 0xFFu;      // (level 1 = the root's 8 children)
         hipLaunchKernelGGL(fhm::k_mesh_cells, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n, d == 0 ? 0 : 1,
-                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n, assemble ? (uint8_t*)d_cls.p : nullptr, assemble ? (uint32_t*)d_slot.p : nullptr);
+                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n, keep ? (uint8_t*)d_cls.p : nullptr, keep ? (uint32_t*)d_slot.p : nullptr, child_mask);
         MESH_TRY(hipGetLastError());
         uint32_t c[4];
         MESH_TRY(hipMemcpyAsync(c, counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (assemble) {
+        if (keep) {
             M->cls.emplace_back(n); M->slot.emplace_back(n);
             MESH_TRY(hipMemcpyAsync(M->cls.back().data(), d_cls.p, n, hipMemcpyDeviceToHost, ctx->stream));
             MESH_TRY(hipMemcpyAsync(M->slot.back().data(), d_slot.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
         MESH_TRY(hipStreamSynchronize(ctx->stream));
-        M->cells_evaluated += n; M->full += c[1]; M->empty += c[2];
-        M->per_level.push_back(n);
+        const uint32_t n_here = child_mask == 0xFFu ? n : (uint32_t)__builtin_popcount(child_mask);
+        M->cells_evaluated += n_here; M->full += c[1]; M->empty += c[2];
+        M->per_level.push_back(n_here);
         cur ^= 1;
         n_in = c[0];
         if (d == depth) n_leaf_cells = c[0];
@@ -1882,8 +1906,20 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
 #undef MESH_TRY
     cleanup();
     t_copy = now() - t_start - t_cells - t_leaf;
+    MeshTimes MT{times, t_start, t_cells, t_leaf, t_copy, n_leaf_cells};
+    if (assemble) mesh_assemble(M, depth, P.has_mat != 0, P.mat, MT);
+    else if (times)
+        fprintf(stderr, "fhip mesh depth %u (part %u of %u): cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s\n", depth, part, n_parts,
+                t_cells, (unsigned long long)M->cells_evaluated, t_leaf, n_leaf_cells, t_copy);
+    *out = M;
+    return FHIP_OK;
+}
+// Octree assembly (cell collapse included) and dual walk on the host's threads, from the classes / slots / leaf records in M
+static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T) {
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     double t_asm = 0, t_walk = 0;
-    if (assemble) {
+    {
         const float rb[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
         fhmesh::Hermite h;
         // (a level the recursion never reached - everything above it was decided - has no arrays: only levels 0 .. cls.size()-1 are indexed)
@@ -1899,40 +1935,197 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             SA.o.root = SA.build(0, 0, rb, &h);
             A.o = std::move(SA.o);
         }
-        if (P.has_mat)       // octree.rs:58-65: vertices back to model space (nalgebra transform_point)
+        if (has_mat)       // octree.rs:58-65: vertices back to model space (nalgebra transform_point)
             for (auto& v : A.o.verts) {
                 const float x = v.x, y = v.y, z = v.z;
-                const float n = ((P.mat[12] * x + P.mat[13] * y) + P.mat[14] * z) + P.mat[15];
-                float a = ((P.mat[0] * x + P.mat[1] * y) + P.mat[2] * z) + P.mat[3];
-                float b = ((P.mat[4] * x + P.mat[5] * y) + P.mat[6] * z) + P.mat[7];
-                float c = ((P.mat[8] * x + P.mat[9] * y) + P.mat[10] * z) + P.mat[11];
+                const float n = ((mat[12] * x + mat[13] * y) + mat[14] * z) + mat[15];
+                float a = ((mat[0] * x + mat[1] * y) + mat[2] * z) + mat[3];
+                float b = ((mat[4] * x + mat[5] * y) + mat[6] * z) + mat[7];
+                float c = ((mat[8] * x + mat[9] * y) + mat[10] * z) + mat[11];
                 if (n != 0.0f) { a = a / n; b = b / n; c = c / n; }
                 v.x = a; v.y = b; v.z = c;
             }
-        t_asm = now() - t_start - t_cells - t_leaf - t_copy;
-        M->leaves.p = nullptr; M->leaves.n = 0;      // (borrowed from the context: gone with the assembly)
+        t_asm = now() - t0;
+        M->leaves.p = nullptr; M->leaves.n = 0;      // (borrowed from the context or from the parts' buffers: gone with the assembly)
+        M->leaves.seg_p.clear(); M->leaves.seg_start.clear();
         fhmesh::ParallelWalker W(A.o);
         W.run();
-        t_walk = now() - t_start - t_cells - t_leaf - t_copy - t_asm;
+        t_walk = now() - t0 - t_asm;
         M->octree_cells = A.o.cells.size(); M->octree_verts = A.o.verts.size();
         M->vertices.swap(W.vertices);
         M->triangles.swap(W.triangles);
     }
-    if (times)
+    if (T.on)
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
-                depth, t_cells, (unsigned long long)M->cells_evaluated, t_leaf, n_leaf_cells, t_copy, t_asm, t_walk, now() - t_start);
-    *out = M;
-    return FHIP_OK;
+                depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, T.t_copy, t_asm, t_walk, now() - T.t_start);
 }
 fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
-    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, false, out);
+    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, MESH_SAMPLE, 0, 1, out);
 }
 // Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225): fhip_mesh_sample, then the octree assembled from the device's
 // results (cell collapse included) and the dual walk on the host
 fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
-    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, true, out);
+    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, MESH_BUILD, 0, 1, out);
+}
+// ---- the build sharded by the root's octants (Octree::build_inner_mt, octree.rs:94-210, across GPUs): every part runs the
+// device side for its octants; the parts' results travel as flat buffers to one place, where fhip_mesh_merge puts the level
+// arrays together (slots of later parts shifted by the ambiguous cells before them) and runs assembly and dual walk
+fhip_status fhip_mesh_sample_part(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                                  const uint64_t* var_keys, const float* var_values, uint32_t n_vars, uint32_t part, uint32_t n_parts, fhip_mesh** out) {
+    return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, MESH_PART, part, n_parts, out);
+}
+namespace {
+struct MeshPartHeader {       // followed by n_levels u64 level sizes, then per level {cls bytes padded to 8, slot words padded to 8}, then the leaf records
+    uint32_t magic, version, depth, part, n_parts, n_levels, leaf_size, pad;
+    uint64_t n_leaves, cells_evaluated, full, empty;
+};
+constexpr uint32_t MESH_PART_MAGIC = 0x504d4846u;     // "FHMP"
+inline uint64_t pad8(uint64_t n) { return (n + 7) & ~7ull; }
+}
+uint64_t fhip_mesh_part_bytes(const fhip_mesh* m) {
+    uint64_t n = sizeof(MeshPartHeader) + 8ull * m->cls.size();
+    for (auto& c : m->cls) n += pad8(c.size()) + pad8(4ull * c.size());
+    return n + (uint64_t)m->leaves.size() * sizeof(FhMeshLeaf);
+}
+void fhip_mesh_part_export(const fhip_mesh* m, void* out) {
+    char* p = (char*)out;
+    MeshPartHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = MESH_PART_MAGIC; h.version = 1; h.depth = m->depth; h.part = m->part; h.n_parts = m->n_parts; h.n_levels = (uint32_t)m->cls.size();
+    h.leaf_size = (uint32_t)sizeof(FhMeshLeaf); h.n_leaves = m->leaves.size(); h.cells_evaluated = m->cells_evaluated; h.full = m->full; h.empty = m->empty;
+    memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    for (auto& c : m->cls) { const uint64_t n = c.size(); memcpy(p, &n, 8); p += 8; }
+    for (size_t d = 0; d < m->cls.size(); d++) {
+        const size_t n = m->cls[d].size();
+        memset(p, 0, pad8(n)); memcpy(p, m->cls[d].data(), n); p += pad8(n);
+        memset(p, 0, pad8(4 * n)); memcpy(p, m->slot[d].data(), 4 * n); p += pad8(4 * n);
+    }
+    if (m->leaves.size()) memcpy(p, m->leaves.data(), m->leaves.size() * sizeof(FhMeshLeaf));
+}
+fhip_status fhip_mesh_merge(fhip_ctx* ctx, const void* const* parts, const uint64_t* part_bytes, uint32_t n_parts, const float* world_to_model, fhip_mesh** out) {
+    if (!out) return FHIP_ERR_BAD_TAPE;
+    *out = nullptr;
+    if (!parts || !part_bytes || n_parts < 1 || n_parts > 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "mesh merge: 1..8 parts");
+    struct View { MeshPartHeader h; const uint64_t* level_n; std::vector<const uint8_t*> cls; std::vector<const uint32_t*> slot; const FhMeshLeaf* leaves; };
+    std::vector<View> V(n_parts);
+    for (uint32_t k = 0; k < n_parts; k++) {       // part k of the array must BE part k
+        const char* p = (const char*)parts[k];
+        if (!p || part_bytes[k] < sizeof(MeshPartHeader)) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: short part");
+        View& v = V[k];
+        memcpy(&v.h, p, sizeof(v.h));
+        if (v.h.magic != MESH_PART_MAGIC || v.h.version != 1 || v.h.leaf_size != sizeof(FhMeshLeaf)) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: not a mesh part of this library");
+        if (v.h.n_parts != n_parts || v.h.part != k || v.h.depth != V[0].h.depth || v.h.n_levels < 1 || v.h.n_levels > 21)
+            return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: parts do not belong together (part index, part count or depth)");
+        uint64_t need = sizeof(MeshPartHeader) + 8ull * v.h.n_levels;
+        if (part_bytes[k] < need) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: short part");
+        v.level_n = (const uint64_t*)(p + sizeof(MeshPartHeader));
+        const char* q = p + need;
+        for (uint32_t d = 0; d < v.h.n_levels; d++) {
+            const uint64_t n = v.level_n[d];
+            if (n > (1ull << 30)) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: level size");
+            need += pad8(n) + pad8(4 * n);
+            if (part_bytes[k] < need) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: short part");
+            v.cls.push_back((const uint8_t*)q); q += pad8(n);
+            v.slot.push_back((const uint32_t*)q); q += pad8(4 * n);
+        }
+        if (part_bytes[k] < need + v.h.n_leaves * sizeof(FhMeshLeaf)) return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: short part");
+        v.leaves = (const FhMeshLeaf*)q;
+    }
+    const uint32_t depth = V[0].h.depth;
+    fhip_mesh* M = new fhip_mesh();
+    M->depth = depth;
+    // the root: evaluated by every part, with the same result
+    for (uint32_t k = 0; k < n_parts; k++)
+        if (V[k].level_n[0] != 1 || V[k].cls[0][0] != V[0].cls[0][0]) { delete M; return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: the parts disagree about the root cell"); }
+    const bool whole = n_parts == 1 || V[0].h.n_levels == 1;       // nothing below the root (decided, or a leaf at depth 0): part 0 has it all
+    const uint32_t np = whole ? 1 : n_parts;
+    uint32_t levels = 0;
+    for (uint32_t k = 0; k < np; k++) levels = std::max(levels, V[k].h.n_levels);
+    M->cells_evaluated = 1; M->full = 0; M->empty = 0;
+    for (uint32_t k = 0; k < np; k++) { M->cells_evaluated += V[k].h.cells_evaluated - 1; M->full += V[k].h.full; M->empty += V[k].h.empty; }
+    if (!whole && V[0].cls[0][0] != 3) { delete M; return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: levels below a decided root"); }
+    std::vector<uint64_t> shift(np, 0);       // slots of part k at the level before: + shift[k]
+    M->cls.resize(levels); M->slot.resize(levels);
+    for (uint32_t d = 0; d < levels; d++) {
+        std::vector<uint8_t>& C = M->cls[d];
+        std::vector<uint32_t>& S = M->slot[d];
+        std::vector<uint64_t> amb(np, 0);
+        if (d == 0) { C.assign(1, V[0].cls[0][0]); S.assign(1, V[0].slot[0][0]); if (!whole) S[0] = 0; amb.assign(np, 0); }
+        else if (d == 1 && !whole) {     // the root's eight children, each from the part that owns it
+            C.assign(8, 0); S.assign(8, 0xFFFFFFFFu);
+            for (uint32_t k = 0; k < np; k++) {
+                if (V[k].h.n_levels < 2 || V[k].level_n[1] != 8) { delete M; return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: a part without the root's children"); }
+                const uint32_t mask = mesh_part_mask(k, n_parts);
+                for (uint32_t o = 0; o < 8; o++) {
+                    const uint8_t c = V[k].cls[1][o];
+                    if (((mask >> o) & 1u) != (c != 0 ? 1u : 0u)) { delete M; return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: a part covers the wrong octants"); }
+                    if (c == 3) amb[k]++;
+                }
+            }
+            uint64_t off = 0;
+            for (uint32_t k = 0; k < np; k++) {
+                for (uint32_t o = 0; o < 8; o++) if (V[k].cls[1][o]) { C[o] = V[k].cls[1][o]; S[o] = V[k].cls[1][o] == 3 ? (uint32_t)(off + V[k].slot[1][o]) : 0xFFFFFFFFu; }
+                shift[k] = off; off += amb[k];
+            }
+            continue;
+        } else {
+            // children of the level above's ambiguous cells: part k's array sits at 8 * (its slots' shift at the level above)
+            uint64_t total = 0;
+            for (uint32_t k = 0; k < np; k++) total += V[k].h.n_levels > d ? V[k].level_n[d] : 0;
+            C.resize(total); S.resize(total);
+            // (two passes over the parts, each on the host's threads: the ambiguous cells of every part, then the copies with
+            //  the slots shifted by the ambiguous cells of the parts before)
+            std::vector<uint64_t> n_of(np, 0), at_of(np, 0), next_shift(np, 0);
+            uint64_t at = 0;
+            for (uint32_t k = 0; k < np; k++) {
+                n_of[k] = V[k].h.n_levels > d ? V[k].level_n[d] : 0;
+                if (at != shift[k] * 8 && n_of[k]) { delete M; return fail(ctx, FHIP_ERR_BAD_TAPE, "mesh merge: level arrays do not line up"); }
+                at_of[k] = at; at += n_of[k];
+            }
+            fhmesh::parallel_for(np, [&](size_t k) {
+                uint64_t a = 0;
+                const uint8_t* c = n_of[k] ? V[k].cls[d] : nullptr;
+                for (uint64_t i = 0; i < n_of[k]; i++) a += c[i] == 3;
+                amb[k] = a;
+            });
+            uint64_t off = 0;
+            for (uint32_t k = 0; k < np; k++) { next_shift[k] = off; off += amb[k]; }
+            constexpr uint64_t CHUNK = 1u << 20;
+            std::vector<std::array<uint64_t, 3>> jobs;      // part, first cell, cells
+            for (uint32_t k = 0; k < np; k++) for (uint64_t i = 0; i < n_of[k]; i += CHUNK) jobs.push_back({k, i, std::min(CHUNK, n_of[k] - i)});
+            fhmesh::parallel_for(jobs.size(), [&](size_t j) {
+                const uint32_t k = (uint32_t)jobs[j][0];
+                const uint8_t* c = V[k].cls[d] + jobs[j][1];
+                const uint32_t* sl = V[k].slot[d] + jobs[j][1];
+                uint8_t* co = C.data() + at_of[k] + jobs[j][1];
+                uint32_t* so = S.data() + at_of[k] + jobs[j][1];
+                const uint32_t sh = (uint32_t)next_shift[k];
+                for (uint64_t i = 0; i < jobs[j][2]; i++) { co[i] = c[i]; so[i] = c[i] == 3 ? sh + sl[i] : 0xFFFFFFFFu; }
+            });
+            shift = next_shift;
+            continue;
+        }
+    }
+    // leaf records: in part order (= slot order at the leaf depth), left where they are
+    uint64_t n_leaves = 0;
+    M->leaves.seg_start.push_back(0);
+    for (uint32_t k = 0; k < np; k++) {
+        M->leaves.seg_p.push_back(V[k].leaves);
+        n_leaves += V[k].h.n_leaves;
+        M->leaves.seg_start.push_back(n_leaves);
+    }
+    M->leaves.n = n_leaves;
+    M->ambiguous_leaves = n_leaves;
+    for (uint32_t d = 0; d < levels; d++) M->per_level.push_back(M->cls[d].size());
+    float mat[16];
+    bool ident = true;
+    if (world_to_model) for (int i = 0; i < 16; i++) { mat[i] = world_to_model[i]; ident &= world_to_model[i] == ((i % 5 == 0) ? 1.0f : 0.0f); }
+    MeshTimes MT{getenv("FHIP_MESH_TIMES") != nullptr, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), 0, 0, 0, (uint32_t)n_leaves};
+    mesh_assemble(M, depth, world_to_model && !ident, mat, MT);
+    *out = M;
+    return FHIP_OK;
 }
 void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_t* root, const float* verts, uint64_t n_verts, int parallel,
                           uint64_t counts[2], uint64_t* tris, float* verts_out) {

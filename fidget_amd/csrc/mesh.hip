@@ -57,11 +57,12 @@ __device__ __forceinline__ float lerp_pos(float lo, float hi, uint32_t p) {   //
 
 // interval evaluation + classification of the cells of one level.  expand: cell i is child (i & 7) of in[i >> 3]
 __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMeshCell* in, uint32_t n, int expand, FhMeshCell* out, uint32_t* counters /* amb, full, empty */,
-                                                      uint32_t out_cap, uint8_t* cls /* per cell: 1 empty 2 full 3 ambiguous */, uint32_t* slot /* of an ambiguous cell in out */) {
+                                                      uint32_t out_cap, uint8_t* cls /* per cell: 1 empty 2 full 3 ambiguous, 0 another part's */, uint32_t* slot /* of an ambiguous cell in out */,
+                                                      uint32_t child_mask /* expand: the corners evaluated here (0xFF but below the root of a sharded build) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.x * WAVE + lane;
-    const bool act = i < n;
+    const bool act = i < n && (!expand || ((child_mask >> (i & 7)) & 1u));
     FhMeshCell c;
     {
         const FhMeshCell p = in[expand ? min(i, n - 1) >> 3 : min(i, n - 1)];
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMes
         sl = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
         if (sl < out_cap) out[sl] = c;
     }
-    if (act && cls) { cls[i] = full ? 2 : (empty ? 1 : 3); slot[i] = sl; }
+    if (i < n && cls) { cls[i] = !act ? 0 : (full ? 2 : (empty ? 1 : 3)); slot[i] = sl; }
 }
 
 // f32 value of the tape at this lane's point (lanes evaluate different points of the same leaf)

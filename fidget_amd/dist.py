@@ -247,3 +247,112 @@ def assemble_blocks(parts, out, rects, split, image_depth, merge):
             merge(acc, parts[r][:n].contiguous(), image_depth)
         out[y0:y1, x0:x1] = acc.reshape(y1 - y0, x1 - x0, 4)
     return out
+
+
+# ---- the mesh build sharded by the root's octants (Mesh) --------------------------------------------------
+def mesh_part_octants(part, n_parts):
+    """the root's octants part `part` of `n_parts` evaluates (the rule of fhip_mesh_sample_part): o * n_parts // 8 == part"""
+    return [o for o in range(8) if o * n_parts // 8 == part]
+
+
+def gather_bytes(buf, dst=0, device=None):
+    """Variable-length uint8 buffers of all ranks -> list in rank order on rank `dst` (None elsewhere): lengths by one
+    all_gather, then one send / recv per rank (the gather of variable-length cells and vertices of SURVEY 8e).  `device`:
+    where the tensors of the exchange live (a CUDA device for the nccl backend, None = host for gloo)."""
+    import torch
+    import torch.distributed as dist
+    buf = np.ascontiguousarray(buf, np.uint8)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return [buf]
+    rank = dist.get_rank()
+    size = torch.tensor([buf.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    if rank == dst:
+        out = []
+        for r in range(world):
+            if r == dst:
+                out.append(buf)
+                continue
+            t = torch.empty(int(sizes[r].item()), dtype=torch.uint8, device=device)
+            if t.numel():
+                dist.recv(t, src=r)
+            out.append(t.cpu().numpy())
+        return out
+    if buf.size:
+        dist.send(torch.from_numpy(buf).to(device) if device is not None else torch.from_numpy(buf), dst=dst)
+    return None
+
+
+class _SharedParts:
+    """Transport of the parts between the processes of ONE node without a copy through the devices: every rank writes its
+    part into a POSIX shared-memory segment of its own, rank `dst` maps the others' segments and merges out of them."""
+
+    def __init__(self, tag):
+        self.tag, self.own, self.maps = tag, None, []
+
+    def name(self, rank):
+        return f"fhip_mesh_{self.tag}_{rank}"
+
+    def alloc(self, rank, nbytes):
+        from multiprocessing import shared_memory
+        self.own = shared_memory.SharedMemory(name=self.name(rank), create=True, size=max(int(nbytes), 1))
+        return np.frombuffer(self.own.buf, np.uint8, int(nbytes))
+
+    def attach(self, rank, nbytes):
+        from multiprocessing import shared_memory
+        m = shared_memory.SharedMemory(name=self.name(rank))
+        self.maps.append(m)
+        return np.frombuffer(m.buf, np.uint8, int(nbytes))
+
+    def close(self):
+        for m in self.maps:
+            m.close()
+        self.maps = []
+        if self.own is not None:
+            self.own.close()
+            self.own.unlink()
+            self.own = None
+
+
+def mesh_sharded(make_part, merge, dst=0, transport=None, device=None):
+    """Octree::build_inner_mt across the ranks (fidget-mesh/src/octree.rs:94-210): rank r runs the device side of the build
+    for its octants - `make_part(r, world, alloc)` returns the flat part buffer (fidget_amd.mesh_part; `alloc(nbytes)` hands
+    out the memory to write it into) - the buffers travel to rank `dst`, which calls `merge(parts)` (fidget_amd.mesh_merge)
+    and returns its result; the other ranks return None.  Transport "shm": shared memory (all ranks on one node - the
+    default when they are); "dist": gather_bytes over the process group.  More than 8 ranks: the ranks above 7 idle."""
+    import os
+    import socket
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    n_parts = min(world, 8)
+    if world == 1:
+        return merge([make_part(0, 1, lambda n: np.zeros(int(n), np.uint8))])
+    if transport is None:
+        hosts = [None] * world
+        dist.all_gather_object(hosts, socket.gethostname())
+        transport = "shm" if len(set(hosts)) == 1 else "dist"
+    if transport == "dist":
+        mine = make_part(rank, n_parts, lambda n: np.zeros(int(n), np.uint8)) if rank < n_parts else np.zeros(0, np.uint8)
+        parts = gather_bytes(mine, dst=dst, device=device)
+        return merge(parts[:n_parts]) if rank == dst else None
+    tag = [f"{os.getpid()}_{int.from_bytes(os.urandom(4), 'little')}"] if rank == dst else [None]
+    dist.broadcast_object_list(tag, src=dst)
+    shm = _SharedParts(tag[0])
+    mine = None
+    try:
+        mine = make_part(rank, n_parts, lambda n: shm.alloc(rank, n)) if rank < n_parts else np.zeros(0, np.uint8)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(mine.size))        # (also the barrier: every segment is written)
+        result = None
+        if rank == dst:
+            parts = [mine if r == rank else shm.attach(r, sizes[r]) for r in range(n_parts)]
+            result = merge(parts)
+            del parts
+        dist.barrier()                                         # the segments stay until the merge has read them
+        return result
+    finally:
+        mine = None          # (the arrays over a segment must be gone before it can be closed)
+        shm.close()

@@ -212,6 +212,21 @@ void fhip_mesh_free(fhip_mesh* mesh);
  *        mesh vertices, mesh triangles} */
 void fhip_mesh_counts(const fhip_mesh* mesh, uint64_t out[8]);
 void fhip_mesh_leaves(const fhip_mesh* mesh, void* out);
+/* The build sharded by the root's octants, as Octree::build_inner_mt hands the root's eight children to its workers
+ * (octree.rs:94-123) - here to up to eight GPUs.  fhip_mesh_sample_part runs the device side (cell classification, leaf
+ * sampling) for the octants o with o * n_parts / 8 == part (8 parts: one octant each; 2 parts: the z halves); every part
+ * evaluates the root cell itself.  Its results - per level the cells' classes and slots, and the leaf records - are written
+ * as one flat buffer by fhip_mesh_part_export (fhip_mesh_part_bytes long), which is what travels between processes.
+ * fhip_mesh_merge takes the buffers of ALL parts (parts[k] = part k), puts the level arrays together (build_inner_mt's index
+ * remapping, octree.rs:176-195: slots of later parts shifted by the ambiguous cells before them), and runs octree assembly
+ * (check_done on the merged tree, octree.rs:197-208) and the dual walk: the mesh is the one fhip_mesh_build gives on one GPU,
+ * vertex for vertex and triangle for triangle.  The buffers are only read during the call.  A merge needs no device. */
+fhip_status fhip_mesh_sample_part(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
+                                  const uint64_t* var_keys, const float* var_values, uint32_t n_vars, uint32_t part, uint32_t n_parts, fhip_mesh** out);
+uint64_t fhip_mesh_part_bytes(const fhip_mesh* mesh);
+void fhip_mesh_part_export(const fhip_mesh* mesh, void* out);
+fhip_status fhip_mesh_merge(fhip_ctx* ctx, const void* const* parts, const uint64_t* part_bytes, uint32_t n_parts, const float* world_to_model,
+                            fhip_mesh** out);
 
 /* ---- profiling ----------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a render is bracketed by HIP events on the context's

@@ -252,3 +252,126 @@ def test_direct_rccl_single_rank_on_the_callers_stream():
         assert torch.equal(recv[0], send)
     finally:
         comm.close()
+
+
+# ---- the mesh build sharded by the root's octants ----------------------------------------------------------------------
+def test_mesh_part_octants_partition_the_root():
+    for n in range(1, 9):
+        parts = [D.mesh_part_octants(k, n) for k in range(n)]
+        assert sorted(o for p in parts for o in p) == list(range(8)) and all(parts)
+    assert D.mesh_part_octants(1, 2) == [4, 5, 6, 7]         # two parts: the z halves
+    assert [D.mesh_part_octants(k, 8) for k in range(8)] == [[k] for k in range(8)]
+
+
+def _part_blob(depth, part, n_parts, levels, full=0, empty=0, cells=1):
+    """a part buffer in the layout of fhip_mesh_part_export, without leaf records: levels = [(classes, slots), ..]"""
+    hdr = np.zeros(8, np.uint32)
+    hdr[:] = [0x504d4846, 1, depth, part, n_parts, len(levels), 528, 0]
+    out = [hdr.tobytes(), np.array([0, cells, full, empty], np.uint64).tobytes(), np.array([len(c) for c, _ in levels], np.uint64).tobytes()]
+    for c, sl in levels:
+        cb = np.zeros((len(c) + 7) // 8 * 8, np.uint8)
+        cb[:len(c)] = c
+        sb = np.zeros((len(c) + 1) // 2 * 2, np.uint32)
+        sb[:len(c)] = sl
+        out += [cb.tobytes(), sb.tobytes()]
+    return np.frombuffer(b"".join(out), np.uint8).copy()
+
+
+def test_mesh_merge_on_the_host():
+    """fhip_mesh_merge needs no device: hand-made parts without ambiguous leaves - a decided root; a root whose eight children
+    are decided, four by each of two parts - and what it must refuse"""
+    import fidget_amd as F
+    NO = 0xFFFFFFFF
+    tris, verts, counts = F.mesh_merge([_part_blob(3, 0, 1, [([2], [NO])], full=1)])
+    assert len(tris) == 0 and len(verts) == 0 and counts["cells"] == 1 and counts["full"] == 1
+    a = _part_blob(1, 0, 2, [([3], [0]), ([1, 2, 1, 2, 0, 0, 0, 0], [NO] * 8)], full=2, empty=2, cells=5)
+    b = _part_blob(1, 1, 2, [([3], [0]), ([0, 0, 0, 0, 2, 2, 1, 1], [NO] * 8)], full=2, empty=2, cells=5)
+    tris, verts, counts = F.mesh_merge([a, b])
+    assert len(tris) == 0 and counts == {"cells": 9, "full": 4, "empty": 4, "leaf_cells": 0, "levels": 2}
+    for bad in ([b, a],                                   # part k must be buffer k
+                [a],                                      # a part of two, alone
+                [a, a],
+                [a, b[:40]],                              # cut short
+                [a, _part_blob(1, 1, 2, [([3], [0]), ([0, 0, 0, 2, 2, 2, 1, 1], [NO] * 8)])],      # covers an octant of part 0
+                [a, _part_blob(2, 1, 2, [([3], [0]), ([0, 0, 0, 0, 2, 2, 1, 1], [NO] * 8)])],      # another depth
+                [a, _part_blob(1, 1, 2, [([2], [NO])])]):                                           # another root
+        with pytest.raises(RuntimeError):
+            F.mesh_merge(bad)
+    junk = a.copy()
+    junk[0] ^= 1
+    with pytest.raises(RuntimeError):
+        F.mesh_merge([junk, b])
+
+
+def _worker_mesh(rank, world, port, transport):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def make_part(r, n, alloc):
+        buf = alloc(1000 + 77 * r)
+        buf[:] = (np.arange(buf.size) * (r + 1) % 251).astype(np.uint8)
+        return buf
+
+    def merge(parts):
+        return [int(p.size) for p in parts], [int(np.asarray(p, np.uint64).sum()) for p in parts]
+
+    got = D.mesh_sharded(make_part, merge, dst=0, transport=transport)
+    ok = 1
+    if rank == 0:
+        want = [(np.arange(1000 + 77 * r) * (r + 1) % 251).astype(np.uint8) for r in range(world)]
+        ok = int(got == ([w.size for w in want], [int(w.astype(np.uint64).sum()) for w in want]))
+    else:
+        ok = int(got is None)
+    import torch
+    t = torch.tensor([ok])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    assert t.item() == 1
+
+
+@pytest.mark.parametrize("transport", ["shm", "dist", None])
+def test_mesh_sharded_protocol_two_ranks_gloo(transport):
+    """the parts' way to the merging rank: shared-memory segments (one node) and send / recv of variable-length buffers"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_mesh, args=(2, port, transport), nprocs=2, join=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("sphere", 0), ("sphere", 1), ("sphere", 5), ("colonnade.vm", 6), ("bear.vm", 5), ("gyroid-sphere.vm", 6)])
+def test_mesh_parts_merge_to_the_single_gpu_mesh(model, depth):
+    """fhip_mesh_sample_part for every part (one after the other on this GPU) + fhip_mesh_merge == fhip_mesh_build: same counters,
+    vertices and triangles, for 2, 3 and 8 parts"""
+    import fidget_amd as F
+    if model == "sphere":
+        c = F.Context()
+        x, y, z = c.x(), c.y(), c.z()
+        r = c.sqrt(c.add(c.add(c.square(c.sub(x, 0.1)), c.square(c.add(y, 0.05))), c.square(c.sub(z, 0.2))))
+        shape = F.Shape(c, c.sub(r, 0.6))
+    else:
+        shape = F.Shape.from_vm(os.path.join(ROOT, "models", model))
+    tris, verts, counts = F.mesh(shape, depth)
+    for n in (2, 3, 8):
+        parts = [F.mesh_part(shape, depth, k, n) for k in range(n)]
+        t2, v2, c2 = F.mesh_merge(parts, hip=shape.hip)
+        assert c2 == counts, (n, c2, counts)
+        assert np.array_equal(t2, tris) and np.array_equal(v2.view(np.uint32), verts.view(np.uint32)), n
+    if depth >= 5:
+        assert len(tris) > 100
+
+
+@pytest.mark.gpu
+def test_mesh_parts_with_a_camera():
+    """world_to_model goes to the parts (evaluation) and to the merge (vertices back to model space, octree.rs:58-65)"""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(os.path.join(ROOT, "models", "colonnade.vm"))
+    w2m = np.array([[0.5, 0, 0, 0.1], [0, 0.5, 0, -0.2], [0, 0, 0.5, 0.3], [0, 0, 0, 1]], np.float32)
+    tris, verts, counts = F.mesh(shape, 5, world_to_model=w2m)
+    parts = [F.mesh_part(shape, 5, k, 4, world_to_model=w2m) for k in range(4)]
+    t2, v2, c2 = F.mesh_merge(parts, world_to_model=w2m)
+    assert c2 == counts and np.array_equal(t2, tris) and np.array_equal(v2.view(np.uint32), verts.view(np.uint32)) and len(tris) > 100

@@ -20,6 +20,23 @@ for depth in depths:
     res[f"depth {depth}"] = {"s": dt, "triangles": len(tris), "vertices": len(verts), **counts}
     print(depth, res[f"depth {depth}"], flush=True)
     del tris, verts
+# the build sharded by the root's octants (fidget_amd.mesh_part / mesh_merge), its parts one after the other on this one GPU:
+# what each rank of an N-GPU build would spend on its part, and what the merging rank spends afterwards
+n_parts = int(os.environ.get("MESH_TIMES_PARTS", "0"))
+if n_parts > 1:
+    for depth in depths:
+        part_s, blobs = [], []
+        for k in range(n_parts):
+            t0 = time.perf_counter()
+            blobs.append(F.mesh_part(shape, depth, k, n_parts))
+            part_s.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        tris, verts, counts = F.mesh_merge(blobs, hip=hip)
+        merge_s = time.perf_counter() - t0
+        res[f"depth {depth}, {n_parts} parts"] = {"part_s": part_s, "part_bytes": [int(b.size) for b in blobs], "merge_s": merge_s,
+                                                "slowest_part_plus_merge_s": max(part_s) + merge_s, "triangles": len(tris), "vertices": len(verts), **counts}
+        print(depth, res[f"depth {depth}, {n_parts} parts"], flush=True)
+        del tris, verts, blobs
 if "--oracle" in os.environ.get("MESH_TIMES_FLAGS", ""):
     import oracle as O
     for depth in [d for d in depths if d <= 8]:
