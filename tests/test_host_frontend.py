@@ -35,6 +35,24 @@ def test_library_exports_every_declared_symbol():
     assert sorted(F.EXPORTS) == declared
 
 
+def test_integration_binding_names_the_declared_functions():
+    """INTEGRATION.md's `extern "C"` block (the reference-side binding) only names functions the header declares, with the
+    header's argument count"""
+    hdr = open(os.path.join(ROOT, "include", "fidget_hip.h")).read()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    ffi = dict(re.findall(r"pub fn (fhip_\w+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", block, re.S))
+    assert len(ffi) >= 30
+    flat = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name, args in ffi.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", flat, re.S)
+        assert m, f"{name} is not declared in include/fidget_hip.h"
+        n_c = len([a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"])
+        n_rs = len([a for a in args.split(",") if a.strip()])
+        assert n_c == n_rs, f"{name}: {n_rs} arguments in INTEGRATION.md, {n_c} in the header"
+
+
 def canon_product(shape):
     """(name, form, imm-or-slot) per op, evaluation order, registers abstracted to value numbers."""
     cur, nxt, out = {}, 0, []
