@@ -711,7 +711,7 @@ def render2d(shape, width, height=None, z=0.0, pixel_perfect=False, world_to_mod
 
 
 def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_sizes=None, vars=None, out=None,
-             shard=0, n_shards=1, mode=None, threads=None, block=None):
+             shard=0, n_shards=1, mode=None, threads=None, block=None, host_out=None):
     """fidget_raster::voxel::render on the GPU.  Returns (GeometryPixel [h,w] image, stats, seconds).
     Multi-GPU parts: (shard, n_shards) = root-tile columns round robin; block = (index, (nx, ny, nz)) = one block of an
     nx x ny x nz split of the volume (fhip_render3d_block)."""
@@ -737,7 +737,9 @@ def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_si
             raise ValueError("MissingVar")
         hip.check(st)
         return out, None, None
-    img = np.zeros((height, width), dtype=GEOMETRY_PIXEL)
+    # (host_out: a caller's own [height, width] GEOMETRY_PIXEL array to land in - pinned memory, say)
+    img = np.zeros((height, width), dtype=GEOMETRY_PIXEL) if host_out is None else host_out
+    assert img.dtype == GEOMETRY_PIXEL and img.shape == (height, width) and img.flags.c_contiguous
     import time
     t0 = time.perf_counter()
     st = call(_p(img), 0)
