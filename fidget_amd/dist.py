@@ -13,6 +13,14 @@ B. blocks (the north star's octants: 2 x 2 x 2 on 8 GPUs) - rank r renders block
    fidget-raster/src/voxel.rs:527-550 (larger depth wins, ties to the range nearer the camera, then the depth >= D-1
    clamp): fhip_merge_depth.  A z split forfeits occlusion culling between the ranges (the back ranks render what the
    front would have hidden), which is why A exists; bench.py measures both.
+
+C. frames - a SEQUENCE of frames sharded by frame: every rank renders whole frames, rank 0 gathers the finished images
+   (gather_frames).  A 1024^3 frame is bound by the latency of its coarse tile levels, which sharding the frame does not
+   shorten; sharding the sequence is what scales at that size (bench.py measures it next to A and B).
+
+The collectives can be queued through RCCL's C API on the render's own stream (DirectRccl): a collective library's stream
+waiting for the frame's end costs the frame pipeline half its rate.  The mesh build shards by the root's octants
+(mesh_sharded: fhip_mesh_sample_part per rank, fhip_mesh_merge on one).
 """
 import numpy as np
 
