@@ -1632,8 +1632,8 @@ struct fhip_mesh {
     // ambiguous cells (= parent index of their children / leaf record index)
     std::vector<std::vector<uint8_t>> cls;
     std::vector<std::vector<uint32_t>> slot;
-    std::vector<fhmesh::V3> vertices;                    // fhip_mesh_build: Mesh::vertices
-    std::vector<std::array<uint64_t, 3>> triangles;      // ... Mesh::triangles
+    fhmesh::VertVec vertices;                            // fhip_mesh_build: Mesh::vertices
+    fhmesh::TriVec triangles;                            // ... Mesh::triangles
     uint64_t octree_cells = 0, octree_verts = 0;
     uint32_t depth = 0, part = 0, n_parts = 1;           // fhip_mesh_sample_part: which of the root's octants this one covers
 };
@@ -1748,6 +1748,9 @@ struct ParallelMeshAssembler {
     }
     fhmesh::Cell run(const float* rb, fhmesh::Hermite* h) {
         fhmesh::tables();
+        const bool times = getenv("FHIP_MESH_TIMES") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         plan(0, 0, rb);
         subs.resize(tasks.size());
         fhmesh::parallel_for(tasks.size(), [&](size_t k) {
@@ -1755,11 +1758,13 @@ struct ParallelMeshAssembler {
             subs[k].root = A.build(L, tasks[k].i, tasks[k].b, &subs[k].h);
             subs[k].o = std::move(A.o);
         });
+        const double t1 = now();
         size_t total_c = 64, total_v = 64;
         for (auto& S : subs) { total_c += S.o.cells.size() + 1; total_v += S.o.verts.size(); }
         o.cells.reserve(total_c + 600 * tasks.size() / 512 + 4096);
         o.verts.reserve(total_v + 4096);
         const fhmesh::Cell root = top(0, 0, rb, h);
+        const double t2 = now();
         fhmesh::parallel_for(subs.size(), [&](size_t k) {
             Sub& S = subs[k];
             // (a top-level collapse may have cut the arrays back below this subtree: then it is unreachable and not copied)
@@ -1769,6 +1774,7 @@ struct ParallelMeshAssembler {
                 memcpy(&o.verts[S.vo], S.o.verts.data(), S.o.verts.size() * sizeof(fhmesh::V3));
             S.o = fhmesh::Octree();
         });
+        if (times) fprintf(stderr, "fhip mesh assembly: %zu subtrees below level %u %.4f s, levels above + room %.4f s, splice %.4f s\n", tasks.size(), L, t1 - t0, t2 - t1, now() - t2);
         return root;
     }
 };
@@ -1923,7 +1929,7 @@ static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const floa
         const float rb[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
         fhmesh::Hermite h;
         // (a level the recursion never reached - everything above it was decided - has no arrays: only levels 0 .. cls.size()-1 are indexed)
-        const uint32_t split = std::min<uint32_t>(depth, getenv("FHIP_MESH_SPLIT") ? (uint32_t)atoi(getenv("FHIP_MESH_SPLIT")) : 4u);
+        const uint32_t split = std::min<uint32_t>(depth, getenv("FHIP_MESH_SPLIT") ? (uint32_t)atoi(getenv("FHIP_MESH_SPLIT")) : 5u);
         const bool par = split >= 1 && M->cls.size() > split && fhmesh::mesh_threads() > 1;
         struct { fhmesh::Octree o; } A;
         if (par) {
@@ -2136,8 +2142,8 @@ void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_
     for (uint64_t i = 0; i < n_cells; i++) for (int k = 0; k < 8; k++) o.cells[i][k] = cell(cells + (i * 8 + k) * 3);
     o.verts.resize(n_verts);
     for (uint64_t i = 0; i < n_verts; i++) o.verts[i] = fhmesh::V3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
-    std::vector<std::array<uint64_t, 3>> t;
-    std::vector<fhmesh::V3> v;
+    fhmesh::TriVec t;
+    fhmesh::VertVec v;
     if (parallel) { fhmesh::ParallelWalker W(o); W.run(); t.swap(W.triangles); v.swap(W.vertices); }
     else { fhmesh::Walker W(o); W.cell(fhmesh::CellRef()); t.swap(W.triangles); v.swap(W.vertices); }
     counts[0] = t.size(); counts[1] = v.size();

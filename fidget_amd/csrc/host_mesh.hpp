@@ -10,6 +10,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <array>
@@ -17,6 +18,7 @@
 #include <cmath>
 #include <functional>
 #include <memory>
+#include <chrono>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -183,6 +185,8 @@ struct default_init_allocator : std::allocator<T> {
     template <class U> void construct(U* p) { ::new ((void*)p) U; }
     template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };
+using VertVec = std::vector<V3, default_init_allocator<V3>>;
+using TriVec = std::vector<std::array<uint64_t, 3>, default_init_allocator<std::array<uint64_t, 3>>>;
 struct Octree {
     Cell root;
     std::vector<std::array<Cell, 8>> cells;
@@ -276,8 +280,8 @@ struct Octree {
 // dc.rs / builder.rs
 struct Walker {
     const Octree& o;
-    std::vector<std::array<uint64_t, 3>> triangles;
-    std::vector<V3> vertices;
+    TriVec triangles;
+    VertVec vertices;
     std::vector<size_t> map;
     explicit Walker(const Octree& oc) : o(oc) {}
     static void frame(int f, int* t, int* u, int* v) { static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}}; *t = FR[f][0]; *u = FR[f][1]; *v = FR[f][2]; }
@@ -379,8 +383,8 @@ static inline void parallel_for(size_t n, const std::function<void(size_t)>& f) 
 // call order numbers the vertices by first use (builder.rs) and writes the triangles.
 struct ParallelWalker {
     const Octree& o;
-    std::vector<std::array<uint64_t, 3>> triangles;
-    std::vector<V3> vertices;
+    TriVec triangles;
+    VertVec vertices;
     explicit ParallelWalker(const Octree& oc) : o(oc) {}
     struct Call { uint8_t kind, f; CellRef c[4]; };        // kind 0 cell(c0), 1 face(f, c0, c1), 2 edge(f, c0..c3)
     struct Rec { uint64_t iv, vs[4]; uint8_t winding, push; };
@@ -475,6 +479,9 @@ struct ParallelWalker {
     }
     void run() {
         tables();
+        const bool times = getenv("FHIP_MESH_TIMES") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         std::vector<Call> calls(1);
         calls[0] = Call{};
         const size_t want = (size_t)mesh_threads() * 64;
@@ -489,27 +496,99 @@ struct ParallelWalker {
             if (next.size() == calls.size()) break;
             calls.swap(next);
         }
+        const double t1 = now();
         std::vector<std::vector<Rec>> recs(calls.size());
         parallel_for(calls.size(), [&](size_t i) { walk(calls[i], recs[i]); });
-        // octree vertex -> mesh vertex + 1 (0: not seen yet); calloc: only the pages that are touched cost anything
-        uint32_t* map = (uint32_t*)calloc(std::max<size_t>(o.verts.size(), 1), sizeof(uint32_t));
+        const double t2 = now();
         size_t nrec = 0;
-        for (auto& r : recs) nrec += r.size();
-        triangles.reserve(nrec * 4);
-        vertices.reserve(nrec * 2);
-        auto vertex = [&](uint64_t v) {
-            if (map[v] == 0) { vertices.push_back(o.verts[v]); map[v] = (uint32_t)vertices.size(); }
-            return (uint64_t)(map[v] - 1);
-        };
-        for (auto& rs : recs)
-            for (const Rec& r : rs) {
-                const uint64_t iv = vertex(r.iv);
-                uint64_t vs[4];
-                for (int i = 0; i < 4; i++) vs[i] = vertex(r.vs[i]);
-                for (int j = 0; j < 4; j++)
-                    if (r.push & (1 << j)) triangles.push_back({vs[j], vs[(j + r.winding) % 4], iv});
+        std::vector<size_t> rec_base(recs.size() + 1, 0);
+        for (size_t c = 0; c < recs.size(); c++) { rec_base[c] = nrec; nrec += recs[c].size(); }
+        rec_base[recs.size()] = nrec;
+        const size_t nv = std::max<size_t>(o.verts.size(), 1);
+        if (mesh_threads() > 1 && nrec * 5 < 0x7FFFFFF0ull) {
+            // MeshBuilder numbers the vertices by first use (builder.rs), records in call order, within a record iv, vs[0..3].
+            // In parallel, with the same result: reference number p = 5 * record + slot; first[v] = the smallest p that names v
+            // (atomic min, chunks in parallel); the references with first[v] == p are the first uses, counted per chunk, and a
+            // prefix sum over the chunks gives every chunk the number of its first new vertex and of its first triangle.
+            // (one array of the octree's vertex count for both: once a chunk has numbered its new vertices it overwrites their
+            // entries with TAG | number - a reference number never has the top bit - which is what the triangles then read)
+            uint32_t* first = (uint32_t*)malloc(nv * sizeof(uint32_t));
+            constexpr uint32_t TAG = 0x80000000u;
+            {
+                const size_t CH = 1u << 20, nch = (nv + CH - 1) / CH;
+                parallel_for(nch, [&](size_t i) { memset(first + i * CH, 0xFF, std::min(CH, nv - i * CH) * sizeof(uint32_t)); });
             }
-        free(map);
+            auto ref = [](const Rec& r, int k) { return k == 0 ? r.iv : r.vs[k - 1]; };
+            const double n0 = now();
+            parallel_for(recs.size(), [&](size_t c) {
+                uint32_t p = (uint32_t)(rec_base[c] * 5);
+                for (const Rec& r : recs[c])
+                    for (int k = 0; k < 5; k++, p++) {
+                        uint32_t* f = &first[ref(r, k)];
+                        uint32_t cur = __atomic_load_n(f, __ATOMIC_RELAXED);
+                        while (p < cur && !__atomic_compare_exchange_n(f, &cur, p, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                    }
+            });
+            const double n1 = now();
+            std::vector<size_t> vbase(recs.size() + 1, 0), tbase(recs.size() + 1, 0);
+            parallel_for(recs.size(), [&](size_t c) {
+                uint32_t p = (uint32_t)(rec_base[c] * 5);
+                size_t nvert = 0, ntri = 0;
+                for (const Rec& r : recs[c]) {
+                    for (int k = 0; k < 5; k++, p++) nvert += first[ref(r, k)] == p;
+                    ntri += (size_t)__builtin_popcount(r.push & 15u);
+                }
+                vbase[c + 1] = nvert; tbase[c + 1] = ntri;
+            });
+            for (size_t c = 0; c < recs.size(); c++) { vbase[c + 1] += vbase[c]; tbase[c + 1] += tbase[c]; }
+            const double n2 = now();
+            vertices.resize(vbase[recs.size()]);
+            triangles.resize(tbase[recs.size()]);
+            const double n3 = now();
+            parallel_for(recs.size(), [&](size_t c) {
+                uint32_t p = (uint32_t)(rec_base[c] * 5);
+                size_t id = vbase[c];
+                for (const Rec& r : recs[c])
+                    for (int k = 0; k < 5; k++, p++) {
+                        const uint64_t v = ref(r, k);
+                        // (another chunk may be looking at the same entry: it sees the first use's number or the tagged value, neither is its own p)
+                        if (__atomic_load_n(&first[v], __ATOMIC_RELAXED) == p) { vertices[id] = o.verts[v]; __atomic_store_n(&first[v], TAG | (uint32_t)id, __ATOMIC_RELAXED); id++; }
+                    }
+            });
+            parallel_for(recs.size(), [&](size_t c) {
+                size_t t = tbase[c];
+                for (const Rec& r : recs[c]) {
+                    const uint64_t iv = first[r.iv] & ~TAG;
+                    uint64_t vs[4];
+                    for (int i = 0; i < 4; i++) vs[i] = first[r.vs[i]] & ~TAG;
+                    for (int j = 0; j < 4; j++)
+                        if (r.push & (1 << j)) triangles[t++] = {vs[j], vs[(j + r.winding) % 4], iv};
+                }
+            });
+            const double n4 = now();
+            free(first);
+            if (times) fprintf(stderr, "fhip dual walk numbering: %zu octree vertices; clear %.4f s, first uses %.4f s, counts %.4f s, room %.4f s, vertices + triangles %.4f s, free %.4f s\n",
+                               nv, n0 - t2, n1 - n0, n2 - n1, n3 - n2, n4 - n3, now() - n4);
+        } else {
+            // octree vertex -> mesh vertex + 1 (0: not seen yet); calloc: only the pages that are touched cost anything
+            uint32_t* map = (uint32_t*)calloc(nv, sizeof(uint32_t));
+            triangles.reserve(nrec * 4);
+            vertices.reserve(nrec * 2);
+            auto vertex = [&](uint64_t v) {
+                if (map[v] == 0) { vertices.push_back(o.verts[v]); map[v] = (uint32_t)vertices.size(); }
+                return (uint64_t)(map[v] - 1);
+            };
+            for (auto& rs : recs)
+                for (const Rec& r : rs) {
+                    const uint64_t iv = vertex(r.iv);
+                    uint64_t vs[4];
+                    for (int i = 0; i < 4; i++) vs[i] = vertex(r.vs[i]);
+                    for (int j = 0; j < 4; j++)
+                        if (r.push & (1 << j)) triangles.push_back({vs[j], vs[(j + r.winding) % 4], iv});
+                }
+            free(map);
+        }
+        if (times) fprintf(stderr, "fhip dual walk: unroll %.4f s (%zu calls), sub-walks %.4f s (%zu records), numbering %.4f s\n", t1 - t0, calls.size(), t2 - t1, nrec, now() - t2);
     }
 };
 
