@@ -124,6 +124,11 @@ struct fhip_ctx : FrameBufs {
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[4];   // pinned (upload_frame)
     void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
     size_t mesh_pinned_cap = 0;
+    // ... and the two largest host-side temporaries of the assembly, kept for the same reason (fresh memory of that size is
+    // faulted in page by page and handed back page by page): the octree's cell / vertex arrays and the dual walk's first-use table
+    void* mesh_octree_cache = nullptr;       // fhmesh::Octree*
+    uint32_t* mesh_first = nullptr;
+    size_t mesh_first_cap = 0;
     uint32_t staging_next = 0;
     size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
     bool profiling = false;
@@ -134,6 +139,7 @@ struct fhip_ctx : FrameBufs {
 };
 
 static fhip_status finish_render(fhip_ctx* ctx);
+static void mesh_cache_release(void* octree);      // (defined with the mesh code)
 static fhip_status fail(fhip_ctx* ctx, fhip_status s, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return s;
@@ -248,6 +254,8 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
+    mesh_cache_release(c->mesh_octree_cache);
+    free(c->mesh_first);
     if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
@@ -1786,7 +1794,7 @@ static uint32_t mesh_part_mask(uint32_t part, uint32_t n_parts) {
     return m;
 }
 struct MeshTimes { bool on; double t_start, t_cells, t_leaf, t_copy; uint32_t n_leaf_cells; };
-static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T);
+static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T);
 enum MeshMode { MESH_SAMPLE, MESH_BUILD, MESH_PART };
 static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, MeshMode mode, uint32_t part, uint32_t n_parts, fhip_mesh** out) {
@@ -1913,7 +1921,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     cleanup();
     t_copy = now() - t_start - t_cells - t_leaf;
     MeshTimes MT{times, t_start, t_cells, t_leaf, t_copy, n_leaf_cells};
-    if (assemble) mesh_assemble(M, depth, P.has_mat != 0, P.mat, MT);
+    if (assemble) mesh_assemble(ctx, M, depth, P.has_mat != 0, P.mat, MT);
     else if (times)
         fprintf(stderr, "fhip mesh depth %u (part %u of %u): cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s\n", depth, part, n_parts,
                 t_cells, (unsigned long long)M->cells_evaluated, t_leaf, n_leaf_cells, t_copy);
@@ -1921,7 +1929,8 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     return FHIP_OK;
 }
 // Octree assembly (cell collapse included) and dual walk on the host's threads, from the classes / slots / leaf records in M
-static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T) {
+static void mesh_cache_release(void* octree) { delete (fhmesh::Octree*)octree; }
+static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double t_asm = 0, t_walk = 0;
@@ -1934,6 +1943,10 @@ static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const floa
         struct { fhmesh::Octree o; } A;
         if (par) {
             ParallelMeshAssembler PA{*M, depth, split, {}, {}, {}, 0};
+            if (ctx && ctx->mesh_octree_cache) {       // the arrays of the last build: their room, not their contents
+                PA.o = std::move(*(fhmesh::Octree*)ctx->mesh_octree_cache);
+                PA.o.cells.clear(); PA.o.verts.clear(); PA.o.root = fhmesh::Cell();
+            }
             PA.o.root = PA.run(rb, &h);
             A.o = std::move(PA.o);
         } else {
@@ -1955,11 +1968,16 @@ static void mesh_assemble(fhip_mesh* M, uint32_t depth, bool has_mat, const floa
         M->leaves.p = nullptr; M->leaves.n = 0;      // (borrowed from the context or from the parts' buffers: gone with the assembly)
         M->leaves.seg_p.clear(); M->leaves.seg_start.clear();
         fhmesh::ParallelWalker W(A.o);
+        if (ctx) { W.scratch = &ctx->mesh_first; W.scratch_cap = &ctx->mesh_first_cap; }
         W.run();
         t_walk = now() - t0 - t_asm;
         M->octree_cells = A.o.cells.size(); M->octree_verts = A.o.verts.size();
         M->vertices.swap(W.vertices);
         M->triangles.swap(W.triangles);
+        if (ctx && par) {
+            if (!ctx->mesh_octree_cache) ctx->mesh_octree_cache = new fhmesh::Octree();
+            *(fhmesh::Octree*)ctx->mesh_octree_cache = std::move(A.o);
+        }
     }
     if (T.on)
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
@@ -2129,7 +2147,7 @@ fhip_status fhip_mesh_merge(fhip_ctx* ctx, const void* const* parts, const uint6
     bool ident = true;
     if (world_to_model) for (int i = 0; i < 16; i++) { mat[i] = world_to_model[i]; ident &= world_to_model[i] == ((i % 5 == 0) ? 1.0f : 0.0f); }
     MeshTimes MT{getenv("FHIP_MESH_TIMES") != nullptr, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), 0, 0, 0, (uint32_t)n_leaves};
-    mesh_assemble(M, depth, world_to_model && !ident, mat, MT);
+    mesh_assemble(ctx, M, depth, world_to_model && !ident, mat, MT);
     *out = M;
     return FHIP_OK;
 }

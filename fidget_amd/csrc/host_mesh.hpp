@@ -363,7 +363,7 @@ struct Walker {
 static inline unsigned mesh_threads() {
     if (const char* e = getenv("FHIP_MESH_THREADS")) return (unsigned)std::max(1, atoi(e));
     const unsigned hc = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(hc ? hc : 1u, 128u));
+    return std::max(1u, std::min(hc ? hc : 1u, 32u));      // (measured on 2 x 64 cores: 32 threads beat 64, 128 and 256 - the work is bound by memory, not by arithmetic)
 }
 static inline void parallel_for(size_t n, const std::function<void(size_t)>& f) {
     const unsigned nt = (unsigned)std::min<size_t>(mesh_threads(), n);
@@ -386,6 +386,8 @@ struct ParallelWalker {
     TriVec triangles;
     VertVec vertices;
     explicit ParallelWalker(const Octree& oc) : o(oc) {}
+    uint32_t** scratch = nullptr;      // the caller's first-use table and its capacity in entries, kept between runs (or none)
+    size_t* scratch_cap = nullptr;
     struct Call { uint8_t kind, f; CellRef c[4]; };        // kind 0 cell(c0), 1 face(f, c0, c1), 2 edge(f, c0..c3)
     struct Rec { uint64_t iv, vs[4]; uint8_t winding, push; };
     static void frame(int f, int* t, int* u, int* v) { Walker::frame(f, t, u, v); }
@@ -505,14 +507,21 @@ struct ParallelWalker {
         for (size_t c = 0; c < recs.size(); c++) { rec_base[c] = nrec; nrec += recs[c].size(); }
         rec_base[recs.size()] = nrec;
         const size_t nv = std::max<size_t>(o.verts.size(), 1);
+        uint32_t* first = nullptr;
         if (mesh_threads() > 1 && nrec * 5 < 0x7FFFFFF0ull) {
+            if (scratch) {
+                if (*scratch_cap < nv) { free(*scratch); *scratch = (uint32_t*)malloc((nv + nv / 8) * sizeof(uint32_t)); *scratch_cap = *scratch ? nv + nv / 8 : 0; }
+                first = *scratch;
+            } else
+                first = (uint32_t*)malloc(nv * sizeof(uint32_t));
+        }
+        if (first) {
             // MeshBuilder numbers the vertices by first use (builder.rs), records in call order, within a record iv, vs[0..3].
             // In parallel, with the same result: reference number p = 5 * record + slot; first[v] = the smallest p that names v
             // (atomic min, chunks in parallel); the references with first[v] == p are the first uses, counted per chunk, and a
             // prefix sum over the chunks gives every chunk the number of its first new vertex and of its first triangle.
             // (one array of the octree's vertex count for both: once a chunk has numbered its new vertices it overwrites their
             // entries with TAG | number - a reference number never has the top bit - which is what the triangles then read)
-            uint32_t* first = (uint32_t*)malloc(nv * sizeof(uint32_t));
             constexpr uint32_t TAG = 0x80000000u;
             {
                 const size_t CH = 1u << 20, nch = (nv + CH - 1) / CH;
@@ -566,7 +575,7 @@ struct ParallelWalker {
                 }
             });
             const double n4 = now();
-            free(first);
+            if (!scratch) free(first);
             if (times) fprintf(stderr, "fhip dual walk numbering: %zu octree vertices; clear %.4f s, first uses %.4f s, counts %.4f s, room %.4f s, vertices + triangles %.4f s, free %.4f s\n",
                                nv, n0 - t2, n1 - n0, n2 - n1, n3 - n2, n4 - n3, now() - n4);
         } else {
