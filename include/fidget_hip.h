@@ -201,7 +201,7 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
  * the octree assembled from the device's results - cell collapse (check_done / try_collapse, octree.rs:256-385) with the merged
  * Hermite data included - and the dual walk (dc.rs) on the host -> Mesh { vertices, triangles } (lib.rs:64-69).  Both host steps
  * run on the host's threads (independent subtrees, as build_inner_mt octree.rs:94-210; independent sub-walks) and give the cells,
- * vertices and triangles of the single-threaded recursion, in its order (FHIP_MESH_THREADS, default: all cores up to 128).  The
+ * vertices and triangles of the single-threaded recursion, in its order (FHIP_MESH_THREADS, default: all cores up to 32 - more were measured slower).  The
  * leaf records are not kept with the mesh (fhip_mesh_leaves after a build copies nothing). */
 fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
