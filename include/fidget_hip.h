@@ -220,7 +220,8 @@ void fhip_mesh_leaves(const fhip_mesh* mesh, void* out);
  * fhip_mesh_merge takes the buffers of ALL parts (parts[k] = part k), puts the level arrays together (build_inner_mt's index
  * remapping, octree.rs:176-195: slots of later parts shifted by the ambiguous cells before them), and runs octree assembly
  * (check_done on the merged tree, octree.rs:197-208) and the dual walk: the mesh is the one fhip_mesh_build gives on one GPU,
- * vertex for vertex and triangle for triangle.  The buffers are only read during the call.  A merge needs no device. */
+ * vertex for vertex and triangle for triangle.  The buffers (8-byte aligned) are only read during the call.  A merge needs no
+ * device; with a context it reuses the context's host-side caches. */
 fhip_status fhip_mesh_sample_part(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                                   const uint64_t* var_keys, const float* var_values, uint32_t n_vars, uint32_t part, uint32_t n_parts, fhip_mesh** out);
 uint64_t fhip_mesh_part_bytes(const fhip_mesh* mesh);
