@@ -311,6 +311,12 @@ class _SharedParts:
     def attach(self, rank, nbytes):
         from multiprocessing import shared_memory
         m = shared_memory.SharedMemory(name=self.name(rank))
+        try:        # (Python < 3.13 registers attached segments with this process' resource tracker too, which would unlink the
+            #          owner's segment a second time at exit and say so on stderr: the owner unlinks it, nobody else)
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(m._name, "shared_memory")
+        except Exception:
+            pass
         self.maps.append(m)
         return np.frombuffer(m.buf, np.uint8, int(nbytes))
 
