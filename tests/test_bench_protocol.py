@@ -1,0 +1,161 @@
+"""bench.py's multi-rank protocol without GPUs: two processes on gloo run bench.main() with the device library replaced by
+a stand-in that writes each rank's share of a known frame (shards by the owner map, blocks by their rectangle and z range, whole
+frames) and with torch's CUDA entry points stubbed.  What is checked is the control flow the driver's N > 1 runs depend on and
+that cannot be run on the one-GPU box: the three shardings are timed, combined through fidget_amd/dist.py (the torch.distributed
+collectives here: FHIP_NO_DIRECT_RCCL), every combined image equals the frame, and rank 0 prints ONE JSON line with the
+contract's fields."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N = 256
+
+
+def _frame():
+    rng = np.random.default_rng(5)
+    full = np.zeros((N, N, 4), np.int32)
+    depth = rng.integers(0, N - 1, size=(N, N)).astype(np.int32)          # (below the saturation clamp)
+    depth[rng.random((N, N)) < 0.3] = 0
+    full[..., 3] = depth
+    full[..., :3] = np.where(depth[..., None] > 0, rng.integers(1, 1 << 30, size=(N, N, 3)), 0).astype(np.int32)
+    return full
+
+
+def _worker(rank, world, port, out_path, direct):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if not direct:
+        os.environ["FHIP_NO_DIRECT_RCCL"] = "1"
+    import fidget_amd as F
+    from fidget_amd import dist as D
+    from test_multi_gpu import _parts_of, merge_ref
+    full = _frame()
+
+    if direct:
+        # bench.py's path through a communicator of its own (probe, agreement, unique id broadcast, trial collectives,
+        # use_direct_rccl), with the communicator itself played by the process group: RCCL needs the GPUs
+        class FakeRccl:
+            @staticmethod
+            def probe(lib_path=None):
+                pass
+
+            def __init__(self, rank, world, bcast_bytes=None, lib_path=None):
+                raw = bytes(range(128)) if rank == 0 else bytes(128)
+                assert bcast_bytes(raw, 0) == bytes(range(128))             # the unique id reaches every rank
+                self.rank, self.world = rank, world
+
+            def reduce_sum(self, t, dst, stream):
+                assert stream == 0
+                dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+
+            def gather(self, send, recv, dst, stream):
+                assert stream == 0 and (recv is not None) == (self.rank == dst)
+                dist.gather(send, [recv[r] for r in range(self.world)] if recv is not None else None, dst=dst)
+
+            def close(self):
+                pass
+
+        D.DirectRccl = FakeRccl
+
+    # ---- torch: CUDA entry points and device placement stubbed -----------------------------------------------------
+    class Stream:
+        cuda_stream = 0
+
+    class Event:
+        def __init__(self, enable_timing=False):
+            self.t = 0.0
+
+        def record(self, stream=None):
+            import time
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda d=None: None
+    torch.cuda.current_stream = lambda d=None: Stream()
+    torch.cuda.Event = Event
+    for name in ("zeros", "tensor", "full", "arange", "empty"):
+        real = getattr(torch, name)
+        setattr(torch, name, (lambda real: lambda *a, **k: real(*a, **{kk: vv for kk, vv in k.items() if kk != "device"}))(real))
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size)
+
+    # ---- the device library's stand-in --------------------------------------------------------------------------------
+    class Hip:
+        tile_phases = None
+
+        def __init__(self, device, stream):
+            pass
+
+        def sync(self): pass
+        def counters(self): return {"arena_ops": 0, "arena_overflow": 0}
+        def profile(self, on): pass
+        def profile_read(self): return {k: (0.0, 0) for k in ("tiles", "points", "normals", "other")}
+        def profile_read_kernels(self): return {}
+        def wave_stats(self): pass
+
+    class Shape:
+        @staticmethod
+        def from_vm(path, hip=None):
+            assert os.path.exists(path)
+            return Shape()
+
+    def render3d(shape, n, out=None, shard=0, n_shards=1, block=None, **kw):
+        assert n == N and out is not None
+        if block is not None:
+            part = _parts_of(full, block[1], N, block[0], np.random.default_rng(block[0]))
+        elif n_shards > 1:
+            own = D.owner_map(N, N, D.root_tile(N), n_shards)
+            part = np.where((own == shard)[..., None], full, 0).astype(np.int32)
+        else:
+            part = full
+        out.copy_(torch.from_numpy(part))
+        return out, None, None
+
+    F.HipContext, F.Shape, F.render3d = Hip, Shape, render3d
+    F.merge_depth = lambda a, b, d, hip=None: merge_ref(a, b, d)
+
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--size", str(N)]
+    if rank == 0:
+        sys.stdout = open(out_path, "w")
+    bench.main()
+    sys.stdout.flush()
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_bench_two_ranks_protocol(tmp_path, direct):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "rank0.out")
+    mp.spawn(_worker, args=(2, port, out_path, direct), nprocs=2, join=True)
+    lines = [l for l in open(out_path).read().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in r, key
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["unit"] == "Mvoxel/s" and r["higher_is_better"] is True
+    assert r["vs_baseline"] is None and r["data"] == "synthetic" and "workload" in r["config"] and "sharding" in r["config"]
+    p = r["partitions"]
+    assert p["images_equal"] is True and p["frames"]["images_equal"] is True and p["frames"]["frames_per_step"] == 2
+    for k in ("columns", "blocks", "frames"):
+        assert p[k]["ms_per_step"] > 0 and p[k]["value"] > 0
+    best = max(p[k]["value"] for k in ("columns", "blocks", "frames"))
+    assert abs(r["value"] - best) <= 1e-6 * best                      # `value` is the fastest sharding's
+    assert r["scaling"] == ("weak" if best == p["frames"]["value"] else "strong")
+    assert ("DirectRccl" in r["collectives"]) if direct else ("torch.distributed" in r["collectives"])
+    assert "roofline" not in r and "cpu_baseline" not in r         # rank 0 at N = 1 only
