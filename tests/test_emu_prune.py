@@ -118,3 +118,83 @@ def test_big_list_and_tape_group_mode(big, mode):
     """the second slot list (big = 1) and the level-0 tape-group mode (choice words from S->chwr)"""
     sh, tape, ik = shape_of(2)
     assert check(tape, children((0.1, -0.2, 0.0), 0.4), ik, sh.slot_count(), only=4, big=big, mode=mode, level=0 if mode == 2 else 1) > 0
+
+
+def run_export_then_prune(tape, xyz, in_kind, n_regs, n_choices, level=1):
+    """The pre-pass pair as capi.hip launches it for a level with long tapes: fh_tiles in export mode (flags bit 1: forward pass,
+    classification, choice words to S->chw, the children to prune only MARKED: c_len = ~0, c_off = end of their arena slot),
+    then fh_prune1, one wave per child, on the same state."""
+    from test_emu_tiles import ARENA_OPS as A_OPS
+    off = U.offsets()
+    mem = E.Memory()
+    n = len(tape)
+    arena = np.zeros(A_OPS, np.uint64)
+    arena[16:16 + n] = tape
+    a_arena = mem.map(arena, "arena")
+    st, slot = U.Blob(off["sizeof_state"]), U.Blob(off["sizeof_slot"])
+    slot.u32(0, 16); slot.u32(4, n); slot.u32(8, n_regs | (n_choices << 16)); slot.u32(12, 2)
+    slot.u64(16, (1 << 64) - 1)
+    for k in range(6):
+        slot.arr(40 + 256 * k, np.asarray(xyz[k], F32))
+    a_slot = mem.map(slot.b, "slot")
+    head0 = 16 + n + 16
+    mr, mc = max(n_regs, 32), max(n_choices, 256)
+    words = (mc + 15) // 16
+    chw = np.zeros(words * 64, U32)
+    a_chw = mem.map(chw, "chw")
+    st.u64(off["arena"], a_arena); st.u32(off["arena_cap"], A_OPS - 64); st.u32(off["arena_head"], head0)
+    st.u64(off["slots"], a_slot); st.u64(off["slots"] + 8, a_slot); st.u64(off["chw"], a_chw); st.u64(off["chw"] + 8, a_chw)
+    st.u32(off["slot_cap"], 1); st.u32(off["slot_cap"] + 4, 1)
+    for big in (0, 1):
+        st.u32(off["n_slots"] + 4 * (big * 8 + level), 1)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
+    a_st = mem.map(st.b, "state")
+    ka = np.zeros(10, U32)
+    ka[0], ka[1] = a_st & 0xFFFFFFFF, a_st >> 32
+    ka[2:10] = [level, 0, mr, mc, 1, 2 | (words << 16), 0, 0]
+    lds = mr * 512 + words * 256 + mr * 64 + 256
+    E.launch(U.program(), mem, "fh_tiles", ka.tobytes(), 1, lds_bytes=lds, n_vgpr=84)
+    g = lambda k: slot.b[40 + k * 256: 40 + (k + 1) * 256]
+    marked = np.nonzero(g(12).view(U32) == 0xFFFFFFFF)[0]
+    ends = g(11).view(U32).copy()
+    head = int(st.get_u32(off["arena_head"])[0])
+    kp = np.zeros(6, U32)
+    kp[0], kp[1] = a_st & 0xFFFFFFFF, a_st >> 32
+    kp[2:6] = [level, 0, words * 16, 1]
+    E.launch(U.program(), mem, "fh_prune1", kp.tobytes(), 64, lds_bytes=16, n_vgpr=24)
+    return dict(res=(g(9).view(F32).copy(), g(10).view(F32).copy()), coff=g(11).view(U32).copy(), clen=g(12).view(U32).copy(),
+                crc=g(13).view(U32).copy(), arena=arena, marked=marked, ends=ends, head=head, head0=head0)
+
+
+@pytest.mark.parametrize("seed", [0, 2, 3])
+def test_export_mode_then_prune1(seed):
+    """fh_tiles' export mode and fh_prune1 agree about where the choice words and the marks live: together they give the
+    interval results and the child tapes of the one-kernel path (and of the numpy restatement)"""
+    sh, tape, ik = shape_of(seed)
+    n_regs, n_choices = sh.slot_count(), sh.choice_count()
+    if n_regs > 128:
+        pytest.skip("fh_prune1: 128 registers")
+    rng = np.random.default_rng(100 + seed)
+    done = 0
+    for _ in range(6):
+        xyz = children(rng.uniform(-0.7, 0.7, 3), rng.uniform(0.15, 0.5))
+        r = run_export_then_prune(tape, xyz, ik, n_regs, n_choices)
+        inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(ik) if k < 3}
+        el, eh, ch, _ = U.ref_interval(tape, inputs, 64)
+        assert (el.view(U32) == r["res"][0].view(U32)).all() and (eh.view(U32) == r["res"][1].view(U32)).all()
+        amb = ~(eh < 0) & ~(el > 0)
+        decided = (ch != 3).any(axis=0) if len(ch) else np.zeros(64, bool)
+        want = np.nonzero(amb & decided)[0]
+        assert list(r["marked"]) == list(want)
+        assert r["head"] == r["head0"] + len(want) * len(tape)
+        for lane in want:
+            ops, regs, kept = U.ref_prune(tape, ch[:, lane])
+            assert r["clen"][lane] == len(ops) and r["coff"][lane] == r["ends"][lane] - len(ops)
+            got = r["arena"][r["coff"][lane]: r["coff"][lane] + len(ops)]
+            assert (got == np.array(ops, np.uint64)).all(), f"lane {lane}"
+            assert r["crc"][lane] == (regs | (kept << 16))
+        done += len(want) > 0
+        if done == 2:
+            break
+    assert done > 0 or n_choices == 0
