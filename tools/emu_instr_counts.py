@@ -80,21 +80,27 @@ for lane in np.nonzero(~(eh < 0) & ~(el > 0))[0]:
 mat = np.eye(4, dtype=np.float32)
 mat[:3, :3] *= 2.0 / 16
 mat[:3, 3] = -1.0
-for cls, leaves in sorted(by_class.items()):
-    leaves.sort(key=lambda t: t[0])
-    runs = []
-    for n_ops, lregs, leaf in (leaves[0], leaves[-1]):
-        zbuf, ws = C.run_columns(leaf, lregs, ik, mat.reshape(-1), (0, 0, 0), size=16)      # (layer 0: the block rotation, a modulo by subtraction, is then trivial as it is at 1024^2)
-        runs.append((n_ops, counts(max(ws, key=lambda w: w.counts.get('valu', 0)))))      # (the workgroup that finds the leaf)
-    passes = {8: 1, 16: 2, 32: 4}[cls]
-    (n0, c0), (n1, c1) = runs
-    e = {"leaf_tapes_ops": [n0, n1], "voxels": 512, "passes_over_the_tape": passes, "workgroup_total": [c0, c1]}
-    if n1 > n0:
-        slope = {k: (c1.get(k, 0) - c0.get(k, 0)) / ((n1 - n0) * passes) for k in c1}
-        e["per_op_and_pass"] = {k: round(v, 2) for k, v in slope.items()}
-        e["set_up_per_workgroup"] = {k: round(c0.get(k, 0) - slope[k] * n0 * passes, 1) for k in c1}
-    res[f"fh_columns: leaf tapes of <= {cls} registers"] = e
-    print("fh_columns", cls, e, flush=True)
+real_kernarg = C.col_kernarg
+for general in (False, True):
+    # prospero's leaf tapes read no z: the kernel takes them as column-invariant (one voxel per pixel).  `general`: the kernarg of
+    # FHIP_NO_COLUMN_INV (every input counts as varying along the column) - all 512 voxels, what a tape with z in it gets
+    C.col_kernarg = (lambda a_st, in_kind, m: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(a_st, in_kind, m))) if general else real_kernarg
+    for cls, leaves in sorted(by_class.items()):
+        leaves.sort(key=lambda t: t[0])
+        runs = []
+        for n_ops, lregs, leaf in (leaves[0], leaves[-1]):
+            zbuf, ws = C.run_columns(leaf, lregs, ik, mat.reshape(-1), (0, 0, 0), size=16)      # (layer 0: the block rotation, a modulo by subtraction, is then trivial as it is at 1024^2)
+            runs.append((n_ops, counts(max(ws, key=lambda w: w.counts.get('valu', 0)))))      # (the workgroup that finds the leaf)
+        (n0, c0), (n1, c1) = runs
+        e = {"leaf_tapes_ops": [n0, n1], "voxels_evaluated": 512 if general else 64, "workgroup_total": [c0, c1]}
+        if n1 > n0:
+            slope = {k: (c1.get(k, 0) - c0.get(k, 0)) / (n1 - n0) for k in c1}
+            e["per_op (all passes over the tape)"] = {k: round(v, 2) for k, v in slope.items()}
+            e["set_up_per_leaf"] = {k: round(c0.get(k, 0) - slope[k] * n0, 1) for k in c1}
+        key = f"fh_columns: leaf tapes of <= {cls} registers, " + ("every voxel (general path)" if general else "column-invariant (one voxel per pixel)")
+        res[key] = e
+        print(key, e, flush=True)
+C.col_kernarg = real_kernarg
 
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "instr_per_op.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
