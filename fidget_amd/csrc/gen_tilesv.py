@@ -864,15 +864,16 @@ class TilesV(Tiles):
 	v_cndmask_b32_e64 {V_CRC}, {V_CRC}, {T[5]}, {S_PRUNE}
 	s_branch {p}_store
 {p}_overflow:
-	; arena full: the children keep the parent tape; the reservation is given back (the bump pointer must not creep
-	; towards 2^32 under a long run of failures)
+	; arena full: the children keep the parent tape; the bump pointer is clamped back to the capacity (it must not creep
+	; towards 2^32 under a long run of failures, and it must never fall below a range that was granted - which giving the
+	; reservation back by subtraction could do)
 	v_cmp_eq_u32 vcc, 0, {V_LANE}
 	s_and_saveexec_b64 {S_SAVE}, vcc
 	v_mov_b32 {T[0]}, 1
 	v_mov_b32 {T[1]}, 0
-	v_mov_b32 {T[2]}, {S_T1}
+	v_mov_b32 {T[2]}, {S_ARENACAP}
 	global_atomic_add {T[1]}, {T[0]}, {S_STATE} offset:{o['arena_overflow']}
-	global_atomic_sub {T[1]}, {T[2]}, {S_STATE} offset:{o['arena_head']}
+	global_atomic_umin {T[1]}, {T[2]}, {S_STATE} offset:{o['arena_head']}
 	s_mov_b64 exec, {S_SAVE}
 {p}_store:
 	; diagnostics (flags bit 0; the atomics serialise, never in production runs): shader clocks of the forward pass and

@@ -39,12 +39,14 @@ typedef unsigned long long Q4 __attribute__((ext_vector_type(4), aligned(8)));
 FH_DEV uint64_t q4_pick(Q4 q, int u) { return u == 0 ? q.x : (u == 1 ? q.y : (u == 2 ? q.z : q.w)); }
 
 FH_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-// Arena reservation of `n` ops by one lane: the bump pointer moves back when the reservation does not fit, so that it
-// cannot creep past 2^32 and wrap under a long run of failures (arena_cap <= 2^31 ops, at most a few thousand waves in
-// flight add <= 2^18 ops each).  Returns ~0u on failure.
+// Arena reservation of `n` ops by one lane.  The bump pointer only ever grows, except that a reservation that does not
+// fit clamps it back to the capacity (atomicMin): it can then never fall below a range that was granted (a give-back by
+// subtraction could: two failures and a success in between leave it inside the successful range), and it cannot creep
+// past 2^32 and wrap under a long run of failures either (arena_cap <= 2^31 ops, at most a few thousand waves in flight
+// add <= 2^18 ops each before they clamp).  Returns ~0u on failure.
 FH_DEV uint32_t arena_reserve(FhRenderState* S, uint32_t n) {
     const uint32_t base = atomicAdd(&S->arena_head, n);
-    if (base + n < base || base + n > S->arena_cap) { atomicSub(&S->arena_head, n); return 0xFFFFFFFFu; }
+    if (base + n < base || base + n > S->arena_cap) { atomicMin(&S->arena_head, S->arena_cap); return 0xFFFFFFFFu; }
     return base;
 }
 FH_DEV uint64_t ballot(bool p) { return __ballot(p); }

@@ -226,6 +226,9 @@ def test_arena_overflow_keeps_parent_tape():
     xyz = children(np.array([0.0, 0.0, 0.0]), 0.5)
     r = run_tiles("fh_tiles_v32", tape, xyz, ik, sh.slot_count(), sh.choice_count(), arena_cap=16 + len(tape) + 20)
     assert r["overflow"] == 1 and (r["coff"] == 16).all() and (r["clen"] == len(tape)).all()
+    # the failed reservation clamps the bump pointer to the capacity: it never falls below a range another wave was granted
+    # (a give-back by subtraction could, between two failures with a success in between)
+    assert r["head"] == 16 + len(tape) + 20 and r["head"] >= r["head0"]
 
 
 @pytest.mark.parametrize("kernel", ["fh_tiles_v32", "fh_tiles_v64"])

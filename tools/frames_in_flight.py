@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: throughput with N frames in flight (one fhip context + stream per frame slot)."""
+"""GPU box (run by hand, not a test): throughput with N frames in flight (one fhip context + stream per frame slot)."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1493,6 +1493,9 @@ class Wave:
     def i_global_atomic_sub(self, i, *ops):
         self._gatomic(i, ops, lambda o, v: o - v, 1)
 
+    def i_global_atomic_umin(self, i, *ops):
+        self._gatomic(i, ops, min, 1)
+
     def i_global_atomic_add_x2(self, i, *ops):
         self._gatomic(i, ops, lambda o, v: o + v, 2)
 
