@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of fidget-hip on MI355X.
+"""bench.py - headline benchmark of fidget-hip on MI355X.
 
 Metric (BASELINE.json): Mvoxel/s of the heightmap+normals render (interval + point
 evaluation) of prospero.vm at 1024^3, nominal volume / wall time
@@ -7,30 +7,35 @@ evaluation) of prospero.vm at 1024^3, nominal volume / wall time
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  A step is
-one full frame; frames are queued back to back and the library pipelines them (the coarse
-levels of frame n + 1 beside the slabs of frame n; `frame_latency_ms` is one frame alone).  With N > 1 three
-shardings of fidget_amd/dist.py are timed, K steps each.  One frame sharded over the ranks, no
-collective inside the render, total work fixed ("strong"): "columns" (root-tile column index
-% N == rank at full depth; ONE RCCL SUM reduce of the partial images) and "blocks" (the north
-star's octants, 2 x 2 x 2 at N = 8: a gather of the ranks' own rectangles, then the
-front-to-back depth merge on rank 0).  The frame SEQUENCE sharded by frame ("frames": every rank
-renders whole frames, rank 0 gathers the finished frames; a step is then N frames and per-GPU
-work is fixed: "weak").  A 1024^3 frame of this model is bound by the latency of its coarse tile
-levels, which does not shrink with N, so sharding one frame gains little at this size and
-sharding the sequence is what scales.  `value` is the fastest of the three
-(named in config.sharding, `scaling` says which kind it is); all three are listed under
-"partitions" with their own `value`.
+One process per GPU (the driver launches N>1 through torch.distributed.run).  A step is one full frame,
+inputs resident in HBM, output left in HBM; frames are queued back to back and the library pipelines them
+(the coarse levels of frame n + 1 beside the slabs of frame n).
 
-Prints ONE JSON line on rank 0, including
-  roofline     — for the dominant kernel (fh_tiles, the assembly tile-stage interpreter; a second
-                 object covers fh_columns, the leaf interpreter): algorithmic
-                 bytes (8 B per tape word per wavefront pass, exact because pruning
-                 is deterministic; taken from the oracle's / the device's counters) / the kernel's
-                 launches, each between its own pair of HIP events on the stream it is launched
-                 on (three extra, un-pipelined frames after the timed loop), vs the 8 TB/s HBM peak;
-  cpu_baseline — the C++ oracle (restatement of the reference's VmShape path, OpenMP over
-                 root tiles like render_tiles' rayon pool) on this box's host cores, same frame.
+What the ONE JSON line says, and how to read it:
+
+  value / ms_per_step        the timed K frames of the DEFAULT path.  prospero.vm has no z: every one of its tapes takes
+                             the column-invariance short cuts, so next to it stand
+  general                    the same K frames with the short cuts off (context option no_column_inv): what a model with z
+                             in every tape gets from the same kernels; its image is compared with the default path's;
+  frame_latency_ms           one frame alone, nothing in flight before it (the reference's -N loop is blocking frames),
+                             for both paths; host_output_frame_ms: the blocking call with a HOST output buffer, device to
+                             host copy included (what the Rust trait's render returns; never `value`);
+  roofline                   PRIMARY: the dominant kernel of the GENERAL path (the leaf interpreter fh_columns), numerator
+                             from the device's own counters of the very frames whose launches are timed (leaf tape words x
+                             passes, counted where the leaves are queued), every launch between its own pair of HIP events
+                             on the stream it is launched on; `alu` beside the HBM figure: f32 lane-operations per second
+                             against the plain-f32 VALU rate - the resource that actually binds an interpreter;
+  roofline_default_path      the same kernel on the default path; roofline_tiles / roofline_tiles_default_path: the
+                             tile-stage kernel fh_tiles_v32 likewise (tape ops read + written at the per-slab level);
+  cpu_baseline               the C++ oracle (restatement of the reference's VmShape path, OpenMP over root tiles like
+                             render_tiles' rayon pool) on this box's host cores, same frame; parity of the device image
+                             against it at full size; `c3_bear`: BASELINE configuration 3 with its measured normal error.
+
+N > 1: ONE frame sharded over the ranks (total work fixed: "strong") - "columns" (root-tile column index % N == rank at
+full depth; one RCCL SUM reduce of the partial images) and "blocks" (the north star's octants, 2 x 2 x 2 at N = 8: a
+gather of the ranks' rectangles, then the front-to-back depth merge on rank 0).  `value` is the better of these two.  A
+third sharding, whole frames of the SEQUENCE per rank ("frames": per-GPU work fixed, i.e. weak scaling), is timed and
+listed under `partitions` only - it is not the north star's number.
 """
 import argparse
 import json
@@ -43,7 +48,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 78.6e12  # plain f32 VALU lane-operations per second: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (= the 157.3 TFLOP/s vector peak / 2 flops per FMA)
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r03.json")
 
 
 def main():
@@ -53,8 +60,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--model", default="prospero.vm")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity / configuration-3 leg")
     ap.add_argument("--no-general", action="store_true", help="skip the frames with the column-invariance short cuts off (profiling runs: per-kernel statistics of the default path only)")
+    ap.add_argument("--only-general", action="store_true", help="profiling runs: time only the frames with the short cuts off")
     args = ap.parse_args()
 
     import torch
@@ -141,8 +149,8 @@ def main():
     frames_recv = None
 
     def step_frames():
-        # frame-level sharding of the frame SEQUENCE: every rank renders a whole frame of its own (frame r of each group of
-        # `world` consecutive frames), rank 0 collects the finished frames; no collective inside a frame, no merge rule
+        # the frame SEQUENCE sharded by frame: every rank renders a whole frame of its own (frame r of each group of `world`
+        # consecutive frames), rank 0 collects the finished frames; no collective inside a frame, no merge rule
         F.render3d(shape, n, out=out)
         gather_frames(out, frames_recv, dst=0)
 
@@ -172,105 +180,113 @@ def main():
             dt = float(t.item())
         return dt
 
+    def latency(step, reps=7):
+        # one frame alone: nothing in flight before it, waited for
+        lat = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(lat))
+
     partitions = {}
+    general = None
+    host_frame = None
+    lat_general = None
     if world > 1:
         # the stream of the context is torch's current stream: collectives and renders are ordered on it
         dt_b = timed(step_blocks)
         img_b, ms_b = out.clone(), list(frame_ms)
+        lat_b = latency(step_blocks)
         dt_c = timed(step_columns)
         ms_c = list(frame_ms)
-        partitions = {"columns": {"ms_per_step": dt_c / args.steps * 1e3, "combine": "1 RCCL reduce (SUM) of the full image"},
-                      "blocks": {"ms_per_step": dt_b / args.steps * 1e3, "split": list(split),
+        lat_c = latency(step_columns)
+        partitions = {"columns": {"ms_per_step": dt_c / args.steps * 1e3, "frame_latency_ms": lat_c, "scaling": "strong",
+                                  "combine": "1 RCCL reduce (SUM) of the full image"},
+                      "blocks": {"ms_per_step": dt_b / args.steps * 1e3, "frame_latency_ms": lat_b, "scaling": "strong", "split": list(split),
                                  "combine": "RCCL gather of each rank's rectangle + front-to-back depth merge on rank 0"}}
         if rank == 0:
             partitions["images_equal"] = bool(torch.equal(img_b, out))
             frames_recv = torch.zeros((world, n, n, 4), dtype=torch.int32, device=dev)
         img_c = out.clone()
         dt_f = timed(step_frames)        # one step = `world` frames
-        partitions["frames"] = {"ms_per_step": dt_f / args.steps * 1e3, "frames_per_step": world,
-                                "combine": "none inside a frame: every rank renders whole frames of the sequence; RCCL gather of the finished frames (16 MiB each) to rank 0"}
+        partitions["frames"] = {"ms_per_step": dt_f / args.steps * 1e3, "frames_per_step": world, "scaling": "weak",
+                                "combine": "none inside a frame: every rank renders whole frames of the sequence; RCCL gather of the finished frames (16 MiB each) to rank 0",
+                                "note": "per-GPU work fixed, total work grows with N: listed for comparison, never `value`"}
         if rank == 0:
             partitions["frames"]["images_equal"] = bool((frames_recv == img_c[None]).all())
         for k, f in (("columns", 1), ("blocks", 1), ("frames", world)):
             partitions[k]["value"] = (n ** 3) * f / (partitions[k]["ms_per_step"] * 1e-3) / 1e6
-        # `value` is the fastest of the three.  One frame sharded over the ranks (A, B: the north star's split) is bound by
-        # the latency of its coarse levels, which does not shrink with the rank count; a sequence of
-        # frames sharded by frame (C) is what scales at this size, and then per-GPU work is fixed: "weak".
-        dt_one, step_one, sharding_one = ((dt_c, step_columns, "root-tile columns round-robin, 1 RCCL reduce") if dt_c <= dt_b else
-                                          (dt_b, step_blocks, f"blocks {split[0]}x{split[1]}x{split[2]} (octant split), RCCL gather + depth merge"))
-        if dt_f / world < dt_one:
-            dt, step, frames_per_step = dt_f, step_frames, world
-            sharding = f"whole frames of the sequence round-robin over the ranks, RCCL gather of the finished frames to rank 0 (one frame sharded: {sharding_one}, see partitions)"
+        # `value`: ONE frame sharded over the ranks - the north star's number - by the better of the two partitions
+        if dt_c <= dt_b:
+            dt, step, sharding, lat_default = dt_c, step_columns, "root-tile columns round-robin, 1 RCCL reduce", lat_c
+            frame_ms[:] = ms_c
         else:
-            dt, step, frames_per_step, sharding = dt_one, step_one, 1, sharding_one
-            frame_ms[:] = ms_c if dt_c <= dt_b else ms_b
+            dt, step, sharding, lat_default = dt_b, step_blocks, f"blocks {split[0]}x{split[1]}x{split[2]} (octant split), RCCL gather + depth merge", lat_b
+            frame_ms[:] = ms_b
     else:
-        step, frames_per_step = step_columns, 1
-        dt = timed(step)
+        step = step_columns
         sharding = "single GPU"
-    # the same frames with the column-invariance short cuts off (FHIP_NO_COLUMN_INV: leaves evaluated once per voxel, every tile
-    # of a z-stack evaluated) - prospero.vm has no z, so every one of its tapes takes them; this is what a model with z in
-    # every tape gets from the same kernels
-    general = None
-    if world == 1 and not args.no_general:
-        os.environ["FHIP_NO_COLUMN_INV"] = "1"
-        saved = list(frame_ms)
-        dt_g = timed(step)
-        general = {"ms_per_step": dt_g / args.steps * 1e3, "ms_per_step_median": float(np.median(frame_ms)), "value": (n ** 3) * args.steps / dt_g / 1e6,
-                   "note": "FHIP_NO_COLUMN_INV=1: no tape treated as independent of z (same image)"}
-        frame_ms[:] = saved
-        del os.environ["FHIP_NO_COLUMN_INV"]
+        if args.only_general:
+            hip.set_option("no_column_inv", 1)
+        dt = timed(step)
+        lat_default = latency(step)
+        img_default = out.clone()
+        # the same frames with the column-invariance short cuts off: leaves evaluated once per voxel, every tile of a z-stack
+        # evaluated - prospero.vm has no z, so every one of its tapes takes the short cuts
+        if not args.no_general and not args.only_general:
+            saved = list(frame_ms)
+            with hip.options(no_column_inv=1):
+                dt_g = timed(step)
+                lat_general = latency(step)
+                hip.sync()
+            general = {"ms_per_step": dt_g / args.steps * 1e3, "ms_per_step_median": float(np.median(frame_ms)), "value": (n ** 3) * args.steps / dt_g / 1e6,
+                       "frame_latency_ms": lat_general, "image_equals_default_path": bool(torch.equal(out, img_default)),
+                       "note": "context option no_column_inv = 1: no tape treated as independent of z"}
+            frame_ms[:] = saved
+            for _ in range(2):
+                step()
+        # the blocking call with a host output buffer (pinned): what a caller of the reference's blocking API gets
+        pinned = torch.zeros((n, n, 16), dtype=torch.uint8).pin_memory().numpy().view(F.GEOMETRY_PIXEL).reshape(n, n)
         for _ in range(2):
-            step()
-    # one frame alone (nothing in flight before it, waited for): asynchronous frames are pipelined - the coarse levels of
-    # frame n + 1 run beside the slabs of frame n - so the throughput above is not 1 / latency
-    lat = []
-    for _ in range(5):
-        fence()
-        t0 = time.perf_counter()
-        step()
-        torch.cuda.synchronize(dev)
-        lat.append((time.perf_counter() - t0) * 1e3)
+            F.render3d(shape, n, host_out=pinned)
+        host_frame = float(np.median([F.render3d(shape, n, host_out=pinned)[2] * 1e3 for _ in range(9)]))
     hip.sync()
     counters = hip.counters()
 
     # ---- per-kernel timing with HIP events on the render stream (separate, profiled frames) ----
-    hip.profile(True)
-    prof = {"tiles": [0.0, 0], "points": [0.0, 0], "normals": [0.0, 0], "other": [0.0, 0]}
+    # Every launch of an assembly kernel sits between its own pair of events; the same frames fill the device's op counters
+    # (tile levels: tape ops read / written; leaf stage: tape words x passes, lane operations), so numerator and denominator
+    # of every roofline figure below come from the same frames.
     PROF_FRAMES = 3
-    kern = {}   # per assembly kernel: every launch between its own pair of HIP events
-    for _ in range(PROF_FRAMES):
-        F.render3d(shape, n, out=out, shard=rank, n_shards=world)
-        for k, (ms, cnt) in hip.profile_read().items():
-            prof[k][0] += ms
-            prof[k][1] += cnt
-        for k, (ms, cnt) in hip.profile_read_kernels().items():
-            kern.setdefault(k, [0.0, 0])
-            kern[k][0] += ms
-            kern[k][1] += cnt
-    # ... and one profiled frame with the column-invariance short cuts off: the leaf kernel then does all the work the
-    # algorithmic byte count stands for (with them on it skips most of it, and its roofline fraction flatters it)
-    kern_general, tile_phases_general = {}, None
-    if world == 1 and not args.no_general:
-        os.environ["FHIP_NO_COLUMN_INV"] = "1"
-        F.render3d(shape, n, out=out)
-        hip.profile_read()
-        for k, (ms, cnt) in hip.profile_read_kernels().items():
-            kern_general[k] = (ms, cnt)
-        hip.wave_stats()
-        tile_phases_general = hip.tile_phases     # tape ops read / written per tile level when no tile is skipped as a copy along z
-        del os.environ["FHIP_NO_COLUMN_INV"]
-        hip.profile(False)
-        F.render3d(shape, n, out=out)       # (leaves the default path's image in `out` and its counters in the context)
-        hip.profile(True)
-        F.render3d(shape, n, out=out)
-        hip.profile_read(); hip.profile_read_kernels()
-    hip.profile(False)
-    hip.wave_stats()
-    tile_phases = hip.tile_phases  # device counters of the last frame: tape ops read / written per tile level
+
+    def profiled(no_inv):
+        prof = {"tiles": [0.0, 0], "points": [0.0, 0], "normals": [0.0, 0], "other": [0.0, 0]}
+        kern, leaf, tiles = {}, None, None
+        with hip.options(no_column_inv=1 if no_inv else hip.option("no_column_inv")):
+            hip.profile(True)
+            for _ in range(PROF_FRAMES):
+                F.render3d(shape, n, out=out, shard=rank, n_shards=world)
+                for k, (ms, cnt) in hip.profile_read().items():
+                    prof[k][0] += ms
+                    prof[k][1] += cnt
+                for k, (ms, cnt) in hip.profile_read_kernels().items():
+                    kern.setdefault(k, [0.0, 0])
+                    kern[k][0] += ms
+                    kern[k][1] += cnt
+                hip.wave_stats()
+                tiles, leaf = hip.tile_phases, hip.leaf_stats()     # (per frame: the counters are reset by every render)
+            hip.profile(False)
+        return {"prof": prof, "kern": kern, "leaf": leaf, "tiles": tiles}
+
+    prof_default = profiled(False) if not args.only_general else None
+    prof_general = profiled(True) if (world == 1 and not args.no_general) else None
+    F.render3d(shape, n, out=out, shard=rank, n_shards=world)       # (leaves the timed path's image in `out`)
     if world > 1:
         step()  # leave `out` holding the combined image on rank 0
-        fence()
+    fence()
 
     if rank != 0:
         if world > 1:
@@ -278,33 +294,114 @@ def main():
         return
 
     ms_per_step = dt / args.steps * 1e3
-    value = (n ** 3) * frames_per_step * args.steps / dt / 1e6
+    value = (n ** 3) * args.steps / dt / 1e6
+    pmain = prof_default or prof_general
     result = {
         "metric": "Mvoxel/s (interval+point eval) on prospero.vm 1024^3",
         "value": value, "unit": "Mvoxel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(frame_ms)), "ms_per_step_min": float(np.min(frame_ms)),
-        "higher_is_better": True, "scaling": "weak" if frames_per_step > 1 else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "frame_latency_ms": float(np.median(lat)),
-        "without_column_invariance": general,
+        "frame_latency_ms": lat_default,
+        "general": general,
+        "host_output_frame_ms": host_frame,
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
                    "sharding": sharding,
                    "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (two buffer "
                              "sets per context: the coarse levels of a frame run beside the previous frame's slabs), every frame does all of its "
-                             "work; frame_latency_ms is one frame alone",
-                   "column_invariance": "tapes that read no input varying along z (under this camera: no z) are evaluated once per pixel "
-                                        "column / once per z-stack of tiles (DESIGN.md section 2); prospero.vm is an extrusion, so all of its "
-                                        "tapes qualify - `without_column_invariance` times the same frames with the short cuts off"},
-        "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in prof.items()},
-        "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in prof.items()},
-        "asm_kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in kern.items() if v[1]},
+                             "work; frame_latency_ms is one frame alone, host_output_frame_ms the blocking call with a host buffer",
+                   "column_invariance": ("OFF for every number of this line (--only-general)" if args.only_general else
+                                         "tapes that read no input varying along z (under this camera: no z) are evaluated once per pixel "
+                                         "column / once per z-stack of tiles (DESIGN.md section 2); prospero.vm is an extrusion, so all of its "
+                                         "tapes qualify - `general` times the same frames with the short cuts off, and `roofline` is that path's")},
+        "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in pmain["prof"].items()},
+        "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in pmain["prof"].items()},
+        "asm_kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in pmain["kern"].items() if v[1]},
         "arena_ops_last_slab": counters["arena_ops"], "arena_overflow": counters["arena_overflow"],
     }
+    if prof_general and prof_default:
+        result["general"]["asm_kernel_ms_per_frame"] = {k: v[0] / PROF_FRAMES for k, v in prof_general["kern"].items() if v[1]}
     if partitions:
         result["partitions"] = partitions
         result["collectives"] = direct_note
 
-    # ---- cpu_baseline + parity + algorithmic bytes (oracle; rank 0, N = 1 only) -----------------
+    # ---- roofline: numerators from the device counters of the profiled frames themselves ----------------
+    # HBM traffic per launch: rocprofv3 PMC passes of tools/profile_round.sh, committed under profiles/ (counters cannot be
+    # collected inside the timed run); the file names the hash of the device sources it was measured on and is ignored
+    # (traffic = null) when that is not this build.  FETCH_SIZE doubled per MI355X_MICROARCH.md.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_hash import source_hash
+    traffic, traffic_note = {}, None
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+        if traffic.get("source_hash") != source_hash():
+            traffic_note = f"{TRAFFIC_FILE} was measured on sources {traffic.get('source_hash')}, this build is {source_hash()}: traffic not reported"
+            traffic = {}
+    else:
+        traffic_note = f"{TRAFFIC_FILE} not present: traffic not reported"
+
+    def roof(P, path, kernel, alg_bytes_per_frame, lane_ops_per_frame, note):
+        ms, launches = P["kern"].get(kernel, (0.0, 0))
+        if not launches:
+            return None
+        per_frame_ms, launches_pf = ms / PROF_FRAMES, launches // PROF_FRAMES
+        achieved = alg_bytes_per_frame / (per_frame_ms * 1e-3) / 1e9
+        t = (traffic.get(path) or {}).get(kernel)
+        tb = None
+        if t:
+            tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
+        r = {"bound": "hbm", "kernel": kernel, "path": path, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
+             "algorithmic_bytes_per_launch": alg_bytes_per_frame / max(launches_pf, 1), "avg_launch_ms": per_frame_ms / max(launches_pf, 1),
+             "launches_per_frame": launches_pf, "note": note}
+        if lane_ops_per_frame:
+            a = lane_ops_per_frame / (per_frame_ms * 1e-3)
+            r["alu"] = {"bound": "valu", "achieved": a / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s", "frac": a / VALU_PEAK_LANE_OPS,
+                        "lane_ops_per_launch": lane_ops_per_frame / max(launches_pf, 1),
+                        "note": "useful f32 lane-operations (tape ops x lanes evaluating them; an interval op counts once per child) against the "
+                                "plain-f32 VALU rate: what binds an interpreter - it issues ~20-40 instructions per useful op (DESIGN.md section 6)"}
+        if t and "valu_per_launch" in t and per_frame_ms > 0:
+            cycles = per_frame_ms / max(launches_pf, 1) * 1e-3 * t.get("clock_hz", 2.4e9)
+            ipc = (t["valu_per_launch"] + t["salu_per_launch"]) / (cycles * 1024)
+            r["issue"] = {"bound": "instruction issue", "achieved": ipc, "peak": 0.57, "unit": "wave-instructions / cycle / SIMD",
+                          "frac": ipc / 0.57, "valu_per_launch": t["valu_per_launch"], "salu_per_launch": t["salu_per_launch"]}
+        if traffic_note:
+            r["traffic_note"] = traffic_note
+        return r
+
+    def roofs(P, path):
+        leaf, tiles = P["leaf"], P["tiles"]
+        kname = "fh_columns"
+        r_leaf = roof(P, path, kname, 8.0 * leaf["tape_words_read"] + n * n * 16, leaf["lane_ops"],
+                      "leaf interpreter: algorithmic bytes = 8 B x (leaf tape ops x passes of the kernel over the tape) + the 16 B image pixel once, from "
+                      "the device's counters of the timed frames; tape words are wave-uniform loads served by L2 / the scalar cache, so the kernel is bound "
+                      "by instruction issue, not by HBM (DESIGN.md sections 4 and 6)")
+        lv = [v for k, v in tiles.items() if int(k[1:]) >= 2]
+        r_tiles = roof(P, path, "fh_tiles_v32", 8.0 * (sum(v["ops"] for v in lv) + sum(v["ops_written"] for v in lv)),
+                       64.0 * sum(v["ops"] for v in lv),
+                       "interval interpreter + lockstep prune with the register file in VGPRs (per-slab level): bound by the latency of each parent's "
+                       "dependent op chain (one wave per parent); algorithmic bytes = tape ops read + written at that level in the timed frames")
+        return r_leaf, r_tiles
+
+    if world > 1:
+        prof_general = prof_default = None      # (the roofline objects are rank 0's at N = 1, as the contract says)
+    if prof_general:
+        r_leaf, r_tiles = roofs(prof_general, "general")
+        per_frame = lambda r: r["avg_launch_ms"] * r["launches_per_frame"] if r else 0.0
+        result["roofline"] = r_leaf if per_frame(r_leaf) >= per_frame(r_tiles) else r_tiles
+        result["roofline_leaf"], result["roofline_tiles"] = r_leaf, r_tiles
+    if prof_default:
+        d_leaf, d_tiles = roofs(prof_default, "default")
+        result["roofline_default_path"] = d_leaf
+        result["roofline_tiles_default_path"] = d_tiles
+        if "roofline" not in result:
+            per_frame = lambda r: r["avg_launch_ms"] * r["launches_per_frame"] if r else 0.0
+            result["roofline"] = d_leaf if per_frame(d_leaf) >= per_frame(d_tiles) else d_tiles
+    if world == 1:
+        result["device_counters"] = {k: {"leaf": v["leaf"], "tile_levels": v["tiles"]} for k, v in (("general", prof_general), ("default", prof_default)) if v}
+
+    # ---- cpu_baseline + parity (oracle; rank 0, N = 1 only) -----------------------------------------------------------------
     if not args.no_cpu and world == 1:
         import oracle as O
         oshape = O.Shape.from_vm(os.path.join(ROOT, "models", args.model))
@@ -312,7 +409,8 @@ def main():
         got = out.cpu().numpy().view(np.uint32).reshape(n, n, 4)
         want = ref.view(np.uint32).reshape(n, n, 4)
         result["parity"] = {"depth_equal": bool((got[..., 3] == want[..., 3]).all()),
-                            "normals_equal": bool((got[..., :3].view(np.float32) == want[..., :3].view(np.float32)).all())}
+                            "normals_equal": bool((got[..., :3].view(np.float32) == want[..., :3].view(np.float32)).all()),
+                            "general_path_image_equals_default": None if not general else general["image_equals_default_path"]}
         cores = O.max_threads()
         CPU_FRAMES = 10
         secs = sorted(O.render3d(oshape, n)[2] for _ in range(CPU_FRAMES))
@@ -327,81 +425,33 @@ def main():
                                             "61.7/23.6 = 2.6x, README.md:154)",
                                   "one_thread": {"value": (small ** 3) / one / 1e6, "unit": "Mvoxel/s", "cores": 1,
                                                  "sample": f"median of 3 frames at {small}^3 (1/{(n // small) ** 3} of the volume), one thread"}}
-        # ---- roofline ---------------------------------------------------------------
-        # Algorithmic bytes: 8 B per tape word read per wavefront pass + 8 B per tape word written
-        # + 2 bit per recorded choice + the W*H*16 B image once.  The tile stage's op counts come
-        # from the device's own counters (its subdivision 128/32/8 differs from the oracle's
-        # 128/64/32/16/8 schedule; pruning is deterministic, so they are exact for this frame);
-        # the leaf stage's from the oracle (same leaves, same pruned tapes).
-        # HBM traffic per launch: rocprofv3 PMC passes of tools/profile_round.sh, committed under profiles/ (counters cannot
-        # be collected inside the timed run); the file names the hash of the device sources it was measured on and is
-        # ignored (traffic = null) when that is not this build.  FETCH_SIZE doubled per MI355X_MICROARCH.md.
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from src_hash import source_hash
-        traffic, traffic_note = {}, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-            if traffic.get("source_hash") != source_hash():
-                traffic_note = f"profiles/traffic_r02.json was measured on sources {traffic.get('source_hash')}, this build is {source_hash()}: traffic not reported"
-                traffic = {}
-
-        def roof(kernel, alg_bytes, k_ms, launches, note):
-            # the kernel's own launches, each timed with HIP events on its stream (profiled frames); these
-            # averages are the ones profiles/*/kernel_stats.csv (rocprofv3 --stats) has to agree with
-            if kernel in kern and kern[kernel][1]:
-                k_ms, launches = kern[kernel][0] / PROF_FRAMES, kern[kernel][1] // PROF_FRAMES
-            achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            t = traffic.get(kernel)
-            tb = None
-            if t:
-                tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
-            r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
-                 "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1), "avg_launch_ms": k_ms / max(launches, 1),
-                 "launches_per_frame": launches, "note": note}
-            if t and "valu_per_launch" in t and k_ms > 0:
-                # the bound that actually holds: wave-instructions issued per SIMD per cycle against the ceiling the
-                # micro-benchmarks give for independent VALU work at 4 waves per SIMD (profiles/r02/ubench.json)
-                cycles = k_ms / max(launches, 1) * 1e-3 * t.get("clock_hz", 2.4e9)
-                ipc = (t["valu_per_launch"] + t["salu_per_launch"]) / (cycles * 1024)
-                r["issue"] = {"bound": "instruction issue", "achieved": ipc, "peak": 0.57, "unit": "wave-instructions / cycle / SIMD",
-                              "frac": ipc / 0.57, "valu_per_launch": t["valu_per_launch"], "salu_per_launch": t["salu_per_launch"]}
-            if traffic_note:
-                r["traffic_note"] = traffic_note
-            g = kern_general.get(kernel)
-            if g and g[1] and g[0] > 0:
-                # the same algorithmic bytes over the kernel's time when nothing is skipped as column-invariant
-                r["without_column_invariance"] = {"avg_launch_ms": g[0] / g[1], "achieved": alg_bytes / (g[0] * 1e-3) / 1e9,
-                                                  "frac": alg_bytes / (g[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            return r
-
-        kms, kl = result["kernel_ms_per_frame"], result["kernel_launches_per_frame"]
-        # Two kernels carry the frame: fh_columns (leaf interpreter) and fh_tiles_v32 (tile stage of the per-slab level and part
-        # of level 1).  `roofline` is the one with more time per frame in this run (profiles/: rocprofv3 --stats agrees), the other
-        # follows as `roofline_leaf` / `roofline_tiles`.  ALGORITHMIC bytes: the leaf stage's from the oracle (every voxel of every
-        # leaf), the tile stage's from the device's op counters of a frame with the column-invariance short cuts off (every tile of
-        # the 128 / 32 / 8 subdivision) - prospero's tapes are column-invariant, so the default path evaluates one leaf per stack,
-        # once per pixel, and one z-layer of tiles: it touches far fewer bytes (`traffic`), and `without_column_invariance` gives
-        # the same figure with the short cuts off.
-        leaf_bytes = 8.0 * st["float_wave_ops"] + n * n * 16
-        r_leaf = roof("fh_columns", leaf_bytes, kms["points"], 8,
-                      "tape words are wave-uniform loads served by L2: the leaf interpreter is bound by instruction issue (see `issue`), "
-                      "not by HBM: DESIGN.md sections 4 and 6.  Algorithmic bytes are the oracle's (every voxel of every leaf); the "
-                      "column-invariance short cuts skip most of that work for prospero.vm - see `without_column_invariance`")
-        tp = tile_phases_general or tile_phases
-        lv = [v for k, v in tp.items() if int(k[1:]) >= 2]
-        tile_bytes = 8.0 * (sum(v["ops"] for v in lv) + sum(v["ops_written"] for v in lv))
-        r_tiles = roof("fh_tiles_v32", tile_bytes, kms["tiles"], 8,
-                       "interval interpreter + lockstep prune with the register file in VGPRs: bound by the latency of each parent's "
-                       "dependent op chain (one wave per parent) and by instruction issue; algorithmic bytes = tape ops read + written at "
-                       "the per-slab level with no tile skipped as a copy along z")
-        def per_frame(r):
-            return r["avg_launch_ms"] * r["launches_per_frame"]
-        result["roofline"] = r_tiles if per_frame(r_tiles) > per_frame(r_leaf) else r_leaf
-        result["roofline_leaf"], result["roofline_tiles"] = r_leaf, r_tiles
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
+        # BASELINE configuration 3 (the gradient path on a tape with transcendental opcodes): frame time and the measured error
+        # of the normals, in ulp of the gradient's scale (its largest component), against the oracle (glibc libm)
+        bear = os.path.join(ROOT, "models", "bear.vm")
+        if os.path.exists(bear) and args.model == "prospero.vm":
+            m = 512
+            bs, bo = F.Shape.from_vm(bear, hip=hip), O.Shape.from_vm(bear)
+            bout = torch.zeros((m, m, 4), dtype=torch.int32, device=dev)
+            for _ in range(3):
+                F.render3d(bs, m, out=bout)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                F.render3d(bs, m, out=bout)
+            fence()
+            bms = (time.perf_counter() - t0) / 10 * 1e3
+            a = bout.cpu().numpy().view(np.uint32).reshape(m, m, 4)
+            b = O.render3d(bo, m)[0]
+            an, bn = a[..., :3].view(np.float32), b["normal"]
+            scale = np.maximum(np.abs(bn).max(axis=2, keepdims=True), 2.0 ** -100)
+            with np.errstate(invalid="ignore"):
+                ulp = np.abs(an - bn) / (scale * 2.0 ** -23)
+            result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
+                                 "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
+                                 "note": "transcendental opcodes: the north star grants 1 ulp per f32 value; per opcode the device is within 1 ulp of glibc over all "
+                                         "2^32 inputs (profiles/r02/math_sweep.json), a gradient chains several of them"}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -48,14 +48,14 @@ HIP_TILES_2D, HIP_TILES_3D = [128, 16], [128, 32, 8]
 VM_TILES_2D, VM_TILES_3D = [128, 32, 8], [128, 64, 32, 16, 8]
 
 EXPORTS = [
-    "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset",
+    "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset", "fhip_ctx_set_option", "fhip_ctx_get_option",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
     "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -127,6 +127,7 @@ def lib():
             "fhip_ctx_create": (i32, [i32, vp, C.POINTER(vp)]), "fhip_ctx_destroy": (None, [vp]),
             "fhip_last_error": (C.c_char_p, [vp]), "fhip_ctx_sync": (i32, [vp]),
             "fhip_cancel": (None, [vp]), "fhip_cancel_reset": (None, [vp]),
+            "fhip_ctx_set_option": (i32, [vp, C.c_char_p, i32]), "fhip_ctx_get_option": (i32, [vp, C.c_char_p, C.POINTER(i32)]),
             "fhip_tape_from_bytecode": (i32, [vp, vp, C.c_size_t, C.POINTER(vp)]), "fhip_tape_free": (None, [vp]),
             "fhip_tape_len": (u32, [vp]), "fhip_tape_choice_count": (u32, [vp]), "fhip_tape_reg_count": (u32, [vp]),
             "fhip_tape_var_count": (u32, [vp]), "fhip_tape_output_count": (u32, [vp]),
@@ -155,7 +156,7 @@ def lib():
             "fhip_mesh_merge": (i32, [vp, vp, vp, u32, vp, C.POINTER(vp)]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
-            "fhip_debug_stats": (i32, [vp, vp]),
+            "fhip_debug_stats": (i32, [vp, vp]), "fhip_debug_leaf_stats": (i32, [vp, vp]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
             "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]), "fhip_tape_term_group": (i32, [vp, vp, u32, vp]),
             "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
@@ -214,6 +215,32 @@ class HipContext:
     def cancel_reset(self):
         lib().fhip_cancel_reset(self._h)
 
+    def set_option(self, name, value=1):
+        """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "slab_contexts", ...).  The environment
+        (FHIP_<NAME>) is read once, when the context is created; this is the only way to change a switch afterwards."""
+        self.check(lib().fhip_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def option(self, name):
+        v = C.c_int(0)
+        self.check(lib().fhip_ctx_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: switches set for the duration of a block, then restored."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return scope()
+
     def profile(self, on):
         lib().fhip_profile_enable(self._h, int(on))
 
@@ -262,6 +289,12 @@ class HipContext:
         buf = np.zeros(n, np.uint64)
         got = lib().fhip_debug_arena(self._h, int(off), int(n), _p(buf))
         return buf[:got]
+
+    def leaf_stats(self):
+        """Leaf-stage counters of the last profiled 3D frame (render_state.h leaf_stat)."""
+        c = np.zeros(8, np.uint64)
+        self.check(lib().fhip_debug_leaf_stats(self._h, _p(c)))
+        return {"leaves": int(c[0]), "tape_ops": int(c[1]), "tape_words_read": int(c[2]), "lane_ops": int(c[3])}
 
     def wave_stats(self):
         """Per kernel kind: mean / max busy microseconds of the waves that found work, their

@@ -2,8 +2,10 @@
 // Single translation unit: the kernels are included so that one `hipcc -shared` builds
 // everything for gfx950.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -74,6 +76,37 @@ static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_e
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
+// Behaviour switches of a context - diagnostics and tuning, none is needed in normal use.  They are part of the context, not of
+// the process: read ONCE from the environment when the context is created (FHIP_<NAME IN CAPITALS>, for runs of unmodified
+// programs under a switch) and changed afterwards only through fhip_ctx_set_option(ctx, "<name>", value) - nothing in a
+// render's launch path looks at the environment.  name, default; DESIGN.md section 5 says what each one selects.
+#define FH_OPTION_LIST(X)                                                                                                       \
+    X(no_asm, 0) X(no_split, 0) X(probe, 0) X(no_pipeline, 0) X(slab_contexts, 4) X(no_frame_pipeline, 0) X(arena_mb, 4096)     \
+    X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
+    X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
+    X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2)                        \
+    /* fixed when the context is created (they decide which streams exist): environment only */                                 \
+    X(leaf_streams, 1) X(pre_priority, 0)
+struct FhOptions {
+#define X(name, dflt) int name = dflt;
+    FH_OPTION_LIST(X)
+#undef X
+};
+struct FhOptionEntry { const char* name; int FhOptions::*field; };
+static const FhOptionEntry FH_OPTION_TABLE[] = {
+#define X(name, dflt) {#name, &FhOptions::name},
+    FH_OPTION_LIST(X)
+#undef X
+};
+static void options_from_env(FhOptions& o) {
+    for (const FhOptionEntry& e : FH_OPTION_TABLE) {
+        std::string var = "FHIP_";
+        for (const char* c = e.name; *c; c++) var += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(var.c_str())) o.*(e.field) = *v ? atoi(v) : 1;    // (set but empty counts as 1)
+    }
+}
+
 // Everything one frame of a render owns on the device.  A context holds two sets: an asynchronous 3D render takes the set
 // the previous frame did not use, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
 // run on a stream of their own beside the previous frame's slabs (frame pipelining, FHIP_NO_FRAME_PIPELINE=1 turns it off).
@@ -96,6 +129,7 @@ struct FrameBufs {
     }
 };
 struct fhip_ctx : FrameBufs {
+    FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
     FrameBufs other;                // the set of the frame before (or after) the current one
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
@@ -121,6 +155,7 @@ struct fhip_ctx : FrameBufs {
     bool launch_failed = false;     // an assembly kernel launch of the current frame failed (reported when the frame has been queued)
     std::atomic<int> cancelled{0};
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
+    DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[4];   // pinned (upload_frame)
     void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
     size_t mesh_pinned_cap = 0;
@@ -137,6 +172,17 @@ struct fhip_ctx : FrameBufs {
     FhRenderState last_state;
     bool have_last_state = false;
 };
+
+// The cached forms of some options (what the rest of the driver reads)
+static void apply_options(fhip_ctx* c) {
+    c->use_asm = c->opt.no_asm == 0;
+    c->use_split = c->opt.no_split == 0;
+    c->probe = c->opt.probe != 0;
+    c->use_pipeline = c->opt.no_pipeline == 0;
+    c->frame_pipeline = c->opt.no_frame_pipeline == 0;
+    c->slab_contexts = (uint32_t)std::min(4, std::max(2, c->opt.slab_contexts));
+    c->arena_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
+}
 
 static fhip_status finish_render(fhip_ctx* ctx);
 static void mesh_cache_release(void* octree);      // (defined with the mesh code)
@@ -180,7 +226,8 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-    if (const char* mb = getenv("FHIP_ARENA_MB")) c->arena_bytes = (size_t)atol(mb) << 20;
+    options_from_env(c->opt);
+    apply_options(c);
     // allow the full 160 KiB of LDS for the interpreters' register files
     const void* fns[] = {(const void*)k_eval_f32<false>, (const void*)k_eval_interval<false>, (const void*)k_eval_grad<false>,
                          (const void*)k_tiles<false, false, true, 16>, (const void*)k_tiles<false, true, true, 16>,
@@ -194,13 +241,8 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (hipModuleLoadData(&c->asm_mod, fh_interp_co) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     for (int i = 0; i < FH_ASM_COUNT; i++)
         if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-    if (const char* e = getenv("FHIP_NO_ASM")) c->use_asm = atoi(e) == 0;
     (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     (void)hipGetLastError();
-    if (const char* e = getenv("FHIP_NO_SPLIT")) c->use_split = atoi(e) == 0;
-    if (const char* e = getenv("FHIP_PROBE")) c->probe = atoi(e) != 0;
-    if (const char* e = getenv("FHIP_NO_PIPELINE")) c->use_pipeline = atoi(e) == 0;
-    if (const char* e = getenv("FHIP_SLAB_CONTEXTS")) c->slab_contexts = (uint32_t)std::min(4, std::max(2, atoi(e)));
     {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -210,19 +252,19 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
-    if (getenv("FHIP_LEAF_STREAMS") && atoi(getenv("FHIP_LEAF_STREAMS")) == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
+    if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
-    if (const char* e = getenv("FHIP_NO_FRAME_PIPELINE")) c->frame_pipeline = atoi(e) == 0;
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const int pp = getenv("FHIP_PRE_PRIORITY") ? atoi(getenv("FHIP_PRE_PRIORITY")) : 0;
+        const int pp = c->opt.pre_priority;
         const hipError_t e = pp == 0 ? hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking)
                                      : hipStreamCreateWithPriority(&c->stream_pre, hipStreamNonBlocking, pp == 1 ? lo : hi);
         if (e != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     }
+    if (c->sticky.ensure(256) != hipSuccess || hipMemset(c->sticky.p, 0, 256) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
         (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
@@ -243,7 +285,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->tmp_out, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e};
+    DevBuf* bufs[] = {&c->tmp_out, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->sticky};
     for (DevBuf* b : bufs) b->release();
     c->release_all();
     c->other.release_all();
@@ -286,10 +328,37 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
         const fhip_status s2 = finish_render(c);
         if (st == FHIP_OK) st = s2;
     }
+    // frames older than the last two (their buffer sets have been re-used since): the flag every frame's last kernel latches
+    uint32_t sticky = 0;
+    HIP_TRY(c, hipMemcpy(&sticky, c->sticky.p, 4, hipMemcpyDeviceToHost));
+    if (sticky) {
+        HIP_TRY(c, hipMemset(c->sticky.p, 0, 4));
+        if (st == FHIP_OK) st = fail(c, FHIP_ERR_OVERFLOW, "device work queue overflow in an earlier asynchronous frame");
+    }
     return st;
 }
 void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
 void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
+// Behaviour switches (FH_OPTION_LIST above).  Waits for the frames in flight first: a switch never changes under a frame.
+fhip_status fhip_ctx_set_option(fhip_ctx* c, const char* name, int value) {
+    if (!c || !name) return FHIP_ERR_UNSUPPORTED;
+    if (!strcmp(name, "leaf_streams") || !strcmp(name, "pre_priority")) return fail(c, FHIP_ERR_UNSUPPORTED, std::string(name) + " is fixed when the context is created");
+    for (const FhOptionEntry& e : FH_OPTION_TABLE)
+        if (!strcmp(e.name, name)) {
+            if (c->opt.*(e.field) == value) return FHIP_OK;
+            const fhip_status st = fhip_ctx_sync(c);
+            c->opt.*(e.field) = value;
+            apply_options(c);
+            return st;
+        }
+    return fail(c, FHIP_ERR_UNSUPPORTED, std::string("unknown option ") + name);
+}
+fhip_status fhip_ctx_get_option(const fhip_ctx* c, const char* name, int* value) {
+    if (!c || !name || !value) return FHIP_ERR_UNSUPPORTED;
+    for (const FhOptionEntry& e : FH_OPTION_TABLE)
+        if (!strcmp(e.name, name)) { *value = c->opt.*(e.field); return FHIP_OK; }
+    return FHIP_ERR_UNSUPPORTED;
+}
 
 // ---- tapes -----------------------------------------------------------------------------
 static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** out) {
@@ -386,6 +455,9 @@ static bool tape_asm_ok(const fh::HostTape& t) {
 static fhip_status tape_to_device(fhip_ctx* ctx, const fhip_tape* t) {
     std::lock_guard<std::mutex> guard(t->upload_lock);
     (void)hipSetDevice(ctx->device);
+    // (a tape's lazily made device copies live on the device of the first context that needed them: a tape used from several
+    // devices has to be built per device - refused rather than dereferenced from the wrong one)
+    if (t->device >= 0 && t->device != ctx->device) return fail(ctx, FHIP_ERR_UNSUPPORTED, "this tape's device copies belong to another device: build the tape per device");
     if (t->d_ops) return FHIP_OK;
     t->device = ctx->device;
     size_t bytes = (t->t.ops.size() + 16) * 8;  // slack: the interpreters prefetch up to 12 ops past the end
@@ -689,9 +761,9 @@ static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint3
     return std::vector<uint32_t>(tiles + i, tiles + n);
 }
 
-static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size) {
+static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size, bool vm_tiles) {
     std::vector<uint32_t> v = trim_tiles(VM_TILES_3D, 5, max_size);
-    if (getenv("FHIP_VM_TILES")) return v;  // diagnostics: the reference's own subdivision
+    if (vm_tiles) return v;  // diagnostics: the reference's own subdivision
     std::vector<uint32_t> out{v[0]};
     for (uint32_t t = v[0]; t > 8;) { t = std::max<uint32_t>(t / 4, 8); out.push_back(t); }
     return out;
@@ -754,7 +826,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
     R.full = tape_is_full(t);
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
-    R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !getenv("FHIP_NO_COLUMNS_T"));
+    R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
     R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
@@ -860,18 +932,18 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
-    R.split = ctx->use_split && R.tl == 64 && (is3d || !getenv("FHIP_NO_SPLIT_2D"));
-    R.asm_tiles = R.split && ctx->use_asm && !getenv("FHIP_NO_ASM_TILES") && tape_asm_ok(t) && t.n_regs <= 128;
+    R.split = ctx->use_split && R.tl == 64 && (is3d || !ctx->opt.no_split_2d);
+    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && tape_asm_ok(t) && t.n_regs <= 128;
     // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
     // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
     {
-        static const uint32_t p1_levels = getenv("FHIP_PRUNE1_LEVELS") ? (uint32_t)atoi(getenv("FHIP_PRUNE1_LEVELS")) : 1u;
+        const uint32_t p1_levels = (uint32_t)std::max(0, ctx->opt.prune1_levels);
         R.exp_levels = is3d ? std::min(S.pre_levels, p1_levels) : std::min(1u, p1_levels);
     }
-    R.prune1 = R.asm_tiles && R.exp_levels > 0 && !getenv("FHIP_NO_PRUNE1");
+    R.prune1 = R.asm_tiles && R.exp_levels > 0 && !ctx->opt.no_prune1;
     // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
     // waves, then the tree itself; the prune sees the root tape with its usual choices
-    R.groups = R.prune1 && !tape->tgroups.empty() && !getenv("FHIP_NO_TAPE_GROUPS");
+    R.groups = R.prune1 && !tape->tgroups.empty() && !ctx->opt.no_tape_groups;
     S.n_tgroups = 0;
     if (R.groups) {
         uint32_t off = (uint32_t)t.ops.size() + 16, mr = 1, mc = 0;
@@ -889,6 +961,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
             S.troot_len = (uint32_t)t.ops.size(); S.troot_choices = t.n_choices; S.troot_regs = std::max<uint32_t>(t.n_regs, 1);
             S.arena_head = S.arena_root_end = off;
             std::lock_guard<std::mutex> guard(tape->upload_lock);
+            if (tape->device >= 0 && tape->device != ctx->device) return fail(ctx, FHIP_ERR_UNSUPPORTED, "this tape's device copies belong to another device: build the tape per device");
+            tape->device = ctx->device;
             if (!tape->d_top) {
                 static_assert(sizeof(FhTopOp) == sizeof(fh::TopOp), "top op layout");
                 HIP_TRY(ctx, hipMalloc((void**)&tape->d_top, tape->plan.top.size() * sizeof(FhTopOp)));
@@ -936,7 +1010,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     S.normals = (float*)ctx->normals.p;
     S.image2d = nullptr;
     memset(S.stat, 0, sizeof(S.stat));
-    S.want_stats = (ctx->profiling || ctx->probe || getenv("FHIP_STATS")) ? 1 : 0;
+    memset(S.leaf_stat, 0, sizeof(S.leaf_stat));
+    S.want_stats = (ctx->profiling || ctx->probe || ctx->opt.stats) ? 1 : 0;
     if (((size_t)t.ops.size() + 64) * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
     // level-0 groups sit at the back of queue[0] (the "big" half), in reverse order
     std::reverse(R.roots.begin(), R.roots.end());
@@ -957,6 +1032,7 @@ static fhip_status finish_render(fhip_ctx* ctx) {
         ctx->last_state.queue_overflow += ctx->last_state_b.queue_overflow;
         ctx->last_state.arena_overflow += ctx->last_state_b.arena_overflow;
         for (int i = 0; i < 64; i++) ctx->last_state.stat[i] += ctx->last_state_b.stat[i];
+        for (int i = 0; i < 8; i++) ctx->last_state.leaf_stat[i] += ctx->last_state_b.leaf_stat[i];
     }
     ctx->have_last_state = true;
     if (ctx->last_state.queue_overflow) return fail(ctx, FHIP_ERR_OVERFLOW, "device work queue overflow");
@@ -1015,7 +1091,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     // Persistent waves with a static round robin over the parents.  (FHIP_ONE_EACH_TILES=1: one short
     // workgroup per parent instead - measured slower in the pipelined frame: the tile stage then
     // takes more of the machine from the leaf kernel it overlaps with.)
-    const uint32_t one_each = getenv("FHIP_ONE_EACH_TILES") ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
+    const uint32_t one_each = ctx->opt.one_each_tiles ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
     const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
     const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
@@ -1061,12 +1137,12 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // boundaries per slab, whatever the number of hardware queues.)
             hipStream_t const rest_stream = ctx->stream2;
             const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && rest_stream &&
-                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !getenv("FHIP_PIPE_SERIAL") && is3d;
+                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !ctx->opt.pipe_serial && is3d;
             hipStream_t const big_stream = side ? rest_stream : nullptr;
             // Tapes of <= 32 registers / 256 choices (the small slot list: every parent of the leaf level) and, from the other
             // list, those of <= 64 / 512 go to the kernels that keep the interval file, the choices and the prune's register
             // map in VGPRs (fh_tiles_v32: 16 waves per CU, fh_tiles_v64: 8; no LDS); what is left takes the LDS layouts.
-            static const bool use_v = !getenv("FHIP_NO_TILES_V");
+            const bool use_v = !ctx->opt.no_tiles_v;
             const bool vk = use_v && !exp;
             bool both_lists = false;
             if (level > 0) {
@@ -1078,9 +1154,9 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 // (a pre-pass level has a few hundred parents in the two lists together: fh_tiles_v64 takes both in ONE launch
                 // below - the level's time is its slowest parent's either way, and a launch of its own for the small list put
                 // another 130 us on the coarse levels' chain)
-                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side && !getenv("FHIP_NO_BOTH_LISTS");
+                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side && !ctx->opt.no_both_lists;
                 if (vk && !both_lists) {
-                    static const int v32_waves = getenv("FHIP_V32_WAVES") ? atoi(getenv("FHIP_V32_WAVES")) : 16;
+                    const int v32_waves = ctx->opt.v32_waves;
                     ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
                     (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
                 } else if (vk) {
@@ -1093,11 +1169,11 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // (leaving the per-slab levels' big-list parents to the root-sized LDS launch alone - one launch less on the slab's tile
             // chain - was measured: 1.02 vs 1.04 ms per frame, within the noise; not done)
             if (vk && level > 0) {
-                static const int v64_waves = getenv("FHIP_V64_WAVES") ? atoi(getenv("FHIP_V64_WAVES")) : 8;
+                const int v64_waves = ctx->opt.v64_waves;
                 // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
                 // VGPRs each, queued behind the leaf kernel of the slab in front, was measured to hold the tile chain up for
                 // 130 us: a small persistent grid there)
-                static const int v64_slab_waves = getenv("FHIP_V64_SLAB_WAVES") ? atoi(getenv("FHIP_V64_SLAB_WAVES")) : 128;
+                const int v64_slab_waves = ctx->opt.v64_slab_waves;
                 const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
                 ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
                 ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
@@ -1110,7 +1186,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
             // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
             // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
-            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !getenv("FHIP_NO_MID");
+            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !ctx->opt.no_mid;
             if (mid) {
                 const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
@@ -1141,7 +1217,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
     // (last level: fewer waves, several parents each - one leaf reservation per wave)
-    static const int push_mul = getenv("FHIP_PUSH_WAVES") ? atoi(getenv("FHIP_PUSH_WAVES")) : 2;
+    const int push_mul = ctx->opt.push_waves;
     const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
@@ -1185,7 +1261,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
     memcpy(P.mat, m4, sizeof(m4));
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : (getenv("FHIP_VM_TILES") ? trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height))
+                                                     : (ctx->opt.vm_tiles ? trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height))
                                                                                 : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height)));
     st = prepare(ctx, tape, false, ts, PartSpec{}, R);
     if (st) return st;
@@ -1236,13 +1312,13 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     fhip_screen_to_world(size, 3, s2w);
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : hip_tiles_3d(std::max(cfg->width, cfg->height));
+                                                     : hip_tiles_3d(std::max(cfg->width, cfg->height), ctx->opt.vm_tiles != 0);
     // Frame pipelining (asynchronous renders): this frame takes the buffer set the previous frame did not use, and everything up
     // to and including its coarse levels is queued on a stream of its own - it depends on nothing the previous frame does, so it
     // runs beside that frame's slabs.  The slabs' tile chains follow on the side stream (after the previous frame's), the leaf
     // chains and the final image on the caller's stream as before.
     hipStream_t const main_stream = ctx->stream;
-    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !getenv("FHIP_PIPE_SERIAL");
+    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (fpipe) {
         std::swap(static_cast<FrameBufs&>(*ctx), ctx->other);
@@ -1267,9 +1343,9 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
         // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying
         // along z - which is what a model with z in every tape gets)
-        const bool no_inv = getenv("FHIP_NO_COLUMN_INV") != nullptr;
+        const bool no_inv = ctx->opt.no_column_inv != 0;
         if (no_inv) R.col_depmask = 0xFFFFFFFFu;
-        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !no_inv && !getenv("FHIP_NO_ZREP");
+        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !no_inv && !ctx->opt.no_zrep;
     }
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
@@ -1279,7 +1355,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     if (st) return st;
     // (FHIP_DEBUG_ZFILL, diagnostics: every pixel already at the far depth - the front slab's leaf kernel then finds all its
     // leaves but nothing pending, which times its per-workgroup and per-leaf set-up without the interpretation)
-    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, getenv("FHIP_DEBUG_ZFILL") ? 0xFF : 0, npix * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, ctx->opt.debug_zfill ? 0xFF : 0, npix * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
     const uint32_t n_groups = R.groups_per_slab;
     const uint32_t pre = R.S.pre_levels;
@@ -1299,7 +1375,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
     FhRenderState* const dS0 = dS;
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
-    hipStream_t const side_stream = getenv("FHIP_PIPE_SERIAL") ? main_stream : ctx->stream2;  // diagnostics
+    hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
     const uint32_t NC = pipe ? ctx->slab_contexts : 1;
     ctx->forked = pipe ? NC : 0;
     if (pipe) {
@@ -1326,9 +1402,9 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             // the usual pyramid (three levels, 4 x 4 each, 8 x 8 leaf tiles) has a kernel of its own
             // (up to 1024 x 1024: at 2048 x 2048 it was measured SLOWER than the generic kernel - 11.2 vs 8.2 ms per frame)
             const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
-                              ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !getenv("FHIP_OLD_PYR");
+                              ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !ctx->opt.old_pyr;
             const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
-            if (rebuild && pyr3 && pre == 2 && !getenv("FHIP_NO_SLAB_BEGIN")) {
+            if (rebuild && pyr3 && pre == 2 && !ctx->opt.no_slab_begin) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
                 hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
                 return;
@@ -1348,7 +1424,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         }
         // (diagnostics, FHIP_LEAF_STREAMS=2: leaf kernels of consecutive slabs on two streams, so that the tail of one overlaps
         // the head of the next - any interleaving gives the same image - at the price of lanes that no longer see the hits in front)
-        static const bool tail1 = !getenv("FHIP_TAIL_STREAM") || atoi(getenv("FHIP_TAIL_STREAM")) == 1;
+        const bool tail1 = ctx->opt.tail_stream == 1;
         hipStream_t const leaf_stream = (pipe && tail1 && R.asm_points && ctx->stream3 && ctx->stream_leaf2 && (idx & 1)) ? ctx->stream_leaf2 : main_stream;
         if (pipe) HIP_TRY(ctx, hipStreamWaitEvent(leaf_stream, ctx->ev_tiles[idx], 0));
         // The leaf kernel is the slab's critical chain.  What surrounds it - the footprint lists (needed by the normals and the
@@ -1356,7 +1432,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         // hits - are small launches that leave the machine mostly idle, so in the pipelined frame they run on a third stream
         // beside the leaf kernel of the NEXT slab: the normals kernel only takes hits of its own slab's depth range, and a hit
         // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
-        static const int tail_mode = getenv("FHIP_TAIL_STREAM") ? atoi(getenv("FHIP_TAIL_STREAM")) : 1;   // 0: off, 1: lists + normals, 2: normals only
+        const int tail_mode = ctx->opt.tail_stream;   // 0: off, 1: lists + normals, 2: normals only
         const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.tiles[0], z_hi = z_lo + P.tiles[0];
         auto classify_work = [&] {
@@ -1391,14 +1467,14 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
                 // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
                 // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
-                static const uint32_t col_waves = getenv("FHIP_COL_WAVES") ? (uint32_t)atoi(getenv("FHIP_COL_WAVES")) : 0u;
+                const uint32_t col_waves = (uint32_t)std::max(0, ctx->opt.col_waves);
                 // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
                 // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
                 struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
                 else {
-                    static const uint32_t blk = 1u << (getenv("FHIP_COL_BLKL") ? atoi(getenv("FHIP_COL_BLKL")) : 2);   // footprints per workgroup: gen_interp.py BLKL
+                    const uint32_t blk = 1u << ctx->opt.col_blkl;   // footprints per workgroup: gen_interp.py BLKL
                     (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16), leaf_stream);
                 }
             } else if (R.full) {
@@ -1423,7 +1499,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
     }
     if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
-    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out); });
+    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p); });
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;
@@ -1820,11 +1896,16 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     for (int s = 0; s < FH_MAX_INPUTS; s++) { P.in_kind[s] = R.in_kind[s]; P.in_value[s] = R.in_value[s]; }
     const size_t lds_iv = (size_t)P.n_regs * WAVE * 8, lds_leaf = (size_t)P.n_regs * WAVE * 16;
     if (lds_leaf + 1024 > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)fhm::k_mesh_cells, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
-        (void)hipFuncSetAttribute((const void*)fhm::k_mesh_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX - 2048);
-        attr_done = true;
+    {   // (function attributes are per device; contexts on several host threads may arrive here together)
+        static std::mutex attr_lock;
+        static bool attr_done[64] = {};
+        std::lock_guard<std::mutex> guard(attr_lock);
+        const int d = ctx->device & 63;
+        if (!attr_done[d]) {
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_cells, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX - 2048);
+            attr_done[d] = true;
+        }
     }
     fhip_mesh* M = new fhip_mesh();
     M->depth = depth; M->part = part; M->n_parts = n_parts;
@@ -2212,6 +2293,13 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
     fhip_status st = finish_render(ctx);
     if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
     for (int i = 0; i < 64; i++) out[i] = ctx->last_state.stat[i];
+    return FHIP_OK;
+}
+// ... and the leaf stage's counters of the last (profiled) 3D frame: render_state.h leaf_stat
+fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]) {
+    fhip_status st = finish_render(ctx);
+    if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
+    for (int i = 0; i < 8; i++) out[i] = ctx->last_state.leaf_stat[i];
     return FHIP_OK;
 }
 

@@ -36,9 +36,7 @@ struct Tables {
     int e2v[256][12][2];                                              // CELL_TO_EDGE_TO_VERT: (vertex, intersection) offsets or -1
 };
 // build.rs:26-160
-static inline const Tables& tables() {
-    static Tables* T = nullptr;
-    if (T) return *T;
+static inline Tables* build_tables() {
     Tables* t = new Tables();
     for (int i = 0; i < 256; i++) {
         int region_of[2][8];
@@ -92,7 +90,10 @@ static inline const Tables& tables() {
             }
         }
     }
-    T = t;
+    return t;
+}
+static inline const Tables& tables() {
+    static const Tables* const T = build_tables();     // (initialised once, thread-safe: contexts on several host threads build meshes)
     return *T;
 }
 static inline int to_undirected(int start, int end) {     // types.rs DirectedEdge::to_undirected

@@ -965,6 +965,16 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             const uint32_t namb = (uint32_t)__popcll(am), slot = (uint32_t)__popcll(am & ((1ull << lane) - 1));
             // Leaves of a column-invariant parent: the ninst leaves stacked along z hold the same value in every voxel of a pixel's
             // column, so a pixel is hit in the nearest of them or in none - ONE leaf, the nearest, stands for the stack.
+            if (S->want_stats) {    // algorithmic accounting of the leaf stage (render_state.h leaf_stat)
+                const uint32_t passes = inv ? 1u : (child.n_regs <= 8 ? 1u : (child.n_regs <= 16 ? 2u : (child.n_regs <= 32 ? 4u : 8u)));
+                uint32_t s1, s2;
+                wave_excl_sum(amb ? child.len : 0u, s1);
+                wave_excl_sum(amb ? child.len * passes : 0u, s2);
+                if (lane == 0) {
+                    atomicAdd(&S->leaf_stat[0], (unsigned long long)namb); atomicAdd(&S->leaf_stat[1], (unsigned long long)s1);
+                    atomicAdd(&S->leaf_stat[2], (unsigned long long)s2); atomicAdd(&S->leaf_stat[3], (unsigned long long)s1 * (inv ? 64u : 512u));
+                }
+            }
             {
                 const uint32_t lb = leaf_base, iz = cz + (ninst - 1) * T;
                 leaf_base += namb;
@@ -1414,9 +1424,16 @@ __global__ void __launch_bounds__(256) k_slab_begin3(FhRenderState* S, uint32_t 
 }
 
 // Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
-__global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out) {
+// ... and the frame's queue-overflow flags (one per slab context) are latched into the context's sticky word: with frames
+// pipelined over two buffer sets, a set is re-used by the frame after next before the host has looked at its flags.
+__global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out, uint32_t n_ctx, uint32_t* sticky) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const size_t n = (size_t)P.width * P.height;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sticky) {
+        uint32_t q = 0;
+        for (uint32_t k = 0; k < n_ctx; k++) q |= S[k].queue_overflow;
+        if (q) atomicOr(sticky, 1u);
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t d = (uint32_t)(S->zbuf[i] >> 32);
         FhGeometryPixel o;

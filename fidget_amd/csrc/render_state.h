@@ -135,4 +135,9 @@ struct FhRenderState {
     // same-address atomics per parent tile: only in profiled frames)
     uint32_t want_stats, pad_stats;
     unsigned long long stat[64];
+    // ... and of the leaf stage, counted where the leaves are queued (tpush_body, profiled frames only): [0] leaves, [1] their tape
+    // ops, [2] tape ops x passes of the leaf kernel over the tape (<= 8 registers: one pass covers the leaf's 8 voxels per
+    // pixel column, <= 16: two, <= 32: four, LDS class: eight; a leaf of a column-invariant parent: one) = 8-byte tape
+    // words the leaf kernel reads, [3] tape ops x voxels evaluated (64 pixel columns x 8 voxels, or x 1 when column-invariant)
+    unsigned long long leaf_stat[8];
 };

@@ -191,16 +191,20 @@ def block_rect(width, height, root, split, index):
     return y0, y1, x0, x1
 
 
-def gather_blocks(out, image_depth, split, merge, dst=0):
+def gather_blocks(out, image_depth, split, merge, dst=0, root=None):
     """Partition B: every rank passes its partial image `out` ([H, W, 4] int32 torch tensor, zero outside its block);
     rank `dst` gathers the ranks' rectangles and merges the z ranges of each with `merge(front, back, image_depth)`
-    (in place on `front`; fidget_amd.merge_depth on the GPU).  Returns the full image on `dst` (in `out`), `out` elsewhere."""
+    (in place on `front`; fidget_amd.merge_depth on the GPU).  Returns the full image on `dst` (in `out`), `out` elsewhere.
+    `root`: the root tile size of the RENDER (its tile_sizes after trimming, lib.rs:59-66) when it was given explicit
+    tile sizes - the blocks are runs of root-tile columns, so the rectangles gathered here must be cut with the same size;
+    default: the root tile of the default tile list, which is what render3d(block=...) without tile_sizes uses."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     H, W = out.shape[0], out.shape[1]
-    root = root_tile(max(W, H))
+    root = root_tile(max(W, H)) if root is None else int(root)
+    assert root > 0 and root % 8 == 0, "root tile size of the render (a multiple of the 8-voxel leaf)"
     rects = [block_rect(W, H, root, split, r) for r in range(world)]
     area = max(max((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in rects), 1)
     y0, y1, x0, x1 = rects[rank]
@@ -361,11 +365,18 @@ def mesh_sharded(make_part, merge, dst=0, transport=None, device=None):
         sizes = [None] * world
         dist.all_gather_object(sizes, int(mine.size))        # (also the barrier: every segment is written)
         result = None
+        err = None
         if rank == dst:
-            parts = [mine if r == rank else shm.attach(r, sizes[r]) for r in range(n_parts)]
-            result = merge(parts)
-            del parts
+            try:
+                # (a rank whose make_part never asked `alloc` for memory has no segment: its part is empty, nothing to attach)
+                parts = [mine if r == rank else (shm.attach(r, sizes[r]) if sizes[r] else np.zeros(0, np.uint8)) for r in range(n_parts)]
+                result = merge(parts)
+                del parts
+            except Exception as e:      # noqa: BLE001 - the other ranks wait at the barrier below: reach it, then raise
+                err = e
         dist.barrier()                                         # the segments stay until the merge has read them
+        if err is not None:
+            raise err
         return result
     finally:
         mine = None          # (the arrays over a segment must be gone before it can be closed)

@@ -12,6 +12,9 @@ extern "C" {
  * (100 MHz), waves that found work, work units; then per 3D tile level: [32+l] ticks in the
  * forward interval pass, [40+l] ticks in classify + prune, [48+l] tape ops evaluated, [56+l] ops of pruned tapes written. */
 fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
+/* Leaf-stage counters of the last profiled 3D frame, counted where the leaves are queued: [0] leaves, [1] their tape ops,
+ * [2] tape ops x passes of the leaf kernel over the tape (8-byte words it reads), [3] tape ops x voxels evaluated. */
+fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]);
 /* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);

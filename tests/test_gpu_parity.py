@@ -289,16 +289,13 @@ def test_render3d_column_invariant_parents(name, size, monkeypatch):
     under a rotated camera nothing is invariant and nothing changes either."""
     p, o = both(name)
     ref = O.render3d(o, size)[0]
-    for var in (None, "FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):       # everything on; the tile stage's short cut off; all of them off
-        for v in ("FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):
-            monkeypatch.delenv(v, raising=False)
-        if var:
-            monkeypatch.setenv(var, "1")
-        a = F.render3d(p, size)[0]
+    hip = p.hip
+    for var in (None, "no_zrep", "no_column_inv"):       # everything on; the tile stage's short cut off; all of them off
+        with hip.options(**({var: 1} if var else {})):   # (switches are the context's: fhip_ctx_set_option, not the environment)
+            a = F.render3d(p, size)[0]
         assert (a["depth"] == ref["depth"]).all(), f"{var}: {(a['depth'] != ref['depth']).sum()} depths differ"
         assert same_bits_f32(a["normal"], ref["normal"])
-    for v in ("FHIP_NO_ZREP", "FHIP_NO_COLUMN_INV"):
-        monkeypatch.delenv(v, raising=False)
+    assert hip.option("no_zrep") == 0 and hip.option("no_column_inv") == 0
     cam = bench_camera(0.0)
     a, b = F.render3d(p, size, world_to_model=cam)[0], O.render3d(o, size, world_to_model=cam)[0]
     assert (a["depth"] == b["depth"]).all()
@@ -328,12 +325,9 @@ def test_render3d_partly_column_invariant_shapes(kind, monkeypatch):
     for whd, cam in (((256, 256, 256), None), ((384, 256, 512), None), ((256, 256, 256), scaled)):
         ref = O.render3d(o, *whd, world_to_model=cam)[0]
         assert ref["depth"].max() > 0 and (ref["depth"] == 0).any()
-        for var in (None, "FHIP_NO_COLUMN_INV"):
-            monkeypatch.delenv("FHIP_NO_COLUMN_INV", raising=False)
-            if var:
-                monkeypatch.setenv(var, "1")
-            a = F.render3d(p, *whd, world_to_model=cam)[0]
+        for var in (None, "no_column_inv"):
+            with p.hip.options(**({var: 1} if var else {})):
+                a = F.render3d(p, *whd, world_to_model=cam)[0]
             assert (a["depth"] == ref["depth"]).all(), f"kind {kind} {whd} {var}: {(a['depth'] != ref['depth']).sum()} depths differ"
             same = (a["normal"] == ref["normal"]) | (np.isnan(a["normal"]) & np.isnan(ref["normal"]))
             assert same.all(), f"kind {kind} {whd} {var}: {(~same).any(axis=2).sum()} normals differ"
-    monkeypatch.delenv("FHIP_NO_COLUMN_INV", raising=False)
