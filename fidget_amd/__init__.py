@@ -55,7 +55,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_tape_links", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -156,7 +156,7 @@ def lib():
             "fhip_mesh_merge": (i32, [vp, vp, vp, u32, vp, C.POINTER(vp)]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
-            "fhip_debug_stats": (i32, [vp, vp]), "fhip_debug_leaf_stats": (i32, [vp, vp]),
+            "fhip_debug_stats": (i32, [vp, vp]), "fhip_debug_leaf_stats": (i32, [vp, vp]), "fhip_debug_tape_links": (u32, [vp, vp, u32]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
             "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]), "fhip_tape_term_group": (i32, [vp, vp, u32, vp]),
             "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
@@ -512,6 +512,24 @@ class Shape:
         return lib().fhip_tape_axis_slot(self._h, axis)
 
     def var_index(self, index): return lib().fhip_tape_var_slot(self._h, int(index))
+
+    def words(self):
+        """Device tape as raw 8-byte ops (tape_format.h), evaluation order."""
+        n = self.size()
+        w = np.zeros(max(n, 1), dtype=np.uint64)
+        lib().fhip_tape_ops(self._h, _p(w), n)
+        return w[:n]
+
+    def links(self):
+        """Per-op links for the linked prune (fhip_debug_tape_links; host_graph.hpp compute_links): [n, 5] = (opcode, class, choice ordinal,
+        producer of a, producer of b) - a producer is an op index, 0x8000 | ordinal for a choice op, 0xFFFF for none; None when the tape
+        does not qualify."""
+        n = self.size()
+        w = np.zeros(max(n, 1), dtype=np.uint64)
+        if lib().fhip_debug_tape_links(self._h, _p(w), n) != n:
+            return None
+        w = w[:n]
+        return np.stack([w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFFFF, (w >> 32) & 0xFFFF, (w >> 48) & 0xFFFF], axis=1).astype(np.int64)
 
     def ops(self):
         """Device tape as (name, out, a, b, imm_bits) tuples in evaluation order."""

@@ -20,6 +20,7 @@
 #include "kernels.hip"
 #include "effects.hip"
 #include "mesh.hip"
+#include "prune2.hip"
 #include "host_mesh.hpp"
 
 #define FH_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
@@ -54,6 +55,9 @@ struct fhip_tape {
     std::vector<fh::HostTape> tgroups;
     mutable FhTopOp* d_top = nullptr;
     mutable uint32_t* d_chsrc = nullptr;
+    mutable uint64_t* d_links = nullptr;   // links of the full tape (host_graph.hpp compute_links) for the linked prune, when it qualifies
+    mutable uint16_t* d_ctab = nullptr;    // ... and the op index of every choice
+    mutable bool links_tried = false;
     // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
     // reference's workers): its lazily created device copies are made under this lock, on the device of the first
     // context that needs them (HIP allocations are visible to every device of the process with peer access; a tape
@@ -85,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -271,6 +275,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
         (void)hipEventCreateWithFlags(&c->ev_leaves[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming);
     }
+    (void)hipFuncSetAttribute((const void*)k_prune2, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     {
         const void* fb[] = {(const void*)k_teval3d<false, true>, (const void*)k_teval3d<true, true>};
         for (const void* f : fb) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
@@ -487,6 +492,8 @@ void fhip_tape_free(fhip_tape* t) {
     if (t->d_ops) (void)hipFree(t->d_ops);
     if (t->d_top) (void)hipFree(t->d_top);
     if (t->d_chsrc) (void)hipFree(t->d_chsrc);
+    if (t->d_links) (void)hipFree(t->d_links);
+    if (t->d_ctab) (void)hipFree(t->d_ctab);
     delete t;
 }
 uint32_t fhip_tape_len(const fhip_tape* t) { return (uint32_t)t->t.ops.size(); }
@@ -729,6 +736,10 @@ struct RenderSetup {
     size_t lds_tiles_group = 0;
     bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
     bool prune1 = false;      // ... and, on the first exp_levels levels, the prune as one wave per child (fh_prune1)
+    bool prune2 = false;      // ... by the linked prune (prune2.hip k_prune2: visits only the ops a child keeps) where the tape qualifies
+    const uint64_t* d_links = nullptr;
+    const uint16_t* d_ctab = nullptr;
+    size_t lds_prune2 = 0;
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
@@ -971,6 +982,26 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 HIP_TRY(ctx, hipMemcpy(tape->d_chsrc, tape->plan.choice_src.data(), tape->plan.choice_src.size() * 4, hipMemcpyHostToDevice));
             }
             S.ttop = tape->d_top; S.chsrc = tape->d_chsrc;
+            // the linked prune of the root level (option prune2, off by default: measured 0.73 ms against fh_prune1's 0.34 ms per
+            // 1024^3 frame of prospero.vm - a child of that root tape keeps ~580 ops, up to 1011, not the handful the design
+            // assumed, and per kept op the compiled walk is no cheaper than the assembly sweep; profiles/r03c): links of the
+            // root tape, made once with it
+            if (ctx->opt.prune2 && !tape->links_tried) {
+                tape->links_tried = true;
+                std::vector<uint64_t> lk;
+                std::vector<uint16_t> cops;
+                if (fh::compute_links(t, lk, cops)) {
+                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_links, lk.size() * 8));
+                    HIP_TRY(ctx, hipMemcpy(tape->d_links, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
+                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_ctab, std::max<size_t>(cops.size(), 1) * 2));
+                    HIP_TRY(ctx, hipMemcpy(tape->d_ctab, cops.data(), cops.size() * 2, hipMemcpyHostToDevice));
+                }
+            }
+            R.lds_prune2 = (size_t)t.ops.size() * 16 + (size_t)FH_P2_WPB * fh_p2_wave_lds((uint32_t)t.ops.size(), t.n_choices);
+            R.prune2 = tape->d_links && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
+                       R.lds_prune2 <= FH_LDS_MAX;
+            R.d_ctab = tape->d_ctab;
+            R.d_links = tape->d_links;
             const size_t blocks = qcaps[0];
             HIP_TRY(ctx, ctx->tvals.ensure(blocks * S.n_terms * WAVE * 8));
             HIP_TRY(ctx, ctx->topch.ensure(blocks * S.n_top * WAVE));
@@ -1096,7 +1127,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] {
-        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+        // (pre-pass levels below the root: the children of a parent shared out over several slots - tsetup_body; option
+        // l1_split: 0 chosen on the device from the number of parents, 1 off, 2 / 4 / 8 fixed)
+        const uint32_t csplit = (level > 0 && (uint32_t)level < R.S.pre_levels && R.asm_tiles) ? (uint32_t)std::max(0, std::min(8, ctx->opt.l1_split)) : 1u;
+        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level, csplit);
         else hipLaunchKernelGGL(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
     });
     if (R.groups && level == 0) {
@@ -1114,8 +1148,16 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             if (root_words) hipLaunchKernelGGL(k_tscatter3d, dim3(root_words, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
-            struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
-            (void)launch_asm(ctx, FH_ASM_PRUNE1, blocks * 64, &kp, sizeof(kp));
+            if (R.prune2) {
+                hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
+                if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
+                hipLaunchKernelGGL(k_prune2, dim3(blocks * (64 / FH_P2_WPB)), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
+                                   (const uint2*)R.d_links, R.d_ctab, 0u);
+                if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({FH_ASM_PRUNE1, {ea, eb}}); }
+            } else {
+                struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
+                (void)launch_asm(ctx, FH_ASM_PRUNE1, blocks * 64, &kp, sizeof(kp));
+            }
         });
     } else if (R.asm_tiles) {
         launch(ctx, FHIP_K_TILES, [&] {
@@ -2294,6 +2336,14 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
     if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
     for (int i = 0; i < 64; i++) out[i] = ctx->last_state.stat[i];
     return FHIP_OK;
+}
+// Diagnostics: the links of a tape as the linked prune gets them (host_graph.hpp compute_links); 0: the tape does not qualify
+uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t cap) {
+    std::vector<uint64_t> lk;
+    std::vector<uint16_t> cops;
+    if (!fh::compute_links(tape->t, lk, cops)) return 0;
+    for (size_t i = 0; i < lk.size() && i < cap; i++) out[i] = lk[i];
+    return (uint32_t)lk.size();
 }
 // ... and the leaf stage's counters of the last (profiled) 3D frame: render_state.h leaf_stat
 fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]) {

@@ -364,6 +364,43 @@ struct HostTape {
     VarTable vars;
 };
 
+// Links of a register-allocated tape for the linked prune (prune2.hip): the tape's dependency graph with the register numbers
+// taken out.  Per op 8 bytes: word 0 = opcode | class << 8 | choice ordinal << 16 (choice ops before this one), word 1 = fa | fb << 16
+// - the op that produced operand a / b (the last writer of that register before this op, looking through register copies):
+// its index, or 0x8000 | its choice ordinal when it is a min / max / and / or, 0xFFFF when there is no such operand.  Per
+// choice 2 bytes: the index of the op.  Returns false when the tape is outside what the linked prune handles (more than
+// 16383 ops or 32767 choices - the field widths -, an OUTPUT that is not the one last op, an operand nobody wrote).
+static inline bool compute_links(const HostTape& t, std::vector<uint64_t>& out, std::vector<uint16_t>& choice_ops) {
+    const size_t n = t.ops.size();
+    out.clear();
+    choice_ops.clear();
+    if (n == 0 || n > 0x3FFFu || t.n_choices > 0x7FFFu || FH_W_OP((uint32_t)t.ops[n - 1]) != FH_OUTPUT) return false;
+    std::vector<int> last(FH_MAX_REGS, -1);
+    std::vector<uint32_t> field(n, 0xFFFFu);     // what a consumer's link says when op i produced its operand
+    out.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t w0 = (uint32_t)t.ops[i], w1 = (uint32_t)(t.ops[i] >> 32);
+        const int op = (int)FH_W_OP(w0);
+        const uint32_t ro = FH_W_OUT(w0), ra = FH_W_A(w0);
+        const bool rr = fh_is_rr(op), choice = fh_is_choice(op);
+        uint32_t kind = 2, fa = 0xFFFFu, fb = 0xFFFFu;     // (classes: prune2.hip FH_LK_*)
+        if (op == FH_OUTPUT) { if (i + 1 != n) return false; kind = 0; }
+        else if (op == FH_INPUT || op == FH_COPY_IMM) kind = 1;
+        else if (op == FH_COPY_REG) kind = 4;
+        else if (choice) kind = rr ? 5 : 6;
+        else if (rr) kind = 3;
+        if (kind != 1) { if (ra >= FH_MAX_REGS || last[ra] < 0) return false; fa = field[last[ra]]; }
+        if (rr) { if (w1 >= FH_MAX_REGS || last[w1] < 0) return false; fb = field[last[w1]]; }
+        const uint32_t ci = (uint32_t)choice_ops.size();
+        out.push_back((uint64_t)((uint32_t)op | (kind << 8) | (ci << 16)) | ((uint64_t)(fa | (fb << 16)) << 32));
+        if (op == FH_COPY_REG) field[i] = fa;                         // a copy is its source
+        else if (choice) { field[i] = 0x8000u | ci; choice_ops.push_back((uint16_t)i); }
+        else field[i] = (uint32_t)i;
+        if (op != FH_OUTPUT) last[ro] = (int)i;
+    }
+    return true;
+}
+
 struct RegPool {  // lowest-free-first over FH_MAX_REGS registers
     uint64_t free_[FH_MAX_REGS / 64];
     int high = 0;

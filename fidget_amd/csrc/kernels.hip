@@ -570,8 +570,14 @@ __global__ void __launch_bounds__(WAVE) k_tape_flags(FhRenderState* S, int level
 // assembly, or k_teval3d below for tapes outside its opcode set) -> k_tpush3d.  Same
 // algorithm as k_tiles; the parent travels between the kernels in an FhSlot.
 // ======================================================================================
+// `split`: the children of ONE parent spread over up to `split` slots (0: chosen from the number of parents; 1: off).  The
+// pre-pass levels below the root have a few hundred parents with tapes of hundreds of ops, one wave each, on a machine of 1024
+// SIMDs, and the level takes as long as its slowest parent: forward pass + a lockstep prune whose cost grows with the
+// number of children that keep different ops.  Several waves per parent, each evaluating the parent's tape for ALL lanes
+// but classifying and pruning only its share of the children, repeat the forward pass on SIMDs that would be idle and
+// shorten the prune.  Slots are independent for everything downstream (the push stage sees F small parents).
 template <bool IS3D>
-FH_DEV void tsetup_body(FhRenderState* S, int level) {
+FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
@@ -584,13 +590,21 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
     // serialise in L2 and cost more than this kernel's work)
     // Tape parallelism at level 0: every block of root tiles gets one slot per independent tape
     // group (slots g0 .. g0 + G - 1, same children, different tapes); k_ttop3d merges them.
-    const uint32_t G = (level == 0 && S->n_tgroups) ? S->n_tgroups : 1;
-    const uint32_t ns = min(S->count[level], S->slot_cap[0]), nb = min(S->count_big[level], S->slot_cap[1] / G);
-    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns; S->n_slots[1][level] = nb * G; }
+    const uint32_t TG = (level == 0 && S->n_tgroups) ? S->n_tgroups : 1;
+    uint32_t F = 1;
+    if (TG == 1 && level > 0 && split != 1) {
+        const uint32_t total = max(S->count[level] + S->count_big[level], 1u);
+        if (split) F = split;
+        else while (F < 8 && total * F * 2 <= 1536) F *= 2;       // (fh_tiles_v64: 2 waves per SIMD, 2048 at a time)
+        while (F > 1 && (S->count[level] * F > S->slot_cap[0] || S->count_big[level] * F > S->slot_cap[1])) F >>= 1;
+    }
+    const uint32_t G = TG * F;      // slots per parent (tape groups at level 0, shares of the children below it)
+    const uint32_t ns = min(S->count[level], S->slot_cap[0] / G), nb = min(S->count_big[level], S->slot_cap[1] / G);
+    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns * G; S->n_slots[1][level] = nb * G; }
     for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
         const bool big = gi >= ns;
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
-        FhSlot* const slg = &S->slots[big ? 1 : 0][big ? (gi - ns) * G : gi];
+        FhSlot* const slg = &S->slots[big ? 1 : 0][(big ? (gi - ns) : gi) * G];
         FhSlot& sl = *slg;
         // Column-invariant parents (k_tape_flags: the tape reads no input that changes along z, axis-aligned camera): the
         // children of a z-layer are those of every other layer, and the copies of the parent stacked along z (g.n tiles one
@@ -601,7 +615,7 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
         const bool inv = IS3D && level > 0 && ((g.stride >> 31) != 0 || zrep > 1);   // (a copy-carrying entry's tape is invariant: pruning only removes ops)
         if (IS3D && level > 0) {  // the whole parent may have been occluded since it was queued
             const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
-            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane == 0) sl.act = 0; continue; }
+            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane < (int)G) slg[lane].act = 0; continue; }
         }
         uint32_t nchild, cx, cy, cz;
         if (level == 0) {
@@ -626,15 +640,20 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
         IV X, Y, Z;
         xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
                     IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z), X, Y, Z);     // (2D: pixel.rs:325-333)
+        // a share of the children: the active lanes whose rank among them falls into the k-th of F equal parts (x-fastest
+        // lane order: neighbours stay together, and neighbours keep much the same ops)
+        const uint32_t na = (uint32_t)__popcll(actm), arank = (uint32_t)__popcll(actm & ((1ull << lane) - 1));
         for (uint32_t k = 0; k < G; k++) {
             FhSlot& so = slg[k];
+            const uint64_t share = F > 1 ? ballot(act && arank * F / na == k) : actm;
             if (lane == 0) {
-                const FhTapeRef tr = (G > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
+                const FhTapeRef tr = (TG > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
                 so.tape = tr;
-                so.level = (uint32_t)level; so.act = actm; so.base = 0; so.overflow = 0;
+                so.level = (uint32_t)level; so.act = share; so.base = 0; so.overflow = 0;
                 // (levels >= 1 have no term values: the field carries inv | zrep << 8 to the push stage)
-                so.tvals = (G > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : (float*)(uintptr_t)((inv ? 1u : 0u) | (zrep << 8));
+                so.tvals = (TG > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : (float*)(uintptr_t)((inv ? 1u : 0u) | (zrep << 8));
             }
+            if (share == 0) continue;
             so.xyz[0][lane] = X.lo; so.xyz[1][lane] = X.hi; so.xyz[2][lane] = Y.lo; so.xyz[3][lane] = Y.hi;
             so.xyz[4][lane] = Z.lo; so.xyz[5][lane] = Z.hi;
             so.corner[0][lane] = cx; so.corner[1][lane] = cy; so.corner[2][lane] = cz;
@@ -642,10 +661,10 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) { tsetup_body<true>(S, level); }
+__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level, uint32_t split) { tsetup_body<true>(S, level, split); }
 // ... and of the 2D renderer when its tile sizes give 64 children per parent (the 128 / 16 hint): same slots, same
 // evaluate + prune kernels; children are the n x n sub-tiles at the slice height z
-__global__ void __launch_bounds__(WAVE) k_tsetup2d(FhRenderState* S, int level) { tsetup_body<false>(S, level); }
+__global__ void __launch_bounds__(WAVE) k_tsetup2d(FhRenderState* S, int level) { tsetup_body<false>(S, level, 1u); }
 
 // Tape parallelism at level 0 (host_graph.hpp plan_terms), after the groups' forward passes left the
 // terms' intervals in S->tvals: the root min / max tree over those terms, with the Choice every op

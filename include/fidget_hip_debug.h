@@ -15,6 +15,9 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]);
 /* Leaf-stage counters of the last profiled 3D frame, counted where the leaves are queued: [0] leaves, [1] their tape ops,
  * [2] tape ops x passes of the leaf kernel over the tape (8-byte words it reads), [3] tape ops x voxels evaluated. */
 fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]);
+/* The per-op links of a tape for the linked prune (prune2.hip): word 0 = producer op of operand a | of operand b << 16 (0xFFFF none),
+ * word 1 = choice index | op class << 16; returns the number of ops, 0 when the tape does not qualify. */
+uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t cap);
 /* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
