@@ -89,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 2)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -722,7 +722,7 @@ static const uint32_t VM_TILES_3D[] = {128, 64, 32, 16, 8};  // fidget-core/src/
 struct RenderSetup {
     FhRenderState S;
     std::vector<FhGroup> roots;
-    uint32_t n_slabs = 1;
+    uint32_t n_slabs = 1, n_layers = 1;      // z-slabs (steps of the per-slab chains), root-tile layers
     uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
     size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
@@ -834,7 +834,16 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     P.max_choices = t.n_choices;
     P.roots_x = (P.width + ts[0] - 1) / ts[0];
     P.roots_y = (P.height + ts[0] - 1) / ts[0];
-    R.n_slabs = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
+    // z-slabs: the per-slab chains (tile stage, leaf kernel, tail) take `slab_layers` root-tile layers per step when the coarse
+    // levels are evaluated for the whole volume up front (the length of the tile chain is its number of steps: every step's
+    // launches leave most of the machine idle); one layer per step otherwise
+    const uint32_t n_layers = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
+    const bool prepass_ok = is3d && ts.size() >= 3 && n_layers <= FH_MAX_SLABS;
+    uint32_t SL = prepass_ok ? (uint32_t)std::max(1, std::min(8, ctx->opt.slab_layers)) : 1u;
+    while (SL > 1 && (ts[0] * SL / 8 > 32 || SL > n_layers)) SL >>= 1;     // (the leaf kernel's grid: <= 32 eight-voxel layers per slab)
+    P.slab = ts[0] * SL;
+    R.n_slabs = is3d ? (P.depth + P.slab - 1) / P.slab : 1;
+    R.n_layers = n_layers;
     R.full = tape_is_full(t);
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
     R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
@@ -851,17 +860,19 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
 
     // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
     S.n_slabs = R.n_slabs;
-    S.pre_levels = (is3d && ts.size() >= 3 && R.n_slabs <= FH_MAX_SLABS) ? 2 : 0;
-    const uint32_t slabs_in_q0 = S.pre_levels ? R.n_slabs : 1;   // (bound for the queue capacities; a z-split part uses fewer)
+    S.pre_levels = prepass_ok ? 2 : 0;
 
-    // z-slabs of this part: slab k of the block split belongs to iz = k * nz / n_slabs (iz = nz - 1: the front)
-    R.slab_lo = 0; R.slab_hi = R.n_slabs;
+    // root-tile layers of this part: layer k of the block split belongs to iz = k * nz / n_layers (iz = nz - 1: the front);
+    // its z-slabs are those that hold one of its layers (a slab shared with another part has work for this part's layers only)
+    uint32_t layer_lo = 0, layer_hi = n_layers;
     if (part.nz > 1) {
-        R.slab_lo = R.n_slabs; R.slab_hi = 0;
-        for (uint32_t k = 0; k < R.n_slabs; k++)
-            if ((uint64_t)k * part.nz / R.n_slabs == part.iz) { R.slab_lo = std::min(R.slab_lo, k); R.slab_hi = std::max(R.slab_hi, k + 1); }
-        if (R.slab_lo >= R.slab_hi) R.slab_lo = R.slab_hi = 0;   // more parts than slabs: nothing to do
+        layer_lo = n_layers; layer_hi = 0;
+        for (uint32_t k = 0; k < n_layers; k++)
+            if ((uint64_t)k * part.nz / n_layers == part.iz) { layer_lo = std::min(layer_lo, k); layer_hi = std::max(layer_hi, k + 1); }
+        if (layer_lo >= layer_hi) layer_lo = layer_hi = 0;   // more parts than layers: nothing to do
     }
+    R.slab_lo = layer_lo / SL; R.slab_hi = (layer_hi + SL - 1) / SL;
+    if (!S.pre_levels) { R.slab_lo = layer_lo; R.slab_hi = layer_hi; }
     // root groups: runs of <= TL root tiles of this part, index = first + lane * stride (one set per slab in pre-pass mode)
     struct Run { uint32_t first, n, stride; };
     std::vector<Run> runs;
@@ -879,17 +890,17 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         for (size_t i = 0; i < mine.size(); i += TL) runs.push_back(Run{mine[i], (uint32_t)std::min<size_t>(TL, mine.size() - i), n_shards});
     }
     FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
-    const uint32_t q0_slabs = S.pre_levels ? R.slab_hi - R.slab_lo : 1;
-    for (uint32_t k = 0; k < q0_slabs; k++)
+    const uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
+    for (uint32_t k = 0; k < q0_layers; k++)
         for (const Run& r : runs) {
             FhGroup g{};
             g.tape = root;
             g.first = r.first; g.n = r.n; g.stride = r.stride;
-            g.z = (R.slab_hi - 1 - k) * ts[0];  // front slabs first
+            g.z = (layer_hi - 1 - k) * ts[0];  // front layers first
             R.roots.push_back(g);
         }
-    R.groups_per_slab = (uint32_t)(R.roots.size() / std::max<uint32_t>(q0_slabs, 1));
-    if (R.slab_lo >= R.slab_hi) { R.roots.clear(); R.groups_per_slab = 0; }
+    R.groups_per_slab = (uint32_t)(R.roots.size() / std::max<uint32_t>(q0_layers, 1));
+    if (layer_lo >= layer_hi) { R.roots.clear(); R.groups_per_slab = 0; }
 
     // capacities (exact upper bounds): queue[l] holds the tiles of size ts[l-1] that can be
     // ambiguous, per slab for the per-slab levels and for the whole volume for pre-pass levels
@@ -897,13 +908,13 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     qcaps[0] = std::max<uint32_t>((uint32_t)R.roots.size(), 1);
     for (size_t l = 1; l < ts.size(); l++) {
         const uint64_t tp = ts[l - 1];
-        uint64_t c = (uint64_t)((P.width + tp - 1) / tp) * ((P.height + tp - 1) / tp) * (is3d ? ts[0] / tp : 1);
+        uint64_t c = (uint64_t)((P.width + tp - 1) / tp) * ((P.height + tp - 1) / tp) * (is3d ? P.slab / tp : 1);
         if (l < S.pre_levels) c *= R.n_slabs;
         qcaps[l] = (uint32_t)std::max<uint64_t>(c, 1);
     }
     const uint64_t tl = ts.back();
     const uint64_t fw = (P.width + tl - 1) / tl, fhh = (P.height + tl - 1) / tl;
-    const uint64_t leaf_cap = fw * fhh * (is3d ? ts[0] / tl : 1);
+    const uint64_t leaf_cap = fw * fhh * (is3d ? P.slab / tl : 1);
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
     R.n_footprints = (uint32_t)(fw * fhh);
 
@@ -1476,7 +1487,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
         const int tail_mode = ctx->opt.tail_stream;   // 0: off, 1: lists + normals, 2: normals only
         const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points;   // (the HIP leaf kernels walk the footprint lists)
-        const uint32_t z_lo = (uint32_t)k * P.tiles[0], z_hi = z_lo + P.tiles[0];
+        const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
             launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
             if (P.max_regs > 32)
@@ -1517,7 +1528,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
                 else {
                     const uint32_t blk = 1u << ctx->opt.col_blkl;   // footprints per workgroup: gen_interp.py BLKL
-                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, std::min<uint32_t>(P.tiles[0] / 8, 16), leaf_stream);
+                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
                 }
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);

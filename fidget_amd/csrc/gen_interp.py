@@ -848,7 +848,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_waitcnt lgkmcnt(0)
 	s_load_dwordx16 s[{m}:{m + 15}], {S_STATE}, {o['P.mat']}
 	s_load_dwordx2 s[24:25], {S_STATE}, {o['P.width']}
-	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.tiles']}
+	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.slab']}
 	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
 	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
             const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
             // the last pre-pass level parks its output in the queue of the children's z-slab
             const bool park = IS3D && S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
-            const uint32_t slab = park ? g.z / P.tiles[0] : 0;
+            const uint32_t slab = park ? g.z / P.slab : 0;
             FhGroup* const qdst = park ? S->squeue + (size_t)slab * S->squeue_cap : S->queue[level + 1];
             const uint32_t qcap = park ? S->squeue_cap : S->qcap[level + 1];
             uint32_t qs = 0, qb = 0;
@@ -530,8 +530,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 S->leaves[lb + slot] = lf;
                 if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
-                    const uint32_t layers = P.tiles[0] / T;
-                    S->leaf_table[(size_t)((cz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
+                    S->leaf_table[(size_t)((cz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                         FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
                 }
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
@@ -963,7 +962,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             const uint32_t slot_b = wave_excl_sum((amb && !small) ? 1u : 0u, nb);
             // the last pre-pass level parks its output in the queue of the children's z-slab
             const bool park = IS3D && S->pre_levels > 0 && (uint32_t)(level + 1) == S->pre_levels;
-            const uint32_t slab = park ? uni(__shfl(cz, __builtin_ctzll(am), WAVE)) / P.tiles[0] : 0;
+            const uint32_t slab = park ? uni(__shfl(cz, __builtin_ctzll(am), WAVE)) / P.slab : 0;
             FhGroup* const qdst = park ? S->squeue + (size_t)slab * S->squeue_cap : S->queue[level + 1];
             const uint32_t qcap = park ? S->squeue_cap : S->qcap[level + 1];
             uint32_t qs = 0, qb = 0;
@@ -1003,7 +1002,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                     S->leaves[lb + slot] = lf;
                     if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                     if (IS3D)
-                        S->leaf_table[(size_t)((iz % P.tiles[0]) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
+                        S->leaf_table[(size_t)((iz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                             FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
                 } else if (amb) atomicAdd(&S->queue_overflow, 1u);
             }
@@ -1174,7 +1173,7 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
-    const uint32_t layers = P.tiles[0] / T;
+    const uint32_t layers = P.slab / T;
     const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
     const FhLeafRef* col = S->leaf_table + fi;  // [layer][footprint]
     uint32_t mx = 0;
@@ -1313,7 +1312,7 @@ FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint3
     for (uint32_t k = i; k < table_words; k += stride) S->leaf_table[k] = FhLeafRef{0, 0, 0, 0};
     const uint32_t P0 = S->pre_levels;
     if (i == 0) {
-        S->slab_z = slab * S->P.tiles[0];
+        S->slab_z = slab * S->P.slab;
         for (uint32_t l = P0; l < FH_MAX_LEVELS; l++) {
             S->count[l] = 0; S->cursor[l] = 0; S->count_big[l] = 0; S->cursor_big[l] = 0;
             S->setup_cur[l] = 0; S->push_cur[l] = 0;
@@ -1331,7 +1330,7 @@ FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint3
         S->n_leaves = 0; S->n_leaves_lds = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
     }
-    if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.tiles[0];
+    if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.slab;      // (no pre-pass: slab = one root-tile layer)
     // the coarse levels of the min-depth pyramid are rebuilt by k_minpyramid (not for the first slab: empty image)
     if (reset_root_mind) {
         const uint32_t T = S->P.tiles[0], n = ((S->P.width + T - 1) / T) * ((S->P.height + T - 1) / T);

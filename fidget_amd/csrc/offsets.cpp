@@ -8,7 +8,7 @@
 int main() {
 #define O(name, expr) printf("%s\"%s\": %zu", first ? "{" : ", ", name, (size_t)offsetof(FhRenderState, expr)), first = false
     bool first = true;
-    O("P.mat", P.mat); O("P.width", P.width); O("P.height", P.height); O("P.tiles", P.tiles);
+    O("P.mat", P.mat); O("P.width", P.width); O("P.height", P.height); O("P.tiles", P.tiles); O("P.slab", P.slab);
     O("P.in_kind", P.in_kind); O("P.in_value", P.in_value);
     O("arena", arena); O("leaves", leaves); O("leaf_table", leaf_table); O("slab_z", slab_z); O("zbuf", zbuf);
     O("arena_cap", arena_cap); O("arena_head", arena_head); O("arena_overflow", arena_overflow);

@@ -71,6 +71,8 @@ struct FhRender {
     uint32_t pixel_perfect;
     uint32_t n_levels;
     uint32_t tiles[FH_MAX_LEVELS];   // tile sizes, largest first (after TileSizesRef trimming)
+    uint32_t slab;                   // 3D: voxels per z-slab = a multiple of tiles[0] (one root-tile layer, or several taken in ONE step of the
+                                     // per-slab chains: the tile chain's length is its number of steps, not the work per step)
     uint32_t roots_x, roots_y;       // root tile grid
     uint32_t max_regs, max_choices;  // of the root tape: bounds for every tape of the frame
     uint32_t in_kind[FH_MAX_INPUTS]; // per input slot: 0 x, 1 y, 2 z, 3 bound constant

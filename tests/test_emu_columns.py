@@ -51,7 +51,7 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     a_tab, a_leaves, a_z = mem.map(table), mem.map(leaves), mem.map(zbuf)
     st = U.Blob(off["sizeof_state"])
     st.arr(off["P.mat"], np.asarray(mat, F32))
-    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size)
+    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size); st.u32(off["P.slab"], size)
     for s in range(16):
         st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
@@ -215,7 +215,7 @@ def run_block(leaves_spec, in_kind, mat, size=16, zbuf_init=None, kernel="fh_col
     a_arena, a_tab, a_leaves, a_z = mem.map(arena), mem.map(table), mem.map(leaves), mem.map(zbuf)
     st = U.Blob(off["sizeof_state"])
     st.arr(off["P.mat"], np.asarray(mat, F32))
-    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size)
+    st.u32(off["P.width"], size); st.u32(off["P.height"], size); st.u32(off["P.tiles"], size); st.u32(off["P.slab"], size)
     for s in range(16):
         st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)

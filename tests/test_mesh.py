@@ -184,8 +184,8 @@ def test_qef_rank2_and_near_planar(oracle_mod):     # qef.rs:133-168
     assert np.linalg.norm(pos - np.array([-0.5, -0.25, 0.5])) < 1e-3
 
 
-@pytest.mark.parametrize("mask", list(range(0, 256, 5)) + [255])
-def test_mesh_manifold(mask, oracle_mod):     # octree.rs:1345-1391 (a fifth of the 256 masks: the CPU suite has a time budget)
+@pytest.mark.parametrize("mask", list(range(256)))
+def test_mesh_manifold(mask, oracle_mod):     # octree.rs:1345-1391: every one of the 256 corner masks
     O = oracle_mod
     c = O.Context()
     parts = [sphere(c, (0.5 if j & 1 else 0.0, 0.5 if j & 2 else 0.0, 0.5 if j & 4 else 0.0), 0.1) for j in range(8) if mask & (1 << j)]
@@ -202,12 +202,12 @@ def test_mesh_manifold(mask, oracle_mod):     # octree.rs:1345-1391 (a fifth of 
     check_for_edge_matching(t)
 
 
-def test_colonnade_manifold_and_bounds(oracle_mod):   # octree.rs:1476-1500 (depth 5), 1502-1530 (bounds; depth 6 here, 8 there)
+def test_colonnade_manifold_and_bounds(oracle_mod):   # octree.rs:1476-1500 (manifold, depth 5), 1502-1530 (bounds, depth 8)
     O = oracle_mod
     s = O.Shape.from_vm(model_path("colonnade.vm"))
     t, v = O.Octree(s, 5).walk_dual()
     check_for_edge_matching(t)
-    _, v = O.Octree(s, 6).walk_dual()
+    _, v = O.Octree(s, 8).walk_dual()
     assert (v[:, 0] < 1).all() and (v[:, 0] > -1).all() and (v[:, 1] < 1).all() and (v[:, 1] > -1).all() and (v[:, 2] < 1).all() and (v[:, 2] > -0.5).all()
 
 
@@ -257,6 +257,10 @@ def _key(bounds):
     return tuple(np.asarray(bounds, np.float32).view(np.uint32).tolist())
 
 
+MESH_GRAD_ULP = 64                  # gradients of transcendental tapes at edge intersections, ulp of the gradient's largest component
+MESH_GRAD_ULP_SEEN = [0.0]          # ... and the worst one a run has seen (printed by the tests that use the bound)
+
+
 def _compare(F, O, fshape, oshape, depth, w2m=None, transcendental=False):
     leaves, counts = F.mesh_sample(fshape, depth, world_to_model=w2m)
     o = O.Octree(oshape, depth, world_to_model=w2m)
@@ -279,7 +283,9 @@ def _compare(F, O, fshape, oshape, depth, w2m=None, transcendental=False):
             if same:
                 g, w = lf["grad"][:ne], sm["grad"][i, :ne]
                 scale = np.abs(w[:, :3]).max(axis=1, keepdims=True)
-                assert (np.abs(g[:, :3] - w[:, :3]) <= 64 * 2.0 ** -23 * np.maximum(scale, 1e-30)).all()
+                ulp = np.abs(g[:, :3] - w[:, :3]) / (2.0 ** -23 * np.maximum(scale, 1e-30))
+                MESH_GRAD_ULP_SEEN[0] = max(MESH_GRAD_ULP_SEEN[0], float(ulp.max()) if ulp.size else 0.0)
+                assert (ulp <= MESH_GRAD_ULP).all(), f"gradient {float(ulp.max()):.1f} ulp of its scale from the oracle's"
             continue
         assert (lf["inter"][:ne] == sm["inter"][i, :ne]).all(), "edge-search intersections differ"
         assert (lf["pos"][:ne].view(np.uint32) == sm["pos"][i, :ne].view(np.uint32)).all()
@@ -329,6 +335,7 @@ def test_device_leaf_samples_transcendental(model, depth, oracle_mod):
     import fidget_amd as F
     O = oracle_mod
     counts, n = _compare(F, O, F.Shape.from_vm(model_path(model)), O.Shape.from_vm(model_path(model)), depth, transcendental=True)
+    print(f"{model} depth {depth}: worst gradient {MESH_GRAD_ULP_SEEN[0]:.2f} ulp of its scale (bound {MESH_GRAD_ULP})")
     assert n > 100
 
 
@@ -368,6 +375,82 @@ def test_device_mesh_models(model, depth, oracle_mod):
     assert len(tris) > 100
     if model == "colonnade.vm":
         check_for_edge_matching(tris)
+
+
+@pytest.mark.gpu
+def test_device_mesh_colonnade_at_the_reference_s_depth(oracle_mod):     # octree.rs:1502-1530 builds colonnade at depth 8
+    """the device mesh at the depth the reference's own bound test uses: triangles and vertices identical to the oracle's, and the
+    reference's bounds hold for it"""
+    import fidget_amd as F
+    O = oracle_mod
+    tris, verts = _same_mesh(F, O, F.Shape.from_vm(model_path("colonnade.vm")), O.Shape.from_vm(model_path("colonnade.vm")), 8)
+    assert len(tris) > 50000
+    v = verts
+    assert (v[:, 0] < 1).all() and (v[:, 0] > -1).all() and (v[:, 1] < 1).all() and (v[:, 1] > -1).all() and (v[:, 2] < 1).all() and (v[:, 2] > -0.5).all()
+    check_for_edge_matching(tris)
+
+
+def match_meshes(ta, va, tb, vb, tol):
+    """Tolerance-aware comparison of two meshes whose vertices may differ in the last bits (transcendental opcodes: 1 ulp per
+    value is granted) and, where such a difference flips a decision, in a handful of cells: vertices of `a` are paired with the
+    nearest vertex of `b` within `tol`; triangles of `a` are carried over to `b`'s numbering (rotated to start at their
+    smallest index, orientation kept) and compared as sets.  Returns the counts a test bounds."""
+    from scipy.spatial import cKDTree
+    va, vb = np.asarray(va, np.float64).reshape(-1, 3), np.asarray(vb, np.float64).reshape(-1, 3)
+    ta, tb = np.asarray(ta, np.int64).reshape(-1, 3), np.asarray(tb, np.int64).reshape(-1, 3)
+    d, idx = cKDTree(vb).query(va, distance_upper_bound=tol)
+    ok = np.isfinite(d)
+    back = cKDTree(va).query(vb, distance_upper_bound=tol)[0]
+    to_b = np.where(ok, idx, -1)
+
+    def canon(t):
+        k = np.argmin(t, axis=1)
+        r = np.stack([np.take_along_axis(t, ((k + j) % 3)[:, None], axis=1)[:, 0] for j in range(3)], axis=1)
+        return {tuple(x) for x in r.tolist()}
+    mapped = to_b[ta]
+    whole = (mapped >= 0).all(axis=1)
+    sa, sb = canon(mapped[whole]), canon(tb)
+    return {"verts_a": len(va), "verts_b": len(vb), "unmatched_a": int((~ok).sum()), "unmatched_b": int((~np.isfinite(back)).sum()),
+            "max_dist": float(d[ok].max()) if ok.any() else 0.0, "tris_a": len(ta), "tris_b": len(tb),
+            "tris_only_a": int((~whole).sum()) + len(sa - sb), "tris_only_b": len(sb - sa)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 7), ("bear.vm", 6)])
+def test_device_mesh_transcendental_models_match_within_tolerance(model, depth, oracle_mod):
+    """BASELINE configuration 5's model two levels above the old comparison (and bear.vm): the device mesh against the oracle's
+    through a matcher that knows what may differ - sin / cos / exp are within 1 ulp of libm on the device, so positions agree to
+    a few ulp of the cell size and a decision on a knife's edge may fall the other way in a few cells out of a million.
+    Bounds: measured on an MI355X (profiles/r03e/mesh_match.json) with a margin."""
+    import fidget_amd as F
+    O = oracle_mod
+    tris, verts, counts = F.mesh(F.Shape.from_vm(model_path(model)), depth)
+    t, v = O.Octree(O.Shape.from_vm(model_path(model)), depth).walk_dual()
+    m = match_meshes(tris, verts, t, v, tol=2.0 ** -(depth + 6))          # 1 / 64 of a leaf cell's edge
+    print(model, depth, m)
+    n_v, n_t = max(m["verts_a"], m["verts_b"]), max(m["tris_a"], m["tris_b"])
+    assert m["unmatched_a"] <= max(8, n_v // 1000) and m["unmatched_b"] <= max(8, n_v // 1000), m
+    assert m["tris_only_a"] <= max(16, n_t // 500) and m["tris_only_b"] <= max(16, n_t // 500), m
+    check_for_edge_matching(tris)
+
+
+def test_mesh_matcher_on_known_differences():
+    """the matcher itself: identical meshes match fully; a moved vertex, a dropped triangle and a renumbering are counted"""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3], [1, 2, 4]])
+    m = match_meshes(t, v, t, v, 1e-3)
+    assert m["unmatched_a"] == m["unmatched_b"] == m["tris_only_a"] == m["tris_only_b"] == 0 and m["max_dist"] == 0
+    perm = np.array([4, 3, 2, 1, 0])
+    v2 = v[perm] + np.float32(1e-5)
+    inv = np.argsort(perm)
+    t2 = inv[t][:, [1, 2, 0]]                      # renumbered, rotated: the same triangles
+    m = match_meshes(t, v, t2, v2, 1e-3)
+    assert m["unmatched_a"] == m["unmatched_b"] == m["tris_only_a"] == m["tris_only_b"] == 0 and 0 < m["max_dist"] < 1e-4
+    v3 = v.copy(); v3[4] += 0.5
+    m = match_meshes(t, v3, t[:2], v, 1e-3)
+    assert m["unmatched_a"] == 1 and m["unmatched_b"] == 1 and m["tris_only_a"] == 1 and m["tris_only_b"] == 0
+    m = match_meshes(t[:, [0, 2, 1]], v, t, v, 1e-3)      # flipped orientation is a different triangle
+    assert m["tris_only_a"] == 3 and m["tris_only_b"] == 3
 
 
 @pytest.mark.gpu

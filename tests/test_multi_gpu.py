@@ -224,6 +224,46 @@ def test_device_blocks_merge_to_the_frame(split, model):
     assert torch.equal(out, full), f"{int((out != full).any(dim=2).sum())} pixels differ"
 
 
+@pytest.mark.gpu
+def test_octant_split_of_the_headline_frame(oracle_mod):
+    """The north star's sharding at its own size, with the eight ranks played by this GPU one after the other: prospero.vm at
+    1024^3 split 2 x 2 x 2 (fhip_render3d_block), each rank's rectangle cut out as gather_blocks sends it, the z ranges merged
+    front to back on the device (fhip_merge_depth) - the single-GPU frame, which is the oracle's frame, bit for bit."""
+    import torch
+    import fidget_amd as F
+    n, split = 1024, (2, 2, 2)
+    path = os.path.join(ROOT, "models", "prospero.vm")
+    shape = F.Shape.from_vm(path)
+    full = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+    F.render3d(shape, n, out=full)
+    rects = [D.block_rect(n, n, D.root_tile(n), split, r) for r in range(8)]
+    area = max((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in rects)
+    parts = []
+    for r in range(8):
+        part = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+        F.render3d(shape, n, out=part, block=(r, split))
+        y0, y1, x0, x1 = rects[r]
+        send = torch.zeros((area, 4), dtype=torch.int32, device="cuda")
+        send[:(y1 - y0) * (x1 - x0)] = part[y0:y1, x0:x1].reshape(-1, 4)
+        parts.append(send)
+    out = torch.zeros_like(full)
+    D.assemble_blocks(parts, out, rects, split, n, lambda a, b, d: F.merge_depth(a, b, d, hip=shape.hip))
+    shape.hip.sync()
+    assert torch.equal(out, full), f"{int((out != full).any(dim=2).sum())} pixels differ from the single-GPU frame"
+    ref = oracle_mod.render3d(oracle_mod.Shape.from_vm(path), n)[0]
+    got = out.cpu().numpy().view(np.uint32).reshape(n, n, 4)
+    assert (got[..., 3] == ref["depth"]).all() and (got[..., :3] == ref["normal"].view(np.uint32)).all()
+
+
+def test_block_rects_follow_the_render_s_root_tile():
+    """gather_blocks cuts the ranks' rectangles with the root tile of the RENDER: a render given explicit tile sizes (root 64 at
+    256^2, where the default list gives 128) covers other columns per block than the default"""
+    split = (2, 1, 1)
+    assert D.root_tile(256) == 128
+    assert D.block_rect(320, 256, 128, split, 0) == (0, 256, 0, 256) and D.block_rect(320, 256, 128, split, 1) == (0, 256, 256, 320)
+    assert D.block_rect(320, 256, 64, split, 0) == (0, 256, 0, 192) and D.block_rect(320, 256, 64, split, 1) == (0, 256, 192, 320)
+
+
 def test_direct_rccl_library_loads():
     """bench.py's ranks agree on this before any of them enters ncclCommInitRank (a collective): the library loads through
     ctypes and exports the six entry points DirectRccl binds"""
