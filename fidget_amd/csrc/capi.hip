@@ -89,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 2)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 4) X(l1_on_side, 1)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -139,7 +139,7 @@ struct fhip_ctx : FrameBufs {
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
     hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
     hipEvent_t ev_rest_fork = nullptr, ev_rest_join = nullptr;
-    hipEvent_t ev_pre = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_l0 = nullptr;
     hipModule_t asm_mod = nullptr;
     hipFunction_t asm_fn[FH_ASM_COUNT] = {};
     bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
@@ -254,6 +254,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_l0, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
     if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
@@ -299,6 +300,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->ev_rest_fork) (void)hipEventDestroy(c->ev_rest_fork);
     if (c->ev_rest_join) (void)hipEventDestroy(c->ev_rest_join);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_l0) (void)hipEventDestroy(c->ev_l0);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
     mesh_cache_release(c->mesh_octree_cache);
@@ -840,7 +842,9 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     const uint32_t n_layers = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
     const bool prepass_ok = is3d && ts.size() >= 3 && n_layers <= FH_MAX_SLABS;
     uint32_t SL = prepass_ok ? (uint32_t)std::max(1, std::min(8, ctx->opt.slab_layers)) : 1u;
-    while (SL > 1 && (ts[0] * SL / 8 > 32 || SL > n_layers)) SL >>= 1;     // (the leaf kernel's grid: <= 32 eight-voxel layers per slab)
+    // (the leaf table: <= 64 eight-voxel layers per slab; at least two slabs, so that the tile stage of one still runs beside the
+    // leaf kernel of the other - bear.vm at 512^3, four layers: 3.68 ms per frame as two slabs, 3.77 as one)
+    while (SL > 1 && (ts[0] * SL / 8 > 64 || SL * 2 > n_layers)) SL >>= 1;
     P.slab = ts[0] * SL;
     R.n_slabs = is3d ? (P.depth + P.slab - 1) / P.slab : 1;
     R.n_layers = n_layers;
@@ -1414,8 +1418,19 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     const uint32_t pre = R.S.pre_levels;
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
     const int class_blocks = (int)((R.n_footprints + 255) / 256);
+    // Pipelined frames: the root level stays on the pre-pass stream, the level below it moves to the head of this frame's tile
+    // chains on the side stream.  The two coarse levels of a frame are one dependent chain of ~0.9 ms that, on one stream, set
+    // the frame rate; split, the root level of frame n + 1 runs beside level 1 and the slabs of frame n, and the side stream
+    // carries level 1 + the (now few) slab steps of its own frame.  (A frame alone sees no difference: the same chain.)
+    const bool l1_side = fpipe && ctx->opt.l1_on_side && pre > 1 && ctx->stream2 && !ctx->opt.pipe_serial &&
+                         ctx->use_pipeline && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
     if (pre && n_groups) {  // coarse levels of every slab in one go
         for (uint32_t l = 0; l < pre; l++) {
+            if (l == 1 && l1_side) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream_pre));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_l0, 0));
+                ctx->stream = ctx->stream2;
+            }
             if (R.zrep && l > 0) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
             launch_tiles(ctx, R, dS, (int)l, true);
         }
@@ -1438,7 +1453,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
     if (fpipe) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream_pre));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));     // (the stream the last coarse-level kernel went to)
         HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
         ctx->stream = main_stream;
     }
