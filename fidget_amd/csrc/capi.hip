@@ -89,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 4) X(l1_on_side, 1)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -134,7 +134,12 @@ struct FrameBufs {
 };
 struct fhip_ctx : FrameBufs {
     FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
-    FrameBufs other;                // the set of the frame before (or after) the current one
+    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of 1 + FH_EXTRA_SETS).  Three
+    // sets: one frame alone takes ~1.5 ms from its first coarse-level kernel to its image, so with two sets - a set is free
+    // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way
+#define FH_EXTRA_SETS 2
+    FrameBufs others[FH_EXTRA_SETS];
+    uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
     hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
@@ -186,6 +191,7 @@ static void apply_options(fhip_ctx* c) {
     c->frame_pipeline = c->opt.no_frame_pipeline == 0;
     c->slab_contexts = (uint32_t)std::min(4, std::max(2, c->opt.slab_contexts));
     c->arena_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
+    c->extra_sets = (uint32_t)std::min(FH_EXTRA_SETS, std::max(1, c->opt.frame_sets - 1));
 }
 
 static fhip_status finish_render(fhip_ctx* ctx);
@@ -259,7 +265,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
     if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->other.ev_done, hipEventDisableTiming);
+    for (auto& o : c->others) (void)hipEventCreateWithFlags(&o.ev_done, hipEventDisableTiming);
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
         int lo = 0, hi = 0;
@@ -294,7 +300,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     DevBuf* bufs[] = {&c->tmp_out, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->sticky};
     for (DevBuf* b : bufs) b->release();
     c->release_all();
-    c->other.release_all();
+    for (auto& o : c->others) o.release_all();
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream_leaf2) { (void)hipStreamSynchronize(c->stream_leaf2); (void)hipStreamDestroy(c->stream_leaf2); }
     if (c->ev_rest_fork) (void)hipEventDestroy(c->ev_rest_fork);
@@ -324,12 +330,14 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
     (void)hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     fhip_status st = FHIP_OK;
-    if (c->other.async_pending) {      // the frame before the last one (frame pipelining): same check, then back to the last frame's set
-        std::swap(static_cast<FrameBufs&>(*c), c->other);
-        c->async_pending = false;
-        st = finish_render(c);
-        std::swap(static_cast<FrameBufs&>(*c), c->other);
-    }
+    for (auto& o : c->others)
+        if (o.async_pending) {      // the frames before the last one (frame pipelining): same check, then back to the last frame's set
+            std::swap(static_cast<FrameBufs&>(*c), o);
+            c->async_pending = false;
+            const fhip_status s1 = finish_render(c);
+            if (st == FHIP_OK) st = s1;
+            std::swap(static_cast<FrameBufs&>(*c), o);
+        }
     if (c->async_pending) {
         c->async_pending = false;
         const fhip_status s2 = finish_render(c);
@@ -1378,7 +1386,8 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (fpipe) {
-        std::swap(static_cast<FrameBufs&>(*ctx), ctx->other);
+        // (rotate: the current set goes to the back of the ring, the set used longest ago comes forward)
+        for (uint32_t i = 0; i < ctx->extra_sets; i++) std::swap(static_cast<FrameBufs&>(*ctx), ctx->others[i]);
         ctx->stream = ctx->stream_pre;
         if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
     }
@@ -1458,13 +1467,26 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         ctx->stream = main_stream;
     }
     int last_tail_idx = -1;
-    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
-        if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
-        const int idx = (int)R.slab_hi - 1 - k;
+    // Where a slab's tile chain goes: the side stream, or (option tiles_stream = 1, pipelined frames of at most as many slabs
+    // as there are slab contexts) the tail stream, every slab's chain queued there BEFORE the tail work of the first slab - the
+    // side stream then carries level 1 of the coarse levels alone, the pre-pass stream the root level, and the three chains
+    // of consecutive frames run beside each other.
+    // (2, the default: there when the ROOT tape reads no input that changes along a pixel column - then no tape of the frame does,
+    // the leaf stage is light and the tail stream has room; a frame whose leaf kernels fill the machine wants its tile chains on
+    // the high-priority side stream: prospero.vm 1024^3 0.77 -> 0.64 ms per frame there, the same frames with the column-invariance
+    // short cuts off 1.86 -> 2.01)
+    bool root_invariant = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
+    for (uint64_t w : tape->t.ops)
+        if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { root_invariant = false; break; }
+    const bool tiles_first = pipe && l1_side && (ctx->opt.tiles_stream == 1 || (ctx->opt.tiles_stream == 2 && root_invariant)) && ctx->stream3 &&
+                             ctx->opt.tail_stream == 1 && R.asm_points && R.slab_hi - R.slab_lo <= NC;
+    hipStream_t const tile_stream = tiles_first ? ctx->stream3 : side_stream;
+    if (tiles_first) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_fork, 0));
+    auto tile_step = [&](int k, int idx) -> fhip_status {
         dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
         if (pipe) {
-            ctx->stream = side_stream;
-            if (idx >= (int)NC) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_leaves[idx - (int)NC], 0));  // context free again
+            ctx->stream = tile_stream;
+            if (idx >= (int)NC) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_leaves[idx - (int)NC], 0));  // context free again
         }
         launch(ctx, FHIP_K_OTHER, [&] {
             // the usual pyramid (three levels, 4 x 4 each, 8 x 8 leaf tiles) has a kernel of its own
@@ -1487,9 +1509,24 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         });
         for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
         if (pipe) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], side_stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], tile_stream));
             ctx->stream = main_stream;
         }
+        return FHIP_OK;
+    };
+    if (tiles_first)
+        for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {
+            const fhip_status ts_ = tile_step(k, (int)R.slab_hi - 1 - k);
+            if (ts_) { ctx->stream = main_stream; return ts_; }
+        }
+    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
+        if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
+        const int idx = (int)R.slab_hi - 1 - k;
+        if (!tiles_first) {
+            const fhip_status ts_ = tile_step(k, idx);
+            if (ts_) { ctx->stream = main_stream; return ts_; }
+        }
+        dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
         // (diagnostics, FHIP_LEAF_STREAMS=2: leaf kernels of consecutive slabs on two streams, so that the tail of one overlaps
         // the head of the next - any interleaving gives the same image - at the price of lanes that no longer see the hits in front)
         const bool tail1 = ctx->opt.tail_stream == 1;

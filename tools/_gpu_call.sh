@@ -1,6 +1,14 @@
-mkdir -p gpurun_out/r03g
-bash tools/sweep_env.sh "FHIP_SLAB_LAYERS=2" "FHIP_SLAB_LAYERS=4" "FHIP_SLAB_LAYERS=8" "FHIP_SLAB_LAYERS=4 FHIP_SLAB_CONTEXTS=2" > gpurun_out/r03g/slab4.txt 2>&1
-cat gpurun_out/r03g/slab4.txt
-FHIP_SLAB_LAYERS=4 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_render_random.py -m gpu -x -q > gpurun_out/r03g/tests4.log 2>&1; tail -3 gpurun_out/r03g/tests4.log
-sed -i 's/for sl in (1, 2, 4)/for sl in (2, 4)/' tools/slab_probe.py; sed -i 's/"r03f"/"r03g"/g' tools/slab_probe.py
-python tools/slab_probe.py 2>&1 | tail -9
+mkdir -p gpurun_out/r03i
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03i/tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03i/tests.log
+grep -n "passed\|failed\|rc=" gpurun_out/r03i/tests.log | tail -3
+timeout 600 python bench.py > gpurun_out/r03i/bench.json 2> gpurun_out/r03i/bench.err
+python - <<'P'
+import json
+d=json.load(open("gpurun_out/r03i/bench.json"))
+g=d["general"]
+print("value", round(d["value"]), "ms", round(d["ms_per_step"],4), "median", round(d["ms_per_step_median"],4), "lat", round(d["frame_latency_ms"],3), "host", round(d["host_output_frame_ms"],3))
+print("general ms", round(g["ms_per_step"],4), "lat", round(g["frame_latency_ms"],3), "img eq", g["image_equals_default_path"])
+r=d["roofline"]; print("roofline", r["kernel"], r["path"], "frac", round(r["frac"],4), "alu", round(r["alu"]["frac"],4), "avg_launch_ms", round(r["avg_launch_ms"],4), r["launches_per_frame"])
+r=d["roofline_tiles"]; print("tiles", r["kernel"], "frac", round(r["frac"],4), "avg_launch_ms", round(r["avg_launch_ms"],4), r["launches_per_frame"])
+print("parity", d["parity"], "cpu", round(d["cpu_baseline"]["value"]), "c3", d["c3_bear"]["ms_per_frame"], d["c3_bear"]["normal_max_ulp_of_gradient_scale"])
+P
