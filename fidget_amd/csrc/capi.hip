@@ -136,7 +136,7 @@ struct fhip_ctx : FrameBufs {
     FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
     // the sets of the frames before the current one: a frame takes the set used longest ago (ring of 1 + FH_EXTRA_SETS).  Three
     // sets: one frame alone takes ~1.5 ms from its first coarse-level kernel to its image, so with two sets - a set is free
-    // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way
+    // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way (a fourth set: measured, no gain)
 #define FH_EXTRA_SETS 2
     FrameBufs others[FH_EXTRA_SETS];
     uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
@@ -165,7 +165,7 @@ struct fhip_ctx : FrameBufs {
     std::atomic<int> cancelled{0};
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
     DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
-    struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[4];   // pinned (upload_frame)
+    struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[8];   // pinned (upload_frame)
     void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
     size_t mesh_pinned_cap = 0;
     // ... and the two largest host-side temporaries of the assembly, kept for the same reason (fresh memory of that size is
@@ -1094,10 +1094,10 @@ static fhip_status finish_render(fhip_ctx* ctx) {
 }
 
 static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R) {
-    // The frame's state and root groups go through pinned staging slots (a ring of four, each guarded by an event): a copy from
+    // The frame's state and root groups go through pinned staging slots (a ring of eight, each guarded by an event): a copy from
     // pageable memory would make the host wait for everything queued on the stream before it, i.e. for the previous frame.
     const size_t roots_bytes = R.roots.size() * sizeof(FhGroup);
-    fhip_ctx::Staging& sg = ctx->staging[ctx->staging_next++ % 4];
+    fhip_ctx::Staging& sg = ctx->staging[ctx->staging_next++ % 8];
     if (sg.ev && sg.used) HIP_TRY(ctx, hipEventSynchronize(sg.ev));
     if (!sg.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
     if (sg.cap < sizeof(FhRenderState) + roots_bytes) {
