@@ -115,7 +115,7 @@ static void options_from_env(FhOptions& o) {
 // the previous frame did not use, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
 // run on a stream of their own beside the previous frame's slabs (frame pipelining, FHIP_NO_FRAME_PIPELINE=1 turns it off).
 struct FrameBufs {
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch;
     DevBuf queue[FH_MAX_LEVELS];
     uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
     uint32_t resident_groups = 0;
@@ -125,7 +125,7 @@ struct FrameBufs {
     bool ev_done_valid = false;
     void release_all() {
         DevBuf* bufs[] = {&state, &arena, &leaves, &leaf_table, &zbuf, &normals, &fp_lists, &mind, &squeue, &slots[0], &slots[1],
-                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr};
+                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr, &gscratch};
         for (DevBuf* b : bufs) b->release();
         for (auto& q : queue) q.release();
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -753,6 +753,8 @@ struct RenderSetup {
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
+    bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
+    uint32_t hbm_waves = 0;
 };
 
 static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
@@ -837,8 +839,10 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     if (fanout > 64) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 64 children");
     const uint32_t TL = R.tl = fanout > 16 ? 64 : 16;
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
-    // (the device prunes keep old -> new register maps in bytes with 0xFF = dead: 255 registers at most)
-    if (t.n_regs > 255) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 255 registers");
+    // (register numbers are 12-bit fields of a tape word.  The device prunes keep old -> new register maps in bytes with 0xFF =
+    // dead: a CHILD tape has 255 registers at most - one that would need more keeps its parent's tape; the root tape may have
+    // more, its register file then lives in HBM: gscratch below)
+    if (t.n_regs >= FH_MAX_REGS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 4095 registers");
     if (t.ops.size() >= (1u << 24)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support tapes of up to 2^24 ops");   // (FhLeafRef packs length | registers << 24)
     P.max_regs = std::max<uint32_t>(t.n_regs, 1);
     P.max_choices = t.n_choices;
@@ -868,7 +872,20 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
     R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
     R.lds_normals_small = (size_t)32 * WAVE * 16;
-    if (R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file exceeds LDS");
+    // A register file that does not fit LDS (more than ~160 registers for the gradients, ~280 for the intervals) lives in HBM:
+    // the reference spills registers beyond its file to memory slots (compiler/alloc.rs:116-125), this is the device's form of
+    // it - the root-sized kernel variants take a region of `gscratch` per workgroup instead of LDS.  A slow path by design
+    // (a few hundred workgroups, no pipelining: render3d_part), for tapes the fast paths cannot take anyway.
+    S.gscratch = nullptr; S.gscratch_stride = 0;
+    R.big_hbm = R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX || R.lds_points_big > FH_LDS_MAX;
+    if (R.big_hbm) {
+        const size_t stride = (std::max(std::max(R.lds_tiles_big, R.lds_normals_big), R.lds_points_big) + 255) & ~(size_t)255;
+        if (stride >= ((size_t)1 << 31)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file too large");
+        R.hbm_waves = (uint32_t)std::max<size_t>(64, std::min<size_t>((size_t)ctx->n_cu * 4, ((size_t)1 << 30) / stride));
+        HIP_TRY(ctx, ctx->gscratch.ensure((size_t)R.hbm_waves * stride));
+        S.gscratch = (char*)ctx->gscratch.p; S.gscratch_stride = (uint32_t)stride;
+        R.lds_tiles_big = R.lds_normals_big = R.lds_points_big = 0;      // (no dynamic LDS for those launches; grids: blocks_big)
+    }
 
     // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
     S.n_slabs = R.n_slabs;
@@ -1072,6 +1089,11 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     return FHIP_OK;
 }
 
+static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu);
+// ... of a root-sized launch: as many workgroups as LDS lets run, or the number of HBM register-file regions
+static int blocks_big(const fhip_ctx* ctx, const RenderSetup& R, size_t lds, int max_per_cu) {
+    return R.big_hbm ? (int)R.hbm_waves : blocks_for(ctx, lds, max_per_cu);
+}
 static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu) {
     int per_cu = lds ? (int)std::min<size_t>((size_t)max_per_cu, FH_LDS_MAX / std::max<size_t>(lds, 1)) : max_per_cu;
     per_cu = std::max(per_cu, 1);
@@ -1147,7 +1169,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     // takes more of the machine from the leaf kernel it overlaps with.)
     const uint32_t one_each = ctx->opt.one_each_tiles ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
     const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
-    const int gb = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_big, 8);
+    const int gb = one_each && !R.big_hbm ? (int)one_each : blocks_big(ctx, R, R.lds_tiles_big, 8);
     const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] {
         // (pre-pass levels below the root: the children of a parent shared out over several slots - tsetup_body; option
@@ -1296,7 +1318,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
 
 static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
     if (R.split) return launch_tiles_split(ctx, R, dS, level, is3d);
-    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_for(ctx, R.lds_tiles_big, 8);
+    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_big(ctx, R, R.lds_tiles_big, 8);
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(true, false, true, gb, R.lds_tiles_big); }
         else { if (R.full) FH_LAUNCH_TILES(false, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(false, false, true, gb, R.lds_tiles_big); }
@@ -1347,7 +1369,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     });
     if (P.max_regs > 32)
         launch(ctx, FHIP_K_POINTS, [&] {
-            const int g = blocks_for(ctx, R.lds_points_big, 16);
+            const int g = blocks_big(ctx, R, R.lds_points_big, 16);
             if (R.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
             else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
         });
@@ -1383,7 +1405,10 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     // runs beside that frame's slabs.  The slabs' tile chains follow on the side stream (after the previous frame's), the leaf
     // chains and the final image on the caller's stream as before.
     hipStream_t const main_stream = ctx->stream;
-    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial;
+    // (a tape whose register files live in HBM takes the slow path: one region per workgroup, shared by the launches of a frame, so
+    // nothing of the frame runs beside anything else)
+    const bool huge = (size_t)std::max<uint32_t>(tape->t.n_regs, 1) * WAVE * 16 > FH_LDS_MAX || tiles_lds(std::max<uint32_t>(tape->t.n_regs, 1), tape->t.n_choices, 64) > FH_LDS_MAX;
+    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial && !huge;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (fpipe) {
         // (rotate: the current set goes to the back of the ring, the set used longest ago comes forward)
@@ -1451,7 +1476,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     // pyramid is then one slab stale, which is still exact (depths only grow).  Two slab contexts
     // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
     FhRenderState* const dS0 = dS;
-    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
+    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
     hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
     const uint32_t NC = pipe ? ctx->slab_contexts : 1;
     ctx->forked = pipe ? NC : 0;
@@ -1544,14 +1569,14 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
             if (P.max_regs > 32)
                 launch(ctx, FHIP_K_POINTS, [&] {
-                    const int g = blocks_for(ctx, R.lds_points_big, 16);
+                    const int g = blocks_big(ctx, R, R.lds_points_big, 16);
                     if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
                     else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
                 });
         };
         auto normals_work = [&] {
             launch(ctx, FHIP_K_NORMALS, [&] {
-                const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_for(ctx, R.lds_normals_big, 8);
+                const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_big(ctx, R, R.lds_normals_big, 8);
                 if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 if (P.max_regs > 32) {

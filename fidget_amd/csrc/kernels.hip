@@ -58,6 +58,13 @@ FH_DEV bool op_is_heavy(uint32_t op) {
            op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR;
 }
 
+// Where a root-sized kernel variant keeps its register file: LDS, or this workgroup's region of S->gscratch when the tape's
+// file does not fit LDS (render_state.h gscratch: the slow path for tapes of several hundred registers)
+FH_DEV char* big_file(FhRenderState* S, char* smem) {
+    const uint32_t stride = S->gscratch_stride;
+    return stride ? S->gscratch + (size_t)blockIdx.x * stride : smem;
+}
+
 // --------------------------------------------------------------------------------------
 // LDS register file.  LANES is the lane stride (64 for point kernels, 16 for the tile kernel).
 template <class T, int LANES>
@@ -207,13 +214,15 @@ FH_DEV uint32_t wave_excl_sum(uint32_t v, uint32_t& total) {
 struct Pool {
     uint64_t f0, f1, f2, f3;
     int high;
-    FH_DEV void init() { f0 = f1 = f2 = f3 = ~0ull; high = 0; }
+    bool over;      // more than 255 registers were wanted at once: the tape being written is void (its child keeps the parent's)
+    FH_DEV void init() { f0 = f1 = f2 = ~0ull; f3 = ~0ull >> 1; high = 0; over = false; }      // (255 is DEAD in the byte maps)
     FH_DEV int take() {
         int r;
         if (f0) { r = __builtin_ctzll(f0); f0 &= f0 - 1; }
         else if (f1) { r = 64 + __builtin_ctzll(f1); f1 &= f1 - 1; }
         else if (f2) { r = 128 + __builtin_ctzll(f2); f2 &= f2 - 1; }
-        else { r = 192 + __builtin_ctzll(f3); f3 &= f3 - 1; }
+        else if (f3) { r = 192 + __builtin_ctzll(f3); f3 &= f3 - 1; }
+        else { over = true; return 0; }
         high = max(high, r + 1);
         return r;
     }
@@ -300,7 +309,7 @@ FH_DEV void prune_sweep(ctape_t tape, uint32_t len, uint32_t n_choices, const ui
         if (EMIT) *--dst = fh_pack(op, no, na, nb, w1);
         count++;
     }
-    out_len = count;
+    out_len = (EMIT && pool.over) ? 0xFFFFFFFFu : count;      // ~0: more than 255 registers, the child keeps the parent tape
     out_regs = (uint32_t)pool.high;
     out_choices = kept_choices;
 }
@@ -341,8 +350,9 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
     const int lane16 = lane & (TL - 1);
     const uint32_t max_regs = BIG ? P.max_regs : SMALL_REGS;
     const uint32_t max_choices = BIG ? P.max_choices : SMALL_CHOICES;
-    IV* regs = (IV*)smem;                                                       // [max_regs][TL]
-    uint32_t* chbits = (uint32_t*)(smem + (size_t)max_regs * TL * sizeof(IV)); // [(max_choices+15)/16][TL]
+    char* const file = BIG ? big_file(S, smem) : smem;
+    IV* regs = (IV*)file;                                                       // [max_regs][TL]
+    uint32_t* chbits = (uint32_t*)(file + (size_t)max_regs * TL * sizeof(IV)); // [(max_choices+15)/16][TL]
     uint8_t* map = (uint8_t*)(chbits + (size_t)((max_choices + 15) / 16) * TL);  // [max_regs][TL]
     const uint32_t T = P.tiles[level];
     const bool last_level = (level + 1 == (int)P.n_levels);
@@ -478,7 +488,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                     uint64_t* dst = S->arena + base + (rank + 1) * len;
                     prune_sweep<true, TL>(tape, len, n_choices, chbits, map, lane16, prune, dst, clen, cregs, cch);
                 }
-                if (prune) {
+                if (prune && clen != 0xFFFFFFFFu) {
                     child.off = base + (rank + 1) * len - clen; child.len = clen;
                     child.n_regs = (uint16_t)cregs; child.n_choices = (uint16_t)cch;
                 }
@@ -531,7 +541,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     S->leaf_table[(size_t)((cz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
-                        FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
+                        FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
                 }
             } else if (amb) atomicAdd(&S->queue_overflow, 1u);
         }
@@ -869,7 +879,7 @@ FH_DEV void teval_slots(FhRenderState* S, int level, char* smem, uint32_t first,
                 for (uint32_t r = 0; r < n_regs; r++) map[r * TL + lane] = DEAD;
                 uint32_t l2 = 0, r2 = 0, c2 = 0;
                 prune_sweep<true, TL>(tape, len, n_choices, chbits, map, lane, prune, S->arena + base + (rank + 1) * len, l2, r2, c2);
-                if (prune) { coff = base + (rank + 1) * len - l2; clen = l2; cregs = r2; cch = c2; }
+                if (prune && l2 != 0xFFFFFFFFu) { coff = base + (rank + 1) * len - l2; clen = l2; cregs = r2; cch = c2; }
                 if (lane == 0) sl.base = base;
             } else if (lane == 0) {
                 sl.overflow = 1;
@@ -882,7 +892,7 @@ FH_DEV void teval_slots(FhRenderState* S, int level, char* smem, uint32_t first,
 template <bool FULL, bool BIG>
 __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    teval_slots<FULL, BIG>(S, level, smem, blockIdx.x, gridDim.x);
+    teval_slots<FULL, BIG>(S, level, BIG ? big_file(S, smem) : smem, blockIdx.x, gridDim.x);
 }
 
 // Step 3: fills of the decided children, queue / leaf entries for the ambiguous ones
@@ -1003,7 +1013,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                     if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                     if (IS3D)
                         S->leaf_table[(size_t)((iz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
-                            FhLeafRef{lb + slot + 1, child.off, child.len | ((uint32_t)child.n_regs << 24), cx | (cy << 16)};  // [layer][footprint]
+                            FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
                 } else if (amb) atomicAdd(&S->queue_overflow, 1u);
             }
         }
@@ -1160,7 +1170,7 @@ __global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
             float x[1], y[1], z[1], res[1] = {0.0f};
             xf_point(mat, (float)px, (float)py, P.z, x[0], y[0], z[0]);
             if (NR) run_points<(NR ? NR : 1), 1, FULL>(tape, lf.tape.len, P, x, y, z, res);
-            else res[0] = run_points_lds<FULL>(tape, lf.tape.len, P, (float*)smem, lane, x[0], y[0], z[0]);
+            else res[0] = run_points_lds<FULL>(tape, lf.tape.len, P, (float*)big_file(S, smem), lane, x[0], y[0], z[0]);
             if (p < T * T && px < P.width && py < P.height)
                 S->image2d[(size_t)py * P.width + px] = isnan_(res[0]) ? u2f(0x7FC00000u) : res[0];  // pixel.rs:235-241
         }
@@ -1230,7 +1240,7 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
             float x[ZB], y[ZB], z[ZB], res[ZB];
             FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
             if (NR) run_points<(NR ? NR : 1), ZB, FULL>(tape, len, P, x, y, z, res);
-            else res[0] = run_points_lds<FULL>(tape, len, P, (float*)smem, lane, x[0], y[0], z[0]);
+            else res[0] = run_points_lds<FULL>(tape, len, P, (float*)big_file(S, smem), lane, x[0], y[0], z[0]);
             FOR_Z {
                 if (pending && res[j] < 0.0f) {  // first voxel inside, front to back
                     depth = lz + (uint32_t)(k - j) + 1;
@@ -1258,7 +1268,7 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T;
-    Regs<GR, WAVE> R{(GR*)smem, lane};
+    Regs<GR, WAVE> R{(GR*)(BIG ? big_file(S, smem) : smem), lane};
     Mat4 mat;
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];

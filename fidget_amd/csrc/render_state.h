@@ -133,6 +133,11 @@ struct FhRenderState {
     uint64_t* zbuf;         // 3D: depth << 32 | leaf id (+1) of a hit whose normal is pending
     float* normals;         // 3D: 3 floats per pixel
     float* image2d;         // 2D: RawDistancePixel bits
+    // Register files (and choice words, prune maps) of tapes too large for the 160 KB of LDS - the role of the reference's spill
+    // slots (RegOp::Load / Store, compiler/alloc.rs:116-125: registers beyond the file live in memory): the root-sized kernel
+    // variants then keep theirs in HBM, one region of gscratch_stride bytes per workgroup; 0: LDS as usual
+    char* gscratch;
+    uint32_t gscratch_stride, pad_gscratch;
     // statistics (optional, for bench / roofline accounting); want_stats: count tape ops per level (two
     // same-address atomics per parent tile: only in profiled frames)
     uint32_t want_stats, pad_stats;

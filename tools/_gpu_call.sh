@@ -1,1 +1,2 @@
-bash tools/sweep_env.sh "FHIP_FRAME_SETS=3" "FHIP_FRAME_SETS=4" "FHIP_FRAME_SETS=4 FHIP_TILES_STREAM=0"
+mkdir -p gpurun_out/r03j
+timeout 600 python -m pytest tests/test_spills.py -m gpu -x -q > gpurun_out/r03j/spills.log 2>&1; tail -30 gpurun_out/r03j/spills.log
