@@ -383,17 +383,18 @@ static fhip_status finish_tape(fhip_ctx* ctx, fh::SsaProgram& prog, fhip_tape** 
     if (t->t.n_vars > FH_MAX_INPUTS) { delete t; return fail(ctx, FHIP_ERR_UNSUPPORTED, "more than 16 input variables"); }
     // (FHIP_GROUPS_MIN_OPS / FHIP_GROUPS_MIN_TERMS: tests lower the thresholds to send small shapes down this path)
     const size_t min_ops = getenv("FHIP_GROUPS_MIN_OPS") ? (size_t)atol(getenv("FHIP_GROUPS_MIN_OPS")) : 1024;
-    const uint32_t min_terms = getenv("FHIP_GROUPS_MIN_TERMS") ? (uint32_t)atol(getenv("FHIP_GROUPS_MIN_TERMS")) : 2 * FH_MAX_GROUPS;
+    const uint32_t min_terms = getenv("FHIP_GROUPS_MIN_TERMS") ? (uint32_t)atol(getenv("FHIP_GROUPS_MIN_TERMS")) : 32;
+    const uint32_t want_groups = (uint32_t)std::min<long>(FH_MAX_GROUPS, std::max<long>(2, getenv("FHIP_GROUPS") ? atol(getenv("FHIP_GROUPS")) : 32));
     if (t->t.ops.size() >= min_ops && !getenv("FHIP_NO_GROUPS")) {
         std::vector<fh::SsaProgram> gp;
-        const int op = fh::split_root(prog, FH_MAX_GROUPS, min_terms, gp);
+        const int op = fh::split_root(prog, want_groups, min_terms, gp);
         if (op >= 0) {
             t->groups.resize(gp.size());
             bool ok = true;
             for (size_t g = 0; g < gp.size() && ok; g++) ok = fh::allocate(gp[g], t->groups[g], err);
             if (ok) t->group_op = op; else t->groups.clear();
         }
-        if (fh::plan_terms(prog, FH_MAX_GROUPS, min_terms, 16, t->plan)) {
+        if (fh::plan_terms(prog, want_groups, min_terms, 16, t->plan)) {
             t->tgroups.resize(t->plan.groups.size());
             bool ok = true;
             for (size_t g = 0; g < t->tgroups.size() && ok; g++) ok = fh::allocate(t->plan.groups[g], t->tgroups[g], err);
@@ -952,7 +953,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
     if (S.pre_levels) HIP_TRY(ctx, ctx->squeue.ensure((size_t)qcaps[S.pre_levels] * R.n_slabs * sizeof(FhGroup)));
     HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
-    const size_t extra = ctx->slab_contexts - 1;
+    const size_t extra = std::min<uint32_t>(ctx->slab_contexts, std::max<uint32_t>(R.n_slabs, 1)) - 1;      // (slab contexts beyond the first)
     if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(extra * leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
         if (P.width > 65535 || P.height > 65535) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images up to 65535 x 65535");
@@ -1478,7 +1479,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     FhRenderState* const dS0 = dS;
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
     hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
-    const uint32_t NC = pipe ? ctx->slab_contexts : 1;
+    const uint32_t NC = pipe ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;     // (no more contexts than slabs: each takes its share of the arena)
     ctx->forked = pipe ? NC : 0;
     if (pipe) {
         hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,

@@ -8,7 +8,7 @@
 #define FH_MAX_LEVELS 8
 #define FH_MAX_INPUTS 16
 #define FH_MAX_SLABS 64
-#define FH_MAX_GROUPS 16  // independent sub-tapes of a root min / max (tape parallelism at level 0)
+#define FH_MAX_GROUPS 32  // independent sub-tapes of a root min / max (tape parallelism at level 0): at most; FHIP_GROUPS when a tape is built
 
 // One wave's worth of interval work: a parent tile (or, at level 0, a run of root tiles)
 // together with the tape that evaluates its children.

@@ -18,7 +18,7 @@ def test_split_exists_for_prospero():
     import fidget_amd as F
     s = F.Shape.from_vm(model_path("prospero.vm"))
     op, gs = s.groups()
-    assert op == "min" and 2 <= len(gs) <= 16
+    assert op == "min" and 2 <= len(gs) <= 32           # (FH_MAX_GROUPS)
     assert max(g.size() for g in gs) < s.size() // 4          # the point: short independent chains
     assert F.Shape.from_vm(model_path("hi.vm")).groups() == ("", [])
 
@@ -71,7 +71,7 @@ def test_term_plan_for_prospero():
     import fidget_amd as F
     s = F.Shape.from_vm(model_path("prospero.vm"))
     p = s.term_plan()
-    assert 2 <= p["groups"] <= 16 and p["terms"] >= 600
+    assert 2 <= p["groups"] <= 32 and p["terms"] >= 600
     assert p["choices"] == s.choice_count()
     assert p["tree_regs"] == 1 and p["tree_ops"] >= p["terms"] - 1
     assert F.Shape.from_vm(model_path("hi.vm")).term_plan()["groups"] == 0

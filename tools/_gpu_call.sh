@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r03j
-timeout 600 python -m pytest tests/test_spills.py -m gpu -x -q > gpurun_out/r03j/spills.log 2>&1; tail -30 gpurun_out/r03j/spills.log
+bash tools/sweep_env.sh "FHIP_GROUPS=16" "FHIP_GROUPS=24" "FHIP_GROUPS=32"
+FHIP_GROUPS=32 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "headline or column_invariant" 2>&1 | tail -2
