@@ -1429,8 +1429,9 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
             R.col_slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
             const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
             if (dep && slot[ax] >= 0) R.col_depmask |= 1u << slot[ax];
+            if (dep) R.col_flags |= 0x20000u << ax;     // (bits 17 .. 19: this axis of the model changes along a pixel column - from the camera alone)
         }
-        R.col_flags = proj ? 0x10000u : 0u;
+        R.col_flags |= proj ? 0x10000u : 0u;
         // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
         const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
         // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying

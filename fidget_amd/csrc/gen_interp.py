@@ -584,6 +584,17 @@ class Interp:
         a(f"\ts_branch {lab['done']}")
         for axis, (row, acc) in (("x", (0, V_AX)), ("y", (1, V_AY)), ("z", (2, V_AZ))):
             a(f"{lab[axis]}:")
+            # The axis' matrix row has no z coefficient and the matrix is not projective (kernarg flags bit 17 + row clear: from
+            # the camera alone, whatever the tape-level short cuts are set to): m[4r+2] is a zero, m[4r+2] * z is that same zero
+            # for every voxel (z >= 0), so the 8 samples are ONE value, ((m[4r] x + m[4r+1] y) + m[4r+2]) + m[4r+3] - the sum in
+            # the order of the general path, bit for bit - instead of a convert, a multiply and two adds per sample.
+            vary = a.label("in_vary_" + axis)
+            a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, {17 + row}\n\ts_cbranch_scc1 {vary}")
+            a(f"\tv_add_f32 {VT[0]}, s{m + 4 * row + 2}, {acc}\n\tv_add_f32 {VT[0]}, s{m + 4 * row + 3}, {VT[0]}\n\tv_mov_b32 {VT[1]}, {VT[0]}")
+            self.idx_on(S_OUT, DST)
+            for k in range(self.zb // 2):
+                a(f"\tv_pk_mov_b32 {self.FP(k)}, {self.P(VT, 0)}, {self.P(VT, 0)} op_sel:[0,1]")
+            a(f"\ts_branch {lab['done']}\n{vary}:")
             a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
             for j in range(self.zb):      # z of sample j = lz + k - j
                 a(f"\tv_cvt_f32_u32 {VT[j]}, {S_T0}")
@@ -857,7 +868,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_bfe_i32 {S_SLOTY}, s49, 0x80008
 	s_bfe_i32 {S_SLOTZ}, s49, 0x80010
 	s_mov_b32 {S_DEPMASK}, s50
-	s_and_b32 s51, s51, 0x10000
+	s_and_b32 s51, s51, 0xf0000                      ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column
 	s_or_b32 {S_WGY}, {S_WGY}, s51
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
@@ -1130,16 +1141,20 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_cbranch_scc0 {skip}
 	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
 {skip}:""")
+        # first voxel inside, front to back (sample j: depth = lz + (k - j) + 1): the samples' "value < 0" bits shifted into a mask
+        # through the carry (sample 0 ends up highest), its leading bit is the hit - 2 instructions per sample instead of 8
+        a(f"\tv_mov_b32 {V_S0}, 0")
         for j in range(zb):
-            # first voxel inside, front to back: depth = lz + (k - j) + 1
-            a(f"""
-	v_cmp_gt_f32 vcc, 0, {VRES[j]}
+            a(f"\tv_cmp_gt_f32 vcc, 0, {VRES[j]}\n\tv_addc_co_u32 {V_S0}, vcc, {V_S0}, {V_S0}, vcc")
+        a(f"""
+	v_ffbh_u32 {V_S1}, {V_S0}                          ; = 32 - zb + j of the first sample inside
+	v_cmp_ne_u32 vcc, 0, {V_S0}
 	s_add_u32 {S_T0}, {S_LZ}, {S_K}
-	s_add_u32 {S_T0}, {S_T0}, {1 - j}
-	v_mov_b32 {V_S0}, {S_T0}
+	s_add_u32 {S_T0}, {S_T0}, {33 - zb}
+	v_sub_u32 {V_S1}, {S_T0}, {V_S1}
 	s_and_b64 {S_M[0]}, vcc, {S_PEND}
 	s_andn2_b64 {S_PEND}, {S_PEND}, {S_M[0]}
-	v_cndmask_b32_e64 {V_DEPTH}, {V_DEPTH}, {V_S0}, {S_M[0]}
+	v_cndmask_b32_e64 {V_DEPTH}, {V_DEPTH}, {V_S1}, {S_M[0]}
 	v_cndmask_b32_e64 {V_HIT}, {V_HIT}, {V_IDV}, {S_M[0]}""")
         if zb < 8:
             a(f"""

@@ -27,11 +27,14 @@ def col_kernarg(a_st, in_kind, mat):
         if k < 3:
             slot[k] = s_
     slots = sum((0xFF if slot[ax] < 0 else slot[ax]) << (8 * ax) for ax in range(3))
-    dep = 0
+    dep, flags = 0, 0x10000 if proj else 0
     for ax in range(3):
-        if slot[ax] >= 0 and (proj or (int(u[4 * ax + 2]) & 0x7FFFFFFF)):
+        varies = proj or (int(u[4 * ax + 2]) & 0x7FFFFFFF)
+        if slot[ax] >= 0 and varies:
             dep |= 1 << slot[ax]
-    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, 0x10000 if proj else 0, 0, 0], U32)
+        if varies:
+            flags |= 0x20000 << ax          # (bits 17 .. 19: this axis of the model changes along a pixel column)
+    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, 0, 0], U32)
 
 
 def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns"):
