@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "kernels.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
+_SOURCES = ["capi.hip", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
             "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
@@ -294,7 +294,8 @@ class HipContext:
         """Leaf-stage counters of the last profiled 3D frame (render_state.h leaf_stat)."""
         c = np.zeros(8, np.uint64)
         self.check(lib().fhip_debug_leaf_stats(self._h, _p(c)))
-        return {"leaves": int(c[0]), "tape_ops": int(c[1]), "tape_words_read": int(c[2]), "lane_ops": int(c[3])}
+        return {"leaves": int(c[0]), "tape_ops": int(c[1]), "tape_words_read": int(c[2]), "lane_ops": int(c[3]),
+                "prune2_phase_clocks_max": [int(v) for v in c[4:8]]}
 
     def wave_stats(self):
         """Per kernel kind: mean / max busy microseconds of the waves that found work, their

@@ -56,7 +56,7 @@ struct fhip_tape {
     mutable FhTopOp* d_top = nullptr;
     mutable uint32_t* d_chsrc = nullptr;
     mutable uint64_t* d_links = nullptr;   // links of the full tape (host_graph.hpp compute_links) for the linked prune, when it qualifies
-    mutable uint16_t* d_ctab = nullptr;    // ... and the op index of every choice
+    mutable uint64_t* d_ctab = nullptr;    // ... and per choice its op's operands and index
     mutable bool links_tried = false;
     // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
     // reference's workers): its lazily created device copies are made under this lock, on the device of the first
@@ -89,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -749,7 +749,7 @@ struct RenderSetup {
     bool prune1 = false;      // ... and, on the first exp_levels levels, the prune as one wave per child (fh_prune1)
     bool prune2 = false;      // ... by the linked prune (prune2.hip k_prune2: visits only the ops a child keeps) where the tape qualifies
     const uint64_t* d_links = nullptr;
-    const uint16_t* d_ctab = nullptr;
+    const uint64_t* d_ctab = nullptr;
     size_t lds_prune2 = 0;
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
@@ -1023,22 +1023,21 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 HIP_TRY(ctx, hipMemcpy(tape->d_chsrc, tape->plan.choice_src.data(), tape->plan.choice_src.size() * 4, hipMemcpyHostToDevice));
             }
             S.ttop = tape->d_top; S.chsrc = tape->d_chsrc;
-            // the linked prune of the root level (option prune2, off by default: measured 0.73 ms against fh_prune1's 0.34 ms per
-            // 1024^3 frame of prospero.vm - a child of that root tape keeps ~580 ops, up to 1011, not the handful the design
-            // assumed, and per kept op the compiled walk is no cheaper than the assembly sweep; profiles/r03c): links of the
-            // root tape, made once with it
+            // the linked prune of the root level (option prune2; prune2.hip): links of the root tape, made once with it.  0.275 ms
+            // against fh_prune1's 0.344 per 1024^3 frame of prospero.vm (a child of that root tape keeps ~580 ops, up to 1011);
+            // fh_prune1 stays behind it for the children it leaves marked (more than 64 registers / FH_P2_MAX_KEPT ops)
             if (ctx->opt.prune2 && !tape->links_tried) {
                 tape->links_tried = true;
                 std::vector<uint64_t> lk;
-                std::vector<uint16_t> cops;
+                std::vector<uint64_t> cops;
                 if (fh::compute_links(t, lk, cops)) {
                     HIP_TRY(ctx, hipMalloc((void**)&tape->d_links, lk.size() * 8));
                     HIP_TRY(ctx, hipMemcpy(tape->d_links, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
-                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_ctab, std::max<size_t>(cops.size(), 1) * 2));
-                    HIP_TRY(ctx, hipMemcpy(tape->d_ctab, cops.data(), cops.size() * 2, hipMemcpyHostToDevice));
+                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_ctab, std::max<size_t>(cops.size(), 1) * 8));
+                    HIP_TRY(ctx, hipMemcpy(tape->d_ctab, cops.data(), cops.size() * 8, hipMemcpyHostToDevice));
                 }
             }
-            R.lds_prune2 = (size_t)t.ops.size() * 16 + (size_t)FH_P2_WPB * fh_p2_wave_lds((uint32_t)t.ops.size(), t.n_choices);
+            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices);
             R.prune2 = tape->d_links && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
                        R.lds_prune2 <= FH_LDS_MAX;
             R.d_ctab = tape->d_ctab;
@@ -1197,8 +1196,14 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (R.prune2) {
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
-                hipLaunchKernelGGL(k_prune2, dim3(blocks * (64 / FH_P2_WPB)), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
-                                   (const uint2*)R.d_links, R.d_ctab, 0u);
+                hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 0u);
+                // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or 2048 kept ops:
+                // none for the models here; a wave whose child is done leaves at once)
+                struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
+                size_t kp_bytes = sizeof(kp);
+                void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &kp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &kp_bytes, HIP_LAUNCH_PARAM_END};
+                (void)hipModuleLaunchKernel(ctx->asm_fn[FH_ASM_PRUNE1], blocks * 64, 1, 1, WAVE, 1, 1, 0, ctx->stream, nullptr, extra);
                 if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({FH_ASM_PRUNE1, {ea, eb}}); }
             } else {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -2430,7 +2435,7 @@ fhip_status fhip_debug_stats(fhip_ctx* ctx, uint64_t out[64]) {
 // Diagnostics: the links of a tape as the linked prune gets them (host_graph.hpp compute_links); 0: the tape does not qualify
 uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t cap) {
     std::vector<uint64_t> lk;
-    std::vector<uint16_t> cops;
+    std::vector<uint64_t> cops;
     if (!fh::compute_links(tape->t, lk, cops)) return 0;
     for (size_t i = 0; i < lk.size() && i < cap; i++) out[i] = lk[i];
     return (uint32_t)lk.size();

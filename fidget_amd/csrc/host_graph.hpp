@@ -368,9 +368,9 @@ struct HostTape {
 // taken out.  Per op 8 bytes: word 0 = opcode | class << 8 | choice ordinal << 16 (choice ops before this one), word 1 = fa | fb << 16
 // - the op that produced operand a / b (the last writer of that register before this op, looking through register copies):
 // its index, or 0x8000 | its choice ordinal when it is a min / max / and / or, 0xFFFF when there is no such operand.  Per
-// choice 2 bytes: the index of the op.  Returns false when the tape is outside what the linked prune handles (more than
+// choice 8 bytes: word 0 = the op's fa | fb << 16 again, word 1 = the index of the op | its class << 16 (a batch of ordinals: one load).  Returns false when the tape is outside what the linked prune handles (more than
 // 16383 ops or 32767 choices - the field widths -, an OUTPUT that is not the one last op, an operand nobody wrote).
-static inline bool compute_links(const HostTape& t, std::vector<uint64_t>& out, std::vector<uint16_t>& choice_ops) {
+static inline bool compute_links(const HostTape& t, std::vector<uint64_t>& out, std::vector<uint64_t>& choice_ops) {
     const size_t n = t.ops.size();
     out.clear();
     choice_ops.clear();
@@ -394,7 +394,7 @@ static inline bool compute_links(const HostTape& t, std::vector<uint64_t>& out, 
         const uint32_t ci = (uint32_t)choice_ops.size();
         out.push_back((uint64_t)((uint32_t)op | (kind << 8) | (ci << 16)) | ((uint64_t)(fa | (fb << 16)) << 32));
         if (op == FH_COPY_REG) field[i] = fa;                         // a copy is its source
-        else if (choice) { field[i] = 0x8000u | ci; choice_ops.push_back((uint16_t)i); }
+        else if (choice) { field[i] = 0x8000u | ci; choice_ops.push_back((uint64_t)(fa | (fb << 16)) | ((uint64_t)((uint32_t)i | (kind << 16)) << 32)); }
         else field[i] = (uint32_t)i;
         if (op != FH_OUTPUT) last[ro] = (int)i;
     }

@@ -1,67 +1,96 @@
-// k_prune2 - the linked prune: VmData::simplify for ONE child tile per wavefront, visiting only the ops the child keeps.
+// k_prune2 - the linked prune: VmData::simplify for ONE child tile per wavefront, with the work that is sequential by nature
+// reduced to the ops the child keeps, and everything else done 64 ops at a time.
 //
 // VmData::simplify (fidget-core/src/vm/data.rs:123-318, restated as prune_sweep in kernels.hip) walks the parent tape
-// backwards and asks of every op whether its output register is wanted.  A child of the root tape keeps ~3 % of it (prospero:
-// 150-210 of 6363 ops), so nearly all of that walk finds out that an op is dead or that a decided min / max merely passes its
-// operand on - the scalar sweep fh_prune1 needs ~26-38 k instructions per child for it, 340 us for the root level, a third of
-// the frame's longest chain.
+// backwards and asks of every op whether its output register is wanted.  The scalar sweep fh_prune1 does that for a child of the
+// root tape in ~115 instructions per kept op, one after the other: 343 us for prospero's root level (a child keeps 579 ops in
+// the median, 1 011 at most, of 6 363), the longest kernel of the frame.  What is truly sequential in simplify is only the
+// register allocation; the rest is data parallel once register numbers are out of the way.
 //
-// Here the tape comes with LINKS (host_graph.hpp compute_links, made once per tape): per op, which op produced each operand -
-// in SSA terms, register numbers no longer matter - and for a producer that is itself a min / max / and / or, the ordinal
-// of that choice instead.  Then
-//   A  the child's choices turn every choice op into "kept", "is its left / right operand" or "is its immediate"; chains
-//      of passed-on operands (prospero's root is a chain of 664 min ops of which a child keeps a handful) are followed for
-//      ALL choice ops at once by pointer jumping, 64 ordinals per step in tape order: E[q] = the op whose value choice q's
-//      output really is;
-//   B  a walk over the kept ops only: a bit mask of wanted ops, the highest one visited next, its output register freed, its
-//      operands' producers (through E) given registers and marked wanted - the reverse sweep of simplify restricted to live ops,
-//      with the same lowest-free-first register pool, keyed by the producing op rather than by the parent's register number;
-//   C  (emit_links) links of the child tape for the prune of ITS children.
-// No register copies are ever emitted: a consumer of a decided choice reads the surviving operand's register directly.
-// The tapes differ from fh_prune1's (which inserts a copy where an operand outlives the choice that passed it on) in
-// register numbers and in those copies only; values are those of the parent tape on the child's region, op for op
-// (tests/test_prune2.py evaluates both on points of the tile).
+// The tape comes with LINKS (host_graph.hpp compute_links, made once per tape): per op, which op produced each operand - in SSA
+// terms - and for a producer that is itself a min / max / and / or, the ordinal of that choice instead.  Then, per child:
+//   A  the choices turn every choice op into "kept", "is its left / right operand" or "is its immediate"; chains of passed-on
+//      operands (prospero's root is a chain of 664 min ops) are followed for ALL choice ops at once by pointer jumping, 64
+//      ordinals per step in tape order: E[q] = the op whose value choice q's output really is;
+//   B1 liveness: 64 ops at a time from the end of the tape, lane = op, a bit mask of wanted ops; a wanted op marks the ops that
+//      really produce its operands (through E).  Producers have lower indices, so one pass with a fixed point inside a batch
+//      (an op wanted by another op of its own batch) does it; batches without a wanted op cost one word;
+//   B2 the kept ops' positions in the child tape (prefix population counts), per kept op its operands' positions and whether it
+//      is their last use (an atomic maximum per value);
+//   B3 the one sequential step, in tape order over the KEPT ops only: registers are returned at a value's last use and taken at
+//      its definition (lowest free first) - linear scan, optimal for a straight-line program.  The loop lives in SGPRs and
+//      cross-lane reads: the kept ops' records come 64 at a time into VGPRs, the registers of the last 256 values sit in four
+//      VGPRs (older values: LDS), nothing waits for memory;
+//   B4 the child's ops, 64 at a time.
+// No register copies are ever emitted: a consumer of a decided choice reads the surviving operand's register directly.  The
+// tapes differ from fh_prune1's (which re-uses the parent's structure and inserts a copy where an operand outlives the choice
+// that passed it on) in register numbers and in those copies; values are those of the parent tape on the child's region, op for
+// op (tests/test_prune2.py evaluates both on points of the tile).
 //
-//   grid   : 64 / WPB workgroups of WPB waves per slot; wave = one child lane of the slot
-//   LDS    : the parent's ops and links, 16 B per op, staged once per workgroup (its WPB children share the parent);
-//            per wave: op -> new register (1 B per parent op), the wanted-op mask, E (2 B per choice)
-//   limits : <= 8192 ops, <= 4096 choices, <= 255 registers in the CHILD (more: the child keeps the parent tape), one OUTPUT
-//            op, the last one - capi.hip checks and keeps fh_prune1 otherwise
+//   grid   : one wave per child lane of a slot, FH_P2_WPB waves per workgroup: they share the parent's links, staged in LDS
+//            (8 B per op: the liveness pass would otherwise wait for a load per batch)
+//   limits : <= 8192 ops, <= 4096 choices in the parent, <= 1536 kept ops and <= 64 registers in the child (more: the child
+//            is left to the scalar sweep launched behind this kernel), one OUTPUT op, the last one - capi.hip checks and keeps fh_prune1 otherwise
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "render_state.h"
 
-#define FH_P2_WPB 4
+#define FH_P2_WPB 3
+#define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // workgroups per slot (the last one's spare waves idle)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
+#define FH_P2_MAX_KEPT 1536u
 // op classes of a link
 enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4, FH_LK_CRR = 5, FH_LK_CRI = 6 };
 // Link of an op, 8 bytes: word 0 = opcode | class << 8 | choice ordinal << 16, word 1 = fa | fb << 16: the producers of operands a and
 // b as op indices, 0x8000 | ordinal when the producer is a choice op, 0xFFFF none.  Register copies are looked through.
-// Per choice (second table, 2 bytes): the index of the op.
-#define FH_LK_NONE16 0xFFFFu
+// Per choice (second table, 8 bytes, so that a batch of ordinals is one coalesced load): word 0 = fa | fb << 16 of the op, word 1 =
+// its index | class << 16.
 #define FH_LK_CHOICE 0x8000u
 #define FH_LK_IMM 0x4000u        // E: the choice's value is its immediate (reg,imm op decided Right): the op stays, as COPY_IMM
 
-static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_ops, uint32_t n_choices) {
-    return (((size_t)n_ops + 15) & ~(size_t)15) + 1024 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + 16;
+// bytes of LDS per wave: wanted-op mask (128 x 8), position prefixes (128 x 2), E (2 per choice), kept-op records (8 each), last
+// uses (4 each), registers by position (1 each), registers returning at a position (2 each)
+static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices) {
+    return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)FH_P2_MAX_KEPT * (8 + 4 + 1 + 2) + 64;
 }
 
 namespace fhp2 {
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) { return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// v_writelane_b32: `old` with lane `lane` replaced by `v` (both wave-uniform; the lane select goes through M0: two SGPR operands
+// would break the constant-bus rule).  (This compiler has no builtin for it.)
+__device__ __forceinline__ uint32_t wlane(uint32_t v, uint32_t lane, uint32_t old) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(rfl(v)), "s"(rfl(lane)) : "m0");
+#else
+    (void)v; (void)lane;
+#endif
+    return old;
+}
+__device__ __forceinline__ uint32_t excl_sum(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
 }  // namespace fhp2
 
 // mode 0: slots[big] of `level`, choice words S->chw[big] with `cw_stride` words per slot; mode 2 (tape groups, level 0): slot =
 // block * n_tgroups, choice words S->chwr (k_tscatter3d).  links / ctab: the parent's links when it is the root tape (device
 // copies made with the tape).
 __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride,
-                                                           const uint2* __restrict__ links, const uint16_t* __restrict__ ctab, uint32_t emit_links) {
+                                                           const uint2* __restrict__ links, const uint2* __restrict__ ctab, uint32_t emit_links) {
     using namespace fhp2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the walk branches on is made wave-uniform explicitly)
-    const uint32_t per_slot = 64 / FH_P2_WPB;
+    const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the sequential step branches on is made wave-uniform explicitly)
+    const uint32_t per_slot = FH_P2_PER_SLOT;
     const uint32_t sidx = blockIdx.x / per_slot;
     const uint32_t G = mode == 2 ? rfl(S->n_tgroups) : 1u;
     if (sidx * G >= rfl(S->n_slots[big][level])) return;
@@ -70,147 +99,189 @@ __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uin
     const uint32_t c0 = (blockIdx.x % per_slot) * FH_P2_WPB, c = c0 + wave;      // this wave's child lane
     {   // any of this workgroup's children marked for the prune?  (c_len == ~0: k_tmark3d / the export mode of the forward kernels)
         bool any = false;
-        for (uint32_t k = 0; k < FH_P2_WPB; k++) any |= sl.c_len[c0 + k] == 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < FH_P2_WPB; k++) any |= c0 + k < 64 && sl.c_len[c0 + k] == 0xFFFFFFFFu;
         if (!any) return;
     }
     const uint32_t off = rfl(sl.tape.off), n = rfl(sl.tape.len), nch = rfl((uint32_t)sl.tape.n_choices);
-    uint4* const recs = (uint4*)smem;
-    {   // stage the parent: {link word 0, link word 1, op word 1 (immediate), op word 0} per op
-        const uint2* const ops = (const uint2*)(S->arena + off);
-        for (uint32_t i = threadIdx.x; i < n; i += FH_P2_WPB * 64) {
-            const uint2 o = ops[i], l = links[i];
-            recs[i] = make_uint4(l.x, l.y, o.y, o.x);
-        }
-    }
-    char* const mine = smem + (size_t)n * 16 + (size_t)wave * fh_p2_wave_lds(n, nch);
-    uint8_t* const map = (uint8_t*)mine;                                   // op index -> new register, 0xFF: none
-    uint64_t* const mask = (uint64_t*)(mine + (((size_t)n + 15) & ~(size_t)15));    // wanted ops, 64 per word (128 words)
-    uint16_t* const E = (uint16_t*)((char*)mask + 1024);                  // per choice: the op its value is (| FH_LK_IMM)
-    const bool marked = rfl(sl.c_len[c]) == 0xFFFFFFFFu;
-    const uint32_t n_words = (n + 63) >> 6;
-    if (marked) {
-        for (uint32_t k = lane; k < (n + 15) / 16; k += 64) ((uint4*)map)[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (uint32_t k = lane; k < n_words; k += 64) mask[k] = 0;
-    }
+    const uint2* const ops = (const uint2*)(S->arena + off);
+    uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
+    for (uint32_t i = threadIdx.x; i < n; i += FH_P2_WPB * 64) lks[i] = links[i];
+    char* const mine = smem + (((size_t)n * 8 + 15) & ~(size_t)15) + (size_t)wave * fh_p2_wave_lds(nch);
+    uint64_t* const mask = (uint64_t*)mine;                               // wanted ops, 64 per word (128 words)
+    uint16_t* const pref = (uint16_t*)(mine + 1024);                    // kept ops before each word
+    uint16_t* const E = (uint16_t*)(mine + 1280);                       // per choice: the op its value is (| FH_LK_IMM)
+    uint2* const comp = (uint2*)(mine + 1280 + (((size_t)nch * 2 + 15) & ~(size_t)15));       // per kept op: operand positions, op index | flags << 16
+    uint32_t* const lastuse = (uint32_t*)((char*)comp + (size_t)FH_P2_MAX_KEPT * 8);
+    uint8_t* const regb = (uint8_t*)((char*)lastuse + (size_t)FH_P2_MAX_KEPT * 4);
+    uint8_t* const frees = regb + (size_t)FH_P2_MAX_KEPT;                 // registers that return at a time: bytes [2 t], [2 t + 1] (operand a / b of op t; 0xFF none)
+    const uint32_t nw = (n + 63) >> 6;
     __syncthreads();
-    if (!marked) return;
+    if (c >= 64 || rfl(sl.c_len[c]) != 0xFFFFFFFFu) return;             // not marked for the prune
 
+    const bool probe = S->want_stats != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
+    const uint64_t t_a = probe ? clock64() : 0;
     // ---- A: what every choice op's value is -------------------------------------------------------------------------------------
     // 64 ordinals at a time, in tape order: an operand's producer has a lower ordinal, so a pointer out of the batch lands on a
     // final entry, and pointers inside the batch are followed by six rounds of jumping between lanes.
     {
         const uint32_t* const cws = mode == 2 ? S->chwr + (size_t)sidx * G * cw_stride * 64 : S->chw[big] + (size_t)sidx * cw_stride * 64;
+        uint32_t* const cwl = (uint32_t*)comp;       // (the child's choice words, staged where the kept-op records go later: one load latency for all)
+        for (uint32_t k = lane; k < (nch + 15) / 16; k += 64) cwl[k] = cws[(size_t)k * 64 + c];
+        uint2 tn = lane < nch ? ctab[lane] : make_uint2(0, 0);
         for (uint32_t q0 = 0; q0 < nch; q0 += 64) {
             const uint32_t q = q0 + lane;
+            const uint2 t = tn;
+            if (q + 64 < nch) tn = ctab[q + 64];      // (the next batch's entries arrive while this one is resolved)
             uint32_t e = 0;
             if (q < nch) {
-                const uint32_t i = ctab[q];
-                const uint4 r = recs[i];
-                const uint32_t ch = (cws[(size_t)(q >> 4) * 64 + c] >> ((q & 15) * 2)) & 3u;
-                const uint32_t kind = (r.x >> 8) & 0xFFu;
-                if (ch == FH_CHOICE_LEFT) e = r.y & 0xFFFFu;
-                else if (ch == FH_CHOICE_RIGHT) e = kind == FH_LK_CRR ? r.y >> 16 : (i | FH_LK_IMM);
+                const uint32_t i = t.y & 0xFFFFu, kind = t.y >> 16;
+                const uint32_t ch = (cwl[q >> 4] >> ((q & 15) * 2)) & 3u;
+                if (ch == FH_CHOICE_LEFT) e = t.x & 0xFFFFu;
+                else if (ch == FH_CHOICE_RIGHT) e = kind == FH_LK_CRR ? t.x >> 16 : (i | FH_LK_IMM);
                 else e = i;
                 if ((e & FH_LK_CHOICE) && (e & 0x7FFFu) < q0) e = E[e & 0x7FFFu];     // out of the batch: final
             }
-#pragma unroll
-            for (int round = 0; round < 6; round++) {
-                const uint32_t t = __shfl(e, (int)((e & 0x7FFFu) - q0) & 63, 64);
-                if (e & FH_LK_CHOICE) e = t;
+            for (int round = 0; round < 6 && __ballot((e & FH_LK_CHOICE) != 0) != 0; round++) {
+                const uint32_t t2 = __shfl(e, (int)((e & 0x7FFFu) - q0) & 63, 64);
+                if (e & FH_LK_CHOICE) e = t2;
             }
             if (q < nch) E[q] = (uint16_t)e;
         }
     }
-    // ---- B: the walk ------------------------------------------------------------------------------------------------------------
+    // The ops a kept op's operands really come from (its link in l).  The three E entries it may need - its own choice's (a reg,imm
+    // choice that became its immediate has no operands), its operands' producers' when those are choices - are loaded together.
+    auto resolve = [&](uint2 l, bool& has_a, bool& has_b, bool& imm, uint32_t& ta, uint32_t& tb) {
+        const uint32_t kind = (l.x >> 8) & 0xFFu, fa = l.y & 0xFFFFu, fb = l.y >> 16;
+        const uint32_t e_own = E[kind == FH_LK_CRI ? (l.x >> 16) : 0u];
+        const uint32_t e_a = E[(fa & FH_LK_CHOICE) ? (fa & 0x7FFFu) : 0u], e_b = E[(fb & FH_LK_CHOICE) ? (fb & 0x7FFFu) : 0u];
+        imm = kind == FH_LK_CRI && (e_own & FH_LK_IMM) != 0;
+        has_a = !imm && kind != FH_LK_NONE;
+        has_b = !imm && (kind == FH_LK_RR || kind == FH_LK_CRR);
+        ta = (fa & FH_LK_CHOICE) ? (e_a & 0x3FFFu) : fa;
+        tb = (fb & FH_LK_CHOICE) ? (e_b & 0x3FFFu) : fb;
+    };
+
+    const uint64_t t_b1 = probe ? clock64() : 0;
+    // ---- B1: liveness -----------------------------------------------------------------------------------------------------------
+    for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
+    for (uint32_t b = nw; b-- > 0;) {
+        const uint32_t i = (b << 6) | lane;
+        const uint2 l = i < n ? lks[i] : make_uint2(FH_LK_NONE << 8, 0xFFFFFFFFu);      // (read beside the mask word: one wait for both)
+        uint64_t word = rfl64(mask[b]);
+        if (word == 0) continue;
+        bool has_a, has_b, imm;
+        uint32_t ta, tb;
+        resolve(l, has_a, has_b, imm, ta, tb);
+        uint64_t done = 0;
+        for (;;) {
+            const uint64_t newly = word & ~done;
+            if (newly == 0) break;
+            const bool my = (newly >> lane) & 1;
+            if (my && has_a) atomicOr((unsigned long long*)&mask[ta >> 6], 1ull << (ta & 63));
+            if (my && has_b) atomicOr((unsigned long long*)&mask[tb >> 6], 1ull << (tb & 63));
+            done |= newly;
+            // a producer inside this batch: one more round (otherwise nothing else can mark this batch any more)
+            if (__ballot(my && ((has_a && (ta >> 6) == b) || (has_b && (tb >> 6) == b))) == 0) break;
+            word = rfl64(mask[b]);
+        }
+    }
+    const uint64_t t_b2 = probe ? clock64() : 0;
+    // ---- B2: positions, operand positions, last uses ----------------------------------------------------------------------------
+    uint32_t m;
+    {
+        const uint32_t c0 = lane < nw ? (uint32_t)__popcll(mask[lane]) : 0u, c1 = lane + 64 < nw ? (uint32_t)__popcll(mask[lane + 64]) : 0u;
+        uint32_t t0, t1;
+        const uint32_t e0 = excl_sum(c0, lane, t0), e1 = excl_sum(c1, lane, t1);
+        pref[lane] = (uint16_t)e0; pref[lane + 64] = (uint16_t)(t0 + e1);
+        m = rfl(t0 + t1);
+    }
+    if (m > FH_P2_MAX_KEPT) { if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32); return; }          // (left marked: the scalar sweep launched behind this kernel takes it)
+    for (uint32_t k = lane; k < m; k += 64) { lastuse[k] = 0; ((uint16_t*)frees)[k] = 0xFFFFu; }
+    auto pos_of = [&](uint32_t t) -> uint32_t { return (uint32_t)pref[t >> 6] + (uint32_t)__popcll(mask[t >> 6] & ((1ull << (t & 63)) - 1)); };
+    for (uint32_t b = 0; b < nw; b++) {
+        const uint64_t word = rfl64(mask[b]);
+        if (word == 0) continue;
+        if ((word >> lane) & 1) {
+            const uint32_t i = (b << 6) | lane;
+            const uint32_t p = (uint32_t)pref[b] + (uint32_t)__popcll(word & ((1ull << lane) - 1));
+            const uint2 l = lks[i];
+            bool has_a, has_b, imm;
+            uint32_t ta, tb;
+            resolve(l, has_a, has_b, imm, ta, tb);
+            const uint32_t kind = (l.x >> 8) & 0xFFu;
+            uint32_t pa = 0, pb = 0;
+            if (has_a) { pa = pos_of(ta); atomicMax(&lastuse[pa], p); }
+            if (has_b) { pb = pos_of(tb); atomicMax(&lastuse[pb], p); }
+            // flags: 0 has a, 1 has b, 2 became its immediate, 3 a kept choice, 4 the OUTPUT op
+            const uint32_t flags = (has_a ? 1u : 0u) | (has_b ? 2u : 0u) | (imm ? 4u : 0u) | ((kind >= FH_LK_CRR && !imm) ? 8u : 0u) | (kind == FH_LK_OUT ? 16u : 0u);
+            comp[p] = make_uint2(pa | (pb << 16), i | (flags << 16));
+        }
+    }
+    const uint64_t t_b3 = probe ? clock64() : 0;
+    // ---- B3: registers, in tape order over the kept ops -----------------------------------------------------------------------------
+    // Linear scan with the look-ups taken out of the loop: a value's register is not looked up when an op reads it (that is
+    // done for all ops at once afterwards) - what the sequential step needs is only WHEN registers come back.  A value knows its
+    // last use u from B2 and which operand of op u it is; when it gets its register r, "free r" is posted to time u (slot a or b
+    // of frees[u]; for a time inside the current 64-op batch: into the batch's VGPR copy).  Op t then returns the registers posted
+    // to it, takes the lowest free one for its own value and posts that.  ~30 scalar / cross-lane instructions per kept op, no
+    // memory wait.  Registers 0 .. 63 only: a child that wants more is left to the scalar sweep.
+    uint64_t pool = ~0ull;
+    uint32_t overflow = 0;
+    for (uint32_t base = 0; base < m; base += 64) {
+        const uint32_t pl = base + lane;
+        uint32_t vd = 16u << 24, vfr = 0xFFFFu;         // (lanes past the end: an OUTPUT-like no-op)
+        if (pl < m) {
+            const uint32_t u = lastuse[pl];                               // last use of this op's value (0 for the OUTPUT op)
+            const uint32_t slot = u ? ((comp[u].x & 0xFFFFu) == pl ? 0u : 1u) : 0u;
+            vd = u | (slot << 16) | ((comp[pl].y >> 16) << 24);           // ... which operand of that op it is, this op's flags
+            vfr = ((const uint16_t*)frees)[pl];                          // registers posted to this time by earlier batches (a | b << 8, 0xFF none)
+        }
+        const uint32_t cnt = min(64u, m - base);
+        uint32_t outv = 0;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t fr = rdl(vfr, k), d = rdl(vd, k), fl = d >> 24;
+            const uint32_t fa = fr & 0xFFu, fb = (fr >> 8) & 0xFFu;
+            pool |= (fa < 64u ? 1ull << fa : 0ull) | (fb < 64u ? 1ull << fb : 0ull);
+            uint32_t ro = 0;
+            if (!(fl & 16u)) {
+                overflow |= pool ? 0u : 1u;
+                ro = pool ? (uint32_t)__builtin_ctzll(pool) : 0u;
+                pool &= pool - 1;
+                const uint32_t u = d & 0xFFFFu, sl1 = (d >> 16) & 1u, sh = sl1 * 8u;
+                if ((u >> 6) == (base >> 6)) {       // it dies inside this batch: into the batch's copy
+                    const uint32_t old = rdl(vfr, u & 63u);
+                    vfr = wlane((old & ~(0xFFu << sh)) | (ro << sh), u & 63u, vfr);
+                } else if (lane == 0) frees[u * 2u + sl1] = (uint8_t)ro;
+            }
+            outv = wlane(ro, k, outv);
+        }
+        if (pl < m) regb[pl] = (uint8_t)outv;
+    }
+    if (overflow) { if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); } return; }          // more than 64 registers: left marked for the scalar sweep
+    // ---- B4: the child's ops, 64 at a time ----------------------------------------------------------------------------------------------
     const uint32_t end = rfl(sl.c_off[c]);        // one past the child's last op (arena index)
-    uint64_t* const dst = S->arena;
-    uint64_t pool0 = ~0ull, pool1 = ~0ull, pool2 = ~0ull, pool3 = ~0ull;    // free new registers, 1 = free (lowest first)
-    uint32_t high = 0, count = 0, kept = 0, overflow = 0;
-    auto take = [&]() -> uint32_t {
-        const bool a = pool0 != 0, b = pool1 != 0, cc = pool2 != 0;
-        const uint64_t p = a ? pool0 : (b ? pool1 : (cc ? pool2 : pool3));
-        const uint32_t base = a ? 0u : (b ? 64u : (cc ? 128u : 192u));
-        const uint32_t r = base + (p ? (uint32_t)__builtin_ctzll(p) : 63u);
-        const uint64_t q = p & (p - 1);
-        pool0 = a ? q : pool0; pool1 = (!a && b) ? q : pool1; pool2 = (!a && !b && cc) ? q : pool2; pool3 = (!a && !b && !cc) ? q : pool3;
-        overflow |= (r >= 255u) ? 1u : 0u;        // (255 = "none" in the map; a child of a <= 128-register parent never gets there)
-        high = max(high, r + 1);
-        return r;
-    };
-    auto give = [&](uint32_t r) {
-        const uint64_t b = 1ull << (r & 63);
-        const uint32_t w = r >> 6;
-        pool0 |= w == 0 ? b : 0ull; pool1 |= w == 1 ? b : 0ull; pool2 |= w == 2 ? b : 0ull; pool3 |= w == 3 ? b : 0ull;
-    };
-    // the wanted-op mask: `s0` / `s1` say which of its words are non-zero, (cw, cb) is the word being walked (bits at and above
-    // the last visit cleared).  Marks always go to lower ops than the one being visited.  (Written without branches between
-    // the words: the optimiser otherwise turns them into one indexed update of a stack array.)
-    uint64_t s0 = 0, s1 = 0;
-    uint32_t cw = (n - 1) >> 6;
-    uint64_t cb = 1ull << ((n - 1) & 63);       // the OUTPUT op, the last of the tape
-    auto mark = [&](uint32_t t) {
-        const uint32_t w = t >> 6;
-        const uint64_t b = 1ull << (t & 63), sb = 1ull << (w & 63);
-        const bool same = w == cw;
-        cb |= same ? b : 0ull;
-        s0 |= (!same && w < 64) ? sb : 0ull;
-        s1 |= (!same && w >= 64) ? sb : 0ull;
-        if (!same && lane == 0) atomicOr((unsigned long long*)&mask[w], (unsigned long long)b);
-    };
-    // the op an operand field stands for
-    auto eff = [&](uint32_t f) -> uint32_t { return (f & FH_LK_CHOICE) ? (uint32_t)rfl((uint32_t)E[f & 0x7FFFu]) & 0x3FFFu : f; };
-    // register of the value op `p` produces, given one (and the op marked wanted) at its last use = first visit
-    auto use = [&](uint32_t p) -> uint32_t {
-        uint32_t m = rfl((uint32_t)map[p]);
-        if (m == 0xFFu) {
-            m = take();
-            if (lane == 0) map[p] = (uint8_t)m;
-            mark(p);
-        }
-        return m;
-    };
-    for (;;) {
-        if (cb == 0) {      // the next lower word with a wanted op
-            const uint64_t m1 = cw >= 64 ? s1 & ((1ull << (cw & 63)) - 1) : 0ull;
-            const uint64_t m0 = cw >= 64 ? s0 : s0 & ((1ull << (cw & 63)) - 1);
-            if ((m0 | m1) == 0) break;
-            cw = m1 ? 127u - (uint32_t)__builtin_clzll(m1) : 63u - (uint32_t)__builtin_clzll(m0);
-            cb = rfl64(mask[cw]);
-            continue;
-        }
-        const uint32_t bit = 63u - (uint32_t)__builtin_clzll(cb);
-        cb &= ~(1ull << bit);
-        const uint32_t i = (cw << 6) | bit;
-        const uint4 r = recs[i];
-        const uint32_t hdr = rfl(r.x), pf = rfl(r.y), w1 = rfl(r.z);
-        const uint32_t op = hdr & 0xFFu, kind = (hdr >> 8) & 0xFFu;
-        if (kind == FH_LK_OUT) {
-            const uint32_t na = use(eff(pf & 0xFFFFu));
-            count++;
-            if (lane == 0) dst[end - count] = fh_pack(op, 0, na, 0, w1);
-            continue;
-        }
-        const uint32_t no = rfl((uint32_t)map[i]);
-        give(no);
-        bool imm = false;
-        if (kind >= FH_LK_CRR) imm = (rfl((uint32_t)E[hdr >> 16]) & FH_LK_IMM) != 0;
+    uint64_t* const dst = S->arena + (end - m);
+    uint32_t high = 0, kept = 0;
+    for (uint32_t pl = lane; pl < m; pl += 64) {
+        const uint2 cr = comp[pl];
+        const uint32_t fl = cr.y >> 16;
+        const uint2 opw = ops[cr.y & 0xFFFFu];
+        const uint32_t ro = regb[pl], ra = (fl & 1u) ? regb[cr.x & 0xFFFFu] : 0u, rb = (fl & 2u) ? regb[cr.x >> 16] : 0u;
         uint64_t word;
-        if (imm) word = fh_pack(FH_COPY_IMM, no, 0, 0, w1);
-        else {
-            uint32_t na = 0, nb = w1;
-            if (kind != FH_LK_NONE) na = use(eff(pf & 0xFFFFu));
-            if (kind == FH_LK_RR || kind == FH_LK_CRR) nb = use(eff(pf >> 16));
-            kept += kind >= FH_LK_CRR ? 1u : 0u;
-            word = (uint64_t)(op | (no << 8) | (na << 20)) | ((uint64_t)nb << 32);
-        }
-        count++;
-        if (lane == 0) dst[end - count] = word;
+        if (fl & 4u) word = fh_pack(FH_COPY_IMM, ro, 0, 0, opw.y);
+        else if (fl & 16u) word = fh_pack(FH_OUTPUT, 0, ra, 0, opw.y);
+        else word = (uint64_t)((opw.x & 0xFFu) | (ro << 8) | (ra << 20)) | ((uint64_t)((fl & 2u) ? rb : opw.y) << 32);
+        dst[pl] = word;
+        high = max(high, (fl & 16u) ? 0u : ro + 1u);
+        kept += (fl >> 3) & 1u;
     }
-    if (overflow) {     // more than 255 registers: the child keeps the parent tape (what the arena-overflow path does too)
-        if (lane == 0) { sl.c_off[c] = off; sl.c_len[c] = n; sl.c_rc[c] = (uint32_t)sl.tape.n_regs | ((uint32_t)sl.tape.n_choices << 16); }
-        return;
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) { high = max(high, (uint32_t)__shfl_xor(high, dlt, 64)); kept += (uint32_t)__shfl_xor(kept, dlt, 64); }
+    if (probe && lane == 0) {
+        const uint64_t t_e = clock64();
+        atomicMax(&S->leaf_stat[4], (unsigned long long)(t_b1 - t_a)); atomicMax(&S->leaf_stat[5], (unsigned long long)(t_b2 - t_b1));
+        atomicMax(&S->leaf_stat[6], (unsigned long long)(t_b3 - t_b2)); atomicMax(&S->leaf_stat[7], (unsigned long long)(t_e - t_b3));
     }
-    const uint32_t start = end - count;
-    if (lane == 0) { sl.c_off[c] = start; sl.c_len[c] = count; sl.c_rc[c] = high | (kept << 16); }
+    if (lane == 0) { sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = high | (kept << 16); }
     (void)emit_links;
 }

@@ -1,7 +1,7 @@
 """The linked prune (fidget_amd/csrc/prune2.hip k_prune2: one wave per child of the root level, visiting only the ops the
 child keeps, through the per-op links of host_graph.hpp compute_links) - VmData::simplify (fidget-core/src/vm/data.rs:123-318)
-restricted to the live part of the tape's dependency graph.  An option (prune2 = 1): on prospero.vm's root level it is slower than
-the assembly sweep it was written to replace (profiles/r03c), so the default stays fh_prune1.  Its tapes differ from the scalar sweep's (fh_prune1) in register
+restricted to the live part of the tape's dependency graph.  Option prune2 (on by default; the assembly sweep fh_prune1 runs
+behind it for the children it leaves marked, and alone with prune2 = 0).  Its tapes differ from the scalar sweep's (fh_prune1) in register
 numbers and in the copies that sweep inserts; what must hold is what simplify promises: on its tile, a child tape computes the
 parent tape's value, bit for bit - and the frames are the same images."""
 import os
@@ -81,7 +81,8 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
     info = np.zeros(4, np.uint32)
     if F.lib().fhip_tape_term_plan(s._h, F._p(info)) == 0:
         pytest.skip("this tape is not split at its root (no term plan): the root level takes the other path")
-    img_a, a = _children(hip, s, size)
+    with hip.options(prune2=0):
+        img_a, a = _children(hip, s, size)           # the scalar sweep alone
     with hip.options(prune2=1):
         img_b, b = _children(hip, s, size)
     assert (img_a["depth"] == img_b["depth"]).all() and (img_a["normal"].view(np.uint32) == img_b["normal"].view(np.uint32)).all()
@@ -92,14 +93,19 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
     F.lib().fhip_screen_to_world(F._p(np.array([size, size, size], np.uint32)), 3, F._p(mat))      # voxel -> model (identity camera)
     mat = mat.reshape(4, 4).astype(np.float64)
     rng = np.random.default_rng(7)
-    shorter = 0
+    shorter = fallback = 0
     for k in sorted(b)[:: max(1, len(b) // 40)]:            # a sample of the children (each costs two passes over the root tape in numpy)
         tape, regs, choices = b[k]
-        assert len(tape) <= len(a[k][0])                   # never longer than the scalar sweep's (which inserts copies)
-        shorter += len(tape) < len(a[k][0])
-        assert len(tape) < len(root) // 2 and regs <= 128
         outs = (tape.astype(np.uint64) >> np.uint64(8)) & np.uint64(0xFFF)
-        assert int(outs.max()) < regs and int((tape & np.uint64(0xFF)).tolist().count(2)) == 0      # registers in range, no COPY_REG
+        assert int(outs.max()) < regs
+        if regs > 64 or len(tape) > 1536:
+            # beyond the linked prune's limits: left to the scalar sweep launched behind it - its tape, word for word
+            assert tape.tobytes() == a[k][0].tobytes()
+            fallback += 1
+        else:
+            assert len(tape) <= len(a[k][0])                   # never longer than the scalar sweep's (which inserts copies)
+            shorter += len(tape) < len(a[k][0])
+            assert int((tape & np.uint64(0xFF)).tolist().count(2)) == 0      # no COPY_REG
         m = 256
         vox = np.stack([np.float64(k[ax]) + rng.random(m) * 128.0 for ax in range(3)] + [np.ones(m)])      # points of the tile, in voxels
         pts = (mat @ vox)[:3].astype(np.float32)
@@ -107,4 +113,5 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
         want = U.ref_f32(root, inputs, m)
         got = U.ref_f32(tape, inputs, m)
         assert (want[0].view(np.uint32) == got[0].view(np.uint32)).all(), f"child {k}: values differ from the root tape's"
-    print("children shorter than the scalar sweep's:", shorter)
+    print("children shorter than the scalar sweep's:", shorter, "left to the scalar sweep:", fallback)
+    assert fallback < len(b) or size < 1024
