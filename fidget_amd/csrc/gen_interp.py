@@ -28,8 +28,8 @@ beside it for free.  So the decode exists in eight copies, one per slot of the t
 batches the tape comes in by (no queue shifting, no counters; a handler ends with a jump to the
 next copy), the handler table has an "in place" half that the decode selects when out == a, and
 the leaf kernel, whose tapes are short, takes a whole tape of up to 64 ops with ONE vector load,
-lane = op, decodes it with vector code into four VGPRs (handler address, file indices of out and
-a, word 1) and dispatches with four v_readlane and a jump.  Shape tapes have one output and it is
+lane = op, decodes it with vector code into three VGPRs (handler address, file indices of out and
+a in one, word 1) and dispatches with three v_readlane and a jump.  Shape tapes have one output and it is
 their last op: the OUTPUT handler of the leaf kernel returns to the caller, nothing is counted.
 
 Tape format: tape_format.h (8 bytes per op: opcode | out<<8 | a<<20, then b / imm / slot).
@@ -109,7 +109,7 @@ S_OUTP = "s[32:33]"     # bulk
 # ---- fixed VGPRs (ZB <= 8) ------------------------------------------------------------------
 V_LANE = "v0"
 V_PXF, V_PYF = "v1", "v6"
-V_PIX = "v[2:3]"
+V_PIX = "v2"                # byte offset of this lane's pixel in the z-buffer
 V_HIT, V_DEPTH = "v4", "v5"     # stored together as the 64-bit z-buffer word
 V_IDS = "v54"            # (= V_ENT[0])
 V_AX, V_AY, V_AZ = "v8", "v9", "v59"
@@ -309,8 +309,36 @@ class Interp:
 	v_div_fixup_f32 {R[j]}, {d[0]}, {b}, {a}""")
 
     def f_sqrt(self, A, R):
-        # correctly rounded sqrtf: scale denormals, v_sqrt_f32, one ulp fix-up either way
+        # correctly rounded sqrtf: v_sqrt_f32 (1 ulp), then one ulp either way by the sign of the exact residuals.  Arguments
+        # below 2^-96 (denormal results of the residuals), zeros and negative ones take the full sequence (scaled by 2^32, the
+        # result by 2^-16, zeros / +inf passed through); when no sample of the op is one of those - the smallest sample is
+        # tested - 9 instructions per sample do, with the same result: nothing is scaled, and +inf / NaN come out of the
+        # residuals' NaN compares unchanged.
         d = VD
+        slow, done = self.a.label("sqrt_small"), self.a.label("sqrt_done")
+        t = d[6]
+        if self.zb == 8:
+            self.a(f"\tv_min3_f32 {t}, {A[0]}, {A[1]}, {A[2]}\n\tv_min3_f32 {t}, {t}, {A[3]}, {A[4]}\n\tv_min3_f32 {t}, {t}, {A[5]}, {A[6]}\n\tv_min_f32 {t}, {t}, {A[7]}")
+        elif self.zb == 4:
+            self.a(f"\tv_min3_f32 {t}, {A[0]}, {A[1]}, {A[2]}\n\tv_min_f32 {t}, {t}, {A[3]}")
+        else:
+            self.a(f"\tv_min_f32 {t}, {A[0]}, {A[1]}")
+        self.a(f"\tv_cmp_gt_f32 vcc, {V_SQRTC}, {t}\n\ts_cbranch_vccnz {slow}")
+        for j in range(self.zb):
+            a = A[j]
+            self.a(f"""
+	v_sqrt_f32 {d[0]}, {a}
+	s_nop 0
+	v_add_u32 {d[2]}, -1, {d[0]}
+	v_add_u32 {d[3]}, 1, {d[0]}
+	v_fma_f32 {d[4]}, -{d[2]}, {d[0]}, {a}
+	v_fma_f32 {d[5]}, -{d[3]}, {d[0]}, {a}
+	v_cmp_ge_f32_e64 {S_M[0]}, 0, {d[4]}
+	v_cmp_lt_f32_e64 {S_M[1]}, 0, {d[5]}
+	s_nop 0
+	v_cndmask_b32_e64 {d[0]}, {d[0]}, {d[2]}, {S_M[0]}
+	v_cndmask_b32_e64 {R[j]}, {d[0]}, {d[3]}, {S_M[1]}""")
+        self.a(f"\ts_branch {done}\n{slow}:")
         for j in range(self.zb):
             a = A[j]
             self.a(f"""
@@ -336,6 +364,7 @@ class Interp:
 	v_cmp_class_f32 vcc, {d[1]}, {d[3]}
 	s_nop 1
 	v_cndmask_b32 {R[j]}, {d[0]}, {d[1]}, vcc""")
+        self.a(f"{done}:")
 
     def f_round(self, A, R):
         # roundf: half away from zero
@@ -488,8 +517,35 @@ class Interp:
             # place.  a < b ? a : b written as !(a < b) ? b : a so that `a`, the relative operand, stays SRC0.
             ncmp = "v_cmp_nlt_f32_e64" if base == "MIN" else "v_cmp_ngt_f32_e64"
             def body(ncmp=ncmp):
+                # !(a < b) ? b : a alone is right unless a is a NaN and b is not (it then takes b): the samples of a are summed
+                # first - a NaN among them makes the sum one (so may an inf - inf: that only costs the long way round) - and
+                # the two tests and two selects per sample (dev_ops.hpp f_min / f_max to the letter) are left to that case.
+                slow = a.label("mm_nan")
                 self.read_b(VU, already_on=False)
+                self.idx_idx(S_A)                   # (mode still SRC0 | SRC1: both operands a's samples, plain destination)
+                if zb >= 4:
+                    for k in range(zb // 4):
+                        a(f"\tv_pk_add_f32 {self.P(VW, k)}, {self.FP(2 * k)}, {self.FP(2 * k + 1)}")
+                    self.idx_off()
+                    if zb == 8:
+                        a(f"\tv_pk_add_f32 {self.P(VW, 0)}, {self.P(VW, 0)}, {self.P(VW, 1)}")
+                    a(f"\tv_add_f32 {VW[0]}, {VW[0]}, {VW[1]}")
+                else:
+                    a(f"\tv_add_f32 {VW[0]}, {F(0)}, {F(1)}")
+                    self.idx_off()
+                a(f"\tv_cmp_u_f32 vcc, {VW[0]}, {VW[0]}")
                 self.idx_on(S_A, SRC0 | DST)
+                a(f"\ts_cbranch_vccnz {slow}")
+                for g in range(0, zb, 4):
+                    js = list(range(g, min(g + 4, zb)))
+                    for j in js:
+                        a(f"\t{ncmp} {S_M[j % 4]}, {F(j)}, {VU[j]}")
+                    if len(js) < 3:
+                        a(f"\ts_nop {2 - len(js)}")
+                    for j in js:
+                        a(f"\tv_cndmask_b32_e64 {F(j)}, {F(j)}, {VU[j]}, {S_M[j % 4]}")
+                self.ret()
+                a(f"{slow}:")
                 for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
                     for q in (0, 1):
                         a(f"\t{ncmp} {S_M[2 * q]}, {F(j + q)}, {VU[j + q]}")
@@ -707,9 +763,9 @@ class Interp:
 	s_set_gpr_idx_off                               ; (the handlers leave their index mode on)
 	v_readlane_b32 s44, {V_DEC[0]}, {S_LEN}
 	v_readlane_b32 {S_OUT}, {V_DEC[1]}, {S_LEN}
-	v_readlane_b32 {S_A}, {V_DEC[2]}, {S_LEN}
 	v_readlane_b32 {S_W1}, {V_DEC[3]}, {S_LEN}
 	s_add_u32 {S_LEN}, {S_LEN}, 1
+	s_lshr_b32 {S_A}, {S_OUT}, 8
 	s_setpc_b64 {S_JMP}""")
         a(f"""
 .L{n}_done:
@@ -999,19 +1055,14 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	v_cvt_f32_u32 {V_PYF}, {V_S1}
 	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_S0}
 	v_cmp_gt_u32_e64 {S_M[1]}, {S_HEIGHT}, {V_S1}
-	v_mul_lo_u32 {V_S2}, {V_S1}, {S_WIDTH}
-	v_add_u32 {V_S2}, {V_S2}, {V_S0}
-	v_mov_b32 {V_S3}, 0
-	v_lshlrev_b64 {V_PIX}, 3, v[{V_S2[1:]}:{V_S3[1:]}]
-	v_mov_b32 {V_S3}, s37
-	v_add_co_u32 v2, vcc, s36, v2
-	v_addc_co_u32 v3, vcc, {V_S3}, v3, vcc
+	v_mul_u32_u24 {V_S2}, {V_S1}, {S_WIDTH}                 ; (y, width < 2^24; the z-buffer is addressed as base + 32-bit byte offset)
+	v_add_lshl_u32 {V_PIX}, {V_S2}, {V_S0}, 3
 	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
 	v_mov_b32 {V_DEPTH}, -1                         ; pixels outside the image never become pending
 	v_mov_b32 {V_HIT}, 0
 	s_mov_b64 {S_SAVE}, exec
 	s_mov_b64 exec, {S_M[0]}
-	global_load_dword {V_DEPTH}, {V_PIX}, off offset:4
+	global_load_dword {V_DEPTH}, {V_PIX}, {S_ZBUF} offset:4
 	s_mov_b64 exec, {S_SAVE}
 	; the next leaf of the block: its tape (if it is one of up to 64 ops for this kernel) is requested now, behind this
 	; leaf's own loads, and arrives while this leaf is interpreted
@@ -1115,14 +1166,12 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	v_cndmask_b32 v22, 0, v22, vcc
 	v_lshlrev_b32 v61, {it.lg}, v19
 	v_lshl_or_b32 v22, v22, 6, v18
-	v_lshlrev_b32 v62, {it.lg}, v20
+	v_lshl_or_b32 v61, v20, {it.lg + 8}, v61          ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
 	v_lshlrev_b32 v22, {it.hl}, v22
 	v_add_u32 v60, s42, v22
 .L{name}_pass:""")
-        for j in range(zb):
-            a(f"\tv_mov_b32 {VRES[j]}, 0")
         a(f"""
-	s_mov_b64 {S_TAPE}, {S_TBASE}""")
+	s_mov_b64 {S_TAPE}, {S_TBASE}""")           # (VRES needs no initial value: a shape tape ends with its OUTPUT op, whose handler fills it)
         ret, here = a.label("ret"), a.label("pc")
         a(f"""
 	s_getpc_b64 {S_RET}
@@ -1172,7 +1221,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	; z-buffer word = max(word, depth << 32 | leaf) for the lanes that were hit
 	v_cmp_ne_u32 vcc, 0, {V_HIT}
 	s_and_saveexec_b64 {S_SAVE}, vcc
-	global_atomic_umax_x2 {V_PIX}, v[4:5], off
+	global_atomic_umax_x2 {V_PIX}, v[4:5], {S_ZBUF}
 	s_mov_b64 exec, {S_SAVE}
 .Lfh_columns_leaf_drain:
 	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight

@@ -337,3 +337,36 @@ def test_render3d_partly_column_invariant_shapes(kind, monkeypatch):
             assert (a["depth"] == ref["depth"]).all(), f"kind {kind} {whd} {var}: {(a['depth'] != ref['depth']).sum()} depths differ"
             same = (a["normal"] == ref["normal"]) | (np.isnan(a["normal"]) & np.isnan(ref["normal"]))
             assert same.all(), f"kind {kind} {whd} {var}: {(~same).any(axis=2).sum()} normals differ"
+
+
+@pytest.mark.gpu
+def test_bulk_sqrt_min_max_bit_exact_over_the_float_range():
+    """The assembly interpreters' sqrt (a short sequence, or the scaled one when a sample of the op is tiny, zero or negative) and
+    their in-place min / max (one test and one select per sample unless a's samples sum to a NaN) through fhip_float_eval on
+    4 M inputs covering every exponent, both signs, the denormals, zeros, infinities and NaNs: sqrtf is correctly rounded
+    (numpy's is), min / max are dev_ops.hpp f_min / f_max - bit for bit, NaN for NaN (vm/mod.rs:885-896, 1004-1037)."""
+    import fidget_amd as F
+    hip = F.default_context()
+    ctx = F.Context()
+    x, y = ctx.x(), ctx.y()
+    n = 1 << 22
+    rng = np.random.default_rng(11)
+    xs = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    xs[: 1 << 16] = (np.arange(1 << 16, dtype=np.uint32) << 16) | 0x8001            # every sign / exponent / top mantissa pattern
+    xs[1 << 16: (1 << 16) + 8] = [0, 0x80000000, 0x7F800000, 0xFF800000, 0x7FC00000, 1, 0x007FFFFF, 0x00800000]
+    ys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    ys[::7] = xs[::7]                                                                # equal operands, among them +0 / -0 pairs
+    ys[3::1001] = 0x7FC00000
+    xf, yf = xs.view(np.float32), ys.view(np.float32)
+    zero = np.zeros(n, np.float32)
+    with np.errstate(all="ignore"):
+        for name, node, want in (
+            ("sqrt", ctx.sqrt(x), np.sqrt(xf)),
+            ("sqrt|x|", ctx.sqrt(ctx.abs(x)), np.sqrt(np.abs(xf))),                  # no negative sample: mostly the short sequence
+            ("min", ctx.min(x, y), np.where(xf < yf, xf, np.where(yf < xf, yf, np.where(np.isnan(xf) | np.isnan(yf), np.float32(np.nan), yf)))),
+            ("max", ctx.max(x, y), np.where(xf > yf, xf, np.where(yf > xf, yf, np.where(np.isnan(xf) | np.isnan(yf), np.float32(np.nan), yf)))),
+        ):
+            s = F.Shape(ctx, node, hip=hip)
+            got = np.asarray(s.eval_float_slice(xf, yf, zero), np.float32)
+            ok = (got.view(np.uint32) == want.astype(np.float32).view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), f"{name}: {(~ok).sum()} of {n} differ, first at input {hex(int(xs[np.nonzero(~ok)[0][0]]))}"

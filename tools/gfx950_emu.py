@@ -1155,6 +1155,11 @@ class Wave:
         r = np.where(z, np.where(np.signbit(x) & np.signbit(y), F32(-0.0), F32(0.0)), r)
         return r.astype(F32)
 
+    def i_v_min3_f32(self, i, d, a, b, c):
+        self.count("valu")
+        x, y, z = self.fsrc(a, 0), self.fsrc(b, 1), self.fsrc(c, 2)
+        self.vdst(d, self._fmin(self._fmin(x, y), z))
+
     def i_v_min_f32(self, i, d, a, b):
         self._v2(i, d, a, b, self._fmin, "f")
 
