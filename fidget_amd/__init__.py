@@ -256,7 +256,8 @@ class HipContext:
         ms = np.zeros(8, np.float64)
         n = np.zeros(8, np.uint32)
         self.check(lib().fhip_profile_read_kernels(self._h, _p(ms), _p(n)))
-        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_tiles_v32", "fh_tiles_v64"]
+        # (fh_prune1: the root level's prune, i.e. k_prune2 with the scalar sweep behind it when option prune2 is on; k_prune2_l1: level 1's)
+        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_tiles_v32", "fh_tiles_v64", "k_prune2_l1"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def counters(self):

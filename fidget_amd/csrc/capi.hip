@@ -89,7 +89,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -117,6 +117,7 @@ static void options_from_env(FhOptions& o) {
 struct FrameBufs {
     DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch;
     DevBuf queue[FH_MAX_LEVELS];
+    uint32_t frame_stamp = 0;       // FhRenderState::frame_stamp of the last frame prepared
     uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
     uint32_t resident_groups = 0;
     uint32_t forked = 0;            // slab contexts of the last 3D frame of this set (0: not pipelined)
@@ -751,6 +752,10 @@ struct RenderSetup {
     const uint64_t* d_links = nullptr;
     const uint64_t* d_ctab = nullptr;
     size_t lds_prune2 = 0;
+    bool prune2_l1 = false;   // ... and level 1 by the same kernel, on the links the level-0 launch leaves in front of every child tape (option
+                              // prune2_l1, off: fh_tiles_v64's forward pass alone takes 0.13 ms of its 0.39, but one wave per 32^3 child - 6 120 of them,
+                              // 2 to a SIMD, each bound by scalar issue - takes 0.75 ms where the lockstep sweep takes 0.26; profiles/r03o)
+    size_t lds_prune2_l1 = 0;
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
@@ -890,6 +895,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
 
     // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
     S.n_slabs = R.n_slabs;
+    S.frame_stamp = ++ctx->frame_stamp;
     S.pre_levels = prepass_ok ? 2 : 0;
 
     // root-tile layers of this part: layer k of the block split belongs to iz = k * nz / n_layers (iz = nz - 1: the front);
@@ -1042,6 +1048,9 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                        R.lds_prune2 <= FH_LDS_MAX;
             R.d_ctab = tape->d_ctab;
             R.d_links = tape->d_links;
+            R.lds_prune2_l1 = (((size_t)FH_P2_L1_OPS * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_L1_WPB * fh_p2_wave_lds(FH_P2_L1_CHOICES, FH_P2_L1_OPS);
+            R.prune2_l1 = R.prune2 && is3d && S.pre_levels > 1 && ctx->opt.prune2_l1 && !ctx->opt.no_tiles_v && R.exp_levels <= 1 &&
+                          R.lds_prune2_l1 <= FH_LDS_MAX;
             const size_t blocks = qcaps[0];
             HIP_TRY(ctx, ctx->tvals.ensure(blocks * S.n_terms * WAVE * 8));
             HIP_TRY(ctx, ctx->topch.ensure(blocks * S.n_top * WAVE));
@@ -1197,7 +1206,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 0u);
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u), R.S.troot_len, R.S.troot_choices,
+                                   (uint32_t)FH_P2_MAX_KEPT);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or 2048 kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -1271,8 +1281,13 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
                 ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
                 if (both_lists) ka.flags |= 16u;
+                // (level 1 with the linked prune: parents whose tape carries this frame's links get their choices exported - chw[1]
+                // with this stride, chw[0] with 16 words - and their children marked for k_prune2 below; the others are pruned here)
+                const bool linked = R.prune2_l1 && !per_slab;
+                const uint32_t plain_flags = ka.flags;
+                if (linked) ka.flags = (ka.flags & 0xFFFFu) | 2u | (((R.S.P.max_choices + 15) / 16) << 16);
                 (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
-                ka.flags &= ~16u;
+                ka.flags = plain_flags & ~16u;
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
             }
@@ -1291,6 +1306,14 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (side) {
                 (void)hipEventRecord(ctx->ev_rest_join, rest_stream);
                 (void)hipStreamWaitEvent(ctx->stream, ctx->ev_rest_join, 0);
+            }
+            if (R.prune2_l1 && use_v && level > 0 && (uint32_t)level < R.S.pre_levels) {
+                hipEvent_t ea = nullptr, eb = nullptr;      // (slot 7 of the per-kernel profile)
+                if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
+                hipLaunchKernelGGL(k_prune2, dim3(ctx->n_cu * 2), dim3(FH_P2_L1_WPB * 64), R.lds_prune2_l1, ctx->stream, dS, (uint32_t)level, 2u, 0u,
+                                   (R.S.P.max_choices + 15) / 16, (const uint2*)nullptr, (const uint2*)nullptr, ctx->opt.prune2_probe_level == 1 ? 2u : 0u,
+                                   (uint32_t)FH_P2_L1_OPS, (uint32_t)FH_P2_L1_CHOICES, (uint32_t)FH_P2_L1_OPS);
+                if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({7, {ea, eb}}); }
             }
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};

@@ -29,7 +29,8 @@ map ([reg][lane] bytes, LDS as well) costs four more round trips per op: ~340 cy
 
 kernarg: as fh_tiles { FhRenderState* S; u32 level; u32 big; u32 max_regs; u32 max_choices; u32 n_waves; u32 flags;
          u32 skip_regs; u32 skip_choices }: slots whose tape exceeds (max_regs, max_choices) or fits
-         (skip_regs, skip_choices) are left to another launch; flags are ignored (no export / probe modes).
+         (skip_regs, skip_choices) are left to another launch; flags: bit 0 probes, bit 4 both lists, bit 1 (+ bits 31:16) export of
+         the choices of parents that carry links (see the kernel body); the other modes of fh_tiles do not exist here.
 """
 from gen_interp import OPS, UNSUPPORTED, HSTRIDE_LOG2
 import gen_tiles as GT
@@ -842,6 +843,54 @@ class TilesV(Tiles):
 	v_add_u32 {T[0]}, 1, {V_RANK}
 	v_mul_lo_u32 {T[0]}, {T[0]}, {S_LEN}
 	v_add_u32 {V_END}, {S_BASE}, {T[0]}
+	; flags bit 1 (level 1 behind the linked prune of level 0, prune2.hip): a parent whose tape carries this frame's links - the word
+	; in front of [choice table | links | tape] is frame_stamp << 32 | len | choices << 16 - is not pruned here: its choice words go
+	; to chw[list] (16 words per slot in list 0, flags[31:16] in list 1), its ambiguous children are marked (c_len = ~0, c_off = the
+	; end of their arena slot) and k_prune2, launched behind this kernel, writes their tapes - one wave per child instead of the
+	; lockstep sweep over the parent's ops below.
+	s_bitcmp1_b32 s101, 1
+	s_cbranch_scc0 {p}_sweep
+	s_add_u32 {S_T0}, {S_LEN}, {S_NCH}
+	s_add_u32 {S_T0}, {S_T0}, 1
+	s_sub_u32 s76, {S_OFF}, {S_T0}
+	s_cbranch_scc1 {p}_sweep                          ; (the tape starts too low in the arena to have anything in front)
+	s_mov_b32 s77, 0
+	s_lshl_b64 s[76:77], s[76:77], 3
+	s_add_u32 s76, s76, s10
+	s_addc_u32 s77, s77, s11
+	s_load_dwordx2 s[76:77], s[76:77], 0x0
+	s_load_dword {S_T2}, {S_STATE}, {o['frame_stamp']}
+	s_lshl_b32 {S_T1}, {S_NCH}, 16
+	s_or_b32 {S_T1}, {S_T1}, {S_LEN}
+	s_waitcnt lgkmcnt(0)
+	s_cmp_eq_u32 s76, {S_T1}
+	s_cbranch_scc0 {p}_sweep
+	s_cmp_eq_u32 s77, {S_T2}
+	s_cbranch_scc0 {p}_sweep
+	; the choice words: chw[list] + slot index * stride
+	s_bfe_u32 {S_T0}, s70, 0x10001                    ; which list
+	s_lshl_b32 {S_T1}, {S_T0}, 3
+	s_add_u32 s76, s4, {S_T1}
+	s_addc_u32 s77, s5, 0
+	s_load_dwordx2 s[76:77], s[76:77], {o['chw']}
+	s_lshr_b32 {S_T2}, s101, 16
+	s_cmp_eq_u32 {S_T0}, 0
+	s_cselect_b32 {S_T2}, 16, {S_T2}
+	s_lshl_b32 {S_T2}, {S_T2}, 8                      ; bytes per slot
+	s_sub_u32 {S_T3}, {S_SI}, {S_NWG}                 ; this slot's index (the round robin has moved on)
+	s_mul_hi_u32 {S_T1}, {S_T3}, {S_T2}
+	s_mul_i32 {S_T3}, {S_T3}, {S_T2}
+	s_waitcnt lgkmcnt(0)
+	s_add_u32 s76, s76, {S_T3}
+	s_addc_u32 s77, s77, {S_T1}
+""" + "".join(("\ts_add_u32 s76, s76, 0x1000\n\ts_addc_u32 s77, s77, 0\n" if w and w % 16 == 0 else "") +
+              f"\ts_cmp_le_u32 {S_NCH}, {16 * w}\n\ts_cbranch_scc1 {p}_exported\n\tglobal_store_dword {V_L4}, v{self.CHF + w}, s[76:77] offset:{(w % 16) * 256}\n"
+              for w in range(self.ncw)) + f"""{p}_exported:
+	v_mov_b32 {T[1]}, -1
+	v_cndmask_b32_e64 {V_COFF}, {V_COFF}, {V_END}, {S_PRUNE}
+	v_cndmask_b32_e64 {V_CLEN}, {V_CLEN}, {T[1]}, {S_PRUNE}
+	s_branch {p}_store
+{p}_sweep:
 	v_mov_b32 {T[0]}, {V_END}
 	v_mov_b32 {T[1]}, 0
 	v_lshlrev_b64 {V_DST}, 3, v[16:17]
@@ -917,6 +966,7 @@ class TilesV(Tiles):
 	s_and_b32 s70, s70, 0xfffffffe
 	s_bfe_u32 {S_BIG}, s70, 0x10001
 	s_xor_b32 {S_BIG}, {S_BIG}, 1
+	s_xor_b32 s70, s70, 2                            ; (bit 1 stays the list being walked: the export mode reads it)
 	s_lshr_b32 {S_LEVEL}, s70, 8
 	s_mov_b32 {S_SI}, s86
 	s_branch {p}_list

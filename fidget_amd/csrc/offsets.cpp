@@ -12,7 +12,7 @@ int main() {
     O("P.in_kind", P.in_kind); O("P.in_value", P.in_value);
     O("arena", arena); O("leaves", leaves); O("leaf_table", leaf_table); O("slab_z", slab_z); O("zbuf", zbuf);
     O("arena_cap", arena_cap); O("arena_head", arena_head); O("arena_overflow", arena_overflow);
-    O("chw", chw); O("tgroup", tgroup); O("n_tgroups", n_tgroups); O("chwr", chwr); O("slots", slots); O("slot_cap", slot_cap); O("n_slots", n_slots); O("eval_cur", eval_cur);
+    O("chw", chw); O("frame_stamp", frame_stamp); O("tgroup", tgroup); O("n_tgroups", n_tgroups); O("chwr", chwr); O("slots", slots); O("slot_cap", slot_cap); O("n_slots", n_slots); O("eval_cur", eval_cur);
     O("fp_list", fp_list); O("fp_count", fp_count); O("fp_cursor", fp_cursor); O("stat", stat);
     O("count", count); O("count_big", count_big); O("queue", queue); O("qcap", qcap); O("squeue", squeue); O("n_leaves", n_leaves);
     O("leaf_cap", leaf_cap); O("P.depth", P.depth); O("P.n_levels", P.n_levels); O("P.max_regs", P.max_regs);

@@ -27,17 +27,31 @@
 // that passed it on) in register numbers and in those copies; values are those of the parent tape on the child's region, op for
 // op (tests/test_prune2.py evaluates both on points of the tile).
 //
-//   grid   : one wave per child lane of a slot, FH_P2_WPB waves per workgroup: they share the parent's links, staged in LDS
+//   grid   : one wave per child lane of a slot, blockDim / 64 waves per workgroup: they share the parent's links, staged in LDS
 //            (8 B per op: the liveness pass would otherwise wait for a load per batch)
-//   limits : <= 8192 ops, <= 4096 choices in the parent, <= 1536 kept ops and <= 64 registers in the child (more: the child
+//   limits : <= 8192 ops, <= 4096 choices in the parent, <= cap_kept kept ops and <= 64 registers in the child (more: the child
 //            is left to the scalar sweep launched behind this kernel), one OUTPUT op, the last one - capi.hip checks and keeps fh_prune1 otherwise
+//
+// Links for the level below.  A child tape written here is itself the parent tape of the next level, and its links cost little
+// more than the tape: with `emit_links` the child's links, its choice table and a stamp go in front of the tape, inside the
+// child's arena slot (which is as long as the parent tape: [ stamp | choice table kc | links m | tape m ] must fit it):
+//   arena[off - m - kc - 1] = frame stamp << 32 | m | kc << 16,   choice table at off - m - kc,   links at off - m
+// - only for children of at most FH_P2_L1_OPS ops and FH_P2_L1_CHOICES choices, the bounds of the launch that reads them (level
+// 1: mode 0, links == nullptr: a slot's parent qualifies when the stamp in front of its tape is this frame's and says its length
+// and choices; the forward kernel fh_tiles_v64 makes the same test and exports choices for those parents only).  A child of such a
+// parent never needs more registers than the parent (<= 64: the scan is optimal and the child's values are a subset with the same
+// or shorter lives) nor more kept ops than cap_kept = FH_P2_L1_OPS: nothing is left marked at that level.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "render_state.h"
 
-#define FH_P2_WPB 3
-#define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // workgroups per slot (the last one's spare waves idle)
+#define FH_P2_WPB 3                                             // level 0: waves per workgroup
+#define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // ... workgroups per slot (the last one's spare waves idle)
+#define FH_P2_L1_WPB 4                                          // level 1
+#define FH_P2_L1_PER_SLOT (64 / FH_P2_L1_WPB)
+#define FH_P2_L1_OPS 1024u                                      // level 1: parents with links have at most this many ops ...
+#define FH_P2_L1_CHOICES 512u                                   // ... and choices (fh_tiles_v64's own bound)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
 #define FH_P2_MAX_KEPT 1536u
@@ -52,8 +66,8 @@ enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4,
 
 // bytes of LDS per wave: wanted-op mask (128 x 8), position prefixes (128 x 2), E (2 per choice), kept-op records (8 each), last
 // uses (4 each), registers by position (1 each), registers returning at a position (2 each)
-static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices) {
-    return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)FH_P2_MAX_KEPT * (8 + 4 + 1 + 2) + 64;
+static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices, uint32_t cap_kept = FH_P2_MAX_KEPT) {
+    return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)cap_kept * (8 + 4 + 1 + 2) + 64;
 }
 
 namespace fhp2 {
@@ -82,43 +96,55 @@ __device__ __forceinline__ uint32_t excl_sum(uint32_t v, uint32_t lane, uint32_t
 }
 }  // namespace fhp2
 
-// mode 0: slots[big] of `level`, choice words S->chw[big] with `cw_stride` words per slot; mode 2 (tape groups, level 0): slot =
-// block * n_tgroups, choice words S->chwr (k_tscatter3d).  links / ctab: the parent's links when it is the root tape (device
-// copies made with the tape).
-__global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride,
-                                                           const uint2* __restrict__ links, const uint2* __restrict__ ctab, uint32_t emit_links) {
+// mode 2 (tape groups, level 0): slot = block * n_tgroups, choice words S->chwr (k_tscatter3d) with `cw_stride` words per slot, links /
+// ctab: the root tape's (device copies made with the tape).  mode 0 (level 1): slots[big] of `level` (big == 2: both lists, the
+// large one in the first `slots_cap` * per_slot workgroups), choice words S->chw[big] (16 words per slot in list 0, cw_stride
+// in list 1), links == nullptr: every parent's own, in front of its tape (see the head of this file).
+// cap_ops / cap_choices / cap_kept size the LDS areas (links, E, per kept op records).
+// One work item: the (up to) blockDim / 64 children `blk` % per_slot of slot `blk` / per_slot.
+__device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride, const uint2* __restrict__ links,
+                                        const uint2* __restrict__ ctab, uint32_t emit_links, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
+                                        uint32_t blk, char* smem) {
     using namespace fhp2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the sequential step branches on is made wave-uniform explicitly)
-    const uint32_t per_slot = FH_P2_PER_SLOT;
-    const uint32_t sidx = blockIdx.x / per_slot;
+    const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
+    const uint32_t sidx = blk / per_slot;
     const uint32_t G = mode == 2 ? rfl(S->n_tgroups) : 1u;
     if (sidx * G >= rfl(S->n_slots[big][level])) return;
     FhSlot& sl = S->slots[big][(size_t)sidx * G];
     if (sl.act == 0) return;
-    const uint32_t c0 = (blockIdx.x % per_slot) * FH_P2_WPB, c = c0 + wave;      // this wave's child lane
+    const uint32_t c0 = (blk % per_slot) * wpb, c = c0 + wave;      // this wave's child lane
     {   // any of this workgroup's children marked for the prune?  (c_len == ~0: k_tmark3d / the export mode of the forward kernels)
         bool any = false;
-        for (uint32_t k = 0; k < FH_P2_WPB; k++) any |= c0 + k < 64 && sl.c_len[c0 + k] == 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < wpb; k++) any |= c0 + k < 64 && sl.c_len[c0 + k] == 0xFFFFFFFFu;
         if (!any) return;
     }
     const uint32_t off = rfl(sl.tape.off), n = rfl(sl.tape.len), nch = rfl((uint32_t)sl.tape.n_choices);
+    if (n > cap_ops || nch > cap_choices) return;                       // (left marked)
+    if (links == nullptr) {
+        // the parent's own links: stamped by the launch that wrote its tape
+        if (off < n + nch + 1u) return;
+        const uint64_t stamp = S->arena[off - n - nch - 1u];
+        if (stamp != (((uint64_t)S->frame_stamp << 32) | n | (nch << 16))) return;
+        links = (const uint2*)(S->arena + (off - n));
+        ctab = (const uint2*)(S->arena + (off - n - nch));
+    }
     const uint2* const ops = (const uint2*)(S->arena + off);
     uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
-    for (uint32_t i = threadIdx.x; i < n; i += FH_P2_WPB * 64) lks[i] = links[i];
-    char* const mine = smem + (((size_t)n * 8 + 15) & ~(size_t)15) + (size_t)wave * fh_p2_wave_lds(nch);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lks[i] = links[i];
+    char* const mine = smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)wave * fh_p2_wave_lds(cap_choices, cap_kept);
     uint64_t* const mask = (uint64_t*)mine;                               // wanted ops, 64 per word (128 words)
     uint16_t* const pref = (uint16_t*)(mine + 1024);                    // kept ops before each word
     uint16_t* const E = (uint16_t*)(mine + 1280);                       // per choice: the op its value is (| FH_LK_IMM)
-    uint2* const comp = (uint2*)(mine + 1280 + (((size_t)nch * 2 + 15) & ~(size_t)15));       // per kept op: operand positions, op index | flags << 16
-    uint32_t* const lastuse = (uint32_t*)((char*)comp + (size_t)FH_P2_MAX_KEPT * 8);
-    uint8_t* const regb = (uint8_t*)((char*)lastuse + (size_t)FH_P2_MAX_KEPT * 4);
-    uint8_t* const frees = regb + (size_t)FH_P2_MAX_KEPT;                 // registers that return at a time: bytes [2 t], [2 t + 1] (operand a / b of op t; 0xFF none)
+    uint2* const comp = (uint2*)(mine + 1280 + (((size_t)cap_choices * 2 + 15) & ~(size_t)15));       // per kept op: operand positions, op index | flags << 16
+    uint32_t* const lastuse = (uint32_t*)((char*)comp + (size_t)cap_kept * 8);
+    uint8_t* const regb = (uint8_t*)((char*)lastuse + (size_t)cap_kept * 4);
+    uint8_t* const frees = regb + (size_t)cap_kept;                       // registers that return at a time: bytes [2 t], [2 t + 1] (operand a / b of op t; 0xFF none)
     const uint32_t nw = (n + 63) >> 6;
     __syncthreads();
     if (c >= 64 || rfl(sl.c_len[c]) != 0xFFFFFFFFu) return;             // not marked for the prune
 
-    const bool probe = S->want_stats != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
+    const bool probe = S->want_stats != 0 && (emit_links & 2u) != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
     const uint64_t t_a = probe ? clock64() : 0;
     // ---- A: what every choice op's value is -------------------------------------------------------------------------------------
     // 64 ordinals at a time, in tape order: an operand's producer has a lower ordinal, so a pointer out of the batch lands on a
@@ -195,7 +221,7 @@ __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uin
         pref[lane] = (uint16_t)e0; pref[lane + 64] = (uint16_t)(t0 + e1);
         m = rfl(t0 + t1);
     }
-    if (m > FH_P2_MAX_KEPT) { if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32); return; }          // (left marked: the scalar sweep launched behind this kernel takes it)
+    if (m > cap_kept) { if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32); return; }          // (left marked: the scalar sweep launched behind this kernel takes it)
     for (uint32_t k = lane; k < m; k += 64) { lastuse[k] = 0; ((uint16_t*)frees)[k] = 0xFFFFu; }
     auto pos_of = [&](uint32_t t) -> uint32_t { return (uint32_t)pref[t >> 6] + (uint32_t)__popcll(mask[t >> 6] & ((1ull << (t & 63)) - 1)); };
     for (uint32_t b = 0; b < nw; b++) {
@@ -259,14 +285,31 @@ __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uin
     }
     if (overflow) { if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); } return; }          // more than 64 registers: left marked for the scalar sweep
     // ---- B4: the child's ops, 64 at a time ----------------------------------------------------------------------------------------------
-    const uint32_t end = rfl(sl.c_off[c]);        // one past the child's last op (arena index)
+    const uint32_t end = rfl(sl.c_off[c]);        // one past the child's last op (arena index); the child's slot is [end - n, end)
     uint64_t* const dst = S->arena + (end - m);
+    // links of the child for the level below: ordinals of its kept choices by position (where the frees were: B3 is over)
+    uint16_t* const cidx = (uint16_t*)frees;
+    uint32_t kc = 0;
+    bool lk = (emit_links & 1u) != 0 && m <= FH_P2_L1_OPS;
+    if (lk) {
+        for (uint32_t base = 0; base < m; base += 64) {
+            const uint32_t pl = base + lane;
+            const bool ch = pl < m && ((comp[pl].y >> 16) & 8u) != 0;
+            const uint64_t bal = __ballot(ch);
+            if (pl < m) cidx[pl] = ch ? (uint16_t)(kc + (uint32_t)__popcll(bal & ((1ull << lane) - 1))) : (uint16_t)0xFFFFu;
+            kc += (uint32_t)__popcll(bal);
+        }
+        kc = rfl(kc);
+        lk = kc <= FH_P2_L1_CHOICES && 2u * m + kc + 1u <= n;
+    }
+    uint2* const dlk = (uint2*)(dst - m);
+    uint2* const dct = (uint2*)(dst - m - kc);
     uint32_t high = 0, kept = 0;
     for (uint32_t pl = lane; pl < m; pl += 64) {
         const uint2 cr = comp[pl];
-        const uint32_t fl = cr.y >> 16;
-        const uint2 opw = ops[cr.y & 0xFFFFu];
-        const uint32_t ro = regb[pl], ra = (fl & 1u) ? regb[cr.x & 0xFFFFu] : 0u, rb = (fl & 2u) ? regb[cr.x >> 16] : 0u;
+        const uint32_t fl = cr.y >> 16, i = cr.y & 0xFFFFu, pa = cr.x & 0xFFFFu, pb = cr.x >> 16;
+        const uint2 opw = ops[i];
+        const uint32_t ro = regb[pl], ra = (fl & 1u) ? regb[pa] : 0u, rb = (fl & 2u) ? regb[pb] : 0u;
         uint64_t word;
         if (fl & 4u) word = fh_pack(FH_COPY_IMM, ro, 0, 0, opw.y);
         else if (fl & 16u) word = fh_pack(FH_OUTPUT, 0, ra, 0, opw.y);
@@ -274,6 +317,14 @@ __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uin
         dst[pl] = word;
         high = max(high, (fl & 16u) ? 0u : ro + 1u);
         kept += (fl >> 3) & 1u;
+        if (lk) {
+            const uint32_t kind = (fl & 4u) ? (uint32_t)FH_LK_NONE : ((lks[i].x >> 8) & 0xFFu);
+            const uint32_t qa = (fl & 1u) ? cidx[pa] : 0xFFFFu, qb = (fl & 2u) ? cidx[pb] : 0xFFFFu, own = cidx[pl];
+            const uint32_t fa = (fl & 1u) ? (qa != 0xFFFFu ? (FH_LK_CHOICE | qa) : pa) : 0xFFFFu;
+            const uint32_t fb = (fl & 2u) ? (qb != 0xFFFFu ? (FH_LK_CHOICE | qb) : pb) : 0xFFFFu;
+            dlk[pl] = make_uint2(((uint32_t)word & 0xFFu) | (kind << 8) | ((own != 0xFFFFu ? own : 0u) << 16), fa | (fb << 16));
+            if (own != 0xFFFFu) dct[own] = make_uint2(fa | (fb << 16), pl | (kind << 16));
+        }
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) { high = max(high, (uint32_t)__shfl_xor(high, dlt, 64)); kept += (uint32_t)__shfl_xor(kept, dlt, 64); }
@@ -282,6 +333,27 @@ __global__ void __launch_bounds__(FH_P2_WPB * 64) k_prune2(FhRenderState* S, uin
         atomicMax(&S->leaf_stat[4], (unsigned long long)(t_b1 - t_a)); atomicMax(&S->leaf_stat[5], (unsigned long long)(t_b2 - t_b1));
         atomicMax(&S->leaf_stat[6], (unsigned long long)(t_b3 - t_b2)); atomicMax(&S->leaf_stat[7], (unsigned long long)(t_e - t_b3));
     }
-    if (lane == 0) { sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = high | (kept << 16); }
-    (void)emit_links;
+    if (lane == 0) {
+        if (lk) S->arena[end - 2u * m - kc - 1u] = ((uint64_t)S->frame_stamp << 32) | m | (kc << 16);
+        sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = high | (kept << 16);
+    }
+}
+
+// grid: mode 2 one workgroup per item; mode 0 (level 1) any number of workgroups - they stride over the items of the slots the
+// level really has (n_slots is the device's; an item whose children are not marked costs three loads).
+__global__ void __launch_bounds__(256) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride,
+                                                const uint2* __restrict__ links, const uint2* __restrict__ ctab, uint32_t emit_links,
+                                                uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
+    if (big != 2) {
+        p2_item(S, level, big, mode, cw_stride, links, ctab, emit_links, cap_ops, cap_choices, cap_kept, blockIdx.x, smem);
+        return;
+    }
+    const uint32_t n1 = fhp2::rfl(S->n_slots[1][level]) * per_slot, n0 = fhp2::rfl(S->n_slots[0][level]) * per_slot;
+    for (uint32_t it = blockIdx.x; it < n1 + n0; it += gridDim.x) {
+        __syncthreads();        // (the waves still reading the links of the item before)
+        if (it < n1) p2_item(S, level, 1u, mode, cw_stride, links, ctab, emit_links, cap_ops, cap_choices, cap_kept, it, smem);
+        else p2_item(S, level, 0u, mode, 16u, links, ctab, emit_links, cap_ops, cap_choices, cap_kept, it - n1, smem);
+    }
 }

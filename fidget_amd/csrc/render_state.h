@@ -123,7 +123,8 @@ struct FhRenderState {
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
     uint32_t n_leaves_lds;  // 3D: leaves of this slab that need the LDS register file (> 32 registers)
     FhLeafRef* leaf_table;  // 3D: [layer][footprint] -> leaf id + 1 and what the leaf kernel needs of the leaf (layer = 8-voxel layer of the slab)
-    uint32_t slab_z, pad_slab;   // 3D: z of the current slab's first voxel (a leaf's z = slab_z + 8 * layer)
+    uint32_t slab_z;        // 3D: z of the current slab's first voxel (a leaf's z = slab_z + 8 * layer)
+    uint32_t frame_stamp;   // a number no other frame of this context has: what the linked prune signs the links it leaves in the arena with (prune2.hip)
     // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
     uint32_t* fp_list[3];
     uint32_t fp_count[3], fp_cursor[3];

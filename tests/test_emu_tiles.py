@@ -273,3 +273,81 @@ def test_both_slot_lists_in_one_launch(kernel):
         g = lambda k: sl.b[40 + k * 256: 40 + (k + 1) * 256]
         assert (g(9).view(U32) == ref["res"][0].view(U32)).all() and (g(10).view(U32) == ref["res"][1].view(U32)).all()
         assert (g(12).view(U32) == ref["clen"]).all() and (g(13).view(U32) == ref["crc"]).all()
+
+
+def test_v64_exports_choices_of_parents_that_carry_links():
+    """flags bit 1 (level 1 behind the linked prune, prune2.hip): a parent whose tape has this frame's stamp in front - frame_stamp << 32
+    | len | choices << 16 at off - len - choices - 1 - gets its choice words written to chw[list] ([slot][word][lane], 16 words per
+    slot in list 0, flags[31:16] in list 1) and its ambiguous, decided children marked (c_len = ~0, c_off = end of their arena slot);
+    a parent without the stamp (or with another frame's) is pruned in the kernel as ever.  Both lists in one launch."""
+    off = U.offsets()
+    sh, tape, ik = shape_of(2)
+    n, regs, nch = len(tape), sh.slot_count(), sh.choice_count()
+    boxes = [children((0.1, -0.2, 0.3), 0.5), children((-0.3, 0.25, 0.0), 0.45), children((0.2, 0.1, -0.1), 0.4)]
+    alone = [run_tiles("fh_tiles_v64", tape, b, ik, regs, nch) for b in boxes]
+    STAMP, STRIDE1 = 77, 40
+    mem = E.Memory()
+    arena = np.zeros(ARENA_OPS, np.uint64)
+    offs = [2048, 4096, 8192]                       # three copies of the tape: stamped, not stamped, stamped by another frame
+    for o_ in offs:
+        arena[o_:o_ + n] = tape
+    arena[offs[0] - n - nch - 1] = (STAMP << 32) | n | (nch << 16)
+    arena[offs[2] - n - nch - 1] = ((STAMP - 1) << 32) | n | (nch << 16)
+    a_arena = mem.map(arena, "arena")
+    st = U.Blob(off["sizeof_state"])
+    lists = [U.Blob(off["sizeof_slot"] * 2), U.Blob(off["sizeof_slot"] * 2)]           # list 1 (big): slots A (stamped), C; list 0: slot B... and A again
+    plan = {(1, 0): (0, 0), (1, 1): (2, 2), (0, 0): (1, 1), (0, 1): (0, 2)}             # (list, index) -> (tape copy, box)
+    for (lst, idx), (tcopy, box) in plan.items():
+        b0 = off["sizeof_slot"] * idx
+        sl = lists[lst]
+        sl.u32(b0 + 0, offs[tcopy]); sl.u32(b0 + 4, n); sl.u32(b0 + 8, regs | (nch << 16)); sl.u32(b0 + 12, 2)
+        sl.u64(b0 + 16, (1 << 64) - 1)
+        for k in range(6):
+            sl.arr(b0 + 40 + 256 * k, np.asarray(boxes[box][k], F32))
+    a_l0, a_l1 = mem.map(lists[0].b, "slots0"), mem.map(lists[1].b, "slots1")
+    chw = [np.full(2 * 16 * 64, 0xDEADBEEF, U32), np.full(2 * STRIDE1 * 64, 0xDEADBEEF, U32)]
+    a_c0, a_c1 = mem.map(chw[0], "chw0"), mem.map(chw[1], "chw1")
+    head0 = 16384
+    st.u64(off["arena"], a_arena); st.u32(off["arena_cap"], ARENA_OPS - 64); st.u32(off["arena_head"], head0)
+    st.u64(off["slots"], a_l0); st.u64(off["slots"] + 8, a_l1)
+    st.u64(off["chw"], a_c0); st.u64(off["chw"] + 8, a_c1)
+    st.u32(off["frame_stamp"], STAMP)
+    st.u32(off["slot_cap"], 2); st.u32(off["slot_cap"] + 4, 2)
+    level = 1
+    for big in (0, 1):
+        st.u32(off["n_slots"] + 4 * (big * 8 + level), 2)
+    for s in range(16):
+        st.u32(off["P.in_kind"] + 4 * s, ik[s] if s < len(ik) else 3)
+    a_st = mem.map(st.b, "state")
+    ka = np.zeros(10, U32)
+    ka[0], ka[1] = a_st & 0xFFFFFFFF, a_st >> 32
+    ka[2:10] = [level, 1, 64, 512, 1, 16 | 2 | (STRIDE1 << 16), 0, 0]
+    E.launch(U.program(), mem, "fh_tiles_v64", ka.tobytes(), 1, lds_bytes=16, n_vgpr=N_VGPR["fh_tiles_v64"])
+    head = int(st.get_u32(off["arena_head"])[0])
+    for (lst, idx), (tcopy, box) in plan.items():
+        b0 = off["sizeof_slot"] * idx
+        g = lambda k: lists[lst].b[b0 + 40 + k * 256: b0 + 40 + (k + 1) * 256]
+        ref = alone[box]
+        assert (g(9).view(U32) == ref["res"][0].view(U32)).all() and (g(10).view(U32) == ref["res"][1].view(U32)).all()
+        pruned = ref["clen"] != n if True else None          # (children the kernel pruned when it ran the slot alone)
+        coff, clen, crc = g(11).view(U32), g(12).view(U32), g(13).view(U32)
+        if tcopy != 0:
+            # no stamp of this frame: pruned here, as alone (the tapes land elsewhere in the arena: compare contents)
+            assert (clen == ref["clen"]).all() and (crc == ref["crc"]).all()
+            for lane in np.nonzero(pruned)[0]:
+                assert (arena[coff[lane]:coff[lane] + clen[lane]] == ref["arena"][ref["coff"][lane]:ref["coff"][lane] + ref["clen"][lane]]).all()
+            continue
+        assert pruned.any()
+        assert (clen[pruned] == 0xFFFFFFFF).all() and (clen[~pruned] == n).all() and (coff[~pruned] == offs[0]).all()
+        assert (crc == (regs | (nch << 16))).all()
+        ends = np.sort(coff[pruned])
+        assert ((ends[1:] - ends[:-1]) == n).all() and ends[0] - n >= head0 and ends[-1] <= head, "one arena slot of the parent's length per marked child"
+        xyz = boxes[box]
+        inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(ik) if k < 3}
+        _, _, ch, _ = U.ref_interval(tape, inputs, 64)
+        stride = STRIDE1 if lst == 1 else 16
+        words = chw[lst][idx * stride * 64:(idx + 1) * stride * 64].reshape(stride, 64)
+        for q in range(nch):
+            got = (words[q >> 4] >> U32((q & 15) * 2)) & U32(3)
+            assert (got[pruned] == ch[q][pruned]).all(), f"choice {q}"
+        assert (words[(nch + 15) // 16:] == 0xDEADBEEF).all()
