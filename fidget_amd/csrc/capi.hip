@@ -1044,8 +1044,10 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 }
             }
             R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices);
+            // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
+            // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)
             R.prune2 = tape->d_links && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
-                       R.lds_prune2 <= FH_LDS_MAX;
+                       R.lds_prune2 <= FH_LDS_MAX && R.roots.size() * 64 <= (size_t)2 * ctx->n_cu * FH_P2_WPB;      // (a root group = up to 64 root tiles)
             R.d_ctab = tape->d_ctab;
             R.d_links = tape->d_links;
             R.lds_prune2_l1 = (((size_t)FH_P2_L1_OPS * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_L1_WPB * fh_p2_wave_lds(FH_P2_L1_CHOICES, FH_P2_L1_OPS);
@@ -1208,7 +1210,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
                                    (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u), R.S.troot_len, R.S.troot_choices,
                                    (uint32_t)FH_P2_MAX_KEPT);
-                // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or 2048 kept ops:
+                // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
                 size_t kp_bytes = sizeof(kp);

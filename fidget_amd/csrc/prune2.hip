@@ -46,7 +46,7 @@
 
 #include "render_state.h"
 
-#define FH_P2_WPB 3                                             // level 0: waves per workgroup
+#define FH_P2_WPB 4                                             // level 0: waves per workgroup (one per SIMD: the sequential step is scalar code)
 #define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // ... workgroups per slot (the last one's spare waves idle)
 #define FH_P2_L1_WPB 4                                          // level 1
 #define FH_P2_L1_PER_SLOT (64 / FH_P2_L1_WPB)
@@ -54,7 +54,7 @@
 #define FH_P2_L1_CHOICES 512u                                   // ... and choices (fh_tiles_v64's own bound)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
-#define FH_P2_MAX_KEPT 1536u
+#define FH_P2_MAX_KEPT 1280u                                    // (4 waves' areas + prospero's links = 152 KB of the CU's 160)
 // op classes of a link
 enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4, FH_LK_CRR = 5, FH_LK_CRI = 6 };
 // Link of an op, 8 bytes: word 0 = opcode | class << 8 | choice ordinal << 16, word 1 = fa | fb << 16: the producers of operands a and
