@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "render_state.h", "tape_format.h",
+_SOURCES = ["capi.hip", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "host_regtape.hpp", "render_state.h", "tape_format.h",
             "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
@@ -49,7 +49,7 @@ VM_TILES_2D, VM_TILES_3D = [128, 32, 8], [128, 64, 32, 16, 8]
 
 EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset", "fhip_ctx_set_option", "fhip_ctx_get_option",
-    "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_choice_count", "fhip_tape_reg_count",
+    "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_reg_tape", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
     "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
@@ -129,7 +129,7 @@ def lib():
             "fhip_cancel": (None, [vp]), "fhip_cancel_reset": (None, [vp]),
             "fhip_ctx_set_option": (i32, [vp, C.c_char_p, i32]), "fhip_ctx_get_option": (i32, [vp, C.c_char_p, C.POINTER(i32)]),
             "fhip_tape_from_bytecode": (i32, [vp, vp, C.c_size_t, C.POINTER(vp)]), "fhip_tape_free": (None, [vp]),
-            "fhip_tape_len": (u32, [vp]), "fhip_tape_choice_count": (u32, [vp]), "fhip_tape_reg_count": (u32, [vp]),
+            "fhip_tape_len": (u32, [vp]), "fhip_tape_reg_tape": (i32, [vp, u32, vp, u32, vp, u32, vp]), "fhip_tape_choice_count": (u32, [vp]), "fhip_tape_reg_count": (u32, [vp]),
             "fhip_tape_var_count": (u32, [vp]), "fhip_tape_output_count": (u32, [vp]),
             "fhip_tape_ops": (u32, [vp, vp, u32]),
             "fhip_simplify": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
@@ -500,9 +500,52 @@ class Shape:
         return Shape(_h=h, hip=hip, _vars=tuple(axis_slots))
 
     # sizes ---------------------------------------------------------------
-    def size(self): return lib().fhip_tape_len(self._h)
+    def device_len(self): return lib().fhip_tape_len(self._h)
+
+    def size(self):
+        """Function::size (eval/mod.rs:171) = VmData<N>::len(): the device tape's length - one op per SSA op - or, for a Shape made with
+        fewer than 255 registers, the reference's RegTape under that limit with its loads and stores (fhip_tape_reg_tape)."""
+        return self.device_len() if self.n_regs == 255 else self.reg_tape()[1][0]
     __len__ = size
-    def ssa_len(self): return self.size()  # device tapes carry no load/store: one op per SSA op
+    def ssa_len(self): return self.device_len()  # device tapes carry no load/store: one op per SSA op
+
+    def reg_tape(self, n_regs=None, want_words=False):
+        """RegTape::new::<N> + Bytecode::new of this tape (host side): ([(op, form, out, a, b, idx, imm bits)] in evaluation order - the
+        oracle's asm_ops() records -, (len, slot_count, reg_count, mem_count)[, bytecode words])."""
+        n_regs = self.n_regs if n_regs is None else n_regs
+        info = np.zeros(4, np.uint32)
+        st = lib().fhip_tape_reg_tape(self._h, n_regs, None, 0, None, 0, _p(info))
+        if st not in (0, 6):
+            raise FidgetHipError(st, "register allocation")
+        n = int(info[0])
+        rec = np.zeros((n, 4), np.uint32)
+        words = np.zeros(2 * n + 4, np.uint32)
+        st = lib().fhip_tape_reg_tape(self._h, n_regs, _p(rec), n, _p(words), len(words), _p(info))
+        if want_words and st == 6:
+            raise ValueError("ReservedRegister")
+        NAMES = ["Output", "Input", "CopyReg", "CopyImm", "Neg", "Abs", "Recip", "Sqrt", "Square", "Floor", "Ceil", "Round", "Sin", "Cos", "Tan",
+                 "Asin", "Acos", "Atan", "Exp", "Ln", "Not", "Rand"]
+        BIN = ["Add", "Sub", "Mul", "Div", "Atan2", "Compare", "Mix", "Mod", "Min", "Max", "And", "Or"]
+        ops = []
+        for op, o, a, w in rec.tolist():
+            if op == 52: ops.append(("Load", "", o, 0, 0, w, 0))
+            elif op == 53: ops.append(("Store", "", 0, a, 0, w, 0))
+            elif op == 0: ops.append(("Output", "", 0, a, 0, w, 0))
+            elif op == 1: ops.append(("Input", "", o, 0, 0, w, 0))
+            elif op == 3: ops.append(("CopyImm", "", o, 0, 0, 0, w))
+            elif op < 22: ops.append((NAMES[op], "Reg", o, a, 0, 0, 0))
+            elif op < 34: ops.append((BIN[op - 22], "RegReg", o, a, w, 0, 0))
+            elif op < 46: ops.append((BIN[op - 34], "RegImm", o, a, 0, 0, w))
+            else: ops.append((["Sub", "Div", "Atan2", "Compare", "Mix", "Mod"][op - 46], "ImmReg", o, a, 0, 0, w))
+        out = (ops, tuple(int(v) for v in info))
+        return out + (words,) if want_words else out
+
+    def asm_ops(self): return self.reg_tape()[0]
+
+    def bytecode(self):
+        """fidget_bytecode::Bytecode::new of the tape as VmData<n_regs>: (words, reg_count, mem_count)"""
+        _, info, words = self.reg_tape(want_words=True)
+        return words, info[2], info[3]
     def choice_count(self): return lib().fhip_tape_choice_count(self._h)
     def output_count(self): return lib().fhip_tape_output_count(self._h)
     def slot_count(self): return lib().fhip_tape_reg_count(self._h)
@@ -517,7 +560,7 @@ class Shape:
 
     def words(self):
         """Device tape as raw 8-byte ops (tape_format.h), evaluation order."""
-        n = self.size()
+        n = self.device_len()
         w = np.zeros(max(n, 1), dtype=np.uint64)
         lib().fhip_tape_ops(self._h, _p(w), n)
         return w[:n]
@@ -526,7 +569,7 @@ class Shape:
         """Per-op links for the linked prune (fhip_debug_tape_links; host_graph.hpp compute_links): [n, 5] = (opcode, class, choice ordinal,
         producer of a, producer of b) - a producer is an op index, 0x8000 | ordinal for a choice op, 0xFFFF for none; None when the tape
         does not qualify."""
-        n = self.size()
+        n = self.device_len()
         w = np.zeros(max(n, 1), dtype=np.uint64)
         if lib().fhip_debug_tape_links(self._h, _p(w), n) != n:
             return None
@@ -535,7 +578,7 @@ class Shape:
 
     def ops(self):
         """Device tape as (name, out, a, b, imm_bits) tuples in evaluation order."""
-        n = self.size()
+        n = self.device_len()
         w = np.zeros(max(n, 1), dtype=np.uint64)
         lib().fhip_tape_ops(self._h, _p(w), n)
         out = []
@@ -551,7 +594,7 @@ class Shape:
         if st != 0:
             raise ValueError(STATUS.get(st, str(st)))
         return Shape(_h=h, hip=self._hip, _vars=self._vars if self._vars is not None else tuple(self.axis_index(a) for a in range(3)),
-                     n_regs=self.n_regs)._with_named(self)
+                     n_regs=self.n_regs if n_regs is None else n_regs)._with_named(self)
 
     def _with_named(self, parent):
         self._named_parent = parent  # children keep the parent's Var::V slots

@@ -17,6 +17,7 @@
 #include "../../include/fidget_hip.h"
 #include "../../include/fidget_hip_debug.h"
 #include "host_graph.hpp"
+#include "host_regtape.hpp"
 #include "kernels.hip"
 #include "effects.hip"
 #include "mesh.hip"
@@ -513,6 +514,25 @@ uint32_t fhip_tape_choice_count(const fhip_tape* t) { return t->t.n_choices; }
 uint32_t fhip_tape_reg_count(const fhip_tape* t) { return t->t.n_regs; }
 uint32_t fhip_tape_var_count(const fhip_tape* t) { return t->t.n_vars; }
 uint32_t fhip_tape_output_count(const fhip_tape* t) { return t->t.n_outputs; }
+fhip_status fhip_tape_reg_tape(const fhip_tape* t, uint32_t n_regs, uint32_t* reg_ops, uint32_t cap_ops, uint32_t* words, uint32_t cap_words,
+                               uint32_t info[4]) {
+    fh::RegTapeOut rt;
+    std::string err;
+    for (int i = 0; i < 4; i++) info[i] = 0;
+    if (!fh::reg_tape(t->t, n_regs, rt, err)) return FHIP_ERR_BAD_TAPE;
+    info[0] = (uint32_t)rt.ops.size(); info[1] = rt.slot_count;
+    if (reg_ops)
+        for (size_t i = 0; i < rt.ops.size() && i < cap_ops; i++) {
+            const fh::RegOp& o = rt.ops[rt.ops.size() - 1 - i];       // evaluation order
+            reg_ops[4 * i] = o.op; reg_ops[4 * i + 1] = o.out; reg_ops[4 * i + 2] = o.a;
+            reg_ops[4 * i + 3] = fh_is_rr(o.op) ? (uint32_t)o.b : o.w;
+        }
+    std::vector<uint32_t> w;
+    const bool ok = fh::reg_tape_bytecode(rt, n_regs, w, info[2], info[3]);
+    if (!ok) return FHIP_ERR_UNSUPPORTED;
+    if (words) for (size_t i = 0; i < w.size() && i < cap_words; i++) words[i] = w[i];
+    return FHIP_OK;
+}
 uint32_t fhip_tape_ops(const fhip_tape* t, uint64_t* ops, uint32_t cap) {
     for (uint32_t i = 0; i < t->t.ops.size() && i < cap; i++) ops[i] = t->t.ops[i];
     return (uint32_t)t->t.ops.size();

@@ -73,6 +73,17 @@ uint32_t fhip_tape_var_count(const fhip_tape* tape);    /* Tape::vars().len()  e
 uint32_t fhip_tape_output_count(const fhip_tape* tape); /* Tape::output_count  eval/mod.rs:47 */
 /* Copy the device-format ops (8 bytes each, evaluation order) to `ops`; returns the length */
 uint32_t fhip_tape_ops(const fhip_tape* tape, uint64_t* ops, uint32_t cap);
+/* The tape as the reference's VmData<N> holds it: RegTape::new::<N> (fidget-core/src/compiler/reg_tape.rs:26-32) - the
+ * single-pass RegisterAllocator<N> with its LRU eviction and Load / Store spills to memory slots >= N
+ * (compiler/alloc.rs:13-708, compiler/lru.rs:19-76) - over this tape's ops, and Bytecode::new of that
+ * (fidget-bytecode/src/lib.rs:203-332).  Host side only; what the device runs is the library's own dense allocation.
+ * reg_ops (may be NULL): 4 words per RegOp in evaluation order (VmData::iter_asm, vm/data.rs:320-323): opcode (tape_format.h FhOp; 52
+ * Load, 53 Store), out, a (lhs / the stored register), then b, or the immediate bits, or the input / output / memory slot.
+ * words (may be NULL): the bytecode, start and end markers included.  info = { RegTape::len(), RegTape::slot_count(),
+ * Bytecode::reg_count, Bytecode::mem_count }.  1 <= n_regs <= 255.  FHIP_ERR_UNSUPPORTED: the reserved register 255 would be in
+ * use (lib.rs ReservedRegister); info[0..1] are valid then. */
+fhip_status fhip_tape_reg_tape(const fhip_tape* tape, uint32_t n_regs, uint32_t* reg_ops, uint32_t cap_ops, uint32_t* words,
+                               uint32_t cap_words, uint32_t info[4]);
 
 /* Tape parallelism (no counterpart in the reference): when the root of the function is a min / max
  * of many parts, the same function as `count` independent tapes whose outputs combine, in order,

@@ -52,8 +52,8 @@ def test_constant_tape(be):  # ssa_tape.rs:456-462
 
 
 def oracle_only(be):
-    if be.__name__ != "oracle":
-        pytest.skip("pins the reference's RegisterAllocator / Bytecode::new (oracle); the device tape has no spills")
+    """(no longer a skip: the HIP backend answers VmData<N>-shaped questions - len() with loads and stores, iter_asm(), the bytecode -
+    through the reference's allocator on the host, include/fidget_hip.h fhip_tape_reg_tape; what the device runs has no spills)"""
 
 
 def test_simplify_reg_count_change(be):  # vm/data.rs:415-436
@@ -161,3 +161,46 @@ def test_model_sizes(be, name, ops, choices):
     s = be.Shape.from_vm(model_path(name))
     assert s.ssa_len() == ops and s.choice_count() == choices
     assert s.axis_index(2) == -1 and s.var_count() == 2
+
+
+@pytest.mark.parametrize("name,n_regs", [("hi.vm", 255), ("hi.vm", 6), ("hi.vm", 3), ("prospero.vm", 255), ("prospero.vm", 24), ("prospero.vm", 3),
+                                          ("colonnade.vm", 255), ("colonnade.vm", 12), ("bear.vm", 255), ("bear.vm", 8), ("gyroid-sphere.vm", 4)])
+def test_reg_tape_and_bytecode_of_the_models_are_the_oracles(name, n_regs, oracle_mod):
+    """RegisterAllocator<N> + Lru<N> + RegTape::new + Bytecode::new (compiler/alloc.rs:13-708, lru.rs:19-76, reg_tape.rs:26-61,
+    fidget-bytecode/src/lib.rs:203-332) as the library restates them for its own tapes (host_regtape.hpp), against the oracle's
+    VmData<N> of the same model: every RegOp with its loads and stores, slot count, the bytecode word for word - N = 255 (the
+    VM's), 24 / 12 (the JITs'), and small enough to spill all the time."""
+    import fidget_amd as F
+    from conftest import model_path
+    o = oracle_mod.Shape.from_vm(model_path(name), n_regs=n_regs)
+    p = F.Shape.from_vm(model_path(name))
+    ops, info = p.reg_tape(n_regs)
+    want = o.asm_ops()
+    assert len(ops) == len(want) == o.size() and info[0] == len(want)
+    for k, (a, b) in enumerate(zip(ops, want)):
+        assert a == b, f"op {k}: {a} vs the oracle's {b}"
+    assert any(op[0] == "Load" for op in ops) == (n_regs < 255 and o.size() > p.device_len())
+    try:
+        w, regs, mem = o.bytecode()
+    except ValueError:
+        with pytest.raises(ValueError):
+            F.Shape.from_vm(model_path(name), n_regs=n_regs).bytecode()
+        return
+    pw, pregs, pmem = F.Shape.from_vm(model_path(name), n_regs=n_regs).bytecode()
+    assert (pregs, pmem) == (regs, mem) and (np.asarray(pw) == np.asarray(w)).all()
+
+
+def test_reg_tape_of_simplified_tapes_is_the_oracles(oracle_mod):
+    """... and after simplify (vm/data.rs:123-318 allocates while it simplifies; here the simplified tape is allocated afterwards:
+    the same ops in the same order): random choice vectors on hi.vm and prospero.vm, N = 255 and N = 5."""
+    import fidget_amd as F
+    from conftest import model_path
+    rng = np.random.default_rng(3)
+    for name, n_regs in (("hi.vm", 5), ("prospero.vm", 255), ("prospero.vm", 5)):
+        o = oracle_mod.Shape.from_vm(model_path(name), n_regs=n_regs)
+        p = F.Shape.from_vm(model_path(name), n_regs=n_regs)
+        for _ in range(3):
+            ch = rng.choice([1, 2, 3], size=o.choice_count(), p=[0.3, 0.3, 0.4]).astype(np.uint8)
+            so, sp = o.simplify(ch), p.simplify(ch)
+            assert sp.size() == so.size()
+            assert sp.asm_ops() == so.asm_ops()
