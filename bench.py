@@ -162,9 +162,20 @@ def main():
     frame_ms = []
 
     def timed(step):
+        import gc
         for _ in range(args.warmup):
             step()
         fence()
+        # (the host only queues work here: a collection of the interpreter's garbage in the middle of the loop - 20 ms with torch and
+        # numpy loaded - drains the three frames the pipeline holds and shows up as one frame of 10 x the median)
+        gc.collect()
+        gc.disable()
+        try:
+            return _timed(step)
+        finally:
+            gc.enable()
+
+    def _timed(step):
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
         marks[0].record(stream)
