@@ -75,9 +75,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -90,7 +90,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -762,6 +762,7 @@ struct RenderSetup {
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
     bool asm_points = false;  // leaf stage on the assembly interpreters
     bool asm_points_t = false;  // ... on fh_columns_t (tapes with transcendental / modulo / rng opcodes)
+    bool asm_normals = false;   // normals by the assembly gradient interpreter fh_normals (gen_normals.py): footprints of leaves of <= 32 registers
     bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
     bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
     uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
@@ -890,6 +891,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
     R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
     R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
+    R.asm_normals = R.asm_points && !R.asm_points_t && !ctx->opt.no_asm_normals;
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
@@ -1629,7 +1631,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         auto normals_work = [&] {
             launch(ctx, FHIP_K_NORMALS, [&] {
                 const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_big(ctx, R, R.lds_normals_big, 8);
-                if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                if (R.asm_normals) {
+                    // (list 0 of k_classify3d holds every footprint whose leaves need <= 32 registers: the assembly interpreter's file)
+                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * std::max(1, ctx->opt.normals_waves)), R.col_slots, z_lo, z_hi, {0, 0}};
+                    (void)launch_asm(ctx, FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
+                }
+                else if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 if (P.max_regs > 32) {
                     if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);

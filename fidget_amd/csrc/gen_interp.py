@@ -726,7 +726,7 @@ class Interp:
 	s_load_dwordx8 s[{other}:{other + 7}], {S_FETCH}, 0x0
 	s_add_u32 s72, s72, 0x20
 	s_addc_u32 s73, s73, 0""")
-            if self.kind == "bulk":
+            if self.kind in ("bulk", "grad"):      # (tapes of any length and number of outputs: the ops are counted)
                 a(f"""
 	s_sub_u32 {S_LEN}, {S_LEN}, 1
 	s_cbranch_scc1 .L{n}_done""")
@@ -1393,6 +1393,8 @@ def main():
     from gen_tilesv import gen_tilesv
     ks.append(gen_tilesv(a, off, 32, 16))
     ks.append(gen_tilesv(a, off, 64, 32))
+    from gen_normals import gen_normals
+    ks.append(gen_normals(a, off))
     ks.append(gen_probe(a))
     from gen_ubench import gen_ubench
     ks.append(gen_ubench(a))

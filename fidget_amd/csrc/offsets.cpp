@@ -10,7 +10,7 @@ int main() {
     bool first = true;
     O("P.mat", P.mat); O("P.width", P.width); O("P.height", P.height); O("P.tiles", P.tiles); O("P.slab", P.slab);
     O("P.in_kind", P.in_kind); O("P.in_value", P.in_value);
-    O("arena", arena); O("leaves", leaves); O("leaf_table", leaf_table); O("slab_z", slab_z); O("zbuf", zbuf);
+    O("arena", arena); O("leaves", leaves); O("leaf_table", leaf_table); O("slab_z", slab_z); O("zbuf", zbuf); O("normals", normals);
     O("arena_cap", arena_cap); O("arena_head", arena_head); O("arena_overflow", arena_overflow);
     O("chw", chw); O("frame_stamp", frame_stamp); O("tgroup", tgroup); O("n_tgroups", n_tgroups); O("chwr", chwr); O("slots", slots); O("slot_cap", slot_cap); O("n_slots", n_slots); O("eval_cur", eval_cur);
     O("fp_list", fp_list); O("fp_count", fp_count); O("fp_cursor", fp_cursor); O("stat", stat);

@@ -1,6 +1,4 @@
-for K in 60 100 60 100; do
-python bench.py --no-cpu --steps $K 2>/dev/null | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); g=d['general']
-print('K', d['steps'], 'default mean', round(d['ms_per_step'],4), 'median', round(d['ms_per_step_median'],4), '| general mean', round(g['ms_per_step'],4), 'median', round(g['ms_per_step_median'],4))"
-done
+mkdir -p gpurun_out/r03v
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03v/gpu_suite.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03v/gpu_suite.log
+grep -n "passed\|failed\|rc=\|Error\|assert" gpurun_out/r03v/gpu_suite.log | tail -6
+bash tools/sweep_env.sh "" "FHIP_NO_ASM_NORMALS=1" "" "FHIP_NORMALS_WAVES=16"
