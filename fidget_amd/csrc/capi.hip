@@ -75,9 +75,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -456,6 +456,13 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
         if (ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
     }
     return e;
+}
+static bool tape_has_mod(const fh::HostTape& t) {
+    for (uint64_t w : t.ops) {
+        const uint32_t op = FH_W_OP((uint32_t)w);
+        if (op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR) return true;
+    }
+    return false;
 }
 // The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
 static bool tape_asm_ok(const fh::HostTape& t) {
@@ -891,7 +898,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
     R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
     R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
-    R.asm_normals = R.asm_points && !R.asm_points_t && !ctx->opt.no_asm_normals;
+    // (fh_normals_t has the transcendental, rng and atan2 handlers; a modulo's gradient - div_euclid - keeps the C++ kernel)
+    R.asm_normals = R.asm_points && !ctx->opt.no_asm_normals && (!R.asm_points_t || !tape_has_mod(t));
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
@@ -1634,7 +1642,7 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 if (R.asm_normals) {
                     // (list 0 of k_classify3d holds every footprint whose leaves need <= 32 registers: the assembly interpreter's file)
                     struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * std::max(1, ctx->opt.normals_waves)), R.col_slots, z_lo, z_hi, {0, 0}};
-                    (void)launch_asm(ctx, FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
+                    (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
                 }
                 else if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);

@@ -1395,6 +1395,8 @@ def main():
     ks.append(gen_tilesv(a, off, 64, 32))
     from gen_normals import gen_normals
     ks.append(gen_normals(a, off))
+    if len(sys.argv) > 3:
+        ks.append(gen_normals(a, off, trans=sys.argv[3]))
     ks.append(gen_probe(a))
     from gen_ubench import gen_ubench
     ks.append(gen_ubench(a))

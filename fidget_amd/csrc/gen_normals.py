@@ -25,6 +25,7 @@ from gen_interp import (Interp, OPS, FILE, S_KERNARG, S_STATE, S_MAT, S_SIGN, S_
                         handler_base, call_interp)
 
 NR = 32
+T_BASE = FILE + NR * 4      # register window of the transcendental routines (fh_normals_t)
 S_SLOTX, S_SLOTY, S_SLOTZ = "s0", "s1", "s3"
 S_WI, S_NWG, S_NFP = "s6", "s7", "s40"
 S_WIDTH, S_HEIGHT = "s24", "s25"
@@ -42,8 +43,22 @@ XR = [["v14", "v15", "v16", "v17"], ["v52", "v53", "v54", "v55"], ["v56", "v57",
 class GradInterp(Interp):
     INPLACE = set()
 
-    def __init__(self, a, name, off):
-        super().__init__(a, name, NR, 4, "grad", off)
+    def __init__(self, a, name, off, trans=False):
+        super().__init__(a, name, NR, 4, "grad", off, trans=trans)
+
+    def call(self, fn, arg, res, arg2=None):
+        """res = <fn>(arg [, arg2]) by the compiled routine fh_tn_<fn> (gen_trans.py, embedded with its vector registers in
+        v[T_BASE .. T_BASE + 25] behind the register file); clobbers those, s86..s97 and vcc"""
+        here, ret = self.a.label("call"), self.a.label("ret")
+        self.a(f"\tv_mov_b32 v{T_BASE}, {arg}" + (f"\n\tv_mov_b32 v{T_BASE + 1}, {arg2}" if arg2 else ""))
+        self.a(f"""
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_branch fh_tn_{fn}
+{ret}:
+	v_mov_b32 {res}, v{T_BASE}""")
 
     # ---- scalar helpers on plain VGPRs -----------------------------------------------------------
     def div1(self, n, d, r):
@@ -187,10 +202,80 @@ class GradInterp(Interp):
                 self.write_out(VW)
             return self.out_of_line(op.lower(), body)
         if "_" not in op:
-            return self.ret()              # transcendental / rng: never reached (the host keeps those tapes on the C++ kernel)
+            if not self.trans:
+                return self.ret()          # transcendental / rng: never reached (the host keeps those tapes on the C++ kernel)
+            def body(op=op):               # dev_ops.hpp GRAD::unary, FULL
+                self.read_a(VT)
+                self.idx_off()
+                v, c = VT[0], VU[0]
+                if op == "SIN":
+                    self.call("cos", v, c)
+                    self.call("sin", v, VW[0])
+                    for j in (1, 2, 3):
+                        a(f"\tv_mul_f32 {VW[j]}, {VT[j]}, {c}")
+                elif op == "COS":
+                    self.call("sin", v, c)
+                    a(f"\tv_xor_b32 {c}, {S_SIGN}, {c}")
+                    self.call("cos", v, VW[0])
+                    for j in (1, 2, 3):
+                        a(f"\tv_mul_f32 {VW[j]}, {VT[j]}, {c}")
+                elif op == "TAN":
+                    self.call("cos", v, c)
+                    a(f"\tv_mul_f32 {c}, {c}, {c}")
+                    self.call("tan", v, VW[0])
+                    for j in (1, 2, 3):
+                        self.div1(VT[j], c, VW[j])
+                elif op in ("ASIN", "ACOS"):
+                    a(f"\tv_mul_f32 {VU[1]}, {v}, {v}\n\tv_sub_f32 {VU[1]}, 1.0, {VU[1]}")
+                    self.sqrt1(VU[1], c)
+                    self.call(op.lower(), v, VW[0])
+                    for j in (1, 2, 3):
+                        if op == "ACOS":
+                            a(f"\tv_xor_b32 {VU[1]}, {S_SIGN}, {VT[j]}")
+                            self.div1(VU[1], c, VW[j])
+                        else:
+                            self.div1(VT[j], c, VW[j])
+                elif op == "ATAN":
+                    a(f"\tv_mul_f32 {c}, {v}, {v}\n\tv_add_f32 {c}, 1.0, {c}")
+                    self.call("atan", v, VW[0])
+                    for j in (1, 2, 3):
+                        self.div1(VT[j], c, VW[j])
+                elif op == "EXP":
+                    self.call("exp", v, VW[0])
+                    for j in (1, 2, 3):
+                        a(f"\tv_mul_f32 {VW[j]}, {VW[0]}, {VT[j]}")
+                elif op == "LN":
+                    self.call("ln", v, VW[0])
+                    for j in (1, 2, 3):
+                        self.div1(VT[j], v, VW[j])
+                else:                       # RAND: gr1(f_rand(a.v)) - bits (hash >> 9) | 1.0, minus 1 (rng/mod.rs:19-23)
+                    self.pcg_consts()
+                    self.pcg(v, VW[0])
+                    a(f"\tv_lshrrev_b32 {VW[0]}, 9, {VW[0]}\n\tv_or_b32 {VW[0]}, 0x3f800000, {VW[0]}\n\tv_add_f32 {VW[0]}, -1.0, {VW[0]}")
+                    self.gr1(VW, VW[0])
+                self.write_out(VW)
+            return self.out_of_line(op.lower(), body)
         base, form = op.rsplit("_", 1)
-        if base in ("ATAN2", "MOD", "MIX"):
-            return self.ret()
+        if base == "MOD" or (base in ("ATAN2", "MIX") and not self.trans):
+            return self.ret()              # (tapes with a modulo keep the C++ kernel: its gradient needs div_euclid)
+        if base in ("ATAN2", "MIX"):
+            def body(base=base, form=form):
+                A, B = self.operands(form)
+                if base == "MIX":           # gr1(rng::mix): hash(a + hash(b)) on the bit patterns (rng/mod.rs:30-33)
+                    self.pcg_consts()
+                    self.pcg(B[0], VW[0])
+                    a(f"\tv_add_u32 {VW[0]}, {A[0]}, {VW[0]}")
+                    self.pcg(VW[0], VW[0])
+                    self.gr1(VW, VW[0])
+                else:                       # atan2(y = a, x = b): d = b.v b.v + a.v a.v; (b.v a.dk - a.v b.dk) / d
+                    sq, t0, t1 = VD[5], VD[6], VD[7]
+                    a(f"\tv_mul_f32 {sq}, {B[0]}, {B[0]}\n\tv_mul_f32 {t0}, {A[0]}, {A[0]}\n\tv_add_f32 {sq}, {sq}, {t0}")
+                    for j in (1, 2, 3):
+                        a(f"\tv_mul_f32 {t0}, {B[0]}, {A[j]}\n\tv_mul_f32 {t1}, {A[0]}, {B[j]}\n\tv_sub_f32 {t0}, {t0}, {t1}")
+                        self.div1(t0, sq, VW[j])
+                    self.call("atan2", A[0], VW[0], B[0])
+                self.write_out(VW)
+            return self.out_of_line(op.lower(), body)
         def body(base=base, form=form):
             A, B = self.operands(form)
             if base == "ADD":
@@ -261,11 +346,12 @@ class GradInterp(Interp):
         self.ret()
 
 
-def gen_normals(a, off):
-    name = "fh_normals"
+def gen_normals(a, off, trans=None):
+    """fh_normals, or with `trans` (the compiled routines' assembly) fh_normals_t: handlers for the transcendental, rng and atan2 opcodes too"""
+    name = "fh_normals_t" if trans else "fh_normals"
     o, m = off, S_MAT
-    it = GradInterp(a, name + "_g", off)
-    nvg = FILE + NR * 4
+    it = GradInterp(a, name + "_g", off, trans=bool(trans))
+    nvg = T_BASE + 26 if trans else FILE + NR * 4
     kernel_header(a, name, 32, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
@@ -389,5 +475,8 @@ def gen_normals(a, off):
 .L{name}_exit:
 	s_waitcnt vmcnt(0)""")
     kernel_footer(a, name, 32, nvg, 102, True)
+    if trans:
+        import gen_trans
+        gen_trans.embed(a, trans, v_base=T_BASE, prefix="fh_tn_")
     it.emit()
     return name, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6

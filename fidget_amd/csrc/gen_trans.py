@@ -11,7 +11,7 @@ FUNCS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod
 MAX_V, MAX_S = 26, 10
 
 
-def _rename(body, name):
+def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_"):
     def v1(m):
         n = int(m.group(1))
         assert n < MAX_V, (name, m.group(0))
@@ -41,9 +41,9 @@ def _rename(body, name):
         code = line.split(";")[0].rstrip()
         if not code.strip() or code.strip().startswith("."):
             if re.match(r"^\.LBB\d+_\d+:", code.strip()):
-                out.append(re.sub(r"\.LBB(\d+)_(\d+)", rf".Lfh_t_{name}_bb\2", code.strip()))
+                out.append(re.sub(r"\.LBB(\d+)_(\d+)", rf".L{prefix}{name}_bb\2", code.strip()))
             continue
-        code = re.sub(r"\.LBB(\d+)_(\d+)", rf".Lfh_t_{name}_bb\2", code)
+        code = re.sub(r"\.LBB(\d+)_(\d+)", rf".L{prefix}{name}_bb\2", code)
         code = re.sub(r"\bv\[(\d+):(\d+)\]", v2, code)
         code = re.sub(r"\bv(\d+)\b", v1, code)
         code = re.sub(r"\bs\[(\d+):(\d+)\]", s2, code)
@@ -54,10 +54,12 @@ def _rename(body, name):
     return "\n".join(out)
 
 
-def embed(a, path):
+def embed(a, path, v_base=V_BASE, prefix="fh_t_"):
+    """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
+    window embeds its own copies: `s_branch` reaches 128 KB)"""
     txt = open(path).read()
     for f in FUNCS:
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f
-        a(f"\t.p2align 6\nfh_t_{f}:")
-        a(_rename(m.group(1), f))
+        a(f"\t.p2align 6\n{prefix}{f}:")
+        a(_rename(m.group(1), f, v_base, prefix))

@@ -370,3 +370,20 @@ def test_bulk_sqrt_min_max_bit_exact_over_the_float_range():
             got = np.asarray(s.eval_float_slice(xf, yf, zero), np.float32)
             ok = (got.view(np.uint32) == want.astype(np.float32).view(np.uint32)) | (np.isnan(got) & np.isnan(want))
             assert ok.all(), f"{name}: {(~ok).sum()} of {n} differ, first at input {hex(int(xs[np.nonzero(~ok)[0][0]]))}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("prospero.vm", 512), ("colonnade.vm", 256), ("bear.vm", 256), ("gyroid-sphere.vm", 128)])
+def test_assembly_normals_are_the_hip_kernels(name, size):
+    """fh_normals / fh_normals_t (gen_normals.py: the gradient interpreter in assembly, with the compiled transcendental routines for
+    bear.vm and gyroid-sphere.vm) against k_normals3d, the HIP C++ kernel it replaces (option no_asm_normals): the same image, normals
+    bit for bit - also under a perspective camera, where the input gradients go through the division by w."""
+    import fidget_amd as F
+    hip = F.HipContext(0)
+    p = F.Shape.from_vm(model_path(name), hip=hip)
+    for cam in (None, bench_camera(0.3)):
+        a = F.render3d(p, size, world_to_model=cam)[0]
+        with hip.options(no_asm_normals=1):
+            b = F.render3d(p, size, world_to_model=cam)[0]
+        assert (a["depth"] == b["depth"]).all() and (a["depth"] > 0).any()
+        assert same_bits_f32(a["normal"], b["normal"]), f"{name}: {(a['normal'].view(np.uint32) != b['normal'].view(np.uint32)).any(axis=2).sum()} normals differ"
