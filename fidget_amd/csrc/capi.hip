@@ -75,9 +75,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -90,7 +90,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -254,6 +254,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     for (int i = 0; i < FH_ASM_COUNT; i++)
         if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES_T], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
     (void)hipGetLastError();
     {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
         int lo = 0, hi = 0;
@@ -456,6 +457,18 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
         if (ctx->err.empty()) ctx->err = std::string("launch of ") + FH_ASM_NAMES[which] + ": " + hipGetErrorString(e);
     }
     return e;
+}
+// ... the *_t tile kernels add the unary transcendental ones
+static bool tape_tiles_t_ok(const fh::HostTape& t) {
+    for (uint64_t w : t.ops) {
+        const uint32_t op = FH_W_OP((uint32_t)w);
+        if (op == FH_RAND) return false;
+        if (op >= FH_ADD_RR) {
+            const int base = op >= FH_SUB_IR ? (int[]){1, 3, 4, 5, 6, 7}[op - FH_SUB_IR] : (int)((op - FH_ADD_RR) % 12);
+            if (base == 4 || base == 6 || base == 7) return false;  // atan2, mix, mod
+        }
+    }
+    return true;
 }
 static bool tape_has_mod(const fh::HostTape& t) {
     for (uint64_t w : t.ops) {
@@ -772,6 +785,7 @@ struct RenderSetup {
     bool asm_normals = false;   // normals by the assembly gradient interpreter fh_normals (gen_normals.py): footprints of leaves of <= 32 registers
     bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
     bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
+    bool asm_tiles_t = false; // ... by the *_t variants (transcendental opcodes)
     uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
     size_t lds_tiles_group = 0;
     bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
@@ -1021,14 +1035,18 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
     R.split = ctx->use_split && R.tl == 64 && (is3d || !ctx->opt.no_split_2d);
-    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && tape_asm_ok(t) && t.n_regs <= 128;
+    // (tapes with sin cos tan asin acos atan exp ln: the *_t variants of the tile kernels, which carry those interval handlers;
+    // atan2, mod, mix, rand keep the HIP tile stage)
+    R.asm_tiles_t = !tape_asm_ok(t) && tape_tiles_t_ok(t) && !ctx->opt.no_asm_tiles_t;
+    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && (tape_asm_ok(t) || R.asm_tiles_t) && t.n_regs <= 128;
+    R.asm_tiles_t = R.asm_tiles_t && R.asm_tiles;
     // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
     // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
     {
         const uint32_t p1_levels = (uint32_t)std::max(0, ctx->opt.prune1_levels);
         R.exp_levels = is3d ? std::min(S.pre_levels, p1_levels) : std::min(1u, p1_levels);
     }
-    R.prune1 = R.asm_tiles && R.exp_levels > 0 && !ctx->opt.no_prune1;
+    R.prune1 = R.asm_tiles && !R.asm_tiles_t && R.exp_levels > 0 && !ctx->opt.no_prune1;      // (the *_t kernels have no export mode)
     // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
     // waves, then the tree itself; the prune sees the root tape with its usual choices
     R.groups = R.prune1 && !tape->tgroups.empty() && !ctx->opt.no_tape_groups;
@@ -1257,6 +1275,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
             // the prune runs as one wave per child (fh_prune1)
             const bool exp = R.prune1 && (uint32_t)level < R.exp_levels;      // level 0 only: 8 parents, 6363-op tape (measured)
+            const int K_TILES = R.asm_tiles_t ? FH_ASM_TILES_T : FH_ASM_TILES;
             struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
             ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
             ka.skip_regs = ka.skip_choices = 0;
@@ -1293,10 +1312,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 if (vk && !both_lists) {
                     const int v32_waves = ctx->opt.v32_waves;
                     ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
-                    (void)launch_asm(ctx, FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
+                    (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V32_T : FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
                 } else if (vk) {
                 } else
-                    (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
+                    (void)launch_asm(ctx, K_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
             }
             ka.big = 1;
             if (exp) ka.flags |= ((R.S.P.max_choices + 15) / 16) << 16;  // one stride in chw[1] for the medium and the large layout
@@ -1318,7 +1337,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 const bool linked = R.prune2_l1 && !per_slab;
                 const uint32_t plain_flags = ka.flags;
                 if (linked) ka.flags = (ka.flags & 0xFFFFu) | 2u | (((R.S.P.max_choices + 15) / 16) << 16);
-                (void)launch_asm(ctx, FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
+                (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V64_T : FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
                 ka.flags = plain_flags & ~16u;
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
@@ -1330,11 +1349,11 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (mid) {
                 const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
-                (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid, 1, big_stream);
+                (void)launch_asm(ctx, K_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid, 1, big_stream);
                 ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
             }
             ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
-            if (rest) (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big, 1, big_stream);
+            if (rest) (void)launch_asm(ctx, K_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big, 1, big_stream);
             if (side) {
                 (void)hipEventRecord(ctx->ev_rest_join, rest_stream);
                 (void)hipStreamWaitEvent(ctx->stream, ctx->ev_rest_join, 0);

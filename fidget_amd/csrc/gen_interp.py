@@ -1397,6 +1397,9 @@ def main():
     ks.append(gen_normals(a, off))
     if len(sys.argv) > 3:
         ks.append(gen_normals(a, off, trans=sys.argv[3]))
+        ks.append(gen_tiles(a, off, trans=sys.argv[3]))
+        ks.append(gen_tilesv(a, off, 32, 16, trans=sys.argv[3]))
+        ks.append(gen_tilesv(a, off, 64, 32, trans=sys.argv[3]))
     ks.append(gen_probe(a))
     from gen_ubench import gen_ubench
     ks.append(gen_ubench(a))

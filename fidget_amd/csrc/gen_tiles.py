@@ -103,12 +103,136 @@ SLOT_SIZE = 40 + 64 * 4 * 14
 SL_ACT, SL_XYZ, SL_CORNER, SL_RES, SL_COFF, SL_CLEN, SL_CRC = 16, 40, 40 + 6 * 256, 40 + 9 * 256, 40 + 11 * 256, 40 + 12 * 256, 40 + 13 * 256
 
 
+TRANS_UNARY = ("SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "EXP", "LN")
+T_SMAP = [78, 79, 80, 81, 82, 83, 84, 85, 88, 89]      # scalar registers of the compiled routines in the tile kernels: the prune's masks
+                                                        # (dead in the forward pass) and S_SAVE; return address s[96:97] (= S_M[3])
+
+
 class Tiles:
-    def __init__(self, a, off):
+    def __init__(self, a, off, trans=None):
         self.a, self.off = a, off
         self.name = "fh_tiles"
         self.next = ".Lfh_tiles_next"
         self.ool = []
+        # `trans` (the compiled routines' assembly): handlers for the transcendental opcodes (the *_t kernels).  The routines'
+        # vector registers go behind the kernel's own (t_base), their labels get t_prefix.
+        self.trans, self.t_base, self.t_prefix = trans, N_VGPR, "fh_til_"
+        self.n_vgpr = N_VGPR + (26 if trans else 0)
+
+    # ---- transcendental opcodes: interval rules of types/interval.rs:136-302 (dev_ops.hpp iv_sincos .. iv_ln) around the compiled
+    # f32 routines (gen_trans.py), which are what the HIP kernels inline: same bounds, bit for bit --------------------------------
+    def tcall(self, fn, arg, res):
+        """res = <fn>(arg); clobbers the routines' window, s78..s85, s88, s89, s96, s97 and vcc"""
+        here, ret = self.a.label("tcall"), self.a.label("tret")
+        self.a(f"""
+	v_mov_b32 v{self.t_base}, {arg}
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_branch {self.t_prefix}{fn}
+{ret}:
+	v_mov_b32 {res}, v{self.t_base}""")
+
+    def quadrant(self, x, q):
+        """q = iv_quadrant(x) as a float 0..3: rem_euclid(floorf(x * 2 / PI), 4), NaN -> 0 (dev_ops.hpp; interval.rs:143-147)"""
+        a = self.a
+        a(f"\tv_add_f32 {q}, {x}, {x}\n\tv_mov_b32 {T[10]}, 0x40490fdb")
+        self.div(q, T[10], q, d=T[5:10])
+        a(f"""
+	v_floor_f32 {q}, {q}
+	v_mul_f32 {T[10]}, 0.25, {q}
+	v_trunc_f32 {T[10]}, {T[10]}
+	v_fma_f32 {q}, -4.0, {T[10]}, {q}                     ; fmodf(q, 4): exact (q is an integer, 4 a power of two)
+	v_add_f32 {T[10]}, 4.0, {q}
+	v_cmp_gt_f32 vcc, 0, {q}
+	s_nop 1
+	v_cndmask_b32 {q}, {q}, {T[10]}, vcc
+	v_cmp_gt_f32 vcc, {q}, 0                              ; !(q > 0): NaN and 0 -> 0
+	s_nop 1
+	v_cndmask_b32 {q}, 0, {q}, vcc""")
+
+    def b_trans(self, op):
+        a = self.a
+        fn = op.lower()
+        fl, fu, lq, uq, d = T[0], T[1], T[2], T[3], T[4]
+        if op in ("EXP", "ATAN", "LN", "ASIN", "ACOS", "TAN"):
+            self.tcall(fn, AL, fl)
+            self.tcall(fn, AH, fu)
+            if op == "ACOS":                      # decreasing
+                a(f"\tv_mov_b32 {RL}, {fu}\n\tv_mov_b32 {RH}, {fl}")
+            else:
+                a(f"\tv_mov_b32 {RL}, {fl}\n\tv_mov_b32 {RH}, {fu}")
+            if op == "LN":                        # a.lo <= 0 -> NaN
+                a(f"\tv_cmp_ge_f32_e64 {S_M[0]}, 0, {AL}")
+                self.nan_out(S_M[0])
+            elif op in ("ASIN", "ACOS"):          # a.lo < -1 || a.hi > 1 -> NaN
+                a(f"\tv_cmp_gt_f32_e64 {S_M[0]}, -1.0, {AL}\n\tv_cmp_gt_f32_e64 {S_M[1]}, {AH}, 1.0\n\ts_nop 0\n\ts_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}")
+                self.nan_out(S_M[0])
+            elif op == "TAN":                     # hi - lo >= PI -> NaN; tan(hi) >= tan(lo) ? [l, u] : NaN
+                a(f"""
+	v_sub_f32 {d}, {AH}, {AL}
+	v_mov_b32 {T[10]}, 0x40490fdb
+	v_cmp_ge_f32_e64 {S_M[0]}, {d}, {T[10]}
+	v_cmp_nge_f32_e64 {S_M[1]}, {fu}, {fl}
+	s_nop 0
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}""")
+                self.nan_out(S_M[0])
+            return
+        # SIN / COS (iv_sincos): the function at both ends, the quadrants of both ends, then the table
+        self.tcall(fn, AL, fl)
+        self.tcall(fn, AH, fu)
+        self.quadrant(AL, lq)
+        self.quadrant(AH, uq)
+        if op == "COS":                           # cos(x) = sin(x + pi/2): quadrants rotated by one
+            for q in (lq, uq):
+                a(f"\tv_add_f32 {q}, 1.0, {q}\n\tv_cmp_eq_f32 vcc, 4.0, {q}\n\ts_nop 1\n\tv_cndmask_b32 {q}, {q}, 0, vcc")
+        lqd, uqd, same, c30, c12, big = S_M[0], S_M[1], S_M[2], S_M[3], S_MA, S_MB
+        a(f"""
+	v_sub_f32 {d}, {AH}, {AL}
+	v_min_f32 {T[5]}, {fl}, {fu}
+	v_max_f32 {T[6]}, {fl}, {fu}
+	v_mov_b32 {T[10]}, 0x40490fdb
+	; decreasing quadrants: 1, 2  <=>  |q - 1.5| < 1
+	v_add_f32 {T[7]}, -1.5, {lq}
+	v_add_f32 {T[8]}, -1.5, {uq}
+	v_cmp_lt_f32_e64 {lqd}, |{T[7]}|, 1.0
+	v_cmp_lt_f32_e64 {uqd}, |{T[8]}|, 1.0
+	v_cmp_eq_f32_e64 {same}, {lq}, {uq}
+	v_cmp_gt_f32_e64 {c30}, {T[7]}, 1.0                  ; lq == 3  (lq - 1.5 = 1.5; 3.0 is no inline constant)
+	v_cmp_eq_f32_e64 {S_T64}, 0, {uq}
+	v_cmp_eq_f32_e64 {c12}, 1.0, {lq}
+	v_cmp_eq_f32_e64 vcc, 2.0, {uq}
+	v_cmp_ge_f32_e64 {big}, {d}, {T[10]}
+	s_and_b64 {c30}, {c30}, {S_T64}
+	s_and_b64 {c12}, {c12}, vcc
+	; increasing: (same && !lq_dec) || (3 -> 0); decreasing: (same && lq_dec) || (1 -> 2); both only while hi - lo < PI
+	s_andn2_b64 {S_T64}, {same}, {lqd}
+	s_or_b64 {c30}, {c30}, {S_T64}
+	s_and_b64 {S_T64}, {same}, {lqd}
+	s_or_b64 {c12}, {c12}, {S_T64}
+	s_andn2_b64 {c30}, {c30}, {big}
+	s_andn2_b64 {c12}, {c12}, {big}
+	; (0 | 3) -> (1 | 2): [min, 1];  (1 | 2) -> (3 | 0): [-1, max]
+	s_andn2_b64 {same}, {uqd}, {lqd}
+	s_andn2_b64 {big}, {lqd}, {uqd}
+	v_mov_b32 {RL}, -1.0
+	v_mov_b32 {RH}, 1.0""")
+        self.sel(RL, RL, T[5], same)
+        self.sel(RH, RH, T[6], big)
+        self.sel(RL, RL, fl, c30)
+        self.sel(RH, RH, fu, c30)
+        self.sel(RL, RL, fu, c12)
+        self.sel(RH, RH, fl, c12)
+        a(f"""
+	v_mov_b32 {T[10]}, 0x40c90fdb
+	v_cmp_ge_f32_e64 {S_M[0]}, {d}, {T[10]}            ; hi - lo >= TAU: [-1, 1]
+	v_cmp_u_f32_e64 {S_M[1]}, {AL}, {AH}
+	s_nop 0""")
+        self.sel(RL, RL, "-1.0", S_M[0])
+        self.sel(RH, RH, "1.0", S_M[0])
+        self.nan_out(S_M[1])
+
 
     # ---- helpers -------------------------------------------------------------------------
     def done(self):
@@ -448,6 +572,12 @@ class Tiles:
                 self.done()
             a("\ts_waitcnt lgkmcnt(0)")
             return self.ool_body(op.lower(), body)
+        if op in TRANS_UNARY:
+            def body(op=op):
+                self.b_trans(op)
+                self.done()
+            a("\ts_waitcnt lgkmcnt(0)")
+            return self.ool_body(op.lower(), body)
         if op in ("FLOOR", "CEIL"):
             ins = "v_floor_f32" if op == "FLOOR" else "v_ceil_f32"
             a(f"\ts_waitcnt lgkmcnt(0)\n\t{ins} {RL}, {AL}\n\t{ins} {RH}, {AH}")
@@ -596,7 +726,7 @@ class Tiles:
             a(f"\t.p2align {HSTRIDE_LOG2}")
             a(f".Lfh_tiles_h{i}:  ; {op}")
             base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-            if base in UNSUPPORTED:
+            if base in UNSUPPORTED and not (self.trans and base in TRANS_UNARY):
                 a(f"\ts_branch {self.next}")
             else:
                 self.handler(op)
@@ -1222,9 +1352,9 @@ class Tiles:
 		.amdhsa_system_sgpr_workgroup_id_y 0
 		.amdhsa_system_sgpr_workgroup_id_z 0
 		.amdhsa_system_vgpr_workitem_id 0
-		.amdhsa_next_free_vgpr {N_VGPR}
+		.amdhsa_next_free_vgpr {self.n_vgpr}
 		.amdhsa_next_free_sgpr 102
-		.amdhsa_accum_offset {(N_VGPR + 3) // 4 * 4}
+		.amdhsa_accum_offset {(self.n_vgpr + 3) // 4 * 4}
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
 		.amdhsa_float_round_mode_16_64 0
@@ -1234,12 +1364,25 @@ class Tiles:
 		.amdhsa_ieee_mode 1
 	.end_amdhsa_kernel
 	.text""")
+        if self.trans:
+            import gen_trans
+            gen_trans.embed(a, self.trans, v_base=self.t_base, prefix=self.t_prefix, s_map=T_SMAP)
         self.emit_forward()
         self.emit_prune(1)
         self.emit_prune(4)
 
 
-def gen_tiles(a, off):
+def gen_tiles(a, off, trans=None):
+    """fh_tiles, or with `trans` (the compiled routines' assembly) fh_tiles_t: the same kernel with handlers for the transcendental
+    opcodes (generated into a scratch buffer, its labels and name renamed)"""
+    if trans:
+        b = Asm()
+        b.uid = a.uid + 200000
+        t = Tiles(b, off, trans=trans)
+        t.emit_kernel()
+        a(b.text().replace(".Lfh_tiles_", ".Lfh_tiles_t_").replace("fh_tiles", "fh_tiles_t").replace("fh_tiles_t_t_", "fh_tiles_t_"))
+        a.uid = max(a.uid, b.uid)
+        return "fh_tiles_t", 40, t.n_vgpr, [(8, "global_buffer")] + [(4, "by_value")] * 8
     t = Tiles(a, off)
     t.emit_kernel()
     return t.name, 40, N_VGPR, [(8, "global_buffer")] + [(4, "by_value")] * 8

@@ -38,7 +38,7 @@ from gen_tiles import (Tiles, S_KERNARG, S_STATE, S_LEVEL, S_BIG, S_MAXREGS, S_M
                        S_LEN, S_RC, S_ACT, S_SIGN, S_ABSM, S_DECIDED, S_CI, S_NREGS, S_NCH, S_PRUNE, S_BASE, S_MA, S_MB, S_HBASE, S_TAPE,
                        S_REM, S_K, S_W0, S_W1, S_T0, S_OUT, S_A, S_T1, S_OP, S_RET, S_T64, S_LIVE, S_ALIAS, S_CIMM, S_KEEP, S_PC, S_SAVE,
                        S_M, S_T2, S_T3, S_SKIPR, S_SKIPC, S_SI, S_NWG, V_LANE, V_L4, VX, VY, VZ, AL, AH, BL, BH, RL, RH, T, V_CW, V_C,
-                       V_RESL, V_RESH, V_QNAN, V_SQRTC, V_ONE, SLOT_SIZE, SL_ACT, SL_XYZ, SL_RES, SL_COFF, SL_CLEN, SL_CRC)
+                       V_RESL, V_RESH, V_QNAN, V_SQRTC, V_ONE, SLOT_SIZE, SL_ACT, SL_XYZ, SL_RES, SL_COFF, SL_CLEN, SL_CRC, TRANS_UNARY, T_SMAP)
 
 SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
 
@@ -81,15 +81,18 @@ DEADV = 0xFF
 
 
 class TilesV(Tiles):
-    def __init__(self, a, off, nr, ncw):
-        super().__init__(a, off)
+    def __init__(self, a, off, nr, ncw, trans=None):
+        super().__init__(a, off, trans=trans)
         self.nr, self.ncw = nr, ncw
-        self.name = f"fh_tiles_v{nr}"
+        self.name = f"fh_tiles_v{nr}" + ("_t" if trans else "")
         self.p = f".L{self.name}"
         self.next = f"{self.p}_next"
         self.CHF = N_WORK
         self.FILE = N_WORK + ncw
         self.n_vgpr = self.FILE + 2 * nr
+        if trans:       # the routines' register window behind the register file
+            self.t_base, self.t_prefix = self.n_vgpr, f"fh_ti{nr}_"
+            self.n_vgpr += 26
         self.W = (nr + 31) // 32
         self.uid = 0
 
@@ -190,6 +193,12 @@ class TilesV(Tiles):
             a("\ts_set_gpr_idx_off")
             if op == "NEG":
                 return body()
+            return self.ool_body(op.lower(), body)
+        if op in TRANS_UNARY:
+            def body(op=op):
+                self.b_trans(op)
+                self.done()
+            a("\ts_set_gpr_idx_off")
             return self.ool_body(op.lower(), body)
         if op in ("FLOOR", "CEIL"):
             ins = "v_floor_f32" if op == "FLOOR" else "v_ceil_f32"
@@ -307,7 +316,7 @@ class TilesV(Tiles):
             else:
                 op = OPS[i]
                 base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-                if base in UNSUPPORTED:
+                if base in UNSUPPORTED and not (self.trans and base in TRANS_UNARY):
                     self.dispatch()
                 else:
                     self.handler(op)
@@ -998,11 +1007,14 @@ class TilesV(Tiles):
 		.amdhsa_ieee_mode 1
 	.end_amdhsa_kernel
 	.text""")
+        if self.trans:
+            import gen_trans
+            gen_trans.embed(a, self.trans, v_base=self.t_base, prefix=self.t_prefix, s_map=T_SMAP)
         self.emit_forward()
         self.emit_prune()
 
 
-def gen_tilesv(a, off, nr, ncw):
-    t = TilesV(a, off, nr, ncw)
+def gen_tilesv(a, off, nr, ncw, trans=None):
+    t = TilesV(a, off, nr, ncw, trans=trans)
     t.emit_kernel()
     return t.name, 40, t.n_vgpr, [(8, "global_buffer")] + [(4, "by_value")] * 8

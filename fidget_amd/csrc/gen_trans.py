@@ -11,7 +11,7 @@ FUNCS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod
 MAX_V, MAX_S = 26, 10
 
 
-def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_"):
+def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None):
     def v1(m):
         n = int(m.group(1))
         assert n < MAX_V, (name, m.group(0))
@@ -26,7 +26,7 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_"):
         if n in (30, 31):
             return S_RET + (n - 30)
         assert n < MAX_S, (name, n)
-        return S_BASE + n
+        return S_BASE + n if s_map is None else s_map[n]
 
     def s1(m):
         return f"s{smap(int(m.group(1)))}"
@@ -54,12 +54,13 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_"):
     return "\n".join(out)
 
 
-def embed(a, path, v_base=V_BASE, prefix="fh_t_"):
+def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None):
     """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
-    window embeds its own copies: `s_branch` reaches 128 KB)"""
+    window embeds its own copies: `s_branch` reaches 128 KB); s_map: the ten scalar registers s0..s9 go to (default s86..s95; pairs
+    must stay even-aligned pairs), the return address always to s[96:97]"""
     txt = open(path).read()
     for f in FUNCS:
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f
         a(f"\t.p2align 6\n{prefix}{f}:")
-        a(_rename(m.group(1), f, v_base, prefix))
+        a(_rename(m.group(1), f, v_base, prefix, s_map))

@@ -112,24 +112,27 @@ def rem_euclid(a, b):
 TRANS = {"SIN": np.sin, "COS": np.cos, "TAN": np.tan, "ASIN": np.arcsin, "ACOS": np.arccos, "ATAN": np.arctan, "EXP": np.exp, "LN": np.log}
 
 
-def trans_hooks(prog):
-    """native stand-ins for the compiled routines embedded by gen_trans.py (the emulator has no f64 ISA): argument(s) in v128 (,
-    v129), result in v128 for the lanes in exec, return to s[96:97]"""
+def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96))):
+    """native stand-ins for the compiled routines embedded by gen_trans.py (the emulator has no f64 ISA): argument(s) in v<v_base> (,
+    v<v_base + 1>), result in v<v_base> for the lanes in exec, return to s[96:97]; the routines' register window and scalar
+    registers come back clobbered"""
     def mk(fn, nargs):
         def hook(w):
             m = w._bits(w.exec)
-            args = [w.v[128 + k].view(F32).copy() for k in range(nargs)]
+            args = [w.v[v_base + k].view(F32).copy() for k in range(nargs)]
             r = fn(*args).astype(F32).view(U32)
-            w.v[128][m] = r[m]
-            w.v[129:154] = 0xDEADBEEF            # the routines may clobber their whole register window
-            w.s[86:96] = 0xDEADBEEF
+            w.v[v_base][m] = r[m]
+            w.v[v_base + 1:v_base + 26] = 0xDEADBEEF            # the routines may clobber their whole register window
+            for sr in sregs:
+                w.s[sr] = 0xDEADBEEF
+            w.vcc = 0xDEADBEEFDEADBEEF
             return int(w.s[96]) | (int(w.s[97]) << 32)
         return hook
     h = {}
     for name, fn in TRANS.items():
-        h[prog.symbols["fh_t_" + name.lower()]] = mk(lambda x, fn=fn: t64(fn, x), 1)
-    h[prog.symbols["fh_t_atan2"]] = mk(lambda y, x: t64(np.arctan2, y, x), 2)
-    h[prog.symbols["fh_t_mod"]] = mk(rem_euclid, 2)
+        h[prog.symbols[prefix + name.lower()]] = mk(lambda x, fn=fn: t64(fn, x), 1)
+    h[prog.symbols[prefix + "atan2"]] = mk(lambda y, x: t64(np.arctan2, y, x), 2)
+    h[prog.symbols[prefix + "mod"]] = mk(rem_euclid, 2)
     return h
 
 
@@ -220,6 +223,53 @@ def _nan(lo, hi):
     return np.isnan(lo) | np.isnan(hi)
 
 
+def _iv_quadrant(x):
+    """dev_ops.hpp iv_quadrant (interval.rs:143-147): rem_euclid(floorf(x * 2 / PI), 4) as u8, NaN -> 0"""
+    PI = F32(3.14159274101257324)
+    q = rem_euclid(np.floor(((x * F32(2)).astype(F32) / PI).astype(F32)).astype(F32), F32(4))
+    return np.where(q > 0, q, F32(0)).astype(np.int64)
+
+
+def _iv_trans(name, al, ah):
+    """interval rules of the transcendental opcodes (types/interval.rs:136-302 as dev_ops.hpp iv_sincos .. iv_ln restates them)"""
+    NAN = F32(np.nan)
+    PI, TAU = F32(3.14159274101257324), F32(6.28318548202514648)
+    f = lambda x: t64(TRANS[name], x)
+    fl, fu = f(al), f(ah)
+    if name in ("EXP", "ATAN"):
+        return fl, fu
+    if name == "LN":
+        bad = al <= 0
+        return np.where(bad, NAN, fl), np.where(bad, NAN, fu)
+    if name in ("ASIN", "ACOS"):
+        bad = (al < -1) | (ah > 1)
+        lo, hi = (fl, fu) if name == "ASIN" else (fu, fl)
+        return np.where(bad, NAN, lo), np.where(bad, NAN, hi)
+    d = (ah - al).astype(F32)
+    if name == "TAN":
+        bad = (d >= PI) | ~(fu >= fl)
+        return np.where(bad, NAN, fl), np.where(bad, NAN, fu)
+    lq, uq = _iv_quadrant(al), _iv_quadrant(ah)
+    if name == "COS":
+        lq, uq = (lq + 1) & 3, (uq + 1) & 3
+    n = len(al)
+    lo, hi = np.full(n, -1, F32), np.full(n, 1, F32)
+    dec_l, dec_u = (lq == 1) | (lq == 2), (uq == 1) | (uq == 2)
+    small = ~(d >= PI)
+    inc = (((lq == uq) & ~dec_l) | ((lq == 3) & (uq == 0))) & small
+    dec = (((lq == uq) & dec_l) | ((lq == 1) & (uq == 2))) & small
+    up, down = ~dec_l & dec_u, dec_l & ~dec_u
+    lo = np.where(up, _rmin(fl, fu), lo); hi = np.where(down, _rmax(fl, fu), hi)
+    lo = np.where(inc, fl, lo); hi = np.where(inc, fu, hi)
+    lo = np.where(dec, fu, lo); hi = np.where(dec, fl, hi)
+    single = al == ah
+    lo = np.where(single, fl, lo); hi = np.where(single, fl, hi)
+    full = (d >= TAU)
+    lo = np.where(full, F32(-1), lo); hi = np.where(full, F32(1), hi)
+    nn = np.isnan(al) | np.isnan(ah)
+    return np.where(nn, NAN, lo).astype(F32), np.where(nn, NAN, hi).astype(F32)
+
+
 def ref_interval(tape, inputs, n):
     """inputs: slot -> (lo[n], hi[n]).  Returns (result lo, hi, choices [n_choice_ops][n] u8, {slot: (lo, hi)} of all outputs)."""
     regs = {}
@@ -273,6 +323,8 @@ def ref_interval(tape, inputs, n):
                     zero = (al == 0) & (ah == 0)
                     first = ~contains & ~_nan(al, ah)
                     r = (np.where(first, F32(0), np.where(zero, F32(1), F32(0))), np.where(first, F32(0), F32(1)))
+                elif name in TRANS:
+                    r = _iv_trans(name, al, ah)
                 else:
                     raise NotImplementedError(name)
                 regs[ro] = (r[0].astype(F32), r[1].astype(F32))

@@ -14,8 +14,12 @@ from emu_util import E, F32, U32
 from conftest import model_path
 from test_render_random import build
 
-N_VGPR = {"fh_tiles": 84, "fh_tiles_v32": 128, "fh_tiles_v64": 208}
-LIMITS = {"fh_tiles": (128, 4096), "fh_tiles_v32": (32, 256), "fh_tiles_v64": (64, 512)}
+N_VGPR = {"fh_tiles": 84, "fh_tiles_v32": 128, "fh_tiles_v64": 208, "fh_tiles_t": 110, "fh_tiles_v32_t": 154, "fh_tiles_v64_t": 234}
+LIMITS = {"fh_tiles": (128, 4096), "fh_tiles_v32": (32, 256), "fh_tiles_v64": (64, 512), "fh_tiles_t": (128, 4096), "fh_tiles_v32_t": (32, 256),
+          "fh_tiles_v64_t": (64, 512)}
+# the *_t kernels (handlers for the transcendental opcodes): where the compiled routines sit in each (gen_tiles.py / gen_tilesv.py)
+T_HOOKS = {"fh_tiles_t": ("fh_til_", 84), "fh_tiles_v32_t": ("fh_ti32_", 128), "fh_tiles_v64_t": ("fh_ti64_", 208)}
+T_SREGS = (78, 79, 80, 81, 82, 83, 84, 85, 88, 89)
 ARENA_OPS = 1 << 17
 
 
@@ -46,13 +50,14 @@ def run_tiles(kernel, tape, xyz, in_kind, n_regs, n_choices, act=(1 << 64) - 1, 
             st.f32(off["P.in_value"] + 4 * s, in_value[s])
     a_st = mem.map(st.b, "state")
     mr, mc = limits or LIMITS[kernel]
-    if kernel == "fh_tiles":
+    if kernel in ("fh_tiles", "fh_tiles_t"):
         mr, mc = max(n_regs, 32), max(n_choices, 256)
     ka = np.zeros(10, U32)
     ka[0], ka[1] = a_st & 0xFFFFFFFF, a_st >> 32
     ka[2:10] = [level, 0, mr, mc, 1, 0, skip[0], skip[1]]
-    lds = mr * 512 + ((mc + 15) // 16) * 256 + mr * 64 + 256 if kernel == "fh_tiles" else 0
-    w = E.launch(U.program(), mem, kernel, ka.tobytes(), 1, lds_bytes=max(lds, 16), n_vgpr=N_VGPR[kernel])[0]
+    lds = mr * 512 + ((mc + 15) // 16) * 256 + mr * 64 + 256 if kernel in ("fh_tiles", "fh_tiles_t") else 0
+    hooks = U.trans_hooks(U.program(), T_HOOKS[kernel][0], T_HOOKS[kernel][1], T_SREGS) if kernel in T_HOOKS else None
+    w = E.launch(U.program(), mem, kernel, ka.tobytes(), 1, lds_bytes=max(lds, 16), n_vgpr=N_VGPR[kernel], hooks=hooks)[0]
     g = lambda k: slot.b[40 + k * 256: 40 + (k + 1) * 256]
     return dict(res=(g(9).view(F32).copy(), g(10).view(F32).copy()), coff=g(11).view(U32).copy(), clen=g(12).view(U32).copy(),
                 crc=g(13).view(U32).copy(), arena=arena, wave=w, head=int(st.get_u32(off["arena_head"])[0]), head0=head0,
@@ -351,3 +356,38 @@ def test_v64_exports_choices_of_parents_that_carry_links():
             got = (words[q >> 4] >> U32((q & 15) * 2)) & U32(3)
             assert (got[pruned] == ch[q][pruned]).all(), f"choice {q}"
         assert (words[(nch + 15) // 16:] == 0xDEADBEEF).all()
+
+
+def trans_shape(which):
+    """shapes with the transcendental opcodes, every interval rule of types/interval.rs:136-302 exercised over the boxes below"""
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    if which == 0:      # gyroid-like: sin / cos of scaled axes (quadrant tables, the >= TAU and >= PI cases at large scales)
+        n = c.sub(c.add(c.add(c.mul(c.sin(c.mul(x, 7.0)), c.cos(c.mul(y, 5.0))), c.mul(c.sin(c.mul(y, 2.5)), c.cos(c.mul(z, 11.0)))),
+                        c.min(c.sin(c.mul(z, 0.7)), c.cos(x))), 0.2)
+    elif which == 1:    # exp / ln / atan, a union with a sphere
+        r2 = c.add(c.add(c.square(x), c.square(y)), c.square(z))
+        n = c.min(c.sub(c.exp(c.neg(r2)), 0.5), c.add(c.ln(c.add(r2, 0.05)), c.atan(c.mul(x, 4.0))))
+    else:               # tan / asin / acos: domains left on purpose in part of the boxes
+        n = c.max(c.sub(c.tan(c.mul(x, 1.3)), c.asin(c.mul(y, 1.4))), c.sub(c.acos(c.mul(z, 1.2)), 1.0))
+    sh = F.Shape(c, n)
+    ik = [3] * 16
+    for a in range(3):
+        s_ = sh.axis_index(a)
+        if s_ >= 0:
+            ik[s_] = a
+    return sh, U.shape_tape(sh), ik
+
+
+@pytest.mark.parametrize("kernel", ["fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t"])
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_transcendental_interval_handlers(kernel, which):
+    """the *_t tile kernels: interval sin cos tan asin acos atan exp ln (dev_ops.hpp iv_sincos .. iv_ln around the compiled f32
+    routines) - results, choices and pruned child tapes against the numpy restatement, small and large boxes (a box many periods wide
+    is [-1, 1]; one inside a quadrant is monotonic; domains of asin / acos / ln / tan left in some children)"""
+    sh, tape, ik = trans_shape(which)
+    if sh.slot_count() > LIMITS[kernel][0] or sh.choice_count() > LIMITS[kernel][1]:
+        pytest.skip("tape outside this kernel's register file")
+    for center, half in (((0.1, -0.2, 0.3), 0.5), ((-0.3, 0.25, 0.0), 0.06), ((0.4, 0.4, -0.4), 2.5), ((0.7, -0.6, 0.2), 0.2)):
+        check_slot(kernel, tape, children(center, half), ik, sh.slot_count(), sh.choice_count())

@@ -387,3 +387,34 @@ def test_assembly_normals_are_the_hip_kernels(name, size):
             b = F.render3d(p, size, world_to_model=cam)[0]
         assert (a["depth"] == b["depth"]).all() and (a["depth"] > 0).any()
         assert same_bits_f32(a["normal"], b["normal"]), f"{name}: {(a['normal'].view(np.uint32) != b['normal'].view(np.uint32)).any(axis=2).sum()} normals differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("bear.vm", 256), ("bear.vm", 512), ("gyroid-sphere.vm", 256)])
+def test_assembly_tile_stage_of_transcendental_tapes(name, size):
+    """fh_tiles_t / fh_tiles_v32_t / fh_tiles_v64_t (the tile kernels with interval sin cos tan asin acos atan exp ln: gen_tiles.py
+    b_trans around the compiled routines) against the HIP C++ tile stage k_teval3d they replace for such tapes (option
+    no_asm_tiles_t): the same image, and the same tapes for the tiles below the root level, word for word - also under a perspective
+    camera.  The 2D renderer goes through the same kernels."""
+    import fidget_amd as F
+    hip = F.HipContext(0)
+    p = F.Shape.from_vm(model_path(name), hip=hip)
+
+    def tiles():
+        g, _ = hip.groups(0, 1)
+        return {(int(e["x"]), int(e["y"]), int(e["z"])): (hip.arena_ops(int(e["off"]), int(e["len"])).tobytes(), int(e["regs"]), int(e["choices"])) for e in g}
+
+    for cam in (None, bench_camera(0.3)):
+        a = F.render3d(p, size, world_to_model=cam)[0]
+        ta = tiles()
+        with hip.options(no_asm_tiles_t=1):
+            b = F.render3d(p, size, world_to_model=cam)[0]
+            tb = tiles()
+        assert (a["depth"] == b["depth"]).all() and (a["depth"] > 0).any()
+        assert same_bits_f32(a["normal"], b["normal"])
+        assert ta.keys() == tb.keys() and len(ta) > 0
+        assert all(ta[k] == tb[k] for k in ta), f"{sum(ta[k] != tb[k] for k in ta)} of {len(ta)} level-1 tapes differ"
+    a2 = F.render2d(p, size)[0]
+    with hip.options(no_asm_tiles_t=1):
+        b2 = F.render2d(p, size)[0]
+    assert (a2.view(np.uint32) == b2.view(np.uint32)).all() or same_bits_f32(a2, b2)
