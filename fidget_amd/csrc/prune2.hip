@@ -18,9 +18,11 @@
 //   B2 the kept ops' positions in the child tape (prefix population counts), per kept op its operands' positions and whether it
 //      is their last use (an atomic maximum per value);
 //   B3 the one sequential step, in tape order over the KEPT ops only: registers are returned at a value's last use and taken at
-//      its definition (lowest free first) - linear scan, optimal for a straight-line program.  The loop lives in SGPRs and
-//      cross-lane reads: the kept ops' records come 64 at a time into VGPRs, the registers of the last 256 values sit in four
-//      VGPRs (older values: LDS), nothing waits for memory;
+//      its definition (lowest free first) - linear scan, optimal for a straight-line program.  Nothing is looked up in the loop: a
+//      value that gets register r posts "free r" to the op where it dies (that op's record, or - for an op of the same 64-op batch -
+//      the batch's copy in a VGPR), and every op starts by returning what was posted to it.  The loop is inline assembly
+//      (p2_scan_batch: SGPRs, v_readlane / v_writelane, one LDS byte store per value that outlives its batch; 33 instructions per
+//      kept op), nothing in it waits for memory;
 //   B4 the child's ops, 64 at a time.
 // No register copies are ever emitted: a consumer of a decided choice reads the surviving operand's register directly.  The
 // tapes differ from fh_prune1's (which re-uses the parent's structure and inserts a copy where an operand outlives the choice
@@ -73,17 +75,6 @@ static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices, uint
 namespace fhp2 {
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) { return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32); }
-__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
-// v_writelane_b32: `old` with lane `lane` replaced by `v` (both wave-uniform; the lane select goes through M0: two SGPR operands
-// would break the constant-bus rule).  (This compiler has no builtin for it.)
-__device__ __forceinline__ uint32_t wlane(uint32_t v, uint32_t lane, uint32_t old) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(rfl(v)), "s"(rfl(lane)) : "m0");
-#else
-    (void)v; (void)lane;
-#endif
-    return old;
-}
 __device__ __forceinline__ uint32_t excl_sum(uint32_t v, uint32_t lane, uint32_t& total) {
     uint32_t x = v;
 #pragma unroll
