@@ -1188,9 +1188,14 @@ __global__ void k_classify3d(FhRenderState* S, int merge01) {
     const FhLeafRef* col = S->leaf_table + fi;  // [layer][footprint]
     uint32_t mx = 0;
     bool any = false;
-    for (uint32_t l = 0; l < layers && fi < fw * fh; l++) {
-        const uint32_t id = col[(size_t)l * fw * fh].id;
-        if (id) { any = true; mx = max(mx, (uint32_t)S->leaves[id - 1].tape.n_regs); }
+    // (the table entry carries the leaf's register count beside its number: no dependent load of the leaf record per layer - a
+    // z-slab of four root-tile layers has 64 of them -, and the loads of a column are independent of each other)
+    if (fi < fw * fh) {
+#pragma unroll 8
+        for (uint32_t l = 0; l < layers; l++) {
+            const FhLeafRef e = col[(size_t)l * fw * fh];
+            if (e.id) { any = true; mx = max(mx, e.len_regs >> 24); }
+        }
     }
     // one atomic per wave and class instead of one per footprint
     // merge01: the assembly leaf kernel picks the register-file shape per leaf, one list for <= 32 registers
