@@ -161,6 +161,7 @@ class Interp:
     def __init__(self, a, name, nr, zb, kind, off, trans=False):
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
+        self.t_base = 128    # ... whose register window starts here (behind the register file)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.hl = HSTRIDE_LOG2
         self.next = f".L{name}_next"
@@ -450,9 +451,9 @@ class Interp:
                 self.read_a(VT)
                 self.idx_off()
                 for j in Z:
-                    a(f"\tv_mov_b32 v128, {VT[j]}")
+                    a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
                     self.call(fn)
-                    a(f"\tv_mov_b32 {VU[j]}, v128")
+                    a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         if op == "RAND":
@@ -483,9 +484,9 @@ class Interp:
                         self.pcg(VW[j], VW[j])
                 else:
                     for j in Z:
-                        a(f"\tv_mov_b32 v128, {A[j]}\n\tv_mov_b32 v129, {B[j]}")
+                        a(f"\tv_mov_b32 v{self.t_base}, {A[j]}\n\tv_mov_b32 v{self.t_base + 1}, {B[j]}")
                         self.call(base.lower())
-                        a(f"\tv_mov_b32 {VW[j]}, v128")
+                        a(f"\tv_mov_b32 {VW[j]}, v{self.t_base}")
                 self.write_out(VW)
             return self.out_of_line(op.lower(), body)
         if base in ("ADD", "SUB", "MUL") and form != "RR":
@@ -890,8 +891,12 @@ def gen_columns(a, variants, off, trans=None):
 def _gen_columns_body(a, variants, off, kname, trans):
     o = off
     m = S_MAT
-    nvg = 160 if trans else FILE + 64      # (the routines' register window v128..v153)
+    file_regs = max(nr * zb for nr, zb in variants)
+    t_base = FILE + file_regs                # the routines' register window: 26 VGPRs behind the register file
+    nvg = t_base + 26 if trans else FILE + file_regs
     its = [Interp(a, f"{kname}_{nr}x{zb}", nr, zb, "columns", off, trans=bool(trans)) for nr, zb in variants]
+    for it in its:
+        it.t_base = t_base
     inplace_mask = 0
     for k, op in enumerate(OPS):
         if op in Interp.INPLACE:
@@ -1230,7 +1235,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
     kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans)
+        gen_trans.embed(a, trans, v_base=t_base)
     for it in its:
         it.emit()
     return kname, nvg
@@ -1381,7 +1386,11 @@ def main():
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
     ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
-        n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off, trans=sys.argv[3])
+        # (a register file of 128 VGPRs here - 16 registers x 8 voxels, 32 x 4: the tapes that carry these opcodes are smooth blends
+        # that prune little - bear.vm's leaves keep 350-430 ops in 17-23 registers -, and two passes of four voxels pay the per-op
+        # dispatch half as often as four passes of two: 2.80 -> 2.40 ms per 512^3 frame; 218 VGPRs with the routines' window, two
+        # waves per SIMD as with 160)
+        n, nvg = gen_columns(a, ((16, 8), (32, 4), (32, 2)), off, trans=sys.argv[3])
         ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)

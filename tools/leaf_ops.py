@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import fidget_amd as F
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+model = sys.argv[2] if len(sys.argv) > 2 else "prospero.vm"
 hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
-shape = F.Shape.from_vm(os.path.join(ROOT, "models", "prospero.vm"), hip=hip)
+shape = F.Shape.from_vm(os.path.join(ROOT, "models", model), hip=hip)
 out = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
 F.render3d(shape, n, out=out)
 hip.sync()
@@ -33,6 +34,7 @@ for i in pick:
         if has_a and a[k] == o[k]: inpl_a[nm] += 1
         elif 22 <= op[k] < 34 and w1[k] == o[k]: inpl_b[nm] += 1
 tot = sum(cnt.values())
+print(model, n, "leaves in the last slab", len(lv), "tape length p50/p90/max", np.percentile(lv["len"], [50, 90, 100]), "registers p50/p90/max", np.percentile(lv["regs"], [50, 90, 100]))
 print("ops sampled", tot, "from", len(pick), "leaves")
 for nm, c in cnt.most_common():
     print(f"{nm:12s} {100*c/tot:5.1f} %   out==a {100*inpl_a[nm]/c:5.1f} %   out==b {100*inpl_b[nm]/c:5.1f} %")
