@@ -266,3 +266,44 @@ def test_block_of_leaves_with_tapes_requested_ahead():
             hit = e != 0
             want[hit] = (e[hit] & ~np.uint64(0xFFFFFFFF)) | np.uint64(i + 1)
         assert (got == want).all()
+
+
+def wide_trans_shape():
+    """a smooth blend in the manner of bear.vm - 18 exp(-k r_i^2) terms, each used twice (a sum of them over a sum of pairwise
+    products), so that all are alive at once: 22 registers, fh_columns_t's 32 x 4 class (two passes of four voxels per lane)"""
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    nt, t = 18, []
+    for i in range(nt):
+        cx, cy, cz = 0.3 * np.cos(i), 0.3 * np.sin(2 * i), 0.2 * np.cos(3 * i + 1)
+        r2 = c.add(c.add(c.square(c.sub(x, float(cx))), c.square(c.sub(y, float(cy)))), c.square(c.sub(z, float(cz))))
+        t.append(c.exp(c.mul(r2, -3.0 - 0.5 * i)))
+    A = t[0]
+    for k in range(1, nt):
+        A = c.add(A, t[k])
+    B = c.mul(t[0], t[nt - 1])
+    for k in range(1, nt - 1):
+        B = c.add(B, c.mul(t[k], t[nt - 1 - k]))
+    n = c.sub(c.div(A, c.add(B, 0.1)), c.sqrt(c.add(c.ln(c.add(c.square(x), 1.5)), c.sin(y))))
+    sh = F.Shape(c, n)
+    ik = [3] * 16
+    for a in range(3):
+        s = sh.axis_index(a)
+        if s >= 0:
+            ik[s] = a
+    return sh, U.shape_tape(sh), ik
+
+
+def test_transcendental_leaf_kernel_32x4_class():
+    sh, tape, ik = wide_trans_shape()
+    assert 16 < sh.slot_count() <= 32, sh.slot_count()
+    hits = misses = 0
+    for mat in (AFFINE, ROTATED):
+        for leaf in ((0, 8, 0), (8, 0, 8), (8, 8, 0)):
+            got, _ = run_columns(tape, sh.slot_count(), ik, mat, leaf, kernel="fh_columns_t")
+            want = expect(tape, ik, mat, leaf, 16)
+            assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+            hits += int((want != 0).sum()); misses += int((want == 0).sum())
+    print("pixels hit", hits, "not hit", misses)
+    assert hits > 0

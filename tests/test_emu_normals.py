@@ -72,6 +72,23 @@ def ref_grad(tape, inputs, n):
                 elif name == "CEIL": r = G.one(np.ceil(v), n)
                 elif name == "ROUND": r = G.one(U._round(v), n)
                 elif name == "NOT": r = G.one((v == 0).astype(F32), n)
+                elif name in U.TRANS:      # dev_ops.hpp GRAD::unary, FULL
+                    f = lambda fn, x=v: U.t64(fn, x)
+                    mulk = lambda c: [(a.c[k] * c).astype(F32) for k in (1, 2, 3)]
+                    divk = lambda c, neg=False: [((-a.c[k] if neg else a.c[k]) / c).astype(F32) for k in (1, 2, 3)]
+                    if name == "SIN": r = G(f(np.sin), *mulk(f(np.cos)))
+                    elif name == "COS": r = G(f(np.cos), *mulk((-f(np.sin)).astype(F32)))
+                    elif name == "TAN":
+                        c0 = f(np.cos)
+                        r = G(f(np.tan), *divk((c0 * c0).astype(F32)))
+                    elif name in ("ASIN", "ACOS"):
+                        rt = np.sqrt((F32(1) - (v * v).astype(F32)).astype(F32)).astype(F32)
+                        r = G(f(U.TRANS[name]), *divk(rt, neg=name == "ACOS"))
+                    elif name == "ATAN": r = G(f(np.arctan), *divk(((v * v).astype(F32) + F32(1)).astype(F32)))
+                    elif name == "EXP":
+                        e = f(np.exp)
+                        r = G(e, *[(e * a.c[k]).astype(F32) for k in (1, 2, 3)])
+                    else: r = G(f(np.log), *divk(v))
                 else: raise NotImplementedError(name)
                 regs[ro] = r
             else:
@@ -101,7 +118,7 @@ def xf_grad(m, px, py, pz):
     return [g_div(r[i], r[3]) for i in range(3)]
 
 
-def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20):
+def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel="fh_normals"):
     """tapes: [(ops, n_regs)]; hits: {(px, py): (leaf index, depth)}.  Returns (zbuf, normals) after one launch over all footprints."""
     off = U.offsets()
     mem = E.Memory()
@@ -134,7 +151,9 @@ def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20):
             slot[k] = s_
     slots = sum((0xFF if slot[ax] < 0 else slot[ax]) << (8 * ax) for ax in range(3))
     ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, 3, slots, z_lo, z_hi, 0, 0], U32)
-    E.launch(U.program(), mem, "fh_normals", ka.tobytes(), 3, lds_bytes=16, n_vgpr=192, wg_y_sgpr=None)
+    trans = kernel == "fh_normals_t"
+    E.launch(U.program(), mem, kernel, ka.tobytes(), 3, lds_bytes=16, n_vgpr=218 if trans else 192, wg_y_sgpr=None,
+             hooks=U.trans_hooks(U.program(), "fh_tn_", 192) if trans else None)
     return zbuf, normals.reshape(size * size, 3)
 
 
@@ -191,3 +210,34 @@ def test_normals_of_a_prospero_leaf_parent():
     want_z, want_n = expect([(tape, regs)], ik, mat, hits, 16)
     assert (got_z == want_z).all() and same(got_n, want_n)
     assert np.isfinite(want_n[want_z != 0].astype(np.float64)).all() is not None
+
+
+def trans_grad_shape(which):
+    import fidget_amd as F
+    c = F.Context()
+    x, y, z = c.x(), c.y(), c.z()
+    if which == 0:
+        n = c.sub(c.add(c.mul(c.sin(c.mul(x, 3.0)), c.cos(c.mul(y, 2.0))), c.mul(c.exp(c.mul(z, -0.7)), c.atan(c.add(x, y)))), 0.2)
+    else:
+        n = c.add(c.sub(c.tan(c.mul(x, 0.4)), c.asin(c.mul(y, 0.3))), c.mul(c.acos(c.mul(z, 0.3)), c.ln(c.add(c.square(x), 0.5))))
+    sh = F.Shape(c, n)
+    ik = [3] * 16
+    for a in range(3):
+        s_ = sh.axis_index(a)
+        if s_ >= 0:
+            ik[s_] = a
+    return sh, U.shape_tape(sh), ik
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("mat", [AFFINE, PERSPECTIVE], ids=["affine", "perspective"])
+def test_normals_with_transcendental_opcodes(which, mat):
+    """fh_normals_t: gradients of sin cos tan asin acos atan exp ln as dev_ops.hpp GRAD has them, the values themselves by the compiled
+    routines (stood in for natively in the emulator: what is tested is the call sequence, the register window behind the 32-register
+    gradient file, and the derivative formulas around the calls)"""
+    sh, tape, ik = trans_grad_shape(which)
+    rng = np.random.default_rng(which)
+    hits = {(int(rng.integers(0, 16)), int(rng.integers(0, 16))): (0, int(rng.integers(1, 15))) for _ in range(50)}
+    got_z, got_n = run_normals([(tape, sh.slot_count())], ik, mat, hits, kernel="fh_normals_t")
+    want_z, want_n = expect([(tape, sh.slot_count())], ik, mat, hits, 16)
+    assert (got_z == want_z).all() and same(got_n, want_n), f"{(got_n.view(U32) != want_n.view(U32)).any(axis=1).sum()} normals differ"
