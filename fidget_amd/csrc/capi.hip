@@ -90,7 +90,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -2087,12 +2087,55 @@ static uint32_t mesh_part_mask(uint32_t part, uint32_t n_parts) {
 }
 struct MeshTimes { bool on; double t_start, t_cells, t_leaf, t_copy; uint32_t n_leaf_cells; };
 static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_mat, const float* mat, MeshTimes& T);
+// The octree assembled on the device (mesh_collapse.hpp oct_assemble; kernels in mesh.hip): arrays in HBM, one launch per pass and level
+struct OctDevX {
+    hipStream_t st;
+    std::vector<void*> owned;
+    hipError_t err = hipSuccess;
+    void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+    void* alloc(size_t b) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, b ? b : 4);
+        if (e != hipSuccess) { chk(e); return nullptr; }
+        owned.push_back(p);
+        return p;
+    }
+    void zero(void* p, size_t b) { chk(hipMemsetAsync(p, 0, b, st)); }
+    void read(void* d, const void* s, size_t b) { chk(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st)); chk(hipStreamSynchronize(st)); }
+    void kind(const fhmesh::OctLevel& D, const fhmesh::OctLevel& C, const fhmesh::OctLeaves& L, const FhMdcTable* T, uint32_t* counter, uint32_t n) {
+        if (!n) return;
+        hipLaunchKernelGGL(fhm::k_oct_kind, dim3((n + 255) / 256), dim3(256), 0, st, D, C, L, T, counter, n);
+        chk(hipGetLastError());
+    }
+    void collapse(const fhmesh::OctLevel& D, const fhmesh::OctLevel& C, const fhmesh::OctLeaves& L, const FhMdcTable* T, uint32_t n) {
+        if (!n) return;
+        hipLaunchKernelGGL(fhm::k_oct_collapse, dim3((n + 63) / 64), dim3(64), 0, st, D, C, L, T, n);
+        chk(hipGetLastError());
+    }
+    void place(const fhmesh::OctLevel& D, const fhmesh::OctLevel& C, const fhmesh::OctLeaves& L, const FhMdcTable* T, fhmesh::Cell* cells, fhmesh::V3* verts, const float* mat, uint32_t n) {
+        if (!n) return;
+        hipLaunchKernelGGL(fhm::k_oct_place, dim3((n + 255) / 256), dim3(256), 0, st, D, C, L, T, cells, verts, mat, n);
+        chk(hipGetLastError());
+    }
+    void leaf_verts(const fhmesh::OctLeaves& L, fhmesh::V3* verts, const float* mat, uint32_t n) {
+        if (!n) return;
+        hipLaunchKernelGGL(fhm::k_oct_leaf_verts, dim3((n + 255) / 256), dim3(256), 0, st, L, verts, mat, n);
+        chk(hipGetLastError());
+    }
+    void release() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
+};
+static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
+                                       bool has_mat, const float* mat, MeshTimes& T);
 enum MeshMode { MESH_SAMPLE, MESH_BUILD, MESH_PART };
 static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, MeshMode mode, uint32_t part, uint32_t n_parts, fhip_mesh** out) {
     if (!out) return FHIP_ERR_BAD_TAPE;
     *out = nullptr;
-    const bool assemble = mode == MESH_BUILD, keep = mode != MESH_SAMPLE;
+    const bool assemble = mode == MESH_BUILD;
+    // fhip_mesh_build assembles the octree on the device: the levels' arrays and the leaf records stay in HBM, the host gets the finished
+    // octree for the dual walk.  (Option mesh_device_assembly 0: on the host's threads from copies of both, as fhip_mesh_merge does.)
+    const bool dev_asm = assemble && n_parts == 1 && ctx->opt.mesh_device_assembly;
+    const bool keep = mode != MESH_SAMPLE && !dev_asm;
     if (depth > 20) return fail(ctx, FHIP_ERR_UNSUPPORTED, "octree depth above 20");
     if (n_parts < 1 || n_parts > 8 || part >= n_parts) return fail(ctx, FHIP_ERR_UNSUPPORTED, "mesh parts: 1..8, part < n_parts");
     const fh::HostTape& t = tape->t;
@@ -2130,7 +2173,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
     DevBuf bufs[2], counters, table, leaves, d_cls, d_slot;
-    auto cleanup = [&] { bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release(); };
+    std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
+    if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
+    std::vector<uint32_t> lv_n_amb;
+    auto cleanup = [&] {
+        bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
+        for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
+    };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
     MESH_TRY(counters.ensure(16));
     FhMeshCell root;
@@ -2145,12 +2194,17 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         const uint64_t n64 = d == 0 ? 1 : (uint64_t)n_in * 8;
         if (n64 > (1ull << 30)) { cleanup(); delete M; return fail(ctx, FHIP_ERR_OVERFLOW, "octree level above 2^30 cells"); }
         const uint32_t n = (uint32_t)n64;
-        MESH_TRY(bufs[cur ^ 1].ensure((size_t)n * sizeof(FhMeshCell)));
+        DevBuf& out_cells = dev_asm ? lv_amb[d] : bufs[cur ^ 1];
+        const void* in_cells = (dev_asm && d > 0) ? lv_amb[d - 1].p : bufs[cur].p;
+        MESH_TRY(out_cells.ensure((size_t)n * sizeof(FhMeshCell)));
         MESH_TRY(hipMemsetAsync(counters.p, 0, 16, ctx->stream));
         if (keep) { MESH_TRY(d_cls.ensure(n)); MESH_TRY(d_slot.ensure((size_t)n * 4)); }
+        if (dev_asm) { MESH_TRY(lv_cls[d].ensure(n)); MESH_TRY(lv_slot[d].ensure((size_t)n * 4)); }
+        uint8_t* const cls_p = dev_asm ? (uint8_t*)lv_cls[d].p : (keep ? (uint8_t*)d_cls.p : nullptr);
+        uint32_t* const slot_p = dev_asm ? (uint32_t*)lv_slot[d].p : (keep ? (uint32_t*)d_slot.p : nullptr);
         const uint32_t child_mask = (d == 1 && n_parts > 1) ? mesh_part_mask(part, n_parts) : 0xFFu;      // (level 1 = the root's 8 children)
-        hipLaunchKernelGGL(fhm::k_mesh_cells, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)bufs[cur].p, n, d == 0 ? 0 : 1,
-                           (FhMeshCell*)bufs[cur ^ 1].p, (uint32_t*)counters.p, n, keep ? (uint8_t*)d_cls.p : nullptr, keep ? (uint32_t*)d_slot.p : nullptr, child_mask);
+        hipLaunchKernelGGL(fhm::k_mesh_cells, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)in_cells, n, d == 0 ? 0 : 1,
+                           (FhMeshCell*)out_cells.p, (uint32_t*)counters.p, n, cls_p, slot_p, child_mask);
         MESH_TRY(hipGetLastError());
         uint32_t c[4];
         MESH_TRY(hipMemcpyAsync(c, counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -2165,16 +2219,32 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         M->per_level.push_back(n_here);
         cur ^= 1;
         n_in = c[0];
+        lv_n_amb.push_back(c[0]);
         if (d == depth) n_leaf_cells = c[0];
         if (n_in == 0) break;
     }
     M->ambiguous_leaves = n_leaf_cells;
     t_cells = now() - t_start;
-    if (n_leaf_cells) {
-        FhMdcTable T;
-        build_mdc_table(T);
-        MESH_TRY(table.ensure(sizeof(T)));
-        MESH_TRY(hipMemcpyAsync(table.p, &T, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    FhMdcTable mdc;
+    if (n_leaf_cells || dev_asm) {
+        build_mdc_table(mdc);
+        MESH_TRY(table.ensure(sizeof(mdc)));
+        MESH_TRY(hipMemcpyAsync(table.p, &mdc, sizeof(mdc), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_leaf_cells && dev_asm) {      // the records stay in HBM
+        MESH_TRY(leaves.ensure((size_t)n_leaf_cells * sizeof(FhMeshLeaf)));
+        const uint32_t CH = 1u << 19;
+        const void* const leaf_cells = lv_amb[depth].p;
+        for (uint32_t off = 0; off < n_leaf_cells; off += CH) {
+            const uint32_t cnt = std::min<uint32_t>(CH, n_leaf_cells - off);
+            hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)leaf_cells + off, cnt,
+                               (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off);
+            MESH_TRY(hipGetLastError());
+            hipLaunchKernelGGL(fhm::k_mesh_leaf_qef, dim3((cnt + WAVE - 1) / WAVE), dim3(WAVE), 0, ctx->stream, (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off, cnt);
+            MESH_TRY(hipGetLastError());
+        }
+        if (times) { MESH_TRY(hipStreamSynchronize(ctx->stream)); t_leaf = now() - t_start - t_cells; }
+    } else if (n_leaf_cells) {
         MESH_TRY(leaves.ensure((size_t)n_leaf_cells * sizeof(FhMeshLeaf)));
         // in chunks: the records of chunk k travel to the host (second stream) while chunk k + 1 is sampled
         const size_t leaf_bytes = (size_t)n_leaf_cells * sizeof(FhMeshLeaf);
@@ -2201,6 +2271,8 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p + off, cnt,
                                (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off);
             chk(hipGetLastError());
+            hipLaunchKernelGGL(fhm::k_mesh_leaf_qef, dim3((cnt + WAVE - 1) / WAVE), dim3(WAVE), 0, ctx->stream, (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off, cnt);
+            chk(hipGetLastError());
             hipEvent_t ev = nullptr;
             chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             if (ev) evs.push_back(ev);
@@ -2213,6 +2285,18 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         chk(hipStreamSynchronize(copy_stream));
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
         MESH_TRY(first_err);
+    }
+    if (dev_asm) {
+        std::vector<fhmesh::OctLevel> lv(lv_n_amb.size());
+        for (size_t d = 0; d < lv.size(); d++) {
+            lv[d].cls = (const uint8_t*)lv_cls[d].p; lv[d].slot = (const uint32_t*)lv_slot[d].p;
+            lv[d].amb = (const FhMeshCell*)lv_amb[d].p; lv[d].n_amb = lv_n_amb[d];
+        }
+        MeshTimes MT{times, t_start, t_cells, t_leaf, 0.0, n_leaf_cells};
+        MESH_TRY(mesh_assemble_device(ctx, M, depth, lv, (const FhMeshLeaf*)leaves.p, n_leaf_cells, (const FhMdcTable*)table.p, P.has_mat != 0, P.mat, MT));
+        cleanup();
+        *out = M;
+        return FHIP_OK;
     }
 #undef MESH_TRY
     cleanup();
@@ -2279,6 +2363,65 @@ static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_
     if (T.on)
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
                 depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, T.t_copy, t_asm, t_walk, now() - T.t_start);
+}
+// fhip_mesh_build's second half: the octree assembled in HBM (check_done / collapse / places, mesh_collapse.hpp), its blocks of cells and its
+// vertices copied to the context's pinned landing area - the cells first, the dual walk starts on them while the vertices are still on
+// their way - then Octree::walk_dual on the host's threads.  The leaf records (528 bytes each) never leave the device.
+static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
+                                       bool has_mat, const float* mat, MeshTimes& T) {
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    OctDevX x{ctx->stream, {}, hipSuccess};
+    float* d_mat = nullptr;
+    if (has_mat) {
+        d_mat = (float*)x.alloc(64);
+        if (d_mat) x.chk(hipMemcpyAsync(d_mat, mat, 64, hipMemcpyHostToDevice, ctx->stream));
+    }
+    fhmesh::OctOut oo;
+    const bool ok = x.err == hipSuccess && fhmesh::oct_assemble(x, depth, lv.data(), (uint32_t)lv.size(), rec, n_rec, table, d_mat, &oo);
+    if (!ok || x.err != hipSuccess) { const hipError_t e = x.err != hipSuccess ? x.err : hipErrorOutOfMemory; (void)hipStreamSynchronize(ctx->stream); x.release(); return e; }
+    const size_t cell_bytes = (size_t)oo.n_blocks * 8 * sizeof(fhmesh::Cell), vert_bytes = (size_t)oo.n_verts * sizeof(fhmesh::V3);
+    const size_t need = ((cell_bytes + 255) & ~(size_t)255) + vert_bytes + 256;
+    if (ctx->mesh_pinned_cap < need) {
+        if (ctx->mesh_pinned) (void)hipHostFree(ctx->mesh_pinned);
+        ctx->mesh_pinned = nullptr; ctx->mesh_pinned_cap = 0;
+        const hipError_t e = hipHostMalloc(&ctx->mesh_pinned, need + need / 8, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); x.release(); return e; }
+        ctx->mesh_pinned_cap = need + need / 8;
+    }
+    char* const land = (char*)ctx->mesh_pinned;
+    fhmesh::Octree o;
+    o.root = oo.root;
+    o.cells_view = (const std::array<fhmesh::Cell, 8>*)land; o.n_cells_view = oo.n_blocks;
+    o.verts_view = (const fhmesh::V3*)(land + ((cell_bytes + 255) & ~(size_t)255)); o.n_verts_view = oo.n_verts;
+    hipStream_t const copy_stream = ctx->stream2 ? ctx->stream2 : ctx->stream;
+    hipEvent_t placed = nullptr;
+    x.chk(hipEventCreateWithFlags(&placed, hipEventDisableTiming));
+    if (placed) { x.chk(hipEventRecord(placed, ctx->stream)); x.chk(hipStreamWaitEvent(copy_stream, placed, 0)); }
+    if (vert_bytes) x.chk(hipMemcpyAsync((void*)o.verts_view, oo.verts, vert_bytes, hipMemcpyDeviceToHost, copy_stream));
+    if (cell_bytes) x.chk(hipMemcpyAsync((void*)o.cells_view, oo.cells, cell_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    x.chk(hipStreamSynchronize(ctx->stream));
+    const double t_asm = now() - t0;
+    if (x.err != hipSuccess) { (void)hipStreamSynchronize(copy_stream); if (placed) (void)hipEventDestroy(placed); x.release(); return x.err; }
+    fhmesh::ParallelWalker W(o);
+    W.scratch = &ctx->mesh_first; W.scratch_cap = &ctx->mesh_first_cap;
+    hipError_t copy_err = hipSuccess;
+    bool waited = false;
+    W.verts_ready = [&] { if (!waited) { copy_err = hipStreamSynchronize(copy_stream); waited = true; } };
+    W.run();
+    W.verts_ready();
+    const double t_walk = now() - t0 - t_asm;
+    if (placed) (void)hipEventDestroy(placed);
+    x.release();
+    if (copy_err != hipSuccess) return copy_err;
+    M->octree_cells = oo.n_blocks; M->octree_verts = oo.n_verts;
+    M->vertices.swap(W.vertices);
+    M->triangles.swap(W.triangles);
+    if (T.on)
+        fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), assembly on the device + cells to the host %.4f s (%u blocks, %u vertices), "
+                        "dual walk (vertices arriving beside it) %.4f s, total %.4f s\n",
+                depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, t_asm, oo.n_blocks, oo.n_verts, t_walk, now() - T.t_start);
+    return hipSuccess;
 }
 fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {

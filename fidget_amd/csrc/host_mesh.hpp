@@ -9,6 +9,7 @@
 // Integer / topological code, plus the QEF of a collapsed cell (mesh_qef.hpp, the definition the device kernel uses too).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,13 +24,12 @@
 #include <utility>
 #include <vector>
 
+#include "mesh_collapse.hpp"
 #include "mesh_qef.hpp"
 
 namespace fhmesh {
 
-enum { AX = 1, AY = 2, AZ = 4 };
-static inline int axis_next(int a) { return (a << 1) > AZ ? AX : (a << 1); }   // types.rs Axis::next
-static inline int axis_index(int a) { return a == 1 ? 0 : (a == 2 ? 1 : 2); }
+// (AX / AY / AZ, axis_next, axis_index, to_undirected, Cell, V3, LeafIntersection, Hermite, collapsible_children: mesh_collapse.hpp)
 
 struct Tables {
     std::vector<std::vector<std::pair<uint8_t, uint8_t>>> v2e[256];   // CELL_TO_VERT_TO_EDGES
@@ -96,84 +96,16 @@ static inline const Tables& tables() {
     static const Tables* const T = build_tables();     // (initialised once, thread-safe: contexts on several host threads build meshes)
     return *T;
 }
-static inline int to_undirected(int start, int end) {     // types.rs DirectedEdge::to_undirected
-    const int t = start ^ end, u = axis_next(t), v = axis_next(u);
-    return axis_index(t) * 4 + ((start & v) ? 2 : 0) + ((start & u) ? 1 : 0);
-}
 static inline void edge_corners(int e, int* start, int* end) {   // types.rs Edge::corners
     static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}};
     const int t = FR[e / 4][0], u = ((e % 4) % 2 != 0) ? FR[e / 4][1] : 0, v = ((e % 4) / 2 != 0) ? FR[e / 4][2] : 0;
     *start = u | v; *end = t | u | v;
 }
 
-enum CellKind : uint8_t { C_INVALID = 0, C_EMPTY, C_FULL, C_BRANCH, C_LEAF };
-struct Cell {
-    uint8_t kind = C_INVALID, mask = 0;
-    uint32_t index = 0;
-    bool corner(int c) const { return kind == C_LEAF ? ((mask >> c) & 1) : kind == C_FULL; }
-};
-struct V3 { float x, y, z; };
 struct CellRef {       // CellIndex (cell.rs:87-110) without the bounds: where the cell is stored, how deep it is
     int64_t ci = -1;
     uint8_t cj = 0;
     uint32_t depth = 0;
-};
-
-static const float QEF_ERR_EMPTY = -1.0f, QEF_ERR_INVALID = -2.0f;
-struct LeafIntersection { float pos[4] = {0, 0, 0, 0}, grad[4] = {0, 0, 0, 0}; };
-static inline fhq::Qef qef_zero() { fhq::Qef q; q.init(); return q; }
-static inline fhq::Qef qef_of(const LeafIntersection& i) { fhq::Qef q = qef_zero(); if (i.pos[3] != 0.0f) q.add(i.pos, i.grad); return q; }
-// LeafHermiteData (octree.rs:866-1035)
-struct Hermite {
-    LeafIntersection inter[12];
-    fhq::Qef face[6], center;
-    float qef_err = QEF_ERR_EMPTY;
-    Hermite() { for (auto& f : face) f.init(); center.init(); }
-    static bool merge(const Hermite* leafs, Hermite* out) {
-        *out = Hermite();
-        for (int i = 0; i < 8; i++) if (leafs[i].qef_err == QEF_ERR_INVALID) return false;
-        for (int t : {AX, AY, AZ}) {
-            const int u = axis_next(t), v = axis_next(u);
-            for (int edge = 0; edge < 4; edge++) {
-                int start = 0;
-                if (edge & 1) start |= u;
-                if (edge & 2) start |= v;
-                const int end = start | t, e = axis_index(t) * 4 + edge;
-                const LeafIntersection &a = leafs[start].inter[e], &b = leafs[end].inter[e];
-                if (a.pos[3] > 0.0f && !(b.pos[3] > 0.0f)) out->inter[e] = a;
-                else if (!(a.pos[3] > 0.0f) && b.pos[3] > 0.0f) out->inter[e] = b;
-            }
-        }
-        for (int t : {AX, AY, AZ}) {
-            const int u = axis_next(t), v = axis_next(t);   // (octree.rs:946-947: both are t.next())
-            for (int fc = 0; fc < 2; fc++) {
-                const int a = fc == 1 ? t : 0, b = a | u, c = a | v, d = a | u | v, f = axis_index(t) * 2 + fc;
-                for (int q : {a, b, c, d}) out->face[f].merge(leafs[q].face[f]);
-                const int ev = axis_index(v) * 4 + fc * 2 + 1;
-                out->face[f].merge(qef_of(leafs[a].inter[ev]));
-                out->face[f].merge(qef_of(leafs[b].inter[ev]));
-                out->face[f].merge(qef_of(leafs[a].inter[ev]));
-                out->face[f].merge(qef_of(leafs[c].inter[ev]));
-            }
-        }
-        for (int t : {AX, AY, AZ}) {
-            const int u = axis_next(t), v = axis_next(t);
-            const int a = 0, b = a | u, c = a | v, d = a | u | v;
-            for (int q : {a, b, c, d}) out->center.merge(leafs[q].face[axis_index(t) * 2 + 1]);
-            out->center.merge(qef_of(leafs[a].inter[axis_index(u) * 4 + 3]));
-            out->center.merge(qef_of(leafs[b].inter[axis_index(u) * 4 + 3]));
-        }
-        for (int i = 0; i < 8; i++) out->center.merge(leafs[i].center);
-        out->qef_err = INFINITY;
-        for (int i = 0; i < 8; i++) if (leafs[i].qef_err >= 0.0f) out->qef_err = fminf(out->qef_err, leafs[i].qef_err);
-        return true;
-    }
-    void solve(float* pos, float* err) const {
-        fhq::Qef q = center;
-        for (auto& i : inter) q.merge(qef_of(i));
-        for (auto& f : face) q.merge(f);
-        q.solve(pos, err);
-    }
 };
 
 // (vector growth without value-initialisation: the parallel assembly makes room for a subtree's vertices first and fills it in
@@ -192,8 +124,15 @@ struct Octree {
     Cell root;
     std::vector<std::array<Cell, 8>> cells;
     std::vector<V3, default_init_allocator<V3>> verts;
+    // fhip_mesh_build: the arrays as the device assembled them, in the context's pinned landing area, instead of the vectors
+    const std::array<Cell, 8>* cells_view = nullptr;
+    const V3* verts_view = nullptr;
+    size_t n_cells_view = 0, n_verts_view = 0;
     Cell& at(const CellRef& c) { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
-    const Cell& at(const CellRef& c) const { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
+    const Cell& at(const CellRef& c) const { return c.ci < 0 ? root : (cells_view ? cells_view[(size_t)c.ci][c.cj] : cells[(size_t)c.ci][c.cj]); }
+    const V3& vert(size_t v) const { return verts_view ? verts_view[v] : verts[v]; }
+    size_t n_verts() const { return verts_view ? n_verts_view : verts.size(); }
+    size_t n_cells() const { return cells_view ? n_cells_view : cells.size(); }
     bool is_leaf(const CellRef& c) const { const uint8_t k = at(c).kind; return k == C_LEAF || k == C_FULL || k == C_EMPTY; }
     CellRef child(const CellRef& c, int i) const {
         const Cell& x = at(c);
@@ -204,38 +143,10 @@ struct Octree {
     // octree.rs:389-470
     bool collapsible(size_t rootc, uint8_t* out_mask) const {
         const auto& cs = cells[rootc];
-        const Tables& T = tables();
-        int mask = 0;
-        for (int i = 0; i < 8; i++) {
-            int b;
-            if (cs[i].kind == C_LEAF) { if (T.v2e[cs[i].mask].size() > 1) return false; b = (cs[i].mask >> i) & 1; }
-            else if (cs[i].kind == C_EMPTY) b = 0;
-            else if (cs[i].kind == C_FULL) b = 1;
-            else return false;
-            mask |= b << i;
-        }
-        static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}};
-        for (auto& f : FR) {
-            const int t = f[0], u = f[1], v = f[2];
-            for (int i = 0; i < 4; i++) {
-                const int a = ((i & 1) ? u : 0) | ((i & 2) ? v : 0), b = a | t;
-                const bool center = cs[a].corner(b);
-                if ((((mask >> a) & 1) != 0) != center && (((mask >> b) & 1) != 0) != center) return false;
-            }
-            for (int i = 0; i < 2; i++) {
-                const int a = ((i & 1) == 0) ? t : 0, b = a | u, c = a | v, d = a | u | v;
-                const bool center = cs[a].corner(d);
-                bool all = true;
-                for (int q : {a, b, c, d}) all &= ((((mask >> q) & 1) != 0) != center);
-                if (all) return false;
-            }
-            const bool center = cs[0].corner(t | u | v);
-            bool all = true;
-            for (int q = 0; q < 8; q++) all &= ((((mask >> q) & 1) != 0) != center);
-            if (all) return false;
-        }
-        if (T.v2e[mask].size() == 1) { *out_mask = (uint8_t)mask; return true; }
-        return false;
+        static const struct NV { uint8_t n[256]; NV() { for (int m = 0; m < 256; m++) n[m] = (uint8_t)tables().v2e[m].size(); } } nv;
+        uint8_t kind[8], mask[8];
+        for (int i = 0; i < 8; i++) { kind[i] = cs[i].kind; mask[i] = cs[i].mask; }
+        return collapsible_children(kind, mask, nv.n, out_mask);
     }
     // octree.rs:256-340; bounds = this cell's x.lo x.hi y.lo y.hi z.lo z.hi
     Cell check_done(const float* bounds, size_t index, const Hermite* hd, Hermite* hermite) {
@@ -288,7 +199,7 @@ struct Walker {
     static void frame(int f, int* t, int* u, int* v) { static const int FR[3][3] = {{AX, AY, AZ}, {AY, AZ, AX}, {AZ, AX, AY}}; *t = FR[f][0]; *u = FR[f][1]; *v = FR[f][2]; }
     size_t vertex(size_t v) {
         if (v >= map.size()) map.resize(v + 1, (size_t)-1);
-        if (map[v] == (size_t)-1) { map[v] = vertices.size(); vertices.push_back(o.verts[v]); }
+        if (map[v] == (size_t)-1) { map[v] = vertices.size(); vertices.push_back(o.vert(v)); }
         return map[v];
     }
     void cell(const CellRef& c) {
@@ -387,6 +298,7 @@ struct ParallelWalker {
     TriVec triangles;
     VertVec vertices;
     explicit ParallelWalker(const Octree& oc) : o(oc) {}
+    std::function<void()> verts_ready;  // called before the first vertex is read (the cells are read from the start): the caller's copy of the vertices may still be under way
     uint32_t** scratch = nullptr;      // the caller's first-use table and its capacity in entries, kept between runs (or none)
     size_t* scratch_cap = nullptr;
     struct Call { uint8_t kind, f; CellRef c[4]; };        // kind 0 cell(c0), 1 face(f, c0, c1), 2 edge(f, c0..c3)
@@ -507,7 +419,7 @@ struct ParallelWalker {
         std::vector<size_t> rec_base(recs.size() + 1, 0);
         for (size_t c = 0; c < recs.size(); c++) { rec_base[c] = nrec; nrec += recs[c].size(); }
         rec_base[recs.size()] = nrec;
-        const size_t nv = std::max<size_t>(o.verts.size(), 1);
+        const size_t nv = std::max<size_t>(o.n_verts(), 1);
         uint32_t* first = nullptr;
         if (mesh_threads() > 1 && nrec * 5 < 0x7FFFFFF0ull) {
             if (scratch) {
@@ -552,6 +464,7 @@ struct ParallelWalker {
             });
             for (size_t c = 0; c < recs.size(); c++) { vbase[c + 1] += vbase[c]; tbase[c + 1] += tbase[c]; }
             const double n2 = now();
+            if (verts_ready) verts_ready();
             vertices.resize(vbase[recs.size()]);
             triangles.resize(tbase[recs.size()]);
             const double n3 = now();
@@ -562,7 +475,7 @@ struct ParallelWalker {
                     for (int k = 0; k < 5; k++, p++) {
                         const uint64_t v = ref(r, k);
                         // (another chunk may be looking at the same entry: it sees the first use's number or the tagged value, neither is its own p)
-                        if (__atomic_load_n(&first[v], __ATOMIC_RELAXED) == p) { vertices[id] = o.verts[v]; __atomic_store_n(&first[v], TAG | (uint32_t)id, __ATOMIC_RELAXED); id++; }
+                        if (__atomic_load_n(&first[v], __ATOMIC_RELAXED) == p) { vertices[id] = o.vert(v); __atomic_store_n(&first[v], TAG | (uint32_t)id, __ATOMIC_RELAXED); id++; }
                     }
             });
             parallel_for(recs.size(), [&](size_t c) {
@@ -582,10 +495,11 @@ struct ParallelWalker {
         } else {
             // octree vertex -> mesh vertex + 1 (0: not seen yet); calloc: only the pages that are touched cost anything
             uint32_t* map = (uint32_t*)calloc(nv, sizeof(uint32_t));
+            if (verts_ready) verts_ready();
             triangles.reserve(nrec * 4);
             vertices.reserve(nrec * 2);
             auto vertex = [&](uint64_t v) {
-                if (map[v] == 0) { vertices.push_back(o.verts[v]); map[v] = (uint32_t)vertices.size(); }
+                if (map[v] == 0) { vertices.push_back(o.vert(v)); map[v] = (uint32_t)vertices.size(); }
                 return (uint64_t)(map[v] - 1);
             };
             for (auto& rs : recs)

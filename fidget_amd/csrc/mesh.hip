@@ -5,39 +5,24 @@
 //                 cells are appended to the next level's list (or, at the last level, to the leaf list);
 //   k_mesh_leaf   one wavefront per ambiguous leaf cell (octree.rs:590-862): the 8 corners (bulk f32) -> corner mask ->
 //                 edges of the Manifold Dual Contouring table -> 4 rounds of 16-point search per edge (4 edges per 64-lane
-//                 pass) -> intersections (u16 cell coordinates) -> gradients there -> one QEF per cell vertex (qef.rs).
+//                 pass) -> intersections (u16 cell coordinates) -> gradients there;
+//   k_mesh_leaf_qef  one lane per leaf record: one QEF per cell vertex (qef.rs).
 //
 // Every cell is evaluated with the shape's own tape (values do not depend on tape simplification); pruning
-// the tape down the octree as the render's tile stage does is the next step for large tapes.  The octree bookkeeping
-// (cell collapse, the dual walk) has no evaluation in it and stays on the host side of the boundary.
+// the tape down the octree as the render's tile stage does is the next step for large tapes.
+//
+//   k_oct_kind / k_oct_collapse / k_oct_place / k_oct_leaf_verts   the octree assembled from those results without leaving HBM
+//                 (octree.rs:256-470 check_done / collapsible, 866-1035 merged Hermite data; mesh_collapse.hpp): level by level
+//                 bottom-up what every ambiguous cell becomes, top-down where its vertices and its block of eight cells go.
+//                 The dual walk (dc.rs) has no evaluation in it and stays on the host side of the boundary.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "dev_ops.hpp"
+#include "mesh_collapse.hpp"
 #include "mesh_qef.hpp"
 // (included by capi.hip after kernels.hip: Regs, step, ballot, uni, ctape_t)
 
-struct FhMeshCell {
-    float b[6];        // x.lo x.hi y.lo y.hi z.lo z.hi
-    uint64_t path;     // 3 bits per level below the root (corner index), leading 1
-};
-struct FhMeshLeaf {
-    float b[6];
-    uint64_t path;
-    uint32_t mask, n_edges, n_verts, pad;
-    uint16_t inter[12][3];
-    uint16_t pad2[4];
-    float pos[12][3];
-    float grad[12][4];   // dx dy dz v
-    float vert[4][3];
-    float qef_err[4];
-};
-// CELL_TO_VERT_TO_EDGES (fidget-mesh/build.rs), flattened: per mask the edges in vertex order as (start, end), edges per vertex
-struct FhMdcTable {
-    uint8_t n_edges[256], n_verts[256];
-    uint8_t per_vert[256][4];
-    uint8_t edge[256][12][2];
-};
 struct FhMeshParams {
     const uint64_t* tape;
     uint32_t len, n_regs;
@@ -131,7 +116,6 @@ __device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<fl
 __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMeshCell* cells, uint32_t n, const FhMdcTable* T, FhMeshLeaf* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint16_t s_start[12][3], s_end[12][3];
-    __shared__ float s_pos[12][3], s_grad[12][4];
     const int lane = threadIdx.x;
     const uint32_t li = blockIdx.x;
     if (li >= n) return;
@@ -210,38 +194,66 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
             for (int k = 0; k < 3; k++) o->inter[lane][k] = q[k];
             o->pos[lane][0] = px; o->pos[lane][1] = py; o->pos[lane][2] = pz;
             o->grad[lane][0] = result.dx; o->grad[lane][1] = result.dy; o->grad[lane][2] = result.dz; o->grad[lane][3] = result.v;
-            s_pos[lane][0] = px; s_pos[lane][1] = py; s_pos[lane][2] = pz;
-            s_grad[lane][0] = result.dx; s_grad[lane][1] = result.dy; s_grad[lane][2] = result.dz; s_grad[lane][3] = result.v;
         }
     }
-    __syncthreads();
-    // one QEF per cell vertex (octree.rs:805-848), vertices in order: a NaN gradient snaps the vertex to that intersection and
-    // stops its loop WITHOUT consuming the edge (the reference's `break` comes before `i += 1`), so the next vertex starts there
-    if (lane == 0) {
-        uint32_t i = 0;
-        for (uint32_t vtx = 0; vtx < nv; vtx++) {
-            fhq::Qef q;
-            q.init();
-            bool forced = false;
-            float pos[3] = {0, 0, 0}, err = -1.0f;
-            for (uint32_t k = 0; k < T->per_vert[mask][vtx]; k++) {
-                const uint32_t ii = i < 12 ? i : 11;
-                const float* g = s_grad[ii];
-                if (g[0] != g[0] || g[1] != g[1] || g[2] != g[2] || g[3] != g[3]) {
-                    forced = true;
-                    for (int a = 0; a < 3; a++) pos[a] = s_pos[ii][a];
-                    err = -2.0f;
-                    break;
-                }
-                q.add(s_pos[ii], g);
-                i++;
-            }
-            if (!forced) q.solve(pos, &err);
-            for (int a = 0; a < 3; a++) o->vert[vtx][a] = pos[a];
-            o->qef_err[vtx] = err;
-        }
-    }
+    // (the QEFs of the cell vertices: k_mesh_leaf_qef, one LANE per record - here they kept a whole wavefront waiting on lane 0)
     if (lane == 0) { o->n_edges = ne; o->n_verts = nv; }
+}
+
+// one QEF per cell vertex (octree.rs:805-848), vertices in order: a NaN gradient snaps the vertex to that intersection and
+// stops its loop WITHOUT consuming the edge (the reference's `break` comes before `i += 1`), so the next vertex starts there.
+// One lane per leaf record: the Jacobi sweeps of fhq::Qef::solve are a few thousand dependent f64 operations, which at the end of
+// k_mesh_leaf occupied a wavefront for the sake of one lane.
+__global__ void __launch_bounds__(WAVE) k_mesh_leaf_qef(const FhMdcTable* T, FhMeshLeaf* recs, uint32_t n) {
+    const uint32_t li = blockIdx.x * WAVE + threadIdx.x;
+    if (li >= n) return;
+    FhMeshLeaf* o = &recs[li];
+    const uint32_t mask = o->mask;
+    if (mask == 0 || mask == 255) return;
+    const uint32_t nv = T->n_verts[mask];
+    uint32_t i = 0;
+    for (uint32_t vtx = 0; vtx < nv; vtx++) {
+        fhq::Qef q;
+        q.init();
+        bool forced = false;
+        float pos[3] = {0, 0, 0}, err = -1.0f;
+        for (uint32_t k = 0; k < T->per_vert[mask][vtx]; k++) {
+            const uint32_t ii = i < 12 ? i : 11;
+            float g[4], p[3];
+            for (int a = 0; a < 4; a++) g[a] = o->grad[ii][a];
+            for (int a = 0; a < 3; a++) p[a] = o->pos[ii][a];
+            if (g[0] != g[0] || g[1] != g[1] || g[2] != g[2] || g[3] != g[3]) {
+                forced = true;
+                for (int a = 0; a < 3; a++) pos[a] = p[a];
+                err = -2.0f;
+                break;
+            }
+            q.add(p, g);
+            i++;
+        }
+        if (!forced) q.solve(pos, &err);
+        for (int a = 0; a < 3; a++) o->vert[vtx][a] = pos[a];
+        o->qef_err[vtx] = err;
+    }
+}
+
+// ---- the octree assembled on the device (mesh_collapse.hpp: one thread per ambiguous cell / candidate / leaf record and pass) ----------
+__global__ void __launch_bounds__(256) k_oct_kind(fhmesh::OctLevel D, fhmesh::OctLevel C, fhmesh::OctLeaves L, const FhMdcTable* T, uint32_t* counter, uint32_t n) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) fhmesh::oct_kind(D, C, L, T, s, counter);
+}
+__global__ void __launch_bounds__(64) k_oct_collapse(fhmesh::OctLevel D, fhmesh::OctLevel C, fhmesh::OctLeaves L, const FhMdcTable* T, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) fhmesh::oct_collapse(D, C, L, T, k);
+}
+__global__ void __launch_bounds__(256) k_oct_place(fhmesh::OctLevel D, fhmesh::OctLevel C, fhmesh::OctLeaves L, const FhMdcTable* T, fhmesh::Cell* cells, fhmesh::V3* verts,
+                                                    const float* mat, uint32_t n) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) fhmesh::oct_place(D, C, L, T, s, cells, verts, mat);
+}
+__global__ void __launch_bounds__(256) k_oct_leaf_verts(fhmesh::OctLeaves L, fhmesh::V3* verts, const float* mat, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fhmesh::oct_leaf_verts(L, i, verts, mat);
 }
 
 }  // namespace fhm

@@ -391,6 +391,24 @@ def test_device_mesh_colonnade_at_the_reference_s_depth(oracle_mod):     # octre
     check_for_edge_matching(tris)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 8), ("colonnade.vm", 7), ("bear.vm", 6), ("prospero.vm", 7)])
+def test_device_assembly_equals_the_host_assembly(model, depth):
+    """fhip_mesh_build assembles the octree in HBM (k_oct_*: check_done / collapse / places, mesh_collapse.hpp) and hands the host the
+    finished octree; with the option off, the host's threads assemble it from copies of the levels and the leaf records, as
+    fhip_mesh_merge does.  Same per-cell functions, same octree: the meshes are equal bit for bit, at sizes the oracle would take
+    minutes for (a million cells), collapsed cells on several levels included (colonnade's flat faces)."""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(model_path(model))
+    assert shape.hip.option("mesh_device_assembly") == 1
+    tris, verts, counts = F.mesh(shape, depth)
+    with shape.hip.options(mesh_device_assembly=0):
+        t2, v2, c2 = F.mesh(shape, depth)
+    assert counts == c2 and len(tris) > 10000
+    assert tris.shape == t2.shape and (tris == t2).all()
+    assert verts.shape == v2.shape and (verts.view(np.uint32) == v2.view(np.uint32)).all()
+
+
 def match_meshes(ta, va, tb, vb, tol):
     """Tolerance-aware comparison of two meshes whose vertices may differ in the last bits (transcendental opcodes: 1 ulp per
     value is granted) and, where such a difference flips a decision, in a handful of cells: vertices of `a` are paired with the

@@ -14,12 +14,28 @@ depths = [int(a) for a in sys.argv[1:]] or [6, 7, 8, 9]
 shape = F.Shape.from_vm(os.path.join(ROOT, "models", "gyroid-sphere.vm"), hip=hip)
 F.mesh(shape, 4)
 for depth in depths:
-    t0 = time.perf_counter()
-    tris, verts, counts = F.mesh(shape, depth)
-    dt = time.perf_counter() - t0
+    for rep in range(int(os.environ.get("MESH_TIMES_REPS", "1"))):      # (the first build of a size also pins its landing area and makes room)
+        t0 = time.perf_counter()
+        tris, verts, counts = F.mesh(shape, depth)
+        dt = time.perf_counter() - t0
+        print(depth, "build", rep, dt, flush=True)
     res[f"depth {depth}"] = {"s": dt, "triangles": len(tris), "vertices": len(verts), **counts}
     print(depth, res[f"depth {depth}"], flush=True)
     del tris, verts
+    if os.environ.get("MESH_TIMES_HOST_ASM"):      # the same build with the octree assembled on the host's threads (the round-2 path)
+        with hip.options(mesh_device_assembly=0):
+            for rep in range(2):
+                t0 = time.perf_counter()
+                tris, verts, counts = F.mesh(shape, depth)
+                dt = time.perf_counter() - t0
+                del tris, verts
+        res[f"depth {depth}, host assembly"] = {"s": dt}
+        print(depth, "host assembly", dt, flush=True)
+        t0 = time.perf_counter()
+        tris, verts, counts = F.mesh(shape, depth)
+        res[f"depth {depth}"]["s_again"] = time.perf_counter() - t0
+        print(depth, "device assembly again", res[f"depth {depth}"]["s_again"], flush=True)
+        del tris, verts
 # the build sharded by the root's octants (fidget_amd.mesh_part / mesh_merge), its parts one after the other on this one GPU:
 # what each rank of an N-GPU build would spend on its part, and what the merging rank spends afterwards
 n_parts = int(os.environ.get("MESH_TIMES_PARTS", "0"))

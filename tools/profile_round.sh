@@ -12,11 +12,15 @@ cd /tmp && export TMPDIR=/tmp
 for PATHNAME in default general; do
   if [ $PATHNAME = default ]; then FLAG="--no-general"; else FLAG="--only-general"; fi
   CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu $FLAG"
+  if [ -z "${PROFILE_ROUND_QUICK:-}" ]; then
   rm -rf /tmp/p_stats
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $CMD > $OUT/stats_run_$PATHNAME.log 2>&1
   cp /tmp/p_stats/s_kernel_stats.csv $OUT/kernel_stats_$PATHNAME.csv 2>/dev/null || find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$PATHNAME.csv \;
   grep '^{"metric"' $OUT/stats_run_$PATHNAME.log > $OUT/bench_under_rocprof_$PATHNAME.json
-  for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SMEM"; do
+  fi
+  # (PROFILE_ROUND_QUICK=1: only the passes bench.py's roofline reads - traffic and instruction counts)
+  for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" ${PROFILE_ROUND_QUICK:+SKIP} "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SMEM"; do
+    if [ "$C" = SKIP ]; then break; fi
     N=$(echo $C | tr ' ' '_')
     rm -rf /tmp/p_$N
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$N -o c -- $CMD > $OUT/pmc_${PATHNAME}_$N.log 2>&1
