@@ -1,12 +1,18 @@
 #!/bin/bash
-# scratch: the mesh path with the octree assembled on the device
+# scratch: the round's profile on the final sources, the bench line with it, then the GPU tests
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03y
-timeout 900 python -m pytest tests/test_mesh.py tests/test_multi_gpu.py -x -q -m gpu -k "mesh" > gpurun_out/r03y/mesh_tests.log 2>&1
-tail -5 gpurun_out/r03y/mesh_tests.log
-timeout 600 python tools/mesh_times.py 9 10 > gpurun_out/r03y/mesh_times.log 2>&1
-grep "fhip mesh depth\|^10\|^9" gpurun_out/r03y/mesh_times.log
-cp gpurun_out/mesh_times.json gpurun_out/r03y/ 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03y/prof_mesh -o mesh -- python $GRAFT_REPO_ROOT/tools/mesh_times.py 10 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/r03y/prof_mesh -name "*kernel_stats.csv" | head -1); head -12 $f
+timeout -k 5 150 bash tools/profile_round.sh r03 > gpurun_out/r03y/profile_round.log 2>&1
+tail -2 gpurun_out/r03y/profile_round.log
+cp gpurun_out/prof_r03/traffic.json profiles/traffic_r03.json
+timeout -k 5 90 python bench.py > gpurun_out/r03y/bench.json 2> gpurun_out/r03y/bench.err
+python - <<'PY'
+import json
+try:
+    r = json.load(open("gpurun_out/r03y/bench.json"))
+    print(r["value"], r["ms_per_step"], r.get("frame_latency_ms"), r["roofline"].get("traffic"), r["roofline"].get("traffic_note"))
+except Exception as e:
+    print("bench:", e)
+PY
+timeout -k 5 230 python -m pytest tests -x -q -m gpu -k "not mesh" > gpurun_out/r03y/gpu_suite.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03y/gpu_suite.log
+tail -4 gpurun_out/r03y/gpu_suite.log
