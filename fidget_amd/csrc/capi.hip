@@ -2125,7 +2125,7 @@ struct OctDevX {
     void release() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
 static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
-                                       bool has_mat, const float* mat, MeshTimes& T);
+                                       bool has_mat, const float* mat, MeshTimes& T, std::string& why);
 enum MeshMode { MESH_SAMPLE, MESH_BUILD, MESH_PART };
 static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, MeshMode mode, uint32_t part, uint32_t n_parts, fhip_mesh** out) {
@@ -2293,7 +2293,10 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             lv[d].amb = (const FhMeshCell*)lv_amb[d].p; lv[d].n_amb = lv_n_amb[d];
         }
         MeshTimes MT{times, t_start, t_cells, t_leaf, 0.0, n_leaf_cells};
-        MESH_TRY(mesh_assemble_device(ctx, M, depth, lv, (const FhMeshLeaf*)leaves.p, n_leaf_cells, (const FhMdcTable*)table.p, P.has_mat != 0, P.mat, MT));
+        std::string why;
+        const hipError_t ae = mesh_assemble_device(ctx, M, depth, lv, (const FhMeshLeaf*)leaves.p, n_leaf_cells, (const FhMdcTable*)table.p, P.has_mat != 0, P.mat, MT, why);
+        if (ae != hipSuccess && !why.empty()) { cleanup(); delete M; return fail(ctx, FHIP_ERR_OVERFLOW, why); }
+        MESH_TRY(ae);
         cleanup();
         *out = M;
         return FHIP_OK;
@@ -2364,62 +2367,66 @@ static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
                 depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, T.t_copy, t_asm, t_walk, now() - T.t_start);
 }
-// fhip_mesh_build's second half: the octree assembled in HBM (check_done / collapse / places, mesh_collapse.hpp), its blocks of cells and its
-// vertices copied to the context's pinned landing area - the cells first, the dual walk starts on them while the vertices are still on
-// their way - then Octree::walk_dual on the host's threads.  The leaf records (528 bytes each) never leave the device.
+// fhip_mesh_build's second half: the octree assembled in HBM (check_done / collapse / places, mesh_collapse.hpp), its blocks of cells copied
+// to the context's pinned landing area, Octree::walk_dual on the host's threads over them, and the mesh's vertices - the walk knows which
+// of the octree's they are - gathered on the device.  Neither the leaf records (528 bytes each) nor the octree's vertices (at depth 10:
+// 191 M, of which the mesh uses 7.5 M) leave the device.
 static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
-                                       bool has_mat, const float* mat, MeshTimes& T) {
+                                       bool has_mat, const float* mat, MeshTimes& T, std::string& why) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     OctDevX x{ctx->stream, {}, hipSuccess};
+    auto give_up = [&](hipError_t e) { (void)hipStreamSynchronize(ctx->stream); x.release(); return e; };
     float* d_mat = nullptr;
     if (has_mat) {
         d_mat = (float*)x.alloc(64);
         if (d_mat) x.chk(hipMemcpyAsync(d_mat, mat, 64, hipMemcpyHostToDevice, ctx->stream));
     }
     fhmesh::OctOut oo;
-    const bool ok = x.err == hipSuccess && fhmesh::oct_assemble(x, depth, lv.data(), (uint32_t)lv.size(), rec, n_rec, table, d_mat, &oo);
-    if (!ok || x.err != hipSuccess) { const hipError_t e = x.err != hipSuccess ? x.err : hipErrorOutOfMemory; (void)hipStreamSynchronize(ctx->stream); x.release(); return e; }
-    const size_t cell_bytes = (size_t)oo.n_blocks * 8 * sizeof(fhmesh::Cell), vert_bytes = (size_t)oo.n_verts * sizeof(fhmesh::V3);
-    const size_t need = ((cell_bytes + 255) & ~(size_t)255) + vert_bytes + 256;
-    if (ctx->mesh_pinned_cap < need) {
+    const int rc = x.err != hipSuccess ? (int)fhmesh::OCT_NO_MEMORY : fhmesh::oct_assemble(x, depth, lv.data(), (uint32_t)lv.size(), rec, n_rec, table, d_mat, &oo);
+    if (rc == fhmesh::OCT_TOO_MANY_VERTICES) { why = "the octree has more than 2^32 vertices"; return give_up(hipErrorInvalidValue); }
+    if (rc != fhmesh::OCT_OK || x.err != hipSuccess) return give_up(x.err != hipSuccess ? x.err : hipErrorOutOfMemory);
+    const size_t cell_bytes = (size_t)oo.n_blocks * 8 * sizeof(fhmesh::Cell);
+    if (ctx->mesh_pinned_cap < cell_bytes + 256) {
         if (ctx->mesh_pinned) (void)hipHostFree(ctx->mesh_pinned);
         ctx->mesh_pinned = nullptr; ctx->mesh_pinned_cap = 0;
-        const hipError_t e = hipHostMalloc(&ctx->mesh_pinned, need + need / 8, hipHostMallocDefault);
-        if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); x.release(); return e; }
-        ctx->mesh_pinned_cap = need + need / 8;
+        const size_t room = cell_bytes + cell_bytes / 8 + 256;
+        const hipError_t e = hipHostMalloc(&ctx->mesh_pinned, room, hipHostMallocDefault);
+        if (e != hipSuccess) return give_up(e);
+        ctx->mesh_pinned_cap = room;
     }
-    char* const land = (char*)ctx->mesh_pinned;
     fhmesh::Octree o;
     o.root = oo.root;
-    o.cells_view = (const std::array<fhmesh::Cell, 8>*)land; o.n_cells_view = oo.n_blocks;
-    o.verts_view = (const fhmesh::V3*)(land + ((cell_bytes + 255) & ~(size_t)255)); o.n_verts_view = oo.n_verts;
-    hipStream_t const copy_stream = ctx->stream2 ? ctx->stream2 : ctx->stream;
-    hipEvent_t placed = nullptr;
-    x.chk(hipEventCreateWithFlags(&placed, hipEventDisableTiming));
-    if (placed) { x.chk(hipEventRecord(placed, ctx->stream)); x.chk(hipStreamWaitEvent(copy_stream, placed, 0)); }
-    if (vert_bytes) x.chk(hipMemcpyAsync((void*)o.verts_view, oo.verts, vert_bytes, hipMemcpyDeviceToHost, copy_stream));
-    if (cell_bytes) x.chk(hipMemcpyAsync((void*)o.cells_view, oo.cells, cell_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    o.cells_view = (const std::array<fhmesh::Cell, 8>*)ctx->mesh_pinned; o.n_cells_view = oo.n_blocks;
+    o.verts_view = nullptr; o.n_verts_view = oo.n_verts;      // (never read: the walk gathers through the device)
+    if (cell_bytes) x.chk(hipMemcpyAsync(ctx->mesh_pinned, oo.cells, cell_bytes, hipMemcpyDeviceToHost, ctx->stream));
     x.chk(hipStreamSynchronize(ctx->stream));
+    if (x.err != hipSuccess) return give_up(x.err);
     const double t_asm = now() - t0;
-    if (x.err != hipSuccess) { (void)hipStreamSynchronize(copy_stream); if (placed) (void)hipEventDestroy(placed); x.release(); return x.err; }
     fhmesh::ParallelWalker W(o);
     W.scratch = &ctx->mesh_first; W.scratch_cap = &ctx->mesh_first_cap;
-    hipError_t copy_err = hipSuccess;
-    bool waited = false;
-    W.verts_ready = [&] { if (!waited) { copy_err = hipStreamSynchronize(copy_stream); waited = true; } };
+    W.gather = [&](const uint32_t* idx, size_t n, fhmesh::V3* out) {
+        if (!n) return true;
+        uint32_t* d_idx = (uint32_t*)x.alloc(n * 4);
+        fhmesh::V3* d_out = (fhmesh::V3*)x.alloc(n * sizeof(fhmesh::V3));
+        if (!d_idx || !d_out) return false;
+        x.chk(hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(fhm::k_oct_gather, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const fhmesh::V3*)oo.verts, (const uint32_t*)d_idx, d_out, (uint32_t)n);
+        x.chk(hipGetLastError());
+        x.chk(hipMemcpyAsync(out, d_out, n * sizeof(fhmesh::V3), hipMemcpyDeviceToHost, ctx->stream));
+        x.chk(hipStreamSynchronize(ctx->stream));
+        return x.err == hipSuccess;
+    };
     W.run();
-    W.verts_ready();
     const double t_walk = now() - t0 - t_asm;
-    if (placed) (void)hipEventDestroy(placed);
+    if (W.gather_failed) return give_up(x.err != hipSuccess ? x.err : hipErrorOutOfMemory);
     x.release();
-    if (copy_err != hipSuccess) return copy_err;
     M->octree_cells = oo.n_blocks; M->octree_verts = oo.n_verts;
     M->vertices.swap(W.vertices);
     M->triangles.swap(W.triangles);
     if (T.on)
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), assembly on the device + cells to the host %.4f s (%u blocks, %u vertices), "
-                        "dual walk (vertices arriving beside it) %.4f s, total %.4f s\n",
+                        "dual walk + the mesh's vertices gathered %.4f s, total %.4f s\n",
                 depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, t_asm, oo.n_blocks, oo.n_verts, t_walk, now() - T.t_start);
     return hipSuccess;
 }
@@ -2602,7 +2609,15 @@ void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_
     for (uint64_t i = 0; i < n_verts; i++) o.verts[i] = fhmesh::V3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
     fhmesh::TriVec t;
     fhmesh::VertVec v;
-    if (parallel) { fhmesh::ParallelWalker W(o); W.run(); t.swap(W.triangles); v.swap(W.vertices); }
+    if (parallel == 2) {     // as fhip_mesh_build runs it: the cells through a view, the octree's vertices never read - the mesh's are gathered afterwards
+        fhmesh::Octree w;
+        w.root = o.root;
+        w.cells_view = o.cells.data(); w.n_cells_view = o.cells.size(); w.n_verts_view = o.verts.size();
+        fhmesh::ParallelWalker W(w);
+        W.gather = [&](const uint32_t* idx, size_t n, fhmesh::V3* out) { for (size_t i = 0; i < n; i++) out[i] = o.verts[idx[i]]; return true; };
+        W.run();
+        t.swap(W.triangles); v.swap(W.vertices);
+    } else if (parallel) { fhmesh::ParallelWalker W(o); W.run(); t.swap(W.triangles); v.swap(W.vertices); }
     else { fhmesh::Walker W(o); W.cell(fhmesh::CellRef()); t.swap(W.triangles); v.swap(W.vertices); }
     counts[0] = t.size(); counts[1] = v.size();
     if (tris) memcpy(tris, t.data(), t.size() * 24);

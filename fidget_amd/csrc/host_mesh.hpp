@@ -130,8 +130,8 @@ struct Octree {
     size_t n_cells_view = 0, n_verts_view = 0;
     Cell& at(const CellRef& c) { return c.ci < 0 ? root : cells[(size_t)c.ci][c.cj]; }
     const Cell& at(const CellRef& c) const { return c.ci < 0 ? root : (cells_view ? cells_view[(size_t)c.ci][c.cj] : cells[(size_t)c.ci][c.cj]); }
-    const V3& vert(size_t v) const { return verts_view ? verts_view[v] : verts[v]; }
-    size_t n_verts() const { return verts_view ? n_verts_view : verts.size(); }
+    const V3& vert(size_t v) const { return cells_view ? verts_view[v] : verts[v]; }      // (verts_view may be null: then the walk gathers, ParallelWalker::gather)
+    size_t n_verts() const { return cells_view ? n_verts_view : verts.size(); }
     size_t n_cells() const { return cells_view ? n_cells_view : cells.size(); }
     bool is_leaf(const CellRef& c) const { const uint8_t k = at(c).kind; return k == C_LEAF || k == C_FULL || k == C_EMPTY; }
     CellRef child(const CellRef& c, int i) const {
@@ -298,7 +298,10 @@ struct ParallelWalker {
     TriVec triangles;
     VertVec vertices;
     explicit ParallelWalker(const Octree& oc) : o(oc) {}
-    std::function<void()> verts_ready;  // called before the first vertex is read (the cells are read from the start): the caller's copy of the vertices may still be under way
+    // The octree's vertices may not be on the host at all (fhip_mesh_build: 191 M of them at depth 10, of which the mesh uses 7.5 M):
+    // then `gather` fetches the mesh's - out[i] = octree vertex idx[i] - once the walk knows which they are.  false: it failed.
+    std::function<bool(const uint32_t* idx, size_t n, V3* out)> gather;
+    bool gather_failed = false;
     uint32_t** scratch = nullptr;      // the caller's first-use table and its capacity in entries, kept between runs (or none)
     size_t* scratch_cap = nullptr;
     struct Call { uint8_t kind, f; CellRef c[4]; };        // kind 0 cell(c0), 1 face(f, c0, c1), 2 edge(f, c0..c3)
@@ -464,8 +467,8 @@ struct ParallelWalker {
             });
             for (size_t c = 0; c < recs.size(); c++) { vbase[c + 1] += vbase[c]; tbase[c + 1] += tbase[c]; }
             const double n2 = now();
-            if (verts_ready) verts_ready();
             vertices.resize(vbase[recs.size()]);
+            std::vector<uint32_t, default_init_allocator<uint32_t>> gidx(gather ? vertices.size() : 0);
             triangles.resize(tbase[recs.size()]);
             const double n3 = now();
             parallel_for(recs.size(), [&](size_t c) {
@@ -475,7 +478,11 @@ struct ParallelWalker {
                     for (int k = 0; k < 5; k++, p++) {
                         const uint64_t v = ref(r, k);
                         // (another chunk may be looking at the same entry: it sees the first use's number or the tagged value, neither is its own p)
-                        if (__atomic_load_n(&first[v], __ATOMIC_RELAXED) == p) { vertices[id] = o.vert(v); __atomic_store_n(&first[v], TAG | (uint32_t)id, __ATOMIC_RELAXED); id++; }
+                        if (__atomic_load_n(&first[v], __ATOMIC_RELAXED) == p) {
+                            if (gather) gidx[id] = (uint32_t)v; else vertices[id] = o.vert(v);
+                            __atomic_store_n(&first[v], TAG | (uint32_t)id, __ATOMIC_RELAXED);
+                            id++;
+                        }
                     }
             });
             parallel_for(recs.size(), [&](size_t c) {
@@ -488,6 +495,7 @@ struct ParallelWalker {
                         if (r.push & (1 << j)) triangles[t++] = {vs[j], vs[(j + r.winding) % 4], iv};
                 }
             });
+            if (gather && !gather(gidx.data(), gidx.size(), vertices.data())) gather_failed = true;
             const double n4 = now();
             if (!scratch) free(first);
             if (times) fprintf(stderr, "fhip dual walk numbering: %zu octree vertices; clear %.4f s, first uses %.4f s, counts %.4f s, room %.4f s, vertices + triangles %.4f s, free %.4f s\n",
@@ -495,11 +503,14 @@ struct ParallelWalker {
         } else {
             // octree vertex -> mesh vertex + 1 (0: not seen yet); calloc: only the pages that are touched cost anything
             uint32_t* map = (uint32_t*)calloc(nv, sizeof(uint32_t));
-            if (verts_ready) verts_ready();
             triangles.reserve(nrec * 4);
             vertices.reserve(nrec * 2);
+            std::vector<uint32_t> gidx;
             auto vertex = [&](uint64_t v) {
-                if (map[v] == 0) { vertices.push_back(o.vert(v)); map[v] = (uint32_t)vertices.size(); }
+                if (map[v] == 0) {
+                    if (gather) { gidx.push_back((uint32_t)v); map[v] = (uint32_t)gidx.size(); }
+                    else { vertices.push_back(o.vert(v)); map[v] = (uint32_t)vertices.size(); }
+                }
                 return (uint64_t)(map[v] - 1);
             };
             for (auto& rs : recs)
@@ -511,6 +522,7 @@ struct ParallelWalker {
                         if (r.push & (1 << j)) triangles.push_back({vs[j], vs[(j + r.winding) % 4], iv});
                 }
             free(map);
+            if (gather) { vertices.resize(gidx.size()); if (!gather(gidx.data(), gidx.size(), vertices.data())) gather_failed = true; }
         }
         if (times) fprintf(stderr, "fhip dual walk: unroll %.4f s (%zu calls), sub-walks %.4f s (%zu records), numbering %.4f s\n", t1 - t0, calls.size(), t2 - t1, nrec, now() - t2);
     }

@@ -256,4 +256,10 @@ __global__ void __launch_bounds__(256) k_oct_leaf_verts(fhmesh::OctLeaves L, fhm
     if (i < n) fhmesh::oct_leaf_verts(L, i, verts, mat);
 }
 
+// the mesh's vertices out of the octree's (the dual walk on the host says which: first uses, in its order)
+__global__ void __launch_bounds__(256) k_oct_gather(const fhmesh::V3* verts, const uint32_t* idx, fhmesh::V3* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = verts[idx[i]];
+}
+
 }  // namespace fhm

@@ -276,7 +276,8 @@ struct OctChildSrc {
 // lets through are listed for pass 2
 FHQ_HD static inline void oct_kind(const OctLevel& D, const OctLevel& C, const OctLeaves& L, const FhMdcTable* T, uint32_t s, uint32_t* n_cand) {
     uint8_t kind[8], mask[8];
-    uint32_t tv = 0, tb = 0;
+    uint64_t tv = 0;       // (32-bit vertex indices, as the host's octree has them: the count saturates, oct_assemble refuses)
+    uint32_t tb = 0;
     int full = 0, empty = 0;
     bool branch = false;
     for (int c = 0; c < 8; c++) {
@@ -287,7 +288,7 @@ FHQ_HD static inline void oct_kind(const OctLevel& D, const OctLevel& C, const O
         else if (ch.kind == C_EMPTY) empty++;
         else if (ch.kind != C_LEAF) branch = true;       // (a branch; or a cell of another part: nothing collapses over it)
     }
-    OctRes r{C_BRANCH, 0, 0, tv, tb + 1, 0xFFFFFFFFu};
+    OctRes r{C_BRANCH, 0, 0, tv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tv, tb + 1, 0xFFFFFFFFu};
     if (!branch) {
         if (full == 8) { r.kind = C_FULL; r.tb = 0; }
         else if (empty == 8) { r.kind = C_EMPTY; r.tb = 0; }
@@ -316,7 +317,8 @@ FHQ_HD static inline void oct_collapse(const OctLevel& D, const OctLevel& C, con
     OctRes r = D.res[s];
     r.kind = C_LEAF;
     r.own = (uint16_t)(1 + T->per_vert[r.mask][0]);
-    r.tv += r.own; r.tb = 0; r.herm = k;
+    r.tv = r.tv > 0xFFFFFFFFu - r.own ? 0xFFFFFFFFu : r.tv + r.own;
+    r.tb = 0; r.herm = k;
     D.res[s] = r;
 }
 // what the parent's block (or Octree::root) says of a cell whose vertices start at v and whose first block is b
@@ -365,22 +367,24 @@ FHQ_HD static inline void oct_leaf_verts(const OctLeaves& L, uint32_t i, V3* ver
 // pass, capi.hip; a plain loop in the tests' host build of these functions): alloc(bytes) -> pointer or null, zero(p, bytes),
 // read(dst, src, bytes) (a synchronising copy to the host), kind / collapse / place / leaf_verts(.., n).  lv[0 .. n_levels - 1]: the levels
 // the recursion evaluated, with cls / slot / amb / n_amb filled in (n_amb of the leaf level = n_rec); the leaf level is level `depth`, if
-// the recursion got there.  false: out of memory (X keeps what alloc handed out).
+// the recursion got there.  Returns OCT_OK, OCT_NO_MEMORY (X keeps what alloc handed out) or OCT_TOO_MANY_VERTICES (the octree's vertex
+// indices are 32 bits wide, here as in the host's assembly).
 struct OctOut { Cell root; Cell* cells = nullptr; V3* verts = nullptr; uint32_t n_blocks = 0, n_verts = 0; };
+enum { OCT_OK = 0, OCT_NO_MEMORY = 1, OCT_TOO_MANY_VERTICES = 2 };
 template <class X>
-static inline bool oct_assemble(X& x, uint32_t depth, OctLevel* lv, uint32_t n_levels, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* T, const float* mat,
+static inline int oct_assemble(X& x, uint32_t depth, OctLevel* lv, uint32_t n_levels, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* T, const float* mat,
                                 OctOut* out) {
     *out = OctOut();
     uint8_t root_cls = 0;
     x.read(&root_cls, lv[0].cls, 1);
-    if (root_cls != 3) { out->root.kind = root_cls == 2 ? C_FULL : C_EMPTY; return true; }
+    if (root_cls != 3) { out->root.kind = root_cls == 2 ? C_FULL : C_EMPTY; return OCT_OK; }
     const bool leaf_level = n_levels == depth + 1 && n_rec > 0;
     OctLeaves leaves;
     leaves.T = T;
     if (leaf_level) {
         leaves.rec = rec;
         leaves.vo = (uint32_t*)x.alloc((size_t)n_rec * 4);
-        if (!leaves.vo) return false;
+        if (!leaves.vo) return OCT_NO_MEMORY;
     }
     const OctLeaves none{nullptr, nullptr, T};
     OctChild top{C_INVALID, 0, 0, 0, 0, 0};
@@ -391,14 +395,14 @@ static inline bool oct_assemble(X& x, uint32_t depth, OctLevel* lv, uint32_t n_l
         top.kind = lf.mask == 0 ? C_EMPTY : (lf.mask == 255 ? C_FULL : C_LEAF);
         if (top.kind == C_LEAF) { top.mask = (uint8_t)lf.mask; top.tv = top.own = lf.n_verts + lf.n_edges; }
     } else {
-        if (n_levels < 2) return true;       // (cannot be: an ambiguous root above the leaf level has children)
+        if (n_levels < 2) return OCT_OK;       // (cannot be: an ambiguous root above the leaf level has children)
         uint32_t* counter = (uint32_t*)x.alloc(4);
-        if (!counter) return false;
+        if (!counter) return OCT_NO_MEMORY;
         for (uint32_t d = n_levels - 1; d-- > 0;) {
             OctLevel& D = lv[d];
             D.res = (OctRes*)x.alloc((size_t)D.n_amb * sizeof(OctRes));
             D.cand = (uint32_t*)x.alloc((size_t)D.n_amb * 4);
-            if (!D.res || !D.cand) return false;
+            if (!D.res || !D.cand) return OCT_NO_MEMORY;
             x.zero(counter, 4);
             const OctLeaves& L = (d + 1 == depth) ? leaves : none;
             x.kind(D, lv[d + 1], L, T, counter, D.n_amb);
@@ -406,7 +410,7 @@ static inline bool oct_assemble(X& x, uint32_t depth, OctLevel* lv, uint32_t n_l
             x.read(&nc, counter, 4);
             if (nc) {
                 D.pool = (OctCollapsed*)x.alloc((size_t)nc * sizeof(OctCollapsed));
-                if (!D.pool) return false;
+                if (!D.pool) return OCT_NO_MEMORY;
                 x.collapse(D, lv[d + 1], L, T, nc);
             }
         }
@@ -414,23 +418,24 @@ static inline bool oct_assemble(X& x, uint32_t depth, OctLevel* lv, uint32_t n_l
         x.read(&r, lv[0].res, sizeof(r));
         top.kind = r.kind; top.mask = r.mask; top.tv = r.tv; top.tb = r.tb; top.own = r.own;
     }
+    if (top.tv >= 0xFFFFFF00u) return OCT_TOO_MANY_VERTICES;
     out->root = oct_cell(top, 0, 0);
     out->n_verts = top.tv; out->n_blocks = top.tb;
-    if (top.tv) { out->verts = (V3*)x.alloc((size_t)top.tv * sizeof(V3)); if (!out->verts) return false; }
-    if (top.tb) { out->cells = (Cell*)x.alloc((size_t)top.tb * 8 * sizeof(Cell)); if (!out->cells) return false; }
+    if (top.tv) { out->verts = (V3*)x.alloc((size_t)top.tv * sizeof(V3)); if (!out->verts) return OCT_NO_MEMORY; }
+    if (top.tb) { out->cells = (Cell*)x.alloc((size_t)top.tb * 8 * sizeof(Cell)); if (!out->cells) return OCT_NO_MEMORY; }
     if (depth > 0) {
         lv[0].place = (OctPlace*)x.alloc(sizeof(OctPlace));
-        if (!lv[0].place) return false;
+        if (!lv[0].place) return OCT_NO_MEMORY;
         x.zero(lv[0].place, sizeof(OctPlace));
         for (uint32_t d = 0; d + 1 < n_levels; d++) {
             OctLevel& C = lv[d + 1];
             const bool to_leaves = d + 1 == depth;
-            if (!to_leaves && C.n_amb) { C.place = (OctPlace*)x.alloc((size_t)C.n_amb * sizeof(OctPlace)); if (!C.place) return false; }
+            if (!to_leaves && C.n_amb) { C.place = (OctPlace*)x.alloc((size_t)C.n_amb * sizeof(OctPlace)); if (!C.place) return OCT_NO_MEMORY; }
             x.place(lv[d], C, to_leaves ? leaves : none, T, out->cells, out->verts, mat, lv[d].n_amb);
         }
     }
     if (leaf_level) x.leaf_verts(leaves, out->verts, mat, n_rec);
-    return true;
+    return OCT_OK;
 }
 
 }  // namespace fhmesh

@@ -47,7 +47,7 @@ void* fh_asm_run(uint32_t depth, uint32_t n_levels, const uint32_t* n_cells, con
         lv[d].amb = amb[d].data();
         co += n_cells[d]; bo += n_amb[d];
     }
-    if (!oct_assemble(r->x, depth, lv.data(), n_levels, (const FhMeshLeaf*)rec, n_rec, (const FhMdcTable*)table, mat, &r->out)) { delete r; return nullptr; }
+    if (oct_assemble(r->x, depth, lv.data(), n_levels, (const FhMeshLeaf*)rec, n_rec, (const FhMdcTable*)table, mat, &r->out) != OCT_OK) { delete r; return nullptr; }
     for (uint32_t d = 0; d + 1 < n_levels; d++)
         for (uint32_t s = 0; lv[d].res && s < lv[d].n_amb; s++) r->collapsed += lv[d].res[s].kind == C_LEAF;
     return r;

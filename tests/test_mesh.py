@@ -508,8 +508,8 @@ def test_library_dual_walk_sequential_and_parallel(model, depth, threads, oracle
     ref_t, ref_v = oc.walk_dual()
     kinds = {"Invalid": 0, "Empty": 1, "Full": 2, "Branch": 3, "Leaf": 4}
     root = np.array([kinds[oc.root[0]], oc.root[1], oc.root[2]], np.uint32)
-    monkeypatch.setenv("FHIP_MESH_THREADS", str(threads))
-    for parallel in (0, 1):
+    for parallel, th in ((0, threads), (1, threads), (2, threads), (2, 1)):     # 2: as fhip_mesh_build walks - cells through a view, the mesh's vertices gathered
+        monkeypatch.setenv("FHIP_MESH_THREADS", str(th))
         t, v = F.debug_walk_dual(oc.cells, root, oc.verts, parallel)
         assert len(ref_t) > 1000
         assert (t == ref_t).all() and t.shape == ref_t.shape
