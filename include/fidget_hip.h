@@ -218,8 +218,8 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
 /* fidget_mesh::Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225; Settings: depth, world_to_model): fhip_mesh_sample, then
  * the octree assembled from the device's results - cell collapse (check_done / try_collapse, octree.rs:256-385) with the merged
- * Hermite data included - ON THE DEVICE, level by level (the leaf records never leave HBM; the host receives the octree's blocks
- * of cells and its vertices), and the dual walk (dc.rs) on the host's threads (independent sub-walks; FHIP_MESH_THREADS, default:
+ * Hermite data included - ON THE DEVICE, level by level (neither the leaf records nor the octree's vertices leave HBM: the host
+ * receives the octree's blocks of cells, and the vertices the walk finds the mesh to use), and the dual walk (dc.rs) on the host's threads (independent sub-walks; FHIP_MESH_THREADS, default:
  * all cores up to 32 - more were measured slower) -> Mesh { vertices, triangles } (lib.rs:64-69): the cells, vertices and
  * triangles of the single-threaded recursion, in its order.  Context option "mesh_device_assembly" 0: the assembly on the
  * host's threads too (independent subtrees, as build_inner_mt octree.rs:94-210), from copies of the levels and the leaf records -
