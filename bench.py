@@ -29,7 +29,8 @@ What the ONE JSON line says, and how to read it:
                              tile-stage kernel fh_tiles_v32 likewise (tape ops read + written at the per-slab level);
   cpu_baseline               the C++ oracle (restatement of the reference's VmShape path, OpenMP over root tiles like
                              render_tiles' rayon pool) on this box's host cores, same frame; parity of the device image
-                             against it at full size; `c3_bear`: BASELINE configuration 3 with its measured normal error.
+                             against it at full size; `c3_bear`: BASELINE configuration 3 with its measured normal error; `c5_mesh`:
+                             BASELINE configuration 5, seconds per mesh build.
 
 N > 1: ONE frame sharded over the ranks (total work fixed: "strong") - "columns" (root-tile column index % N == rank at
 full depth; one RCCL SUM reduce of the partial images) and "blocks" (the north star's octants, 2 x 2 x 2 at N = 8: a
@@ -463,6 +464,29 @@ def main():
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
                                  "note": "transcendental opcodes: the north star grants 1 ulp per f32 value; per opcode the device is within 1 ulp of glibc over all "
                                          "2^32 inputs (profiles/r02/math_sweep.json), a gradient chains several of them"}
+        # BASELINE configuration 5 (Manifold Dual Contouring of gyroid-sphere at octree depth 10 = 1024^3: fhip_mesh_build, the octree
+        # assembled on the device, the dual walk on the host's threads): seconds per build, in a process of its own (tools/mesh_times.py,
+        # the script profiles/r03z/mesh_times.log comes from) so that nothing it does can cost this line
+        if args.model == "prospero.vm" and os.path.exists(os.path.join(ROOT, "models", "gyroid-sphere.vm")):
+            try:
+                import re
+                import subprocess
+                env = dict(os.environ, MESH_TIMES_REPS="3")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=180)
+                builds = [float(m.group(1)) for m in re.finditer(r"^10 build \d+ ([0-9.]+)$", r.stdout, re.M)]
+                inside = [float(m.group(1)) for m in re.finditer(r"^fhip mesh depth 10: .* total ([0-9.]+) s$", r.stderr, re.M)]
+                counts = re.search(r"'triangles': (\d+), 'vertices': (\d+)", r.stdout)
+                if r.returncode == 0 and len(builds) >= 2:
+                    result["c5_mesh"] = {"workload": "gyroid-sphere.vm Manifold Dual Contouring, octree depth 10 (1024^3)", "s_per_build": min(builds[1:]),
+                                         "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
+                                         "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
+                                         "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of two after the first "
+                                                 "build of this size; parity: tests/test_mesh.py (identical to the oracle's mesh where the oracle finishes in "
+                                                 "seconds; within the transcendental tolerance for this model)"}
+                else:
+                    result["c5_mesh"] = {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+            except Exception as e:      # (a time-out included: the line's other fields do not depend on this leg)
+                result["c5_mesh"] = {"error": repr(e)}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
