@@ -54,6 +54,22 @@ VALU_PEAK_LANE_OPS = 78.6e12  # plain f32 VALU lane-operations per second: 256 C
 TRAFFIC_FILE = os.path.join("profiles", "traffic_r03.json")
 
 
+def parse_mesh_times(stdout, stderr):
+    """What tools/mesh_times.py 10 (MESH_TIMES_REPS >= 2) printed -> the `c5_mesh` object, or None if it did not get through its builds"""
+    import re
+    builds = [float(m.group(1)) for m in re.finditer(r"^10 build \d+ ([0-9.]+)$", stdout, re.M)]
+    inside = [float(m.group(1)) for m in re.finditer(r"^fhip mesh depth 10: .* total ([0-9.]+) s$", stderr, re.M)]
+    counts = re.search(r"'triangles': (\d+), 'vertices': (\d+)", stdout)
+    if len(builds) < 2:
+        return None
+    return {"workload": "gyroid-sphere.vm Manifold Dual Contouring, octree depth 10 (1024^3)", "s_per_build": min(builds[1:]),
+            "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
+            "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
+            "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of the builds after the first "
+                    "of this size; parity: tests/test_mesh.py (identical to the oracle's mesh where the oracle finishes in seconds; within the "
+                    "transcendental tolerance for this model)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,22 +485,11 @@ def main():
         # the script profiles/r03z/mesh_times.log comes from) so that nothing it does can cost this line
         if args.model == "prospero.vm" and os.path.exists(os.path.join(ROOT, "models", "gyroid-sphere.vm")):
             try:
-                import re
                 import subprocess
                 env = dict(os.environ, MESH_TIMES_REPS="3")
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=180)
-                builds = [float(m.group(1)) for m in re.finditer(r"^10 build \d+ ([0-9.]+)$", r.stdout, re.M)]
-                inside = [float(m.group(1)) for m in re.finditer(r"^fhip mesh depth 10: .* total ([0-9.]+) s$", r.stderr, re.M)]
-                counts = re.search(r"'triangles': (\d+), 'vertices': (\d+)", r.stdout)
-                if r.returncode == 0 and len(builds) >= 2:
-                    result["c5_mesh"] = {"workload": "gyroid-sphere.vm Manifold Dual Contouring, octree depth 10 (1024^3)", "s_per_build": min(builds[1:]),
-                                         "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
-                                         "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
-                                         "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of two after the first "
-                                                 "build of this size; parity: tests/test_mesh.py (identical to the oracle's mesh where the oracle finishes in "
-                                                 "seconds; within the transcendental tolerance for this model)"}
-                else:
-                    result["c5_mesh"] = {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+                c5 = parse_mesh_times(r.stdout, r.stderr) if r.returncode == 0 else None
+                result["c5_mesh"] = c5 if c5 else {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
             except Exception as e:      # (a time-out included: the line's other fields do not depend on this leg)
                 result["c5_mesh"] = {"error": repr(e)}
     print(json.dumps(result))

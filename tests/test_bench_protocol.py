@@ -170,3 +170,19 @@ def test_bench_two_ranks_protocol(tmp_path, direct):
     assert p["columns"]["frame_latency_ms"] > 0 and p["blocks"]["frame_latency_ms"] > 0
     assert ("DirectRccl" in r["collectives"]) if direct else ("torch.distributed" in r["collectives"])
     assert "roofline" not in r and "cpu_baseline" not in r         # rank 0 at N = 1 only
+
+
+def test_c5_mesh_leg_reads_the_mesh_tools_output():
+    """bench.py's `c5_mesh` comes from tools/mesh_times.py run as a process of its own; what it prints is parsed by
+    bench.parse_mesh_times - here on the committed output of that very command on an MI355X (profiles/r03z/mesh_times.log)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = open(os.path.join(root, "profiles", "r03z", "mesh_times.log")).read()
+    c5 = bench.parse_mesh_times(log, log)
+    assert c5["triangles"] == 15050590 and c5["vertices"] == 7521871
+    assert 1.0 < c5["s_per_build_inside_the_library"] < c5["s_per_build"] < c5["s_first_build"] < 2.0
+    assert bench.parse_mesh_times("Traceback (most recent call last): ...", "") is None
+    assert bench.parse_mesh_times("10 build 0 1.5\n", "") is None          # (one build only: nothing after the first)
