@@ -2163,6 +2163,9 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         if (!attr_done[d]) {
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_cells, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX - 2048);
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_corners, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_edges, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_grads, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
             attr_done[d] = true;
         }
     }
@@ -2172,12 +2175,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
-    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot;
+    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
         bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
+        edge_list.release(); edge_count.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
     };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -2231,17 +2235,48 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         MESH_TRY(table.ensure(sizeof(mdc)));
         MESH_TRY(hipMemcpyAsync(table.p, &mdc, sizeof(mdc), hipMemcpyHostToDevice, ctx->stream));
     }
+    // one chunk of leaf cells sampled into records: as passes in which every lane has a point of its own (corners, the edge search over the
+    // chunk's list of edges, gradients), or - FHIP_MESH_LEAF_PASSES=0 - one wavefront per cell (k_mesh_leaf); then the cell vertices' QEFs
+    const uint32_t LEAF_CH = 1u << 19;
+    const char* const lp_env = getenv("FHIP_MESH_LEAF_PASSES");        // diagnostic: 0 = k_mesh_leaf, the kernel the passes are checked against
+    const bool leaf_passes = !(lp_env && lp_env[0] == '0');
+    const size_t lds_f32 = (size_t)P.n_regs * WAVE * 4;
+    auto sample_chunk = [&](const FhMeshCell* cells, FhMeshLeaf* recs, uint32_t cnt) -> hipError_t {
+        hipError_t e = hipSuccess;
+        auto ck = [&](hipError_t x) { if (x != hipSuccess && e == hipSuccess) e = x; };
+        if (leaf_passes && cnt < (1u << 28)) {
+            ck(edge_list.ensure((size_t)LEAF_CH * 12 * 4));
+            ck(edge_count.ensure(4));
+            if (e != hipSuccess) return e;
+            ck(hipMemsetAsync(edge_count.p, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(fhm::k_mesh_corners, dim3((cnt + 7) / 8), dim3(WAVE), lds_f32, ctx->stream, P, cells, cnt, (const FhMdcTable*)table.p, recs,
+                               (uint32_t*)edge_count.p, (uint32_t*)edge_list.p);
+            ck(hipGetLastError());
+            uint32_t n_edges = 0;
+            ck(hipMemcpyAsync(&n_edges, edge_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            ck(hipStreamSynchronize(ctx->stream));
+            if (e == hipSuccess && n_edges) {
+                hipLaunchKernelGGL(fhm::k_mesh_edges, dim3((n_edges + 3) / 4), dim3(WAVE), lds_f32, ctx->stream, P, (const FhMdcTable*)table.p, recs, (const uint32_t*)edge_list.p, n_edges);
+                ck(hipGetLastError());
+                hipLaunchKernelGGL(fhm::k_mesh_grads, dim3((n_edges + WAVE - 1) / WAVE), dim3(WAVE), lds_leaf, ctx->stream, P, recs, (const uint32_t*)edge_list.p, n_edges);
+                ck(hipGetLastError());
+            }
+        } else {
+            hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, cells, cnt, (const FhMdcTable*)table.p, recs);
+            ck(hipGetLastError());
+        }
+        hipLaunchKernelGGL(fhm::k_mesh_leaf_qef, dim3((cnt + WAVE - 1) / WAVE), dim3(WAVE), 0, ctx->stream, (const FhMdcTable*)table.p, recs, cnt);
+        ck(hipGetLastError());
+        return e;
+    };
     if (n_leaf_cells && dev_asm) {      // the records stay in HBM
         MESH_TRY(leaves.ensure((size_t)n_leaf_cells * sizeof(FhMeshLeaf)));
-        const uint32_t CH = 1u << 19;
+        const uint32_t CH = LEAF_CH;
         const void* const leaf_cells = lv_amb[depth].p;
         for (uint32_t off = 0; off < n_leaf_cells; off += CH) {
             const uint32_t cnt = std::min<uint32_t>(CH, n_leaf_cells - off);
-            hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)leaf_cells + off, cnt,
-                               (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off);
-            MESH_TRY(hipGetLastError());
-            hipLaunchKernelGGL(fhm::k_mesh_leaf_qef, dim3((cnt + WAVE - 1) / WAVE), dim3(WAVE), 0, ctx->stream, (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off, cnt);
-            MESH_TRY(hipGetLastError());
+            const hipError_t se = sample_chunk((const FhMeshCell*)leaf_cells + off, (FhMeshLeaf*)leaves.p + off, cnt);
+            MESH_TRY(se);
         }
         if (times) { MESH_TRY(hipStreamSynchronize(ctx->stream)); t_leaf = now() - t_start - t_cells; }
     } else if (n_leaf_cells) {
@@ -2260,7 +2295,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         } else
             MESH_TRY(hipHostMalloc((void**)&M->leaves.p, leaf_bytes, hipHostMallocDefault));
         M->leaves.n = n_leaf_cells;
-        const uint32_t CH = 1u << 19;
+        const uint32_t CH = LEAF_CH;
         std::vector<hipEvent_t> evs;
         hipStream_t const copy_stream = ctx->stream2 ? ctx->stream2 : ctx->stream;
         bool ok = true;
@@ -2268,11 +2303,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         auto chk = [&](hipError_t e) { if (e != hipSuccess && ok) { ok = false; first_err = e; } };
         for (uint32_t off = 0; off < n_leaf_cells && ok; off += CH) {
             const uint32_t cnt = std::min<uint32_t>(CH, n_leaf_cells - off);
-            hipLaunchKernelGGL(fhm::k_mesh_leaf, dim3(cnt), dim3(WAVE), lds_leaf, ctx->stream, P, (const FhMeshCell*)bufs[cur].p + off, cnt,
-                               (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off);
-            chk(hipGetLastError());
-            hipLaunchKernelGGL(fhm::k_mesh_leaf_qef, dim3((cnt + WAVE - 1) / WAVE), dim3(WAVE), 0, ctx->stream, (const FhMdcTable*)table.p, (FhMeshLeaf*)leaves.p + off, cnt);
-            chk(hipGetLastError());
+            chk(sample_chunk((const FhMeshCell*)bufs[cur].p + off, (FhMeshLeaf*)leaves.p + off, cnt));
             hipEvent_t ev = nullptr;
             chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             if (ev) evs.push_back(ev);

@@ -3,9 +3,11 @@
 //   k_mesh_cells  one lane per octree cell of a level: cell bounds (cell.rs:184-194 midpoint splitting), interval
 //                 evaluation of the shape's tape (octree.rs:521-544), classification Full / Empty / ambiguous; the ambiguous
 //                 cells are appended to the next level's list (or, at the last level, to the leaf list);
-//   k_mesh_leaf   one wavefront per ambiguous leaf cell (octree.rs:590-862): the 8 corners (bulk f32) -> corner mask ->
-//                 edges of the Manifold Dual Contouring table -> 4 rounds of 16-point search per edge (4 edges per 64-lane
-//                 pass) -> intersections (u16 cell coordinates) -> gradients there;
+//   k_mesh_corners / k_mesh_edges / k_mesh_grads   the ambiguous leaf cells sampled (octree.rs:590-862) in passes over a chunk of them,
+//                 every lane a point of its own: the 8 corners (bulk f32) -> corner mask -> edges of the Manifold Dual Contouring
+//                 table -> 4 rounds of 16-point search per edge (one wave per four edges) -> intersections (u16 cell
+//                 coordinates) -> gradients there (one lane per edge);
+//   k_mesh_leaf   the same with one wavefront per leaf cell (FHIP_MESH_LEAF_PASSES=0; what the passes are checked against);
 //   k_mesh_leaf_qef  one lane per leaf record: one QEF per cell vertex (qef.rs).
 //
 // Every cell is evaluated with the shape's own tape (values do not depend on tape simplification); pruning
@@ -198,6 +200,115 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
     }
     // (the QEFs of the cell vertices: k_mesh_leaf_qef, one LANE per record - here they kept a whole wavefront waiting on lane 0)
     if (lane == 0) { o->n_edges = ne; o->n_verts = nv; }
+}
+
+// ---- the same leaf sampling as passes over all leaf cells of a chunk (what fhip_mesh_* run; FHIP_MESH_LEAF_PASSES=0: k_mesh_leaf) --------------------------------------
+// k_mesh_leaf gives a leaf a wavefront and leaves most of its lanes idle most of the time: 8 of 64 at the corners, 16 x (edges mod 4)
+// in the last pass of a search round, one per edge in the gradient pass - about half of its lane-evaluations are wasted, and every one
+// is ~90 f64 operations for a sin / cos.  Here every lane of every pass has a point of its own: corners 8 cells per wave; the edge
+// search one wave per FOUR EDGES, of whatever cells (the cells' edges are appended to a list as the corners find them; the 16 lanes of an
+// edge keep its bracket in registers through the four rounds: no LDS, no barriers); gradients one lane per edge.  Per lane the arithmetic
+// is k_mesh_leaf's, operation for operation: the records are the same, bit for bit.
+__global__ void __launch_bounds__(WAVE) k_mesh_corners(FhMeshParams P, const FhMeshCell* cells, uint32_t n, const FhMdcTable* T, FhMeshLeaf* out,
+                                                        uint32_t* edge_count, uint32_t* edge_list /* (cell << 4) | edge */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x, cr = lane & 7;
+    const uint32_t li = blockIdx.x * 8 + (lane >> 3);
+    const bool act = li < n;
+    const FhMeshCell c = cells[act ? li : n - 1];
+    Regs<float, WAVE> R{(float*)smem, lane};
+    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4]);
+    const uint32_t mask = (uint32_t)((ballot(v < 0.0f) >> (lane & ~7)) & 0xFFull);
+    const uint32_t ne = (mask == 0 || mask == 255) ? 0u : T->n_edges[mask];
+    // this wave's edges: one reservation in the list, the cells' shares in cell order
+    uint32_t before = 0, total = 0;
+    for (int g = 0; g < 8; g++) {
+        const uint32_t ng = (uint32_t)__shfl((int)(act ? ne : 0u), g * 8);
+        if (g < (lane >> 3)) before += ng;
+        total += ng;
+    }
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(edge_count, total);
+    base = uni(base);
+    if (!act) return;
+    FhMeshLeaf* o = &out[li];
+    if (cr < 6) o->b[cr] = c.b[cr];
+    if (cr == 0) { o->path = c.path; o->mask = mask; o->n_edges = ne; o->n_verts = ne ? T->n_verts[mask] : 0u; o->pad = 0; }
+    for (uint32_t e = cr; e < ne; e += 8) edge_list[base + before + e] = (li << 4) | e;
+}
+
+__global__ void __launch_bounds__(WAVE) k_mesh_edges(FhMeshParams P, const FhMdcTable* T, FhMeshLeaf* out, const uint32_t* edge_list, uint32_t n_edges) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x, grp = lane >> 4;
+    const uint32_t j = lane & 15;
+    const uint32_t k = blockIdx.x * 4 + grp;
+    const bool valid = k < n_edges;
+    const uint32_t ent = edge_list[valid ? k : 0];
+    FhMeshLeaf* o = &out[ent >> 4];
+    const uint32_t e = ent & 15u, mask = o->mask;
+    float b[6];
+    for (int q = 0; q < 6; q++) b[q] = o->b[q];
+    // the edge's end points in u16 cell coordinates (octree.rs:662-695), as k_mesh_leaf sets them up
+    uint32_t s[3] = {0, 0, 0}, t[3];
+    {
+        const int st = T->edge[mask][e][0], en = T->edge[mask][e][1];
+        const int axis = st ^ en, ai = axis == 1 ? 0 : (axis == 2 ? 1 : 2);
+        const int i1 = (ai + 1) % 3, i2 = (ai + 2) % 3;
+        s[i1] = (st & (1 << i1)) ? 65535u : 0u;
+        s[i2] = (st & (1 << i2)) ? 65535u : 0u;
+        for (int q = 0; q < 3; q++) t[q] = s[q];
+        s[ai] = (en & axis) ? 0u : 65535u;
+        t[ai] = (en & axis) ? 65535u : 0u;
+    }
+    Regs<float, WAVE> R{(float*)smem, lane};
+    for (int round = 0; round < 4; round++) {       // N-ary search: 16 points per round (octree.rs:697-768)
+        uint32_t p[3];
+        for (int q = 0; q < 3; q++) p[q] = (s[q] * (15u - j) + t[q] * j) / 15u;
+        const float r = eval_point(P, R, lerp_pos(b[0], b[1], p[0]), lerp_pos(b[2], b[3], p[1]), lerp_pos(b[4], b[5], p[2]));
+        const uint32_t m16 = (uint32_t)(ballot(r >= 0.0f) >> (grp * 16)) & 0xFFFFu;
+        uint32_t frac = m16 ? (uint32_t)__builtin_ctz(m16) : 16u;
+        if (frac == 0) frac = 1;
+        if (frac > 15) frac = 15;
+        for (int q = 0; q < 3; q++) {
+            const uint32_t lo = (uint32_t)(uint16_t)((s[q] * (15u - (frac - 1)) + t[q] * (frac - 1)) / 15u);
+            const uint32_t hi = (uint32_t)(uint16_t)((s[q] * (15u - frac) + t[q] * frac) / 15u);
+            s[q] = lo; t[q] = hi;
+        }
+    }
+    if (valid && j == 0) {
+        uint16_t qq[3];
+        for (int q = 0; q < 3; q++) qq[q] = (uint16_t)((s[q] + t[q]) / 2u);
+        for (int q = 0; q < 3; q++) o->inter[e][q] = qq[q];
+        o->pos[e][0] = lerp_pos(b[0], b[1], qq[0]); o->pos[e][1] = lerp_pos(b[2], b[3], qq[1]); o->pos[e][2] = lerp_pos(b[4], b[5], qq[2]);
+    }
+}
+
+// gradients at the intersections (octree.rs:771-803): one lane per edge
+__global__ void __launch_bounds__(WAVE) k_mesh_grads(FhMeshParams P, FhMeshLeaf* out, const uint32_t* edge_list, uint32_t n_edges) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t k = blockIdx.x * WAVE + lane;
+    const bool valid = k < n_edges;
+    const uint32_t ent = edge_list[valid ? k : 0];
+    FhMeshLeaf* o = &out[ent >> 4];
+    const uint32_t e = ent & 15u;
+    const float px = o->pos[e][0], py = o->pos[e][1], pz = o->pos[e][2];
+    GR gx = gr(px, 1.0f, 0.0f, 0.0f), gy = gr(py, 0.0f, 1.0f, 0.0f), gz = gr(pz, 0.0f, 0.0f, 1.0f);
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int q = 0; q < 16; q++) m.m[q] = P.mat[q];
+        xf_grad(m, gx, gy, gz, gx, gy, gz);
+    }
+    Regs<GR, WAVE> G{(GR*)smem, lane};
+    GR result = gr1(qnan());
+    const ctape_t tape = (ctape_t)P.tape;
+    for (uint32_t q = 0; q < P.len; q++) {
+        step<GRAD, WAVE, true>(
+            tape[q], G, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot]))); },
+            [&](uint32_t, GR v) { result = v; }, [&](int) {});
+    }
+    if (valid) { o->grad[e][0] = result.dx; o->grad[e][1] = result.dy; o->grad[e][2] = result.dz; o->grad[e][3] = result.v; }
 }
 
 // one QEF per cell vertex (octree.rs:805-848), vertices in order: a NaN gradient snaps the vertex to that intersection and

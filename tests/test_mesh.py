@@ -392,6 +392,33 @@ def test_device_mesh_colonnade_at_the_reference_s_depth(oracle_mod):     # octre
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 7), ("colonnade.vm", 6), ("bear.vm", 5)])
+def test_leaf_passes_equal_the_per_cell_kernel(model, depth, monkeypatch):
+    """The leaf sampling as passes over a chunk's cells (k_mesh_corners / k_mesh_edges / k_mesh_grads: every lane a point of its own) writes
+    the records of k_mesh_leaf (one wavefront per cell), bit for bit - per lane the arithmetic is the same."""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(model_path(model))
+    monkeypatch.delenv("FHIP_MESH_LEAF_PASSES", raising=False)
+    a, ca = F.mesh_sample(shape, depth)
+    monkeypatch.setenv("FHIP_MESH_LEAF_PASSES", "0")          # (read by every build: the per-cell kernel)
+    b, cb = F.mesh_sample(shape, depth)
+    monkeypatch.delenv("FHIP_MESH_LEAF_PASSES")
+    assert ca == cb and len(a) == len(b) > 1000
+    a, b = a[np.argsort(a["path"], kind="stable")], b[np.argsort(b["path"], kind="stable")]       # (a level's cells take their slots from an atomic counter: any order)
+    assert len(np.unique(a["path"])) == len(a)
+    for f in ("bounds", "path", "mask", "n_edges", "n_verts"):
+        assert (a[f] == b[f]).all(), f
+    ne, nv = a["n_edges"], a["n_verts"]
+    e_ok = np.arange(12)[None, :] < ne[:, None]
+    v_ok = np.arange(4)[None, :] < nv[:, None]
+    assert (a["inter"][e_ok] == b["inter"][e_ok]).all()
+    for f, ok in (("pos", e_ok), ("grad", e_ok), ("vert", v_ok)):
+        x, y = a[f][ok].view(np.uint32), b[f][ok].view(np.uint32)
+        assert (x == y).all(), f
+    assert (a["qef_err"][v_ok].view(np.uint32) == b["qef_err"][v_ok].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 8), ("colonnade.vm", 7), ("bear.vm", 6), ("prospero.vm", 7)])
 def test_device_assembly_equals_the_host_assembly(model, depth):
     """fhip_mesh_build assembles the octree in HBM (k_oct_*: check_done / collapse / places, mesh_collapse.hpp) and hands the host the
