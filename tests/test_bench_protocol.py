@@ -141,24 +141,24 @@ def _worker(rank, world, port, out_path, direct):
     sys.stdout.flush()
 
 
-@pytest.mark.parametrize("direct", [False, True])
-def test_bench_two_ranks_protocol(tmp_path, direct):
+@pytest.mark.parametrize("direct,world", [(False, 2), (True, 2), (True, 4)])
+def test_bench_two_ranks_protocol(tmp_path, direct, world):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out_path = str(tmp_path / "rank0.out")
-    mp.spawn(_worker, args=(2, port, out_path, direct), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out_path, direct), nprocs=world, join=True)
     lines = [l for l in open(out_path).read().splitlines() if l.strip()]
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in r, key
-    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["unit"] == "Mvoxel/s" and r["higher_is_better"] is True
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["unit"] == "Mvoxel/s" and r["higher_is_better"] is True
     assert r["vs_baseline"] is None and r["data"] == "synthetic" and "workload" in r["config"] and "sharding" in r["config"]
     p = r["partitions"]
-    assert p["images_equal"] is True and p["frames"]["images_equal"] is True and p["frames"]["frames_per_step"] == 2
+    assert p["images_equal"] is True and p["frames"]["images_equal"] is True and p["frames"]["frames_per_step"] == world
     for k in ("columns", "blocks", "frames"):
         assert p[k]["ms_per_step"] > 0 and p[k]["value"] > 0
     # `value` is ONE frame sharded over the ranks (the north star's number: total work fixed), by the better of the two
