@@ -75,9 +75,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_FLOAT_16x4_T, FH_ASM_FLOAT_32x2_T, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t", "fh_float_eval_16x4_t", "fh_float_eval_32x2_t"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -701,12 +701,15 @@ static fhip_status bulk_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* 
     const size_t lds = (size_t)nr * WAVE * 4 * comp;
     const bool g = lds > FH_LDS_MAX;
     if (g) HIP_TRY(ctx, ctx->io_e.ensure(lds * grid));
-    if (comp == 1 && ctx->use_asm && nr <= 32 && tape_asm_ok(t)) {
-        // 64 * ZB samples per wave, register file in VGPRs (gen_interp.py)
+    if (comp == 1 && ctx->use_asm && nr <= 32) {
+        // 64 * ZB samples per wave, register file in VGPRs (gen_interp.py); tapes with transcendental / modulo / rng opcodes: the kernels
+        // whose handlers call the compiled routines
+        const bool plain = tape_asm_ok(t);
         struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } ka = {
             tape->d_ops, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (uint32_t)t.ops.size(), n};
         const uint32_t per = nr <= 16 ? 256 : 128;
-        HIP_TRY(ctx, launch_asm(ctx, nr <= 16 ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_32x2, (n + per - 1) / per, &ka, sizeof(ka)));
+        HIP_TRY(ctx, launch_asm(ctx, nr <= 16 ? (plain ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_16x4_T) : (plain ? FH_ASM_FLOAT_32x2 : FH_ASM_FLOAT_32x2_T), (n + per - 1) / per, &ka,
+                                sizeof(ka)));
     } else if (comp == 1) {
         if (g) hipLaunchKernelGGL(k_eval_f32<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
                            (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)nullptr, (uint8_t*)nullptr, 0u, (float*)ctx->io_e.p, nr);
