@@ -2178,13 +2178,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
-    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count;
+    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
         bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
-        edge_list.release(); edge_count.release();
+        edge_list.release(); edge_count.release(); edge_br.release(); edge_vars.release(); edge_vals.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
     };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -2243,6 +2243,10 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     const uint32_t LEAF_CH = 1u << 19;
     const char* const lp_env = getenv("FHIP_MESH_LEAF_PASSES");        // diagnostic: 0 = k_mesh_leaf, the kernel the passes are checked against
     const bool leaf_passes = !(lp_env && lp_env[0] == '0');
+    const char* const be_env = getenv("FHIP_MESH_BULK_EDGES");          // diagnostic: 0 = the edge search by k_mesh_edges (the generic interpreter)
+    const bool bulk_edges = leaf_passes && ctx->use_asm && P.n_regs <= 32 && !(be_env && be_env[0] == '0');
+    uint32_t n_slots = std::max<uint32_t>(t.n_vars, 1);
+    for (uint32_t sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) n_slots = std::max(n_slots, sl + 1);
     const size_t lds_f32 = (size_t)P.n_regs * WAVE * 4;
     auto sample_chunk = [&](const FhMeshCell* cells, FhMeshLeaf* recs, uint32_t cnt) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -2258,7 +2262,38 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             uint32_t n_edges = 0;
             ck(hipMemcpyAsync(&n_edges, edge_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             ck(hipStreamSynchronize(ctx->stream));
-            if (e == hipSuccess && n_edges) {
+            if (e == hipSuccess && n_edges && bulk_edges) {
+                // the four rounds as passes over the chunk's edges, the samples' values from the assembly bulk interpreter (mesh_edges.hpp)
+                const uint32_t n = n_edges * 16u;
+                ck(edge_br.ensure((size_t)n_edges * sizeof(fhmesh::EdgeBracket)));
+                ck(edge_vars.ensure((size_t)n_slots * n * 4));
+                ck(edge_vals.ensure((size_t)n * 4));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(fhm::k_mesh_edge_begin, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, (const FhMdcTable*)table.p, (const FhMeshLeaf*)recs,
+                                   (const uint32_t*)edge_list.p, n_edges, (fhmesh::EdgeBracket*)edge_br.p);
+                ck(hipGetLastError());
+                for (uint32_t sl = 0; sl < n_slots; sl++)
+                    if (P.in_kind[sl] >= 3) {
+                        hipLaunchKernelGGL(fhm::k_mesh_fill, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (float*)edge_vars.p + (size_t)sl * n, P.in_value[sl], n);
+                        ck(hipGetLastError());
+                    }
+                struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } ka = {tape->d_ops, (const float*)edge_vars.p, (float*)edge_vals.p, P.len, n};
+                const bool plain = tape_asm_ok(t);
+                const uint32_t per = P.n_regs <= 16 ? 256 : 128;
+                const int which = P.n_regs <= 16 ? (plain ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_16x4_T) : (plain ? FH_ASM_FLOAT_32x2 : FH_ASM_FLOAT_32x2_T);
+                for (int round = 0; round < 4 && e == hipSuccess; round++) {
+                    hipLaunchKernelGGL(fhm::k_mesh_edge_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P, (const FhMeshLeaf*)recs, (const uint32_t*)edge_list.p,
+                                       (const fhmesh::EdgeBracket*)edge_br.p, n_edges, (float*)edge_vars.p, n);
+                    ck(hipGetLastError());
+                    ck(launch_asm(ctx, which, (n + per - 1) / per, &ka, sizeof(ka)));
+                    hipLaunchKernelGGL(fhm::k_mesh_edge_narrow, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, (fhmesh::EdgeBracket*)edge_br.p, (const float*)edge_vals.p, n_edges);
+                    ck(hipGetLastError());
+                }
+                hipLaunchKernelGGL(fhm::k_mesh_edge_end, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, recs, (const uint32_t*)edge_list.p, (const fhmesh::EdgeBracket*)edge_br.p, n_edges);
+                ck(hipGetLastError());
+                hipLaunchKernelGGL(fhm::k_mesh_grads, dim3((n_edges + WAVE - 1) / WAVE), dim3(WAVE), lds_leaf, ctx->stream, P, recs, (const uint32_t*)edge_list.p, n_edges);
+                ck(hipGetLastError());
+            } else if (e == hipSuccess && n_edges) {
                 hipLaunchKernelGGL(fhm::k_mesh_edges, dim3((n_edges + 3) / 4), dim3(WAVE), lds_f32, ctx->stream, P, (const FhMdcTable*)table.p, recs, (const uint32_t*)edge_list.p, n_edges);
                 ck(hipGetLastError());
                 hipLaunchKernelGGL(fhm::k_mesh_grads, dim3((n_edges + WAVE - 1) / WAVE), dim3(WAVE), lds_leaf, ctx->stream, P, recs, (const uint32_t*)edge_list.p, n_edges);
