@@ -75,9 +75,9 @@ struct fhip_graph {
 __asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
 #endif
 extern "C" const char fh_interp_co[];
-enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_COUNT };
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_FLOAT_16x4_T, FH_ASM_FLOAT_32x2_T, FH_ASM_COUNT };
 static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
-                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t"};
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t", "fh_float_eval_16x4_t", "fh_float_eval_32x2_t"};
 // register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
 static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
 
@@ -701,12 +701,15 @@ static fhip_status bulk_eval(fhip_ctx* ctx, const fhip_tape* tape, const float* 
     const size_t lds = (size_t)nr * WAVE * 4 * comp;
     const bool g = lds > FH_LDS_MAX;
     if (g) HIP_TRY(ctx, ctx->io_e.ensure(lds * grid));
-    if (comp == 1 && ctx->use_asm && nr <= 32 && tape_asm_ok(t)) {
-        // 64 * ZB samples per wave, register file in VGPRs (gen_interp.py)
+    if (comp == 1 && ctx->use_asm && nr <= 32) {
+        // 64 * ZB samples per wave, register file in VGPRs (gen_interp.py); tapes with transcendental / modulo / rng opcodes: the kernels
+        // whose handlers call the compiled routines
+        const bool plain = tape_asm_ok(t);
         struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } ka = {
             tape->d_ops, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (uint32_t)t.ops.size(), n};
         const uint32_t per = nr <= 16 ? 256 : 128;
-        HIP_TRY(ctx, launch_asm(ctx, nr <= 16 ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_32x2, (n + per - 1) / per, &ka, sizeof(ka)));
+        HIP_TRY(ctx, launch_asm(ctx, nr <= 16 ? (plain ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_16x4_T) : (plain ? FH_ASM_FLOAT_32x2 : FH_ASM_FLOAT_32x2_T), (n + per - 1) / per, &ka,
+                                sizeof(ka)));
     } else if (comp == 1) {
         if (g) hipLaunchKernelGGL(k_eval_f32<true>, dim3(grid), dim3(WAVE), 0, ctx->stream, tape->d_ops, (uint32_t)t.ops.size(),
                            (const float*)ctx->io_a.p, n, (float*)ctx->io_b.p, (uint8_t*)nullptr, (uint8_t*)nullptr, 0u, (float*)ctx->io_e.p, nr);
@@ -2175,13 +2178,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
-    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count;
+    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
         bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
-        edge_list.release(); edge_count.release();
+        edge_list.release(); edge_count.release(); edge_br.release(); edge_vars.release(); edge_vals.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
     };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -2240,6 +2243,10 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     const uint32_t LEAF_CH = 1u << 19;
     const char* const lp_env = getenv("FHIP_MESH_LEAF_PASSES");        // diagnostic: 0 = k_mesh_leaf, the kernel the passes are checked against
     const bool leaf_passes = !(lp_env && lp_env[0] == '0');
+    const char* const be_env = getenv("FHIP_MESH_BULK_EDGES");          // diagnostic: 0 = the edge search by k_mesh_edges (the generic interpreter)
+    const bool bulk_edges = leaf_passes && ctx->use_asm && P.n_regs <= 32 && !(be_env && be_env[0] == '0');
+    uint32_t n_slots = std::max<uint32_t>(t.n_vars, 1);
+    for (uint32_t sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) n_slots = std::max(n_slots, sl + 1);
     const size_t lds_f32 = (size_t)P.n_regs * WAVE * 4;
     auto sample_chunk = [&](const FhMeshCell* cells, FhMeshLeaf* recs, uint32_t cnt) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -2255,7 +2262,38 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             uint32_t n_edges = 0;
             ck(hipMemcpyAsync(&n_edges, edge_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             ck(hipStreamSynchronize(ctx->stream));
-            if (e == hipSuccess && n_edges) {
+            if (e == hipSuccess && n_edges && bulk_edges) {
+                // the four rounds as passes over the chunk's edges, the samples' values from the assembly bulk interpreter (mesh_edges.hpp)
+                const uint32_t n = n_edges * 16u;
+                ck(edge_br.ensure((size_t)n_edges * sizeof(fhmesh::EdgeBracket)));
+                ck(edge_vars.ensure((size_t)n_slots * n * 4));
+                ck(edge_vals.ensure((size_t)n * 4));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(fhm::k_mesh_edge_begin, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, (const FhMdcTable*)table.p, (const FhMeshLeaf*)recs,
+                                   (const uint32_t*)edge_list.p, n_edges, (fhmesh::EdgeBracket*)edge_br.p);
+                ck(hipGetLastError());
+                for (uint32_t sl = 0; sl < n_slots; sl++)
+                    if (P.in_kind[sl] >= 3) {
+                        hipLaunchKernelGGL(fhm::k_mesh_fill, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (float*)edge_vars.p + (size_t)sl * n, P.in_value[sl], n);
+                        ck(hipGetLastError());
+                    }
+                struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } ka = {tape->d_ops, (const float*)edge_vars.p, (float*)edge_vals.p, P.len, n};
+                const bool plain = tape_asm_ok(t);
+                const uint32_t per = P.n_regs <= 16 ? 256 : 128;
+                const int which = P.n_regs <= 16 ? (plain ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_16x4_T) : (plain ? FH_ASM_FLOAT_32x2 : FH_ASM_FLOAT_32x2_T);
+                for (int round = 0; round < 4 && e == hipSuccess; round++) {
+                    hipLaunchKernelGGL(fhm::k_mesh_edge_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P, (const FhMeshLeaf*)recs, (const uint32_t*)edge_list.p,
+                                       (const fhmesh::EdgeBracket*)edge_br.p, n_edges, (float*)edge_vars.p, n);
+                    ck(hipGetLastError());
+                    ck(launch_asm(ctx, which, (n + per - 1) / per, &ka, sizeof(ka)));
+                    hipLaunchKernelGGL(fhm::k_mesh_edge_narrow, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, (fhmesh::EdgeBracket*)edge_br.p, (const float*)edge_vals.p, n_edges);
+                    ck(hipGetLastError());
+                }
+                hipLaunchKernelGGL(fhm::k_mesh_edge_end, dim3((n_edges + 255) / 256), dim3(256), 0, ctx->stream, recs, (const uint32_t*)edge_list.p, (const fhmesh::EdgeBracket*)edge_br.p, n_edges);
+                ck(hipGetLastError());
+                hipLaunchKernelGGL(fhm::k_mesh_grads, dim3((n_edges + WAVE - 1) / WAVE), dim3(WAVE), lds_leaf, ctx->stream, P, recs, (const uint32_t*)edge_list.p, n_edges);
+                ck(hipGetLastError());
+            } else if (e == hipSuccess && n_edges) {
                 hipLaunchKernelGGL(fhm::k_mesh_edges, dim3((n_edges + 3) / 4), dim3(WAVE), lds_f32, ctx->stream, P, (const FhMdcTable*)table.p, recs, (const uint32_t*)edge_list.p, n_edges);
                 ck(hipGetLastError());
                 hipLaunchKernelGGL(fhm::k_mesh_grads, dim3((n_edges + WAVE - 1) / WAVE), dim3(WAVE), lds_leaf, ctx->stream, P, recs, (const uint32_t*)edge_list.p, n_edges);

@@ -162,6 +162,7 @@ class Interp:
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.t_base = 128    # ... whose register window starts here (behind the register file)
+        self.t_prefix = "fh_t_"   # ... and whose labels start with this (every kernel embeds its own copies)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.hl = HSTRIDE_LOG2
         self.next = f".L{name}_next"
@@ -229,7 +230,7 @@ class Interp:
 {here}:
 	s_add_u32 s96, s96, {ret} - {here}
 	s_addc_u32 s97, s97, 0
-	s_branch fh_t_{fn}
+	s_branch {self.t_prefix}{fn}
 {ret}:""")
 
     def pcg_consts(self):
@@ -1241,11 +1242,17 @@ def _gen_columns_body(a, variants, off, kname, trans):
     return kname, nvg
 
 
-def gen_bulk(a, nr, zb, off):
-    """fh_float_eval: kernarg = {tape*, vars*, out*, len u32, n u32}; vars / out are [slot][n]."""
-    name = f"fh_float_eval_{nr}x{zb}"
-    it = Interp(a, name, nr, zb, "bulk", off)
-    kernel_header(a, name, 32, FILE + nr * zb)
+def gen_bulk(a, nr, zb, off, trans=None):
+    """fh_float_eval: kernarg = {tape*, vars*, out*, len u32, n u32}; vars / out are [slot][n].
+    trans: the variant for tapes with transcendental / modulo / rng opcodes (fh_float_eval_<nr>x<zb>_t): the handlers call the compiled
+    routines, embedded behind the kernel with a register window of 26 VGPRs behind the register file."""
+    name = f"fh_float_eval_{nr}x{zb}" + ("_t" if trans else "")
+    it = Interp(a, name, nr, zb, "bulk", off, trans=bool(trans))
+    n_vgpr = FILE + nr * zb + (26 if trans else 0)
+    if trans:
+        it.t_base = FILE + nr * zb
+        it.t_prefix = f"fh_tb{nr}_"
+    kernel_header(a, name, 32, n_vgpr)
     a(f"""
 	s_load_dwordx2 {S_TAPE}, {S_KERNARG}, 0x0
 	s_load_dwordx2 {S_VARS}, {S_KERNARG}, 0x8
@@ -1267,8 +1274,11 @@ def gen_bulk(a, nr, zb, off):
 	v_cndmask_b32_e64 {VOFF[j]}, 0, {VOFF[j]}, {S_ACT[j]}
 	v_lshlrev_b32 {VOFF[j]}, 2, {VOFF[j]}""")
     call_interp(a, it)
-    kernel_footer(a, name, 32, FILE + nr * zb, 100, True)
+    kernel_footer(a, name, 32, n_vgpr, 100, True)
     it.emit()
+    if trans:
+        import gen_trans
+        gen_trans.embed(a, trans, v_base=it.t_base, prefix=it.t_prefix)
     return name
 
 
@@ -1409,6 +1419,10 @@ def main():
         ks.append(gen_tiles(a, off, trans=sys.argv[3]))
         ks.append(gen_tilesv(a, off, 32, 16, trans=sys.argv[3]))
         ks.append(gen_tilesv(a, off, 64, 32, trans=sys.argv[3]))
+    if len(sys.argv) > 3:
+        for nr, zb in ((16, 4), (32, 2)):
+            n = gen_bulk(a, nr, zb, off, trans=sys.argv[3])
+            ks.append((n, 32, FILE + nr * zb + 26, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
     ks.append(gen_probe(a))
     from gen_ubench import gen_ubench
     ks.append(gen_ubench(a))

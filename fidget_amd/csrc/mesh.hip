@@ -22,6 +22,7 @@
 
 #include "dev_ops.hpp"
 #include "mesh_collapse.hpp"
+#include "mesh_edges.hpp"
 #include "mesh_qef.hpp"
 // (included by capi.hip after kernels.hip: Regs, step, ballot, uni, ctape_t)
 
@@ -37,10 +38,7 @@ struct FhMeshParams {
 namespace fhm {
 using namespace fhd;
 
-__device__ __forceinline__ float lerp_pos(float lo, float hi, uint32_t p) {   // cell.rs:208-217, Interval::lerp
-    const float f = (float)p / 65535.0f;
-    return lo * (1.0f - f) + hi * f;
-}
+using fhmesh::lerp_pos;
 
 // interval evaluation + classification of the cells of one level.  expand: cell i is child (i & 7) of in[i >> 3]
 __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMeshCell* in, uint32_t n, int expand, FhMeshCell* out, uint32_t* counters /* amb, full, empty */,
@@ -281,6 +279,58 @@ __global__ void __launch_bounds__(WAVE) k_mesh_edges(FhMeshParams P, const FhMdc
         for (int q = 0; q < 3; q++) o->inter[e][q] = qq[q];
         o->pos[e][0] = lerp_pos(b[0], b[1], qq[0]); o->pos[e][1] = lerp_pos(b[2], b[3], qq[1]); o->pos[e][2] = lerp_pos(b[4], b[5], qq[2]);
     }
+}
+
+// ---- ... and with the values from the assembly bulk interpreter (fh_float_eval_*[_t]: 256 or 128 samples per wave at ~22 instructions per op,
+// where eval_point's generic interpreter spends ~40 per op on 64): the four rounds as passes over the chunk's edges - this round's 16 sample
+// points per edge written as the interpreter's [slot][n] input arrays, the interpreter, the brackets narrowed by the signs (mesh_edges.hpp).
+__global__ void __launch_bounds__(256) k_mesh_edge_begin(const FhMdcTable* T, const FhMeshLeaf* recs, const uint32_t* edge_list, uint32_t n_edges, fhmesh::EdgeBracket* br) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_edges) return;
+    const uint32_t ent = edge_list[k], mask = recs[ent >> 4].mask, e = ent & 15u;
+    br[k] = fhmesh::edge_ends(T->edge[mask][e][0], T->edge[mask][e][1]);
+}
+// one lane per sample: sample i = 16 * edge + j; vars[slot * n + i] for the tape's x / y / z slots (constant slots are filled once per chunk)
+__global__ void __launch_bounds__(256) k_mesh_edge_points(FhMeshParams P, const FhMeshLeaf* recs, const uint32_t* edge_list, const fhmesh::EdgeBracket* br, uint32_t n_edges,
+                                                           float* vars, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_edges * 16u) return;
+    const uint32_t k = i >> 4, j = i & 15u;
+    const FhMeshLeaf* o = &recs[edge_list[k] >> 4];
+    uint32_t p[3];
+    fhmesh::edge_sample(br[k], j, p);
+    float x = lerp_pos(o->b[0], o->b[1], p[0]), y = lerp_pos(o->b[2], o->b[3], p[1]), z = lerp_pos(o->b[4], o->b[5], p[2]);
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int q = 0; q < 16; q++) m.m[q] = P.mat[q];
+        xf_point(m, x, y, z, x, y, z);
+    }
+    for (uint32_t s = 0; s < FH_MAX_INPUTS; s++) {
+        const uint32_t kd = P.in_kind[s];
+        if (kd < 3) vars[(size_t)s * n + i] = kd == 0 ? x : (kd == 1 ? y : z);
+    }
+}
+__global__ void __launch_bounds__(256) k_mesh_fill(float* p, float v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) k_mesh_edge_narrow(fhmesh::EdgeBracket* br, const float* values, uint32_t n_edges) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_edges) return;
+    uint32_t m16 = 0;
+    for (uint32_t j = 0; j < 16; j++) m16 |= (values[(size_t)k * 16 + j] >= 0.0f ? 1u : 0u) << j;
+    br[k] = fhmesh::edge_narrow(br[k], m16);
+}
+__global__ void __launch_bounds__(256) k_mesh_edge_end(FhMeshLeaf* recs, const uint32_t* edge_list, const fhmesh::EdgeBracket* br, uint32_t n_edges) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_edges) return;
+    const uint32_t ent = edge_list[k], e = ent & 15u;
+    FhMeshLeaf* o = &recs[ent >> 4];
+    uint16_t q[3];
+    fhmesh::edge_mid(br[k], q);
+    for (int a = 0; a < 3; a++) o->inter[e][a] = q[a];
+    o->pos[e][0] = lerp_pos(o->b[0], o->b[1], q[0]); o->pos[e][1] = lerp_pos(o->b[2], o->b[3], q[1]); o->pos[e][2] = lerp_pos(o->b[4], o->b[5], q[2]);
 }
 
 // gradients at the intersections (octree.rs:771-803): one lane per edge

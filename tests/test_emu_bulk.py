@@ -11,7 +11,7 @@ from emu_util import E, F32, U32
 OP = {n: i for i, n in enumerate(U.OPS)}
 
 
-def run_bulk(kernel, zb, tape, inputs, n, n_out):
+def run_bulk(kernel, zb, tape, inputs, n, n_out, trans=False):
     mem = E.Memory()
     a_tape = mem.map(np.concatenate([np.asarray(tape, np.uint64), np.zeros(16, np.uint64)]))      # (the scalar fetch runs two batches of 4 ops ahead)
     vars_ = np.zeros((max(inputs) + 1, n), F32)
@@ -21,7 +21,8 @@ def run_bulk(kernel, zb, tape, inputs, n, n_out):
     a_vars, a_out = mem.map(vars_), mem.map(out)
     ka = np.array([a_tape & 0xFFFFFFFF, a_tape >> 32, a_vars & 0xFFFFFFFF, a_vars >> 32, a_out & 0xFFFFFFFF, a_out >> 32, len(tape), n], U32)
     nr = {4: 16, 2: 32}[zb]
-    E.launch(U.program(), mem, kernel, ka.tobytes(), (n + 64 * zb - 1) // (64 * zb), lds_bytes=16, n_vgpr=64 + nr * zb, wg_y_sgpr=None)
+    hooks = U.trans_hooks(U.program(), f"fh_tb{nr}_", 64 + nr * zb) if trans else None      # (the compiled routines: stood in for by the host's libm, as for fh_columns_t)
+    E.launch(U.program(), mem, kernel, ka.tobytes(), (n + 64 * zb - 1) // (64 * zb), lds_bytes=16, n_vgpr=64 + nr * zb + (26 if trans else 0), wg_y_sgpr=None, hooks=hooks)
     return out
 
 
@@ -59,3 +60,28 @@ def test_sqrt_min_max_two_speed_paths(kernel, zb, fill):
     want = U.ref_f32(np.asarray(tape, np.uint64), {0: x, 1: y}, n)
     for slot in range(6):
         assert same(got[slot], want[slot]), f"output {slot}: {np.nonzero(got[slot].view(U32) != want[slot].view(U32))[0][:8]}"
+
+
+@pytest.mark.parametrize("kernel,zb", [("fh_float_eval_16x4_t", 4), ("fh_float_eval_32x2_t", 2)])
+def test_bulk_kernels_with_transcendental_handlers(kernel, zb):
+    """fh_float_eval_*_t: the bulk interpreter with handlers for sin cos tan asin acos atan exp ln, atan2, the modulo and the rng opcodes
+    (they call the compiled routines embedded behind the kernel) next to the plain ones, in place and not; a last, partial wave"""
+    rng = np.random.default_rng(11)
+    n = 64 * zb + 37
+    x = rng.uniform(-3.0, 3.0, n).astype(F32); y = rng.uniform(-0.99, 0.99, n).astype(F32)
+    x[:6] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30]
+    P = U.pack
+    tape = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 1)]
+    outs = 0
+    for name in ("SIN", "COS", "TAN", "ATAN", "EXP"):
+        tape += [P(OP[name], 2, 0, 0), P(OP["OUTPUT"], 0, 2, outs)]; outs += 1
+    for name in ("ASIN", "ACOS"):
+        tape += [P(OP[name], 3, 1, 0), P(OP["OUTPUT"], 0, 3, outs)]; outs += 1
+    tape += [P(OP["ABS"], 4, 0, 0), P(OP["LN"], 4, 4, 0), P(OP["OUTPUT"], 0, 4, outs)]; outs += 1          # ln |x|, in place
+    tape += [P(OP["ATAN2_RR"], 5, 1, 0), P(OP["OUTPUT"], 0, 5, outs)]; outs += 1
+    tape += [P(OP["MOD_RI"], 6, 0, int(U.f2u(0.7))), P(OP["OUTPUT"], 0, 6, outs)]; outs += 1
+    tape += [P(OP["MUL_RR"], 7, 2, 3), P(OP["ADD_RR"], 7, 7, 4), P(OP["SQRT"], 7, 7, 0), P(OP["OUTPUT"], 0, 7, outs)]; outs += 1     # plain handlers among them
+    got = run_bulk(kernel, zb, tape, {0: x, 1: y}, n, outs, trans=True)
+    want = U.ref_f32(np.asarray(tape, np.uint64), {0: x, 1: y}, n)
+    for slot in range(outs):
+        assert same(got[slot], want[slot]), (slot, got[slot][:8], np.asarray(want[slot])[:8])

@@ -419,6 +419,29 @@ def test_leaf_passes_equal_the_per_cell_kernel(model, depth, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 7), ("colonnade.vm", 6), ("bear.vm", 5), ("prospero.vm", 5)])
+def test_bulk_edge_passes_equal_the_hip_edge_search(model, depth, monkeypatch):
+    """The four rounds of the edge search as passes around the assembly bulk interpreter (k_mesh_edge_* + fh_float_eval_*[_t]) against
+    k_mesh_edges (the generic interpreter, FHIP_MESH_BULK_EDGES=0): the same records, bit for bit - the values are the same f32 values."""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(model_path(model))
+    monkeypatch.delenv("FHIP_MESH_BULK_EDGES", raising=False)
+    a, ca = F.mesh_sample(shape, depth)
+    monkeypatch.setenv("FHIP_MESH_BULK_EDGES", "0")
+    b, cb = F.mesh_sample(shape, depth)
+    monkeypatch.delenv("FHIP_MESH_BULK_EDGES")
+    assert ca == cb and len(a) == len(b) > 500
+    a, b = a[np.argsort(a["path"], kind="stable")], b[np.argsort(b["path"], kind="stable")]
+    ne, nv = a["n_edges"], a["n_verts"]
+    assert (ne == b["n_edges"]).all() and (a["mask"] == b["mask"]).all()
+    e_ok = np.arange(12)[None, :] < ne[:, None]
+    v_ok = np.arange(4)[None, :] < nv[:, None]
+    assert (a["inter"][e_ok] == b["inter"][e_ok]).all()
+    for f, ok in (("pos", e_ok), ("grad", e_ok), ("vert", v_ok)):
+        assert (a[f][ok].view(np.uint32) == b[f][ok].view(np.uint32)).all(), f
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 8), ("colonnade.vm", 7), ("bear.vm", 6), ("prospero.vm", 7)])
 def test_device_assembly_equals_the_host_assembly(model, depth):
     """fhip_mesh_build assembles the octree in HBM (k_oct_*: check_done / collapse / places, mesh_collapse.hpp) and hands the host the
