@@ -478,8 +478,8 @@ def main():
                 ulp = np.abs(an - bn) / (scale * 2.0 ** -23)
             result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
-                                 "note": "transcendental opcodes: the north star grants 1 ulp per f32 value; per opcode the device is within 1 ulp of glibc over all "
-                                         "2^32 inputs (profiles/r02/math_sweep.json), a gradient chains several of them"}
+                                 "note": "transcendental opcodes: the device runs the host libm's f32 routines restated operation by operation "
+                                         "(fidget_amd/csrc/trans_libm.hpp; 0 of 2^32 arguments differ per routine, profiles/r04a/math_sweep.json)"}
         # BASELINE configuration 5 (Manifold Dual Contouring of gyroid-sphere at octree depth 10 = 1024^3: fhip_mesh_build, the octree
         # assembled on the device, the dual walk on the host's threads): seconds per build, in a process of its own (tools/mesh_times.py,
         # the script profiles/r03z/mesh_times.log comes from) so that nothing it does can cost this line

@@ -16,6 +16,7 @@ checks run anywhere), but creating a context without a HIP device raises.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 import sys
 
@@ -25,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
 _SOURCES = ["capi.hip", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "mesh_collapse.hpp", "mesh_edges.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "host_regtape.hpp", "render_state.h", "tape_format.h",
-            "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_normals.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "offsets.cpp", "../../include/fidget_hip.h",
+            "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_normals.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "trans_libm.hpp", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
@@ -86,9 +87,20 @@ def build(force=False, verbose=False):
     run(["g++", "-std=c++17", "-I", _CSRC, os.path.join(_CSRC, "offsets.cpp"), "-o", os.path.join(gen, "offsets")])
     with open(os.path.join(gen, "offsets.json"), "w") as f:
         subprocess.check_call([os.path.join(gen, "offsets")], stdout=f)
-    # the transcendental routines the assembly interpreters call: compiler output of trans_funcs.hip, embedded by gen_trans.py
-    run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", _CSRC,
-         "-o", os.path.join(gen, "trans_funcs.s"), os.path.join(_CSRC, "trans_funcs.hip")])
+    # the transcendental routines the assembly interpreters call: trans_funcs.hip through LLVM IR, where the functions are limited to
+    # 8 scalar registers + vcc / the return address ("amdgpu-num-sgpr": clang takes that attribute on kernels only; the handlers
+    # that call them have ten free) -> llc -> assembly, embedded by gen_trans.py
+    ll = os.path.join(gen, "trans_funcs.ll")
+    run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "-emit-llvm", "--cuda-device-only", "-I", _CSRC,
+         "-o", ll, os.path.join(_CSRC, "trans_funcs.hip")])
+    ir = open(ll).read()
+    m = re.search(r"^define [^\n]*@fh_t_sin\([^\n]*\) (#\d+)", ir, re.M)
+    assert m, "trans_funcs.ll: fh_t_sin not found"
+    ir, n = re.subn(rf"^attributes {m.group(1)} = {{ ", f'attributes {m.group(1)} = {{ "amdgpu-num-sgpr"="18" ', ir, flags=re.M)
+    assert n == 1
+    with open(ll, "w") as f:
+        f.write(ir)
+    run([os.path.join(llvm, "llc"), "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O3", "-o", os.path.join(gen, "trans_funcs.s"), ll])
     run([sys.executable, os.path.join(_CSRC, "gen_interp.py"), os.path.join(gen, "offsets.json"),
          os.path.join(gen, "interp_gfx950.s"), os.path.join(gen, "trans_funcs.s")])
     run([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",

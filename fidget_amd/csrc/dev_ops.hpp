@@ -7,14 +7,16 @@
 // round-to-nearest op by op.  `/` and sqrtf are the correctly rounded forms
 // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); denormals are kept.
 //
-// Transcendentals: the reference calls the platform libm through Rust's std;
-// here they are evaluated in f64 (ocml) and rounded once to f32, which is
-// within 1 ulp of glibc's f32 routines (measured in tests/test_gpu_math.py).
+// Transcendentals: the reference calls the platform libm through Rust's std and
+// its tests compare with those calls exactly; trans_libm.hpp restates that libm's
+// (glibc 2.35, x86-64 FMA variants) f32 routines operation by operation, so the
+// device returns the host's bits (tools/libm_sweep.cpp, tests/test_gpu_math.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "tape_format.h"
+#include "trans_libm.hpp"
 
 #define FH_DEV __device__ __forceinline__
 
@@ -29,16 +31,16 @@ FH_DEV bool isnan_(float f) { return f != f; }
 FH_DEV float rmin(float a, float b) { return fminf(a, b); }
 FH_DEV float rmax(float a, float b) { return fmaxf(a, b); }
 
-// ---- transcendental f32 via f64 -------------------------------------------------
-FH_DEV float t_sin(float a) { return (float)sin((double)a); }
-FH_DEV float t_cos(float a) { return (float)cos((double)a); }
-FH_DEV float t_tan(float a) { return (float)tan((double)a); }
-FH_DEV float t_asin(float a) { return (float)asin((double)a); }
-FH_DEV float t_acos(float a) { return (float)acos((double)a); }
-FH_DEV float t_atan(float a) { return (float)atan((double)a); }
-FH_DEV float t_exp(float a) { return (float)exp((double)a); }
-FH_DEV float t_ln(float a) { return (float)log((double)a); }
-FH_DEV float t_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+// ---- transcendental f32: the host libm's routines (trans_libm.hpp) ---------------
+FH_DEV float t_sin(float a) { return fhlm::sincosf_<fhlm::MemTables, false>(a); }
+FH_DEV float t_cos(float a) { return fhlm::sincosf_<fhlm::MemTables, true>(a); }
+FH_DEV float t_tan(float a) { return fhlm::tanf_<fhlm::MemTables>(a); }
+FH_DEV float t_asin(float a) { return fhlm::asinf_(a); }
+FH_DEV float t_acos(float a) { return fhlm::acosf_(a); }
+FH_DEV float t_atan(float a) { return fhlm::atanf_(a); }
+FH_DEV float t_exp(float a) { return fhlm::expf_<fhlm::MemTables>(a); }
+FH_DEV float t_ln(float a) { return fhlm::logf_<fhlm::MemTables>(a); }
+FH_DEV float t_atan2(float y, float x) { return fhlm::atan2f_(y, x); }
 
 // ---- rng (rng/mod.rs:8-33) ---------------------------------------------------------
 FH_DEV uint32_t pcg(uint32_t v) {

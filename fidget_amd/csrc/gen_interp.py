@@ -1393,6 +1393,9 @@ def main():
     a = Asm()
     a('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6')
     ks = []
+    if len(sys.argv) > 3:
+        import gen_trans
+        gen_trans.tables(a, sys.argv[3])   # the compiled routines' constant tables, once for all the kernels that embed them
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
     ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)

@@ -1,14 +1,32 @@
-"""Embeds the compiled transcendental routines (trans_funcs.hip -> hipcc -S) in the interpreters' code object.
+"""Embeds the compiled transcendental routines (trans_funcs.hip -> LLVM IR -> llc, fidget_amd.build) in the interpreters' code object.
 
 Each function body is taken from the compiler's assembly, its registers moved into the window the interpreters keep free
 while a handler runs (v0..v25 -> v128..v153, s0..s9 -> s86..s95, return address s[30:31] -> s[96:97]; vcc and exec are used
 as they are: exec is restored by the functions themselves), its local labels made unique.  Calling convention for the
-handlers: argument(s) in v128 (, v129), result in v128, `s_getpc / s_add / s_branch` with the return address in s[96:97]."""
+handlers: argument(s) in v128 (, v129), result in v128, `s_getpc / s_add / s_branch` with the return address in s[96:97].
+The routines' tables (trans_libm.hpp MemTables: 2^(i/32), logf's 1/c and log c, the bits of 4/pi) are loaded pc-relative from
+.rodata: `tables()` emits them once per code object under the names the renamed code refers to."""
 import re
 
 V_BASE, S_BASE, S_RET = 128, 86, 96
 FUNCS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod"]
 MAX_V, MAX_S = 26, 10
+
+
+_TAB_SYM = re.compile(r"_ZZN4fhlm9MemTables\d+(\w+?)EjE1T")   # function-local `static const T[]` of fhlm::MemTables::<name>
+
+
+def tables(a, path):
+    """the routines' constant tables as `fh_tab_<name>` in .rodata (once per code object, before any embed())"""
+    txt = open(path).read()
+    a("\t.section\t.rodata,\"a\",@progbits")
+    found = 0
+    for m in re.finditer(r"^(_ZZN4fhlm9MemTables\d+\w+?EjE1T):\n((?:\t\.(?:quad|long)\t[^\n]*\n)+)", txt, re.M):
+        a(f"\t.p2align 4\n{_TAB_SYM.sub(lambda t: 'fh_tab_' + t.group(1), m.group(1))}:")
+        a("\n".join(l.split(";")[0].rstrip() for l in m.group(2).rstrip("\n").split("\n")))
+        found += 1
+    assert found == 4, found
+    a("\t.text")
 
 
 def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None):
@@ -44,12 +62,17 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None):
                 out.append(re.sub(r"\.LBB(\d+)_(\d+)", rf".L{prefix}{name}_bb\2", code.strip()))
             continue
         code = re.sub(r"\.LBB(\d+)_(\d+)", rf".L{prefix}{name}_bb\2", code)
+        sym = _TAB_SYM.search(code)
+        if sym:   # `s_add_u32 s4, s4, <table>@rel32@lo+4`: keep the symbol out of the register renaming
+            code = code.replace(sym.group(0), "@TAB@")
         code = re.sub(r"\bv\[(\d+):(\d+)\]", v2, code)
         code = re.sub(r"\bv(\d+)\b", v1, code)
         code = re.sub(r"\bs\[(\d+):(\d+)\]", s2, code)
         code = re.sub(r"\bs(\d+)\b", s1, code)
-        for bad in ("scratch", "buffer_", "s_swappc", "s_getpc", "ds_", "global_", "flat_", "m0"):
+        for bad in ("scratch", "buffer_", "s_swappc", "ds_", "global_store", "global_atomic", "flat_", "m0", "v_writelane", "v_readlane"):
             assert bad not in code, (name, code)
+        if sym:
+            code = code.replace("@TAB@", "fh_tab_" + sym.group(1))
         out.append(code)
     return "\n".join(out)
 

@@ -1487,9 +1487,10 @@ __global__ void k_merge_depth(FhGeometryPixel* front, const FhGeometryPixel* bac
     }
 }
 
-// Accuracy sweep of the transcendental opcodes (diagnostics; tests/test_gpu_math.py): x_i = bits(first + i * stride),
-// y = the device's f32 result (f64 evaluation rounded once, dev_ops.hpp t_*), compared with ref[i] (the host libm's):
-// out[0] = max ulp distance, out[1] = results that differ, out[2] = results more than 1 ulp apart, out[3] = an input of the worst case
+// Sweep of the transcendental opcodes (diagnostics; tests/test_gpu_math.py): x_i = bits(first + i * stride), y = the device's f32
+// result (dev_ops.hpp t_* = trans_libm.hpp), compared with ref[i] (the host libm's; op 8 = atan2 with the second argument the oracle's
+// sweep uses): out[0] = max ulp distance, out[1] = results whose BITS differ (a NaN equals any NaN; +0 and -0 differ), out[2] = results
+// more than 1 ulp apart, out[3] = an input of the worst case
 __global__ void k_math_sweep(int op, uint32_t first, uint32_t stride, size_t n, const float* __restrict__ ref, unsigned long long* out) {
     unsigned long long worst = 0, ndiff = 0, nbad = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1504,6 +1505,7 @@ __global__ void k_math_sweep(int op, uint32_t first, uint32_t stride, size_t n, 
             case 4: y = t_acos(x); break;
             case 5: y = t_atan(x); break;
             case 6: y = t_exp(x); break;
+            case 8: y = t_atan2(x, u2f(xb * 2654435761u + 0x9E3779B9u)); break;
             default: y = t_ln(x); break;
         }
         const float r = ref[i];
@@ -1514,7 +1516,8 @@ __global__ void k_math_sweep(int op, uint32_t first, uint32_t stride, size_t n, 
         const long long kb = b < 0 ? -(long long)(f2u(r) & 0x7fffffffu) : (long long)b;
         unsigned long long d = (unsigned long long)(ka > kb ? ka - kb : kb - ka);
         if (isnan_(y) != isnan_(r)) d = 0xFFFFFFFFull;
-        if (d) ndiff++;
+        if (f2u(y) != f2u(r)) ndiff++;
+        if (!d && f2u(y) != f2u(r)) d = 1;   // +0 against -0
         if (d > 1) nbad++;
         if (d > (worst >> 32)) worst = (d << 32) | xb;
     }

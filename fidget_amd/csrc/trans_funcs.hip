@@ -1,11 +1,12 @@
 // Transcendental / modulo routines for the assembly interpreters, as out-of-line device functions.
 //
 // The reference evaluates sin, cos, ... with the platform libm; the device's definition of those opcodes is dev_ops.hpp
-// t_* (f64 evaluation, one rounding to f32) and the HIP kernels inline exactly these expressions.  The assembly
-// interpreters must return the same bits, so they CALL the same code: this file is compiled to gfx950 assembly
-// (hipcc -S; no scratch, no tables: ocml's argument reduction uses v_trig_preop_f64), gen_interp.py renames the registers
-// of each function into a window the interpreters keep free (v0.. -> v128.., s0.. -> s86.., return address
-// s[30:31] -> s[96:97]) and embeds the bodies in the interpreters' code object.
+// t_* (trans_libm.hpp: the host libm's routines restated) and the HIP kernels inline exactly these functions.  The assembly
+// interpreters must return the same bits, so they CALL the same code: this file is compiled to gfx950 assembly (hipcc to LLVM IR,
+// llc with the functions limited to eight scalar registers: fidget_amd.build; no scratch; the tables of expf / logf / the large
+// argument reduction are loaded from .rodata), gen_trans.py renames the registers of each function into a window the interpreters
+// keep free (v0.. -> v128.., s0.. -> s86.., return address s[30:31] -> s[96:97]) and embeds the bodies and the tables in the
+// interpreters' code object.
 #include <hip/hip_runtime.h>
 
 #include "dev_ops.hpp"

@@ -20,6 +20,13 @@
 // square root) returns the host's bits; both sides must be compiled with floating-point contraction OFF.  `tools/libm_sweep.cpp`
 // compares every routine with the running libm over all 2^32 arguments on the CPU, `tools/math_sweep.py` on the device.
 //
+// Shape of the code: the routines are also compiled into the assembly interpreters (trans_funcs.hip, gen_trans.py), where a routine
+// has ten scalar registers; a saved execution mask per nested branch would not fit.  So every routine is ONE straight path that all
+// lanes run, at most one wave-uniform skip around a rare case, and selects: the library's branches are the same arithmetic on the
+// branch's lanes only - evaluating a branch for lanes that do not take it changes nothing a select does not discard (no traps, no
+// flags are observed).  Where a small-argument branch of the library is the general path with n = 0 (sinf, cosf, tanf below pi / 4)
+// the general path is used: identical operations with exact identities (x - 0 * c, x * 1).
+//
 // NaN results: the value class is the host's; the payload / sign of a NaN is not modelled (x86 produces the negative default NaN for
 // an invalid operation, the GPU the positive one - as for every other opcode).
 #pragma once
@@ -76,34 +83,6 @@ struct MemTables {
 };
 
 // ---- sinf / cosf (s_sincosf.h) ----
-// sinf_poly with the coefficients of __sincosf_table[0] {c0 c1 s1 c2 s2 c3 s3 c4}.  Table 1 (chosen when n & 2) holds the same sine
-// and the NEGATED cosine coefficients; a chain of fused multiply-adds over negated constants returns exactly the negated value,
-// so `neg_cos` flips the cosine branch's sign instead of switching tables.
-FHLM float sincosf_poly(double x, double x2, int n, bool neg_cos) {
-    if ((n & 1) == 0) {
-        const double x3 = x * x2;
-        const double s1 = fma_(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);  // s2 + x2 * s3
-        const double x7 = x3 * x2;
-        const double s = fma_(x3, -0x1.555545995a603p-3, x);  // x + x3 * s1
-        return (float)fma_(x7, s1, s);                        // s + x7 * s1
-    }
-    const double x4 = x2 * x2;
-    const double c2 = fma_(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);  // c3 + x2 * c4
-    const double c1 = fma_(x2, -0x1.ffffffd0c621cp-2, 0x1p0);                   // c0 + x2 * c1
-    const double x6 = x4 * x2;
-    const double c = fma_(x4, 0x1.55553e1068f19p-5, c1);  // c1 + x4 * c2
-    const float r = (float)fma_(x6, c2, c);               // c + x6 * c2
-    return neg_cos ? -r : r;
-}
-
-// reduce_fast: |x| < 120; x * (2^24 * 2 / pi), rounded to the nearest multiple of 2^24 by an integer add and shift
-FHLM double sincosf_reduce_fast(double x, int* np) {
-    const double r = x * 0x1.45F306DC9C883p+23;
-    const int n = ((int32_t)r + 0x800000) >> 24;
-    *np = n;
-    return fma_(-(double)n, 0x1.921FB54442D18p0, x);  // x - n * hpi, fused
-}
-
 // reduce_large: 120 <= |x| < inf; xi = the bits of x.  192 bits of 4 / pi against the 24-bit mantissa, in integers.
 template <class Tab>
 FHLM double sincosf_reduce_large(uint32_t xi, int* np) {
@@ -123,42 +102,52 @@ FHLM double sincosf_reduce_large(uint32_t xi, int* np) {
     return x * 0x1.921FB54442D18p-62;
 }
 
+// sinf_poly with the coefficients of __sincosf_table[0] {c0 c1 s1 c2 s2 c3 s3 c4}.  Table 1 (chosen when the quadrant has bit 1 set)
+// holds the same sine and the NEGATED cosine coefficients; a chain of fused multiply-adds over negated constants returns exactly
+// the negated value, so the cosine branch's sign is flipped instead of switching tables.
 template <class Tab, bool IS_COS>
 FHLM float sincosf_(float y) {
-    double x = (double)y;
-    const uint32_t top = (f2u(y) >> 20) & 0x7ff;  // abstop12
-    int n, ns;  // quadrant; quadrant + sign bit (large arguments are reduced from |y|): the latter picks sign and table, the former the polynomial
-    if (top < 0x3f4) {  // |y| < pi / 4  (abstop12(pio4) = 0x3f4)
-        const double x2 = x * x;
-        if (top < 0x398) return IS_COS ? 1.0f : y;  // |y| < 2^-12
-        return sincosf_poly(x, x2, IS_COS ? 1 : 0, false);
+    const uint32_t yi = f2u(y);
+    const uint32_t top = (yi >> 20) & 0x7ff;  // abstop12
+    const double xd = (double)y;
+    // reduce_fast (|y| < 120): x * (2^24 * 2 / pi), rounded to the nearest multiple of 2^24 by an integer add and shift; x - n * hpi is
+    // one fused operation.  For |y| < pi / 4 it gives n = 0 and x unchanged, and the library's small-argument branch is the n = 0 path.
+    const double r = xd * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;  // quadrant: picks the polynomial
+    double x = fma_(-(double)n, 0x1.921FB54442D18p0, xd);
+    int ns = n;                             // quadrant + sign bit (large arguments are reduced from |y|): picks sign and table
+    if (top >= 0x42f) {                     // |y| >= 120 (inf / NaN: overridden below)
+        x = sincosf_reduce_large<Tab>(yi, &n);
+        ns = n + (int)(yi >> 31);
     }
-    if (top < 0x42f) {  // |y| < 120
-        x = sincosf_reduce_fast(x, &n);
-        ns = n;
-    } else if (top < 0x7f8) {
-        const uint32_t xi = f2u(y);
-        x = sincosf_reduce_large<Tab>(xi, &n);
-        ns = n + (int)(xi >> 31);
+    const double x2 = x * x;
+    x = u2d(d2u(x) ^ ((uint64_t)((ns ^ (ns >> 1)) & 1) << 63));  // x * sign[ns & 3], sign = {1, -1, -1, 1}
+    const int np = IS_COS ? n ^ 1 : n;
+    float res;
+    if ((np & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = fma_(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);  // s2 + x2 * s3
+        const double x7 = x3 * x2;
+        const double s = fma_(x3, -0x1.555545995a603p-3, x);  // x + x3 * s1
+        res = (float)fma_(x7, s1, s);                         // s + x7 * s1
     } else {
-        return nan_();  // inf, NaN: __math_invalidf
+        const double x4 = x2 * x2;
+        const double c2 = fma_(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);  // c3 + x2 * c4
+        const double c1 = fma_(x2, -0x1.ffffffd0c621cp-2, 0x1p0);                   // c0 + x2 * c1
+        const double x6 = x4 * x2;
+        const double c = fma_(x4, 0x1.55553e1068f19p-5, c1);  // c1 + x4 * c2
+        res = (float)fma_(x6, c2, c);                         // c + x6 * c2
+        res = u2f(f2u(res) ^ ((uint32_t)(ns & 2) << 30));     // table 1
     }
-    const double s = ((ns & 3) == 1 || (ns & 3) == 2) ? -1.0 : 1.0;  // sign[ns & 3] = {1, -1, -1, 1}
-    return sincosf_poly(x * s, x * x, IS_COS ? n ^ 1 : n, (ns & 2) != 0);
+    res = top < 0x398 ? (IS_COS ? 1.0f : y) : res;  // |y| < 2^-12
+    return top >= 0x7f8 ? nan_() : res;             // inf, NaN: __math_invalidf
 }
 
 // ---- expf (e_expf.c) ----
 template <class Tab>
 FHLM float expf_(float x) {
     const double xd = (double)x;
-    const uint32_t abstop = (f2u(x) >> 20) & 0x7ff;
-    if (abstop >= 0x42b) {  // |x| >= 88 or NaN
-        if (f2u(x) == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8) return x + x;
-        if (x > 0x1.62e42ep6f) return u2f(0x7f800000u);  // overflow
-        if (x < -0x1.9fe368p6f) return 0.0f;             // underflow
-        if (x < -0x1.9d1d9ep6f) return u2f(1u);          // __math_may_uflowf: 0x1.4p-75f squared = the smallest subnormal
-    }
+    const uint32_t xi = f2u(x), abstop = (xi >> 20) & 0x7ff;
     // x * N / ln2 = k + r; the source's `z = InvLn2N * xd; kd = z + SHIFT; ...; r = z - kd` compiles to two fused operations
     const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+5;
     double kd = fma_(InvLn2N, xd, SHIFT);
@@ -172,21 +161,23 @@ FHLM float expf_(float x) {
     double y = fma_(0x1.62e42ff0c52d6p-6, r, 1.0);
     y = fma_(z, r2, y);
     y = y * s;
-    return (float)y;
+    float res = (float)y;
+    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
+        res = x < -0x1.9d1d9ep6f ? u2f(1u) : res;            // __math_may_uflowf: 0x1.4p-75f squared = the smallest subnormal
+        res = x < -0x1.9fe368p6f ? 0.0f : res;               // underflow
+        res = x > 0x1.62e42ep6f ? u2f(0x7f800000u) : res;    // overflow
+        res = abstop >= 0x7f8 ? x + x : res;                 // inf, NaN
+        res = xi == 0xff800000u ? 0.0f : res;
+    }
+    return res;
 }
 
 // ---- logf (e_logf.c) ----
 template <class Tab>
 FHLM float logf_(float x) {
-    uint32_t ix = f2u(x);
-    if (ix == 0x3f800000u) return 0.0f;
-    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {  // x < 2^-126, inf or NaN
-        if (ix * 2 == 0) return u2f(0xff800000u);         // log(+-0) = -inf
-        if (ix == 0x7f800000u) return x;
-        if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return nan_();
-        ix = f2u(x * 0x1p23f);  // subnormal: normalise
-        ix -= 23u << 23;
-    }
+    const uint32_t ix0 = f2u(x);
+    const bool special = ix0 - 0x00800000u >= 0x7f800000u - 0x00800000u;  // x < 2^-126, inf or NaN
+    const uint32_t ix = special ? f2u(x * 0x1p23f) - (23u << 23) : ix0;  // subnormal: normalise
     const uint32_t tmp = ix - 0x3f330000u;
     const uint32_t i = (tmp >> 19) & 15;
     const int k = (int32_t)tmp >> 23;
@@ -199,7 +190,13 @@ FHLM float logf_(float x) {
     double y = fma_(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);  // A[1] * r + A[2]
     y = fma_(-0x1.00ea348b88334p-2, r2, y);                            // A[0] * r2 + y
     y = fma_(y, r2, y0 + r);
-    return (float)y;
+    float res = (float)y;
+    if (special) {
+        res = ((ix0 & 0x80000000u) || ix0 * 2 >= 0xff000000u) ? nan_() : res;
+        res = ix0 == 0x7f800000u ? x : res;
+        res = ix0 * 2 == 0 ? u2f(0xff800000u) : res;  // log(+-0) = -inf
+    }
+    return ix0 == 0x3f800000u ? 0.0f : res;
 }
 
 // ---- fdlibm routines: binary32 arithmetic, one rounding per operation (no fused multiply-add anywhere) ----
@@ -207,26 +204,22 @@ FHLM float fabsf_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 FHLM float sqrtf_(float x) { return __builtin_sqrtf(x); }           // correctly rounded on both sides
 FHLM float trunc12(float x) { return u2f(f2u(x) & 0xfffff000u); }  // SET_FLOAT_WORD(w, i & 0xfffff000)
 
-// __kernel_tanf (k_tanf.c): tan(x + y) for |x + y| <= pi / 4 when iy = 1, -1 / tan when iy = -1
-FHLM float kernel_tanf(float x, float y, int iy) {
+// __kernel_tanf (k_tanf.c): tan(x + y) for |x + y| <= pi / 4 when iy = 1, -1 / tan when iy = -1.  The library's three divisions
+// (|x| >= 0.6744; the accurate -1 / (x + r); |x| < 2^-13) are one division with selected operands.
+FHLM float kernel_tanf(float x0, float y0, int iy) {
     const float T0 = 0x1.555556p-2f, T1 = 0x1.111112p-3f, T2 = 0x1.ba1ba2p-5f, T3 = 0x1.664f48p-6f, T4 = 0x1.226e3ep-7f,
                 T5 = 0x1.d6d22cp-9f, T6 = 0x1.7dbc9p-10f, T7 = 0x1.344d9p-11f, T8 = 0x1.026f72p-12f, T9 = 0x1.47e88ap-14f,
                 T10 = 0x1.2b80f4p-14f, T11 = -0x1.375cbep-16f, T12 = 0x1.b2a708p-16f;
     const float pio4 = 0x1.921fb4p-1f, pio4lo = 0x1.4442dp-25f;
-    const int32_t hx = (int32_t)f2u(x);
+    const int32_t hx = (int32_t)f2u(x0);
     const int32_t ix = hx & 0x7fffffff;
-    if (ix < 0x39000000) {  // |x| < 2^-13: (int)x == 0
-        if ((ix | (iy + 1)) == 0) return 1.0f / fabsf_(x);
-        if (iy == 1) return x;
-        return -1.0f / x;
-    }
-    if (ix >= 0x3f2ca140) {  // |x| >= 0.6744
-        if (hx < 0) { x = -x; y = -y; }
-        const float z = pio4 - x, w = pio4lo - y;
-        x = z + w;
-        y = 0.0f;
-        if (fabsf_(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
-    }
+    const bool tiny = ix < 0x39000000;  // |x| < 2^-13: (int)x == 0
+    const bool big = ix >= 0x3f2ca140;  // |x| >= 0.6744
+    const float sgn = (float)(1 - ((hx >> 30) & 2)), fiy = (float)iy;
+    // big: x, y = |x|, y * sign; z = pio4 - x; w = pio4lo - y; x = z + w; y = 0
+    const float ax = u2f(f2u(x0) & 0x7fffffffu), ay = u2f(f2u(y0) ^ (f2u(x0) & 0x80000000u));
+    const float x = big ? (pio4 - ax) + (pio4lo - ay) : x0;
+    const float y = big ? 0.0f : y0;
     const float z = x * x;
     float w = z * z;
     float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
@@ -235,39 +228,41 @@ FHLM float kernel_tanf(float x, float y, int iy) {
     r = y + z * (s * (r + v) + y);
     r += T0 * s;
     w = x + r;
-    if (ix >= 0x3f2ca140) {
-        v = (float)iy;
-        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
-    }
-    if (iy == 1) return w;
+    // big: w * w / (w + v) with v = iy;  otherwise -1 / w;  tiny: -1 / x (1 / |x| when x = 0 and iy = -1: -1 / -0)
+    const float num = big ? w * w : -1.0f;
+    const float den = tiny ? (ix == 0 ? -0.0f : x0) : big ? w + fiy : w;
+    const float a = num / den;
+    const float res_big = fabsf_(x) < 0x1p-13f ? (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x)
+                                                : sgn * (fiy - 2.0f * (x - (a - r)));
     // -1 / (x + r), accurately
     const float zz = trunc12(w);
     v = r - (zz - x);
-    const float a = -1.0f / w;
     const float t = trunc12(a);
     s = 1.0f + t * zz;
-    return t + a * (s + t * v);
+    const float res_inv = t + a * (s + t * v);
+    float res = iy == 1 ? w : res_inv;
+    res = big ? res_big : res;
+    return tiny ? (iy == 1 ? x0 : a) : res;
 }
 
-// tanf (s_tanf.c; since glibc 2.33 the reduction is sincosf's, in binary64 WITHOUT fused operations - this file has no _fma variant)
+// tanf (s_tanf.c; since glibc 2.33 the reduction is sincosf's, in binary64 WITHOUT fused operations - this file has no _fma variant).
+// Below pi / 4 the reduction gives n = 0, y[0] = x and y[1] = 0: the library's first branch.
 template <class Tab>
 FHLM float tanf_(float x) {
-    const uint32_t ix = f2u(x) & 0x7fffffffu;
-    if (ix <= 0x3f490fdau) return kernel_tanf(x, 0.0f, 1);
-    if (ix >= 0x7f800000u) return nan_();
+    const uint32_t xi = f2u(x);
+    const uint32_t top = (xi >> 20) & 0x7ff;
     double dx = (double)x;
-    int n;
-    if (((f2u(x) >> 20) & 0x7ff) < 0x42f) {  // |x| < 120: reduce_fast with a separate multiply and subtract
-        const double r = dx * 0x1.45F306DC9C883p+23;
-        n = ((int32_t)r + 0x800000) >> 24;
-        dx = dx - (double)n * 0x1.921FB54442D18p0;
-    } else {
-        dx = sincosf_reduce_large<Tab>(f2u(x), &n);
-        if (f2u(x) >> 31) dx = -dx;
+    const double r = dx * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    dx = dx - (double)n * 0x1.921FB54442D18p0;
+    if (top >= 0x42f) {  // |x| >= 120
+        dx = sincosf_reduce_large<Tab>(xi, &n);
+        dx = u2d(d2u(dx) ^ ((uint64_t)(xi >> 31) << 63));
     }
     const float y0 = (float)dx;
     const float y1 = (float)(dx - (double)y0);
-    return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+    const float res = kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+    return top >= 0x7f8 ? nan_() : res;
 }
 
 // asinf (e_asinf.c, glibc's polynomial)
@@ -276,29 +271,22 @@ FHLM float asinf_(float x) {
     const float p0 = 0x1.5555c8p-3f, p1 = 0x1.3301e4p-4f, p2 = 0x1.747e4ap-5f, p3 = 0x1.8c283cp-6f, p4 = 0x1.596d28p-5f;
     const int32_t hx = (int32_t)f2u(x);
     const int32_t ix = hx & 0x7fffffff;
-    if (ix == 0x3f800000) return x * pio2_hi + x * pio2_lo;
-    if (ix > 0x3f800000) return nan_();
-    if (ix < 0x3f000000) {
-        if (ix < 0x32000000) return x;  // |x| < 2^-27
-        const float t = x * x;
-        const float w = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
-        return x + x * w;
-    }
-    float w = 1.0f - fabsf_(x);
-    float t = w * 0.5f;
-    float p = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+    const bool small = ix < 0x3f000000;  // |x| < 0.5
+    const float t = small ? x * x : (1.0f - fabsf_(x)) * 0.5f;
+    const float p = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+    const float res_small = x + x * p;
     const float s = sqrtf_(t);
-    if (ix >= 0x3F79999A) {  // |x| > 0.975
-        t = pio2_hi - (2.0f * (s + s * p) - pio2_lo);
-    } else {
-        w = trunc12(s);
-        const float c = (t - w * w) / (s + w);
-        const float r = p;
-        p = 2.0f * s * r - (pio2_lo - 2.0f * c);
-        const float q = pio4_hi - 2.0f * w;
-        t = pio4_hi - (p - q);
-    }
-    return hx > 0 ? t : -t;
+    const float res_hi = pio2_hi - (2.0f * (s + s * p) - pio2_lo);  // |x| > 0.975
+    const float w = trunc12(s);
+    const float c = (t - w * w) / (s + w);
+    const float pp = 2.0f * s * p - (pio2_lo - 2.0f * c);
+    const float q = pio4_hi - 2.0f * w;
+    const float res_mid = pio4_hi - (pp - q);
+    float res = ix >= 0x3F79999A ? res_hi : res_mid;
+    res = hx > 0 ? res : -res;
+    res = small ? (ix < 0x32000000 ? x : res_small) : res;  // |x| < 2^-27: x
+    res = ix == 0x3f800000 ? x * pio2_hi + x * pio2_lo : res;
+    return ix > 0x3f800000 ? nan_() : res;
 }
 
 // acosf (e_acosf.c)
@@ -308,71 +296,55 @@ FHLM float acosf_(float x) {
                 pS5 = 0x1.23de1p-15f, qS1 = -0x1.33a272p+1f, qS2 = 0x1.02ae5ap+1f, qS3 = -0x1.6066c2p-1f, qS4 = 0x1.3b8c5cp-4f;
     const int32_t hx = (int32_t)f2u(x);
     const int32_t ix = hx & 0x7fffffff;
-    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
-    if (ix > 0x3f800000) return nan_();
-    if (ix < 0x3f000000) {
-        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
-        const float z = x * x;
-        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const float r = p / q;
-        return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    if (hx < 0) {
-        const float z = (1.0f + x) * 0.5f;
-        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const float s = sqrtf_(z);
-        const float r = p / q;
-        const float w = r * s - pio2_lo;
-        return pi - 2.0f * (s + w);
-    }
-    const float z = (1.0f - x) * 0.5f;
-    const float s = sqrtf_(z);
-    const float df = trunc12(s);
-    const float c = (z - df * df) / (s + df);
+    const bool small = ix < 0x3f000000;  // |x| < 0.5
+    // z = x^2, (1 + x) / 2 or (1 - x) / 2: 1 - |x| is 1 + x for negative x
+    const float z = small ? x * x : (1.0f - fabsf_(x)) * 0.5f;
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
     const float r = p / q;
-    const float w = r * s + c;
-    return 2.0f * (df + w);
+    const float res_small = pio2_hi - (x - (pio2_lo - x * r));
+    const float s = sqrtf_(z);
+    const float res_neg = pi - 2.0f * (s + (r * s - pio2_lo));  // x < -0.5
+    const float df = trunc12(s);
+    const float c = (z - df * df) / (s + df);
+    const float res_pos = 2.0f * (df + (r * s + c));  // x > 0.5
+    float res = hx < 0 ? res_neg : res_pos;
+    res = small ? (ix <= 0x32800000 ? pio2_hi + pio2_lo : res_small) : res;
+    res = ix == 0x3f800000 ? (hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;
+    return ix > 0x3f800000 ? nan_() : res;
 }
 
-// atanf (s_atanf.c)
-FHLM float atanf_(float x) {
+// atanf (s_atanf.c): the four reductions' divisions are one division with selected operands
+FHLM float atanf_(float x0) {
     const float hi0 = 0x1.dac67p-2f, hi1 = 0x1.921fb4p-1f, hi2 = 0x1.f730bcp-1f, hi3 = 0x1.921fb4p+0f;
     const float lo0 = 0x1.586ed2p-28f, lo1 = 0x1.4442dp-25f, lo2 = 0x1.281f68p-25f, lo3 = 0x1.4442dp-24f;
     const float aT0 = 0x1.555556p-2f, aT1 = -0x1.99999ap-3f, aT2 = 0x1.24924ap-3f, aT3 = -0x1.c71c7p-4f, aT4 = 0x1.745cdcp-4f,
                 aT5 = -0x1.3b0f2ap-4f, aT6 = 0x1.10d66ap-4f, aT7 = -0x1.dde2d6p-5f, aT8 = 0x1.97b4b2p-5f, aT9 = -0x1.2b4442p-5f,
                 aT10 = 0x1.0ad3aep-6f;
-    const int32_t hx = (int32_t)f2u(x);
+    const int32_t hx = (int32_t)f2u(x0);
     const int32_t ix = hx & 0x7fffffff;
-    float hi = 0.0f, lo = 0.0f;
-    int id;
-    if (ix >= 0x4c000000) {  // |x| >= 2^25
-        if (ix > 0x7f800000) return x + x;
-        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
-    }
-    if (ix < 0x3ee00000) {  // |x| < 0.4375
-        if (ix < 0x31000000) return x;
-        id = -1;
-    } else {
-        x = fabsf_(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { id = 0; hi = hi0; lo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else { id = 1; hi = hi1; lo = lo1; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { id = 2; hi = hi2; lo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else { id = 3; hi = hi3; lo = lo3; x = -1.0f / x; }
-        }
-    }
+    const float ax = fabsf_(x0);
+    const bool direct = ix < 0x3ee00000;  // |x| < 0.4375: no reduction
+    const bool r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;
+    // (every candidate is computed, then selected: nested conditional expressions come back from the compiler as nested branches)
+    const float n0 = 2.0f * ax - 1.0f, n1 = ax - 1.0f, n2 = ax - 1.5f, d0 = 2.0f + ax, d1 = ax + 1.0f, d2 = 1.0f + 1.5f * ax;
+    float num = -1.0f, den = ax, hi = hi3, lo = lo3;
+    num = r2 ? n2 : num; den = r2 ? d2 : den; hi = r2 ? hi2 : hi; lo = r2 ? lo2 : lo;
+    num = r1 ? n1 : num; den = r1 ? d1 : den; hi = r1 ? hi1 : hi; lo = r1 ? lo1 : lo;
+    num = r0 ? n0 : num; den = r0 ? d0 : den; hi = r0 ? hi0 : hi; lo = r0 ? lo0 : lo;
+    num = direct ? x0 : num; den = direct ? 1.0f : den;  // x / 1 = x: one unconditional division instead of a branch around it
+    const float x = num / den;
     const float z = x * x;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
-    const float r = hi - ((x * (s1 + s2) - lo) - x);
-    return hx < 0 ? -r : r;
+    const float rr = hi - ((x * (s1 + s2) - lo) - x);
+    const float res_direct = x - x * (s1 + s2), res_huge = u2f(f2u(hi3 + lo3) | (f2u(x0) & 0x80000000u));
+    float res = u2f(f2u(rr) ^ (f2u(x0) & 0x80000000u));  // hx < 0 ? -rr : rr
+    res = direct ? res_direct : res;
+    res = ix < 0x31000000 ? x0 : res;        // |x| < 2^-29: x
+    res = ix >= 0x4c000000 ? res_huge : res;  // |x| >= 2^25: +-(hi3 + lo3)
+    return ix > 0x7f800000 ? x0 + x0 : res;
 }
 
 // atan2f (e_atan2f.c)
@@ -380,27 +352,33 @@ FHLM float atan2f_(float y, float x) {
     const float pi_o_4 = 0x1.921fb6p-1f, pi_o_2 = 0x1.921fb6p+0f, pi = 0x1.921fb6p+1f, pi_lo = -0x1.777a5cp-24f;
     const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
-    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-    if (hx == 0x3f800000) return atanf_(y);
-    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
-    if (iy == 0) return m < 2 ? y : (m == 2 ? pi : -pi);
-    if (ix == 0) return hy < 0 ? -pi_o_2 : pi_o_2;
-    if (ix == 0x7f800000) {
-        if (iy == 0x7f800000) return m == 0 ? pi_o_4 : m == 1 ? -pi_o_4 : m == 2 ? 3.0f * pi_o_4 : -3.0f * pi_o_4;
-        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi : -pi;
-    }
-    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 : pi_o_2;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);  // 2 * sign(x) + sign(y)
+    const bool x_one = hx == 0x3f800000;
+    const float t = atanf_(x_one ? y : fabsf_(y / x));
     const int k = (iy - ix) >> 23;
-    float z;
-    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
-    else if (hx < 0 && k < -60) z = 0.0f;
-    else z = atanf_(fabsf_(y / x));
-    switch (m) {
-        case 0: return z;
-        case 1: return u2f(f2u(z) ^ 0x80000000u);
-        case 2: return pi - (z - pi_lo);
-        default: return (z - pi_lo) - pi;
-    }
+    float z = t;
+    z = (hx < 0 && k < -60) ? 0.0f : z;          // |y| / x < -2^60
+    z = k > 60 ? pi_o_2 + 0.5f * pi_lo : z;      // |y / x| > 2^60
+    const float zl = z - pi_lo;
+    const float q0 = z, q1 = u2f(f2u(z) ^ 0x80000000u), q2 = pi - zl, q3 = zl - pi;
+    float res = q3;
+    res = m == 2 ? q2 : res;
+    res = m == 1 ? q1 : res;
+    res = m == 0 ? q0 : res;
+    const float ysign = u2f(f2u(y) & 0x80000000u);
+    const float ypi2 = u2f(f2u(pi_o_2) | f2u(ysign));  // hy < 0 ? -pi_o_2 : pi_o_2
+    const bool y_inf = iy == 0x7f800000, x_inf = ix == 0x7f800000;
+    res = y_inf ? ypi2 : res;
+    // x is inf: +-pi/4, +-3pi/4 when y is too; +-0, +-pi otherwise - the sign is y's
+    const float both = u2f(f2u(hx < 0 ? 3.0f * pi_o_4 : pi_o_4) | f2u(ysign));
+    const float one = u2f(f2u(hx < 0 ? pi : 0.0f) | f2u(ysign));
+    const float xinf_res = y_inf ? both : one;
+    res = x_inf ? xinf_res : res;
+    res = ix == 0 ? ypi2 : res;  // x = 0
+    res = iy == 0 ? one : res;   // y = 0: +-0 for positive x (= y), +-pi for negative
+    res = x_one ? t : res;
+    const float nan_res = x + y;
+    return (ix > 0x7f800000 || iy > 0x7f800000) ? nan_res : res;
 }
 
 }  // namespace fhlm

@@ -546,7 +546,7 @@ def to_rgba_distance(image):
     return _rgba(lib().orc_fx_to_rgba_distance, image)
 
 
-MATH_OPS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln"]
+MATH_OPS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2"]
 
 
 def math_unary(op, first, stride, count):

@@ -289,6 +289,7 @@ void orc_fx_to_rgba_distance(const float* img, uint64_t n, uint8_t* out) { fx_to
 
 // ---- libm sweep: the reference's transcendental opcodes call the platform libm in f32 (glibc here) --------------------
 // out[i] = f(x_i), x_i = the float with bit pattern first + i * stride; op: 0 sin 1 cos 2 tan 3 asin 4 acos 5 atan 6 exp 7 ln
+// 8 atan2(x_i, w_i) with w_i = the float with bit pattern x_i's bits * 2654435761 + 0x9E3779B9 (a second argument that covers the range)
 void orc_math_unary(int op, uint32_t first, uint32_t stride, uint64_t count, float* out) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)count; i++) {
@@ -302,6 +303,7 @@ void orc_math_unary(int op, uint32_t first, uint32_t stride, uint64_t count, flo
             case 4: y = acosf(x); break;
             case 5: y = atanf(x); break;
             case 6: y = expf(x); break;
+            case 8: y = atan2f(x, u2f((first + (uint32_t)i * stride) * 2654435761u + 0x9E3779B9u)); break;
             default: y = logf(x); break;
         }
         out[i] = y;

@@ -3,6 +3,7 @@ restatements of what they compute, on the device tape format (tape_format.h).
 
 TEST INFRASTRUCTURE ONLY.  The numpy evaluators follow fidget_amd/csrc/dev_ops.hpp (which cites
 fidget-core/src/types/{float,interval}.rs line by line) and kernels.hip prune_sweep (vm/data.rs:123-318)."""
+import ctypes
 import json
 import os
 import struct
@@ -97,10 +98,20 @@ def pcg(v):
     return (((w >> 22) ^ w) & 0xFFFFFFFF).astype(U32)
 
 
+_libm = ctypes.CDLL("libm.so.6")
+for _n in ("sinf", "cosf", "tanf", "asinf", "acosf", "atanf", "expf", "logf", "atan2f"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float] * (2 if _n == "atan2f" else 1)
+
+
 def t64(fn, *a):
-    """the device's definition of a transcendental opcode: f64 evaluation, one rounding (dev_ops.hpp t_*)"""
-    with np.errstate(all="ignore"):
-        return fn(*[np.asarray(x, F32).astype(np.float64) for x in a]).astype(F32)
+    """the device's definition of a transcendental opcode: the host libm's f32 routine (dev_ops.hpp t_* = trans_libm.hpp, which
+    restates it bit for bit); fn: the libm function's name"""
+    a = [np.asarray(x, F32) for x in a]
+    shape = np.broadcast(*a).shape
+    a = [np.broadcast_to(x, shape).reshape(-1) for x in a]
+    f = getattr(_libm, fn)
+    return np.array([f(*[float(x[k]) for x in a]) for k in range(a[0].size)], F32).reshape(shape)
 
 
 def rem_euclid(a, b):
@@ -109,7 +120,7 @@ def rem_euclid(a, b):
         return np.where(r < 0, (r + np.abs(b)).astype(F32), r).astype(F32)
 
 
-TRANS = {"SIN": np.sin, "COS": np.cos, "TAN": np.tan, "ASIN": np.arcsin, "ACOS": np.arccos, "ATAN": np.arctan, "EXP": np.exp, "LN": np.log}
+TRANS = {"SIN": "sinf", "COS": "cosf", "TAN": "tanf", "ASIN": "asinf", "ACOS": "acosf", "ATAN": "atanf", "EXP": "expf", "LN": "logf"}
 
 
 def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96))):
@@ -131,7 +142,7 @@ def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96))):
     h = {}
     for name, fn in TRANS.items():
         h[prog.symbols[prefix + name.lower()]] = mk(lambda x, fn=fn: t64(fn, x), 1)
-    h[prog.symbols[prefix + "atan2"]] = mk(lambda y, x: t64(np.arctan2, y, x), 2)
+    h[prog.symbols[prefix + "atan2"]] = mk(lambda y, x: t64("atan2f", y, x), 2)
     h[prog.symbols[prefix + "mod"]] = mk(rem_euclid, 2)
     return h
 
@@ -191,7 +202,7 @@ def ref_f32(tape, inputs, n):
             elif bn == "COMPARE":
                 r = _f_compare(a, b)
             elif bn == "ATAN2":
-                r = t64(np.arctan2, a, b)
+                r = t64("atan2f", a, b)
             elif bn == "MOD":
                 r = rem_euclid(a, b)
             elif bn == "MIX":

@@ -76,19 +76,19 @@ def ref_grad(tape, inputs, n):
                     f = lambda fn, x=v: U.t64(fn, x)
                     mulk = lambda c: [(a.c[k] * c).astype(F32) for k in (1, 2, 3)]
                     divk = lambda c, neg=False: [((-a.c[k] if neg else a.c[k]) / c).astype(F32) for k in (1, 2, 3)]
-                    if name == "SIN": r = G(f(np.sin), *mulk(f(np.cos)))
-                    elif name == "COS": r = G(f(np.cos), *mulk((-f(np.sin)).astype(F32)))
+                    if name == "SIN": r = G(f("sinf"), *mulk(f("cosf")))
+                    elif name == "COS": r = G(f("cosf"), *mulk((-f("sinf")).astype(F32)))
                     elif name == "TAN":
-                        c0 = f(np.cos)
-                        r = G(f(np.tan), *divk((c0 * c0).astype(F32)))
+                        c0 = f("cosf")
+                        r = G(f("tanf"), *divk((c0 * c0).astype(F32)))
                     elif name in ("ASIN", "ACOS"):
                         rt = np.sqrt((F32(1) - (v * v).astype(F32)).astype(F32)).astype(F32)
                         r = G(f(U.TRANS[name]), *divk(rt, neg=name == "ACOS"))
-                    elif name == "ATAN": r = G(f(np.arctan), *divk(((v * v).astype(F32) + F32(1)).astype(F32)))
+                    elif name == "ATAN": r = G(f("atanf"), *divk(((v * v).astype(F32) + F32(1)).astype(F32)))
                     elif name == "EXP":
-                        e = f(np.exp)
+                        e = f("expf")
                         r = G(e, *[(e * a.c[k]).astype(F32) for k in (1, 2, 3)])
-                    else: r = G(f(np.log), *divk(v))
+                    else: r = G(f("logf"), *divk(v))
                 else: raise NotImplementedError(name)
                 regs[ro] = r
             else:

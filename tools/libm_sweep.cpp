@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     const unsigned stride = argc > 2 ? atoi(argv[2]) : 1;
     int bad = 0;
     for (const Case& c : cases) {
-        if (argc > 1 && strcmp(argv[1], "all") && strcmp(argv[1], c.name)) continue;
+        if (argc > 1 && strcmp(argv[1], "all") && strcmp(argv[1], "unary") && strcmp(argv[1], c.name)) continue;
         unsigned long long differ = 0;
         unsigned first = 0;
         bool have = false;
