@@ -517,7 +517,9 @@ class Shape:
     def size(self):
         """Function::size (eval/mod.rs:171) = VmData<N>::len(): the device tape's length - one op per SSA op - or, for a Shape made with
         fewer than 255 registers, the reference's RegTape under that limit with its loads and stores (fhip_tape_reg_tape)."""
-        return self.device_len() if self.n_regs == 255 else self.reg_tape()[1][0]
+        if self.n_regs == 255 and lib().fhip_tape_reg_count(self._h) <= 255:
+            return self.device_len()
+        return int(self.reg_tape()[1][0])     # (also for a tape that needs more than 255 registers: VmData<255>::len() counts its loads / stores)
     __len__ = size
     def ssa_len(self): return self.device_len()  # device tapes carry no load/store: one op per SSA op
 

@@ -1010,6 +1010,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(extra * leaf_cap * sizeof(FhLeaf)));
     if (is3d) {
         if (P.width > 65535 || P.height > 65535) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images up to 65535 x 65535");
+        // (the assembly leaf and normals kernels address the z-buffer as base + a 32-bit byte offset of 8 bytes per pixel)
+        if ((uint64_t)P.width * P.height >= ((uint64_t)1 << 29)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images of fewer than 2^29 pixels");
         HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * sizeof(FhLeafRef)));
         HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * sizeof(FhLeafRef)));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
@@ -1041,7 +1043,9 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // (tapes with sin cos tan asin acos atan exp ln: the *_t variants of the tile kernels, which carry those interval handlers;
     // atan2, mod, mix, rand keep the HIP tile stage)
     R.asm_tiles_t = !tape_asm_ok(t) && tape_tiles_t_ok(t) && !ctx->opt.no_asm_tiles_t;
-    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && (tape_asm_ok(t) || R.asm_tiles_t) && t.n_regs <= 128;
+    // (not with a register file in HBM: the assembly tile kernels - fh_prune1, the groups path and the linked prune with them - keep
+    // registers AND choices in LDS, and a tape of few registers can still outgrow it by its choices alone, ~5 600 of them)
+    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && (tape_asm_ok(t) || R.asm_tiles_t) && t.n_regs <= 128 && !R.big_hbm;
     R.asm_tiles_t = R.asm_tiles_t && R.asm_tiles;
     // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
     // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
@@ -1088,16 +1092,24 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 std::vector<uint64_t> lk;
                 std::vector<uint64_t> cops;
                 if (fh::compute_links(t, lk, cops)) {
-                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_links, lk.size() * 8));
-                    HIP_TRY(ctx, hipMemcpy(tape->d_links, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
-                    HIP_TRY(ctx, hipMalloc((void**)&tape->d_ctab, std::max<size_t>(cops.size(), 1) * 8));
-                    HIP_TRY(ctx, hipMemcpy(tape->d_ctab, cops.data(), cops.size() * 8, hipMemcpyHostToDevice));
+                    // (published together or not at all: a failure half way must not leave links without their choice table)
+                    uint64_t *dl = nullptr, *dc = nullptr;
+                    hipError_t e = hipMalloc((void**)&dl, lk.size() * 8);
+                    if (e == hipSuccess) e = hipMemcpy(dl, lk.data(), lk.size() * 8, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMalloc((void**)&dc, std::max<size_t>(cops.size(), 1) * 8);
+                    if (e == hipSuccess) e = hipMemcpy(dc, cops.data(), cops.size() * 8, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) {
+                        if (dl) (void)hipFree(dl);
+                        if (dc) (void)hipFree(dc);
+                        HIP_TRY(ctx, e);
+                    }
+                    tape->d_links = dl; tape->d_ctab = dc;
                 }
             }
             R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices);
             // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
             // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)
-            R.prune2 = tape->d_links && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
+            R.prune2 = tape->d_links && tape->d_ctab && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
                        R.lds_prune2 <= FH_LDS_MAX && R.roots.size() * 64 <= (size_t)2 * ctx->n_cu * FH_P2_WPB;      // (a root group = up to 64 root tiles)
             R.d_ctab = tape->d_ctab;
             R.d_links = tape->d_links;

@@ -242,7 +242,8 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     auto resolve = [&](uint2 l, bool& has_a, bool& has_b, bool& imm, uint32_t& ta, uint32_t& tb) {
         const uint32_t kind = (l.x >> 8) & 0xFFu, fa = l.y & 0xFFFFu, fb = l.y >> 16;
         const uint32_t e_own = E[kind == FH_LK_CRI ? (l.x >> 16) : 0u];
-        const uint32_t e_a = E[(fa & FH_LK_CHOICE) ? (fa & 0x7FFFu) : 0u], e_b = E[(fb & FH_LK_CHOICE) ? (fb & 0x7FFFu) : 0u];
+        // (0xFFFF = no operand, and the padding link 0xFFFFFFFF, have the choice bit set too: entry 0 for them, never index 0x7FFF)
+        const uint32_t e_a = E[((fa & FH_LK_CHOICE) && fa != 0xFFFFu) ? (fa & 0x7FFFu) : 0u], e_b = E[((fb & FH_LK_CHOICE) && fb != 0xFFFFu) ? (fb & 0x7FFFu) : 0u];
         imm = kind == FH_LK_CRI && (e_own & FH_LK_IMM) != 0;
         has_a = !imm && kind != FH_LK_NONE;
         has_b = !imm && (kind == FH_LK_RR || kind == FH_LK_CRR);
