@@ -25,8 +25,11 @@ What the ONE JSON line says, and how to read it:
                              passes, counted where the leaves are queued), every launch between its own pair of HIP events
                              on the stream it is launched on; `alu` beside the HBM figure: f32 lane-operations per second
                              against the plain-f32 VALU rate - the resource that actually binds an interpreter;
-  roofline_default_path      the same kernel on the default path; roofline_tiles / roofline_tiles_default_path: the
-                             tile-stage kernel fh_tiles_v32 likewise (tape ops read + written at the per-slab level);
+                             `path_frame` inside it: that path's ms_per_step / value / single-frame latency;
+  roofline_timed_path        the dominant kernel of the path `value` times (prospero.vm: level 1's fh_tiles_v64), same fields;
+  roofline_default_path      the leaf kernel on the default path; roofline_tiles / roofline_tiles_l1 / roofline_prune (and their
+                             *_default_path twins): the per-slab tile kernel fh_tiles_v32, level 1's fh_tiles_v64 and the root
+                             level's prune likewise (tape ops read + written at their level in the timed frames);
   cpu_baseline               the C++ oracle (restatement of the reference's VmShape path, OpenMP over root tiles like
                              render_tiles' rayon pool) on this box's host cores, same frame; parity of the device image
                              against it at full size; `c3_bear`: BASELINE configuration 3 with its measured normal error; `c5_mesh`:
@@ -51,7 +54,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 78.6e12  # plain f32 VALU lane-operations per second: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (= the 157.3 TFLOP/s vector peak / 2 flops per FMA)
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r03.json")
+ISSUE_PEAK = 0.57              # wave-instructions per cycle per SIMD, measured (see `issue.peak_note`)
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r04.json")
 
 
 def parse_mesh_times(stdout, stderr):
@@ -66,8 +70,8 @@ def parse_mesh_times(stdout, stderr):
             "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
             "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
             "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of the builds after the first "
-                    "of this size; parity: tests/test_mesh.py (identical to the oracle's mesh where the oracle finishes in seconds; within the "
-                    "transcendental tolerance for this model)"}
+                    "of this size; parity: tests/test_mesh.py (identical to the oracle's mesh, triangle for triangle and vertex for vertex, up to "
+                    "depth 7 where the oracle finishes in seconds)"}
 
 
 def main():
@@ -335,6 +339,9 @@ def main():
         "host_output_frame_ms": host_frame,
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
                    "sharding": sharding,
+                   "general_path": None if not general else {"ms_per_step": general["ms_per_step"], "value": general["value"],
+                                                             "frame_latency_ms": general["frame_latency_ms"],
+                                                             "what": "the same frames with the column-invariance short cuts off: what a model with z in its tapes gets"},
                    "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (two buffer "
                              "sets per context: the coarse levels of a frame run beside the previous frame's slabs), every frame does all of its "
                              "work; frame_latency_ms is one frame alone, host_output_frame_ms the blocking call with a host buffer",
@@ -392,8 +399,11 @@ def main():
         if t and "valu_per_launch" in t and per_frame_ms > 0:
             cycles = per_frame_ms / max(launches_pf, 1) * 1e-3 * t.get("clock_hz", 2.4e9)
             ipc = (t["valu_per_launch"] + t["salu_per_launch"]) / (cycles * 1024)
-            r["issue"] = {"bound": "instruction issue", "achieved": ipc, "peak": 0.57, "unit": "wave-instructions / cycle / SIMD",
-                          "frac": ipc / 0.57, "valu_per_launch": t["valu_per_launch"], "salu_per_launch": t["salu_per_launch"]}
+            r["issue"] = {"bound": "instruction issue", "achieved": ipc, "peak": ISSUE_PEAK, "unit": "wave-instructions / cycle / SIMD",
+                          "frac": ipc / ISSUE_PEAK, "valu_per_launch": t["valu_per_launch"], "salu_per_launch": t["salu_per_launch"],
+                          "peak_note": "measured, not a data-sheet figure: independent v_mov_b32 in 4 waves per SIMD retire one instruction per 7.05 "
+                                       "cycles per wave (profiles/r02/ubench.json test 0, 4096 waves) = 0.57 per cycle per SIMD; a lone wave gets "
+                                       "one per 5.25 cycles = 0.19"}
         if traffic_note:
             r["traffic_note"] = traffic_note
         return r
@@ -410,22 +420,41 @@ def main():
                        64.0 * sum(v["ops"] for v in lv),
                        "interval interpreter + lockstep prune with the register file in VGPRs (per-slab level): bound by the latency of each parent's "
                        "dependent op chain (one wave per parent); algorithmic bytes = tape ops read + written at that level in the timed frames")
-        return r_leaf, r_tiles
+        # the two kernels of the coarse chain: level 1 - fh_tiles_v64, one wave per 128^3 parent walking its tape
+        # forward and in the lockstep prune - and the root level's prune (k_prune2 + fh_prune1 behind it, timed together as "fh_prune1")
+        l1, l0 = tiles.get("l1"), tiles.get("l0")
+        r_l1 = roof(P, path, "fh_tiles_v64", 8.0 * (l1["ops"] + l1["ops_written"]), 64.0 * l1["ops"],
+                    "level 1 (32^3 children of the 128^3 root tiles): interval interpreter + lockstep prune, register file in VGPRs; one wave per parent, "
+                    "so the launch lasts as long as its longest parent's dependent chain (~1 000 ops forward, the same backwards); algorithmic bytes = "
+                    "tape ops read + written at this level in the timed frames") if l1 else None
+        r_prune = roof(P, path, "fh_prune1", 8.0 * (3.0 * l0["ops"] + l0["ops_written"]), 0,
+                       "root level's prune (prune2.hip k_prune2, one wave per root tile's child tape, + fh_prune1 for the children it leaves): algorithmic "
+                       "bytes = the root tape with its links (8 + 16 B per op) staged once per workgroup + the child tapes written") if l0 else None
+        return r_leaf, r_tiles, r_l1, r_prune
 
     if world > 1:
         prof_general = prof_default = None      # (the roofline objects are rank 0's at N = 1, as the contract says)
+    per_frame = lambda r: r["avg_launch_ms"] * r["launches_per_frame"] if r else 0.0
     if prof_general:
-        r_leaf, r_tiles = roofs(prof_general, "general")
-        per_frame = lambda r: r["avg_launch_ms"] * r["launches_per_frame"] if r else 0.0
-        result["roofline"] = r_leaf if per_frame(r_leaf) >= per_frame(r_tiles) else r_tiles
-        result["roofline_leaf"], result["roofline_tiles"] = r_leaf, r_tiles
+        r_leaf, r_tiles, r_l1, r_prune = roofs(prof_general, "general")
+        # PRIMARY: the dominant kernel of the general path (what a model with z in its tapes gets) - with that path's own frame time,
+        # rate and latency inside the object, so that a record that keeps `roofline` keeps them
+        result["roofline"] = dict(max((r for r in (r_leaf, r_tiles, r_l1, r_prune) if r), key=per_frame))
+        result["roofline"]["path_frame"] = {"path": "general (column-invariance short cuts off)", "ms_per_step": general["ms_per_step"],
+                                            "value": general["value"], "unit": "Mvoxel/s", "frame_latency_ms": general["frame_latency_ms"]}
+        result["roofline_leaf"], result["roofline_tiles"], result["roofline_tiles_l1"], result["roofline_prune"] = r_leaf, r_tiles, r_l1, r_prune
     if prof_default:
-        d_leaf, d_tiles = roofs(prof_default, "default")
+        d_leaf, d_tiles, d_l1, d_prune = roofs(prof_default, "default")
         result["roofline_default_path"] = d_leaf
         result["roofline_tiles_default_path"] = d_tiles
+        # the dominant kernel of the path that `value` times (prospero.vm: level 1, fh_tiles_v64)
+        dom = max((r for r in (d_leaf, d_tiles, d_l1, d_prune) if r), key=per_frame)
+        result["roofline_timed_path"] = dict(dom)
+        result["roofline_timed_path"]["path_frame"] = {"path": "default (the frames `value` times)", "ms_per_step": ms_per_step, "value": value,
+                                                       "unit": "Mvoxel/s", "frame_latency_ms": lat_default}
+        result["roofline_tiles_l1_default_path"], result["roofline_prune_default_path"] = d_l1, d_prune
         if "roofline" not in result:
-            per_frame = lambda r: r["avg_launch_ms"] * r["launches_per_frame"] if r else 0.0
-            result["roofline"] = d_leaf if per_frame(d_leaf) >= per_frame(d_tiles) else d_tiles
+            result["roofline"] = result["roofline_timed_path"]
     if world == 1:
         result["device_counters"] = {k: {"leaf": v["leaf"], "tile_levels": v["tiles"]} for k, v in (("general", prof_general), ("default", prof_default)) if v}
 
