@@ -320,6 +320,20 @@ def main():
         step()  # leave `out` holding the combined image on rank 0
     fence()
 
+    # N > 1: what each rank's share of a frame costs, stage by stage (sums of kernel times over the rank's profiled frames, columns
+    # sharding): the coarse chain - root level forward + prune, level 1 - is as LONG on every rank as on one GPU (each parent / child is
+    # one wave whatever their number), the per-slab tile stage, the leaves and the normals shrink with the rank's share; a scaling curve
+    # taken with this line can be read against these
+    per_rank = None
+    if world > 1:
+        k, pr = prof_default["kern"], prof_default["prof"]
+        ms = lambda d, key: (d.get(key, (0.0, 0))[0]) / PROF_FRAMES
+        coarse = sum(ms(k, x) for x in ("fh_tiles", "fh_prune1", "fh_tiles_v64"))
+        mine = {"rank": rank, "coarse_chain_ms": coarse, "slab_ms": max(ms(pr, "tiles") - coarse, 0.0) + ms(pr, "points") + ms(pr, "normals"),
+                "tile_stage_ms": ms(pr, "tiles"), "leaf_ms": ms(pr, "points"), "normals_ms": ms(pr, "normals"), "other_ms": ms(pr, "other")}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -359,6 +373,7 @@ def main():
     if partitions:
         result["partitions"] = partitions
         result["collectives"] = direct_note
+        result["per_rank"] = per_rank
 
     # ---- roofline: numerators from the device counters of the profiled frames themselves ----------------
     # HBM traffic per launch: rocprofv3 PMC passes of tools/profile_round.sh, committed under profiles/ (counters cannot be

@@ -141,7 +141,7 @@ def _worker(rank, world, port, out_path, direct):
     sys.stdout.flush()
 
 
-@pytest.mark.parametrize("direct,world", [(False, 2), (True, 2), (True, 4)])
+@pytest.mark.parametrize("direct,world", [(False, 2), (True, 2), (True, 4), (True, 8)])     # 8: the node the scaling run uses (octants 2 x 2 x 2)
 def test_bench_two_ranks_protocol(tmp_path, direct, world):
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -170,6 +170,11 @@ def test_bench_two_ranks_protocol(tmp_path, direct, world):
     assert p["columns"]["frame_latency_ms"] > 0 and p["blocks"]["frame_latency_ms"] > 0
     assert ("DirectRccl" in r["collectives"]) if direct else ("torch.distributed" in r["collectives"])
     assert "roofline" not in r and "cpu_baseline" not in r         # rank 0 at N = 1 only
+    # every rank's stage times of its share of a frame, gathered to rank 0
+    assert [q["rank"] for q in r["per_rank"]] == list(range(world))
+    assert all({"coarse_chain_ms", "slab_ms", "tile_stage_ms", "leaf_ms", "normals_ms"} <= set(q) for q in r["per_rank"])
+    if world == 8:
+        assert p["blocks"]["split"] == [2, 2, 2]
 
 
 def test_c5_mesh_leg_reads_the_mesh_tools_output():
