@@ -20,7 +20,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+# FIDGET_SANITIZE=1 (tests/test_sanitizers.py): the same sources under AddressSanitizer + UndefinedBehaviorSanitizer, as a library
+# of its own; the process must have been started with the sanitizer runtimes preloaded
+_SANITIZE = os.environ.get("FIDGET_SANITIZE") == "1"
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle_san.so" if _SANITIZE else "liboracle.so")
 
 UNARY = ["neg", "abs", "recip", "sqrt", "square", "floor", "ceil", "round", "sin", "cos", "tan",
          "asin", "acos", "atan", "exp", "ln", "not", "rand"]
@@ -47,7 +50,7 @@ def build(force=False):
         os.path.getmtime(os.path.join(_HERE, "src", f)) > os.path.getmtime(_LIB_PATH)
         for f in os.listdir(os.path.join(_HERE, "src"))
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["san"] if _SANITIZE else []) + (["-B"] if force else []))
     return _LIB_PATH
 
 

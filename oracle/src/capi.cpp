@@ -17,6 +17,11 @@ struct OrcShape {
     VmDataP d;
 };
 
+// memcpy whose source may be an empty vector's null data(): undefined behaviour even for zero bytes (found by UBSan, tests/test_sanitizers.py)
+static inline void copy_bytes(void* dst, const void* src, size_t n) {
+    if (n) std::memcpy(dst, src, n);
+}
+
 extern "C" {
 
 // ---- Context -------------------------------------------------------------
@@ -166,7 +171,7 @@ int orc_eval_interval(void* s, const float* vars, uint32_t nvars, float* out, ui
     int r = e.eval(d, v.data(), nvars);
     if (r < 0) return r;
     for (size_t i = 0; i < e.out.size(); i++) { out[2 * i] = e.out[i].lo; out[2 * i + 1] = e.out[i].hi; }
-    if (choices) std::memcpy(choices, e.choices.data(), e.choices.size());
+    if (choices) copy_bytes(choices, e.choices.data(), e.choices.size());
     return r;
 }
 int orc_eval_point(void* s, const float* vars, uint32_t nvars, float* out, uint8_t* choices) {
@@ -175,7 +180,7 @@ int orc_eval_point(void* s, const float* vars, uint32_t nvars, float* out, uint8
     int r = e.eval(d, vars, nvars);
     if (r < 0) return r;
     for (size_t i = 0; i < e.out.size(); i++) out[i] = e.out[i];
-    if (choices) std::memcpy(choices, e.choices.data(), e.choices.size());
+    if (choices) copy_bytes(choices, e.choices.data(), e.choices.size());
     return r;
 }
 // Bulk f32: vars[i] -> n floats; out = output_count x n (output-major).
@@ -185,7 +190,7 @@ int orc_eval_float_slice(void* s, const float* const* vars, uint32_t nvars, uint
     BulkEval<float> e;
     int r = e.eval(d, vars, nvars, n);
     if (r < 0) return r;
-    for (size_t o = 0; o < e.out.size(); o++) std::memcpy(out + o * n, e.out[o].data(), n * 4);
+    for (size_t o = 0; o < e.out.size(); o++) copy_bytes(out + o * n, e.out[o].data(), n * 4);
     return 0;
 }
 // Bulk grad: vars[i] -> n x {v,dx,dy,dz}
@@ -196,7 +201,7 @@ int orc_eval_grad_slice(void* s, const float* const* vars, uint32_t nvars, uint3
     for (uint32_t i = 0; i < nvars; i++) v[i] = (const Grad*)vars[i];
     int r = e.eval(d, v.data(), nvars, n);
     if (r < 0) return r;
-    for (size_t o = 0; o < e.out.size(); o++) std::memcpy(out + o * n * 4, e.out[o].data(), n * 16);
+    for (size_t o = 0; o < e.out.size(); o++) copy_bytes(out + o * n * 4, e.out[o].data(), n * 16);
     return 0;
 }
 uint64_t orc_invalid_intervals() { return g_invalid_intervals; }
@@ -208,12 +213,12 @@ void orc_screen_to_world(const uint32_t* size, int n, float* out) { screen_to_wo
 void orc_mat_mul(const float* a, const float* b, int dim, float* out) { mat_mul(a, b, dim, out); }
 void orc_transform_point(const float* mat4, float x, float y, float z, float* out) {
     Mat4 m;
-    std::memcpy(m.m, mat4, 64);
+    copy_bytes(m.m, mat4, 64);
     transform_f32(m, x, y, z, out, out + 1, out + 2);
 }
 void orc_transform_interval(const float* mat4, const float* xyz /*3x{lo,hi}*/, float* out /*3x{lo,hi}*/) {
     Mat4 m;
-    std::memcpy(m.m, mat4, 64);
+    copy_bytes(m.m, mat4, 64);
     Interval o[3];
     transform_interval(m, Interval(xyz[0], xyz[1]), Interval(xyz[2], xyz[3]), Interval(xyz[4], xyz[5]), o);
     for (int i = 0; i < 3; i++) { out[2 * i] = o[i].lo; out[2 * i + 1] = o[i].hi; }
@@ -246,7 +251,7 @@ int orc_render2d(void* s, const float* world_to_model, uint32_t w, uint32_t h, f
                                var_vals, n_vars);
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
-    if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));
+    if (stats) copy_bytes(stats, &r.stats, sizeof(RenderStats));
     return r.ok ? 0 : -1;
 }
 // world_to_model: row-major 4x4 (may be NULL).  out = w*h GeometryPixel {f32 normal[3]; u32 depth}
@@ -267,7 +272,7 @@ int orc_render3d(void* s, const float* world_to_model, uint32_t w, uint32_t h, u
                                var_vals, n_vars);
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
-    if (stats) std::memcpy(stats, &r.stats, sizeof(RenderStats));
+    if (stats) copy_bytes(stats, &r.stats, sizeof(RenderStats));
     return r.ok ? 0 : -1;
 }
 
@@ -344,7 +349,7 @@ void orc_mesh_counts(void* h, uint64_t out[8]) {
     out[0] = m->o.cells.size(); out[1] = m->o.verts.size(); out[2] = m->o.samples.size(); out[3] = m->o.interval_evals;
     out[4] = m->o.root.kind; out[5] = m->o.root.mask; out[6] = m->o.root.index; out[7] = 0;
 }
-void orc_mesh_verts(void* h, float* out) { OrcMesh* m = (OrcMesh*)h; std::memcpy(out, m->o.verts.data(), m->o.verts.size() * 12); }
+void orc_mesh_verts(void* h, float* out) { OrcMesh* m = (OrcMesh*)h; copy_bytes(out, m->o.verts.data(), m->o.verts.size() * 12); }
 // cells: per cell 3 x u32 (kind, mask, index), 8 per group
 void orc_mesh_cells(void* h, uint32_t* out) {
     OrcMesh* m = (OrcMesh*)h;
@@ -359,8 +364,8 @@ void orc_mesh_samples(void* h, float* bounds, uint32_t* info, uint16_t* inter, f
     for (auto& s : m->o.samples) {
         for (int k = 0; k < 3; k++) { bounds[i * 6 + 2 * k] = s.bounds.b[k].lo; bounds[i * 6 + 2 * k + 1] = s.bounds.b[k].hi; }
         info[i * 3] = s.mask; info[i * 3 + 1] = s.n_edges; info[i * 3 + 2] = s.n_verts;
-        std::memcpy(inter + i * 36, s.inter, 72); std::memcpy(pos + i * 36, s.pos, 144); std::memcpy(grad + i * 48, s.grad, 192);
-        std::memcpy(vert + i * 12, s.vert, 48);
+        copy_bytes(inter + i * 36, s.inter, 72); copy_bytes(pos + i * 36, s.pos, 144); copy_bytes(grad + i * 48, s.grad, 192);
+        copy_bytes(vert + i * 12, s.vert, 48);
         i++;
     }
 }
@@ -372,8 +377,8 @@ void orc_mesh_walk_dual(void* h, uint64_t out[2]) {
 }
 void orc_mesh_dual_copy(void* h, uint64_t* tris, float* verts) {
     OrcMesh* m = (OrcMesh*)h;
-    std::memcpy(tris, m->m.triangles.data(), m->m.triangles.size() * 24);
-    std::memcpy(verts, m->m.vertices.data(), m->m.vertices.size() * 12);
+    copy_bytes(tris, m->m.triangles.data(), m->m.triangles.size() * 24);
+    copy_bytes(verts, m->m.vertices.data(), m->m.vertices.size() * 12);
 }
 // CELL_TO_VERT_TO_EDGES / CELL_TO_EDGE_TO_VERT (build.rs): for mask: out[0] = vertices, then per vertex: count, (start, end)...; e2v[12][2]
 void orc_mesh_table(int mask, int32_t* v2e, int32_t* e2v) {

@@ -19,10 +19,12 @@ CSRC = os.path.join(ROOT, "fidget_amd", "csrc")
 def edges_lib():
     out = os.path.join(ROOT, "tests", "host_build", "_build")
     os.makedirs(out, exist_ok=True)
-    so = os.path.join(out, "libmesh_edges_host.so")
+    san = os.environ.get("FIDGET_SANITIZE") == "1"      # tests/test_sanitizers.py: the same sources under ASan + UBSan
+    so = os.path.join(out, "libmesh_edges_host_san.so" if san else "libmesh_edges_host.so")
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("mesh_edges.hpp", "mesh_qef.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I", CSRC, SRC, "-o", so])
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if san else ["-O2"]
+        subprocess.check_call(["g++", "-std=c++17"] + flags + ["-ffp-contract=off", "-fPIC", "-shared", "-I", CSRC, SRC, "-o", so])
     lib = C.CDLL(so)
     lib.fh_edge_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.fh_edge_points.argtypes = [C.c_void_p] * 3
