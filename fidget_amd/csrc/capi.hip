@@ -781,6 +781,7 @@ struct RenderSetup {
     uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
     size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
+    size_t mind_words = 0;      // words of the min-depth pyramid (cleared at the head of the frame)
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
     bool asm_points = false;  // leaf stage on the assembly interpreters
@@ -1021,7 +1022,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         size_t mind_words = 0;
         for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
         HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->mind.p, 0, mind_words * 4, ctx->stream));  // empty image: nothing occluded
+        R.mind_words = mind_words;   // (cleared - empty image: nothing occluded - by the frame's first launch, upload_frame)
         uint32_t* mp = (uint32_t*)ctx->mind.p;
         for (size_t l = 0; l < ts.size(); l++) {
             S.mind[l] = mp;
@@ -1189,7 +1190,8 @@ static fhip_status finish_render(fhip_ctx* ctx) {
     return FHIP_OK;
 }
 
-static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R) {
+struct FrameClear { void* p = nullptr; size_t bytes = 0; uint32_t fill = 0; };   // a buffer the frame starts from cleared (bytes: a multiple of 4)
+static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R, const FrameClear (&clear)[3]) {
     // The frame's state and root groups go through pinned staging slots (a ring of eight, each guarded by an event): a copy from
     // pageable memory would make the host wait for everything queued on the stream before it, i.e. for the previous frame.
     const size_t roots_bytes = R.roots.size() * sizeof(FhGroup);
@@ -1204,7 +1206,6 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     }
     memcpy(sg.p, &R.S, sizeof(FhRenderState));
     if (roots_bytes) memcpy((char*)sg.p + sizeof(FhRenderState), R.roots.data(), roots_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, sg.p, sizeof(FhRenderState), hipMemcpyHostToDevice, ctx->stream));
     // The root tape and its groups sit below arena_root_end, where no frame writes: a shape rendered
     // again finds them there (17 small copies, 0.1 ms of a 4 ms frame, otherwise).
     if (ctx->resident_serial != tape->serial || ctx->resident_groups != R.S.n_tgroups) {
@@ -1216,10 +1217,24 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         ctx->resident_serial = tape->serial;
         ctx->resident_groups = R.S.n_tgroups;
     }
+    // state, root groups and the cleared buffers in one launch (k_frame_begin reads the pinned slot itself)
+    static_assert(sizeof(FhRenderState) % 4 == 0 && sizeof(FhGroup) % 4 == 0, "copied as 32-bit words");
+    FhFrameBegin fb;
+    memset(&fb, 0, sizeof(fb));
+    fb.state_dst = (uint32_t*)ctx->state.p; fb.state_src = (const uint32_t*)sg.p; fb.state_words = (uint32_t)(sizeof(FhRenderState) / 4);
     if (!R.roots.empty()) {
-        FhGroup* back = (FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size());
-        HIP_TRY(ctx, hipMemcpyAsync(back, (char*)sg.p + sizeof(FhRenderState), roots_bytes, hipMemcpyHostToDevice, ctx->stream));
+        fb.roots_dst = (uint32_t*)((FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size()));
+        fb.roots_src = (const uint32_t*)((const char*)sg.p + sizeof(FhRenderState));
+        fb.roots_words = (uint32_t)(roots_bytes / 4);
     }
+    size_t most = 0;
+    for (int k = 0; k < 3; k++) {
+        fb.clear[k] = (uint32_t*)clear[k].p; fb.clear_words[k] = clear[k].bytes / 4; fb.fill[k] = clear[k].fill;
+        if (clear[k].p) most = std::max(most, clear[k].bytes);
+    }
+    const unsigned blocks = (unsigned)std::max<size_t>(2, std::min<size_t>((size_t)ctx->n_cu * 8, (most + 256 * 64 - 1) / (256 * 64)));
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks), dim3(256), 0, ctx->stream, fb);
+    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sg.ev, ctx->stream));
     sg.used = true;
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
@@ -1452,7 +1467,8 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * 4)); d_out = (float*)ctx->tmp_out.p; }
     R.S.image2d = d_out;
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
-    st = upload_frame(ctx, tape, R);
+    const FrameClear no_clear[3] = {};
+    st = upload_frame(ctx, tape, R, no_clear);
     if (st) return st;
     for (uint32_t l = 0; l < P.n_levels; l++) {
         if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
@@ -1538,12 +1554,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
-    st = upload_frame(ctx, tape, R);
-    if (st) return st;
     // (FHIP_DEBUG_ZFILL, diagnostics: every pixel already at the far depth - the front slab's leaf kernel then finds all its
     // leaves but nothing pending, which times its per-workgroup and per-leaf set-up without the interpretation)
-    HIP_TRY(ctx, hipMemsetAsync(ctx->zbuf.p, ctx->opt.debug_zfill ? 0xFF : 0, npix * 8, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->normals.p, 0, npix * 12, ctx->stream));
+    const FrameClear clear3[3] = {{ctx->zbuf.p, npix * 8, ctx->opt.debug_zfill ? 0xFFFFFFFFu : 0u}, {ctx->normals.p, npix * 12, 0u},
+                                  {ctx->mind.p, R.mind_words * 4, 0u}};
+    st = upload_frame(ctx, tape, R, clear3);
+    if (st) return st;
     const uint32_t n_groups = R.groups_per_slab;
     const uint32_t pre = R.S.pre_levels;
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
