@@ -94,10 +94,14 @@ def build(force=False, verbose=False):
     run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "-emit-llvm", "--cuda-device-only", "-I", _CSRC,
          "-o", ll, os.path.join(_CSRC, "trans_funcs.hip")])
     ir = open(ll).read()
-    m = re.search(r"^define [^\n]*@fh_t_sin\([^\n]*\) (#\d+)", ir, re.M)
-    assert m, "trans_funcs.ll: fh_t_sin not found"
-    ir, n = re.subn(rf"^attributes {m.group(1)} = {{ ", f'attributes {m.group(1)} = {{ "amdgpu-num-sgpr"="18" ', ir, flags=re.M)
-    assert n == 1
+    groups = set()
+    for fn in ("fh_t_sin", "fh_t_atan2", "fh_t_mod", "fh_t_sin4", "fh_t_ln4"):
+        m = re.search(rf"^define [^\n]*@{fn}\([^\n]*\) (#\d+)", ir, re.M)
+        assert m, f"trans_funcs.ll: {fn} not found"
+        groups.add(m.group(1))
+    for g in groups:
+        ir, n = re.subn(rf"^attributes {g} = {{ ", f'attributes {g} = {{ "amdgpu-num-sgpr"="18" ', ir, flags=re.M)
+        assert n == 1
     with open(ll, "w") as f:
         f.write(ir)
     run([os.path.join(llvm, "llc"), "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O3", "-o", os.path.join(gen, "trans_funcs.s"), ll])

@@ -162,6 +162,7 @@ class Interp:
         self.a, self.name, self.nr, self.zb, self.kind, self.off = a, name, nr, zb, kind, off
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.t_base = 128    # ... whose register window starts here (behind the register file)
+        self.wide_trans = False   # the four-sample routines are embedded too (window of gen_trans.WIDE_V registers)
         self.t_prefix = "fh_t_"   # ... and whose labels start with this (every kernel embeds its own copies)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.hl = HSTRIDE_LOG2
@@ -451,10 +452,18 @@ class Interp:
             def body(fn=op.lower()):
                 self.read_a(VT)
                 self.idx_off()
-                for j in Z:
-                    a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
-                    self.call(fn)
-                    a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
+                if self.wide_trans and fn in ("sin", "cos", "exp", "ln") and self.zb % 4 == 0:
+                    for j0 in range(0, self.zb, 4):       # four samples per call (gen_trans.FUNCS4)
+                        for k in range(4):
+                            a(f"\tv_mov_b32 v{self.t_base + k}, {VT[j0 + k]}")
+                        self.call(fn + "4")
+                        for k in range(4):
+                            a(f"\tv_mov_b32 {VU[j0 + k]}, v{self.t_base + k}")
+                else:
+                    for j in Z:
+                        a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
+                        self.call(fn)
+                        a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         if op == "RAND":
@@ -893,11 +902,12 @@ def _gen_columns_body(a, variants, off, kname, trans):
     o = off
     m = S_MAT
     file_regs = max(nr * zb for nr, zb in variants)
-    t_base = FILE + file_regs                # the routines' register window: 26 VGPRs behind the register file
-    nvg = t_base + 26 if trans else FILE + file_regs
+    t_base = FILE + file_regs                # the routines' register window behind the register file: 64 VGPRs (the four-sample routines;
+    nvg = t_base + 64 if trans else FILE + file_regs   # 192 + 64 = 256: still two waves per SIMD, as with 26)
     its = [Interp(a, f"{kname}_{nr}x{zb}", nr, zb, "columns", off, trans=bool(trans)) for nr, zb in variants]
     for it in its:
         it.t_base = t_base
+        it.wide_trans = bool(trans)
     inplace_mask = 0
     for k, op in enumerate(OPS):
         if op in Interp.INPLACE:
@@ -1236,7 +1246,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
     kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans, v_base=t_base)
+        gen_trans.embed(a, trans, v_base=t_base, wide=True)
     for it in its:
         it.emit()
     return kname, nvg

@@ -10,7 +10,8 @@ import re
 
 V_BASE, S_BASE, S_RET = 128, 86, 96
 FUNCS = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod"]
-MAX_V, MAX_S = 26, 10
+FUNCS4 = ["sin4", "cos4", "exp4", "ln4"]     # four samples per call (v0..v3 in and out): embedded with a window of WIDE_V registers
+MAX_V, MAX_S, WIDE_V = 26, 10, 64
 
 
 _TAB_SYM = re.compile(r"_ZZN4fhlm9MemTables\d+(\w+?)EjE1T")   # function-local `static const T[]` of fhlm::MemTables::<name>
@@ -29,15 +30,22 @@ def tables(a, path):
     a("\t.text")
 
 
-def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None):
+def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None, MAX_V=MAX_V):
+    def compact(n):
+        """the compiler leaves the callee-saved blocks v40..v47, v56..v63, v72..v79, ... alone; the window has no such gaps (blocks
+        of eight move as a whole: 64-bit operands stay even-aligned)"""
+        b = n // 8
+        assert b < 5 or b % 2 == 0, (name, n)      # a callee-saved register would have been spilled to scratch
+        return n - 8 * len([x for x in range(5, b) if x % 2])
+
     def v1(m):
-        n = int(m.group(1))
+        n = compact(int(m.group(1)))
         assert n < MAX_V, (name, m.group(0))
         return f"v{V_BASE + n}"
 
     def v2(m):
-        a, b = int(m.group(1)), int(m.group(2))
-        assert b < MAX_V, (name, m.group(0))
+        a, b = compact(int(m.group(1))), compact(int(m.group(2)))
+        assert b < MAX_V and b - a == int(m.group(2)) - int(m.group(1)), (name, m.group(0))
         return f"v[{V_BASE + a}:{V_BASE + b}]"
 
     def smap(n):
@@ -77,13 +85,14 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None):
     return "\n".join(out)
 
 
-def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None):
+def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
     """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
     window embeds its own copies: `s_branch` reaches 128 KB); s_map: the ten scalar registers s0..s9 go to (default s86..s95; pairs
-    must stay even-aligned pairs), the return address always to s[96:97]"""
+    must stay even-aligned pairs), the return address always to s[96:97]; wide: also the four-sample routines FUNCS4, and a window of
+    WIDE_V registers"""
     txt = open(path).read()
-    for f in FUNCS:
+    for f in FUNCS + (FUNCS4 if wide else []):
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f
         a(f"\t.p2align 6\n{prefix}{f}:")
-        a(_rename(m.group(1), f, v_base, prefix, s_map))
+        a(_rename(m.group(1), f, v_base, prefix, s_map, WIDE_V if wide else MAX_V))

@@ -21,9 +21,19 @@ FH_NI float fh_t_atan(float a) { return fhd::t_atan(a); }
 FH_NI float fh_t_exp(float a) { return fhd::t_exp(a); }
 FH_NI float fh_t_ln(float a) { return fhd::t_ln(a); }
 FH_NI float fh_t_atan2(float y, float x) { return fhd::t_atan2(y, x); }
+// Four samples per call (arguments and results in v0..v3) for the leaf interpreter, which evaluates an op for the 8 voxels of a lane: the
+// call, the constants and - for expf / logf - the latency of the table loads are paid once per four samples instead of once per sample.
+typedef float fh_f4 __attribute__((ext_vector_type(4)));
+#define FH_T4(name, fn) FH_NI fh_f4 fh_t_##name##4(fh_f4 a) { fh_f4 r; for (int k = 0; k < 4; k++) r[k] = fhd::fn(a[k]); return r; }
+FH_T4(sin, t_sin)
+FH_T4(cos, t_cos)
+FH_T4(exp, t_exp)
+FH_T4(ln, t_ln)
 FH_NI float fh_t_mod(float a, float b) { return fhd::rem_euclid(a, b); }
 // (a kernel that references them keeps the functions in the device image)
 __global__ void fh_trans_keep(float* p) {
     p[0] = fh_t_sin(p[0]) + fh_t_cos(p[0]) + fh_t_tan(p[1]) + fh_t_asin(p[2]) + fh_t_acos(p[2]) + fh_t_atan(p[2]) + fh_t_exp(p[1]) + fh_t_ln(p[2]) +
            fh_t_atan2(p[3], p[4]) + fh_t_mod(p[3], p[4]);
+    const fh_f4 a = {p[5], p[6], p[7], p[8]}, r = fh_t_sin4(a) + fh_t_cos4(a) + fh_t_exp4(a) + fh_t_ln4(a);
+    p[1] = r[0] + r[1] + r[2] + r[3];
 }

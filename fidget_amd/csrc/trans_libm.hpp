@@ -46,6 +46,15 @@ FHLM uint64_t d2u(double f) { return __builtin_bit_cast(uint64_t, f); }
 FHLM double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 FHLM double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 FHLM float nan_() { return u2f(0x7FC00000u); }
+// A value the device compiler must take as it is (an empty asm on a vector register): a comparison recomputed from it is not merged with
+// an earlier one, so its lane mask does not occupy scalar registers in between (the four-sample routines of trans_funcs.hip would
+// otherwise hold four such masks at once and spill them).  Nothing on the host.
+FHLM uint32_t opaque_(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 
 // ---- tables (e_exp2f_data.c: 2^(i/32) with the exponent bits of i/32 taken off; e_logf_data.c; s_sincosf_data.c __inv_pio4) ----
 struct MemTables {
@@ -162,13 +171,13 @@ FHLM float expf_(float x) {
     y = fma_(z, r2, y);
     y = y * s;
     float res = (float)y;
-    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
-        res = x < -0x1.9d1d9ep6f ? u2f(1u) : res;            // __math_may_uflowf: 0x1.4p-75f squared = the smallest subnormal
-        res = x < -0x1.9fe368p6f ? 0.0f : res;               // underflow
-        res = x > 0x1.62e42ep6f ? u2f(0x7f800000u) : res;    // overflow
-        res = abstop >= 0x7f8 ? x + x : res;                 // inf, NaN
-        res = xi == 0xff800000u ? 0.0f : res;
-    }
+    // |x| >= 88 or NaN (abstop >= 0x42b) - as selects, taken by the comparisons themselves: no branch, so that the four-sample routine
+    // is one block and its table loads are issued together
+    res = x < -0x1.9d1d9ep6f ? u2f(1u) : res;          // __math_may_uflowf: 0x1.4p-75f squared = the smallest subnormal
+    res = x < -0x1.9fe368p6f ? 0.0f : res;             // underflow
+    res = x > 0x1.62e42ep6f ? u2f(0x7f800000u) : res;  // overflow
+    res = abstop >= 0x7f8 ? x + x : res;               // inf, NaN
+    res = xi == 0xff800000u ? 0.0f : res;
     return res;
 }
 
@@ -191,12 +200,12 @@ FHLM float logf_(float x) {
     y = fma_(-0x1.00ea348b88334p-2, r2, y);                            // A[0] * r2 + y
     y = fma_(y, r2, y0 + r);
     float res = (float)y;
-    if (special) {
-        res = ((ix0 & 0x80000000u) || ix0 * 2 >= 0xff000000u) ? nan_() : res;
-        res = ix0 == 0x7f800000u ? x : res;
-        res = ix0 * 2 == 0 ? u2f(0xff800000u) : res;  // log(+-0) = -inf
-    }
-    return ix0 == 0x3f800000u ? 0.0f : res;
+    const uint32_t ix1 = opaque_(ix0);  // (= ix0: the comparisons below are made here, not kept from above)
+    // x < 2^-126, inf or NaN - as selects (no branch: see expf_)
+    res = (ix1 - 0x00800000u >= 0x7f800000u - 0x00800000u && ((ix1 & 0x80000000u) || ix1 * 2 >= 0xff000000u)) ? nan_() : res;
+    res = ix1 == 0x7f800000u ? x : res;
+    res = ix1 * 2 == 0 ? u2f(0xff800000u) : res;  // log(+-0) = -inf
+    return ix1 == 0x3f800000u ? 0.0f : res;
 }
 
 // ---- fdlibm routines: binary32 arithmetic, one rounding per operation (no fused multiply-add anywhere) ----

@@ -123,17 +123,21 @@ def rem_euclid(a, b):
 TRANS = {"SIN": "sinf", "COS": "cosf", "TAN": "tanf", "ASIN": "asinf", "ACOS": "acosf", "ATAN": "atanf", "EXP": "expf", "LN": "logf"}
 
 
-def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96))):
+def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96)), window=26):
     """native stand-ins for the compiled routines embedded by gen_trans.py (the emulator has no f64 ISA): argument(s) in v<v_base> (,
     v<v_base + 1>), result in v<v_base> for the lanes in exec, return to s[96:97]; the routines' register window and scalar
-    registers come back clobbered"""
-    def mk(fn, nargs):
+    registers come back clobbered.  The four-sample routines (gen_trans.FUNCS4, where embedded): v<v_base> .. v<v_base + 3> in and out."""
+    def mk(fn, nargs, nres=1):
         def hook(w):
             m = w._bits(w.exec)
             args = [w.v[v_base + k].view(F32).copy() for k in range(nargs)]
-            r = fn(*args).astype(F32).view(U32)
-            w.v[v_base][m] = r[m]
-            w.v[v_base + 1:v_base + 26] = 0xDEADBEEF            # the routines may clobber their whole register window
+            if nres == 1:
+                res = [fn(*args)]
+            else:
+                res = [fn(x) for x in args]
+            for k, r in enumerate(res):
+                w.v[v_base + k][m] = r.astype(F32).view(U32)[m]
+            w.v[v_base + nres:v_base + window] = 0xDEADBEEF        # the routines may clobber their whole register window
             for sr in sregs:
                 w.s[sr] = 0xDEADBEEF
             w.vcc = 0xDEADBEEFDEADBEEF
@@ -142,6 +146,8 @@ def trans_hooks(prog, prefix="fh_t_", v_base=128, sregs=tuple(range(86, 96))):
     h = {}
     for name, fn in TRANS.items():
         h[prog.symbols[prefix + name.lower()]] = mk(lambda x, fn=fn: t64(fn, x), 1)
+        if prefix + name.lower() + "4" in prog.symbols:
+            h[prog.symbols[prefix + name.lower() + "4"]] = mk(lambda x, fn=fn: t64(fn, x), 4, 4)
     h[prog.symbols[prefix + "atan2"]] = mk(lambda y, x: t64("atan2f", y, x), 2)
     h[prog.symbols[prefix + "mod"]] = mk(rem_euclid, 2)
     return h

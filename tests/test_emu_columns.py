@@ -62,8 +62,8 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     a_st = mem.map(st.b)
     ka = col_kernarg(a_st, in_kind, mat)
     trans = kernel == "fh_columns_t"
-    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=218 if trans else 128,
-                     hooks=U.trans_hooks(U.program(), v_base=192) if trans else None)
+    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=256 if trans else 128,
+                     hooks=U.trans_hooks(U.program(), v_base=192, window=64) if trans else None)
     return zbuf, waves
 
 
