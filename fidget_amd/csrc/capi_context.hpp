@@ -1,0 +1,152 @@
+// Fragment of capi.hip (contexts and their options); not a stand-alone header: included by capi.hip only.
+// ---- context ---------------------------------------------------------------------------
+fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
+    if (!out) return FHIP_ERR_BAD_TAPE;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return FHIP_ERR_HIP;
+    fhip_ctx* c = new fhip_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    options_from_env(c->opt);
+    apply_options(c);
+    // allow the full 160 KiB of LDS for the interpreters' register files
+    const void* fns[] = {(const void*)k_eval_f32<false>, (const void*)k_eval_interval<false>, (const void*)k_eval_grad<false>,
+                         (const void*)k_tiles<false, false, true, 16>, (const void*)k_tiles<false, true, true, 16>,
+                         (const void*)k_tiles<true, false, true, 16>, (const void*)k_tiles<true, true, true, 16>,
+                         (const void*)k_tiles<false, false, true, 64>, (const void*)k_tiles<false, true, true, 64>,
+                         (const void*)k_tiles<true, false, true, 64>, (const void*)k_tiles<true, true, true, 64>,
+                         (const void*)k_pixels2d<0, false>, (const void*)k_pixels2d<0, true>,
+                         (const void*)k_leaves3d<2, 0, 1, false>, (const void*)k_leaves3d<2, 0, 1, true>,
+                         (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    if (hipModuleLoadData(&c->asm_mod, fh_interp_co) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    for (int i = 0; i < FH_ASM_COUNT; i++)
+        if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES_T], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    (void)hipGetLastError();
+    {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    }
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_l0, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
+    if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    for (auto& o : c->others) (void)hipEventCreateWithFlags(&o.ev_done, hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int pp = c->opt.pre_priority;
+        const hipError_t e = pp == 0 ? hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking)
+                                     : hipStreamCreateWithPriority(&c->stream_pre, hipStreamNonBlocking, pp == 1 ? lo : hi);
+        if (e != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    }
+    if (c->sticky.ensure(256) != hipSuccess || hipMemset(c->sticky.p, 0, 256) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
+    for (int i = 0; i < FH_MAX_SLABS; i++) {
+        (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_leaves[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming);
+    }
+    (void)hipFuncSetAttribute((const void*)k_prune2, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    {
+        const void* fb[] = {(const void*)k_teval3d<false, true>, (const void*)k_teval3d<true, true>};
+        for (const void* f : fb) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+    }
+    *out = c;
+    return FHIP_OK;
+}
+void fhip_ctx_destroy(fhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->tmp_out, &c->io_a, &c->io_b, &c->io_c, &c->io_d, &c->io_e, &c->sticky};
+    for (DevBuf* b : bufs) b->release();
+    c->release_all();
+    for (auto& o : c->others) o.release_all();
+    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
+    if (c->stream_leaf2) { (void)hipStreamSynchronize(c->stream_leaf2); (void)hipStreamDestroy(c->stream_leaf2); }
+    if (c->ev_rest_fork) (void)hipEventDestroy(c->ev_rest_fork);
+    if (c->ev_rest_join) (void)hipEventDestroy(c->ev_rest_join);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_l0) (void)hipEventDestroy(c->ev_l0);
+    for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
+    if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
+    mesh_cache_release(c->mesh_octree_cache);
+    free(c->mesh_first);
+    if (c->asm_mod) (void)hipModuleUnload(c->asm_mod);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+    for (hipEvent_t e : c->ev_aux) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_tiles) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_leaves) (void)hipEventDestroy(e);
+    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (auto& e : c->asm_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    delete c;
+}
+const char* fhip_last_error(const fhip_ctx* c) { return c ? c->err.c_str() : "no context"; }
+// Waits for everything queued on the context.  An asynchronous render (out_is_device) cannot report what only the
+// device knows when it returns: its queue-overflow flag (the queues are sized to exact upper bounds, so this would be
+// a bug, not a condition) is read here.
+fhip_status fhip_ctx_sync(fhip_ctx* c) {
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fhip_status st = FHIP_OK;
+    for (auto& o : c->others)
+        if (o.async_pending) {      // the frames before the last one (frame pipelining): same check, then back to the last frame's set
+            std::swap(static_cast<FrameBufs&>(*c), o);
+            c->async_pending = false;
+            const fhip_status s1 = finish_render(c);
+            if (st == FHIP_OK) st = s1;
+            std::swap(static_cast<FrameBufs&>(*c), o);
+        }
+    if (c->async_pending) {
+        c->async_pending = false;
+        const fhip_status s2 = finish_render(c);
+        if (st == FHIP_OK) st = s2;
+    }
+    // frames older than the last two (their buffer sets have been re-used since): the flag every frame's last kernel latches
+    uint32_t sticky = 0;
+    HIP_TRY(c, hipMemcpy(&sticky, c->sticky.p, 4, hipMemcpyDeviceToHost));
+    if (sticky) {
+        HIP_TRY(c, hipMemset(c->sticky.p, 0, 4));
+        if (st == FHIP_OK) st = fail(c, FHIP_ERR_OVERFLOW, "device work queue overflow in an earlier asynchronous frame");
+    }
+    return st;
+}
+void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
+void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
+// Behaviour switches (FH_OPTION_LIST above).  Waits for the frames in flight first: a switch never changes under a frame.
+fhip_status fhip_ctx_set_option(fhip_ctx* c, const char* name, int value) {
+    if (!c || !name) return FHIP_ERR_UNSUPPORTED;
+    if (!strcmp(name, "leaf_streams") || !strcmp(name, "pre_priority")) return fail(c, FHIP_ERR_UNSUPPORTED, std::string(name) + " is fixed when the context is created");
+    for (const FhOptionEntry& e : FH_OPTION_TABLE)
+        if (!strcmp(e.name, name)) {
+            if (c->opt.*(e.field) == value) return FHIP_OK;
+            const fhip_status st = fhip_ctx_sync(c);
+            c->opt.*(e.field) = value;
+            apply_options(c);
+            return st;
+        }
+    return fail(c, FHIP_ERR_UNSUPPORTED, std::string("unknown option ") + name);
+}
+fhip_status fhip_ctx_get_option(const fhip_ctx* c, const char* name, int* value) {
+    if (!c || !name || !value) return FHIP_ERR_UNSUPPORTED;
+    for (const FhOptionEntry& e : FH_OPTION_TABLE)
+        if (!strcmp(e.name, name)) { *value = c->opt.*(e.field); return FHIP_OK; }
+    return FHIP_ERR_UNSUPPORTED;
+}

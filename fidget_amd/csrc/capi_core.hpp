@@ -1,0 +1,198 @@
+// Fragment of capi.hip (context, device buffers, error plumbing, kernel launch helpers: everything the sections of the C ABI share (before `extern "C"`)); not a stand-alone header: included by capi.hip only.
+// ----------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+static std::atomic<uint64_t> g_tape_serial{1};
+struct fhip_tape {
+    const uint64_t serial = g_tape_serial.fetch_add(1);   // identity for "these tapes are already in the arena"
+    fh::HostTape t;
+    mutable uint64_t* d_ops = nullptr;  // uploaded on first device use (tape construction is host-only)
+    // tape parallelism (host_graph.hpp split_root): when the root is a min / max of many parts, the
+    // same function as `groups.size()` independent tapes whose outputs combine with `group_op`
+    std::vector<fh::HostTape> groups;
+    int group_op = -1;
+    // ... and the renderer's form of it (plan_terms): groups that output the root tree's terms, the
+    // tree as a small program over them, and where every choice of the full tape is recorded
+    fh::TermPlan plan;
+    std::vector<fh::HostTape> tgroups;
+    mutable FhTopOp* d_top = nullptr;
+    mutable uint32_t* d_chsrc = nullptr;
+    mutable uint64_t* d_links = nullptr;   // links of the full tape (host_graph.hpp compute_links) for the linked prune, when it qualifies
+    mutable uint64_t* d_ctab = nullptr;    // ... and per choice its op's operands and index
+    mutable bool links_tried = false;
+    // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
+    // reference's workers): its lazily created device copies are made under this lock, on the device of the first
+    // context that needs them (HIP allocations are visible to every device of the process with peer access; a tape
+    // used from several devices should be built per device)
+    mutable std::mutex upload_lock;
+    mutable int device = -1;
+};
+struct fhip_graph {
+    fh::Graph g;
+};
+
+// The assembly interpreters (gen_interp.py -> interp_gfx950.co), embedded at build time
+#ifndef __HIP_DEVICE_COMPILE__
+__asm__(".section .rodata\n.global fh_interp_co\n.p2align 6\nfh_interp_co:\n.incbin \"" FH_INTERP_CO "\"\n.previous\n");
+#endif
+extern "C" const char fh_interp_co[];
+enum { FH_ASM_COLUMNS = 0, FH_ASM_FLOAT_16x4, FH_ASM_FLOAT_32x2, FH_ASM_TILES, FH_ASM_PRUNE1, FH_ASM_TILES_V32, FH_ASM_TILES_V64, FH_ASM_PROBE, FH_ASM_UBENCH, FH_ASM_COLUMNS_T, FH_ASM_NORMALS, FH_ASM_NORMALS_T, FH_ASM_TILES_T, FH_ASM_TILES_V32_T, FH_ASM_TILES_V64_T, FH_ASM_FLOAT_16x4_T, FH_ASM_FLOAT_32x2_T, FH_ASM_COUNT };
+static const char* const FH_ASM_NAMES[FH_ASM_COUNT] = {"fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1",
+                                                       "fh_tiles_v32", "fh_tiles_v64", "fh_probe", "fh_ubench", "fh_columns_t", "fh_normals", "fh_normals_t", "fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t", "fh_float_eval_16x4_t", "fh_float_eval_32x2_t"};
+// register-file shapes of the VGPR tile kernels (gen_tilesv.py): registers, choices
+static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOICES = 512;
+
+// Behaviour switches of a context - diagnostics and tuning, none is needed in normal use.  They are part of the context, not of
+// the process: read ONCE from the environment when the context is created (FHIP_<NAME IN CAPITALS>, for runs of unmodified
+// programs under a switch) and changed afterwards only through fhip_ctx_set_option(ctx, "<name>", value) - nothing in a
+// render's launch path looks at the environment.  name, default; DESIGN.md section 5 says what each one selects.
+#define FH_OPTION_LIST(X)                                                                                                       \
+    X(no_asm, 0) X(no_split, 0) X(probe, 0) X(no_pipeline, 0) X(slab_contexts, 4) X(no_frame_pipeline, 0) X(arena_mb, 4096)     \
+    X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
+    X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
+    X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    /* fixed when the context is created (they decide which streams exist): environment only */                                 \
+    X(leaf_streams, 1) X(pre_priority, 0)
+struct FhOptions {
+#define X(name, dflt) int name = dflt;
+    FH_OPTION_LIST(X)
+#undef X
+};
+struct FhOptionEntry { const char* name; int FhOptions::*field; };
+static const FhOptionEntry FH_OPTION_TABLE[] = {
+#define X(name, dflt) {#name, &FhOptions::name},
+    FH_OPTION_LIST(X)
+#undef X
+};
+static void options_from_env(FhOptions& o) {
+    for (const FhOptionEntry& e : FH_OPTION_TABLE) {
+        std::string var = "FHIP_";
+        for (const char* c = e.name; *c; c++) var += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(var.c_str())) o.*(e.field) = *v ? atoi(v) : 1;    // (set but empty counts as 1)
+    }
+}
+
+// Everything one frame of a render owns on the device.  A context holds two sets: an asynchronous 3D render takes the set
+// the previous frame did not use, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
+// run on a stream of their own beside the previous frame's slabs (frame pipelining, FHIP_NO_FRAME_PIPELINE=1 turns it off).
+struct FrameBufs {
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch;
+    DevBuf queue[FH_MAX_LEVELS];
+    uint32_t frame_stamp = 0;       // FhRenderState::frame_stamp of the last frame prepared
+    uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
+    uint32_t resident_groups = 0;
+    uint32_t forked = 0;            // slab contexts of the last 3D frame of this set (0: not pipelined)
+    bool async_pending = false;     // the last render of this set left its result on the device: its overflow flags have not been read yet
+    hipEvent_t ev_done = nullptr;   // recorded when the last frame of this set has been queued completely
+    bool ev_done_valid = false;
+    void release_all() {
+        DevBuf* bufs[] = {&state, &arena, &leaves, &leaf_table, &zbuf, &normals, &fp_lists, &mind, &squeue, &slots[0], &slots[1],
+                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr, &gscratch};
+        for (DevBuf* b : bufs) b->release();
+        for (auto& q : queue) q.release();
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        ev_done = nullptr;
+    }
+};
+struct fhip_ctx : FrameBufs {
+    FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
+    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of 1 + FH_EXTRA_SETS).  Three
+    // sets: one frame alone takes ~1.5 ms from its first coarse-level kernel to its image, so with two sets - a set is free
+    // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way (a fourth set: measured, no gain)
+#define FH_EXTRA_SETS 2
+    FrameBufs others[FH_EXTRA_SETS];
+    uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
+    bool frame_pipeline = true;
+    hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
+    hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
+    hipEvent_t ev_rest_fork = nullptr, ev_rest_join = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_l0 = nullptr;
+    hipModule_t asm_mod = nullptr;
+    hipFunction_t asm_fn[FH_ASM_COUNT] = {};
+    bool use_asm = true;  // FHIP_NO_ASM=1 keeps everything on the C++ kernels (diagnostics)
+    bool probe = false;     // FHIP_PROBE=1: per-phase clocks in fh_tiles (slows it down; tools/wave_stats.py)
+    bool use_split = true;  // FHIP_NO_SPLIT=1: monolithic k_tiles for the 3D tile stage (diagnostics)
+    // 3D: the tile stage of slab k+1 runs on a second stream while slab k's leaves are evaluated
+    bool use_pipeline = true;  // FHIP_NO_PIPELINE=1 serialises the slabs on one stream (diagnostics)
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    std::vector<hipEvent_t> ev_tiles, ev_leaves, ev_aux;
+    hipEvent_t ev_fork = nullptr;
+    FhRenderState last_state_b;
+    uint32_t slab_contexts = 4;   // FHIP_SLAB_CONTEXTS (2 .. 4): how far the tile chain may run ahead of the leaf chain (measured: 2.03 / 1.60 / 1.55 ms per frame with 2 / 3 / 4)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    std::string err;
+    bool launch_failed = false;     // an assembly kernel launch of the current frame failed (reported when the frame has been queued)
+    std::atomic<int> cancelled{0};
+    DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
+    DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
+    struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[8];   // pinned (upload_frame)
+    void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
+    size_t mesh_pinned_cap = 0;
+    // ... and the two largest host-side temporaries of the assembly, kept for the same reason (fresh memory of that size is
+    // faulted in page by page and handed back page by page): the octree's cell / vertex arrays and the dual walk's first-use table
+    void* mesh_octree_cache = nullptr;       // fhmesh::Octree*
+    uint32_t* mesh_first = nullptr;
+    size_t mesh_first_cap = 0;
+    uint32_t staging_next = 0;
+    size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
+    bool profiling = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> asm_events;   // ... and per assembly kernel launch
+    FhRenderState last_state;
+    bool have_last_state = false;
+};
+
+// The cached forms of some options (what the rest of the driver reads)
+static void apply_options(fhip_ctx* c) {
+    c->use_asm = c->opt.no_asm == 0;
+    c->use_split = c->opt.no_split == 0;
+    c->probe = c->opt.probe != 0;
+    c->use_pipeline = c->opt.no_pipeline == 0;
+    c->frame_pipeline = c->opt.no_frame_pipeline == 0;
+    c->slab_contexts = (uint32_t)std::min(4, std::max(2, c->opt.slab_contexts));
+    c->arena_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
+    c->extra_sets = (uint32_t)std::min(FH_EXTRA_SETS, std::max(1, c->opt.frame_sets - 1));
+}
+
+static fhip_status finish_render(fhip_ctx* ctx);
+static void mesh_cache_release(void* octree);      // (defined with the mesh code)
+static fhip_status fail(fhip_ctx* ctx, fhip_status s, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return s;
+}
+#define HIP_TRY(ctx, call)                                                                                       \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+template <class F>
+static void launch(fhip_ctx* ctx, int klass, F&& f) {
+    if (ctx->profiling) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, ctx->stream);
+        f();
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->prof_events.push_back({klass, {a, b}});
+    } else {
+        f();
+    }
+}

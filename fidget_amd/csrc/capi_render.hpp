@@ -1,0 +1,1027 @@
+// Fragment of capi.hip (the 2D / 3D tile renderers: frame set-up, the coarse levels, slabs, streams and frame pipelining); not a stand-alone header: included by capi.hip only.
+// ---- renders ---------------------------------------------------------------------------
+static const uint32_t VM_TILES_2D[] = {128, 32, 8};        // fidget-core/src/vm/mod.rs:255-257
+static const uint32_t VM_TILES_3D[] = {128, 64, 32, 16, 8};  // fidget-core/src/vm/mod.rs:251-253
+// RenderHints of the HIP shape (the reference lets every shape type pick its own, shape.rs RenderHints):
+// a fan-out of 4^3 = 64 children fills a wavefront
+// (128 -> 32 -> 8).  The root tile stays the one the reference's VmShape hints give for the image
+// size, so that exactly the same voxels are covered (a root tile overhanging the image in z is
+// evaluated there by the reference too).
+
+struct RenderSetup {
+    FhRenderState S;
+    std::vector<FhGroup> roots;
+    uint32_t n_slabs = 1, n_layers = 1;      // z-slabs (steps of the per-slab chains), root-tile layers
+    uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
+    size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
+    uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
+    size_t mind_words = 0;      // words of the min-depth pyramid (cleared at the head of the frame)
+    uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
+    bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
+    bool asm_points = false;  // leaf stage on the assembly interpreters
+    bool asm_points_t = false;  // ... on fh_columns_t (tapes with transcendental / modulo / rng opcodes)
+    bool asm_normals = false;   // normals by the assembly gradient interpreter fh_normals (gen_normals.py): footprints of leaves of <= 32 registers
+    bool split = false;       // 3D tile stage as setup / evaluate+prune / push kernels
+    bool asm_tiles = false;   // ... with the evaluate+prune step in assembly (fh_tiles)
+    bool asm_tiles_t = false; // ... by the *_t variants (transcendental opcodes)
+    uint32_t group_regs = 0, group_choices = 0;  // bounds over the tape's groups
+    size_t lds_tiles_group = 0;
+    bool groups = false;      // ... and level 0 evaluated as the tape's independent groups (tape parallelism)
+    bool prune1 = false;      // ... and, on the first exp_levels levels, the prune as one wave per child (fh_prune1)
+    bool prune2 = false;      // ... by the linked prune (prune2.hip k_prune2: visits only the ops a child keeps) where the tape qualifies
+    const uint64_t* d_links = nullptr;
+    const uint64_t* d_ctab = nullptr;
+    size_t lds_prune2 = 0;
+    bool prune2_l1 = false;   // ... and level 1 by the same kernel, on the links the level-0 launch leaves in front of every child tape (option
+                              // prune2_l1, off: fh_tiles_v64's forward pass alone takes 0.13 ms of its 0.39, but one wave per 32^3 child - 6 120 of them,
+                              // 2 to a SIMD, each bound by scalar issue - takes 0.75 ms where the lockstep sweep takes 0.26; profiles/r03o)
+    size_t lds_prune2_l1 = 0;
+    uint32_t exp_levels = 0;
+    uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
+    bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
+    bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
+    uint32_t hbm_waves = 0;
+};
+
+static fhip_status bind_inputs(fhip_ctx* ctx, const fhip_tape* tape, const int32_t* axis_slots, const uint64_t* keys,
+                               const float* vals, uint32_t n, FhRender& P) {
+    const fh::HostTape& t = tape->t;
+    std::vector<char> bound(FH_MAX_INPUTS, 0);
+    for (uint32_t s = 0; s < FH_MAX_INPUTS; s++) { P.in_kind[s] = 3; P.in_value[s] = 0.0f; }
+    for (int a = 0; a < 3; a++) {
+        const int s = axis_slots ? axis_slots[a] : t.vars.axis[a];
+        if (s >= 0 && s < FH_MAX_INPUTS) { P.in_kind[s] = (uint32_t)a; bound[s] = 1; }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        // graph-built tapes: keys are Var::V indices; bytecode tapes (axis_slots given): keys are slots
+        const int s = axis_slots ? (int)keys[i] : t.vars.slot_of(3, keys[i]);
+        if (s >= 0 && s < FH_MAX_INPUTS) { P.in_value[s] = vals[i]; bound[s] = 1; }
+    }
+    for (uint32_t s = 0; s < t.n_vars; s++)
+        if (!bound[s]) return fail(ctx, FHIP_ERR_MISSING_VAR, "a variable of the shape has no value");
+    return FHIP_OK;
+}
+
+// fidget-raster/src/lib.rs:59-66
+static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint32_t max_size) {
+    uint32_t i = n;
+    for (uint32_t k = 0; k < n; k++) if (tiles[k] < max_size) { i = k; break; }
+    i = i ? i - 1 : 0;
+    return std::vector<uint32_t>(tiles + i, tiles + n);
+}
+
+static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size, bool vm_tiles) {
+    std::vector<uint32_t> v = trim_tiles(VM_TILES_3D, 5, max_size);
+    if (vm_tiles) return v;  // diagnostics: the reference's own subdivision
+    std::vector<uint32_t> out{v[0]};
+    for (uint32_t t = v[0]; t > 8;) { t = std::max<uint32_t>(t / 4, 8); out.push_back(t); }
+    return out;
+}
+
+// 2D hint of the HIP shape: 128 -> 16 with 16 x 16 pixel leaves - what fidget-jit uses (fidget-jit/src/lib.rs:984-986); a fan-out
+// of 64 children per parent fills a wavefront of the tile-stage kernels (the VM's 128 / 32 / 8 fans out by 16)
+static const uint32_t HIP_TILES_2D[] = {128, 16};
+static bool tape_is_full(const fh::HostTape& t) {
+    for (uint64_t w : t.ops) {
+        const uint32_t op = FH_W_OP((uint32_t)w);
+        if ((op >= FH_SIN && op <= FH_LN) || op == FH_ATAN2_RR || op == FH_ATAN2_RI || op == FH_ATAN2_IR ||
+            op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR)
+            return true;
+    }
+    return false;
+}
+
+// medium LDS layout of the tile stage (pre-pass levels below the root): 48 KB, three waves per CU
+static const uint32_t MID_REGS = 64, MID_CHOICES = 768;
+static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {
+    size_t b = (size_t)regs * TL * 8 + (size_t)((choices + 15) / 16) * TL * 4 + (size_t)regs * TL + 256;
+    return (b + 15) & ~(size_t)15;
+}
+
+// Which part of the volume a render covers (multi-GPU): root-tile columns round robin (index % n_shards == shard, full
+// depth), or a block of an nx x ny x nz split of the root-tile grid and of the z-slabs (octants: 2 x 2 x 2)
+struct PartSpec {
+    uint32_t shard = 0, n_shards = 1;
+    uint32_t ix = 0, nx = 1, iy = 0, ny = 1, iz = 0, nz = 1;
+};
+static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
+                           const PartSpec& part, RenderSetup& R) {
+    const uint32_t shard = part.shard, n_shards = part.n_shards;
+    FhRenderState& S = R.S;
+    FhRender& P = S.P;
+    const fh::HostTape& t = tape->t;
+    if (t.n_outputs != 1) return fail(ctx, FHIP_ERR_BAD_TAPE, "shape tapes have exactly one output");
+    if (ts.empty() || ts.size() > FH_MAX_LEVELS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "1..8 tile levels supported");
+    P.n_levels = (uint32_t)ts.size();
+    uint32_t fanout = 1;
+    for (size_t i = 0; i < ts.size(); i++) {
+        P.tiles[i] = ts[i];
+        if (i) {
+            if (ts[i - 1] <= ts[i] || ts[i - 1] % ts[i]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad tile size list");
+            const uint32_t n = ts[i - 1] / ts[i];
+            fanout = std::max(fanout, is3d ? n * n * n : n * n);
+        }
+    }
+    if (fanout > 64) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 64 children");
+    const uint32_t TL = R.tl = fanout > 16 ? 64 : 16;
+    if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
+    // (register numbers are 12-bit fields of a tape word.  The device prunes keep old -> new register maps in bytes with 0xFF =
+    // dead: a CHILD tape has 255 registers at most - one that would need more keeps its parent's tape; the root tape may have
+    // more, its register file then lives in HBM: gscratch below)
+    if (t.n_regs >= FH_MAX_REGS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support up to 4095 registers");
+    if (t.ops.size() >= (1u << 24)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "renders support tapes of up to 2^24 ops");   // (FhLeafRef packs length | registers << 24)
+    P.max_regs = std::max<uint32_t>(t.n_regs, 1);
+    P.max_choices = t.n_choices;
+    P.roots_x = (P.width + ts[0] - 1) / ts[0];
+    P.roots_y = (P.height + ts[0] - 1) / ts[0];
+    // z-slabs: the per-slab chains (tile stage, leaf kernel, tail) take `slab_layers` root-tile layers per step when the coarse
+    // levels are evaluated for the whole volume up front (the length of the tile chain is its number of steps: every step's
+    // launches leave most of the machine idle); one layer per step otherwise
+    const uint32_t n_layers = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
+    const bool prepass_ok = is3d && ts.size() >= 3 && n_layers <= FH_MAX_SLABS;
+    uint32_t SL = prepass_ok ? (uint32_t)std::max(1, std::min(8, ctx->opt.slab_layers)) : 1u;
+    // (the leaf table: <= 64 eight-voxel layers per slab; at least two slabs, so that the tile stage of one still runs beside the
+    // leaf kernel of the other - bear.vm at 512^3, four layers: 3.68 ms per frame as two slabs, 3.77 as one)
+    while (SL > 1 && (ts[0] * SL / 8 > 64 || SL * 2 > n_layers)) SL >>= 1;
+    P.slab = ts[0] * SL;
+    R.n_slabs = is3d ? (P.depth + P.slab - 1) / P.slab : 1;
+    R.n_layers = n_layers;
+    R.full = tape_is_full(t);
+    // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
+    R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
+    R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
+    // (fh_normals_t has the transcendental, rng and atan2 handlers; a modulo's gradient - div_euclid - keeps the C++ kernel)
+    R.asm_normals = R.asm_points && !ctx->opt.no_asm_normals && (!R.asm_points_t || !tape_has_mod(t));
+
+    // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
+    R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
+    R.lds_tiles_small = tiles_lds(SMALL_REGS, SMALL_CHOICES, TL);
+    R.lds_tiles_mid = tiles_lds(MID_REGS, MID_CHOICES, TL);
+    R.lds_points_big = (size_t)P.max_regs * WAVE * 4;
+    R.lds_normals_big = (size_t)P.max_regs * WAVE * 16;
+    R.lds_normals_small = (size_t)32 * WAVE * 16;
+    // A register file that does not fit LDS (more than ~160 registers for the gradients, ~280 for the intervals) lives in HBM:
+    // the reference spills registers beyond its file to memory slots (compiler/alloc.rs:116-125), this is the device's form of
+    // it - the root-sized kernel variants take a region of `gscratch` per workgroup instead of LDS.  A slow path by design
+    // (a few hundred workgroups, no pipelining: render3d_part), for tapes the fast paths cannot take anyway.
+    S.gscratch = nullptr; S.gscratch_stride = 0;
+    R.big_hbm = R.lds_tiles_big > FH_LDS_MAX || R.lds_normals_big > FH_LDS_MAX || R.lds_points_big > FH_LDS_MAX;
+    if (R.big_hbm) {
+        const size_t stride = (std::max(std::max(R.lds_tiles_big, R.lds_normals_big), R.lds_points_big) + 255) & ~(size_t)255;
+        if (stride >= ((size_t)1 << 31)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "register file too large");
+        R.hbm_waves = (uint32_t)std::max<size_t>(64, std::min<size_t>((size_t)ctx->n_cu * 4, ((size_t)1 << 30) / stride));
+        HIP_TRY(ctx, ctx->gscratch.ensure((size_t)R.hbm_waves * stride));
+        S.gscratch = (char*)ctx->gscratch.p; S.gscratch_stride = (uint32_t)stride;
+        R.lds_tiles_big = R.lds_normals_big = R.lds_points_big = 0;      // (no dynamic LDS for those launches; grids: blocks_big)
+    }
+
+    // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
+    S.n_slabs = R.n_slabs;
+    S.frame_stamp = ++ctx->frame_stamp;
+    S.pre_levels = prepass_ok ? 2 : 0;
+
+    // root-tile layers of this part: layer k of the block split belongs to iz = k * nz / n_layers (iz = nz - 1: the front);
+    // its z-slabs are those that hold one of its layers (a slab shared with another part has work for this part's layers only)
+    uint32_t layer_lo = 0, layer_hi = n_layers;
+    if (part.nz > 1) {
+        layer_lo = n_layers; layer_hi = 0;
+        for (uint32_t k = 0; k < n_layers; k++)
+            if ((uint64_t)k * part.nz / n_layers == part.iz) { layer_lo = std::min(layer_lo, k); layer_hi = std::max(layer_hi, k + 1); }
+        if (layer_lo >= layer_hi) layer_lo = layer_hi = 0;   // more parts than layers: nothing to do
+    }
+    R.slab_lo = layer_lo / SL; R.slab_hi = (layer_hi + SL - 1) / SL;
+    if (!S.pre_levels) { R.slab_lo = layer_lo; R.slab_hi = layer_hi; }
+    // root groups: runs of <= TL root tiles of this part, index = first + lane * stride (one set per slab in pre-pass mode)
+    struct Run { uint32_t first, n, stride; };
+    std::vector<Run> runs;
+    if (part.nx > 1 || part.ny > 1) {       // a block of root-tile columns: per x, the run of its y range (x-major numbering)
+        for (uint32_t tx = 0; tx < P.roots_x; tx++) {
+            if ((uint64_t)tx * part.nx / P.roots_x != part.ix) continue;
+            uint32_t y0 = P.roots_y, y1 = 0;
+            for (uint32_t ty = 0; ty < P.roots_y; ty++)
+                if ((uint64_t)ty * part.ny / P.roots_y == part.iy) { y0 = std::min(y0, ty); y1 = std::max(y1, ty + 1); }
+            for (uint32_t ty = y0; ty < y1; ty += TL) runs.push_back(Run{tx * P.roots_y + ty, std::min<uint32_t>(TL, y1 - ty), 1});
+        }
+    } else {
+        std::vector<uint32_t> mine;
+        for (uint32_t ri = shard; ri < P.roots_x * P.roots_y; ri += n_shards) mine.push_back(ri);
+        for (size_t i = 0; i < mine.size(); i += TL) runs.push_back(Run{mine[i], (uint32_t)std::min<size_t>(TL, mine.size() - i), n_shards});
+    }
+    FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
+    const uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
+    for (uint32_t k = 0; k < q0_layers; k++)
+        for (const Run& r : runs) {
+            FhGroup g{};
+            g.tape = root;
+            g.first = r.first; g.n = r.n; g.stride = r.stride;
+            g.z = (layer_hi - 1 - k) * ts[0];  // front layers first
+            R.roots.push_back(g);
+        }
+    R.groups_per_slab = (uint32_t)(R.roots.size() / std::max<uint32_t>(q0_layers, 1));
+    if (layer_lo >= layer_hi) { R.roots.clear(); R.groups_per_slab = 0; }
+
+    // capacities (exact upper bounds): queue[l] holds the tiles of size ts[l-1] that can be
+    // ambiguous, per slab for the per-slab levels and for the whole volume for pre-pass levels
+    uint32_t qcaps[FH_MAX_LEVELS] = {0};
+    qcaps[0] = std::max<uint32_t>((uint32_t)R.roots.size(), 1);
+    for (size_t l = 1; l < ts.size(); l++) {
+        const uint64_t tp = ts[l - 1];
+        uint64_t c = (uint64_t)((P.width + tp - 1) / tp) * ((P.height + tp - 1) / tp) * (is3d ? P.slab / tp : 1);
+        if (l < S.pre_levels) c *= R.n_slabs;
+        qcaps[l] = (uint32_t)std::max<uint64_t>(c, 1);
+    }
+    const uint64_t tl = ts.back();
+    const uint64_t fw = (P.width + tl - 1) / tl, fhh = (P.height + tl - 1) / tl;
+    const uint64_t leaf_cap = fw * fhh * (is3d ? P.slab / tl : 1);
+    R.table_words = is3d ? (uint32_t)leaf_cap : 0;
+    R.n_footprints = (uint32_t)(fw * fhh);
+
+    HIP_TRY(ctx, ctx->state.ensure(4 * sizeof(FhRenderState)));
+    { void* const before = ctx->arena.p; HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes)); if (ctx->arena.p != before) ctx->resident_serial = 0; }
+    for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
+    if (S.pre_levels) HIP_TRY(ctx, ctx->squeue.ensure((size_t)qcaps[S.pre_levels] * R.n_slabs * sizeof(FhGroup)));
+    HIP_TRY(ctx, ctx->leaves.ensure(leaf_cap * sizeof(FhLeaf)));
+    const size_t extra = std::min<uint32_t>(ctx->slab_contexts, std::max<uint32_t>(R.n_slabs, 1)) - 1;      // (slab contexts beyond the first)
+    if (is3d) HIP_TRY(ctx, ctx->leaves_b.ensure(extra * leaf_cap * sizeof(FhLeaf)));
+    if (is3d) {
+        if (P.width > 65535 || P.height > 65535) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images up to 65535 x 65535");
+        // (the assembly leaf and normals kernels address the z-buffer as base + a 32-bit byte offset of 8 bytes per pixel)
+        if ((uint64_t)P.width * P.height >= ((uint64_t)1 << 29)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D renders support images of fewer than 2^29 pixels");
+        HIP_TRY(ctx, ctx->leaf_table.ensure(leaf_cap * sizeof(FhLeafRef)));
+        HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * sizeof(FhLeafRef)));
+        HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
+        HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
+        HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
+        HIP_TRY(ctx, ctx->fp_lists_b.ensure(extra * (size_t)R.n_footprints * 4 * 3));
+        size_t mind_words = 0;
+        for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
+        HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
+        R.mind_words = mind_words;   // (cleared - empty image: nothing occluded - by the frame's first launch, upload_frame)
+        uint32_t* mp = (uint32_t*)ctx->mind.p;
+        for (size_t l = 0; l < ts.size(); l++) {
+            S.mind[l] = mp;
+            mp += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
+        }
+        for (int c = 0; c < 3; c++) S.fp_list[c] = (uint32_t*)ctx->fp_lists.p + (size_t)c * R.n_footprints;
+    }
+    S.arena = (uint64_t*)ctx->arena.p;
+    S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 64, 0x7FFFFFE0u);  // slack: the interpreters prefetch up to 12 ops past a tape's end
+    S.arena_head = S.arena_root_end = (uint32_t)t.ops.size();
+    S.arena_overflow = 0;
+    for (int l = 0; l < FH_MAX_LEVELS; l++) {
+        S.queue[l] = (FhGroup*)ctx->queue[l].p;
+        S.count[l] = S.cursor[l] = S.count_big[l] = S.cursor_big[l] = 0;
+    }
+    S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
+    for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
+    R.split = ctx->use_split && R.tl == 64 && (is3d || !ctx->opt.no_split_2d);
+    // (tapes with sin cos tan asin acos atan exp ln: the *_t variants of the tile kernels, which carry those interval handlers;
+    // atan2, mod, mix, rand keep the HIP tile stage)
+    R.asm_tiles_t = !tape_asm_ok(t) && tape_tiles_t_ok(t) && !ctx->opt.no_asm_tiles_t;
+    // (not with a register file in HBM: the assembly tile kernels - fh_prune1, the groups path and the linked prune with them - keep
+    // registers AND choices in LDS, and a tape of few registers can still outgrow it by its choices alone, ~5 600 of them)
+    R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && (tape_asm_ok(t) || R.asm_tiles_t) && t.n_regs <= 128 && !R.big_hbm;
+    R.asm_tiles_t = R.asm_tiles_t && R.asm_tiles;
+    // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
+    // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
+    {
+        const uint32_t p1_levels = (uint32_t)std::max(0, ctx->opt.prune1_levels);
+        R.exp_levels = is3d ? std::min(S.pre_levels, p1_levels) : std::min(1u, p1_levels);
+    }
+    R.prune1 = R.asm_tiles && !R.asm_tiles_t && R.exp_levels > 0 && !ctx->opt.no_prune1;      // (the *_t kernels have no export mode)
+    // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
+    // waves, then the tree itself; the prune sees the root tape with its usual choices
+    R.groups = R.prune1 && !tape->tgroups.empty() && !ctx->opt.no_tape_groups;
+    S.n_tgroups = 0;
+    if (R.groups) {
+        uint32_t off = (uint32_t)t.ops.size() + 16, mr = 1, mc = 0;
+        for (size_t g = 0; g < tape->tgroups.size(); g++) {
+            const fh::HostTape& gt = tape->tgroups[g];
+            S.tgroup[g] = FhTapeRef{off, (uint32_t)gt.ops.size(), (uint16_t)gt.n_regs, (uint16_t)gt.n_choices};
+            off += (uint32_t)gt.ops.size() + 16;  // slack: the interpreters prefetch past a tape's end
+            mr = std::max(mr, gt.n_regs); mc = std::max(mc, gt.n_choices);
+        }
+        R.group_regs = mr; R.group_choices = mc;
+        R.lds_tiles_group = tiles_lds(mr, mc, TL);
+        if (mr <= 128 && R.lds_tiles_group <= FH_LDS_MAX && (size_t)off * 8 + 4096 <= ctx->arena_bytes) {
+            S.n_tgroups = (uint32_t)tape->tgroups.size();
+            S.n_terms = tape->plan.n_terms; S.n_top = (uint32_t)tape->plan.top.size(); S.top_chain = tape->plan.chain ? 1 : 0;
+            S.troot_len = (uint32_t)t.ops.size(); S.troot_choices = t.n_choices; S.troot_regs = std::max<uint32_t>(t.n_regs, 1);
+            S.arena_head = S.arena_root_end = off;
+            std::lock_guard<std::mutex> guard(tape->upload_lock);
+            if (tape->device >= 0 && tape->device != ctx->device) return fail(ctx, FHIP_ERR_UNSUPPORTED, "this tape's device copies belong to another device: build the tape per device");
+            tape->device = ctx->device;
+            if (!tape->d_top) {
+                static_assert(sizeof(FhTopOp) == sizeof(fh::TopOp), "top op layout");
+                HIP_TRY(ctx, hipMalloc((void**)&tape->d_top, tape->plan.top.size() * sizeof(FhTopOp)));
+                HIP_TRY(ctx, hipMemcpy(tape->d_top, tape->plan.top.data(), tape->plan.top.size() * sizeof(FhTopOp), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMalloc((void**)&tape->d_chsrc, std::max<size_t>(tape->plan.choice_src.size(), 1) * 4));
+                HIP_TRY(ctx, hipMemcpy(tape->d_chsrc, tape->plan.choice_src.data(), tape->plan.choice_src.size() * 4, hipMemcpyHostToDevice));
+            }
+            S.ttop = tape->d_top; S.chsrc = tape->d_chsrc;
+            // the linked prune of the root level (option prune2; prune2.hip): links of the root tape, made once with it.  0.275 ms
+            // against fh_prune1's 0.344 per 1024^3 frame of prospero.vm (a child of that root tape keeps ~580 ops, up to 1011);
+            // fh_prune1 stays behind it for the children it leaves marked (more than 64 registers / FH_P2_MAX_KEPT ops)
+            if (ctx->opt.prune2 && !tape->links_tried) {
+                tape->links_tried = true;
+                std::vector<uint64_t> lk;
+                std::vector<uint64_t> cops;
+                if (fh::compute_links(t, lk, cops)) {
+                    // (published together or not at all: a failure half way must not leave links without their choice table)
+                    uint64_t *dl = nullptr, *dc = nullptr;
+                    hipError_t e = hipMalloc((void**)&dl, lk.size() * 8);
+                    if (e == hipSuccess) e = hipMemcpy(dl, lk.data(), lk.size() * 8, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMalloc((void**)&dc, std::max<size_t>(cops.size(), 1) * 8);
+                    if (e == hipSuccess) e = hipMemcpy(dc, cops.data(), cops.size() * 8, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) {
+                        if (dl) (void)hipFree(dl);
+                        if (dc) (void)hipFree(dc);
+                        HIP_TRY(ctx, e);
+                    }
+                    tape->d_links = dl; tape->d_ctab = dc;
+                }
+            }
+            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices);
+            // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
+            // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)
+            R.prune2 = tape->d_links && tape->d_ctab && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
+                       R.lds_prune2 <= FH_LDS_MAX && R.roots.size() * 64 <= (size_t)2 * ctx->n_cu * FH_P2_WPB;      // (a root group = up to 64 root tiles)
+            R.d_ctab = tape->d_ctab;
+            R.d_links = tape->d_links;
+            R.lds_prune2_l1 = (((size_t)FH_P2_L1_OPS * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_L1_WPB * fh_p2_wave_lds(FH_P2_L1_CHOICES, FH_P2_L1_OPS);
+            R.prune2_l1 = R.prune2 && is3d && S.pre_levels > 1 && ctx->opt.prune2_l1 && !ctx->opt.no_tiles_v && R.exp_levels <= 1 &&
+                          R.lds_prune2_l1 <= FH_LDS_MAX;
+            const size_t blocks = qcaps[0];
+            HIP_TRY(ctx, ctx->tvals.ensure(blocks * S.n_terms * WAVE * 8));
+            HIP_TRY(ctx, ctx->topch.ensure(blocks * S.n_top * WAVE));
+            HIP_TRY(ctx, ctx->chwr.ensure(blocks * S.n_tgroups * ((t.n_choices + 15) / 16) * WAVE * 4 + 256));
+            S.tvals = (float*)ctx->tvals.p; S.topch = (uint8_t*)ctx->topch.p; S.chwr = (uint32_t*)ctx->chwr.p;
+        } else R.groups = false;
+    }
+    if (R.prune1) {  // choice words of the pre-pass levels' forward passes: [slot][word][lane]
+        uint32_t cap = 1;
+        for (uint32_t l = 0; l < std::max(S.pre_levels, R.exp_levels); l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
+        const size_t words[2] = {(SMALL_CHOICES + 15) / 16, ((size_t)P.max_choices + 15) / 16};
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx, ctx->chw[k].ensure(std::max<size_t>(cap * words[k] * 256, 256)));
+            S.chw[k] = (uint32_t*)ctx->chw[k].p;
+        }
+    }
+    if (R.split) {
+        uint32_t cap = 1;
+        for (size_t l = 0; l < ts.size(); l++) cap = std::max(cap, qcaps[l] * (l == 0 && R.groups ? S.n_tgroups : 1u));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx, ctx->slots[k].ensure((size_t)cap * sizeof(FhSlot)));
+            S.slots[k] = (FhSlot*)ctx->slots[k].p;
+            S.slot_cap[k] = cap;
+        }
+    }
+    S.squeue = (FhGroup*)ctx->squeue.p;
+    S.squeue_cap = qcaps[S.pre_levels];
+    S.arena_frame_end = S.arena_root_end;
+    for (int k = 0; k < FH_MAX_SLABS; k++) S.scount[k] = S.scount_big[k] = 0;
+    S.queue_overflow = 0;
+    S.leaves = (FhLeaf*)ctx->leaves.p;
+    S.leaf_cap = (uint32_t)leaf_cap;
+    S.n_leaves = S.leaf_cursor = S.leaf_cursor_big = S.normal_cursor = S.normal_cursor_big = 0;
+    S.leaf_table = (FhLeafRef*)ctx->leaf_table.p;
+    for (int c = 0; c < 3; c++) S.fp_count[c] = S.fp_cursor[c] = 0;
+    S.zbuf = (uint64_t*)ctx->zbuf.p;
+    S.normals = (float*)ctx->normals.p;
+    S.image2d = nullptr;
+    memset(S.stat, 0, sizeof(S.stat));
+    memset(S.leaf_stat, 0, sizeof(S.leaf_stat));
+    S.want_stats = (ctx->profiling || ctx->probe || ctx->opt.stats) ? 1 : 0;
+    if (((size_t)t.ops.size() + 64) * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
+    // level-0 groups sit at the back of queue[0] (the "big" half), in reverse order
+    std::reverse(R.roots.begin(), R.roots.end());
+    return FHIP_OK;
+}
+
+static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu);
+// ... of a root-sized launch: as many workgroups as LDS lets run, or the number of HBM register-file regions
+static int blocks_big(const fhip_ctx* ctx, const RenderSetup& R, size_t lds, int max_per_cu) {
+    return R.big_hbm ? (int)R.hbm_waves : blocks_for(ctx, lds, max_per_cu);
+}
+static int blocks_for(const fhip_ctx* ctx, size_t lds, int max_per_cu) {
+    int per_cu = lds ? (int)std::min<size_t>((size_t)max_per_cu, FH_LDS_MAX / std::max<size_t>(lds, 1)) : max_per_cu;
+    per_cu = std::max(per_cu, 1);
+    return ctx->n_cu * per_cu;
+}
+
+static fhip_status finish_render(fhip_ctx* ctx) {
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_state, ctx->state.p, sizeof(FhRenderState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t k = 1; k < ctx->forked; k++) {  // the other slab contexts keep their own counters
+        HIP_TRY(ctx, hipMemcpy(&ctx->last_state_b, (char*)ctx->state.p + k * sizeof(FhRenderState), sizeof(FhRenderState), hipMemcpyDeviceToHost));
+        ctx->last_state.queue_overflow += ctx->last_state_b.queue_overflow;
+        ctx->last_state.arena_overflow += ctx->last_state_b.arena_overflow;
+        for (int i = 0; i < 64; i++) ctx->last_state.stat[i] += ctx->last_state_b.stat[i];
+        for (int i = 0; i < 8; i++) ctx->last_state.leaf_stat[i] += ctx->last_state_b.leaf_stat[i];
+    }
+    ctx->have_last_state = true;
+    if (ctx->last_state.queue_overflow) return fail(ctx, FHIP_ERR_OVERFLOW, "device work queue overflow");
+    return FHIP_OK;
+}
+
+struct FrameClear { void* p = nullptr; size_t bytes = 0; uint32_t fill = 0; };   // a buffer the frame starts from cleared (bytes: a multiple of 4)
+static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetup& R, const FrameClear (&clear)[3]) {
+    // The frame's state and root groups go through pinned staging slots (a ring of eight, each guarded by an event): a copy from
+    // pageable memory would make the host wait for everything queued on the stream before it, i.e. for the previous frame.
+    const size_t roots_bytes = R.roots.size() * sizeof(FhGroup);
+    fhip_ctx::Staging& sg = ctx->staging[ctx->staging_next++ % 8];
+    if (sg.ev && sg.used) HIP_TRY(ctx, hipEventSynchronize(sg.ev));
+    if (!sg.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+    if (sg.cap < sizeof(FhRenderState) + roots_bytes) {
+        if (sg.p) (void)hipHostFree(sg.p);
+        sg.p = nullptr; sg.cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&sg.p, sizeof(FhRenderState) + roots_bytes + 4096, hipHostMallocDefault));
+        sg.cap = sizeof(FhRenderState) + roots_bytes + 4096;
+    }
+    memcpy(sg.p, &R.S, sizeof(FhRenderState));
+    if (roots_bytes) memcpy((char*)sg.p + sizeof(FhRenderState), R.roots.data(), roots_bytes);
+    // The root tape and its groups sit below arena_root_end, where no frame writes: a shape rendered
+    // again finds them there (17 small copies, 0.1 ms of a 4 ms frame, otherwise).
+    if (ctx->resident_serial != tape->serial || ctx->resident_groups != R.S.n_tgroups) {
+        ctx->resident_serial = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->arena.p, tape->t.ops.data(), tape->t.ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t g = 0; g < R.S.n_tgroups; g++)  // the group tapes follow the root tape
+            HIP_TRY(ctx, hipMemcpyAsync((uint64_t*)ctx->arena.p + R.S.tgroup[g].off, tape->tgroups[g].ops.data(),
+                                        tape->tgroups[g].ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->resident_serial = tape->serial;
+        ctx->resident_groups = R.S.n_tgroups;
+    }
+    // state, root groups and the cleared buffers in one launch (k_frame_begin reads the pinned slot itself)
+    static_assert(sizeof(FhRenderState) % 4 == 0 && sizeof(FhGroup) % 4 == 0, "copied as 32-bit words");
+    FhFrameBegin fb;
+    memset(&fb, 0, sizeof(fb));
+    fb.state_dst = (uint32_t*)ctx->state.p; fb.state_src = (const uint32_t*)sg.p; fb.state_words = (uint32_t)(sizeof(FhRenderState) / 4);
+    if (!R.roots.empty()) {
+        fb.roots_dst = (uint32_t*)((FhGroup*)ctx->queue[0].p + (R.S.qcap[0] - R.roots.size()));
+        fb.roots_src = (const uint32_t*)((const char*)sg.p + sizeof(FhRenderState));
+        fb.roots_words = (uint32_t)(roots_bytes / 4);
+    }
+    size_t most = 0;
+    for (int k = 0; k < 3; k++) {
+        fb.clear[k] = (uint32_t*)clear[k].p; fb.clear_words[k] = clear[k].bytes / 4; fb.fill[k] = clear[k].fill;
+        if (clear[k].p) most = std::max(most, clear[k].bytes);
+    }
+    const unsigned blocks = (unsigned)std::max<size_t>(2, std::min<size_t>((size_t)ctx->n_cu * 8, (most + 256 * 64 - 1) / (256 * 64)));
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks), dim3(256), 0, ctx->stream, fb);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(sg.ev, ctx->stream));
+    sg.used = true;
+    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->prof_events.clear();
+    for (auto& e : ctx->asm_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    ctx->asm_events.clear();
+    return FHIP_OK;
+}
+
+// One level of the tile hierarchy: the small-LDS variant for the bulk of the groups and the
+// root-sized variant for the few large tapes (both always launched; empty queues exit at once).
+#define FH_LAUNCH_TILES(IS3D, FULL, BIG, grid, lds)                                                                  \
+    do {                                                                                                            \
+        if (R.tl == 64) hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 64>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level); \
+        else hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
+    } while (0)
+// 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
+static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
+    // Persistent waves with a static round robin over the parents.  (FHIP_ONE_EACH_TILES=1: one short
+    // workgroup per parent instead - measured slower in the pipelined frame: the tile stage then
+    // takes more of the machine from the leaf kernel it overlaps with.)
+    const uint32_t one_each = ctx->opt.one_each_tiles ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
+    const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
+    const int gb = one_each && !R.big_hbm ? (int)one_each : blocks_big(ctx, R, R.lds_tiles_big, 8);
+    const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
+    launch(ctx, FHIP_K_TILES, [&] {
+        // (pre-pass levels below the root: the children of a parent shared out over several slots - tsetup_body; option
+        // l1_split: 0 chosen on the device from the number of parents, 1 off, 2 / 4 / 8 fixed)
+        const uint32_t csplit = (level > 0 && (uint32_t)level < R.S.pre_levels && R.asm_tiles) ? (uint32_t)std::max(0, std::min(8, ctx->opt.l1_split)) : 1u;
+        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level, csplit);
+        else hipLaunchKernelGGL(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+    });
+    if (R.groups && level == 0) {
+        // Tape parallelism: the root tree's terms by independent groups, one wave per (block of root
+        // tiles, group) -> the tree over the terms (result, marks, arena) -> the root tape's choice words
+        // gathered from both -> one wave per ambiguous child prunes the root tape -> push.
+        launch(ctx, FHIP_K_TILES, [&] {
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
+            const int gg = blocks_for(ctx, R.lds_tiles_group, 8);
+            ka.S = dS; ka.level = 0; ka.big = 1; ka.max_regs = R.group_regs; ka.max_choices = R.group_choices;
+            ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u | 8u; ka.skip_regs = ka.skip_choices = 0;
+            (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
+            const uint32_t blocks = R.S.qcap[0], root_words = (R.S.troot_choices + 15) / 16, group_words = (R.group_choices + 15) / 16;
+            if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (root_words) hipLaunchKernelGGL(k_tscatter3d, dim3(root_words, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
+            if (R.prune2) {
+                hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
+                if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
+                hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u), R.S.troot_len, R.S.troot_choices,
+                                   (uint32_t)FH_P2_MAX_KEPT);
+                // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
+                // none for the models here; a wave whose child is done leaves at once)
+                struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
+                size_t kp_bytes = sizeof(kp);
+                void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &kp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &kp_bytes, HIP_LAUNCH_PARAM_END};
+                (void)hipModuleLaunchKernel(ctx->asm_fn[FH_ASM_PRUNE1], blocks * 64, 1, 1, WAVE, 1, 1, 0, ctx->stream, nullptr, extra);
+                if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({FH_ASM_PRUNE1, {ea, eb}}); }
+            } else {
+                struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
+                (void)launch_asm(ctx, FH_ASM_PRUNE1, blocks * 64, &kp, sizeof(kp));
+            }
+        });
+    } else if (R.asm_tiles) {
+        launch(ctx, FHIP_K_TILES, [&] {
+            // pre-pass levels: long tapes, few parents -> the forward pass exports its choices and
+            // the prune runs as one wave per child (fh_prune1)
+            const bool exp = R.prune1 && (uint32_t)level < R.exp_levels;      // level 0 only: 8 parents, 6363-op tape (measured)
+            const int K_TILES = R.asm_tiles_t ? FH_ASM_TILES_T : FH_ASM_TILES;
+            struct { FhRenderState* S; uint32_t level, big, max_regs, max_choices, n_waves, flags, skip_regs, skip_choices; } ka;
+            ka.S = dS; ka.level = (uint32_t)level; ka.flags = (ctx->probe ? 1u : 0u) | (exp ? 2u : 0u);
+            ka.skip_regs = ka.skip_choices = 0;
+            // Pre-pass levels below the root: the small-layout parents and the others are different slot lists;
+            // their launches run side by side (second stream) instead of one after the other.
+            // (Only for a frame alone, whose coarse levels are on the caller's stream: in a pipelined frame they are off the critical
+            // path, and the side stream carries the previous frame's tile chains, where this frame's level-1 kernel sat for 170 us
+            // of every frame - 1.64 -> 1.60 ms without the fork.  Forking to the tail stream instead: 2.0 ms; to streams of their
+            // own, also for the per-slab levels' nearly always empty big-list launches: 3.5 ms - streams beyond four share
+            // hardware queues (GPU_MAX_HW_QUEUES) and serialise against each other.)
+            // (A fifth stream for the per-slab levels' nearly always empty big-list launches, with GPU_MAX_HW_QUEUES=8 in the
+            // environment: 2.3 ms per frame instead of 1.03 - more than four streams in flight cost far more than two kernel
+            // boundaries per slab, whatever the number of hardware queues.)
+            hipStream_t const rest_stream = ctx->stream2;
+            const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && rest_stream &&
+                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !ctx->opt.pipe_serial && is3d;
+            hipStream_t const big_stream = side ? rest_stream : nullptr;
+            // Tapes of <= 32 registers / 256 choices (the small slot list: every parent of the leaf level) and, from the other
+            // list, those of <= 64 / 512 go to the kernels that keep the interval file, the choices and the prune's register
+            // map in VGPRs (fh_tiles_v32: 16 waves per CU, fh_tiles_v64: 8; no LDS); what is left takes the LDS layouts.
+            const bool use_v = !ctx->opt.no_tiles_v;
+            const bool vk = use_v && !exp;
+            bool both_lists = false;
+            if (level > 0) {
+                ka.big = 0; ka.max_regs = SMALL_REGS; ka.max_choices = SMALL_CHOICES; ka.n_waves = (uint32_t)gs;
+                if (side) {
+                    (void)hipEventRecord(ctx->ev_rest_fork, ctx->stream);
+                    (void)hipStreamWaitEvent(rest_stream, ctx->ev_rest_fork, 0);
+                }
+                // (a pre-pass level has a few hundred parents in the two lists together: fh_tiles_v64 takes both in ONE launch
+                // below - the level's time is its slowest parent's either way, and a launch of its own for the small list put
+                // another 130 us on the coarse levels' chain)
+                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side && !ctx->opt.no_both_lists;
+                if (vk && !both_lists) {
+                    const int v32_waves = ctx->opt.v32_waves;
+                    ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
+                    (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V32_T : FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
+                } else if (vk) {
+                } else
+                    (void)launch_asm(ctx, K_TILES, (uint32_t)gs, &ka, sizeof(ka), R.lds_tiles_small);
+            }
+            ka.big = 1;
+            if (exp) ka.flags |= ((R.S.P.max_choices + 15) / 16) << 16;  // one stride in chw[1] for the medium and the large layout
+            bool rest = true;   // anything left for the root-sized LDS layout?
+            // (leaving the per-slab levels' big-list parents to the root-sized LDS launch alone - one launch less on the slab's tile
+            // chain - was measured: 1.02 vs 1.04 ms per frame, within the noise; not done)
+            if (vk && level > 0) {
+                const int v64_waves = ctx->opt.v64_waves;
+                // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
+                // VGPRs each, queued behind the leaf kernel of the slab in front, was measured to hold the tile chain up for
+                // 130 us: a small persistent grid there)
+                const int v64_slab_waves = ctx->opt.v64_slab_waves;
+                const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
+                ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
+                ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
+                if (both_lists) ka.flags |= 16u;
+                // (level 1 with the linked prune: parents whose tape carries this frame's links get their choices exported - chw[1]
+                // with this stride, chw[0] with 16 words - and their children marked for k_prune2 below; the others are pruned here)
+                const bool linked = R.prune2_l1 && !per_slab;
+                const uint32_t plain_flags = ka.flags;
+                if (linked) ka.flags = (ka.flags & 0xFFFFu) | 2u | (((R.S.P.max_choices + 15) / 16) << 16);
+                (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V64_T : FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
+                ka.flags = plain_flags & ~16u;
+                ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
+                rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
+            }
+            // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
+            // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
+            // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
+            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !ctx->opt.no_mid;
+            if (mid) {
+                const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
+                ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
+                (void)launch_asm(ctx, K_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid, 1, big_stream);
+                ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
+            }
+            ka.max_regs = R.S.P.max_regs; ka.max_choices = R.S.P.max_choices; ka.n_waves = (uint32_t)gb;
+            if (rest) (void)launch_asm(ctx, K_TILES, (uint32_t)gb, &ka, sizeof(ka), R.lds_tiles_big, 1, big_stream);
+            if (side) {
+                (void)hipEventRecord(ctx->ev_rest_join, rest_stream);
+                (void)hipStreamWaitEvent(ctx->stream, ctx->ev_rest_join, 0);
+            }
+            if (R.prune2_l1 && use_v && level > 0 && (uint32_t)level < R.S.pre_levels) {
+                hipEvent_t ea = nullptr, eb = nullptr;      // (slot 7 of the per-kernel profile)
+                if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
+                hipLaunchKernelGGL(k_prune2, dim3(ctx->n_cu * 2), dim3(FH_P2_L1_WPB * 64), R.lds_prune2_l1, ctx->stream, dS, (uint32_t)level, 2u, 0u,
+                                   (R.S.P.max_choices + 15) / 16, (const uint2*)nullptr, (const uint2*)nullptr, ctx->opt.prune2_probe_level == 1 ? 2u : 0u,
+                                   (uint32_t)FH_P2_L1_OPS, (uint32_t)FH_P2_L1_CHOICES, (uint32_t)FH_P2_L1_OPS);
+                if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({7, {ea, eb}}); }
+            }
+            if (exp) {
+                struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
+                const uint32_t bound = R.S.qcap[level] * 64;  // 64 waves per possible parent; unmarked children exit at once
+                if (level > 0) (void)launch_asm(ctx, FH_ASM_PRUNE1, bound, &kp, sizeof(kp));
+                kp.big = 1; kp.max_choices = R.S.P.max_choices;
+                (void)launch_asm(ctx, FH_ASM_PRUNE1, bound, &kp, sizeof(kp));
+            }
+        });
+    } else
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (level > 0) {
+            if (R.full) hipLaunchKernelGGL((k_teval3d<true, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+            else hipLaunchKernelGGL((k_teval3d<false, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+        }
+        if (R.full) hipLaunchKernelGGL((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+        else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+    });
+    // (last level: fewer waves, several parents each - one leaf reservation per wave)
+    const int push_mul = ctx->opt.push_waves;
+    const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+        else {
+            hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+            const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);
+            hipLaunchKernelGGL(k_tfill2d, dim3(64, slots_max), dim3(256), 0, ctx->stream, dS, level);
+        }
+    });
+}
+
+static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
+    if (R.split) return launch_tiles_split(ctx, R, dS, level, is3d);
+    const int gs = blocks_for(ctx, R.lds_tiles_small, 8), gb = blocks_big(ctx, R, R.lds_tiles_big, 8);
+    launch(ctx, FHIP_K_TILES, [&] {
+        if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(true, false, true, gb, R.lds_tiles_big); }
+        else { if (R.full) FH_LAUNCH_TILES(false, true, true, gb, R.lds_tiles_big); else FH_LAUNCH_TILES(false, false, true, gb, R.lds_tiles_big); }
+    });
+    if (level > 0)
+        launch(ctx, FHIP_K_TILES, [&] {
+            if (is3d) { if (R.full) FH_LAUNCH_TILES(true, true, false, gs, R.lds_tiles_small); else FH_LAUNCH_TILES(true, false, false, gs, R.lds_tiles_small); }
+            else { if (R.full) FH_LAUNCH_TILES(false, true, false, gs, R.lds_tiles_small); else FH_LAUNCH_TILES(false, false, false, gs, R.lds_tiles_small); }
+        });
+}
+
+fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
+                          int out_is_device) {
+    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    RenderSetup R;
+    memset(&R.S, 0, sizeof(R.S));
+    FhRender& P = R.S.P;
+    P.width = cfg->width; P.height = cfg->height; P.depth = 0; P.z = cfg->z; P.pixel_perfect = cfg->pixel_perfect ? 1 : 0;
+    fhip_status st = bind_inputs(ctx, tape, cfg->axis_slots, cfg->var_keys, cfg->var_values, cfg->n_vars, P);
+    if (st) return st;
+    // mat = world_to_model * screen_to_world, lifted to 4x4 preserving Z (pixel.rs:122-124, 281-285)
+    const uint32_t size[2] = {cfg->width, cfg->height};
+    float s2w[9], m3[9];
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    fhip_screen_to_world(size, 2, s2w);
+    mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 3, m3);
+    const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
+    memcpy(P.mat, m4, sizeof(m4));
+    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                                     : (ctx->opt.vm_tiles ? trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height))
+                                                                                : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height)));
+    st = prepare(ctx, tape, false, ts, PartSpec{}, R);
+    if (st) return st;
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    float* d_out = out;
+    if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * 4)); d_out = (float*)ctx->tmp_out.p; }
+    R.S.image2d = d_out;
+    FhRenderState* dS = (FhRenderState*)ctx->state.p;
+    const FrameClear no_clear[3] = {};
+    st = upload_frame(ctx, tape, R, no_clear);
+    if (st) return st;
+    for (uint32_t l = 0; l < P.n_levels; l++) {
+        if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+        launch_tiles(ctx, R, dS, (int)l, false);
+    }
+    launch(ctx, FHIP_K_POINTS, [&] {
+        if (R.full) hipLaunchKernelGGL((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+        else hipLaunchKernelGGL((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+    });
+    if (P.max_regs > 32)
+        launch(ctx, FHIP_K_POINTS, [&] {
+            const int g = blocks_big(ctx, R, R.lds_points_big, 16);
+            if (R.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+            else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+        });
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->stream));     // (a later pipelined 3D frame that takes this buffer set waits for it)
+    ctx->ev_done_valid = true;
+    if (!out_is_device) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        return finish_render(ctx);
+    }
+    return FHIP_OK;
+}
+
+static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                 int out_is_device, const PartSpec& part) {
+    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    (void)hipSetDevice(ctx->device);
+    RenderSetup R;
+    memset(&R.S, 0, sizeof(R.S));
+    FhRender& P = R.S.P;
+    P.width = cfg->width; P.height = cfg->height; P.depth = cfg->depth; P.z = 0; P.pixel_perfect = 0;
+    fhip_status st = bind_inputs(ctx, tape, cfg->axis_slots, cfg->var_keys, cfg->var_values, cfg->n_vars, P);
+    if (st) return st;
+    const uint32_t size[3] = {cfg->width, cfg->height, cfg->depth};
+    float s2w[16];
+    const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    fhip_screen_to_world(size, 3, s2w);
+    mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
+    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                                     : hip_tiles_3d(std::max(cfg->width, cfg->height), ctx->opt.vm_tiles != 0);
+    // Frame pipelining (asynchronous renders): this frame takes the buffer set the previous frame did not use, and everything up
+    // to and including its coarse levels is queued on a stream of its own - it depends on nothing the previous frame does, so it
+    // runs beside that frame's slabs.  The slabs' tile chains follow on the side stream (after the previous frame's), the leaf
+    // chains and the final image on the caller's stream as before.
+    hipStream_t const main_stream = ctx->stream;
+    // (a tape whose register files live in HBM takes the slow path: one region per workgroup, shared by the launches of a frame, so
+    // nothing of the frame runs beside anything else)
+    const bool huge = (size_t)std::max<uint32_t>(tape->t.n_regs, 1) * WAVE * 16 > FH_LDS_MAX || tiles_lds(std::max<uint32_t>(tape->t.n_regs, 1), tape->t.n_choices, 64) > FH_LDS_MAX;
+    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial && !huge;
+    struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    if (fpipe) {
+        // (rotate: the current set goes to the back of the ring, the set used longest ago comes forward)
+        for (uint32_t i = 0; i < ctx->extra_sets; i++) std::swap(static_cast<FrameBufs&>(*ctx), ctx->others[i]);
+        ctx->stream = ctx->stream_pre;
+        if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
+    }
+    st = prepare(ctx, tape, true, ts, part, R);
+    if (st) return st;
+    {   // input slots of the axes, and which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix)
+        uint32_t u[16];
+        memcpy(u, P.mat, sizeof(u));
+        const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
+        int slot[3] = {-1, -1, -1};
+        for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis)
+        for (int ax = 0; ax < 3; ax++) {
+            R.col_slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
+            const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
+            if (dep && slot[ax] >= 0) R.col_depmask |= 1u << slot[ax];
+            if (dep) R.col_flags |= 0x20000u << ax;     // (bits 17 .. 19: this axis of the model changes along a pixel column - from the camera alone)
+        }
+        R.col_flags |= proj ? 0x10000u : 0u;
+        // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
+        const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
+        // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying
+        // along z - which is what a model with z in every tape gets)
+        const bool no_inv = ctx->opt.no_column_inv != 0;
+        if (no_inv) R.col_depmask = 0xFFFFFFFFu;
+        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !no_inv && !ctx->opt.no_zrep;
+    }
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    FhGeometryPixel* d_out = (FhGeometryPixel*)out;
+    if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
+    FhRenderState* dS = (FhRenderState*)ctx->state.p;
+    // (FHIP_DEBUG_ZFILL, diagnostics: every pixel already at the far depth - the front slab's leaf kernel then finds all its
+    // leaves but nothing pending, which times its per-workgroup and per-leaf set-up without the interpretation)
+    const FrameClear clear3[3] = {{ctx->zbuf.p, npix * 8, ctx->opt.debug_zfill ? 0xFFFFFFFFu : 0u}, {ctx->normals.p, npix * 12, 0u},
+                                  {ctx->mind.p, R.mind_words * 4, 0u}};
+    st = upload_frame(ctx, tape, R, clear3);
+    if (st) return st;
+    const uint32_t n_groups = R.groups_per_slab;
+    const uint32_t pre = R.S.pre_levels;
+    const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
+    const int class_blocks = (int)((R.n_footprints + 255) / 256);
+    // Pipelined frames: the root level stays on the pre-pass stream, the level below it moves to the head of this frame's tile
+    // chains on the side stream.  The two coarse levels of a frame are one dependent chain of ~0.9 ms that, on one stream, set
+    // the frame rate; split, the root level of frame n + 1 runs beside level 1 and the slabs of frame n, and the side stream
+    // carries level 1 + the (now few) slab steps of its own frame.  (A frame alone sees no difference: the same chain.)
+    const bool l1_side = fpipe && ctx->opt.l1_on_side && pre > 1 && ctx->stream2 && !ctx->opt.pipe_serial &&
+                         ctx->use_pipeline && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
+    if (pre && n_groups) {  // coarse levels of every slab in one go
+        for (uint32_t l = 0; l < pre; l++) {
+            if (l == 1 && l1_side) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream_pre));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_l0, 0));
+                ctx->stream = ctx->stream2;
+            }
+            if (R.zrep && l > 0) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            launch_tiles(ctx, R, dS, (int)l, true);
+        }
+        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
+        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
+    }
+    // Two-stream pipeline over the z-slabs: the tile stage of a slab runs on the side stream while
+    // the leaves of the slab in front of it are evaluated on the caller's stream.  The occlusion
+    // pyramid is then one slab stale, which is still exact (depths only grow).  Two slab contexts
+    // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
+    FhRenderState* const dS0 = dS;
+    const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
+    hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
+    const uint32_t NC = pipe ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;     // (no more contexts than slabs: each takes its share of the arena)
+    ctx->forked = pipe ? NC : 0;
+    if (pipe) {
+        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
+                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
+    }
+    if (fpipe) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));     // (the stream the last coarse-level kernel went to)
+        HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
+        ctx->stream = main_stream;
+    }
+    int last_tail_idx = -1;
+    // Where a slab's tile chain goes: the side stream, or (option tiles_stream = 1, pipelined frames of at most as many slabs
+    // as there are slab contexts) the tail stream, every slab's chain queued there BEFORE the tail work of the first slab - the
+    // side stream then carries level 1 of the coarse levels alone, the pre-pass stream the root level, and the three chains
+    // of consecutive frames run beside each other.
+    // (2, the default: there when the ROOT tape reads no input that changes along a pixel column - then no tape of the frame does,
+    // the leaf stage is light and the tail stream has room; a frame whose leaf kernels fill the machine wants its tile chains on
+    // the high-priority side stream: prospero.vm 1024^3 0.77 -> 0.64 ms per frame there, the same frames with the column-invariance
+    // short cuts off 1.86 -> 2.01)
+    bool root_invariant = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
+    for (uint64_t w : tape->t.ops)
+        if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { root_invariant = false; break; }
+    const bool tiles_first = pipe && l1_side && (ctx->opt.tiles_stream == 1 || (ctx->opt.tiles_stream == 2 && root_invariant)) && ctx->stream3 &&
+                             ctx->opt.tail_stream == 1 && R.asm_points && R.slab_hi - R.slab_lo <= NC;
+    hipStream_t const tile_stream = tiles_first ? ctx->stream3 : side_stream;
+    if (tiles_first) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_fork, 0));
+    auto tile_step = [&](int k, int idx) -> fhip_status {
+        dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
+        if (pipe) {
+            ctx->stream = tile_stream;
+            if (idx >= (int)NC) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_leaves[idx - (int)NC], 0));  // context free again
+        }
+        launch(ctx, FHIP_K_OTHER, [&] {
+            // the usual pyramid (three levels, 4 x 4 each, 8 x 8 leaf tiles) has a kernel of its own
+            // (up to 1024 x 1024: at 2048 x 2048 it was measured SLOWER than the generic kernel - 11.2 vs 8.2 ms per frame)
+            const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
+                              ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !ctx->opt.old_pyr;
+            const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
+            if (rebuild && pyr3 && pre == 2 && !ctx->opt.no_slab_begin) {
+                const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
+                hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
+                return;
+            }
+            hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
+                               (pyr3 && rebuild) ? 1u : 0u);
+            if (rebuild && pyr3) {
+                const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
+                hipLaunchKernelGGL(k_minpyramid3, dim3(n1), dim3(256), 0, ctx->stream, dS);
+            } else if (rebuild)
+                hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
+        });
+        for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
+        if (pipe) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles[idx], tile_stream));
+            ctx->stream = main_stream;
+        }
+        return FHIP_OK;
+    };
+    if (tiles_first)
+        for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {
+            const fhip_status ts_ = tile_step(k, (int)R.slab_hi - 1 - k);
+            if (ts_) { ctx->stream = main_stream; return ts_; }
+        }
+    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
+        if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
+        const int idx = (int)R.slab_hi - 1 - k;
+        if (!tiles_first) {
+            const fhip_status ts_ = tile_step(k, idx);
+            if (ts_) { ctx->stream = main_stream; return ts_; }
+        }
+        dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
+        // (diagnostics, FHIP_LEAF_STREAMS=2: leaf kernels of consecutive slabs on two streams, so that the tail of one overlaps
+        // the head of the next - any interleaving gives the same image - at the price of lanes that no longer see the hits in front)
+        const bool tail1 = ctx->opt.tail_stream == 1;
+        hipStream_t const leaf_stream = (pipe && tail1 && R.asm_points && ctx->stream3 && ctx->stream_leaf2 && (idx & 1)) ? ctx->stream_leaf2 : main_stream;
+        if (pipe) HIP_TRY(ctx, hipStreamWaitEvent(leaf_stream, ctx->ev_tiles[idx], 0));
+        // The leaf kernel is the slab's critical chain.  What surrounds it - the footprint lists (needed by the normals and the
+        // LDS-class leaves only), those leaves (any order with the others: atomic-max z-buffer) and the normals of the slab's
+        // hits - are small launches that leave the machine mostly idle, so in the pipelined frame they run on a third stream
+        // beside the leaf kernel of the NEXT slab: the normals kernel only takes hits of its own slab's depth range, and a hit
+        // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
+        const int tail_mode = ctx->opt.tail_stream;   // 0: off, 1: lists + normals, 2: normals only
+        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points;   // (the HIP leaf kernels walk the footprint lists)
+        const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
+        auto classify_work = [&] {
+            launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
+            if (P.max_regs > 32)
+                launch(ctx, FHIP_K_POINTS, [&] {
+                    const int g = blocks_big(ctx, R, R.lds_points_big, 16);
+                    if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                    else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                });
+        };
+        auto normals_work = [&] {
+            launch(ctx, FHIP_K_NORMALS, [&] {
+                const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_big(ctx, R, R.lds_normals_big, 8);
+                if (R.asm_normals) {
+                    // (list 0 of k_classify3d holds every footprint whose leaves need <= 32 registers: the assembly interpreter's file)
+                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * std::max(1, ctx->opt.normals_waves)), R.col_slots, z_lo, z_hi, {0, 0}};
+                    (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
+                }
+                else if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                if (P.max_regs > 32) {
+                    if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                    else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                }
+            });
+        };
+        if (tail && tail_mode == 1) {
+            ctx->stream = ctx->stream3;
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_tiles[idx], 0));
+            classify_work();
+            ctx->stream = main_stream;
+        } else classify_work();
+        launch(ctx, FHIP_K_POINTS, [&] {
+            // class 0: <= 16 registers, 4 voxels per lane; class 1: <= 32 registers, 2 per lane; class 2: LDS file
+            if (R.asm_points) {
+                // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
+                // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
+                // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
+                const uint32_t col_waves = (uint32_t)std::max(0, ctx->opt.col_waves);
+                // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
+                // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
+                const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
+                if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
+                else {
+                    const uint32_t blk = 1u << ctx->opt.col_blkl;   // footprints per workgroup: gen_interp.py BLKL
+                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
+                }
+            } else if (R.full) {
+                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+            } else {
+                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+            }
+        });
+        if (tail) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[idx], leaf_stream));          // the slab's leaf kernel is through
+            ctx->stream = ctx->stream3;
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_aux[idx], 0));
+            normals_work();
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], ctx->stream3));       // slab context free again; the last one: image complete
+            ctx->stream = main_stream;
+            last_tail_idx = idx;
+            continue;
+        }
+        normals_work();
+        if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
+    }
+    if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
+    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p); });
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
+    ctx->async_pending = out_is_device != 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream));     // (a later pipelined frame that takes this set waits for it)
+    ctx->ev_done_valid = true;
+    if (!out_is_device) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
+        return finish_render(ctx);
+    }
+    return FHIP_OK;
+}
+fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                          int out_is_device) {
+    return render3d_part(ctx, tape, cfg, out, out_is_device, PartSpec{});
+}
+fhip_status fhip_render3d_shard(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t shard, uint32_t n_shards) {
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad shard");
+    PartSpec p;
+    p.shard = shard; p.n_shards = n_shards;
+    return render3d_part(ctx, tape, cfg, out, out_is_device, p);
+}
+// Octant-style shards: block `index` = ix + nx * (iy + ny * iz) of an nx x ny x nz split of the volume (root-tile
+// columns in x and y, z-slabs in z; iz = nz - 1 is the front).  Pixels outside the block's columns stay {0,0,0,0}.
+fhip_status fhip_render3d_block(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                int out_is_device, uint32_t index, const uint32_t split[3]) {
+    if (!split || !split[0] || !split[1] || !split[2] || index >= split[0] * split[1] * split[2]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad block");
+    PartSpec p;
+    p.nx = split[0]; p.ny = split[1]; p.nz = split[2];
+    p.ix = index % p.nx; p.iy = (index / p.nx) % p.ny; p.iz = index / (p.nx * p.ny);
+    return render3d_part(ctx, tape, cfg, out, out_is_device, p);
+}
+// Merge of two partial images of the same pixels from different z ranges (the stitch rule of voxel.rs:527-550 applied
+// across shards): the larger depth wins, a tie goes to `front` (the range nearer the camera: a hit there carries the
+// normal, the other side's equal depth is a filled tile's z + T + 1 with no normal); then the clamp depth >= D - 1 ->
+// (D, [0, 0, 1]).  In place on `front`; device pointers; n pixels.
+fhip_status fhip_merge_depth(fhip_ctx* ctx, void* front, const void* back, uint64_t n_pixels, uint32_t image_depth) {
+    if (!n_pixels) return FHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    hipLaunchKernelGGL(k_merge_depth, dim3((unsigned)std::min<uint64_t>((n_pixels + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+                       (FhGeometryPixel*)front, (const FhGeometryPixel*)back, (size_t)n_pixels, image_depth);
+    HIP_TRY(ctx, hipGetLastError());
+    return FHIP_OK;
+}
