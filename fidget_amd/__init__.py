@@ -25,7 +25,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
-_SOURCES = ["capi.hip", "capi_core.hpp", "capi_context.hpp", "capi_tapes.hpp", "capi_eval.hpp", "capi_render.hpp", "capi_effects.hpp", "capi_mesh.hpp", "capi_debug.hpp", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "mesh_collapse.hpp", "mesh_edges.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "host_regtape.hpp", "render_state.h", "tape_format.h",
+_SOURCES = ["capi.hip", "capi_core.hpp", "capi_context.hpp", "capi_tapes.hpp", "capi_eval.hpp", "capi_render.hpp", "capi_effects.hpp", "capi_mesh.hpp", "capi_debug.hpp", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "mesh_collapse.hpp", "mesh_edges.hpp", "mesh_walk.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "host_regtape.hpp", "render_state.h", "tape_format.h",
             "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_normals.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "trans_libm.hpp", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
 

@@ -270,6 +270,114 @@ struct OctDevX {
     }
     void release() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
+// Octree::walk_dual on the device: where mesh_walk.hpp's arrays live and how its passes run (one kernel launch per pass)
+struct WalkDevX {
+    hipStream_t st;
+    std::vector<void*> owned;
+    hipError_t err = hipSuccess;
+    void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+    void* alloc(size_t b) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, b ? b : 4);
+        if (e != hipSuccess) { chk(e); return nullptr; }
+        owned.push_back(p);
+        return p;
+    }
+    void free(void* p) {
+        for (size_t i = owned.size(); i-- > 0;) if (owned[i] == p) { owned.erase(owned.begin() + (long)i); break; }
+        (void)hipFree(p);
+    }
+    void forget(void* p) { for (size_t i = owned.size(); i-- > 0;) if (owned[i] == p) { owned.erase(owned.begin() + (long)i); break; } }   // the caller keeps it
+    void release() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
+    void zero(void* p, size_t b) { chk(hipMemsetAsync(p, 0, b, st)); }
+    void fill_ff(void* p, size_t b) { if (b) chk(hipMemsetAsync(p, 0xFF, b, st)); }
+    void read(void* d, const void* s, size_t b) { chk(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st)); chk(hipStreamSynchronize(st)); }
+    void write(void* d, const void* s, size_t b) { chk(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, st)); chk(hipStreamSynchronize(st)); }
+    static dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+    bool scan(const uint32_t* in, uint32_t n, uint32_t* out) {
+        const uint32_t nb = (n + 1 + fhm::FH_SCAN_PER_BLOCK - 1) / fhm::FH_SCAN_PER_BLOCK;
+        if (nb == 1) {
+            hipLaunchKernelGGL(fhm::k_scan_block, dim3(1), dim3(256), 0, st, in, n, out, (uint32_t*)nullptr);
+            chk(hipGetLastError());
+            return err == hipSuccess;
+        }
+        uint32_t* sums = (uint32_t*)alloc((size_t)nb * 4);
+        uint32_t* sums_off = (uint32_t*)alloc((size_t)(nb + 1) * 4);
+        if (!sums || !sums_off) return false;
+        hipLaunchKernelGGL(fhm::k_scan_block, dim3(nb), dim3(256), 0, st, in, n, out, sums);
+        chk(hipGetLastError());
+        if (!scan(sums, nb, sums_off)) return false;
+        hipLaunchKernelGGL(fhm::k_scan_add, grid((uint64_t)n + 1), dim3(256), 0, st, out, n, (const uint32_t*)sums_off);
+        chk(hipGetLastError());
+        free(sums); free(sums_off);
+        return err == hipSuccess;
+    }
+    void count(const fhmesh::WalkTree& o, const fhmesh::WalkItem* items, uint32_t n, uint32_t* cnt, uint32_t* live) {
+        hipLaunchKernelGGL(fhm::k_walk_count, grid(n), dim3(256), 0, st, o, items, n, cnt, live);
+        chk(hipGetLastError());
+    }
+    void expand(const fhmesh::WalkTree& o, const fhmesh::WalkItem* items, uint32_t n, const uint32_t* off, fhmesh::WalkItem* next) {
+        hipLaunchKernelGGL(fhm::k_walk_expand, grid(n), dim3(256), 0, st, o, items, n, off, next);
+        chk(hipGetLastError());
+    }
+    void first_min(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first) {
+        hipLaunchKernelGGL(fhm::k_walk_first, grid((uint64_t)n * 5), dim3(256), 0, st, recs, n, first);
+        chk(hipGetLastError());
+    }
+    void rec_counts(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, uint32_t* nn, uint32_t* nt) {
+        hipLaunchKernelGGL(fhm::k_walk_rec_counts, grid(n), dim3(256), 0, st, recs, n, first, nn, nt);
+        chk(hipGetLastError());
+    }
+    void rec_number(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first, const uint32_t* vb, const fhmesh::V3* octree_verts, fhmesh::V3* verts) {
+        hipLaunchKernelGGL(fhm::k_walk_rec_number, grid(n), dim3(256), 0, st, recs, n, first, vb, octree_verts, verts);
+        chk(hipGetLastError());
+    }
+    void rec_triangles(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, const uint32_t* tb, uint64_t* tris) {
+        hipLaunchKernelGGL(fhm::k_walk_rec_triangles, grid(n), dim3(256), 0, st, recs, n, first, tb, tris);
+        chk(hipGetLastError());
+    }
+};
+// ... and on the host: the same passes as plain loops (fhip_debug_walk_dual mode 3: how they are tested without a GPU)
+struct WalkHostX {
+    void* alloc(size_t b) { return malloc(b ? b : 4); }
+    void free(void* p) { ::free(p); }
+    void zero(void* p, size_t b) { memset(p, 0, b); }
+    void fill_ff(void* p, size_t b) { memset(p, 0xFF, b); }
+    void read(void* d, const void* s, size_t b) { memcpy(d, s, b); }
+    void write(void* d, const void* s, size_t b) { memcpy(d, s, b); }
+    bool scan(const uint32_t* in, uint32_t n, uint32_t* out) { uint32_t run = 0; for (uint32_t i = 0; i < n; i++) { out[i] = run; run += in[i]; } out[n] = run; return true; }
+    void count(const fhmesh::WalkTree& o, const fhmesh::WalkItem* items, uint32_t n, uint32_t* cnt, uint32_t* live) {
+        for (uint32_t i = n; i-- > 0;) { cnt[i] = fhmesh::wk_count(o, items[i]); if ((items[i].hdr & 3u) != fhmesh::WK_REC) *live = 1; }      // (any order)
+    }
+    void expand(const fhmesh::WalkTree& o, const fhmesh::WalkItem* items, uint32_t n, const uint32_t* off, fhmesh::WalkItem* next) {
+        for (uint32_t i = n; i-- > 0;) if (off[i + 1] != off[i]) fhmesh::wk_expand(o, items[i], next + off[i]);
+    }
+    void first_min(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first) {
+        for (uint64_t i = (uint64_t)n * 5; i-- > 0;) { uint32_t& f = first[recs[i / 5].a[i % 5]]; if ((uint32_t)i < f) f = (uint32_t)i; }
+    }
+    void rec_counts(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, uint32_t* nn, uint32_t* nt) {
+        for (uint32_t i = 0; i < n; i++) fhmesh::wk_rec_counts(recs[i], i, first, &nn[i], &nt[i]);
+    }
+    void rec_number(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first, const uint32_t* vb, const fhmesh::V3* octree_verts, fhmesh::V3* verts) {
+        for (uint32_t i = n; i-- > 0;) fhmesh::wk_rec_number(recs[i], i, first, vb[i], octree_verts, verts);
+    }
+    void rec_triangles(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, const uint32_t* tb, uint64_t* tris) {
+        for (uint32_t i = n; i-- > 0;) fhmesh::wk_rec_triangles(recs[i], first, tb[i], tris);
+    }
+};
+static const fhmesh::WalkTable& walk_table() {       // CELL_TO_EDGE_TO_VERT out of host_mesh.hpp's tables
+    static const fhmesh::WalkTable* const W = [] {
+        fhmesh::WalkTable* w = new fhmesh::WalkTable();
+        const fhmesh::Tables& T = fhmesh::tables();
+        for (int m = 0; m < 256; m++) {
+            w->any[m][0] = w->any[m][1] = -1;
+            for (int e = 0; e < 12; e++) { w->e2v[m][e][0] = (int8_t)T.e2v[m][e][0]; w->e2v[m][e][1] = (int8_t)T.e2v[m][e][1]; }
+            for (int e = 0; e < 12; e++) if (T.e2v[m][e][0] >= 0) { w->any[m][0] = (int8_t)T.e2v[m][e][0]; w->any[m][1] = (int8_t)T.e2v[m][e][1]; break; }
+        }
+        return w;
+    }();
+    return *W;
+}
 static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
                                        bool has_mat, const float* mat, MeshTimes& T, std::string& why);
 enum MeshMode { MESH_SAMPLE, MESH_BUILD, MESH_PART };
@@ -598,6 +706,55 @@ static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t dep
     const int rc = x.err != hipSuccess ? (int)fhmesh::OCT_NO_MEMORY : fhmesh::oct_assemble(x, depth, lv.data(), (uint32_t)lv.size(), rec, n_rec, table, d_mat, &oo);
     if (rc == fhmesh::OCT_TOO_MANY_VERTICES) { why = "the octree has more than 2^32 vertices"; return give_up(hipErrorInvalidValue); }
     if (rc != fhmesh::OCT_OK || x.err != hipSuccess) return give_up(x.err != hipSuccess ? x.err : hipErrorOutOfMemory);
+    // Octree::walk_dual on the device too (mesh_walk.hpp; option mesh_device_walk, on): cells and octree vertices are read where the assembly
+    // left them, the mesh's vertices and triangles come to the host through the context's pinned landing area.  Octrees beyond its limits
+    // (2^24 blocks, 2^31 / 5 quads) and any failure fall back to the host's threads below.
+    if (ctx->opt.mesh_device_walk) {
+        WalkDevX w{ctx->stream, {}, hipSuccess};
+        fhmesh::WalkTable* d_tab = (fhmesh::WalkTable*)w.alloc(sizeof(fhmesh::WalkTable));
+        fhmesh::WalkOut wo;
+        int wrc = fhmesh::WALK_NO_MEMORY;
+        if (d_tab) {
+            w.write(d_tab, &walk_table(), sizeof(fhmesh::WalkTable));
+            wrc = fhmesh::walk_dual_passes(w, oo.cells, oo.n_blocks, oo.root, oo.verts, oo.n_verts, d_tab, &wo);
+        }
+        if (wrc == fhmesh::WALK_OK && w.err == hipSuccess) {
+            const double t_asm = now() - t0;
+            const size_t vbytes = (size_t)wo.n_verts * sizeof(fhmesh::V3), tbytes = (size_t)wo.n_tris * 24, need = ((vbytes + 255) & ~(size_t)255) + tbytes + 256;
+            if (ctx->mesh_pinned_cap < need) {
+                if (ctx->mesh_pinned) (void)hipHostFree(ctx->mesh_pinned);
+                ctx->mesh_pinned = nullptr; ctx->mesh_pinned_cap = 0;
+                if (hipHostMalloc(&ctx->mesh_pinned, need + need / 8, hipHostMallocDefault) == hipSuccess) ctx->mesh_pinned_cap = need + need / 8;
+            }
+            if (ctx->mesh_pinned_cap >= need) {
+                char* pv = (char*)ctx->mesh_pinned;
+                char* pt = pv + ((vbytes + 255) & ~(size_t)255);
+                if (vbytes) w.chk(hipMemcpyAsync(pv, wo.verts, vbytes, hipMemcpyDeviceToHost, ctx->stream));
+                if (tbytes) w.chk(hipMemcpyAsync(pt, wo.tris, tbytes, hipMemcpyDeviceToHost, ctx->stream));
+                w.chk(hipStreamSynchronize(ctx->stream));
+                if (w.err == hipSuccess) {
+                    M->vertices.resize(wo.n_verts);
+                    M->triangles.resize(wo.n_tris);
+                    const size_t CH = (size_t)4 << 20, nv_ch = (vbytes + CH - 1) / CH, nt_ch = (tbytes + CH - 1) / CH;
+                    fhmesh::parallel_for(nv_ch + nt_ch, [&](size_t i) {
+                        if (i < nv_ch) memcpy((char*)M->vertices.data() + i * CH, pv + i * CH, std::min(CH, vbytes - i * CH));
+                        else { const size_t j = i - nv_ch; memcpy((char*)M->triangles.data() + j * CH, pt + j * CH, std::min(CH, tbytes - j * CH)); }
+                    });
+                    w.release();
+                    x.release();
+                    M->octree_cells = oo.n_blocks; M->octree_verts = oo.n_verts;
+                    if (T.on)
+                        fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), assembly on the device %.4f s (%u blocks, %u vertices), "
+                                        "dual walk on the device + the mesh to the host %.4f s (%u levels, %llu items, %u quads), total %.4f s\n",
+                                depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, t_asm, oo.n_blocks, oo.n_verts, now() - t0 - t_asm,
+                                wo.levels, (unsigned long long)wo.items, wo.n_records, now() - T.t_start);
+                    return hipSuccess;
+                }
+            }
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        w.release();        // (the host's walk takes over: too big an octree for the passes' 32-bit numbers, or no memory for them)
+    }
     const size_t cell_bytes = (size_t)oo.n_blocks * 8 * sizeof(fhmesh::Cell);
     if (ctx->mesh_pinned_cap < cell_bytes + 256) {
         if (ctx->mesh_pinned) (void)hipHostFree(ctx->mesh_pinned);
@@ -821,6 +978,18 @@ void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_
     for (uint64_t i = 0; i < n_verts; i++) o.verts[i] = fhmesh::V3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
     fhmesh::TriVec t;
     fhmesh::VertVec v;
+    if (parallel == 3) {     // the passes fhip_mesh_build runs on the device (mesh_walk.hpp), here as loops on the host
+        WalkHostX hx;
+        fhmesh::WalkOut wo;
+        const int rc = fhmesh::walk_dual_passes(hx, (const fhmesh::Cell*)o.cells.data(), (uint32_t)o.cells.size(), o.root, o.verts.data(), (uint32_t)o.verts.size(), &walk_table(), &wo);
+        counts[0] = counts[1] = 0;
+        if (rc != fhmesh::WALK_OK) { counts[0] = ~0ull; return; }
+        counts[0] = wo.n_tris; counts[1] = wo.n_verts;
+        if (tris && wo.tris) memcpy(tris, wo.tris, (size_t)wo.n_tris * 24);
+        if (verts_out && wo.verts) memcpy(verts_out, wo.verts, (size_t)wo.n_verts * 12);
+        hx.free(wo.tris); hx.free(wo.verts);
+        return;
+    }
     if (parallel == 2) {     // as fhip_mesh_build runs it: the cells through a view, the octree's vertices never read - the mesh's are gathered afterwards
         fhmesh::Octree w;
         w.root = o.root;

@@ -22,6 +22,7 @@
 
 #include "dev_ops.hpp"
 #include "mesh_collapse.hpp"
+#include "mesh_walk.hpp"
 #include "mesh_edges.hpp"
 #include "mesh_qef.hpp"
 // (included by capi.hip after kernels.hip: Regs, step, ballot, uni, ctape_t)
@@ -423,4 +424,61 @@ __global__ void __launch_bounds__(256) k_oct_gather(const fhmesh::V3* verts, con
     if (i < n) out[i] = verts[idx[i]];
 }
 
+
+// ---- Octree::walk_dual on the device (mesh_walk.hpp: the recursion as level arrays, MeshBuilder's numbering by atomic minima) ----------
+__global__ void __launch_bounds__(256) k_walk_count(fhmesh::WalkTree o, const fhmesh::WalkItem* items, uint32_t n, uint32_t* cnt, uint32_t* live) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fhmesh::WalkItem k = items[i];
+    cnt[i] = fhmesh::wk_count(o, k);
+    if ((k.hdr & 3u) != fhmesh::WK_REC) *live = 1;      // (every writer writes the same value)
+}
+__global__ void __launch_bounds__(256) k_walk_expand(fhmesh::WalkTree o, const fhmesh::WalkItem* items, uint32_t n, const uint32_t* off, fhmesh::WalkItem* next) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t at = off[i];
+    if (off[i + 1] == at) return;
+    fhmesh::wk_expand(o, items[i], next + at);
+}
+__global__ void __launch_bounds__(256) k_walk_first(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // one thread per reference: 5 per record
+    if (i >= n * 5u) return;
+    atomicMin(&first[recs[i / 5u].a[i % 5u]], i);
+}
+__global__ void __launch_bounds__(256) k_walk_rec_counts(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, uint32_t* nn, uint32_t* nt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fhmesh::wk_rec_counts(recs[i], i, first, &nn[i], &nt[i]);
+}
+__global__ void __launch_bounds__(256) k_walk_rec_number(const fhmesh::WalkItem* recs, uint32_t n, uint32_t* first, const uint32_t* vb, const fhmesh::V3* octree_verts, fhmesh::V3* verts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fhmesh::wk_rec_number(recs[i], i, first, vb[i], octree_verts, verts);
+}
+__global__ void __launch_bounds__(256) k_walk_rec_triangles(const fhmesh::WalkItem* recs, uint32_t n, const uint32_t* first, const uint32_t* tb, uint64_t* tris) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fhmesh::wk_rec_triangles(recs[i], first, tb[i], tris);
+}
+// exclusive prefix sums: out[i] = in[0] + .. + in[i - 1] for i in [0, n] (in[n] is not read), a block of 256 threads over 2048 elements;
+// sums[block] = the block's total; k_scan_add adds the (already scanned) block totals back
+constexpr uint32_t FH_SCAN_PER_BLOCK = 2048;
+__global__ void __launch_bounds__(256) k_scan_block(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* sums) {
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * FH_SCAN_PER_BLOCK + threadIdx.x * 8u;
+    uint32_t v[8], s = 0;
+    for (uint32_t k = 0; k < 8; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t k = 0; k < 8; k++) { if (base + k <= n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255 && sums) sums[blockIdx.x] = part[255];
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* out, uint32_t n, const uint32_t* block_off) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) out[i] += block_off[i / FH_SCAN_PER_BLOCK];
+}
 }  // namespace fhm

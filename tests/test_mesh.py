@@ -441,6 +441,23 @@ def test_device_assembly_equals_the_host_assembly(model, depth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 9), ("colonnade.vm", 8), ("bear.vm", 7), ("prospero.vm", 7), ("tanglecube.vm", 6)])
+def test_device_dual_walk_equals_the_host_walk(model, depth):
+    """fhip_mesh_build walks the dual on the device (mesh_walk.hpp: the recursion as level arrays in call order, MeshBuilder's numbering
+    by atomic minima and prefix sums); with the option off, the host's threads walk the octree copied out of HBM.  Same triangles, same
+    vertices, in the same order - at sizes far beyond the oracle's reach (gyroid-sphere at depth 9: 12.8 M triangles)."""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(model_path(model))
+    assert shape.hip.option("mesh_device_walk") == 1
+    tris, verts, counts = F.mesh(shape, depth)
+    with shape.hip.options(mesh_device_walk=0):
+        t2, v2, c2 = F.mesh(shape, depth)
+    assert counts == c2 and len(tris) > 1000
+    assert tris.shape == t2.shape and (tris == t2).all()
+    assert verts.shape == v2.shape and (verts.view(np.uint32) == v2.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 7), ("bear.vm", 6)])
 def test_device_mesh_transcendental_models_identical(model, depth, oracle_mod):
     """BASELINE configuration 5's model (and bear.vm): triangles and vertices identical to the oracle's, element for element - sin / cos /
@@ -485,7 +502,9 @@ def test_library_dual_walk_sequential_and_parallel(model, depth, threads, oracle
     ref_t, ref_v = oc.walk_dual()
     kinds = {"Invalid": 0, "Empty": 1, "Full": 2, "Branch": 3, "Leaf": 4}
     root = np.array([kinds[oc.root[0]], oc.root[1], oc.root[2]], np.uint32)
-    for parallel, th in ((0, threads), (1, threads), (2, threads), (2, 1)):     # 2: as fhip_mesh_build walks - cells through a view, the mesh's vertices gathered
+    # 2: the host's walk as fhip_mesh_build ran it - cells through a view, the mesh's vertices gathered; 3: the passes fhip_mesh_build runs on
+    # the device (mesh_walk.hpp: the recursion as level arrays, numbering by minima and prefix sums), here as loops on the host
+    for parallel, th in ((0, threads), (1, threads), (2, threads), (2, 1), (3, 1)):
         monkeypatch.setenv("FHIP_MESH_THREADS", str(th))
         t, v = F.debug_walk_dual(oc.cells, root, oc.verts, parallel)
         assert len(ref_t) > 1000
