@@ -112,7 +112,7 @@ struct fhip_ctx : FrameBufs {
     // the sets of the frames before the current one: a frame takes the set used longest ago (ring of 1 + FH_EXTRA_SETS).  Three
     // sets: one frame alone takes ~1.5 ms from its first coarse-level kernel to its image, so with two sets - a set is free
     // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way (a fourth set: measured, no gain)
-#define FH_EXTRA_SETS 2
+#define FH_EXTRA_SETS 4
     FrameBufs others[FH_EXTRA_SETS];
     uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
     bool frame_pipeline = true;
