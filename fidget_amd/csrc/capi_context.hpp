@@ -32,7 +32,17 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+        // (FHIP_SIDE_CUS=n, experiment, fixed at creation: the side stream - level 1 of the coarse levels, one wave per parent - alone on n
+        // compute units, the pre-pass and tail streams on the others; such streams are BLOCKING ones - the runtime has no other kind with a
+        // mask - so only for callers that do not render on the null stream)
+        const int n_side = std::min(c->opt.side_cus, c->n_cu - 8);
+        if (n_side > 0) {
+            uint32_t m[16] = {0}, inv[16] = {0};
+            for (int i = 0; i < c->n_cu; i++) (i < n_side ? m : inv)[i / 32] |= 1u << (i % 32);
+            const uint32_t words = (uint32_t)((c->n_cu + 31) / 32);
+            if (hipExtStreamCreateWithCUMask(&c->stream2, words, m) != hipSuccess || hipExtStreamCreateWithCUMask(&c->stream3, words, inv) != hipSuccess ||
+                hipExtStreamCreateWithCUMask(&c->stream_pre, words, inv) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+        } else if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
@@ -42,8 +52,8 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     for (auto& o : c->others) (void)hipEventCreateWithFlags(&o.ev_done, hipEventDisableTiming);
-    if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-    {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
+    if (!c->stream3 && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    if (!c->stream_pre) {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const int pp = c->opt.pre_priority;

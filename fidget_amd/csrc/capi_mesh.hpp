@@ -507,9 +507,31 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             ck(edge_count.ensure(4));
             if (e != hipSuccess) return e;
             ck(hipMemsetAsync(edge_count.p, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(fhm::k_mesh_corners, dim3((cnt + 7) / 8), dim3(WAVE), lds_f32, ctx->stream, P, cells, cnt, (const FhMdcTable*)table.p, recs,
-                               (uint32_t*)edge_count.p, (uint32_t*)edge_list.p);
-            ck(hipGetLastError());
+            if (bulk_edges) {      // the corners through the assembly bulk interpreter too (k_mesh_corners: 48 of a 350 ms build through the generic one)
+                const uint32_t np = cnt * 8u;
+                ck(edge_vars.ensure((size_t)n_slots * np * 4));
+                ck(edge_vals.ensure((size_t)np * 4));
+                if (e != hipSuccess) return e;
+                for (uint32_t sl = 0; sl < n_slots; sl++)
+                    if (P.in_kind[sl] >= 3) {
+                        hipLaunchKernelGGL(fhm::k_mesh_fill, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, (float*)edge_vars.p + (size_t)sl * np, P.in_value[sl], np);
+                        ck(hipGetLastError());
+                    }
+                hipLaunchKernelGGL(fhm::k_mesh_corner_points, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, P, cells, cnt, (float*)edge_vars.p);
+                ck(hipGetLastError());
+                struct { const uint64_t* tape; const float* vars; float* out; uint32_t len, n; } kc = {tape->d_ops, (const float*)edge_vars.p, (float*)edge_vals.p, P.len, np};
+                const bool plain_c = tape_asm_ok(t);
+                const uint32_t per_c = P.n_regs <= 16 ? 256 : 128;
+                const int which_c = P.n_regs <= 16 ? (plain_c ? FH_ASM_FLOAT_16x4 : FH_ASM_FLOAT_16x4_T) : (plain_c ? FH_ASM_FLOAT_32x2 : FH_ASM_FLOAT_32x2_T);
+                ck(launch_asm(ctx, which_c, (np + per_c - 1) / per_c, &kc, sizeof(kc)));
+                hipLaunchKernelGGL(fhm::k_mesh_corner_masks, dim3((cnt + 7) / 8), dim3(WAVE), 0, ctx->stream, cells, cnt, (const float*)edge_vals.p, (const FhMdcTable*)table.p, recs,
+                                   (uint32_t*)edge_count.p, (uint32_t*)edge_list.p);
+                ck(hipGetLastError());
+            } else {
+                hipLaunchKernelGGL(fhm::k_mesh_corners, dim3((cnt + 7) / 8), dim3(WAVE), lds_f32, ctx->stream, P, cells, cnt, (const FhMdcTable*)table.p, recs,
+                                   (uint32_t*)edge_count.p, (uint32_t*)edge_list.p);
+                ck(hipGetLastError());
+            }
             uint32_t n_edges = 0;
             ck(hipMemcpyAsync(&n_edges, edge_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             ck(hipStreamSynchronize(ctx->stream));

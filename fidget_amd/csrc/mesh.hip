@@ -236,6 +236,53 @@ __global__ void __launch_bounds__(WAVE) k_mesh_corners(FhMeshParams P, const FhM
     for (uint32_t e = cr; e < ne; e += 8) edge_list[base + before + e] = (li << 4) | e;
 }
 
+// The corners as passes around the assembly bulk interpreter, like the edge search (capi_mesh.hpp sample_chunk): k_mesh_corner_points writes the
+// chunk's 8 n corner points as the interpreter's [slot][8 n] arrays (after xf_point when there is a matrix: what eval_point does), the
+// interpreter evaluates them, k_mesh_corner_masks does the rest of k_mesh_corners from the values - same points, same f32 evaluator
+// semantics (tests/test_render_random.py drives every opcode through both), so the same masks and records.
+__global__ void __launch_bounds__(256) k_mesh_corner_points(FhMeshParams P, const FhMeshCell* cells, uint32_t n, float* vars) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 8u) return;
+    const FhMeshCell c = cells[i >> 3];
+    const uint32_t cr = i & 7u;
+    float x = (cr & 1) ? c.b[1] : c.b[0], y = (cr & 2) ? c.b[3] : c.b[2], z = (cr & 4) ? c.b[5] : c.b[4];
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int q = 0; q < 16; q++) m.m[q] = P.mat[q];
+        xf_point(m, x, y, z, x, y, z);
+    }
+    const size_t np = (size_t)n * 8;
+    for (uint32_t s = 0; s < FH_MAX_INPUTS; s++) {
+        const uint32_t kd = P.in_kind[s];
+        if (kd < 3) vars[(size_t)s * np + i] = kd == 0 ? x : (kd == 1 ? y : z);
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_mesh_corner_masks(const FhMeshCell* cells, uint32_t n, const float* values, const FhMdcTable* T, FhMeshLeaf* out,
+                                                             uint32_t* edge_count, uint32_t* edge_list /* (cell << 4) | edge */) {
+    const int lane = threadIdx.x, cr = lane & 7;
+    const uint32_t li = blockIdx.x * 8 + (lane >> 3);
+    const bool act = li < n;
+    const FhMeshCell c = cells[act ? li : n - 1];
+    const float v = values[(size_t)(act ? li : n - 1) * 8 + cr];
+    const uint32_t mask = (uint32_t)((ballot(v < 0.0f) >> (lane & ~7)) & 0xFFull);
+    const uint32_t ne = (mask == 0 || mask == 255) ? 0u : T->n_edges[mask];
+    uint32_t before = 0, total = 0;
+    for (int g = 0; g < 8; g++) {
+        const uint32_t ng = (uint32_t)__shfl((int)(act ? ne : 0u), g * 8);
+        if (g < (lane >> 3)) before += ng;
+        total += ng;
+    }
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(edge_count, total);
+    base = uni(base);
+    if (!act) return;
+    FhMeshLeaf* o = &out[li];
+    if (cr < 6) o->b[cr] = c.b[cr];
+    if (cr == 0) { o->path = c.path; o->mask = mask; o->n_edges = ne; o->n_verts = ne ? T->n_verts[mask] : 0u; o->pad = 0; }
+    for (uint32_t e = cr; e < ne; e += 8) edge_list[base + before + e] = (li << 4) | e;
+}
+
 __global__ void __launch_bounds__(WAVE) k_mesh_edges(FhMeshParams P, const FhMdcTable* T, FhMeshLeaf* out, const uint32_t* edge_list, uint32_t n_edges) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x, grp = lane >> 4;
