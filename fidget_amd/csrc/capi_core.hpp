@@ -63,7 +63,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_cus, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 3)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -195,4 +195,55 @@ static void launch(fhip_ctx* ctx, int klass, F&& f) {
     } else {
         f();
     }
+}
+
+// VmData::simplify (vm/data.rs:123-318) on the host: the reverse sweep over `p` with one choice per min / max / and / or op (in tape
+// order), dense re-allocation of the registers (lowest free first).  false: a choice was Unknown.  (fhip_simplify; the mesher's tape
+// simplification at its split level, capi_mesh.hpp)
+static bool simplify_host(const fh::HostTape& p, const uint8_t* choices, fh::HostTape& out) {
+    std::vector<int> map(FH_MAX_REGS, -1);
+    fh::RegPool pool;
+    std::vector<uint64_t> rev;
+    uint32_t ci = p.n_choices, kept = 0;
+    auto use = [&](uint32_t r) { if (map[r] < 0) map[r] = pool.take(); return (uint32_t)map[r]; };
+    for (size_t k = p.ops.size(); k-- > 0;) {
+        const uint64_t w = p.ops[k];
+        const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+        const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
+        const bool is_choice = fh_is_choice(op);
+        uint32_t c = FH_CHOICE_BOTH;
+        if (is_choice) {
+            c = choices[--ci];
+            if (c == FH_CHOICE_UNKNOWN) return false;
+        }
+        if (op == FH_OUTPUT) { rev.push_back(fh_pack(op, 0, use(ra), 0, w1)); continue; }
+        const int no = map[ro];
+        if (no < 0) continue;
+        map[ro] = -1;
+        int alias = -1;
+        bool copy_imm = false;
+        if (op == FH_COPY_REG) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_LEFT) alias = (int)ra;
+        else if (is_choice && c == FH_CHOICE_RIGHT) { if (fh_is_rr(op)) alias = (int)rb; else copy_imm = true; }
+        if (alias >= 0) {
+            if (map[alias] < 0) { map[alias] = no; continue; }
+            pool.give(no);
+            rev.push_back(fh_pack(FH_COPY_REG, no, map[alias], 0, 0));
+            continue;
+        }
+        pool.give(no);
+        if (copy_imm) { rev.push_back(fh_pack(FH_COPY_IMM, no, 0, 0, w1)); continue; }
+        uint32_t na = 0, nb = 0;
+        if (op != FH_INPUT && op != FH_COPY_IMM) na = use(ra);
+        if (fh_is_rr(op)) nb = use(rb);
+        if (is_choice) kept++;
+        rev.push_back(fh_pack(op, no, na, nb, w1));
+    }
+    out.ops.assign(rev.rbegin(), rev.rend());
+    out.n_regs = pool.high;
+    out.n_choices = kept;
+    out.n_outputs = p.n_outputs;
+    out.n_vars = p.n_vars;  // children keep the parent's variable slots (vm/data.rs:316)
+    out.vars = p.vars;
+    return true;
 }

@@ -81,6 +81,7 @@ struct fhip_mesh {
     fhmesh::VertVec vertices;                            // fhip_mesh_build: Mesh::vertices
     fhmesh::TriVec triangles;                            // ... Mesh::triangles
     uint64_t octree_cells = 0, octree_verts = 0;
+    uint64_t sub_tapes = 0, sub_ops = 0;                 // tapes simplified at the split level and their ops together (0: the root tape everywhere)
     uint32_t depth = 0, part = 0, n_parts = 1;           // fhip_mesh_sample_part: which of the root's octants this one covers
 };
 // Assembly of the octree from the device's results, as Octree::recurse unwinds (octree.rs:556-583), then Octree::walk_dual
@@ -416,6 +417,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         const int d = ctx->device & 63;
         if (!attr_done[d]) {
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_cells, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
+            (void)hipFuncSetAttribute((const void*)fhm::k_mesh_choices, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX - 2048);
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_corners, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
             (void)hipFuncSetAttribute((const void*)fhm::k_mesh_edges, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
@@ -429,13 +431,14 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
-    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals;
+    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals, sub_ops, sub_tab, sub_choices;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
         bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
         edge_list.release(); edge_count.release(); edge_br.release(); edge_vars.release(); edge_vals.release();
+        sub_ops.release(); sub_tab.release(); sub_choices.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
     };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -445,6 +448,11 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     root.path = 1;
     MESH_TRY(bufs[0].ensure(sizeof(FhMeshCell)));
     MESH_TRY(hipMemcpyAsync(bufs[0].p, &root, sizeof(root), hipMemcpyHostToDevice, ctx->stream));
+    // (option mesh_simplify_min_ops, default 256: shorter tapes are evaluated as they are - gyroid-sphere's 28 ops gain nothing and keep the
+    // assembly bulk interpreter for their leaf samples; 0 = never.  The level: 4 - 4 096 cells at most, a 16th of the region across, where
+    // prospero.vm's 6 363 ops are down to a few hundred - or two above the leaves of a shallower octree)
+    const uint32_t split_level = (ctx->opt.mesh_simplify_min_ops > 0 && t.ops.size() >= (size_t)ctx->opt.mesh_simplify_min_ops && t.n_choices > 0 && depth >= 3)
+                                     ? std::min<uint32_t>(4, depth - 2) : 0;
     uint32_t n_in = 1;      // cells in bufs[cur] to evaluate (level 0) or whose 8 children to evaluate
     int cur = 0;
     uint32_t n_leaf_cells = 0;
@@ -480,9 +488,48 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
         lv_n_amb.push_back(c[0]);
         if (d == depth) n_leaf_cells = c[0];
         if (n_in == 0) break;
+        if (d == split_level && split_level > 0) {
+            // Tape simplification down the octree (octree.rs:546-553), once: the choices of the root tape over every ambiguous cell of this
+            // level (k_mesh_choices), VmData::simplify under them on the host's threads, the simplified tapes back as one array with a
+            // table indexed by the cell's path; every launch from here on gives a lane the tape of its cell's ancestor at this level.
+            const uint32_t na = c[0], nch = t.n_choices;
+            MESH_TRY(sub_choices.ensure((size_t)na * nch));
+            hipLaunchKernelGGL(fhm::k_mesh_choices, dim3((na + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)out_cells.p, na, nch, (uint8_t*)sub_choices.p);
+            MESH_TRY(hipGetLastError());
+            std::vector<uint8_t> ch((size_t)na * nch);
+            std::vector<FhMeshCell> amb(na);
+            MESH_TRY(hipMemcpyAsync(ch.data(), sub_choices.p, ch.size(), hipMemcpyDeviceToHost, ctx->stream));
+            MESH_TRY(hipMemcpyAsync(amb.data(), out_cells.p, (size_t)na * sizeof(FhMeshCell), hipMemcpyDeviceToHost, ctx->stream));
+            MESH_TRY(hipStreamSynchronize(ctx->stream));
+            std::vector<fh::HostTape> sub(na);
+            std::vector<uint8_t> ok(na, 0);
+            fhmesh::parallel_for(na, [&](size_t j) { ok[j] = simplify_host(t, ch.data() + j * nch, sub[j]) ? 1 : 0; });
+            const size_t n_tab = (size_t)1 << (3 * split_level);
+            std::vector<uint2> tab(n_tab, make_uint2(0, 0));
+            std::vector<uint64_t> ops;
+            for (uint32_t j = 0; j < na; j++) {
+                if (!ok[j] || sub[j].ops.empty() || sub[j].ops.size() >= t.ops.size()) continue;     // (nothing gained: the root tape)
+                const uint64_t idx = amb[j].path - ((uint64_t)1 << (3 * split_level));
+                if (idx >= n_tab) continue;
+                tab[(size_t)idx] = make_uint2((uint32_t)ops.size(), (uint32_t)sub[j].ops.size());
+                ops.insert(ops.end(), sub[j].ops.begin(), sub[j].ops.end());
+                M->sub_tapes++; M->sub_ops += sub[j].ops.size();
+            }
+            if (!ops.empty()) {
+                MESH_TRY(sub_ops.ensure(ops.size() * 8));
+                MESH_TRY(sub_tab.ensure(n_tab * sizeof(uint2)));
+                MESH_TRY(hipMemcpyAsync(sub_ops.p, ops.data(), ops.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                MESH_TRY(hipMemcpyAsync(sub_tab.p, tab.data(), n_tab * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+                MESH_TRY(hipStreamSynchronize(ctx->stream));
+                P.sub_ops = (const uint64_t*)sub_ops.p; P.sub_tab = (const uint2*)sub_tab.p; P.split_level = split_level;
+            }
+        }
     }
     M->ambiguous_leaves = n_leaf_cells;
     t_cells = now() - t_start;
+    if (times && M->sub_tapes)
+        fprintf(stderr, "fhip mesh: tape simplified at level %u: %llu cells with tapes of their own, %.1f ops on average (root tape: %zu)\n", split_level,
+                (unsigned long long)M->sub_tapes, (double)M->sub_ops / (double)M->sub_tapes, t.ops.size());
     FhMdcTable mdc;
     if (n_leaf_cells || dev_asm) {
         build_mdc_table(mdc);
@@ -495,7 +542,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     const char* const lp_env = getenv("FHIP_MESH_LEAF_PASSES");        // diagnostic: 0 = k_mesh_leaf, the kernel the passes are checked against
     const bool leaf_passes = !(lp_env && lp_env[0] == '0');
     const char* const be_env = getenv("FHIP_MESH_BULK_EDGES");          // diagnostic: 0 = the edge search by k_mesh_edges (the generic interpreter)
-    const bool bulk_edges = leaf_passes && ctx->use_asm && P.n_regs <= 32 && !(be_env && be_env[0] == '0');
+    const bool bulk_edges = leaf_passes && ctx->use_asm && P.n_regs <= 32 && !(be_env && be_env[0] == '0') && !P.sub_tab;     // (one tape per launch)
     uint32_t n_slots = std::max<uint32_t>(t.n_vars, 1);
     for (uint32_t sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) n_slots = std::max(n_slots, sl + 1);
     const size_t lds_f32 = (size_t)P.n_regs * WAVE * 4;

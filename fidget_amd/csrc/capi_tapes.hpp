@@ -186,51 +186,8 @@ fhip_status fhip_simplify(fhip_ctx* ctx, const fhip_tape* tape, const uint8_t* c
                           fhip_tape** child) {
     const fh::HostTape& p = tape->t;
     if (n_choices != p.n_choices) return fail(ctx, FHIP_ERR_BAD_CHOICE_SLICE, "choice slice length mismatch");
-    std::vector<int> map(FH_MAX_REGS, -1);
-    fh::RegPool pool;
-    std::vector<uint64_t> rev;
-    uint32_t ci = n_choices, kept = 0;
-    auto use = [&](uint32_t r) { if (map[r] < 0) map[r] = pool.take(); return (uint32_t)map[r]; };
-    for (size_t k = p.ops.size(); k-- > 0;) {
-        const uint64_t w = p.ops[k];
-        const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
-        const uint32_t op = FH_W_OP(w0), ro = FH_W_OUT(w0), ra = FH_W_A(w0), rb = w1;
-        const bool is_choice = fh_is_choice(op);
-        uint32_t c = FH_CHOICE_BOTH;
-        if (is_choice) {
-            c = choices[--ci];
-            if (c == FH_CHOICE_UNKNOWN) return fail(ctx, FHIP_ERR_BAD_CHOICE_SLICE, "Choice::Unknown in trace");
-        }
-        if (op == FH_OUTPUT) { rev.push_back(fh_pack(op, 0, use(ra), 0, w1)); continue; }
-        const int no = map[ro];
-        if (no < 0) continue;
-        map[ro] = -1;
-        int alias = -1;
-        bool copy_imm = false;
-        if (op == FH_COPY_REG) alias = (int)ra;
-        else if (is_choice && c == FH_CHOICE_LEFT) alias = (int)ra;
-        else if (is_choice && c == FH_CHOICE_RIGHT) { if (fh_is_rr(op)) alias = (int)rb; else copy_imm = true; }
-        if (alias >= 0) {
-            if (map[alias] < 0) { map[alias] = no; continue; }
-            pool.give(no);
-            rev.push_back(fh_pack(FH_COPY_REG, no, map[alias], 0, 0));
-            continue;
-        }
-        pool.give(no);
-        if (copy_imm) { rev.push_back(fh_pack(FH_COPY_IMM, no, 0, 0, w1)); continue; }
-        uint32_t na = 0, nb = 0;
-        if (op != FH_INPUT && op != FH_COPY_IMM) na = use(ra);
-        if (fh_is_rr(op)) nb = use(rb);
-        if (is_choice) kept++;
-        rev.push_back(fh_pack(op, no, na, nb, w1));
-    }
     fhip_tape* t = new fhip_tape();
-    t->t.ops.assign(rev.rbegin(), rev.rend());
-    t->t.n_regs = pool.high;
-    t->t.n_choices = kept;
-    t->t.n_outputs = p.n_outputs;
-    t->t.n_vars = p.n_vars;  // children keep the parent's variable slots (vm/data.rs:316)
-    t->t.vars = p.vars;
+    if (!simplify_host(p, choices, t->t)) { delete t; return fail(ctx, FHIP_ERR_BAD_CHOICE_SLICE, "Choice::Unknown in trace"); }
     *child = t;
     return FHIP_OK;
 }

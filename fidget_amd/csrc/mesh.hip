@@ -10,8 +10,9 @@
 //   k_mesh_leaf   the same with one wavefront per leaf cell (FHIP_MESH_LEAF_PASSES=0; what the passes are checked against);
 //   k_mesh_leaf_qef  one lane per leaf record: one QEF per cell vertex (qef.rs).
 //
-// Every cell is evaluated with the shape's own tape (values do not depend on tape simplification); pruning
-// the tape down the octree as the render's tile stage does is the next step for large tapes.
+// Tapes of 256 ops and more are simplified once down the octree (FhMeshParams::sub_tab: at the split level every ambiguous cell gets the root
+// tape simplified under its own choices, and everything below it is evaluated with that - values do not depend on which ancestor's tape
+// evaluates a cell); small tapes are evaluated as they are, the leaf samples through the assembly bulk interpreter.
 //
 //   k_oct_kind / k_oct_collapse / k_oct_place / k_oct_leaf_verts   the octree assembled from those results without leaving HBM
 //                 (octree.rs:256-470 check_done / collapsible, 866-1035 merged Hermite data; mesh_collapse.hpp): level by level
@@ -34,12 +35,30 @@ struct FhMeshParams {
     uint32_t has_mat;
     uint32_t in_kind[FH_MAX_INPUTS];
     float in_value[FH_MAX_INPUTS];
+    // Tape simplification down the octree (octree.rs:546-553, RenderHints::simplify_tree_during_meshing): once, at `split_level` - every
+    // ambiguous cell there has a simplified tape of its own (VmData::simplify of the root tape under the cell's choices), which all the
+    // cells and leaf samples below it use.  sub_tab[path of the ancestor at split_level - 8^split_level] = {offset into sub_ops, ops};
+    // ops == 0 / sub_tab == null: the root tape.  (Values do not depend on which of an ancestor's tapes evaluates a cell: a min / max
+    // decided over the ancestor's region is decided the same way everywhere inside it.)
+    const uint64_t* sub_ops;
+    const uint2* sub_tab;
+    uint32_t split_level, pad_;
 };
 
 namespace fhm {
 using namespace fhd;
 
 using fhmesh::lerp_pos;
+
+// the tape of the cell with this path (3 bits per level below a leading 1)
+__device__ __forceinline__ void mesh_tape(const FhMeshParams& P, uint64_t path, const uint64_t*& ops, uint32_t& len) {
+    ops = P.tape; len = P.len;
+    if (!P.sub_tab) return;
+    const int up = (63 - __clzll((long long)path)) - 3 * (int)P.split_level;
+    if (up <= 0) return;          // (at the split level itself a cell is still evaluated with the tape it inherited)
+    const uint2 e = P.sub_tab[(uint32_t)((path >> up) - (1ull << (3 * P.split_level)))];
+    if (e.y) { ops = P.sub_ops + e.x; len = e.y; }
+}
 
 // interval evaluation + classification of the cells of one level.  expand: cell i is child (i & 7) of in[i >> 3]
 __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMeshCell* in, uint32_t n, int expand, FhMeshCell* out, uint32_t* counters /* amb, full, empty */,
@@ -71,12 +90,14 @@ __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMes
     }
     Regs<IV, WAVE> R{(IV*)smem, lane};
     IV result = iv_nan();
-    const ctape_t tape = (ctape_t)P.tape;
-    for (uint32_t k = 0; k < P.len; k++) {
-        step<IVAL, WAVE, true>(
-            tape[k], R,
-            [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); },
-            [&](uint32_t, IV v) { result = v; }, [&](int) {});
+    auto in_iv = [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); };
+    if (P.sub_tab) {       // every lane its cell's tape (a wave's cells mostly share an ancestor: their parents were neighbours)
+        const uint64_t* ops; uint32_t len;
+        mesh_tape(P, c.path, ops, len);
+        for (uint32_t k = 0; k < len; k++) step<IVAL, WAVE, true>(ops[k], R, in_iv, [&](uint32_t, IV v) { result = v; }, [&](int) {});
+    } else {
+        const ctape_t tape = (ctape_t)P.tape;
+        for (uint32_t k = 0; k < P.len; k++) step<IVAL, WAVE, true>(tape[k], R, in_iv, [&](uint32_t, IV v) { result = v; }, [&](int) {});
     }
     const bool full = act && result.hi < 0.0f, empty = act && !full && result.lo > 0.0f, amb = act && !full && !empty;
     const uint64_t am = ballot(amb);
@@ -96,8 +117,35 @@ __global__ void __launch_bounds__(WAVE) k_mesh_cells(FhMeshParams P, const FhMes
     if (i < n && cls) { cls[i] = !act ? 0 : (full ? 2 : (empty ? 1 : 3)); slot[i] = sl; }
 }
 
+// The choices of the root tape over each of n cells (the ambiguous cells of the split level): choices[cell * n_choices + ordinal] = what the
+// interval evaluation decided at that min / max / and / or (vm/mod.rs:436-517), for VmData::simplify on the host (capi_mesh.hpp)
+__global__ void __launch_bounds__(WAVE) k_mesh_choices(FhMeshParams P, const FhMeshCell* cells, uint32_t n, uint32_t n_choices, uint8_t* choices) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * WAVE + lane;
+    const FhMeshCell c = cells[min(i, n - 1)];
+    IV X = iv(c.b[0], c.b[1]), Y = iv(c.b[2], c.b[3]), Z = iv(c.b[4], c.b[5]);
+    if (P.has_mat) {
+        Mat4 m;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m.m[k] = P.mat[k];
+        xf_interval(m, X, Y, Z, X, Y, Z);
+    }
+    Regs<IV, WAVE> R{(IV*)smem, lane};
+    uint8_t* const mine = choices + (size_t)min(i, n - 1) * n_choices;
+    uint32_t ci = 0;
+    const ctape_t tape = (ctape_t)P.tape;
+    for (uint32_t k = 0; k < P.len; k++) {
+        step<IVAL, WAVE, true>(
+            tape[k], R,
+            [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); },
+            [&](uint32_t, IV) {}, [&](int ch) { if (i < n) mine[ci] = (uint8_t)ch; ci++; });
+    }
+}
+
 // f32 value of the tape at this lane's point (lanes evaluate different points of the same leaf)
-__device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<float, WAVE>& R, float x, float y, float z) {
+// (path: the leaf cell's, which says whose simplified tape to take when the octree was split, FhMeshParams)
+__device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<float, WAVE>& R, float x, float y, float z, uint64_t path) {
     if (P.has_mat) {
         Mat4 m;
 #pragma unroll
@@ -105,11 +153,29 @@ __device__ __forceinline__ float eval_point(const FhMeshParams& P, const Regs<fl
         xf_point(m, x, y, z, x, y, z);
     }
     float result = qnan();
-    const ctape_t tape = (ctape_t)P.tape;
-    for (uint32_t k = 0; k < P.len; k++) {
-        step<F32, WAVE, true>(
-            tape[k], R, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? x : (kd == 1 ? y : (kd == 2 ? z : P.in_value[slot])); },
-            [&](uint32_t, float v) { result = v; }, [&](int) {});
+    auto in_f = [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? x : (kd == 1 ? y : (kd == 2 ? z : P.in_value[slot])); };
+    if (P.sub_tab) {
+        const uint64_t* ops; uint32_t len;
+        mesh_tape(P, path, ops, len);
+        for (uint32_t k = 0; k < len; k++) step<F32, WAVE, true>(ops[k], R, in_f, [&](uint32_t, float v) { result = v; }, [&](int) {});
+    } else {
+        const ctape_t tape = (ctape_t)P.tape;
+        for (uint32_t k = 0; k < P.len; k++) step<F32, WAVE, true>(tape[k], R, in_f, [&](uint32_t, float v) { result = v; }, [&](int) {});
+    }
+    return result;
+}
+// ... and its gradient there
+template <class GX>
+__device__ __forceinline__ GR eval_grad(const FhMeshParams& P, const Regs<GR, WAVE>& G, const GX& gx, const GX& gy, const GX& gz, uint64_t path) {
+    GR result = gr1(qnan());
+    auto in_g = [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot]))); };
+    if (P.sub_tab) {
+        const uint64_t* ops; uint32_t len;
+        mesh_tape(P, path, ops, len);
+        for (uint32_t k = 0; k < len; k++) step<GRAD, WAVE, true>(ops[k], G, in_g, [&](uint32_t, GR v) { result = v; }, [&](int) {});
+    } else {
+        const ctape_t tape = (ctape_t)P.tape;
+        for (uint32_t k = 0; k < P.len; k++) step<GRAD, WAVE, true>(tape[k], G, in_g, [&](uint32_t, GR v) { result = v; }, [&](int) {});
     }
     return result;
 }
@@ -124,7 +190,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
     Regs<float, WAVE> R{(float*)smem, lane};
     // corners (cell.rs:196-206): bit 0 x, 1 y, 2 z
     const int cr = lane & 7;
-    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4]);
+    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4], c.path);
     const uint32_t mask = (uint32_t)(ballot(v < 0.0f) & 0xFFull);
     FhMeshLeaf* o = &out[li];
     if (lane < 6) o->b[lane] = c.b[lane];
@@ -151,7 +217,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
             const uint32_t ee = valid ? e : 0;
             uint32_t p[3];
             for (int k = 0; k < 3; k++) p[k] = ((uint32_t)s_start[ee][k] * (15u - j) + (uint32_t)s_end[ee][k] * j) / 15u;
-            const float r = eval_point(P, R, lerp_pos(c.b[0], c.b[1], p[0]), lerp_pos(c.b[2], c.b[3], p[1]), lerp_pos(c.b[4], c.b[5], p[2]));
+            const float r = eval_point(P, R, lerp_pos(c.b[0], c.b[1], p[0]), lerp_pos(c.b[2], c.b[3], p[1]), lerp_pos(c.b[4], c.b[5], p[2]), c.path);
             const uint64_t nonneg = ballot(r >= 0.0f);
             const uint32_t m16 = (uint32_t)(nonneg >> ((lane >> 4) * 16)) & 0xFFFFu;
             uint32_t frac = m16 ? (uint32_t)__builtin_ctz(m16) : 16u;
@@ -184,13 +250,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_leaf(FhMeshParams P, const FhMesh
         }
         __syncthreads();
         Regs<GR, WAVE> G{(GR*)smem, lane};
-        GR result = gr1(qnan());
-        const ctape_t tape = (ctape_t)P.tape;
-        for (uint32_t k = 0; k < P.len; k++) {
-            step<GRAD, WAVE, true>(
-                tape[k], G, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot]))); },
-                [&](uint32_t, GR v) { result = v; }, [&](int) {});
-        }
+        const GR result = eval_grad(P, G, gx, gy, gz, c.path);
         if (lane < (int)ne) {
             for (int k = 0; k < 3; k++) o->inter[lane][k] = q[k];
             o->pos[lane][0] = px; o->pos[lane][1] = py; o->pos[lane][2] = pz;
@@ -216,7 +276,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_corners(FhMeshParams P, const FhM
     const bool act = li < n;
     const FhMeshCell c = cells[act ? li : n - 1];
     Regs<float, WAVE> R{(float*)smem, lane};
-    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4]);
+    const float v = eval_point(P, R, (cr & 1) ? c.b[1] : c.b[0], (cr & 2) ? c.b[3] : c.b[2], (cr & 4) ? c.b[5] : c.b[4], c.path);
     const uint32_t mask = (uint32_t)((ballot(v < 0.0f) >> (lane & ~7)) & 0xFFull);
     const uint32_t ne = (mask == 0 || mask == 255) ? 0u : T->n_edges[mask];
     // this wave's edges: one reservation in the list, the cells' shares in cell order
@@ -310,7 +370,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_edges(FhMeshParams P, const FhMdc
     for (int round = 0; round < 4; round++) {       // N-ary search: 16 points per round (octree.rs:697-768)
         uint32_t p[3];
         for (int q = 0; q < 3; q++) p[q] = (s[q] * (15u - j) + t[q] * j) / 15u;
-        const float r = eval_point(P, R, lerp_pos(b[0], b[1], p[0]), lerp_pos(b[2], b[3], p[1]), lerp_pos(b[4], b[5], p[2]));
+        const float r = eval_point(P, R, lerp_pos(b[0], b[1], p[0]), lerp_pos(b[2], b[3], p[1]), lerp_pos(b[4], b[5], p[2]), o->path);
         const uint32_t m16 = (uint32_t)(ballot(r >= 0.0f) >> (grp * 16)) & 0xFFFFu;
         uint32_t frac = m16 ? (uint32_t)__builtin_ctz(m16) : 16u;
         if (frac == 0) frac = 1;
@@ -399,13 +459,7 @@ __global__ void __launch_bounds__(WAVE) k_mesh_grads(FhMeshParams P, FhMeshLeaf*
         xf_grad(m, gx, gy, gz, gx, gy, gz);
     }
     Regs<GR, WAVE> G{(GR*)smem, lane};
-    GR result = gr1(qnan());
-    const ctape_t tape = (ctape_t)P.tape;
-    for (uint32_t q = 0; q < P.len; q++) {
-        step<GRAD, WAVE, true>(
-            tape[q], G, [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? gx : (kd == 1 ? gy : (kd == 2 ? gz : gr1(P.in_value[slot]))); },
-            [&](uint32_t, GR v) { result = v; }, [&](int) {});
-    }
+    const GR result = eval_grad(P, G, gx, gy, gz, o->path);
     if (valid) { o->grad[e][0] = result.dx; o->grad[e][1] = result.dy; o->grad[e][2] = result.dz; o->grad[e][3] = result.v; }
 }
 

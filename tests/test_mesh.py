@@ -441,6 +441,30 @@ def test_device_assembly_equals_the_host_assembly(model, depth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("prospero.vm", 7), ("colonnade.vm", 8), ("bear.vm", 7), ("prospero.vm", 3), ("colonnade.vm", 4)])
+def test_tape_simplification_down_the_octree_leaves_the_mesh_unchanged(model, depth):
+    """Tapes of 256 ops and more are simplified once on the way down (octree.rs:546-553; capi_mesh.hpp: at level min(4, depth - 2) every
+    ambiguous cell gets the root tape simplified under its own choices, and the cells and leaf samples below it are evaluated with that);
+    with the option at 0 everything is evaluated with the root tape, as until round 3.  A min / max decided over a cell is decided the
+    same way everywhere inside it, so the two builds give the same cells, the same leaf records and the same mesh - bit for bit."""
+    import fidget_amd as F
+    shape = F.Shape.from_vm(model_path(model))
+    assert shape.hip.option("mesh_simplify_min_ops") == 256 and len(shape) >= 256
+    tris, verts, counts = F.mesh(shape, depth)
+    with shape.hip.options(mesh_simplify_min_ops=0):
+        t2, v2, c2 = F.mesh(shape, depth)
+    assert counts == c2
+    assert tris.shape == t2.shape and (tris == t2).all()
+    assert verts.shape == v2.shape and (verts.view(np.uint32) == v2.view(np.uint32)).all()
+    a, ca = F.mesh_sample(shape, min(depth, 6))
+    with shape.hip.options(mesh_simplify_min_ops=0):
+        b, cb = F.mesh_sample(shape, min(depth, 6))
+    assert ca == cb and len(a) == len(b)
+    a, b = a[np.argsort(a["path"], kind="stable")], b[np.argsort(b["path"], kind="stable")]
+    assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 9), ("colonnade.vm", 8), ("bear.vm", 7), ("prospero.vm", 7), ("tanglecube.vm", 6)])
 def test_device_dual_walk_equals_the_host_walk(model, depth):
     """fhip_mesh_build walks the dual on the device (mesh_walk.hpp: the recursion as level arrays in call order, MeshBuilder's numbering
