@@ -81,6 +81,7 @@ struct fhip_mesh {
     fhmesh::VertVec vertices;                            // fhip_mesh_build: Mesh::vertices
     fhmesh::TriVec triangles;                            // ... Mesh::triangles
     uint64_t octree_cells = 0, octree_verts = 0;
+    uint64_t sub_skipped = 0;                            // ... or how many there would have been, when they were not worth using
     uint64_t sub_tapes = 0, sub_ops = 0;                 // tapes simplified at the split level and their ops together (0: the root tape everywhere)
     uint32_t depth = 0, part = 0, n_parts = 1;           // fhip_mesh_sample_part: which of the root's octants this one covers
 };
@@ -515,6 +516,12 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                 ops.insert(ops.end(), sub[j].ops.begin(), sub[j].ops.end());
                 M->sub_tapes++; M->sub_ops += sub[j].ops.size();
             }
+            // ... where it pays: the lanes of a wave then walk tapes of their own through the generic interpreter, and a tape that fits the
+            // assembly bulk interpreter (<= 32 registers) gives that up for its leaf samples - bear.vm's smooth blend keeps 3/4 of its ops
+            // at this level and meshes twice as fast WITHOUT (measured, profiles/r04g); prospero.vm keeps 1/20 and gains 16x
+            const double kept = M->sub_tapes ? (double)M->sub_ops / ((double)M->sub_tapes * (double)t.ops.size()) : 1.0;
+            const bool bulk_capable = ctx->use_asm && P.n_regs <= 32;
+            if (kept >= (bulk_capable ? 0.25 : 0.75)) { ops.clear(); M->sub_skipped = M->sub_tapes; M->sub_tapes = 0; }
             if (!ops.empty()) {
                 MESH_TRY(sub_ops.ensure(ops.size() * 8));
                 MESH_TRY(sub_tab.ensure(n_tab * sizeof(uint2)));
@@ -527,9 +534,10 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     }
     M->ambiguous_leaves = n_leaf_cells;
     t_cells = now() - t_start;
-    if (times && M->sub_tapes)
-        fprintf(stderr, "fhip mesh: tape simplified at level %u: %llu cells with tapes of their own, %.1f ops on average (root tape: %zu)\n", split_level,
-                (unsigned long long)M->sub_tapes, (double)M->sub_ops / (double)M->sub_tapes, t.ops.size());
+    if (times && (M->sub_tapes || M->sub_skipped))
+        fprintf(stderr, "fhip mesh: tape simplified at level %u: %llu cells with tapes of their own, %.1f ops on average (root tape: %zu)%s\n", split_level,
+                (unsigned long long)(M->sub_tapes + M->sub_skipped), (double)M->sub_ops / (double)(M->sub_tapes + M->sub_skipped), t.ops.size(),
+                M->sub_skipped ? " - not used: too little gained" : "");
     FhMdcTable mdc;
     if (n_leaf_cells || dev_asm) {
         build_mdc_table(mdc);
