@@ -452,7 +452,7 @@ class Interp:
             def body(fn=op.lower()):
                 self.read_a(VT)
                 self.idx_off()
-                if self.wide_trans and fn in ("sin", "cos", "exp", "ln") and self.zb % 4 == 0:
+                if self.zb % 4 == 0 and ((self.wide_trans is True and fn in ("sin", "cos", "exp", "ln")) or (self.wide_trans == "sincos" and fn in ("sin", "cos"))):
                     for j0 in range(0, self.zb, 4):       # four samples per call (gen_trans.FUNCS4)
                         for k in range(4):
                             a(f"\tv_mov_b32 v{self.t_base + k}, {VT[j0 + k]}")
@@ -1262,6 +1262,7 @@ def gen_bulk(a, nr, zb, off, trans=None):
     if trans:
         it.t_base = FILE + nr * zb
         it.t_prefix = f"fh_tb{nr}_"
+        it.wide_trans = "sincos"     # four samples per call for sin / cos (they fit the 26-register window: the mesher's gyroid is made of them)
     kernel_header(a, name, 32, n_vgpr)
     a(f"""
 	s_load_dwordx2 {S_TAPE}, {S_KERNARG}, 0x0
@@ -1288,7 +1289,7 @@ def gen_bulk(a, nr, zb, off, trans=None):
     it.emit()
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans, v_base=it.t_base, prefix=it.t_prefix)
+        gen_trans.embed(a, trans, v_base=it.t_base, prefix=it.t_prefix, wide="sincos")
     return name
 
 

@@ -91,8 +91,10 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
     must stay even-aligned pairs), the return address always to s[96:97]; wide: also the four-sample routines FUNCS4, and a window of
     WIDE_V registers"""
     txt = open(path).read()
-    for f in FUNCS + (FUNCS4 if wide else []):
+    # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
+    extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
+    for f in FUNCS + extra:
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f
         a(f"\t.p2align 6\n{prefix}{f}:")
-        a(_rename(m.group(1), f, v_base, prefix, s_map, WIDE_V if wide else MAX_V))
+        a(_rename(m.group(1), f, v_base, prefix, s_map, WIDE_V if wide is True else MAX_V))
