@@ -455,8 +455,9 @@ def main():
         # PRIMARY: the dominant kernel of the general path (what a model with z in its tapes gets) - with that path's own frame time,
         # rate and latency inside the object, so that a record that keeps `roofline` keeps them
         result["roofline"] = dict(max((r for r in (r_leaf, r_tiles, r_l1, r_prune) if r), key=per_frame))
-        result["roofline"]["path_frame"] = {"path": "general (column-invariance short cuts off)", "ms_per_step": general["ms_per_step"],
-                                            "value": general["value"], "unit": "Mvoxel/s", "frame_latency_ms": general["frame_latency_ms"]}
+        gp = general or {"ms_per_step": ms_per_step, "value": value, "frame_latency_ms": lat_default}      # (--only-general: the timed frames are the general path's)
+        result["roofline"]["path_frame"] = {"path": "general (column-invariance short cuts off)", "ms_per_step": gp["ms_per_step"],
+                                            "value": gp["value"], "unit": "Mvoxel/s", "frame_latency_ms": gp["frame_latency_ms"]}
         result["roofline_leaf"], result["roofline_tiles"], result["roofline_tiles_l1"], result["roofline_prune"] = r_leaf, r_tiles, r_l1, r_prune
     if prof_default:
         d_leaf, d_tiles, d_l1, d_prune = roofs(prof_default, "default")

@@ -462,12 +462,12 @@ def test_tape_simplification_down_the_octree_leaves_the_mesh_unchanged(model, de
     assert ca == cb and len(a) == len(b)
     a, b = a[np.argsort(a["path"], kind="stable")], b[np.argsort(b["path"], kind="stable")]
     for f in ("path", "bounds", "mask", "n_edges", "n_verts"):
-        assert (a[f].view(np.uint8) == b[f].view(np.uint8)).all(), f
+        assert np.ascontiguousarray(a[f]).tobytes() == np.ascontiguousarray(b[f]).tobytes(), f
     ne, nv = a["n_edges"].astype(np.int64), a["n_verts"].astype(np.int64)
     used_e, used_v = np.arange(12)[None, :] < ne[:, None], np.arange(a["vert"].shape[1])[None, :] < nv[:, None]       # (the slots a record uses; the rest is whatever the buffer held)
     for f in ("inter", "pos", "grad"):
-        assert (a[f][used_e].view(np.uint8) == b[f][used_e].view(np.uint8)).all(), f
-    assert (a["vert"][used_v].view(np.uint8) == b["vert"][used_v].view(np.uint8)).all()
+        assert np.ascontiguousarray(a[f][used_e]).tobytes() == np.ascontiguousarray(b[f][used_e]).tobytes(), f
+    assert np.ascontiguousarray(a["vert"][used_v]).tobytes() == np.ascontiguousarray(b["vert"][used_v]).tobytes()
 
 
 @pytest.mark.gpu
