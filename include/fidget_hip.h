@@ -218,10 +218,12 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
                              const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out);
 /* fidget_mesh::Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225; Settings: depth, world_to_model): fhip_mesh_sample, then
  * the octree assembled from the device's results - cell collapse (check_done / try_collapse, octree.rs:256-385) with the merged
- * Hermite data included - ON THE DEVICE, level by level (neither the leaf records nor the octree's vertices leave HBM: the host
- * receives the octree's blocks of cells, and the vertices the walk finds the mesh to use), and the dual walk (dc.rs) on the host's threads (independent sub-walks; FHIP_MESH_THREADS, default:
- * all cores up to 32 - more were measured slower) -> Mesh { vertices, triangles } (lib.rs:64-69): the cells, vertices and
- * triangles of the single-threaded recursion, in its order.  Context option "mesh_device_assembly" 0: the assembly on the
+ * Hermite data included - ON THE DEVICE, level by level, and the dual walk (dc.rs, builder.rs) on the device too: the recursion's calls
+ * as level arrays in call order, MeshBuilder's numbering by first use through atomic minima and prefix sums (neither the leaf records
+ * nor the octree leave HBM: the host receives the mesh) -> Mesh { vertices, triangles } (lib.rs:64-69): the cells, vertices and
+ * triangles of the single-threaded recursion, in its order.  Tapes of 256 ops and more are simplified once on the way down
+ * (octree.rs:546-553; option "mesh_simplify_min_ops", 0 = never): the mesh does not depend on it.  Context option "mesh_device_walk" 0:
+ * the walk on the host's threads (independent sub-walks; FHIP_MESH_THREADS, default: all cores up to 32); "mesh_device_assembly" 0: the assembly on the
  * host's threads too (independent subtrees, as build_inner_mt octree.rs:94-210), from copies of the levels and the leaf records -
  * the path fhip_mesh_merge takes; same per-cell functions, same octree.  The leaf records are not kept with the mesh
  * (fhip_mesh_leaves after a build copies nothing). */
