@@ -47,6 +47,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_l0, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_l1, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
     if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
@@ -93,6 +94,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->ev_rest_join) (void)hipEventDestroy(c->ev_rest_join);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_l0) (void)hipEventDestroy(c->ev_l0);
+    if (c->ev_l1) (void)hipEventDestroy(c->ev_l1);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
     mesh_cache_release(c->mesh_octree_cache);

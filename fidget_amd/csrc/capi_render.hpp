@@ -804,15 +804,36 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     // carries level 1 + the (now few) slab steps of its own frame.  (A frame alone sees no difference: the same chain.)
     const bool l1_side = fpipe && ctx->opt.l1_on_side && pre > 1 && ctx->stream2 && !ctx->opt.pipe_serial &&
                          ctx->use_pipeline && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
+    // (option side_only_l1, on: the side stream - the busiest one of a pipelined frame, 0.43 ms of the 0.526 - carries level 1's evaluate + prune
+    // launches and nothing else: the flags of level 1's tapes are set at the end of the root level on the pre-pass stream, and what follows
+    // level 1 - the flags of its children, the frame mark, the fork of the slab contexts - goes to the stream the tile chains run on)
+    // (only for frames whose tile chains will run on the tail stream - `tiles_first` below, the same conditions: a frame with heavy leaf
+    // kernels keeps its tile chains on the side stream, and its fork must not queue behind the previous frame's tail work)
+    bool l1_only = false;
+    if (l1_side && ctx->opt.side_only_l1 && pre == 2 && ctx->stream3 && ctx->opt.tail_stream == 1 && R.asm_points) {
+        const bool pipe_plan = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
+        const uint32_t nc_plan = pipe_plan ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;
+        bool inv = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
+        for (uint64_t w : tape->t.ops)
+            if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { inv = false; break; }
+        l1_only = pipe_plan && (ctx->opt.tiles_stream == 1 || (ctx->opt.tiles_stream == 2 && inv)) && R.slab_hi - R.slab_lo <= nc_plan;
+    }
     if (pre && n_groups) {  // coarse levels of every slab in one go
         for (uint32_t l = 0; l < pre; l++) {
+            const bool flags_here = R.zrep && l > 0;
             if (l == 1 && l1_side) {
+                if (flags_here && l1_only) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream_pre));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_l0, 0));
                 ctx->stream = ctx->stream2;
             }
-            if (R.zrep && l > 0) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
             launch_tiles(ctx, R, dS, (int)l, true);
+        }
+        if (l1_only) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_l1, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_l1, 0));
+            ctx->stream = ctx->stream3;
         }
         if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
         launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
