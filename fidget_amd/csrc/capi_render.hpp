@@ -520,7 +520,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u), R.S.troot_len, R.S.troot_choices,
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u) | (ctx->opt.chain_prio ? 4u : 0u), R.S.troot_len, R.S.troot_choices,
                                    (uint32_t)FH_P2_MAX_KEPT);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
@@ -601,7 +601,15 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 const bool linked = R.prune2_l1 && !per_slab;
                 const uint32_t plain_flags = ka.flags;
                 if (linked) ka.flags = (ka.flags & 0xFFFFu) | 2u | (((R.S.P.max_choices + 15) / 16) << 16);
+                // (option chain_prio, on: level 1 of the coarse chain at issue priority 3 - its waves are dependent chains on SIMDs they
+                // share with the other streams' kernels in a pipelined frame)
+                if (ctx->opt.chain_prio && !per_slab) ka.flags |= 0x200u;
                 (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V64_T : FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
+                if (ctx->post_v64_stream && !per_slab && !big_stream) {      // (side_only_l1: the level's remaining launches - the LDS layouts' rest, the push - leave the side stream)
+                    (void)hipEventRecord(ctx->ev_l1, ctx->stream);
+                    (void)hipStreamWaitEvent(ctx->post_v64_stream, ctx->ev_l1, 0);
+                    ctx->stream = ctx->post_v64_stream;
+                }
                 ka.flags = plain_flags & ~16u;
                 ka.skip_regs = V64_REGS; ka.skip_choices = V64_CHOICES;
                 rest = R.S.P.max_regs > V64_REGS || R.S.P.max_choices > V64_CHOICES;
@@ -755,9 +763,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     const bool huge = (size_t)std::max<uint32_t>(tape->t.n_regs, 1) * WAVE * 16 > FH_LDS_MAX || tiles_lds(std::max<uint32_t>(tape->t.n_regs, 1), tape->t.n_choices, 64) > FH_LDS_MAX;
     const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial && !huge;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    bool frames_queued = false;     // the frame before this one is still under way (the caller queues frames back to back)
     if (fpipe) {
         // (rotate: the current set goes to the back of the ring, the set used longest ago comes forward)
         for (uint32_t i = 0; i < ctx->extra_sets; i++) std::swap(static_cast<FrameBufs&>(*ctx), ctx->others[i]);
+        frames_queued = ctx->extra_sets > 0 && ctx->others[0].ev_done_valid && hipEventQuery(ctx->others[0].ev_done) == hipErrorNotReady;
+        (void)hipGetLastError();
         ctx->stream = ctx->stream_pre;
         if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
     }
@@ -828,9 +839,11 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                 ctx->stream = ctx->stream2;
             }
             if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            ctx->post_v64_stream = (l == 1 && l1_only) ? ctx->stream3 : nullptr;
             launch_tiles(ctx, R, dS, (int)l, true);
+            ctx->post_v64_stream = nullptr;
         }
-        if (l1_only) {
+        if (l1_only && ctx->stream != ctx->stream3) {      // (level 1 did not go through fh_tiles_v64: switch here)
             HIP_TRY(ctx, hipEventRecord(ctx->ev_l1, ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_l1, 0));
             ctx->stream = ctx->stream3;
@@ -930,7 +943,12 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         // beside the leaf kernel of the NEXT slab: the normals kernel only takes hits of its own slab's depth range, and a hit
         // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
         const int tail_mode = ctx->opt.tail_stream;   // 0: off, 1: lists + normals, 2: normals only
-        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points;   // (the HIP leaf kernels walk the footprint lists)
+        // (option tail_on_main - 0 never, 1 always, 2 when frames are queued back to back: when the tile chains run on the tail stream, the
+        // slab's small kernels stay on the caller's stream around its leaf kernel - otherwise the tail stream, serial, waits for every leaf
+        // kernel with the NEXT frame's tile chains queued behind: 0.45 ms of it per frame for 0.40 of work.  A frame alone is 70 us
+        // quicker with them beside its leaf kernels, hence the test)
+        const bool on_main = tiles_first && (ctx->opt.tail_on_main == 1 || (ctx->opt.tail_on_main == 2 && frames_queued));
+        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
             launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });

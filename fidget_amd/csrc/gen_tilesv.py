@@ -720,6 +720,18 @@ class TilesV(Tiles):
 	v_lshlrev_b32 {V_L8}, 3, {V_LANE}
 	v_lshlrev_b32 {V_L4}, 2, {V_LANE}
 	s_waitcnt lgkmcnt(0)
+	; flags bits 9:8: this launch's waves raise their issue priority (s_setprio 3 / 1).  A level of the coarse chain is a few hundred
+	; one-wave parents, each a dependent chain that sets the level's time; beside the other streams' kernels of a pipelined frame
+	; their SIMDs are shared, and the arbiter otherwise hands a chain wave its turn round robin with thousands of throughput waves
+	s_bitcmp1_b32 s101, 9
+	s_cbranch_scc0 {p}_prio_lo
+	s_setprio 3
+	s_branch {p}_prio_done
+{p}_prio_lo:
+	s_bitcmp1_b32 s101, 8
+	s_cbranch_scc0 {p}_prio_done
+	s_setprio 1
+{p}_prio_done:
 	s_mov_b32 {S_LEVEL}, s8
 	s_mov_b32 {S_BIG}, s9
 	s_mov_b32 {S_MAXCH}, s11

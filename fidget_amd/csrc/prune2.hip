@@ -395,6 +395,10 @@ __global__ void __launch_bounds__(256) k_prune2(FhRenderState* S, uint32_t level
                                                 const uint2* __restrict__ links, const uint2* __restrict__ ctab, uint32_t emit_links,
                                                 uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (emit_links bit 2: the waves of the root level's prune at issue priority 2 - one-wave dependent chains on SIMDs they share with the
+    // other streams' kernels in a pipelined frame; level 1's kernel takes 3, capi_render.hpp option chain_prio)
+    if (emit_links & 4u) __builtin_amdgcn_s_setprio(2);
+    emit_links &= 3u;
     const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
     const bool both = big == 2;
     const uint32_t n1 = both ? fhp2::rfl(S->n_slots[1][level]) * per_slot : 0u;

@@ -475,6 +475,9 @@ class Wave:
         self.count("salu")
         self.issue += int(n, 0)
 
+    def i_s_setprio(self, i, n):
+        self.count("salu")      # (issue priority within the SIMD: nothing to model for one wave)
+
     def i_s_waitcnt(self, i, *a):
         self.count("salu")
 
