@@ -96,6 +96,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->ev_l0) (void)hipEventDestroy(c->ev_l0);
     if (c->ev_l1) (void)hipEventDestroy(c->ev_l1);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
+    c->mesh_leaves.release();
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
     mesh_cache_release(c->mesh_octree_cache);
     free(c->mesh_first);

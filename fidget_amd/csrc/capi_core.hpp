@@ -109,9 +109,11 @@ struct FrameBufs {
 };
 struct fhip_ctx : FrameBufs {
     FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
-    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of 1 + FH_EXTRA_SETS).  Three
-    // sets: one frame alone takes ~1.5 ms from its first coarse-level kernel to its image, so with two sets - a set is free
-    // again when its frame is complete - no more than two frames per 1.5 ms could ever be under way (a fourth set: measured, no gain)
+    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of up to 1 + FH_EXTRA_SETS; option
+    // frame_sets, default 4).  A set is free again when its frame is complete, and a pipelined frame takes ~1.5 ms from its first
+    // coarse-level kernel to its image: the period cannot be shorter than that over the number of sets.  Three were enough while the tail
+    // stream bounded the pipeline; since round 4 (capi_render.hpp tail_on_main) three give frames of 0.44 / 0.59 / 0.48 ms in turn, four
+    // 0.49 each, five the same (profiles/r04k)
 #define FH_EXTRA_SETS 4
     FrameBufs others[FH_EXTRA_SETS];
     uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
@@ -142,6 +144,8 @@ struct fhip_ctx : FrameBufs {
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
     DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[8];   // pinned (upload_frame)
+    DevBuf mesh_leaves;               // fhip_mesh_build / fhip_mesh_sample: the leaf records in HBM (17 GB at depth 10), kept between builds - allocating and freeing
+                                      // them per build cost 10-20 ms of every build and, once in a few, two seconds (profiles/r04a, r04h)
     void* mesh_pinned = nullptr;      // fhip_mesh_build: the leaf records' landing area on the host, kept between calls (pinning 17 GB takes over a second)
     size_t mesh_pinned_cap = 0;
     // ... and the two largest host-side temporaries of the assembly, kept for the same reason (fresh memory of that size is

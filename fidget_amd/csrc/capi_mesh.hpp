@@ -432,12 +432,13 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
-    DevBuf bufs[2], counters, table, leaves, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals, sub_ops, sub_tab, sub_choices;
+    DevBuf& leaves = ctx->mesh_leaves;      // (kept with the context between builds)
+    DevBuf bufs[2], counters, table, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals, sub_ops, sub_tab, sub_choices;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
-        bufs[0].release(); bufs[1].release(); counters.release(); table.release(); leaves.release(); d_cls.release(); d_slot.release();
+        bufs[0].release(); bufs[1].release(); counters.release(); table.release(); d_cls.release(); d_slot.release();
         edge_list.release(); edge_count.release(); edge_br.release(); edge_vars.release(); edge_vals.release();
         sub_ops.release(); sub_tab.release(); sub_choices.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
