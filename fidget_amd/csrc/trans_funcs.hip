@@ -27,8 +27,9 @@ typedef float fh_f4 __attribute__((ext_vector_type(4)));
 #define FH_T4(name, fn) FH_NI fh_f4 fh_t_##name##4(fh_f4 a) { fh_f4 r; for (int k = 0; k < 4; k++) r[k] = fhd::fn(a[k]); return r; }
 FH_T4(sin, t_sin)
 FH_T4(cos, t_cos)
-FH_T4(exp, t_exp)
-FH_T4(ln, t_ln)
+// (exp / ln: the four main paths as one block - the table loads go out together - and the rare cases behind one test, trans_libm.hpp)
+FH_NI fh_f4 fh_t_exp4(fh_f4 a) { float x[4] = {a[0], a[1], a[2], a[3]}, r[4]; fhlm::expf4_<fhlm::MemTables>(x, r); return fh_f4{r[0], r[1], r[2], r[3]}; }
+FH_NI fh_f4 fh_t_ln4(fh_f4 a) { float x[4] = {a[0], a[1], a[2], a[3]}, r[4]; fhlm::logf4_<fhlm::MemTables>(x, r); return fh_f4{r[0], r[1], r[2], r[3]}; }
 FH_NI float fh_t_mod(float a, float b) { return fhd::rem_euclid(a, b); }
 // (a kernel that references them keeps the functions in the device image)
 __global__ void fh_trans_keep(float* p) {

@@ -153,10 +153,10 @@ FHLM float sincosf_(float y) {
 }
 
 // ---- expf (e_expf.c) ----
+// the library's main path, for every argument (what it returns for |x| >= 88 or NaN is replaced by expf_fix_)
 template <class Tab>
-FHLM float expf_(float x) {
+FHLM float expf_main_(float x) {
     const double xd = (double)x;
-    const uint32_t xi = f2u(x), abstop = (xi >> 20) & 0x7ff;
     // x * N / ln2 = k + r; the source's `z = InvLn2N * xd; kd = z + SHIFT; ...; r = z - kd` compiles to two fused operations
     const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+5;
     double kd = fma_(InvLn2N, xd, SHIFT);
@@ -170,9 +170,12 @@ FHLM float expf_(float x) {
     double y = fma_(0x1.62e42ff0c52d6p-6, r, 1.0);
     y = fma_(z, r2, y);
     y = y * s;
-    float res = (float)y;
-    // |x| >= 88 or NaN (abstop >= 0x42b) - as selects, taken by the comparisons themselves: no branch, so that the four-sample routine
-    // is one block and its table loads are issued together
+    return (float)y;
+}
+FHLM bool expf_special_(float x) { return ((f2u(x) >> 20) & 0x7ff) >= 0x42b; }  // |x| >= 88 or NaN
+// ... as selects, taken by the comparisons themselves (no branch: for arguments that are not special nothing changes)
+FHLM float expf_fix_(float x, float res) {
+    const uint32_t xi = f2u(x), abstop = (xi >> 20) & 0x7ff;
     res = x < -0x1.9d1d9ep6f ? u2f(1u) : res;          // __math_may_uflowf: 0x1.4p-75f squared = the smallest subnormal
     res = x < -0x1.9fe368p6f ? 0.0f : res;             // underflow
     res = x > 0x1.62e42ep6f ? u2f(0x7f800000u) : res;  // overflow
@@ -180,13 +183,22 @@ FHLM float expf_(float x) {
     res = xi == 0xff800000u ? 0.0f : res;
     return res;
 }
+template <class Tab>
+FHLM float expf_(float x) { return expf_fix_(x, expf_main_<Tab>(x)); }
+// four samples: the main paths as one block (its table loads are issued together), the rare cases behind ONE test
+template <class Tab>
+FHLM void expf4_(const float* x, float* r) {
+    for (int k = 0; k < 4; k++) r[k] = expf_main_<Tab>(x[k]);
+    if (expf_special_(x[0]) | expf_special_(x[1]) | expf_special_(x[2]) | expf_special_(x[3]))
+        for (int k = 0; k < 4; k++) r[k] = expf_fix_(x[k], r[k]);
+}
 
 // ---- logf (e_logf.c) ----
+FHLM bool logf_special_(uint32_t ix) { return ix - 0x00800000u >= 0x7f800000u - 0x00800000u; }  // x < 2^-126, inf or NaN
 template <class Tab>
-FHLM float logf_(float x) {
+FHLM float logf_main_(float x) {
     const uint32_t ix0 = f2u(x);
-    const bool special = ix0 - 0x00800000u >= 0x7f800000u - 0x00800000u;  // x < 2^-126, inf or NaN
-    const uint32_t ix = special ? f2u(x * 0x1p23f) - (23u << 23) : ix0;  // subnormal: normalise
+    const uint32_t ix = logf_special_(ix0) ? f2u(x * 0x1p23f) - (23u << 23) : ix0;  // subnormal: normalise
     const uint32_t tmp = ix - 0x3f330000u;
     const uint32_t i = (tmp >> 19) & 15;
     const int k = (int32_t)tmp >> 23;
@@ -199,13 +211,25 @@ FHLM float logf_(float x) {
     double y = fma_(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);  // A[1] * r + A[2]
     y = fma_(-0x1.00ea348b88334p-2, r2, y);                            // A[0] * r2 + y
     y = fma_(y, r2, y0 + r);
-    float res = (float)y;
-    const uint32_t ix1 = opaque_(ix0);  // (= ix0: the comparisons below are made here, not kept from above)
-    // x < 2^-126, inf or NaN - as selects (no branch: see expf_)
-    res = (ix1 - 0x00800000u >= 0x7f800000u - 0x00800000u && ((ix1 & 0x80000000u) || ix1 * 2 >= 0xff000000u)) ? nan_() : res;
+    return (float)y;
+}
+// x < 2^-126, inf, NaN, and x = 1 (which the library answers before anything else) - as selects
+FHLM float logf_fix_(float x, float res) {
+    const uint32_t ix1 = opaque_(f2u(x));  // (the comparisons below are made here, not kept from the main path)
+    res = (logf_special_(ix1) && ((ix1 & 0x80000000u) || ix1 * 2 >= 0xff000000u)) ? nan_() : res;
     res = ix1 == 0x7f800000u ? x : res;
     res = ix1 * 2 == 0 ? u2f(0xff800000u) : res;  // log(+-0) = -inf
     return ix1 == 0x3f800000u ? 0.0f : res;
+}
+template <class Tab>
+FHLM float logf_(float x) { return logf_fix_(x, logf_main_<Tab>(x)); }
+template <class Tab>
+FHLM void logf4_(const float* x, float* r) {
+    for (int k = 0; k < 4; k++) r[k] = logf_main_<Tab>(x[k]);
+    bool any = false;
+    for (int k = 0; k < 4; k++) { const uint32_t ix = opaque_(f2u(x[k])); any = any | logf_special_(ix) | (ix == 0x3f800000u); }
+    if (any)
+        for (int k = 0; k < 4; k++) r[k] = logf_fix_(x[k], r[k]);
 }
 
 // ---- fdlibm routines: binary32 arithmetic, one rounding per operation (no fused multiply-add anywhere) ----

@@ -211,7 +211,7 @@ def test_render3d_reference_bench_camera_full_size():
 
 @pytest.mark.gpu
 def test_render3d_frames_in_flight():
-    """Asynchronous renders are pipelined across frames (two buffer sets per context, the coarse levels of frame n + 1
+    """Asynchronous renders are pipelined across frames (four buffer sets per context, the coarse levels of frame n + 1
     beside the slabs of frame n): a queue of frames of different shapes, sizes and cameras, nothing waited for in between,
     gives the images the oracle gives, every one of them; a synchronous render in the middle of the queue as well."""
     import torch
@@ -238,6 +238,37 @@ def test_render3d_frames_in_flight():
         assert ((an == b["normal"]) | (np.isnan(an) & np.isnan(b["normal"]))).all(), f"frame {i} ({m} {n}): normals differ"
     b = O.render3d(oshape["tanglecube.vm"], 64)[0]
     assert (mid["depth"] == b["depth"]).all() and same_bits_f32(mid["normal"], b["normal"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"FHIP_FRAME_SETS": "2"}, {"FHIP_FRAME_SETS": "3", "FHIP_TAIL_ON_MAIN": "1"}, {"FHIP_FRAME_SETS": "5", "FHIP_TAIL_ON_MAIN": "0"},
+                                 {"FHIP_SIDE_ONLY_L1": "0", "FHIP_TAIL_ON_MAIN": "1"}, {"FHIP_CHAIN_PRIO": "1"}, {"FHIP_TILES_STREAM": "0"}, {"FHIP_NO_COLUMN_INV": "1"}])
+def test_render3d_frames_in_flight_under_the_pipeline_options(env, monkeypatch):
+    """The frame pipeline's switches (buffer sets 2..5, where the slab's small kernels run, what the side stream carries, issue priority,
+    where the tile chains run, the column-invariance short cuts) decide WHEN and WHERE a frame's kernels run, never what they compute: a
+    queue of frames of different shapes, sizes and cameras gives the oracle's images under every setting (round 4 changed three defaults)."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)          # (a context reads the environment once, when it is created)
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    for k, v in env.items():
+        assert hip.option(k[5:].lower()) == int(v)
+    jobs = [("prospero.vm", 512, None), ("colonnade.vm", 256, bench_camera(0.3)), ("prospero.vm", 1024, None), ("tanglecube.vm", 128, None),
+            ("prospero.vm", 1024, None), ("colonnade.vm", 512, None), ("prospero.vm", 256, bench_camera(0.15))]
+    shapes = {m: F.Shape.from_vm(model_path(m), hip=hip) for m, _, _ in jobs}
+    outs = [torch.zeros((n, n, 4), dtype=torch.int32, device="cuda") for _, n, _ in jobs]
+    for rep in range(3):
+        for i, (m, n, cam) in enumerate(jobs):
+            F.render3d(shapes[m], n, world_to_model=cam, out=outs[i])
+    torch.cuda.synchronize()
+    hip.sync()
+    oshape = {m: O.Shape.from_vm(model_path(m)) for m in shapes}
+    for i, (m, n, cam) in enumerate(jobs):
+        b = O.render3d(oshape[m], n, world_to_model=cam)[0]
+        a = outs[i].cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        assert (a[:, :, 3] == b["depth"]).all(), f"frame {i} ({m} {n}): {(a[:, :, 3] != b['depth']).sum()} depths differ"
+        an = a[:, :, :3].copy().view(np.float32)
+        assert ((an == b["normal"]) | (np.isnan(an) & np.isnan(b["normal"]))).all(), f"frame {i} ({m} {n}): normals differ"
 
 
 @pytest.mark.gpu

@@ -10,12 +10,16 @@
 
 using namespace fhlm;
 typedef float (*fn1)(float);
+// the four-sample routines of the leaf interpreter, through one of their samples (the others: fixed ordinary arguments)
+static float exp4_first(float x) { const float a[4] = {x, 1.5f, -3.25f, 20.0f}; float r[4]; expf4_<MemTables>(a, r); return r[0]; }
+static float ln4_last(float x) { const float a[4] = {2.5f, 0.75f, 1.0e-3f, x}; float r[4]; logf4_<MemTables>(a, r); return r[3]; }
 struct Case { const char* name; fn1 mine, ref; };
 
 int main(int argc, char** argv) {
     const Case cases[] = {
         {"sin", sincosf_<MemTables, false>, sinf}, {"cos", sincosf_<MemTables, true>, cosf},
         {"exp", expf_<MemTables>, expf},           {"ln", logf_<MemTables>, logf},
+        {"exp4", exp4_first, expf},                {"ln4", ln4_last, logf},
 #ifdef FHLM_HAVE_FDLIBM
         {"tan", tanf_<MemTables>, tanf},           {"asin", asinf_, asinf}, {"acos", acosf_, acosf}, {"atan", atanf_, atanf},
 #endif
