@@ -531,8 +531,8 @@ def main():
         if args.model == "prospero.vm" and os.path.exists(os.path.join(ROOT, "models", "gyroid-sphere.vm")):
             try:
                 import subprocess
-                env = dict(os.environ, MESH_TIMES_REPS="3")
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=180)
+                env = dict(os.environ, MESH_TIMES_REPS="5")     # (the best of four builds after the first: one build in a few is slower by 0.2 s, one in eight by 2 s - DESIGN.md section 9)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=240)
                 c5 = parse_mesh_times(r.stdout, r.stderr) if r.returncode == 0 else None
                 result["c5_mesh"] = c5 if c5 else {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
             except Exception as e:      # (a time-out included: the line's other fields do not depend on this leg)

@@ -3,7 +3,7 @@
 # bench.py ties to the render sources' hash), the bench line, the other configurations, the mesh timings.  usage: gpurun -- 'bash tools/round_final.sh [tag]'
 # (what the letter-named calls of round 4 ran is in DESIGN.md next to their results under profiles/r04*)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04n}
+TAG=${1:-r04p}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -15,7 +15,7 @@ cp gpurun_out/prof_$TAG/*.csv gpurun_out/prof_$TAG/*.txt gpurun_out/prof_$TAG/*.
 export ROUND_TAG=$TAG
 timeout -k 5 400 python bench.py > $O/bench.json 2> $O/bench.err; python - <<'PY'
 import json,os
-d=json.loads(open(os.path.join(os.environ["GRAFT_REPO_ROOT"],"gpurun_out/"+os.environ.get("ROUND_TAG","r04n")+"/bench.json")).read().strip().split("\n")[-1])
+d=json.loads(open(os.path.join(os.environ["GRAFT_REPO_ROOT"],"gpurun_out/"+os.environ.get("ROUND_TAG","r04p")+"/bench.json")).read().strip().split("\n")[-1])
 print({k:d[k] for k in ("value","ms_per_step","frame_latency_ms","host_output_frame_ms")}, d["general"]["ms_per_step"], d["general"]["frame_latency_ms"], d["c3_bear"], d["parity"], d["c5_mesh"])
 print(json.dumps(d["roofline"])[:900])
 PY
