@@ -765,9 +765,10 @@ static void mesh_assemble(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, bool has_
         fprintf(stderr, "fhip mesh depth %u: cells %.4f s (%llu evaluated), leaf kernel %.4f s (%u leaves), copies %.4f s, assembly %.4f s, dual walk %.4f s, total %.4f s\n",
                 depth, T.t_cells, (unsigned long long)M->cells_evaluated, T.t_leaf, T.n_leaf_cells, T.t_copy, t_asm, t_walk, now() - T.t_start);
 }
-// fhip_mesh_build's second half: the octree assembled in HBM (check_done / collapse / places, mesh_collapse.hpp), its blocks of cells copied
-// to the context's pinned landing area, Octree::walk_dual on the host's threads over them, and the mesh's vertices - the walk knows which
-// of the octree's they are - gathered on the device.  Neither the leaf records (528 bytes each) nor the octree's vertices (at depth 10:
+// fhip_mesh_build's second half: the octree assembled in HBM (check_done / collapse / places, mesh_collapse.hpp), then Octree::walk_dual on the
+// device too (mesh_walk.hpp; the finished mesh travels to the host through the context's pinned landing area) - or, option mesh_device_walk 0
+// and for octrees beyond the device walk's 32-bit numbers, its blocks of cells copied to the host, the walk on the host's threads over them,
+// and the mesh's vertices - the walk knows which of the octree's they are - gathered on the device.  Neither the leaf records (528 bytes each) nor the octree's vertices (at depth 10:
 // 191 M, of which the mesh uses 7.5 M) leave the device.
 static hipError_t mesh_assemble_device(fhip_ctx* ctx, fhip_mesh* M, uint32_t depth, std::vector<fhmesh::OctLevel>& lv, const FhMeshLeaf* rec, uint32_t n_rec, const FhMdcTable* table,
                                        bool has_mat, const float* mat, MeshTimes& T, std::string& why) {
@@ -882,7 +883,7 @@ fhip_status fhip_mesh_sample(fhip_ctx* ctx, const fhip_tape* tape, uint32_t dept
     return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, MESH_SAMPLE, 0, 1, out);
 }
 // Octree::build + Octree::walk_dual (octree.rs:48-68, 219-225): fhip_mesh_sample, then the octree assembled from the device's
-// results (cell collapse included) and the dual walk on the host
+// results (cell collapse included) and the dual walk, both on the device (mesh_assemble_device)
 fhip_status fhip_mesh_build(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth, const float* world_to_model, const int32_t* axis_slots,
                             const uint64_t* var_keys, const float* var_values, uint32_t n_vars, fhip_mesh** out) {
     return mesh_run(ctx, tape, depth, world_to_model, axis_slots, var_keys, var_values, n_vars, MESH_BUILD, 0, 1, out);

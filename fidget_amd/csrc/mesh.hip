@@ -17,7 +17,8 @@
 //   k_oct_kind / k_oct_collapse / k_oct_place / k_oct_leaf_verts   the octree assembled from those results without leaving HBM
 //                 (octree.rs:256-470 check_done / collapsible, 866-1035 merged Hermite data; mesh_collapse.hpp): level by level
 //                 bottom-up what every ambiguous cell becomes, top-down where its vertices and its block of eight cells go.
-//                 The dual walk (dc.rs) has no evaluation in it and stays on the host side of the boundary.
+//   k_walk_* / k_scan_*   Octree::walk_dual (dc.rs, builder.rs) on that octree: the recursion's calls as level arrays in call order, the
+//                 mesh's vertices numbered by first use through atomic minima and prefix sums (mesh_walk.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(256) k_oct_leaf_verts(fhmesh::OctLeaves L, fhm
     if (i < n) fhmesh::oct_leaf_verts(L, i, verts, mat);
 }
 
-// the mesh's vertices out of the octree's (the dual walk on the host says which: first uses, in its order)
+// the mesh's vertices out of the octree's (for the dual walk on the HOST, option mesh_device_walk 0: it says which - first uses, in its order)
 __global__ void __launch_bounds__(256) k_oct_gather(const fhmesh::V3* verts, const uint32_t* idx, fhmesh::V3* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = verts[idx[i]];
