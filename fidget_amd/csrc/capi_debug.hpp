@@ -122,6 +122,29 @@ fhip_status fhip_debug_math_sweep(fhip_ctx* ctx, int op, uint32_t first, uint32_
     return FHIP_OK;
 }
 
+// Diagnostics: the embedded copy `copy` (order of gen_trans.COPIES) of compiled routine `fn` (index into gen_trans.FUNCS + FUNCS4)
+// over the n floats with bit patterns first .. first + n - 1 (n a multiple of 256), against the routine as the HIP kernels inline
+// it: out = {results whose bits differ, an input where they do}; a (copy, fn) that does not exist reports every result
+fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, uint32_t first, uint64_t n, uint64_t out[2]) {
+    (void)hipSetDevice(ctx->device);
+    if (!n || n % 256 || n > (1ull << 28)) return fail(ctx, FHIP_ERR_UNSUPPORTED, "trans probe: n must be a multiple of 256, at most 2^28");
+    if (!ctx->asm_fn[FH_ASM_TRANS_PROBE]) return fail(ctx, FHIP_ERR_UNSUPPORTED, "trans probe: the assembly kernels are not loaded");
+    HIP_TRY(ctx, ctx->io_a.ensure(n * 4));
+    HIP_TRY(ctx, ctx->io_b.ensure(64));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_a.p, 0x5A, n * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0, 64, ctx->stream));
+    struct { void* out; uint32_t first, copy, fn, pad; } ka = {ctx->io_a.p, first, copy, fn, 0};
+    if (launch_asm(ctx, FH_ASM_TRANS_PROBE, (uint32_t)(n / 256), &ka, sizeof(ka)) != hipSuccess) return FHIP_ERR_HIP;
+    hipLaunchKernelGGL(k_trans_compare, dim3(ctx->n_cu * 16), dim3(256), 0, ctx->stream, (int)fn, first, (size_t)n, (const uint32_t*)ctx->io_a.p,
+                       (unsigned long long*)ctx->io_b.p);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long r[2];
+    HIP_TRY(ctx, hipMemcpyAsync(r, ctx->io_b.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = r[1]; out[1] = r[0] & 0xFFFFFFFFull;
+    return FHIP_OK;
+}
+
 // Diagnostics: `n` ops of the tape arena starting at op `off` (the tapes the last frame left there)
 uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out) {
     if ((size_t)(off + (size_t)n) * 8 > ctx->arena_bytes) return 0;

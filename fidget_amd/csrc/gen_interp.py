@@ -1293,6 +1293,75 @@ def gen_bulk(a, nr, zb, off, trans=None):
     return name
 
 
+def gen_trans_probe(a):
+    """fh_trans_probe: every embedded copy of the compiled routines (gen_trans.COPIES), callable on its own.
+    kernarg = {out*, first u32, copy u32, fn u32}; lane l of workgroup w evaluates routine `fn` (index into gen_trans.FUNCS + FUNCS4) of
+    copy `copy` on the four floats with bit patterns first + 4 (64 w + l) + j, second argument bits x * 2654435761 + 0x9E3779B9, and
+    stores the results at out[4 (64 w + l) + j].  fhip_debug_trans_probe compares them with the inlined routines of the HIP kernels
+    (which tests/test_gpu_math.py holds against the host libm over all 2^32 inputs): the renamed, compacted text the hot kernels run
+    is then checked itself, not only the source it came from.  An unknown (copy, fn) leaves `out` untouched."""
+    import gen_trans
+    name = "fh_trans_probe"
+    nvg = 256
+    kernel_header(a, name, 24, nvg, wg_id=True)
+    a(f"""
+	s_load_dwordx4 s[4:7], s[0:1], 0x0
+	s_load_dword s8, s[0:1], 0x10
+	v_lshl_add_u32 v1, s2, 6, v0
+	v_lshlrev_b32 v1, 2, v1                         ; element index of the lane's first float
+	s_mov_b32 s10, 0x9E3779B1                       ; 2654435761
+	s_mov_b32 s11, 0x9E3779B9
+	s_waitcnt lgkmcnt(0)""")
+    for j in range(4):
+        a(f"""
+	v_add3_u32 v{2 + j}, v1, s6, {j}
+	v_mul_lo_u32 v{6 + j}, v{2 + j}, s10
+	v_add_u32 v{6 + j}, s11, v{6 + j}""")
+    all_fns = gen_trans.FUNCS + gen_trans.FUNCS4
+    for ci, (prefix, vb, fns) in enumerate(gen_trans.COPIES):
+        nxt = a.label("copy")
+        a(f"\ts_cmp_lg_u32 s7, {ci}\n\ts_cbranch_scc1 {nxt}")
+        for fn in fns:
+            fi = all_fns.index(fn)
+            skip = a.label("fn")
+            a(f"\ts_cmp_lg_u32 s8, {fi}\n\ts_cbranch_scc1 {skip}")
+            for j in ([0] if fn.endswith("4") else range(4)):
+                if fn.endswith("4"):
+                    for k in range(4):
+                        a(f"\tv_mov_b32 v{vb + k}, v{2 + k}")
+                else:
+                    a(f"\tv_mov_b32 v{vb}, v{2 + j}\n\tv_mov_b32 v{vb + 1}, v{6 + j}")
+                here, ret, h2 = a.label("call"), a.label("ret"), a.label("far")
+                # (the copies lie anywhere in the code object: a computed jump, not s_branch's 128 KB)
+                a(f"""
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_getpc_b64 s[98:99]
+{h2}:
+	s_mov_b32 s100, {prefix}{fn} - {h2}
+	s_ashr_i32 s101, s100, 31
+	s_add_u32 s98, s98, s100
+	s_addc_u32 s99, s99, s101
+	s_setpc_b64 s[98:99]
+{ret}:""")
+                if fn.endswith("4"):
+                    for k in range(4):
+                        a(f"\tv_mov_b32 v{10 + k}, v{vb + k}")
+                else:
+                    a(f"\tv_mov_b32 v{10 + j}, v{vb}")
+            a(f"\ts_branch .Lfh_trans_probe_store\n{skip}:")
+        a(f"\ts_endpgm\n{nxt}:")
+    a(f"""
+	s_endpgm
+.Lfh_trans_probe_store:
+	v_lshlrev_b32 v1, 2, v1
+	global_store_dwordx4 v1, v[10:13], s[4:5]""")
+    kernel_footer(a, name, 24, nvg, 102, True)
+    return name, 24, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 4
+
+
 def gen_probe(a):
     """fh_probe: does M0-relative VGPR addressing apply to packed (VOP3P) operands?  out[0..7] (diagnostics)."""
     name = "fh_probe"
@@ -1438,6 +1507,8 @@ def main():
             n = gen_bulk(a, nr, zb, off, trans=sys.argv[3])
             ks.append((n, 32, FILE + nr * zb + 26, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))
     ks.append(gen_probe(a))
+    if len(sys.argv) > 3:
+        ks.append(gen_trans_probe(a))
     from gen_ubench import gen_ubench
     ks.append(gen_ubench(a))
     metadata(a, ks)

@@ -85,6 +85,9 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None, MAX_V=MAX_V):
     return "\n".join(out)
 
 
+COPIES = []      # (prefix, v_base, routine names) of every embed(): the probe kernel (gen_interp.py gen_trans_probe) reaches each copy
+
+
 def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
     """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
     window embeds its own copies: `s_branch` reaches 128 KB); s_map: the ten scalar registers s0..s9 go to (default s86..s95; pairs
@@ -93,6 +96,7 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
     txt = open(path).read()
     # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
     extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
+    COPIES.append((prefix, v_base, FUNCS + extra))
     for f in FUNCS + extra:
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f

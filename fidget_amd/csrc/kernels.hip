@@ -1550,6 +1550,34 @@ __global__ void k_math_sweep(int op, uint32_t first, uint32_t stride, size_t n, 
     if (worst) atomicMax(&out[0], worst);
 }
 
+// The embedded copies of the compiled routines (fh_trans_probe, gen_interp.py) against the inlined ones above: got[i] = what copy
+// computed for x = bits(first + i) (second argument as in k_math_sweep's op 8); fn indexes gen_trans.FUNCS + FUNCS4.  out[1] = results
+// whose bits differ (a NaN equals any NaN), out[0] = (1 << 32 | an input where they do)
+__global__ void k_trans_compare(int fn, uint32_t first, size_t n, const uint32_t* __restrict__ got, unsigned long long* out) {
+    unsigned long long ndiff = 0, where = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t xb = first + (uint32_t)i;
+        const float x = u2f(xb), b = u2f(xb * 2654435761u + 0x9E3779B9u);
+        float y;
+        switch (fn) {
+            case 0: case 10: y = t_sin(x); break;
+            case 1: case 11: y = t_cos(x); break;
+            case 2: y = t_tan(x); break;
+            case 3: y = t_asin(x); break;
+            case 4: y = t_acos(x); break;
+            case 5: y = t_atan(x); break;
+            case 6: case 12: y = t_exp(x); break;
+            case 8: y = t_atan2(x, b); break;
+            case 9: y = rem_euclid(x, b); break;
+            default: y = t_ln(x); break;
+        }
+        const float g = u2f(got[i]);
+        if (isnan_(y) && isnan_(g)) continue;
+        if (f2u(y) != got[i]) { ndiff++; where = (1ull << 32) | xb; }
+    }
+    if (ndiff) { atomicAdd(&out[1], ndiff); atomicMax(&out[0], where); }
+}
+
 // ---- micro-benchmark of the point interpreter (diagnostics only; fhip_debug_bench) -----------
 template <int NR, int ZB>
 __global__ void __launch_bounds__(WAVE) k_bench_points(FhRenderState* S, const uint64_t* tape_g, uint32_t len, uint32_t reps, float* out) {

@@ -64,3 +64,53 @@ def test_transcendental_bits_equal_libm(op, oracle_mod):
         if r["max_ulp"] > worst["max_ulp"]:
             worst["max_ulp"], worst["worst_input_bits"] = r["max_ulp"], r["worst_input_bits"]
     assert worst["differ"] == 0, f"{op}: {worst}"
+
+
+# the copies of the compiled routines inside the assembly kernels (gen_trans.COPIES, in the order gen_interp.py's main() embeds them)
+# and the routines each holds (gen_trans.FUNCS + FUNCS4)
+ROUTINES = ["sin", "cos", "tan", "asin", "acos", "atan", "exp", "ln", "atan2", "mod", "sin4", "cos4", "exp4", "ln4"]
+COPIES = [("fh_columns_t", 14), ("fh_normals_t", 10), ("fh_tiles_t", 10), ("fh_tiles_v32_t", 10), ("fh_tiles_v64_t", 10),
+          ("fh_float_eval_16x4_t", 12), ("fh_float_eval_32x2_t", 12)]
+
+
+def test_the_probe_reaches_every_embedded_copy():
+    """CPU leg: the generator's list of copies is the one the GPU test walks"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "fidget_amd", "csrc"))
+    import importlib
+    gen_trans = importlib.import_module("gen_trans")
+    assert gen_trans.FUNCS + gen_trans.FUNCS4 == ROUTINES
+    src = open(os.path.join(ROOT, "fidget_amd", "csrc", "_gen", "interp_gfx950.s")).read()
+    for prefix, n in (("fh_t_", 14), ("fh_tn_", 10), ("fh_til_", 10), ("fh_ti32_", 10), ("fh_ti64_", 10), ("fh_tb16_", 12), ("fh_tb32_", 12)):
+        for r in ROUTINES[:n]:
+            assert f"s_mov_b32 s100, {prefix}{r} - " in src, (prefix, r)      # fh_trans_probe's jump to that copy
+    assert src.count(" - .Lfar_") == sum(4 * min(n, 10) + (n - 10) for _, n in COPIES)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("copy", range(len(COPIES)), ids=[c[0] for c in COPIES])
+def test_embedded_routines_equal_the_inlined_ones(copy):
+    """The text the hot kernels execute - the routines compiled apart (SGPR budget), renamed into each kernel's register window and
+    compacted by gen_trans.py - against the routines as hipcc inlines them into the HIP kernels, which the test above holds to the
+    host libm: all 2^32 arguments of every routine of every copy (second arguments of atan2 / mod: a hash of the first)."""
+    import fidget_amd as F
+    hip = F.default_context()
+    n = 1 << 28
+    for fn in range(COPIES[copy][1]):
+        differ, where = 0, None
+        for c in range(16):
+            out = np.zeros(2, np.uint64)
+            hip.check(F.lib().fhip_debug_trans_probe(hip._h, copy, fn, (c * n) & 0xFFFFFFFF, n, out.ctypes.data_as(F.C.c_void_p)))
+            differ += int(out[0])
+            if out[0]:
+                where = hex(int(out[1]))
+        assert differ == 0, f"{COPIES[copy][0]} {ROUTINES[fn]}: {differ} results differ, e.g. at input bits {where}"
+
+
+@pytest.mark.gpu
+def test_the_probe_reports_a_copy_that_is_not_there():
+    import fidget_amd as F
+    hip = F.default_context()
+    out = np.zeros(2, np.uint64)
+    hip.check(F.lib().fhip_debug_trans_probe(hip._h, 1, 12, 0x3F000000, 1 << 16, out.ctypes.data_as(F.C.c_void_p)))   # fh_normals_t has no exp4
+    assert out[0] > 60000
