@@ -507,14 +507,14 @@ def main():
             m = 512
             bs, bo = F.Shape.from_vm(bear, hip=hip), O.Shape.from_vm(bear)
             bout = torch.zeros((m, m, 4), dtype=torch.int32, device=dev)
-            for _ in range(3):
+            for _ in range(8):      # (the frame lanes - capi_render.hpp render3d_lane - get their buffers with their first frame each)
                 F.render3d(bs, m, out=bout)
             fence()
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(20):
                 F.render3d(bs, m, out=bout)
             fence()
-            bms = (time.perf_counter() - t0) / 10 * 1e3
+            bms = (time.perf_counter() - t0) / 20 * 1e3
             a = bout.cpu().numpy().view(np.uint32).reshape(m, m, 4)
             b = O.render3d(bo, m)[0]
             an, bn = a[..., :3].view(np.float32), b["normal"]
@@ -523,6 +523,8 @@ def main():
                 ulp = np.abs(an - bn) / (scale * 2.0 ** -23)
             result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
+                                 "frames": "20 queued back to back on one stream; the library runs whole frames of such tapes on three child contexts in turn "
+                                           "(option frame_lanes; " + str(int(F.lib().fhip_debug_lane_frames(hip._h))) + " frames of this context went that way)",
                                  "note": "transcendental opcodes: the device runs the host libm's f32 routines restated operation by operation "
                                          "(fidget_amd/csrc/trans_libm.hpp; 0 of 2^32 arguments differ per routine, profiles/r04a/math_sweep.json)"}
         # BASELINE configuration 5 (Manifold Dual Contouring of gyroid-sphere at octree depth 10 = 1024^3: fhip_mesh_build, the octree

@@ -77,10 +77,13 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     *out = c;
     return FHIP_OK;
 }
+static void lanes_release(fhip_ctx* ctx);      // (capi_render.hpp)
 void fhip_ctx_destroy(fhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    lanes_release(c);
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream);
@@ -132,6 +135,10 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
         const fhip_status s2 = finish_render(c);
         if (st == FHIP_OK) st = s2;
     }
+    for (fhip_ctx* L : c->lanes) {      // frames that went to the lanes: each lane's own checks
+        const fhip_status s3 = fhip_ctx_sync(L);
+        if (s3 && st == FHIP_OK) { st = s3; c->err = L->err; }
+    }
     // frames older than the last two (their buffer sets have been re-used since): the flag every frame's last kernel latches
     uint32_t sticky = 0;
     HIP_TRY(c, hipMemcpy(&sticky, c->sticky.p, 4, hipMemcpyDeviceToHost));
@@ -153,6 +160,7 @@ fhip_status fhip_ctx_set_option(fhip_ctx* c, const char* name, int value) {
             const fhip_status st = fhip_ctx_sync(c);
             c->opt.*(e.field) = value;
             apply_options(c);
+            lanes_release(c);      // (the lanes carry a copy of the options: made again, with the new ones, by the next frame that wants them)
             return st;
         }
     return fail(c, FHIP_ERR_UNSUPPORTED, std::string("unknown option ") + name);

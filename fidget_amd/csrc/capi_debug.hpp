@@ -145,6 +145,9 @@ fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, ui
     return FHIP_OK;
 }
 
+// Diagnostics: how many 3D frames of this context went to a frame lane (capi_render.hpp render3d_lane) so far
+uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx) { return ctx ? ctx->lane_frames : 0; }
+
 // Diagnostics: `n` ops of the tape arena starting at op `off` (the tapes the last frame left there)
 uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out) {
     if ((size_t)(off + (size_t)n) * 8 > ctx->arena_bytes) return 0;

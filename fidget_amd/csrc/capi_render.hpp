@@ -736,8 +736,8 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     return FHIP_OK;
 }
 
-static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
-                                 int out_is_device, const PartSpec& part) {
+static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                  int out_is_device, const PartSpec& part) {
     if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
     (void)hipSetDevice(ctx->device);
     RenderSetup R;
@@ -1030,6 +1030,88 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
         return finish_render(ctx);
     }
     return FHIP_OK;
+}
+// Frame lanes (option frame_lanes, default 3; 0 / 1: off).  The stage pipeline above runs the stages of consecutive frames beside
+// each other, each stage on its stream; how far that goes is set by the busiest stream.  For tapes with transcendental opcodes the
+// busiest stream carries the leaf kernels - fh_columns_t with its 256 VGPRs, two waves per SIMD - and one such kernel leaves most of
+// the machine's issue slots idle however the streams are arranged: bear.vm 512^3, 1.86 ms per queued frame with 3.2 ms of kernels in
+// it.  For those frames, when the caller queues them back to back (the frame before is still under way), WHOLE frames run beside
+// each other instead: lane i % K is a child context that keeps to one stream of its own (no_pipeline), renders into an image of its
+// own, and the caller's stream waits for it and copies the image out - so `out` is only ever touched on the caller's stream, in
+// order.  Measured with separate contexts driven in turn (tools/two_contexts.py, profiles/r04r): bear.vm 512^3 1.86 -> 1.38 ms with
+// three lanes (1.41 with four, 2.19 with two), 1024^3 5.25 -> 4.7; prospero.vm, whose kernels are the 128 / 160-VGPR ones, loses
+// (0.51 -> 0.59; with the column short cuts off 1.61 -> 1.99), which is why only the `_t` frames go this way.  A frame alone, a
+// host output buffer, a shard or a profiled frame take the stage pipeline as before.
+static bool lanes_wanted(fhip_ctx* ctx, const fhip_tape* tape, int out_is_device, const PartSpec& part) {
+    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats) return false;
+    if (!ctx->use_pipeline || !ctx->frame_pipeline || ctx->opt.pipe_serial || !ctx->use_asm || ctx->opt.no_columns_t || ctx->opt.side_cus) return false;
+    if (part.n_shards != 1 || part.nx * part.ny * part.nz != 1) return false;
+    if (tape_asm_ok(tape->t) || !ctx->ev_last_valid) return false;
+    const hipError_t q = hipEventQuery(ctx->ev_last);
+    (void)hipGetLastError();
+    return q == hipErrorNotReady;
+}
+static void lanes_release(fhip_ctx* ctx) {
+    for (fhip_ctx* L : ctx->lanes) {
+        hipStream_t const s = L->lane_stream_owned ? L->stream : nullptr;
+        if (L->lane_done) (void)hipEventDestroy(L->lane_done);
+        if (L->lane_copied) (void)hipEventDestroy(L->lane_copied);
+        L->lane_img.release();
+        fhip_ctx_destroy(L);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    ctx->lanes.clear();
+}
+static fhip_status render3d_lane(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out, const PartSpec& part) {
+    const uint32_t K = (uint32_t)std::min(ctx->opt.frame_lanes, 8);
+    while (ctx->lanes.size() < K) {
+        // (the first three lanes ride on the streams of the stage pipeline, which is idle while the lanes run: the runtime shares a few
+        // hardware queues - four by default - among all streams that have work, and lanes on streams of their own ended up two to a
+        // queue behind the idle ones: bear.vm 512^3 1.55 ms per frame instead of 1.4)
+        hipStream_t const mine[3] = {ctx->stream_pre, ctx->stream3, ctx->stream2};
+        const size_t k = ctx->lanes.size();
+        hipStream_t s = k < 3 ? mine[k] : nullptr;
+        const bool owned = !s;
+        if (owned) HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        fhip_ctx* L = nullptr;
+        const fhip_status st = fhip_ctx_create(ctx->device, (void*)s, &L);
+        if (st) { if (owned) (void)hipStreamDestroy(s); return fail(ctx, st, "frame lanes: no child context"); }
+        L->lane_stream_owned = owned;
+        L->opt = ctx->opt;
+        L->opt.no_pipeline = 1;
+        L->opt.frame_lanes = 0;
+        apply_options(L);
+        L->is_lane = true;
+        (void)hipEventCreateWithFlags(&L->lane_done, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&L->lane_copied, hipEventDisableTiming);
+        ctx->lanes.push_back(L);
+    }
+    fhip_ctx* const L = ctx->lanes[ctx->lane_next++ % K];
+    L->cancelled.store(ctx->cancelled.load());
+    const size_t bytes = (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel);
+    HIP_TRY(ctx, L->lane_img.ensure(bytes));
+    if (L->lane_copied_valid) HIP_TRY(ctx, hipStreamWaitEvent(L->stream, L->lane_copied, 0));   // (its previous image has been copied out)
+    const fhip_status st = render3d_frame(L, tape, cfg, L->lane_img.p, 1, part);
+    if (st) { ctx->err = L->err; return st; }
+    HIP_TRY(ctx, hipEventRecord(L->lane_done, L->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, L->lane_done, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(out, L->lane_img.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(L->lane_copied, ctx->stream));
+    L->lane_copied_valid = true;
+    ctx->lane_frames++;
+    return FHIP_OK;
+}
+static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
+                                 int out_is_device, const PartSpec& part) {
+    (void)hipSetDevice(ctx->device);
+    const fhip_status st = lanes_wanted(ctx, tape, out_is_device, part) ? render3d_lane(ctx, tape, cfg, out, part)
+                                                                         : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
+    if (st == FHIP_OK && out_is_device && !ctx->is_lane && ctx->opt.frame_lanes >= 2) {
+        if (!ctx->ev_last) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_last, ctx->stream));
+        ctx->ev_last_valid = true;
+    }
+    return st;
 }
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                           int out_is_device) {

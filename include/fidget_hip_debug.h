@@ -22,6 +22,9 @@ uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t ca
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
 fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_interp.py gen_probe), 16 x 64 floats */
+/* 3D frames of this context that went to a frame lane so far (option frame_lanes: whole frames of a queued sequence on child contexts;
+ * the statistics the other debug calls return are then those of the last frame that did NOT) */
+uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx);
 /* embedded copy `copy` of compiled routine `fn` (gen_trans.py COPIES / FUNCS + FUNCS4) over the floats with bits first .. first + n - 1
  * against the routine as the HIP kernels inline it: out = {results whose bits differ, an input where they do} */
 fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, uint32_t first, uint64_t n, uint64_t out[2]);

@@ -272,6 +272,52 @@ def test_render3d_frames_in_flight_under_the_pipeline_options(env, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [3, 4, 2, 0])
+def test_render3d_frame_lanes(lanes):
+    """Option frame_lanes: queued frames whose kernels are the `_t` ones (tapes with transcendental opcodes) run WHOLE, on child
+    contexts in turn, and come back through a copy on the caller's stream.  A queue that mixes such frames - different shapes, sizes,
+    cameras - with frames of the stage pipeline (prospero) and a host-output frame in the middle gives the oracle's images, frame by
+    frame; the counter says the lanes were really taken, and not with the option off."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("frame_lanes", lanes)
+    jobs = [("bear.vm", 256, None), ("bear.vm", 128, bench_camera(0.3)), ("gyroid-sphere.vm", 256, None), ("prospero.vm", 512, None),
+            ("bear.vm", 256, bench_camera(0.15)), ("gyroid-sphere.vm", 128, bench_camera(0.3)), ("bear.vm", 192, None), ("bear.vm", 256, None),
+            ("prospero.vm", 256, None), ("gyroid-sphere.vm", 256, None)]
+    shapes = {m: F.Shape.from_vm(model_path(m), hip=hip) for m, _, _ in jobs}
+    outs = [torch.zeros((n, n, 4), dtype=torch.int32, device="cuda") for _, n, _ in jobs]
+    mid = None
+    for rep in range(3):
+        for i, (m, n, cam) in enumerate(jobs):
+            F.render3d(shapes[m], n, world_to_model=cam, out=outs[i])
+            if rep == 1 and i == 5:
+                mid = F.render3d(shapes["bear.vm"], 64)[0]       # host output: the stage pipeline, waits for its own frame only
+    hip.sync()
+    torch.cuda.synchronize()
+    taken = F.lib().fhip_debug_lane_frames(hip._h)
+    assert (taken >= 12) if lanes >= 2 else (taken == 0), taken
+    oshape = {m: O.Shape.from_vm(model_path(m)) for m in shapes}
+    for i, (m, n, cam) in enumerate(jobs):
+        b = O.render3d(oshape[m], n, world_to_model=cam)[0]
+        a = outs[i].cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        assert (a[:, :, 3] == b["depth"]).all(), f"frame {i} ({m} {n}): {(a[:, :, 3] != b['depth']).sum()} depths differ"
+        an = a[:, :, :3].copy().view(np.float32)
+        assert ((an == b["normal"]) | (np.isnan(an) & np.isnan(b["normal"]))).all(), f"frame {i} ({m} {n}): normals differ"
+    b = O.render3d(oshape["bear.vm"], 64)[0]
+    assert (mid["depth"] == b["depth"]).all() and same_bits_f32(mid["normal"], b["normal"])
+    # a switch between frames: the lanes are given up and made again under the new options
+    hip.set_option("no_column_inv", 1)
+    for i, (m, n, cam) in enumerate(jobs[:3] * 2):
+        F.render3d(shapes[m], n, world_to_model=cam, out=outs[i % 3])
+    hip.sync()
+    for i, (m, n, cam) in enumerate(jobs[:3]):
+        b = O.render3d(oshape[m], n, world_to_model=cam)[0]
+        a = outs[i].cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        assert (a[:, :, 3] == b["depth"]).all()
+    del shapes, hip
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,n_regs,size", [("colonnade.vm", 255, 256), ("colonnade.vm", 6, 128), ("prospero.vm", 24, 256)])
 def test_render_from_reference_bytecode(name, n_regs, size):
     """The words a Rust `fidget-hip` shim hands over (fidget_bytecode::Bytecode of a VmData<N>; N < 255 gives tapes with Mem

@@ -12,7 +12,8 @@ import fidget_amd as F
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 model = sys.argv[2] if len(sys.argv) > 2 else "prospero.vm"
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 120
-for K in (1, 2, 3, 4):
+KS = [int(k) for k in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2, 3, 4]
+for K in KS:
     streams = [torch.cuda.Stream() for _ in range(K)]
     hips = [F.HipContext(0, s.cuda_stream) for s in streams]
     shapes = [F.Shape.from_vm(os.path.join(ROOT, "models", model), hip=h) for h in hips]
