@@ -12,6 +12,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/fidget_hip.h"

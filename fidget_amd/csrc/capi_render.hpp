@@ -682,8 +682,8 @@ static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS,
         });
 }
 
-fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
-                          int out_is_device) {
+static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
+                                  int out_is_device) {
     if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
     RenderSetup R;
     memset(&R.S, 0, sizeof(R.S));
@@ -1042,14 +1042,18 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 // three lanes (1.41 with four, 2.19 with two), 1024^3 5.25 -> 4.7; prospero.vm, whose kernels are the 128 / 160-VGPR ones, loses
 // (0.51 -> 0.59; with the column short cuts off 1.61 -> 1.99), which is why only the `_t` frames go this way.  A frame alone, a
 // host output buffer, a shard or a profiled frame take the stage pipeline as before.
-static bool lanes_wanted(fhip_ctx* ctx, const fhip_tape* tape, int out_is_device, const PartSpec& part) {
-    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats) return false;
-    if (!ctx->use_pipeline || !ctx->frame_pipeline || ctx->opt.pipe_serial || !ctx->use_asm || ctx->opt.no_columns_t || ctx->opt.side_cus) return false;
-    if (part.n_shards != 1 || part.nx * part.ny * part.nz != 1) return false;
-    if (tape_asm_ok(tape->t) || !ctx->ev_last_valid) return false;
-    const hipError_t q = hipEventQuery(ctx->ev_last);
+static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
+    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats || ctx->opt.side_cus) return false;
+    if (!ctx->ev_last_valid) return false;
+    const hipError_t q = hipEventQuery(ctx->ev_last);      // the frame before this one: still under way?
     (void)hipGetLastError();
     return q == hipErrorNotReady;
+}
+static bool lanes_wanted(fhip_ctx* ctx, const fhip_tape* tape, int out_is_device, const PartSpec& part) {
+    if (!ctx->use_pipeline || !ctx->frame_pipeline || ctx->opt.pipe_serial || !ctx->use_asm || ctx->opt.no_columns_t) return false;
+    if (part.n_shards != 1 || part.nx * part.ny * part.nz != 1) return false;
+    if (tape_asm_ok(tape->t)) return false;     // (the stage pipeline is the faster arrangement for these)
+    return lanes_possible(ctx, out_is_device);
 }
 static void lanes_release(fhip_ctx* ctx) {
     for (fhip_ctx* L : ctx->lanes) {
@@ -1062,7 +1066,8 @@ static void lanes_release(fhip_ctx* ctx) {
     }
     ctx->lanes.clear();
 }
-static fhip_status render3d_lane(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out, const PartSpec& part) {
+// One frame on the next lane: render(lane, image) queues it on the lane's stream into the lane's own image of `bytes` bytes
+static fhip_status run_on_lane(fhip_ctx* ctx, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
     const uint32_t K = (uint32_t)std::min(ctx->opt.frame_lanes, 8);
     while (ctx->lanes.size() < K) {
         // (the first three lanes ride on the streams of the stage pipeline, which is idle while the lanes run: the runtime shares a few
@@ -1088,10 +1093,9 @@ static fhip_status render3d_lane(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     }
     fhip_ctx* const L = ctx->lanes[ctx->lane_next++ % K];
     L->cancelled.store(ctx->cancelled.load());
-    const size_t bytes = (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel);
     HIP_TRY(ctx, L->lane_img.ensure(bytes));
     if (L->lane_copied_valid) HIP_TRY(ctx, hipStreamWaitEvent(L->stream, L->lane_copied, 0));   // (its previous image has been copied out)
-    const fhip_status st = render3d_frame(L, tape, cfg, L->lane_img.p, 1, part);
+    const fhip_status st = render(L, L->lane_img.p);
     if (st) { ctx->err = L->err; return st; }
     HIP_TRY(ctx, hipEventRecord(L->lane_done, L->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, L->lane_done, 0));
@@ -1101,17 +1105,31 @@ static fhip_status render3d_lane(fhip_ctx* ctx, const fhip_tape* tape, const fhi
     ctx->lane_frames++;
     return FHIP_OK;
 }
+static fhip_status frame_queued(fhip_ctx* ctx, int out_is_device) {      // (the end of this frame, for the next one's lanes_possible)
+    if (!out_is_device || ctx->is_lane || ctx->opt.frame_lanes < 2) return FHIP_OK;
+    if (!ctx->ev_last) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_last, ctx->stream));
+    ctx->ev_last_valid = true;
+    return FHIP_OK;
+}
 static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                  int out_is_device, const PartSpec& part) {
     (void)hipSetDevice(ctx->device);
-    const fhip_status st = lanes_wanted(ctx, tape, out_is_device, part) ? render3d_lane(ctx, tape, cfg, out, part)
-                                                                         : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
-    if (st == FHIP_OK && out_is_device && !ctx->is_lane && ctx->opt.frame_lanes >= 2) {
-        if (!ctx->ev_last) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_last, ctx->stream));
-        ctx->ev_last_valid = true;
-    }
-    return st;
+    const fhip_status st = lanes_wanted(ctx, tape, out_is_device, part)
+        ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel), out,
+                      [&](fhip_ctx* L, void* img) { return render3d_frame(L, tape, cfg, img, 1, part); })
+        : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
+    return st ? st : frame_queued(ctx, out_is_device);
+}
+// 2D frames have no stage pipeline at all - a frame is one chain of tile levels and a pixel kernel on the caller's stream - so every
+// queued 2D frame with a device output takes a lane: prospero.vm 4096^2 0.475 -> 0.333 ms per frame, 1024^2 0.83 -> 0.50 with three
+// one-stream contexts in turn (profiles/r04r/frame_major3.txt)
+fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out, int out_is_device) {
+    (void)hipSetDevice(ctx->device);
+    const fhip_status st = lanes_possible(ctx, out_is_device)
+        ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * 4, out, [&](fhip_ctx* L, void* img) { return render2d_frame(L, tape, cfg, (float*)img, 1); })
+        : render2d_frame(ctx, tape, cfg, out, out_is_device);
+    return st ? st : frame_queued(ctx, out_is_device);
 }
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                           int out_is_device) {

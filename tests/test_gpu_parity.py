@@ -318,6 +318,37 @@ def test_render3d_frame_lanes(lanes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [3, 0])
+def test_render2d_frame_lanes(lanes):
+    """... and every queued 2D frame with a device output (a 2D frame has no stage pipeline to lose): a queue of 2D frames of different
+    models, sizes, z and pixel_perfect, with 3D frames in between, against the oracle frame by frame."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("frame_lanes", lanes)
+    jobs = [("prospero.vm", 1024, 0.0, False), ("hi.vm", 256, 0.0, False), ("bear.vm", 512, 0.1, False), ("prospero.vm", 512, 0.0, True),
+            ("colonnade.vm", 512, 0.2, False), ("gyroid-sphere.vm", 256, 0.0, False), ("prospero.vm", 2048, 0.0, False), ("quarter.vm", 128, 0.0, True)]
+    shapes = {m: F.Shape.from_vm(model_path(m), hip=hip) for m, _, _, _ in jobs}
+    outs = [torch.zeros((n, n), dtype=torch.float32, device="cuda") for _, n, _, _ in jobs]
+    out3 = torch.zeros((128, 128, 4), dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        for i, (m, n, z, pp) in enumerate(jobs):
+            F.render2d(shapes[m], n, z=z, pixel_perfect=pp, out=outs[i])
+            if i == 4:
+                F.render3d(shapes["bear.vm"], 128, out=out3)
+    hip.sync()
+    torch.cuda.synchronize()
+    taken = F.lib().fhip_debug_lane_frames(hip._h)
+    assert (taken >= 20) if lanes >= 2 else (taken == 0), taken
+    for i, (m, n, z, pp) in enumerate(jobs):
+        b = O.render2d(O.Shape.from_vm(model_path(m)), n, z=z, pixel_perfect=pp, tile_sizes=F.HIP_TILES_2D)[0]
+        assert same_bits_f32(outs[i].cpu().numpy(), b), f"2D frame {i} ({m} {n})"
+    b = O.render3d(O.Shape.from_vm(model_path("bear.vm")), 128)[0]
+    a = out3.cpu().numpy().view(np.uint32).reshape(128, 128, 4)
+    assert (a[:, :, 3] == b["depth"]).all()
+    del shapes, hip
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,n_regs,size", [("colonnade.vm", 255, 256), ("colonnade.vm", 6, 128), ("prospero.vm", 24, 256)])
 def test_render_from_reference_bytecode(name, n_regs, size):
     """The words a Rust `fidget-hip` shim hands over (fidget_bytecode::Bytecode of a VmData<N>; N < 255 gives tapes with Mem
