@@ -181,11 +181,19 @@ def main():
         torch.cuda.synchronize(dev)
 
     frame_ms = []
+    tuning = {"frames": 0, "last": None}
 
     def timed(step):
         import gc
         for _ in range(args.warmup):
             step()
+        # (the library times the first ~50 queued frames of a kind under its two frame arrangements - stage pipeline, frame lanes - and keeps
+        # the faster, capi_render.hpp lane_mode: those frames are warm-up too, counted in config.tuning_frames)
+        ms3, ln = (F.C.c_float * 3)(), F.C.c_int(0)
+        while world == 1 and tuning["frames"] < 400 and 0 <= F.lib().fhip_debug_lane_tune(hip._h, ms3, F.C.byref(ln)) < 4:
+            step()
+            tuning["frames"] += 1
+        tuning["last"] = {"stage_pipeline_ms": [ms3[0], ms3[2]], "frame_lanes_ms": ms3[1], "kept": "frame lanes" if ln.value else "stage pipeline"}
         fence()
         # (the host only queues work here: a collection of the interpreter's garbage in the middle of the loop - 20 ms with torch and
         # numpy loaded - drains the three frames the pipeline holds and shows up as one frame of 10 x the median)
@@ -349,6 +357,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frame_latency_ms": lat_default,
+        "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "last_measured": tuning["last"],
+                              "note": "the library measures a run of queued frames of one kind under its stage pipeline and on its frame lanes and keeps the faster "
+                                      "(DESIGN.md section 4); bench.py lets that finish before the timed frames"},
         "general": general,
         "host_output_frame_ms": host_frame,
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
@@ -507,7 +518,7 @@ def main():
             m = 512
             bs, bo = F.Shape.from_vm(bear, hip=hip), O.Shape.from_vm(bear)
             bout = torch.zeros((m, m, 4), dtype=torch.int32, device=dev)
-            for _ in range(8):      # (the frame lanes - capi_render.hpp render3d_lane - get their buffers with their first frame each)
+            for _ in range(60):      # (the library's arrangement tuner takes ~50 queued frames of a kind, capi_render.hpp lane_mode)
                 F.render3d(bs, m, out=bout)
             fence()
             t0 = time.perf_counter()

@@ -63,7 +63,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_only_l1, 1) X(chain_prio, 0) X(tail_on_main, 2) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(frame_lanes, 3) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 4)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_only_l1, 1) X(chain_prio, 0) X(tail_on_main, 2) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(frame_lanes, 3) X(lanes_all, 0) X(lanes_tune, 1) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 4)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {
@@ -167,6 +167,20 @@ struct fhip_ctx : FrameBufs {
     uint64_t lane_frames = 0;         // frames that went to a lane so far (fhip_debug_lane_frames)
     hipEvent_t ev_last = nullptr;     // the end of the last 3D frame on the caller's stream ("is the frame before still under way?")
     bool ev_last_valid = false;
+    // Which of the two arrangements a queued 3D frame takes is MEASURED, per (tape, image size): consecutive queued frames of one kind
+    // run a window under the stage pipeline, then one on the lanes, each timed between two events on the caller's stream, and the
+    // faster arrangement is kept (capi_render.hpp lane_mode; option lanes_tune)
+    struct LaneTune {
+        uint64_t key = 0, used = 0;
+        int phase = 0;               // 0 / 1 / 2: windows under the stage pipeline, on the lanes, under the stage pipeline again; 3 waiting for the last window's end; 4 decided
+        uint32_t n = 0;              // consecutive queued frames of this kind in the current window
+        bool lanes = false;          // (decided) the lanes were faster
+        float ms[3] = {0.0f, 0.0f, 0.0f};  // ms per frame of the three windows
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    };
+    std::vector<LaneTune> lane_tune;
+    uint64_t tune_last_key = 0, tune_clock = 0;
+    int tune_cur = -1;                // the entry of the frame being queued (frame_queued marks its window), or -1
     // ... and what a context has when it IS a lane: its stream is its own, its image goes to the caller's buffer by a copy on the
     // caller's stream
     bool is_lane = false, lane_stream_owned = false;

@@ -147,6 +147,19 @@ fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, ui
 
 // Diagnostics: how many 3D frames of this context went to a frame lane (capi_render.hpp render3d_lane) so far
 uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx) { return ctx ? ctx->lane_frames : 0; }
+// ... and what the arrangement tuner (capi_render.hpp lane_mode) knows about the kind of 3D frame queued last: its phase (0 / 1 / 2 measuring the
+// stage pipeline, the lanes, the stage pipeline again; 3 waiting; 4 decided; -1: no such frame yet, or the last frame broke the sequence),
+// ms[0 .. 2] = ms per frame of the three windows, *lanes = the decision
+int fhip_debug_lane_tune(const fhip_ctx* ctx, float ms[3], int* lanes) {
+    if (!ctx) return -1;
+    for (const auto& t : ctx->lane_tune)
+        if (t.key == ctx->tune_last_key) {
+            if (ms) { ms[0] = t.ms[0]; ms[1] = t.ms[1]; ms[2] = t.ms[2]; }
+            if (lanes) *lanes = t.lanes ? 1 : 0;
+            return t.phase;
+        }
+    return -1;
+}
 
 // Diagnostics: `n` ops of the tape arena starting at op `off` (the tapes the last frame left there)
 uint32_t fhip_debug_arena(fhip_ctx* ctx, uint32_t off, uint32_t n, uint64_t* out) {

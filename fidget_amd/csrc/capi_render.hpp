@@ -1049,13 +1049,9 @@ static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
     (void)hipGetLastError();
     return q == hipErrorNotReady;
 }
-static bool lanes_wanted(fhip_ctx* ctx, const fhip_tape* tape, int out_is_device, const PartSpec& part) {
-    if (!ctx->use_pipeline || !ctx->frame_pipeline || ctx->opt.pipe_serial || !ctx->use_asm || ctx->opt.no_columns_t) return false;
-    if (part.n_shards != 1 || part.nx * part.ny * part.nz != 1) return false;
-    if (tape_asm_ok(tape->t)) return false;     // (the stage pipeline is the faster arrangement for these)
-    return lanes_possible(ctx, out_is_device);
-}
+static void lane_tune_release(fhip_ctx* ctx);
 static void lanes_release(fhip_ctx* ctx) {
+    lane_tune_release(ctx);       // (what was measured was measured under the options of the moment)
     for (fhip_ctx* L : ctx->lanes) {
         hipStream_t const s = L->lane_stream_owned ? L->stream : nullptr;
         if (L->lane_done) (void)hipEventDestroy(L->lane_done);
@@ -1105,20 +1101,98 @@ static fhip_status run_on_lane(fhip_ctx* ctx, size_t bytes, void* out, const std
     ctx->lane_frames++;
     return FHIP_OK;
 }
+// Stage pipeline or lanes?  Measured with three lanes on the stage pipeline's streams (ms per queued frame, profiles/r04r/lanes_all.txt):
+// prospero.vm 1024^3 0.505 / 0.570 (0.540 with four), with the column short cuts off 1.625 / 1.73 - but 512^3 1.66 / 1.15, 2048^3 2.18 / 1.99,
+// colonnade.vm 1024^3 0.605 / 0.454, 512^3 0.334 / 0.248, bear.vm 512^3 1.84 / 1.37.  The stage pipeline wins where a frame's stages happen to be
+// of equal length, which is a property of the model AND the size; nothing the host knows before the frame predicts it.  So it is measured:
+// consecutive queued frames of one kind (tape, image size) run TUNE_WIN frames under the stage pipeline, TUNE_WIN on the lanes and TUNE_WIN
+// under the stage pipeline again (a burst of frames starts on a machine whose clocks are still coming up, which counted against whatever
+// was measured first: the general path's stage pipeline read 2.0 ms in the first window and runs at 1.63), each window timed between two
+// events on the caller's stream after TUNE_SKIP frames of settling; the lanes are kept if they beat the better of the two stage windows
+// by 3 %, for the life of the context (or until an option changes).  Frames that break the sequence - another kind, a frame alone - restart the
+// window, so a queue of mixed frames never decides and keeps the prior: lanes for tapes with transcendental opcodes, the stage pipeline
+// otherwise.  Both arrangements give the same image, bit for bit (tests/test_gpu_parity.py).
+static constexpr uint32_t TUNE_SKIP = 6, TUNE_WIN = 10;
+static void lane_tune_release(fhip_ctx* ctx) {
+    for (auto& t : ctx->lane_tune)
+        for (hipEvent_t& e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    ctx->lane_tune.clear();
+    ctx->tune_last_key = 0;
+    ctx->tune_cur = -1;
+}
+static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, int out_is_device, const PartSpec& part) {
+    ctx->tune_cur = -1;
+    const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline && !ctx->opt.pipe_serial &&
+                          part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
+    const bool prior = ctx->use_asm && !ctx->opt.no_columns_t && (!tape_asm_ok(tape->t) || ctx->opt.lanes_all);
+    if (!possible) { ctx->tune_last_key = 0; return false; }       // (a frame alone, a shard, ...: the stage pipeline; the sequence is broken)
+    if (!ctx->opt.lanes_tune) return prior;
+    uint64_t key = tape->serial * 0x9E3779B97F4A7C15ull;
+    key ^= ((uint64_t)cfg->width << 42) ^ ((uint64_t)cfg->height << 21) ^ (uint64_t)cfg->depth;
+    key |= 1;
+    int at = -1;
+    for (size_t i = 0; i < ctx->lane_tune.size(); i++) if (ctx->lane_tune[i].key == key) at = (int)i;
+    if (at < 0) {
+        if (ctx->lane_tune.size() < 32) { ctx->lane_tune.emplace_back(); at = (int)ctx->lane_tune.size() - 1; }
+        else {      // the entry used longest ago makes room
+            at = 0;
+            for (size_t i = 1; i < ctx->lane_tune.size(); i++) if (ctx->lane_tune[i].used < ctx->lane_tune[at].used) at = (int)i;
+            for (hipEvent_t& e : ctx->lane_tune[at].ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            ctx->lane_tune[at] = fhip_ctx::LaneTune();
+        }
+        ctx->lane_tune[at].key = key;
+    }
+    fhip_ctx::LaneTune& T = ctx->lane_tune[at];
+    T.used = ++ctx->tune_clock;
+    if (T.phase == 4) { ctx->tune_last_key = key; return T.lanes; }
+    if (ctx->tune_last_key != key) {       // the first frame of a run of this kind: the window starts again behind it, and it goes where the prior says
+        ctx->tune_last_key = key;
+        if (T.phase < 3) { T.n = 0; return prior; }
+    }
+    if (T.phase == 3) {
+        const hipError_t q = hipEventQuery(T.ev[5]);
+        (void)hipGetLastError();
+        if (q != hipSuccess) return false;        // (under the stage pipeline until the last window's last event has passed)
+        bool ok = true;
+        for (int w = 0; w < 3; w++) {
+            float t = 0.0f;
+            ok = ok && hipEventElapsedTime(&t, T.ev[2 * w], T.ev[2 * w + 1]) == hipSuccess && t > 0.0f;
+            T.ms[w] = t / TUNE_WIN;
+        }
+        (void)hipGetLastError();
+        T.lanes = ok ? T.ms[1] < 0.97f * std::min(T.ms[0], T.ms[2]) : prior;
+        T.phase = 4;
+        return T.lanes;
+    }
+    ctx->tune_cur = at;
+    return T.phase == 1;
+}
 static fhip_status frame_queued(fhip_ctx* ctx, int out_is_device) {      // (the end of this frame, for the next one's lanes_possible)
     if (!out_is_device || ctx->is_lane || ctx->opt.frame_lanes < 2) return FHIP_OK;
     if (!ctx->ev_last) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_last, ctx->stream));
     ctx->ev_last_valid = true;
+    if (ctx->tune_cur >= 0) {       // a frame of a measuring window: its marks
+        fhip_ctx::LaneTune& T = ctx->lane_tune[(size_t)ctx->tune_cur];
+        ctx->tune_cur = -1;
+        T.n++;
+        if (T.n == TUNE_SKIP || T.n == TUNE_SKIP + TUNE_WIN) {
+            hipEvent_t& e = T.ev[2 * T.phase + (T.n == TUNE_SKIP ? 0 : 1)];
+            if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+            HIP_TRY(ctx, hipEventRecord(e, ctx->stream));
+            if (T.n == TUNE_SKIP + TUNE_WIN) { T.phase++; T.n = 0; }
+        }
+    }
     return FHIP_OK;
 }
 static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                  int out_is_device, const PartSpec& part) {
     (void)hipSetDevice(ctx->device);
-    const fhip_status st = lanes_wanted(ctx, tape, out_is_device, part)
+    const fhip_status st = lane_mode(ctx, tape, cfg, out_is_device, part)
         ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel), out,
                       [&](fhip_ctx* L, void* img) { return render3d_frame(L, tape, cfg, img, 1, part); })
         : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
+    if (st) ctx->tune_cur = -1;
     return st ? st : frame_queued(ctx, out_is_device);
 }
 // 2D frames have no stage pipeline at all - a frame is one chain of tile levels and a pixel kernel on the caller's stream - so every
@@ -1126,6 +1200,8 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
 // one-stream contexts in turn (profiles/r04r/frame_major3.txt)
 fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out, int out_is_device) {
     (void)hipSetDevice(ctx->device);
+    ctx->tune_cur = -1;
+    ctx->tune_last_key = 0;       // (a 2D frame between two 3D frames of one kind: their window starts again)
     const fhip_status st = lanes_possible(ctx, out_is_device)
         ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * 4, out, [&](fhip_ctx* L, void* img) { return render2d_frame(L, tape, cfg, (float*)img, 1); })
         : render2d_frame(ctx, tape, cfg, out, out_is_device);

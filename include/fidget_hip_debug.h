@@ -25,6 +25,10 @@ fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_inte
 /* 3D frames of this context that went to a frame lane so far (option frame_lanes: whole frames of a queued sequence on child contexts;
  * the statistics the other debug calls return are then those of the last frame that did NOT) */
 uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx);
+/* the arrangement tuner's state for the kind of 3D frame (tape, image size) queued last: returns its phase (0 / 1 / 2 measuring the stage pipeline,
+ * the lanes, the stage pipeline again; 3 waiting for the last window's end; 4 decided; -1 none); ms[0 .. 2] = ms per frame of the three windows,
+ * *lanes = the decision */
+int fhip_debug_lane_tune(const fhip_ctx* ctx, float ms[3], int* lanes);
 /* embedded copy `copy` of compiled routine `fn` (gen_trans.py COPIES / FUNCS + FUNCS4) over the floats with bits first .. first + n - 1
  * against the routine as the HIP kernels inline it: out = {results whose bits differ, an input where they do} */
 fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, uint32_t first, uint64_t n, uint64_t out[2]);

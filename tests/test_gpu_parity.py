@@ -318,6 +318,38 @@ def test_render3d_frame_lanes(lanes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,n", [("colonnade.vm", 256), ("prospero.vm", 512)])
+def test_render3d_arrangement_tuner(model, n):
+    """A run of queued frames of one kind is measured under the stage pipeline, on the lanes and under the stage pipeline again, and the
+    faster arrangement kept (capi_render.hpp lane_mode): every frame of the run - whichever arrangement it fell to - is the oracle's image,
+    the tuner reaches its decision, and a frame of another kind in between only restarts a window."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    shape, other = F.Shape.from_vm(model_path(model), hip=hip), F.Shape.from_vm(model_path("tanglecube.vm"), hip=hip)
+    outs = [torch.zeros((n, n, 4), dtype=torch.int32, device="cuda") for _ in range(7)]
+    o2 = torch.zeros((64, 64, 4), dtype=torch.int32, device="cuda")
+    ms, ln = (F.C.c_float * 3)(), F.C.c_int(0)
+    for i in range(90):
+        F.render3d(shape, n, out=outs[i % 7])
+        if i == 20:
+            F.render3d(other, 64, out=o2)
+    hip.sync()
+    assert F.lib().fhip_debug_lane_tune(hip._h, ms, F.C.byref(ln)) == 4 and min(ms) > 0.0, list(ms)
+    b = O.render3d(O.Shape.from_vm(model_path(model)), n)[0]
+    for o in outs:
+        a = o.cpu().numpy().view(np.uint32).reshape(n, n, 4)
+        assert (a[:, :, 3] == b["depth"]).all() and same_bits_f32(a[:, :, :3].copy().view(np.float32), b["normal"])
+    taken = F.lib().fhip_debug_lane_frames(hip._h)
+    assert taken >= 10          # (the lanes' window at least)
+    for i in range(12):         # decided: the run goes on in the arrangement kept
+        F.render3d(shape, n, out=outs[i % 7])
+    hip.sync()
+    now = F.lib().fhip_debug_lane_frames(hip._h)
+    assert now - taken in ((10, 11, 12) if ln.value else (0,)), (taken, now, ln.value)
+    del shape, other, hip
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lanes", [3, 0])
 def test_render2d_frame_lanes(lanes):
     """... and every queued 2D frame with a device output (a 2D frame has no stage pipeline to lose): a queue of 2D frames of different

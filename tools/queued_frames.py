@@ -28,3 +28,7 @@ for rep in range(3):
     hip.sync()
     res.append((time.perf_counter() - t0) / frames * 1e3)
 print(f"{model} {n}^3: {min(res):.3f} ms per queued frame (runs: {' '.join(f'{r:.3f}' for r in res)}), last image equals a frame alone: {bool(torch.equal(out, alone))}", flush=True)
+ms = (F.C.c_float * 3)()
+ln = F.C.c_int(0)
+ph = F.lib().fhip_debug_lane_tune(hip._h, ms, F.C.byref(ln))
+print(f"  arrangement tuner: phase {ph}, stage pipeline {ms[0]:.3f} ms per frame, lanes {ms[1]:.3f}, stage pipeline again {ms[2]:.3f}, decision: {'lanes' if ln.value else 'stage pipeline'}; {F.lib().fhip_debug_lane_frames(hip._h)} frames went to lanes", flush=True)
