@@ -534,7 +534,7 @@ def main():
                 ulp = np.abs(an - bn) / (scale * 2.0 ** -23)
             result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
-                                 "frames": "20 queued back to back on one stream; the library runs whole frames of such tapes on three child contexts in turn "
+                                 "frames": "20 queued back to back on one stream; the library runs whole queued frames on child contexts in turn where that measures faster "
                                            "(option frame_lanes; " + str(int(F.lib().fhip_debug_lane_frames(hip._h))) + " frames of this context went that way)",
                                  "note": "transcendental opcodes: the device runs the host libm's f32 routines restated operation by operation "
                                          "(fidget_amd/csrc/trans_libm.hpp; 0 of 2^32 arguments differ per routine, profiles/r04a/math_sweep.json)"}

@@ -1031,17 +1031,14 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     }
     return FHIP_OK;
 }
-// Frame lanes (option frame_lanes, default 3; 0 / 1: off).  The stage pipeline above runs the stages of consecutive frames beside
-// each other, each stage on its stream; how far that goes is set by the busiest stream.  For tapes with transcendental opcodes the
-// busiest stream carries the leaf kernels - fh_columns_t with its 256 VGPRs, two waves per SIMD - and one such kernel leaves most of
-// the machine's issue slots idle however the streams are arranged: bear.vm 512^3, 1.86 ms per queued frame with 3.2 ms of kernels in
-// it.  For those frames, when the caller queues them back to back (the frame before is still under way), WHOLE frames run beside
-// each other instead: lane i % K is a child context that keeps to one stream of its own (no_pipeline), renders into an image of its
-// own, and the caller's stream waits for it and copies the image out - so `out` is only ever touched on the caller's stream, in
-// order.  Measured with separate contexts driven in turn (tools/two_contexts.py, profiles/r04r): bear.vm 512^3 1.86 -> 1.38 ms with
-// three lanes (1.41 with four, 2.19 with two), 1024^3 5.25 -> 4.7; prospero.vm, whose kernels are the 128 / 160-VGPR ones, loses
-// (0.51 -> 0.59; with the column short cuts off 1.61 -> 1.99), which is why only the `_t` frames go this way.  A frame alone, a
-// host output buffer, a shard or a profiled frame take the stage pipeline as before.
+// Frame lanes (option frame_lanes, default 4; 0 / 1: off).  The stage pipeline above runs the stages of consecutive frames beside
+// each other, each stage on its stream; how far that goes is set by the busiest stream.  The other arrangement for frames that the
+// caller queues back to back (the frame before is still under way): WHOLE frames beside each other - lane i % K is a child context
+// that keeps to one stream (no_pipeline) and renders into an image of its own; the caller's stream waits for it and copies the image
+// out, so `out` is only ever touched on the caller's stream, in order.  First measured with separate contexts driven in turn
+// (tools/two_contexts.py under FHIP_NO_PIPELINE=1, profiles/r04r): bear.vm 512^3 - fh_columns_t with its 256 VGPRs, two waves per SIMD,
+// 3.2 ms of kernels in a frame of 1.86 ms - 1.38 ms with three contexts; which arrangement a 3D frame takes is decided by lane_mode
+// below.  A frame alone, a host output buffer, a shard or a profiled frame take the stage pipeline as before.
 static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
     if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats || ctx->opt.side_cus) return false;
     if (!ctx->ev_last_valid) return false;
@@ -1063,8 +1060,8 @@ static void lanes_release(fhip_ctx* ctx) {
     ctx->lanes.clear();
 }
 // One frame on the next lane: render(lane, image) queues it on the lane's stream into the lane's own image of `bytes` bytes
-static fhip_status run_on_lane(fhip_ctx* ctx, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
-    const uint32_t K = (uint32_t)std::min(ctx->opt.frame_lanes, 8);
+static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
+    const uint32_t K = std::min((uint32_t)std::min(ctx->opt.frame_lanes, 8), max_lanes);
     while (ctx->lanes.size() < K) {
         // (the first three lanes ride on the streams of the stage pipeline, which is idle while the lanes run: the runtime shares a few
         // hardware queues - four by default - among all streams that have work, and lanes on streams of their own ended up two to a
@@ -1189,12 +1186,15 @@ static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhi
                                  int out_is_device, const PartSpec& part) {
     (void)hipSetDevice(ctx->device);
     const fhip_status st = lane_mode(ctx, tape, cfg, out_is_device, part)
-        ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel), out,
+        ? run_on_lane(ctx, 8, (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel), out,
                       [&](fhip_ctx* L, void* img) { return render3d_frame(L, tape, cfg, img, 1, part); })
         : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
     if (st) ctx->tune_cur = -1;
     return st ? st : frame_queued(ctx, out_is_device);
 }
+// (Four lanes by default, the fourth on a stream of its own: against three, prospero.vm 512^3 1.14 -> 0.91 ms per frame, colonnade.vm 1024^3 /
+// 512^3 0.441 / 0.252 -> 0.413 / 0.212, bear.vm the same, gyroid-sphere 1024^3 1.14 -> 1.18; 2D frames keep to the three on the stage
+// pipeline's streams: 4096^2 0.266 with three, 0.306 with four - profiles/r04r/lanes_3_or_4.txt.)
 // 2D frames have no stage pipeline at all - a frame is one chain of tile levels and a pixel kernel on the caller's stream - so every
 // queued 2D frame with a device output takes a lane: prospero.vm 4096^2 0.475 -> 0.333 ms per frame, 1024^2 0.83 -> 0.50 with three
 // one-stream contexts in turn (profiles/r04r/frame_major3.txt)
@@ -1203,7 +1203,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     ctx->tune_cur = -1;
     ctx->tune_last_key = 0;       // (a 2D frame between two 3D frames of one kind: their window starts again)
     const fhip_status st = lanes_possible(ctx, out_is_device)
-        ? run_on_lane(ctx, (size_t)cfg->width * cfg->height * 4, out, [&](fhip_ctx* L, void* img) { return render2d_frame(L, tape, cfg, (float*)img, 1); })
+        ? run_on_lane(ctx, 3, (size_t)cfg->width * cfg->height * 4, out, [&](fhip_ctx* L, void* img) { return render2d_frame(L, tape, cfg, (float*)img, 1); })
         : render2d_frame(ctx, tape, cfg, out, out_is_device);
     return st ? st : frame_queued(ctx, out_is_device);
 }
