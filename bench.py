@@ -189,11 +189,14 @@ def main():
             step()
         # (the library times the first ~50 queued frames of a kind under its two frame arrangements - stage pipeline, frame lanes - and keeps
         # the faster, capi_render.hpp lane_mode: those frames are warm-up too, counted in config.tuning_frames)
-        ms3, ln = (F.C.c_float * 3)(), F.C.c_int(0)
-        while world == 1 and tuning["frames"] < 400 and 0 <= F.lib().fhip_debug_lane_tune(hip._h, ms3, F.C.byref(ln)) < 4:
+        while world == 1 and tuning["frames"] < 400 and 0 <= hip.lane_tune()["phase"] < 4:
             step()
             tuning["frames"] += 1
-        tuning["last"] = {"stage_pipeline_ms": [ms3[0], ms3[2]], "frame_lanes_ms": ms3[1], "kept": "frame lanes" if ln.value else "stage pipeline"}
+        if world > 1:       # (every rank the same number of steps - there are collectives in them -, so a fixed count here: what the tuner takes, and a few)
+            for _ in range(60):
+                step()
+            tuning["frames"] += 60
+        tuning["last"] = hip.lane_tune()
         fence()
         # (the host only queues work here: a collection of the interpreter's garbage in the middle of the loop - 20 ms with torch and
         # numpy loaded - drains the three frames the pipeline holds and shows up as one frame of 10 x the median)
@@ -535,7 +538,7 @@ def main():
             result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
                                  "frames": "20 queued back to back on one stream; the library runs whole queued frames on child contexts in turn where that measures faster "
-                                           "(option frame_lanes; " + str(int(F.lib().fhip_debug_lane_frames(hip._h))) + " frames of this context went that way)",
+                                           "(option frame_lanes; " + str(hip.lane_frames()) + " frames of this context went that way)",
                                  "note": "transcendental opcodes: the device runs the host libm's f32 routines restated operation by operation "
                                          "(fidget_amd/csrc/trans_libm.hpp; 0 of 2^32 arguments differ per routine, profiles/r04a/math_sweep.json)"}
         # BASELINE configuration 5 (Manifold Dual Contouring of gyroid-sphere at octree depth 10 = 1024^3: fhip_mesh_build, the octree

@@ -234,6 +234,17 @@ class HipContext:
     def cancel_reset(self):
         lib().fhip_cancel_reset(self._h)
 
+    def lane_tune(self):
+        """What the frame arrangement tuner knows about the kind of 3D frame queued last (fhip_debug_lane_tune): phase 0 .. 2 measuring
+        (stage pipeline, lanes, stage pipeline again), 3 waiting, 4 decided, -1 none; ms per frame of the three windows; the decision."""
+        ms, ln = (C.c_float * 3)(), C.c_int(0)
+        ph = lib().fhip_debug_lane_tune(self._h, ms, C.byref(ln))
+        return {"phase": int(ph), "stage_pipeline_ms": [float(ms[0]), float(ms[2])], "frame_lanes_ms": float(ms[1]), "kept": "frame lanes" if ln.value else "stage pipeline"}
+
+    def lane_frames(self):
+        """Frames of this context that went to a frame lane so far (fhip_debug_lane_frames)"""
+        return int(lib().fhip_debug_lane_frames(self._h))
+
     def set_option(self, name, value=1):
         """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "slab_contexts", ...).  The environment
         (FHIP_<NAME>) is read once, when the context is created; this is the only way to change a switch afterwards."""

@@ -1038,7 +1038,9 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 // out, so `out` is only ever touched on the caller's stream, in order.  First measured with separate contexts driven in turn
 // (tools/two_contexts.py under FHIP_NO_PIPELINE=1, profiles/r04r): bear.vm 512^3 - fh_columns_t with its 256 VGPRs, two waves per SIMD,
 // 3.2 ms of kernels in a frame of 1.86 ms - 1.38 ms with three contexts; which arrangement a 3D frame takes is decided by lane_mode
-// below.  A frame alone, a host output buffer, a shard or a profiled frame take the stage pipeline as before.
+// below.  A frame alone, a host output buffer or a profiled frame take the stage pipeline as before.  Parts of a frame (shards, blocks: what a rank of a
+// multi-GPU job renders) are frames like any other here (option lanes_parts): one octant of prospero.vm 1024^3, queued, 0.72 -> 0.31 ms; a
+// column shard of eight stays where it is, 0.43 (profiles/r04r/lanes_parts.txt).
 static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
     if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats || ctx->opt.side_cus) return false;
     if (!ctx->ev_last_valid) return false;
@@ -1119,13 +1121,14 @@ static void lane_tune_release(fhip_ctx* ctx) {
 }
 static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, int out_is_device, const PartSpec& part) {
     ctx->tune_cur = -1;
-    const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline && !ctx->opt.pipe_serial &&
-                          part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
+    const bool whole = part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
+    const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline && !ctx->opt.pipe_serial && (whole || ctx->opt.lanes_parts);
     const bool prior = ctx->use_asm && !ctx->opt.no_columns_t && (!tape_asm_ok(tape->t) || ctx->opt.lanes_all);
     if (!possible) { ctx->tune_last_key = 0; return false; }       // (a frame alone, a shard, ...: the stage pipeline; the sequence is broken)
     if (!ctx->opt.lanes_tune) return prior;
     uint64_t key = tape->serial * 0x9E3779B97F4A7C15ull;
     key ^= ((uint64_t)cfg->width << 42) ^ ((uint64_t)cfg->height << 21) ^ (uint64_t)cfg->depth;
+    key ^= (((uint64_t)part.shard * 64 + part.n_shards) * 0xD6E8FEB86659FD93ull) ^ ((((uint64_t)part.ix * 16 + part.iy) * 16 + part.iz) * 4096 + (part.nx * 16 + part.ny) * 16 + part.nz) * 0xA24BAED4963EE407ull;
     key |= 1;
     int at = -1;
     for (size_t i = 0; i < ctx->lane_tune.size(); i++) if (ctx->lane_tune[i].key == key) at = (int)i;

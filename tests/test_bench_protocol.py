@@ -106,6 +106,8 @@ def _worker(rank, world, port, out_path, direct):
         def wave_stats(self): pass
         def leaf_stats(self): return {"leaves": 0, "tape_ops": 0, "tape_words_read": 0, "lane_ops": 0}
         def option(self, name): return 0
+        def lane_tune(self): return {"phase": -1, "stage_pipeline_ms": [0.0, 0.0], "frame_lanes_ms": 0.0, "kept": "stage pipeline"}
+        def lane_frames(self): return 0
         def set_option(self, name, value=1): pass
 
         def options(self, **kw):

@@ -350,6 +350,47 @@ def test_render3d_arrangement_tuner(model, n):
 
 
 @pytest.mark.gpu
+def test_render3d_lanes_for_parts_of_a_frame():
+    """Shards and blocks - what a rank of a multi-GPU job renders - queued back to back take the lanes like whole frames (option lanes_parts):
+    every part, whichever arrangement its frames fell to, equals the part rendered alone by a context without lanes, and the parts of a
+    split still merge to the oracle's frame."""
+    import torch
+    n = 512
+    ref_ctx = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    ref_ctx.set_option("frame_lanes", 0)
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    sa, sb = F.Shape.from_vm(model_path("prospero.vm"), hip=ref_ctx), F.Shape.from_vm(model_path("prospero.vm"), hip=hip)
+    parts = [{"block": (i, (2, 2, 2))} for i in range(8)] + [{"shard": 1, "n_shards": 4}]
+    outs = [torch.zeros((n, n, 4), dtype=torch.int32, device="cuda") for _ in parts]
+    for rep in range(3):                         # mixed: the prior (stage pipeline) ...
+        for kw, o in zip(parts, outs):
+            F.render3d(sb, n, out=o, **kw)
+    for kw, o in zip(parts[6:8], outs[6:8]):       # ... and runs of one kind, long enough for the tuner to take them through the lanes
+        for i in range(60):
+            F.render3d(sb, n, out=o, **kw)
+    hip.sync()
+    assert F.lib().fhip_debug_lane_frames(hip._h) >= 20
+    for kw, o in zip(parts, outs):
+        alone = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+        F.render3d(sa, n, out=alone, **kw)
+        ref_ctx.sync()
+        assert torch.equal(o, alone), kw
+    # front to back over the two z halves of every column block, then the union of the four column blocks: the whole frame
+    img = None
+    for ix in range(2):
+        for iy in range(2):
+            front, back = outs[ix + 2 * iy + 4].clone(), outs[ix + 2 * iy]
+            F.merge_depth(front, back, n, hip=hip)
+            img = front if img is None else torch.maximum(img.view(torch.int64), front.view(torch.int64)).view(torch.int32)
+    hip.sync()
+    whole = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
+    F.render3d(sa, n, out=whole)
+    ref_ctx.sync()
+    assert torch.equal(img[..., 3], whole[..., 3])
+    del sa, sb, hip, ref_ctx
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lanes", [3, 0])
 def test_render2d_frame_lanes(lanes):
     """... and every queued 2D frame with a device output (a 2D frame has no stage pipeline to lose): a queue of 2D frames of different
