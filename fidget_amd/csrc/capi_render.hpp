@@ -1062,8 +1062,9 @@ static void lanes_release(fhip_ctx* ctx) {
     ctx->lanes.clear();
 }
 // One frame on the next lane: render(lane, image) queues it on the lane's stream into the lane's own image of `bytes` bytes
-static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
+static fhip_status run_on_lane_(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
     const uint32_t K = std::min((uint32_t)std::min(ctx->opt.frame_lanes, 8), max_lanes);
+    if (ctx->opt.lanes_fail) return fail(ctx, FHIP_ERR_HIP, "frame lanes: failure provoked (option lanes_fail)");
     while (ctx->lanes.size() < K) {
         // (the first three lanes ride on the streams of the stage pipeline, which is idle while the lanes run: the runtime shares a few
         // hardware queues - four by default - among all streams that have work, and lanes on streams of their own ended up two to a
@@ -1100,7 +1101,19 @@ static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, 
     ctx->lane_frames++;
     return FHIP_OK;
 }
-// Stage pipeline or lanes?  Measured with three lanes on the stage pipeline's streams (ms per queued frame, profiles/r04r/lanes_all.txt):
+// (FHIP_LANE_FALLBACK: the lanes' own resources could not be had - device memory for a child context's buffers, say: the caller renders the
+// frame under the stage pipeline instead, and the context gives its lanes up for good; option lanes_fail provokes it, for the test)
+static const fhip_status FHIP_LANE_FALLBACK = (fhip_status)1000;
+static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
+    const fhip_status st = run_on_lane_(ctx, max_lanes, bytes, out, render);
+    if (st != FHIP_ERR_HIP) return st;
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);      // (nothing of the lanes may be pending on the caller's stream when they go)
+    ctx->opt.frame_lanes = 0;
+    lanes_release(ctx);
+    ctx->err.clear();
+    return FHIP_LANE_FALLBACK;
+}// Stage pipeline or lanes?  Measured with three lanes on the stage pipeline's streams (ms per queued frame, profiles/r04r/lanes_all.txt):
 // prospero.vm 1024^3 0.505 / 0.570 (0.540 with four), with the column short cuts off 1.625 / 1.73 - but 512^3 1.66 / 1.15, 2048^3 2.18 / 1.99,
 // colonnade.vm 1024^3 0.605 / 0.454, 512^3 0.334 / 0.248, bear.vm 512^3 1.84 / 1.37.  The stage pipeline wins where a frame's stages happen to be
 // of equal length, which is a property of the model AND the size; nothing the host knows before the frame predicts it.  So it is measured:
@@ -1188,10 +1201,11 @@ static fhip_status frame_queued(fhip_ctx* ctx, int out_is_device) {      // (the
 static fhip_status render3d_part(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                  int out_is_device, const PartSpec& part) {
     (void)hipSetDevice(ctx->device);
-    const fhip_status st = lane_mode(ctx, tape, cfg, out_is_device, part)
+    fhip_status st = lane_mode(ctx, tape, cfg, out_is_device, part)
         ? run_on_lane(ctx, 8, (size_t)cfg->width * cfg->height * sizeof(FhGeometryPixel), out,
                       [&](fhip_ctx* L, void* img) { return render3d_frame(L, tape, cfg, img, 1, part); })
         : render3d_frame(ctx, tape, cfg, out, out_is_device, part);
+    if (st == FHIP_LANE_FALLBACK) st = render3d_frame(ctx, tape, cfg, out, out_is_device, part);
     if (st) ctx->tune_cur = -1;
     return st ? st : frame_queued(ctx, out_is_device);
 }
@@ -1205,9 +1219,10 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
     (void)hipSetDevice(ctx->device);
     ctx->tune_cur = -1;
     ctx->tune_last_key = 0;       // (a 2D frame between two 3D frames of one kind: their window starts again)
-    const fhip_status st = lanes_possible(ctx, out_is_device)
+    fhip_status st = lanes_possible(ctx, out_is_device)
         ? run_on_lane(ctx, 3, (size_t)cfg->width * cfg->height * 4, out, [&](fhip_ctx* L, void* img) { return render2d_frame(L, tape, cfg, (float*)img, 1); })
         : render2d_frame(ctx, tape, cfg, out, out_is_device);
+    if (st == FHIP_LANE_FALLBACK) st = render2d_frame(ctx, tape, cfg, out, out_is_device);
     return st ? st : frame_queued(ctx, out_is_device);
 }
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,

@@ -350,6 +350,29 @@ def test_render3d_arrangement_tuner(model, n):
 
 
 @pytest.mark.gpu
+def test_frame_lanes_that_cannot_be_had_fall_back_to_the_stage_pipeline():
+    """The lanes need device memory of their own (a child context's buffers); when that fails the frame is rendered under the stage pipeline
+    and the context gives its lanes up - the caller sees frames, not an error (option lanes_fail provokes the failure)."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("lanes_fail", 1)
+    shape = F.Shape.from_vm(model_path("bear.vm"), hip=hip)
+    outs = [torch.zeros((128, 128, 4), dtype=torch.int32, device="cuda") for _ in range(3)]
+    o2 = torch.zeros((256, 256), dtype=torch.float32, device="cuda")
+    for i in range(9):
+        F.render3d(shape, 128, out=outs[i % 3])
+        F.render2d(shape, 256, out=o2)
+    hip.sync()
+    assert hip.lane_frames() == 0 and hip.option("frame_lanes") == 0
+    b = O.render3d(O.Shape.from_vm(model_path("bear.vm")), 128)[0]
+    for o in outs:
+        a = o.cpu().numpy().view(np.uint32).reshape(128, 128, 4)
+        assert (a[:, :, 3] == b["depth"]).all() and same_bits_f32(a[:, :, :3].copy().view(np.float32), b["normal"])
+    assert same_bits_f32(o2.cpu().numpy(), O.render2d(O.Shape.from_vm(model_path("bear.vm")), 256, tile_sizes=F.HIP_TILES_2D)[0])
+    del shape, hip
+
+
+@pytest.mark.gpu
 def test_render3d_lanes_for_parts_of_a_frame():
     """Shards and blocks - what a rank of a multi-GPU job renders - queued back to back take the lanes like whole frames (option lanes_parts):
     every part, whichever arrangement its frames fell to, equals the part rendered alone by a context without lanes, and the parts of a
