@@ -160,7 +160,7 @@ struct fhip_ctx : FrameBufs {
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> asm_events;   // ... and per assembly kernel launch
     FhRenderState last_state;
     bool have_last_state = false;
-    // Frame lanes (capi_render.hpp render3d_lane; option frame_lanes): child contexts, each on one stream of its own, that take whole
+    // Frame lanes (capi_render.hpp run_on_lane; option frame_lanes): child contexts, each on one stream of its own, that take whole
     // frames of a queued sequence in turn when the frames' kernels are the 256-VGPR ones
     std::vector<fhip_ctx*> lanes;
     uint32_t lane_next = 0;

@@ -145,7 +145,7 @@ fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, ui
     return FHIP_OK;
 }
 
-// Diagnostics: how many 3D frames of this context went to a frame lane (capi_render.hpp render3d_lane) so far
+// Diagnostics: how many frames of this context went to a frame lane (capi_render.hpp run_on_lane) so far
 uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx) { return ctx ? ctx->lane_frames : 0; }
 // ... and what the arrangement tuner (capi_render.hpp lane_mode) knows about the kind of 3D frame queued last: its phase (0 / 1 / 2 measuring the
 // stage pipeline, the lanes, the stage pipeline again; 3 waiting; 4 decided; -1: no such frame yet, or the last frame broke the sequence),

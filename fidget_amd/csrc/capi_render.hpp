@@ -1113,7 +1113,8 @@ static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, 
     lanes_release(ctx);
     ctx->err.clear();
     return FHIP_LANE_FALLBACK;
-}// Stage pipeline or lanes?  Measured with three lanes on the stage pipeline's streams (ms per queued frame, profiles/r04r/lanes_all.txt):
+}
+// Stage pipeline or lanes?  Measured with three lanes on the stage pipeline's streams (ms per queued frame, profiles/r04r/lanes_all.txt):
 // prospero.vm 1024^3 0.505 / 0.570 (0.540 with four), with the column short cuts off 1.625 / 1.73 - but 512^3 1.66 / 1.15, 2048^3 2.18 / 1.99,
 // colonnade.vm 1024^3 0.605 / 0.454, 512^3 0.334 / 0.248, bear.vm 512^3 1.84 / 1.37.  The stage pipeline wins where a frame's stages happen to be
 // of equal length, which is a property of the model AND the size; nothing the host knows before the frame predicts it.  So it is measured:
@@ -1137,7 +1138,7 @@ static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_
     const bool whole = part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
     const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline && !ctx->opt.pipe_serial && (whole || ctx->opt.lanes_parts);
     const bool prior = ctx->use_asm && !ctx->opt.no_columns_t && (!tape_asm_ok(tape->t) || ctx->opt.lanes_all);
-    if (!possible) { ctx->tune_last_key = 0; return false; }       // (a frame alone, a shard, ...: the stage pipeline; the sequence is broken)
+    if (!possible) { ctx->tune_last_key = 0; return false; }       // (a frame alone, a profiled frame, ...: the stage pipeline; the sequence is broken)
     if (!ctx->opt.lanes_tune) return prior;
     uint64_t key = tape->serial * 0x9E3779B97F4A7C15ull;
     key ^= ((uint64_t)cfg->width << 42) ^ ((uint64_t)cfg->height << 21) ^ (uint64_t)cfg->depth;
