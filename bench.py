@@ -153,6 +153,11 @@ def main():
 
     n = args.size
     stream = torch.cuda.current_stream(dev)
+    mem_info = getattr(torch.cuda, "mem_get_info", None)
+    try:        # (device memory the library takes: hipMalloc'd by the context, not by torch)
+        free_before = mem_info(dev)[0]
+    except Exception:       # noqa: BLE001
+        free_before = None
     hip = F.HipContext(local, stream.cuda_stream)
     shape = F.Shape.from_vm(os.path.join(ROOT, "models", args.model), hip=hip)
     out = torch.zeros((n, n, 4), dtype=torch.int32, device=dev)  # GeometryPixel = 4 x 32-bit words
@@ -298,6 +303,12 @@ def main():
         host_frame = float(np.median([F.render3d(shape, n, host_out=pinned)[2] * 1e3 for _ in range(9)]))
     hip.sync()
     counters = hip.counters()
+    device_bytes = None
+    if free_before is not None:
+        try:
+            device_bytes = int(free_before - mem_info(dev)[0])
+        except Exception:       # noqa: BLE001
+            device_bytes = None
 
     # ---- per-kernel timing with HIP events on the render stream (separate, profiled frames) ----
     # Every launch of an assembly kernel sits between its own pair of events; the same frames fill the device's op counters
@@ -360,6 +371,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frame_latency_ms": lat_default,
+        "device_bytes": device_bytes,
         "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "last_measured": tuning["last"],
                               "note": "the library measures a run of queued frames of one kind under its stage pipeline and on its frame lanes and keeps the faster "
                                       "(DESIGN.md section 4); bench.py lets that finish before the timed frames"},
@@ -368,15 +380,13 @@ def main():
         "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
                    "sharding": sharding,
                    "general_path": None if not general else {"ms_per_step": general["ms_per_step"], "value": general["value"],
-                                                             "frame_latency_ms": general["frame_latency_ms"],
-                                                             "what": "the same frames with the column-invariance short cuts off: what a model with z in its tapes gets"},
+                                                             "frame_latency_ms": general["frame_latency_ms"]},
                    "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (two buffer "
                              "sets per context: the coarse levels of a frame run beside the previous frame's slabs), every frame does all of its "
                              "work; frame_latency_ms is one frame alone, host_output_frame_ms the blocking call with a host buffer",
-                   "column_invariance": ("OFF for every number of this line (--only-general)" if args.only_general else
-                                         "tapes that read no input varying along z (under this camera: no z) are evaluated once per pixel "
-                                         "column / once per z-stack of tiles (DESIGN.md section 2); prospero.vm is an extrusion, so all of its "
-                                         "tapes qualify - `general` times the same frames with the short cuts off, and `roofline` is that path's")},
+                   "column_invariance": ("off for every number of this line (--only-general)" if args.only_general else
+                                         "prospero.vm reads no z, so `value` evaluates each tape once per pixel column (DESIGN.md section 2); "
+                                         "general_path = the same frames with that short cut off, what a model with z gets")},
         "kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in pmain["prof"].items()},
         "kernel_launches_per_frame": {k: v[1] // PROF_FRAMES for k, v in pmain["prof"].items()},
         "asm_kernel_ms_per_frame": {k: v[0] / PROF_FRAMES for k, v in pmain["kern"].items() if v[1]},
@@ -499,19 +509,12 @@ def main():
                             "normals_equal": bool((got[..., :3].view(np.float32) == want[..., :3].view(np.float32)).all()),
                             "general_path_image_equals_default": None if not general else general["image_equals_default_path"]}
         cores = O.max_threads()
-        CPU_FRAMES = 10
+        CPU_FRAMES = 7
         secs = sorted(O.render3d(oshape, n)[2] for _ in range(CPU_FRAMES))
         med = float(np.median(secs))
-        small = max(n // 4, 64)
-        O.render3d(oshape, small, threads=1)
-        one = float(np.median([O.render3d(oshape, small, threads=1)[2] for _ in range(3)]))
         result["cpu_baseline"] = {"value": (n ** 3) / med / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
-                                  "sample": f"median of {CPU_FRAMES} full {n}^3 frames after one warm-up frame ({med:.3f} s each, min {secs[0]:.3f}, "
-                                            f"on {cores} threads); C++ restatement of the reference VmShape interpreter path (OpenMP over root "
-                                            "tiles like render_tiles' rayon pool), not the Rust JIT (published JIT/VM ratio on M1 Max: "
-                                            "61.7/23.6 = 2.6x, README.md:154)",
-                                  "one_thread": {"value": (small ** 3) / one / 1e6, "unit": "Mvoxel/s", "cores": 1,
-                                                 "sample": f"median of 3 frames at {small}^3 (1/{(n // small) ** 3} of the volume), one thread"}}
+                                  "sample": f"median of {CPU_FRAMES} full {n}^3 frames after one warm-up ({med:.3f} s each, min {secs[0]:.3f}) on {cores} threads; "
+                                            "C++ restatement of the reference's VmShape path, OpenMP over root tiles; not the Rust JIT (no toolchain)"}
         result["oracle_counters"] = {k: st[k] for k in ("interval_evals", "interval_ops", "float_evals", "float_points",
                                                          "float_lane_ops", "float_wave_ops", "grad_points")}
         # BASELINE configuration 3 (the gradient path on a tape with transcendental opcodes): frame time and the measured error
@@ -553,9 +556,102 @@ def main():
                 result["c5_mesh"] = c5 if c5 else {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
             except Exception as e:      # (a time-out included: the line's other fields do not depend on this leg)
                 result["c5_mesh"] = {"error": repr(e)}
-    print(json.dumps(result))
+    line = compact_line(result)
+    details_path = write_details(result)
+    if details_path:
+        line["details"] = details_path
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    print(text)
     if world > 1:
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 6000       # bytes: the driver's record keeps the line whole only when it is short (round 4's 20.6 KB line came back unparsed)
+
+
+def _rnd(x, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a dump)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _rnd(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_rnd(v, sig) for v in x]
+    return x
+
+
+def _roof_short(r):
+    """One roofline object of the line: the contract's fields (bound achieved peak unit frac traffic) + what they were computed from,
+    the instruction-side figures as fractions; the prose lives in DESIGN.md section 5 and in the details file."""
+    if not r:
+        return None
+    o = {k: r[k] for k in ("bound", "kernel", "path", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                           "avg_launch_ms", "launches_per_frame") if k in r}
+    if r.get("alu"):
+        o["alu"] = {k: r["alu"][k] for k in ("achieved", "peak", "unit", "frac")}
+    if r.get("issue"):
+        o["issue"] = {k: r["issue"][k] for k in ("achieved", "peak", "unit", "frac")}
+    if r.get("path_frame"):
+        o["path_frame"] = {k: r["path_frame"][k] for k in ("ms_per_step", "value", "frame_latency_ms")}
+    if r.get("traffic_note"):
+        o["traffic_note"] = r["traffic_note"][:120]
+    return o
+
+
+def compact_line(result):
+    """The ONE JSON line: one object per fact, no prose beyond a sentence, < LINE_LIMIT bytes (tests/test_bench_protocol.py holds the key
+    set and the size).  Everything else bench.py measured - per-kernel times, device counters, the other kernels' rooflines, the notes -
+    goes to the details file the line names."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes")
+    line = {k: result[k] for k in keep if k in result}
+    cfg = result["config"]
+    line["config"] = {"workload": cfg["workload"], "sharding": cfg["sharding"], "column_invariance": cfg["column_invariance"][:300],
+                      "general_path": {k: cfg["general_path"][k] for k in ("ms_per_step", "value", "frame_latency_ms")} if cfg.get("general_path") else None}
+    for k in ("roofline", "roofline_timed_path"):
+        if result.get(k):
+            line[k] = _roof_short(result[k])
+    if result.get("cpu_baseline"):
+        line["cpu_baseline"] = {k: result["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+    if result.get("parity"):
+        line["parity"] = result["parity"]
+    if result.get("c3_bear"):
+        line["c3_bear"] = {k: result["c3_bear"].get(k) for k in ("workload", "ms_per_frame", "depth_equal", "normals_bit_equal_fraction")}
+    if result.get("c5_mesh"):
+        c5 = result["c5_mesh"]
+        line["c5_mesh"] = ({k: c5.get(k) for k in ("workload", "s_per_build", "s_per_build_inside_the_library", "triangles", "vertices",
+                                                    "parity", "cpu_s_per_build", "cpu_threads") if k in c5}
+                           if "error" not in c5 else {"error": str(c5["error"])[:200]})
+    if result.get("partitions"):
+        short = {}
+        for k, v in result["partitions"].items():
+            short[k] = {kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "frame_latency_ms", "scaling", "split", "frames_per_step",
+                                                                  "images_equal")} if isinstance(v, dict) else v
+        line["partitions"] = short
+        line["collectives"] = (result.get("collectives") or "")[:100]
+        line["per_rank"] = result.get("per_rank")
+    line = _rnd(line)
+    # should the line still outgrow the limit (a long error text, 8 ranks of stage times): shed the optional objects, never the contract's
+    for k in ("per_rank", "c3_bear", "c5_mesh", "parity", "roofline_timed_path"):
+        if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT - 200:
+            break
+        line.pop(k, None)
+    return line
+
+
+def write_details(result):
+    """Everything bench.py measured, as one JSON file next to the run (gpurun_out/ travels back from the GPU box); the path goes into the line"""
+    for d in ("gpurun_out", "."):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            rel = os.path.join(d, f"bench_details_n{result['n_gpus']}.json")
+            with open(os.path.join(ROOT, rel), "w") as f:
+                json.dump(result, f, indent=1)
+            return rel
+        except OSError:
+            continue
+    return None
 
 
 if __name__ == "__main__":

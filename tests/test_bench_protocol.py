@@ -154,6 +154,7 @@ def test_bench_two_ranks_protocol(tmp_path, direct, world):
     mp.spawn(_worker, args=(world, port, out_path, direct), nprocs=world, join=True)
     lines = [l for l in open(out_path).read().splitlines() if l.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 6000, len(lines[0])          # the driver's record keeps a short line whole (round 4's 20.6 KB line came back unparsed)
     r = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in r, key
@@ -193,3 +194,57 @@ def test_c5_mesh_leg_reads_the_mesh_tools_output():
     assert 1.0 < c5["s_per_build_inside_the_library"] < c5["s_per_build"] < c5["s_first_build"] < 2.0
     assert bench.parse_mesh_times("Traceback (most recent call last): ...", "") is None
     assert bench.parse_mesh_times("10 build 0 1.5\n", "") is None          # (one build only: nothing after the first)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_the_single_gpu_line_is_short_and_has_the_contract_keys():
+    """bench.py's N = 1 line is cut down by compact_line from everything the run measured: here on the full record of an MI355X run
+    (profiles/r04z/bench.json, the 20.6 KB line the driver could not parse) - under 6 000 bytes, one object per fact, the contract's
+    keys, `roofline` and `cpu_baseline` with their fields."""
+    bench = _bench_module()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04z", "bench.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 15000
+    full["device_bytes"] = 1 << 30
+    full["c5_mesh"].update(parity={"triangles_equal": True, "vertices_equal": True}, cpu_s_per_build=10.0, cpu_threads=128)
+    line = bench.compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 6000, len(text)
+    assert set(line) == {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "config", "roofline",
+                         "roofline_timed_path", "cpu_baseline", "parity", "c3_bear", "c5_mesh"}
+    assert set(line["config"]) == {"workload", "sharding", "column_invariance", "general_path"}
+    assert set(line["config"]["general_path"]) == {"ms_per_step", "value", "frame_latency_ms"}
+    for k in ("roofline", "roofline_timed_path"):
+        r = line[k]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "path", "avg_launch_ms", "alu", "issue", "path_frame"} <= set(r)
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 * r["frac"]
+        assert all(isinstance(v, (int, float, str, type(None))) for kk, v in r.items() if kk not in ("alu", "issue", "path_frame"))
+    assert line["roofline"]["kernel"] == "fh_columns" and line["roofline"]["path"] == "general"
+    assert line["roofline_timed_path"]["path"] == "default"
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline"]["kind"] == "port"
+    assert line["c5_mesh"]["parity"] == {"triangles_equal": True, "vertices_equal": True} and line["c5_mesh"]["cpu_s_per_build"] == 10.0
+    # nothing in the line is said twice, and no value is a paragraph
+    def strings(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in strings(line)) < 400
+
+
+def test_a_line_that_would_outgrow_the_limit_sheds_optional_objects_first():
+    bench = _bench_module()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04z", "bench.json")).read().strip().splitlines()[-1])
+    full["per_rank"] = [{"rank": r, "note": "x" * 600} for r in range(8)]
+    full["partitions"] = {"columns": {"ms_per_step": 1.0, "value": 1.0, "frame_latency_ms": 1.0, "scaling": "strong"}}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line, separators=(",", ":"))) < 6000
+    assert "per_rank" not in line and "roofline" in line and "cpu_baseline" in line and "config" in line
