@@ -29,21 +29,22 @@ enum { WK_CELL = 0, WK_FACE = 1, WK_EDGE = 2, WK_REC = 3 };
 struct WalkItem {
     uint32_t hdr, a[5];
 };
-// a cell reference: (block * 8 + child) << 4 | depth; the root is not stored in a block
+// a cell reference: (block * 8 + child) << 5 | depth (5 bits: fhip_mesh_build accepts depths up to 20; 27 bits of cell index for
+// < 2^24 blocks; all ones would need depth 31, so it is free for the root); the root is not stored in a block
 constexpr uint32_t WREF_ROOT = 0xFFFFFFFFu;
-constexpr uint32_t WALK_MAX_BLOCKS = 1u << 24, WALK_MAX_DEPTH = 15;
+constexpr uint32_t WALK_MAX_BLOCKS = 1u << 24, WALK_MAX_DEPTH = 30, WREF_DEPTH_BITS = 5;
 struct WalkTree {
     const Cell* cells;      // blocks of eight
     Cell root;
     const WalkTable* T;
 };
-FHQ_HD static inline Cell wk_at(const WalkTree& o, uint32_t r) { return r == WREF_ROOT ? o.root : o.cells[r >> 4]; }
-FHQ_HD static inline uint32_t wk_depth(uint32_t r) { return r == WREF_ROOT ? 0u : (r & 15u); }
+FHQ_HD static inline Cell wk_at(const WalkTree& o, uint32_t r) { return r == WREF_ROOT ? o.root : o.cells[r >> WREF_DEPTH_BITS]; }
+FHQ_HD static inline uint32_t wk_depth(uint32_t r) { return r == WREF_ROOT ? 0u : (r & ((1u << WREF_DEPTH_BITS) - 1u)); }
 FHQ_HD static inline bool wk_is_leaf(const WalkTree& o, uint32_t r) { const uint8_t k = wk_at(o, r).kind; return k == C_LEAF || k == C_FULL || k == C_EMPTY; }
 FHQ_HD static inline uint32_t wk_child(const WalkTree& o, uint32_t r, int i) {
     const Cell x = wk_at(o, r);
     if (x.kind != C_BRANCH) return r;
-    return ((x.index * 8u + (uint32_t)i) << 4) | (wk_depth(r) + 1u);
+    return ((x.index * 8u + (uint32_t)i) << WREF_DEPTH_BITS) | (wk_depth(r) + 1u);
 }
 FHQ_HD static inline void wk_frame(int f, int* t, int* u, int* v) {
     *t = f == 0 ? AX : (f == 1 ? AY : AZ);

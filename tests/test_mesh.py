@@ -540,3 +540,22 @@ def test_library_dual_walk_sequential_and_parallel(model, depth, threads, oracle
         assert len(ref_t) > 1000
         assert (t == ref_t).all() and t.shape == ref_t.shape
         assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("depth", [16, 18])
+def test_dual_walk_passes_beyond_depth_15(depth, oracle_mod):
+    """the device walk's cell references held the depth in 4 bits while fhip_mesh_build accepts depths up to 20 - at
+    depth 16 the reference named the wrong cell.  Five bits now: a tiny sphere meshed at depth 16 / 18 (few cells, all of them deep)
+    through the very passes the device runs (fhip_debug_walk_dual mode 3, plain loops on the host) gives the oracle's walk_dual."""
+    import fidget_amd as F
+    O = oracle_mod
+    c = O.Context()
+    oc = O.Octree(O.Shape(c, sphere(c, (0.30001, -0.2, 0.1), 3.0e-4 if depth == 16 else 0.9e-4)), depth)
+    ref_t, ref_v = oc.walk_dual()
+    kinds = {"Invalid": 0, "Empty": 1, "Full": 2, "Branch": 3, "Leaf": 4}
+    root = np.array([kinds[oc.root[0]], oc.root[1], oc.root[2]], np.uint32)
+    assert len(ref_t) > 100
+    for mode in (0, 3):
+        t, v = F.debug_walk_dual(oc.cells, root, oc.verts, mode)
+        assert t.shape == ref_t.shape and (t == ref_t).all()
+        assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
