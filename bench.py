@@ -66,12 +66,19 @@ def parse_mesh_times(stdout, stderr):
     counts = re.search(r"'triangles': (\d+), 'vertices': (\d+)", stdout)
     if len(builds) < 2:
         return None
-    return {"workload": "gyroid-sphere.vm Manifold Dual Contouring, octree depth 10 (1024^3)", "s_per_build": min(builds[1:]),
-            "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
-            "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
-            "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of the builds after the first "
-                    "of this size; parity: tests/test_mesh.py (identical to the oracle's mesh, triangle for triangle and vertex for vertex, up to "
-                    "depth 7 where the oracle finishes in seconds)"}
+    c5 = {"workload": "gyroid-sphere.vm Manifold Dual Contouring, octree depth 10 (1024^3)", "s_per_build": min(builds[1:]),
+          "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
+          "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
+          "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of the builds after the first of this size"}
+    # MESH_TIMES_PARITY: the CPU oracle's multithreaded build (Octree::build_inner_mt restated) + walk_dual at the same depth, timed, and the
+    # device mesh compared with it element for element
+    par = re.search(r"^parity depth 10 triangles_equal (True|False) vertices_equal (True|False) cpu_s ([0-9.]+) cpu_build_s ([0-9.]+) threads (\d+) "
+                    r"sha_device (\w+) sha_oracle (\w+)$", stdout, re.M)
+    if par:
+        c5["parity"] = {"triangles_equal": par.group(1) == "True", "vertices_equal": par.group(2) == "True", "sha_device": par.group(6), "sha_oracle": par.group(7),
+                        "against": "oracle build_mt + walk_dual at depth 10, element for element"}
+        c5["cpu_s_per_build"], c5["cpu_build_s"], c5["cpu_threads"] = float(par.group(3)), float(par.group(4)), int(par.group(5))
+    return c5
 
 
 def main():
@@ -550,8 +557,8 @@ def main():
         if args.model == "prospero.vm" and os.path.exists(os.path.join(ROOT, "models", "gyroid-sphere.vm")):
             try:
                 import subprocess
-                env = dict(os.environ, MESH_TIMES_REPS="5")     # (the best of four builds after the first: one build in a few is slower by 0.2 s, one in eight by 2 s - DESIGN.md section 9)
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=240)
+                env = dict(os.environ, MESH_TIMES_REPS="5", MESH_TIMES_PARITY="1")     # (the best of four builds after the first: one build in a few is slower by 0.2 s, one in eight by 2 s - DESIGN.md section 9)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_times.py"), "10"], env=env, capture_output=True, text=True, timeout=420)
                 c5 = parse_mesh_times(r.stdout, r.stderr) if r.returncode == 0 else None
                 result["c5_mesh"] = c5 if c5 else {"error": f"tools/mesh_times.py 10: rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
             except Exception as e:      # (a time-out included: the line's other fields do not depend on this leg)

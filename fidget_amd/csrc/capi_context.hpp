@@ -1,8 +1,56 @@
 // Fragment of capi.hip (contexts and their options); not a stand-alone header: included by capi.hip only.
+// ---- the host's libm against the routines the device restates (include/fidget_hip.h) -------------------------------------------------
+int fhip_libm_probe(char* msg, size_t cap) {
+    using namespace fhlm;
+    struct R1 { const char* name; float (*mine)(float); float (*host)(float); };
+    const R1 r1[] = {{"sinf", [](float x) { return sincosf_<MemTables, false>(x); }, [](float x) { return ::sinf(x); }},
+                     {"cosf", [](float x) { return sincosf_<MemTables, true>(x); }, [](float x) { return ::cosf(x); }},
+                     {"tanf", [](float x) { return tanf_<MemTables>(x); }, [](float x) { return ::tanf(x); }},
+                     {"asinf", [](float x) { return asinf_(x); }, [](float x) { return ::asinf(x); }},
+                     {"acosf", [](float x) { return acosf_(x); }, [](float x) { return ::acosf(x); }},
+                     {"atanf", [](float x) { return atanf_(x); }, [](float x) { return ::atanf(x); }},
+                     {"expf", [](float x) { return expf_<MemTables>(x); }, [](float x) { return ::expf(x); }},
+                     {"logf", [](float x) { return logf_<MemTables>(x); }, [](float x) { return ::logf(x); }}};
+    // 32 arguments: ordinary values of both signs, points around the reductions' boundaries (pi/4 multiples, 120, 2^-12, 1), tiny / huge
+    static const float args[32] = {0.1f, -0.3f, 0.5f, 0.7853982f, 0.7853981f, 1.0f, -1.0f, 1.5707964f, 2.0f, 3.0f, 3.1415927f, -4.5f, 6.2831855f, 10.0f,
+                                   -25.132742f, 100.0f, 119.99999f, 120.0f, 1000.5f, -31415.926f, 1.0e6f, 3.0e8f, 1.0e-3f, 2.4414062e-4f, -1.0e-5f,
+                                   1.0e-20f, 0.9999999f, 0.99f, -0.6f, 0.25f, 87.0f, -80.0f};
+    int bad = 0;
+    if (msg && cap) msg[0] = 0;
+    auto differ = [](float a, float b) { return !(a != a && b != b) && f2u(a) != f2u(b); };
+    for (const R1& r : r1)
+        for (float x : args) {
+            volatile float xv = x;          // (no constant folding of the host's call: the RUNNING libm is what is asked)
+            const float a = r.mine(xv), b = r.host(xv);
+            if (differ(a, b) && bad++ == 0 && msg && cap)
+                snprintf(msg, cap, "%s(%a): device family 0x%08x, host libm 0x%08x", r.name, (double)x, f2u(a), f2u(b));
+        }
+    for (int i = 0; i < 32; i++) {
+        volatile float y = args[i], x = args[(i * 7 + 3) & 31];
+        const float a = atan2f_(y, x), b = ::atan2f(y, x);
+        if (differ(a, b) && bad++ == 0 && msg && cap)
+            snprintf(msg, cap, "atan2f(%a, %a): device family 0x%08x, host libm 0x%08x", (double)y, (double)x, f2u(a), f2u(b));
+    }
+    return bad;
+}
+static void libm_probe_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        char msg[160];
+        const int bad = fhip_libm_probe(msg, sizeof msg);
+        const char* q = getenv("FHIP_QUIET");
+        if (bad && !(q && q[0] == '1'))
+            fprintf(stderr, "fidget-hip: this host's libm is not the one the device restates (glibc 2.35 x86-64, FMA variants; trans_libm.hpp): %d of 288 "
+                            "probe arguments differ, first %s.  Transcendental opcodes on the device will differ from this host's CPU evaluators "
+                            "in the last bits for some arguments.\n", bad, msg);
+    });
+}
+
 // ---- context ---------------------------------------------------------------------------
 fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (!out) return FHIP_ERR_BAD_TAPE;
     *out = nullptr;
+    libm_probe_once();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return FHIP_ERR_HIP;
     fhip_ctx* c = new fhip_ctx();

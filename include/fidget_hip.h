@@ -46,6 +46,17 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out);
 void fhip_ctx_destroy(fhip_ctx* ctx);
 const char* fhip_last_error(const fhip_ctx* ctx);
 fhip_status fhip_ctx_sync(fhip_ctx* ctx);
+/* The device evaluates sin cos tan asin acos atan atan2 exp ln with the routines of glibc 2.35's x86-64 libm (its FMA variants)
+ * restated operation by operation (fidget_amd/csrc/trans_libm.hpp) - the libm the reference's f32 methods call on the deployment
+ * image, whose values its own bulk test demands bit for bit (fidget-core/src/eval/test/float_slice.rs:404-412).  On a host with
+ * ANOTHER libm (glibc >= 2.41's CORE-MATH routines, a CPU without FMA, musl) the reference's CPU evaluators - and this repository's
+ * oracle - return other bits for some arguments, and a comparison of device against host values fails for that reason alone.
+ * This call says so: 32 arguments per routine (ordinary values, the reduction's range boundaries, tiny and huge ones) through the
+ * restated routines compiled for the host against the RUNNING libm; returns the number that differ (0: this host's libm is the one
+ * the device restates) and, when `msg` is given, the first difference by name - "sinf(0x1.8p+1): device family 0x..., host libm
+ * 0x...".  No device is touched.  fhip_ctx_create runs it once per process and prints the message to stderr if there is one
+ * (FHIP_QUIET=1: does not). */
+int fhip_libm_probe(char* msg, size_t cap);
 /* render/config.rs:38-80: cooperative cancellation, honoured between kernel waves */
 void fhip_cancel(fhip_ctx* ctx);
 void fhip_cancel_reset(fhip_ctx* ctx);

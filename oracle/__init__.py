@@ -104,6 +104,7 @@ def lib():
             "orc_max_threads": (i32, []),
             "orc_math_unary": (None, [i32, u32, u32, C.c_uint64, vp]),
             "orc_mesh_build": (vp, [vp, vp, u32, i32, vp, vp, u32]), "orc_mesh_free": (None, [vp]),
+            "orc_mesh_build_mt": (vp, [vp, vp, u32, i32, vp, vp, u32, i32, i32]),
             "orc_mesh_counts": (None, [vp, vp]), "orc_mesh_verts": (None, [vp, vp]), "orc_mesh_cells": (None, [vp, vp]),
             "orc_mesh_samples": (None, [vp, vp, vp, vp, vp, vp, vp]), "orc_mesh_walk_dual": (None, [vp, vp]),
             "orc_mesh_dual_copy": (None, [vp, vp, vp]), "orc_mesh_table": (None, [i32, vp, vp]),
@@ -564,14 +565,19 @@ CELL_KINDS = ["Invalid", "Empty", "Full", "Branch", "Leaf"]
 
 
 class Octree:
-    """fidget_mesh::Octree::build (octree.rs:48-68, single-threaded path).  Attributes: root (kind, mask, index), cells
-    [n, 8, 3] (kind, mask, index), verts [n, 3]; samples: the leaf sampling data (bounds, mask, intersections as u16
-    positions and f32 points, gradients (dx, dy, dz, v), cell vertices) in evaluation order."""
+    """fidget_mesh::Octree::build (octree.rs:48-68): the single-threaded path, or with `threads` the multithreaded constructor
+    (Settings::threads, build_inner_mt octree.rs:94-210: sub-cells split off breadth-first until there are 10 x threads of them, one
+    octree each, spliced and fixed up - another cell / vertex layout, the same tree and the same walk_dual).  Attributes: root (kind,
+    mask, index), cells [n, 8, 3] (kind, mask, index), verts [n, 3]; samples (keep_samples): the leaf sampling data (bounds, mask,
+    intersections as u16 positions and f32 points, gradients (dx, dy, dz, v), cell vertices) in evaluation order."""
 
-    def __init__(self, shape, depth, world_to_model=None, mode=SIMPLIFY_REFERENCE, vars=None):
+    def __init__(self, shape, depth, world_to_model=None, mode=SIMPLIFY_REFERENCE, vars=None, threads=None, keep_samples=True):
         w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
         vk, vv = _vars(vars)
-        self._h = lib().orc_mesh_build(shape._h, _p(w2m), depth, mode, _p(vk), _p(vv), len(vk))
+        if threads:
+            self._h = lib().orc_mesh_build_mt(shape._h, _p(w2m), depth, mode, _p(vk), _p(vv), len(vk), int(threads), 1 if keep_samples else 0)
+        else:
+            self._h = lib().orc_mesh_build_mt(shape._h, _p(w2m), depth, mode, _p(vk), _p(vv), len(vk), 0, 1 if keep_samples else 0)
         if not self._h:
             raise ValueError("MissingVar")
         c = np.zeros(8, np.uint64)

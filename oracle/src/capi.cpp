@@ -322,7 +322,8 @@ struct OrcMesh {
     bool walked = false;
 };
 // world_to_model: row-major 4x4 or NULL (= identity); returns NULL if a variable has no value
-void* orc_mesh_build(void* s, const float* world_to_model, uint32_t depth, int mode, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars) {
+static void* mesh_build(void* s, const float* world_to_model, uint32_t depth, int mode, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars, int threads,
+                        int keep_samples) {
     VmDataP shape = ((OrcShape*)s)->d;
     Axes axes(*shape->vars);
     if (!bind_vars(*shape->vars, var_keys, var_vals, n_vars, axes)) return nullptr;
@@ -331,16 +332,29 @@ void* orc_mesh_build(void* s, const float* world_to_model, uint32_t depth, int m
     if (world_to_model) {
         for (int i = 0; i < 16; i++) { m.m[i] = world_to_model[i]; ident &= (world_to_model[i] == ((i % 5 == 0) ? 1.0f : 0.0f)); }
     }
-    mesh::Builder b(depth, (world_to_model && !ident) ? &m : nullptr, axes, mode);
-    RenderHandle root(shape);
-    mesh::Hermite h;
-    b.recurse(&root, mesh::CellIndex(), &h);
     OrcMesh* out = new OrcMesh();
-    out->o = std::move(b.o);
+    if (threads > 0) {      // Settings::threads = Some(pool): Octree::build_inner_mt (octree.rs:94-210)
+        out->o = mesh::build_mt(shape, depth, (world_to_model && !ident) ? &m : nullptr, axes, mode, threads, keep_samples != 0, nullptr);
+    } else {
+        mesh::Builder b(depth, (world_to_model && !ident) ? &m : nullptr, axes, mode);
+        b.keep_samples = keep_samples != 0;
+        RenderHandle root(shape);
+        mesh::Hermite h;
+        b.recurse(&root, mesh::CellIndex(), &h);
+        out->o = std::move(b.o);
+    }
     if (world_to_model && !ident) {      // octree.rs:58-65: vertices back to model space
         for (auto& v : out->o.verts) transform_f32(m, v.x, v.y, v.z, &v.x, &v.y, &v.z);
     }
     return out;
+}
+void* orc_mesh_build(void* s, const float* world_to_model, uint32_t depth, int mode, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars) {
+    return mesh_build(s, world_to_model, depth, mode, var_keys, var_vals, n_vars, 0, 1);
+}
+// threads > 0: the multithreaded constructor (the reference's Settings::threads); keep_samples 0: no per-leaf sampling records
+void* orc_mesh_build_mt(void* s, const float* world_to_model, uint32_t depth, int mode, const uint64_t* var_keys, const float* var_vals, uint32_t n_vars, int threads,
+                        int keep_samples) {
+    return mesh_build(s, world_to_model, depth, mode, var_keys, var_vals, n_vars, threads, keep_samples);
 }
 void orc_mesh_free(void* h) { delete (OrcMesh*)h; }
 // counts: cells (groups of 8), verts, leaf samples, interval evaluations, root kind, root mask, root index

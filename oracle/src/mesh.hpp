@@ -12,6 +12,7 @@
 // only to rounding (the reference's own tests use 1e-3 .. 2/65535 tolerances), and cell collapse
 // decisions that compare such errors (try_collapse) can differ in ties.
 #pragma once
+#include <deque>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -395,6 +396,7 @@ struct Builder {
     Mat4 mat;
     Axes axes;
     int mode;
+    bool keep_samples = true;          // (the per-leaf sampling records are for the device tests; a depth-10 build would hold 16 GB of them)
     TracingEval<Interval> eval_interval;
     BulkEval<float> eval_float;
     BulkEval<Grad> eval_grad;
@@ -554,7 +556,7 @@ struct Builder {
         }
         ls.n_verts = (uint8_t)cv.size();
         for (size_t k = 0; k < cv.size() && k < 4; k++) { ls.vert[k][0] = cv[k].x; ls.vert[k][1] = cv[k].y; ls.vert[k][2] = cv[k].z; }
-        o.samples.push_back(ls);
+        if (keep_samples) o.samples.push_back(ls);
         const size_t index = o.verts.size();
         for (auto& v : cv) o.verts.push_back(v);
         for (int e = 0; e < ne; e++) o.verts.push_back(V3f{ls.pos[e][0], ls.pos[e][1], ls.pos[e][2]});
@@ -564,6 +566,78 @@ struct Builder {
 };
 
 // ---- dc.rs / builder.rs: the dual walk --------------------------------------------------------------------
+// Octree::build_inner_mt (octree.rs:94-210): cells split off breadth-first until there are >= 10 x threads of them (never evaluated:
+// they are taken to be ambiguous), every one built as an octree of its own by a worker with a fresh RenderHandle on the ROOT tape,
+// the sub-octrees appended in task order with their cell and vertex indices shifted (176-195), then check_done over the split cells
+// in reverse (197-208).  The cell / vertex LAYOUT differs from the single-threaded build's (and depends on `threads` through the task
+// count, as in the reference); the tree - and so walk_dual's mesh - does not.
+static inline Octree build_mt(VmDataP shape, uint32_t depth, const Mat4* m, const Axes& axes, int mode, int threads, bool keep_samples, uint64_t* interval_evals) {
+    Octree root;
+    std::deque<CellIndex> todo;
+    todo.push_back(CellIndex());
+    std::vector<std::pair<CellIndex, size_t>> fixup;
+    std::vector<std::array<Hermite, 8>> hermites;
+    size_t pow8 = 1;
+    for (uint32_t i = 0; i < depth && pow8 < ((size_t)1 << 40); i++) pow8 *= 8;
+    const size_t target = std::min(pow8, (size_t)std::max(threads, 1) * 10);
+    while (todo.size() < target) {
+        const CellIndex next = todo.front();
+        todo.pop_front();
+        const size_t index = root.cells.size();
+        root.cells.push_back(std::array<Cell, 8>());
+        hermites.push_back(std::array<Hermite, 8>());
+        for (int i = 0; i < 8; i++) todo.push_back(next.child(index, i));
+        fixup.push_back({next, index});
+    }
+    struct Output { Octree octree; Hermite hermite; };
+    std::vector<CellIndex> tasks(todo.begin(), todo.end());
+    std::vector<Output> out(tasks.size());
+    uint64_t evals = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(threads, 1)) reduction(+ : evals)
+    for (int64_t t = 0; t < (int64_t)tasks.size(); t++) {
+        Builder b(depth, m, axes, mode);
+        b.keep_samples = keep_samples;
+        RenderHandle rh(shape);
+        CellIndex local = tasks[(size_t)t];
+        local.ci = -1; local.cj = 0;            // "patch our cell so that it builds at index 0" (octree.rs:139-143): depth and bounds stay
+        b.recurse(&rh, local, &out[(size_t)t].hermite);
+        evals += b.o.interval_evals;
+        out[(size_t)t].octree = std::move(b.o);
+    }
+    std::vector<size_t> cell_off{root.cells.size()}, vert_off{0};
+    for (size_t i = 0; i < out.size(); i++) {
+        hermites[(size_t)tasks[i].ci][tasks[i].cj] = out[i].hermite;
+        cell_off.push_back(cell_off.back() + out[i].octree.cells.size());
+        vert_off.push_back(vert_off.back() + out[i].octree.verts.size());
+    }
+    root.cells.reserve(cell_off.back());
+    root.verts.reserve(vert_off.back());
+    for (size_t i = 0; i < out.size(); i++) {
+        auto remap = [&](Cell c) {
+            if (c.kind == C_LEAF) c.index += (uint32_t)vert_off[i];
+            else if (c.kind == C_BRANCH) c.index += (uint32_t)cell_off[i];
+            return c;
+        };
+        for (auto& cs : out[i].octree.cells) { std::array<Cell, 8> r; for (int k = 0; k < 8; k++) r[k] = remap(cs[k]); root.cells.push_back(r); }
+        root.verts.insert(root.verts.end(), out[i].octree.verts.begin(), out[i].octree.verts.end());
+        if (keep_samples) root.samples.insert(root.samples.end(), out[i].octree.samples.begin(), out[i].octree.samples.end());
+        root.at(tasks[i]) = remap(out[i].octree.root);
+        out[i].octree = Octree();
+    }
+    for (size_t k = fixup.size(); k-- > 0;) {
+        const CellIndex& cell = fixup[k].first;
+        const size_t index = fixup[k].second;
+        const std::array<Hermite, 8> h = hermites[index];
+        Hermite scratch;
+        Hermite* dst = cell.ci >= 0 ? &hermites[(size_t)cell.ci][cell.cj] : &scratch;
+        const Cell r = root.check_done(cell, index, h.data(), dst);
+        root.at(cell) = r;
+    }
+    root.interval_evals = evals;
+    if (interval_evals) *interval_evals = evals;
+    return root;
+}
+
 struct Walker {
     const Octree& o;
     MeshOut out;

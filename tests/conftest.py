@@ -49,3 +49,16 @@ def oracle_mod():
 
 def model_path(name):
     return os.path.join(MODELS, name)
+
+
+def pytest_report_header(config):
+    """Names the one environmental reason a device-against-oracle comparison of a transcendental tape can fail: the oracle calls THIS host's
+    libm, the device restates glibc 2.35's x86-64 routines (fhip_libm_probe, include/fidget_hip.h)."""
+    try:
+        n, first = _hip().libm_probe()
+    except Exception as e:       # noqa: BLE001  (library not built yet: the build check says so elsewhere)
+        return f"fidget-hip libm probe: not run ({e!r})"
+    if n == 0:
+        return "fidget-hip libm probe: this host's libm is the one the device restates (0 of 288 probe arguments differ)"
+    return (f"fidget-hip libm probe: MISMATCH - {n} of 288 probe arguments differ, first {first}.  Tests that compare transcendental "
+            "values of the device (or of trans_libm.hpp) with the oracle / the running libm will fail for THIS reason.")

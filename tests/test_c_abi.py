@@ -49,3 +49,15 @@ def test_c_program_renders_hi_and_matches_the_golden_image(exe):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of 1024 pixels differ" in r.stdout
+
+
+def test_libm_probe_names_this_hosts_libm():
+    """fhip_libm_probe (no device): on the deployment image - glibc 2.35, x86-64 with FMA - the restated routines are the running libm's,
+    0 of 288 arguments differ; the message buffer is left empty and a small buffer is respected."""
+    import fidget_amd as F
+    n, first = F.libm_probe()
+    assert n == 0 and first == "", (n, first)
+    import ctypes as C
+    assert F.lib().fhip_libm_probe(None, 0) == 0
+    buf = C.create_string_buffer(4)
+    assert F.lib().fhip_libm_probe(buf, 4) == 0 and buf.value == b""

@@ -404,12 +404,13 @@ def test_render3d_lanes_for_parts_of_a_frame():
         for iy in range(2):
             front, back = outs[ix + 2 * iy + 4].clone(), outs[ix + 2 * iy]
             F.merge_depth(front, back, n, hip=hip)
-            img = front if img is None else torch.maximum(img.view(torch.int64), front.view(torch.int64)).view(torch.int32)
+            img = front if img is None else img + front          # (the column blocks are disjoint and a part's image is zero outside its block)
     hip.sync()
     whole = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
     F.render3d(sa, n, out=whole)
     ref_ctx.sync()
     assert torch.equal(img[..., 3], whole[..., 3])
+    assert torch.equal(img, whole)          # depths AND normals (the merged frame was compared by depth only)
     del sa, sb, hip, ref_ctx
 
 

@@ -21,6 +21,25 @@ for depth in depths:
         print(depth, "build", rep, dt, flush=True)
     res[f"depth {depth}"] = {"s": dt, "triangles": len(tris), "vertices": len(verts), **counts}
     print(depth, res[f"depth {depth}"], flush=True)
+    if os.environ.get("MESH_TIMES_PARITY"):
+        # the same mesh from the CPU oracle's multithreaded constructor (Octree::build_inner_mt restated, oracle/src/mesh.hpp build_mt) on
+        # every host thread + its walk_dual: the CPU baseline of this configuration, and the device mesh compared with it element for element
+        import hashlib
+        import oracle as O
+        oshape = O.Shape.from_vm(os.path.join(ROOT, "models", "gyroid-sphere.vm"))
+        th = O.max_threads()
+        t0 = time.perf_counter()
+        oc = O.Octree(oshape, depth, threads=th, keep_samples=False)
+        t_build = time.perf_counter() - t0
+        ot, ov = oc.walk_dual()
+        t_cpu = time.perf_counter() - t0
+        te = bool(ot.shape == tris.shape and (ot == tris).all())
+        ve = bool(ov.shape == verts.shape and (ov.view(np.uint32) == verts.view(np.uint32)).all())
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+        print(f"parity depth {depth} triangles_equal {te} vertices_equal {ve} cpu_s {t_cpu:.3f} cpu_build_s {t_build:.3f} threads {th} "
+              f"sha_device {sha(tris)}{sha(verts)} sha_oracle {sha(ot)}{sha(ov)}", flush=True)
+        res[f"depth {depth}"].update(parity={"triangles_equal": te, "vertices_equal": ve}, cpu_s_per_build=t_cpu, cpu_build_s=t_build, cpu_threads=th)
+        del oc, ot, ov
     del tris, verts
     if os.environ.get("MESH_TIMES_HOST_ASM"):      # the same build with the octree assembled on the host's threads (the round-2 path)
         with hip.options(mesh_device_assembly=0):
