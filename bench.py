@@ -384,7 +384,7 @@ def main():
                                       "(DESIGN.md section 4); bench.py lets that finish before the timed frames"},
         "general": general,
         "host_output_frame_ms": host_frame,
-        "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (tiles 128/32/8), world_to_model=I",
+        "config": {"workload": f"{args.model} 3D heightmap+normals {n}^3, HipShape render hints (the library's tiles: 128/32/8, or 32/8 when the root level has few tiles), world_to_model=I",
                    "sharding": sharding,
                    "general_path": None if not general else {"ms_per_step": general["ms_per_step"], "value": general["value"],
                                                              "frame_latency_ms": general["frame_latency_ms"]},
@@ -461,20 +461,25 @@ def main():
                       "leaf interpreter: algorithmic bytes = 8 B x (leaf tape ops x passes of the kernel over the tape) + the 16 B image pixel once, from "
                       "the device's counters of the timed frames; tape words are wave-uniform loads served by L2 / the scalar cache, so the kernel is bound "
                       "by instruction issue, not by HBM (DESIGN.md sections 4 and 6)")
-        lv = [v for k, v in tiles.items() if int(k[1:]) >= 2]
+        # tile levels of the frame: l0 the root level, the last one the per-slab level above the leaves (fh_tiles_v32), what lies between -
+        # level 1 of the 128 / 32 / 8 hierarchy; none when the library took root tiles of 32^3 (capi_render.hpp root32_max) - fh_tiles_v64
+        levels = sorted(int(k[1:]) for k in tiles)
+        last = levels[-1] if levels else 0
+        lv = [tiles[f"l{l}"] for l in levels if l == last and l > 0]
+        mids = [tiles[f"l{l}"] for l in levels if 0 < l < last]
         r_tiles = roof(P, path, "fh_tiles_v32", 8.0 * (sum(v["ops"] for v in lv) + sum(v["ops_written"] for v in lv)),
                        64.0 * sum(v["ops"] for v in lv),
                        "interval interpreter + lockstep prune with the register file in VGPRs (per-slab level): bound by the latency of each parent's "
-                       "dependent op chain (one wave per parent); algorithmic bytes = tape ops read + written at that level in the timed frames")
+                       "dependent op chain (one wave per parent); algorithmic bytes = tape ops read + written at that level in the timed frames") if lv else None
         # the two kernels of the coarse chain: level 1 - fh_tiles_v64, one wave per 128^3 parent walking its tape
         # forward and in the lockstep prune - and the root level's prune (k_prune2 + fh_prune1 behind it, timed together as "fh_prune1")
-        l1, l0 = tiles.get("l1"), tiles.get("l0")
-        r_l1 = roof(P, path, "fh_tiles_v64", 8.0 * (l1["ops"] + l1["ops_written"]), 64.0 * l1["ops"],
+        l0 = tiles.get("l0")
+        r_l1 = roof(P, path, "fh_tiles_v64", 8.0 * (sum(v["ops"] for v in mids) + sum(v["ops_written"] for v in mids)), 64.0 * sum(v["ops"] for v in mids),
                     "level 1 (32^3 children of the 128^3 root tiles): interval interpreter + lockstep prune, register file in VGPRs; one wave per parent, "
                     "so the launch lasts as long as its longest parent's dependent chain (~1 000 ops forward, the same backwards); algorithmic bytes = "
-                    "tape ops read + written at this level in the timed frames") if l1 else None
+                    "tape ops read + written at this level in the timed frames") if mids else None
         r_prune = roof(P, path, "fh_prune1", 8.0 * (3.0 * l0["ops"] + l0["ops_written"]), 0,
-                       "root level's prune (prune2.hip k_prune2, one wave per root tile's child tape, + fh_prune1 for the children it leaves): algorithmic "
+                       "root level's prune (prune2.hip k_prune2, one wave per child tape of the root tape, + fh_prune1 for the children it leaves): algorithmic "
                        "bytes = the root tape with its links (8 + 16 B per op) staged once per workgroup + the child tapes written") if l0 else None
         return r_leaf, r_tiles, r_l1, r_prune
 

@@ -63,7 +63,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
     X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
     X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_only_l1, 1) X(chain_prio, 0) X(tail_on_main, 2) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(frame_lanes, 4) X(lanes_all, 0) X(lanes_tune, 1) X(lanes_parts, 1) X(lanes_fail, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 4)                        \
+    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_only_l1, 1) X(chain_prio, 0) X(tail_on_main, 2) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(frame_lanes, 4) X(lanes_all, 0) X(lanes_tune, 1) X(lanes_parts, 1) X(lanes_fail, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 4) X(root32_max, 4096) X(no_root_zrep, 0)                        \
     /* fixed when the context is created (they decide which streams exist): environment only */                                 \
     X(leaf_streams, 1) X(pre_priority, 0)
 struct FhOptions {

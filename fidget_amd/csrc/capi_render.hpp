@@ -39,6 +39,8 @@ struct RenderSetup {
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
+    bool xy_fixed = false, root_invariant = false;   // 3D, set before prepare(): x and y do not move along a pixel column; the ROOT tape reads nothing that does
+    bool root_zrep = false;   // ... then the root level evaluates ONE layer of root tiles per z-slab and hands the result to the layers stacked on it
     bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
     uint32_t hbm_waves = 0;
 };
@@ -104,6 +106,32 @@ struct PartSpec {
     uint32_t shard = 0, n_shards = 1;
     uint32_t ix = 0, nx = 1, iy = 0, ny = 1, iz = 0, nz = 1;
 };
+// 3D: input slots of the axes, which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective
+// matrix), and whether the root tape reads any of them - from the camera matrix, the input binding and the tape alone (before prepare)
+static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P, RenderSetup& R) {
+    uint32_t u[16];
+    memcpy(u, P.mat, sizeof(u));
+    const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
+    int slot[3] = {-1, -1, -1};
+    for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis)
+    for (int ax = 0; ax < 3; ax++) {
+        R.col_slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
+        const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
+        if (dep && slot[ax] >= 0) R.col_depmask |= 1u << slot[ax];
+        if (dep) R.col_flags |= 0x20000u << ax;     // (bits 17 .. 19: this axis of the model changes along a pixel column - from the camera alone)
+    }
+    R.col_flags |= proj ? 0x10000u : 0u;
+    // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
+    R.xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
+    // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying
+    // along z - which is what a model with z in every tape gets)
+    const bool no_inv = ctx->opt.no_column_inv != 0;
+    if (no_inv) R.col_depmask = 0xFFFFFFFFu;
+    R.root_invariant = !no_inv && R.col_depmask != 0xFFFFFFFFu;
+    for (uint64_t w : tape->t.ops)
+        if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { R.root_invariant = false; break; }
+}
+
 static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
                            const PartSpec& part, RenderSetup& R) {
     const uint32_t shard = part.shard, n_shards = part.n_shards;
@@ -138,8 +166,10 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // levels are evaluated for the whole volume up front (the length of the tile chain is its number of steps: every step's
     // launches leave most of the machine idle); one layer per step otherwise
     const uint32_t n_layers = is3d ? (P.depth + ts[0] - 1) / ts[0] : 1;
-    const bool prepass_ok = is3d && ts.size() >= 3 && n_layers <= FH_MAX_SLABS;
-    uint32_t SL = prepass_ok ? (uint32_t)std::max(1, std::min(8, ctx->opt.slab_layers)) : 1u;
+    // (a two-level list - root tiles of 32^3 straight above the leaves, what small images and parts of a frame take - gets a pre-pass of
+    // its ONE coarse level; option slab_layers counts layers of 128 voxels, whatever the root tile)
+    const bool prepass_ok = is3d && ts.size() >= 2 && n_layers <= FH_MAX_SLABS;
+    uint32_t SL = prepass_ok ? (uint32_t)std::max(1, std::min(8, ctx->opt.slab_layers)) * std::max<uint32_t>(1, 128 / ts[0]) : 1u;
     // (the leaf table: <= 64 eight-voxel layers per slab; at least two slabs, so that the tile stage of one still runs beside the
     // leaf kernel of the other - bear.vm at 512^3, four layers: 3.68 ms per frame as two slabs, 3.77 as one)
     while (SL > 1 && (ts[0] * SL / 8 > 64 || SL * 2 > n_layers)) SL >>= 1;
@@ -178,7 +208,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // pre-pass: with >= 3 levels the two coarsest levels are evaluated for all z-slabs at once
     S.n_slabs = R.n_slabs;
     S.frame_stamp = ++ctx->frame_stamp;
-    S.pre_levels = prepass_ok ? 2 : 0;
+    S.pre_levels = prepass_ok ? std::min<uint32_t>(2, (uint32_t)ts.size() - 1) : 0;
 
     // root-tile layers of this part: layer k of the block split belongs to iz = k * nz / n_layers (iz = nz - 1: the front);
     // its z-slabs are those that hold one of its layers (a slab shared with another part has work for this part's layers only)
@@ -208,7 +238,28 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         for (size_t i = 0; i < mine.size(); i += TL) runs.push_back(Run{mine[i], (uint32_t)std::min<size_t>(TL, mine.size() - i), n_shards});
     }
     FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
-    const uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
+    // Column invariance at the ROOT: a root tape that reads no input varying along a pixel column, under a camera
+    // that keeps x and y fixed along it, has the same interval, the same choices and the same pruned tape in every root tile of a
+    // column of root tiles.  One layer per z-slab is evaluated (the slab's back-most: FhGroup::x = how many layers of the slab it stands
+    // for) and the push stage hands the result to the stack - a fill with the nearest copy's depth, ONE queue entry carrying the copies,
+    // exactly what the levels below do for column-invariant parents.  prospero.vm at 1024^3: 64 root tiles instead of 512.
+    R.root_zrep = is3d && S.pre_levels > 0 && ctx->use_split && TL == 64 && R.xy_fixed && R.root_invariant && !ctx->opt.no_zrep && !ctx->opt.no_root_zrep;
+    uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
+    if (R.root_zrep) {
+        q0_layers = 0;
+        for (uint32_t sb = R.slab_hi; sb-- > R.slab_lo;) {       // front slabs first
+            const uint32_t lo = std::max(layer_lo, sb * SL), hi = std::min(layer_hi, (sb + 1) * SL);
+            if (lo >= hi) continue;
+            q0_layers++;
+            for (const Run& r : runs) {
+                FhGroup g{};
+                g.tape = root;
+                g.first = r.first; g.n = r.n; g.stride = r.stride;
+                g.z = lo * ts[0]; g.x = hi - lo;
+                R.roots.push_back(g);
+            }
+        }
+    } else
     for (uint32_t k = 0; k < q0_layers; k++)
         for (const Run& r : runs) {
             FhGroup g{};
@@ -751,8 +802,32 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     fhip_screen_to_world(size, 3, s2w);
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
-    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : hip_tiles_3d(std::max(cfg->width, cfg->height), ctx->opt.vm_tiles != 0);
+    column_setup(ctx, tape, P, R);
+    std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                               : hip_tiles_3d(std::max(cfg->width, cfg->height), ctx->opt.vm_tiles != 0);
+    // Few tiles, long tape (a small image, a part of a frame on one rank of several, a model without z): root tiles of 32^3 straight
+    // above the leaves.  With 128^3 root tiles such a frame is a handful of one-wave chains over tapes that a 128^3 tile barely prunes
+    // (prospero.vm at 512^3: a root tile keeps up to 1 795 of 6 363 ops - beyond the linked prune's and fh_tiles_v64's limits, so the
+    // LDS-file kernel and the scalar sweep walk them: 3.3 ms for one frame).  The root level's forward pass is parallel over the tape
+    // (term groups) however many tiles there are, and the linked prune handles a thousand children in one round, each a wave: pruning
+    // the ROOT tape per 32^3 tile costs what pruning it per 128^3 tile costs, its tapes are what level 1 would have arrived at, and
+    // level 1 - the longest kernel of the frame - is not run at all: 512^3 3.25 -> 1.45 ms alone.  A 3D image does not depend on the
+    // tile sizes, so this is the library's choice whenever the caller gave none: taken while the root level has at
+    // most `root32_max` children - counting one layer per z-slab when the root tape reads nothing that changes along a pixel column
+    // (root_zrep, prepare) - and the tape is one the groups + linked prune path takes.
+    if (!cfg->tile_sizes && !ctx->opt.vm_tiles && ctx->opt.root32_max > 0 && ts.size() == 3 && ts[0] == 128 && ctx->use_split && ctx->use_asm &&
+        !tape->tgroups.empty() && !ctx->opt.no_tape_groups && !ctx->opt.no_prune1 && ctx->opt.prune2 && tape_asm_ok(tape->t) &&
+        tape->t.ops.size() <= FH_P2_MAX_OPS && tape->t.n_choices <= FH_P2_MAX_CHOICES) {
+        const uint64_t cols = (uint64_t)((P.width + 31) / 32) * ((P.height + 31) / 32) / std::max<uint32_t>(1, part.n_shards * part.nx * part.ny);
+        const bool dedupe = R.xy_fixed && R.root_invariant && !ctx->opt.no_zrep;
+        const uint64_t layers = dedupe ? (uint64_t)std::max<uint32_t>(2, (P.depth + 511) / 512) : (uint64_t)((P.depth + 31) / 32) / std::max<uint32_t>(1, part.nz);
+        // (measured, profiles/r05c: up to two rounds of the linked prune's workgroups - 2 048 children - always; up to root32_max when a
+        // 128^3 root tile is a quarter of the image or more - there the 128^3 tiles' tapes stay long whatever is done: 512^3 with z in
+        // every tape, 4 096 children, 3.65 -> 1.72 ms; an octant of a 1024^3 frame, as many children of a model twice the size: 1.10 -> 1.33)
+        const uint64_t children = cols * std::max<uint64_t>(layers, 1);
+        if ((children <= 2048 || (children <= (uint64_t)ctx->opt.root32_max && std::max(P.width, P.height) <= 512)) && (P.depth + 31) / 32 <= FH_MAX_SLABS)
+            ts = {32, 8};
+    }
     // Frame pipelining (asynchronous renders): this frame takes the buffer set the previous frame did not use, and everything up
     // to and including its coarse levels is queued on a stream of its own - it depends on nothing the previous frame does, so it
     // runs beside that frame's slabs.  The slabs' tile chains follow on the side stream (after the previous frame's), the leaf
@@ -774,27 +849,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     }
     st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
-    {   // input slots of the axes, and which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix)
-        uint32_t u[16];
-        memcpy(u, P.mat, sizeof(u));
-        const bool proj = (((u[12] | u[13] | u[14]) & 0x7FFFFFFFu) | (u[15] ^ 0x3F800000u)) != 0;
-        int slot[3] = {-1, -1, -1};
-        for (int sl = 0; sl < FH_MAX_INPUTS; sl++) if (P.in_kind[sl] < 3) slot[P.in_kind[sl]] = sl;   // (the last slot of an axis)
-        for (int ax = 0; ax < 3; ax++) {
-            R.col_slots |= (uint32_t)(slot[ax] < 0 ? 0xFF : slot[ax]) << (8 * ax);
-            const bool dep = proj || (u[4 * ax + 2] & 0x7FFFFFFFu) != 0;
-            if (dep && slot[ax] >= 0) R.col_depmask |= 1u << slot[ax];
-            if (dep) R.col_flags |= 0x20000u << ax;     // (bits 17 .. 19: this axis of the model changes along a pixel column - from the camera alone)
-        }
-        R.col_flags |= proj ? 0x10000u : 0u;
-        // tiles of a tape that reads nothing varying along z repeat along z: worth looking for when x and y do not vary with it
-        const bool xy_fixed = !proj && (slot[0] < 0 || !((R.col_depmask >> slot[0]) & 1)) && (slot[1] < 0 || !((R.col_depmask >> slot[1]) & 1));
-        // (FHIP_NO_COLUMN_INV=1, diagnostics / bench: no column-invariance short cut anywhere - every input counts as varying
-        // along z - which is what a model with z in every tape gets)
-        const bool no_inv = ctx->opt.no_column_inv != 0;
-        if (no_inv) R.col_depmask = 0xFFFFFFFFu;
-        R.zrep = R.split && R.S.pre_levels > 0 && xy_fixed && !no_inv && !ctx->opt.no_zrep;
-    }
+    R.zrep = R.split && R.S.pre_levels > 0 && R.xy_fixed && !ctx->opt.no_column_inv && !ctx->opt.no_zrep;
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }

@@ -627,6 +627,8 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
             if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane < (int)G) slg[lane].act = 0; continue; }
         }
         uint32_t nchild, cx, cy, cz;
+        // (level 0 with a column-invariant root tape, capi_render.hpp root_zrep: the group's root tiles stand for g.x layers stacked on them)
+        const uint32_t copies0 = (IS3D && level == 0 && g.x > 1) ? g.x : 1u;
         if (level == 0) {
             nchild = g.n;
             const uint32_t ri = g.first + lane * g.stride;  // root index, x-major (lib.rs:116-123)
@@ -637,7 +639,7 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
             cx = g.x + (lane % n) * T; cy = g.y + ((lane / n) % n) * T; cz = IS3D ? g.z + (lane / (n * n)) * T : 0u;
         }
         bool act = lane < (int)nchild && cx < P.width && cy < P.height;
-        uint32_t cz_top = cz;       // z of the instance nearest the camera among those this lane stands for
+        uint32_t cz_top = cz + (copies0 - 1) * T;       // z of the instance nearest the camera among those this lane stands for
         if (inv) {
             const uint32_t n = P.tiles[level - 1] / T;
             if (lane / (n * n) != 0) act = false;
@@ -658,7 +660,7 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
             if (lane == 0) {
                 const FhTapeRef tr = (TG > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
                 so.tape = tr;
-                so.level = (uint32_t)level; so.act = share; so.base = 0; so.overflow = 0;
+                so.level = (uint32_t)level | (copies0 << 8); so.act = share; so.base = 0; so.overflow = 0;     // (bits 8..: layers a root tile stands for)
                 // (levels >= 1 have no term values: the field carries inv | zrep << 8 to the push stage)
                 so.tvals = (TG > 1) ? S->tvals + (size_t)(gi - ns) * S->n_terms * WAVE * 2 : (float*)(uintptr_t)((inv ? 1u : 0u) | (zrep << 8));
             }
@@ -927,9 +929,11 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         const float lo = sl.res[0][lane], hi = sl.res[1][lane];
         const uint32_t cx = sl.corner[0][lane], cy = sl.corner[1][lane], cz = sl.corner[2][lane];
         // column-invariant parent (tsetup_body): every active lane stands for `ninst` tiles stacked along z, one T apart
+        // (root level: a tile of a column-invariant root tape stands for the layers stacked on it - tsetup_body copies0 - one T apart too)
+        const uint32_t copies0 = (IS3D && level == 0) ? uni(sl.level >> 8) : 1u;
         const uint32_t zi = (IS3D && level > 0) ? uni((uint32_t)(uintptr_t)sl.tvals) : 0u;
-        const bool inv = (zi & 1) != 0;
-        const uint32_t ninst = inv ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u;
+        const bool inv = (zi & 1) != 0 || copies0 > 1;
+        const uint32_t ninst = level == 0 ? copies0 : (inv ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u);
         const bool fills = IS3D || !P.pixel_perfect;                                       // pixel.rs:345-368
         const bool full = act && fills && hi < 0.0f, empty = act && fills && !full && lo > 0.0f;  // voxel.rs:310-320
         const bool amb = act && !full && !empty;

@@ -616,3 +616,48 @@ def test_assembly_tile_stage_of_transcendental_tapes(name, size):
     with hip.options(no_asm_tiles_t=1):
         b2 = F.render2d(p, size)[0]
     assert (a2.view(np.uint32) == b2.view(np.uint32)).all() or same_bits_f32(a2, b2)
+
+
+@pytest.mark.parametrize("size,camera", [(512, None), (256, None), (320, None), (384, "rot"), (512, "persp"), (1024, None)])
+def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
+    """Round 5: when the root level has few children the library renders with root tiles of 32^3 straight above the leaves (the linked
+    prune of the ROOT tape per 32^3 tile, no level 1), and a root tape that reads nothing varying along a pixel column is evaluated for
+    one layer of root tiles per z-slab (capi_render.hpp root32_max, root_zrep).  Neither may change a pixel: the oracle's image under
+    every combination of the two - and with the column short cuts off (a tape with z everywhere), and under cameras that move x and y
+    along a column (no invariance anywhere: rotated, perspective), and as the eight octants of the frame."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("frame_lanes", 0)
+    p, o = F.Shape.from_vm(model_path("prospero.vm"), hip=hip), O.Shape.from_vm(model_path("prospero.vm"))
+    m = None
+    if camera == "rot":
+        c, s_ = np.cos(0.4), np.sin(0.4)
+        m = np.array([[c, 0, s_, 0.05], [0, 1, 0, -0.02], [-s_, 0, c, 0.1], [0, 0, 0, 1]], np.float32)
+    elif camera == "persp":
+        m = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.3, 1]], np.float32)
+    ref = O.render3d(o, size, world_to_model=m)[0]
+    ref_words = np.concatenate([ref["normal"].view(np.uint32), ref["depth"][..., None]], axis=2)
+    for root32_max, no_root_zrep, no_inv in ((4096, 0, 0), (0, 0, 0), (4096, 1, 0), (0, 1, 0), (4096, 0, 1), (1 << 20, 0, 0), (1 << 20, 0, 1)):
+        if size == 1024 and root32_max == (1 << 20) and no_inv:
+            continue        # (32 768 children through the scalar sweep: right, and slow)
+        with hip.options(root32_max=root32_max, no_root_zrep=no_root_zrep, no_column_inv=no_inv):
+            out = torch.zeros((size, size, 4), dtype=torch.int32, device="cuda")
+            F.render3d(p, size, world_to_model=m, out=out)
+            hip.sync()
+            got = out.cpu().numpy().view(np.uint32)
+            assert (got[..., 3] == ref_words[..., 3]).all(), (root32_max, no_root_zrep, no_inv, int((got[..., 3] != ref_words[..., 3]).sum()))
+            assert same_bits_f32(got[..., :3].view(np.float32), ref_words[..., :3].view(np.float32)), (root32_max, no_root_zrep, no_inv)
+            if camera is None and size in (512, 1024):       # the frame as eight octants: each block's own tile choice, merged front to back
+                img = None
+                for ix in range(2):
+                    for iy in range(2):
+                        parts = []
+                        for iz in (1, 0):
+                            t = torch.zeros((size, size, 4), dtype=torch.int32, device="cuda")
+                            F.render3d(p, size, out=t, block=(ix + 2 * iy + 4 * iz, (2, 2, 2)))
+                            parts.append(t)
+                        F.merge_depth(parts[0], parts[1], size, hip=hip)
+                        img = parts[0] if img is None else img + parts[0]
+                hip.sync()
+                assert torch.equal(img, out), (root32_max, no_root_zrep, no_inv)
+    del p, hip
