@@ -32,6 +32,7 @@ struct RenderSetup {
     const uint64_t* d_links = nullptr;
     const uint64_t* d_ctab = nullptr;
     size_t lds_prune2 = 0;
+    uint32_t p2_cap_kept = 0;      // kept ops per child the linked prune's LDS areas are sized for (children beyond: the scalar sweep behind it)
     bool prune2_l1 = false;   // ... and level 1 by the same kernel, on the links the level-0 launch leaves in front of every child tape (option
                               // prune2_l1, off: fh_tiles_v64's forward pass alone takes 0.13 ms of its 0.39, but one wave per 32^3 child - 6 120 of them,
                               // 2 to a SIMD, each bound by scalar issue - takes 0.75 ms where the lockstep sweep takes 0.26; profiles/r03o)
@@ -392,7 +393,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                     tape->d_links = dl; tape->d_ctab = dc;
                 }
             }
-            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices);
+            R.p2_cap_kept = (uint32_t)FH_P2_MAX_KEPT;
+            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices, R.p2_cap_kept);
             // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
             // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)
             R.prune2 = tape->d_links && tape->d_ctab && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
@@ -572,7 +574,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
                                    (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u) | (ctx->opt.chain_prio ? 4u : 0u), R.S.troot_len, R.S.troot_choices,
-                                   (uint32_t)FH_P2_MAX_KEPT);
+                                   R.p2_cap_kept);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -954,6 +956,13 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
                               ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !ctx->opt.old_pyr;
             const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
+            // (32 / 8 with its one pre-pass level: both pyramid levels rebuilt and the slab reset in one launch as well)
+            const bool pyr2 = P.n_levels == 2 && P.tiles[1] == 8 && P.tiles[0] == 32 && pre == 1 && !ctx->opt.no_slab_begin;
+            if (rebuild && pyr2) {
+                const uint32_t n0 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
+                hipLaunchKernelGGL(k_slab_begin2, dim3(n0 + reset_blocks), dim3(256), 0, ctx->stream, dS, n0, R.table_words, (uint32_t)k, n_groups);
+                return;
+            }
             if (rebuild && pyr3 && pre == 2 && !ctx->opt.no_slab_begin) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
                 hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);

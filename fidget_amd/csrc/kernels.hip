@@ -1484,6 +1484,35 @@ __global__ void __launch_bounds__(256) k_slab_begin3(FhRenderState* S, uint32_t 
     reset_slab_body(S, (blockIdx.x - n1) * blockDim.x + threadIdx.x, (gridDim.x - n1) * blockDim.x, table_words, slab, n_root_groups, 0);
 }
 
+// ... and for the two-level pyramid of a frame with root tiles of 32^3 (32 / 8, one pre-pass level: capi_render.hpp root32_max): one block
+// of four waves per root tile, four leaf tiles per wave, lane = pixel; both levels are written outright (no level above them to fold into)
+FH_DEV void minpyramid2_body(FhRenderState* S, uint32_t block) {
+    __shared__ uint32_t part[4];
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t T1 = P.tiles[1], T0 = P.tiles[0];
+    const uint32_t n0x = (P.width + T0 - 1) / T0, n1x = (P.width + T1 - 1) / T1;
+    const uint32_t bx = block % n0x, by = block / n0x;
+    const uint32_t ty = by * 4 + w, y = ty * T1 + (lane >> 3);
+    uint32_t row = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t tx = bx * 4 + i, x = tx * T1 + (lane & 7);
+        uint32_t mn = (x < P.width && y < P.height) ? (uint32_t)(S->zbuf[(size_t)y * P.width + x] >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, WAVE));
+        if (lane == 0 && tx * T1 < P.width && ty * T1 < P.height) S->mind[1][ty * n1x + tx] = mn;
+        row = min(row, mn);
+    }
+    if (lane == 0) part[w] = row;
+    __syncthreads();
+    if (threadIdx.x == 0) S->mind[0][by * n0x + bx] = min(min(part[0], part[1]), min(part[2], part[3]));
+}
+__global__ void __launch_bounds__(256) k_slab_begin2(FhRenderState* S, uint32_t n0, uint32_t table_words, uint32_t slab, uint32_t n_root_groups) {
+    if (blockIdx.x < n0) { minpyramid2_body(S, blockIdx.x); return; }
+    reset_slab_body(S, (blockIdx.x - n0) * blockDim.x + threadIdx.x, (gridDim.x - n0) * blockDim.x, table_words, slab, n_root_groups, 0);
+}
+
 // Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
 // ... and the frame's queue-overflow flags (one per slab context) are latched into the context's sticky word: with frames
 // pipelined over two buffer sets, a set is re-used by the frame after next before the host has looked at its flags.
