@@ -905,8 +905,6 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_l1, 0));
             ctx->stream = ctx->stream3;
         }
-        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
-        launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
     }
     // Two-stream pipeline over the z-slabs: the tile stage of a slab runs on the side stream while
     // the leaves of the slab in front of it are evaluated on the caller's stream.  The occlusion
@@ -917,9 +915,22 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
     const uint32_t NC = pipe ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;     // (no more contexts than slabs: each takes its share of the arena)
     ctx->forked = pipe ? NC : 0;
+    if (pre && n_groups) {
+        // (one coarse level - root tiles of 32^3 - in a pipelined frame: that level IS the frame's longest chain and the pre-pass stream the
+        // pacemaker of the pipeline, so what follows its push - the flags of the parked parents, the frame mark, the fork of the slab
+        // contexts - goes to the head of the tile chains on the side stream, which has no level 1 to carry in such a frame)
+        if (fpipe && pipe && pre == 1 && side_stream && side_stream != ctx->stream) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_l0, 0));
+            ctx->stream = side_stream;
+        }
+        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
+        if (!pipe) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
+    }
     if (pipe) {
         hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
-                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints);
+                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints,
+                           (pre && n_groups) ? 1u : 0u);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }

@@ -610,7 +610,11 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
     const uint32_t G = TG * F;      // slots per parent (tape groups at level 0, shares of the children below it)
     const uint32_t ns = min(S->count[level], S->slot_cap[0] / G), nb = min(S->count_big[level], S->slot_cap[1] / G);
     if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns * G; S->n_slots[1][level] = nb * G; }
-    for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
+    // (root level with tape groups: a parent has one slot per group - 32 for prospero.vm - and a frame of few root tiles is a handful of
+    // parents: the slots of a parent are shared out over `parts` waves, each repeating the little arithmetic and writing its slots)
+    const uint32_t parts = TG > 1 ? max(1u, min(TG, gridDim.x / max(ns + nb, 1u))) : 1u;
+    for (uint32_t wi = blockIdx.x; wi < (ns + nb) * parts; wi += gridDim.x) {
+        const uint32_t gi = wi / parts, part = wi % parts;
         const bool big = gi >= ns;
         const AS4 FhGroup& g = *(const AS4 FhGroup*)&S->queue[level][big ? S->qcap[level] - 1 - (gi - ns) : gi];
         FhSlot* const slg = &S->slots[big ? 1 : 0][(big ? (gi - ns) : gi) * G];
@@ -624,7 +628,7 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
         const bool inv = IS3D && level > 0 && ((g.stride >> 31) != 0 || zrep > 1);   // (a copy-carrying entry's tape is invariant: pruning only removes ops)
         if (IS3D && level > 0) {  // the whole parent may have been occluded since it was queued
             const uint32_t Tp = P.tiles[level - 1], ntxp = (P.width + Tp - 1) / Tp;
-            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane < (int)G) slg[lane].act = 0; continue; }
+            if (S->mind[level - 1][(g.y / Tp) * ntxp + g.x / Tp] >= g.z + (zrep - 1) * Tp + Tp + 1) { if (lane < (int)G && part == 0) slg[lane].act = 0; continue; }
         }
         uint32_t nchild, cx, cy, cz;
         // (level 0 with a column-invariant root tape, capi_render.hpp root_zrep: the group's root tiles stand for g.x layers stacked on them)
@@ -647,14 +651,14 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
         }
         if (IS3D && act && mind[(cy / T) * ntx + cx / T] >= cz_top + T + 1) act = false;  // voxel.rs:283-289
         const uint64_t actm = ballot(act);
-        if (actm == 0) { if (lane < (int)G) slg[lane].act = 0; continue; }
+        if (actm == 0) { if (lane < (int)G && part == 0) slg[lane].act = 0; continue; }
         IV X, Y, Z;
         xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
                     IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z), X, Y, Z);     // (2D: pixel.rs:325-333)
         // a share of the children: the active lanes whose rank among them falls into the k-th of F equal parts (x-fastest
         // lane order: neighbours stay together, and neighbours keep much the same ops)
         const uint32_t na = (uint32_t)__popcll(actm), arank = (uint32_t)__popcll(actm & ((1ull << lane) - 1));
-        for (uint32_t k = 0; k < G; k++) {
+        for (uint32_t k = part; k < G; k += parts) {
             FhSlot& so = slg[k];
             const uint64_t share = F > 1 ? ballot(act && arank * F / na == k) : actm;
             if (lane == 0) {
@@ -1362,7 +1366,8 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
 __global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, FhLeafRef* leaf_table, uint32_t* fp_lists,
-                             size_t leaf_cap, size_t n_footprints) {
+                             size_t leaf_cap, size_t n_footprints, uint32_t mark) {
+    if (mark) A->arena_frame_end = min(A->arena_head, A->arena_cap);      // (k_mark_frame's work in the same launch: one kernel boundary less on the coarse chain)
     // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
     const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
     const uint32_t part = (A->arena_cap - lo) / n;
