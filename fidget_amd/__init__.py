@@ -247,7 +247,7 @@ class HipContext:
         return int(lib().fhip_debug_lane_frames(self._h))
 
     def set_option(self, name, value=1):
-        """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "slab_contexts", ...).  The environment
+        """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "frame_sets", ...).  The environment
         (FHIP_<NAME>) is read once, when the context is created; this is the only way to change a switch afterwards."""
         self.check(lib().fhip_ctx_set_option(self._h, name.encode(), int(value)))
 
@@ -287,8 +287,8 @@ class HipContext:
         ms = np.zeros(8, np.float64)
         n = np.zeros(8, np.uint32)
         self.check(lib().fhip_profile_read_kernels(self._h, _p(ms), _p(n)))
-        # (fh_prune1: the root level's prune, i.e. k_prune2 with the scalar sweep behind it when option prune2 is on; k_prune2_l1: level 1's)
-        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_tiles_v32", "fh_tiles_v64", "k_prune2_l1"]
+        # (fh_prune1: the root level's prune, i.e. k_prune2 with the scalar sweep behind it when option prune2 is on)
+        names = ["fh_columns", "fh_float_eval_16x4", "fh_float_eval_32x2", "fh_tiles", "fh_prune1", "fh_tiles_v32", "fh_tiles_v64", "unused"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def counters(self):

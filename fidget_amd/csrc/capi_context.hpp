@@ -80,17 +80,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     {   // the side stream carries the (latency-bound) tile stage of the next slab: highest priority
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        // (FHIP_SIDE_CUS=n, experiment, fixed at creation: the side stream - level 1 of the coarse levels, one wave per parent - alone on n
-        // compute units, the pre-pass and tail streams on the others; such streams are BLOCKING ones - the runtime has no other kind with a
-        // mask - so only for callers that do not render on the null stream)
-        const int n_side = std::min(c->opt.side_cus, c->n_cu - 8);
-        if (n_side > 0) {
-            uint32_t m[16] = {0}, inv[16] = {0};
-            for (int i = 0; i < c->n_cu; i++) (i < n_side ? m : inv)[i / 32] |= 1u << (i % 32);
-            const uint32_t words = (uint32_t)((c->n_cu + 31) / 32);
-            if (hipExtStreamCreateWithCUMask(&c->stream2, words, m) != hipSuccess || hipExtStreamCreateWithCUMask(&c->stream3, words, inv) != hipSuccess ||
-                hipExtStreamCreateWithCUMask(&c->stream_pre, words, inv) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-        } else if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
@@ -98,18 +88,10 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     (void)hipEventCreateWithFlags(&c->ev_l1, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_rest_join, hipEventDisableTiming);
-    if (c->opt.leaf_streams == 2) (void)hipStreamCreateWithFlags(&c->stream_leaf2, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     for (auto& o : c->others) (void)hipEventCreateWithFlags(&o.ev_done, hipEventDisableTiming);
     if (!c->stream3 && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-    if (!c->stream_pre) {   // FHIP_PRE_PRIORITY: 0 default, 1 lowest, 2 highest (diagnostics)
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const int pp = c->opt.pre_priority;
-        const hipError_t e = pp == 0 ? hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking)
-                                     : hipStreamCreateWithPriority(&c->stream_pre, hipStreamNonBlocking, pp == 1 ? lo : hi);
-        if (e != hipSuccess) { delete c; return FHIP_ERR_HIP; }
-    }
+    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     if (c->sticky.ensure(256) != hipSuccess || hipMemset(c->sticky.p, 0, 256) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
@@ -140,7 +122,6 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     c->release_all();
     for (auto& o : c->others) o.release_all();
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
-    if (c->stream_leaf2) { (void)hipStreamSynchronize(c->stream_leaf2); (void)hipStreamDestroy(c->stream_leaf2); }
     if (c->ev_rest_fork) (void)hipEventDestroy(c->ev_rest_fork);
     if (c->ev_rest_join) (void)hipEventDestroy(c->ev_rest_join);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);

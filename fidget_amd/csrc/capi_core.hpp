@@ -59,13 +59,17 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
 // programs under a switch) and changed afterwards only through fhip_ctx_set_option(ctx, "<name>", value) - nothing in a
 // render's launch path looks at the environment.  name, default; DESIGN.md section 5 says what each one selects.
 #define FH_OPTION_LIST(X)                                                                                                       \
-    X(no_asm, 0) X(no_split, 0) X(probe, 0) X(no_pipeline, 0) X(slab_contexts, 4) X(no_frame_pipeline, 0) X(arena_mb, 4096)     \
-    X(vm_tiles, 0) X(no_columns_t, 0) X(no_split_2d, 0) X(no_asm_tiles, 0) X(prune1_levels, 1) X(no_prune1, 0)                  \
-    X(no_tape_groups, 0) X(stats, 0) X(one_each_tiles, 0) X(pipe_serial, 0) X(no_tiles_v, 0) X(no_both_lists, 0)               \
-    X(v32_waves, 16) X(v64_waves, 8) X(v64_slab_waves, 128) X(no_mid, 0) X(push_waves, 2) X(no_column_inv, 0) X(no_zrep, 0)     \
-    X(debug_zfill, 0) X(old_pyr, 0) X(no_slab_begin, 0) X(tail_stream, 1) X(col_waves, 0) X(col_blkl, 2) X(l1_split, 1) X(prune2, 1) X(prune2_l1, 0) X(no_asm_normals, 0) X(no_asm_tiles_t, 0) X(normals_waves, 8) X(prune2_probe_level, 0) X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(side_only_l1, 1) X(chain_prio, 0) X(tail_on_main, 2) X(mesh_simplify_min_ops, 256) X(side_cus, 0) X(frame_lanes, 4) X(lanes_all, 0) X(lanes_tune, 1) X(lanes_parts, 1) X(lanes_fail, 0) X(slab_layers, 4) X(l1_on_side, 1) X(tiles_stream, 2) X(frame_sets, 4) X(root32_max, 4096) X(no_root_zrep, 0)                        \
-    /* fixed when the context is created (they decide which streams exist): environment only */                                 \
-    X(leaf_streams, 1) X(pre_priority, 0)
+    /* kernel selection (each falls back to the HIP C++ path of the same stage, which tapes outside the assembly set take anyway) */ \
+    X(no_asm, 0) X(no_split, 0) X(no_asm_tiles, 0) X(no_tiles_v, 0) X(no_asm_tiles_t, 0) X(no_columns_t, 0) X(no_asm_normals, 0)   \
+    X(no_tape_groups, 0) X(prune2, 1)                                                                                           \
+    /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level */ \
+    X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096)                                                                       \
+    /* pipelining and resources */                                                                                             \
+    X(no_pipeline, 0) X(frame_sets, 4) X(frame_lanes, 4) X(lanes_tune, 1) X(lanes_fail, 0) X(slab_layers, 4) X(arena_mb, 4096)  \
+    /* mesher */                                                                                                               \
+    X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(mesh_simplify_min_ops, 256)                                             \
+    /* diagnostics */                                                                                                          \
+    X(probe, 0) X(stats, 0)
 struct FhOptions {
 #define X(name, dflt) int name = dflt;
     FH_OPTION_LIST(X)
@@ -119,7 +123,6 @@ struct fhip_ctx : FrameBufs {
     uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
-    hipStream_t stream_leaf2 = nullptr; // FHIP_LEAF_STREAMS=2 (diagnostics): the leaf kernels of odd slabs
     hipEvent_t ev_rest_fork = nullptr, ev_rest_join = nullptr;
     hipEvent_t ev_pre = nullptr, ev_l0 = nullptr, ev_l1 = nullptr;
     hipStream_t post_v64_stream = nullptr;   // launch_tiles_split: where the launches behind level 1's fh_tiles_v64 go (side_only_l1), or null
@@ -195,8 +198,8 @@ static void apply_options(fhip_ctx* c) {
     c->use_split = c->opt.no_split == 0;
     c->probe = c->opt.probe != 0;
     c->use_pipeline = c->opt.no_pipeline == 0;
-    c->frame_pipeline = c->opt.no_frame_pipeline == 0;
-    c->slab_contexts = (uint32_t)std::min(4, std::max(2, c->opt.slab_contexts));
+    c->frame_pipeline = true;
+    c->slab_contexts = 4;
     c->arena_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
     c->extra_sets = (uint32_t)std::min(FH_EXTRA_SETS, std::max(1, c->opt.frame_sets - 1));
 }

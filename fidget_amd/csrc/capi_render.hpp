@@ -33,10 +33,6 @@ struct RenderSetup {
     const uint64_t* d_ctab = nullptr;
     size_t lds_prune2 = 0;
     uint32_t p2_cap_kept = 0;      // kept ops per child the linked prune's LDS areas are sized for (children beyond: the scalar sweep behind it)
-    bool prune2_l1 = false;   // ... and level 1 by the same kernel, on the links the level-0 launch leaves in front of every child tape (option
-                              // prune2_l1, off: fh_tiles_v64's forward pass alone takes 0.13 ms of its 0.39, but one wave per 32^3 child - 6 120 of them,
-                              // 2 to a SIMD, each bound by scalar issue - takes 0.75 ms where the lockstep sweep takes 0.26; profiles/r03o)
-    size_t lds_prune2_l1 = 0;
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
@@ -73,9 +69,8 @@ static std::vector<uint32_t> trim_tiles(const uint32_t* tiles, uint32_t n, uint3
     return std::vector<uint32_t>(tiles + i, tiles + n);
 }
 
-static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size, bool vm_tiles) {
+static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size) {
     std::vector<uint32_t> v = trim_tiles(VM_TILES_3D, 5, max_size);
-    if (vm_tiles) return v;  // diagnostics: the reference's own subdivision
     std::vector<uint32_t> out{v[0]};
     for (uint32_t t = v[0]; t > 8;) { t = std::max<uint32_t>(t / 4, 8); out.push_back(t); }
     return out;
@@ -244,7 +239,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // column of root tiles.  One layer per z-slab is evaluated (the slab's back-most: FhGroup::x = how many layers of the slab it stands
     // for) and the push stage hands the result to the stack - a fill with the nearest copy's depth, ONE queue entry carrying the copies,
     // exactly what the levels below do for column-invariant parents.  prospero.vm at 1024^3: 64 root tiles instead of 512.
-    R.root_zrep = is3d && S.pre_levels > 0 && ctx->use_split && TL == 64 && R.xy_fixed && R.root_invariant && !ctx->opt.no_zrep && !ctx->opt.no_root_zrep;
+    R.root_zrep = is3d && S.pre_levels > 0 && ctx->use_split && TL == 64 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0;
     uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
     if (R.root_zrep) {
         q0_layers = 0;
@@ -326,7 +321,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     }
     S.count_big[0] = (uint32_t)R.roots.size();  // the root tape always takes the large LDS layout
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
-    R.split = ctx->use_split && R.tl == 64 && (is3d || !ctx->opt.no_split_2d);
+    R.split = ctx->use_split && R.tl == 64 && true;
     // (tapes with sin cos tan asin acos atan exp ln: the *_t variants of the tile kernels, which carry those interval handlers;
     // atan2, mod, mix, rand keep the HIP tile stage)
     R.asm_tiles_t = !tape_asm_ok(t) && tape_tiles_t_ok(t) && !ctx->opt.no_asm_tiles_t;
@@ -336,11 +331,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.asm_tiles_t = R.asm_tiles_t && R.asm_tiles;
     // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
     // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
-    {
-        const uint32_t p1_levels = (uint32_t)std::max(0, ctx->opt.prune1_levels);
-        R.exp_levels = is3d ? std::min(S.pre_levels, p1_levels) : std::min(1u, p1_levels);
-    }
-    R.prune1 = R.asm_tiles && !R.asm_tiles_t && R.exp_levels > 0 && !ctx->opt.no_prune1;      // (the *_t kernels have no export mode)
+    R.exp_levels = is3d ? std::min(S.pre_levels, 1u) : 1u;
+    R.prune1 = R.asm_tiles && !R.asm_tiles_t && R.exp_levels > 0;      // (the *_t kernels have no export mode)
     // tape parallelism: level 0 evaluates the root tree's terms as independent groups on different
     // waves, then the tree itself; the prune sees the root tape with its usual choices
     R.groups = R.prune1 && !tape->tgroups.empty() && !ctx->opt.no_tape_groups;
@@ -401,9 +393,6 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                        R.lds_prune2 <= FH_LDS_MAX && R.roots.size() * 64 <= (size_t)2 * ctx->n_cu * FH_P2_WPB;      // (a root group = up to 64 root tiles)
             R.d_ctab = tape->d_ctab;
             R.d_links = tape->d_links;
-            R.lds_prune2_l1 = (((size_t)FH_P2_L1_OPS * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_L1_WPB * fh_p2_wave_lds(FH_P2_L1_CHOICES, FH_P2_L1_OPS);
-            R.prune2_l1 = R.prune2 && is3d && S.pre_levels > 1 && ctx->opt.prune2_l1 && !ctx->opt.no_tiles_v && R.exp_levels <= 1 &&
-                          R.lds_prune2_l1 <= FH_LDS_MAX;
             const size_t blocks = qcaps[0];
             HIP_TRY(ctx, ctx->tvals.ensure(blocks * S.n_terms * WAVE * 8));
             HIP_TRY(ctx, ctx->topch.ensure(blocks * S.n_top * WAVE));
@@ -540,18 +529,13 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
     } while (0)
 // 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
 static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
-    // Persistent waves with a static round robin over the parents.  (FHIP_ONE_EACH_TILES=1: one short
-    // workgroup per parent instead - measured slower in the pipelined frame: the tile stage then
-    // takes more of the machine from the leaf kernel it overlaps with.)
-    const uint32_t one_each = ctx->opt.one_each_tiles ? std::min<uint32_t>(R.S.qcap[level], 1u << 20) : 0u;
-    const int gs = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_small, 8);
-    const int gb = one_each && !R.big_hbm ? (int)one_each : blocks_big(ctx, R, R.lds_tiles_big, 8);
-    const int gp = one_each ? (int)one_each : ctx->n_cu * 8;
+    // Persistent waves with a static round robin over the parents (one short workgroup per parent was measured slower in the
+    // pipelined frame: the tile stage then takes more of the machine from the leaf kernel it overlaps with).
+    const int gs = blocks_for(ctx, R.lds_tiles_small, 8);
+    const int gb = blocks_big(ctx, R, R.lds_tiles_big, 8);
+    const int gp = ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] {
-        // (pre-pass levels below the root: the children of a parent shared out over several slots - tsetup_body; option
-        // l1_split: 0 chosen on the device from the number of parents, 1 off, 2 / 4 / 8 fixed)
-        const uint32_t csplit = (level > 0 && (uint32_t)level < R.S.pre_levels && R.asm_tiles) ? (uint32_t)std::max(0, std::min(8, ctx->opt.l1_split)) : 1u;
-        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level, csplit);
+        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
         else hipLaunchKernelGGL(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
     });
     if (R.groups && level == 0) {
@@ -572,9 +556,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (R.prune2) {
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
-                hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, 2u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, (R.prune2_l1 ? 1u : 0u) | (ctx->opt.prune2_probe_level == 0 ? 2u : 0u) | (ctx->opt.chain_prio ? 4u : 0u), R.S.troot_len, R.S.troot_choices,
-                                   R.p2_cap_kept);
+                hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u, R.S.troot_len, R.S.troot_choices, R.p2_cap_kept);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -608,7 +591,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // boundaries per slab, whatever the number of hardware queues.)
             hipStream_t const rest_stream = ctx->stream2;
             const bool side = level > 0 && (uint32_t)level < R.S.pre_levels && ctx->use_pipeline && !ctx->profiling && rest_stream &&
-                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && !ctx->opt.pipe_serial && is3d;
+                              ctx->stream != rest_stream && ctx->stream != ctx->stream_pre && is3d;
             hipStream_t const big_stream = side ? rest_stream : nullptr;
             // Tapes of <= 32 registers / 256 choices (the small slot list: every parent of the leaf level) and, from the other
             // list, those of <= 64 / 512 go to the kernels that keep the interval file, the choices and the prune's register
@@ -625,10 +608,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 // (a pre-pass level has a few hundred parents in the two lists together: fh_tiles_v64 takes both in ONE launch
                 // below - the level's time is its slowest parent's either way, and a launch of its own for the small list put
                 // another 130 us on the coarse levels' chain)
-                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side && !ctx->opt.no_both_lists;
+                both_lists = vk && (uint32_t)level < R.S.pre_levels && !side;
                 if (vk && !both_lists) {
-                    const int v32_waves = ctx->opt.v32_waves;
-                    ka.n_waves = one_each ? one_each : (uint32_t)(ctx->n_cu * v32_waves);
+                    const int v32_waves = 16;
+                    ka.n_waves = (uint32_t)(ctx->n_cu * v32_waves);
                     (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V32_T : FH_ASM_TILES_V32, ka.n_waves, &ka, sizeof(ka));
                 } else if (vk) {
                 } else
@@ -640,23 +623,16 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // (leaving the per-slab levels' big-list parents to the root-sized LDS launch alone - one launch less on the slab's tile
             // chain - was measured: 1.02 vs 1.04 ms per frame, within the noise; not done)
             if (vk && level > 0) {
-                const int v64_waves = ctx->opt.v64_waves;
+                const int v64_waves = 8;
                 // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
                 // VGPRs each, queued behind the leaf kernel of the slab in front, was measured to hold the tile chain up for
                 // 130 us: a small persistent grid there)
-                const int v64_slab_waves = ctx->opt.v64_slab_waves;
+                const int v64_slab_waves = 128;
                 const bool per_slab = (uint32_t)level >= R.S.pre_levels && R.S.pre_levels > 0;
                 ka.max_regs = V64_REGS; ka.max_choices = V64_CHOICES;
-                ka.n_waves = one_each ? one_each : (per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves));
+                ka.n_waves = per_slab ? (uint32_t)v64_slab_waves : (uint32_t)(ctx->n_cu * v64_waves);
                 if (both_lists) ka.flags |= 16u;
-                // (level 1 with the linked prune: parents whose tape carries this frame's links get their choices exported - chw[1]
-                // with this stride, chw[0] with 16 words - and their children marked for k_prune2 below; the others are pruned here)
-                const bool linked = R.prune2_l1 && !per_slab;
                 const uint32_t plain_flags = ka.flags;
-                if (linked) ka.flags = (ka.flags & 0xFFFFu) | 2u | (((R.S.P.max_choices + 15) / 16) << 16);
-                // (option chain_prio, on: level 1 of the coarse chain at issue priority 3 - its waves are dependent chains on SIMDs they
-                // share with the other streams' kernels in a pipelined frame)
-                if (ctx->opt.chain_prio && !per_slab) ka.flags |= 0x200u;
                 (void)launch_asm(ctx, R.asm_tiles_t ? FH_ASM_TILES_V64_T : FH_ASM_TILES_V64, ka.n_waves, &ka, sizeof(ka), 0, 1, big_stream);
                 if (ctx->post_v64_stream && !per_slab && !big_stream) {      // (side_only_l1: the level's remaining launches - the LDS layouts' rest, the push - leave the side stream)
                     (void)hipEventRecord(ctx->ev_l1, ctx->stream);
@@ -670,9 +646,9 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // Pre-pass levels below the root: a few hundred parents whose tapes are far smaller than the
             // root's.  With the root-sized LDS layout only one wave fits a CU (256 at a time); a medium
             // layout takes those that fit it three to a CU, the root-sized launch takes the rest.
-            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big && !ctx->opt.no_mid;
+            const bool mid = !(vk && level > 0) && level > 0 && (uint32_t)level < R.S.pre_levels && R.lds_tiles_mid * 2 <= R.lds_tiles_big;
             if (mid) {
-                const int gm = one_each ? (int)one_each : blocks_for(ctx, R.lds_tiles_mid, 8);
+                const int gm = blocks_for(ctx, R.lds_tiles_mid, 8);
                 ka.max_regs = MID_REGS; ka.max_choices = MID_CHOICES; ka.n_waves = (uint32_t)gm;
                 (void)launch_asm(ctx, K_TILES, (uint32_t)gm, &ka, sizeof(ka), R.lds_tiles_mid, 1, big_stream);
                 ka.skip_regs = MID_REGS; ka.skip_choices = MID_CHOICES;
@@ -682,14 +658,6 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (side) {
                 (void)hipEventRecord(ctx->ev_rest_join, rest_stream);
                 (void)hipStreamWaitEvent(ctx->stream, ctx->ev_rest_join, 0);
-            }
-            if (R.prune2_l1 && use_v && level > 0 && (uint32_t)level < R.S.pre_levels) {
-                hipEvent_t ea = nullptr, eb = nullptr;      // (slot 7 of the per-kernel profile)
-                if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
-                hipLaunchKernelGGL(k_prune2, dim3(ctx->n_cu * 2), dim3(FH_P2_L1_WPB * 64), R.lds_prune2_l1, ctx->stream, dS, (uint32_t)level, 2u, 0u,
-                                   (R.S.P.max_choices + 15) / 16, (const uint2*)nullptr, (const uint2*)nullptr, ctx->opt.prune2_probe_level == 1 ? 2u : 0u,
-                                   (uint32_t)FH_P2_L1_OPS, (uint32_t)FH_P2_L1_CHOICES, (uint32_t)FH_P2_L1_OPS);
-                if (ctx->profiling) { (void)hipEventRecord(eb, ctx->stream); ctx->asm_events.push_back({7, {ea, eb}}); }
             }
             if (exp) {
                 struct { FhRenderState* S; uint32_t level, big, max_choices, pad; } kp = {dS, (uint32_t)level, 0, SMALL_CHOICES, 0};
@@ -709,8 +677,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
     // (last level: fewer waves, several parents each - one leaf reservation per wave)
-    const int push_mul = ctx->opt.push_waves;
-    const int gpush = (level + 1 == (int)R.S.P.n_levels && !one_each) ? ctx->n_cu * push_mul : gp;
+    const int push_mul = 2;
+    const int gpush = (level + 1 == (int)R.S.P.n_levels) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
         else {
@@ -753,8 +721,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
     memcpy(P.mat, m4, sizeof(m4));
     const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : (ctx->opt.vm_tiles ? trim_tiles(VM_TILES_2D, 3, std::max(cfg->width, cfg->height))
-                                                                                : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height)));
+                                                     : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height));
     st = prepare(ctx, tape, false, ts, PartSpec{}, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
@@ -806,7 +773,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 4, P.mat);  // voxel.rs:107-109
     column_setup(ctx, tape, P, R);
     std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                               : hip_tiles_3d(std::max(cfg->width, cfg->height), ctx->opt.vm_tiles != 0);
+                                               : hip_tiles_3d(std::max(cfg->width, cfg->height));
     // Few tiles, long tape (a small image, a part of a frame on one rank of several, a model without z): root tiles of 32^3 straight
     // above the leaves.  With 128^3 root tiles such a frame is a handful of one-wave chains over tapes that a 128^3 tile barely prunes
     // (prospero.vm at 512^3: a root tile keeps up to 1 795 of 6 363 ops - beyond the linked prune's and fh_tiles_v64's limits, so the
@@ -817,11 +784,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // tile sizes, so this is the library's choice whenever the caller gave none: taken while the root level has at
     // most `root32_max` children - counting one layer per z-slab when the root tape reads nothing that changes along a pixel column
     // (root_zrep, prepare) - and the tape is one the groups + linked prune path takes.
-    if (!cfg->tile_sizes && !ctx->opt.vm_tiles && ctx->opt.root32_max > 0 && ts.size() == 3 && ts[0] == 128 && ctx->use_split && ctx->use_asm &&
-        !tape->tgroups.empty() && !ctx->opt.no_tape_groups && !ctx->opt.no_prune1 && ctx->opt.prune2 && tape_asm_ok(tape->t) &&
+    if (!cfg->tile_sizes && ctx->opt.root32_max > 0 && ts.size() == 3 && ts[0] == 128 && ctx->use_split && ctx->use_asm &&
+        !tape->tgroups.empty() && !ctx->opt.no_tape_groups && ctx->opt.prune2 && tape_asm_ok(tape->t) &&
         tape->t.ops.size() <= FH_P2_MAX_OPS && tape->t.n_choices <= FH_P2_MAX_CHOICES) {
         const uint64_t cols = (uint64_t)((P.width + 31) / 32) * ((P.height + 31) / 32) / std::max<uint32_t>(1, part.n_shards * part.nx * part.ny);
-        const bool dedupe = R.xy_fixed && R.root_invariant && !ctx->opt.no_zrep;
+        const bool dedupe = R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0;
         const uint64_t layers = dedupe ? (uint64_t)std::max<uint32_t>(2, (P.depth + 511) / 512) : (uint64_t)((P.depth + 31) / 32) / std::max<uint32_t>(1, part.nz);
         // (measured, profiles/r05c: up to two rounds of the linked prune's workgroups - 2 048 children - always; up to root32_max when a
         // 128^3 root tile is a quarter of the image or more - there the 128^3 tiles' tapes stay long whatever is done: 512^3 with z in
@@ -838,7 +805,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // (a tape whose register files live in HBM takes the slow path: one region per workgroup, shared by the launches of a frame, so
     // nothing of the frame runs beside anything else)
     const bool huge = (size_t)std::max<uint32_t>(tape->t.n_regs, 1) * WAVE * 16 > FH_LDS_MAX || tiles_lds(std::max<uint32_t>(tape->t.n_regs, 1), tape->t.n_choices, 64) > FH_LDS_MAX;
-    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !ctx->opt.pipe_serial && !huge;
+    const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !huge;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     bool frames_queued = false;     // the frame before this one is still under way (the caller queues frames back to back)
     if (fpipe) {
@@ -851,14 +818,14 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     }
     st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
-    R.zrep = R.split && R.S.pre_levels > 0 && R.xy_fixed && !ctx->opt.no_column_inv && !ctx->opt.no_zrep;
+    R.zrep = R.split && R.S.pre_levels > 0 && R.xy_fixed && !ctx->opt.no_column_inv && ctx->opt.no_zrep != 1;
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * sizeof(FhGeometryPixel))); d_out = (FhGeometryPixel*)ctx->tmp_out.p; }
     FhRenderState* dS = (FhRenderState*)ctx->state.p;
     // (FHIP_DEBUG_ZFILL, diagnostics: every pixel already at the far depth - the front slab's leaf kernel then finds all its
     // leaves but nothing pending, which times its per-workgroup and per-leaf set-up without the interpretation)
-    const FrameClear clear3[3] = {{ctx->zbuf.p, npix * 8, ctx->opt.debug_zfill ? 0xFFFFFFFFu : 0u}, {ctx->normals.p, npix * 12, 0u},
+    const FrameClear clear3[3] = {{ctx->zbuf.p, npix * 8, 0u}, {ctx->normals.p, npix * 12, 0u},
                                   {ctx->mind.p, R.mind_words * 4, 0u}};
     st = upload_frame(ctx, tape, R, clear3);
     if (st) return st;
@@ -870,7 +837,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // chains on the side stream.  The two coarse levels of a frame are one dependent chain of ~0.9 ms that, on one stream, set
     // the frame rate; split, the root level of frame n + 1 runs beside level 1 and the slabs of frame n, and the side stream
     // carries level 1 + the (now few) slab steps of its own frame.  (A frame alone sees no difference: the same chain.)
-    const bool l1_side = fpipe && ctx->opt.l1_on_side && pre > 1 && ctx->stream2 && !ctx->opt.pipe_serial &&
+    const bool l1_side = fpipe && pre > 1 && ctx->stream2 &&
                          ctx->use_pipeline && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
     // (option side_only_l1, on: the side stream - the busiest one of a pipelined frame, 0.43 ms of the 0.526 - carries level 1's evaluate + prune
     // launches and nothing else: the flags of level 1's tapes are set at the end of the root level on the pre-pass stream, and what follows
@@ -878,13 +845,13 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // (only for frames whose tile chains will run on the tail stream - `tiles_first` below, the same conditions: a frame with heavy leaf
     // kernels keeps its tile chains on the side stream, and its fork must not queue behind the previous frame's tail work)
     bool l1_only = false;
-    if (l1_side && ctx->opt.side_only_l1 && pre == 2 && ctx->stream3 && ctx->opt.tail_stream == 1 && R.asm_points) {
+    if (l1_side && pre == 2 && ctx->stream3 && R.asm_points) {
         const bool pipe_plan = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
         const uint32_t nc_plan = pipe_plan ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;
         bool inv = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
         for (uint64_t w : tape->t.ops)
             if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { inv = false; break; }
-        l1_only = pipe_plan && (ctx->opt.tiles_stream == 1 || (ctx->opt.tiles_stream == 2 && inv)) && R.slab_hi - R.slab_lo <= nc_plan;
+        l1_only = pipe_plan && inv && R.slab_hi - R.slab_lo <= nc_plan;
     }
     if (pre && n_groups) {  // coarse levels of every slab in one go
         for (uint32_t l = 0; l < pre; l++) {
@@ -912,7 +879,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // (dS, dS + 1) alternate; each owns its leaves, leaf table, footprint lists and arena half.
     FhRenderState* const dS0 = dS;
     const bool pipe = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
-    hipStream_t const side_stream = ctx->opt.pipe_serial ? main_stream : ctx->stream2;  // diagnostics
+    hipStream_t const side_stream = ctx->stream2;
     const uint32_t NC = pipe ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;     // (no more contexts than slabs: each takes its share of the arena)
     ctx->forked = pipe ? NC : 0;
     if (pre && n_groups) {
@@ -951,8 +918,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     bool root_invariant = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
     for (uint64_t w : tape->t.ops)
         if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { root_invariant = false; break; }
-    const bool tiles_first = pipe && l1_side && (ctx->opt.tiles_stream == 1 || (ctx->opt.tiles_stream == 2 && root_invariant)) && ctx->stream3 &&
-                             ctx->opt.tail_stream == 1 && R.asm_points && R.slab_hi - R.slab_lo <= NC;
+    const bool tiles_first = pipe && l1_side && root_invariant && ctx->stream3 && R.asm_points && R.slab_hi - R.slab_lo <= NC;
     hipStream_t const tile_stream = tiles_first ? ctx->stream3 : side_stream;
     if (tiles_first) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_fork, 0));
     auto tile_step = [&](int k, int idx) -> fhip_status {
@@ -965,16 +931,16 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             // the usual pyramid (three levels, 4 x 4 each, 8 x 8 leaf tiles) has a kernel of its own
             // (up to 1024 x 1024: at 2048 x 2048 it was measured SLOWER than the generic kernel - 11.2 vs 8.2 ms per frame)
             const bool pyr3 = P.n_levels == 3 && P.tiles[2] == 8 && P.tiles[1] == 32 && P.tiles[0] == 128 &&
-                              ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024 && !ctx->opt.old_pyr;
+                              ((P.width + 31) / 32) * ((P.height + 31) / 32) <= 1024;
             const bool rebuild = k != (int)R.slab_hi - 1;  // the first slab sees an empty image (pyramid pre-zeroed)
             // (32 / 8 with its one pre-pass level: both pyramid levels rebuilt and the slab reset in one launch as well)
-            const bool pyr2 = P.n_levels == 2 && P.tiles[1] == 8 && P.tiles[0] == 32 && pre == 1 && !ctx->opt.no_slab_begin;
+            const bool pyr2 = P.n_levels == 2 && P.tiles[1] == 8 && P.tiles[0] == 32 && pre == 1;
             if (rebuild && pyr2) {
                 const uint32_t n0 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
                 hipLaunchKernelGGL(k_slab_begin2, dim3(n0 + reset_blocks), dim3(256), 0, ctx->stream, dS, n0, R.table_words, (uint32_t)k, n_groups);
                 return;
             }
-            if (rebuild && pyr3 && pre == 2 && !ctx->opt.no_slab_begin) {
+            if (rebuild && pyr3 && pre == 2) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
                 hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
                 return;
@@ -1007,22 +973,19 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             if (ts_) { ctx->stream = main_stream; return ts_; }
         }
         dS = dS0 + (pipe ? (uint32_t)idx % NC : 0u);
-        // (diagnostics, FHIP_LEAF_STREAMS=2: leaf kernels of consecutive slabs on two streams, so that the tail of one overlaps
-        // the head of the next - any interleaving gives the same image - at the price of lanes that no longer see the hits in front)
-        const bool tail1 = ctx->opt.tail_stream == 1;
-        hipStream_t const leaf_stream = (pipe && tail1 && R.asm_points && ctx->stream3 && ctx->stream_leaf2 && (idx & 1)) ? ctx->stream_leaf2 : main_stream;
+        hipStream_t const leaf_stream = main_stream;
         if (pipe) HIP_TRY(ctx, hipStreamWaitEvent(leaf_stream, ctx->ev_tiles[idx], 0));
         // The leaf kernel is the slab's critical chain.  What surrounds it - the footprint lists (needed by the normals and the
         // LDS-class leaves only), those leaves (any order with the others: atomic-max z-buffer) and the normals of the slab's
         // hits - are small launches that leave the machine mostly idle, so in the pipelined frame they run on a third stream
         // beside the leaf kernel of the NEXT slab: the normals kernel only takes hits of its own slab's depth range, and a hit
         // behind them can never replace them.  (Measured with three slab contexts, ms per frame: everything on the caller's stream 2.44, the normals only on the third stream 2.30, lists + normals 2.16 - once the min-depth pyramid kernel of the tile chain ran in blocks of four waves: its 16-wave blocks found no room beside a leaf kernel that is never interrupted, 166 us instead of 10.  FHIP_TAIL_STREAM=0 / 2 / 1.)
-        const int tail_mode = ctx->opt.tail_stream;   // 0: off, 1: lists + normals, 2: normals only
+        const int tail_mode = 1;   // (lists + normals on the tail stream; normals only - 2 - and off - 0 - were measured slower: DESIGN_HISTORY.md)
         // (option tail_on_main - 0 never, 1 always, 2 when frames are queued back to back: when the tile chains run on the tail stream, the
         // slab's small kernels stay on the caller's stream around its leaf kernel - otherwise the tail stream, serial, waits for every leaf
         // kernel with the NEXT frame's tile chains queued behind: 0.45 ms of it per frame for 0.40 of work.  A frame alone is 70 us
         // quicker with them beside its leaf kernels, hence the test)
-        const bool on_main = tiles_first && (ctx->opt.tail_on_main == 1 || (ctx->opt.tail_on_main == 2 && frames_queued));
+        const bool on_main = tiles_first && frames_queued;
         const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
@@ -1039,7 +1002,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_big(ctx, R, R.lds_normals_big, 8);
                 if (R.asm_normals) {
                     // (list 0 of k_classify3d holds every footprint whose leaves need <= 32 registers: the assembly interpreter's file)
-                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * std::max(1, ctx->opt.normals_waves)), R.col_slots, z_lo, z_hi, {0, 0}};
+                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * 8), R.col_slots, z_lo, z_hi, {0, 0}};
                     (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
                 }
                 else if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
@@ -1061,17 +1024,12 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             if (R.asm_points) {
                 // one launch for classes 0 and 1: 128 VGPRs -> 4 waves per SIMD
                 // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
-                // (FHIP_COL_WAVES=n: n persistent waves per CU instead, diagnostics)
-                const uint32_t col_waves = (uint32_t)std::max(0, ctx->opt.col_waves);
                 // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
                 // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
-                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, (uint32_t)ctx->n_cu * col_waves, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
-                if (col_waves) (void)launch_asm(ctx, which, ka.n_waves, &ka, sizeof(ka), 0, 1, leaf_stream);
-                else {
-                    const uint32_t blk = 1u << ctx->opt.col_blkl;   // footprints per workgroup: gen_interp.py BLKL
-                    (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
-                }
+                const uint32_t blk = 4;   // footprints per workgroup: gen_interp.py FH_BLKL = 2
+                (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
@@ -1117,7 +1075,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 // multi-GPU job renders) are frames like any other here (option lanes_parts): one octant of prospero.vm 1024^3, queued, 0.72 -> 0.31 ms; a
 // column shard of eight stays where it is, 0.43 (profiles/r04r/lanes_parts.txt).
 static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
-    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats || ctx->opt.side_cus) return false;
+    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats) return false;
     if (!ctx->ev_last_valid) return false;
     const hipError_t q = hipEventQuery(ctx->ev_last);      // the frame before this one: still under way?
     (void)hipGetLastError();
@@ -1211,8 +1169,8 @@ static void lane_tune_release(fhip_ctx* ctx) {
 static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, int out_is_device, const PartSpec& part) {
     ctx->tune_cur = -1;
     const bool whole = part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
-    const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline && !ctx->opt.pipe_serial && (whole || ctx->opt.lanes_parts);
-    const bool prior = ctx->use_asm && !ctx->opt.no_columns_t && (!tape_asm_ok(tape->t) || ctx->opt.lanes_all);
+    const bool possible = lanes_possible(ctx, out_is_device) && ctx->use_pipeline && ctx->frame_pipeline;
+    const bool prior = ctx->use_asm && !ctx->opt.no_columns_t && !tape_asm_ok(tape->t);
     if (!possible) { ctx->tune_last_key = 0; return false; }       // (a frame alone, a profiled frame, ...: the stage pipeline; the sequence is broken)
     if (!ctx->opt.lanes_tune) return prior;
     uint64_t key = tape->serial * 0x9E3779B97F4A7C15ull;

@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(WAVE) k_tape_flags(FhRenderState* S, int level
 // but classifying and pruning only its share of the children, repeat the forward pass on SIMDs that would be idle and
 // shorten the prune.  Slots are independent for everything downstream (the push stage sees F small parents).
 template <bool IS3D>
-FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
+FH_DEV void tsetup_body(FhRenderState* S, int level) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
@@ -600,14 +600,9 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
     // Tape parallelism at level 0: every block of root tiles gets one slot per independent tape
     // group (slots g0 .. g0 + G - 1, same children, different tapes); k_ttop3d merges them.
     const uint32_t TG = (level == 0 && S->n_tgroups) ? S->n_tgroups : 1;
-    uint32_t F = 1;
-    if (TG == 1 && level > 0 && split != 1) {
-        const uint32_t total = max(S->count[level] + S->count_big[level], 1u);
-        if (split) F = split;
-        else while (F < 8 && total * F * 2 <= 1536) F *= 2;       // (fh_tiles_v64: 2 waves per SIMD, 2048 at a time)
-        while (F > 1 && (S->count[level] * F > S->slot_cap[0] || S->count_big[level] * F > S->slot_cap[1])) F >>= 1;
-    }
-    const uint32_t G = TG * F;      // slots per parent (tape groups at level 0, shares of the children below it)
+    // (sharing a level-1 parent's children out over 2 / 4 / 8 slots was measured in round 3 - the kernel 412 -> 377 / 371 / 453 us, the frame
+    // unchanged: the lockstep prune's cost is the ops SOME child keeps, and neighbours keep much the same - and taken out)
+    const uint32_t G = TG;      // slots per parent (tape groups at level 0)
     const uint32_t ns = min(S->count[level], S->slot_cap[0] / G), nb = min(S->count_big[level], S->slot_cap[1] / G);
     if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns * G; S->n_slots[1][level] = nb * G; }
     // (root level with tape groups: a parent has one slot per group - 32 for prospero.vm - and a frame of few root tiles is a handful of
@@ -655,12 +650,9 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
         IV X, Y, Z;
         xf_interval(mat, iv((float)cx, (float)cx + (float)T), iv((float)cy, (float)cy + (float)T),
                     IS3D ? iv((float)cz, (float)cz + (float)T) : iv(P.z, P.z), X, Y, Z);     // (2D: pixel.rs:325-333)
-        // a share of the children: the active lanes whose rank among them falls into the k-th of F equal parts (x-fastest
-        // lane order: neighbours stay together, and neighbours keep much the same ops)
-        const uint32_t na = (uint32_t)__popcll(actm), arank = (uint32_t)__popcll(actm & ((1ull << lane) - 1));
         for (uint32_t k = part; k < G; k += parts) {
             FhSlot& so = slg[k];
-            const uint64_t share = F > 1 ? ballot(act && arank * F / na == k) : actm;
+            const uint64_t share = actm;
             if (lane == 0) {
                 const FhTapeRef tr = (TG > 1) ? S->tgroup[k] : FhTapeRef{g.tape.off, g.tape.len, g.tape.n_regs, g.tape.n_choices};
                 so.tape = tr;
@@ -676,10 +668,10 @@ FH_DEV void tsetup_body(FhRenderState* S, int level, uint32_t split) {
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level, uint32_t split) { tsetup_body<true>(S, level, split); }
+__global__ void __launch_bounds__(WAVE) k_tsetup3d(FhRenderState* S, int level) { tsetup_body<true>(S, level); }
 // ... and of the 2D renderer when its tile sizes give 64 children per parent (the 128 / 16 hint): same slots, same
 // evaluate + prune kernels; children are the n x n sub-tiles at the slice height z
-__global__ void __launch_bounds__(WAVE) k_tsetup2d(FhRenderState* S, int level) { tsetup_body<false>(S, level, 1u); }
+__global__ void __launch_bounds__(WAVE) k_tsetup2d(FhRenderState* S, int level) { tsetup_body<false>(S, level); }
 
 // Tape parallelism at level 0 (host_graph.hpp plan_terms), after the groups' forward passes left the
 // terms' intervals in S->tvals: the root min / max tree over those terms, with the Choice every op

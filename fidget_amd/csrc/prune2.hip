@@ -34,15 +34,9 @@
 //   limits : <= 8192 ops, <= 4096 choices in the parent, <= cap_kept kept ops and <= 64 registers in the child (more: the child
 //            is left to the scalar sweep launched behind this kernel), one OUTPUT op, the last one - capi.hip checks and keeps fh_prune1 otherwise
 //
-// Links for the level below.  A child tape written here is itself the parent tape of the next level, and its links cost little
-// more than the tape: with `emit_links` the child's links, its choice table and a stamp go in front of the tape, inside the
-// child's arena slot (which is as long as the parent tape: [ stamp | choice table kc | links m | tape m ] must fit it):
-//   arena[off - m - kc - 1] = frame stamp << 32 | m | kc << 16,   choice table at off - m - kc,   links at off - m
-// - only for children of at most FH_P2_L1_OPS ops and FH_P2_L1_CHOICES choices, the bounds of the launch that reads them (level
-// 1: mode 0, links == nullptr: a slot's parent qualifies when the stamp in front of its tape is this frame's and says its length
-// and choices; the forward kernel fh_tiles_v64 makes the same test and exports choices for those parents only).  A child of such a
-// parent never needs more registers than the parent (<= 64: the scan is optimal and the child's values are a subset with the same
-// or shorter lives) nor more kept ops than cap_kept = FH_P2_L1_OPS: nothing is left marked at that level.
+// (Handing the links down - a child tape written here carrying its own links for a linked prune of level 1 - was built and measured in
+// round 3: one wave per 32^3 child, 6 120 of them, 0.75 ms where the lockstep sweep of fh_tiles_v64 prunes a parent's children at once in
+// 0.26; taken out in round 5, DESIGN_HISTORY.md.  With root tiles of 32^3 the children of THIS kernel are the 32^3 tiles.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -50,10 +44,6 @@
 
 #define FH_P2_WPB 4                                             // level 0: waves per workgroup (one per SIMD: the sequential step is scalar code)
 #define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // ... workgroups per slot (the last one's spare waves idle)
-#define FH_P2_L1_WPB 4                                          // level 1
-#define FH_P2_L1_PER_SLOT (64 / FH_P2_L1_WPB)
-#define FH_P2_L1_OPS 1024u                                      // level 1: parents with links have at most this many ops ...
-#define FH_P2_L1_CHOICES 512u                                   // ... and choices (fh_tiles_v64's own bound)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
 #define FH_P2_MAX_KEPT 1280u                                    // (4 waves' areas + prospero's links = 152 KB of the CU's 160)
@@ -159,20 +149,18 @@ __device__ __forceinline__ void p2_scan_batch(uint32_t d, uint32_t& fr, uint32_t
 }
 }  // namespace fhp2
 
-// mode 2 (tape groups, level 0): slot = block * n_tgroups, choice words S->chwr (k_tscatter3d) with `cw_stride` words per slot, links /
-// ctab: the root tape's (device copies made with the tape).  mode 0 (level 1): slots[big] of `level` (big == 2: both lists, the
-// large one in the first `slots_cap` * per_slot workgroups), choice words S->chw[big] (16 words per slot in list 0, cw_stride
-// in list 1), links == nullptr: every parent's own, in front of its tape (see the head of this file).
-// cap_ops / cap_choices / cap_kept size the LDS areas (links, E, per kept op records).
+// Tape groups, level 0: slot = block * n_tgroups, choice words S->chwr (k_tscatter3d) with `cw_stride` words per slot, links / ctab:
+// the root tape's (device copies made with the tape).  cap_ops / cap_choices / cap_kept size the LDS areas (links, E, per kept op
+// records).  `flags` bit 1: profiled frames record the slowest child's shader clocks per phase.
 // One work item: the (up to) blockDim / 64 children `blk` % per_slot of slot `blk` / per_slot.
-__device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride, const uint2* __restrict__ links,
-                                        const uint2* __restrict__ ctab, uint32_t emit_links, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
+__device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
+                                        const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
                                         uint32_t blk, char* smem) {
     using namespace fhp2;
     const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the sequential step branches on is made wave-uniform explicitly)
     const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
     const uint32_t sidx = blk / per_slot;
-    const uint32_t G = mode == 2 ? rfl(S->n_tgroups) : 1u;
+    const uint32_t G = rfl(S->n_tgroups);
     if (sidx * G >= rfl(S->n_slots[big][level])) return;
     FhSlot& sl = S->slots[big][(size_t)sidx * G];
     if (sl.act == 0) return;
@@ -184,14 +172,6 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     }
     const uint32_t off = rfl(sl.tape.off), n = rfl(sl.tape.len), nch = rfl((uint32_t)sl.tape.n_choices);
     if (n > cap_ops || nch > cap_choices) return;                       // (left marked)
-    if (links == nullptr) {
-        // the parent's own links: stamped by the launch that wrote its tape
-        if (off < n + nch + 1u) return;
-        const uint64_t stamp = S->arena[off - n - nch - 1u];
-        if (stamp != (((uint64_t)S->frame_stamp << 32) | n | (nch << 16))) return;
-        links = (const uint2*)(S->arena + (off - n));
-        ctab = (const uint2*)(S->arena + (off - n - nch));
-    }
     const uint2* const ops = (const uint2*)(S->arena + off);
     uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lks[i] = links[i];
@@ -207,13 +187,13 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     __syncthreads();
     if (c >= 64 || rfl(sl.c_len[c]) != 0xFFFFFFFFu) return;             // not marked for the prune
 
-    const bool probe = S->want_stats != 0 && (emit_links & 2u) != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
+    const bool probe = S->want_stats != 0 && (flags & 2u) != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
     const uint64_t t_a = probe ? clock64() : 0;
     // ---- A: what every choice op's value is -------------------------------------------------------------------------------------
     // 64 ordinals at a time, in tape order: an operand's producer has a lower ordinal, so a pointer out of the batch lands on a
     // final entry, and pointers inside the batch are followed by six rounds of jumping between lanes.
     {
-        const uint32_t* const cws = mode == 2 ? S->chwr + (size_t)sidx * G * cw_stride * 64 : S->chw[big] + (size_t)sidx * cw_stride * 64;
+        const uint32_t* const cws = S->chwr + (size_t)sidx * G * cw_stride * 64;
         uint32_t* const cwl = (uint32_t*)comp;       // (the child's choice words, staged where the kept-op records go later: one load latency for all)
         for (uint32_t k = lane; k < (nch + 15) / 16; k += 64) cwl[k] = cws[(size_t)k * 64 + c];
         uint2 tn = lane < nch ? ctab[lane] : make_uint2(0, 0);
@@ -337,23 +317,6 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     // ---- B4: the child's ops, 64 at a time ----------------------------------------------------------------------------------------------
     const uint32_t end = rfl(sl.c_off[c]);        // one past the child's last op (arena index); the child's slot is [end - n, end)
     uint64_t* const dst = S->arena + (end - m);
-    // links of the child for the level below: ordinals of its kept choices by position (where the frees were: B3 is over)
-    uint16_t* const cidx = (uint16_t*)frees;
-    uint32_t kc = 0;
-    bool lk = (emit_links & 1u) != 0 && m <= FH_P2_L1_OPS;
-    if (lk) {
-        for (uint32_t base = 0; base < m; base += 64) {
-            const uint32_t pl = base + lane;
-            const bool ch = pl < m && ((comp[pl].y >> 16) & 8u) != 0;
-            const uint64_t bal = __ballot(ch);
-            if (pl < m) cidx[pl] = ch ? (uint16_t)(kc + (uint32_t)__popcll(bal & ((1ull << lane) - 1))) : (uint16_t)0xFFFFu;
-            kc += (uint32_t)__popcll(bal);
-        }
-        kc = rfl(kc);
-        lk = kc <= FH_P2_L1_CHOICES && 2u * m + kc + 1u <= n;
-    }
-    uint2* const dlk = (uint2*)(dst - m);
-    uint2* const dct = (uint2*)(dst - m - kc);
     uint32_t high = 0, kept = 0;
     for (uint32_t pl = lane; pl < m; pl += 64) {
         const uint2 cr = comp[pl];
@@ -367,14 +330,6 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
         dst[pl] = word;
         high = max(high, (fl & 16u) ? 0u : ro + 1u);
         kept += (fl >> 3) & 1u;
-        if (lk) {
-            const uint32_t kind = (fl & 4u) ? (uint32_t)FH_LK_NONE : ((lks[i].x >> 8) & 0xFFu);
-            const uint32_t qa = (fl & 1u) ? cidx[pa] : 0xFFFFu, qb = (fl & 2u) ? cidx[pb] : 0xFFFFu, own = cidx[pl];
-            const uint32_t fa = (fl & 1u) ? (qa != 0xFFFFu ? (FH_LK_CHOICE | qa) : pa) : 0xFFFFu;
-            const uint32_t fb = (fl & 2u) ? (qb != 0xFFFFu ? (FH_LK_CHOICE | qb) : pb) : 0xFFFFu;
-            dlk[pl] = make_uint2(((uint32_t)word & 0xFFu) | (kind << 8) | ((own != 0xFFFFu ? own : 0u) << 16), fa | (fb << 16));
-            if (own != 0xFFFFu) dct[own] = make_uint2(fa | (fb << 16), pl | (kind << 16));
-        }
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) { high = max(high, (uint32_t)__shfl_xor(high, dlt, 64)); kept += (uint32_t)__shfl_xor(kept, dlt, 64); }
@@ -384,29 +339,13 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
         atomicMax(&S->leaf_stat[6], (unsigned long long)(t_b3 - t_b2)); atomicMax(&S->leaf_stat[7], (unsigned long long)(t_e - t_b3));
     }
     if (lane == 0) {
-        if (lk) S->arena[end - 2u * m - kc - 1u] = ((uint64_t)S->frame_stamp << 32) | m | (kc << 16);
         sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = high | (kept << 16);
     }
 }
 
-// grid: mode 2 one workgroup per item; mode 0 (level 1) any number of workgroups - they stride over the items of the slots the
-// level really has (n_slots is the device's; an item whose children are not marked costs three loads).
-__global__ void __launch_bounds__(256) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t mode, uint32_t cw_stride,
-                                                const uint2* __restrict__ links, const uint2* __restrict__ ctab, uint32_t emit_links,
-                                                uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
+// grid: one workgroup per item (FH_P2_WPB children of one slot)
+__global__ void __launch_bounds__(256) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
+                                                const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // (emit_links bit 2: the waves of the root level's prune at issue priority 2 - one-wave dependent chains on SIMDs they share with the
-    // other streams' kernels in a pipelined frame; level 1's kernel takes 3, capi_render.hpp option chain_prio)
-    if (emit_links & 4u) __builtin_amdgcn_s_setprio(2);
-    emit_links &= 3u;
-    const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
-    const bool both = big == 2;
-    const uint32_t n1 = both ? fhp2::rfl(S->n_slots[1][level]) * per_slot : 0u;
-    const uint32_t total = both ? n1 + fhp2::rfl(S->n_slots[0][level]) * per_slot : gridDim.x;      // (one list: one workgroup per item)
-    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
-        __syncthreads();        // (the waves still reading the links of the item before)
-        const bool second = both && it >= n1;
-        p2_item(S, level, both ? (second ? 0u : 1u) : big, mode, second ? 16u : cw_stride, links, ctab, emit_links, cap_ops, cap_choices, cap_kept,
-                second ? it - n1 : it, smem);
-    }
+    p2_item(S, level, big, cw_stride, links, ctab, flags, cap_ops, cap_choices, cap_kept, blockIdx.x, smem);
 }

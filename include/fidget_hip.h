@@ -64,7 +64,7 @@ void fhip_cancel_reset(fhip_ctx* ctx);
  * the reference's knobs; these carry the back end's own: which kernels, how many slab contexts, the column-invariance short
  * cuts ...).  A context reads FHIP_<NAME> from the environment ONCE, when it is created; afterwards only this call changes
  * a switch - a render never consults the environment.  It waits for the context's frames in flight first.  Names and
- * defaults: FH_OPTION_LIST in fidget_amd/csrc/capi.hip; e.g. "no_column_inv", "slab_contexts",
+ * defaults: FH_OPTION_LIST in fidget_amd/csrc/capi_core.hpp; e.g. "no_column_inv", "frame_sets",
  * "arena_mb".  Unknown names (and the two that are fixed at creation) return FHIP_ERR_UNSUPPORTED. */
 fhip_status fhip_ctx_set_option(fhip_ctx* ctx, const char* name, int value);
 fhip_status fhip_ctx_get_option(const fhip_ctx* ctx, const char* name, int* value);

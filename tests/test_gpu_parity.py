@@ -241,12 +241,13 @@ def test_render3d_frames_in_flight():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"FHIP_FRAME_SETS": "2"}, {"FHIP_FRAME_SETS": "3", "FHIP_TAIL_ON_MAIN": "1"}, {"FHIP_FRAME_SETS": "5", "FHIP_TAIL_ON_MAIN": "0"},
-                                 {"FHIP_SIDE_ONLY_L1": "0", "FHIP_TAIL_ON_MAIN": "1"}, {"FHIP_CHAIN_PRIO": "1"}, {"FHIP_TILES_STREAM": "0"}, {"FHIP_NO_COLUMN_INV": "1"}])
+@pytest.mark.parametrize("env", [{"FHIP_FRAME_SETS": "2"}, {"FHIP_FRAME_SETS": "3", "FHIP_ROOT32_MAX": "0"}, {"FHIP_FRAME_SETS": "5", "FHIP_NO_ZREP": "1"},
+                                 {"FHIP_SLAB_LAYERS": "1"}, {"FHIP_SLAB_LAYERS": "2", "FHIP_NO_ZREP": "2"}, {"FHIP_FRAME_LANES": "0"}, {"FHIP_NO_COLUMN_INV": "1"}])
 def test_render3d_frames_in_flight_under_the_pipeline_options(env, monkeypatch):
-    """The frame pipeline's switches (buffer sets 2..5, where the slab's small kernels run, what the side stream carries, issue priority,
-    where the tile chains run, the column-invariance short cuts) decide WHEN and WHERE a frame's kernels run, never what they compute: a
-    queue of frames of different shapes, sizes and cameras gives the oracle's images under every setting (round 4 changed three defaults)."""
+    """The frame pipeline's switches (buffer sets 2..5, z-slab thickness, the library's tile choice, sharing of tiles along z, frame lanes,
+    the column-invariance short cuts) decide WHEN and WHERE a frame's kernels run, never what they compute: a queue of frames of different
+    shapes, sizes and cameras gives the oracle's images under every setting.  (Round 5 fixed the switches of rounds 2-4 whose measurement
+    was settled - where the slab's small kernels run, what the side stream carries, issue priority ... - at their measured values.)"""
     import torch
     for k, v in env.items():
         monkeypatch.setenv(k, v)          # (a context reads the environment once, when it is created)
@@ -374,7 +375,7 @@ def test_frame_lanes_that_cannot_be_had_fall_back_to_the_stage_pipeline():
 
 @pytest.mark.gpu
 def test_render3d_lanes_for_parts_of_a_frame():
-    """Shards and blocks - what a rank of a multi-GPU job renders - queued back to back take the lanes like whole frames (option lanes_parts):
+    """Shards and blocks - what a rank of a multi-GPU job renders - queued back to back take the lanes like whole frames :
     every part, whichever arrangement its frames fell to, equals the part rendered alone by a context without lanes, and the parts of a
     split still merge to the oracle's frame."""
     import torch
@@ -622,7 +623,7 @@ def test_assembly_tile_stage_of_transcendental_tapes(name, size):
 def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
     """Round 5: when the root level has few children the library renders with root tiles of 32^3 straight above the leaves (the linked
     prune of the ROOT tape per 32^3 tile, no level 1), and a root tape that reads nothing varying along a pixel column is evaluated for
-    one layer of root tiles per z-slab (capi_render.hpp root32_max, root_zrep).  Neither may change a pixel: the oracle's image under
+    one layer of root tiles per z-slab (capi_render.hpp root32_max, root_zrep; option no_zrep 2 / 1: not at the root / nowhere).  Neither may change a pixel: the oracle's image under
     every combination of the two - and with the column short cuts off (a tape with z everywhere), and under cameras that move x and y
     along a column (no invariance anywhere: rotated, perspective), and as the eight octants of the frame."""
     import torch
@@ -637,16 +638,16 @@ def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
         m = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.3, 1]], np.float32)
     ref = O.render3d(o, size, world_to_model=m)[0]
     ref_words = np.concatenate([ref["normal"].view(np.uint32), ref["depth"][..., None]], axis=2)
-    for root32_max, no_root_zrep, no_inv in ((4096, 0, 0), (0, 0, 0), (4096, 1, 0), (0, 1, 0), (4096, 0, 1), (1 << 20, 0, 0), (1 << 20, 0, 1)):
+    for root32_max, no_zrep, no_inv in ((4096, 0, 0), (0, 0, 0), (4096, 2, 0), (0, 2, 0), (4096, 1, 0), (4096, 0, 1), (1 << 20, 0, 0), (1 << 20, 0, 1)):
         if size == 1024 and root32_max == (1 << 20) and no_inv:
             continue        # (32 768 children through the scalar sweep: right, and slow)
-        with hip.options(root32_max=root32_max, no_root_zrep=no_root_zrep, no_column_inv=no_inv):
+        with hip.options(root32_max=root32_max, no_zrep=no_zrep, no_column_inv=no_inv):
             out = torch.zeros((size, size, 4), dtype=torch.int32, device="cuda")
             F.render3d(p, size, world_to_model=m, out=out)
             hip.sync()
             got = out.cpu().numpy().view(np.uint32)
-            assert (got[..., 3] == ref_words[..., 3]).all(), (root32_max, no_root_zrep, no_inv, int((got[..., 3] != ref_words[..., 3]).sum()))
-            assert same_bits_f32(got[..., :3].view(np.float32), ref_words[..., :3].view(np.float32)), (root32_max, no_root_zrep, no_inv)
+            assert (got[..., 3] == ref_words[..., 3]).all(), (root32_max, no_zrep, no_inv, int((got[..., 3] != ref_words[..., 3]).sum()))
+            assert same_bits_f32(got[..., :3].view(np.float32), ref_words[..., :3].view(np.float32)), (root32_max, no_zrep, no_inv)
             if camera is None and size in (512, 1024):       # the frame as eight octants: each block's own tile choice, merged front to back
                 img = None
                 for ix in range(2):
@@ -659,5 +660,5 @@ def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
                         F.merge_depth(parts[0], parts[1], size, hip=hip)
                         img = parts[0] if img is None else img + parts[0]
                 hip.sync()
-                assert torch.equal(img, out), (root32_max, no_root_zrep, no_inv)
+                assert torch.equal(img, out), (root32_max, no_zrep, no_inv)
     del p, hip

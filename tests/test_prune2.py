@@ -60,21 +60,26 @@ def test_links_of_a_tape_name_the_producer_of_every_operand(name):
     assert got is not None and (got == np.array(lk, np.int64)).all()
 
 
-def _children(hip, shape, size):
-    img = F.render3d(shape, size)[0]
-    g, _ = hip.groups(0, 1)
+def _children(hip, shape, size, tile):
+    """the child tapes the root level's prune left: 128^3 root tiles -> the queue of level 1; root tiles of 32^3 (one coarse level) -> the
+    parents parked per z-slab"""
+    img = F.render3d(shape, size, tile_sizes=[128, 32, 8] if tile == 128 else [32, 8])[0]
     tapes = {}
-    for e in g:
-        tapes[(int(e["x"]), int(e["y"]), int(e["z"]))] = (hip.arena_ops(int(e["off"]), int(e["len"])), int(e["regs"]), int(e["choices"]))
+    lists = [hip.groups(0, 1)[0]] if tile == 128 else [hip.groups(1, k)[0] for k in range(8)]
+    for g in lists:
+        for e in g:
+            tapes[(int(e["x"]), int(e["y"]), int(e["z"]))] = (hip.arena_ops(int(e["off"]), int(e["len"])), int(e["regs"]), int(e["choices"]))
     return img, tapes
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,size", [("prospero.vm", 512), ("prospero.vm", 1024), ("colonnade.vm", 512)])
-def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
+@pytest.mark.parametrize("name,size,tile", [("prospero.vm", 512, 128), ("prospero.vm", 1024, 128), ("colonnade.vm", 512, 128), ("prospero.vm", 512, 32),
+                                            ("prospero.vm", 1024, 32)])
+def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size, tile):
     """simplify's contract, checked directly: every child tape the root level's prune wrote, evaluated (numpy f32, the emulator
-    tests' restatement of the device ops) at random points of its 128^3 tile, gives the root tape's value bit for bit; the frame is
-    the scalar sweep's frame; and the linked prune really ran and pruned."""
+    tests' restatement of the device ops) at random points of its tile - 128^3, or 32^3 when the root level stands straight above the
+    leaves (round 5) - gives the root tape's value bit for bit; the frame is the scalar sweep's frame; and the linked prune really ran
+    and pruned."""
     import emu_util as U
     hip = F.HipContext(0)
     s = F.Shape.from_vm(model_path(name), hip=hip)
@@ -82,9 +87,9 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
     if F.lib().fhip_tape_term_plan(s._h, F._p(info)) == 0:
         pytest.skip("this tape is not split at its root (no term plan): the root level takes the other path")
     with hip.options(prune2=0):
-        img_a, a = _children(hip, s, size)           # the scalar sweep alone
+        img_a, a = _children(hip, s, size, tile)           # the scalar sweep alone
     with hip.options(prune2=1):
-        img_b, b = _children(hip, s, size)
+        img_b, b = _children(hip, s, size, tile)
     assert (img_a["depth"] == img_b["depth"]).all() and (img_a["normal"].view(np.uint32) == img_b["normal"].view(np.uint32)).all()
     assert len(b) > 8 and a.keys() == b.keys()
     root = s.words()
@@ -107,7 +112,7 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
             shorter += len(tape) < len(a[k][0])
             assert int((tape & np.uint64(0xFF)).tolist().count(2)) == 0      # no COPY_REG
         m = 256
-        vox = np.stack([np.float64(k[ax]) + rng.random(m) * 128.0 for ax in range(3)] + [np.ones(m)])      # points of the tile, in voxels
+        vox = np.stack([np.float64(k[ax]) + rng.random(m) * float(tile) for ax in range(3)] + [np.ones(m)])      # points of the tile, in voxels
         pts = (mat @ vox)[:3].astype(np.float32)
         inputs = {ik[ax]: pts[ax] for ax in range(3) if ik[ax] >= 0}
         want = U.ref_f32(root, inputs, m)
@@ -117,62 +122,3 @@ def test_linked_prune_children_compute_the_root_tape_on_their_tile(name, size):
     assert fallback < len(b) or size < 1024
 
 
-def _parked(hip, shape, size):
-    """the 32^3 tiles level 1 left for the slabs: corner -> (tape, registers, choices)"""
-    hip.profile(True)
-    try:
-        img = F.render3d(shape, size)[0]
-        launches = hip.profile_read_kernels().get("k_prune2_l1", (0.0, 0))[1]
-    finally:
-        hip.profile(False)
-    tiles = {}
-    for k in range((size + 127) // 128):
-        g, _ = hip.groups(1, k)
-        for e in g:
-            tiles[(int(e["x"]), int(e["y"]), int(e["z"]))] = (int(e["off"]), int(e["len"]), int(e["regs"]), int(e["choices"]))
-    return img, tiles, launches
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,size", [("prospero.vm", 1024), ("prospero.vm", 512), ("colonnade.vm", 512)])
-def test_linked_prune_of_level_1_on_the_links_level_0_leaves(name, size):
-    """Level 1 (128^3 parents, 32^3 children) through k_prune2 on the links the level-0 launch wrote in front of every child tape
-    (option prune2_l1): the tapes of the 32^3 tiles compute the root tape's value on their tile, bit for bit; they are never
-    longer than the lockstep sweep's (fh_tiles_v64) and hold no register copies; same frame."""
-    import emu_util as U
-    hip = F.HipContext(0)
-    s = F.Shape.from_vm(model_path(name), hip=hip)
-    info = np.zeros(4, np.uint32)
-    if F.lib().fhip_tape_term_plan(s._h, F._p(info)) == 0:
-        pytest.skip("this tape is not split at its root (no term plan): the root level takes the other path")
-    with hip.options(prune2_l1=0):
-        img_a, a, la = _parked(hip, s, size)
-        ta = {k: hip.arena_ops(v[0], v[1]) for k, v in list(a.items())[:: max(1, len(a) // 60)]}
-    with hip.options(prune2_l1=1):
-        img_b, b, lb = _parked(hip, s, size)
-        tb = {k: hip.arena_ops(b[k][0], b[k][1]) for k in ta}
-    assert la == 0 and lb == 1
-    assert (img_a["depth"] == img_b["depth"]).all() and (img_a["normal"].view(np.uint32) == img_b["normal"].view(np.uint32)).all()
-    assert a.keys() == b.keys() and len(b) > 8
-    root = s.words()
-    ik = [s.axis_index(ax) for ax in range(3)]
-    mat = np.zeros(16, np.float32)
-    F.lib().fhip_screen_to_world(F._p(np.array([size, size, size], np.uint32)), 3, F._p(mat))
-    mat = mat.reshape(4, 4).astype(np.float64)
-    rng = np.random.default_rng(9)
-    shorter = linked = 0
-    for k in sorted(tb):
-        tape, ref = tb[k], ta[k]
-        assert int((((tape.astype(np.uint64) >> np.uint64(8)) & np.uint64(0xFFF)).max())) < b[k][2]
-        if size >= 1024:
-            assert len(tape) <= len(ref)
-        shorter += len(tape) < len(ref)
-        linked += int((tape & np.uint64(0xFF)).tolist().count(2)) == 0
-        m = 192
-        vox = np.stack([np.float64(k[ax]) + rng.random(m) * 32.0 for ax in range(3)] + [np.ones(m)])
-        pts = (mat @ vox)[:3].astype(np.float32)
-        inputs = {ik[ax]: pts[ax] for ax in range(3) if ik[ax] >= 0}
-        want = U.ref_f32(root, inputs, m)
-        got = U.ref_f32(tape, inputs, m)
-        assert (want[0].view(np.uint32) == got[0].view(np.uint32)).all(), f"tile {k}: values differ from the root tape's"
-    print("tiles sampled", len(tb), "shorter than the lockstep sweep's", shorter, "without register copies", linked)
