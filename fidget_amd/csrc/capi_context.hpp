@@ -93,6 +93,12 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     if (!c->stream3 && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     if (c->sticky.ensure(256) != hipSuccess || hipMemset(c->sticky.p, 0, 256) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    {
+        void* hf = nullptr;
+        if (hipHostMalloc(&hf, 64, hipHostMallocDefault) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+        memset(hf, 0, 64);
+        c->host_flags = (volatile uint32_t*)hf;
+    }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);
     for (int i = 0; i < FH_MAX_SLABS; i++) {
         (void)hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming);
@@ -129,6 +135,7 @@ void fhip_ctx_destroy(fhip_ctx* c) {
     if (c->ev_l1) (void)hipEventDestroy(c->ev_l1);
     for (auto& sg : c->staging) { if (sg.p) (void)hipHostFree(sg.p); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     c->mesh_leaves.release();
+    if (c->host_flags) (void)hipHostFree((void*)c->host_flags);
     if (c->mesh_pinned) (void)hipHostFree(c->mesh_pinned);
     mesh_cache_release(c->mesh_octree_cache);
     free(c->mesh_first);
@@ -177,8 +184,22 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
     }
     return st;
 }
-void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
-void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
+// (the frame lanes are contexts of their own that copy the flag when a frame is handed to them: a cancel from another thread while that
+// frame is being queued reaches them here, so that their per-level checks see it mid-frame as the parent's do)
+void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); for (fhip_ctx* L : c->lanes) if (L) L->cancelled.store(1); }
+void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); for (fhip_ctx* L : c->lanes) if (L) L->cancelled.store(0); }
+// Device and pinned memory the context keeps between calls for speed alone - the mesher's leaf records (17 GB after one depth-10 build),
+// its landing area and host-side caches, the frame lanes (child contexts with buffers of their own) - given back.  The next call that
+// wants them makes them again.  Waits for the context's work first.
+fhip_status fhip_ctx_trim(fhip_ctx* c) {
+    if (!c) return FHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipDeviceSynchronize());
+    lanes_release(c);
+    c->mesh_leaves.release();
+    if (c->mesh_pinned) { (void)hipHostFree(c->mesh_pinned); c->mesh_pinned = nullptr; c->mesh_pinned_cap = 0; }
+    return FHIP_OK;
+}
 // Behaviour switches (FH_OPTION_LIST above).  Waits for the frames in flight first: a switch never changes under a frame.
 fhip_status fhip_ctx_set_option(fhip_ctx* c, const char* name, int value) {
     if (!c || !name) return FHIP_ERR_UNSUPPORTED;

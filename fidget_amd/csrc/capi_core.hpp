@@ -157,7 +157,14 @@ struct fhip_ctx : FrameBufs {
     uint32_t* mesh_first = nullptr;
     size_t mesh_first_cap = 0;
     uint32_t staging_next = 0;
-    size_t arena_bytes = (size_t)4 << 30;  // tape arena (FHIP_ARENA_MB overrides)
+    // Tape arena, per buffer set: starts at FH_ARENA_START_MB (prospero.vm at 1024^3 peaks at 79 MB per z-slab context) and is grown
+    // twofold - up to option arena_mb, default 4 GiB - when a frame ran out: the frame itself is still right (children keep their parent's
+    // tape, tests/test_gpu_parity.py test_render3d_survives_a_full_tape_arena), its last kernel says so in `host_flags` - a pinned word the
+    // device writes and the host reads without waiting for anything - and the next render call grows the arena first.  Until round 4 every
+    // set held the full 4 GiB: 18.6 GB per context for a peak use of 0.1.
+    size_t arena_bytes = (size_t)256 << 20, arena_cap_bytes = (size_t)4 << 30;
+    int last_hip_error = 0;                     // the HIP error code behind the last FHIP_ERR_HIP (HIP_TRY)
+    volatile uint32_t* host_flags = nullptr;    // pinned: [0] a frame's arena overflowed, [1] peak arena ops of any frame
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> asm_events;   // ... and per assembly kernel launch
@@ -193,6 +200,7 @@ struct fhip_ctx : FrameBufs {
 };
 
 // The cached forms of some options (what the rest of the driver reads)
+#define FH_ARENA_START_MB 256
 static void apply_options(fhip_ctx* c) {
     c->use_asm = c->opt.no_asm == 0;
     c->use_split = c->opt.no_split == 0;
@@ -200,7 +208,8 @@ static void apply_options(fhip_ctx* c) {
     c->use_pipeline = c->opt.no_pipeline == 0;
     c->frame_pipeline = true;
     c->slab_contexts = 4;
-    c->arena_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
+    c->arena_cap_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
+    c->arena_bytes = std::min(c->arena_cap_bytes, std::max(c->arena_bytes, (size_t)FH_ARENA_START_MB << 20));
     c->extra_sets = (uint32_t)std::min(FH_EXTRA_SETS, std::max(1, c->opt.frame_sets - 1));
 }
 
@@ -213,8 +222,10 @@ static fhip_status fail(fhip_ctx* ctx, fhip_status s, const std::string& msg) {
 #define HIP_TRY(ctx, call)                                                                                       \
     do {                                                                                                         \
         hipError_t e_ = (call);                                                                                  \
-        if (e_ != hipSuccess)                                                                                    \
+        if (e_ != hipSuccess) {                                                                                  \
+            if (ctx) (ctx)->last_hip_error = (int)e_;                                                            \
             return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+        }                                                                                                        \
     } while (0)
 
 template <class F>

@@ -128,6 +128,21 @@ static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P
         if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { R.root_invariant = false; break; }
 }
 
+// A frame before this one ran out of tape arena (k_finish3d / k_latch_arena said so in the pinned host word): wait for what is in flight
+// and let the sets come back twice as large, up to option arena_mb.  The frames that overflowed were right (their tiles kept their
+// parents' tapes), only slower.
+static fhip_status grow_arena_if_asked(fhip_ctx* ctx, size_t tape_ops) {
+    const size_t need = ((tape_ops + 64) * 8 + 4096) * 4;       // (root tape + its groups, with room to prune into)
+    bool grow = ctx->host_flags && ctx->host_flags[0] != 0 && ctx->arena_bytes < ctx->arena_cap_bytes;
+    size_t want = grow ? ctx->arena_bytes * 2 : ctx->arena_bytes;
+    if (want < need) { want = need; grow = ctx->arena_bytes < std::min(need, ctx->arena_cap_bytes); }
+    if (!grow) return FHIP_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());       // (every stream of the context, its lanes included: a set's arena is about to be replaced)
+    ctx->host_flags[0] = 0;
+    ctx->arena_bytes = std::min(ctx->arena_cap_bytes, want);
+    return FHIP_OK;
+}
+
 static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, const std::vector<uint32_t>& ts,
                            const PartSpec& part, RenderSetup& R) {
     const uint32_t shard = part.shard, n_shards = part.n_shards;
@@ -283,6 +298,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
     R.n_footprints = (uint32_t)(fw * fhh);
 
+    { const fhip_status gs_ = grow_arena_if_asked(ctx, t.ops.size()); if (gs_) return gs_; }
     HIP_TRY(ctx, ctx->state.ensure(4 * sizeof(FhRenderState)));
     { void* const before = ctx->arena.p; HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes)); if (ctx->arena.p != before) ctx->resident_serial = 0; }
     for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
@@ -746,6 +762,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             if (R.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
             else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
         });
+    if (ctx->host_flags) hipLaunchKernelGGL(k_latch_arena, dim3(1), dim3(1), 0, ctx->stream, dS, 1u, ctx->host_flags);    // (an arena that ran out: grown before the next frame)
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->stream));     // (a later pipelined 3D frame that takes this buffer set waits for it)
     ctx->ev_done_valid = true;
@@ -1052,7 +1069,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
     }
     if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
-    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p); });
+    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p, ctx->host_flags); });
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;
@@ -1138,8 +1155,21 @@ static fhip_status run_on_lane_(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes,
 // frame under the stage pipeline instead, and the context gives its lanes up for good; option lanes_fail provokes it, for the test)
 static const fhip_status FHIP_LANE_FALLBACK = (fhip_status)1000;
 static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, void* out, const std::function<fhip_status(fhip_ctx*, void*)>& render) {
+    ctx->last_hip_error = 0;
+    for (fhip_ctx* L : ctx->lanes) if (L) L->last_hip_error = 0;
     const fhip_status st = run_on_lane_(ctx, max_lanes, bytes, out, render);
     if (st != FHIP_ERR_HIP) return st;
+    // Only what says "the lanes' resources cannot be had" sends the frame back to the stage pipeline: out of memory (a child context's
+    // buffers, its image), a child context or stream that could not be made, the provoked failure of the test.  Any other HIP error - a
+    // fault inside the lane's render - is the caller's to see, with the lane's message.
+    bool resources = ctx->opt.lanes_fail != 0 || ctx->last_hip_error == (int)hipErrorOutOfMemory || ctx->err.rfind("frame lanes:", 0) == 0;
+    for (fhip_ctx* L : ctx->lanes) if (L && L->last_hip_error == (int)hipErrorOutOfMemory) resources = true;
+    if (!resources) return st;
+    if (ctx->mesh_leaves.cap) {       // (a mesh build's leaf records - gigabytes kept for the next build - may be what the lanes had no room beside)
+        (void)hipDeviceSynchronize();
+        ctx->mesh_leaves.release();
+    }
+    fprintf(stderr, "fidget-hip: frame lanes given up for this context (%s); frames keep to the stage pipeline\n", ctx->err.c_str());
     (void)hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);      // (nothing of the lanes may be pending on the caller's stream when they go)
     ctx->opt.frame_lanes = 0;

@@ -1513,13 +1513,23 @@ __global__ void __launch_bounds__(256) k_slab_begin2(FhRenderState* S, uint32_t 
 // Final image (voxel.rs:524-552): saturated columns become (D, [0,0,1])
 // ... and the frame's queue-overflow flags (one per slab context) are latched into the context's sticky word: with frames
 // pipelined over two buffer sets, a set is re-used by the frame after next before the host has looked at its flags.
-__global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out, uint32_t n_ctx, uint32_t* sticky) {
+// The frame's arena state goes to a pinned host word the same way (capi_core.hpp host_flags: [0] the arena ran out somewhere in the frame,
+// [1] the most ops any slab context had in use): the next render call reads it without waiting and grows the arena.
+FH_DEV void latch_arena(const FhRenderState* S, uint32_t n_ctx, volatile uint32_t* host_flags) {
+    uint32_t a = 0, peak = 0;
+    for (uint32_t k = 0; k < n_ctx; k++) { a |= S[k].arena_overflow; peak = max(peak, S[k].arena_head); }
+    if (a) host_flags[0] = 1u;
+    if (peak > host_flags[1]) host_flags[1] = peak;
+}
+__global__ void k_latch_arena(const FhRenderState* S, uint32_t n_ctx, volatile uint32_t* host_flags) { latch_arena(S, n_ctx, host_flags); }
+__global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out, uint32_t n_ctx, uint32_t* sticky, volatile uint32_t* host_flags) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const size_t n = (size_t)P.width * P.height;
     if (blockIdx.x == 0 && threadIdx.x == 0 && sticky) {
         uint32_t q = 0;
         for (uint32_t k = 0; k < n_ctx; k++) q |= S[k].queue_overflow;
         if (q) atomicOr(sticky, 1u);
+        if (host_flags) latch_arena(S, n_ctx, host_flags);
     }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t d = (uint32_t)(S->zbuf[i] >> 32);

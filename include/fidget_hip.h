@@ -46,6 +46,10 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out);
 void fhip_ctx_destroy(fhip_ctx* ctx);
 const char* fhip_last_error(const fhip_ctx* ctx);
 fhip_status fhip_ctx_sync(fhip_ctx* ctx);
+/* Gives back the device and pinned memory a context keeps between calls for speed alone: the mesher's leaf records (17 GB after a
+ * depth-10 build), its landing area, the frame lanes (child contexts with buffers of their own - up to four, each a context's worth of
+ * buffers: option frame_lanes).  Waits for the context's work; whatever is needed again is made again by the call that needs it. */
+fhip_status fhip_ctx_trim(fhip_ctx* ctx);
 /* The device evaluates sin cos tan asin acos atan atan2 exp ln with the routines of glibc 2.35's x86-64 libm (its FMA variants)
  * restated operation by operation (fidget_amd/csrc/trans_libm.hpp) - the libm the reference's f32 methods call on the deployment
  * image, whose values its own bulk test demands bit for bit (fidget-core/src/eval/test/float_slice.rs:404-412).  On a host with

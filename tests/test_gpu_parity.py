@@ -662,3 +662,36 @@ def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
                 hip.sync()
                 assert torch.equal(img, out), (root32_max, no_zrep, no_inv)
     del p, hip
+
+
+def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
+    """Round 5: a buffer set's tape arena starts at 256 MB and grows when a frame ran out (the frame is still right); until round 4 every set
+    held 4 GiB - 18.6 GB per context for a peak use of 0.1.  A context that has rendered the headline frame a few times holds under 3 GB;
+    fhip_ctx_trim gives the frame lanes and the mesher's leaf records back; a small arena cap still gives the oracle's image."""
+    import torch
+    free0 = torch.cuda.mem_get_info()[0]
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("frame_lanes", 0)
+    p = F.Shape.from_vm(model_path("prospero.vm"), hip=hip)
+    out = torch.zeros((1024, 1024, 4), dtype=torch.int32, device="cuda")
+    for no_inv, bound in ((0, 3.0), (1, 6.5)):        # (GiB: four buffer sets of 0.33 GB + the arena: 256 MB, 1 GB when every tape has z - 65 M ops in flight per set)
+        with hip.options(no_column_inv=no_inv):
+            for _ in range(16):
+                F.render3d(p, 1024, out=out)
+            hip.sync()
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert used < bound * 2 ** 30, (no_inv, used)
+    ref = O.render3d(O.Shape.from_vm(model_path("prospero.vm")), 1024)[0]
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got[..., 3] == ref["depth"]).all() and same_bits_f32(got[..., :3].view(np.float32), ref["normal"])
+    hip.set_option("frame_lanes", 4)
+    small = torch.zeros((256, 256, 4), dtype=torch.int32, device="cuda")
+    b = F.Shape.from_vm(model_path("bear.vm"), hip=hip)
+    for _ in range(40):
+        F.render3d(b, 256, out=small)          # (a transcendental tape's queued frames take the lanes: child contexts)
+    hip.sync()
+    with_lanes = free0 - torch.cuda.mem_get_info()[0]
+    hip.trim()
+    after = free0 - torch.cuda.mem_get_info()[0]
+    assert after <= with_lanes and (F.lib().fhip_debug_lane_frames(hip._h) == 0 or after < with_lanes)
+    del p, b, hip

@@ -1,5 +1,3 @@
-for e in "FHIP_LANES_TUNE=0" ""; do
-  echo "== $e"; env $e python bench.py --no-cpu --no-general --steps 200 2>/dev/null | python -c "
+python bench.py --no-cpu --steps 200 2>/dev/null | python -c "
 import json,sys
-r=json.loads(sys.stdin.read()); print(r['ms_per_step'], r['ms_per_step_median'], r['frame_latency_ms'], r['device_bytes'])"
-done
+r=json.loads(sys.stdin.read()); print('default', r['ms_per_step'], r['ms_per_step_median'], r['frame_latency_ms'], 'general', r['config']['general_path'], 'device_bytes', r['device_bytes'])"
