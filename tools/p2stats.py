@@ -12,7 +12,6 @@ if len(sys.argv) > 2:
     hip.set_option("root32_max", int(sys.argv[2]))
 shape = F.Shape.from_vm(os.path.join(ROOT, "models", "prospero.vm"), hip=hip)
 out = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
-hip.set_option("prune2_probe_level", 0)
 for _ in range(2):
     F.render3d(shape, n, out=out); hip.sync()
 print(n, "phase clocks max (A, B1, B2, B3+B4):", hip.leaf_stats()["prune2_phase_clocks_max"], flush=True)
