@@ -736,8 +736,35 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     mat_product(cfg->world_to_model ? cfg->world_to_model : ident, s2w, 3, m3);
     const float m4[16] = {m3[0], m3[1], 0, m3[2], m3[3], m3[4], 0, m3[5], 0, 0, 1, 0, m3[6], m3[7], 0, m3[8]};
     memcpy(P.mat, m4, sizeof(m4));
-    const std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
-                                                     : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height));
+    std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
+                                               : trim_tiles(HIP_TILES_2D, 2, std::max(cfg->width, cfg->height));
+    // A 2D fill says at which level of the caller's list it was decided (pixel.rs:225-229), so the list is part of the result and is kept -
+    // but a step of the list whose fan-out exceeds the 64 lanes of a wavefront (128 -> 8: 256 children) is taken in two: a level in between
+    // that the caller does not see.  A tile decided there is what its children of the caller's next level would ALL have been decided as
+    // (interval arithmetic is inclusion monotone), so its fill carries THEIR level; an undecided one hands them a tape pruned once more,
+    // which changes no value.  The image is the one the caller's list gives, fill tags included.
+    std::vector<uint32_t> tags;
+    {
+        std::vector<uint32_t> out;
+        for (size_t i = 0; i < ts.size(); i++) {
+            if (i) {
+                uint32_t a = ts[i - 1];
+                const uint32_t b = ts[i];
+                if (a <= b || a % b) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad tile size list");
+                while (a / b > 8) {       // the largest tile below `a` that takes at most 8 x 8 of `a` and is made of whole `b`s
+                    uint32_t c = 0;
+                    for (uint32_t k = 8; k >= 2 && !c; k--) if (a % k == 0 && (a / k) % b == 0 && a / k > b) c = a / k;
+                    if (!c) break;        // (no such divisor: left to prepare(), which refuses the fan-out)
+                    out.push_back(c); tags.push_back((uint32_t)i);
+                    a = c;
+                }
+            }
+            out.push_back(ts[i]); tags.push_back((uint32_t)i);
+        }
+        if (out.size() > FH_MAX_LEVELS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "1..8 tile levels supported");
+        ts = out;
+    }
+    for (size_t i = 0; i < FH_MAX_LEVELS; i++) P.tag[i] = i < tags.size() ? tags[i] : (uint32_t)i;
     st = prepare(ctx, tape, false, ts, PartSpec{}, R);
     if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
@@ -791,6 +818,21 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     column_setup(ctx, tape, P, R);
     std::vector<uint32_t> ts = cfg->tile_sizes ? trim_tiles(cfg->tile_sizes, cfg->n_tile_sizes, std::max(cfg->width, cfg->height))
                                                : hip_tiles_3d(std::max(cfg->width, cfg->height));
+    bool own_tiles = !cfg->tile_sizes;
+    if (cfg->tile_sizes) {
+        // Any list the reference accepts (TileSizes::new, fidget-core/src/render/mod.rs:181-251: descending, each a multiple of the next;
+        // fidget-jit's own hint is [64, 16, 8], a caller's [64, 16, 4] is valid there) is accepted here: what the device's kernels cannot
+        // take as given - leaves other than 8^3 (one 8 x 8 footprint per wavefront), a fan-out above 64 children (one per lane) - is
+        // rendered with the library's list instead.  A 3D image does not depend on the tile sizes, so the caller
+        // cannot tell, except by the time; fhip_render_counters out[7] counts such frames.
+        bool valid = cfg->n_tile_sizes >= 1 && cfg->tile_sizes[cfg->n_tile_sizes - 1] >= 1, native = valid;
+        for (uint32_t i = 1; i < cfg->n_tile_sizes && valid; i++)
+            valid = cfg->tile_sizes[i - 1] > cfg->tile_sizes[i] && cfg->tile_sizes[i] > 0 && cfg->tile_sizes[i - 1] % cfg->tile_sizes[i] == 0;
+        if (!valid) return fail(ctx, FHIP_ERR_UNSUPPORTED, "bad tile size list");
+        native = ts.back() == 8 && ts.size() <= FH_MAX_LEVELS;
+        for (size_t i = 1; i < ts.size() && native; i++) { const uint32_t n = ts[i - 1] / ts[i]; native = n * n * n <= 64; }
+        if (!native) { ts = hip_tiles_3d(std::max(cfg->width, cfg->height)); own_tiles = true; ctx->substituted_tiles++; }
+    }
     // Few tiles, long tape (a small image, a part of a frame on one rank of several, a model without z): root tiles of 32^3 straight
     // above the leaves.  With 128^3 root tiles such a frame is a handful of one-wave chains over tapes that a 128^3 tile barely prunes
     // (prospero.vm at 512^3: a root tile keeps up to 1 795 of 6 363 ops - beyond the linked prune's and fh_tiles_v64's limits, so the
@@ -801,7 +843,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // tile sizes, so this is the library's choice whenever the caller gave none: taken while the root level has at
     // most `root32_max` children - counting one layer per z-slab when the root tape reads nothing that changes along a pixel column
     // (root_zrep, prepare) - and the tape is one the groups + linked prune path takes.
-    if (!cfg->tile_sizes && ctx->opt.root32_max > 0 && ts.size() == 3 && ts[0] == 128 && ctx->use_split && ctx->use_asm &&
+    if (own_tiles && ctx->opt.root32_max > 0 && ts.size() == 3 && ts[0] == 128 && ctx->use_split && ctx->use_asm &&
         !tape->tgroups.empty() && !ctx->opt.no_tape_groups && ctx->opt.prune2 && tape_asm_ok(tape->t) &&
         tape->t.ops.size() <= FH_P2_MAX_OPS && tape->t.n_choices <= FH_P2_MAX_CHOICES) {
         const uint64_t cols = (uint64_t)((P.width + 31) / 32) * ((P.height + 31) / 32) / std::max<uint32_t>(1, part.n_shards * part.nx * part.ny);

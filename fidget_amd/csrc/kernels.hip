@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                     }
                 } else {
                     const bool inside = (fullm >> c) & 1;
-                    const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (inside ? 1u : 0u) | (0xF6u << 9));
+                    const float f = u2f(0x7FC00000u | (P.tag[level] << 1) | (inside ? 1u : 0u) | (0xF6u << 9));
                     for (uint32_t p = lane; p < T * T; p += WAVE) {
                         const uint32_t x = ccx + (p % T), y = ccy + (p / T);
                         if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;
@@ -948,7 +948,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                 }
             } else {
                 const bool inside = (fullm >> c) & 1;
-                const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (inside ? 1u : 0u) | (0xF6u << 9));   // pixel.rs:225-229
+                const float f = u2f(0x7FC00000u | (P.tag[level] << 1) | (inside ? 1u : 0u) | (0xF6u << 9));   // pixel.rs:225-229
                 for (uint32_t p = lane; p < T * T; p += WAVE) {
                     const uint32_t x = ccx + (p % T), y = ccy + (p / T);
                     if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;
@@ -1035,7 +1035,7 @@ __global__ void __launch_bounds__(256) k_tfill2d(FhRenderState* S, int level) {
     const bool full = hi < 0.0f, empty = !full && lo > 0.0f;
     if (!full && !empty) return;
     const uint32_t T = P.tiles[level], cx = sl.corner[0][c], cy = sl.corner[1][c];
-    const float f = u2f(0x7FC00000u | ((uint32_t)level << 1) | (full ? 1u : 0u) | (0xF6u << 9));
+    const float f = u2f(0x7FC00000u | (P.tag[level] << 1) | (full ? 1u : 0u) | (0xF6u << 9));
     for (uint32_t p = threadIdx.x; p < T * T; p += blockDim.x) {
         const uint32_t x = cx + (p % T), y = cy + (p / T);
         if (x < P.width && y < P.height) S->image2d[(size_t)y * P.width + x] = f;

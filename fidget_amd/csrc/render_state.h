@@ -77,6 +77,8 @@ struct FhRender {
     uint32_t max_regs, max_choices;  // of the root tape: bounds for every tape of the frame
     uint32_t in_kind[FH_MAX_INPUTS]; // per input slot: 0 x, 1 y, 2 z, 3 bound constant
     float in_value[FH_MAX_INPUTS];
+    uint32_t tag[FH_MAX_LEVELS];     // 2D: the level a fill of this level says it was decided at (pixel.rs:225-229) - its own index, or, for a level the
+                                     // library put between two of the caller's (fan-out above 64), the index of the caller's level below it
 };
 
 struct FhRenderState {

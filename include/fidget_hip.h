@@ -163,8 +163,11 @@ typedef struct fhip_render2d_config {
 typedef struct fhip_render3d_config {
     uint32_t width, height, depth;
     const float* world_to_model;   /* row-major 4x4, NULL = identity */
-    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_3d() of the HIP shape: the root tile the
-                                    * VmShape hints give for this image size, then fan-out 4^3: {128,32,8} */
+    const uint32_t* tile_sizes;    /* NULL = RenderHints::tile_sizes_3d() of the HIP shape: the root tile the VmShape hints give for this
+                                    * image size, then fan-out 4^3: {128,32,8} - or {32,8} when the root level has few tiles (a small
+                                    * image, a part of a frame, a model without z).  Any list TileSizes::new accepts
+                                    * (render/mod.rs:181-251) is accepted; one the kernels cannot take as given (leaves other than 8,
+                                    * fan-out above 64) is replaced by the library's: a 3D image does not depend on the tile sizes */
     uint32_t n_tile_sizes;
     const uint64_t* var_keys;
     const float* var_values;
@@ -277,7 +280,9 @@ fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4])
 /* ... and per assembly kernel, each launch bracketed by its own pair of events:
  * index 0 fh_columns, 1 / 2 fh_float_eval_{16x4, 32x2}, 3 fh_tiles, 4 fh_prune1 */
 fhip_status fhip_profile_read_kernels(fhip_ctx* ctx, double ms[8], uint32_t launches[8]);
-/* Device-side counters of the last render: arena ops used (peak), arena overflows, leaves */
+/* Counters of the last render: [0] arena ops used (peak), [1] arena overflows, [2] leaves of the last slab, [3] queue overflows,
+ * [4..6] queue entries per tile level below the root; [7] (context total) 3D frames whose tile_sizes were valid but not a list the
+ * kernels take - leaves other than 8^3, a fan-out above 64 - and were rendered with the library's own list (same image) */
 fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
 
 /* Diagnostics (wave statistics, arena / queue dumps, micro-benchmarks, the tape-group plans) are declared in

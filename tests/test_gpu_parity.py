@@ -695,3 +695,36 @@ def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
     after = free0 - torch.cuda.mem_get_info()[0]
     assert after <= with_lanes and (F.lib().fhip_debug_lane_frames(hip._h) == 0 or after < with_lanes)
     del p, b, hip
+
+
+def test_render3d_takes_every_tile_list_the_reference_takes():
+    """TileSizes::new (fidget-core/src/render/mod.rs:181-251) accepts any descending list whose entries divide their predecessors; fidget-jit's
+    hint is [64, 16, 8].  Until round 4 a list whose last entry is not 8 or whose fan-out exceeds 64 was refused; now it is rendered with the
+    library's own list - the 3D image does not depend on the tile sizes - and counted.  Invalid lists are still refused."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    p, o = F.Shape.from_vm(model_path("colonnade.vm"), hip=hip), O.Shape.from_vm(model_path("colonnade.vm"))
+    ref = O.render3d(o, 192)[0]
+    F.render3d(p, 192)
+    before = hip.counters()["substituted_tile_lists"]
+    for k, ts in enumerate(([64, 16, 8], [64, 16, 4], [128, 8], [256, 64, 16, 8, 2], [96, 32, 16], [8], [5])):
+        a = F.render3d(p, 192, tile_sizes=ts)[0]
+        assert (a["depth"] == ref["depth"]).all() and same_bits_f32(a["normal"], ref["normal"]), ts
+    assert hip.counters()["substituted_tile_lists"] - before == 5        # ([64, 16, 8] and [8] are taken as given)
+    for bad in ([8, 16], [64, 24, 8], [16, 16]):
+        with pytest.raises(F.FidgetHipError):
+            F.render3d(p, 192, tile_sizes=bad)
+
+
+@pytest.mark.parametrize("name,size,ts", [("prospero.vm", 512, [128, 8]), ("prospero.vm", 700, [256, 16]), ("hi.vm", 256, [128, 4]), ("colonnade.vm", 300, [64, 2]),
+                                          ("prospero.vm", 1024, [512, 8]), ("quarter.vm", 256, [256, 8])])
+def test_render2d_takes_a_fan_out_above_64_in_two_steps(name, size, ts):
+    """A step of the caller's 2D tile list with more than 64 children per parent (128 -> 8: 256) was refused until round 4.  It is taken in
+    two now - a level in between that the caller does not see, whose fills carry the level of the caller's next one (pixel.rs:225-229) - and
+    the image is the reference's for the CALLER's list, fill tags included: the oracle renders with exactly that list."""
+    p, o = both(name)
+    a = F.render2d(p, size, tile_sizes=ts)[0]
+    b = O.render2d(o, size, tile_sizes=ts)[0]
+    assert same_bits_f32(a, b), f"{ts}: {(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
+    assert (F.pixel_fill_depth(a) == O.pixel_fill_depth(b)).all()
+    assert F.pixel_fill_depth(a).max() <= len(ts) - 1
