@@ -55,7 +55,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 78.6e12  # plain f32 VALU lane-operations per second: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (= the 157.3 TFLOP/s vector peak / 2 flops per FMA)
 ISSUE_PEAK = 0.57              # wave-instructions per cycle per SIMD, measured (see `issue.peak_note`)
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r04.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
 
 
 def parse_mesh_times(stdout, stderr):
@@ -388,8 +388,8 @@ def main():
                    "sharding": sharding,
                    "general_path": None if not general else {"ms_per_step": general["ms_per_step"], "value": general["value"],
                                                              "frame_latency_ms": general["frame_latency_ms"]},
-                   "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (two buffer "
-                             "sets per context: the coarse levels of a frame run beside the previous frame's slabs), every frame does all of its "
+                   "frames": "queued back to back on one stream, as a caller rendering a sequence would; the library pipelines them (four buffer "
+                             "sets per context: the coarse levels of a frame run beside the previous frames' slabs), every frame does all of its "
                              "work; frame_latency_ms is one frame alone, host_output_frame_ms the blocking call with a host buffer",
                    "column_invariance": ("off for every number of this line (--only-general)" if args.only_general else
                                          "prospero.vm reads no z, so `value` evaluates each tape once per pixel column (DESIGN.md section 2); "

@@ -89,9 +89,9 @@ static void options_from_env(FhOptions& o) {
     }
 }
 
-// Everything one frame of a render owns on the device.  A context holds two sets: an asynchronous 3D render takes the set
-// the previous frame did not use, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
-// run on a stream of their own beside the previous frame's slabs (frame pipelining, FHIP_NO_FRAME_PIPELINE=1 turns it off).
+// Everything one frame of a render owns on the device.  A context holds several sets (option frame_sets, 4): an asynchronous 3D render
+// takes the set used longest ago, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
+// run on a stream of their own beside the previous frames' slabs (frame pipelining; option no_pipeline turns all pipelining off).
 struct FrameBufs {
     DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch;
     DevBuf queue[FH_MAX_LEVELS];

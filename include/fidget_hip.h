@@ -182,7 +182,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
                           int out_is_device);
 /* fidget_raster::voxel::render (voxel.rs:500-553).  out: width*height GeometryPixel
  * {f32 normal[3]; u32 depth} (voxel.rs:122-134).
- * Asynchronous renders (out_is_device) of one context are pipelined across frames: the context keeps two sets of device
+ * Asynchronous renders (out_is_device) of one context are pipelined across frames: the context keeps several sets (option frame_sets, 4) of device
  * buffers, and the coarse tile levels of a frame run on an internal stream beside the slabs of the frame before it.  For the
  * caller nothing changes: `out` is written on the context's stream, in call order; fhip_ctx_sync waits for every frame. */
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,

@@ -8,7 +8,8 @@ register tape -> interval / point / bulk-f32 / bulk-grad interpreters ->
 The reference is Rust and cannot be compiled in this environment (no rustc /
 cargo, crates not vendored), so there is no ``oracle/_ref``; the restatement is
 pinned against the reference's own known-answer tests and golden images in
-``tests/test_oracle_*.py`` (see each test's file:line citation).
+``tests/test_kat_*.py``, ``tests/test_compiler_kat.py``, ``tests/test_reference_units.py``,
+``tests/test_render_golden.py`` and ``tests/test_mesh.py`` (see each test's file:line citation).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this package.  ``fidget_amd`` never does.
