@@ -37,6 +37,8 @@ struct RenderSetup {
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
     bool zrep = false;        // ... column-invariant parents are evaluated for one z-layer only (k_tape_flags)
     bool xy_fixed = false, root_invariant = false;   // 3D, set before prepare(): x and y do not move along a pixel column; the ROOT tape reads nothing that does
+    bool one_level_64 = false;   // 2D, a one-level list: root groups of 64 tiles through the split tile stage (render2d_frame's small-image passes)
+    bool classify_only = false;  // ... and the pass that only classifies its tiles and writes their fills (no prune, no leaves)
     bool root_zrep = false;   // ... then the root level evaluates ONE layer of root tiles per z-slab and hands the result to the layers stacked on it
     bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
     uint32_t hbm_waves = 0;
@@ -162,7 +164,8 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         }
     }
     if (fanout > 64) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tile fan-out above 64 children");
-    const uint32_t TL = R.tl = fanout > 16 ? 64 : 16;
+    // (a one-level 2D list - the small-image passes of render2d_frame: root groups of 64 tiles - takes the 64-lane tile stage too)
+    const uint32_t TL = R.tl = (fanout > 16 || (!is3d && ts.size() == 1 && R.one_level_64)) ? 64 : 16;
     if (is3d && ts.back() != 8) return fail(ctx, FHIP_ERR_UNSUPPORTED, "3D leaves must be 8^3 (one 8x8 footprint per wave)");
     // (register numbers are 12-bit fields of a tape word.  The device prunes keep old -> new register maps in bytes with 0xFF =
     // dead: a CHILD tape has 255 registers at most - one that would need more keeps its parent's tape; the root tape may have
@@ -568,6 +571,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
             else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (R.classify_only) return;       // (the fills of the decided tiles follow below; nothing is pruned or queued)
             if (root_words) hipLaunchKernelGGL(k_tscatter3d, dim3(root_words, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
             if (R.prune2) {
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
@@ -698,7 +702,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
         else {
-            hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+            if (!R.classify_only) hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
             const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);
             hipLaunchKernelGGL(k_tfill2d, dim3(64, slots_max), dim3(256), 0, ctx->stream, dS, level);
         }
@@ -764,32 +768,66 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         if (out.size() > FH_MAX_LEVELS) return fail(ctx, FHIP_ERR_UNSUPPORTED, "1..8 tile levels supported");
         ts = out;
     }
-    for (size_t i = 0; i < FH_MAX_LEVELS; i++) P.tag[i] = i < tags.size() ? tags[i] : (uint32_t)i;
-    st = prepare(ctx, tape, false, ts, PartSpec{}, R);
-    if (st) return st;
     const size_t npix = (size_t)cfg->width * cfg->height;
     float* d_out = out;
     if (!out_is_device) { HIP_TRY(ctx, ctx->tmp_out.ensure(npix * 4)); d_out = (float*)ctx->tmp_out.p; }
-    R.S.image2d = d_out;
-    FhRenderState* dS = (FhRenderState*)ctx->state.p;
-    const FrameClear no_clear[3] = {};
-    st = upload_frame(ctx, tape, R, no_clear);
-    if (st) return st;
-    for (uint32_t l = 0; l < P.n_levels; l++) {
-        if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
-        launch_tiles(ctx, R, dS, (int)l, false);
-    }
-    launch(ctx, FHIP_K_POINTS, [&] {
-        if (R.full) hipLaunchKernelGGL((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
-        else hipLaunchKernelGGL((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
-    });
-    if (P.max_regs > 32)
+    // One pass over a tile list: the tile levels, then the leaf pixels (`classify_only`: the root level's fills, nothing else)
+    auto pass = [&](RenderSetup& Q, const std::vector<uint32_t>& tiles, const std::vector<uint32_t>& tg) -> fhip_status {
+        for (size_t i = 0; i < FH_MAX_LEVELS; i++) Q.S.P.tag[i] = i < tg.size() ? tg[i] : (uint32_t)i;
+        fhip_status ps = prepare(ctx, tape, false, tiles, PartSpec{}, Q);
+        if (ps) return ps;
+        Q.S.image2d = d_out;
+        FhRenderState* dS = (FhRenderState*)ctx->state.p;
+        const FrameClear no_clear[3] = {};
+        ps = upload_frame(ctx, tape, Q, no_clear);
+        if (ps) return ps;
+        for (uint32_t l = 0; l < Q.S.P.n_levels; l++) {
+            if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+            launch_tiles(ctx, Q, dS, (int)l, false);
+        }
+        if (Q.classify_only) return FHIP_OK;
         launch(ctx, FHIP_K_POINTS, [&] {
-            const int g = blocks_big(ctx, R, R.lds_points_big, 16);
-            if (R.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-            else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+            if (Q.full) hipLaunchKernelGGL((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+            else hipLaunchKernelGGL((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
         });
-    if (ctx->host_flags) hipLaunchKernelGGL(k_latch_arena, dim3(1), dim3(1), 0, ctx->stream, dS, 1u, ctx->host_flags);    // (an arena that ran out: grown before the next frame)
+        if (Q.S.P.max_regs > 32)
+            launch(ctx, FHIP_K_POINTS, [&] {
+                const int g = blocks_big(ctx, Q, Q.lds_points_big, 16);
+                if (Q.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
+                else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
+            });
+        if (ctx->host_flags) hipLaunchKernelGGL(k_latch_arena, dim3(1), dim3(1), 0, ctx->stream, dS, 1u, ctx->host_flags);    // (an arena that ran out: grown before the next frame)
+        return FHIP_OK;
+    };
+    // Small images of a large tape (round 5).  With 128 x 128 root tiles a 256 x 256 image is FOUR one-wave chains over a tape that a quarter
+    // of the image barely prunes: 4.1 ms for prospero.vm, where the 4096 x 4096 image takes 0.5.  The root level's forward pass is parallel
+    // over the tape whatever the number of tiles (term groups) and the linked prune takes a thousand children in a round, so the ROOT tape
+    // is pruned per leaf tile directly - a one-level pass over the list's last entry - and the pixels are evaluated from those tapes;
+    // values and decisions are the two-level recursion's (inclusion monotone intervals).  What the caller's list
+    // still decides is the level a fill SAYS it was decided at (pixel.rs:225-229): a leaf tile's fill is tagged with the last level, and a
+    // second, classify-only pass over the root tiles writes the fills of the decided ones - level 0 - over whatever their leaf tiles
+    // wrote (a decided root tile's leaf tiles are all decided the same way, so nothing else is overwritten).
+    const fh::HostTape& tt = tape->t;
+    const bool small_ok = ts.size() == 2 && tags.size() == 2 && ts[1] >= 8 && ts[0] / ts[1] <= 8 && ctx->opt.root32_max > 0 && ctx->use_split && ctx->use_asm &&
+                          !tape->tgroups.empty() && !ctx->opt.no_tape_groups && ctx->opt.prune2 && tape_asm_ok(tt) && tt.ops.size() <= FH_P2_MAX_OPS &&
+                          tt.n_choices <= FH_P2_MAX_CHOICES &&
+                          (uint64_t)((P.width + ts[1] - 1) / ts[1]) * ((P.height + ts[1] - 1) / ts[1]) <= 2048u &&
+                          (uint64_t)((P.width + ts[0] - 1) / ts[0]) * ((P.height + ts[0] - 1) / ts[0]) <= 64u;
+    if (small_ok) {
+        RenderSetup A = R;
+        A.one_level_64 = true;
+        st = pass(A, std::vector<uint32_t>{ts[1]}, std::vector<uint32_t>{1u});
+        if (st) return st;
+        if (!P.pixel_perfect) {       // (pixel-perfect renders have no fills: pixel.rs:345-368)
+            RenderSetup B = R;
+            B.one_level_64 = true; B.classify_only = true;
+            st = pass(B, std::vector<uint32_t>{ts[0]}, std::vector<uint32_t>{0u});
+            if (st) return st;
+        }
+    } else {
+        st = pass(R, ts, tags);
+        if (st) return st;
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->stream));     // (a later pipelined 3D frame that takes this buffer set waits for it)
     ctx->ev_done_valid = true;

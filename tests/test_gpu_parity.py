@@ -728,3 +728,27 @@ def test_render2d_takes_a_fan_out_above_64_in_two_steps(name, size, ts):
     assert same_bits_f32(a, b), f"{ts}: {(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
     assert (F.pixel_fill_depth(a) == O.pixel_fill_depth(b)).all()
     assert F.pixel_fill_depth(a).max() <= len(ts) - 1
+
+
+@pytest.mark.parametrize("size,ts", [(64, None), (100, None), (256, None), (300, None), (512, None), (700, None), (256, [64, 8]), (384, [128, 32]), (200, [32, 8])])
+def test_render2d_small_images_of_a_large_tape(size, ts):
+    """Round 5: a small 2D image of a large tape (few root tiles, none of which prunes the tape much) is rendered as a one-level pass of the
+    ROOT tape over the leaf tiles + a classify-only pass over the root tiles for the fills' level tags (capi_render.hpp render2d_frame).
+    The image is the two-level recursion's, tags included: the oracle with the same list; the same with the short cut off; rectangular and
+    pixel-perfect renders too."""
+    import torch
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    p, o = F.Shape.from_vm(model_path("prospero.vm"), hip=hip), O.Shape.from_vm(model_path("prospero.vm"))
+    b = O.render2d(o, size, tile_sizes=ts or F.HIP_TILES_2D)[0]
+    for off in (0, 1):
+        with hip.options(root32_max=0 if off else 4096):
+            a = F.render2d(p, size, tile_sizes=ts)[0]
+            assert same_bits_f32(a, b), f"{ts} off={off}: {(a.view(np.uint32) != b.view(np.uint32)).sum()} pixels differ"
+            assert (F.pixel_fill_depth(a) == O.pixel_fill_depth(b)).all()
+    a = F.render2d(p, size, size // 2 + 8, tile_sizes=ts)[0]
+    b = O.render2d(o, size, size // 2 + 8, tile_sizes=ts or F.HIP_TILES_2D)[0]
+    assert same_bits_f32(a, b)
+    a = F.render2d(p, size, pixel_perfect=True, tile_sizes=ts)[0]
+    b = O.render2d(o, size, pixel_perfect=True, tile_sizes=ts or F.HIP_TILES_2D)[0]
+    assert same_bits_f32(a, b)
+    del p, hip
