@@ -428,9 +428,18 @@ def main():
             return None
         per_frame_ms, launches_pf = ms / PROF_FRAMES, launches // PROF_FRAMES
         achieved = alg_bytes_per_frame / (per_frame_ms * 1e-3) / 1e9
-        t = (traffic.get(path) or {}).get(kernel)
+        # (the per-kernel profile times the root level's prune - k_prune2 and the scalar sweep behind it - as one slot, "fh_prune1": its counters
+        # are the two kernels' together, per pair of launches)
+        tp = traffic.get(path) or {}
+        parts = [tp[k] for k in (("k_prune2", "fh_prune1") if kernel == "fh_prune1" else (kernel,)) if k in tp]
+        t = None
+        if parts:
+            t = {"launches_per_frame": max(q["launches_per_frame"] for q in parts)}
+            for key in ("fetch_kb_per_frame", "write_kb_per_frame", "valu_per_launch", "salu_per_launch"):
+                if all(key in q for q in parts):
+                    t[key] = sum(q[key] for q in parts)
         tb = None
-        if t:
+        if t and "fetch_kb_per_frame" in t and "write_kb_per_frame" in t:
             tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
         r = {"bound": "hbm", "kernel": kernel, "path": path, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
