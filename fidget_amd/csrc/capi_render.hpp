@@ -136,7 +136,7 @@ static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P
 static fhip_status grow_arena_if_asked(fhip_ctx* ctx, size_t tape_ops) {
     const size_t need = ((tape_ops + 64) * 8 + 4096) * 4;       // (root tape + its groups, with room to prune into)
     bool grow = ctx->host_flags && ctx->host_flags[0] != 0 && ctx->arena_bytes < ctx->arena_cap_bytes;
-    size_t want = grow ? ctx->arena_bytes * 2 : ctx->arena_bytes;
+    size_t want = grow ? ctx->arena_bytes * (ctx->arena_bytes <= ((size_t)FH_ARENA_START_MB << 20) ? 4 : 2) : ctx->arena_bytes;      // (the first step is the big one: a frame that outgrows 256 MB is usually one with z in every tape, at 4 x the ops)
     if (want < need) { want = need; grow = ctx->arena_bytes < std::min(need, ctx->arena_cap_bytes); }
     if (!grow) return FHIP_OK;
     HIP_TRY(ctx, hipDeviceSynchronize());       // (every stream of the context, its lanes included: a set's arena is about to be replaced)

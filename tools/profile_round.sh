@@ -41,9 +41,18 @@ res = {"_comment": "per-kernel PMC totals of `bench.py --steps 5 --warmup 1 --no
 lines = []
 for path in ("default", "general"):
     tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
+    # (the LAST frames of each pass only: the first frames of a context may run out of tape arena - it starts small and grows, the frames
+    # are right but their tiles keep their parents' tapes - and would count 2-4 x the instructions of a steady frame into the mean)
+    LAST = 16
     for f in glob.glob(os.path.join(out, f"pmc_{path}_*.csv")):
-        for r in csv.DictReader(open(f)):
-            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").split("<")[0]
+        rows = list(csv.DictReader(open(f)))
+        name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").split("<")[0]
+        ends = sorted({int(r["End_Timestamp"]) for r in rows if name(r) == "k_finish3d"})
+        after = ends[-LAST - 1] if len(ends) > LAST else 0
+        for r in rows:
+            if int(r["Start_Timestamp"]) <= after:
+                continue
+            k = name(r)
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
     frames = max(n["k_finish3d"].values()) if n["k_finish3d"] else 1
     res[path] = {"frames": frames}
