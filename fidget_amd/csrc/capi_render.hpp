@@ -1123,10 +1123,14 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 // one workgroup per block of 4 footprints of one 8-voxel layer, front layers first
                 // per-frame constants of the leaf kernel (gen_interp.py gen_columns): input slots of the axes, the inputs that change
                 // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
-                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags, {0, 0}};
-                const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 const uint32_t blk = 4;   // footprints per workgroup: gen_interp.py FH_BLKL = 2
-                (void)launch_asm(ctx, which, (R.n_footprints + blk - 1) / blk, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
+                const uint32_t n_blocks = (R.n_footprints + blk - 1) / blk;
+                // (pad[0]: floor(2^32 / blocks per layer) - the kernel rotates a layer's blocks by a per-layer offset, which is what balances
+                // the launch, and takes the remainder by this reciprocal instead of a subtraction loop)
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags,
+                                                                                                   {n_blocks > 1 ? (uint32_t)(((uint64_t)1 << 32) / n_blocks) : 0u, 0}};
+                const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
+                (void)launch_asm(ctx, which, n_blocks, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
             } else if (R.full) {
                 hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
                 hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);

@@ -914,6 +914,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
             inplace_mask |= 1 << k
     S_WGID, S_NWG, S_CNT, S_I, S_L, S_NFPL = "s6", "s7", "s40", "s41", "s27", "s38"
     S_ONE, S_WGY = "s100", "s101"
+    S_RCP = "s33"        # floor(2^32 / blocks per layer), kernarg word 6 (0: none); s33 is free in the leaf kernels (the bulk kernels' S_OUTP)
     import os
     BLKL = int(os.environ.get("FH_BLKL", "2"))   # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast); capi.hip FH_COL_BLKL must agree
     BLK = 1 << BLKL
@@ -924,6 +925,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
 	s_load_dwordx4 s[48:51], {S_KERNARG}, 0x8
+	s_load_dword {S_RCP}, {S_KERNARG}, 0x18
 	s_mov_b32 {S_WGID}, s2
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
@@ -984,8 +986,20 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_haveblock:
 	; rotate the block index by a per-layer offset: with a round-robin stride equal to the number of
 	; blocks a wave would otherwise own the same footprints in every layer (no balance at all)
+	; (the rotation is what balances the launch - without it the heavy footprints' layers pile up on the same compute units: 0.58 -> 0.82 ms
+	; per launch with z in every tape, measured - so it stays, but as a multiplication: (L * 1237 + I) mod CNT through the reciprocal the
+	; host passes in the kernarg, floor(2^32 / CNT), one conditional subtraction behind it; the subtraction loop below, which cost the
+	; average wave ten taken branches before it had looked at a leaf, only runs when no reciprocal came)
 	s_mul_i32 {S_T0}, {S_L}, 1237
 	s_add_u32 {S_T0}, {S_T0}, {S_I}
+	s_cmp_eq_u32 {S_RCP}, 0
+	s_cbranch_scc1 .Lfh_columns_rot
+	s_mul_hi_u32 {S_T1}, {S_T0}, {S_RCP}
+	s_mul_i32 {S_T1}, {S_T1}, {S_CNT}
+	s_sub_u32 {S_T0}, {S_T0}, {S_T1}
+	s_sub_u32 {S_T1}, {S_T0}, {S_CNT}
+	s_cmp_ge_u32 {S_T0}, {S_CNT}
+	s_cselect_b32 {S_T0}, {S_T1}, {S_T0}
 .Lfh_columns_rot:
 	s_cmp_ge_u32 {S_T0}, {S_CNT}
 	s_cbranch_scc0 .Lfh_columns_rotated

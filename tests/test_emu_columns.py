@@ -18,8 +18,9 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
-def col_kernarg(a_st, in_kind, mat):
-    """the leaf kernel's kernarg as capi.hip builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags"""
+def col_kernarg(a_st, in_kind, mat, size=16):
+    """the leaf kernel's kernarg as capi_render.hpp builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags, and
+    floor(2^32 / blocks of four footprints per layer) for the kernel's block rotation (0 when there is one block: the subtraction loop)"""
     u = np.asarray(mat, F32).view(U32)
     proj = bool(((int(u[12]) | int(u[13]) | int(u[14])) & 0x7FFFFFFF) | (int(u[15]) ^ 0x3F800000))
     slot = [-1, -1, -1]
@@ -34,7 +35,8 @@ def col_kernarg(a_st, in_kind, mat):
             dep |= 1 << slot[ax]
         if varies:
             flags |= 0x20000 << ax          # (bits 17 .. 19: this axis of the model changes along a pixel column)
-    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, 0, 0], U32)
+    n_blocks = (((size + 7) // 8) ** 2 + 3) // 4
+    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, (1 << 32) // n_blocks if n_blocks > 1 else 0, 0], U32)
 
 
 def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns"):
@@ -60,7 +62,7 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], lz - lz % size)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat)
+    ka = col_kernarg(a_st, in_kind, mat, size)
     trans = kernel == "fh_columns_t"
     waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=256 if trans else 128,
                      hooks=U.trans_hooks(U.program(), v_base=192, window=64) if trans else None)
@@ -224,7 +226,7 @@ def run_block(leaves_spec, in_kind, mat, size=16, zbuf_init=None, kernel="fh_col
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], slab_z)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat)
+    ka = col_kernarg(a_st, in_kind, mat, size)
     E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=128)
     return zbuf
 
