@@ -299,7 +299,7 @@ class HipContext:
         c = np.zeros(8, np.uint64)
         self.check(lib().fhip_render_counters(self._h, _p(c)))
         return {"arena_ops": int(c[0]), "arena_overflow": int(c[1]), "leaves_last_slab": int(c[2]),
-                "queue_overflow": int(c[3]), "groups_last_slab": [int(v) for v in c[4:7]], "substituted_tile_lists": int(c[7])}
+                "queue_overflow": int(c[3]), "groups_last_slab": [int(v) for v in c[4:6]], "hip_tile_stage_frames": int(c[6]), "substituted_tile_lists": int(c[7])}
 
     def last_leaves(self, cap=1 << 20):
         """Leaf records of the last slab of the last 3D frame: structured array (off, len, regs, choices, x, y, z)."""

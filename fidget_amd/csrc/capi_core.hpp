@@ -163,6 +163,7 @@ struct fhip_ctx : FrameBufs {
     // device writes and the host reads without waiting for anything - and the next render call grows the arena first.  Until round 4 every
     // set held the full 4 GiB: 18.6 GB per context for a peak use of 0.1.
     size_t arena_bytes = (size_t)256 << 20, arena_cap_bytes = (size_t)4 << 30;
+    uint64_t hip_tile_frames = 0;               // frames whose tile stage took the HIP C++ kernels without having been told to (capi_render.hpp prepare)
     uint64_t substituted_tiles = 0;             // 3D frames whose caller's tile list was valid but not one the kernels take: rendered with the library's (same image)
     int last_hip_error = 0;                     // the HIP error code behind the last FHIP_ERR_HIP (HIP_TRY)
     volatile uint32_t* host_flags = nullptr;    // pinned: [0] a frame's arena overflowed, [1] peak arena ops of any frame

@@ -24,7 +24,8 @@ fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]) {
     if (st != FHIP_OK && st != FHIP_ERR_OVERFLOW) return st;
     const FhRenderState& S = ctx->last_state;
     out[0] = S.arena_head; out[1] = S.arena_overflow; out[2] = S.n_leaves; out[3] = S.queue_overflow;
-    for (int i = 0; i < 3; i++) out[4 + i] = S.count[i + 1];
+    for (int i = 0; i < 2; i++) out[4 + i] = S.count[i + 1];
+    out[6] = ctx->hip_tile_frames;        // (frames whose tile stage took the HIP kernels implicitly: tapes beyond the assembly kernels' register files)
     out[7] = ctx->substituted_tiles;      // (3D frames rendered with the library's tile list in place of a caller's the kernels cannot take)
     return FHIP_OK;
 }

@@ -342,12 +342,15 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     for (size_t l = 0; l < ts.size(); l++) S.qcap[l] = qcaps[l];
     R.split = ctx->use_split && R.tl == 64 && true;
     // (tapes with sin cos tan asin acos atan exp ln: the *_t variants of the tile kernels, which carry those interval handlers;
-    // atan2, mod, mix, rand keep the HIP tile stage)
+    // and, since round 5, those for atan2, mod, mix, rand)
     R.asm_tiles_t = !tape_asm_ok(t) && tape_tiles_t_ok(t) && !ctx->opt.no_asm_tiles_t;
     // (not with a register file in HBM: the assembly tile kernels - fh_prune1, the groups path and the linked prune with them - keep
     // registers AND choices in LDS, and a tape of few registers can still outgrow it by its choices alone, ~5 600 of them)
     R.asm_tiles = R.split && ctx->use_asm && !ctx->opt.no_asm_tiles && (tape_asm_ok(t) || R.asm_tiles_t) && t.n_regs <= 128 && !R.big_hbm;
     R.asm_tiles_t = R.asm_tiles_t && R.asm_tiles;
+    // (fhip_render_counters out[6]: frames whose tile stage took the HIP kernels although nobody switched the assembly ones off - left: tapes
+    // of more than 128 registers and register files in HBM)
+    if (!R.asm_tiles && R.split && ctx->use_asm && !ctx->opt.no_asm_tiles) ctx->hip_tile_frames++;
     // levels whose forward pass exports its choices to the one-wave-per-child prune (fh_prune1): long tapes, few parents.
     // 3D: of the pre-pass levels, level 0 (measured); 2D: level 0
     R.exp_levels = is3d ? std::min(S.pre_levels, 1u) : 1u;

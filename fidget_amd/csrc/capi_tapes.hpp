@@ -79,18 +79,9 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
     }
     return e;
 }
-// ... the *_t tile kernels add the unary transcendental ones
-static bool tape_tiles_t_ok(const fh::HostTape& t) {
-    for (uint64_t w : t.ops) {
-        const uint32_t op = FH_W_OP((uint32_t)w);
-        if (op == FH_RAND) return false;
-        if (op >= FH_ADD_RR) {
-            const int base = op >= FH_SUB_IR ? (int[]){1, 3, 4, 5, 6, 7}[op - FH_SUB_IR] : (int)((op - FH_ADD_RR) % 12);
-            if (base == 4 || base == 6 || base == 7) return false;  // atan2, mix, mod
-        }
-    }
-    return true;
-}
+// ... the *_t tile kernels have an interval handler for every opcode (round 5 added atan2, modulo, rand and mix: gen_tiles.py b_atan2 ..
+// b_mix), so every tape the assembly leaf kernels take, the assembly tile kernels take
+static bool tape_tiles_t_ok(const fh::HostTape&) { return true; }
 static bool tape_has_mod(const fh::HostTape& t) {
     for (uint64_t w : t.ops) {
         const uint32_t op = FH_W_OP((uint32_t)w);

@@ -234,6 +234,153 @@ class Tiles:
         self.nan_out(S_M[1])
 
 
+
+    # ---- rand, mix, modulo, atan2: interval rules of types/interval.rs:485-503, 541-627 (dev_ops.hpp iv_rand, iv_mix, iv_rem_euclid,
+    # iv_atan2) - the *_t kernels only: modulo and atan2 CALL the compiled f32 routines (rem_euclid, atan2f), as the HIP kernels inline them ----
+    def tcall2(self, fn, arg0, arg1, res):
+        """res = <fn>(arg0, arg1); clobbers what tcall clobbers"""
+        here, ret = self.a.label("tcall"), self.a.label("tret")
+        self.a(f"""
+	v_mov_b32 v{self.t_base}, {arg0}
+	v_mov_b32 v{self.t_base + 1}, {arg1}
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_branch {self.t_prefix}{fn}
+{ret}:
+	v_mov_b32 {res}, v{self.t_base}""")
+
+    def pcg(self, x, r, k):
+        """r = rng::hash(x) (rng/mod.rs:8-13: the PCG output permutation); k = three scratch registers (r may be x)"""
+        self.a(f"""
+	v_mov_b32 {k[2]}, 747796405
+	v_mul_lo_u32 {k[0]}, {x}, {k[2]}
+	v_add_u32 {k[0]}, 0xac564b05, {k[0]}
+	v_lshrrev_b32 {k[1]}, 28, {k[0]}
+	v_add_u32 {k[1]}, 4, {k[1]}
+	v_lshrrev_b32 {k[1]}, {k[1]}, {k[0]}
+	v_xor_b32 {k[1]}, {k[1]}, {k[0]}
+	v_mov_b32 {k[2]}, 277803737
+	v_mul_lo_u32 {k[1]}, {k[1]}, {k[2]}
+	v_lshrrev_b32 {k[0]}, 22, {k[1]}
+	v_xor_b32 {r}, {k[0]}, {k[1]}""")
+
+    def b_rand(self):
+        """NaN or not one bit pattern -> [0, 1]; else the point rng::rand (rng/mod.rs:19-23): bits (hash >> 9) | 1.0, minus 1"""
+        a = self.a
+        a(f"\tv_cmp_u_f32_e64 {S_M[0]}, {AL}, {AH}\n\tv_cmp_ne_u32_e64 {S_M[1]}, {AL}, {AH}")
+        self.pcg(AL, T[0], T[1:4])
+        a(f"""
+	v_lshrrev_b32 {T[0]}, 9, {T[0]}
+	v_or_b32 {T[0]}, 0x3f800000, {T[0]}
+	v_add_f32 {T[0]}, -1.0, {T[0]}
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	s_nop 1""")
+        self.sel(RL, T[0], "0", S_M[0])
+        self.sel(RH, T[0], "1.0", S_M[0])
+
+    def b_mix(self):
+        """both operands one non-NaN bit pattern -> the point rng::mix (rng/mod.rs:30-33): hash(a + hash(b)); else NaN"""
+        a = self.a
+        a(f"""
+	v_cmp_u_f32_e64 {S_M[0]}, {AL}, {AH}
+	v_cmp_u_f32_e64 {S_M[1]}, {BL}, {BH}
+	v_cmp_ne_u32_e64 {S_M[2]}, {AL}, {AH}
+	v_cmp_ne_u32_e64 {S_T64}, {BL}, {BH}
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	s_or_b64 {S_M[2]}, {S_M[2]}, {S_T64}
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[2]}""")
+        self.pcg(BL, T[0], T[1:4])
+        a(f"\tv_add_u32 {T[0]}, {AL}, {T[0]}")
+        self.pcg(T[0], T[0], T[1:4])
+        a(f"\tv_mov_b32 {RL}, {T[0]}\n\tv_mov_b32 {RH}, {T[0]}")
+        self.nan_out(S_M[0])
+
+    def b_mod(self):
+        """NaN or a divisor that contains 0 -> NaN; a point divisor > 0 and a.lo / d not an integer with the same floor as a.hi / d ->
+        [rem_euclid(a.lo, d), rem_euclid(a.hi, d)]; else [0, |divisor|.hi]"""
+        a = self.a
+        x, y, fx, fy, r1, r2 = T[0], T[1], T[2], T[3], T[10], T[11]
+        self.div(AL, BL, x, d=T[4:10])
+        self.div(AH, BL, y, d=T[4:10])
+        a(f"""
+	v_floor_f32 {fx}, {x}
+	v_floor_f32 {fy}, {y}
+	v_cmp_eq_f32_e64 {S_M[0]}, {BL}, {BH}
+	v_cmp_lt_f32_e64 {S_M[1]}, 0, {BL}
+	v_cmp_neq_f32_e64 {S_M[2]}, {x}, {fx}
+	v_cmp_eq_f32_e64 {S_T64}, {fx}, {fy}
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	s_and_b64 {S_M[2]}, {S_M[2]}, {S_T64}
+	s_and_b64 {S_M[2]}, {S_M[2]}, {S_M[0]}                    ; same: the remainders of both ends bound the result""")
+        self.tcall2("mod", AL, BL, r1)
+        self.tcall2("mod", AH, BL, r2)
+        a(f"""
+	v_cmp_gt_f32_e64 {S_M[0]}, 0, {BL}
+	s_nop 1
+	v_cndmask_b32_e64 {T[4]}, {BH}, -{BL}, {S_M[0]}          ; |divisor|.hi for a divisor that does not contain 0
+	v_cmp_u_f32_e64 {S_M[0]}, {AL}, {AH}
+	v_cmp_u_f32_e64 {S_M[1]}, {BL}, {BH}
+	v_cmp_ge_f32_e64 {S_T64}, 0, {BL}
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	v_cmp_le_f32_e64 {S_M[1]}, 0, {BH}
+	s_nop 0
+	s_and_b64 {S_M[1]}, {S_M[1]}, {S_T64}
+	s_or_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}""")
+        self.sel(RL, "0", r1, S_M[2])
+        self.sel(RH, T[4], r2, S_M[2])
+        self.nan_out(S_M[0])
+
+    def b_atan2(self):
+        """A = y, B = x.  NaN -> NaN; y contains 0 and x.lo < 0 -> [-pi, pi]; else atan2f at two corners chosen by the signs of y and x
+        (interval.rs:541-597), the smaller and the larger of the two"""
+        a = self.a
+        y0, y1, x1, v0, v1 = T[0], T[1], T[2], T[3], T[4]
+        ypos, yneg, xpos, xneg = S_M[0], S_M[1], S_M[2], S_T64
+        a(f"""
+	v_cmp_le_f32_e64 {ypos}, 0, {AL}                        ; y.lo >= 0
+	v_cmp_ge_f32_e64 {yneg}, 0, {AH}                        ; y.hi <= 0
+	v_cmp_le_f32_e64 {xpos}, 0, {BL}                        ; x.lo >= 0
+	v_cmp_ge_f32_e64 {xneg}, 0, {BH}                        ; x.hi <= 0
+	s_andn2_b64 {yneg}, {yneg}, {ypos}
+	s_andn2_b64 {xneg}, {xneg}, {xpos}
+	s_nop 1
+	; y0: y >= 0: x >= 0 ? y.hi : y.lo;  y <= 0: x >= 0 ? y.lo : y.hi;  y mixed: y.lo
+	v_cndmask_b32_e64 {T[5]}, {AL}, {AH}, {xpos}            ; x >= 0 ? y.hi : y.lo
+	v_cndmask_b32_e64 {T[6]}, {AH}, {AL}, {xpos}            ; x >= 0 ? y.lo : y.hi
+	v_mov_b32 {y0}, {AL}
+	v_cndmask_b32_e64 {y0}, {y0}, {T[6]}, {yneg}
+	v_cndmask_b32_e64 {y0}, {y0}, {T[5]}, {ypos}
+	; y1: y >= 0: x <= 0 (strictly mixed excluded) ? y.hi : y.lo;  y <= 0: x <= 0 ? y.lo : y.hi;  y mixed: y.hi
+	v_cndmask_b32_e64 {T[5]}, {AL}, {AH}, {xneg}            ; x <= 0 ? y.hi : y.lo
+	v_cndmask_b32_e64 {T[6]}, {AH}, {AL}, {xneg}            ; x <= 0 ? y.lo : y.hi
+	v_mov_b32 {y1}, {AH}
+	v_cndmask_b32_e64 {y1}, {y1}, {T[6]}, {yneg}
+	v_cndmask_b32_e64 {y1}, {y1}, {T[5]}, {ypos}
+	; x1: x.hi, but x.lo when y is mixed
+	s_or_b64 {xpos}, {ypos}, {yneg}
+	s_nop 1
+	v_cndmask_b32_e64 {x1}, {BL}, {BH}, {xpos}""")
+        self.tcall2("atan2", y0, BL, v0)
+        self.tcall2("atan2", y1, x1, v1)
+        a(f"""
+	v_min_f32 {RL}, {v0}, {v1}
+	v_max_f32 {RH}, {v0}, {v1}
+	v_cmp_ge_f32_e64 {S_M[0]}, 0, {AL}                      ; y.lo <= 0 && y.hi >= 0 && x.lo < 0: the whole circle
+	v_cmp_le_f32_e64 {S_M[1]}, 0, {AH}
+	v_cmp_gt_f32_e64 {S_M[2]}, 0, {BL}
+	v_mov_b32 {T[5]}, 0x40490fdb
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
+	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[2]}
+	v_cmp_u_f32_e64 {S_M[1]}, {AL}, {AH}
+	v_cmp_u_f32_e64 {S_M[2]}, {BL}, {BH}
+	s_nop 0""")
+        self.sel(RL, RL, f"-{T[5]}", S_M[0])
+        self.sel(RH, RH, T[5], S_M[0])
+        a(f"\ts_or_b64 {S_M[1]}, {S_M[1]}, {S_M[2]}")
+        self.nan_out(S_M[1])
+
     # ---- helpers -------------------------------------------------------------------------
     def done(self):
         """store R to the out register, next op"""
@@ -578,6 +725,12 @@ class Tiles:
                 self.done()
             a("\ts_waitcnt lgkmcnt(0)")
             return self.ool_body(op.lower(), body)
+        if op == "RAND":
+            def body():
+                self.b_rand()
+                self.done()
+            a("\ts_waitcnt lgkmcnt(0)")
+            return self.ool_body("rand", body)
         if op in ("FLOOR", "CEIL"):
             ins = "v_floor_f32" if op == "FLOOR" else "v_ceil_f32"
             a(f"\ts_waitcnt lgkmcnt(0)\n\t{ins} {RL}, {AL}\n\t{ins} {RH}, {AH}")
@@ -599,7 +752,7 @@ class Tiles:
         if base == "MUL" and form == "RI":
             base = "MULIMM"
         bodies = {"ADD": self.b_add, "SUB": self.b_sub, "MUL": self.b_mul, "MULIMM": self.b_mul_imm, "DIV": self.b_div,
-                  "COMPARE": self.b_compare}
+                  "COMPARE": self.b_compare, "ATAN2": self.b_atan2, "MOD": self.b_mod, "MIX": self.b_mix}
         if base in bodies:
             def body(fn=bodies[base]):
                 fn()
@@ -726,7 +879,7 @@ class Tiles:
             a(f"\t.p2align {HSTRIDE_LOG2}")
             a(f".Lfh_tiles_h{i}:  ; {op}")
             base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-            if base in UNSUPPORTED and not (self.trans and base in TRANS_UNARY):
+            if base in UNSUPPORTED and not self.trans:
                 a(f"\ts_branch {self.next}")
             else:
                 self.handler(op)

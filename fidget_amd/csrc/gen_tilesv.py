@@ -200,6 +200,12 @@ class TilesV(Tiles):
                 self.done()
             a("\ts_set_gpr_idx_off")
             return self.ool_body(op.lower(), body)
+        if op == "RAND":
+            def body():
+                self.b_rand()
+                self.done()
+            a("\ts_set_gpr_idx_off")
+            return self.ool_body("rand", body)
         if op in ("FLOOR", "CEIL"):
             ins = "v_floor_f32" if op == "FLOOR" else "v_ceil_f32"
             a(f"\ts_set_gpr_idx_off\n\t{ins} {RL}, {AL}\n\t{ins} {RH}, {AH}")
@@ -226,7 +232,7 @@ class TilesV(Tiles):
         if base == "MUL" and form == "RI":
             base = "MULIMM"
         bodies = {"ADD": self.b_add, "SUB": self.b_sub, "MUL": self.b_mul, "MULIMM": self.b_mul_imm, "DIV": self.b_div,
-                  "COMPARE": self.b_compare}
+                  "COMPARE": self.b_compare, "ATAN2": self.b_atan2, "MOD": self.b_mod, "MIX": self.b_mix}
         if base in bodies:
             def body(fn=bodies[base]):
                 fn()
@@ -316,7 +322,7 @@ class TilesV(Tiles):
             else:
                 op = OPS[i]
                 base = op.rsplit("_", 1)[0] if "_" in op and op not in ("COPY_REG", "COPY_IMM") else op
-                if base in UNSUPPORTED and not (self.trans and base in TRANS_UNARY):
+                if base in UNSUPPORTED and not self.trans:
                     self.dispatch()
                 else:
                     self.handler(op)

@@ -281,7 +281,8 @@ fhip_status fhip_profile_read(fhip_ctx* ctx, double ms[4], uint32_t launches[4])
  * index 0 fh_columns, 1 / 2 fh_float_eval_{16x4, 32x2}, 3 fh_tiles, 4 fh_prune1 */
 fhip_status fhip_profile_read_kernels(fhip_ctx* ctx, double ms[8], uint32_t launches[8]);
 /* Counters of the last render: [0] arena ops used (peak), [1] arena overflows, [2] leaves of the last slab, [3] queue overflows,
- * [4..6] queue entries per tile level below the root; [7] (context total) 3D frames whose tile_sizes were valid but not a list the
+ * [4..5] queue entries per tile level below the root; [6] (context total) frames whose tile stage ran on the HIP C++ kernels without a
+ * switch asking for it (tapes beyond the assembly kernels' register files); [7] (context total) 3D frames whose tile_sizes were valid but not a list the
  * kernels take - leaves other than 8^3, a fan-out above 64 - and were rendered with the library's own list (same image) */
 fhip_status fhip_render_counters(fhip_ctx* ctx, uint64_t out[8]);
 

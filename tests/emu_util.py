@@ -342,6 +342,10 @@ def ref_interval(tape, inputs, n):
                     r = (np.where(first, F32(0), np.where(zero, F32(1), F32(0))), np.where(first, F32(0), F32(1)))
                 elif name in TRANS:
                     r = _iv_trans(name, al, ah)
+                elif name == "RAND":        # dev_ops.hpp iv_rand (interval.rs:619-627): one non-NaN bit pattern -> the point, else [0, 1]
+                    point = ~_nan(al, ah) & (al.view(U32) == ah.view(U32))
+                    v = (((pcg(al.view(U32)) >> U32(9)) | U32(0x3F800000)).view(F32) - F32(1)).astype(F32)
+                    r = (np.where(point, v, F32(0)), np.where(point, v, F32(1)))
                 else:
                     raise NotImplementedError(name)
                 regs[ro] = (r[0].astype(F32), r[1].astype(F32))
@@ -380,6 +384,27 @@ def ref_interval(tape, inputs, n):
                 lo = np.where(nn, NAN, np.where(less, F32(-1), np.where(greater, F32(1), np.where(eq, F32(0), F32(-1)))))
                 hi = np.where(nn, NAN, np.where(less, F32(-1), np.where(greater, F32(1), np.where(eq, F32(0), F32(1)))))
                 r = (lo, hi)
+            elif bn == "MIX":           # iv_mix (interval.rs:600-616): both one non-NaN bit pattern -> the point hash(a + hash(b)), else NaN
+                al, ah, bl, bh = (np.ascontiguousarray(v, F32) for v in (al, ah, bl, bh))
+                point = ~nn & (al.view(U32) == ah.view(U32)) & (bl.view(U32) == bh.view(U32))
+                v = pcg((al.view(U32) + pcg(bl.view(U32))).astype(U32)).view(F32)
+                r = (np.where(point, v, NAN), np.where(point, v, NAN))
+            elif bn == "MOD":           # iv_rem_euclid (interval.rs:485-503)
+                bad = nn | ((bl <= 0) & (bh >= 0))
+                x, y = (al / bl).astype(F32), (ah / bl).astype(F32)
+                same = (bl == bh) & (bl > 0) & (x != np.floor(x)) & (np.floor(x) == np.floor(y))
+                top = np.where(bl < 0, -bl, bh)
+                r = (np.where(bad, NAN, np.where(same, rem_euclid(al, bl), F32(0))), np.where(bad, NAN, np.where(same, rem_euclid(ah, bl), top)))
+            elif bn == "ATAN2":         # iv_atan2 (interval.rs:541-597): a = y, b = x
+                PI = F32(3.14159274101257324)
+                ypos, xpos = al >= 0, bl >= 0
+                yneg, xneg = ~ypos & (ah <= 0), ~xpos & (bh <= 0)
+                y0 = np.where(ypos, np.where(xpos, ah, al), np.where(yneg, np.where(xpos, al, ah), al))
+                y1 = np.where(ypos, np.where(xneg, ah, al), np.where(yneg, np.where(xneg, al, ah), ah))
+                x1 = np.where(ypos | yneg, bh, bl)
+                v0, v1 = t64("atan2f", y0, bl), t64("atan2f", y1, x1)
+                full = (al <= 0) & (ah >= 0) & (bl < 0)
+                r = (np.where(nn, NAN, np.where(full, -PI, _rmin(v0, v1))), np.where(nn, NAN, np.where(full, PI, _rmax(v0, v1))))
             elif bn == "MIN":
                 c = np.where(nn, 3, np.where(ah < bl, 1, np.where(bh < al, 2, 3)))
                 r = (np.where(nn, NAN, _rmin(al, bl)), np.where(nn, NAN, _rmin(ah, bh)))

@@ -81,7 +81,10 @@ def check_slot(kernel, tape, xyz, in_kind, n_regs, n_choices, act=(1 << 64) - 1,
     inputs = {s: (xyz[2 * k], xyz[2 * k + 1]) for s, k in enumerate(in_kind) if k < 3}
     el, eh, ch, _ = U.ref_interval(tape, inputs, 64)
     rl, rh = r["res"]
-    assert (el.view(U32) == rl.view(U32)).all() and (eh.view(U32) == rh.view(U32)).all(), "interval results differ"
+    # (bit for bit; a NaN equals any NaN - its sign and payload are not part of the contract, DESIGN.md section 2: a NaN that has gone
+    # through a subtraction's negated operand carries the other sign on the device)
+    same = lambda e, g: ((e.view(U32) == g.view(U32)) | (np.isnan(e) & np.isnan(g))).all()
+    assert same(el, rl) and same(eh, rh), "interval results differ"
     actm = np.array([(act >> i) & 1 for i in range(64)], bool)
     amb = actm & ~(eh < 0) & ~(el > 0)
     decided = (ch != 3).any(axis=0) if len(ch) else np.zeros(64, bool)
@@ -369,8 +372,18 @@ def trans_shape(which):
     elif which == 1:    # exp / ln / atan, a union with a sphere
         r2 = c.add(c.add(c.square(x), c.square(y)), c.square(z))
         n = c.min(c.sub(c.exp(c.neg(r2)), 0.5), c.add(c.ln(c.add(r2, 0.05)), c.atan(c.mul(x, 4.0))))
-    else:               # tan / asin / acos: domains left on purpose in part of the boxes
+    elif which == 2:    # tan / asin / acos: domains left on purpose in part of the boxes
         n = c.max(c.sub(c.tan(c.mul(x, 1.3)), c.asin(c.mul(y, 1.4))), c.sub(c.acos(c.mul(z, 1.2)), 1.0))
+    elif which == 3:    # atan2 in its three operand forms (every sign case of y and x over the boxes, the whole circle where y has 0 and x < 0)
+        n = c.min(c.sub(c.atan2(y, x), c.mul(z, 2.0)), c.add(c.atan2(c.add(z, 0.1), 0.3), c.atan2(-0.2, c.sub(x, y))))
+    elif which == 4:    # modulo: a point divisor (reg % imm: the same-floor rule), an interval divisor with and without 0, imm % reg
+        n = c.max(c.sub(c.modulo(c.mul(x, 3.0), 0.7), 0.3), c.min(c.modulo(y, c.add(z, 1.5)), c.modulo(2.5, c.add(c.square(x), 0.25))))
+    elif which == 5:    # rand: the point where the operand is ONE bit pattern (floor of a narrow interval), [0, 1] elsewhere
+        fx = c.floor(c.mul(x, 0.4))
+        n = c.min(c.sub(c.add(c.rand(fx), c.mul(c.rand(y), z)), 0.6), c.sub(c.rand(c.floor(c.add(c.mul(z, 3.0), 0.5))), 0.5))
+    else:               # mix in its three operand forms: points where both operands are one bit pattern, NaN in the other lanes
+        fx, fy, fz = c.floor(c.mul(x, 0.4)), c.floor(c.mul(y, 0.3)), c.floor(c.add(c.mul(z, 0.2), 0.5))
+        n = c.sub(c.add(c.mul(c.mix(fy, 3.0), 1.0e-9), c.mul(c.mix(fz, fx), 1.0e-9)), c.mul(c.mix(2.0, fy), 1.0e-9))
     sh = F.Shape(c, n)
     ik = [3] * 16
     for a in range(3):
@@ -381,10 +394,10 @@ def trans_shape(which):
 
 
 @pytest.mark.parametrize("kernel", ["fh_tiles_t", "fh_tiles_v32_t", "fh_tiles_v64_t"])
-@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
 def test_transcendental_interval_handlers(kernel, which):
-    """the *_t tile kernels: interval sin cos tan asin acos atan exp ln (dev_ops.hpp iv_sincos .. iv_ln around the compiled f32
-    routines) - results, choices and pruned child tapes against the numpy restatement, small and large boxes (a box many periods wide
+    """the *_t tile kernels: interval sin cos tan asin acos atan exp ln and (round 5) atan2 / modulo / rand / mix (dev_ops.hpp iv_sincos ..
+    iv_ln, iv_atan2, iv_rem_euclid, iv_rand, iv_mix around the compiled f32 routines) - results, choices and pruned child tapes against the numpy restatement, small and large boxes (a box many periods wide
     is [-1, 1]; one inside a quadrant is monotonic; domains of asin / acos / ln / tan left in some children)"""
     sh, tape, ik = trans_shape(which)
     if sh.slot_count() > LIMITS[kernel][0] or sh.choice_count() > LIMITS[kernel][1]:
