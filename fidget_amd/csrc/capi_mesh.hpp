@@ -433,14 +433,14 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     const double t_start = now();
     double t_cells = 0, t_leaf = 0, t_copy = 0;
     DevBuf& leaves = ctx->mesh_leaves;      // (kept with the context between builds)
-    DevBuf bufs[2], counters, table, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals, sub_ops, sub_tab, sub_choices;
+    DevBuf bufs[2], counters, table, d_cls, d_slot, edge_list, edge_count, edge_br, edge_vars, edge_vals, sub_ops, sub_tab, sub_choices, sub_ops2, sub_tab2;
     std::vector<DevBuf> lv_cls, lv_slot, lv_amb;        // dev_asm: every level's classes, slots and ambiguous cells stay
     if (dev_asm) { lv_cls.resize(depth + 1); lv_slot.resize(depth + 1); lv_amb.resize(depth + 1); }
     std::vector<uint32_t> lv_n_amb;
     auto cleanup = [&] {
         bufs[0].release(); bufs[1].release(); counters.release(); table.release(); d_cls.release(); d_slot.release();
         edge_list.release(); edge_count.release(); edge_br.release(); edge_vars.release(); edge_vals.release();
-        sub_ops.release(); sub_tab.release(); sub_choices.release();
+        sub_ops.release(); sub_tab.release(); sub_choices.release(); sub_ops2.release(); sub_tab2.release();
         for (auto* v : {&lv_cls, &lv_slot, &lv_amb}) for (DevBuf& b : *v) b.release();
     };
 #define MESH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete M; return fail(ctx, FHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -455,6 +455,11 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
     // prospero.vm's 6 363 ops are down to a few hundred - or two above the leaves of a shallower octree)
     const uint32_t split_level = (ctx->opt.mesh_simplify_min_ops > 0 && t.ops.size() >= (size_t)ctx->opt.mesh_simplify_min_ops && t.n_choices > 0 && depth >= 3)
                                      ? std::min<uint32_t>(4, depth - 2) : 0;
+    // ... and once more at depth - 2 (at most level 7: a table of 8^7 entries), from the first split's tapes, when the first one was taken:
+    // prospero.vm's level-4 tapes still hold ~600 ops, and the leaf samples of a depth-8 build walked them 16 M times
+    const uint32_t split_level2 = (split_level == 4 && depth >= 7) ? std::min<uint32_t>(7, depth - 2) : 0;
+    std::vector<fh::HostTape> sub_keep;           // the first split's tapes, by table index (kept for the second)
+    std::vector<int32_t> sub_of;                  // first-split table index -> index into sub_keep, -1: the root tape
     uint32_t n_in = 1;      // cells in bufs[cur] to evaluate (level 0) or whose 8 children to evaluate
     int cur = 0;
     uint32_t n_leaf_cells = 0;
@@ -509,6 +514,7 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
             const size_t n_tab = (size_t)1 << (3 * split_level);
             std::vector<uint2> tab(n_tab, make_uint2(0, 0));
             std::vector<uint64_t> ops;
+            sub_of.assign(n_tab, -1);
             for (uint32_t j = 0; j < na; j++) {
                 if (!ok[j] || sub[j].ops.empty() || sub[j].ops.size() >= t.ops.size()) continue;     // (nothing gained: the root tape)
                 const uint64_t idx = amb[j].path - ((uint64_t)1 << (3 * split_level));
@@ -516,13 +522,14 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                 tab[(size_t)idx] = make_uint2((uint32_t)ops.size(), (uint32_t)sub[j].ops.size());
                 ops.insert(ops.end(), sub[j].ops.begin(), sub[j].ops.end());
                 M->sub_tapes++; M->sub_ops += sub[j].ops.size();
+                if (split_level2) { sub_of[(size_t)idx] = (int32_t)sub_keep.size(); sub_keep.push_back(std::move(sub[j])); }
             }
             // ... where it pays: the lanes of a wave then walk tapes of their own through the generic interpreter, and a tape that fits the
             // assembly bulk interpreter (<= 32 registers) gives that up for its leaf samples - bear.vm's smooth blend keeps 3/4 of its ops
             // at this level and meshes twice as fast WITHOUT (measured, profiles/r04g); prospero.vm keeps 1/20 and gains 16x
             const double kept = M->sub_tapes ? (double)M->sub_ops / ((double)M->sub_tapes * (double)t.ops.size()) : 1.0;
             const bool bulk_capable = ctx->use_asm && P.n_regs <= 32;
-            if (kept >= (bulk_capable ? 0.25 : 0.75)) { ops.clear(); M->sub_skipped = M->sub_tapes; M->sub_tapes = 0; }
+            if (kept >= (bulk_capable ? 0.25 : 0.75)) { ops.clear(); M->sub_skipped = M->sub_tapes; M->sub_tapes = 0; sub_keep.clear(); }
             if (!ops.empty()) {
                 MESH_TRY(sub_ops.ensure(ops.size() * 8));
                 MESH_TRY(sub_tab.ensure(n_tab * sizeof(uint2)));
@@ -530,6 +537,57 @@ static fhip_status mesh_run(fhip_ctx* ctx, const fhip_tape* tape, uint32_t depth
                 MESH_TRY(hipMemcpyAsync(sub_tab.p, tab.data(), n_tab * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
                 MESH_TRY(hipStreamSynchronize(ctx->stream));
                 P.sub_ops = (const uint64_t*)sub_ops.p; P.sub_tab = (const uint2*)sub_tab.p; P.split_level = split_level;
+            }
+        }
+        // (only where the first split left tapes worth pruning again: 128 ops on average - colonnade.vm's are ~50 and a second split cost it 20 %)
+        if (d == split_level2 && split_level2 > 0 && P.sub_tab && !sub_keep.empty() && M->sub_ops >= 128 * M->sub_tapes) {
+            // The second split: the choices of every ambiguous cell of this level over the tape it inherited (its level-4 ancestor's),
+            // VmData::simplify of THAT tape under them, a second table for everything below.
+            const uint32_t na = c[0];
+            uint32_t nch = 1;
+            for (const fh::HostTape& st : sub_keep) nch = std::max(nch, st.n_choices);
+            if ((size_t)na * nch <= ((size_t)3 << 30)) {
+                MESH_TRY(sub_choices.ensure((size_t)na * nch));
+                hipLaunchKernelGGL(fhm::k_mesh_choices, dim3((na + WAVE - 1) / WAVE), dim3(WAVE), lds_iv, ctx->stream, P, (const FhMeshCell*)out_cells.p, na, nch, (uint8_t*)sub_choices.p);
+                MESH_TRY(hipGetLastError());
+                std::vector<uint8_t> ch((size_t)na * nch);
+                std::vector<FhMeshCell> amb(na);
+                MESH_TRY(hipMemcpyAsync(ch.data(), sub_choices.p, ch.size(), hipMemcpyDeviceToHost, ctx->stream));
+                MESH_TRY(hipMemcpyAsync(amb.data(), out_cells.p, (size_t)na * sizeof(FhMeshCell), hipMemcpyDeviceToHost, ctx->stream));
+                MESH_TRY(hipStreamSynchronize(ctx->stream));
+                std::vector<fh::HostTape> sub2(na);
+                std::vector<uint8_t> ok(na, 0);
+                const int up = 3 * (int)(split_level2 - split_level);
+                const uint64_t base1 = (uint64_t)1 << (3 * split_level);
+                fhmesh::parallel_for(na, [&](size_t j) {
+                    const uint64_t i1 = (amb[j].path >> up) - base1;
+                    const int32_t k1 = i1 < sub_of.size() ? sub_of[(size_t)i1] : -1;
+                    if (k1 < 0) return;          // (its ancestor kept the root tape: so does it)
+                    const fh::HostTape& parent = sub_keep[(size_t)k1];
+                    ok[j] = simplify_host(parent, ch.data() + j * nch, sub2[j]) && !sub2[j].ops.empty() && sub2[j].ops.size() < parent.ops.size() ? 1 : 0;
+                });
+                const size_t n_tab2 = (size_t)1 << (3 * split_level2);
+                std::vector<uint2> tab2(n_tab2, make_uint2(0, 0));
+                std::vector<uint64_t> ops2;
+                uint64_t n2 = 0;
+                for (uint32_t j = 0; j < na; j++) {
+                    if (!ok[j]) continue;
+                    const uint64_t idx = amb[j].path - ((uint64_t)1 << (3 * split_level2));
+                    if (idx >= n_tab2 || ops2.size() + sub2[j].ops.size() >= ((size_t)1 << 32)) continue;
+                    tab2[(size_t)idx] = make_uint2((uint32_t)ops2.size(), (uint32_t)sub2[j].ops.size());
+                    ops2.insert(ops2.end(), sub2[j].ops.begin(), sub2[j].ops.end());
+                    n2++;
+                }
+                if (!ops2.empty()) {
+                    MESH_TRY(sub_ops2.ensure(ops2.size() * 8));
+                    MESH_TRY(sub_tab2.ensure(n_tab2 * sizeof(uint2)));
+                    MESH_TRY(hipMemcpyAsync(sub_ops2.p, ops2.data(), ops2.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                    MESH_TRY(hipMemcpyAsync(sub_tab2.p, tab2.data(), n_tab2 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+                    MESH_TRY(hipStreamSynchronize(ctx->stream));
+                    P.sub_ops2 = (const uint64_t*)sub_ops2.p; P.sub_tab2 = (const uint2*)sub_tab2.p; P.split_level2 = split_level2;
+                    if (times) fprintf(stderr, "fhip mesh: tape simplified again at level %u: %llu cells with tapes of their own, %.1f ops on average\n", split_level2,
+                                       (unsigned long long)n2, (double)ops2.size() / (double)n2);
+                }
             }
         }
     }

@@ -44,6 +44,12 @@ struct FhMeshParams {
     const uint64_t* sub_ops;
     const uint2* sub_tab;
     uint32_t split_level, pad_;
+    // ... and a second time, further down (round 5: split_level2 = depth - 2, at most 7): the cells of that level get their ancestor's tape
+    // simplified once more under their own choices - a 4^3-times smaller region, tapes a few times shorter again - for the levels and the leaf
+    // samples below.  Same layout; an entry without a tape of its own (ops == 0) falls back to the first table.
+    const uint64_t* sub_ops2;
+    const uint2* sub_tab2;
+    uint32_t split_level2, pad2_;
 };
 
 namespace fhm {
@@ -55,6 +61,13 @@ using fhmesh::lerp_pos;
 __device__ __forceinline__ void mesh_tape(const FhMeshParams& P, uint64_t path, const uint64_t*& ops, uint32_t& len) {
     ops = P.tape; len = P.len;
     if (!P.sub_tab) return;
+    if (P.sub_tab2) {
+        const int up2 = (63 - __clzll((long long)path)) - 3 * (int)P.split_level2;
+        if (up2 > 0) {
+            const uint2 e2 = P.sub_tab2[(uint32_t)((path >> up2) - (1ull << (3 * P.split_level2)))];
+            if (e2.y) { ops = P.sub_ops2 + e2.x; len = e2.y; return; }
+        }
+    }
     const int up = (63 - __clzll((long long)path)) - 3 * (int)P.split_level;
     if (up <= 0) return;          // (at the split level itself a cell is still evaluated with the tape it inherited)
     const uint2 e = P.sub_tab[(uint32_t)((path >> up) - (1ull << (3 * P.split_level)))];
@@ -135,12 +148,17 @@ __global__ void __launch_bounds__(WAVE) k_mesh_choices(FhMeshParams P, const FhM
     Regs<IV, WAVE> R{(IV*)smem, lane};
     uint8_t* const mine = choices + (size_t)min(i, n - 1) * n_choices;
     uint32_t ci = 0;
+    auto in_iv = [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); };
+    if (P.sub_tab) {       // (the second split: every lane the choices of the tape its cell inherited - the first split's; n_choices = the row length)
+        const uint64_t* ops; uint32_t len;
+        mesh_tape(P, c.path, ops, len);
+        for (uint32_t k = 0; k < len; k++)
+            step<IVAL, WAVE, true>(ops[k], R, in_iv, [&](uint32_t, IV) {}, [&](int ch) { if (i < n && ci < n_choices) mine[ci] = (uint8_t)ch; ci++; });
+        return;
+    }
     const ctape_t tape = (ctape_t)P.tape;
     for (uint32_t k = 0; k < P.len; k++) {
-        step<IVAL, WAVE, true>(
-            tape[k], R,
-            [&](uint32_t slot) { const uint32_t kd = P.in_kind[slot]; return kd == 0 ? X : (kd == 1 ? Y : (kd == 2 ? Z : iv1(P.in_value[slot]))); },
-            [&](uint32_t, IV) {}, [&](int ch) { if (i < n) mine[ci] = (uint8_t)ch; ci++; });
+        step<IVAL, WAVE, true>(tape[k], R, in_iv, [&](uint32_t, IV) {}, [&](int ch) { if (i < n) mine[ci] = (uint8_t)ch; ci++; });
     }
 }
 
