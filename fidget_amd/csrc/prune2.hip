@@ -42,7 +42,8 @@
 
 #include "render_state.h"
 
-#define FH_P2_WPB 4                                             // level 0: waves per workgroup (one per SIMD: the sequential step is scalar code)
+#define FH_P2_WPB 4                                             // children per workgroup (they share the parent's links in LDS)
+#define FH_P2_WPC 4                                             // waves per child (the phases that are parallel over the tape; B1 and B3 are one wave's)
 #define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // ... workgroups per slot (the last one's spare waves idle)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
@@ -59,7 +60,7 @@ enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4,
 // bytes of LDS per wave: wanted-op mask (128 x 8), position prefixes (128 x 2), E (2 per choice), kept-op records (8 each), last
 // uses (4 each), registers by position (1 each), registers returning at a position (2 each)
 static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices, uint32_t cap_kept = FH_P2_MAX_KEPT) {
-    return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)cap_kept * (8 + 4 + 1 + 2) + 64;
+    return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)cap_kept * (8 + 4 + 1 + 2) + 64;       // (the last 64: FH_P2_WPC waves' shared words)
 }
 
 namespace fhp2 {
@@ -152,19 +153,35 @@ __device__ __forceinline__ void p2_scan_batch(uint32_t d, uint32_t& fr, uint32_t
 // Tape groups, level 0: slot = block * n_tgroups, choice words S->chwr (k_tscatter3d) with `cw_stride` words per slot, links / ctab:
 // the root tape's (device copies made with the tape).  cap_ops / cap_choices / cap_kept size the LDS areas (links, E, per kept op
 // records).  `flags` bit 1: profiled frames record the slowest child's shader clocks per phase.
-// One work item: the (up to) blockDim / 64 children `blk` % per_slot of slot `blk` / per_slot.
+// One work item: the (up to) FH_P2_WPB children `blk` % per_slot of slot `blk` / per_slot, FH_P2_WPC waves each.
+//
+// Several waves per child (round 5).  A child used to be ONE wave, alone on its SIMD: 0.19 ms of instruction latency whatever the number
+// of children, the longest kernel of a frame once level 1 was gone.  What of the work is parallel over the tape is now shared by the
+// child's FH_P2_WPC waves (workgroup barriers in between; every wave of the workgroup passes every barrier, a child that is not
+// marked - or drops out: too many kept ops, too many registers - idles through them):
+//   A  in two passes: every wave resolves the batches of 64 ordinals it owns WITHOUT looking outside the batch (a pointer out of
+//      the batch stays a pointer), then one wave walks the batches in order and replaces what is still a pointer by its target's
+//      entry, final by then - one look-up per batch instead of the six jumping rounds;
+//   B1 liveness: one wave (a sweep from the end of the tape: every batch needs the marks of the batches behind it);
+//   B2 positions / operand positions / last uses: batches shared out; B3 the register scan: one wave; B4 emission: shared out.
 __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
                                         const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
                                         uint32_t blk, char* smem) {
     using namespace fhp2;
+    constexpr uint32_t W = FH_P2_WPC;
     const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the sequential step branches on is made wave-uniform explicitly)
-    const uint32_t wpb = blockDim.x >> 6, per_slot = (64 + wpb - 1) / wpb;
+    const uint32_t wpb = FH_P2_WPB, per_slot = (64 + wpb - 1) / wpb;
+    const uint32_t kid = wave / W, sub = wave % W, tid = sub * 64 + lane;       // child of this workgroup, wave of that child, thread of that child
+    // (the wave that runs a child's sequential phases: wave `kid` of the child, so that the workgroup's four leaders sit on four
+    // different SIMDs - consecutive waves of a workgroup go round the SIMDs, and with wave 0 of every child as the leader all four shared
+    // SIMD 0 while the others idled at the barrier: B3 took 1.5 x as long as with one wave per child)
+    const bool lead = sub == kid % W;
     const uint32_t sidx = blk / per_slot;
     const uint32_t G = rfl(S->n_tgroups);
     if (sidx * G >= rfl(S->n_slots[big][level])) return;
     FhSlot& sl = S->slots[big][(size_t)sidx * G];
     if (sl.act == 0) return;
-    const uint32_t c0 = (blk % per_slot) * wpb, c = c0 + wave;      // this wave's child lane
+    const uint32_t c0 = (blk % per_slot) * wpb, c = c0 + kid;      // this wave's child lane
     {   // any of this workgroup's children marked for the prune?  (c_len == ~0: k_tmark3d / the export mode of the forward kernels)
         bool any = false;
         for (uint32_t k = 0; k < wpb; k++) any |= c0 + k < 64 && sl.c_len[c0 + k] == 0xFFFFFFFFu;
@@ -175,7 +192,7 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     const uint2* const ops = (const uint2*)(S->arena + off);
     uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lks[i] = links[i];
-    char* const mine = smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)wave * fh_p2_wave_lds(cap_choices, cap_kept);
+    char* const mine = smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)kid * fh_p2_wave_lds(cap_choices, cap_kept);
     uint64_t* const mask = (uint64_t*)mine;                               // wanted ops, 64 per word (128 words)
     uint16_t* const pref = (uint16_t*)(mine + 1024);                    // kept ops before each word
     uint16_t* const E = (uint16_t*)(mine + 1280);                       // per choice: the op its value is (| FH_LK_IMM)
@@ -183,24 +200,27 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     uint32_t* const lastuse = (uint32_t*)((char*)comp + (size_t)cap_kept * 8);
     uint8_t* const regb = (uint8_t*)((char*)lastuse + (size_t)cap_kept * 4);
     uint8_t* const frees = regb + (size_t)cap_kept;                       // registers that return at a time: bytes [2 t], [2 t + 1] (operand a / b of op t; 0xFF none)
+    uint32_t* const red = (uint32_t*)(frees + (size_t)cap_kept * 2);     // [0] kept ops m (B2), [1] highest register + 1, [2] kept choices (B4), [3] 0: the child goes on (the area's last 64 bytes)
     const uint32_t nw = (n + 63) >> 6;
+    bool on = c < 64 && rfl(sl.c_len[min(c, 63u)]) == 0xFFFFFFFFu;    // marked for the prune; false: this wave only keeps the barriers company
+    if (on && tid < 4) red[tid] = 0;
+    const uint32_t* const cws = S->chwr + (size_t)sidx * G * cw_stride * 64;
+    uint32_t* const cwl = (uint32_t*)comp;       // (the child's choice words, staged where the kept-op records go later: one load latency for all)
+    if (on) for (uint32_t k = tid; k < (nch + 15) / 16; k += 64 * W) cwl[k] = cws[(size_t)k * 64 + c];
     __syncthreads();
-    if (c >= 64 || rfl(sl.c_len[c]) != 0xFFFFFFFFu) return;             // not marked for the prune
 
-    const bool probe = S->want_stats != 0 && (flags & 2u) != 0;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
+    const bool probe = S->want_stats != 0 && (flags & 2u) != 0 && lead;      // (profiled frames: the slowest child's shader clocks per phase, leaf_stat[4..7])
     const uint64_t t_a = probe ? clock64() : 0;
     // ---- A: what every choice op's value is -------------------------------------------------------------------------------------
-    // 64 ordinals at a time, in tape order: an operand's producer has a lower ordinal, so a pointer out of the batch lands on a
-    // final entry, and pointers inside the batch are followed by six rounds of jumping between lanes.
-    {
-        const uint32_t* const cws = S->chwr + (size_t)sidx * G * cw_stride * 64;
-        uint32_t* const cwl = (uint32_t*)comp;       // (the child's choice words, staged where the kept-op records go later: one load latency for all)
-        for (uint32_t k = lane; k < (nch + 15) / 16; k += 64) cwl[k] = cws[(size_t)k * 64 + c];
-        uint2 tn = lane < nch ? ctab[lane] : make_uint2(0, 0);
-        for (uint32_t q0 = 0; q0 < nch; q0 += 64) {
-            const uint32_t q = q0 + lane;
+    // pass 1, batches of 64 ordinals shared out over the child's waves: pointers inside the batch are followed by jumping between lanes (a
+    // producer has a lower ordinal: at most six rounds), pointers out of it are left standing
+    if (on) {
+        const uint32_t nb = (nch + 63) >> 6;
+        uint2 tn = (sub * 64 + lane) < nch ? ctab[sub * 64 + lane] : make_uint2(0, 0);
+        for (uint32_t bi = sub; bi < nb; bi += W) {
+            const uint32_t q0 = bi << 6, q = q0 + lane;
             const uint2 t = tn;
-            if (q + 64 < nch) tn = ctab[q + 64];      // (the next batch's entries arrive while this one is resolved)
+            if (q + 64 * W < nch) tn = ctab[q + 64 * W];      // (the wave's next batch arrives while this one is resolved)
             uint32_t e = 0;
             if (q < nch) {
                 const uint32_t i = t.y & 0xFFFFu, kind = t.y >> 16;
@@ -208,15 +228,29 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
                 if (ch == FH_CHOICE_LEFT) e = t.x & 0xFFFFu;
                 else if (ch == FH_CHOICE_RIGHT) e = kind == FH_LK_CRR ? t.x >> 16 : (i | FH_LK_IMM);
                 else e = i;
-                if ((e & FH_LK_CHOICE) && (e & 0x7FFFu) < q0) e = E[e & 0x7FFFu];     // out of the batch: final
             }
-            for (int round = 0; round < 6 && __ballot((e & FH_LK_CHOICE) != 0) != 0; round++) {
+            // (0xFFFF - no operand - never comes out of a choice table entry that is taken: a choice's operands exist)
+            for (int round = 0; round < 6; round++) {
+                const bool inside = (e & FH_LK_CHOICE) != 0 && (e & 0x7FFFu) >= q0;
+                if (__ballot(inside) == 0) break;
                 const uint32_t t2 = __shfl(e, (int)((e & 0x7FFFu) - q0) & 63, 64);
-                if (e & FH_LK_CHOICE) e = t2;
+                if (inside) e = t2;
             }
             if (q < nch) E[q] = (uint16_t)e;
         }
     }
+    __syncthreads();
+    // pass 2, one wave, batches in order: what still points out of its batch points at an entry that is final by now
+    if (on && lead) {
+        for (uint32_t q0 = 0; q0 < nch; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const uint32_t e = q < nch ? (uint32_t)E[q] : 0u;
+            const bool ptr = (e & FH_LK_CHOICE) != 0;
+            if (__ballot(ptr) == 0) continue;
+            if (ptr) E[q] = E[e & 0x7FFFu];
+        }
+    }
+    __syncthreads();
     // The ops a kept op's operands really come from (its link in l).  The three E entries it may need - its own choice's (a reg,imm
     // choice that became its immediate has no operands), its operands' producers' when those are choices - are loaded together.
     auto resolve = [&](uint2 l, bool& has_a, bool& has_b, bool& imm, uint32_t& ta, uint32_t& tb) {
@@ -232,63 +266,72 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     };
 
     const uint64_t t_b1 = probe ? clock64() : 0;
-    // ---- B1: liveness -----------------------------------------------------------------------------------------------------------
-    for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
-    for (uint32_t b = nw; b-- > 0;) {
-        const uint32_t i = (b << 6) | lane;
-        const uint2 l = i < n ? lks[i] : make_uint2(FH_LK_NONE << 8, 0xFFFFFFFFu);      // (read beside the mask word: one wait for both)
-        uint64_t word = rfl64(mask[b]);
-        if (word == 0) continue;
-        bool has_a, has_b, imm;
-        uint32_t ta, tb;
-        resolve(l, has_a, has_b, imm, ta, tb);
-        uint64_t done = 0;
-        for (;;) {
-            const uint64_t newly = word & ~done;
-            if (newly == 0) break;
-            const bool my = (newly >> lane) & 1;
-            if (my && has_a) atomicOr((unsigned long long*)&mask[ta >> 6], 1ull << (ta & 63));
-            if (my && has_b) atomicOr((unsigned long long*)&mask[tb >> 6], 1ull << (tb & 63));
-            done |= newly;
-            // a producer inside this batch: one more round (otherwise nothing else can mark this batch any more)
-            if (__ballot(my && ((has_a && (ta >> 6) == b) || (has_b && (tb >> 6) == b))) == 0) break;
-            word = rfl64(mask[b]);
-        }
-    }
-    const uint64_t t_b2 = probe ? clock64() : 0;
-    // ---- B2: positions, operand positions, last uses ----------------------------------------------------------------------------
-    uint32_t m;
-    {
-        const uint32_t c0 = lane < nw ? (uint32_t)__popcll(mask[lane]) : 0u, c1 = lane + 64 < nw ? (uint32_t)__popcll(mask[lane + 64]) : 0u;
-        uint32_t t0, t1;
-        const uint32_t e0 = excl_sum(c0, lane, t0), e1 = excl_sum(c1, lane, t1);
-        pref[lane] = (uint16_t)e0; pref[lane + 64] = (uint16_t)(t0 + e1);
-        m = rfl(t0 + t1);
-    }
-    if (m > cap_kept) { if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32); return; }          // (left marked: the scalar sweep launched behind this kernel takes it)
-    for (uint32_t k = lane; k < m; k += 64) { lastuse[k] = 0; ((uint16_t*)frees)[k] = 0; }
-    auto pos_of = [&](uint32_t t) -> uint32_t { return (uint32_t)pref[t >> 6] + (uint32_t)__popcll(mask[t >> 6] & ((1ull << (t & 63)) - 1)); };
-    for (uint32_t b = 0; b < nw; b++) {
-        const uint64_t word = rfl64(mask[b]);
-        if (word == 0) continue;
-        if ((word >> lane) & 1) {
+    // ---- B1: liveness (one wave) ---------------------------------------------------------------------------------------------------
+    if (on && lead) {
+        for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
+        for (uint32_t b = nw; b-- > 0;) {
             const uint32_t i = (b << 6) | lane;
-            const uint32_t p = (uint32_t)pref[b] + (uint32_t)__popcll(word & ((1ull << lane) - 1));
-            const uint2 l = lks[i];
+            const uint2 l = i < n ? lks[i] : make_uint2(FH_LK_NONE << 8, 0xFFFFFFFFu);      // (read beside the mask word: one wait for both)
+            uint64_t word = rfl64(mask[b]);
+            if (word == 0) continue;
             bool has_a, has_b, imm;
             uint32_t ta, tb;
             resolve(l, has_a, has_b, imm, ta, tb);
-            const uint32_t kind = (l.x >> 8) & 0xFFu;
-            uint32_t pa = 0, pb = 0;
-            if (has_a) { pa = pos_of(ta); atomicMax(&lastuse[pa], p); }
-            if (has_b) { pb = pos_of(tb); atomicMax(&lastuse[pb], p); }
-            // flags: 0 has a, 1 has b, 2 became its immediate, 3 a kept choice, 4 the OUTPUT op
-            const uint32_t flags = (has_a ? 1u : 0u) | (has_b ? 2u : 0u) | (imm ? 4u : 0u) | ((kind >= FH_LK_CRR && !imm) ? 8u : 0u) | (kind == FH_LK_OUT ? 16u : 0u);
-            comp[p] = make_uint2(pa | (pb << 16), i | (flags << 16));
+            uint64_t done = 0;
+            for (;;) {
+                const uint64_t newly = word & ~done;
+                if (newly == 0) break;
+                const bool my = (newly >> lane) & 1;
+                if (my && has_a) atomicOr((unsigned long long*)&mask[ta >> 6], 1ull << (ta & 63));
+                if (my && has_b) atomicOr((unsigned long long*)&mask[tb >> 6], 1ull << (tb & 63));
+                done |= newly;
+                // a producer inside this batch: one more round (otherwise nothing else can mark this batch any more)
+                if (__ballot(my && ((has_a && (ta >> 6) == b) || (has_b && (tb >> 6) == b))) == 0) break;
+                word = rfl64(mask[b]);
+            }
+        }
+        // positions of the words' first kept ops (B2 needs them all)
+        const uint32_t k0 = lane < nw ? (uint32_t)__popcll(mask[lane]) : 0u, k1 = lane + 64 < nw ? (uint32_t)__popcll(mask[lane + 64]) : 0u;
+        uint32_t t0, t1;
+        const uint32_t e0 = excl_sum(k0, lane, t0), e1 = excl_sum(k1, lane, t1);
+        pref[lane] = (uint16_t)e0; pref[lane + 64] = (uint16_t)(t0 + e1);
+        if (lane == 0) { red[0] = t0 + t1; if (t0 + t1 > cap_kept) red[3] = 1; }
+    }
+    __syncthreads();
+    const uint64_t t_b2 = probe ? clock64() : 0;
+    // ---- B2: positions, operand positions, last uses (batches shared out) -----------------------------------------------------------
+    const uint32_t m = on ? rfl(red[0]) : 0u;
+    if (on && rfl(red[3]) != 0) {          // (more kept ops than the areas hold: left marked, the scalar sweep launched behind this kernel takes it)
+        if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32);
+        on = false;
+    }
+    if (on) for (uint32_t k = tid; k < m; k += 64 * W) { lastuse[k] = 0; ((uint16_t*)frees)[k] = 0; }
+    __syncthreads();
+    auto pos_of = [&](uint32_t t) -> uint32_t { return (uint32_t)pref[t >> 6] + (uint32_t)__popcll(mask[t >> 6] & ((1ull << (t & 63)) - 1)); };
+    if (on) {
+        for (uint32_t b = sub; b < nw; b += W) {
+            const uint64_t word = rfl64(mask[b]);
+            if (word == 0) continue;
+            if ((word >> lane) & 1) {
+                const uint32_t i = (b << 6) | lane;
+                const uint32_t p = (uint32_t)pref[b] + (uint32_t)__popcll(word & ((1ull << lane) - 1));
+                const uint2 l = lks[i];
+                bool has_a, has_b, imm;
+                uint32_t ta, tb;
+                resolve(l, has_a, has_b, imm, ta, tb);
+                const uint32_t kind = (l.x >> 8) & 0xFFu;
+                uint32_t pa = 0, pb = 0;
+                if (has_a) { pa = pos_of(ta); atomicMax(&lastuse[pa], p); }
+                if (has_b) { pb = pos_of(tb); atomicMax(&lastuse[pb], p); }
+                // flags: 0 has a, 1 has b, 2 became its immediate, 3 a kept choice, 4 the OUTPUT op
+                const uint32_t fl = (has_a ? 1u : 0u) | (has_b ? 2u : 0u) | (imm ? 4u : 0u) | ((kind >= FH_LK_CRR && !imm) ? 8u : 0u) | (kind == FH_LK_OUT ? 16u : 0u);
+                comp[p] = make_uint2(pa | (pb << 16), i | (fl << 16));
+            }
         }
     }
+    __syncthreads();
     const uint64_t t_b3 = probe ? clock64() : 0;
-    // ---- B3: registers, in tape order over the kept ops -----------------------------------------------------------------------------
+    // ---- B3: registers, in tape order over the kept ops (one wave) ------------------------------------------------------------------
     // Linear scan with the look-ups taken out of the loop: a value's register is not looked up when an op reads it (that is
     // done for all ops at once afterwards) - what the sequential step needs is only WHEN registers come back.  A value knows its
     // last use u from B2 and which operand of op u it is; when it gets its register r, "free r" is posted to time u (slot a or b
@@ -296,55 +339,64 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     // to it, takes the lowest free one for its own value and posts that.  ~30 scalar / cross-lane instructions per kept op, no
     // memory wait.  Registers 0 .. 63 only: a child that wants more is left to the scalar sweep.
     // The loop itself is assembly (p2_scan_batch): 33 instructions per kept op against the compiler's ~55, one taken branch.
-    uint64_t pool = ~0ull;
-    uint32_t maxro = 0;
-    const uint32_t frees_lds = (uint32_t)((char*)frees - smem);        // (the dynamic LDS area starts at LDS address 0: no static __shared__ here)
-    for (uint32_t base = 0; base < m; base += 64) {
-        const uint32_t pl = base + lane;
-        uint32_t vd = 16u << 24, vfr = 0;               // (lanes past the end: an OUTPUT-like no-op)
-        if (pl < m) {
-            const uint32_t u = lastuse[pl];                               // last use of this op's value (0 for the OUTPUT op)
-            const uint32_t slot = u ? ((comp[u].x & 0xFFFFu) == pl ? 0u : 1u) : 0u;
-            vd = u | (slot << 16) | ((comp[pl].y >> 16) << 24);           // ... which operand of that op it is, this op's flags
-            vfr = ((const uint16_t*)frees)[pl];                          // registers posted to this time by earlier batches (a | b << 8; each 0x40 | register, or 0)
+    if (on && lead) {
+        uint64_t pool = ~0ull;
+        uint32_t maxro = 0;
+        const uint32_t frees_lds = (uint32_t)((char*)frees - smem);        // (the dynamic LDS area starts at LDS address 0: no static __shared__ here)
+        for (uint32_t base = 0; base < m; base += 64) {
+            const uint32_t pl = base + lane;
+            uint32_t vd = 16u << 24, vfr = 0;               // (lanes past the end: an OUTPUT-like no-op)
+            if (pl < m) {
+                const uint32_t u = lastuse[pl];                               // last use of this op's value (0 for the OUTPUT op)
+                const uint32_t slot = u ? ((comp[u].x & 0xFFFFu) == pl ? 0u : 1u) : 0u;
+                vd = u | (slot << 16) | ((comp[pl].y >> 16) << 24);           // ... which operand of that op it is, this op's flags
+                vfr = ((const uint16_t*)frees)[pl];                          // registers posted to this time by earlier batches (a | b << 8; each 0x40 | register, or 0)
+            }
+            const uint32_t cnt = min(64u, m - base);
+            uint32_t outv = 0;
+            p2_scan_batch(vd, vfr, outv, pool, maxro, cnt, base >> 6, frees_lds);
+            if (pl < m) regb[pl] = (uint8_t)outv;
         }
-        const uint32_t cnt = min(64u, m - base);
-        uint32_t outv = 0;
-        p2_scan_batch(vd, vfr, outv, pool, maxro, cnt, base >> 6, frees_lds);
-        if (pl < m) regb[pl] = (uint8_t)outv;
+        if (maxro >= 64u) {          // more than 64 registers: left marked for the scalar sweep
+            if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); }
+            if (lane == 0) red[3] = 1;
+        }
     }
-    if (maxro >= 64u) { if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); } return; }          // more than 64 registers: left marked for the scalar sweep
-    // ---- B4: the child's ops, 64 at a time ----------------------------------------------------------------------------------------------
-    const uint32_t end = rfl(sl.c_off[c]);        // one past the child's last op (arena index); the child's slot is [end - n, end)
-    uint64_t* const dst = S->arena + (end - m);
-    uint32_t high = 0, kept = 0;
-    for (uint32_t pl = lane; pl < m; pl += 64) {
-        const uint2 cr = comp[pl];
-        const uint32_t fl = cr.y >> 16, i = cr.y & 0xFFFFu, pa = cr.x & 0xFFFFu, pb = cr.x >> 16;
-        const uint2 opw = ops[i];
-        const uint32_t ro = regb[pl], ra = (fl & 1u) ? regb[pa] : 0u, rb = (fl & 2u) ? regb[pb] : 0u;
-        uint64_t word;
-        if (fl & 4u) word = fh_pack(FH_COPY_IMM, ro, 0, 0, opw.y);
-        else if (fl & 16u) word = fh_pack(FH_OUTPUT, 0, ra, 0, opw.y);
-        else word = (uint64_t)((opw.x & 0xFFu) | (ro << 8) | (ra << 20)) | ((uint64_t)((fl & 2u) ? rb : opw.y) << 32);
-        dst[pl] = word;
-        high = max(high, (fl & 16u) ? 0u : ro + 1u);
-        kept += (fl >> 3) & 1u;
-    }
+    __syncthreads();
+    if (on && rfl(red[3]) != 0) on = false;
+    // ---- B4: the child's ops (shared out) ----------------------------------------------------------------------------------------------
+    const uint32_t end = on ? rfl(sl.c_off[c]) : 0u;        // one past the child's last op (arena index); the child's slot is [end - n, end)
+    if (on) {
+        uint64_t* const dst = S->arena + (end - m);
+        uint32_t high = 0, kept = 0;
+        for (uint32_t pl = tid; pl < m; pl += 64 * W) {
+            const uint2 cr = comp[pl];
+            const uint32_t fl = cr.y >> 16, i = cr.y & 0xFFFFu, pa = cr.x & 0xFFFFu, pb = cr.x >> 16;
+            const uint2 opw = ops[i];
+            const uint32_t ro = regb[pl], ra = (fl & 1u) ? regb[pa] : 0u, rb = (fl & 2u) ? regb[pb] : 0u;
+            uint64_t word;
+            if (fl & 4u) word = fh_pack(FH_COPY_IMM, ro, 0, 0, opw.y);
+            else if (fl & 16u) word = fh_pack(FH_OUTPUT, 0, ra, 0, opw.y);
+            else word = (uint64_t)((opw.x & 0xFFu) | (ro << 8) | (ra << 20)) | ((uint64_t)((fl & 2u) ? rb : opw.y) << 32);
+            dst[pl] = word;
+            high = max(high, (fl & 16u) ? 0u : ro + 1u);
+            kept += (fl >> 3) & 1u;
+        }
 #pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) { high = max(high, (uint32_t)__shfl_xor(high, dlt, 64)); kept += (uint32_t)__shfl_xor(kept, dlt, 64); }
-    if (probe && lane == 0) {
+        for (int dlt = 32; dlt > 0; dlt >>= 1) { high = max(high, (uint32_t)__shfl_xor(high, dlt, 64)); kept += (uint32_t)__shfl_xor(kept, dlt, 64); }
+        if (lane == 0) { atomicMax(&red[1], high); atomicAdd(&red[2], kept); }
+    }
+    __syncthreads();
+    if (probe && on && lane == 0) {
         const uint64_t t_e = clock64();
         atomicMax(&S->leaf_stat[4], (unsigned long long)(t_b1 - t_a)); atomicMax(&S->leaf_stat[5], (unsigned long long)(t_b2 - t_b1));
         atomicMax(&S->leaf_stat[6], (unsigned long long)(t_b3 - t_b2)); atomicMax(&S->leaf_stat[7], (unsigned long long)(t_e - t_b3));
     }
-    if (lane == 0) {
-        sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = high | (kept << 16);
-    }
+    if (on && lead && lane == 0) { sl.c_off[c] = end - m; sl.c_len[c] = m; sl.c_rc[c] = red[1] | (red[2] << 16); }
 }
 
 // grid: one workgroup per item (FH_P2_WPB children of one slot)
-__global__ void __launch_bounds__(256) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
+__global__ void __launch_bounds__(FH_P2_WPB * FH_P2_WPC * 64) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
                                                 const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     p2_item(S, level, big, cw_stride, links, ctab, flags, cap_ops, cap_choices, cap_kept, blockIdx.x, smem);
