@@ -441,7 +441,7 @@ def main():
         tb = None
         if t and "fetch_kb_per_frame" in t and "write_kb_per_frame" in t:
             tb = (2.0 * t["fetch_kb_per_frame"] + t["write_kb_per_frame"]) * 1024.0 / max(t["launches_per_frame"], 1)
-        r = {"bound": "hbm", "kernel": kernel, "path": path, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        r = {"bound": "hbm", "kernel": "k_prune2 (+ fh_prune1 behind it)" if kernel == "fh_prune1" else kernel, "path": path, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": achieved / HBM_PEAK_GBS, "traffic": tb,
              "algorithmic_bytes_per_launch": alg_bytes_per_frame / max(launches_pf, 1), "avg_launch_ms": per_frame_ms / max(launches_pf, 1),
              "launches_per_frame": launches_pf, "note": note}

@@ -84,7 +84,7 @@ real_kernarg = C.col_kernarg
 for general in (False, True):
     # prospero's leaf tapes read no z: the kernel takes them as column-invariant (one voxel per pixel).  `general`: the kernarg of
     # FHIP_NO_COLUMN_INV (every input counts as varying along the column) - all 512 voxels, what a tape with z in it gets
-    C.col_kernarg = (lambda a_st, in_kind, m: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(a_st, in_kind, m))) if general else real_kernarg
+    C.col_kernarg = (lambda a_st, in_kind, m, size=16: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(a_st, in_kind, m, size))) if general else real_kernarg
     for cls, leaves in sorted(by_class.items()):
         leaves.sort(key=lambda t: t[0])
         runs = []
