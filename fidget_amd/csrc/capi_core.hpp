@@ -62,8 +62,9 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     /* kernel selection (each falls back to the HIP C++ path of the same stage, which tapes outside the assembly set take anyway) */ \
     X(no_asm, 0) X(no_split, 0) X(no_asm_tiles, 0) X(no_tiles_v, 0) X(no_asm_tiles_t, 0) X(no_columns_t, 0) X(no_asm_normals, 0)   \
     X(no_tape_groups, 0) X(prune2, 1)                                                                                           \
-    /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level */ \
-    X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096)                                                                       \
+    /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level;     \
+       column_walk: the leaf kernel by footprint columns - 1 in frames whose tapes read no z, 0 never, 2 always */                  \
+    X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096) X(column_walk, 1)                                                     \
     /* pipelining and resources */                                                                                             \
     X(no_pipeline, 0) X(frame_sets, 4) X(frame_lanes, 4) X(lanes_tune, 1) X(lanes_fail, 0) X(slab_layers, 4) X(arena_mb, 4096)  \
     /* mesher */                                                                                                               \

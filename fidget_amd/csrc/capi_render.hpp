@@ -106,6 +106,12 @@ struct PartSpec {
 };
 // 3D: input slots of the axes, which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective
 // matrix), and whether the root tape reads any of them - from the camera matrix, the input binding and the tape alone (before prepare)
+// (temporary, for A/B runs on the GPU box: FHIP_DEBUG_BITS - 4: k_prune2's liveness as the sweep over the tape, 16: its register scan in the posting form, 8: the root tree's scan in chunks of 64)
+static uint32_t fh_debug_bits() {
+    static const uint32_t bits = [] { const char* v = getenv("FHIP_DEBUG_BITS"); return v ? (uint32_t)atoi(v) : 0u; }();
+    return bits;
+}
+
 static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P, RenderSetup& R) {
     uint32_t u[16];
     memcpy(u, P.mat, sizeof(u));
@@ -571,7 +577,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u | 8u; ka.skip_regs = ka.skip_choices = 0;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
             const uint32_t blocks = R.S.qcap[0], root_words = (R.S.troot_choices + 15) / 16, group_words = (R.group_choices + 15) / 16;
-            if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (R.S.top_chain && ((fh_debug_bits() & 8u) || R.S.n_top > 64u * FH_CHAIN_SEG)) hipLaunchKernelGGL(k_tchain3d_old, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            else if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
             else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             if (R.classify_only) return;       // (the fills of the decided tiles follow below; nothing is pruned or queued)
@@ -580,7 +587,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * FH_P2_WPC * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u, R.S.troot_len, R.S.troot_choices, R.p2_cap_kept);
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u | (fh_debug_bits() & 20u), R.S.troot_len, R.S.troot_choices, R.p2_cap_kept);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -1128,6 +1135,22 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 // along a pixel column (a z coefficient in the axis' matrix row, or a projective matrix), projective flag
                 const uint32_t blk = 4;   // footprints per workgroup: gen_interp.py FH_BLKL = 2
                 const uint32_t n_blocks = (R.n_footprints + blk - 1) / blk;
+                // Column walk (flags bit 20): one footprint COLUMN of the slab's leaf table per wave instead of one block of four footprints
+                // of one layer.  A frame whose tapes read nothing that changes along a pixel column queues at most one leaf per column
+                // and slab (the nearest of a stack), so its table is nearly empty - prospero 1024^3: 5.5 k leaves in 1 M entries - and
+                // the (blocks, layers) grid is 262 144 workgroups of which 98 % load four empty entries and leave: 66 of the launch's
+                // 71 us.  By columns it is 16 384 waves, each with its column's 64 entries in one load.  Leaves of a column are then
+                // taken one after the other by one wave, front to back, which is wrong for frames with a leaf in most layers (the
+                // launch would last as long as its fullest column: measured in round 3, bear.vm 2.40 -> 4.07 ms): option column_walk
+                // 1 = only where the tapes guarantee sparse columns, 0 never, 2 always (tests).
+                const bool by_columns = ctx->opt.column_walk == 2 || (ctx->opt.column_walk == 1 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0);
+                const uint32_t layers = P.slab / 8;
+                if (by_columns && layers <= 64) {
+                    struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags | (1u << 20), {0, 0}};
+                    const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
+                    (void)launch_asm(ctx, which, (R.n_footprints + 63) / 64 * 64, &ka, sizeof(ka), 0, 1, leaf_stream);
+                    return;
+                }
                 // (pad[0]: floor(2^32 / blocks per layer) - the kernel rotates a layer's blocks by a per-layer offset, which is what balances
                 // the launch, and takes the remainder by this reciprocal instead of a subtraction loop)
                 struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags,

@@ -919,7 +919,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
     BLKL = int(os.environ.get("FH_BLKL", "2"))   # footprints per work item: 4 (small enough to balance, large enough to skip empty space fast); capi.hip FH_COL_BLKL must agree
     BLK = 1 << BLKL
     # kernarg: { FhRenderState* S; u32 n_waves; u32 axis slots x | y << 8 | z << 16 (0xFF: the tape has no such input);
-    #            u32 inputs that change along a pixel column (bit per input slot); u32 flags (bit 16: projective matrix) }
+    #            u32 inputs that change along a pixel column (bit per input slot); u32 flags (bit 16: projective matrix; 20: column mode) }
     # - per frame constants the host works out once: 65 536 workgroups per launch each spent ~130 scalar instructions on them
     kernel_header(a, kname, 32, nvg)
     a(f"""
@@ -942,7 +942,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_bfe_i32 {S_SLOTY}, s49, 0x80008
 	s_bfe_i32 {S_SLOTZ}, s49, 0x80010
 	s_mov_b32 {S_DEPMASK}, s50
-	s_and_b32 s51, s51, 0xf0000                      ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column
+	s_and_b32 s51, s51, 0x1f0000                     ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column; 20: column mode
 	s_or_b32 {S_WGY}, {S_WGY}, s51
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
@@ -977,6 +977,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_cmp_ge_u32 {S_ONE}, 2
 	s_cbranch_scc1 .Lfh_columns_exit
 	s_add_u32 {S_ONE}, {S_ONE}, {S_ONE}
+	s_bitcmp1_b32 {S_WGY}, 20
+	s_cbranch_scc1 .Lfh_columns_column
 	s_cmp_ge_u32 {S_I}, {S_CNT}
 	s_cbranch_scc0 .Lfh_columns_haveblock
 	s_sub_u32 {S_I}, {S_I}, {S_CNT}
@@ -1030,12 +1032,47 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_NXTV}, 0
 	s_nop 2
 	s_mov_b64 {S_LAYMASK}, vcc
+	s_branch .Lfh_columns_leaf
+.Lfh_columns_column:
+	; ---- column mode (kernarg flags bit 20; grid = footprints rounded up to 64, one layer row): the wave takes ONE footprint and
+	; its whole column of the slab's table, lane = layer, front layer in lane 0.  For frames whose tapes read nothing that changes
+	; along a pixel column a slab's column holds at most one leaf (the nearest of a stack is the only one queued), the table is
+	; nearly empty, and the (blocks, layers) grid above is 16 x as many workgroups that find nothing: 66 of the launch's 71 us
+	; at 1024^3.  Workgroup ids go round the 8 XCDs: id = 64 q + 8 a + b runs on XCD b and takes footprint 64 q + 8 b + a, so that
+	; the eight footprints whose entries share a 128-byte line of a layer's row are read through one L2.
+	s_and_b32 {S_T0}, {S_I}, 7
+	s_bfe_u32 {S_T1}, {S_I}, 0x30003
+	s_andn2_b32 s86, {S_I}, 63
+	s_lshl_b32 {S_T0}, {S_T0}, 3
+	s_add_u32 {S_T0}, {S_T0}, s86
+	s_add_u32 {S_T0}, {S_T0}, {S_T1}
+	s_cmp_ge_u32 {S_T0}, {S_NFPL}
+	s_cbranch_scc1 .Lfh_columns_exit
+	v_sub_u32 {V_S0}, {S_L}, {V_LANE}                 ; layer of this lane ({S_L} = layers - 1 here)
+	v_cmp_ge_u32 vcc, {S_L}, {V_LANE}
+	v_mul_lo_u32 {V_S0}, {V_S0}, {S_NFPL}
+	v_mov_b32 {V_ENT[0]}, 0
+	v_add_lshl_u32 {V_S0}, {V_S0}, {S_T0}, 4            ; 16-byte entries, [layer][footprint]
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	global_load_dwordx4 v[{V_ENT[0][1:]}:{V_ENT[3][1:]}], {V_S0}, {S_TABLE}
+	s_mov_b64 exec, {S_SAVE}
+	s_mov_b32 {S_NXTV}, 0
+	s_waitcnt vmcnt(0) lgkmcnt(0)
+	v_cmp_ne_u32 vcc, 0, {V_ENT[0]}
+	s_nop 3
+	s_mov_b64 {S_LAYMASK}, vcc
 .Lfh_columns_leaf:
 	; ---- next leaf of the block: everything needed to start on it is in the entries (no load before the tape's) --------
 	s_cmp_eq_u64 {S_LAYMASK}, 0
 	s_cbranch_scc1 .Lfh_columns_block
 	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
+	s_bitcmp1_b32 {S_WGY}, 20
+	s_cbranch_scc0 .Lfh_columns_layerz
+	s_sub_u32 {S_T0}, {S_L}, {S_ZL}                  ; column mode: the lane is the layer, counted from the front
+	s_lshl_b32 {S_T0}, {S_T0}, 3
+	s_add_u32 {S_LZ}, {S_T0}, {S_SLABZ}
+.Lfh_columns_layerz:
 	s_nop 0
 	v_readlane_b32 {S_ID}, {V_ENT[0]}, {S_ZL}
 	v_readlane_b32 s84, {V_ENT[1]}, {S_ZL}

@@ -684,7 +684,56 @@ FH_DEV IV top_comb(bool is_min, IV a, IV b) {
     if (iv_has_nan(a) || iv_has_nan(b)) return iv_nan();
     return is_min ? iv(rmin(a.lo, b.lo), rmin(a.hi, b.hi)) : iv(rmax(a.lo, b.lo), rmax(a.hi, b.hi));
 }
+// The scan, one wave per child.  Lane l takes the contiguous segment of ceil(n_top / 64) ops starting at l * that: it folds its
+// segment (the loads of its terms are independent and issued together), the 64 segment totals are scanned across the lanes once, and the
+// lane walks its segment again with the accumulator that reaches it, recording the choices: per + 6 + per dependent steps (28 for
+// prospero's 664 ops) where scanning chunk after chunk of 64 ops took 11 x (6 cross-lane steps + a round of loads).  min / max of the
+// bounds with NaN absorbing is associative and exact: any bracketing gives the chunked scan's accumulators bit for bit.
+#define FH_CHAIN_SEG 16       // ops per lane held in registers: chains of up to 1 024 ops (longer ones: the chunked scan below)
 __global__ void __launch_bounds__(WAVE) k_tchain3d(FhRenderState* S) {
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x, b = blockIdx.y, G = S->n_tgroups, n_top = S->n_top;
+    if (b >= S->n_slots[1][0] / G) return;
+    FhSlot& p = S->slots[1][(size_t)b * G];
+    if (((p.act >> c) & 1) == 0) return;
+    const IV* const tv = (const IV*)S->tvals + (size_t)b * S->n_terms * WAVE;
+    uint8_t* const tc = S->topch + ((size_t)b * WAVE + c) * n_top;
+    const uint32_t* const top = (const uint32_t*)S->ttop;
+    const bool is_min = (top[0] & 0xFF) == FH_MIN_RR || (top[0] & 0xFF) == FH_MIN_RI;
+    const float ident = is_min ? u2f(0x7f800000u) : u2f(0xff800000u);
+    const uint32_t per = (n_top + WAVE - 1) / WAVE, j0 = (uint32_t)lane * per;
+    IV e[FH_CHAIN_SEG];
+#pragma unroll
+    for (int k = 0; k < FH_CHAIN_SEG; k++) {
+        const uint32_t j = j0 + k;
+        e[k] = iv(ident, ident);
+        if ((uint32_t)k < per && j < n_top) {
+            const uint32_t bk = top[3 * j] >> 24, bv = top[3 * j + 2];
+            e[k] = bk == 1 ? tv[(size_t)bv * WAVE + c] : iv1(u2f(bv));
+        }
+    }
+    IV incl = e[0];
+#pragma unroll
+    for (int k = 1; k < FH_CHAIN_SEG; k++) incl = top_comb(is_min, incl, e[k]);      // (past the segment's end: the identity)
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const IV o = iv(__shfl_up(incl.lo, d, WAVE), __shfl_up(incl.hi, d, WAVE));
+        if (lane >= d) incl = top_comb(is_min, o, incl);
+    }
+    const IV start = tv[(size_t)top[1] * WAVE + c];   // the chain starts from the first op's `a`, a term
+    IV before = iv(__shfl_up(incl.lo, 1, WAVE), __shfl_up(incl.hi, 1, WAVE));
+    before = lane == 0 ? start : top_comb(is_min, start, before);
+#pragma unroll
+    for (int k = 0; k < FH_CHAIN_SEG; k++) {
+        int ch;
+        if (is_min) (void)iv_min(before, e[k], ch); else (void)iv_max(before, e[k], ch);
+        if ((uint32_t)k < per && j0 + k < n_top) tc[j0 + k] = (uint8_t)ch;
+        before = top_comb(is_min, before, e[k]);
+    }
+    if (lane == WAVE - 1) { p.res[0][c] = before.lo; p.res[1][c] = before.hi; }
+}
+// (chains of more than 64 x FH_CHAIN_SEG ops, and FHIP_DEBUG_BITS 8)
+__global__ void __launch_bounds__(WAVE) k_tchain3d_old(FhRenderState* S) {
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x, b = blockIdx.y, G = S->n_tgroups, n_top = S->n_top;
     if (b >= S->n_slots[1][0] / G) return;

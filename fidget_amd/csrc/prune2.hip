@@ -148,6 +148,39 @@ __device__ __forceinline__ void p2_scan_batch(uint32_t d, uint32_t& fr, uint32_t
     (void)d; (void)fr; (void)out; (void)pool; (void)maxro; (void)cnt; (void)batch; (void)frees_lds;
 #endif
 }
+// B3's loop, second form (round 5): the registers themselves keep the time they come back.  rel: lane r = the position of the last use
+// of the value that register r holds (0: never used).  Op k of the batch, at position kabs, may take every register with rel <= kabs -
+// a value that dies AT op k gives its register to op k's result, as linear scan does -: one compare for all 64 registers, the lowest set
+// bit, two v_writelane (the register's new last use; the op's register).  u: lane k = last use of op k's value.  Nothing is posted
+// anywhere, nothing is looked up, no branch but the loop's: 13 instructions per kept op where the posting form above takes 33 and up to
+// three taken branches.  Same policy (lowest free register first), same registers.
+__device__ __forceinline__ void p2_scan_batch2(uint32_t u, uint32_t& rel, uint32_t& out, uint32_t& maxro, uint32_t cnt, uint32_t kabs0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t k, su, ro, kabs = kabs0;
+    asm volatile(
+        "s_mov_b32 %[k], 0\n"
+        "L_p2b_loop_%=:\n\t"
+        "v_readlane_b32 %[su], %[u], %[k]\n\t"
+        "v_cmp_ge_u32 vcc, %[kabs], %[rel]\n\t"
+        "s_add_u32 %[kabs], %[kabs], 1\n\t"
+        "s_nop 0\n\t"
+        "s_ff1_i32_b64 %[ro], vcc\n\t"
+        "s_mov_b32 m0, %[ro]\n\t"
+        "s_max_u32 %[maxro], %[maxro], %[ro]\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %[rel], %[su], m0\n\t"
+        "s_mov_b32 m0, %[k]\n\t"
+        "s_add_u32 %[k], %[k], 1\n\t"
+        "v_writelane_b32 %[out], %[ro], m0\n\t"
+        "s_cmp_lt_u32 %[k], %[cnt]\n\t"
+        "s_cbranch_scc1 L_p2b_loop_%="
+        : [rel] "+v"(rel), [out] "+v"(out), [maxro] "+s"(maxro), [kabs] "+s"(kabs), [k] "=&s"(k), [su] "=&s"(su), [ro] "=&s"(ro)
+        : [u] "v"(u), [cnt] "s"(cnt)
+        : "m0", "scc", "vcc", "memory");
+#else
+    (void)u; (void)rel; (void)out; (void)maxro; (void)cnt; (void)kabs0;
+#endif
+}
 }  // namespace fhp2
 
 // Tape groups, level 0: slot = block * n_tgroups, choice words S->chwr (k_tscatter3d) with `cw_stride` words per slot, links / ctab:
@@ -267,7 +300,38 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
 
     const uint64_t t_b1 = probe ? clock64() : 0;
     // ---- B1: liveness (one wave) ---------------------------------------------------------------------------------------------------
-    if (on && lead) {
+    if (on && lead && (flags & 4u) == 0) {
+        // A work queue from the OUTPUT op: up to 64 queued ops a round, lane = op; a lane looks up its op's producers (through E) and sets
+        // their bits in the mask, and whoever finds a bit clear queues that op - once.  A child of the root tape keeps 100 - 200 of its
+        // 6 363 ops in sub-graphs 20 - 50 ops deep and ~10 wide, so this is 20 - 50 rounds of five LDS round trips; the sweep over the tape's
+        // 100 batches it replaces (below, flags bit 2) met a wanted op in nearly every batch and paid 1 300 cycles for each: 128 k cycles of
+        // the kernel's 360 k.  The queue (2 bytes per op, each kept op enters once) lies where the kept-op records go in B2.
+        for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
+        uint16_t* const queue = (uint16_t*)comp;
+        const uint32_t qcap = cap_kept * 4u;
+        if (lane == 0) queue[0] = (uint16_t)(n - 1);
+        uint32_t head = 0, tail = 1;
+        bool over = false;
+        const uint64_t below = (1ull << lane) - 1;
+        while (head < tail) {
+            const uint32_t cnt = min(64u, tail - head);
+            bool has_a = false, has_b = false, imm = false;
+            uint32_t ta = 0, tb = 0;
+            if (lane < cnt) resolve(lks[queue[head + lane]], has_a, has_b, imm, ta, tb);
+            head += cnt;
+            bool new_a = false, new_b = false;
+            if (has_a) { const uint64_t bit = 1ull << (ta & 63); new_a = (atomicOr((unsigned long long*)&mask[ta >> 6], bit) & bit) == 0; }
+            if (has_b) { const uint64_t bit = 1ull << (tb & 63); new_b = (atomicOr((unsigned long long*)&mask[tb >> 6], bit) & bit) == 0; }
+            const uint64_t ma = __ballot(new_a), mb = __ballot(new_b);
+            const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+            if (tail + na + nb > qcap) { over = true; break; }       // (more than the areas hold: the scalar sweep takes this child)
+            if (new_a) queue[tail + (uint32_t)__popcll(ma & below)] = (uint16_t)ta;
+            if (new_b) queue[tail + na + (uint32_t)__popcll(mb & below)] = (uint16_t)tb;
+            tail += na + nb;
+        }
+        if (over && lane == 0) red[3] = 1;
+    }
+    if (on && lead && (flags & 4u) != 0) {
         for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
         for (uint32_t b = nw; b-- > 0;) {
             const uint32_t i = (b << 6) | lane;
@@ -290,6 +354,8 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
                 word = rfl64(mask[b]);
             }
         }
+    }
+    if (on && lead) {
         // positions of the words' first kept ops (B2 needs them all)
         const uint32_t k0 = lane < nw ? (uint32_t)__popcll(mask[lane]) : 0u, k1 = lane + 64 < nw ? (uint32_t)__popcll(mask[lane + 64]) : 0u;
         uint32_t t0, t1;
@@ -339,7 +405,21 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     // to it, takes the lowest free one for its own value and posts that.  ~30 scalar / cross-lane instructions per kept op, no
     // memory wait.  Registers 0 .. 63 only: a child that wants more is left to the scalar sweep.
     // The loop itself is assembly (p2_scan_batch): 33 instructions per kept op against the compiler's ~55, one taken branch.
-    if (on && lead) {
+    if (on && lead && (flags & 16u) == 0) {
+        uint32_t maxro = 0, rel = 0;
+        for (uint32_t base = 0; base < m; base += 64) {
+            const uint32_t pl = base + lane;
+            const uint32_t u = pl < m ? lastuse[pl] : 0u;          // (0 for the OUTPUT op, the last one: it takes the register its operand gives back, which nobody reads)
+            uint32_t outv = 0;
+            p2_scan_batch2(u, rel, outv, maxro, min(64u, m - base), base);
+            if (pl < m) regb[pl] = (uint8_t)outv;
+        }
+        if (maxro >= 64u) {          // more than 64 registers: left marked for the scalar sweep
+            if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); }
+            if (lane == 0) red[3] = 1;
+        }
+    }
+    if (on && lead && (flags & 16u) != 0) {
         uint64_t pool = ~0ull;
         uint32_t maxro = 0;
         const uint32_t frees_lds = (uint32_t)((char*)frees - smem);        // (the dynamic LDS area starts at LDS address 0: no static __shared__ here)

@@ -18,7 +18,7 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
-def col_kernarg(a_st, in_kind, mat, size=16):
+def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False):
     """the leaf kernel's kernarg as capi_render.hpp builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags, and
     floor(2^32 / blocks of four footprints per layer) for the kernel's block rotation (0 when there is one block: the subtraction loop)"""
     u = np.asarray(mat, F32).view(U32)
@@ -36,10 +36,12 @@ def col_kernarg(a_st, in_kind, mat, size=16):
         if varies:
             flags |= 0x20000 << ax          # (bits 17 .. 19: this axis of the model changes along a pixel column)
     n_blocks = (((size + 7) // 8) ** 2 + 3) // 4
+    if column_mode:
+        flags |= 1 << 20                     # (one footprint column per wave, lane = layer)
     return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, (1 << 32) // n_blocks if n_blocks > 1 else 0, 0], U32)
 
 
-def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns"):
+def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns", column_mode=False, more_leaves=()):
     off = U.offsets()
     mem = E.Memory()
     arena = np.zeros(4096, np.uint64)
@@ -52,6 +54,9 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     lx, ly, lz = leaf_xyz
     leaves[0] = [16, len(tape), n_regs | (n_choices << 16), lx, ly, lz]
     table[(lz % size) // 8 * nfp + (ly // 8) * (size // 8) + lx // 8] = [1, 16, len(tape) | (n_regs << 24), lx | (ly << 16)]
+    for k, (mx, my, mz) in enumerate(more_leaves):      # (the same tape at other places of the same slab: leaf ids 2, 3, ..)
+        assert mz - mz % size == lz - lz % size
+        table[(mz % size) // 8 * nfp + (my // 8) * (size // 8) + mx // 8] = [2 + k, 16, len(tape) | (n_regs << 24), mx | (my << 16)]
     zbuf = np.zeros(size * size, np.uint64) if zbuf_init is None else zbuf_init.copy()
     a_tab, a_leaves, a_z = mem.map(table), mem.map(leaves), mem.map(zbuf)
     st = U.Blob(off["sizeof_state"])
@@ -62,9 +67,10 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], lz - lz % size)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat, size)
+    ka = col_kernarg(a_st, in_kind, mat, size, column_mode)
     trans = kernel == "fh_columns_t"
-    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=256 if trans else 128,
+    gx, gy = ((nfp + 63) // 64 * 64, 1) if column_mode else ((nfp + 3) // 4, layers)
+    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=256 if trans else 128,
                      hooks=U.trans_hooks(U.program(), v_base=192, window=64) if trans else None)
     return zbuf, waves
 
@@ -88,6 +94,7 @@ def expect(tape, in_kind, mat, leaf_xyz, size, zbuf_init=None):
 
 
 AFFINE = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0, 0, 0, 1]                 # screen_to_world of a 16^3 volume
+AFFINE32 = [0.0625, 0, 0, -1, 0, -0.0625, 0, 0.9375, 0, 0, 0.0625, -1, 0, 0, 0, 1]            # ... of a 32^3 volume
 ROTATED = [0.1, 0.05, 0.02, -1.1, -0.04, -0.11, 0.03, 0.9, 0.01, 0.02, 0.12, -0.95, 0, 0, 0, 1]
 PERSPECTIVE = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0.01, -0.005, 0.0375, 0.7]   # w = 0.7 + ... (never 0 here)
 W_ZERO = [0.125, 0, 0, -1, 0, -0.125, 0, 0.875, 0, 0, 0.125, -1, 0, 0, 0.125, -1.0]              # w = z/8 - 1: exactly 0 at z = 8
@@ -309,3 +316,34 @@ def test_transcendental_leaf_kernel_32x4_class():
             hits += int((want != 0).sum()); misses += int((want == 0).sum())
     print("pixels hit", hits, "not hit", misses)
     assert hits > 0
+
+
+ROTATED32 = [0.05, 0.025, 0.01, -1.1, -0.02, -0.055, 0.015, 0.9, 0.005, 0.01, 0.06, -0.95, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("mat", [AFFINE32, ROTATED32], ids=["affine", "rotated"])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_column_mode_gives_the_layer_modes_words(kind, mat):
+    """kernarg flags bit 20: one footprint column per wave (lane = layer, front layer first) instead of one block of four footprints
+    of one layer - the arrangement for frames whose leaf table is nearly empty.  Same z-buffer words, leaf ids included, with several
+    leaves in a column and leaves in other columns; and an empty column costs a wave one load and nothing else."""
+    sh, tape, ik = column_shape(kind)
+    size = 32
+    leaves = [(8, 16, 8), (8, 16, 24), (8, 16, 0), (24, 0, 16), (0, 24, 24)]
+    z = np.zeros(size * size, np.uint64)
+    z[3::11] = np.uint64((5 << 32) | 9)
+    a, wa = run_columns(tape, sh.slot_count(), ik, mat, leaves[0], size=size, zbuf_init=z, more_leaves=leaves[1:])
+    b, wb = run_columns(tape, sh.slot_count(), ik, mat, leaves[0], size=size, zbuf_init=z, more_leaves=leaves[1:], column_mode=True)
+    assert (a != z).any()
+    assert (a == b).all(), f"{(a != b).sum()} z-buffer words differ"
+    # the words themselves: leaf by leaf against numpy (ids 1 .. 5; the maximum per pixel, as the atomic takes it)
+    want = z.copy()
+    for k, leaf in enumerate(leaves):
+        w = expect(tape, ik, mat, leaf, size, z)
+        hit = w != z
+        w = np.where(hit, (w & ~np.uint64(0xFFFFFFFF)) | np.uint64(k + 1), w)
+        want = np.maximum(want, w)
+    # (a pixel that a nearer leaf of its column hit is not evaluated again by the leaves behind it: the words are the same either way)
+    assert (b == want).all(), f"{(b != want).sum()} z-buffer words differ from numpy's"
+    busy = [w for w in wb if w.counts.get("vmem", 0) > 1]
+    assert len(wb) == 64 and len(busy) == 3, (len(wb), len(busy))        # 16 footprints in a grid of 64, three columns with leaves

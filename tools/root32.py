@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """GPU box: 3D frames with root tiles of 32^3 straight above the leaves (tile_sizes [32, 8]: ONE coarse level - the root tape pruned per
 32^3 tile by the linked prune, no level 1) against the default 128 / 32 / 8, lone and queued, image compared.
-usage: root32.py [model]"""
+usage: root32.py [model]       (ROOT32_QUICK=1: no frame lanes, column invariance on, the library's tile choice only)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import fidget_amd as F
 model = sys.argv[1] if len(sys.argv) > 1 else "prospero.vm"
-for lanes in (0, 4):
+QUICK = bool(os.environ.get("ROOT32_QUICK"))
+for lanes in ((0,) if QUICK else (0, 4)):
   hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
   hip.set_option("frame_lanes", lanes)
   shape = F.Shape.from_vm(os.path.join(ROOT, "models", model), hip=hip)
-  for no_inv in (0, 1):
+  for no_inv in ((0,) if QUICK else (0, 1)):
     hip.set_option("no_column_inv", no_inv)
     for what in ("512", "256", "128", "1024", "2048", "octant"):
         n = 1024 if what == "octant" else int(what)
         kw = {"block": (7, (2, 2, 2))} if what == "octant" else {}
         imgs = {}
-        for tiles in ("128/32/8", "auto"):
+        for tiles in (("auto",) if QUICK else ("128/32/8", "auto")):
             hip.set_option("root32_max", 0 if tiles == "128/32/8" else int(os.environ.get("ROOT32_MAX", "4096")))
             out = torch.zeros((n, n, 4), dtype=torch.int32, device="cuda")
             call = lambda: F.render3d(shape, n, out=out, **kw)
