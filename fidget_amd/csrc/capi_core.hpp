@@ -31,6 +31,7 @@ struct fhip_tape {
     mutable uint32_t* d_chsrc = nullptr;
     mutable uint64_t* d_links = nullptr;   // links of the full tape (host_graph.hpp compute_links) for the linked prune, when it qualifies
     mutable uint64_t* d_ctab = nullptr;    // ... and per choice its op's operands and index
+    mutable uint32_t n_chain = 0;          // ... and, behind that table, the root chain's ops in evaluation order: choice ordinal | op index << 16 (plan.chain)
     mutable bool links_tried = false;
     // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
     // reference's workers): its lazily created device copies are made under this lock, on the device of the first
@@ -62,7 +63,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     /* kernel selection (each falls back to the HIP C++ path of the same stage, which tapes outside the assembly set take anyway) */ \
     X(no_asm, 0) X(no_split, 0) X(no_asm_tiles, 0) X(no_tiles_v, 0) X(no_asm_tiles_t, 0) X(no_columns_t, 0) X(no_asm_normals, 0)   \
     X(no_tape_groups, 0) X(prune2, 1)                                                                                           \
-    /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level;     \
+    /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level, 3 = every slab rendered;     \
        column_walk: the leaf kernel by footprint columns - 1 in frames whose tapes read no z, 0 never, 2 always */                  \
     X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096) X(column_walk, 1)                                                     \
     /* pipelining and resources */                                                                                             \

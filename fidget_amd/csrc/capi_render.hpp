@@ -32,6 +32,7 @@ struct RenderSetup {
     const uint64_t* d_links = nullptr;
     const uint64_t* d_ctab = nullptr;
     size_t lds_prune2 = 0;
+    uint32_t n_chain = 0;          // ops of the root chain (their table lies behind d_ctab's t.n_choices entries)
     uint32_t p2_cap_kept = 0;      // kept ops per child the linked prune's LDS areas are sized for (children beyond: the scalar sweep behind it)
     uint32_t exp_levels = 0;
     uint32_t col_slots = 0, col_depmask = 0, col_flags = 0;   // 3D: axis slots x | y << 8 | z << 16 (0xFF none), inputs varying along a pixel column, bit 16 projective
@@ -40,6 +41,8 @@ struct RenderSetup {
     bool one_level_64 = false;   // 2D, a one-level list: root groups of 64 tiles through the split tile stage (render2d_frame's small-image passes)
     bool classify_only = false;  // ... and the pass that only classifies its tiles and writes their fills (no prune, no leaves)
     bool root_zrep = false;   // ... then the root level evaluates ONE layer of root tiles per z-slab and hands the result to the layers stacked on it
+    bool front_only = false;  // ... and only the front slab is rendered (slab_stop = slab_hi - 1)
+    uint32_t slab_stop = 0;   // the slabs rendered: slab_hi - 1 down to slab_stop (= slab_lo unless front_only)
     bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
     uint32_t hbm_waves = 0;
 };
@@ -106,7 +109,7 @@ struct PartSpec {
 };
 // 3D: input slots of the axes, which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective
 // matrix), and whether the root tape reads any of them - from the camera matrix, the input binding and the tape alone (before prepare)
-// (temporary, for A/B runs on the GPU box: FHIP_DEBUG_BITS - 4: k_prune2's liveness as the sweep over the tape, 16: its register scan in the posting form, 8: the root tree's scan in chunks of 64)
+// (temporary, for A/B runs on the GPU box: FHIP_DEBUG_BITS - 4: k_prune2's liveness as the sweep over the tape, 16: its register scan in the posting form, 32: its liveness pass without the chain's head start, 8: the root tree's scan in chunks of 64)
 static uint32_t fh_debug_bits() {
     static const uint32_t bits = [] { const char* v = getenv("FHIP_DEBUG_BITS"); return v ? (uint32_t)atoi(v) : 0u; }();
     return bits;
@@ -263,11 +266,19 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // column of root tiles.  One layer per z-slab is evaluated (the slab's back-most: FhGroup::x = how many layers of the slab it stands
     // for) and the push stage hands the result to the stack - a fill with the nearest copy's depth, ONE queue entry carrying the copies,
     // exactly what the levels below do for column-invariant parents.  prospero.vm at 1024^3: 64 root tiles instead of 512.
-    R.root_zrep = is3d && S.pre_levels > 0 && ctx->use_split && TL == 64 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0;
+    R.root_zrep = is3d && S.pre_levels > 0 && ctx->use_split && TL == 64 && R.xy_fixed && R.root_invariant && (ctx->opt.no_zrep == 0 || ctx->opt.no_zrep == 3);
+    // ... and of such a frame ONLY THE FRONT SLAB is rendered at all.  Nothing the frame evaluates depends on z: every tile, every leaf of
+    // a slab further back repeats the front slab's result for its column with a smaller depth - a filled tile is filled in front of it, a
+    // leaf's hits are the front leaf's hits, a pixel the front slab left empty is outside the model at every z - and the image takes the
+    // largest depth.  The slabs behind the first (prospero.vm at 1024^3: half the root level's children - the linked prune then runs
+    // its workgroups in one round instead of two -, one of two tile chains, one of two leaf launches) are not queued.  (no_zrep 3: every
+    // slab, as before.)
+    R.front_only = R.root_zrep && ctx->opt.no_zrep == 0;
+    R.slab_stop = R.front_only && R.slab_hi > R.slab_lo ? R.slab_hi - 1 : R.slab_lo;
     uint32_t q0_layers = S.pre_levels ? layer_hi - layer_lo : 1;
     if (R.root_zrep) {
         q0_layers = 0;
-        for (uint32_t sb = R.slab_hi; sb-- > R.slab_lo;) {       // front slabs first
+        for (uint32_t sb = R.slab_hi; sb-- > R.slab_stop;) {       // front slabs first
             const uint32_t lo = std::max(layer_lo, sb * SL), hi = std::min(layer_hi, (sb + 1) * SL);
             if (lo >= hi) continue;
             q0_layers++;
@@ -401,6 +412,19 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 if (fh::compute_links(t, lk, cops)) {
                     // (published together or not at all: a failure half way must not leave links without their choice table)
                     uint64_t *dl = nullptr, *dc = nullptr;
+                    // the root chain's ops (plan.chain: acc = min / max(acc, term) all the way to the OUTPUT op) in evaluation order, behind the choice
+                    // table: the linked prune's liveness pass starts from every kept op of the chain at once instead of walking it link by link
+                    std::vector<uint32_t> chain;
+                    if (tape->plan.chain && tape->plan.top.size() < 65536) {
+                        chain.assign(tape->plan.top.size(), 0xFFFFFFFFu);
+                        for (size_t q = 0; q < tape->plan.choice_src.size() && q < cops.size(); q++)
+                            if ((tape->plan.choice_src[q] >> 24) == 255 && (tape->plan.choice_src[q] & 0xFFFFFFu) < chain.size())
+                                chain[tape->plan.choice_src[q] & 0xFFFFFFu] = (uint32_t)q | ((uint32_t)((cops[q] >> 32) & 0xFFFFu) << 16);
+                        for (uint32_t c : chain) if (c == 0xFFFFFFFFu) { chain.clear(); break; }
+                    }
+                    const size_t n_cops = std::max<size_t>(cops.size(), 1);
+                    cops.resize(n_cops + (chain.size() + 1) / 2, 0);
+                    if (!chain.empty()) memcpy(cops.data() + n_cops, chain.data(), chain.size() * 4);
                     hipError_t e = hipMalloc((void**)&dl, lk.size() * 8);
                     if (e == hipSuccess) e = hipMemcpy(dl, lk.data(), lk.size() * 8, hipMemcpyHostToDevice);
                     if (e == hipSuccess) e = hipMalloc((void**)&dc, std::max<size_t>(cops.size(), 1) * 8);
@@ -410,11 +434,12 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                         if (dc) (void)hipFree(dc);
                         HIP_TRY(ctx, e);
                     }
-                    tape->d_links = dl; tape->d_ctab = dc;
+                    tape->d_links = dl; tape->d_ctab = dc; tape->n_chain = (uint32_t)chain.size();
                 }
             }
             R.p2_cap_kept = (uint32_t)FH_P2_MAX_KEPT;
-            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices, R.p2_cap_kept);
+            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices, R.p2_cap_kept) + (((size_t)tape->n_chain * 4 + 15) & ~(size_t)15);
+            R.n_chain = tape->n_chain;
             // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
             // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)
             R.prune2 = tape->d_links && tape->d_ctab && ctx->opt.prune2 && t.ops.size() <= FH_P2_MAX_OPS && t.n_choices <= FH_P2_MAX_CHOICES &&
@@ -587,7 +612,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * FH_P2_WPC * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u | (fh_debug_bits() & 20u), R.S.troot_len, R.S.troot_choices, R.p2_cap_kept);
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u | (fh_debug_bits() & 20u), R.S.troot_len, R.S.troot_choices, R.p2_cap_kept,
+                                   (const uint32_t*)(R.d_ctab + std::max<uint32_t>(R.S.troot_choices, 1)), (fh_debug_bits() & 32u) ? 0u : R.n_chain);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -895,8 +921,9 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         !tape->tgroups.empty() && !ctx->opt.no_tape_groups && ctx->opt.prune2 && tape_asm_ok(tape->t) &&
         tape->t.ops.size() <= FH_P2_MAX_OPS && tape->t.n_choices <= FH_P2_MAX_CHOICES) {
         const uint64_t cols = (uint64_t)((P.width + 31) / 32) * ((P.height + 31) / 32) / std::max<uint32_t>(1, part.n_shards * part.nx * part.ny);
-        const bool dedupe = R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0;
-        const uint64_t layers = dedupe ? (uint64_t)std::max<uint32_t>(2, (P.depth + 511) / 512) : (uint64_t)((P.depth + 31) / 32) / std::max<uint32_t>(1, part.nz);
+        const bool dedupe = R.xy_fixed && R.root_invariant && (ctx->opt.no_zrep == 0 || ctx->opt.no_zrep == 3);
+        const uint64_t layers = dedupe ? (ctx->opt.no_zrep == 0 ? 1u : (uint64_t)std::max<uint32_t>(2, (P.depth + 511) / 512))      // (one layer per slab; the front slab only)
+                                       : (uint64_t)((P.depth + 31) / 32) / std::max<uint32_t>(1, part.nz);
         // (measured, profiles/r05c: up to two rounds of the linked prune's workgroups - 2 048 children - always; up to root32_max when a
         // 128^3 root tile is a quarter of the image or more - there the 128^3 tiles' tapes stay long whatever is done: 512^3 with z in
         // every tape, 4 096 children, 3.65 -> 1.72 ms; an octant of a 1024^3 frame, as many children of a model twice the size: 1.10 -> 1.33)
@@ -1068,11 +1095,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         return FHIP_OK;
     };
     if (tiles_first)
-        for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {
+        for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_stop && n_groups; k--) {
             const fhip_status ts_ = tile_step(k, (int)R.slab_hi - 1 - k);
             if (ts_) { ctx->stream = main_stream; return ts_; }
         }
-    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_lo && n_groups; k--) {  // front to back (voxel.rs:252-261)
+    for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_stop && n_groups; k--) {  // front to back (voxel.rs:252-261)
         if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
         const int idx = (int)R.slab_hi - 1 - k;
         if (!tiles_first) {
@@ -1143,7 +1170,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 // taken one after the other by one wave, front to back, which is wrong for frames with a leaf in most layers (the
                 // launch would last as long as its fullest column: measured in round 3, bear.vm 2.40 -> 4.07 ms): option column_walk
                 // 1 = only where the tapes guarantee sparse columns, 0 never, 2 always (tests).
-                const bool by_columns = ctx->opt.column_walk == 2 || (ctx->opt.column_walk == 1 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0);
+                const bool by_columns = ctx->opt.column_walk == 2 || (ctx->opt.column_walk == 1 && R.xy_fixed && R.root_invariant && (ctx->opt.no_zrep == 0 || ctx->opt.no_zrep == 3));
                 const uint32_t layers = P.slab / 8;
                 if (by_columns && layers <= 64) {
                     struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags | (1u << 20), {0, 0}};

@@ -199,7 +199,7 @@ __device__ __forceinline__ void p2_scan_batch2(uint32_t u, uint32_t& rel, uint32
 //   B2 positions / operand positions / last uses: batches shared out; B3 the register scan: one wave; B4 emission: shared out.
 __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
                                         const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
-                                        uint32_t blk, char* smem) {
+                                        const uint32_t* __restrict__ chain, uint32_t n_chain, uint32_t blk, char* smem) {
     using namespace fhp2;
     constexpr uint32_t W = FH_P2_WPC;
     const uint32_t lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);      // (everything the sequential step branches on is made wave-uniform explicitly)
@@ -225,6 +225,9 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     const uint2* const ops = (const uint2*)(S->arena + off);
     uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lks[i] = links[i];
+    // (the root chain's ops, evaluation order: choice ordinal | op index << 16 - behind the children's areas, shared like the links)
+    uint32_t* const chl = (uint32_t*)(smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(cap_choices, cap_kept));
+    for (uint32_t i = threadIdx.x; i < n_chain; i += blockDim.x) chl[i] = chain[i];
     char* const mine = smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)kid * fh_p2_wave_lds(cap_choices, cap_kept);
     uint64_t* const mask = (uint64_t*)mine;                               // wanted ops, 64 per word (128 words)
     uint16_t* const pref = (uint16_t*)(mine + 1024);                    // kept ops before each word
@@ -307,13 +310,39 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
         // 100 batches it replaces (below, flags bit 2) met a wanted op in nearly every batch and paid 1 300 cycles for each: 128 k cycles of
         // the kernel's 360 k.  The queue (2 bytes per op, each kept op enters once) lies where the kept-op records go in B2.
         for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
-        uint16_t* const queue = (uint16_t*)comp;
-        const uint32_t qcap = cap_kept * 4u;
+        // (the queue lies behind the child's staged choice words, which the head start below still reads)
+        const uint32_t cw_bytes = (((nch + 15) / 16) * 4 + 15) & ~15u;
+        uint16_t* const queue = (uint16_t*)((char*)comp + cw_bytes);
+        const uint32_t qcap = (cap_kept * 8u - cw_bytes) / 2u;
         if (lane == 0) queue[0] = (uint16_t)(n - 1);
         uint32_t head = 0, tail = 1;
         bool over = false;
         const uint64_t below = (1ull << lane) - 1;
-        while (head < tail) {
+        // Head start: the root of most models is a chain, acc = min(acc, term) from the first term to the OUTPUT op (prospero: 664 ops),
+        // and the kept ops of that chain are one dependent path - 60 - 100 rounds of this queue with one useful lane each.  But which of
+        // them are wanted is known without walking: from the chain's end down, an op that kept both operands is wanted and the walk goes
+        // on below it, one that took its left operand (the chain) is passed through, the first that took its right operand (its term) ends
+        // the chain - everything below is dead from here.  So the chain is read 64 ops at a time from its end, its kept ops are marked
+        // and queued at once, and the rounds that follow are as deep as the deepest TERM (10 - 25).
+        for (uint32_t top = n_chain; top > 0;) {
+            const uint32_t cnt = min(64u, top);
+            uint32_t ch = 0, i = 0;
+            if (lane < cnt) {
+                const uint32_t e = chl[top - 1 - lane], q = e & 0xFFFFu;
+                i = e >> 16;
+                ch = (cwl[q >> 4] >> ((q & 15) * 2)) & 3u;
+            }
+            const uint64_t cut = __ballot(ch == FH_CHOICE_RIGHT);
+            const bool seed = ch == FH_CHOICE_BOTH && (cut == 0 || lane < (uint32_t)__builtin_ctzll(cut));
+            if (seed) atomicOr((unsigned long long*)&mask[i >> 6], 1ull << (i & 63));
+            const uint64_t ms = __ballot(seed);
+            if (tail + (uint32_t)__popcll(ms) > qcap) { over = true; break; }
+            if (seed) queue[tail + (uint32_t)__popcll(ms & below)] = (uint16_t)i;
+            tail += (uint32_t)__popcll(ms);
+            if (cut) break;
+            top -= cnt;
+        }
+        while (!over && head < tail) {
             const uint32_t cnt = min(64u, tail - head);
             bool has_a = false, has_b = false, imm = false;
             uint32_t ta = 0, tb = 0;
@@ -477,7 +506,8 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
 
 // grid: one workgroup per item (FH_P2_WPB children of one slot)
 __global__ void __launch_bounds__(FH_P2_WPB * FH_P2_WPC * 64) k_prune2(FhRenderState* S, uint32_t level, uint32_t big, uint32_t cw_stride, const uint2* __restrict__ links,
-                                                const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept) {
+                                                const uint2* __restrict__ ctab, uint32_t flags, uint32_t cap_ops, uint32_t cap_choices, uint32_t cap_kept,
+                                                const uint32_t* __restrict__ chain, uint32_t n_chain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    p2_item(S, level, big, cw_stride, links, ctab, flags, cap_ops, cap_choices, cap_kept, blockIdx.x, smem);
+    p2_item(S, level, big, cw_stride, links, ctab, flags, cap_ops, cap_choices, cap_kept, chain, n_chain, blockIdx.x, smem);
 }
