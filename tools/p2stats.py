@@ -17,5 +17,6 @@ for _ in range(2):
 print(n, "phase clocks max (A, B1, B2, B3+B4):", hip.leaf_stats()["prune2_phase_clocks_max"], flush=True)
 hip.wave_stats()
 print("tile levels:", hip.tile_phases, flush=True)
-g, cnt = hip.groups(1, 0)
-print("parked parents of slab 0:", cnt, "len min/median/max", int(g["len"].min()), int(np.median(g["len"])), int(g["len"].max()), "regs max", int(g["regs"].max()), "choices max", int(g["choices"].max()), flush=True)
+slab = (n + 511) // 512 - 1       # (the front slab: the only one a frame without z renders)
+g, cnt = hip.groups(1, slab)
+print(f"parked parents of slab {slab}:", cnt, "len min/median/max", int(g["len"].min()), int(np.median(g["len"])), int(g["len"].max()), "regs max", int(g["regs"].max()), "choices max", int(g["choices"].max()), flush=True)
