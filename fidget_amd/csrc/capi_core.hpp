@@ -31,6 +31,7 @@ struct fhip_tape {
     mutable uint32_t* d_chsrc = nullptr;
     mutable uint64_t* d_links = nullptr;   // links of the full tape (host_graph.hpp compute_links) for the linked prune, when it qualifies
     mutable uint64_t* d_ctab = nullptr;    // ... and per choice its op's operands and index
+    mutable std::atomic<uint32_t> input_slots{0x80000000u};   // the input slots the tape reads, bit per slot (bit 31: not looked up yet)
     mutable uint32_t n_chain = 0;          // ... and, behind that table, the root chain's ops in evaluation order: choice ordinal | op index << 16 (plan.chain)
     mutable bool links_tried = false;
     // A tape is immutable and may be shared by contexts on different threads (one context per thread, as the
@@ -297,3 +298,37 @@ static bool simplify_host(const fh::HostTape& p, const uint8_t* choices, fh::Hos
     out.vars = p.vars;
     return true;
 }
+
+// Launches of the library's own __global__ kernels in the render path: through hipModuleLaunchKernel with the arguments packed here,
+// on the function handle of the kernel's symbol, looked up once per device.  A frame is ~25 launches and its queued rate had become the
+// HOST's (tools/host_enqueue.py: 0.19 ms of calls per frame against 0.17 ms of kernels on the busiest stream); hipLaunchKernelGGL finds
+// the kernel by its host address and marshals argument by argument on every call - 5.9 against 3.3 us per call under rocprofv3's HIP trace.
+template <class T> struct FhKArgs;
+template <class... K> struct FhKArgs<void (*)(K...)> {
+    template <class... A> static size_t pack(char* buf, A&&... a) {
+        size_t off = 0;
+        auto put = [&](auto v) {
+            constexpr size_t al = alignof(decltype(v));
+            off = (off + al - 1) & ~(al - 1);
+            memcpy(buf + off, &v, sizeof(v));
+            off += sizeof(v);
+        };
+        (put(static_cast<K>(std::forward<A>(a))), ...);
+        return off;
+    }
+    static constexpr size_t bytes = (sizeof(K) + ... + 0) + 16 * sizeof...(K);      // (an upper bound with padding)
+};
+template <auto Kernel, class... A>
+static inline void fh_launch(int device, dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
+    static hipFunction_t fns[16] = {};
+    static bool no_handle = false;
+    hipFunction_t& fn = fns[device & 15];
+    if (!fn && !no_handle && (hipGetFuncBySymbol(&fn, (const void*)Kernel) != hipSuccess || !fn)) { fn = nullptr; no_handle = true; (void)hipGetLastError(); }
+    if (!fn) { hipLaunchKernelGGL(Kernel, g, b, lds, st, std::forward<A>(a)...); return; }
+    alignas(16) char buf[FhKArgs<decltype(Kernel)>::bytes];
+    size_t bytes = FhKArgs<decltype(Kernel)>::pack(buf, std::forward<A>(a)...);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    (void)hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, (unsigned)lds, st, nullptr, extra);
+}
+#define FH_KLAUNCH(kernel, grid, block, lds, stream, ...) fh_launch<kernel>(ctx->device, grid, block, lds, stream, ##__VA_ARGS__)
+

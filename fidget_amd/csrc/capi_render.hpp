@@ -115,6 +115,23 @@ static uint32_t fh_debug_bits() {
     return bits;
 }
 
+// (temporary: FHIP_DEBUG_BITS 64 - where the host thread's time of a 3D frame goes, printed every 200 frames)
+struct HostSpans {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { last = std::chrono::steady_clock::now(); }
+    void mark(int k) { const auto now = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double, std::micro>(now - last).count(); last = now; }
+    void frame() {
+        if (++n % 200 == 0) {
+            fprintf(stderr, "fidget-hip host us per frame: set-up %.1f prepare %.1f upload %.1f coarse %.1f slabs %.1f finish %.1f\n", t[0] / 200, t[1] / 200, t[2] / 200, t[3] / 200, t[4] / 200, t[5] / 200);
+            for (double& x : t) x = 0;
+        }
+    }
+};
+static HostSpans g_spans;
+#define FH_SPAN(k) do { if (fh_debug_bits() & 64u) g_spans.mark(k); } while (0)
+
 static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P, RenderSetup& R) {
     uint32_t u[16];
     memcpy(u, P.mat, sizeof(u));
@@ -135,8 +152,18 @@ static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P
     const bool no_inv = ctx->opt.no_column_inv != 0;
     if (no_inv) R.col_depmask = 0xFFFFFFFFu;
     R.root_invariant = !no_inv && R.col_depmask != 0xFFFFFFFFu;
-    for (uint64_t w : tape->t.ops)
-        if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { R.root_invariant = false; break; }
+    if (R.root_invariant) {
+        // (the input slots the tape reads, found once per tape: a frame's set-up walked the tape three times for this)
+        uint32_t reads = tape->input_slots.load(std::memory_order_acquire);
+        if (reads & 0x80000000u) {          // not known yet (bit 31: input slots are < 31... FH_MAX_INPUTS)
+            reads = 0;
+            for (uint64_t w : tape->t.ops)
+                if (FH_W_OP((uint32_t)w) == FH_INPUT) reads |= 1u << ((uint32_t)(w >> 32) & 31u);
+            reads &= 0x7FFFFFFFu;
+            tape->input_slots.store(reads, std::memory_order_release);
+        }
+        R.root_invariant = (reads & R.col_depmask & 0x7FFFFFFFu) == 0;
+    }
 }
 
 // A frame before this one ran out of tape arena (k_finish3d / k_latch_arena said so in the pinned host word): wait for what is in flight
@@ -562,7 +589,7 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         if (clear[k].p) most = std::max(most, clear[k].bytes);
     }
     const unsigned blocks = (unsigned)std::max<size_t>(2, std::min<size_t>((size_t)ctx->n_cu * 8, (most + 256 * 64 - 1) / (256 * 64)));
-    hipLaunchKernelGGL(k_frame_begin, dim3(blocks), dim3(256), 0, ctx->stream, fb);
+    FH_KLAUNCH(k_frame_begin, dim3(blocks), dim3(256), 0, ctx->stream, fb);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sg.ev, ctx->stream));
     sg.used = true;
@@ -577,8 +604,8 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
 // root-sized variant for the few large tapes (both always launched; empty queues exit at once).
 #define FH_LAUNCH_TILES(IS3D, FULL, BIG, grid, lds)                                                                  \
     do {                                                                                                            \
-        if (R.tl == 64) hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 64>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level); \
-        else hipLaunchKernelGGL((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
+        if (R.tl == 64) FH_KLAUNCH((k_tiles<IS3D, FULL, BIG, 64>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level); \
+        else FH_KLAUNCH((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
     } while (0)
 // 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
 static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
@@ -588,8 +615,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gb = blocks_big(ctx, R, R.lds_tiles_big, 8);
     const int gp = ctx->n_cu * 8;
     launch(ctx, FHIP_K_TILES, [&] {
-        if (is3d) hipLaunchKernelGGL(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
-        else hipLaunchKernelGGL(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+        if (is3d) FH_KLAUNCH(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
+        else FH_KLAUNCH(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
     });
     if (R.groups && level == 0) {
         // Tape parallelism: the root tree's terms by independent groups, one wave per (block of root
@@ -602,16 +629,18 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u | 8u; ka.skip_regs = ka.skip_choices = 0;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
             const uint32_t blocks = R.S.qcap[0], root_words = (R.S.troot_choices + 15) / 16, group_words = (R.group_choices + 15) / 16;
-            if (R.S.top_chain && ((fh_debug_bits() & 8u) || R.S.n_top > 64u * FH_CHAIN_SEG)) hipLaunchKernelGGL(k_tchain3d_old, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
-            else if (R.S.top_chain) hipLaunchKernelGGL(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
-            else hipLaunchKernelGGL(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
-            hipLaunchKernelGGL(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (R.S.top_chain && ((fh_debug_bits() & 8u) || R.S.n_top > 64u * FH_CHAIN_SEG)) FH_KLAUNCH(k_tchain3d_old, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            else if (R.S.top_chain) FH_KLAUNCH(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            else FH_KLAUNCH(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
+            // (the marks and the gather of the root tape's choice words do not depend on each other: one launch, the marks in the blocks
+            // behind the gather's)
+            if (R.classify_only || !root_words) FH_KLAUNCH(k_tmark3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             if (R.classify_only) return;       // (the fills of the decided tiles follow below; nothing is pruned or queued)
-            if (root_words) hipLaunchKernelGGL(k_tscatter3d, dim3(root_words, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
+            if (root_words) FH_KLAUNCH(k_tscatter3d, dim3(root_words + 1, blocks), dim3(WAVE), 0, ctx->stream, dS, group_words, root_words);
             if (R.prune2) {
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
-                hipLaunchKernelGGL(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * FH_P2_WPC * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
+                FH_KLAUNCH(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * FH_P2_WPC * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
                                    (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u | (fh_debug_bits() & 20u), R.S.troot_len, R.S.troot_choices, R.p2_cap_kept,
                                    (const uint32_t*)(R.d_ctab + std::max<uint32_t>(R.S.troot_choices, 1)), (fh_debug_bits() & 32u) ? 0u : R.n_chain);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
@@ -726,21 +755,21 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     } else
     launch(ctx, FHIP_K_TILES, [&] {
         if (level > 0) {
-            if (R.full) hipLaunchKernelGGL((k_teval3d<true, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
-            else hipLaunchKernelGGL((k_teval3d<false, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+            if (R.full) FH_KLAUNCH((k_teval3d<true, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
+            else FH_KLAUNCH((k_teval3d<false, false>), dim3(gs), dim3(WAVE), R.lds_tiles_small, ctx->stream, dS, level);
         }
-        if (R.full) hipLaunchKernelGGL((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
-        else hipLaunchKernelGGL((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+        if (R.full) FH_KLAUNCH((k_teval3d<true, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
+        else FH_KLAUNCH((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
     // (last level: fewer waves, several parents each - one leaf reservation per wave)
     const int push_mul = 2;
     const int gpush = (level + 1 == (int)R.S.P.n_levels) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
-        if (is3d) hipLaunchKernelGGL(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+        if (is3d) FH_KLAUNCH(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
         else {
-            if (!R.classify_only) hipLaunchKernelGGL(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+            if (!R.classify_only) FH_KLAUNCH(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
             const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);
-            hipLaunchKernelGGL(k_tfill2d, dim3(64, slots_max), dim3(256), 0, ctx->stream, dS, level);
+            FH_KLAUNCH(k_tfill2d, dim3(64, slots_max), dim3(256), 0, ctx->stream, dS, level);
         }
     });
 }
@@ -823,16 +852,16 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         }
         if (Q.classify_only) return FHIP_OK;
         launch(ctx, FHIP_K_POINTS, [&] {
-            if (Q.full) hipLaunchKernelGGL((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
-            else hipLaunchKernelGGL((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+            if (Q.full) FH_KLAUNCH((k_pixels2d<32, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+            else FH_KLAUNCH((k_pixels2d<32, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
         });
         if (Q.S.P.max_regs > 32)
             launch(ctx, FHIP_K_POINTS, [&] {
                 const int g = blocks_big(ctx, Q, Q.lds_points_big, 16);
-                if (Q.full) hipLaunchKernelGGL((k_pixels2d<0, true>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
-                else hipLaunchKernelGGL((k_pixels2d<0, false>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
+                if (Q.full) FH_KLAUNCH((k_pixels2d<0, true>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
+                else FH_KLAUNCH((k_pixels2d<0, false>), dim3(g), dim3(WAVE), Q.lds_points_big, ctx->stream, dS);
             });
-        if (ctx->host_flags) hipLaunchKernelGGL(k_latch_arena, dim3(1), dim3(1), 0, ctx->stream, dS, 1u, ctx->host_flags);    // (an arena that ran out: grown before the next frame)
+        if (ctx->host_flags) FH_KLAUNCH(k_latch_arena, dim3(1), dim3(1), 0, ctx->stream, dS, 1u, ctx->host_flags);    // (an arena that ran out: grown before the next frame)
         return FHIP_OK;
     };
     // Small images of a large tape (round 5).  With 128 x 128 root tiles a 256 x 256 image is FOUR one-wave chains over a tape that a quarter
@@ -877,6 +906,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                   int out_is_device, const PartSpec& part) {
     if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    if (fh_debug_bits() & 64u) g_spans.start();
     (void)hipSetDevice(ctx->device);
     RenderSetup R;
     memset(&R.S, 0, sizeof(R.S));
@@ -950,8 +980,10 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         ctx->stream = ctx->stream_pre;
         if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
     }
+    FH_SPAN(0);
     st = prepare(ctx, tape, true, ts, part, R);
     if (st) return st;
+    FH_SPAN(1);
     R.zrep = R.split && R.S.pre_levels > 0 && R.xy_fixed && !ctx->opt.no_column_inv && ctx->opt.no_zrep != 1;
     const size_t npix = (size_t)cfg->width * cfg->height;
     FhGeometryPixel* d_out = (FhGeometryPixel*)out;
@@ -963,6 +995,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                                   {ctx->mind.p, R.mind_words * 4, 0u}};
     st = upload_frame(ctx, tape, R, clear3);
     if (st) return st;
+    FH_SPAN(2);
     const uint32_t n_groups = R.groups_per_slab;
     const uint32_t pre = R.S.pre_levels;
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
@@ -982,21 +1015,18 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     if (l1_side && pre == 2 && ctx->stream3 && R.asm_points) {
         const bool pipe_plan = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
         const uint32_t nc_plan = pipe_plan ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;
-        bool inv = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
-        for (uint64_t w : tape->t.ops)
-            if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { inv = false; break; }
-        l1_only = pipe_plan && inv && R.slab_hi - R.slab_lo <= nc_plan;
+        l1_only = pipe_plan && R.root_invariant && R.slab_hi - R.slab_lo <= nc_plan;      // (column_setup: no tape of the frame reads an input that changes along a pixel column)
     }
     if (pre && n_groups) {  // coarse levels of every slab in one go
         for (uint32_t l = 0; l < pre; l++) {
             const bool flags_here = R.zrep && l > 0;
             if (l == 1 && l1_side) {
-                if (flags_here && l1_only) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+                if (flags_here && l1_only) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream_pre));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_l0, 0));
                 ctx->stream = ctx->stream2;
             }
-            if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
             ctx->post_v64_stream = (l == 1 && l1_only) ? ctx->stream3 : nullptr;
             launch_tiles(ctx, R, dS, (int)l, true);
             ctx->post_v64_stream = nullptr;
@@ -1025,21 +1055,27 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_l0, 0));
             ctx->stream = side_stream;
         }
-        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
-        if (!pipe) launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
+        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
+        if (!pipe) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
     }
     if (pipe) {
-        hipLaunchKernelGGL(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
+        FH_KLAUNCH(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
                            (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints,
                            (pre && n_groups) ? 1u : 0u);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
+        if (ctx->stream != side_stream) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
     if (fpipe) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));     // (the stream the last coarse-level kernel went to)
-        HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
+        // (one coarse level, its tail on the side stream, and tile chains to follow there: the caller's stream waits for the first tile
+        // chain's event, which lies behind everything queued so far - no event of its own for that)
+        const bool implied = pipe && pre == 1 && n_groups > 0 && side_stream && ctx->stream == side_stream;
+        if (!implied) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));     // (the stream the last coarse-level kernel went to)
+            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pre, 0));
+        }
         ctx->stream = main_stream;
     }
+    FH_SPAN(3);
     int last_tail_idx = -1;
     // Where a slab's tile chain goes: the side stream, or (option tiles_stream = 1, pipelined frames of at most as many slabs
     // as there are slab contexts) the tail stream, every slab's chain queued there BEFORE the tail work of the first slab - the
@@ -1049,9 +1085,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // the leaf stage is light and the tail stream has room; a frame whose leaf kernels fill the machine wants its tile chains on
     // the high-priority side stream: prospero.vm 1024^3 0.77 -> 0.64 ms per frame there, the same frames with the column-invariance
     // short cuts off 1.86 -> 2.01)
-    bool root_invariant = !ctx->opt.no_column_inv && R.col_depmask != 0xFFFFFFFFu;
-    for (uint64_t w : tape->t.ops)
-        if (FH_W_OP((uint32_t)w) == FH_INPUT && ((R.col_depmask >> ((uint32_t)(w >> 32) & 31u)) & 1u)) { root_invariant = false; break; }
+    const bool root_invariant = R.root_invariant;
     const bool tiles_first = pipe && l1_side && root_invariant && ctx->stream3 && R.asm_points && R.slab_hi - R.slab_lo <= NC;
     hipStream_t const tile_stream = tiles_first ? ctx->stream3 : side_stream;
     if (tiles_first) HIP_TRY(ctx, hipStreamWaitEvent(tile_stream, ctx->ev_fork, 0));
@@ -1071,21 +1105,21 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             const bool pyr2 = P.n_levels == 2 && P.tiles[1] == 8 && P.tiles[0] == 32 && pre == 1;
             if (rebuild && pyr2) {
                 const uint32_t n0 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
-                hipLaunchKernelGGL(k_slab_begin2, dim3(n0 + reset_blocks), dim3(256), 0, ctx->stream, dS, n0, R.table_words, (uint32_t)k, n_groups);
+                FH_KLAUNCH(k_slab_begin2, dim3(n0 + reset_blocks), dim3(256), 0, ctx->stream, dS, n0, R.table_words, (uint32_t)k, n_groups);
                 return;
             }
             if (rebuild && pyr3 && pre == 2) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
-                hipLaunchKernelGGL(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
+                FH_KLAUNCH(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
                 return;
             }
-            hipLaunchKernelGGL(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
+            FH_KLAUNCH(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
                                (pyr3 && rebuild) ? 1u : 0u);
             if (rebuild && pyr3) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
-                hipLaunchKernelGGL(k_minpyramid3, dim3(n1), dim3(256), 0, ctx->stream, dS);
+                FH_KLAUNCH(k_minpyramid3, dim3(n1), dim3(256), 0, ctx->stream, dS);
             } else if (rebuild)
-                hipLaunchKernelGGL(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
+                FH_KLAUNCH(k_minpyramid, dim3(P.roots_x * P.roots_y), dim3(256), 0, ctx->stream, dS);
         });
         for (uint32_t l = pre; l < P.n_levels; l++) launch_tiles(ctx, R, dS, (int)l, true);
         if (pipe) {
@@ -1123,12 +1157,12 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
-            launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
+            launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
             if (P.max_regs > 32)
                 launch(ctx, FHIP_K_POINTS, [&] {
                     const int g = blocks_big(ctx, R, R.lds_points_big, 16);
-                    if (R.full) hipLaunchKernelGGL((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
-                    else hipLaunchKernelGGL((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                    if (R.full) FH_KLAUNCH((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
+                    else FH_KLAUNCH((k_leaves3d<2, 0, 1, false>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
                 });
         };
         auto normals_work = [&] {
@@ -1139,11 +1173,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                     struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * 8), R.col_slots, z_lo, z_hi, {0, 0}};
                     (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
                 }
-                else if (R.full) hipLaunchKernelGGL((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
-                else hipLaunchKernelGGL((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                else if (R.full) FH_KLAUNCH((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
+                else FH_KLAUNCH((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 if (P.max_regs > 32) {
-                    if (R.full) hipLaunchKernelGGL((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
-                    else hipLaunchKernelGGL((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                    if (R.full) FH_KLAUNCH((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
+                    else FH_KLAUNCH((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
                 }
             });
         };
@@ -1185,11 +1219,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 (void)launch_asm(ctx, which, n_blocks, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
             } else if (R.full) {
-                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
-                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                FH_KLAUNCH((k_leaves3d<0, 16, 4, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
+                FH_KLAUNCH((k_leaves3d<1, 32, 2, true>), dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS);
             } else {
-                hipLaunchKernelGGL((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
-                hipLaunchKernelGGL((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                FH_KLAUNCH((k_leaves3d<0, 16, 4, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
+                FH_KLAUNCH((k_leaves3d<1, 32, 2, false>), dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS);
             }
         });
         if (tail) {
@@ -1205,13 +1239,15 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         normals_work();
         if (pipe) HIP_TRY(ctx, hipEventRecord(ctx->ev_leaves[idx], main_stream));
     }
+    FH_SPAN(4);
     if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
-    launch(ctx, FHIP_K_OTHER, [&] { hipLaunchKernelGGL(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p, ctx->host_flags); });
+    launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p, ctx->host_flags); });
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream));     // (a later pipelined frame that takes this set waits for it)
     ctx->ev_done_valid = true;
+    if (fh_debug_bits() & 64u) { g_spans.mark(5); g_spans.frame(); }
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);
@@ -1454,7 +1490,7 @@ fhip_status fhip_render3d_block(fhip_ctx* ctx, const fhip_tape* tape, const fhip
 fhip_status fhip_merge_depth(fhip_ctx* ctx, void* front, const void* back, uint64_t n_pixels, uint32_t image_depth) {
     if (!n_pixels) return FHIP_OK;
     (void)hipSetDevice(ctx->device);
-    hipLaunchKernelGGL(k_merge_depth, dim3((unsigned)std::min<uint64_t>((n_pixels + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+    FH_KLAUNCH(k_merge_depth, dim3((unsigned)std::min<uint64_t>((n_pixels + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
                        (FhGeometryPixel*)front, (const FhGeometryPixel*)back, (size_t)n_pixels, image_depth);
     HIP_TRY(ctx, hipGetLastError());
     return FHIP_OK;

@@ -811,12 +811,12 @@ __global__ void __launch_bounds__(WAVE) k_ttop3d(FhRenderState* S) {
 
 // The tree's result is the root tape's result: ambiguous children reserve arena space for their
 // pruned tape and are marked for fh_prune1, exactly as fh_tiles does in export mode.
-__global__ void __launch_bounds__(WAVE) k_tmark3d(FhRenderState* S) {
+FH_DEV void tmark_body(FhRenderState* S, uint32_t first, uint32_t stride) {
     const int lane = threadIdx.x;
     const uint32_t G = S->n_tgroups;
     const uint32_t nblk = S->n_slots[1][0] / G;
     const FhTapeRef root = FhTapeRef{0, S->troot_len, (uint16_t)S->troot_regs, (uint16_t)S->troot_choices};
-    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    for (uint32_t b = first; b < nblk; b += stride) {
         FhSlot* const slg = &S->slots[1][(size_t)b * G];
         const uint64_t actm = slg[0].act;
         if (lane >= 1 && lane < (int)G) slg[lane].act = 0;   // only the primary slot is pushed
@@ -840,10 +840,14 @@ __global__ void __launch_bounds__(WAVE) k_tmark3d(FhRenderState* S) {
     }
 }
 
+__global__ void __launch_bounds__(WAVE) k_tmark3d(FhRenderState* S) { tmark_body(S, blockIdx.x, gridDim.x); }
+
 // ... and the choice words of the root tape, gathered from the groups' traces and the tree's:
-// grid (word, block), lane = child.
+// grid (word, block), lane = child; the blocks with word == root_words are the marks above (they read the primary slots' results and
+// write what the gather does not read: one launch for both)
 __global__ void __launch_bounds__(WAVE) k_tscatter3d(FhRenderState* S, uint32_t group_words, uint32_t root_words) {
     const int lane = threadIdx.x;
+    if (blockIdx.x == root_words) { tmark_body(S, blockIdx.y, gridDim.y); return; }
     const uint32_t w = blockIdx.x, b = blockIdx.y, G = S->n_tgroups;
     if (b >= S->n_slots[1][0] / G) return;
     if (S->slots[1][(size_t)b * G].act == 0) return;
