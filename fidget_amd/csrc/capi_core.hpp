@@ -126,6 +126,7 @@ struct fhip_ctx : FrameBufs {
     uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
+    uint32_t pre_turn = 0;              // ... frames whose root levels alternate between it and the tail stream: whose turn
     hipEvent_t ev_rest_fork = nullptr, ev_rest_join = nullptr;
     hipEvent_t ev_pre = nullptr, ev_l0 = nullptr, ev_l1 = nullptr;
     hipStream_t post_v64_stream = nullptr;   // launch_tiles_split: where the launches behind level 1's fh_tiles_v64 go (side_only_l1), or null

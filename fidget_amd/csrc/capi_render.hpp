@@ -42,6 +42,7 @@ struct RenderSetup {
     bool classify_only = false;  // ... and the pass that only classifies its tiles and writes their fills (no prune, no leaves)
     bool root_zrep = false;   // ... then the root level evaluates ONE layer of root tiles per z-slab and hands the result to the layers stacked on it
     bool front_only = false;  // ... and only the front slab is rendered (slab_stop = slab_hi - 1)
+    bool alt_pre = false;     // ... and consecutive frames' root levels take the pre-pass and the tail stream in turn (render3d_frame)
     uint32_t slab_stop = 0;   // the slabs rendered: slab_hi - 1 down to slab_stop (= slab_lo unless front_only)
     bool big_hbm = false;     // the root-sized register files live in HBM (S.gscratch): hbm_waves workgroups per root-sized launch
     uint32_t hbm_waves = 0;
@@ -977,8 +978,17 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         for (uint32_t i = 0; i < ctx->extra_sets; i++) std::swap(static_cast<FrameBufs&>(*ctx), ctx->others[i]);
         frames_queued = ctx->extra_sets > 0 && ctx->others[0].ev_done_valid && hipEventQuery(ctx->others[0].ev_done) == hipErrorNotReady;
         (void)hipGetLastError();
-        ctx->stream = ctx->stream_pre;
-        if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_pre, ctx->ev_done, 0));   // the set's previous frame has left it
+        // Two root levels side by side.  A frame of one coarse level whose tapes read no z (front slab only: one light tile chain, a leaf
+        // stage of 5 k leaves) is its root level and little else: 165 us of kernels in one dependent chain on the pre-pass stream against
+        // 100 on the side stream and 100 for lists + leaves + normals together - and that chain set the rate of queued frames.  Such frames
+        // take the pre-pass stream and the tail stream IN TURN for their root level, and keep what the tail stream carried (lists, normals)
+        // on the caller's stream around the leaf kernel: still four streams (a fifth shares a hardware queue with one of them and
+        // serialises against it, measured in round 2), two frames' root levels in flight.  (FHIP_DEBUG_BITS 128: one pre-pass stream.)
+        R.alt_pre = ts.size() == 2 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0 && ctx->stream3 && !(fh_debug_bits() & 128u) &&
+                    part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
+        hipStream_t const pre_stream = R.alt_pre && (ctx->pre_turn++ & 1u) ? ctx->stream3 : ctx->stream_pre;
+        ctx->stream = pre_stream;
+        if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(pre_stream, ctx->ev_done, 0));   // the set's previous frame has left it
     }
     FH_SPAN(0);
     st = prepare(ctx, tape, true, ts, part, R);
@@ -1154,7 +1164,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         // kernel with the NEXT frame's tile chains queued behind: 0.45 ms of it per frame for 0.40 of work.  A frame alone is 70 us
         // quicker with them beside its leaf kernels, hence the test)
         const bool on_main = tiles_first && frames_queued;
-        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main;   // (the HIP leaf kernels walk the footprint lists)
+        const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main && !R.alt_pre;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
             launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
