@@ -71,7 +71,7 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(no_pipeline, 0) X(frame_sets, 4) X(frame_lanes, 4) X(lanes_tune, 1) X(lanes_fail, 0) X(slab_layers, 4) X(arena_mb, 4096)  \
     /* mesher */                                                                                                               \
     X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(mesh_simplify_min_ops, 256)                                             \
-    /* diagnostics */                                                                                                          \
+    /* diagnostics (stats: bit 0 device counters and clocks, bit 1 the host thread's time per frame to stderr) */                                                                                                          \
     X(probe, 0) X(stats, 0)
 struct FhOptions {
 #define X(name, dflt) int name = dflt;

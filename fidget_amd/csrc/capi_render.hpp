@@ -110,13 +110,8 @@ struct PartSpec {
 };
 // 3D: input slots of the axes, which inputs change along a pixel column (a z coefficient in the axis' matrix row, or a projective
 // matrix), and whether the root tape reads any of them - from the camera matrix, the input binding and the tape alone (before prepare)
-// (temporary, for A/B runs on the GPU box: FHIP_DEBUG_BITS - 4: k_prune2's liveness as the sweep over the tape, 16: its register scan in the posting form, 32: its liveness pass without the chain's head start, 8: the root tree's scan in chunks of 64)
-static uint32_t fh_debug_bits() {
-    static const uint32_t bits = [] { const char* v = getenv("FHIP_DEBUG_BITS"); return v ? (uint32_t)atoi(v) : 0u; }();
-    return bits;
-}
-
-// (temporary: FHIP_DEBUG_BITS 64 - where the host thread's time of a 3D frame goes, printed every 200 frames)
+// (option stats, bit 1: where the host thread's time of a 3D frame goes - set-up, prepare, state upload, coarse levels, slabs, finish -
+// printed every 200 frames; tools/host_enqueue.py)
 struct HostSpans {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n = 0;
@@ -131,7 +126,7 @@ struct HostSpans {
     }
 };
 static HostSpans g_spans;
-#define FH_SPAN(k) do { if (fh_debug_bits() & 64u) g_spans.mark(k); } while (0)
+#define FH_SPAN(k) do { if (ctx->opt.stats & 2) g_spans.mark(k); } while (0)
 
 static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P, RenderSetup& R) {
     uint32_t u[16];
@@ -514,7 +509,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     S.image2d = nullptr;
     memset(S.stat, 0, sizeof(S.stat));
     memset(S.leaf_stat, 0, sizeof(S.leaf_stat));
-    S.want_stats = (ctx->profiling || ctx->probe || ctx->opt.stats) ? 1 : 0;
+    S.want_stats = (ctx->profiling || ctx->probe || (ctx->opt.stats & 1)) ? 1 : 0;
     if (((size_t)t.ops.size() + 64) * 8 > ctx->arena_bytes) return fail(ctx, FHIP_ERR_UNSUPPORTED, "tape larger than the arena");
     // level-0 groups sit at the back of queue[0] (the "big" half), in reverse order
     std::reverse(R.roots.begin(), R.roots.end());
@@ -630,7 +625,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             ka.n_waves = (uint32_t)gg; ka.flags = (ctx->probe ? 1u : 0u) | 2u | 4u | 8u; ka.skip_regs = ka.skip_choices = 0;
             (void)launch_asm(ctx, FH_ASM_TILES, (uint32_t)gg, &ka, sizeof(ka), R.lds_tiles_group);
             const uint32_t blocks = R.S.qcap[0], root_words = (R.S.troot_choices + 15) / 16, group_words = (R.group_choices + 15) / 16;
-            if (R.S.top_chain && ((fh_debug_bits() & 8u) || R.S.n_top > 64u * FH_CHAIN_SEG)) FH_KLAUNCH(k_tchain3d_old, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
+            if (R.S.top_chain && R.S.n_top > 64u * FH_CHAIN_SEG) FH_KLAUNCH(k_tchain3d_chunks, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
             else if (R.S.top_chain) FH_KLAUNCH(k_tchain3d, dim3(WAVE, blocks), dim3(WAVE), 0, ctx->stream, dS);
             else FH_KLAUNCH(k_ttop3d, dim3(blocks), dim3(WAVE), 0, ctx->stream, dS);
             // (the marks and the gather of the root tape's choice words do not depend on each other: one launch, the marks in the blocks
@@ -642,8 +637,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
                 hipEvent_t ea = nullptr, eb = nullptr;      // (timed under the fh_prune1 slot of the per-kernel profile: it replaces that launch)
                 if (ctx->profiling) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, ctx->stream); }
                 FH_KLAUNCH(k_prune2, dim3(blocks * FH_P2_PER_SLOT), dim3(FH_P2_WPB * FH_P2_WPC * 64), R.lds_prune2, ctx->stream, dS, 0u, 1u, root_words,
-                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u | (fh_debug_bits() & 20u), R.S.troot_len, R.S.troot_choices, R.p2_cap_kept,
-                                   (const uint32_t*)(R.d_ctab + std::max<uint32_t>(R.S.troot_choices, 1)), (fh_debug_bits() & 32u) ? 0u : R.n_chain);
+                                   (const uint2*)R.d_links, (const uint2*)R.d_ctab, 2u, R.S.troot_len, R.S.troot_choices, R.p2_cap_kept,
+                                   (const uint32_t*)(R.d_ctab + std::max<uint32_t>(R.S.troot_choices, 1)), R.n_chain);
                 // ... and the scalar sweep behind it for the children it left marked (more than 64 registers or FH_P2_MAX_KEPT kept ops:
                 // none for the models here; a wave whose child is done leaves at once)
                 struct { FhRenderState* S; uint32_t level, big, max_choices, mode; } kp = {dS, 0, 1, R.S.troot_choices, 2};
@@ -907,7 +902,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                   int out_is_device, const PartSpec& part) {
     if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
-    if (fh_debug_bits() & 64u) g_spans.start();
+    if (ctx->opt.stats & 2) g_spans.start();
     (void)hipSetDevice(ctx->device);
     RenderSetup R;
     memset(&R.S, 0, sizeof(R.S));
@@ -983,8 +978,8 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         // 100 on the side stream and 100 for lists + leaves + normals together - and that chain set the rate of queued frames.  Such frames
         // take the pre-pass stream and the tail stream IN TURN for their root level, and keep what the tail stream carried (lists, normals)
         // on the caller's stream around the leaf kernel: still four streams (a fifth shares a hardware queue with one of them and
-        // serialises against it, measured in round 2), two frames' root levels in flight.  (FHIP_DEBUG_BITS 128: one pre-pass stream.)
-        R.alt_pre = ts.size() == 2 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0 && ctx->stream3 && !(fh_debug_bits() & 128u) &&
+        // serialises against it, measured in round 2), two frames' root levels in flight.
+        R.alt_pre = ts.size() == 2 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0 && ctx->stream3 &&
                     part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
         hipStream_t const pre_stream = R.alt_pre && (ctx->pre_turn++ & 1u) ? ctx->stream3 : ctx->stream_pre;
         ctx->stream = pre_stream;
@@ -1257,7 +1252,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     ctx->async_pending = out_is_device != 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_done, main_stream));     // (a later pipelined frame that takes this set waits for it)
     ctx->ev_done_valid = true;
-    if (fh_debug_bits() & 64u) { g_spans.mark(5); g_spans.frame(); }
+    if (ctx->opt.stats & 2) { g_spans.mark(5); g_spans.frame(); }
     if (!out_is_device) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, npix * sizeof(FhGeometryPixel), hipMemcpyDeviceToHost, ctx->stream));
         return finish_render(ctx);
@@ -1275,7 +1270,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 // multi-GPU job renders) are frames like any other here (option lanes_parts): one octant of prospero.vm 1024^3, queued, 0.72 -> 0.31 ms; a
 // column shard of eight stays where it is, 0.43 (profiles/r04r/lanes_parts.txt).
 static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
-    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || ctx->opt.stats) return false;
+    if (ctx->opt.frame_lanes < 2 || ctx->is_lane || !out_is_device || ctx->profiling || ctx->probe || (ctx->opt.stats & 1)) return false;
     if (!ctx->ev_last_valid) return false;
     const hipError_t q = hipEventQuery(ctx->ev_last);      // the frame before this one: still under way?
     (void)hipGetLastError();

@@ -689,7 +689,7 @@ FH_DEV IV top_comb(bool is_min, IV a, IV b) {
 // lane walks its segment again with the accumulator that reaches it, recording the choices: per + 6 + per dependent steps (28 for
 // prospero's 664 ops) where scanning chunk after chunk of 64 ops took 11 x (6 cross-lane steps + a round of loads).  min / max of the
 // bounds with NaN absorbing is associative and exact: any bracketing gives the chunked scan's accumulators bit for bit.
-#define FH_CHAIN_SEG 16       // ops per lane held in registers: chains of up to 1 024 ops (longer ones: the chunked scan below)
+#define FH_CHAIN_SEG 16       // ops per lane held in registers: chains of up to 1 024 ops (longer ones: k_tchain3d_chunks below)
 __global__ void __launch_bounds__(WAVE) k_tchain3d(FhRenderState* S) {
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x, b = blockIdx.y, G = S->n_tgroups, n_top = S->n_top;
@@ -732,8 +732,8 @@ __global__ void __launch_bounds__(WAVE) k_tchain3d(FhRenderState* S) {
     }
     if (lane == WAVE - 1) { p.res[0][c] = before.lo; p.res[1][c] = before.hi; }
 }
-// (chains of more than 64 x FH_CHAIN_SEG ops, and FHIP_DEBUG_BITS 8)
-__global__ void __launch_bounds__(WAVE) k_tchain3d_old(FhRenderState* S) {
+// (chains of more than 64 x FH_CHAIN_SEG ops: chunk after chunk of 64 ops, a cross-lane scan each)
+__global__ void __launch_bounds__(WAVE) k_tchain3d_chunks(FhRenderState* S) {
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x, b = blockIdx.y, G = S->n_tgroups, n_top = S->n_top;
     if (b >= S->n_slots[1][0] / G) return;

@@ -12,17 +12,17 @@
 //   A  the choices turn every choice op into "kept", "is its left / right operand" or "is its immediate"; chains of passed-on
 //      operands (prospero's root is a chain of 664 min ops) are followed for ALL choice ops at once by pointer jumping, 64
 //      ordinals per step in tape order: E[q] = the op whose value choice q's output really is;
-//   B1 liveness: 64 ops at a time from the end of the tape, lane = op, a bit mask of wanted ops; a wanted op marks the ops that
-//      really produce its operands (through E).  Producers have lower indices, so one pass with a fixed point inside a batch
-//      (an op wanted by another op of its own batch) does it; batches without a wanted op cost one word;
+//   B1 liveness: a work queue from the OUTPUT op, up to 64 queued ops a round, lane = op: a lane sets the bits of the ops that really
+//      produce its op's operands (through E) in a mask of wanted ops, and whoever finds a bit clear queues that op.  When the root is
+//      a chain acc = min(acc, term) (plan.chain: most models) its kept ops are found without walking it and queued at once, so the
+//      rounds are as many as the deepest TERM is deep (10 - 25), not as the chain is long;
 //   B2 the kept ops' positions in the child tape (prefix population counts), per kept op its operands' positions and whether it
 //      is their last use (an atomic maximum per value);
-//   B3 the one sequential step, in tape order over the KEPT ops only: registers are returned at a value's last use and taken at
-//      its definition (lowest free first) - linear scan, optimal for a straight-line program.  Nothing is looked up in the loop: a
-//      value that gets register r posts "free r" to the op where it dies (that op's record, or - for an op of the same 64-op batch -
-//      the batch's copy in a VGPR), and every op starts by returning what was posted to it.  The loop is inline assembly
-//      (p2_scan_batch: SGPRs, v_readlane / v_writelane, one LDS byte store per value that outlives its batch; 33 instructions per
-//      kept op), nothing in it waits for memory;
+//   B3 the one sequential step, in tape order over the KEPT ops only: linear scan, lowest free register first (optimal for a
+//      straight-line program).  The registers themselves hold the time they come back - a VGPR, lane = register, value = position of
+//      the last use of what the register holds - so an op finds the free ones with ONE compare over all 64, takes the lowest bit, and
+//      two v_writelane record the register's new last use and the op's register: 13 instructions per kept op in inline assembly
+//      (p2_scan_batch2), no look-up, no memory, no branch but the loop's;
 //   B4 the child's ops, 64 at a time.
 // No register copies are ever emitted: a consumer of a decided choice reads the surviving operand's register directly.  The
 // tapes differ from fh_prune1's (which re-uses the parent's structure and inserts a copy where an operand outlives the choice
@@ -58,7 +58,7 @@ enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4,
 #define FH_LK_IMM 0x4000u        // E: the choice's value is its immediate (reg,imm op decided Right): the op stays, as COPY_IMM
 
 // bytes of LDS per wave: wanted-op mask (128 x 8), position prefixes (128 x 2), E (2 per choice), kept-op records (8 each), last
-// uses (4 each), registers by position (1 each), registers returning at a position (2 each)
+// uses (4 each), registers by position (1 each; 2 spare bytes each)
 static inline __host__ __device__ size_t fh_p2_wave_lds(uint32_t n_choices, uint32_t cap_kept = FH_P2_MAX_KEPT) {
     return 1024 + 256 + (((size_t)n_choices * 2 + 15) & ~(size_t)15) + (size_t)cap_kept * (8 + 4 + 1 + 2) + 64;       // (the last 64: FH_P2_WPC waves' shared words)
 }
@@ -76,84 +76,11 @@ __device__ __forceinline__ uint32_t excl_sum(uint32_t v, uint32_t lane, uint32_t
     total = __shfl(x, 63, 64);
     return x - v;
 }
-// B3's inner loop for one batch of <= 64 kept ops, in tape order (see k_prune2, phase B3).  Per lane k of the batch: d = last use u
-// of the op's value | which operand of op u it is << 16 | the op's flags << 24 (bit 28: OUTPUT, takes no register); fr = the registers
-// that return at this op, bytes a | b << 8, each 0x40 | register or 0.  pool: free registers (bit = register); maxro: highest
-// register handed out so far (-1 = 0xFFFFFFFF once the pool ran dry); batch = position >> 6 of this batch; frees_lds: LDS address
-// of the frees table (2 bytes per position) for values that die in a later batch.  out: per lane the op's register.
-// Nothing in the loop waits for memory: the posted frees of this batch live in `fr` (v_readlane / v_writelane), later ones go out
-// by a one-lane ds_write_b8.
-__device__ __forceinline__ void p2_scan_batch(uint32_t d, uint32_t& fr, uint32_t& out, uint64_t& pool, uint32_t& maxro, uint32_t cnt, uint32_t batch,
-                                              uint32_t frees_lds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t k, sfr, sd, t0, t1, ro, rv, u, slt, va, vb;
-    uint64_t msk, save;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "s_mov_b32 %[k], 0\n"
-        "L_p2_loop_%=:\n\t"
-        "v_readlane_b32 %[sfr], %[fr], %[k]\n\t"
-        "v_readlane_b32 %[sd], %[d], %[k]\n\t"
-        "s_bfe_u32 %[t0], %[sfr], 0x10006\n\t"
-        "s_bfm_b64 %[msk], %[t0], %[sfr]\n\t"
-        "s_or_b64 %[pool], %[pool], %[msk]\n\t"
-        "s_lshr_b32 %[t1], %[sfr], 8\n\t"
-        "s_bfe_u32 %[t0], %[sfr], 0x1000e\n\t"
-        "s_bfm_b64 %[msk], %[t0], %[t1]\n\t"
-        "s_or_b64 %[pool], %[pool], %[msk]\n\t"
-        "s_mov_b32 %[ro], 0\n\t"
-        "s_bitcmp1_b32 %[sd], 28\n\t"
-        "s_cbranch_scc1 L_p2_store_%=\n\t"
-        "s_ff1_i32_b64 %[ro], %[pool]\n\t"
-        "s_and_b32 %[u], %[sd], 0xffff\n\t"
-        "s_max_u32 %[maxro], %[maxro], %[ro]\n\t"
-        "s_bitset0_b64 %[pool], %[ro]\n\t"
-        "s_bfe_u32 %[slt], %[sd], 0x10010\n\t"
-        "s_lshr_b32 %[t0], %[u], 6\n\t"
-        "s_or_b32 %[rv], %[ro], 0x40\n\t"
-        "s_cmp_eq_u32 %[t0], %[batch]\n\t"
-        "s_cbranch_scc0 L_p2_cross_%=\n\t"
-        "s_and_b32 %[t0], %[u], 63\n\t"
-        "s_lshl_b32 %[slt], %[slt], 3\n\t"
-        "v_readlane_b32 %[t1], %[fr], %[t0]\n\t"
-        "s_lshl_b32 %[rv], %[rv], %[slt]\n\t"
-        "s_mov_b32 m0, %[t0]\n\t"
-        "s_or_b32 %[t1], %[t1], %[rv]\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %[fr], %[t1], m0\n"
-        "L_p2_store_%=:\n\t"
-        "s_mov_b32 m0, %[k]\n\t"
-        "s_add_u32 %[k], %[k], 1\n\t"
-        "v_writelane_b32 %[out], %[ro], m0\n\t"
-        "s_cmp_lt_u32 %[k], %[cnt]\n\t"
-        "s_cbranch_scc1 L_p2_loop_%=\n\t"
-        "s_branch L_p2_done_%=\n"
-        "L_p2_cross_%=:\n\t"
-        "s_lshl_b32 %[t0], %[u], 1\n\t"
-        "s_add_u32 %[t0], %[t0], %[slt]\n\t"
-        "s_add_u32 %[t0], %[t0], %[fl]\n\t"
-        "v_mov_b32 %[va], %[t0]\n\t"
-        "v_mov_b32 %[vb], %[rv]\n\t"
-        "ds_write_b8 %[va], %[vb]\n\t"
-        "s_branch L_p2_store_%=\n"
-        "L_p2_done_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [fr] "+v"(fr), [out] "+v"(out), [pool] "+s"(pool), [maxro] "+s"(maxro), [k] "=&s"(k), [sfr] "=&s"(sfr), [sd] "=&s"(sd), [t0] "=&s"(t0),
-          [t1] "=&s"(t1), [ro] "=&s"(ro), [rv] "=&s"(rv), [u] "=&s"(u), [slt] "=&s"(slt), [msk] "=&s"(msk), [save] "=&s"(save), [va] "=&v"(va), [vb] "=&v"(vb)
-        : [d] "v"(d), [cnt] "s"(cnt), [batch] "s"(batch), [fl] "s"(frees_lds)
-        : "m0", "scc", "memory");
-#else
-    (void)d; (void)fr; (void)out; (void)pool; (void)maxro; (void)cnt; (void)batch; (void)frees_lds;
-#endif
-}
-// B3's loop, second form (round 5): the registers themselves keep the time they come back.  rel: lane r = the position of the last use
+// B3's loop: the registers themselves keep the time they come back.  rel: lane r = the position of the last use
 // of the value that register r holds (0: never used).  Op k of the batch, at position kabs, may take every register with rel <= kabs -
 // a value that dies AT op k gives its register to op k's result, as linear scan does -: one compare for all 64 registers, the lowest set
 // bit, two v_writelane (the register's new last use; the op's register).  u: lane k = last use of op k's value.  Nothing is posted
-// anywhere, nothing is looked up, no branch but the loop's: 13 instructions per kept op where the posting form above takes 33 and up to
-// three taken branches.  Same policy (lowest free register first), same registers.
+// anywhere, nothing is looked up, no branch but the loop's: 13 instructions per kept op.  Lowest free register first.
 __device__ __forceinline__ void p2_scan_batch2(uint32_t u, uint32_t& rel, uint32_t& out, uint32_t& maxro, uint32_t cnt, uint32_t kabs0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t k, su, ro, kabs = kabs0;
@@ -235,8 +162,7 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     uint2* const comp = (uint2*)(mine + 1280 + (((size_t)cap_choices * 2 + 15) & ~(size_t)15));       // per kept op: operand positions, op index | flags << 16
     uint32_t* const lastuse = (uint32_t*)((char*)comp + (size_t)cap_kept * 8);
     uint8_t* const regb = (uint8_t*)((char*)lastuse + (size_t)cap_kept * 4);
-    uint8_t* const frees = regb + (size_t)cap_kept;                       // registers that return at a time: bytes [2 t], [2 t + 1] (operand a / b of op t; 0xFF none)
-    uint32_t* const red = (uint32_t*)(frees + (size_t)cap_kept * 2);     // [0] kept ops m (B2), [1] highest register + 1, [2] kept choices (B4), [3] 0: the child goes on (the area's last 64 bytes)
+    uint32_t* const red = (uint32_t*)(regb + (size_t)cap_kept * 3);     // [0] kept ops m (B2), [1] highest register + 1, [2] kept choices (B4), [3] 0: the child goes on (the area's last 64 bytes)
     const uint32_t nw = (n + 63) >> 6;
     bool on = c < 64 && rfl(sl.c_len[min(c, 63u)]) == 0xFFFFFFFFu;    // marked for the prune; false: this wave only keeps the barriers company
     if (on && tid < 4) red[tid] = 0;
@@ -303,12 +229,13 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
 
     const uint64_t t_b1 = probe ? clock64() : 0;
     // ---- B1: liveness (one wave) ---------------------------------------------------------------------------------------------------
-    if (on && lead && (flags & 4u) == 0) {
+    if (on && lead) {
         // A work queue from the OUTPUT op: up to 64 queued ops a round, lane = op; a lane looks up its op's producers (through E) and sets
-        // their bits in the mask, and whoever finds a bit clear queues that op - once.  A child of the root tape keeps 100 - 200 of its
-        // 6 363 ops in sub-graphs 20 - 50 ops deep and ~10 wide, so this is 20 - 50 rounds of five LDS round trips; the sweep over the tape's
-        // 100 batches it replaces (below, flags bit 2) met a wanted op in nearly every batch and paid 1 300 cycles for each: 128 k cycles of
-        // the kernel's 360 k.  The queue (2 bytes per op, each kept op enters once) lies where the kept-op records go in B2.
+        // their bits in the mask, and whoever finds a bit clear queues that op - once.  A child of the root tape keeps 100 - 230 of its
+        // 6 363 ops.  (What this replaced: a sweep over the tape's 100 batches of 64 ops from its end, which met a wanted op in nearly
+        // every batch and paid 1 300 cycles for each - 128 k cycles of the kernel's 360 k.  The queue alone was no faster, 126 k: the kept
+        // ops of the root chain are one dependent path, a round each.  With the chain's head start below: 50 k.)
+        // The queue (2 bytes per op, each kept op enters once) lies where the kept-op records go in B2.
         for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
         // (the queue lies behind the child's staged choice words, which the head start below still reads)
         const uint32_t cw_bytes = (((nch + 15) / 16) * 4 + 15) & ~15u;
@@ -360,30 +287,6 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
         }
         if (over && lane == 0) red[3] = 1;
     }
-    if (on && lead && (flags & 4u) != 0) {
-        for (uint32_t k = lane; k < 128; k += 64) mask[k] = (k == ((n - 1) >> 6)) ? 1ull << ((n - 1) & 63) : 0ull;      // the OUTPUT op, the last of the tape
-        for (uint32_t b = nw; b-- > 0;) {
-            const uint32_t i = (b << 6) | lane;
-            const uint2 l = i < n ? lks[i] : make_uint2(FH_LK_NONE << 8, 0xFFFFFFFFu);      // (read beside the mask word: one wait for both)
-            uint64_t word = rfl64(mask[b]);
-            if (word == 0) continue;
-            bool has_a, has_b, imm;
-            uint32_t ta, tb;
-            resolve(l, has_a, has_b, imm, ta, tb);
-            uint64_t done = 0;
-            for (;;) {
-                const uint64_t newly = word & ~done;
-                if (newly == 0) break;
-                const bool my = (newly >> lane) & 1;
-                if (my && has_a) atomicOr((unsigned long long*)&mask[ta >> 6], 1ull << (ta & 63));
-                if (my && has_b) atomicOr((unsigned long long*)&mask[tb >> 6], 1ull << (tb & 63));
-                done |= newly;
-                // a producer inside this batch: one more round (otherwise nothing else can mark this batch any more)
-                if (__ballot(my && ((has_a && (ta >> 6) == b) || (has_b && (tb >> 6) == b))) == 0) break;
-                word = rfl64(mask[b]);
-            }
-        }
-    }
     if (on && lead) {
         // positions of the words' first kept ops (B2 needs them all)
         const uint32_t k0 = lane < nw ? (uint32_t)__popcll(mask[lane]) : 0u, k1 = lane + 64 < nw ? (uint32_t)__popcll(mask[lane + 64]) : 0u;
@@ -400,7 +303,7 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
         if (probe && lane == 0) atomicAdd(&S->leaf_stat[5], 1ull << 32);
         on = false;
     }
-    if (on) for (uint32_t k = tid; k < m; k += 64 * W) { lastuse[k] = 0; ((uint16_t*)frees)[k] = 0; }
+    if (on) for (uint32_t k = tid; k < m; k += 64 * W) lastuse[k] = 0;
     __syncthreads();
     auto pos_of = [&](uint32_t t) -> uint32_t { return (uint32_t)pref[t >> 6] + (uint32_t)__popcll(mask[t >> 6] & ((1ull << (t & 63)) - 1)); };
     if (on) {
@@ -427,43 +330,18 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     __syncthreads();
     const uint64_t t_b3 = probe ? clock64() : 0;
     // ---- B3: registers, in tape order over the kept ops (one wave) ------------------------------------------------------------------
-    // Linear scan with the look-ups taken out of the loop: a value's register is not looked up when an op reads it (that is
-    // done for all ops at once afterwards) - what the sequential step needs is only WHEN registers come back.  A value knows its
-    // last use u from B2 and which operand of op u it is; when it gets its register r, "free r" is posted to time u (slot a or b
-    // of frees[u]; for a time inside the current 64-op batch: into the batch's VGPR copy).  Op t then returns the registers posted
-    // to it, takes the lowest free one for its own value and posts that.  ~30 scalar / cross-lane instructions per kept op, no
-    // memory wait.  Registers 0 .. 63 only: a child that wants more is left to the scalar sweep.
-    // The loop itself is assembly (p2_scan_batch): 33 instructions per kept op against the compiler's ~55, one taken branch.
-    if (on && lead && (flags & 16u) == 0) {
+    // Linear scan: a value's register is not looked up when an op reads it (that is done for all ops at once in B4) - what the sequential
+    // step needs is only WHEN registers come back, and that is kept in the registers' own lanes (p2_scan_batch2).  Registers 0 .. 63 only:
+    // a child that wants more is left to the scalar sweep.  (Until late in round 5 a value posted "free r" to the op where it dies - the
+    // op's record in LDS, or a VGPR copy for an op of the same batch - and every op began by collecting what was posted to it: 33
+    // instructions and up to three taken branches per kept op, 113 k cycles for the slowest child where this loop takes 53 k.)
+    if (on && lead) {
         uint32_t maxro = 0, rel = 0;
         for (uint32_t base = 0; base < m; base += 64) {
             const uint32_t pl = base + lane;
             const uint32_t u = pl < m ? lastuse[pl] : 0u;          // (0 for the OUTPUT op, the last one: it takes the register its operand gives back, which nobody reads)
             uint32_t outv = 0;
             p2_scan_batch2(u, rel, outv, maxro, min(64u, m - base), base);
-            if (pl < m) regb[pl] = (uint8_t)outv;
-        }
-        if (maxro >= 64u) {          // more than 64 registers: left marked for the scalar sweep
-            if (probe && lane == 0) { atomicAdd(&S->leaf_stat[4], 1ull << 32); atomicMax(&S->leaf_stat[6], (unsigned long long)m << 32); }
-            if (lane == 0) red[3] = 1;
-        }
-    }
-    if (on && lead && (flags & 16u) != 0) {
-        uint64_t pool = ~0ull;
-        uint32_t maxro = 0;
-        const uint32_t frees_lds = (uint32_t)((char*)frees - smem);        // (the dynamic LDS area starts at LDS address 0: no static __shared__ here)
-        for (uint32_t base = 0; base < m; base += 64) {
-            const uint32_t pl = base + lane;
-            uint32_t vd = 16u << 24, vfr = 0;               // (lanes past the end: an OUTPUT-like no-op)
-            if (pl < m) {
-                const uint32_t u = lastuse[pl];                               // last use of this op's value (0 for the OUTPUT op)
-                const uint32_t slot = u ? ((comp[u].x & 0xFFFFu) == pl ? 0u : 1u) : 0u;
-                vd = u | (slot << 16) | ((comp[pl].y >> 16) << 24);           // ... which operand of that op it is, this op's flags
-                vfr = ((const uint16_t*)frees)[pl];                          // registers posted to this time by earlier batches (a | b << 8; each 0x40 | register, or 0)
-            }
-            const uint32_t cnt = min(64u, m - base);
-            uint32_t outv = 0;
-            p2_scan_batch(vd, vfr, outv, pool, maxro, cnt, base >> 6, frees_lds);
             if (pl < m) regb[pl] = (uint8_t)outv;
         }
         if (maxro >= 64u) {          // more than 64 registers: left marked for the scalar sweep
