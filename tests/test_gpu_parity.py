@@ -624,7 +624,7 @@ def test_assembly_tile_stage_of_transcendental_tapes(name, size):
 def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
     """Round 5: when the root level has few children the library renders with root tiles of 32^3 straight above the leaves (the linked
     prune of the ROOT tape per 32^3 tile, no level 1), and a root tape that reads nothing varying along a pixel column is evaluated for
-    one layer of root tiles per z-slab (capi_render.hpp root32_max, root_zrep; option no_zrep 2 / 1: not at the root / nowhere).  Neither may change a pixel: the oracle's image under
+    one layer of root tiles per z-slab - and, since nothing such a frame evaluates depends on z, for the FRONT slab only (capi_render.hpp root32_max, root_zrep, front_only; option no_zrep 3 / 2 / 1: every slab / not at the root / nowhere).  None of it may change a pixel: the oracle's image under
     every combination of the two - and with the column short cuts off (a tape with z everywhere), and under cameras that move x and y
     along a column (no invariance anywhere: rotated, perspective), and as the eight octants of the frame."""
     import torch
@@ -639,7 +639,8 @@ def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
         m = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.3, 1]], np.float32)
     ref = O.render3d(o, size, world_to_model=m)[0]
     ref_words = np.concatenate([ref["normal"].view(np.uint32), ref["depth"][..., None]], axis=2)
-    for root32_max, no_zrep, no_inv in ((4096, 0, 0), (0, 0, 0), (4096, 2, 0), (0, 2, 0), (4096, 1, 0), (4096, 0, 1), (1 << 20, 0, 0), (1 << 20, 0, 1)):
+    for root32_max, no_zrep, no_inv in ((4096, 0, 0), (0, 0, 0), (4096, 2, 0), (0, 2, 0), (4096, 1, 0), (4096, 0, 1), (1 << 20, 0, 0), (1 << 20, 0, 1),
+                                        (4096, 3, 0), (0, 3, 0)):
         if size == 1024 and root32_max == (1 << 20) and no_inv:
             continue        # (32 768 children through the scalar sweep: right, and slow)
         with hip.options(root32_max=root32_max, no_zrep=no_zrep, no_column_inv=no_inv):
@@ -753,3 +754,33 @@ def test_render2d_small_images_of_a_large_tape(size, ts):
     b = O.render2d(o, size, pixel_perfect=True, tile_sizes=ts or F.HIP_TILES_2D)[0]
     assert same_bits_f32(a, b)
     del p, hip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(1024, 1024, 768), (512, 384, 1280), (1024, 1024, 1024)])
+def test_render3d_front_slab_only_for_frames_without_z(dims):
+    """A frame whose tapes read nothing that changes along a pixel column renders its front z-slab only (round 5: a tile or a leaf
+    further back repeats the front one's result with a smaller depth).  The oracle's image for volumes whose depth is not a multiple
+    of the slab (a thin front slab), is deeper than wide, and with every slab rendered (no_zrep 3); queued frames alternate their
+    root levels between two streams, so a run of them - different sizes in turn - is checked frame by frame."""
+    import torch
+    w, h, d = dims
+    hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    hip.set_option("frame_lanes", 0)
+    p, o = F.Shape.from_vm(model_path("prospero.vm"), hip=hip), O.Shape.from_vm(model_path("prospero.vm"))
+    ref = O.render3d(o, w, h, d)[0]
+    small = O.render3d(o, 256)[0]
+    for no_zrep in (0, 3):
+        with hip.options(no_zrep=no_zrep):
+            outs = [torch.zeros((h, w, 4), dtype=torch.int32, device="cuda") for _ in range(6)]
+            mids = [torch.zeros((256, 256, 4), dtype=torch.int32, device="cuda") for _ in range(6)]
+            for a, b in zip(outs, mids):
+                F.render3d(p, w, h, d, out=a)
+                F.render3d(p, 256, out=b)
+            hip.sync()
+            for a, b in zip(outs, mids):
+                got = a.cpu().numpy().view(np.uint32)
+                assert (got[..., 3] == ref["depth"]).all(), (no_zrep, int((got[..., 3] != ref["depth"]).sum()))
+                assert same_bits_f32(got[..., :3].view(np.float32), ref["normal"]), no_zrep
+                gs = b.cpu().numpy().view(np.uint32)
+                assert (gs[..., 3] == small["depth"]).all() and same_bits_f32(gs[..., :3].view(np.float32), small["normal"]), no_zrep
