@@ -851,6 +851,25 @@ def render3d(shape, width, height=None, depth=None, world_to_model=None, tile_si
     height = width if height is None else height
     depth = width if depth is None else depth
     hip = shape.hip
+    if out is not None and world_to_model is None and not tile_sizes and not vars and shape._vars is None:
+        # (the same frame again - what a caller that holds its RenderConfig does: the configuration struct is kept with the shape, the call
+        # is the C call and nothing else; queued frames are bound by the thread that queues them)
+        key = (width, height, depth, shard, n_shards, None if block is None else (int(block[0]), tuple(int(b) for b in block[1])))
+        frames = shape.__dict__.setdefault("_frames", {})
+        ent = frames.get(key)
+        if ent is None:
+            cfg = _Cfg3D(width, height, depth, None, None, 0, None, None, 0, None)
+            split = None if block is None else np.array(block[1], dtype=np.uint32)
+            ent = frames[key] = (cfg, C.byref(cfg), split, _p(split))
+        if block is not None:
+            st = lib().fhip_render3d_block(hip._h, shape._h, ent[1], C.c_void_p(out.data_ptr()), 1, key[5][0], ent[3])
+        else:
+            st = lib().fhip_render3d_shard(hip._h, shape._h, ent[1], C.c_void_p(out.data_ptr()), 1, shard, n_shards)
+        if st:
+            if st == 4:
+                raise ValueError("MissingVar")
+            hip.check(st)
+        return out, None, None
     ts = np.array(tile_sizes, dtype=np.uint32) if tile_sizes else None
     w2m = None if world_to_model is None else np.ascontiguousarray(world_to_model, np.float32)
     vk, vv = _var_arrays(shape, vars)

@@ -85,16 +85,6 @@ static std::vector<uint32_t> hip_tiles_3d(uint32_t max_size) {
 // 2D hint of the HIP shape: 128 -> 16 with 16 x 16 pixel leaves - what fidget-jit uses (fidget-jit/src/lib.rs:984-986); a fan-out
 // of 64 children per parent fills a wavefront of the tile-stage kernels (the VM's 128 / 32 / 8 fans out by 16)
 static const uint32_t HIP_TILES_2D[] = {128, 16};
-static bool tape_is_full(const fh::HostTape& t) {
-    for (uint64_t w : t.ops) {
-        const uint32_t op = FH_W_OP((uint32_t)w);
-        if ((op >= FH_SIN && op <= FH_LN) || op == FH_ATAN2_RR || op == FH_ATAN2_RI || op == FH_ATAN2_IR ||
-            op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR)
-            return true;
-    }
-    return false;
-}
-
 // medium LDS layout of the tile stage (pre-pass levels below the root): 48 KB, three waves per CU
 static const uint32_t MID_REGS = 64, MID_CHOICES = 768;
 static size_t tiles_lds(uint32_t regs, uint32_t choices, uint32_t TL) {

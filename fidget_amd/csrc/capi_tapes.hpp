@@ -82,25 +82,31 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
 // ... the *_t tile kernels have an interval handler for every opcode (round 5 added atan2, modulo, rand and mix: gen_tiles.py b_atan2 ..
 // b_mix), so every tape the assembly leaf kernels take, the assembly tile kernels take
 static bool tape_tiles_t_ok(const fh::HostTape&) { return true; }
-static bool tape_has_mod(const fh::HostTape& t) {
+// What kinds of opcodes a tape holds: one walk per tape, remembered in the tape (a frame's set-up asked five times, 4 us each for
+// prospero's 6 363 ops, when the host thread had become the pacemaker of queued frames).  bit 0: looked up; 1: transcendental / rng /
+// atan2 / mix / modulo opcodes (the *_t kernels' handlers); 2: a modulo; 3: transcendental / atan2 / modulo (the C++ kernels' FULL variants)
+static uint32_t tape_class(const fh::HostTape& t) {
+    uint32_t c = __atomic_load_n(&t.op_class, __ATOMIC_ACQUIRE);
+    if (c) return c;
+    c = 1;
     for (uint64_t w : t.ops) {
         const uint32_t op = FH_W_OP((uint32_t)w);
-        if (op == FH_MOD_RR || op == FH_MOD_RI || op == FH_MOD_IR) return true;
-    }
-    return false;
-}
-// The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
-static bool tape_asm_ok(const fh::HostTape& t) {
-    for (uint64_t w : t.ops) {
-        const uint32_t op = FH_W_OP((uint32_t)w);
-        if ((op >= FH_SIN && op <= FH_LN) || op == FH_RAND) return false;
+        if ((op >= FH_SIN && op <= FH_LN) || op == FH_RAND) c |= 2;
+        if (op >= FH_SIN && op <= FH_LN) c |= 8;
         if (op >= FH_ADD_RR) {
             const int base = op >= FH_SUB_IR ? (int[]){1, 3, 4, 5, 6, 7}[op - FH_SUB_IR] : (int)((op - FH_ADD_RR) % 12);
-            if (base == 4 || base == 6 || base == 7) return false;  // atan2, mix, mod
+            if (base == 4 || base == 6 || base == 7) c |= 2;  // atan2, mix, mod
+            if (base == 4 || base == 7) c |= 8;
+            if (base == 7) c |= 4;
         }
     }
-    return true;
+    __atomic_store_n(&t.op_class, c, __ATOMIC_RELEASE);
+    return c;
 }
+static bool tape_has_mod(const fh::HostTape& t) { return (tape_class(t) & 4) != 0; }
+// The assembly interpreters implement every opcode except the transcendental, modulo and rng ones
+static bool tape_asm_ok(const fh::HostTape& t) { return (tape_class(t) & 2) == 0; }
+static bool tape_is_full(const fh::HostTape& t) { return (tape_class(t) & 8) != 0; }
 
 static fhip_status tape_to_device(fhip_ctx* ctx, const fhip_tape* t) {
     std::lock_guard<std::mutex> guard(t->upload_lock);

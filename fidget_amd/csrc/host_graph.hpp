@@ -362,6 +362,7 @@ struct HostTape {
     std::vector<uint64_t> ops;  // evaluation order
     uint32_t n_regs = 0, n_choices = 0, n_outputs = 0, n_vars = 0;
     VarTable vars;
+    mutable uint32_t op_class = 0;   // what kinds of opcodes the tape holds, looked up once (capi_tapes.hpp tape_class; 0: not yet)
 };
 
 // Links of a register-allocated tape for the linked prune (prune2.hip): the tape's dependency graph with the register numbers
