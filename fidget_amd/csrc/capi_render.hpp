@@ -994,7 +994,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     const uint32_t n_groups = R.groups_per_slab;
     const uint32_t pre = R.S.pre_levels;
     const int reset_blocks = (int)std::max<uint32_t>(1, std::min<uint32_t>(1024, (std::max(R.table_words, n_groups) + 255) / 256));
-    const int class_blocks = (int)((R.n_footprints + 255) / 256);
+    const int class_blocks = (int)((R.n_footprints + FH_CLASSIFY_FP - 1) / FH_CLASSIFY_FP);
     // Pipelined frames: the root level stays on the pre-pass stream, the level below it moves to the head of this frame's tile
     // chains on the side stream.  The two coarse levels of a frame are one dependent chain of ~0.9 ms that, on one stream, set
     // the frame rate; split, the root level of frame n + 1 runs beside level 1 and the slabs of frame n, and the side stream

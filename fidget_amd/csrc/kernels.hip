@@ -1232,25 +1232,38 @@ __global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
 
 // Footprint classification for the 3D column kernels: a footprint goes to the variant that
 // fits the largest register count among its leaves (class 0: <= 16, 1: <= 32, 2: LDS).
-__global__ void k_classify3d(FhRenderState* S, int merge01) {
+// grid: blocks of 256 threads = 32 footprints x 8 layer groups: a thread reads every eighth layer of its footprint's column - up to eight
+// independent loads, all in flight at once - and the eight partial maxima meet in LDS.  (One thread per footprint walking its 64
+// layers took 26 us at 1024^2, on the caller's stream of every frame since the tail stream carries root levels: 64 loads, eight in
+// flight.)
+#define FH_CLASSIFY_FP 32
+__global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge01) {
+    __shared__ uint32_t mx_s[FH_CLASSIFY_FP], any_s[FH_CLASSIFY_FP];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.slab / T;
-    const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t fl = threadIdx.x % FH_CLASSIFY_FP, lg = threadIdx.x / FH_CLASSIFY_FP, n_lg = 256 / FH_CLASSIFY_FP;
+    const uint32_t fi = blockIdx.x * FH_CLASSIFY_FP + fl;
+    if (threadIdx.x < FH_CLASSIFY_FP) { mx_s[threadIdx.x] = 0; any_s[threadIdx.x] = 0; }
+    __syncthreads();
     const FhLeafRef* col = S->leaf_table + fi;  // [layer][footprint]
     uint32_t mx = 0;
     bool any = false;
-    // (the table entry carries the leaf's register count beside its number: no dependent load of the leaf record per layer - a
-    // z-slab of four root-tile layers has 64 of them -, and the loads of a column are independent of each other)
+    // (the table entry carries the leaf's register count beside its number: no dependent load of the leaf record per layer)
     if (fi < fw * fh) {
 #pragma unroll 8
-        for (uint32_t l = 0; l < layers; l++) {
+        for (uint32_t l = lg; l < layers; l += n_lg) {
             const FhLeafRef e = col[(size_t)l * fw * fh];
             if (e.id) { any = true; mx = max(mx, e.len_regs >> 24); }
         }
     }
-    // one atomic per wave and class instead of one per footprint
+    if (any) { atomicMax(&mx_s[fl], mx); any_s[fl] = 1; }
+    __syncthreads();
+    if (threadIdx.x >= FH_CLASSIFY_FP) return;
+    mx = mx_s[fl];
+    any = any_s[fl] != 0;
+    // one atomic per block and class instead of one per footprint
     // merge01: the assembly leaf kernel picks the register-file shape per leaf, one list for <= 32 registers
     const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= 32 ? (merge01 ? 0 : 1) : 2));
     const int lane = threadIdx.x & (WAVE - 1);
