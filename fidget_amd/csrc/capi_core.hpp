@@ -321,10 +321,15 @@ template <class... K> struct FhKArgs<void (*)(K...)> {
 };
 template <auto Kernel, class... A>
 static inline void fh_launch(int device, dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
-    static hipFunction_t fns[16] = {};
-    static bool no_handle = false;
-    hipFunction_t& fn = fns[device & 15];
-    if (!fn && !no_handle && (hipGetFuncBySymbol(&fn, (const void*)Kernel) != hipSuccess || !fn)) { fn = nullptr; no_handle = true; (void)hipGetLastError(); }
+    // (contexts live on their own threads: the handle of a (kernel, device) is looked up by whoever comes first, and by a second thread
+    // that comes at the same time - to the same value)
+    static std::atomic<hipFunction_t> fns[16];
+    static std::atomic<bool> no_handle{false};
+    hipFunction_t fn = fns[device & 15].load(std::memory_order_acquire);
+    if (!fn && !no_handle.load(std::memory_order_relaxed)) {
+        if (hipGetFuncBySymbol(&fn, (const void*)Kernel) != hipSuccess || !fn) { fn = nullptr; no_handle.store(true, std::memory_order_relaxed); (void)hipGetLastError(); }
+        else fns[device & 15].store(fn, std::memory_order_release);
+    }
     if (!fn) { hipLaunchKernelGGL(Kernel, g, b, lds, st, std::forward<A>(a)...); return; }
     alignas(16) char buf[FhKArgs<decltype(Kernel)>::bytes];
     size_t bytes = FhKArgs<decltype(Kernel)>::pack(buf, std::forward<A>(a)...);

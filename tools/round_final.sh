@@ -6,6 +6,7 @@ TAG=${1:-r05z}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+timeout -k 5 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout -k 5 900 python -m pytest tests -m gpu -q -x -n 2 --timeout 600 > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log
 grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" $O/gpu_tests.log | tail -4
 timeout -k 5 900 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -30 $O/profile_round.log | cut -c1-200
