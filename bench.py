@@ -247,6 +247,7 @@ def main():
         return float(np.median(lat))
 
     partitions = {}
+    bytes_default = None
     general = None
     host_frame = None
     lat_general = None
@@ -289,6 +290,12 @@ def main():
         dt = timed(step)
         lat_default = latency(step)
         img_default = out.clone()
+        if free_before is not None:       # what the context holds for the path `value` times (before the general path's frames grow the arena)
+            try:
+                hip.sync()
+                bytes_default = int(free_before - mem_info(dev)[0]) - img_default.numel() * 4
+            except Exception:       # noqa: BLE001
+                bytes_default = None
         # the same frames with the column-invariance short cuts off: leaves evaluated once per voxel, every tile of a z-stack
         # evaluated - prospero.vm has no z, so every one of its tapes takes the short cuts
         if not args.no_general and not args.only_general:
@@ -378,7 +385,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frame_latency_ms": lat_default,
-        "device_bytes": device_bytes,
+        "device_bytes": device_bytes, "device_bytes_timed_path": bytes_default,
         "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "last_measured": tuning["last"],
                               "note": "the library measures a run of queued frames of one kind under its stage pipeline and on its frame lanes and keeps the faster "
                                       "(DESIGN.md section 4); bench.py lets that finish before the timed frames"},
@@ -625,7 +632,7 @@ def compact_line(result):
     set and the size).  Everything else bench.py measured - per-kernel times, device counters, the other kernels' rooflines, the notes -
     goes to the details file the line names."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes")
+            "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "device_bytes_timed_path")
     line = {k: result[k] for k in keep if k in result}
     cfg = result["config"]
     line["config"] = {"workload": cfg["workload"], "sharding": cfg["sharding"], "column_invariance": cfg["column_invariance"][:300],
