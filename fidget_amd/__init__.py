@@ -56,7 +56,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_tape_links", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_trans_probe", "fhip_debug_lane_frames", "fhip_debug_lane_tune", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_tape_links", "fhip_debug_tape_chain", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_trans_probe", "fhip_debug_lane_frames", "fhip_debug_lane_tune", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -173,7 +173,7 @@ def lib():
             "fhip_mesh_merge": (i32, [vp, vp, vp, u32, vp, C.POINTER(vp)]),
             "fhip_profile_enable": (None, [vp, i32]), "fhip_profile_read": (i32, [vp, vp, vp]), "fhip_profile_read_kernels": (i32, [vp, vp, vp]),
             "fhip_render_counters": (i32, [vp, vp]),
-            "fhip_debug_stats": (i32, [vp, vp]), "fhip_debug_leaf_stats": (i32, [vp, vp]), "fhip_debug_tape_links": (u32, [vp, vp, u32]),
+            "fhip_debug_stats": (i32, [vp, vp]), "fhip_debug_leaf_stats": (i32, [vp, vp]), "fhip_debug_tape_links": (u32, [vp, vp, u32]), "fhip_debug_tape_chain": (u32, [vp, vp, u32]),
             "fhip_tape_group_count": (u32, [vp]), "fhip_tape_group_op": (i32, [vp]),
             "fhip_tape_group": (i32, [vp, vp, u32, vp]), "fhip_tape_term_plan": (u32, [vp, vp]), "fhip_tape_term_group": (i32, [vp, vp, u32, vp]),
             "fhip_tape_term_tree": (u32, [vp, vp, u32]), "fhip_tape_term_choice_src": (u32, [vp, vp, u32]),
@@ -612,6 +612,13 @@ class Shape:
             return None
         w = w[:n]
         return np.stack([w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFFFF, (w >> 32) & 0xFFFF, (w >> 48) & 0xFFFF], axis=1).astype(np.int64)
+
+    def chain(self):
+        """The root chain for the linked prune's liveness pass (fhip_debug_tape_chain): [n, 2] = (choice ordinal, op index) per chain op in
+        evaluation order; empty when the root tree is no chain"""
+        w = np.zeros(65536, dtype=np.uint32)
+        n = lib().fhip_debug_tape_chain(self._h, _p(w), len(w))
+        return np.stack([w[:n] & 0xFFFF, w[:n] >> 16], axis=1).astype(np.int64)
 
     def ops(self):
         """Device tape as (name, out, a, b, imm_bits) tuples in evaluation order."""

@@ -45,6 +45,16 @@ uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t ca
     for (size_t i = 0; i < lk.size() && i < cap; i++) out[i] = lk[i];
     return (uint32_t)lk.size();
 }
+// ... and its root chain as the linked prune's liveness pass gets it (capi_tapes.hpp chain_table): choice ordinal | op index << 16 per chain
+// op, evaluation order; 0: the root is no chain (or the tape does not qualify)
+uint32_t fhip_debug_tape_chain(const fhip_tape* tape, uint32_t* out, uint32_t cap) {
+    std::vector<uint64_t> lk;
+    std::vector<uint64_t> cops;
+    if (!fh::compute_links(tape->t, lk, cops)) return 0;
+    const std::vector<uint32_t> chain = chain_table(tape, cops);
+    for (size_t i = 0; i < chain.size() && i < cap; i++) out[i] = chain[i];
+    return (uint32_t)chain.size();
+}
 // ... and the leaf stage's counters of the last (profiled) 3D frame: render_state.h leaf_stat
 fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]) {
     fhip_status st = finish_render(ctx);

@@ -427,14 +427,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                     uint64_t *dl = nullptr, *dc = nullptr;
                     // the root chain's ops (plan.chain: acc = min / max(acc, term) all the way to the OUTPUT op) in evaluation order, behind the choice
                     // table: the linked prune's liveness pass starts from every kept op of the chain at once instead of walking it link by link
-                    std::vector<uint32_t> chain;
-                    if (tape->plan.chain && tape->plan.top.size() < 65536) {
-                        chain.assign(tape->plan.top.size(), 0xFFFFFFFFu);
-                        for (size_t q = 0; q < tape->plan.choice_src.size() && q < cops.size(); q++)
-                            if ((tape->plan.choice_src[q] >> 24) == 255 && (tape->plan.choice_src[q] & 0xFFFFFFu) < chain.size())
-                                chain[tape->plan.choice_src[q] & 0xFFFFFFu] = (uint32_t)q | ((uint32_t)((cops[q] >> 32) & 0xFFFFu) << 16);
-                        for (uint32_t c : chain) if (c == 0xFFFFFFFFu) { chain.clear(); break; }
-                    }
+                    std::vector<uint32_t> chain = chain_table(tape, cops);
                     const size_t n_cops = std::max<size_t>(cops.size(), 1);
                     cops.resize(n_cops + (chain.size() + 1) / 2, 0);
                     if (!chain.empty()) memcpy(cops.data() + n_cops, chain.data(), chain.size() * 4);

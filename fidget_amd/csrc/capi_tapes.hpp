@@ -82,6 +82,21 @@ static hipError_t launch_asm(fhip_ctx* ctx, int which, uint32_t waves, void* arg
 // ... the *_t tile kernels have an interval handler for every opcode (round 5 added atan2, modulo, rand and mix: gen_tiles.py b_atan2 ..
 // b_mix), so every tape the assembly leaf kernels take, the assembly tile kernels take
 static bool tape_tiles_t_ok(const fh::HostTape&) { return true; }
+// The root chain of a tape for the linked prune's liveness pass (prune2.hip B1): when the root tree is a chain acc = min / max(acc, term)
+// all the way to the OUTPUT op (plan.chain), its ops in evaluation order as choice ordinal | op index << 16 - `cops` is compute_links'
+// per-choice table (word 1 = the op's index | class << 16).  Empty when the root is no chain.
+static std::vector<uint32_t> chain_table(const fhip_tape* tape, const std::vector<uint64_t>& cops) {
+    std::vector<uint32_t> chain;
+    if (tape->plan.chain && tape->plan.top.size() < 65536) {
+        chain.assign(tape->plan.top.size(), 0xFFFFFFFFu);
+        for (size_t q = 0; q < tape->plan.choice_src.size() && q < cops.size(); q++)
+            if ((tape->plan.choice_src[q] >> 24) == 255 && (tape->plan.choice_src[q] & 0xFFFFFFu) < chain.size())
+                chain[tape->plan.choice_src[q] & 0xFFFFFFu] = (uint32_t)q | ((uint32_t)((cops[q] >> 32) & 0xFFFFu) << 16);
+        for (uint32_t c : chain) if (c == 0xFFFFFFFFu) { chain.clear(); break; }
+    }
+    return chain;
+}
+
 // What kinds of opcodes a tape holds: one walk per tape, remembered in the tape (a frame's set-up asked five times, 4 us each for
 // prospero's 6 363 ops, when the host thread had become the pacemaker of queued frames).  bit 0: looked up; 1: transcendental / rng /
 // atan2 / mix / modulo opcodes (the *_t kernels' handlers); 2: a modulo; 3: transcendental / atan2 / modulo (the C++ kernels' FULL variants)

@@ -18,6 +18,9 @@ fhip_status fhip_debug_leaf_stats(fhip_ctx* ctx, uint64_t out[8]);
 /* The per-op links of a tape for the linked prune (prune2.hip): word 0 = producer op of operand a | of operand b << 16 (0xFFFF none),
  * word 1 = choice index | op class << 16; returns the number of ops, 0 when the tape does not qualify. */
 uint32_t fhip_debug_tape_links(const fhip_tape* tape, uint64_t* out, uint32_t cap);
+/* ... and its root chain (acc = min / max(acc, term) all the way to the OUTPUT op) as the liveness pass of the linked prune gets it:
+   choice ordinal | op index << 16 per chain op, evaluation order; returns the chain's length, 0 when the root is no chain */
+uint32_t fhip_debug_tape_chain(const fhip_tape* tape, uint32_t* out, uint32_t cap);
 /* Copies the FhLeaf records (24 bytes: tape offset, length, registers | choices << 16, x, y, z) of the
  * last slab of the last 3D frame; returns their number. */
 uint32_t fhip_debug_leaves(fhip_ctx* ctx, void* out, uint32_t cap);
