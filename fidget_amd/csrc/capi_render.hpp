@@ -444,7 +444,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
                 }
             }
             R.p2_cap_kept = (uint32_t)FH_P2_MAX_KEPT;
-            R.lds_prune2 = (((size_t)t.ops.size() * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices, R.p2_cap_kept) + (((size_t)tape->n_chain * 4 + 15) & ~(size_t)15);
+            R.lds_prune2 = (size_t)FH_P2_WPB * fh_p2_wave_lds(t.n_choices, R.p2_cap_kept) + (((size_t)tape->n_chain * 4 + 15) & ~(size_t)15);
             R.n_chain = tape->n_chain;
             // (one workgroup of FH_P2_WPB children per CU: beyond two rounds of them - 2048^3 has 4 096 root tiles - the scalar sweep,
             // whose waves all fit the machine at once, is the faster one again: 2.09 against 2.17 ms per frame)

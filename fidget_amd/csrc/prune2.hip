@@ -29,8 +29,7 @@
 // that passed it on) in register numbers and in those copies; values are those of the parent tape on the child's region, op for
 // op (tests/test_prune2.py evaluates both on points of the tile).
 //
-//   grid   : one wave per child lane of a slot, blockDim / 64 waves per workgroup: they share the parent's links, staged in LDS
-//            (8 B per op: the liveness pass would otherwise wait for a load per batch)
+//   grid   : FH_P2_WPC waves per child lane of a slot, FH_P2_WPB children per workgroup
 //   limits : <= 8192 ops, <= 4096 choices in the parent, <= cap_kept kept ops and <= 64 registers in the child (more: the child
 //            is left to the scalar sweep launched behind this kernel), one OUTPUT op, the last one - capi.hip checks and keeps fh_prune1 otherwise
 //
@@ -42,12 +41,12 @@
 
 #include "render_state.h"
 
-#define FH_P2_WPB 4                                             // children per workgroup (they share the parent's links in LDS)
+#define FH_P2_WPB 4                                             // children per workgroup (they share the root chain's table in LDS)
 #define FH_P2_WPC 4                                             // waves per child (the phases that are parallel over the tape; B1 and B3 are one wave's)
 #define FH_P2_PER_SLOT ((64 + FH_P2_WPB - 1) / FH_P2_WPB)      // ... workgroups per slot (the last one's spare waves idle)
 #define FH_P2_MAX_OPS 8192u
 #define FH_P2_MAX_CHOICES 4096u
-#define FH_P2_MAX_KEPT 1280u                                    // (4 waves' areas + prospero's links = 152 KB of the CU's 160)
+#define FH_P2_MAX_KEPT 1280u                                    // (four children's areas: 104 KB of the CU's 160)
 // op classes of a link
 enum { FH_LK_OUT = 0, FH_LK_NONE = 1, FH_LK_A = 2, FH_LK_RR = 3, FH_LK_COPY = 4, FH_LK_CRR = 5, FH_LK_CRI = 6 };
 // Link of an op, 8 bytes: word 0 = opcode | class << 8 | choice ordinal << 16, word 1 = fa | fb << 16: the producers of operands a and
@@ -150,12 +149,15 @@ __device__ __forceinline__ void p2_item(FhRenderState* S, uint32_t level, uint32
     const uint32_t off = rfl(sl.tape.off), n = rfl(sl.tape.len), nch = rfl((uint32_t)sl.tape.n_choices);
     if (n > cap_ops || nch > cap_choices) return;                       // (left marked)
     const uint2* const ops = (const uint2*)(S->arena + off);
-    uint2* const lks = (uint2*)smem;                                     // the parent's links, shared by the workgroup's waves
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lks[i] = links[i];
+    // the parent's links are read where they lie, through L2 (8 B per op, the same 51 KB for every workgroup).  Until the end of round 5
+    // every workgroup staged them in LDS - 155 KB per workgroup with the four children's areas, a compute unit's LDS to itself - for the
+    // liveness pass's sake, which then was a sweep over all of them; the queue reads the links of kept ops only, and with 104 KB other
+    // streams' kernels fit beside this one: 0.139 -> 0.135 ms per frame (profiles/r05i/sweep10)
+    const uint2* const lks = links;
     // (the root chain's ops, evaluation order: choice ordinal | op index << 16 - behind the children's areas, shared like the links)
-    uint32_t* const chl = (uint32_t*)(smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)FH_P2_WPB * fh_p2_wave_lds(cap_choices, cap_kept));
+    uint32_t* const chl = (uint32_t*)(smem + (size_t)FH_P2_WPB * fh_p2_wave_lds(cap_choices, cap_kept));
     for (uint32_t i = threadIdx.x; i < n_chain; i += blockDim.x) chl[i] = chain[i];
-    char* const mine = smem + (((size_t)cap_ops * 8 + 15) & ~(size_t)15) + (size_t)kid * fh_p2_wave_lds(cap_choices, cap_kept);
+    char* const mine = smem + (size_t)kid * fh_p2_wave_lds(cap_choices, cap_kept);
     uint64_t* const mask = (uint64_t*)mine;                               // wanted ops, 64 per word (128 words)
     uint16_t* const pref = (uint16_t*)(mine + 1024);                    // kept ops before each word
     uint16_t* const E = (uint16_t*)(mine + 1280);                       // per choice: the op its value is (| FH_LK_IMM)
