@@ -113,7 +113,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
     *out = c;
     return FHIP_OK;
 }
-static void lanes_release(fhip_ctx* ctx);      // (capi_render.hpp)
+static void lanes_release(fhip_ctx* ctx, bool keep_measurements = false);      // (capi_render.hpp)
 void fhip_ctx_destroy(fhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

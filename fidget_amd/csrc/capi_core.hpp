@@ -181,6 +181,7 @@ struct fhip_ctx : FrameBufs {
     std::vector<fhip_ctx*> lanes;
     uint32_t lane_next = 0;
     uint64_t lane_frames = 0;         // frames that went to a lane so far (fhip_debug_lane_frames)
+    uint64_t lane_frames_wanted = 0;  // ... not counting the tuner's measuring windows
     hipEvent_t ev_last = nullptr;     // the end of the last 3D frame on the caller's stream ("is the frame before still under way?")
     bool ev_last_valid = false;
     // Which of the two arrangements a queued 3D frame takes is MEASURED, per (tape, image size): consecutive queued frames of one kind
@@ -206,7 +207,7 @@ struct fhip_ctx : FrameBufs {
 };
 
 // The cached forms of some options (what the rest of the driver reads)
-#define FH_ARENA_START_MB 256
+#define FH_ARENA_START_MB 128
 static void apply_options(fhip_ctx* c) {
     c->use_asm = c->opt.no_asm == 0;
     c->use_split = c->opt.no_split == 0;

@@ -158,7 +158,7 @@ static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P
 static fhip_status grow_arena_if_asked(fhip_ctx* ctx, size_t tape_ops) {
     const size_t need = ((tape_ops + 64) * 8 + 4096) * 4;       // (root tape + its groups, with room to prune into)
     bool grow = ctx->host_flags && ctx->host_flags[0] != 0 && ctx->arena_bytes < ctx->arena_cap_bytes;
-    size_t want = grow ? ctx->arena_bytes * (ctx->arena_bytes <= ((size_t)FH_ARENA_START_MB << 20) ? 4 : 2) : ctx->arena_bytes;      // (the first step is the big one: a frame that outgrows 256 MB is usually one with z in every tape, at 4 x the ops)
+    size_t want = grow ? ctx->arena_bytes * (ctx->arena_bytes <= ((size_t)FH_ARENA_START_MB << 20) ? 4 : 2) : ctx->arena_bytes;      // (the first step is the big one: a frame that outgrows the first 128 MB is usually one with z in every tape, at 4 x the ops and more)
     if (want < need) { want = need; grow = ctx->arena_bytes < std::min(need, ctx->arena_cap_bytes); }
     if (!grow) return FHIP_OK;
     HIP_TRY(ctx, hipDeviceSynchronize());       // (every stream of the context, its lanes included: a set's arena is about to be replaced)
@@ -1260,8 +1260,8 @@ static bool lanes_possible(fhip_ctx* ctx, int out_is_device) {
     return q == hipErrorNotReady;
 }
 static void lane_tune_release(fhip_ctx* ctx);
-static void lanes_release(fhip_ctx* ctx) {
-    lane_tune_release(ctx);       // (what was measured was measured under the options of the moment)
+static void lanes_release(fhip_ctx* ctx, bool keep_measurements) {
+    if (!keep_measurements) lane_tune_release(ctx);       // (what was measured was measured under the options of the moment)
     for (fhip_ctx* L : ctx->lanes) {
         hipStream_t const s = L->lane_stream_owned ? L->stream : nullptr;
         if (L->lane_done) (void)hipEventDestroy(L->lane_done);
@@ -1310,6 +1310,7 @@ static fhip_status run_on_lane_(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes,
     HIP_TRY(ctx, hipEventRecord(L->lane_copied, ctx->stream));
     L->lane_copied_valid = true;
     ctx->lane_frames++;
+    if (ctx->tune_cur < 0) ctx->lane_frames_wanted++;      // (not a frame of a measuring window: somebody's arrangement of choice)
     return FHIP_OK;
 }
 // (FHIP_LANE_FALLBACK: the lanes' own resources could not be had - device memory for a child context's buffers, say: the caller renders the
@@ -1400,6 +1401,15 @@ static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_
         (void)hipGetLastError();
         T.lanes = ok ? T.ms[1] < 0.97f * std::min(T.ms[0], T.ms[2]) : prior;
         T.phase = 4;
+        // Memory by need: the child contexts exist since the measuring windows (a buffer set each, 0.5 GB).  When the verdict is the stage
+        // pipeline, nothing else has ever used them and no other kind of frame is being measured, they go back - all windows' frames are
+        // through (the last window's last event has passed, above), their images copied out before it.  A later frame that wants lanes
+        // (a 2D queue, another kind's verdict) makes them again.
+        if (!T.lanes && ctx->lane_frames_wanted == 0) {
+            bool others = false;
+            for (const fhip_ctx::LaneTune& o : ctx->lane_tune) others = others || (&o != &T && (o.phase != 4 || o.lanes));
+            if (!others) lanes_release(ctx, true);
+        }
         return T.lanes;
     }
     ctx->tune_cur = at;

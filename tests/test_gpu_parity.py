@@ -667,7 +667,7 @@ def test_render3d_root_tiles_of_32_and_root_column_invariance(size, camera):
 
 
 def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
-    """Round 5: a buffer set's tape arena starts at 256 MB and grows when a frame ran out (the frame is still right); until round 4 every set
+    """Round 5: a buffer set's tape arena starts at 128 MB and grows when a frame ran out (the frame is still right); until round 4 every set
     held 4 GiB - 18.6 GB per context for a peak use of 0.1.  A context that has rendered the headline frame a few times holds under 3 GB;
     fhip_ctx_trim gives the frame lanes and the mesher's leaf records back; a small arena cap still gives the oracle's image."""
     import torch
@@ -676,7 +676,7 @@ def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
     hip.set_option("frame_lanes", 0)
     p = F.Shape.from_vm(model_path("prospero.vm"), hip=hip)
     out = torch.zeros((1024, 1024, 4), dtype=torch.int32, device="cuda")
-    for no_inv, bound in ((0, 3.0), (1, 6.5)):        # (GiB: four buffer sets of 0.33 GB + the arena: 256 MB, 1 GB when every tape has z - 65 M ops in flight per set)
+    for no_inv, bound in ((0, 3.0), (1, 6.5)):        # (GiB: four buffer sets of 0.33 GB + the arena: 128 MB, 1 GB when every tape has z - 65 M ops in flight per set)
         with hip.options(no_column_inv=no_inv):
             for _ in range(16):
                 F.render3d(p, 1024, out=out)
