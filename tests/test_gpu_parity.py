@@ -3,6 +3,8 @@
 Bar (north star): interval pruning decisions and occupancy bit-exact, f32 values within 1 ulp.
 For models without transcendentals (prospero, hi, colonnade, quarter) EVERYTHING is compared
 bit for bit (pixels, fills incl. their recursion level, depth, normals)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -671,6 +673,8 @@ def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
     held 4 GiB - 18.6 GB per context for a peak use of 0.1.  A context that has rendered the headline frame a few times holds under 3 GB;
     fhip_ctx_trim gives the frame lanes and the mesher's leaf records back; a small arena cap still gives the oracle's image."""
     import torch
+    # (free device memory is the DEVICE's: with other test processes on it - pytest -n - the readings mean nothing, and only the images are checked)
+    alone = not os.environ.get("PYTEST_XDIST_WORKER")
     free0 = torch.cuda.mem_get_info()[0]
     hip = F.HipContext(0, torch.cuda.current_stream().cuda_stream)
     hip.set_option("frame_lanes", 0)
@@ -682,7 +686,7 @@ def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
                 F.render3d(p, 1024, out=out)
             hip.sync()
         used = free0 - torch.cuda.mem_get_info()[0]
-        assert used < bound * 2 ** 30, (no_inv, used)
+        assert used < bound * 2 ** 30 or not alone, (no_inv, used)
     ref = O.render3d(O.Shape.from_vm(model_path("prospero.vm")), 1024)[0]
     got = out.cpu().numpy().view(np.uint32)
     assert (got[..., 3] == ref["depth"]).all() and same_bits_f32(got[..., :3].view(np.float32), ref["normal"])
@@ -695,7 +699,7 @@ def test_device_memory_of_a_context_follows_need_and_trim_gives_caches_back():
     with_lanes = free0 - torch.cuda.mem_get_info()[0]
     hip.trim()
     after = free0 - torch.cuda.mem_get_info()[0]
-    assert after <= with_lanes and (F.lib().fhip_debug_lane_frames(hip._h) == 0 or after < with_lanes)
+    assert not alone or (after <= with_lanes and (F.lib().fhip_debug_lane_frames(hip._h) == 0 or after < with_lanes))
     del p, b, hip
 
 
