@@ -347,3 +347,15 @@ def test_column_mode_gives_the_layer_modes_words(kind, mat):
     assert (b == want).all(), f"{(b != want).sum()} z-buffer words differ from numpy's"
     busy = [w for w in wb if w.counts.get("vmem", 0) > 1]
     assert len(wb) == 64 and len(busy) == 3, (len(wb), len(busy))        # 16 footprints in a grid of 64, three columns with leaves
+
+
+def test_column_mode_in_the_transcendental_kernel():
+    """fh_columns_t has the same column walk (the kernels share their generator): a tape with transcendental opcodes, two leaves in one
+    column and one beside it, the words of the layer walk."""
+    sh, tape, ik = trans_shape(0)
+    size = 32
+    leaves = [(8, 16, 24), (8, 16, 8), (16, 16, 16)]
+    a, _ = run_columns(tape, sh.slot_count(), ik, AFFINE32, leaves[0], size=size, more_leaves=leaves[1:], kernel="fh_columns_t")
+    b, wb = run_columns(tape, sh.slot_count(), ik, AFFINE32, leaves[0], size=size, more_leaves=leaves[1:], kernel="fh_columns_t", column_mode=True)
+    assert (a != 0).any() and (a == b).all(), f"{(a != b).sum()} z-buffer words differ"
+    assert len(wb) == 64
