@@ -71,7 +71,22 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
                          (const void*)k_leaves3d<2, 0, 1, false>, (const void*)k_leaves3d<2, 0, 1, true>,
                          (const void*)k_normals3d<false, true>, (const void*)k_normals3d<true, true>};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);
-    if (hipModuleLoadData(&c->asm_mod, fh_interp_co) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    {   // diagnostics (A/B runs of assembly variants, tools/variants.py): FHIP_INTERP_CO=<file> replaces the embedded code object
+        std::vector<char> alt;
+        if (const char* p = getenv("FHIP_INTERP_CO")) {
+            if (FILE* f = fopen(p, "rb")) {
+                fseek(f, 0, SEEK_END);
+                long n = ftell(f);
+                fseek(f, 0, SEEK_SET);
+                alt.resize(n > 0 ? (size_t)n : 0);
+                if (n <= 0 || fread(alt.data(), 1, (size_t)n, f) != (size_t)n) alt.clear();
+                fclose(f);
+            }
+            if (alt.empty()) { fprintf(stderr, "fidget-hip: FHIP_INTERP_CO=%s cannot be read\n", p); delete c; return FHIP_ERR_HIP; }
+            fprintf(stderr, "fidget-hip: assembly kernels from %s\n", p);
+        }
+        if (hipModuleLoadData(&c->asm_mod, alt.empty() ? (const void*)fh_interp_co : (const void*)alt.data()) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
+    }
     for (int i = 0; i < FH_ASM_COUNT; i++)
         if (hipModuleGetFunction(&c->asm_fn[i], c->asm_mod, FH_ASM_NAMES[i]) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
     (void)hipFuncSetAttribute((const void*)c->asm_fn[FH_ASM_TILES], hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX);

@@ -39,7 +39,10 @@ screen-to-model matrix stay on the C++ kernels.
 usage: gen_interp.py offsets.json out.s
 """
 import json
+import os
 import sys
+
+EXP = os.environ.get("FH_EXP", "")     # experiments (tools/build_variant.py): never set in a product build
 
 # ---- opcodes (tape_format.h) ---------------------------------------------------------------
 OPS = ["OUTPUT", "INPUT", "COPY_REG", "COPY_IMM",
@@ -82,6 +85,11 @@ S_OUT = "s67"
 S_A = "s68"
 S_T1 = "s69"
 S_NEXT = "s[70:71]"      # address of the decode copy of the next op
+S_NX, S_NX_LO, S_NX_HI = "s[48:49]", "s48", "s49"   # threaded dispatch: the NEXT op's out | a << 8 and word 1 (the scalar batches are not used then)
+S_JN, S_JN_LO, S_JN_HI = "s[50:51]", "s50", "s51"   # ... and its handler's address
+S_TCUR = "s[52:53]"     # threaded dispatch, tapes of more than 64 ops: the next chunk's first op
+S_REM = "s54"           # ... and the ops from there to the end of the tape
+S_LONG = "s[56:57]"     # ... and the address of the code that fetches and decodes a chunk (the NEXT_CHUNK pseudo-op's target)
 S_JMP = "s[44:45]"       # handler address (the interpreter's tape argument is consumed by then)
 S_FETCH = "s[72:73]"
 S_RET = "s[74:75]"
@@ -168,6 +176,16 @@ class Interp:
         self.hl = HSTRIDE_LOG2
         self.next = f".L{name}_next"
         self.ool = []  # out-of-line handler bodies: (label, callable)
+        # Threaded dispatch (the leaf kernel, round 6): there is no dispatcher to return to - a handler starts by reading the NEXT op's
+        # three decoded words out of the lane that holds it (behind its own vector work in the pipeline: the v_readlane -> scalar use
+        # latency, which was a third of a lone wave's time per op, is off the critical path) and ends with ONE jump, straight into the
+        # next op's handler.  This op's words were read by the handler before it, into S_NX / S_JN.
+        self.threaded = kind == "columns" and EXP != "oldinterp"
+        self.s_out = S_W0 if self.threaded else S_OUT     # bits 7:0: file index of `out` (threaded: word 0 of S_CUR is out | a << 8)
+        self.s_a = S_A                                    # file index of `a` (threaded: handlers that need it shift it out of s_out)
+        if self.threaded:
+            self.hl = 8            # slots of 256 bytes: the prologue, and min / max in place without a jump to their body
+        self.ip_slot_log2 = self.hl
 
     def F(self, j):
         """sample j of the register selected by the index (M0 = register * ZB)"""
@@ -192,24 +210,45 @@ class Interp:
         self.a("\ts_set_gpr_idx_off")
 
     def b_index(self):
-        """S_T1 = file index of the register named by word 1"""
+        """-> the SGPR whose bits 7:0 are the file index of the register named by word 1 (threaded: the decode has shifted it)"""
+        if self.threaded:
+            return S_W1
         self.a(f"\ts_lshl_b32 {S_T1}, {S_W1}, {self.lg}")
+        return S_T1
+
+    def prologue(self, need_a=False, prefetch=True):
+        """threaded dispatch: this op's words S_NX -> S_CUR, the next op's words -> S_NX / S_JN.  (v_readlane honours SRC0-relative
+        index mode and no other - tools/probe_isa.py -: no handler leaves through ret() with SRC0-relative mode on.)"""
+        if not self.threaded:
+            return
+        a = self.a
+        if prefetch:
+            a(f"""
+	s_mov_b64 {S_CUR}, {S_NX}
+	v_readlane_b32 {S_JN_LO}, {V_DEC[0]}, {S_LEN}
+	v_readlane_b32 {S_NX_LO}, {V_DEC[1]}, {S_LEN}
+	v_readlane_b32 {S_NX_HI}, {V_DEC[3]}, {S_LEN}
+	s_add_u32 {S_LEN}, {S_LEN}, 1""")
+        else:
+            a(f"\ts_mov_b64 {S_CUR}, {S_NX}")
+        if need_a:
+            a(f"\ts_lshr_b32 {S_A}, {S_W0}, 8")
 
     def pk_mov(self, dst, src):
         self.a(f"\tv_pk_mov_b32 {dst}, {src}, {src} op_sel:[0,1]")
 
     def read_a(self, dst):
         """dst = file[a]; leaves the index mode on (SRC0 | SRC1 relative)."""
-        self.idx_on(S_A, SRC0 | SRC1)
+        self.idx_on(self.s_a, SRC0 | SRC1)
         for k in range(self.zb // 2):
             self.pk_mov(self.P(dst, k), self.FP(k))
 
     def read_b(self, dst, already_on=True):
-        self.b_index()
+        sb = self.b_index()
         if already_on:
-            self.idx_idx(S_T1)
+            self.idx_idx(sb)
         else:
-            self.idx_on(S_T1, SRC0 | SRC1)
+            self.idx_on(sb, SRC0 | SRC1)
         for k in range(self.zb // 2):
             self.pk_mov(self.P(dst, k), self.FP(k))
 
@@ -217,15 +256,34 @@ class Interp:
         for j in range(self.zb):
             self.a(f"\tv_mov_b32 {dst[j]}, {S_W1}")
 
-    def ret(self):
-        # (a copy of the vector dispatcher here instead - one taken jump per op less - was measured: no change in the leaf
-        # kernel's time, which is set by the number of instructions issued per op, not by the jumps' latency)
+    def ret(self, src0_on=False):
+        """end of a handler.  src0_on: the index mode in force is SRC0-relative (threaded: switched off, the next handler starts
+        with v_readlane)"""
+        if self.threaded:
+            if src0_on:
+                self.idx_off()
+            return self.a(f"\ts_setpc_b64 {S_JN}")
         self.a(f"\ts_setpc_b64 {S_NEXT}")
 
     def call(self, fn):
         """call the embedded routine fh_t_<fn> (gen_trans.py): argument(s) v128 (, v129), result v128, return address s[96:97];
         clobbers v128..v153, s86..s97 and vcc (the mask scratch of the handlers: nothing live)"""
         here, ret = self.a.label("call"), self.a.label("ret")
+        if self.threaded:       # (the handler tables of the threaded dispatch put the routines beyond s_branch's 128 KB: a computed jump)
+            far = self.a.label("far")
+            return self.a(f"""
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_getpc_b64 s[70:71]
+{far}:
+	s_mov_b32 s72, {self.t_prefix}{fn} - {far}
+	s_ashr_i32 s73, s72, 31
+	s_add_u32 s70, s70, s72
+	s_addc_u32 s71, s71, s73
+	s_setpc_b64 s[70:71]
+{ret}:""")
         self.a(f"""
 	s_getpc_b64 s[96:97]
 {here}:
@@ -253,7 +311,7 @@ class Interp:
 
     def write_out(self, src, done=True):
         """file[out] = src; ends the handler."""
-        self.idx_on(S_OUT, DST)
+        self.idx_on(self.s_out, DST)
         for k in range(self.zb // 2):
             self.pk_mov(self.FP(k), self.P(src, k))
         if done:
@@ -399,36 +457,51 @@ class Interp:
                "MIN_RR", "MAX_RR"}
 
     def handler(self, op, inplace=False):
-        """One handler slot.  `inplace`: the decode found out == a (slots 64 + opcode, ops of INPLACE only): the
-        op then works on the file entry itself."""
+        """One handler slot.  `inplace`: the decode found out == a (the in-place table, ops of INPLACE only): the
+        op then works on the file entry itself.  Threaded dispatch: every handler starts with prologue() (this op's words,
+        the next op's prefetch) and none leaves with SRC0-relative index mode on: the in-place forms keep the file operand
+        in src1 where the instruction allows."""
         a, zb, F = self.a, self.zb, self.F
         Z, PZ = range(zb), range(zb // 2)
+        T = self.threaded
+        s_ip = self.s_out if T else S_A          # in place: out == a, either index will do (threaded: the one that needs no shift)
         if op == "OUTPUT":
             return self.h_output()
         if op == "INPUT":
+            self.prologue()
             return self.out_of_line("input", self.h_input)
+        if op in ("INPUT_X", "INPUT_Y", "INPUT_Z"):        # (threaded decode only: an INPUT op whose slot is the axis')
+            self.prologue()
+            return self.h_input_axis("XYZ".index(op[-1]))
+        if op == "NEXT_CHUNK":
+            return a(f"\ts_setpc_b64 {S_LONG}")
         if op == "COPY_REG":
+            self.prologue(need_a=True)
             self.read_a(VT)
             return self.write_out(VT)
         if op == "COPY_IMM":
-            self.idx_on(S_OUT, DST)
+            self.prologue()
+            self.idx_on(self.s_out, DST)
             for j in Z:
                 a(f"\tv_mov_b32 {F(j)}, {S_W1}")
             return self.ret()
         if op in ("NEG", "ABS", "FLOOR", "CEIL"):
+            self.prologue(need_a=not inplace)
             ins = {"NEG": f"v_xor_b32 {{d}}, {S_SIGN}, {{s}}", "ABS": f"v_and_b32 {{d}}, {S_ABSM}, {{s}}",
                    "FLOOR": "v_floor_f32 {d}, {s}", "CEIL": "v_ceil_f32 {d}, {s}"}[op]
             src = SRC1 if op in ("NEG", "ABS") else SRC0
-            self.idx_on(S_A, src | (DST if inplace else 0))
+            self.idx_on(s_ip if inplace else self.s_a, src | (DST if inplace else 0))
             for j in Z:
                 a("\t" + ins.format(d=F(j) if inplace else VT[j], s=F(j)))
-            return self.ret() if inplace else self.write_out(VT)
+            return self.ret(src0_on=src == SRC0) if inplace else self.write_out(VT)
         if op == "SQUARE":
-            self.idx_on(S_A, SRC0 | SRC1 | (DST if inplace else 0))
+            self.prologue(need_a=not inplace)
+            self.idx_on(s_ip if inplace else self.s_a, SRC0 | SRC1 | (DST if inplace else 0))
             for k in PZ:
                 a(f"\tv_pk_mul_f32 {self.FP(k) if inplace else self.P(VT, k)}, {self.FP(k)}, {self.FP(k)}")
-            return self.ret() if inplace else self.write_out(VT)
+            return self.ret(src0_on=True) if inplace else self.write_out(VT)
         if op == "NOT":
+            self.prologue(need_a=True)
             def body():
                 self.read_a(VT)
                 self.idx_off()
@@ -436,6 +509,7 @@ class Interp:
                 self.write_out(VU)
             return self.out_of_line("not", body)
         if op in ("RECIP", "SQRT", "ROUND"):
+            self.prologue(need_a=True)
             def body(op=op):
                 self.read_a(VT)
                 self.idx_off()
@@ -449,6 +523,7 @@ class Interp:
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         if op in ("SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "EXP", "LN"):
+            self.prologue(need_a=True)
             def body(fn=op.lower()):
                 self.read_a(VT)
                 self.idx_off()
@@ -467,6 +542,7 @@ class Interp:
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         if op == "RAND":
+            self.prologue(need_a=True)
             def body():
                 self.read_a(VT)
                 self.idx_off()
@@ -478,6 +554,7 @@ class Interp:
             return self.out_of_line("rand", body)
         base, form = op.rsplit("_", 1)
         if base in ("ATAN2", "MOD", "MIX"):
+            self.prologue(need_a=True)
             def body(base=base, form=form):
                 self.read_a(VT)
                 if form == "RR":
@@ -501,39 +578,44 @@ class Interp:
             return self.out_of_line(op.lower(), body)
         if base in ("ADD", "SUB", "MUL") and form != "RR":
             # register (op) immediate, two samples per instruction: the immediate is the high half of the op's
-            # SGPR pair, selected for both samples.  a - imm = a + (-imm) and imm - a = (-a) + imm, exactly.
+            # SGPR pair, selected for both samples, in src0; the file operand in src1 (no SRC0-relative mode: see prologue).
+            # a - imm = (-imm) + a and imm - a = imm + (-a), exactly.
+            self.prologue(need_a=not inplace)
             ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
-            mod = {("SUB", "RI"): " neg_lo:[0,1] neg_hi:[0,1]", ("SUB", "IR"): " neg_lo:[1,0] neg_hi:[1,0]"}.get((base, form), "")
-            self.idx_on(S_A, SRC0 | (DST if inplace else 0))
+            mod = {("SUB", "RI"): " neg_lo:[1,0] neg_hi:[1,0]", ("SUB", "IR"): " neg_lo:[0,1] neg_hi:[0,1]"}.get((base, form), "")
+            self.idx_on(s_ip if inplace else self.s_a, SRC1 | (DST if inplace else 0))
             for k in PZ:
-                a(f"\t{ins} {self.FP(k) if inplace else self.P(VT, k)}, {self.FP(k)}, {S_CUR} op_sel:[0,1] op_sel_hi:[1,1]{mod}")
+                a(f"\t{ins} {self.FP(k) if inplace else self.P(VT, k)}, {S_CUR}, {self.FP(k)} op_sel:[1,0] op_sel_hi:[1,1]{mod}")
             return self.ret() if inplace else self.write_out(VT)
         if base in ("ADD", "SUB", "MUL"):
             ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
-            negb = " neg_lo:[0,1] neg_hi:[0,1]" if base == "SUB" else ""
-            if inplace:                              # file[a] = file[a] (op) b, b through VU
+            if inplace:                              # file[a] = file[a] (op) b, b through VU:  b (op) a for add / mul, (-b) + a for sub
+                self.prologue()
                 self.read_b(VU, already_on=False)
-                self.idx_on(S_A, SRC0 | DST)
+                self.idx_on(s_ip, SRC1 | DST)
+                negb = " neg_lo:[1,0] neg_hi:[1,0]" if base == "SUB" else ""
                 for k in PZ:
-                    a(f"\t{ins} {self.FP(k)}, {self.FP(k)}, {self.P(VU, k)}{negb}")
+                    a(f"\t{ins} {self.FP(k)}, {self.P(VU, k)}, {self.FP(k)}{negb}")
                 return self.ret()
+            self.prologue(need_a=True)
+            negb = " neg_lo:[0,1] neg_hi:[0,1]" if base == "SUB" else ""
             self.read_a(VT)                          # a in VT; then VT = VT (op) file[b]
-            self.b_index()
-            self.idx_on(S_T1, SRC1)
+            self.idx_on(self.b_index(), SRC1)
             for k in PZ:
                 a(f"\t{ins} {self.P(VT, k)}, {self.P(VT, k)}, {self.FP(k)}{negb}")
             return self.write_out(VT)
         if base in ("MIN", "MAX") and form == "RR" and inplace:
-            # out == a (nearly always: the accumulator of a union / intersection): the file entry is updated in
-            # place.  a < b ? a : b written as !(a < b) ? b : a so that `a`, the relative operand, stays SRC0.
-            ncmp = "v_cmp_nlt_f32_e64" if base == "MIN" else "v_cmp_ngt_f32_e64"
-            def body(ncmp=ncmp):
-                # !(a < b) ? b : a alone is right unless a is a NaN and b is not (it then takes b): the samples of a are summed
+            # out == a (nearly always: the accumulator of a union / intersection): the file entry is updated in place.
+            # min: a < b ? a : b (max: a > b ? a : b) with b in src0 and a, the relative operand, in src1: b > a (b < a) selects a.
+            cmp = "v_cmp_gt_f32_e64" if base == "MIN" else "v_cmp_lt_f32_e64"
+            self.prologue()
+            def body(cmp=cmp):
+                # The select alone is right unless a is a NaN and b is not (it then takes b): the samples of a are summed
                 # first - a NaN among them makes the sum one (so may an inf - inf: that only costs the long way round) - and
                 # the two tests and two selects per sample (dev_ops.hpp f_min / f_max to the letter) are left to that case.
                 slow = a.label("mm_nan")
                 self.read_b(VU, already_on=False)
-                self.idx_idx(S_A)                   # (mode still SRC0 | SRC1: both operands a's samples, plain destination)
+                self.idx_idx(s_ip)                  # (mode still SRC0 | SRC1: both operands a's samples, plain destination)
                 if zb >= 4:
                     for k in range(zb // 4):
                         a(f"\tv_pk_add_f32 {self.P(VW, k)}, {self.FP(2 * k)}, {self.FP(2 * k + 1)}")
@@ -545,28 +627,36 @@ class Interp:
                     a(f"\tv_add_f32 {VW[0]}, {F(0)}, {F(1)}")
                     self.idx_off()
                 a(f"\tv_cmp_u_f32 vcc, {VW[0]}, {VW[0]}")
-                self.idx_on(S_A, SRC0 | DST)
+                self.idx_on(s_ip, SRC1 | DST)
                 a(f"\ts_cbranch_vccnz {slow}")
                 for g in range(0, zb, 4):
                     js = list(range(g, min(g + 4, zb)))
                     for j in js:
-                        a(f"\t{ncmp} {S_M[j % 4]}, {F(j)}, {VU[j]}")
+                        a(f"\t{cmp} {S_M[j % 4]}, {VU[j]}, {F(j)}")
                     if len(js) < 3:
                         a(f"\ts_nop {2 - len(js)}")
                     for j in js:
-                        a(f"\tv_cndmask_b32_e64 {F(j)}, {F(j)}, {VU[j]}, {S_M[j % 4]}")
+                        a(f"\tv_cndmask_b32_e64 {F(j)}, {VU[j]}, {F(j)}, {S_M[j % 4]}")
                 self.ret()
-                a(f"{slow}:")
-                for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
-                    for q in (0, 1):
-                        a(f"\t{ncmp} {S_M[2 * q]}, {F(j + q)}, {VU[j + q]}")
-                        a(f"\tv_cmp_u_f32_e64 {S_M[2 * q + 1]}, {F(j + q)}, {VU[j + q]}")
-                    for q in (0, 1):
-                        a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {VU[j + q]}, {S_M[2 * q]}")
-                        a(f"\tv_cndmask_b32_e64 {F(j + q)}, {F(j + q)}, {V_QNAN}, {S_M[2 * q + 1]}")
-                self.ret()
+                def slow_body():
+                    for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
+                        for q in (0, 1):
+                            a(f"\t{cmp} {S_M[2 * q]}, {VU[j + q]}, {F(j + q)}")
+                            a(f"\tv_cmp_o_f32_e64 {S_M[2 * q + 1]}, {VU[j + q]}, {F(j + q)}")
+                        for q in (0, 1):
+                            a(f"\tv_cndmask_b32_e64 {F(j + q)}, {VU[j + q]}, {F(j + q)}, {S_M[2 * q]}")
+                            a(f"\tv_cndmask_b32_e64 {F(j + q)}, {V_QNAN}, {F(j + q)}, {S_M[2 * q + 1]}")
+                    self.ret()
+                if T:
+                    self.ool.append((slow, slow_body))
+                else:
+                    a(f"{slow}:")
+                    slow_body()
+            if T:           # (threaded: slots of 256 bytes, no jump to the body)
+                return body()
             return self.out_of_line(op.lower() + "_i", body)
         # two plain operands A, B in VT / VU, result in VW
+        self.prologue(need_a=True)
         def body(base=base, form=form):
             self.read_a(VT)
             if form == "RR":
@@ -590,6 +680,8 @@ class Interp:
         a = self.a
         if self.kind == "columns":
             # the one output of a shape tape is its last op: back to the caller
+            if self.threaded:
+                a(f"\ts_lshr_b32 {S_A}, {S_NX_LO}, 8")
             self.read_a(VRES)
             self.idx_off()
             return a(f"\ts_waitcnt lgkmcnt(0)\n\ts_setpc_b64 {S_RET}")
@@ -632,7 +724,6 @@ class Interp:
         # columns: the slot is x, y or z (model coordinates of the ZB voxels of this pass, computed
         # here: ((m[4r] x + m[4r+1] y) + m[4r+2] z) + m[4r+3], dev_ops.hpp xf_point) or a bound constant
         lab = {k: a.label("in_" + k) for k in ("x", "y", "z", "done")}
-        m = S_MAT
         a(f"""
 	s_cmp_eq_u32 {S_W1}, {S_SLOTX}
 	s_cbranch_scc1 {lab['x']}
@@ -645,69 +736,89 @@ class Interp:
 	s_addc_u32 s87, s5, 0
 	s_load_dword {S_T1}, {S_PC}, {self.off['P.in_value']}
 	s_waitcnt lgkmcnt(0)""")
-        self.idx_on(S_OUT, DST)
+        self.idx_on(self.s_out, DST)
         for j in range(self.zb):
             a(f"\tv_mov_b32 {self.F(j)}, {S_T1}")
         a(f"\ts_branch {lab['done']}")
-        for axis, (row, acc) in (("x", (0, V_AX)), ("y", (1, V_AY)), ("z", (2, V_AZ))):
-            a(f"{lab[axis]}:")
-            # The axis' matrix row has no z coefficient and the matrix is not projective (kernarg flags bit 17 + row clear: from
-            # the camera alone, whatever the tape-level short cuts are set to): m[4r+2] is a zero, m[4r+2] * z is that same zero
-            # for every voxel (z >= 0), so the 8 samples are ONE value, ((m[4r] x + m[4r+1] y) + m[4r+2]) + m[4r+3] - the sum in
-            # the order of the general path, bit for bit - instead of a convert, a multiply and two adds per sample.
-            vary = a.label("in_vary_" + axis)
-            a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, {17 + row}\n\ts_cbranch_scc1 {vary}")
-            a(f"\tv_add_f32 {VT[0]}, s{m + 4 * row + 2}, {acc}\n\tv_add_f32 {VT[0]}, s{m + 4 * row + 3}, {VT[0]}\n\tv_mov_b32 {VT[1]}, {VT[0]}")
-            self.idx_on(S_OUT, DST)
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_mov_b32 {self.FP(k)}, {self.P(VT, 0)}, {self.P(VT, 0)} op_sel:[0,1]")
+        for axis in range(3):
+            a(f"{lab['xyz'[axis]]}:")
+            vary = a.label("in_vary")
+            self.axis_const(axis, vary)
             a(f"\ts_branch {lab['done']}\n{vary}:")
-            a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
-            for j in range(self.zb):      # z of sample j = lz + k - j
-                a(f"\tv_cvt_f32_u32 {VT[j]}, {S_T0}")
-                if j + 1 < self.zb:
-                    a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
-            a(f"\ts_mov_b32 s96, s{m + 4 * row + 2}\n\ts_mov_b32 s97, s{m + 4 * row + 3}")
-            a(f"\tv_mov_b32 {VU[0]}, {acc}")       # (an aligned pair for the packed add; its low half serves both samples)
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel_hi:[1,0]")
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, {self.P(VU, 0)} op_sel_hi:[1,0]")
-            proj = a.label("in_proj_" + axis)
-            a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, 16\n\ts_cbranch_scc1 {proj}")
-            self.idx_on(S_OUT, DST)
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_add_f32 {self.FP(k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
-            a(f"\ts_branch {lab['done']}")
-            # projective matrix (shape/mod.rs:906-916, nalgebra transform_point): the row value divided by
-            # w = ((m[12] x + m[13] y) + m[14] z) + m[15] wherever w != 0
-            a(f"{proj}:")
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
-            a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
-            for j in range(self.zb):
-                a(f"\tv_cvt_f32_u32 {VU[j]}, {S_T0}")
-                if j + 1 < self.zb:
-                    a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
-            a(f"\ts_mov_b32 s96, s{m + 14}\n\ts_mov_b32 s97, s{m + 15}")
-            a(f"\tv_mov_b32 {VW[0]}, {V_AW}")
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_mul_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel_hi:[1,0]")
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, {self.P(VW, 0)} op_sel_hi:[1,0]")
-            for k in range(self.zb // 2):
-                a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
-            self.f_div(VT, VU, VW)
-            self.mask_pass(lambda j, mk: f"v_cmp_neq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VT[j]}, {VT[j]}, {VW[j]}, {mk}")
-            self.write_out(VT, done=False)
-            if axis != "z":
+            self.axis_vary(axis)
+            if axis != 2:
                 a(f"\ts_branch {lab['done']}")
         a(f"{lab['done']}:")
         self.idx_off()
         self.ret()
 
+    def h_input_axis(self, axis):
+        """threaded decode: an INPUT op of the x / y / z slot has its own handler (no slot compares, no jump for the common case)"""
+        vary = self.ool_label(f"in_vary_{'xyz'[axis]}", lambda: (self.axis_vary(axis), self.ret()))
+        self.idx_off()          # (plain vector code first: the handler before this one may have left a mode on)
+        self.axis_const(axis, vary)
+        self.ret()
+
+    def axis_const(self, axis, vary):
+        # The axis' matrix row has no z coefficient and the matrix is not projective (kernarg flags bit 17 + row clear: from
+        # the camera alone, whatever the tape-level short cuts are set to): m[4r+2] is a zero, m[4r+2] * z is that same zero
+        # for every voxel (z >= 0), so the 8 samples are ONE value, ((m[4r] x + m[4r+1] y) + m[4r+2]) + m[4r+3] - the sum in
+        # the order of the general path, bit for bit - instead of a convert, a multiply and two adds per sample.
+        a, m, row, acc = self.a, S_MAT, axis, (V_AX, V_AY, V_AZ)[axis]
+        a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, {17 + row}\n\ts_cbranch_scc1 {vary}")
+        a(f"\tv_add_f32 {VT[0]}, s{m + 4 * row + 2}, {acc}\n\tv_add_f32 {VT[0]}, s{m + 4 * row + 3}, {VT[0]}\n\tv_mov_b32 {VT[1]}, {VT[0]}")
+        self.idx_on(self.s_out, DST)
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_mov_b32 {self.FP(k)}, {self.P(VT, 0)}, {self.P(VT, 0)} op_sel:[0,1]")
+
+    def axis_vary(self, axis):
+        """file[out] = the axis' model coordinate of the ZB voxels of this pass (index mode: off on entry, DST-relative on exit)"""
+        a, m, row, acc = self.a, S_MAT, axis, (V_AX, V_AY, V_AZ)[axis]
+        self.idx_off()
+        a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
+        for j in range(self.zb):      # z of sample j = lz + k - j
+            a(f"\tv_cvt_f32_u32 {VT[j]}, {S_T0}")
+            if j + 1 < self.zb:
+                a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
+        a(f"\ts_mov_b32 s96, s{m + 4 * row + 2}\n\ts_mov_b32 s97, s{m + 4 * row + 3}")
+        a(f"\tv_mov_b32 {VU[0]}, {acc}")       # (an aligned pair for the packed add; its low half serves both samples)
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_mul_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel_hi:[1,0]")
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, {self.P(VU, 0)} op_sel_hi:[1,0]")
+        proj, done = a.label("in_proj"), a.label("in_vdone")
+        a(f"\ts_bitcmp1_b32 {S_PROJFLAG}, 16\n\ts_cbranch_scc1 {proj}")
+        self.idx_on(self.s_out, DST)
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_add_f32 {self.FP(k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+        a(f"\ts_branch {done}")
+        # projective matrix (shape/mod.rs:906-916, nalgebra transform_point): the row value divided by
+        # w = ((m[12] x + m[13] y) + m[14] z) + m[15] wherever w != 0
+        a(f"{proj}:")
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_add_f32 {self.P(VT, k)}, {self.P(VT, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+        a(f"\ts_add_u32 {S_T0}, {S_LZ}, {S_K}")
+        for j in range(self.zb):
+            a(f"\tv_cvt_f32_u32 {VU[j]}, {S_T0}")
+            if j + 1 < self.zb:
+                a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
+        a(f"\ts_mov_b32 s96, s{m + 14}\n\ts_mov_b32 s97, s{m + 15}")
+        a(f"\tv_mov_b32 {VW[0]}, {V_AW}")
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_mul_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel_hi:[1,0]")
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, {self.P(VW, 0)} op_sel_hi:[1,0]")
+        for k in range(self.zb // 2):
+            a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
+        self.f_div(VT, VU, VW)
+        self.mask_pass(lambda j, mk: f"v_cmp_neq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VT[j]}, {VT[j]}, {VW[j]}, {mk}")
+        self.write_out(VT, done=False)
+        a(f"{done}:")
+
     # -- the interpreter -------------------------------------------------------------------
     def emit(self):
+        if self.threaded:
+            return self.emit_threaded()
         a, n, lg = self.a, self.name, self.lg
         qa, qb = S_QA, S_QB
         COPY = 128
@@ -796,6 +907,13 @@ class Interp:
                     self.ret()             # never reached for tapes routed here (host checks)
                 elif inplace and op not in self.INPLACE:
                     a(f"\ts_branch .L{n}_h{i}")
+                elif EXP == "nowork" and self.kind == "columns":     # experiment: the dispatch alone (every op a no-op, the result "outside")
+                    if op == "OUTPUT":
+                        for j in range(self.zb):
+                            a(f"\tv_mov_b32 {VRES[j]}, 1.0")
+                        a(f"\ts_setpc_b64 {S_RET}")
+                    else:
+                        self.ret()
                 else:
                     self.handler(op, inplace)
                 # the next .p2align would silently grow the slot: an explicit assertion on its size
@@ -806,11 +924,58 @@ class Interp:
             fn()
 
 
+
+    # pseudo-opcodes of the threaded decode (slots the tape format leaves free)
+    PSEUDO = {52: "INPUT_X", 53: "INPUT_Y", 54: "INPUT_Z", 55: "NEXT_CHUNK"}
+
+    def emit_threaded(self):
+        """entry + handler tables of the threaded dispatch (see __init__): `_gov` starts on the tape the caller has decoded into
+        V_DEC (lane = op): handler address, out | a << 8 file indices, word 1 (b's file index for the RR forms)."""
+        a, n = self.a, self.name
+        a(f"""
+; ---- interpreter {n} (threaded): tape decoded in {V_DEC[0]}, {V_DEC[1]}, {V_DEC[3]}, lane = op; returns to {S_RET} from the OUTPUT op
+.L{n}_gov:
+	s_set_gpr_idx_off
+	s_mov_b32 {S_LEN}, 0
+	s_mov_b32 {S_JN_HI}, s43
+	v_readlane_b32 {S_JN_LO}, {V_DEC[0]}, {S_LEN}
+	v_readlane_b32 {S_NX_LO}, {V_DEC[1]}, {S_LEN}
+	v_readlane_b32 {S_NX_HI}, {V_DEC[3]}, {S_LEN}
+	s_mov_b32 {S_LEN}, 1
+	s_setpc_b64 {S_JN}
+	.p2align {self.ip_slot_log2}
+.L{n}_handlers:""")
+        for inplace in (False, True):
+            lg = self.ip_slot_log2 if inplace else self.hl
+            for i in range(64):
+                a(f"\t.p2align {lg}")
+                lab = f".L{n}_{'i' if inplace else 'h'}{i}"
+                op = OPS[i] if i < len(OPS) else self.PSEUDO.get(i)
+                a(f"{lab}:  ; {op}{' (in place)' if inplace else ''}")
+                base = op.rsplit("_", 1)[0] if op and "_" in op and op not in ("COPY_REG", "COPY_IMM", "NEXT_CHUNK") and not op.startswith("INPUT_") else op
+                if op is None or (base in UNSUPPORTED and not self.trans):
+                    self.prologue()
+                    self.ret()             # never reached for tapes routed here (host checks)
+                elif inplace and op not in self.INPLACE:
+                    a(f"\ts_branch .L{n}_h{i}")
+                elif EXP == "nowork" and op != "NEXT_CHUNK":     # experiment: the dispatch alone (every op a no-op, the result "outside")
+                    if op == "OUTPUT":
+                        for j in range(self.zb):
+                            a(f"\tv_mov_b32 {VRES[j]}, 1.0")
+                        a(f"\ts_setpc_b64 {S_RET}")
+                    else:
+                        self.prologue()
+                        self.ret()
+                else:
+                    self.handler(op, inplace)
+                a(f"\t.if (. - {lab}) > {1 << lg}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
+        a(f"\t.p2align {self.hl}")
+        for lab, fn in self.ool:
+            a(f"{lab}:")
+            fn()
+
 def call_interp(a, it):
     """Call the interpreter `it` as a subroutine."""
-    import os
-    if os.environ.get("FH_EXP") == "nointerp" and it.kind == "columns":   # experiment: set-up cost only
-        return
     ret = a.label("ret")
     here = a.label("pc")
     a(f"""
@@ -878,6 +1043,46 @@ def handler_base(a, it):
 {here}:
 	s_add_u32 s42, s42, .L{it.name}_handlers - {here}
 	s_addc_u32 s43, s43, 0""")
+
+
+def emit_decode(a, it, inplace_mask):
+    """threaded dispatch: the tape words in v[60:61], lane = op -> V_DEC: handler address (the in-place table when out == a and the
+    op has such a form; an INPUT of an axis slot has a handler of its own), file indices out | a << 8, word 1 (the RR forms: b's
+    file index).  Clobbers v18 .. v23, vcc, s[90:97]."""
+    lg, hl, ipl = it.lg, it.hl, it.ip_slot_log2
+    a(f"""
+	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
+	s_mov_b32 s97, {hex(inplace_mask >> 32)}
+	v_and_b32 v18, 0xff, v60
+	v_bfe_u32 v19, v60, 8, 12
+	v_lshrrev_b32 v20, 20, v60
+	v_cmp_eq_u32 vcc, v19, v20
+	v_lshrrev_b64 v[22:23], v18, s[96:97]
+	v_mov_b32 v63, v61
+	v_and_b32 v22, 1, v22
+	v_cndmask_b32 v22, 0, v22, vcc                   ; in place?
+	v_subrev_u32 v21, {OPS.index("ADD_RR")}, v18
+	v_lshlrev_b32 v23, {lg}, v61
+	v_cmp_gt_u32 vcc, {len(BIN)}, v21                ; an RR form: word 1 names a register
+	v_cmp_eq_u32_e64 {S_M[0]}, {OPS.index("INPUT")}, v18
+	v_lshlrev_b32 v19, {lg}, v19
+	v_cndmask_b32 v63, v63, v23, vcc
+	v_lshl_or_b32 v19, v20, {lg + 8}, v19            ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)""")
+    for k, sl in enumerate((S_SLOTX, S_SLOTY, S_SLOTZ)):
+        a(f"\tv_cmp_eq_u32_e64 {S_M[1 + k]}, {sl}, v61")
+    for k in range(3):
+        a(f"\ts_and_b64 {S_M[1 + k]}, {S_M[1 + k]}, {S_M[0]}")
+    for k in range(3):
+        a(f"\tv_cndmask_b32_e64 v18, v18, {52 + k}, {S_M[1 + k]}")
+    a(f"""
+	v_mov_b32 v61, v19
+	v_lshlrev_b32 v20, {hl}, v18
+	v_lshlrev_b32 v21, {ipl}, v18
+	v_add_u32 v21, {64 << hl}, v21
+	v_cmp_eq_u32 vcc, 1, v22
+	s_nop 1
+	v_cndmask_b32 v20, v20, v21, vcc
+	v_add_u32 v60, s42, v20""")
 
 
 def gen_columns(a, variants, off, trans=None):
@@ -1110,7 +1315,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 exec, -1
 	s_branch .Lfh_columns_taperequested
 .Lfh_columns_longtape:
-	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+	{"s_nop 0" if its[0].threaded else f"s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0"}      ; (threaded dispatch: a long tape is fetched and decoded 63 ops at a time, per pass)
 .Lfh_columns_taperequested:
 	; pixel of this lane, its z-buffer word
 	s_mov_b32 {S_NXTV}, 0
@@ -1216,47 +1421,97 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .L{name}_hb:
 	s_add_u32 s42, s42, .L{name}_handlers - .L{name}_hb
 	s_addc_u32 s43, s43, 0""")
-        a(f"""
+        if it.threaded:
+            ret, here = a.label("ret"), a.label("pc")
+            a(f"""
 	s_cmp_gt_u32 {S_LEN0}, 64
-	s_cbranch_scc1 .L{name}_pass
-	; decode the tape, lane = op: handler address (in-place variant when out == a and the op has one), file
-	; indices of out and a; word 1 stays as it is
-	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
-	s_mov_b32 s97, {hex(inplace_mask >> 32)}
-	v_and_b32 v18, 0xff, v60
-	v_bfe_u32 v19, v60, 8, 12
-	v_lshrrev_b32 v20, 20, v60
-	v_cmp_eq_u32 vcc, v19, v20
-	v_lshrrev_b64 v[22:23], v18, s[96:97]
-	v_mov_b32 v63, v61
-	v_and_b32 v22, 1, v22
-	v_cndmask_b32 v22, 0, v22, vcc
-	v_lshlrev_b32 v61, {it.lg}, v19
-	v_lshl_or_b32 v22, v22, 6, v18
-	v_lshl_or_b32 v61, v20, {it.lg + 8}, v61          ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
-	v_lshlrev_b32 v22, {it.hl}, v22
-	v_add_u32 v60, s42, v22
-.L{name}_pass:""")
-        a(f"""
-	s_mov_b64 {S_TAPE}, {S_TBASE}""")           # (VRES needs no initial value: a shape tape ends with its OUTPUT op, whose handler fills it)
-        ret, here = a.label("ret"), a.label("pc")
-        a(f"""
+	s_cbranch_scc1 .L{name}_pass""")
+            emit_decode(a, it, inplace_mask)
+            a(f".L{name}_pass:")        # (VRES needs no initial value: a shape tape ends with its OUTPUT op, whose handler fills it)
+            if EXP == "nointerp":     # experiment: the set-up alone
+                for j in range(zb):
+                    a(f"\tv_mov_b32 {VRES[j]}, 1.0")
+                a(f"\ts_branch {ret}")
+            a(f"""
 	s_getpc_b64 {S_RET}
 {here}:
 	s_add_u32 s74, s74, {ret} - {here}
 	s_addc_u32 s75, s75, 0
 	s_cmp_gt_u32 {S_LEN0}, 64
 	s_cbranch_scc0 .L{name}_gov
-	s_branch .L{name}_go
-{ret}:""")
-        if zb < 8:
-            # the next pass (if any) of a long tape needs its head again: ask for it before the hit test
-            skip = a.label("nohead")
+	; a tape of more than 64 ops: 63 at a time, lane 63 holding a pseudo-op whose handler (NEXT_CHUNK) comes back here
+	s_mov_b64 {S_TCUR}, {S_TBASE}
+	s_mov_b32 {S_REM}, {S_LEN0}
+	s_getpc_b64 {S_LONG}
+.L{name}_longpc:
+	s_add_u32 s56, s56, .L{name}_longchunk - .L{name}_longpc
+	s_addc_u32 s57, s57, 0
+.L{name}_longchunk:
+	s_set_gpr_idx_off
+	s_min_u32 {S_T0}, {S_REM}, 64
+	s_sub_u32 {S_T0}, 64, {S_T0}
+	v_lshlrev_b32 {V_S3}, 3, {V_LANE}
+	s_lshr_b64 exec, -1, {S_T0}
+	global_load_dwordx2 v[60:61], {V_S3}, {S_TCUR}
+	s_mov_b64 exec, -1
+	s_waitcnt vmcnt(0)""")
+            emit_decode(a, it, inplace_mask)
             a(f"""
-	s_cmp_gt_u32 {S_LEN0}, 64
-	s_cbranch_scc0 {skip}
-	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
-{skip}:""")
+	s_cmp_le_u32 {S_REM}, 64
+	s_cbranch_scc1 .L{name}_gov
+	s_add_u32 s86, s42, {55 << it.hl}                 ; NEXT_CHUNK's handler
+	s_add_u32 s52, s52, {63 * 8}
+	s_addc_u32 s53, s53, 0
+	s_sub_u32 {S_REM}, {S_REM}, 63
+	v_writelane_b32 {V_DEC[0]}, s86, 63
+	s_branch .L{name}_gov
+{ret}:""")
+        else:
+            a(f"""
+    	s_cmp_gt_u32 {S_LEN0}, 64
+    	s_cbranch_scc1 .L{name}_pass
+    	; decode the tape, lane = op: handler address (in-place variant when out == a and the op has one), file
+    	; indices of out and a; word 1 stays as it is
+    	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
+    	s_mov_b32 s97, {hex(inplace_mask >> 32)}
+    	v_and_b32 v18, 0xff, v60
+    	v_bfe_u32 v19, v60, 8, 12
+    	v_lshrrev_b32 v20, 20, v60
+    	v_cmp_eq_u32 vcc, v19, v20
+    	v_lshrrev_b64 v[22:23], v18, s[96:97]
+    	v_mov_b32 v63, v61
+    	v_and_b32 v22, 1, v22
+    	v_cndmask_b32 v22, 0, v22, vcc
+    	v_lshlrev_b32 v61, {it.lg}, v19
+    	v_lshl_or_b32 v22, v22, 6, v18
+    	v_lshl_or_b32 v61, v20, {it.lg + 8}, v61          ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
+    	v_lshlrev_b32 v22, {it.hl}, v22
+    	v_add_u32 v60, s42, v22
+    .L{name}_pass:""")
+            a(f"""
+    	s_mov_b64 {S_TAPE}, {S_TBASE}""")           # (VRES needs no initial value: a shape tape ends with its OUTPUT op, whose handler fills it)
+            ret, here = a.label("ret"), a.label("pc")
+            if EXP == "nointerp":     # experiment: the set-up alone
+                for j in range(zb):
+                    a(f"\tv_mov_b32 {VRES[j]}, 1.0")
+                a(f"\ts_branch {ret}")
+            a(f"""
+    	s_getpc_b64 {S_RET}
+    {here}:
+    	s_add_u32 s74, s74, {ret} - {here}
+    	s_addc_u32 s75, s75, 0
+    	s_cmp_gt_u32 {S_LEN0}, 64
+    	s_cbranch_scc0 .L{name}_gov
+    	s_branch .L{name}_go
+    {ret}:""")
+            if zb < 8:
+                # the next pass (if any) of a long tape needs its head again: ask for it before the hit test
+                skip = a.label("nohead")
+                a(f"""
+    	s_cmp_gt_u32 {S_LEN0}, 64
+    	s_cbranch_scc0 {skip}
+    	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
+    {skip}:""")
         # first voxel inside, front to back (sample j: depth = lz + (k - j) + 1): the samples' "value < 0" bits shifted into a mask
         # through the carry (sample 0 ends up highest), its leading bit is the hit - 2 instructions per sample instead of 8
         a(f"\tv_mov_b32 {V_S0}, 0")

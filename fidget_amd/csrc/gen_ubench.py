@@ -26,6 +26,40 @@ TESTS = [
     ("ds_read_b32 dependent (address from the value)", lambda k: "\tds_read_b32 v10, v10\n\ts_waitcnt lgkmcnt(0)"),
     ("v_mul_f32 x4 dependent + s_branch taken", lambda k: f"\tv_mul_f32 v10, v10, v11\n\tv_mul_f32 v10, v10, v11\n\tv_mul_f32 v10, v10, v11\n\tv_mul_f32 v10, v10, v11\n\ts_branch .Lub_t16_{k}\n.Lub_t16_{k}:"),
     ("s_mov_b64 exec + v_mov", lambda k: f"\ts_mov_b64 exec, s[24:25]\n\tv_mov_b32 v{10 + k % 16}, v40"),
+    # ---- round 6: what an op of the leaf interpreter costs, piece by piece
+    ("v_add_f32 independent", lambda k: f"\tv_add_f32 v{10 + k % 16}, v40, v41"),
+    ("v_min_f32 independent", lambda k: f"\tv_min_f32 v{10 + k % 16}, v40, v41"),
+    ("v_cmp_lt_f32 vcc (e32) + v_cndmask (vcc)", lambda k: f"\tv_cmp_lt_f32 vcc, v40, v41\n\tv_cndmask_b32 v{10 + k % 16}, v40, v41, vcc"),
+    ("v_readfirstlane independent", lambda k: f"\tv_readfirstlane_b32 s{40 + k % 8}, v{40 + k % 6}"),
+    ("op as built: idx_off, 3 v_readlane, s_add, s_lshr, s_setpc; idx_on, 4 v_pk_add in place (relative), s_setpc",
+     lambda k: "\ts_set_gpr_idx_off\n\tv_readlane_b32 s40, v40, s21\n\tv_readlane_b32 s41, v41, s21\n\tv_readlane_b32 s42, v42, s21\n"
+               "\ts_add_u32 s30, s30, 40\n\ts_lshr_b32 s43, s41, 8\n\ts_setpc_b64 s[30:31]\n"
+               "\ts_set_gpr_idx_on s22, 9\n\tv_pk_add_f32 v[10:11], v[10:11], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[12:13], v[12:13], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n"
+               "\tv_pk_add_f32 v[14:15], v[14:15], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[16:17], v[16:17], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n"
+               "\ts_add_u32 s30, s30, 44\n\ts_setpc_b64 s[30:31]"),
+    ("op with fixed registers: 2 v_readlane, s_add, s_setpc; 4 v_pk_add (no index mode), s_setpc",
+     lambda k: "\tv_readlane_b32 s40, v40, s21\n\tv_readlane_b32 s42, v42, s21\n"
+               "\ts_add_u32 s30, s30, 24\n\ts_setpc_b64 s[30:31]\n"
+               "\tv_pk_add_f32 v[10:11], v[10:11], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[12:13], v[12:13], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n"
+               "\tv_pk_add_f32 v[14:15], v[14:15], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[16:17], v[16:17], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n"
+               "\ts_add_u32 s30, s30, 40\n\ts_setpc_b64 s[30:31]"),
+    ("the work alone: 4 v_pk_add with an SGPR pair", lambda k: "\tv_pk_add_f32 v[10:11], v[10:11], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[12:13], v[12:13], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n"
+               "\tv_pk_add_f32 v[14:15], v[14:15], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 v[16:17], v[16:17], s[42:43] op_sel:[0,1] op_sel_hi:[1,1]"),
+    ("the work alone, unpacked: 8 v_add_f32 with an SGPR", lambda k: "\n".join(f"\tv_add_f32 v{10 + j}, s43, v{10 + j}" for j in range(8))),
+    ("the dispatch alone: idx_off, 3 v_readlane, s_add, s_lshr, s_setpc", 
+     lambda k: "\ts_set_gpr_idx_off\n\tv_readlane_b32 s40, v40, s21\n\tv_readlane_b32 s41, v41, s21\n\tv_readlane_b32 s42, v42, s21\n"
+               "\ts_add_u32 s30, s30, 40\n\ts_lshr_b32 s43, s41, 8\n\ts_setpc_b64 s[30:31]"),
+    ("min in place as built: 4 v_pk_mov, nan test (3 v_pk_add, v_add, v_cmp, branch), 8 v_cmp to SGPRs + 8 v_cndmask",
+     lambda k: "\n".join([f"\tv_pk_mov_b32 v[{26 + 2 * j}:{27 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}] op_sel:[0,1]" for j in range(4)] +
+                         ["\tv_pk_add_f32 v[34:35], v[10:11], v[12:13]", "\tv_pk_add_f32 v[36:37], v[14:15], v[16:17]", "\tv_pk_add_f32 v[34:35], v[34:35], v[36:37]", "\tv_add_f32 v34, v34, v35",
+                          "\tv_cmp_u_f32 vcc, v34, v34", "\ts_cbranch_vccnz .Lub_exit"] +
+                         [f"\tv_cmp_nlt_f32_e64 s[{40 + 2 * (j % 4)}:{41 + 2 * (j % 4)}], v{10 + j}, v{26 + j}" for j in range(4)] +
+                         [f"\tv_cndmask_b32_e64 v{10 + j}, v{10 + j}, v{26 + j}, s[{40 + 2 * (j % 4)}:{41 + 2 * (j % 4)}]" for j in range(4)] +
+                         [f"\tv_cmp_nlt_f32_e64 s[{40 + 2 * (j % 4)}:{41 + 2 * (j % 4)}], v{10 + j}, v{26 + j}" for j in range(4, 8)] +
+                         [f"\tv_cndmask_b32_e64 v{10 + j}, v{10 + j}, v{26 + j}, s[{40 + 2 * (j % 4)}:{41 + 2 * (j % 4)}]" for j in range(4, 8)])),
+    ("min by v_min_f32: 4 v_pk_mov + 8 v_min_f32", 
+     lambda k: "\n".join([f"\tv_pk_mov_b32 v[{26 + 2 * j}:{27 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}] op_sel:[0,1]" for j in range(4)] +
+                         [f"\tv_min_f32 v{10 + j}, v{10 + j}, v{26 + j}" for j in range(8)])),
 ]
 
 
@@ -40,9 +74,7 @@ def gen_ubench(a):
 {name}:
 	s_load_dwordx2 s[4:5], s[0:1], 0x0
 	s_load_dwordx2 s[6:7], s[0:1], 0x8
-	v_mov_b32 v10, 1.0
-	v_mov_b32 v11, 1.0
-	v_mov_b32 v40, 1.0
+""" + "".join(f"\tv_mov_b32 v{r}, 1.0\n" for r in range(10, 40)) + f"""	v_mov_b32 v40, 1.0
 	v_mov_b32 v41, 2.0
 	v_mov_b32 v42, 1.0
 	v_mov_b32 v43, 2.0

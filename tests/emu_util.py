@@ -31,6 +31,10 @@ _prog = None
 def program():
     global _prog
     if _prog is None:
+        alt = os.environ.get("FH_EMU_CO")       # (a variant's code object, tools/build_variant.py: the emulator tests without the library build)
+        if alt:
+            _prog = E.Program(alt)
+            return _prog
         import fidget_amd
         fidget_amd.build()
         _prog = E.Program(os.path.join(GEN, "interp_gfx950.co"))
