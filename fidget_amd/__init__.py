@@ -251,7 +251,7 @@ class HipContext:
         return int(lib().fhip_debug_lane_frames(self._h))
 
     def set_option(self, name, value=1):
-        """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "frame_sets", ...).  The environment
+        """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "frame_lanes", ...).  The environment
         (FHIP_<NAME>) is read once, when the context is created; this is the only way to change a switch afterwards."""
         self.check(lib().fhip_ctx_set_option(self._h, name.encode(), int(value)))
 

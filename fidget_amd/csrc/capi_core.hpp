@@ -65,10 +65,10 @@ static const uint32_t V32_REGS = 32, V32_CHOICES = 256, V64_REGS = 64, V64_CHOIC
     X(no_asm, 0) X(no_split, 0) X(no_asm_tiles, 0) X(no_tiles_v, 0) X(no_asm_tiles_t, 0) X(no_columns_t, 0) X(no_asm_normals, 0)   \
     X(no_tape_groups, 0) X(prune2, 1)                                                                                           \
     /* short cuts: column invariance off everywhere; no_zrep 1 = no sharing of tiles along z at all, 2 = only not at the root level, 3 = every slab rendered;     \
-       column_walk: the leaf kernel by footprint columns - 1 in frames whose tapes read no z, 0 never, 2 always */                  \
-    X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096) X(column_walk, 1)                                                     \
+       column_walk: the leaf kernel by footprint columns - 1 in frames whose tapes read no z, 0 never, 2 always; column_group: every other frame by groups of 2^g layers of a column (0: by blocks of four footprints of a layer) */                  \
+    X(no_column_inv, 0) X(no_zrep, 0) X(root32_max, 4096) X(column_walk, 1) X(column_group, 2)                                                    \
     /* pipelining and resources */                                                                                             \
-    X(no_pipeline, 0) X(frame_sets, 4) X(frame_lanes, 4) X(lanes_tune, 1) X(lanes_fail, 0) X(slab_layers, 4) X(arena_mb, 4096)  \
+    X(no_pipeline, 0) X(frame_lanes, 4) X(lanes_tune, 1) X(lanes_fail, 0) X(slab_layers, 4) X(arena_mb, 4096)  \
     /* mesher */                                                                                                               \
     X(mesh_device_assembly, 1) X(mesh_device_walk, 1) X(mesh_simplify_min_ops, 256)                                             \
     /* diagnostics (stats: bit 0 device counters and clocks, bit 1 the host thread's time per frame to stderr) */                                                                                                          \
@@ -92,7 +92,7 @@ static void options_from_env(FhOptions& o) {
     }
 }
 
-// Everything one frame of a render owns on the device.  A context holds several sets (option frame_sets, 4): an asynchronous 3D render
+// Everything one frame of a render owns on the device.  A context holds several sets (4): an asynchronous 3D render
 // takes the set used longest ago, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
 // run on a stream of their own beside the previous frames' slabs (frame pipelining; option no_pipeline turns all pipelining off).
 struct FrameBufs {
@@ -116,14 +116,13 @@ struct FrameBufs {
 };
 struct fhip_ctx : FrameBufs {
     FhOptions opt;                  // behaviour switches (FH_OPTION_LIST): environment at creation, fhip_ctx_set_option later
-    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of up to 1 + FH_EXTRA_SETS; option
-    // frame_sets, default 4).  A set is free again when its frame is complete, and a pipelined frame takes ~1.5 ms from its first
+    // the sets of the frames before the current one: a frame takes the set used longest ago (ring of four).  A set is free again when its frame is complete, and a pipelined frame takes ~1.5 ms from its first
     // coarse-level kernel to its image: the period cannot be shorter than that over the number of sets.  Three were enough while the tail
     // stream bounded the pipeline; since round 4 (capi_render.hpp tail_on_main) three give frames of 0.44 / 0.59 / 0.48 ms in turn, four
     // 0.49 each, five the same (profiles/r04k)
 #define FH_EXTRA_SETS 4
     FrameBufs others[FH_EXTRA_SETS];
-    uint32_t extra_sets = FH_EXTRA_SETS;     // option frame_sets - 1
+    uint32_t extra_sets = 3;     // (four sets: more did not raise the pipelined rate, fewer lowered it - round 4)
     bool frame_pipeline = true;
     hipStream_t stream_pre = nullptr;   // coarse levels of a pipelined frame
     uint32_t pre_turn = 0;              // ... frames whose root levels alternate between it and the tail stream: whose turn
@@ -217,7 +216,7 @@ static void apply_options(fhip_ctx* c) {
     c->slab_contexts = 4;
     c->arena_cap_bytes = (size_t)std::max(1, c->opt.arena_mb) << 20;
     c->arena_bytes = std::min(c->arena_cap_bytes, std::max(c->arena_bytes, (size_t)FH_ARENA_START_MB << 20));
-    c->extra_sets = (uint32_t)std::min(FH_EXTRA_SETS, std::max(1, c->opt.frame_sets - 1));
+    c->extra_sets = 3;      // four sets in all
 }
 
 static fhip_status finish_render(fhip_ctx* ctx);

@@ -334,11 +334,30 @@ class Interp:
             for j in g:
                 self.a("\t" + sel(j, S_M[j % 4]))
 
+    def zero_guard(self, A, t, plain=True):
+        """vcc = one of the samples A is a zero (either sign); t: scratch.  (v_min3_f32 drops a NaN operand: V_QNAN pads the first.)"""
+        a, zb = self.a, self.zb
+        a(f"\tv_min3_f32 {t}, {V_QNAN}, |{A[0]}|, |{A[1]}|")
+        for j in range(2, zb, 2):
+            a(f"\tv_min3_f32 {t}, {t}, |{A[j]}|, |{A[j + 1]}|")
+        a(f"\tv_cmp_eq_f32_e64 vcc, {t}, 0")
+
     def f_minmax(self, is_min, A, B, R):
-        # min: a < b ? a : b, max: a > b ? a : b; either NaN -> NaN  (dev_ops.hpp f_min / f_max)
+        # min: a < b ? a : b, max: a > b ? a : b; either NaN -> NaN  (dev_ops.hpp f_min / f_max).
+        # gfx950's v_minimum3_f32 / v_maximum3_f32 (IEEE-754-2019 minimum / maximum: a NaN operand wins) return exactly that but for
+        # min(-0, +0) = -0 (wanted: b, +0) and max(+0, -0) = +0 (wanted: -0) - every pair of special values and 4 M random pairs,
+        # tools/probe_minimum3.cpp -: one instruction per sample unless a sample of `a` is a zero, which takes the compares and selects.
+        a = self.a
+        slow, done = a.label("mm_zero"), a.label("mm_done")
+        self.zero_guard(A, VD[6])
+        a(f"\ts_cbranch_vccnz {slow}")
+        for j in range(self.zb):
+            a(f"\t{'v_minimum3_f32' if is_min else 'v_maximum3_f32'} {R[j]}, {A[j]}, {B[j]}, {B[j]}")
+        a(f"\ts_branch {done}\n{slow}:")
         cmp = "v_cmp_lt_f32_e64" if is_min else "v_cmp_gt_f32_e64"
         self.mask_pass(lambda j, m: f"{cmp} {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {m}")
         self.mask_pass(lambda j, m: f"v_cmp_u_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {m}")
+        a(f"{done}:")
 
     def f_andor(self, is_and, A, B, R):
         # and: a == 0 ? a : b ; or: a != 0 ? a : b
@@ -610,33 +629,16 @@ class Interp:
             cmp = "v_cmp_gt_f32_e64" if base == "MIN" else "v_cmp_lt_f32_e64"
             self.prologue()
             def body(cmp=cmp):
-                # The select alone is right unless a is a NaN and b is not (it then takes b): the samples of a are summed
-                # first - a NaN among them makes the sum one (so may an inf - inf: that only costs the long way round) - and
-                # the two tests and two selects per sample (dev_ops.hpp f_min / f_max to the letter) are left to that case.
-                slow = a.label("mm_nan")
+                # One v_minimum3_f32 / v_maximum3_f32 per sample (see f_minmax) unless a sample of a is a zero: the two tests and
+                # two selects per sample (dev_ops.hpp f_min / f_max to the letter) are left to that case.
+                slow = a.label("mm_zero")
                 self.read_b(VU, already_on=False)
-                self.idx_idx(s_ip)                  # (mode still SRC0 | SRC1: both operands a's samples, plain destination)
-                if zb >= 4:
-                    for k in range(zb // 4):
-                        a(f"\tv_pk_add_f32 {self.P(VW, k)}, {self.FP(2 * k)}, {self.FP(2 * k + 1)}")
-                    self.idx_off()
-                    if zb == 8:
-                        a(f"\tv_pk_add_f32 {self.P(VW, 0)}, {self.P(VW, 0)}, {self.P(VW, 1)}")
-                    a(f"\tv_add_f32 {VW[0]}, {VW[0]}, {VW[1]}")
-                else:
-                    a(f"\tv_add_f32 {VW[0]}, {F(0)}, {F(1)}")
-                    self.idx_off()
-                a(f"\tv_cmp_u_f32 vcc, {VW[0]}, {VW[0]}")
-                self.idx_on(s_ip, SRC1 | DST)
+                self.idx_on(s_ip, SRC1 | SRC2)      # a's samples relative, plain destination: is one of them a zero?
+                self.zero_guard([F(j) for j in Z], VW[0])
+                self.idx_on(s_ip, SRC1 | SRC2 | DST)
                 a(f"\ts_cbranch_vccnz {slow}")
-                for g in range(0, zb, 4):
-                    js = list(range(g, min(g + 4, zb)))
-                    for j in js:
-                        a(f"\t{cmp} {S_M[j % 4]}, {VU[j]}, {F(j)}")
-                    if len(js) < 3:
-                        a(f"\ts_nop {2 - len(js)}")
-                    for j in js:
-                        a(f"\tv_cndmask_b32_e64 {F(j)}, {VU[j]}, {F(j)}, {S_M[j % 4]}")
+                for j in Z:
+                    a(f"\t{'v_minimum3_f32' if base == 'MIN' else 'v_maximum3_f32'} {F(j)}, {VU[j]}, {F(j)}, {F(j)}")
                 self.ret()
                 def slow_body():
                     for j in range(0, zb, 2):          # both tests of a sample before it is overwritten; 4 masks = 2 samples
@@ -1147,7 +1149,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_bfe_i32 {S_SLOTY}, s49, 0x80008
 	s_bfe_i32 {S_SLOTZ}, s49, 0x80010
 	s_mov_b32 {S_DEPMASK}, s50
-	s_and_b32 s51, s51, 0x1f0000                     ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column; 20: column mode
+	s_and_b32 s51, s51, 0x0f1f0000                   ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column; 20: column mode; 24 .. 27: log2 of the layers a wave of column mode takes (bit 28, set here: the lane's pixel state is valid)
 	s_or_b32 {S_WGY}, {S_WGY}, s51
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
@@ -1175,6 +1177,11 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_cbranch_scc0 .Lfh_columns_block
 	s_mov_b32 {S_ONE}, 1
 	s_and_b32 {S_T0}, {S_WGY}, 0xffff
+	s_bitcmp1_b32 {S_WGY}, 20
+	s_cbranch_scc0 .Lfh_columns_ylayer
+	s_bfe_u32 {S_T1}, {S_WGY}, 0x40018                ; column mode: the workgroup's y counts groups of 2^g layers, front group first
+	s_lshl_b32 {S_T0}, {S_T0}, {S_T1}
+.Lfh_columns_ylayer:
 	s_sub_u32 {S_L}, {S_L}, {S_T0}
 	s_cbranch_scc1 .Lfh_columns_exit
 .Lfh_columns_block:
@@ -1246,6 +1253,9 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	; at 1024^3.  Workgroup ids go round the 8 XCDs: id = 64 q + 8 a + b runs on XCD b and takes footprint 64 q + 8 b + a, so that
 	; the eight footprints whose entries share a 128-byte line of a layer's row are read through one L2.
 	s_and_b32 {S_T0}, {S_I}, 7
+	s_lshr_b32 {S_T1}, {S_I}, 6
+	s_add_u32 {S_T0}, {S_T0}, {S_T1}                  ; (the XCD's eight footprints move one place per group of 64: a fixed place would
+	s_and_b32 {S_T0}, {S_T0}, 7                       ; give each XCD the same vertical stripes of every image row - and their geometry)
 	s_bfe_u32 {S_T1}, {S_I}, 0x30003
 	s_andn2_b32 s86, {S_I}, 63
 	s_lshl_b32 {S_T0}, {S_T0}, 3
@@ -1253,11 +1263,15 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_add_u32 {S_T0}, {S_T0}, {S_T1}
 	s_cmp_ge_u32 {S_T0}, {S_NFPL}
 	s_cbranch_scc1 .Lfh_columns_exit
-	v_sub_u32 {V_S0}, {S_L}, {V_LANE}                 ; layer of this lane ({S_L} = layers - 1 here)
+	s_bfe_u32 {S_T1}, {S_WGY}, 0x40018
+	s_lshl_b32 {S_T1}, 1, {S_T1}                      ; the layers of this wave: 2^g from {S_L} (the group's front layer) back, lane = layer
+	v_sub_u32 {V_S0}, {S_L}, {V_LANE}
 	v_cmp_ge_u32 vcc, {S_L}, {V_LANE}
+	v_cmp_gt_u32_e64 {S_M[0]}, {S_T1}, {V_LANE}
 	v_mul_lo_u32 {V_S0}, {V_S0}, {S_NFPL}
 	v_mov_b32 {V_ENT[0]}, 0
 	v_add_lshl_u32 {V_S0}, {V_S0}, {S_T0}, 4            ; 16-byte entries, [layer][footprint]
+	s_and_b64 vcc, vcc, {S_M[0]}
 	s_and_saveexec_b64 {S_SAVE}, vcc
 	global_load_dwordx4 v[{V_ENT[0][1:]}:{V_ENT[3][1:]}], {V_S0}, {S_TABLE}
 	s_mov_b64 exec, {S_SAVE}
@@ -1269,7 +1283,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_leaf:
 	; ---- next leaf of the block: everything needed to start on it is in the entries (no load before the tape's) --------
 	s_cmp_eq_u64 {S_LAYMASK}, 0
-	s_cbranch_scc1 .Lfh_columns_block
+	s_cbranch_scc1 .Lfh_columns_blockend
 	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
 	s_bitcmp1_b32 {S_WGY}, 20
@@ -1317,8 +1331,12 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_longtape:
 	{"s_nop 0" if its[0].threaded else f"s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0"}      ; (threaded dispatch: a long tape is fetched and decoded 63 ops at a time, per pass)
 .Lfh_columns_taperequested:
-	; pixel of this lane, its z-buffer word
+	; pixel of this lane, its z-buffer word.  Column mode: every leaf of the wave has the same footprint - the pixel, its matrix
+	; products and its z-buffer word are set up once (bit 28), hits stay in the lane's registers from leaf to leaf (a pixel hit by a
+	; nearer leaf of the wave is not pending for the next) and go to the z-buffer once, behind the wave's last leaf.
 	s_mov_b32 {S_NXTV}, 0
+	s_bitcmp1_b32 {S_WGY}, 28
+	s_cbranch_scc1 .Lfh_columns_pixelset
 	v_and_b32 {V_S0}, 7, {V_LANE}
 	v_lshrrev_b32 {V_S1}, 3, {V_LANE}
 	v_add_u32 {V_S0}, {S_FX}, {V_S0}
@@ -1336,6 +1354,23 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 exec, {S_M[0]}
 	global_load_dword {V_DEPTH}, {V_PIX}, {S_ZBUF} offset:4
 	s_mov_b64 exec, {S_SAVE}
+	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
+	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
+	v_add_f32 {V_AX}, {V_AX}, {V_S0}
+	v_mul_f32 {V_AY}, s{m + 4}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 5}, {V_PYF}
+	v_add_f32 {V_AY}, {V_AY}, {V_S0}
+	v_mul_f32 {V_AZ}, s{m + 8}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
+	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
+	v_mul_f32 {V_AW}, s{m + 12}, {V_PXF}
+	v_mul_f32 {V_S0}, s{m + 13}, {V_PYF}
+	v_add_f32 {V_AW}, {V_AW}, {V_S0}
+	s_bfe_u32 {S_T0}, {S_WGY}, 0x10014               ; column mode (bit 20) -> bit 28: the set-up stands for the wave's other leaves
+	s_lshl_b32 {S_T0}, {S_T0}, 28
+	s_or_b32 {S_WGY}, {S_WGY}, {S_T0}
+.Lfh_columns_pixelset:
 	; the next leaf of the block: its tape (if it is one of up to 64 ops for this kernel) is requested now, behind this
 	; leaf's own loads, and arrives while this leaf is interpreted
 	s_cmp_eq_u64 {S_LAYMASK}, 0
@@ -1362,19 +1397,6 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 exec, -1
 	s_mov_b32 {S_NXTV}, 1
 .Lfh_columns_noahead:
-	; (m[4r] * x + m[4r+1] * y) per row: constant over the column (dev_ops.hpp xf_point)
-	v_mul_f32 {V_AX}, s{m + 0}, {V_PXF}
-	v_mul_f32 {V_S0}, s{m + 1}, {V_PYF}
-	v_add_f32 {V_AX}, {V_AX}, {V_S0}
-	v_mul_f32 {V_AY}, s{m + 4}, {V_PXF}
-	v_mul_f32 {V_S0}, s{m + 5}, {V_PYF}
-	v_add_f32 {V_AY}, {V_AY}, {V_S0}
-	v_mul_f32 {V_AZ}, s{m + 8}, {V_PXF}
-	v_mul_f32 {V_S0}, s{m + 9}, {V_PYF}
-	v_add_f32 {V_AZ}, {V_AZ}, {V_S0}
-	v_mul_f32 {V_AW}, s{m + 12}, {V_PXF}
-	v_mul_f32 {V_S0}, s{m + 13}, {V_PYF}
-	v_add_f32 {V_AW}, {V_AW}, {V_S0}
 	v_mov_b32 {V_IDV}, {S_ID}
 	s_cmp_eq_u32 {S_NXTV}, 0
 	s_cbranch_scc1 .Lfh_columns_waitall
@@ -1540,6 +1562,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
             a("\ts_branch .Lfh_columns_leaf_done")
     a(f"""
 .Lfh_columns_leaf_done:
+	s_bitcmp1_b32 {S_WGY}, 20
+	s_cbranch_scc1 .Lfh_columns_leaf_drain          ; (column mode: the hits go out behind the wave's last leaf)
 	; z-buffer word = max(word, depth << 32 | leaf) for the lanes that were hit
 	v_cmp_ne_u32 vcc, 0, {V_HIT}
 	s_and_saveexec_b64 {S_SAVE}, vcc
@@ -1548,6 +1572,14 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_leaf_drain:
 	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
 	s_branch .Lfh_columns_leaf
+.Lfh_columns_blockend:
+	s_bitcmp1_b32 {S_WGY}, 28
+	s_cbranch_scc0 .Lfh_columns_block
+	v_cmp_ne_u32 vcc, 0, {V_HIT}
+	s_and_saveexec_b64 {S_SAVE}, vcc
+	global_atomic_umax_x2 {V_PIX}, v[4:5], {S_ZBUF}
+	s_mov_b64 exec, {S_SAVE}
+	s_branch .Lfh_columns_block
 .Lfh_columns_exit:""")
     kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
     if trans:

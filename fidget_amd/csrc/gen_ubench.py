@@ -60,6 +60,12 @@ TESTS = [
     ("min by v_min_f32: 4 v_pk_mov + 8 v_min_f32", 
      lambda k: "\n".join([f"\tv_pk_mov_b32 v[{26 + 2 * j}:{27 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}] op_sel:[0,1]" for j in range(4)] +
                          [f"\tv_min_f32 v{10 + j}, v{10 + j}, v{26 + j}" for j in range(8)])),
+    ("v_minimum3_f32 independent", lambda k: f"\tv_minimum3_f32 v{10 + k % 16}, v40, v41, v41"),
+    ("min by v_minimum3_f32: 4 v_pk_mov, zero test of a (3 v_min3 |a|, v_min, v_cmp, branch), 8 v_minimum3_f32",
+     lambda k: "\n".join([f"\tv_pk_mov_b32 v[{26 + 2 * j}:{27 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}], v[{10 + 2 * j}:{11 + 2 * j}] op_sel:[0,1]" for j in range(4)] +
+                         ["\tv_min3_f32 v34, |v10|, |v11|, |v12|", "\tv_min3_f32 v34, v34, |v13|, |v14|", "\tv_min3_f32 v34, v34, |v15|, |v16|", "\tv_min_f32 v34, v34, |v17|",
+                          "\tv_cmp_eq_f32 vcc, 0, v34", "\ts_cbranch_vccnz .Lub_exit"] +
+                         [f"\tv_minimum3_f32 v{10 + j}, v{10 + j}, v{26 + j}, v{26 + j}" for j in range(8)])),
 ]
 
 

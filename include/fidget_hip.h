@@ -68,7 +68,7 @@ void fhip_cancel_reset(fhip_ctx* ctx);
  * the reference's knobs; these carry the back end's own: which kernels, how many slab contexts, the column-invariance short
  * cuts ...).  A context reads FHIP_<NAME> from the environment ONCE, when it is created; afterwards only this call changes
  * a switch - a render never consults the environment.  It waits for the context's frames in flight first.  Names and
- * defaults: FH_OPTION_LIST in fidget_amd/csrc/capi_core.hpp; e.g. "no_column_inv", "frame_sets",
+ * defaults: FH_OPTION_LIST in fidget_amd/csrc/capi_core.hpp; e.g. "no_column_inv", "frame_lanes",
  * "arena_mb".  Unknown names (and the two that are fixed at creation) return FHIP_ERR_UNSUPPORTED. */
 fhip_status fhip_ctx_set_option(fhip_ctx* ctx, const char* name, int value);
 fhip_status fhip_ctx_get_option(const fhip_ctx* ctx, const char* name, int* value);
@@ -182,7 +182,7 @@ fhip_status fhip_render2d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_rende
                           int out_is_device);
 /* fidget_raster::voxel::render (voxel.rs:500-553).  out: width*height GeometryPixel
  * {f32 normal[3]; u32 depth} (voxel.rs:122-134).
- * Asynchronous renders (out_is_device) of one context are pipelined across frames: the context keeps several sets (option frame_sets, 4) of device
+ * Asynchronous renders (out_is_device) of one context are pipelined across frames: the context keeps four sets of device
  * buffers, and the coarse tile levels of a frame run on an internal stream beside the slabs of the frame before it.  For the
  * caller nothing changes: `out` is written on the context's stream, in call order; fhip_ctx_sync waits for every frame. */
 fhip_status fhip_render3d(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,

@@ -18,7 +18,7 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
-def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False):
+def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False, group_log2=6):
     """the leaf kernel's kernarg as capi_render.hpp builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags, and
     floor(2^32 / blocks of four footprints per layer) for the kernel's block rotation (0 when there is one block: the subtraction loop)"""
     u = np.asarray(mat, F32).view(U32)
@@ -37,11 +37,11 @@ def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False):
             flags |= 0x20000 << ax          # (bits 17 .. 19: this axis of the model changes along a pixel column)
     n_blocks = (((size + 7) // 8) ** 2 + 3) // 4
     if column_mode:
-        flags |= 1 << 20                     # (one footprint column per wave, lane = layer)
+        flags |= (1 << 20) | (group_log2 << 24)   # (one footprint column per wave, lane = layer; 2^g layers of it per wave, grid y = the group)
     return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, (1 << 32) // n_blocks if n_blocks > 1 else 0, 0], U32)
 
 
-def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns", column_mode=False, more_leaves=()):
+def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns", column_mode=False, more_leaves=(), group_log2=6):
     off = U.offsets()
     mem = E.Memory()
     arena = np.zeros(4096, np.uint64)
@@ -67,9 +67,9 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], lz - lz % size)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat, size, column_mode)
+    ka = col_kernarg(a_st, in_kind, mat, size, column_mode, group_log2)
     trans = kernel == "fh_columns_t"
-    gx, gy = ((nfp + 63) // 64 * 64, 1) if column_mode else ((nfp + 3) // 4, layers)
+    gx, gy = ((nfp + 63) // 64 * 64, (layers + (1 << group_log2) - 1) >> group_log2) if column_mode else ((nfp + 3) // 4, layers)
     waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=256 if trans else 128,
                      hooks=U.trans_hooks(U.program(), v_base=192, window=64) if trans else None)
     return zbuf, waves
@@ -347,6 +347,25 @@ def test_column_mode_gives_the_layer_modes_words(kind, mat):
     assert (b == want).all(), f"{(b != want).sum()} z-buffer words differ from numpy's"
     busy = [w for w in wb if w.counts.get("vmem", 0) > 1]
     assert len(wb) == 64 and len(busy) == 3, (len(wb), len(busy))        # 16 footprints in a grid of 64, three columns with leaves
+
+
+@pytest.mark.parametrize("g", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_column_mode_by_groups_of_layers(kind, g):
+    """column mode with 2^g layers of a footprint's column per wave (grid y = the group, front group first): what frames with a leaf
+    in most layers take - the pixel's set-up, its z-buffer word and its hits stay in the wave from leaf to leaf, one atomic per wave.
+    Same words as the layer walk and as numpy; the pixel hit by a wave's nearer leaf is not evaluated by the one behind it."""
+    sh, tape, ik = column_shape(kind)
+    size = 32
+    leaves = [(8, 16, 8), (8, 16, 24), (8, 16, 0), (8, 16, 16), (24, 0, 16), (0, 24, 24), (0, 24, 16)]
+    z = np.zeros(size * size, np.uint64)
+    z[3::11] = np.uint64((5 << 32) | 9)
+    for mat in (AFFINE32, ROTATED32):
+        a, _ = run_columns(tape, sh.slot_count(), ik, mat, leaves[0], size=size, zbuf_init=z, more_leaves=leaves[1:])
+        b, wb = run_columns(tape, sh.slot_count(), ik, mat, leaves[0], size=size, zbuf_init=z, more_leaves=leaves[1:], column_mode=True, group_log2=g)
+        assert (a != z).any()
+        assert (a == b).all(), f"{(a != b).sum()} z-buffer words differ"
+        assert len(wb) == 64 * (4 >> g)
 
 
 def test_column_mode_in_the_transcendental_kernel():
