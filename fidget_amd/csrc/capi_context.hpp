@@ -199,10 +199,10 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
     }
     return st;
 }
-// (the frame lanes are contexts of their own that copy the flag when a frame is handed to them: a cancel from another thread while that
-// frame is being queued reaches them here, so that their per-level checks see it mid-frame as the parent's do)
-void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); for (fhip_ctx* L : c->lanes) if (L) L->cancelled.store(1); }
-void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); for (fhip_ctx* L : c->lanes) if (L) L->cancelled.store(0); }
+// (the frame lanes are contexts of their own whose per-level checks read THIS flag through fhip_ctx::cancel_src: a cancel from another
+// thread reaches a frame a lane is queueing without touching the lanes' vector, which belongs to the render thread)
+void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
+void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
 // Device and pinned memory the context keeps between calls for speed alone - the mesher's leaf records (17 GB after one depth-10 build),
 // its landing area and host-side caches, the frame lanes (child contexts with buffers of their own) - given back.  The next call that
 // wants them makes them again.  Waits for the context's work first.
@@ -213,6 +213,16 @@ fhip_status fhip_ctx_trim(fhip_ctx* c) {
     lanes_release(c);
     c->mesh_leaves.release();
     if (c->mesh_pinned) { (void)hipHostFree(c->mesh_pinned); c->mesh_pinned = nullptr; c->mesh_pinned_cap = 0; }
+    return FHIP_OK;
+}
+static hipError_t sync_own_streams(fhip_ctx* ctx);      // (capi_render.hpp)
+fhip_status fhip_ctx_reserve_arena(fhip_ctx* c, size_t megabytes) {
+    if (!c) return FHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(c->device);
+    const size_t want = std::min(c->arena_cap_bytes, megabytes << 20);
+    if (want <= c->arena_bytes) return FHIP_OK;
+    HIP_TRY(c, sync_own_streams(c));        // (the sets' arenas are replaced as the frames take them in turn)
+    c->arena_bytes = want;
     return FHIP_OK;
 }
 // Behaviour switches (FH_OPTION_LIST above).  Waits for the frames in flight first: a switch never changes under a frame.

@@ -147,6 +147,10 @@ struct fhip_ctx : FrameBufs {
     std::string err;
     bool launch_failed = false;     // an assembly kernel launch of the current frame failed (reported when the frame has been queued)
     std::atomic<int> cancelled{0};
+    // A frame lane (a child context) reads its PARENT's flag: fhip_cancel comes from another thread and must not walk `lanes`, which the
+    // render thread grows, clears and frees (run_on_lane_, lanes_release); a parent outlives its lanes, so the pointer is always good.
+    const std::atomic<int>* cancel_src = nullptr;
+    bool is_cancelled() const { return (cancel_src ? cancel_src : &cancelled)->load() != 0; }
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
     DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[8];   // pinned (upload_frame)

@@ -155,13 +155,30 @@ static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P
 // A frame before this one ran out of tape arena (k_finish3d / k_latch_arena said so in the pinned host word): wait for what is in flight
 // and let the sets come back twice as large, up to option arena_mb.  The frames that overflowed were right (their tiles kept their
 // parents' tapes), only slower.
-static fhip_status grow_arena_if_asked(fhip_ctx* ctx, size_t tape_ops) {
-    const size_t need = ((tape_ops + 64) * 8 + 4096) * 4;       // (root tape + its groups, with room to prune into)
+// Wait for the work of THIS context - its own streams and its lanes' - and nobody else's: other contexts on the device keep running
+// (hipDeviceSynchronize here stalled every thread's context for an arena that belongs to one).
+static hipError_t sync_own_streams(fhip_ctx* ctx) {
+    hipError_t e = hipSuccess;
+    for (hipStream_t s : {ctx->stream, ctx->stream2, ctx->stream3, ctx->stream_pre}) {
+        const hipError_t r = hipStreamSynchronize(s);       // (a null ctx->stream is the device's default stream: the caller chose it)
+        if (r != hipSuccess && e == hipSuccess) e = r;
+    }
+    for (fhip_ctx* L : ctx->lanes)
+        if (L) { const hipError_t r = sync_own_streams(L); if (r != hipSuccess && e == hipSuccess) e = r; }
+    return e;
+}
+// `volume_hint`: voxels of a 3D frame whose ROOT tape reads an input that changes along a pixel column (0: none such, or 2D): every
+// tile of every slab then keeps a tape of its own, and the first 128 MB overflow in the first frame - which is then right but many
+// times slower (children keep their parents' tapes), as are the frames until the growth below has caught up.  Sized at about a byte
+// per voxel from the start instead (prospero.vm 1024^3 with z in every tape: peak 0.9 GB per set), before anything is in flight.
+static fhip_status grow_arena_if_asked(fhip_ctx* ctx, size_t tape_ops, uint64_t volume_hint = 0) {
+    size_t need = ((tape_ops + 64) * 8 + 4096) * 4;       // (root tape + its groups, with room to prune into)
+    if (volume_hint) need = std::max<size_t>(need, std::min<uint64_t>(volume_hint, ctx->arena_cap_bytes));
     bool grow = ctx->host_flags && ctx->host_flags[0] != 0 && ctx->arena_bytes < ctx->arena_cap_bytes;
     size_t want = grow ? ctx->arena_bytes * (ctx->arena_bytes <= ((size_t)FH_ARENA_START_MB << 20) ? 4 : 2) : ctx->arena_bytes;      // (the first step is the big one: a frame that outgrows the first 128 MB is usually one with z in every tape, at 4 x the ops and more)
     if (want < need) { want = need; grow = ctx->arena_bytes < std::min(need, ctx->arena_cap_bytes); }
     if (!grow) return FHIP_OK;
-    HIP_TRY(ctx, hipDeviceSynchronize());       // (every stream of the context, its lanes included: a set's arena is about to be replaced)
+    HIP_TRY(ctx, sync_own_streams(ctx));       // (every stream of the context, its lanes included: a set's arena is about to be replaced)
     ctx->host_flags[0] = 0;
     ctx->arena_bytes = std::min(ctx->arena_cap_bytes, want);
     return FHIP_OK;
@@ -331,7 +348,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     R.table_words = is3d ? (uint32_t)leaf_cap : 0;
     R.n_footprints = (uint32_t)(fw * fhh);
 
-    { const fhip_status gs_ = grow_arena_if_asked(ctx, t.ops.size()); if (gs_) return gs_; }
+    { const fhip_status gs_ = grow_arena_if_asked(ctx, t.ops.size(), is3d && !R.root_invariant ? (uint64_t)P.width * P.height * P.depth : 0); if (gs_) return gs_; }
     HIP_TRY(ctx, ctx->state.ensure(4 * sizeof(FhRenderState)));
     { void* const before = ctx->arena.p; HIP_TRY(ctx, ctx->arena.ensure(ctx->arena_bytes)); if (ctx->arena.p != before) ctx->resident_serial = 0; }
     for (size_t l = 0; l < ts.size(); l++) HIP_TRY(ctx, ctx->queue[l].ensure((size_t)qcaps[l] * sizeof(FhGroup)));
@@ -769,7 +786,7 @@ static void launch_tiles(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS,
 
 static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render2d_config* cfg, float* out,
                                   int out_is_device) {
-    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    if (ctx->is_cancelled()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
     RenderSetup R;
     memset(&R.S, 0, sizeof(R.S));
     FhRender& P = R.S.P;
@@ -826,7 +843,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         ps = upload_frame(ctx, tape, Q, no_clear);
         if (ps) return ps;
         for (uint32_t l = 0; l < Q.S.P.n_levels; l++) {
-            if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+            if (ctx->is_cancelled()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
             launch_tiles(ctx, Q, dS, (int)l, false);
         }
         if (Q.classify_only) return FHIP_OK;
@@ -884,7 +901,7 @@ static fhip_status render2d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
 
 static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_config* cfg, void* out,
                                   int out_is_device, const PartSpec& part) {
-    if (ctx->cancelled.load()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
+    if (ctx->is_cancelled()) return fail(ctx, FHIP_ERR_CANCELLED, "cancelled");
     if (ctx->opt.stats & 2) g_spans.start();
     (void)hipSetDevice(ctx->device);
     RenderSetup R;
@@ -1122,7 +1139,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             if (ts_) { ctx->stream = main_stream; return ts_; }
         }
     for (int k = (int)R.slab_hi - 1; k >= (int)R.slab_stop && n_groups; k--) {  // front to back (voxel.rs:252-261)
-        if (ctx->cancelled.load()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
+        if (ctx->is_cancelled()) { ctx->stream = main_stream; return fail(ctx, FHIP_ERR_CANCELLED, "cancelled"); }
         const int idx = (int)R.slab_hi - 1 - k;
         if (!tiles_first) {
             const fhip_status ts_ = tile_step(k, idx);
@@ -1304,7 +1321,7 @@ static fhip_status run_on_lane_(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes,
         ctx->lanes.push_back(L);
     }
     fhip_ctx* const L = ctx->lanes[ctx->lane_next++ % K];
-    L->cancelled.store(ctx->cancelled.load());
+    L->cancel_src = &ctx->cancelled;
     HIP_TRY(ctx, L->lane_img.ensure(bytes));
     if (L->lane_copied_valid) HIP_TRY(ctx, hipStreamWaitEvent(L->stream, L->lane_copied, 0));   // (its previous image has been copied out)
     const fhip_status st = render(L, L->lane_img.p);

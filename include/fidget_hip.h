@@ -50,6 +50,11 @@ fhip_status fhip_ctx_sync(fhip_ctx* ctx);
  * depth-10 build), its landing area, the frame lanes (child contexts with buffers of their own - up to four, each a context's worth of
  * buffers: option frame_lanes).  Waits for the context's work; whatever is needed again is made again by the call that needs it. */
 fhip_status fhip_ctx_trim(fhip_ctx* ctx);
+/* The tape arena of a buffer set is sized by need: 128 MB, or about a byte per voxel for a 3D frame whose root tape reads an input that
+ * changes along a pixel column, grown when a frame ran out (that frame is still right: its tiles kept their parents' tapes - and many
+ * times slower), never beyond option arena_mb.  A caller that knows better - a sequence of frames of a heavier model to come - says
+ * so here: every set's arena is at least `megabytes` from the next frame on (capped by arena_mb).  Waits for the context's own work. */
+fhip_status fhip_ctx_reserve_arena(fhip_ctx* ctx, size_t megabytes);
 /* The device evaluates sin cos tan asin acos atan atan2 exp ln with the routines of glibc 2.35's x86-64 libm (its FMA variants)
  * restated operation by operation (fidget_amd/csrc/trans_libm.hpp) - the libm the reference's f32 methods call on the deployment
  * image, whose values its own bulk test demands bit for bit (fidget-core/src/eval/test/float_slice.rs:404-412).  On a host with

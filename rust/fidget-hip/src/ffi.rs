@@ -43,6 +43,7 @@ extern "C" {
     pub fn fhip_cancel_reset(ctx: *mut fhip_ctx);
     pub fn fhip_ctx_sync(ctx: *mut fhip_ctx) -> fhip_status;     // waits for the asynchronous renders, reports their overflow flags
     pub fn fhip_ctx_trim(ctx: *mut fhip_ctx) -> fhip_status;     // caches kept for speed alone (mesh leaf records, frame lanes) go back
+    pub fn fhip_ctx_reserve_arena(ctx: *mut fhip_ctx, megabytes: usize) -> fhip_status;     // a sequence of heavier frames to come: arenas sized ahead
     pub fn fhip_ctx_set_option(ctx: *mut fhip_ctx, name: *const c_char, value: c_int) -> fhip_status;   // behaviour switches: see below
     pub fn fhip_ctx_get_option(ctx: *const fhip_ctx, name: *const c_char, value: *mut c_int) -> fhip_status;
 

@@ -243,11 +243,12 @@ def test_render3d_frames_in_flight():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"FHIP_FRAME_SETS": "2"}, {"FHIP_FRAME_SETS": "3", "FHIP_ROOT32_MAX": "0"}, {"FHIP_FRAME_SETS": "5", "FHIP_NO_ZREP": "1"},
+@pytest.mark.parametrize("env", [{"FHIP_COLUMN_GROUP": "0"}, {"FHIP_COLUMN_GROUP": "1", "FHIP_ROOT32_MAX": "0"}, {"FHIP_COLUMN_GROUP": "3", "FHIP_NO_ZREP": "1"},
+                                 {"FHIP_COLUMN_GROUP": "6", "FHIP_NO_COLUMN_INV": "1"},
                                  {"FHIP_SLAB_LAYERS": "1"}, {"FHIP_SLAB_LAYERS": "2", "FHIP_NO_ZREP": "2"}, {"FHIP_FRAME_LANES": "0"}, {"FHIP_NO_COLUMN_INV": "1"},
                                  {"FHIP_COLUMN_WALK": "0"}, {"FHIP_COLUMN_WALK": "2", "FHIP_FRAME_LANES": "0"}, {"FHIP_COLUMN_WALK": "2", "FHIP_NO_COLUMN_INV": "1"}])
 def test_render3d_frames_in_flight_under_the_pipeline_options(env, monkeypatch):
-    """The frame pipeline's switches (buffer sets 2..5, z-slab thickness, the library's tile choice, sharing of tiles along z, frame lanes,
+    """The frame pipeline's switches (the leaf kernel's column groups, z-slab thickness, the library's tile choice, sharing of tiles along z, frame lanes,
     the column-invariance short cuts, the leaf kernel by layers or by footprint columns) decide WHEN and WHERE a frame's kernels run, never what they compute: a queue of frames of different
     shapes, sizes and cameras gives the oracle's images under every setting.  (Round 5 fixed the switches of rounds 2-4 whose measurement
     was settled - where the slab's small kernels run, what the side stream carries, issue priority ... - at their measured values.)"""
