@@ -201,7 +201,7 @@ def main():
             step()
         # (the library times the first ~50 queued frames of a kind under its two frame arrangements - stage pipeline, frame lanes - and keeps
         # the faster, capi_render.hpp lane_mode: those frames are warm-up too, counted in config.tuning_frames)
-        while world == 1 and tuning["frames"] < 400 and 0 <= hip.lane_tune()["phase"] < 4:
+        while world == 1 and tuning["frames"] < TUNING_CAP and 0 <= hip.lane_tune()["phase"] < 4:
             step()
             tuning["frames"] += 1
         if world > 1:       # (every rank the same number of steps - there are collectives in them -, so a fixed count here: what the tuner takes, and a few)
@@ -384,6 +384,7 @@ def main():
         "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(frame_ms)), "ms_per_step_min": float(np.min(frame_ms)),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "tuning_frames": tuning["frames"],
         "frame_latency_ms": lat_default,
         "device_bytes": device_bytes, "device_bytes_timed_path": bytes_default,
         "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "last_measured": tuning["last"],
@@ -572,6 +573,18 @@ def main():
                                            "(option frame_lanes; " + str(hip.lane_frames()) + " frames of this context went that way)",
                                  "note": "transcendental opcodes: the device runs the host libm's f32 routines restated operation by operation "
                                          "(fidget_amd/csrc/trans_libm.hpp; 0 of 2^32 arguments differ per routine, profiles/r04a/math_sweep.json)"}
+        # BASELINE configuration 2 (prospero.vm 2D 4096^2) and a model that DOES read z at the headline size (colonnade.vm 1024^3: nothing
+        # of the column-invariance short cuts applies to it): ms per queued frame, the image against the oracle's at full size, and the
+        # leaf stage's share as a roofline fraction (algorithmic bytes = 8 B x tape ops x passes of the frames' own device counters
+        # + the output pixels, over the frame time: an upper bound of any kernel's fraction in that frame)
+        if args.model == "prospero.vm":
+            try:
+                result["c2_2d"] = side_config_2d(F, O, hip, torch, dev, fence, os.path.join(ROOT, "models", "prospero.vm"), 4096)
+                col = os.path.join(ROOT, "models", "colonnade.vm")
+                if os.path.exists(col):
+                    result["c4z_colonnade"] = side_config_3d(F, O, hip, torch, dev, fence, col, 1024)
+            except Exception as e:      # noqa: BLE001  (the line's other fields do not depend on these legs)
+                result["c2_2d"] = result.get("c2_2d") or {"error": repr(e)[:200]}
         # BASELINE configuration 5 (Manifold Dual Contouring of gyroid-sphere at octree depth 10 = 1024^3: fhip_mesh_build, the octree
         # assembled on the device, the dual walk on the host's threads): seconds per build, in a process of its own (tools/mesh_times.py,
         # the script profiles/r03z/mesh_times.log comes from) so that nothing it does can cost this line
@@ -593,6 +606,53 @@ def main():
     print(text)
     if world > 1:
         dist.destroy_process_group()
+
+
+TUNING_CAP = 64         # untimed frames beyond --warmup the library's arrangement tuner may take (3 windows of 16 queued frames; `tuning_frames` in the line says how many it took)
+def _queued_ms(step, fence, warm=60, frames=20):
+    for _ in range(warm):      # (the library's arrangement tuner takes ~50 queued frames of a kind)
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        step()
+    fence()
+    return (time.perf_counter() - t0) / frames * 1e3
+
+
+def side_config_2d(F, O, hip, torch, dev, fence, model, n):
+    import numpy as np
+    s, o = F.Shape.from_vm(model, hip=hip), O.Shape.from_vm(model)
+    out = torch.zeros((n, n), dtype=torch.float32, device=dev)
+    ms = _queued_ms(lambda: F.render2d(s, n, out=out), fence)
+    a = out.cpu().numpy().view(np.uint32)
+    b = O.render2d(o, n, tile_sizes=F.HIP_TILES_2D)[0].view(np.uint32)
+    px = n * n
+    return {"workload": f"{os.path.basename(model)} 2D {n}^2", "ms_per_frame": ms, "image_equal": bool((a == b).all()),
+            "roofline": {"bound": "hbm", "achieved": px * 4 / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": px * 4 / (ms * 1e-3) / 1e9 / 8000.0,
+                         "what": "4 B per output pixel over the frame time (the frame is its tile chain: latency of dependent kernels, DESIGN.md section 6)"}}
+
+
+def side_config_3d(F, O, hip, torch, dev, fence, model, n):
+    import numpy as np
+    s, o = F.Shape.from_vm(model, hip=hip), O.Shape.from_vm(model)
+    out = torch.zeros((n, n, 4), dtype=torch.int32, device=dev)
+    ms = _queued_ms(lambda: F.render3d(s, n, out=out), fence)
+    hip.sync()
+    hip.profile(True)         # (one frame with the device's op counters, as the main configuration's profiled frames)
+    F.render3d(s, n, out=out)
+    hip.profile_read()
+    hip.wave_stats()
+    leaf = hip.leaf_stats()
+    hip.profile(False)
+    a = out.cpu().numpy().view(np.uint32).reshape(n, n, 4)
+    b = O.render3d(o, n)[0]
+    nb = (a[..., :3] == b["normal"].view(np.uint32)) | (np.isnan(a[..., :3].view(np.float32)) & np.isnan(b["normal"]))
+    alg = 8.0 * leaf["tape_words_read"] + 16.0 * n * n
+    return {"workload": f"{os.path.basename(model)} 3D heightmap+normals {n}^3 (z in the tape: no column-invariance short cut applies)", "ms_per_frame": ms,
+            "depth_equal": bool((a[..., 3] == b["depth"]).all()), "normals_equal": bool(nb.all()),
+            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / 8000.0,
+                         "what": "leaf tape words x passes x 8 B + 16 B per pixel (device counters of one frame) over the frame time"}}
 
 
 LINE_LIMIT = 6000       # bytes: the driver's record keeps the line whole only when it is short (round 4's 20.6 KB line came back unparsed)
@@ -632,7 +692,7 @@ def compact_line(result):
     set and the size).  Everything else bench.py measured - per-kernel times, device counters, the other kernels' rooflines, the notes -
     goes to the details file the line names."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "device_bytes_timed_path")
+            "vs_baseline", "dtype", "data", "tuning_frames", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "device_bytes_timed_path")
     line = {k: result[k] for k in keep if k in result}
     cfg = result["config"]
     line["config"] = {"workload": cfg["workload"], "sharding": cfg["sharding"], "column_invariance": cfg["column_invariance"][:300],
@@ -646,6 +706,9 @@ def compact_line(result):
         line["parity"] = result["parity"]
     if result.get("c3_bear"):
         line["c3_bear"] = {k: result["c3_bear"].get(k) for k in ("workload", "ms_per_frame", "depth_equal", "normals_bit_equal_fraction")}
+    for k in ("c2_2d", "c4z_colonnade"):
+        if result.get(k):
+            line[k] = {kk: (vv if kk != "roofline" else {q: vv[q] for q in ("bound", "achieved", "peak", "unit", "frac")}) for kk, vv in result[k].items()}
     if result.get("c5_mesh"):
         c5 = result["c5_mesh"]
         line["c5_mesh"] = ({k: c5.get(k) for k in ("workload", "s_per_build", "s_per_build_inside_the_library", "triangles", "vertices",
@@ -661,7 +724,7 @@ def compact_line(result):
         line["per_rank"] = result.get("per_rank")
     line = _rnd(line)
     # should the line still outgrow the limit (a long error text, 8 ranks of stage times): shed the optional objects, never the contract's
-    for k in ("per_rank", "c3_bear", "c5_mesh", "parity", "roofline_timed_path"):
+    for k in ("per_rank", "c2_2d", "c4z_colonnade", "c3_bear", "c5_mesh", "parity", "roofline_timed_path"):
         if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT - 200:
             break
         line.pop(k, None)

@@ -213,12 +213,19 @@ def test_the_single_gpu_line_is_short_and_has_the_contract_keys():
     assert len(json.dumps(full)) > 15000
     full["device_bytes"] = 1 << 30
     full["c5_mesh"].update(parity={"triangles_equal": True, "vertices_equal": True}, cpu_s_per_build=10.0, cpu_threads=128)
+    # round 6: the tuner's untimed frames, BASELINE configuration 2 and a z-reading model at the headline size, one compact object each
+    full["tuning_frames"] = 52
+    roof = {"bound": "hbm", "achieved": 250.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.03125, "what": "x" * 200}
+    full["c2_2d"] = {"workload": "prospero.vm 2D 4096^2", "ms_per_frame": 0.25, "image_equal": True, "roofline": dict(roof)}
+    full["c4z_colonnade"] = {"workload": "colonnade.vm 3D heightmap+normals 1024^3", "ms_per_frame": 0.45, "depth_equal": True, "normals_equal": True, "roofline": dict(roof)}
     line = bench.compact_line(full)
     text = json.dumps(line, separators=(",", ":"))
     assert len(text) < 6000, len(text)
     assert set(line) == {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
-                         "vs_baseline", "dtype", "data", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "config", "roofline",
-                         "roofline_timed_path", "cpu_baseline", "parity", "c3_bear", "c5_mesh"}
+                         "vs_baseline", "dtype", "data", "tuning_frames", "frame_latency_ms", "host_output_frame_ms", "device_bytes", "config", "roofline",
+                         "roofline_timed_path", "cpu_baseline", "parity", "c3_bear", "c5_mesh", "c2_2d", "c4z_colonnade"}
+    for k in ("c2_2d", "c4z_colonnade"):
+        assert set(line[k]["roofline"]) == {"bound", "achieved", "peak", "unit", "frac"} and line[k]["ms_per_frame"] > 0
     assert set(line["config"]) == {"workload", "sharding", "column_invariance", "general_path"}
     assert set(line["config"]["general_path"]) == {"ms_per_step", "value", "frame_latency_ms"}
     for k in ("roofline", "roofline_timed_path"):

@@ -84,12 +84,14 @@ real_kernarg = C.col_kernarg
 for general in (False, True):
     # prospero's leaf tapes read no z: the kernel takes them as column-invariant (one voxel per pixel).  `general`: the kernarg of
     # FHIP_NO_COLUMN_INV (every input counts as varying along the column) - all 512 voxels, what a tape with z in it gets
-    C.col_kernarg = (lambda a_st, in_kind, m, size=16: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(a_st, in_kind, m, size))) if general else real_kernarg
+    C.col_kernarg = (lambda *a, **kw: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(*a, **kw))) if general else real_kernarg
     for cls, leaves in sorted(by_class.items()):
         leaves.sort(key=lambda t: t[0])
         runs = []
         for n_ops, lregs, leaf in (leaves[0], leaves[-1]):
-            zbuf, ws = C.run_columns(leaf, lregs, ik, mat.reshape(-1), (0, 0, 0), size=16)      # (layer 0: the block rotation, a modulo by subtraction, is then trivial as it is at 1024^2)
+            # (the general path walks the table by groups of four layers of a footprint's column since round 6 - option column_group = 2 -,
+            # the default path of a model without z by whole columns)
+            zbuf, ws = C.run_columns(leaf, lregs, ik, mat.reshape(-1), (0, 0, 0), size=16, column_mode=True, group_log2=2 if general else 6)
             runs.append((n_ops, counts(max(ws, key=lambda w: w.counts.get('valu', 0)))))      # (the workgroup that finds the leaf)
         (n0, c0), (n1, c1) = runs
         e = {"leaf_tapes_ops": [n0, n1], "voxels_evaluated": 512 if general else 64, "workgroup_total": [c0, c1]}

@@ -81,7 +81,7 @@ el, eh, chs, _ = U.ref_interval(tape2, inputs, 64)
 lanes = np.nonzero(~(eh < 0) & ~(el > 0))[0]
 mat = np.eye(4, dtype=np.float32); mat[:3, :3] *= 2.0 / 16; mat[:3, 3] = -1.0
 real_kernarg = C.col_kernarg
-C.col_kernarg = lambda a_st, in_kind, m: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(a_st, in_kind, m))     # the general path: every voxel
+C.col_kernarg = lambda *a, **kw: (lambda k: (k.__setitem__(4, 0xFFFFFFFF), k)[1])(real_kernarg(*a, **kw))     # the general path: every voxel
 res = {}
 for name, pref in (("lowest free register (as built)", 0), ("the dying operand takes the output's register", 1),
                    ("... and add / mul put their dying operand first", 2)):
