@@ -126,6 +126,8 @@ VT = [f"v{18 + j}" for j in range(8)]
 VU = [f"v{26 + j}" for j in range(8)]
 VW = [f"v{34 + j}" for j in range(8)]
 VD = [f"v{42 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
+V_PINF, V_NINF = "v3", "v62"     # columns (threaded): +inf / -inf, the neutral first operand of v_minimum3_f32 / v_maximum3_f32 in the delta handlers
+S_ONES = "s[58:59]"              # columns (threaded): (1.0, 1.0)
 V_QNAN = "v50"
 V_SQRTC = "v51"
 V_NXT = ("v52", "v53")   # columns: the NEXT leaf's tape words, requested while this leaf is interpreted
@@ -186,6 +188,7 @@ class Interp:
         if self.threaded:
             self.hl = 8            # slots of 256 bytes: the prologue, and min / max in place without a jump to their body
         self.ip_slot_log2 = self.hl
+        self.delta_setup()
 
     def F(self, j):
         """sample j of the register selected by the index (M0 = register * ZB)"""
@@ -632,6 +635,8 @@ class Interp:
                 # One v_minimum3_f32 / v_maximum3_f32 per sample (see f_minmax) unless a sample of a is a zero: the two tests and
                 # two selects per sample (dev_ops.hpp f_min / f_max to the letter) are left to that case.
                 slow = a.label("mm_zero")
+                self.mm_slow = getattr(self, "mm_slow", {})
+                self.mm_slow[base] = slow
                 self.read_b(VU, already_on=False)
                 self.idx_on(s_ip, SRC1 | SRC2)      # a's samples relative, plain destination: is one of them a zero?
                 self.zero_guard([F(j) for j in Z], VW[0])
@@ -927,6 +932,76 @@ class Interp:
 
 
 
+    # Delta handlers (threaded dispatch).  An op that reads one file register and writes another needs two index settings and a copy
+    # through temporaries - unless the DISTANCE between the two registers is part of the instruction: with M0 = the written register,
+    # the read operand is encoded as file + distance * ZB.  One handler per (op, distance) for the forms that matter (prospero's leaf
+    # tapes: 24 % of the ops are register-immediate / unary forms with out != a, 28 % are in-place RR forms whose b is another register):
+    # family U = unary / register-immediate ops with out != a (distance a - out), family B = in-place RR ops (distance b - a).
+    U_OPS = ["COPY_REG", "NEG", "ABS", "SQUARE", "ADD_RI", "SUB_RI", "MUL_RI", "SUB_IR"]
+    B_OPS = ["ADD_RR", "SUB_RR", "MUL_RR", "MIN_RR", "MAX_RR"]
+
+    def delta_setup(self):
+        # (not in the kernel for tapes with transcendental opcodes: their leaves are hundreds of ops of mostly other kinds, and the longer
+        # decode cost bear.vm 1.4 % where prospero.vm's leaf kernel gained 3 %)
+        self.dmax = min(self.nr - 1, 7) if (self.threaded and self.zb >= 4 and not self.trans and EXP != "nodelta") else 0
+        self.nd = 2 * self.dmax + 1
+        self.su = {8: 80, 4: 64}.get(self.zb, 0)       # slot bytes of family U / B
+        self.sb = {8: 160, 4: 112}.get(self.zb, 0)
+
+    def handler_delta(self, fam, op, d):
+        a, zb = self.a, self.zb
+        do = d * zb
+        Fd = lambda j: f"v{FILE + do + j}"
+        FdP = lambda k: f"v[{FILE + do + 2 * k}:{FILE + do + 2 * k + 1}]"
+        Z, PZ = range(zb), range(zb // 2)
+        self.prologue()
+        if fam == "U":
+            if op in ("COPY_REG", "SQUARE"):
+                self.idx_on(self.s_out, SRC0 | SRC1 | DST)
+                for k in PZ:
+                    a(f"\tv_pk_mov_b32 {self.FP(k)}, {FdP(k)}, {FdP(k)} op_sel:[0,1]" if op == "COPY_REG" else f"\tv_pk_mul_f32 {self.FP(k)}, {FdP(k)}, {FdP(k)}")
+                return self.ret(src0_on=True)
+            self.idx_on(self.s_out, SRC1 | DST)
+            if op in ("NEG", "ABS"):
+                for j in Z:
+                    a(f"\tv_xor_b32 {self.F(j)}, {S_SIGN}, {Fd(j)}" if op == "NEG" else f"\tv_and_b32 {self.F(j)}, {S_ABSM}, {Fd(j)}")
+                return self.ret()
+            base, form = op.rsplit("_", 1)
+            ins = "v_pk_mul_f32" if base == "MUL" else "v_pk_add_f32"
+            mod = {("SUB", "RI"): " neg_lo:[1,0] neg_hi:[1,0]", ("SUB", "IR"): " neg_lo:[0,1] neg_hi:[0,1]"}.get((base, form), "")
+            for k in PZ:
+                a(f"\t{ins} {self.FP(k)}, {S_CUR}, {FdP(k)} op_sel:[1,0] op_sel_hi:[1,1]{mod}")
+            return self.ret()
+        base = op.rsplit("_", 1)[0]
+        if base in ("ADD", "SUB"):       # a + b = 1.0 * b + a, a - b = 1.0 * (-b) + a, exactly; b in src1, a in src2: no SRC0-relative mode
+            self.idx_on(self.s_out, SRC1 | SRC2 | DST)
+            neg = " neg_lo:[0,1,0] neg_hi:[0,1,0]" if base == "SUB" else ""
+            for k in PZ:
+                a(f"\tv_pk_fma_f32 {self.FP(k)}, {S_ONES}, {FdP(k)}, {self.FP(k)}{neg}")
+            return self.ret()
+        if base == "MUL":
+            self.idx_on(self.s_out, SRC0 | SRC1 | DST)
+            for k in PZ:
+                a(f"\tv_pk_mul_f32 {self.FP(k)}, {FdP(k)}, {self.FP(k)}")
+            return self.ret(src0_on=True)
+        # min / max in place, b at a distance: see the in-place handler; the neutral first operand (+inf / -inf) keeps src0 plain
+        slow = a.label("mmd_zero")
+        self.idx_on(self.s_out, SRC1 | SRC2)
+        self.zero_guard([self.F(j) for j in Z], VW[0])
+        self.idx_on(self.s_out, SRC1 | SRC2 | DST)
+        a(f"\ts_cbranch_vccnz {slow}")
+        for j in Z:
+            a(f"\t{'v_minimum3_f32' if base == 'MIN' else 'v_maximum3_f32'} {self.F(j)}, {V_PINF if base == 'MIN' else V_NINF}, {Fd(j)}, {self.F(j)}")
+        self.ret()
+
+        def slow_stub(base=base):          # a zero among a's samples: b into VU, then the in-place handler's compares and selects
+            self.idx_on(self.s_out, SRC0 | SRC1)
+            for k in PZ:
+                self.pk_mov(self.P(VU, k), FdP(k))
+            self.idx_on(self.s_out, SRC1 | SRC2 | DST)
+            a(f"\ts_branch {self.mm_slow[base]}")
+        self.ool.append((slow, slow_stub))
+
     # pseudo-opcodes of the threaded decode (slots the tape format leaves free)
     PSEUDO = {52: "INPUT_X", 53: "INPUT_Y", 54: "INPUT_Z", 55: "NEXT_CHUNK"}
 
@@ -971,6 +1046,20 @@ class Interp:
                 else:
                     self.handler(op, inplace)
                 a(f"\t.if (. - {lab}) > {1 << lg}\n\t.error \"handler {op} of {n} exceeds its slot\"\n\t.endif")
+        if self.dmax:
+            for fam, ops, slot in (("U", self.U_OPS, self.su), ("B", self.B_OPS, self.sb)):
+                a(f"\t.p2align 6\n.L{n}_d{fam.lower()}:")
+                # (slot order: the decode counts the family's opcodes AT OR ABOVE the op's - the highest opcode comes first)
+                for op in sorted(ops, key=OPS.index, reverse=True):
+                    for d in range(-self.dmax, self.dmax + 1):
+                        lab = a.label(f"d{fam}_{op}_{d + self.dmax}")
+                        a(f"{lab}:")
+                        if d == 0:
+                            a("\ts_endpgm")          # (never selected: distance 0 is the in-place table's)
+                        else:
+                            self.handler_delta(fam, op, d)
+                        a(f"\t.if (. - {lab}) > {slot}\n\t.error \"delta handler {op} {d} of {n} exceeds its slot\"\n\t.endif")
+                        a(f"\t.org {lab} + {slot}")
         a(f"\t.p2align {self.hl}")
         for lab, fn in self.ool:
             a(f"{lab}:")
@@ -1049,15 +1138,21 @@ def handler_base(a, it):
 
 def emit_decode(a, it, inplace_mask):
     """threaded dispatch: the tape words in v[60:61], lane = op -> V_DEC: handler address (the in-place table when out == a and the
-    op has such a form; an INPUT of an axis slot has a handler of its own), file indices out | a << 8, word 1 (the RR forms: b's
-    file index).  Clobbers v18 .. v23, vcc, s[90:97]."""
-    lg, hl, ipl = it.lg, it.hl, it.ip_slot_log2
+    op has such a form; a delta handler - Interp.handler_delta - when the two registers of the op are close enough; an INPUT of an axis
+    slot has a handler of its own), file indices out | a << 8, word 1 (the RR forms: b's file index).
+    Clobbers v18 .. v33, vcc, s[90:97]."""
+    lg, hl, n = it.lg, it.hl, it.name
+    def mask_of(ops):
+        m = 0
+        for o in ops:
+            m |= 1 << OPS.index(o)
+        return m
     a(f"""
 	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
 	s_mov_b32 s97, {hex(inplace_mask >> 32)}
-	v_and_b32 v18, 0xff, v60
-	v_bfe_u32 v19, v60, 8, 12
-	v_lshrrev_b32 v20, 20, v60
+	v_and_b32 v18, 0xff, v60                          ; opcode
+	v_bfe_u32 v19, v60, 8, 12                         ; out
+	v_lshrrev_b32 v20, 20, v60                        ; a
 	v_cmp_eq_u32 vcc, v19, v20
 	v_lshrrev_b64 v[22:23], v18, s[96:97]
 	v_mov_b32 v63, v61
@@ -1067,24 +1162,52 @@ def emit_decode(a, it, inplace_mask):
 	v_lshlrev_b32 v23, {lg}, v61
 	v_cmp_gt_u32 vcc, {len(BIN)}, v21                ; an RR form: word 1 names a register
 	v_cmp_eq_u32_e64 {S_M[0]}, {OPS.index("INPUT")}, v18
-	v_lshlrev_b32 v19, {lg}, v19
+	v_lshlrev_b32 v26, {lg}, v19
 	v_cndmask_b32 v63, v63, v23, vcc
-	v_lshl_or_b32 v19, v20, {lg + 8}, v19            ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)""")
+	v_lshl_or_b32 v26, v20, {lg + 8}, v26            ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
+	v_lshlrev_b32 v27, {hl}, v18                      ; the handler's offset: generic table ...
+	v_add_u32 v28, {64 << hl}, v27                    ; ... in-place table
+	v_cmp_eq_u32 vcc, 1, v22
+	s_nop 1
+	v_cndmask_b32 v27, v27, v28, vcc""")
+    if it.dmax:
+        D, ND = it.dmax, it.nd
+        um, bm = mask_of(it.U_OPS), mask_of(it.B_OPS)
+        for fam, mask, sub, member, slot in (("U", um, "v_sub_u32 v21, v20, v19", "v_and_b32 v24, 1, v24", it.su),
+                                             ("B", bm, "v_sub_u32 v21, v61, v20", "v_and_b32 v24, v22, v24", it.sb)):
+            # family U (unary / register-immediate, out != a): distance a - out; family B (RR in place - v22: out == a and the op has an
+            # in-place form, as every op of the family has): distance b - a; within +-D and not 0
+            a(f"""
+	s_mov_b32 s96, {hex(mask & 0xffffffff)}
+	s_mov_b32 s97, {hex(mask >> 32)}
+	{sub}
+	v_lshrrev_b64 v[24:25], v18, s[96:97]
+	v_add_u32 v21, {D}, v21
+	v_cmp_gt_u32_e64 {S_M[1]}, {ND}, v21
+	v_cmp_ne_u32_e64 {S_M[2]}, {D}, v21
+	v_bcnt_u32_b32 v23, v24, 0
+	v_bcnt_u32_b32 v23, v25, v23                      ; the family's opcodes at or above this one
+	{member}
+	s_and_b64 {S_M[1]}, {S_M[1]}, {S_M[2]}
+	v_subrev_u32 v23, 1, v23
+	v_mad_u32_u24 v23, v23, {ND}, v21
+	v_cmp_eq_u32 vcc, 1, v24
+	v_mul_u32_u24 v23, {slot}, v23
+	v_add_u32 v23, .L{n}_d{fam.lower()} - .L{n}_handlers, v23
+	s_and_b64 vcc, vcc, {S_M[1]}
+	v_cndmask_b32 v27, v27, v23, vcc""")
     for k, sl in enumerate((S_SLOTX, S_SLOTY, S_SLOTZ)):
         a(f"\tv_cmp_eq_u32_e64 {S_M[1 + k]}, {sl}, v61")
     for k in range(3):
         a(f"\ts_and_b64 {S_M[1 + k]}, {S_M[1 + k]}, {S_M[0]}")
+    a(f"\tv_mov_b32 v28, {52 << hl}")
     for k in range(3):
-        a(f"\tv_cndmask_b32_e64 v18, v18, {52 + k}, {S_M[1 + k]}")
+        a(f"\tv_cndmask_b32_e64 v27, v27, v28, {S_M[1 + k]}")
+        if k < 2:
+            a(f"\tv_add_u32 v28, {1 << hl}, v28")
     a(f"""
-	v_mov_b32 v61, v19
-	v_lshlrev_b32 v20, {hl}, v18
-	v_lshlrev_b32 v21, {ipl}, v18
-	v_add_u32 v21, {64 << hl}, v21
-	v_cmp_eq_u32 vcc, 1, v22
-	s_nop 1
-	v_cndmask_b32 v20, v20, v21, vcc
-	v_add_u32 v60, s42, v20""")
+	v_mov_b32 v61, v26
+	v_add_u32 v60, s42, v27""")
 
 
 def gen_columns(a, variants, off, trans=None):
@@ -1137,6 +1260,10 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
     a(f"""
+	v_mov_b32 {V_PINF}, 0x7f800000
+	v_mov_b32 {V_NINF}, 0xff800000
+	s_mov_b32 s58, 1.0
+	s_mov_b32 s59, 1.0
 	s_waitcnt lgkmcnt(0)
 	s_load_dwordx16 s[{m}:{m + 15}], {S_STATE}, {o['P.mat']}
 	s_load_dwordx2 s[24:25], {S_STATE}, {o['P.width']}
@@ -1460,7 +1587,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_add_u32 s74, s74, {ret} - {here}
 	s_addc_u32 s75, s75, 0
 	s_cmp_gt_u32 {S_LEN0}, 64
-	s_cbranch_scc0 .L{name}_gov
+	s_cbranch_scc0 .L{name}_togov
 	; a tape of more than 64 ops: 63 at a time, lane 63 holding a pseudo-op whose handler (NEXT_CHUNK) comes back here
 	s_mov_b64 {S_TCUR}, {S_TBASE}
 	s_mov_b32 {S_REM}, {S_LEN0}
@@ -1480,13 +1607,16 @@ def _gen_columns_body(a, variants, off, kname, trans):
             emit_decode(a, it, inplace_mask)
             a(f"""
 	s_cmp_le_u32 {S_REM}, 64
-	s_cbranch_scc1 .L{name}_gov
+	s_cbranch_scc1 .L{name}_togov
 	s_add_u32 s86, s42, {55 << it.hl}                 ; NEXT_CHUNK's handler
 	s_add_u32 s52, s52, {63 * 8}
 	s_addc_u32 s53, s53, 0
 	s_sub_u32 {S_REM}, {S_REM}, 63
 	v_writelane_b32 {V_DEC[0]}, s86, 63
-	s_branch .L{name}_gov
+.L{name}_togov:                                  ; (the interpreters lie beyond a branch's 128 KB: a computed jump)
+	s_sub_u32 s44, s42, .L{name}_handlers - .L{name}_gov
+	s_subb_u32 s45, s43, 0
+	s_setpc_b64 s[44:45]
 {ret}:""")
         else:
             a(f"""

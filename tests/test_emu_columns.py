@@ -378,3 +378,66 @@ def test_column_mode_in_the_transcendental_kernel():
     b, wb = run_columns(tape, sh.slot_count(), ik, AFFINE32, leaves[0], size=size, more_leaves=leaves[1:], kernel="fh_columns_t", column_mode=True)
     assert (a != 0).any() and (a == b).all(), f"{(a != b).sum()} z-buffer words differ"
     assert len(wb) == 64
+
+
+def _leaf_values(tape, n_regs, ik, mat, leaf=(0, 0, 0), kernel="fh_columns"):
+    """run ONE leaf of an 8-voxel-per-lane class and return the tape's output for its 64 pixels x 8 voxels as the kernel left it in
+    VRES (v10 .. v17, sample j = voxel z + 7 - j), next to numpy's"""
+    _, ws = run_columns(tape, n_regs, ik, mat, leaf)
+    w = max(ws, key=lambda w: w.counts.get("valu", 0))
+    got = np.stack([np.asarray(w.v[10 + j]).view(F32) for j in range(8)], axis=1)       # [lane][sample]
+    lx, ly, lz = leaf
+    want = np.zeros((64, 8), F32)
+    for lane in range(64):
+        px, py = lx + lane % 8, ly + lane // 8
+        zs = np.arange(lz + 7, lz - 1, -1)
+        X, Y, Z = xf_point(np.asarray(mat, F32), np.full(8, px), np.full(8, py), zs)
+        inputs = {s: (X, Y, Z)[k] for s, k in enumerate(ik) if k < 3}
+        want[lane] = U.ref_f32(tape, inputs, 8)[0]
+    return got, want
+
+
+def _same_bits(a, b):
+    return ((a.view(U32) == b.view(U32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+@pytest.mark.parametrize("mat", [AFFINE, ROTATED], ids=["affine", "rotated"])
+def test_delta_handlers_every_op_and_distance(mat):
+    """Threaded dispatch, round 6: ops that read one file register and write another have a handler per (op, distance between the two
+    registers) - family U: unary / register-immediate ops with out != a, family B: in-place RR ops with b elsewhere (gen_interp.py
+    handler_delta).  Every op of both families at distances -7 .. 7, on operands that hold exact zeros of both signs, infinities and
+    NaNs in some lanes (min / max by v_minimum3_f32 with the zero guard and its slow path): the output VALUES, bit for bit, for
+    every lane and voxel against numpy."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    # registers 0 .. 7: r0 = x, r1 = y, r2 = x - x (+0 everywhere), r3 = -(x - x) (-0), r4 = sqrt(y - 0.3) (NaN where y < 0.3), r5 = 1 / r2 ... built per test
+    def prelude():
+        return [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 1), P(OP["INPUT"], 7, 0, 2),
+                P(OP["SUB_RR"], 2, 0, 0), P(OP["NEG"], 3, 2, 0), P(OP["SUB_RI"], 4, 1, f(0.3)), P(OP["SQRT"], 4, 4, 0),
+                P(OP["MUL_RR"], 5, 0, 7), P(OP["FLOOR"], 6, 5, 0), P(OP["SUB_RR"], 5, 5, 6), P(OP["SUB_RI"], 5, 5, f(0.5))]     # r5: a fraction - 0.5, both signs
+    tapes = []
+    # family U: out = op(a) for every (out, a) pair of distance d among registers holding different kinds of values
+    for op, w1 in (("COPY_REG", 0), ("NEG", 0), ("ABS", 0), ("SQUARE", 0), ("ADD_RI", f(0.25)), ("SUB_RI", f(1.5)), ("MUL_RI", f(-3.0)), ("SUB_IR", f(0.75))):
+        for out, src in ((6, 5), (5, 6), (7, 0), (0, 7), (6, 3), (3, 6), (6, 4), (2, 5), (6, 2), (1, 4)):
+            t = prelude()
+            if src == 6:
+                t.append(P(OP["ADD_RR"], 6, 5, 1))
+            t += [P(OP[op], out, src, w1), P(OP["OUTPUT"], 0, out, 0)]
+            tapes.append((f"{op} r{out} <- r{src}", t))
+    # family B: a = op(a, b) for distances b - a of both signs; a and b among zeros of both signs, NaNs, ordinary values
+    for op in ("ADD_RR", "SUB_RR", "MUL_RR", "MIN_RR", "MAX_RR"):
+        for ra, rb in ((5, 1), (1, 5), (2, 3), (3, 2), (2, 5), (5, 2), (3, 5), (4, 5), (5, 4), (0, 7), (7, 0), (4, 2), (3, 4)):
+            t = prelude() + [P(OP[op], ra, ra, rb), P(OP["OUTPUT"], 0, ra, 0)]
+            tapes.append((f"{op} r{ra} <- r{ra}, r{rb}", t))
+    bad = []
+    for name, t in tapes:
+        got, want = _leaf_values(np.array(t, np.uint64), 8, ik, mat)
+        if not _same_bits(got, want):
+            bad.append((name, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad
+    # the operands did hold what the cases are about (zeros of both signs and NaNs among the voxels)
+    g, w = _leaf_values(np.array(prelude() + [P(OP["MIN_RR"], 3, 3, 2), P(OP["OUTPUT"], 0, 3, 0)], np.uint64), 8, ik, mat)
+    assert _same_bits(g, w) and (w.view(U32) == 0).all()                     # min(-0, +0) = +0: the guard's slow path
+    g, w = _leaf_values(np.array(prelude() + [P(OP["OUTPUT"], 0, 4, 0)], np.uint64), 8, ik, mat)
+    assert np.isnan(w).any() and not np.isnan(w).all()

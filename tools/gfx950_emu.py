@@ -900,6 +900,11 @@ class Wave:
     def i_v_mul_hi_u32(self, i, d, a, b):
         self._v2(i, d, a, b, lambda x, y: ((x.astype(np.uint64) * y.astype(np.uint64)) >> np.uint64(32)).astype(U32))
 
+    def i_v_mad_u32_u24(self, i, d, a, b, c):
+        self.count("valu")
+        x, y, z = self.usrc(a, 0), self.usrc(b, 1), self.usrc(c, 2)
+        self.vdst(d, (((x & U32(0xFFFFFF)).astype(np.uint64) * (y & U32(0xFFFFFF)).astype(np.uint64) + z.astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(U32))
+
     def i_v_mul_u32_u24(self, i, d, a, b):
         self._v2(i, d, a, b, lambda x, y: ((x & U32(0xFFFFFF)).astype(np.uint64) * (y & U32(0xFFFFFF)).astype(np.uint64)).astype(U32))
 
