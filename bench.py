@@ -78,6 +78,13 @@ def parse_mesh_times(stdout, stderr):
         c5["parity"] = {"triangles_equal": par.group(1) == "True", "vertices_equal": par.group(2) == "True", "sha_device": par.group(6), "sha_oracle": par.group(7),
                         "against": "oracle build_mt + walk_dual at depth 10, element for element"}
         c5["cpu_s_per_build"], c5["cpu_build_s"], c5["cpu_threads"] = float(par.group(3)), float(par.group(4)), int(par.group(5))
+    # ... and the distance of the device's vertices from a solve that is not the product's own (LAPACK f64 SVD of the QEFs accumulated from
+    # the device's leaf records, qef.rs's rank rule; tests/qef_independent.py): the oracle shares the product's Jacobi solve, this does not
+    q = re.search(r"^qef_independent depth (\d+) (\{.*\})$", stdout, re.M)
+    if q and c5.get("parity") is not None:
+        qq = json.loads(q.group(2))
+        c5["parity"]["qef_vs_independent_f64_svd"] = {"depth": int(q.group(1)), "vertices": qq["vertices"], "max_deviation_cell_fraction": qq["max_deviation_cell_fraction"],
+                                                      "over_1e-4_of_a_cell": qq["over_1e-4_of_a_cell"], "rank_decisions_within_1e-4_of_the_cutoff": qq["rank_decisions_within_1e-4_of_the_cutoff"]}
     return c5
 
 

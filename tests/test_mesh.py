@@ -600,3 +600,36 @@ def test_device_mesh_equals_the_oracle_at_depth_8_and_9(model, depth, oracle_mod
     assert len(tris) > 100000
     assert tris.shape == t.shape and (tris == t).all()
     assert verts.shape == v.shape and (verts.view(np.uint32) == v.view(np.uint32)).all()
+
+
+# ---- the QEF solve against something that is not itself ------------------------------------------------------------------------
+# Product and oracle share the solve's arithmetic (cyclic Jacobi in f64 for nalgebra's f32 SVD, qef.rs:67-126): their equality pins
+# the pipeline, not the solve.  tests/qef_independent.py solves every vertex's QEF again with LAPACK's f64 SVD under qef.rs's rank
+# rule; the bound is the rounding of an f32 position in units of a leaf cell (coordinates up to 1, cells of 2 / 2^depth), and NO
+# vertex may sit a rank decision away (that would be a fraction of a cell).
+def _qef_bound(depth):
+    return 4 * 2.0 ** -24 / (2.0 / 2 ** depth)
+
+
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 6), ("colonnade.vm", 6), ("bear.vm", 5), ("prospero.vm", 5)])
+def test_oracle_vertices_minimise_their_qef_by_an_independent_solve(model, depth, oracle_mod):
+    import qef_independent as Q
+    from fidget_amd import MESH_LEAF
+    O = oracle_mod
+    sm = O.Octree(O.Shape.from_vm(model_path(model)), depth).samples
+    recs = np.zeros(len(sm["info"]), MESH_LEAF)
+    recs["bounds"] = sm["bounds"]; recs["mask"] = sm["info"][:, 0]; recs["n_edges"] = sm["info"][:, 1]; recs["n_verts"] = sm["info"][:, 2]
+    recs["pos"] = sm["pos"]; recs["grad"] = sm["grad"]; recs["vert"] = sm["vert"]
+    q = Q.check(recs, Q.per_vertex_counts(O.mdc_table))
+    assert q["vertices"] > 1000 and q["max_deviation_cell_fraction"] < _qef_bound(depth), q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,depth", [("gyroid-sphere.vm", 8), ("colonnade.vm", 8), ("bear.vm", 7), ("prospero.vm", 7)])
+def test_device_vertices_minimise_their_qef_by_an_independent_solve(model, depth, oracle_mod):
+    import fidget_amd as F
+    import qef_independent as Q
+    recs, _ = F.mesh_sample(F.Shape.from_vm(model_path(model)), depth)
+    q = Q.check(recs, Q.per_vertex_counts(oracle_mod.mdc_table))
+    print(model, depth, q)
+    assert q["vertices"] > 10000 and q["max_deviation_cell_fraction"] < _qef_bound(depth) and q["over_1e-4_of_a_cell"] == 0, q

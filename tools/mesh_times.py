@@ -40,6 +40,16 @@ for depth in depths:
               f"sha_device {sha(tris)}{sha(verts)} sha_oracle {sha(ot)}{sha(ov)}", flush=True)
         res[f"depth {depth}"].update(parity={"triangles_equal": te, "vertices_equal": ve}, cpu_s_per_build=t_cpu, cpu_build_s=t_build, cpu_threads=th)
         del oc, ot, ov
+        # ... and the vertices against a solve that is NOT the product's own arithmetic (tests/qef_independent.py: the QEFs accumulated
+        # from the device's leaf records as qef.rs does, solved by LAPACK's f64 SVD under qef.rs's rank rule), at depth 8 - the leaf
+        # records of a depth-10 build are 17 GB; the solve per vertex is the same code at any depth
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import qef_independent as Q
+        recs, _ = F.mesh_sample(shape, 8)
+        q = Q.check(recs, Q.per_vertex_counts(O.mdc_table))
+        print("qef_independent depth 8 " + json.dumps(q), flush=True)
+        res[f"depth {depth}"]["qef_independent_check"] = q
+        del recs
     del tris, verts
     if os.environ.get("MESH_TIMES_HOST_ASM"):      # the same build with the octree assembled on the host's threads (the round-2 path)
         with hip.options(mesh_device_assembly=0):
