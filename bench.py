@@ -280,8 +280,29 @@ def main():
                                 "note": "per-GPU work fixed, total work grows with N: listed for comparison, never `value`"}
         if rank == 0:
             partitions["frames"]["images_equal"] = bool((frames_recv == img_c[None]).all())
-        for k, f in (("columns", 1), ("blocks", 1), ("frames", world)):
-            partitions[k]["value"] = (n ** 3) * f / (partitions[k]["ms_per_step"] * 1e-3) / 1e6
+        # ... and what DOES shard: the same frame with the column-invariance short cuts off - every tile of every slab has
+        # a tape of its own, the leaf stage is 1.0 of its 1.5 ms - and a model whose tapes read z, both by blocks; rank 0's merge of frame k is
+        # queued behind its own block of frame k and before frame k + 1, the other ranks are a frame ahead by then
+        with hip.options(no_column_inv=1):
+            dt_bg = timed(step_blocks)
+            lat_bg = latency(step_blocks)
+            hip.sync()
+        partitions["blocks_general_path"] = {"ms_per_step": dt_bg / args.steps * 1e3, "frame_latency_ms": lat_bg, "scaling": "strong", "split": list(split),
+                                             "what": "prospero.vm, column-invariance short cuts off (what a model with z in every tape gets), octant blocks"}
+        zm = os.path.join(ROOT, "models", "colonnade.vm")
+        if os.path.exists(zm) and args.model == "prospero.vm":
+            zshape = F.Shape.from_vm(zm, hip=hip)
+
+            def step_blocks_z():
+                F.render3d(zshape, n, out=out, block=(rank, split))
+                gather_blocks(out, n, split, lambda a, b, d: F.merge_depth(a, b, d, hip=hip), dst=0)
+            dt_z = timed(step_blocks_z)
+            partitions["blocks_colonnade"] = {"ms_per_step": dt_z / args.steps * 1e3, "frame_latency_ms": latency(step_blocks_z), "scaling": "strong", "split": list(split),
+                                              "what": "colonnade.vm 1024^3 (reads z), octant blocks"}
+        step_blocks()
+        for k, f in (("columns", 1), ("blocks", 1), ("frames", world), ("blocks_general_path", 1), ("blocks_colonnade", 1)):
+            if k in partitions:
+                partitions[k]["value"] = (n ** 3) * f / (partitions[k]["ms_per_step"] * 1e-3) / 1e6
         # `value`: ONE frame sharded over the ranks - the north star's number - by the better of the two partitions
         if dt_c <= dt_b:
             dt, step, sharding, lat_default = dt_c, step_columns, "root-tile columns round-robin, 1 RCCL reduce", lat_c
@@ -420,6 +441,7 @@ def main():
         result["partitions"] = partitions
         result["collectives"] = direct_note
         result["per_rank"] = per_rank
+        result["predicted"] = predict_from_stages(per_rank, n, world, partitions)
 
     # ---- roofline: numerators from the device counters of the profiled frames themselves ----------------
     # HBM traffic per launch: rocprofv3 PMC passes of tools/profile_round.sh, committed under profiles/ (counters cannot be
@@ -584,6 +606,14 @@ def main():
         # of the column-invariance short cuts applies to it): ms per queued frame, the image against the oracle's at full size, and the
         # leaf stage's share as a roofline fraction (algorithmic bytes = 8 B x tape ops x passes of the frames' own device counters
         # + the output pixels, over the frame time: an upper bound of any kernel's fraction in that frame)
+        if args.model == "prospero.vm" and general:
+            try:
+                result["multi_gpu_predicted"] = {
+                    "what": "8 GPUs, octant split, predicted on ONE GPU: slowest of the 8 blocks rendered alone + xGMI gather + depth merge (bench.py predict_n8)",
+                    "headline": predict_n8(F, hip, torch, dev, fence, shape, n, False, lat_default),
+                    "general_path": predict_n8(F, hip, torch, dev, fence, shape, n, True, general["frame_latency_ms"])}
+            except Exception as e:      # noqa: BLE001
+                result["multi_gpu_predicted"] = {"error": repr(e)[:200]}
         if args.model == "prospero.vm":
             try:
                 result["c2_2d"] = side_config_2d(F, O, hip, torch, dev, fence, os.path.join(ROOT, "models", "prospero.vm"), 4096)
@@ -616,6 +646,65 @@ def main():
 
 
 TUNING_CAP = 64         # untimed frames beyond --warmup the library's arrangement tuner may take (3 windows of 16 queued frames; `tuning_frames` in the line says how many it took)
+XGMI_LINK_GBS = 64.0        # one direction of one xGMI link as a collective sees it (7 links x ~153 GB/s both ways per GPU, MI355X_MICROARCH.md; ~85 % of 76)
+
+
+def gather_ms(image_bytes, world):
+    """rank 0 receives every other rank's rectangle over that rank's own link (point-to-point fabric: the 1 / N shares arrive side by side)"""
+    return 0.0 if world < 2 else image_bytes / world / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.02
+
+
+def predict_from_stages(per_rank, n, world, partitions):
+    """N > 1: the frame time the ranks' own stage times predict - the slowest rank's coarse chain (as long on every rank as on one GPU: one wave
+    per parent whatever their number) + its share of the slab work, the gather of the 16-byte pixels over xGMI, the merge - next to the
+    measured step, so that a scaling curve can be read against the model"""
+    crit = max(per_rank, key=lambda q: q["coarse_chain_ms"] + q["slab_ms"])
+    g = gather_ms(n * n * 16, world)
+    render = crit["coarse_chain_ms"] + crit["slab_ms"]
+    return {"model": "slowest rank's (coarse chain + slab stages, kernel times of a frame alone) + gather + merge", "critical_rank": crit["rank"],
+            "render_ms": render, "coarse_chain_ms": crit["coarse_chain_ms"], "gather_ms": g, "merge_ms": crit.get("other_ms", 0.0),
+            "frame_alone_ms": render + g + crit.get("other_ms", 0.0),
+            "measured_frame_alone_ms": min(partitions[k]["frame_latency_ms"] for k in ("columns", "blocks")),
+            "measured_ms_per_step": min(partitions[k]["ms_per_step"] for k in ("columns", "blocks")),
+            "note": "queued frames overlap (the measured step is shorter than a frame alone); the coarse chain does not shrink with N"}
+
+
+def predict_n8(F, hip, torch, dev, fence, shape, n, no_inv, frame_alone_ms):
+    """N = 1: what eight GPUs would make of this frame under the north star's octant split, from THIS GPU - each of the 2 x 2 x 2 blocks
+    rendered alone (waited for), the slowest of them + the gather of the rectangles over xGMI + the depth merge of the two z halves on rank 0
+    (measured here on full-size halves).  A prediction, labelled as one: no 8-GPU node was available to the builder."""
+    split = (2, 2, 2)
+    out = torch.zeros((n, n, 4), dtype=torch.int32, device=dev)
+    blocks = []
+    ctx = hip.options(no_column_inv=1) if no_inv else hip.options()
+    with ctx:
+        for k in range(8):
+            for _ in range(3):
+                F.render3d(shape, n, out=out, block=(k, split))
+            ts = []
+            for _ in range(5):
+                fence()
+                t0 = time.perf_counter()
+                F.render3d(shape, n, out=out, block=(k, split))
+                torch.cuda.synchronize(dev)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            blocks.append(float(np.median(ts)))
+        hip.sync()
+    a, b = out.clone(), out.clone()
+    ts = []
+    for _ in range(7):
+        fence()
+        t0 = time.perf_counter()
+        F.merge_depth(a, b, n, hip=hip)
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    merge = float(np.median(ts))
+    g = gather_ms(n * n * 16, 8)
+    pred = max(blocks) + g + merge
+    return {"n_gpus": 8, "split": list(split), "one_gpu_frame_alone_ms": frame_alone_ms, "slowest_block_alone_ms": max(blocks), "fastest_block_alone_ms": min(blocks),
+            "gather_ms": g, "merge_ms": merge, "predicted_frame_alone_ms": pred, "predicted_speedup": frame_alone_ms / pred}
+
+
 def _queued_ms(step, fence, warm=60, frames=20):
     for _ in range(warm):      # (the library's arrangement tuner takes ~50 queued frames of a kind)
         step()
@@ -713,6 +802,12 @@ def compact_line(result):
         line["parity"] = result["parity"]
     if result.get("c3_bear"):
         line["c3_bear"] = {k: result["c3_bear"].get(k) for k in ("workload", "ms_per_frame", "depth_equal", "normals_bit_equal_fraction")}
+    if result.get("multi_gpu_predicted"):
+        mp = result["multi_gpu_predicted"]
+        line["multi_gpu_predicted"] = mp if "error" in mp else {k: ({kk: v[kk] for kk in ("one_gpu_frame_alone_ms", "slowest_block_alone_ms", "gather_ms", "merge_ms", "predicted_frame_alone_ms", "predicted_speedup")}
+                                                                    if isinstance(v, dict) else v[:90]) for k, v in mp.items()}
+    if result.get("predicted"):
+        line["predicted"] = {k: v for k, v in result["predicted"].items() if k not in ("model", "note")}
     for k in ("c2_2d", "c4z_colonnade"):
         if result.get(k):
             line[k] = {kk: (vv if kk != "roofline" else {q: vv[q] for q in ("bound", "achieved", "peak", "unit", "frac")}) for kk, vv in result[k].items()}
@@ -731,7 +826,7 @@ def compact_line(result):
         line["per_rank"] = result.get("per_rank")
     line = _rnd(line)
     # should the line still outgrow the limit (a long error text, 8 ranks of stage times): shed the optional objects, never the contract's
-    for k in ("per_rank", "c2_2d", "c4z_colonnade", "c3_bear", "c5_mesh", "parity", "roofline_timed_path"):
+    for k in ("per_rank", "multi_gpu_predicted", "c2_2d", "c4z_colonnade", "c3_bear", "c5_mesh", "parity", "roofline_timed_path"):
         if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT - 200:
             break
         line.pop(k, None)

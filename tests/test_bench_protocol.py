@@ -174,6 +174,12 @@ def test_bench_two_ranks_protocol(tmp_path, direct, world):
     assert ("DirectRccl" in r["collectives"]) if direct else ("torch.distributed" in r["collectives"])
     assert "roofline" not in r and "cpu_baseline" not in r         # rank 0 at N = 1 only
     # every rank's stage times of its share of a frame, gathered to rank 0
+    # round 6: what shards - the general path and a z-reading model by blocks - next to `value`, and the model the step can be read against
+    for k in ("blocks_general_path", "blocks_colonnade"):
+        assert p[k]["ms_per_step"] > 0 and p[k]["value"] > 0 and p[k]["scaling"] == "strong"
+    pr = r["predicted"]
+    assert {"critical_rank", "render_ms", "coarse_chain_ms", "gather_ms", "merge_ms", "frame_alone_ms", "measured_frame_alone_ms", "measured_ms_per_step"} <= set(pr)
+    assert 0 <= pr["critical_rank"] < world and pr["gather_ms"] > 0 and abs(pr["frame_alone_ms"] - (pr["render_ms"] + pr["gather_ms"] + pr["merge_ms"])) < 1e-3    # (the line's figures are rounded to 5 digits)
     assert [q["rank"] for q in r["per_rank"]] == list(range(world))
     assert all({"coarse_chain_ms", "slab_ms", "tile_stage_ms", "leaf_ms", "normals_ms"} <= set(q) for q in r["per_rank"])
     if world == 8:
