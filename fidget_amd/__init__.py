@@ -52,7 +52,7 @@ EXPORTS = [
     "fhip_ctx_create", "fhip_ctx_destroy", "fhip_ctx_trim", "fhip_ctx_reserve_arena", "fhip_libm_probe", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset", "fhip_ctx_set_option", "fhip_ctx_get_option",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_reg_tape", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
-    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
+    "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_vertices_ptr", "fhip_mesh_triangles_ptr", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
@@ -168,6 +168,7 @@ def lib():
             "fhip_mesh_counts": (None, [vp, vp]), "fhip_mesh_leaves": (None, [vp, vp]),
             "fhip_mesh_build": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(vp)]),
             "fhip_mesh_vertices": (None, [vp, vp]), "fhip_mesh_triangles": (None, [vp, vp]),
+            "fhip_mesh_vertices_ptr": (vp, [vp]), "fhip_mesh_triangles_ptr": (vp, [vp]),
             "fhip_mesh_sample_part": (i32, [vp, vp, u32, vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp)]),
             "fhip_mesh_part_bytes": (C.c_uint64, [vp]), "fhip_mesh_part_export": (None, [vp, vp]),
             "fhip_mesh_merge": (i32, [vp, vp, vp, u32, vp, C.POINTER(vp)]),
@@ -1019,6 +1020,25 @@ def libm_probe():
     return int(n), buf.value.decode()
 
 
+class _MeshHandle:
+    """owner of an fhip_mesh whose arrays numpy views borrow"""
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        if self.h:
+            lib().fhip_mesh_free(self.h)
+            self.h = None
+
+    def view(self, ptr, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if not n or not ptr:
+            return np.zeros(shape, dtype)
+        buf = (C.c_uint8 * n).from_address(ptr)
+        buf._owner = self           # (numpy keeps `buf` as the view's base, `buf` keeps the handle)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 def mesh(shape, depth, world_to_model=None, vars=None):
     """fidget_mesh::Octree::build(...).walk_dual(): (triangles [n, 3] uint64, vertices [m, 3] float32, counts)"""
     return mesh_sample(shape, depth, world_to_model, vars, _build=True)
@@ -1099,12 +1119,11 @@ def mesh_sample(shape, depth, world_to_model=None, vars=None, _build=False):
         assert int(c[4]) == MESH_LEAF.itemsize, (int(c[4]), MESH_LEAF.itemsize)
         counts = {"cells": int(c[0]), "full": int(c[1]), "empty": int(c[2]), "leaf_cells": int(c[3]), "levels": int(c[5])}
         if _build:
-            verts = np.zeros((int(c[6]), 3), np.float32)
-            tris = np.zeros((int(c[7]), 3), np.uint64)
-            if len(verts):
-                lib().fhip_mesh_vertices(h, _p(verts))
-            if len(tris):
-                lib().fhip_mesh_triangles(h, _p(tris))
+            # the arrays where the mesh holds them, no copy: numpy views whose base keeps the handle (freed with the last of them)
+            owner = _MeshHandle(h)
+            h = None
+            verts = owner.view(lib().fhip_mesh_vertices_ptr(owner.h), (int(c[6]), 3), np.float32)
+            tris = owner.view(lib().fhip_mesh_triangles_ptr(owner.h), (int(c[7]), 3), np.uint64)
             return tris, verts, counts
         leaves = np.zeros(int(c[3]), MESH_LEAF)
         if len(leaves):

@@ -1143,6 +1143,8 @@ void fhip_debug_walk_dual(const uint32_t* cells, uint64_t n_cells, const uint32_
 }
 void fhip_mesh_vertices(const fhip_mesh* m, float* out) { memcpy(out, m->vertices.data(), m->vertices.size() * 12); }
 void fhip_mesh_triangles(const fhip_mesh* m, uint64_t* out) { memcpy(out, m->triangles.data(), m->triangles.size() * 24); }
+const float* fhip_mesh_vertices_ptr(const fhip_mesh* m) { return (const float*)m->vertices.data(); }
+const uint64_t* fhip_mesh_triangles_ptr(const fhip_mesh* m) { return (const uint64_t*)m->triangles.data(); }
 void fhip_mesh_free(fhip_mesh* m) { delete m; }
 // out = {cells evaluated (= interval evaluations), Full, Empty, ambiguous cells at the leaf depth (= calls of leaf()), bytes per leaf record, levels}
 void fhip_mesh_counts(const fhip_mesh* m, uint64_t out[8]) {

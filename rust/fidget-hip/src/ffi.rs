@@ -94,6 +94,8 @@ extern "C" {
     pub fn fhip_mesh_counts(mesh: *const fhip_mesh, out: *mut u64);          // [6] vertices, [7] triangles
     pub fn fhip_mesh_vertices(mesh: *const fhip_mesh, out: *mut f32);
     pub fn fhip_mesh_triangles(mesh: *const fhip_mesh, out: *mut u64);
+    pub fn fhip_mesh_vertices_ptr(mesh: *const fhip_mesh) -> *const f32;       // the arrays where the mesh holds them (valid until fhip_mesh_free)
+    pub fn fhip_mesh_triangles_ptr(mesh: *const fhip_mesh) -> *const u64;
     pub fn fhip_mesh_free(mesh: *mut fhip_mesh);
     // the build sharded by the root's octants (Octree::build_inner_mt across GPUs): a part per process, merged in one
     pub fn fhip_mesh_sample_part(ctx: *mut fhip_ctx, tape: *const fhip_tape, depth: u32, world_to_model: *const f32, axis_slots: *const i32,
