@@ -24,7 +24,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libfidget_hip.so")
+LIB_PATH = os.environ.get("FHIP_LIB") or os.path.join(_CSRC, "libfidget_hip.so")     # (FHIP_LIB: a variant build, tools/build_lib_variant.py - A/B runs)
 _SOURCES = ["capi.hip", "capi_core.hpp", "capi_context.hpp", "capi_tapes.hpp", "capi_eval.hpp", "capi_render.hpp", "capi_effects.hpp", "capi_mesh.hpp", "capi_debug.hpp", "kernels.hip", "prune2.hip", "effects.hip", "mesh.hip", "mesh_qef.hpp", "mesh_collapse.hpp", "mesh_edges.hpp", "mesh_walk.hpp", "host_mesh.hpp", "dev_ops.hpp", "host_graph.hpp", "host_regtape.hpp", "render_state.h", "tape_format.h",
             "gen_interp.py", "gen_tiles.py", "gen_tilesv.py", "gen_normals.py", "gen_prune.py", "gen_ubench.py", "gen_trans.py", "trans_funcs.hip", "trans_libm.hpp", "offsets.cpp", "../../include/fidget_hip.h",
             "../../include/fidget_hip_debug.h"]
@@ -72,6 +72,8 @@ def build(force=False, verbose=False):
     interpreters (gen_interp.py -> .s -> code object, embedded in the library) and the HIP
     kernels + C ABI (capi.hip)."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    if os.environ.get("FHIP_LIB"):
+        return LIB_PATH         # (a variant built elsewhere: never rebuilt from here)
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     gen = os.path.join(_CSRC, "_gen")

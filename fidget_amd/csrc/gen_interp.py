@@ -1538,7 +1538,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_nop 3
 	s_mov_b64 {S_PEND}, vcc
 	s_cmp_eq_u64 {S_PEND}, 0
-	s_cbranch_scc1 .Lfh_columns_leaf_drain
+	s_cbranch_scc1 .Lfh_columns_nopending
 	s_mov_b32 {S_K}, 7
 	; does the tape read an input that changes along the column?  (tapes of up to 64 ops: the words are in v[60:61], lane = op)
 	s_mov_b32 {S_INV}, 0
@@ -1702,6 +1702,12 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_leaf_drain:
 	s_waitcnt lgkmcnt(0)                            ; an unused tape-head request may still be in flight
 	s_branch .Lfh_columns_leaf
+.Lfh_columns_nopending:
+	; no pixel of the footprint is pending for this leaf.  Column mode: nor will one be for the leaves behind it (depths only grow, the
+	; leaves' z only falls) - the wave is done
+	s_bitcmp1_b32 {S_WGY}, 20
+	s_cbranch_scc0 .Lfh_columns_leaf_drain
+	s_waitcnt vmcnt(0) lgkmcnt(0)                   ; (the next leaf's tape may be on its way)
 .Lfh_columns_blockend:
 	s_bitcmp1_b32 {S_WGY}, 28
 	s_cbranch_scc0 .Lfh_columns_block
