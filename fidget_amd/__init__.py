@@ -49,7 +49,7 @@ HIP_TILES_2D, HIP_TILES_3D = [128, 16], [128, 32, 8]
 VM_TILES_2D, VM_TILES_3D = [128, 32, 8], [128, 64, 32, 16, 8]
 
 EXPORTS = [
-    "fhip_ctx_create", "fhip_ctx_destroy", "fhip_ctx_trim", "fhip_ctx_reserve_arena", "fhip_libm_probe", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset", "fhip_ctx_set_option", "fhip_ctx_get_option",
+    "fhip_ctx_create", "fhip_ctx_destroy", "fhip_ctx_trim", "fhip_ctx_reserve_arena", "fhip_libm_probe", "fhip_last_error", "fhip_ctx_sync", "fhip_cancel", "fhip_cancel_reset", "fhip_cancel_watch", "fhip_ctx_set_option", "fhip_ctx_get_option",
     "fhip_tape_from_bytecode", "fhip_tape_free", "fhip_tape_len", "fhip_tape_reg_tape", "fhip_tape_choice_count", "fhip_tape_reg_count",
     "fhip_tape_var_count", "fhip_tape_output_count", "fhip_tape_ops", "fhip_simplify", "fhip_interval_eval",
     "fhip_point_eval", "fhip_float_eval", "fhip_grad_eval", "fhip_render2d", "fhip_render3d", "fhip_render3d_shard", "fhip_render3d_block", "fhip_merge_depth", "fhip_denoise_normals", "fhip_compute_ssao", "fhip_blur_ssao", "fhip_apply_shading", "fhip_to_rgba", "fhip_mesh_sample", "fhip_mesh_build", "fhip_mesh_vertices", "fhip_mesh_triangles", "fhip_mesh_vertices_ptr", "fhip_mesh_triangles_ptr", "fhip_mesh_free", "fhip_mesh_counts", "fhip_mesh_leaves", "fhip_mesh_sample_part", "fhip_mesh_part_bytes", "fhip_mesh_part_export", "fhip_mesh_merge",
@@ -145,7 +145,7 @@ def lib():
             "fhip_ctx_create": (i32, [i32, vp, C.POINTER(vp)]), "fhip_ctx_destroy": (None, [vp]),
             "fhip_libm_probe": (i32, [C.c_char_p, C.c_size_t]), "fhip_ctx_trim": (i32, [vp]), "fhip_ctx_reserve_arena": (i32, [vp, C.c_size_t]),
             "fhip_last_error": (C.c_char_p, [vp]), "fhip_ctx_sync": (i32, [vp]),
-            "fhip_cancel": (None, [vp]), "fhip_cancel_reset": (None, [vp]),
+            "fhip_cancel": (None, [vp]), "fhip_cancel_reset": (None, [vp]), "fhip_cancel_watch": (None, [vp, vp]),
             "fhip_ctx_set_option": (i32, [vp, C.c_char_p, i32]), "fhip_ctx_get_option": (i32, [vp, C.c_char_p, C.POINTER(i32)]),
             "fhip_tape_from_bytecode": (i32, [vp, vp, C.c_size_t, C.POINTER(vp)]), "fhip_tape_free": (None, [vp]),
             "fhip_tape_len": (u32, [vp]), "fhip_tape_reg_tape": (i32, [vp, u32, vp, u32, vp, u32, vp]), "fhip_tape_choice_count": (u32, [vp]), "fhip_tape_reg_count": (u32, [vp]),
@@ -242,6 +242,11 @@ class HipContext:
 
     def cancel(self):
         lib().fhip_cancel(self._h)
+
+    def cancel_watch(self, flag):
+        """fhip_cancel_watch: `flag` = a numpy uint8 array of one element the context reads beside its own flag (None: stop watching)"""
+        self._watched = flag          # (kept alive while it is watched)
+        lib().fhip_cancel_watch(self._h, None if flag is None else flag.ctypes.data_as(C.c_void_p))
 
     def cancel_reset(self):
         lib().fhip_cancel_reset(self._h)

@@ -203,6 +203,7 @@ fhip_status fhip_ctx_sync(fhip_ctx* c) {
 // thread reaches a frame a lane is queueing without touching the lanes' vector, which belongs to the render thread)
 void fhip_cancel(fhip_ctx* c) { c->cancelled.store(1); }
 void fhip_cancel_reset(fhip_ctx* c) { c->cancelled.store(0); }
+void fhip_cancel_watch(fhip_ctx* c, const void* flag) { c->watch.store((const volatile unsigned char*)flag); }
 // Device and pinned memory the context keeps between calls for speed alone - the mesher's leaf records (17 GB after one depth-10 build),
 // its landing area and host-side caches, the frame lanes (child contexts with buffers of their own) - given back.  The next call that
 // wants them makes them again.  Waits for the context's work first.

@@ -150,7 +150,14 @@ struct fhip_ctx : FrameBufs {
     // A frame lane (a child context) reads its PARENT's flag: fhip_cancel comes from another thread and must not walk `lanes`, which the
     // render thread grows, clears and frees (run_on_lane_, lanes_release); a parent outlives its lanes, so the pointer is always good.
     const std::atomic<int>* cancel_src = nullptr;
-    bool is_cancelled() const { return (cancel_src ? cancel_src : &cancelled)->load() != 0; }
+    // ... and a flag of the CALLER's, one byte, non-zero = cancel (fhip_cancel_watch): fidget_core::render::CancelToken is an Arc<AtomicBool>
+    // whose address its into_raw() hands out - the Rust crate passes it for the duration of a render, no watcher thread
+    std::atomic<const volatile unsigned char*> watch{nullptr};
+    bool is_cancelled() const {
+        if ((cancel_src ? cancel_src : &cancelled)->load() != 0) return true;
+        const volatile unsigned char* w = watch.load(std::memory_order_relaxed);
+        return w && *w != 0;
+    }
     DevBuf tmp_out, io_a, io_b, io_c, io_d, io_e;
     DevBuf sticky;      // one word: a queue overflow of ANY asynchronous frame since the last fhip_ctx_sync (k_finish3d latches it)
     struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } staging[8];   // pinned (upload_frame)
@@ -324,21 +331,38 @@ template <class... K> struct FhKArgs<void (*)(K...)> {
     static constexpr size_t bytes = (sizeof(K) + ... + 0) + 16 * sizeof...(K);      // (an upper bound with padding)
 };
 template <auto Kernel, class... A>
-static inline void fh_launch(int device, dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
+static inline void fh_launch(fhip_ctx* ctx, dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
     // (contexts live on their own threads: the handle of a (kernel, device) is looked up by whoever comes first, and by a second thread
-    // that comes at the same time - to the same value)
-    static std::atomic<hipFunction_t> fns[16];
-    static std::atomic<bool> no_handle{false};
-    hipFunction_t fn = fns[device & 15].load(std::memory_order_acquire);
-    if (!fn && !no_handle.load(std::memory_order_relaxed)) {
-        if (hipGetFuncBySymbol(&fn, (const void*)Kernel) != hipSuccess || !fn) { fn = nullptr; no_handle.store(true, std::memory_order_relaxed); (void)hipGetLastError(); }
-        else fns[device & 15].store(fn, std::memory_order_release);
+    // that comes at the same time - to the same value.  Per device: a handle, and whether the look-up failed THERE; devices beyond
+    // the table take the launch by symbol)
+    constexpr int MAXDEV = 64;
+    static std::atomic<hipFunction_t> fns[MAXDEV];
+    static std::atomic<bool> no_handle[MAXDEV];
+    const int device = ctx->device;
+    hipFunction_t fn = nullptr;
+    if (device >= 0 && device < MAXDEV) {
+        fn = fns[device].load(std::memory_order_acquire);
+        if (!fn && !no_handle[device].load(std::memory_order_relaxed)) {
+            if (hipGetFuncBySymbol(&fn, (const void*)Kernel) != hipSuccess || !fn) { fn = nullptr; no_handle[device].store(true, std::memory_order_relaxed); (void)hipGetLastError(); }
+            else fns[device].store(fn, std::memory_order_release);
+        }
     }
-    if (!fn) { hipLaunchKernelGGL(Kernel, g, b, lds, st, std::forward<A>(a)...); return; }
-    alignas(16) char buf[FhKArgs<decltype(Kernel)>::bytes];
-    size_t bytes = FhKArgs<decltype(Kernel)>::pack(buf, std::forward<A>(a)...);
-    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-    (void)hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, (unsigned)lds, st, nullptr, extra);
+    hipError_t e;
+    if (!fn) {
+        hipLaunchKernelGGL(Kernel, g, b, lds, st, std::forward<A>(a)...);
+        e = hipGetLastError();
+    } else {
+        alignas(16) char buf[FhKArgs<decltype(Kernel)>::bytes];
+        size_t bytes = FhKArgs<decltype(Kernel)>::pack(buf, std::forward<A>(a)...);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+        e = hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, (unsigned)lds, st, nullptr, extra);
+    }
+    if (e != hipSuccess) {       // (reported when the frame has been queued, as a failed assembly launch is: capi_tapes.hpp launch_asm)
+        ctx->launch_failed = true;
+        ctx->last_hip_error = (int)e;
+        if (ctx->err.empty()) ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+    }
 }
-#define FH_KLAUNCH(kernel, grid, block, lds, stream, ...) fh_launch<kernel>(ctx->device, grid, block, lds, stream, ##__VA_ARGS__)
+#define FH_KLAUNCH(kernel, grid, block, lds, stream, ...) fh_launch<kernel>(ctx, grid, block, lds, stream, ##__VA_ARGS__)
 

@@ -115,7 +115,7 @@ struct HostSpans {
         }
     }
 };
-static HostSpans g_spans;
+static thread_local HostSpans g_spans;      // (one context per thread: each thread's frames, not a mix)
 #define FH_SPAN(k) do { if (ctx->opt.stats & 2) g_spans.mark(k); } while (0)
 
 static void column_setup(fhip_ctx* ctx, const fhip_tape* tape, const FhRender& P, RenderSetup& R) {
@@ -1322,6 +1322,7 @@ static fhip_status run_on_lane_(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes,
     }
     fhip_ctx* const L = ctx->lanes[ctx->lane_next++ % K];
     L->cancel_src = &ctx->cancelled;
+    L->watch.store(ctx->watch.load(std::memory_order_relaxed), std::memory_order_relaxed);
     HIP_TRY(ctx, L->lane_img.ensure(bytes));
     if (L->lane_copied_valid) HIP_TRY(ctx, hipStreamWaitEvent(L->stream, L->lane_copied, 0));   // (its previous image has been copied out)
     const fhip_status st = render(L, L->lane_img.p);

@@ -69,6 +69,11 @@ int fhip_libm_probe(char* msg, size_t cap);
 /* render/config.rs:38-80: cooperative cancellation, honoured between kernel waves */
 void fhip_cancel(fhip_ctx* ctx);
 void fhip_cancel_reset(fhip_ctx* ctx);
+/* A cancel flag of the caller's - one byte, non-zero = cancel - that the context's checks read beside its own until fhip_cancel_watch(ctx,
+ * NULL): fidget_core::render::CancelToken (render/config.rs:38-78) is an Arc<AtomicBool> whose address into_raw() hands out, so the
+ * Rust crate passes the EvalConfig's token for the duration of a render (voxel.rs:52-61; its cancel_render test, voxel.rs:573-590) and
+ * a cancel from any thread ends the render with FHIP_ERR_CANCELLED.  The byte must stay valid while it is watched. */
+void fhip_cancel_watch(fhip_ctx* ctx, const void* flag);
 /* Behaviour switches of a context (the role of the reference's config structs - ThreadPool / TileSizes / RenderConfig carry
  * the reference's knobs; these carry the back end's own: which kernels, how many slab contexts, the column-invariance short
  * cuts ...).  A context reads FHIP_<NAME> from the environment ONCE, when it is created; afterwards only this call changes

@@ -41,6 +41,7 @@ extern "C" {
     pub fn fhip_last_error(ctx: *const fhip_ctx) -> *const c_char;
     pub fn fhip_cancel(ctx: *mut fhip_ctx);
     pub fn fhip_cancel_reset(ctx: *mut fhip_ctx);
+    pub fn fhip_cancel_watch(ctx: *mut fhip_ctx, flag: *const c_void);    // the caller's one-byte cancel flag (CancelToken::into_raw), null: none
     pub fn fhip_ctx_sync(ctx: *mut fhip_ctx) -> fhip_status;     // waits for the asynchronous renders, reports their overflow flags
     pub fn fhip_ctx_trim(ctx: *mut fhip_ctx) -> fhip_status;     // caches kept for speed alone (mesh leaf records, frame lanes) go back
     pub fn fhip_ctx_reserve_arena(ctx: *mut fhip_ctx, megabytes: usize) -> fhip_status;     // a sequence of heavier frames to come: arenas sized ahead

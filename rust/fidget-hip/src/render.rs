@@ -6,6 +6,24 @@ use fidget_raster::{pixel, voxel, voxel::GeometryPixel};
 
 use crate::{axis_slots, ffi, var_key, HipFunction, CTX};
 
+/// The EvalConfig's cancel token (voxel.rs:52-61) handed to the context for the duration of a render: the token is an Arc<AtomicBool>,
+/// `into_raw` gives the flag's address, the library's per-level checks read it beside the context's own flag (fhip_cancel_watch) - a cancel
+/// from any thread ends the render with `None`, as the reference's workers do.  Reclaimed when the guard drops.
+struct Watch(*const std::sync::atomic::AtomicBool);
+impl Watch {
+    fn new(token: &fidget_core::render::CancelToken) -> Self {
+        let raw = token.clone().into_raw();
+        CTX.with(|ctx| unsafe { ffi::fhip_cancel_watch(ctx.raw(), raw.cast()) });
+        Watch(raw)
+    }
+}
+impl Drop for Watch {
+    fn drop(&mut self) {
+        CTX.with(|ctx| unsafe { ffi::fhip_cancel_watch(ctx.raw(), std::ptr::null()) });
+        drop(unsafe { fidget_core::render::CancelToken::from_raw(self.0) });
+    }
+}
+
 fn bound_vars(b: &BoundShape<HipFunction, f32>) -> (Vec<u64>, Vec<f32>) {
     // ShapeVars<f32>: Var::V index -> value (shape/mod.rs:190-232); the keys the tape asks for are b.shape().inner().vars()'s
     let vars = b.vars();
@@ -43,6 +61,10 @@ pub fn render3d(
         axis_slots: axes.as_ptr(),
     };
     let mut out = voxel::Image::new(cfg.image_size); // repr(C) {normal: [f32; 3], depth: u32}: 16 B
+    if eval.cancel.is_cancelled() {
+        return None;
+    }
+    let _watch = Watch::new(&eval.cancel);
     let st = CTX.with(|ctx| unsafe { ffi::fhip_render3d(ctx.raw(), tape.raw(), &c, (&mut out[0] as *mut GeometryPixel).cast(), 0) });
     match st {
         0 => Some(out),
@@ -77,6 +99,10 @@ pub fn render2d(
         axis_slots: axes.as_ptr(),
     };
     let mut out = pixel::Image::new(cfg.image_size); // f32 bit patterns (pixel.rs:159-241)
+    if eval.cancel.is_cancelled() {
+        return None;
+    }
+    let _watch = Watch::new(&eval.cancel);
     let st = CTX.with(|ctx| unsafe { ffi::fhip_render2d(ctx.raw(), tape.raw(), &c, (&mut out[0] as *mut pixel::RawDistancePixel).cast(), 0) });
     match st {
         0 => Some(out),

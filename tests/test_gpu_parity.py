@@ -139,6 +139,31 @@ def test_cancel_token():
 
 
 @pytest.mark.gpu
+def test_cancel_flag_of_the_caller():
+    """fhip_cancel_watch: the context reads a one-byte flag of the caller's beside its own - fidget_core's CancelToken is an
+    Arc<AtomicBool> whose address the Rust crate passes for the duration of a render (rust/fidget-hip/src/render.rs Watch; voxel.rs:573-590
+    cancel_render).  Set: the render refuses; cleared, or no longer watched: it renders the oracle's image."""
+    hip = F.HipContext(0)
+    s = F.Shape.from_vm(model_path("hi.vm"), hip=hip)
+    flag = np.zeros(1, np.uint8)
+    hip.cancel_watch(flag)
+    want = O.render3d(O.Shape.from_vm(model_path("hi.vm")), 64)[0]
+    assert (F.render3d(s, 64)[0]["depth"] == want["depth"]).all()
+    flag[0] = 1
+    with pytest.raises(F.FidgetHipError) as e:
+        F.render3d(s, 64)
+    assert "cancel" in str(e.value).lower()
+    with pytest.raises(F.FidgetHipError):
+        F.render2d(s, 64)
+    hip.cancel_watch(None)
+    assert (F.render3d(s, 64)[0]["depth"] == want["depth"]).all()
+    hip.cancel_watch(flag)
+    flag[0] = 0
+    assert (F.render3d(s, 64)[0]["depth"] == want["depth"]).all()
+    hip.cancel_watch(None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("whd", [(200, 120, 300), (96, 256, 64), (33, 47, 129)])
 def test_render3d_non_cubic(whd):
     w, h, d = whd
