@@ -58,6 +58,9 @@ ISSUE_PEAK = 0.57              # wave-instructions per cycle per SIMD, measured 
 TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
 
 
+MESH_LEAF_BYTES = 528       # sizeof(FhMeshLeaf) = fidget_amd.MESH_LEAF.itemsize (tests/test_bench_protocol.py holds the two together)
+
+
 def parse_mesh_times(stdout, stderr):
     """What tools/mesh_times.py 10 (MESH_TIMES_REPS >= 2) printed -> the `c5_mesh` object, or None if it did not get through its builds"""
     import re
@@ -70,6 +73,13 @@ def parse_mesh_times(stdout, stderr):
           "s_per_build_inside_the_library": min(inside[1:]) if len(inside) >= 2 else None, "s_first_build": builds[0],
           "triangles": int(counts.group(1)) if counts else None, "vertices": int(counts.group(2)) if counts else None,
           "note": "wall time of fidget_amd.mesh (fhip_mesh_build + copying triangles and vertices out), best of the builds after the first of this size"}
+    # the leaf stage (corners, edge search through the bulk interpreter, gradients, QEF vertices): its leaf records are what the build moves
+    ls = [(float(m.group(1)), int(m.group(2))) for m in re.finditer(r"^fhip mesh depth 10: .*leaf kernel ([0-9.]+) s \((\d+) leaves\)", stderr, re.M)]
+    if len(ls) >= 2:
+        sec, leaves = min(ls[1:])
+        c5["roofline"] = {"bound": "hbm", "kernel": "leaf stage (k_mesh_leaf passes + fh_float_eval edge search)", "achieved": leaves * MESH_LEAF_BYTES / sec / 1e9, "peak": 8000.0,
+                          "unit": "GB/s", "frac": leaves * MESH_LEAF_BYTES / sec / 1e9 / 8000.0, "leaf_stage_s": sec, "leaves": leaves,
+                          "what": f"{MESH_LEAF_BYTES} B of leaf record written per ambiguous leaf cell over the leaf stage's time (the records go to pinned host memory in chunks while it runs)"}
     # MESH_TIMES_PARITY: the CPU oracle's multithreaded build (Octree::build_inner_mt restated) + walk_dual at the same depth, timed, and the
     # device mesh compared with it element for element
     par = re.search(r"^parity depth 10 triangles_equal (True|False) vertices_equal (True|False) cpu_s ([0-9.]+) cpu_build_s ([0-9.]+) threads (\d+) "
@@ -590,13 +600,25 @@ def main():
                 F.render3d(bs, m, out=bout)
             fence()
             bms = (time.perf_counter() - t0) / 20 * 1e3
+            hip.sync()
+            hip.profile(True)         # (one frame with the device's op counters: the leaf stage's algorithmic bytes)
+            F.render3d(bs, m, out=bout)
+            hip.profile_read()
+            hip.wave_stats()
+            bleaf = hip.leaf_stats()
+            hip.profile(False)
             a = bout.cpu().numpy().view(np.uint32).reshape(m, m, 4)
             b = O.render3d(bo, m)[0]
             an, bn = a[..., :3].view(np.float32), b["normal"]
             scale = np.maximum(np.abs(bn).max(axis=2, keepdims=True), 2.0 ** -100)
             with np.errstate(invalid="ignore"):
                 ulp = np.abs(an - bn) / (scale * 2.0 ** -23)
+            balg = 8.0 * bleaf["tape_words_read"] + 16.0 * m * m
             result["c3_bear"] = {"workload": f"bear.vm 3D heightmap+normals {m}^3", "ms_per_frame": bms, "depth_equal": bool((a[..., 3] == b["depth"]).all()),
+                                 "roofline": {"bound": "hbm", "achieved": balg / (bms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": balg / (bms * 1e-3) / 1e9 / 8000.0,
+                                              "lane_ops_per_s_T": bleaf["lane_ops"] / (bms * 1e-3) / 1e12,
+                                              "what": "leaf tape words x passes x 8 B + 16 B per pixel (device counters of one frame) over the frame time; its tapes' exp / ln / sin / cos "
+                                                      "are 45-60 instructions per sample (DESIGN.md section 4), which the lane-op rate counts as one"},
                                  "normal_max_ulp_of_gradient_scale": float(np.nanmax(ulp)), "normals_bit_equal_fraction": float((an.view(np.uint32) == bn.view(np.uint32)).mean()),
                                  "frames": "20 queued back to back on one stream; the library runs whole queued frames on child contexts in turn where that measures faster "
                                            "(option frame_lanes; " + str(hip.lane_frames()) + " frames of this context went that way)",
@@ -802,6 +824,8 @@ def compact_line(result):
         line["parity"] = result["parity"]
     if result.get("c3_bear"):
         line["c3_bear"] = {k: result["c3_bear"].get(k) for k in ("workload", "ms_per_frame", "depth_equal", "normals_bit_equal_fraction")}
+        if result["c3_bear"].get("roofline"):
+            line["c3_bear"]["roofline"] = {q: result["c3_bear"]["roofline"][q] for q in ("bound", "achieved", "peak", "unit", "frac")}
     if result.get("multi_gpu_predicted"):
         mp = result["multi_gpu_predicted"]
         line["multi_gpu_predicted"] = mp if "error" in mp else {k: ({kk: v[kk] for kk in ("one_gpu_frame_alone_ms", "slowest_block_alone_ms", "gather_ms", "merge_ms", "predicted_frame_alone_ms", "predicted_speedup")}
@@ -813,8 +837,8 @@ def compact_line(result):
             line[k] = {kk: (vv if kk != "roofline" else {q: vv[q] for q in ("bound", "achieved", "peak", "unit", "frac")}) for kk, vv in result[k].items()}
     if result.get("c5_mesh"):
         c5 = result["c5_mesh"]
-        line["c5_mesh"] = ({k: c5.get(k) for k in ("workload", "s_per_build", "s_per_build_inside_the_library", "triangles", "vertices",
-                                                    "parity", "cpu_s_per_build", "cpu_threads") if k in c5}
+        line["c5_mesh"] = ({k: (c5.get(k) if k != "roofline" else {q: c5[k][q] for q in ("bound", "kernel", "achieved", "peak", "unit", "frac")})
+                            for k in ("workload", "s_per_build", "s_per_build_inside_the_library", "triangles", "vertices", "parity", "cpu_s_per_build", "cpu_threads", "roofline") if k in c5}
                            if "error" not in c5 else {"error": str(c5["error"])[:200]})
     if result.get("partitions"):
         short = {}

@@ -198,6 +198,8 @@ def test_c5_mesh_leg_reads_the_mesh_tools_output():
     c5 = bench.parse_mesh_times(log, log)
     assert c5["triangles"] == 15050590 and c5["vertices"] == 7521871
     assert 1.0 < c5["s_per_build_inside_the_library"] < c5["s_per_build"] < c5["s_first_build"] < 2.0
+    import fidget_amd
+    assert bench.MESH_LEAF_BYTES == fidget_amd.MESH_LEAF.itemsize
     assert bench.parse_mesh_times("Traceback (most recent call last): ...", "") is None
     assert bench.parse_mesh_times("10 build 0 1.5\n", "") is None          # (one build only: nothing after the first)
 
