@@ -55,7 +55,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 78.6e12  # plain f32 VALU lane-operations per second: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (= the 157.3 TFLOP/s vector peak / 2 flops per FMA)
 ISSUE_PEAK = 0.57              # wave-instructions per cycle per SIMD, measured (see `issue.peak_note`)
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r06.json")
 
 
 MESH_LEAF_BYTES = 528       # sizeof(FhMeshLeaf) = fidget_amd.MESH_LEAF.itemsize (tests/test_bench_protocol.py holds the two together)
