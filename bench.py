@@ -210,7 +210,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     frame_ms = []
-    tuning = {"frames": 0, "last": None}
+    tuning = {"frames": 0, "last": None, "per_kind": []}
 
     def timed(step):
         import gc
@@ -218,9 +218,12 @@ def main():
             step()
         # (the library times the first ~50 queued frames of a kind under its two frame arrangements - stage pipeline, frame lanes - and keeps
         # the faster, capi_render.hpp lane_mode: those frames are warm-up too, counted in config.tuning_frames)
-        while world == 1 and tuning["frames"] < TUNING_CAP and 0 <= hip.lane_tune()["phase"] < 4:
+        mine = 0
+        while world == 1 and mine < TUNING_CAP and 0 <= hip.lane_tune()["phase"] < 4:       # (per kind of frame: an option change starts the tuner again)
             step()
-            tuning["frames"] += 1
+            mine += 1
+        tuning["frames"] += mine
+        tuning["per_kind"].append(mine)
         if world > 1:       # (every rank the same number of steps - there are collectives in them -, so a fixed count here: what the tuner takes, and a few)
             for _ in range(60):
                 step()
@@ -425,7 +428,7 @@ def main():
         "tuning_frames": tuning["frames"],
         "frame_latency_ms": lat_default,
         "device_bytes": device_bytes, "device_bytes_timed_path": bytes_default,
-        "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "last_measured": tuning["last"],
+        "frame_arrangement": {"untimed_frames_beyond_warmup": tuning["frames"], "per_kind": tuning["per_kind"], "last_measured": tuning["last"],
                               "note": "the library measures a run of queued frames of one kind under its stage pipeline and on its frame lanes and keeps the faster "
                                       "(DESIGN.md section 4); bench.py lets that finish before the timed frames"},
         "general": general,
@@ -667,7 +670,8 @@ def main():
         dist.destroy_process_group()
 
 
-TUNING_CAP = 64         # untimed frames beyond --warmup the library's arrangement tuner may take (3 windows of 16 queued frames; `tuning_frames` in the line says how many it took)
+TUNING_CAP = 50         # untimed frames beyond --warmup the library's arrangement tuner may take PER KIND of frame (3 windows of 12 queued frames + the verdict; `tuning_frames`
+                        # in the line is the sum over the kinds timed - default path, general path - and says how many it took)
 XGMI_LINK_GBS = 64.0        # one direction of one xGMI link as a collective sees it (7 links x ~153 GB/s both ways per GPU, MI355X_MICROARCH.md; ~85 % of 76)
 
 

@@ -1031,10 +1031,11 @@ class _MeshHandle:
     """owner of an fhip_mesh whose arrays numpy views borrow"""
     def __init__(self, h):
         self.h = h
+        self._free = lib().fhip_mesh_free      # (held here: at interpreter shutdown the module's globals may be gone before the last view)
 
     def __del__(self):
-        if self.h:
-            lib().fhip_mesh_free(self.h)
+        if self.h and self._free is not None:
+            self._free(self.h)
             self.h = None
 
     def view(self, ptr, shape, dtype):

@@ -1366,14 +1366,14 @@ static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, 
 // prospero.vm 1024^3 0.505 / 0.570 (0.540 with four), with the column short cuts off 1.625 / 1.73 - but 512^3 1.66 / 1.15, 2048^3 2.18 / 1.99,
 // colonnade.vm 1024^3 0.605 / 0.454, 512^3 0.334 / 0.248, bear.vm 512^3 1.84 / 1.37.  The stage pipeline wins where a frame's stages happen to be
 // of equal length, which is a property of the model AND the size; nothing the host knows before the frame predicts it.  So it is measured:
-// consecutive queued frames of one kind (tape, image size) run TUNE_WIN frames under the stage pipeline, TUNE_WIN on the lanes and TUNE_WIN
+// consecutive queued frames of one kind (tape, image size) run TUNE_SKIP + TUNE_WIN frames under the stage pipeline, as many on the lanes and as many
 // under the stage pipeline again (a burst of frames starts on a machine whose clocks are still coming up, which counted against whatever
 // was measured first: the general path's stage pipeline read 2.0 ms in the first window and runs at 1.63), each window timed between two
 // events on the caller's stream after TUNE_SKIP frames of settling; the lanes are kept if they beat the better of the two stage windows
 // by 3 %, for the life of the context (or until an option changes).  Frames that break the sequence - another kind, a frame alone - restart the
 // window, so a queue of mixed frames never decides and keeps the prior: lanes for tapes with transcendental opcodes, the stage pipeline
 // otherwise.  Both arrangements give the same image, bit for bit (tests/test_gpu_parity.py).
-static constexpr uint32_t TUNE_SKIP = 6, TUNE_WIN = 10;
+static constexpr uint32_t TUNE_SKIP = 4, TUNE_WIN = 8;       // (round 6: 36 frames to a verdict instead of 48 - a caller's first 50 queued frames of a kind, bench.py's cap)
 static void lane_tune_release(fhip_ctx* ctx) {
     for (auto& t : ctx->lane_tune)
         for (hipEvent_t& e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
