@@ -126,7 +126,8 @@ VT = [f"v{18 + j}" for j in range(8)]
 VU = [f"v{26 + j}" for j in range(8)]
 VW = [f"v{34 + j}" for j in range(8)]
 VD = [f"v{42 + i}" for i in range(8)]   # scratch of the division / sqrt sequences
-V_PINF, V_NINF = "v3", "v62"     # columns (threaded): +inf / -inf, the neutral first operand of v_minimum3_f32 / v_maximum3_f32 in the delta handlers
+V_PINF, V_NINF = "s55", "s60"    # columns (threaded): +inf / -inf, the neutral first operand of v_minimum3_f32 / v_maximum3_f32 in the delta handlers (scalar: src0 of a VOP3)
+V_LUT1, V_LUT2 = "v3", "v62"     # columns (threaded): decode tables, lane = opcode (LUT_BITS below) / lane = input slot (that INPUT op's handler offset); bit 30 of S_WGY: loaded
 S_ONES = "s[58:59]"              # columns (threaded): (1.0, 1.0)
 V_QNAN = "v50"
 V_SQRTC = "v51"
@@ -1128,77 +1129,87 @@ def handler_base(a, it):
 	s_addc_u32 s43, s43, 0""")
 
 
+def lut_bits(it, k):
+    """LUT1[opcode k] of the threaded decode: bits 3:0 family U's index + 1 (counted from the family's highest opcode, 0: not of the family),
+    7:4 family B's, 8 the op has an in-place form, 9 an RR form (word 1 names a register), 10 INPUT.  The same for every register class."""
+    if k >= len(OPS):
+        return 0
+    op = OPS[k]
+    def idx(fam):
+        order = sorted(fam, key=OPS.index, reverse=True)
+        return order.index(op) + 1 if op in fam else 0
+    return idx(Interp.U_OPS) | (idx(Interp.B_OPS) << 4) | ((op in Interp.INPLACE) << 8) | ((op.endswith("_RR")) << 9) | ((op == "INPUT") << 10)
+
+
 def emit_decode(a, it, inplace_mask):
     """threaded dispatch: the tape words in v[60:61], lane = op -> V_DEC: handler address (the in-place table when out == a and the
     op has such a form; a delta handler - Interp.handler_delta - when the two registers of the op are close enough; an INPUT of an axis
-    slot has a handler of its own), file indices out | a << 8, word 1 (the RR forms: b's file index).
+    slot has a handler of its own), file indices out | a << 8, word 1 (the RR forms: b's file index).  What depends on the opcode alone
+    comes out of V_LUT1 by ONE ds_bpermute_b32 (lut_bits), an INPUT op's handler out of V_LUT2 by another (76 -> 48 instructions per leaf).
     Clobbers v18 .. v33, vcc, s[90:97]."""
     lg, hl, n = it.lg, it.hl, it.name
-    def mask_of(ops):
-        m = 0
-        for o in ops:
-            m |= 1 << OPS.index(o)
-        return m
+    D, ND = it.dmax, it.nd
     a(f"""
-	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
-	s_mov_b32 s97, {hex(inplace_mask >> 32)}
 	v_and_b32 v18, 0xff, v60                          ; opcode
+	v_lshlrev_b32 v24, 2, v61
+	v_lshlrev_b32 v25, 2, v18
+	ds_bpermute_b32 v29, v24, {V_LUT2}               ; an INPUT op of this slot: its handler's offset
+	ds_bpermute_b32 v28, v25, {V_LUT1}               ; the opcode's bits
 	v_bfe_u32 v19, v60, 8, 12                         ; out
 	v_lshrrev_b32 v20, 20, v60                        ; a
-	v_cmp_eq_u32 vcc, v19, v20
-	v_lshrrev_b64 v[22:23], v18, s[96:97]
 	v_mov_b32 v63, v61
-	v_and_b32 v22, 1, v22
-	v_cndmask_b32 v22, 0, v22, vcc                   ; in place?
-	v_subrev_u32 v21, {OPS.index("ADD_RR")}, v18
 	v_lshlrev_b32 v23, {lg}, v61
-	v_cmp_gt_u32 vcc, {len(BIN)}, v21                ; an RR form: word 1 names a register
-	v_cmp_eq_u32_e64 {S_M[0]}, {OPS.index("INPUT")}, v18
 	v_lshlrev_b32 v26, {lg}, v19
-	v_cndmask_b32 v63, v63, v23, vcc
+	v_cmp_eq_u32_e64 {S_M[0]}, v19, v20               ; out == a
 	v_lshl_or_b32 v26, v20, {lg + 8}, v26            ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
 	v_lshlrev_b32 v27, {hl}, v18                      ; the handler's offset: generic table ...
-	v_add_u32 v28, {64 << hl}, v27                    ; ... in-place table
-	v_cmp_eq_u32 vcc, 1, v22
-	s_nop 1
-	v_cndmask_b32 v27, v27, v28, vcc""")
-    if it.dmax:
-        D, ND = it.dmax, it.nd
-        um, bm = mask_of(it.U_OPS), mask_of(it.B_OPS)
-        for fam, mask, sub, member, slot in (("U", um, "v_sub_u32 v21, v20, v19", "v_and_b32 v24, 1, v24", it.su),
-                                             ("B", bm, "v_sub_u32 v21, v61, v20", "v_and_b32 v24, v22, v24", it.sb)):
-            # family U (unary / register-immediate, out != a): distance a - out; family B (RR in place - v22: out == a and the op has an
-            # in-place form, as every op of the family has): distance b - a; within +-D and not 0
-            a(f"""
-	s_mov_b32 s96, {hex(mask & 0xffffffff)}
-	s_mov_b32 s97, {hex(mask >> 32)}
-	{sub}
-	v_lshrrev_b64 v[24:25], v18, s[96:97]
-	v_add_u32 v21, {D}, v21
+	v_add_u32 v30, {64 << hl}, v27                    ; ... in-place table""")
+    if D:
+        a(f"""
+	v_sub_u32 v21, v20, v19
+	v_sub_u32 v22, v61, v20
+	v_add_u32 v21, {D}, v21                           ; distance a - out + D (family U), b - a + D (family B)
+	v_add_u32 v22, {D}, v22
 	v_cmp_gt_u32_e64 {S_M[1]}, {ND}, v21
-	v_cmp_ne_u32_e64 {S_M[2]}, {D}, v21
-	v_bcnt_u32_b32 v23, v24, 0
-	v_bcnt_u32_b32 v23, v25, v23                      ; the family's opcodes at or above this one
-	{member}
-	s_and_b64 {S_M[1]}, {S_M[1]}, {S_M[2]}
-	v_subrev_u32 v23, 1, v23
-	v_mad_u32_u24 v23, v23, {ND}, v21
-	v_cmp_eq_u32 vcc, 1, v24
-	v_mul_u32_u24 v23, {slot}, v23
-	v_add_u32 v23, .L{n}_d{fam.lower()} - .L{n}_handlers, v23
-	s_and_b64 vcc, vcc, {S_M[1]}
-	v_cndmask_b32 v27, v27, v23, vcc""")
-    for k, sl in enumerate((S_SLOTX, S_SLOTY, S_SLOTZ)):
-        a(f"\tv_cmp_eq_u32_e64 {S_M[1 + k]}, {sl}, v61")
-    for k in range(3):
-        a(f"\ts_and_b64 {S_M[1 + k]}, {S_M[1 + k]}, {S_M[0]}")
-    a(f"\tv_mov_b32 v28, {52 << hl}")
-    for k in range(3):
-        a(f"\tv_cndmask_b32_e64 v27, v27, v28, {S_M[1 + k]}")
-        if k < 2:
-            a(f"\tv_add_u32 v28, {1 << hl}, v28")
+	v_cmp_gt_u32_e64 {S_M[2]}, {ND}, v22
+	v_cmp_ne_u32_e64 {S_M[3]}, {D}, v22""")
     a(f"""
+	s_waitcnt lgkmcnt(0)
+	v_bfe_u32 v31, v28, 8, 1                          ; has an in-place form
+	v_bfe_u32 v32, v28, 9, 1                          ; RR form
+	v_cmp_eq_u32 vcc, 1, v31
+	v_cmp_eq_u32_e64 {S_PC}, 1, v32
+	v_and_b32 v31, 15, v28                            ; family U: index + 1
+	s_and_b64 {S_M[0]}, {S_M[0]}, vcc                 ; in place: out == a and the op has the form
+	v_bfe_u32 v32, v28, 4, 4                          ; family B
+	v_cndmask_b32_e64 v63, v63, v23, {S_PC}           ; the RR forms: word 1 = b's file index
+	v_cndmask_b32_e64 v27, v27, v30, {S_M[0]}""")
+    if D:
+        a(f"""
+	v_mad_u32_u24 v33, v31, {ND}, v21
+	v_cmp_ne_u32 vcc, 0, v31
+	v_mul_u32_u24 v33, {it.su}, v33
+	s_and_b64 {S_M[1]}, {S_M[1]}, vcc
+	s_andn2_b64 {S_M[1]}, {S_M[1]}, {S_M[0]}          ; (U: not in place - which also says distance != 0 for the ops that have the form; the others: test below)
+	v_add_u32 v33, .L{n}_du - .L{n}_handlers - {ND * it.su}, v33
+	v_cmp_ne_u32 vcc, {D}, v21
+	v_mad_u32_u24 v31, v32, {ND}, v22
+	s_and_b64 {S_M[1]}, {S_M[1]}, vcc
+	v_cmp_ne_u32 vcc, 0, v32
+	v_mul_u32_u24 v31, {it.sb}, v31
+	v_cndmask_b32_e64 v27, v27, v33, {S_M[1]}
+	s_and_b64 {S_M[2]}, {S_M[2]}, vcc
+	s_and_b64 {S_M[2]}, {S_M[2]}, {S_M[3]}
+	v_add_u32 v31, .L{n}_db - .L{n}_handlers - {ND * it.sb}, v31
+	s_and_b64 {S_M[2]}, {S_M[2]}, {S_M[0]}            ; (B: in place)
+	s_nop 0
+	v_cndmask_b32_e64 v27, v27, v31, {S_M[2]}""")
+    a(f"""
+	v_bfe_u32 v32, v28, 10, 1                         ; INPUT
+	v_cmp_eq_u32 vcc, 1, v32
 	v_mov_b32 v61, v26
+	s_nop 0
+	v_cndmask_b32 v27, v27, v29, vcc
 	v_add_u32 v60, s42, v27""")
 
 
@@ -1252,8 +1263,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
     a(f"""
-	v_mov_b32 {V_PINF}, 0x7f800000
-	v_mov_b32 {V_NINF}, 0xff800000
+	s_mov_b32 {V_PINF}, 0x7f800000
+	s_mov_b32 {V_NINF}, 0xff800000
 	s_mov_b32 s58, 1.0
 	s_mov_b32 s59, 1.0
 	s_waitcnt lgkmcnt(0)
@@ -1450,6 +1461,28 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .Lfh_columns_longtape:
 	{"s_nop 0" if its[0].threaded else f"s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0"}      ; (threaded dispatch: a long tape is fetched and decoded 63 ops at a time, per pass)
 .Lfh_columns_taperequested:
+	; the decode's tables, once per wave (bit 30): lane = opcode -> its bits (LUT_BITS; a table behind the kernel), lane = input slot -> the
+	; handler offset of an INPUT op of that slot (the axes' slots have handlers of their own)
+	s_bitcmp1_b32 {S_WGY}, 30
+	s_cbranch_scc1 .Lfh_columns_luts
+	s_getpc_b64 {S_PC}
+.Lfh_columns_lutpc:
+	s_add_u32 s86, s86, .L{kname}_lut - .Lfh_columns_lutpc
+	s_addc_u32 s87, s87, 0
+	v_lshlrev_b32 {V_S4}, 2, {V_LANE}
+	global_load_dword {V_LUT1}, {V_S4}, {S_PC}
+	v_mov_b32 {V_LUT2}, {OPS.index("INPUT") << its[0].hl}
+	v_mov_b32 v18, {52 << its[0].hl}
+	v_cmp_eq_u32_e64 {S_M[0]}, {S_SLOTX}, {V_LANE}
+	v_cmp_eq_u32_e64 {S_M[1]}, {S_SLOTY}, {V_LANE}
+	v_cmp_eq_u32_e64 {S_M[2]}, {S_SLOTZ}, {V_LANE}
+	v_mov_b32 v19, {53 << its[0].hl}
+	v_mov_b32 v20, {54 << its[0].hl}
+	v_cndmask_b32_e64 {V_LUT2}, {V_LUT2}, v18, {S_M[0]}
+	v_cndmask_b32_e64 {V_LUT2}, {V_LUT2}, v19, {S_M[1]}
+	v_cndmask_b32_e64 {V_LUT2}, {V_LUT2}, v20, {S_M[2]}
+	s_bitset1_b32 {S_WGY}, 30
+.Lfh_columns_luts:
 	; pixel of this lane, its z-buffer word.  Column mode: every leaf of the wave has the same footprint - the pixel, its matrix
 	; products and its z-buffer word are set up once (bit 28), hits stay in the lane's registers from leaf to leaf (a pixel hit by a
 	; nearer leaf of the wave is not pending for the next) and go to the z-buffer once, behind the wave's last leaf.
@@ -1730,6 +1763,9 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_branch .Lfh_columns_block
 .Lfh_columns_exit:""")
     kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
+    a(f"\t.p2align 8\n.L{kname}_lut:")
+    for k in range(64):
+        a(f"\t.long {lut_bits(its[0], k)}")
     if trans:
         import gen_trans
         gen_trans.embed(a, trans, v_base=t_base, wide=True)

@@ -74,6 +74,19 @@ class Program:
         txt = subprocess.check_output([objdump, "-d", co_path], text=True)
         self.insts = {}
         self.symbols = {}
+        # the .text section's bytes at their addresses: kernels read tables that lie between them (PC-relative global loads)
+        self.text_base, self.text = 0, np.zeros(0, dtype=np.uint8)
+        try:
+            import tempfile
+            for line in subprocess.check_output([objdump, "-h", co_path], text=True).split("\n"):
+                f = line.split()
+                if len(f) >= 4 and f[1] == ".text":
+                    self.text_base = int(f[3], 16)
+            with tempfile.NamedTemporaryFile(suffix=".bin") as tf:
+                subprocess.check_call([objdump.replace("llvm-objdump", "llvm-objcopy"), "-O", "binary", "-j", ".text", co_path, tf.name])
+                self.text = np.fromfile(tf.name, dtype=np.uint8)
+        except Exception:       # noqa: BLE001  (a kernel that reads its code segment then fails with "outside every buffer")
+            pass
         for line in txt.split("\n"):
             m = re.match(r"^([0-9a-f]{16}) <([^>]+)>:", line)
             if m:
@@ -1392,6 +1405,17 @@ class Wave:
             else:
                 self.lds[ad:ad + nbytes] = self.v[r[0]:r[0] + width, ln].copy().view(np.uint8)
 
+    def i_ds_bpermute_b32(self, i, d, a, b):
+        """dst[lane] = src[(addr[lane] >> 2) & 63] for the active lanes (no LDS memory involved; a disabled source lane reads as 0)"""
+        self.count("lds")
+        addr = self.v[self._vreg(a)[0]].astype(np.int64) + i.mods.get("offset", 0)
+        src = self.v[self._vreg(b)[0]]
+        m = self._bits(self.exec)
+        lane = (addr >> 2) & 63
+        vals = np.where(m[lane], src[lane], 0).astype(U32)
+        self.lgkm_pending = getattr(self, "lgkm_pending", 0)
+        self.vdst(d, vals)
+
     def i_ds_read_b32(self, i, d, a):
         self._ds_read(i, d, a, 4, 1)
 
@@ -1546,6 +1570,8 @@ def launch(prog, mem, kernel, kernarg_bytes, n_workgroups=1, grid_y=1, lds_bytes
     Conventions of the interpreters: s[0:1] = kernarg segment, s2 = workgroup id x, s3 = workgroup id y (when enabled), v0 = lane id.
     Returns the list of waves (for their counters)."""
     ka = mem.map(np.frombuffer(bytes(kernarg_bytes) + b"\0" * 64, dtype=np.uint8).copy(), "kernarg")
+    if len(prog.text) and not any(name == ".text" for _, _, _, name in mem.bufs):
+        mem.bufs.append((prog.text_base, prog.text_base + len(prog.text), prog.text, ".text"))
     waves = []
     for y in range(grid_y):
         for x in range(n_workgroups):
