@@ -143,6 +143,33 @@ FILE = 64
 
 SRC0, SRC1, SRC2, DST = 1, 2, 4, 8
 
+# Two maps of the leaf kernels' vector registers.  The default (above): 64 fixed registers + a file from v64 - the bulk kernels, the
+# normals kernels and fh_columns_t (file of 128 + the routines' window).  COMPACT (fh_columns, round 6): 48 fixed + a file of 80 from v48 =
+# 128 registers, four waves per SIMD as before, but the file holds TEN registers of eight voxels: leaves of 9 and 10 registers (12 % of
+# prospero.vm's, a quarter of the kernel's dispatches) take one pass instead of two of four voxels.  The sixteen registers come from
+# VRES and VW: the OUTPUT handler leaves the result in VT, and the handlers that built a result in VW build it in place over their
+# first operand (VW is VT here - the places where that needed another order of instructions test `VW is VT`).
+_MAPS = {
+    "default": dict(FILE=64, VRES=[f"v{10 + j}" for j in range(8)], VT=[f"v{18 + j}" for j in range(8)], VU=[f"v{26 + j}" for j in range(8)],
+                    VW=[f"v{34 + j}" for j in range(8)], VD=[f"v{42 + i}" for i in range(8)], V_QNAN="v50", V_SQRTC="v51", V_NXT=("v52", "v53"),
+                    V_ENT=("v54", "v55", "v56", "v57"), V_IDV="v58", V_AZ="v59", V_DEC=["v60", "v61", "v62", "v63"], V_LUT1="v3", V_LUT2="v62"),
+    "compact": dict(FILE=48, V_QNAN="v38", V_SQRTC="v39", V_NXT=("v14", "v15"), V_ENT=("v34", "v35", "v36", "v37"), V_IDV="v16", V_AZ="v17",
+                    V_DEC=["v10", "v11", "v13", "v12"], V_LUT1="v3", V_LUT2="v13", VD=[f"v{42 + i}" for i in range(6)] + ["v40", "v41"]),
+}
+
+
+def set_reg_map(name):
+    g = globals()
+    m = dict(_MAPS["default"])
+    m.update(_MAPS[name])
+    if name == "compact":
+        m["VRES"] = m["VW"] = m["VT"]
+    g.update(m)
+    g["REG_MAP"] = name
+
+
+REG_MAP = "default"
+
 
 class Asm:
     def __init__(self):
@@ -183,7 +210,7 @@ class Interp:
         # three decoded words out of the lane that holds it (behind its own vector work in the pipeline: the v_readlane -> scalar use
         # latency, which was a third of a lone wave's time per op, is off the critical path) and ends with ONE jump, straight into the
         # next op's handler.  This op's words were read by the handler before it, into S_NX / S_JN.
-        self.threaded = kind == "columns" and EXP != "oldinterp"
+        self.threaded = kind == "columns"
         self.s_out = S_W0 if self.threaded else S_OUT     # bits 7:0: file index of `out` (threaded: word 0 of S_CUR is out | a << 8)
         self.s_a = S_A                                    # file index of `a` (threaded: handlers that need it shift it out of s_out)
         if self.threaded:
@@ -359,8 +386,17 @@ class Interp:
             a(f"\t{'v_minimum3_f32' if is_min else 'v_maximum3_f32'} {R[j]}, {A[j]}, {B[j]}, {B[j]}")
         a(f"\ts_branch {done}\n{slow}:")
         cmp = "v_cmp_lt_f32_e64" if is_min else "v_cmp_gt_f32_e64"
-        self.mask_pass(lambda j, m: f"{cmp} {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {m}")
-        self.mask_pass(lambda j, m: f"v_cmp_u_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {m}")
+        if R is A or R is B:        # (the compact register map: both tests of a sample before its selects)
+            for j in range(self.zb):
+                a(f"""
+	{cmp} {S_M[0]}, {A[j]}, {B[j]}
+	v_cmp_u_f32_e64 {S_M[1]}, {A[j]}, {B[j]}
+	s_nop 1
+	v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {S_M[0]}
+	v_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {S_M[1]}""")
+        else:
+            self.mask_pass(lambda j, m: f"{cmp} {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {B[j]}, {A[j]}, {m}")
+            self.mask_pass(lambda j, m: f"v_cmp_u_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, {V_QNAN}, {m}")
         a(f"{done}:")
 
     def f_andor(self, is_and, A, B, R):
@@ -370,6 +406,17 @@ class Interp:
 
     def f_compare(self, A, B, R):
         # a < b ? -1 : (a == b ? 0 : (a > b ? 1 : NaN))
+        if R is A or R is B:        # (the compact register map: the result over an operand - a sample's three tests before its selects)
+            for j in range(self.zb):
+                self.a(f"""
+	v_cmp_gt_f32_e64 {S_M[0]}, {A[j]}, {B[j]}
+	v_cmp_eq_f32_e64 {S_M[1]}, {A[j]}, {B[j]}
+	v_cmp_lt_f32_e64 {S_M[2]}, {A[j]}, {B[j]}
+	v_cndmask_b32_e64 {R[j]}, {V_QNAN}, 1.0, {S_M[0]}
+	s_nop 0
+	v_cndmask_b32_e64 {R[j]}, {R[j]}, 0, {S_M[1]}
+	v_cndmask_b32_e64 {R[j]}, {R[j]}, -1.0, {S_M[2]}""")
+            return
         self.mask_pass(lambda j, m: f"v_cmp_gt_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {V_QNAN}, 1.0, {m}")
         self.mask_pass(lambda j, m: f"v_cmp_eq_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, 0, {m}")
         self.mask_pass(lambda j, m: f"v_cmp_lt_f32_e64 {m}, {A[j]}, {B[j]}", lambda j, m: f"v_cndmask_b32_e64 {R[j]}, {R[j]}, -1.0, {m}")
@@ -640,7 +687,7 @@ class Interp:
                 self.mm_slow[base] = slow
                 self.read_b(VU, already_on=False)
                 self.idx_on(s_ip, SRC1 | SRC2)      # a's samples relative, plain destination: is one of them a zero?
-                self.zero_guard([F(j) for j in Z], VW[0])
+                self.zero_guard([F(j) for j in Z], VD[7])
                 self.idx_on(s_ip, SRC1 | SRC2 | DST)
                 a(f"\ts_cbranch_vccnz {slow}")
                 for j in Z:
@@ -811,15 +858,20 @@ class Interp:
             if j + 1 < self.zb:
                 a(f"\ts_sub_u32 {S_T0}, {S_T0}, 1")
         a(f"\ts_mov_b32 s96, s{m + 14}\n\ts_mov_b32 s97, s{m + 15}")
-        a(f"\tv_mov_b32 {VW[0]}, {V_AW}")
+        awp = VD[6:8] if VW is VT else VW          # (an aligned pair whose low half holds m[12] x + m[13] y)
+        a(f"\tv_mov_b32 {awp[0]}, {V_AW}")
         for k in range(self.zb // 2):
             a(f"\tv_pk_mul_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel_hi:[1,0]")
         for k in range(self.zb // 2):
-            a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, {self.P(VW, 0)} op_sel_hi:[1,0]")
+            a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, {self.P(awp, 0)} op_sel_hi:[1,0]")
         for k in range(self.zb // 2):
             a(f"\tv_pk_add_f32 {self.P(VU, k)}, {self.P(VU, k)}, s[96:97] op_sel:[0,1] op_sel_hi:[1,1]")
-        self.f_div(VT, VU, VW)
-        self.mask_pass(lambda j, mk: f"v_cmp_neq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VT[j]}, {VT[j]}, {VW[j]}, {mk}")
+        if VW is VT:        # the compact map: the quotient over the dividend - w == 0 keeps the row value: divided by 1.0 instead, which is exact
+            self.mask_pass(lambda j, mk: f"v_cmp_eq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VU[j]}, {VU[j]}, 1.0, {mk}")
+            self.f_div(VT, VU, VT)
+        else:
+            self.f_div(VT, VU, VW)
+            self.mask_pass(lambda j, mk: f"v_cmp_neq_f32_e64 {mk}, 0, {VU[j]}", lambda j, mk: f"v_cndmask_b32_e64 {VT[j]}, {VT[j]}, {VW[j]}, {mk}")
         self.write_out(VT, done=False)
         a(f"{done}:")
 
@@ -944,7 +996,8 @@ class Interp:
     def delta_setup(self):
         # (not in the kernel for tapes with transcendental opcodes: their leaves are hundreds of ops of mostly other kinds, and the longer
         # decode cost bear.vm 1.4 % where prospero.vm's leaf kernel gained 3 %)
-        self.dmax = min(self.nr - 1, 7) if (self.threaded and self.zb >= 4 and not self.trans and EXP != "nodelta") else 0
+        # (... and the read operand's encoded number, file + distance * ZB, must not fall below v0: the compact map's file starts at v48)
+        self.dmax = min(self.nr - 1, 7, FILE // self.zb) if (self.threaded and self.zb >= 4 and not self.trans and EXP != "nodelta") else 0
         self.nd = 2 * self.dmax + 1
         self.su = {8: 80, 4: 64}.get(self.zb, 0)       # slot bytes of family U / B
         self.sb = {8: 160, 4: 112}.get(self.zb, 0)
@@ -988,7 +1041,7 @@ class Interp:
         # min / max in place, b at a distance: see the in-place handler; the neutral first operand (+inf / -inf) keeps src0 plain
         slow = a.label("mmd_zero")
         self.idx_on(self.s_out, SRC1 | SRC2)
-        self.zero_guard([self.F(j) for j in Z], VW[0])
+        self.zero_guard([self.F(j) for j in Z], VD[7])
         self.idx_on(self.s_out, SRC1 | SRC2 | DST)
         a(f"\ts_cbranch_vccnz {slow}")
         for j in Z:
@@ -1150,15 +1203,15 @@ def emit_decode(a, it, inplace_mask):
     lg, hl, n = it.lg, it.hl, it.name
     D, ND = it.dmax, it.nd
     a(f"""
-	v_and_b32 v18, 0xff, v60                          ; opcode
-	v_lshlrev_b32 v24, 2, v61
+	v_and_b32 v18, 0xff, {V_DEC[0]}                          ; opcode
+	v_lshlrev_b32 v24, 2, {V_DEC[1]}
 	v_lshlrev_b32 v25, 2, v18
 	ds_bpermute_b32 v29, v24, {V_LUT2}               ; an INPUT op of this slot: its handler's offset
 	ds_bpermute_b32 v28, v25, {V_LUT1}               ; the opcode's bits
-	v_bfe_u32 v19, v60, 8, 12                         ; out
-	v_lshrrev_b32 v20, 20, v60                        ; a
-	v_mov_b32 v63, v61
-	v_lshlrev_b32 v23, {lg}, v61
+	v_bfe_u32 v19, {V_DEC[0]}, 8, 12                         ; out
+	v_lshrrev_b32 v20, 20, {V_DEC[0]}                        ; a
+	v_mov_b32 {V_DEC[3]}, {V_DEC[1]}
+	v_lshlrev_b32 v23, {lg}, {V_DEC[1]}
 	v_lshlrev_b32 v26, {lg}, v19
 	v_cmp_eq_u32_e64 {S_M[0]}, v19, v20               ; out == a
 	v_lshl_or_b32 v26, v20, {lg + 8}, v26            ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
@@ -1167,7 +1220,7 @@ def emit_decode(a, it, inplace_mask):
     if D:
         a(f"""
 	v_sub_u32 v21, v20, v19
-	v_sub_u32 v22, v61, v20
+	v_sub_u32 v22, {V_DEC[1]}, v20
 	v_add_u32 v21, {D}, v21                           ; distance a - out + D (family U), b - a + D (family B)
 	v_add_u32 v22, {D}, v22
 	v_cmp_gt_u32_e64 {S_M[1]}, {ND}, v21
@@ -1182,7 +1235,7 @@ def emit_decode(a, it, inplace_mask):
 	v_and_b32 v31, 15, v28                            ; family U: index + 1
 	s_and_b64 {S_M[0]}, {S_M[0]}, vcc                 ; in place: out == a and the op has the form
 	v_bfe_u32 v32, v28, 4, 4                          ; family B
-	v_cndmask_b32_e64 v63, v63, v23, {S_PC}           ; the RR forms: word 1 = b's file index
+	v_cndmask_b32_e64 {V_DEC[3]}, {V_DEC[3]}, v23, {S_PC}           ; the RR forms: word 1 = b's file index
 	v_cndmask_b32_e64 v27, v27, v30, {S_M[0]}""")
     if D:
         a(f"""
@@ -1207,10 +1260,10 @@ def emit_decode(a, it, inplace_mask):
     a(f"""
 	v_bfe_u32 v32, v28, 10, 1                         ; INPUT
 	v_cmp_eq_u32 vcc, 1, v32
-	v_mov_b32 v61, v26
+	v_mov_b32 {V_DEC[1]}, v26
 	s_nop 0
 	v_cndmask_b32 v27, v27, v29, vcc
-	v_add_u32 v60, s42, v27""")
+	v_add_u32 {V_DEC[0]}, s42, v27""")
 
 
 def gen_columns(a, variants, off, trans=None):
@@ -1228,7 +1281,11 @@ def gen_columns(a, variants, off, trans=None):
         r = _gen_columns_body(b, variants, off, kname, trans)
         a(b.text().replace(".Lfh_columns_", ".Lfh_columns_t_"))
         return r
-    return _gen_columns_body(a, variants, off, kname, None)
+    set_reg_map("default" if EXP == "file64" else "compact")
+    try:
+        return _gen_columns_body(a, variants, off, kname, None)
+    finally:
+        set_reg_map("default")
 
 
 def _gen_columns_body(a, variants, off, kname, trans):
@@ -1446,8 +1503,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	; (in flight: the requested tape and, if the last leaf had hits, its z-buffer atomic - loads and atomics complete in no
 	; particular order with each other, so both are waited for)
 	s_waitcnt vmcnt(0)
-	v_mov_b32 v60, {V_NXT[0]}
-	v_mov_b32 v61, {V_NXT[1]}
+	v_mov_b32 {V_DEC[0]}, {V_NXT[0]}
+	v_mov_b32 {V_DEC[1]}, {V_NXT[1]}
 	s_branch .Lfh_columns_taperequested
 .Lfh_columns_request:
 	s_cmp_gt_u32 {S_LEN0}, 64
@@ -1455,11 +1512,11 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	v_lshlrev_b32 {V_S3}, 3, {V_LANE}
 	s_sub_u32 {S_T0}, 64, {S_LEN0}
 	s_lshr_b64 exec, -1, {S_T0}
-	global_load_dwordx2 v[60:61], {V_S3}, {S_TBASE}
+	global_load_dwordx2 v[{V_DEC[0][1:]}:{V_DEC[1][1:]}], {V_S3}, {S_TBASE}
 	s_mov_b64 exec, -1
 	s_branch .Lfh_columns_taperequested
 .Lfh_columns_longtape:
-	{"s_nop 0" if its[0].threaded else f"s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0"}      ; (threaded dispatch: a long tape is fetched and decoded 63 ops at a time, per pass)
+	s_nop 0                                         ; (a long tape is fetched and decoded 63 ops at a time, per pass)
 .Lfh_columns_taperequested:
 	; the decode's tables, once per wave (bit 30): lane = opcode -> its bits (LUT_BITS; a table behind the kernel), lane = input slot -> the
 	; handler offset of an INPUT op of that slot (the axes' slots have handlers of their own)
@@ -1569,8 +1626,8 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_INV}, 0
 	s_cmp_gt_u32 {S_LEN0}, 64
 	s_cbranch_scc1 .Lfh_columns_zdep
-	v_and_b32 v18, 0xff, v60
-	v_lshrrev_b32_e64 v19, v61, {S_DEPMASK}
+	v_and_b32 v18, 0xff, {V_DEC[0]}
+	v_lshrrev_b32_e64 v19, {V_DEC[1]}, {S_DEPMASK}
 	v_and_b32 v19, 1, v19
 	v_cmp_eq_u32 vcc, {OPS.index("INPUT")}, v18
 	v_cmp_eq_u32_e64 {S_M[1]}, 1, v19
@@ -1595,7 +1652,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 .L{name}_hb:
 	s_add_u32 s42, s42, .L{name}_handlers - .L{name}_hb
 	s_addc_u32 s43, s43, 0""")
-        if it.threaded:
+        if True:       # (threaded dispatch: the only form of the leaf kernel)
             ret, here = a.label("ret"), a.label("pc")
             a(f"""
 	s_cmp_gt_u32 {S_LEN0}, 64
@@ -1626,7 +1683,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_sub_u32 {S_T0}, 64, {S_T0}
 	v_lshlrev_b32 {V_S3}, 3, {V_LANE}
 	s_lshr_b64 exec, -1, {S_T0}
-	global_load_dwordx2 v[60:61], {V_S3}, {S_TCUR}
+	global_load_dwordx2 v[{V_DEC[0][1:]}:{V_DEC[1][1:]}], {V_S3}, {S_TCUR}
 	s_mov_b64 exec, -1
 	s_waitcnt vmcnt(0)""")
             emit_decode(a, it, inplace_mask)
@@ -1649,52 +1706,6 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_LEN}, 1
 	s_setpc_b64 {S_JN}
 {ret}:""")
-        else:
-            a(f"""
-    	s_cmp_gt_u32 {S_LEN0}, 64
-    	s_cbranch_scc1 .L{name}_pass
-    	; decode the tape, lane = op: handler address (in-place variant when out == a and the op has one), file
-    	; indices of out and a; word 1 stays as it is
-    	s_mov_b32 s96, {hex(inplace_mask & 0xffffffff)}
-    	s_mov_b32 s97, {hex(inplace_mask >> 32)}
-    	v_and_b32 v18, 0xff, v60
-    	v_bfe_u32 v19, v60, 8, 12
-    	v_lshrrev_b32 v20, 20, v60
-    	v_cmp_eq_u32 vcc, v19, v20
-    	v_lshrrev_b64 v[22:23], v18, s[96:97]
-    	v_mov_b32 v63, v61
-    	v_and_b32 v22, 1, v22
-    	v_cndmask_b32 v22, 0, v22, vcc
-    	v_lshlrev_b32 v61, {it.lg}, v19
-    	v_lshl_or_b32 v22, v22, 6, v18
-    	v_lshl_or_b32 v61, v20, {it.lg + 8}, v61          ; file index of out | of a << 8 (each < 256: s_set_gpr_idx_on takes bits 7:0)
-    	v_lshlrev_b32 v22, {it.hl}, v22
-    	v_add_u32 v60, s42, v22
-    .L{name}_pass:""")
-            a(f"""
-    	s_mov_b64 {S_TAPE}, {S_TBASE}""")           # (VRES needs no initial value: a shape tape ends with its OUTPUT op, whose handler fills it)
-            ret, here = a.label("ret"), a.label("pc")
-            if EXP == "nointerp":     # experiment: the set-up alone
-                for j in range(zb):
-                    a(f"\tv_mov_b32 {VRES[j]}, 1.0")
-                a(f"\ts_branch {ret}")
-            a(f"""
-    	s_getpc_b64 {S_RET}
-    {here}:
-    	s_add_u32 s74, s74, {ret} - {here}
-    	s_addc_u32 s75, s75, 0
-    	s_cmp_gt_u32 {S_LEN0}, 64
-    	s_cbranch_scc0 .L{name}_gov
-    	s_branch .L{name}_go
-    {ret}:""")
-            if zb < 8:
-                # the next pass (if any) of a long tape needs its head again: ask for it before the hit test
-                skip = a.label("nohead")
-                a(f"""
-    	s_cmp_gt_u32 {S_LEN0}, 64
-    	s_cbranch_scc0 {skip}
-    	s_load_dwordx8 s[{S_QA}:{S_QA + 7}], {S_TBASE}, 0x0
-    {skip}:""")
         # first voxel inside, front to back (sample j: depth = lz + (k - j) + 1): the samples' "value < 0" bits shifted into a mask
         # through the carry (sample 0 ends up highest), its leading bit is the hit - 2 instructions per sample instead of 8
         # ... unless no pending pixel has a sample inside at all, which is most leaves of a frame (prospero.vm's general path: 95 %): the
@@ -1998,7 +2009,8 @@ def main():
     if len(sys.argv) > 3:
         import gen_trans
         gen_trans.tables(a, sys.argv[3])   # the compiled routines' constant tables, once for all the kernels that embed them
-    n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)), off)
+    # (register-file shapes of the plain leaf kernel: 10 registers x 8 voxels, 20 x 4, 32 x 2 in the compact map's file of 80)
+    n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)) if EXP == "file64" else ((10, 8), (20, 4), (32, 2)), off)
     ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
         # (a register file of 128 VGPRs here - 16 registers x 8 voxels, 32 x 4: the tapes that carry these opcodes are smooth blends

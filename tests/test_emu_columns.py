@@ -382,10 +382,10 @@ def test_column_mode_in_the_transcendental_kernel():
 
 def _leaf_values(tape, n_regs, ik, mat, leaf=(0, 0, 0), kernel="fh_columns"):
     """run ONE leaf of an 8-voxel-per-lane class and return the tape's output for its 64 pixels x 8 voxels as the kernel left it in
-    VRES (v10 .. v17, sample j = voxel z + 7 - j), next to numpy's"""
+    VT (v18 .. v25: the OUTPUT handler of the compact register map leaves it there; sample j = voxel z + 7 - j), next to numpy's"""
     _, ws = run_columns(tape, n_regs, ik, mat, leaf)
     w = max(ws, key=lambda w: w.counts.get("valu", 0))
-    got = np.stack([np.asarray(w.v[10 + j]).view(F32) for j in range(8)], axis=1)       # [lane][sample]
+    got = np.stack([np.asarray(w.v[18 + j]).view(F32) for j in range(8)], axis=1)       # [lane][sample]: VT, where the compact register map leaves the output
     lx, ly, lz = leaf
     want = np.zeros((64, 8), F32)
     for lane in range(64):
@@ -441,3 +441,33 @@ def test_delta_handlers_every_op_and_distance(mat):
     assert _same_bits(g, w) and (w.view(U32) == 0).all()                     # min(-0, +0) = +0: the guard's slow path
     g, w = _leaf_values(np.array(prelude() + [P(OP["OUTPUT"], 0, 4, 0)], np.uint64), 8, ik, mat)
     assert np.isnan(w).any() and not np.isnan(w).all()
+
+
+@pytest.mark.parametrize("mat", [AFFINE, PERSPECTIVE], ids=["affine", "perspective"])
+def test_generic_binary_ops_in_the_ten_register_file(mat):
+    """fh_columns' compact register map (round 6): a file of ten registers of eight voxels, the handlers' results built in place over
+    their first operand (no separate result registers).  Every two-operand op without a form of its own - div, compare, and, or, min /
+    max with out != a - in the RR, RI and IR forms, between registers 0 .. 9, on operands with zeros of both signs, infinities and
+    NaNs: the output values of every lane and voxel against numpy."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    def prelude():       # r0 = x, r1 = y, r9 = z, r2 = +0, r3 = -0, r4 = sqrt(y - 0.3) (NaN where y < 0.3), r5 = a fraction - 0.5, r8 = 1 / r2 = inf
+        return [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 1), P(OP["INPUT"], 9, 0, 2),
+                P(OP["SUB_RR"], 2, 0, 0), P(OP["NEG"], 3, 2, 0), P(OP["SUB_RI"], 4, 1, f(0.3)), P(OP["SQRT"], 4, 4, 0),
+                P(OP["MUL_RR"], 5, 0, 9), P(OP["FLOOR"], 6, 5, 0), P(OP["SUB_RR"], 5, 5, 6), P(OP["SUB_RI"], 5, 5, f(0.5)),
+                P(OP["RECIP"], 8, 2, 0), P(OP["NEG"], 7, 8, 0)]
+    bad = []
+    for base in ("DIV", "COMPARE", "AND", "OR", "MIN", "MAX"):
+        for out, ra, rb in ((6, 5, 1), (9, 1, 5), (6, 2, 3), (6, 3, 2), (0, 4, 5), (9, 5, 4), (6, 8, 7), (6, 7, 8), (9, 8, 2), (6, 5, 5)):
+            cases = [(f"{base}_RR r{out} <- r{ra}, r{rb}", P(OP[base + "_RR"], out, ra, rb))]
+            for imm in (0.0, -0.0, 0.25, float("inf")):
+                cases.append((f"{base}_RI r{out} <- r{ra}, {imm}", P(OP[base + "_RI"], out, ra, f(imm))))
+                if base + "_IR" in OP:
+                    cases.append((f"{base}_IR r{out} <- {imm}, r{ra}", P(OP[base + "_IR"], out, ra, f(imm))))
+            for name, op in cases[:3] if out != 6 else cases:
+                t = prelude() + [op, P(OP["OUTPUT"], 0, out, 0)]
+                got, want = _leaf_values(np.array(t, np.uint64), 10, ik, mat)
+                if not _same_bits(got, want):
+                    bad.append((name, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad
