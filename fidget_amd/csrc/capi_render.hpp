@@ -1211,21 +1211,26 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 // 1 = only where the tapes guarantee sparse columns, 0 never, 2 always (tests).
                 const bool by_columns = ctx->opt.column_walk == 2 || (ctx->opt.column_walk == 1 && R.xy_fixed && R.root_invariant && (ctx->opt.no_zrep == 0 || ctx->opt.no_zrep == 3));
                 const uint32_t layers = P.slab / 8;
+                // (the slab context's leaf table, as k_fork_state lays the contexts out: the kernel takes it - with the table's shape - from its
+                // kernarg, so that a wave whose part of the table is empty leaves after one dependent load)
+                const uint32_t sk = (uint32_t)(dS - dS0);
+                const void* const slab_table = sk == 0 ? (const void*)R.S.leaf_table : (const void*)((const FhLeafRef*)ctx->leaf_table_b.p + (size_t)(sk - 1) * R.S.leaf_cap);
                 // ... and for every other frame, round 6: the column walk by GROUPS of 2^g layers (flags bits 24 .. 27, grid y = the group,
                 // front group first; option column_group = g, 0: the block walk below).  A wave keeps its footprint: the pixels' set-up,
                 // their matrix products and their z-buffer words are loaded once per wave instead of once per leaf (the z-buffer words
                 // were two thirds of the launch's HBM traffic), hits stay in registers from leaf to leaf and leave in one atomic.
                 const uint32_t g = by_columns ? 6u : (uint32_t)std::min(std::max(ctx->opt.column_group, 0), 6);
                 if ((by_columns && layers <= 64) || (!by_columns && g > 0)) {
-                    struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags | (1u << 20) | (g << 24), {0, 0}};
+                    struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; const void* table; uint32_t nfpl, layers; } ka =
+                        {dS, 0u, R.col_slots, R.col_depmask, R.col_flags | (1u << 20) | (g << 24), {0, 0}, slab_table, R.n_footprints, layers};
                     const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                     (void)launch_asm(ctx, which, (R.n_footprints + 63) / 64 * 64, &ka, sizeof(ka), 0, (layers + (1u << g) - 1) >> g, leaf_stream);
                     return;
                 }
                 // (pad[0]: floor(2^32 / blocks per layer) - the kernel rotates a layer's blocks by a per-layer offset, which is what balances
                 // the launch, and takes the remainder by this reciprocal instead of a subtraction loop)
-                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; } ka = {dS, 0u, R.col_slots, R.col_depmask, R.col_flags,
-                                                                                                   {n_blocks > 1 ? (uint32_t)(((uint64_t)1 << 32) / n_blocks) : 0u, 0}};
+                struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; const void* table; uint32_t nfpl, layers; } ka =
+                    {dS, 0u, R.col_slots, R.col_depmask, R.col_flags, {n_blocks > 1 ? (uint32_t)(((uint64_t)1 << 32) / n_blocks) : 0u, 0}, slab_table, R.n_footprints, layers};
                 const int which = R.asm_points_t ? FH_ASM_COLUMNS_T : FH_ASM_COLUMNS;
                 (void)launch_asm(ctx, which, n_blocks, &ka, sizeof(ka), 0, P.slab / 8, leaf_stream);
             } else if (R.full) {

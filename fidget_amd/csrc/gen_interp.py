@@ -66,7 +66,7 @@ S_SIGN = "s28"          # 0x80000000
 S_ABSM = "s29"          # 0x7fffffff
 S_ARENA = "s[30:31]"
 S_NXTV = "s32"           # columns: the next leaf's tape is on its way into V_NXT
-S_SLABZ = "s26"          # columns: z of the slab's first voxel (S_LAYERS is dead after the prologue)
+S_SLABZ = "s61"          # columns: z of the slab's first voxel
 S_TABLE = "s[34:35]"
 S_ZBUF = "s[36:37]"
 S_FPLIST = "s[38:39]"
@@ -1311,26 +1311,35 @@ def _gen_columns_body(a, variants, off, kname, trans):
     # kernarg: { FhRenderState* S; u32 n_waves; u32 axis slots x | y << 8 | z << 16 (0xFF: the tape has no such input);
     #            u32 inputs that change along a pixel column (bit per input slot); u32 flags (bit 16: projective matrix; 20: column mode) }
     # - per frame constants the host works out once: 65 536 workgroups per launch each spent ~130 scalar instructions on them
-    kernel_header(a, kname, 32, nvg)
+    # kernarg (48 bytes): { FhRenderState* S; u32 n_waves, axis slots, inputs varying along a column, flags, reciprocal, pad;
+    #                       FhLeafRef* leaf table of this slab; u32 footprints per layer; u32 layers of the slab }
+    # - what a wave needs to find out whether its part of the table holds a leaf at all comes with the kernarg: two thirds of a launch's
+    # waves find none, and leave after ONE dependent load (their entries) instead of two (the state's pointers first); the others have
+    # the state's words on their way meanwhile
+    kernel_header(a, kname, 48, nvg)
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
 	s_load_dwordx4 s[48:51], {S_KERNARG}, 0x8
 	s_load_dword {S_RCP}, {S_KERNARG}, 0x18
+	s_load_dwordx4 s[60:63], {S_KERNARG}, 0x20
 	s_mov_b32 {S_WGID}, s2
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
     a(f"""
 	s_mov_b32 {V_PINF}, 0x7f800000
-	s_mov_b32 {V_NINF}, 0xff800000
 	s_mov_b32 s58, 1.0
 	s_mov_b32 s59, 1.0
 	s_waitcnt lgkmcnt(0)
+	s_mov_b64 {S_TABLE}, s[60:61]
+	s_mov_b32 {S_NFPL}, s62
+	s_mov_b32 {S_L}, s63                              ; layers of the slab
+	; the state's words: on their way while the wave looks at its table entries; waited for where the first leaf starts (.Lfh_columns_leaf)
 	s_load_dwordx16 s[{m}:{m + 15}], {S_STATE}, {o['P.mat']}
 	s_load_dwordx2 s[24:25], {S_STATE}, {o['P.width']}
-	s_load_dword {S_LAYERS}, {S_STATE}, {o['P.slab']}
 	s_load_dwordx2 {S_ARENA}, {S_STATE}, {o['arena']}
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
-	s_load_dwordx2 {S_TABLE}, {S_STATE}, {o['leaf_table']}
+	s_load_dword {S_SLABZ}, {S_STATE}, {o['slab_z']}
+	s_mov_b32 {V_NINF}, 0xff800000
 	s_mov_b32 {S_NWG}, s48
 	s_bfe_i32 {S_SLOTX}, s49, 0x80000               ; (s0 / s1 held the kernarg pointer until here)
 	s_bfe_i32 {S_SLOTY}, s49, 0x80008
@@ -1338,19 +1347,10 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_DEPMASK}, s50
 	s_and_b32 s51, s51, 0x0f1f0000                   ; flags bit 16: projective; 17 .. 19: x / y / z of the model changes along a pixel column; 20: column mode; 24 .. 27: log2 of the layers a wave of column mode takes (bit 28, set here: the lane's pixel state is valid)
 	s_or_b32 {S_WGY}, {S_WGY}, s51
-	s_waitcnt lgkmcnt(0)
-	s_lshr_b32 {S_LAYERS}, {S_LAYERS}, 3
-	s_mov_b32 {S_L}, {S_LAYERS}
-	s_load_dword {S_SLABZ}, {S_STATE}, {o['slab_z']}
 	; ({S_DEPMASK}, from the kernarg: the input slots whose value changes along a pixel column - the axis' matrix row has a z
 	; coefficient, or the matrix is projective.  A leaf tape that reads none of them has ONE value per pixel for its 8
 	; voxels and is evaluated once per pixel, below: a vertical wall, an extrusion, whatever pruning left independent of z.)
 	; footprints per layer, blocks of {BLK} of them
-	s_add_u32 {S_T0}, {S_WIDTH}, 7
-	s_lshr_b32 {S_T0}, {S_T0}, 3
-	s_add_u32 {S_T1}, {S_HEIGHT}, 7
-	s_lshr_b32 {S_T1}, {S_T1}, 3
-	s_mul_i32 {S_NFPL}, {S_T0}, {S_T1}
 	s_add_u32 {S_CNT}, {S_NFPL}, {BLK - 1}
 	s_lshr_b32 {S_CNT}, {S_CNT}, {BLKL}
 	; work items = (layer, block), front layer first.  n_waves != 0: persistent waves, wave w takes
@@ -1463,7 +1463,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	global_load_dwordx4 v[{V_ENT[0][1:]}:{V_ENT[3][1:]}], {V_S0}, {S_TABLE}
 	s_mov_b64 exec, {S_SAVE}
 	s_mov_b32 {S_NXTV}, 0
-	s_waitcnt vmcnt(0) lgkmcnt(0)
+	s_waitcnt vmcnt(0)                              ; (the entries alone: a wave that finds none leaves without the state's words)
 	v_cmp_ne_u32 vcc, 0, {V_ENT[0]}
 	s_nop 3
 	s_mov_b64 {S_LAYMASK}, vcc
@@ -1471,6 +1471,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	; ---- next leaf of the block: everything needed to start on it is in the entries (no load before the tape's) --------
 	s_cmp_eq_u64 {S_LAYMASK}, 0
 	s_cbranch_scc1 .Lfh_columns_blockend
+	s_waitcnt lgkmcnt(0)                            ; (the state's words, requested in the prologue)
 	s_ff1_i32_b64 {S_ZL}, {S_LAYMASK}
 	s_bitset0_b64 {S_LAYMASK}, {S_ZL}
 	s_bitcmp1_b32 {S_WGY}, 20
@@ -1773,7 +1774,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b64 exec, {S_SAVE}
 	s_branch .Lfh_columns_block
 .Lfh_columns_exit:""")
-    kernel_footer(a, kname, 32, nvg, 102, True, wg_y=True)
+    kernel_footer(a, kname, 48, nvg, 102, True, wg_y=True)
     a(f"\t.p2align 8\n.L{kname}_lut:")
     for k in range(64):
         a(f"\t.long {lut_bits(its[0], k)}")
@@ -2011,14 +2012,14 @@ def main():
         gen_trans.tables(a, sys.argv[3])   # the compiled routines' constant tables, once for all the kernels that embed them
     # (register-file shapes of the plain leaf kernel: 10 registers x 8 voxels, 20 x 4, 32 x 2 in the compact map's file of 80)
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)) if EXP == "file64" else ((10, 8), (20, 4), (32, 2)), off)
-    ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
+    ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
         # (a register file of 128 VGPRs here - 16 registers x 8 voxels, 32 x 4: the tapes that carry these opcodes are smooth blends
         # that prune little - bear.vm's leaves keep 350-430 ops in 17-23 registers -, and two passes of four voxels pay the per-op
         # dispatch half as often as four passes of two: 2.80 -> 2.40 ms per 512^3 frame; 218 VGPRs with the routines' window, two
         # waves per SIMD as with 160)
         n, nvg = gen_columns(a, ((16, 8), (32, 4), (32, 2)), off, trans=sys.argv[3])
-        ks.append((n, 32, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6))
+        ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)
         ks.append((n, 32, FILE + nr * zb, [(8, "global_buffer")] * 3 + [(4, "by_value")] * 2))

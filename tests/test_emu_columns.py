@@ -18,7 +18,7 @@ def xf_point(m, x, y, z):
         return [np.where(rows[3] != 0, rows[r] / rows[3], rows[r]).astype(F32) for r in range(3)]
 
 
-def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False, group_log2=6):
+def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False, group_log2=6, a_tab=0, layers=None):
     """the leaf kernel's kernarg as capi_render.hpp builds it: state, n_waves = 0, axis slots, inputs varying along a column, flags, and
     floor(2^32 / blocks of four footprints per layer) for the kernel's block rotation (0 when there is one block: the subtraction loop)"""
     u = np.asarray(mat, F32).view(U32)
@@ -38,7 +38,9 @@ def col_kernarg(a_st, in_kind, mat, size=16, column_mode=False, group_log2=6):
     n_blocks = (((size + 7) // 8) ** 2 + 3) // 4
     if column_mode:
         flags |= (1 << 20) | (group_log2 << 24)   # (one footprint column per wave, lane = layer; 2^g layers of it per wave, grid y = the group)
-    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, (1 << 32) // n_blocks if n_blocks > 1 else 0, 0], U32)
+    # (round 6: the slab's leaf table, its footprints per layer and its layers come with the kernarg - a wave looks at its entries before the state's words arrive)
+    return np.array([a_st & 0xFFFFFFFF, a_st >> 32, 0, slots, dep, flags, (1 << 32) // n_blocks if n_blocks > 1 else 0, 0,
+                     a_tab & 0xFFFFFFFF, a_tab >> 32, ((size + 7) // 8) ** 2, size // 8 if layers is None else layers], U32)
 
 
 def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n_choices=0, kernel="fh_columns", column_mode=False, more_leaves=(), group_log2=6):
@@ -67,7 +69,7 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], lz - lz % size)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat, size, column_mode, group_log2)
+    ka = col_kernarg(a_st, in_kind, mat, size, column_mode, group_log2, a_tab=a_tab, layers=layers)
     trans = kernel == "fh_columns_t"
     gx, gy = ((nfp + 63) // 64 * 64, (layers + (1 << group_log2) - 1) >> group_log2) if column_mode else ((nfp + 3) // 4, layers)
     waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=256 if trans else 128,
@@ -233,7 +235,7 @@ def run_block(leaves_spec, in_kind, mat, size=16, zbuf_init=None, kernel="fh_col
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["leaf_table"], a_tab); st.u64(off["zbuf"], a_z)
     st.u32(off["slab_z"], slab_z)
     a_st = mem.map(st.b)
-    ka = col_kernarg(a_st, in_kind, mat, size)
+    ka = col_kernarg(a_st, in_kind, mat, size, a_tab=a_tab, layers=layers)
     E.launch(U.program(), mem, kernel, ka.tobytes(), (nfp + 3) // 4, grid_y=layers, lds_bytes=16, n_vgpr=128)
     return zbuf
 
