@@ -75,7 +75,7 @@ el, eh, chs, _ = U.ref_interval(tape2, inputs, 64)
 by_class = {}
 for lane in np.nonzero(~(eh < 0) & ~(el > 0))[0]:
     ops, lregs, _ = U.ref_prune(tape2, chs[:, lane])
-    cls = 8 if lregs <= 8 else (16 if lregs <= 16 else 32)
+    cls = 10 if lregs <= 10 else (20 if lregs <= 20 else 32)       # (the leaf kernel's register-file shapes: 10 x 8 voxels, 20 x 4, 32 x 2)
     by_class.setdefault(cls, []).append((len(ops), lregs, np.array(ops, np.uint64)))
 mat = np.eye(4, dtype=np.float32)
 mat[:3, :3] *= 2.0 / 16
