@@ -301,7 +301,7 @@ class Interp:
         clobbers v128..v153, s86..s97 and vcc (the mask scratch of the handlers: nothing live)"""
         here, ret = self.a.label("call"), self.a.label("ret")
         if self.threaded:       # (the handler tables of the threaded dispatch put the routines beyond s_branch's 128 KB: a computed jump)
-            far = self.a.label("far")
+            far = self.a.label("fcall")
             return self.a(f"""
 	s_getpc_b64 s[96:97]
 {here}:
