@@ -15,6 +15,8 @@ struct RenderSetup {
     uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
     size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
+    uint32_t hit_bucket_cap = 0;   // the normals kernel's work lists (k_hits3d): entries per bucket, words of the whole thing per slab context
+    size_t hit_words = 0;
     size_t mind_words = 0;      // words of the min-depth pyramid (cleared at the head of the frame)
     uint32_t tl = 16;  // sibling tiles per wave in the tile kernel (16 or 64)
     bool full = false;  // tape uses transcendental / modulo ops -> FULL kernel variants
@@ -364,8 +366,12 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         HIP_TRY(ctx, ctx->leaf_table_b.ensure(extra * leaf_cap * sizeof(FhLeafRef)));
         HIP_TRY(ctx, ctx->zbuf.ensure((size_t)P.width * P.height * 8));
         HIP_TRY(ctx, ctx->normals.ensure((size_t)P.width * P.height * 12));
-        HIP_TRY(ctx, ctx->fp_lists.ensure((size_t)R.n_footprints * 4 * 3));
-        HIP_TRY(ctx, ctx->fp_lists_b.ensure(extra * (size_t)R.n_footprints * 4 * 3));
+        // (three footprint lists and the normals kernel's list of leaves with a hit: at most every leaf of a slab)
+        // (a footprint's pixels name at most one leaf per layer of the slab; footprint i of the class lists goes to bucket i % 64)
+        R.hit_bucket_cap = (uint32_t)(((size_t)R.n_footprints + FH_HIT_BUCKETS - 1) / FH_HIT_BUCKETS * (P.slab / tl));
+        R.hit_words = (size_t)FH_HIT_BUCKETS * (FH_HIT_STRIDE + R.hit_bucket_cap);
+        HIP_TRY(ctx, ctx->fp_lists.ensure(((size_t)R.n_footprints * 3 + R.hit_words) * 4));
+        HIP_TRY(ctx, ctx->fp_lists_b.ensure(extra * ((size_t)R.n_footprints * 3 + R.hit_words) * 4));
         size_t mind_words = 0;
         for (size_t l = 0; l < ts.size(); l++) mind_words += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
         HIP_TRY(ctx, ctx->mind.ensure(mind_words * 4));
@@ -376,6 +382,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
             mp += (size_t)((P.width + ts[l] - 1) / ts[l]) * ((P.height + ts[l] - 1) / ts[l]);
         }
         for (int c = 0; c < 3; c++) S.fp_list[c] = (uint32_t*)ctx->fp_lists.p + (size_t)c * R.n_footprints;
+        S.hit_list = (uint32_t*)ctx->fp_lists.p + (size_t)3 * R.n_footprints;
     }
     S.arena = (uint64_t*)ctx->arena.p;
     S.arena_cap = (uint32_t)std::min<size_t>(ctx->arena_bytes / 8 - 64, 0x7FFFFFE0u);  // slack: the interpreters prefetch up to 12 ops past a tape's end
@@ -1067,7 +1074,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     }
     if (pipe) {
         FH_KLAUNCH(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
-                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints,
+                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints, R.hit_words,
                            (pre && n_groups) ? 1u : 0u);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         if (ctx->stream != side_stream) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
@@ -1173,11 +1180,17 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 });
         };
         auto normals_work = [&] {
+#ifdef FH_EXP_SKIP_NORMALS      // experiment (tools/build_lib_variant.py): a frame without its normals kernels - what they cost beside the leaf kernels
+            return;
+#endif
             launch(ctx, FHIP_K_NORMALS, [&] {
                 const int gs = blocks_for(ctx, R.lds_normals_small, 8), gb = blocks_big(ctx, R, R.lds_normals_big, 8);
                 if (R.asm_normals) {
-                    // (list 0 of k_classify3d holds every footprint whose leaves need <= 32 registers: the assembly interpreter's file)
-                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, pad[2]; } kn = {dS, (uint32_t)(ctx->n_cu * 8), R.col_slots, z_lo, z_hi, {0, 0}};
+                    // (lists 0 and 1 of k_classify3d hold every footprint whose leaves need <= 32 registers - the assembly interpreter's file:
+                    // k_hits3d turns them into the list of leaves that own a hit, the normals kernel takes one leaf per wave pass)
+                    FH_KLAUNCH(k_hits3d, dim3(std::min<uint32_t>((R.n_footprints + 3) / 4, (uint32_t)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, dS, z_lo, z_hi, R.hit_bucket_cap);
+                    // (wave w walks bucket w % 64 with a stride of n_waves / 64)
+                    struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, bucket_cap, pad; } kn = {dS, std::max<uint32_t>((uint32_t)(ctx->n_cu * 8) / FH_HIT_BUCKETS, 1u) * FH_HIT_BUCKETS, R.col_slots, z_lo, z_hi, R.hit_bucket_cap, 0};
                     (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
                 }
                 else if (R.full) FH_KLAUNCH((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);

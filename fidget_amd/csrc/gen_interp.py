@@ -586,8 +586,13 @@ class Interp:
                 if op == "RECIP":
                     one = ["1.0"] * 8
                     self.f_div(one, VT, VU)
+                elif op == "SQRT" and "nosqrt" in EXP.split(","):      # experiment: what the rounding of the root costs
+                    for j in Z:
+                        a(f"\tv_sqrt_f32 {VU[j]}, {VT[j]}")
                 elif op == "SQRT":
                     self.f_sqrt(VT, VU)
+                    if "twicesqrt" in EXP.split(","):     # experiment: the root's cost once more, same results
+                        self.f_sqrt(VT, VU)
                 else:
                     self.f_round(VT, VU)
                 self.write_out(VU)
@@ -597,18 +602,21 @@ class Interp:
             def body(fn=op.lower()):
                 self.read_a(VT)
                 self.idx_off()
-                if self.zb % 4 == 0 and ((self.wide_trans is True and fn in ("sin", "cos", "exp", "ln")) or (self.wide_trans == "sincos" and fn in ("sin", "cos"))):
-                    for j0 in range(0, self.zb, 4):       # four samples per call (gen_trans.FUNCS4)
-                        for k in range(4):
-                            a(f"\tv_mov_b32 v{self.t_base + k}, {VT[j0 + k]}")
-                        self.call(fn + "4")
-                        for k in range(4):
-                            a(f"\tv_mov_b32 {VU[j0 + k]}, v{self.t_base + k}")
-                else:
-                    for j in Z:
-                        a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
-                        self.call(fn)
-                        a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
+                if "no" + fn in EXP.split(","):       # experiment: what the routine costs (a copy in its place)
+                    return self.write_out(VT)
+                for rep in range(2 if "twice" + fn in EXP.split(",") else 1):     # experiment: the routine's cost once more, same results
+                  if self.zb % 4 == 0 and ((self.wide_trans is True and fn in ("sin", "cos", "exp", "ln")) or (self.wide_trans == "sincos" and fn in ("sin", "cos"))):
+                      for j0 in range(0, self.zb, 4):       # four samples per call (gen_trans.FUNCS4)
+                          for k in range(4):
+                              a(f"\tv_mov_b32 v{self.t_base + k}, {VT[j0 + k]}")
+                          self.call(fn + "4")
+                          for k in range(4):
+                              a(f"\tv_mov_b32 {VU[j0 + k]}, v{self.t_base + k}")
+                  else:
+                      for j in Z:
+                          a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
+                          self.call(fn)
+                          a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
                 self.write_out(VU)
             return self.out_of_line(op.lower(), body)
         if op == "RAND":
@@ -720,8 +728,13 @@ class Interp:
             if form != "RR":
                 self.imm_b(VU)
             A, B = (VT, VU) if form != "IR" else (VU, VT)
-            if base == "DIV":
+            if base == "DIV" and "nodiv" in EXP.split(","):      # experiment: what the division costs (a product in its place)
+                for k in PZ:
+                    a(f"\tv_pk_mul_f32 {self.P(VW, k)}, {self.P(A, k)}, {self.P(B, k)}")
+            elif base == "DIV":
                 self.f_div(A, B, VW)
+                if "twicediv" in EXP.split(","):     # experiment: the division's cost once more, same results
+                    self.f_div(A, B, VW)
             elif base == "COMPARE":
                 self.f_compare(A, B, VW)
             elif base in ("MIN", "MAX"):

@@ -9,15 +9,17 @@ everything else follows dev_ops.hpp's gr_* functions operation for operation (no
 root sequences of the leaf handlers) - the normals are the C++ kernel's, which are the oracle's, bit for bit
 (vm/mod.rs:1091-1397 via dev_ops.hpp GRAD).
 
-Per wave: a footprint (8 x 8 pixels) of the slab's list (k_classify3d, list 0: every leaf of <= 32 registers); the lanes' z-buffer
-words say which leaf hit which pixel at which depth; the input gradients of every lane's voxel (dev_ops.hpp xf_grad: the screen ->
-model matrix applied to {x,1,0,0}, {y,0,1,0}, {z,0,0,1}, then the division by w - always, as the C++ does) are made once per
-footprint; then, for each distinct leaf among the lanes, its tape is run for all 64 lanes and the lanes it hit store dx, dy, dz and
-clear the leaf number in their z-buffer word (voxel.rs:447-482).
+Per wave pass: ONE leaf of the slab's list of leaves that own a hit (k_hits3d, kernels.hip: the distinct leaf numbers in the finished
+z-buffer words of the footprints whose leaves need <= 32 registers) - its 8 x 8 pixels' z-buffer words say which of them it hit at which
+depth; the input gradients of every lane's voxel (dev_ops.hpp xf_grad: the screen -> model matrix applied to {x,1,0,0}, {y,0,1,0},
+{z,0,0,1}, then the division by w - always, as the C++ does) are made, the leaf's tape is run for all 64 lanes, and the lanes it hit store
+dx, dy, dz and clear the leaf number in their z-buffer word (voxel.rs:447-482).  (Until round 6 a wave took a footprint and ran the tapes
+of all the leaves among its pixels one after the other: a launch lasted as long as its busiest wave - 414 us on bear.vm 512^3.)
 
-Tapes with transcendental, modulo or rng ops keep the C++ kernel (as they keep the C++ tile stage).
+Tapes with a modulo keep the C++ kernel (its gradient needs div_euclid); fh_normals_t has the transcendental, rng and atan2 handlers.
 
-kernarg: { FhRenderState* S; u32 n_waves; u32 axis slots x | y << 8 | z << 16 (0xFF: none); u32 z_lo; u32 z_hi; u32 pad[2] }
+kernarg: { FhRenderState* S; u32 n_waves (a multiple of 64); u32 axis slots x | y << 8 | z << 16 (0xFF: none); u32 z_lo; u32 z_hi;
+           u32 entries per list of k_hits3d; u32 pad }
          - this launch's hits are those with z_lo < depth <= z_hi.
 """
 from gen_interp import (Interp, OPS, FILE, S_KERNARG, S_STATE, S_MAT, S_SIGN, S_ABSM, S_ARENA, S_TAPE, S_LEN, S_W1, S_T0, S_OUT, S_A, S_T1, S_PC, S_SAVE,
@@ -31,8 +33,8 @@ S_WI, S_NWG, S_NFP = "s6", "s7", "s40"
 S_WIDTH, S_HEIGHT = "s24", "s25"
 S_ZLO, S_ZHI = "s26", "s27"
 S_NORMALS, S_LEAVES, S_ZBUF, S_FPLIST = "s[32:33]", "s[34:35]", "s[36:37]", "s[38:39]"
-S_TODO, S_MINE = "s[80:81]", "s[82:83]"
-S_FX, S_FY, S_CUR = "s76", "s77", "s78"
+S_TODO = "s[80:81]"
+S_CUR = "s78"
 V_PIX, V_ID, V_DEPTH, V_NOFF = "v1", "v2", "v3", "v4"       # byte offset of the pixel's z-buffer word, its two halves, byte offset of its normal
 V_PX, V_PY, V_PZ = "v5", "v6", "v7"
 VRES = ["v10", "v11", "v12", "v13"]
@@ -356,6 +358,7 @@ def gen_normals(a, off, trans=None):
     a(f"""
 	s_load_dwordx2 {S_STATE}, {S_KERNARG}, 0x0
 	s_load_dwordx4 s[48:51], {S_KERNARG}, 0x8
+	s_load_dword s52, {S_KERNARG}, 0x18
 	s_mov_b32 {S_WI}, s2""")
     common_consts(a)
     handler_base(a, it)
@@ -367,33 +370,49 @@ def gen_normals(a, off, trans=None):
 	s_load_dwordx2 {S_ZBUF}, {S_STATE}, {o['zbuf']}
 	s_load_dwordx2 {S_NORMALS}, {S_STATE}, {o['normals']}
 	s_load_dwordx2 {S_LEAVES}, {S_STATE}, {o['leaves']}
-	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['fp_list']}
-	s_load_dword {S_NFP}, {S_STATE}, {o['fp_count']}
-	s_mov_b32 {S_NWG}, s48
+	s_load_dwordx2 {S_FPLIST}, {S_STATE}, {o['hit_list']}
+	s_lshr_b32 {S_NWG}, s48, 6                      ; wave w walks list w % 64 (k_hits3d's buckets) with a stride of n_waves / 64
 	s_bfe_i32 {S_SLOTX}, s49, 0x80000               ; (s0 / s1 held the kernarg pointer until here)
 	s_bfe_i32 {S_SLOTY}, s49, 0x80008
 	s_bfe_i32 {S_SLOTZ}, s49, 0x80010
 	s_mov_b32 {S_ZLO}, s50
 	s_mov_b32 {S_ZHI}, s51
 	s_waitcnt lgkmcnt(0)
+	s_and_b32 {S_T0}, {S_WI}, 63
+	s_lshr_b32 {S_WI}, {S_WI}, 6
+	s_lshl_b32 {S_T1}, {S_T0}, 8                    ; the list's counter: FH_HIT_STRIDE words apart
+	s_add_u32 s86, s38, {S_T1}
+	s_addc_u32 s87, s39, 0
+	s_load_dword {S_NFP}, {S_PC}, 0x0
+	s_mul_i32 {S_T0}, {S_T0}, s52                   ; its entries: behind the 64 counters, `bucket_cap` (kernarg) per list
+	s_lshl_b32 {S_T0}, {S_T0}, 2
+	s_add_u32 {S_T0}, {S_T0}, {64 * 64 * 4}
+	s_add_u32 s38, s38, {S_T0}
+	s_addc_u32 s39, s39, 0
+	s_waitcnt lgkmcnt(0)
+	s_min_u32 {S_NFP}, {S_NFP}, s52
 .L{name}_next:
-	; ---- next footprint of the list: static round robin over the waves ----------------------------------------------
+	; ---- next leaf of the list (k_hits3d: the slab's leaves that own a hit): static round robin over the waves --------------------
 	s_cmp_ge_u32 {S_WI}, {S_NFP}
 	s_cbranch_scc1 .L{name}_exit
 	s_lshl_b32 {S_T0}, {S_WI}, 2
 	s_add_u32 {S_WI}, {S_WI}, {S_NWG}
 	s_add_u32 s86, s38, {S_T0}
 	s_addc_u32 s87, s39, 0
-	s_load_dword {S_T1}, {S_PC}, 0x0
+	s_load_dword {S_CUR}, {S_PC}, 0x0
 	v_and_b32 {V_PX}, 7, {V_LANE}
 	v_lshrrev_b32 {V_PY}, 3, {V_LANE}
 	s_waitcnt lgkmcnt(0)
-	s_and_b32 {S_FX}, {S_T1}, 0xffff
-	s_lshr_b32 {S_FY}, {S_T1}, 16
-	s_lshl_b32 {S_FX}, {S_FX}, 3
-	s_lshl_b32 {S_FY}, {S_FY}, 3
-	v_add_u32 {V_PX}, {S_FX}, {V_PX}
-	v_add_u32 {V_PY}, {S_FY}, {V_PY}
+	s_sub_u32 {S_T0}, {S_CUR}, 1
+	s_mul_hi_u32 {S_T1}, {S_T0}, {o['sizeof_leaf']}
+	s_mul_i32 {S_T0}, {S_T0}, {o['sizeof_leaf']}
+	s_add_u32 s86, s34, {S_T0}
+	s_addc_u32 s87, s35, {S_T1}
+	s_load_dwordx4 s[48:51], {S_PC}, 0x0                 ; FhLeaf: tape offset, length, registers | choices, corner x  (the interpreter's
+	s_load_dword s52, {S_PC}, 0x10                       ; corner y                                       op batches: free between two tapes)
+	s_waitcnt lgkmcnt(0)
+	v_add_u32 {V_PX}, s51, {V_PX}
+	v_add_u32 {V_PY}, s52, {V_PY}
 	v_cmp_gt_u32_e64 {S_M[0]}, {S_WIDTH}, {V_PX}
 	v_cmp_gt_u32_e64 {S_M[1]}, {S_HEIGHT}, {V_PY}
 	v_mul_u32_u24 {V_NOFF}, {V_PY}, {S_WIDTH}
@@ -408,16 +427,15 @@ def gen_normals(a, off, trans=None):
 	global_load_dwordx2 v[2:3], {V_PIX}, {S_ZBUF}
 	s_mov_b64 exec, {S_SAVE}
 	s_waitcnt vmcnt(0)
-	; this launch's hits: z_lo < depth <= z_hi, leaf number still there
+	; the leaf's hits of this launch: its number still in the pixel's word, z_lo < depth <= z_hi
 	v_cmp_lt_u32_e64 {S_M[0]}, {S_ZLO}, {V_DEPTH}
 	v_cmp_ge_u32_e64 {S_M[1]}, {S_ZHI}, {V_DEPTH}
-	v_cmp_ne_u32_e64 {S_M[2]}, 0, {V_ID}
+	v_cmp_eq_u32_e64 {S_M[2]}, {S_CUR}, {V_ID}
 	s_nop 1
 	s_and_b64 {S_M[0]}, {S_M[0]}, {S_M[1]}
 	s_and_b64 {S_TODO}, {S_M[0]}, {S_M[2]}
 	s_cmp_eq_u64 {S_TODO}, 0
 	s_cbranch_scc1 .L{name}_next
-	v_cndmask_b32_e64 {V_ID}, 0, {V_ID}, {S_TODO}
 	; ---- the lanes' input gradients: xf_grad of {{x,1,0,0}}, {{y,0,1,0}}, {{z,0,0,1}} at the voxel above the hit (z = depth - 1) --------
 	v_cvt_f32_u32 {V_PX}, {V_PX}
 	v_cvt_f32_u32 {V_PY}, {V_PY}
@@ -439,38 +457,22 @@ def gen_normals(a, off, trans=None):
     for i, G in enumerate((GX, GY, GZ)):
         it.gr_div(XR[i], XR[3], G)
     a(f"""
-.L{name}_leaf:
-	; ---- the next distinct leaf among the lanes still to do -----------------------------------------------------------------
-	s_ff1_i32_b64 {S_T0}, {S_TODO}
-	s_nop 0
-	v_readlane_b32 {S_CUR}, {V_ID}, {S_T0}
-	s_nop 3
-	v_cmp_eq_u32_e64 {S_MINE}, {S_CUR}, {V_ID}
-	s_sub_u32 {S_T0}, {S_CUR}, 1
-	s_mul_hi_u32 {S_T1}, {S_T0}, {o['sizeof_leaf']}
-	s_mul_i32 {S_T0}, {S_T0}, {o['sizeof_leaf']}
-	s_add_u32 s86, s34, {S_T0}
-	s_addc_u32 s87, s35, {S_T1}
-	s_load_dwordx2 s[84:85], {S_PC}, 0x0                 ; FhLeaf: tape offset, length
-	s_waitcnt lgkmcnt(0)
-	s_mov_b32 {S_LEN}, s85
-	s_mov_b32 s85, 0
-	s_lshl_b64 s[84:85], s[84:85], 3
-	s_add_u32 s44, s84, s30
-	s_addc_u32 s45, s85, s31""")
+	; ---- the leaf's tape for all 64 lanes --------------------------------------------------------------------------------------
+	s_mov_b32 {S_LEN}, s49
+	s_mov_b32 s49, 0
+	s_lshl_b64 s[48:49], s[48:49], 3
+	s_add_u32 s44, s48, s30
+	s_addc_u32 s45, s49, s31""")
     call_interp(a, it)
     a(f"""
 	; the lanes this leaf hit: normal = (dx, dy, dz), z-buffer word = depth << 32 (normal done)
 	s_mov_b64 {S_SAVE}, exec
-	s_and_b64 exec, {S_MINE}, {S_TODO}
+	s_mov_b64 exec, {S_TODO}
 	v_mov_b32 {V_ID}, 0
 	global_store_dword {V_NOFF}, v11, {S_NORMALS}              ; (VGPR tuples start at even registers here: dx, then dy dz)
 	global_store_dwordx2 {V_NOFF}, v[12:13], {S_NORMALS} offset:4
 	global_store_dword {V_PIX}, {V_ID}, {S_ZBUF}
 	s_mov_b64 exec, {S_SAVE}
-	s_andn2_b64 {S_TODO}, {S_TODO}, {S_MINE}
-	s_cmp_eq_u64 {S_TODO}, 0
-	s_cbranch_scc0 .L{name}_leaf
 	s_branch .L{name}_next
 .L{name}_exit:
 	s_waitcnt vmcnt(0)""")

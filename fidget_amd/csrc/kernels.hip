@@ -1388,6 +1388,44 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
     }
 }
 
+// The work list of the assembly normals kernel (fh_normals, gen_normals.py): every leaf that owns a hit of this slab's depth range in the
+// finished z-buffer, once.  A wave per footprint of the classes the assembly kernel takes (lists 0 and 1 of k_classify3d) reads the 64
+// z-buffer words and appends the distinct leaf numbers among them - one atomic per footprint.  The normals kernel then runs ONE tape per
+// wave pass: by footprints (a wave = all the leaves its footprints' pixels were hit by, one after the other) a launch lasted as long as its
+// busiest wave - bear.vm 512^3, 350-430 ops per leaf tape, 2-6 leaves per footprint: 414 us per launch for ~100 us of work per wave slot.
+// The list is FH_HIT_BUCKETS lists (hit_list: the counters, 256 bytes apart, then the buckets of `bucket_cap` entries): footprint wi of the
+// class lists appends to bucket wi % 64, and wave w of the normals kernel walks bucket w % 64.  (One counter for all: 5.5 k atomics that
+// return a value on ONE address took 82 us on prospero.vm 1024^3 - 15 ns each, one after the other.)
+__global__ void __launch_bounds__(256) k_hits3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, uint32_t bucket_cap) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const uint32_t T = P.tiles[P.n_levels - 1];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t n0 = S->fp_count[0], n_all = n0 + S->fp_count[1];
+    const uint32_t waves = gridDim.x * (256 / WAVE);
+    for (uint32_t wi = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE; wi < n_all; wi += waves) {
+        const uint32_t fi = uni(wi < n0 ? S->fp_list[0][wi] : S->fp_list[1][wi - n0]);
+        const uint32_t px = (fi & 0xFFFFu) * T + (lane % T), py = (fi >> 16) * T + (lane / T);
+        const uint64_t zb = (px < P.width && py < P.height) ? S->zbuf[(size_t)py * P.width + px] : 0;
+        uint32_t id = (uint32_t)zb;
+        const uint32_t depth = (uint32_t)(zb >> 32);
+        if (depth <= z_lo || depth > z_hi) id = 0;
+        uint64_t todo = ballot(id != 0);
+        uint32_t k = 0, mine = 0;      // lane k keeps the k-th distinct leaf
+        while (todo) {
+            const uint32_t cur = uni(__shfl(id, __builtin_ctzll(todo), WAVE));
+            if (lane == (int)k) mine = cur;
+            k++;
+            todo &= ~ballot(id == cur);
+        }
+        if (k == 0) continue;
+        const uint32_t b = wi % FH_HIT_BUCKETS;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&S->hit_list[b * FH_HIT_STRIDE], k);
+        base = uni(__shfl(base, 0, WAVE));
+        if ((uint32_t)lane < k && base + lane < bucket_cap) S->hit_list[FH_HIT_BUCKETS * FH_HIT_STRIDE + (size_t)b * bucket_cap + base + lane] = mine;
+    }
+}
+
 // Per-slab reset of the work queues, leaf table and tape arena (frame-persistent tapes stay)
 FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
     for (uint32_t k = i; k < table_words; k += stride) S->leaf_table[k] = FhLeafRef{0, 0, 0, 0};
@@ -1411,6 +1449,8 @@ FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint3
         S->n_leaves = 0; S->n_leaves_lds = 0; S->leaf_cursor = 0; S->leaf_cursor_big = 0; S->normal_cursor = 0; S->normal_cursor_big = 0;
         for (int c = 0; c < 3; c++) { S->fp_count[c] = 0; S->fp_cursor[c] = 0; }
     }
+    if (S->hit_list)
+        for (uint32_t k = i; k < FH_HIT_BUCKETS; k += stride) S->hit_list[k * FH_HIT_STRIDE] = 0;
     if (P0 == 0 && i < n_root_groups) S->queue[0][S->qcap[0] - 1 - i].z = slab * S->P.slab;      // (no pre-pass: slab = one root-tile layer)
     // the coarse levels of the min-depth pyramid are rebuilt by k_minpyramid (not for the first slab: empty image)
     if (reset_root_mind) {
@@ -1424,7 +1464,7 @@ __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t sl
 // Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
 // pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
 __global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, FhLeafRef* leaf_table, uint32_t* fp_lists,
-                             size_t leaf_cap, size_t n_footprints, uint32_t mark) {
+                             size_t leaf_cap, size_t n_footprints, size_t hit_words, uint32_t mark) {
     if (mark) A->arena_frame_end = min(A->arena_head, A->arena_cap);      // (k_mark_frame's work in the same launch: one kernel boundary less on the coarse chain)
     // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
     const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
@@ -1433,8 +1473,8 @@ __global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, FhLea
         FhRenderState* B = A + k;
         *B = *A;
         B->leaves = leaves + (k - 1) * leaf_cap; B->leaf_table = leaf_table + (k - 1) * leaf_cap;
-        uint32_t* fp = fp_lists + (k - 1) * 3 * n_footprints;
-        B->fp_list[0] = fp; B->fp_list[1] = fp + n_footprints; B->fp_list[2] = fp + 2 * n_footprints;
+        uint32_t* fp = fp_lists + (k - 1) * (3 * n_footprints + hit_words);
+        B->fp_list[0] = fp; B->fp_list[1] = fp + n_footprints; B->fp_list[2] = fp + 2 * n_footprints; B->hit_list = fp + 3 * n_footprints;
         B->arena_frame_end = lo + k * part; B->arena_root_end = lo + k * part;
         B->arena_cap = lo + (k + 1) * part;
     }

@@ -43,6 +43,9 @@ struct FhSlot {
 };
 
 // An ambiguous smallest tile: evaluated point by point
+#define FH_HIT_BUCKETS 64u
+#define FH_HIT_STRIDE 64u
+
 struct FhLeaf {
     FhTapeRef tape;
     uint32_t x, y, z;
@@ -130,6 +133,9 @@ struct FhRenderState {
     // 3D: footprints that own leaves this slab, by register-file class (<=16, <=32, LDS)
     uint32_t* fp_list[3];
     uint32_t fp_count[3], fp_cursor[3];
+    // 3D: the slab's leaves that own a hit of the finished z-buffer (leaf index + 1; k_hits3d), one entry = one wave pass of the normals
+    // kernel: FH_HIT_BUCKETS counters FH_HIT_STRIDE words apart, then as many lists of the launch's `bucket_cap` entries each
+    uint32_t* hit_list;
     // 3D: min-depth pyramid, one array per tile level
     uint32_t* mind[FH_MAX_LEVELS];
     // images

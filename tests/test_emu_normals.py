@@ -1,6 +1,6 @@
 """fh_normals (the assembly gradient interpreter, gen_normals.py) on the CPU emulator against a numpy restatement of dev_ops.hpp's
-GRAD semantics (fidget-core/src/types/grad.rs, vm/mod.rs:1091-1397): for every pixel of a footprint whose z-buffer word names a leaf
-of this slab, the gradient of that leaf's tape at the voxel above the hit, through xf_grad (the screen -> model matrix applied to
+GRAD semantics (fidget-core/src/types/grad.rs, vm/mod.rs:1091-1397): for every leaf of the launch's work list and every pixel of its 8 x 8
+whose z-buffer word names it at a depth of this slab, the gradient of that leaf's tape at the voxel above the hit, through xf_grad (the screen -> model matrix applied to
 {x,1,0,0}, {y,0,1,0}, {z,0,0,1} and the division by w) - dx, dy, dz bit for bit, NaN for NaN; the leaf number cleared; pixels of other
 slabs and pixels without a hit untouched.  Several leaves per footprint, affine and projective matrices."""
 import numpy as np
@@ -118,8 +118,8 @@ def xf_grad(m, px, py, pz):
     return [g_div(r[i], r[3]) for i in range(3)]
 
 
-def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel="fh_normals"):
-    """tapes: [(ops, n_regs)]; hits: {(px, py): (leaf index, depth)}.  Returns (zbuf, normals) after one launch over all footprints."""
+def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel="fh_normals", corners=None):
+    """tapes: [(ops, n_regs)]; hits: {(px, py): (leaf index, depth)}; corners: [(x, y)] of each leaf's 8 x 8 pixels.  Returns (zbuf, normals) after one launch."""
     off = U.offsets()
     mem = E.Memory()
     arena = np.zeros(8192, np.uint64)
@@ -133,8 +133,19 @@ def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel
     for (px, py), (leaf, depth) in hits.items():
         zbuf[py * size + px] = (depth << 32) | (leaf + 1)
     normals = np.full(size * size * 3, 7.5, F32)
-    fw = size // 8
-    fps = np.array([(fy << 16) | fx for fy in range(fw) for fx in range(fw)], U32)
+    # the work list k_hits3d makes: every leaf that owns a pixel of the launch's depth range, once (here: in leaf order, plus one leaf
+    # without any hit - the kernel must leave after its z-buffer words)
+    for k, c in enumerate(corners or {}):
+        leaves[k, 3:5] = c
+    n_waves = 128                        # two waves per list
+    ids = sorted({leaf + 1 for leaf, depth in hits.values() if z_lo < depth <= z_hi}) + ([len(tapes)] if tapes else [])
+    cap = 5                              # 64 lists of `cap` entries behind 64 counters 64 words apart (kernels.hip k_hits3d)
+    fps = np.zeros(64 * 64 + 64 * cap, U32)
+    for k, v in enumerate(ids):
+        b = (k * 7) % 64 if k % 3 else k % 2       # (lists of several entries, most lists empty)
+        assert fps[b * 64] < cap
+        fps[64 * 64 + b * cap + fps[b * 64]] = v
+        fps[b * 64] += 1
     a_arena, a_leaves, a_z, a_n, a_fp = mem.map(arena), mem.map(leaves), mem.map(zbuf), mem.map(normals), mem.map(fps)
     st = U.Blob(off["sizeof_state"])
     st.arr(off["P.mat"], np.asarray(mat, F32))
@@ -143,18 +154,34 @@ def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel
         st.u32(off["P.in_kind"] + 4 * s, in_kind[s] if s < len(in_kind) else 3)
         st.f32(off["P.in_value"] + 4 * s, 0.25 + s)
     st.u64(off["arena"], a_arena); st.u64(off["leaves"], a_leaves); st.u64(off["zbuf"], a_z); st.u64(off["normals"], a_n)
-    st.u64(off["fp_list"], a_fp); st.u32(off["fp_count"], len(fps))
+    st.u64(off["hit_list"], a_fp)
     a_st = mem.map(st.b)
     slot = [-1, -1, -1]
     for s_, k in enumerate(list(in_kind) + [3] * (16 - len(in_kind))):
         if k < 3:
             slot[k] = s_
     slots = sum((0xFF if slot[ax] < 0 else slot[ax]) << (8 * ax) for ax in range(3))
-    ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, 3, slots, z_lo, z_hi, 0, 0], U32)
+    ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, n_waves, slots, z_lo, z_hi, cap, 0], U32)
     trans = kernel == "fh_normals_t"
-    E.launch(U.program(), mem, kernel, ka.tobytes(), 3, lds_bytes=16, n_vgpr=218 if trans else 192, wg_y_sgpr=None,
+    E.launch(U.program(), mem, kernel, ka.tobytes(), n_waves, lds_bytes=16, n_vgpr=218 if trans else 192, wg_y_sgpr=None,
              hooks=U.trans_hooks(U.program(), "fh_tn_", 192) if trans else None)
     return zbuf, normals.reshape(size * size, 3)
+
+
+def leaves_of(tapes, size=16):
+    """a leaf per footprint and tape - a leaf's hits lie in its own 8 x 8 pixels: (the leaves' tapes, their corners)"""
+    fw = size // 8
+    lt, cs = [], []
+    for fy in range(fw):
+        for fx in range(fw):
+            for t in tapes:
+                lt.append(t)
+                cs.append((8 * fx, 8 * fy))
+    return lt, cs
+
+
+def leaf_at(px, py, t, n_tapes, size=16):
+    return ((py // 8) * (size // 8) + px // 8) * n_tapes + t
 
 
 def expect(tapes, in_kind, mat, hits, size, z_lo=0, z_hi=1 << 20):
@@ -190,10 +217,12 @@ def test_normals_of_random_shapes(seed, mat):
         tapes.append((tape2, sh2.slot_count()))
     rng = np.random.default_rng(seed)
     hits = {}
+    nt = len(tapes)
+    tapes, corners = leaves_of(tapes)
     for _ in range(70):           # pixels of all four footprints, some sharing a leaf, depths in and out of the slab
         px, py = int(rng.integers(0, 16)), int(rng.integers(0, 16))
-        hits[(px, py)] = (int(rng.integers(0, len(tapes))), int(rng.integers(1, 17)))
-    got_z, got_n = run_normals(tapes, ik, mat, hits, z_lo=2, z_hi=14)
+        hits[(px, py)] = (leaf_at(px, py, int(rng.integers(0, nt)), nt), int(rng.integers(1, 17)))
+    got_z, got_n = run_normals(tapes, ik, mat, hits, z_lo=2, z_hi=14, corners=corners)
     want_z, want_n = expect(tapes, ik, mat, hits, 16, z_lo=2, z_hi=14)
     assert (got_z == want_z).all(), "z-buffer words differ"
     assert same(got_n, want_n), f"{(got_n.view(U32) != want_n.view(U32)).any(axis=1).sum()} normals differ"
@@ -204,10 +233,11 @@ def test_normals_of_a_prospero_leaf_parent():
     ik, ch = chain()
     tape, regs, nch, center, half = ch[1]
     assert regs <= 32
-    hits = {(x, y): (0, 3 + (x + y) % 9) for x in range(0, 16, 3) for y in range(0, 16, 2)}
+    hits = {(x, y): (leaf_at(x, y, 0, 1), 3 + (x + y) % 9) for x in range(0, 16, 3) for y in range(0, 16, 2)}
     mat = [0.125 * 0.25, 0, 0, float(center[0]) - 0.25, 0, -0.125 * 0.25, 0, float(center[1]) + 0.25, 0, 0, 0.125 * 0.25, float(center[2]) - 0.25, 0, 0, 0, 1]
-    got_z, got_n = run_normals([(tape, regs)], ik, mat, hits)
-    want_z, want_n = expect([(tape, regs)], ik, mat, hits, 16)
+    tapes, corners = leaves_of([(tape, regs)])
+    got_z, got_n = run_normals(tapes, ik, mat, hits, corners=corners)
+    want_z, want_n = expect(tapes, ik, mat, hits, 16)
     assert (got_z == want_z).all() and same(got_n, want_n)
     assert np.isfinite(want_n[want_z != 0].astype(np.float64)).all() is not None
 
@@ -237,7 +267,11 @@ def test_normals_with_transcendental_opcodes(which, mat):
     gradient file, and the derivative formulas around the calls)"""
     sh, tape, ik = trans_grad_shape(which)
     rng = np.random.default_rng(which)
-    hits = {(int(rng.integers(0, 16)), int(rng.integers(0, 16))): (0, int(rng.integers(1, 15))) for _ in range(50)}
-    got_z, got_n = run_normals([(tape, sh.slot_count())], ik, mat, hits, kernel="fh_normals_t")
-    want_z, want_n = expect([(tape, sh.slot_count())], ik, mat, hits, 16)
+    hits = {}
+    for _ in range(50):
+        px, py = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        hits[(px, py)] = (leaf_at(px, py, 0, 1), int(rng.integers(1, 15)))
+    tapes, corners = leaves_of([(tape, sh.slot_count())])
+    got_z, got_n = run_normals(tapes, ik, mat, hits, kernel="fh_normals_t", corners=corners)
+    want_z, want_n = expect(tapes, ik, mat, hits, 16)
     assert (got_z == want_z).all() and same(got_n, want_n), f"{(got_n.view(U32) != want_n.view(U32)).any(axis=1).sum()} normals differ"
