@@ -1338,6 +1338,9 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_WGID}, s2
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
+    if trans:       # the table registers of the hand-written exp4 (gen_trans.py), once per wave
+        import gen_trans
+        gen_trans.exp_table_init(a, t_base, lane=V_LANE)
     a(f"""
 	s_mov_b32 {V_PINF}, 0x7f800000
 	s_mov_b32 s58, 1.0
@@ -1868,6 +1871,8 @@ def gen_trans_probe(a):
     for ci, (prefix, vb, fns) in enumerate(gen_trans.COPIES):
         nxt = a.label("copy")
         a(f"\ts_cmp_lg_u32 s7, {ci}\n\ts_cbranch_scc1 {nxt}")
+        if "exp4" in fns:       # (the hand-written exp4 keeps its table in two registers of the window)
+            gen_trans.exp_table_init(a, vb, prefix, lane="v0")
         for fn in fns:
             fi = all_fns.index(fn)
             skip = a.label("fn")
