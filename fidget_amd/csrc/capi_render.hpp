@@ -770,7 +770,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int push_mul = 2;
     const int gpush = (level + 1 == (int)R.S.P.n_levels) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
-        if (is3d) FH_KLAUNCH(k_tpush3d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
+        // (above the leaf level: 16 more waves per parent for the fills of its interval-full children - kernels.hip tfill3d_body)
+        if (is3d) FH_KLAUNCH(k_tpush3d, dim3(gpush, (level + 1 == (int)R.S.P.n_levels) ? 1 : 17), dim3(WAVE), 0, ctx->stream, dS, level);
         else {
             if (!R.classify_only) FH_KLAUNCH(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
             const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);

@@ -987,7 +987,9 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         const bool full = act && fills && hi < 0.0f, empty = act && fills && !full && lo > 0.0f;  // voxel.rs:310-320
         const bool amb = act && !full && !empty;
         const uint64_t fullm = ballot(full);
-        uint64_t fm = IS3D ? fullm : 0ull;      // (2D: k_tfill2d, one workgroup per decided tile - the root level's 128 x 128 fills by 16 waves took 1.9 ms)
+        // (2D: k_tfill2d, one workgroup per decided tile - the root level's 128 x 128 fills by 16 waves took 1.9 ms; 3D above the leaf
+        // level: the launch's fill waves, tfill3d_body - blockIdx.y > 0)
+        uint64_t fm = (IS3D && gridDim.y == 1) ? fullm : 0ull;
         while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317)
             const int c = __builtin_ctzll(fm);
             fm &= fm - 1;
@@ -1072,7 +1074,46 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         }
     }
 }
-__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) { tpush_body<true>(S, level, blockIdx.x, gridDim.x); }
+// 3D fills of the levels above the leaves by waves of their own (k_tpush3d's blockIdx.y = 1 .. parts): a parent's wave took its
+// interval-full children one after the other - T x T atomics each, 1024 at T = 32 - and a model with a solid interior has most of its
+// few dozen pre-pass parents full of them: bear.vm 512^3, 187 us of a 1 ms frame in ONE launch of 64 busy waves.  Here `parts` waves
+// share a parent's children, and a full child behind another full child of the same parent (same x, y, smaller z: its fill is the
+// smaller number of an atomic max) is skipped.
+FH_DEV void tfill3d_body(FhRenderState* S, int level, uint32_t first, uint32_t stride, uint32_t part, uint32_t parts) {
+    const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
+    const int lane = threadIdx.x;
+    const uint32_t T = P.tiles[level];
+    const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    for (uint32_t si = first; si < n0 + n1; si += stride) {
+        const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
+        if (uni((uint32_t)(sl.act != 0)) == 0) continue;
+        const bool full = ((sl.act >> lane) & 1) && sl.res[1][lane] < 0.0f;   // voxel.rs:310-317
+        uint64_t fm = ballot(full);
+        if (fm == 0) continue;
+        const uint32_t cx = sl.corner[0][lane], cy = sl.corner[1][lane], cz = sl.corner[2][lane];
+        // (instances stacked along z by a column-invariant parent: tpush_body)
+        const uint32_t copies0 = level == 0 ? uni(sl.level >> 8) : 1u;
+        const uint32_t zi = level > 0 ? uni((uint32_t)(uintptr_t)sl.tvals) : 0u;
+        const bool inv = (zi & 1) != 0 || copies0 > 1;
+        const uint32_t ninst = level == 0 ? copies0 : (inv ? (zi >> 8) * (P.tiles[level - 1] / T) : 1u);
+        while (fm) {
+            const int c = __builtin_ctzll(fm);
+            fm &= fm - 1;
+            if ((uint32_t)c % parts != part) continue;
+            const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE), ccz = __shfl(cz, c, WAVE);
+            if (ballot(full && cx == ccx && cy == ccy && cz > ccz)) continue;
+            const uint64_t v = (uint64_t)(ccz + (ninst - 1) * T + T + 1) << 32;   // fill_z = corner_z + T + 1 (voxel.rs:283), of the nearest instance
+            for (uint32_t p = lane; p < T * T; p += WAVE) {
+                const uint32_t x = ccx + (p % T), y = ccy + (p / T);
+                if (x < P.width && y < P.height) atomicMax((unsigned long long*)&S->zbuf[(size_t)y * P.width + x], (unsigned long long)v);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
+    if (blockIdx.y == 0) tpush_body<true>(S, level, blockIdx.x, gridDim.x);
+    else tfill3d_body(S, level, blockIdx.x, gridDim.x, blockIdx.y - 1, gridDim.y - 1);
+}
 __global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level, blockIdx.x, gridDim.x); }
 // 2D fills (pixel.rs:345-368, 225-229): a tile whose interval is decided becomes a NaN-boxed fill carrying the level it was
 // decided at and whether it is inside.  grid (64 children, slots of the level's upper bound), one workgroup per tile.
