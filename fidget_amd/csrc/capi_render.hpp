@@ -15,6 +15,7 @@ struct RenderSetup {
     uint32_t slab_lo = 0, slab_hi = 1;   // z-slabs this render covers (all of them unless the volume is split in z: octant shards)
     size_t lds_tiles_mid = 0, lds_tiles_big = 0, lds_tiles_small = 0, lds_points_big = 0, lds_normals_big = 0, lds_normals_small = 0;
     uint32_t table_words = 0, n_footprints = 0, groups_per_slab = 0;
+    bool smooth_tape = false;      // the root tape has a choice in fewer than every tenth op (and more than 200 ops): a blend whose leaves stay long
     uint32_t hit_bucket_cap = 0;   // the normals kernel's work lists (k_hits3d): entries per bucket, words of the whole thing per slab context
     size_t hit_words = 0;
     size_t mind_words = 0;      // words of the min-depth pyramid (cleared at the head of the frame)
@@ -293,6 +294,7 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
         for (size_t i = 0; i < mine.size(); i += TL) runs.push_back(Run{mine[i], (uint32_t)std::min<size_t>(TL, mine.size() - i), n_shards});
     }
     FhTapeRef root{0, (uint32_t)t.ops.size(), (uint16_t)t.n_regs, (uint16_t)t.n_choices};
+    R.smooth_tape = t.ops.size() > 200 && (size_t)t.n_choices * 10 < t.ops.size();
     // Column invariance at the ROOT: a root tape that reads no input varying along a pixel column, under a camera
     // that keeps x and y fixed along it, has the same interval, the same choices and the same pruned tape in every root tile of a
     // column of root tiles.  One layer per z-slab is evaluated (the slab's back-most: FhGroup::x = how many layers of the slab it stands
@@ -1235,7 +1237,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 // front group first; option column_group = g, 0: the block walk below).  A wave keeps its footprint: the pixels' set-up,
                 // their matrix products and their z-buffer words are loaded once per wave instead of once per leaf (the z-buffer words
                 // were two thirds of the launch's HBM traffic), hits stay in registers from leaf to leaf and leave in one atomic.
-                const uint32_t g = by_columns ? 6u : (uint32_t)std::min(std::max(ctx->opt.column_group, 0), 6);
+                // (a blend - few min / max, nothing to prune: bear.vm's leaves keep 350 of the root's 650 ops - wants half the group: a wave's
+                // leaves are taken one after the other, and the launch lasts as long as its fullest waves - 512^3, ms per frame by g = 0 / 1 /
+                // 2 / 3: 1.24 / 0.97 / 1.09 / 1.33; prospero.vm's 22-op leaves on the general path: 0.433 / 0.424 ms per launch by g = 1 / 2)
+                const uint32_t g_opt = (uint32_t)std::min(std::max(ctx->opt.column_group, 0), 6);
+                const uint32_t g = by_columns ? 6u : (R.smooth_tape && g_opt > 1 ? g_opt - 1 : g_opt);
                 if ((by_columns && layers <= 64) || (!by_columns && g > 0)) {
                     struct { FhRenderState* S; uint32_t n_waves, slots, depmask, flags, pad[2]; const void* table; uint32_t nfpl, layers; } ka =
                         {dS, 0u, R.col_slots, R.col_depmask, R.col_flags | (1u << 20) | (g << 24), {0, 0}, slab_table, R.n_footprints, layers};

@@ -201,6 +201,7 @@ class Interp:
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.t_base = 128    # ... whose register window starts here (behind the register file)
         self.wide_trans = False   # the four-sample routines are embedded too (window of gen_trans.WIDE_V registers)
+        self.exp2 = False         # EXP by the hand-written two-sample expf (gen_trans.exp_pair) inside the handler
         self.t_prefix = "fh_t_"   # ... and whose labels start with this (every kernel embeds its own copies)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.hl = HSTRIDE_LOG2
@@ -604,6 +605,21 @@ class Interp:
                 self.idx_off()
                 if "no" + fn in EXP.split(","):       # experiment: what the routine costs (a copy in its place)
                     return self.write_out(VT)
+                if fn == "exp" and self.exp2:
+                    import gen_trans
+                    slow, join = a.label("exp_special"), a.label("exp_done")
+                    gen_trans.exp_consts(a, self.t_base)
+                    gen_trans.exp_special(a, self.t_base, VT[:self.zb], slow)
+                    for j0 in range(0, self.zb, 2):
+                        gen_trans.exp_pair(a, self.t_base, VT[j0:j0 + 2], VU[j0:j0 + 2])
+                    a(f"{join}:")
+                    self.write_out(VU)
+                    a(f"{slow}:")                   # some lane's |x| >= 88: glibc's special cases, by the compiled routine, sample by sample
+                    for j in Z:
+                        a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
+                        self.call(fn)
+                        a(f"\tv_mov_b32 {VU[j]}, v{self.t_base}")
+                    return a(f"\ts_branch {join}")
                 for rep in range(2 if "twice" + fn in EXP.split(",") else 1):     # experiment: the routine's cost once more, same results
                   if self.zb % 4 == 0 and ((self.wide_trans is True and fn in ("sin", "cos", "exp", "ln")) or (self.wide_trans == "sincos" and fn in ("sin", "cos"))):
                       for j0 in range(0, self.zb, 4):       # four samples per call (gen_trans.FUNCS4)
@@ -643,10 +659,10 @@ class Interp:
                 A, B = (VT, VU) if form != "IR" else (VU, VT)
                 if base == "MIX":                 # rng::mix (rng/mod.rs:30-33): hash(a + hash(b)) on the bit patterns
                     self.pcg_consts()
-                    for j in Z:
-                        self.pcg(B[j], VW[j])
-                        a(f"\tv_add_u32 {VW[j]}, {A[j]}, {VW[j]}")
-                        self.pcg(VW[j], VW[j])
+                    for j in Z:                   # (through VD[2]: VW may be VT - the compact map)
+                        self.pcg(B[j], VD[2])
+                        a(f"\tv_add_u32 {VD[2]}, {A[j]}, {VD[2]}")
+                        self.pcg(VD[2], VW[j])
                 else:
                     for j in Z:
                         a(f"\tv_mov_b32 v{self.t_base}, {A[j]}\n\tv_mov_b32 v{self.t_base + 1}, {B[j]}")
@@ -1291,7 +1307,11 @@ def gen_columns(a, variants, off, trans=None):
     if trans:   # same generator into a scratch buffer, labels renamed, the routines embedded next to the handlers (s_branch range)
         b = Asm()
         b.uid = a.uid + 100000
-        r = _gen_columns_body(b, variants, off, kname, trans)
+        set_reg_map("compact")
+        try:
+            r = _gen_columns_body(b, variants, off, kname, trans)
+        finally:
+            set_reg_map("default")
         a(b.text().replace(".Lfh_columns_", ".Lfh_columns_t_"))
         return r
     set_reg_map("default" if EXP == "file64" else "compact")
@@ -1305,12 +1325,19 @@ def _gen_columns_body(a, variants, off, kname, trans):
     o = off
     m = S_MAT
     file_regs = max(nr * zb for nr, zb in variants)
-    t_base = FILE + file_regs                # the routines' register window behind the register file: 64 VGPRs (the four-sample routines;
-    nvg = t_base + 64 if trans else FILE + file_regs   # 192 + 64 = 256: still two waves per SIMD, as with 26)
+    # the routines' register window behind the register file: 24 VGPRs - the one-sample routines, sin4 / cos4, the hand-written expf's
+    # 22 and its table's two: 48 + 96 + 24 = 168 registers, THREE waves per SIMD (round 6; it was 64 + 128 + 64 = 256 and two: the
+    # plain kernel at two / three / four waves takes 0.626 / 0.477 / 0.419 ms per launch on the general path)
+    import gen_trans
+    t_base = FILE + file_regs
+    nvg = t_base + gen_trans.EXP2_WINDOW if trans else FILE + file_regs
+    if EXP.startswith("vgpr") and not trans:      # experiment: the plain kernel at a lower occupancy (registers it does not use)
+        nvg = int(EXP[4:])
     its = [Interp(a, f"{kname}_{nr}x{zb}", nr, zb, "columns", off, trans=bool(trans)) for nr, zb in variants]
     for it in its:
         it.t_base = t_base
-        it.wide_trans = bool(trans)
+        it.wide_trans = "sincos" if trans else False
+        it.exp2 = bool(trans)
     inplace_mask = 0
     for k, op in enumerate(OPS):
         if op in Interp.INPLACE:
@@ -1338,8 +1365,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_mov_b32 {S_WGID}, s2
 	s_mov_b32 {S_WGY}, s3""")
     common_consts(a)
-    if trans:       # the table registers of the hand-written exp4 (gen_trans.py), once per wave
-        import gen_trans
+    if trans:       # the table registers of the hand-written expf (gen_trans.py), once per wave
         gen_trans.exp_table_init(a, t_base, lane=V_LANE)
     a(f"""
 	s_mov_b32 {V_PINF}, 0x7f800000
@@ -1796,7 +1822,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
         a(f"\t.long {lut_bits(its[0], k)}")
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans, v_base=t_base, wide=True)
+        gen_trans.embed(a, trans, v_base=t_base, wide="sincos", exp2=True)
     for it in its:
         it.emit()
     return kname, nvg
@@ -1871,11 +1897,38 @@ def gen_trans_probe(a):
     for ci, (prefix, vb, fns) in enumerate(gen_trans.COPIES):
         nxt = a.label("copy")
         a(f"\ts_cmp_lg_u32 s7, {ci}\n\ts_cbranch_scc1 {nxt}")
-        if "exp4" in fns:       # (the hand-written exp4 keeps its table in two registers of the window)
+        if "exp2" in fns:       # (the hand-written expf keeps its table in two registers of the window)
             gen_trans.exp_table_init(a, vb, prefix, lane="v0")
         for fn in fns:
-            fi = all_fns.index(fn)
             skip = a.label("fn")
+            if fn == "exp2":        # the two-sample expf of the EXP handlers (gen_trans.exp_pair), as they hold it, under exp4's number
+                slow = a.label("probe_exp_special")
+                a(f"\ts_cmp_lg_u32 s8, {all_fns.index('exp4')}\n\ts_cbranch_scc1 {skip}")
+                gen_trans.exp_consts(a, vb)
+                gen_trans.exp_special(a, vb, [f"v{2 + k}" for k in range(4)], slow)
+                gen_trans.exp_pair(a, vb, ["v2", "v3"], ["v10", "v11"])
+                gen_trans.exp_pair(a, vb, ["v4", "v5"], ["v12", "v13"])
+                a(f"\ts_branch .Lfh_trans_probe_store\n{slow}:")
+                for k in range(4):
+                    here, ret, h2 = a.label("call"), a.label("ret"), a.label("far")
+                    a(f"""
+	v_mov_b32 v{vb}, v{2 + k}
+	s_getpc_b64 s[96:97]
+{here}:
+	s_add_u32 s96, s96, {ret} - {here}
+	s_addc_u32 s97, s97, 0
+	s_getpc_b64 s[98:99]
+{h2}:
+	s_mov_b32 s100, {prefix}exp - {h2}
+	s_ashr_i32 s101, s100, 31
+	s_add_u32 s98, s98, s100
+	s_addc_u32 s99, s99, s101
+	s_setpc_b64 s[98:99]
+{ret}:
+	v_mov_b32 v{10 + k}, v{vb}""")
+                a(f"\ts_branch .Lfh_trans_probe_store\n{skip}:")
+                continue
+            fi = all_fns.index(fn)
             a(f"\ts_cmp_lg_u32 s8, {fi}\n\ts_cbranch_scc1 {skip}")
             for j in ([0] if fn.endswith("4") else range(4)):
                 if fn.endswith("4"):
@@ -2032,11 +2085,11 @@ def main():
     n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)) if EXP == "file64" else ((10, 8), (20, 4), (32, 2)), off)
     ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
-        # (a register file of 128 VGPRs here - 16 registers x 8 voxels, 32 x 4: the tapes that carry these opcodes are smooth blends
-        # that prune little - bear.vm's leaves keep 350-430 ops in 17-23 registers -, and two passes of four voxels pay the per-op
-        # dispatch half as often as four passes of two: 2.80 -> 2.40 ms per 512^3 frame; 218 VGPRs with the routines' window, two
-        # waves per SIMD as with 160)
-        n, nvg = gen_columns(a, ((16, 8), (32, 4), (32, 2)), off, trans=sys.argv[3])
+        # (the compact map with a register file of 96 VGPRs - 12 registers x 8 voxels, 24 x 4, 32 x 2: the tapes that carry these opcodes
+        # are smooth blends that prune little - bear.vm's leaves keep 350-430 ops in 17-23 registers -, and two passes of four voxels pay
+        # the per-op dispatch half as often as four passes of two; with the routines' window of 24 registers 168 VGPRs, three waves
+        # per SIMD - it was 64 + 128 + 64 = 256 and two)
+        n, nvg = gen_columns(a, ((22, 8), (32, 4), (32, 2)), off, trans=sys.argv[3])
         ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)

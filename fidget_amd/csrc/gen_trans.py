@@ -85,20 +85,21 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None, MAX_V=MAX_V):
     return "\n".join(out)
 
 
-# ---- expf for four samples, written by hand (the leaf kernel of tapes with transcendental opcodes: a third of bear.vm's time there
-# was the compiled exp4 - 167 instructions per call, 42 per sample) -------------------------------------------------------------
+# ---- expf for two samples at a time, written by hand and part of the EXP handlers themselves (the leaf kernel of tapes with transcendental opcodes: a tenth of bear.vm's frame
+# was the compiled exp4 - 167 instructions per call, 42 per sample - and its window of 64 registers kept the kernel at two waves
+# per SIMD) ----------------------------------------------------------------------------------------------------------------------
 # The same operations as trans_libm.hpp expf_main_ (glibc e_expf.c: two fused operations for k and r, the table value times a degree-3
-# polynomial, all in binary64), 14 instructions per sample:
+# polynomial, all in binary64), 13 instructions per sample in 22 registers of the window:
 #  - the table 2^(i/32) lives in TWO VGPRs of the wave (lane l: entry l % 32; EXP_TAB below, loaded once per wave by exp_table_init): a
 #    sample's entry comes by two ds_bpermute_b32 instead of a 64-bit load from memory whose latency every call waited for;
 #  - `t + (ki << 47)` only touches the table value's high word: (ki << 47) has no low word, so it is one v_lshl_add_u32 of the low word of
 #    kd's bit pattern (bits 0..16 of ki reach bits 47..63);
-#  - the constants that an instruction may take only one of from scalar registers (gfx9: one constant-bus operand) are split between
-#    scalar pairs and two vector pairs set up per call.
-# |x| >= 88 (glibc's special cases: overflow, underflow, infinities) in any lane of any of the four samples: the compiled one-sample
-# routine for each (rare: the path of every shape value far from 0 goes through exp(-large) only in models that saturate).  NaN
-# arguments take the main path and come out NaN (the class is what is modelled, as everywhere).
-EXP_TAB = 62          # window registers v<base + 62>, v<base + 63>: the table's low / high words
+#  - an instruction takes one operand from scalar registers (gfx9: one constant-bus operand): of the pairs (InvLn2N, SHIFT) and (C0, C1)
+#    that meet in one fused operation each, SHIFT and C1 are vector pairs set up per call.
+# |x| >= 88 (glibc's special cases: overflow, underflow, infinities) in any lane of any sample of the op: the compiled one-sample
+# routine for each.  NaN arguments take the main path and come out NaN (the class is what is modelled, as everywhere).
+EXP_TAB = 22          # window registers v<base + 22>, v<base + 23>: the table's low / high words
+EXP2_WINDOW = 24
 
 
 def _f64(x):
@@ -118,7 +119,7 @@ def exp2_table():
 
 
 def exp_table_init(a, v_base, prefix="fh_t_", lane="v0"):
-    """loads the table registers of the hand-written exp4 (once per wave; clobbers s86..s89; `lane` = the lane's number)"""
+    """loads the table registers of the hand-written exp2 (once per wave; clobbers s86..s89; `lane` = the lane's number)"""
     here = a.label("exptab")
     lo, hi = v_base + EXP_TAB, v_base + EXP_TAB + 1
     a(f"""
@@ -134,88 +135,81 @@ def exp_table_init(a, v_base, prefix="fh_t_", lane="v0"):
 	s_waitcnt vmcnt(0)""")
 
 
-def exp4_hand(a, prefix, vb):
-    """<prefix>exp4: v<vb>..v<vb+3> in and out, return address s[96:97]; clobbers v<vb+4>..v<vb+55>, s86..s95, vcc; needs exp_table_init"""
-    X = [f"v{vb + j}" for j in range(4)]
-    pair = lambda r: f"v[{r}:{r + 1}]"
-    P = [vb + 4 + 10 * j for j in range(4)]          # per sample: five pairs A (xd, z) B (kd) C (r, y) D (table value) E (kd - SHIFT, r2)
-    SH, C1, T = vb + 44, vb + 46, vb + 48
-    SAVE, KEEP = vb + 50, vb + 52                    # (slow path: the return address, the four arguments / results - above the one-sample routines' window)
-    TLO, THI = f"v{vb + EXP_TAB}", f"v{vb + EXP_TAB + 1}"
+def exp_consts(a, vb):
+    """the constants of exp_pair: s[86:87] InvLn2N, s[88:89] C0, s[90:91] C2, s92 88.0f; v[vb:vb+1] SHIFT, v[vb+2:vb+3] C1"""
     inv, c0, c2 = _f64("0x1.71547652b82fep+5"), _f64("0x1.c6af84b912394p-20"), _f64("0x1.62e42ff0c52d6p-6")
     sh, c1 = _f64("0x1.8p+52"), _f64("0x1.ebfce50fac4f3p-13")
-    slow = f".L{prefix}exp4_slow"
     a(f"""
-	.p2align 6
-{prefix}exp4:
-	v_max3_f32 v{T}, |{X[0]}|, |{X[1]}|, |{X[2]}|
 	s_mov_b32 s92, 0x42b00000                          ; 88.0
-	v_max_f32_e64 v{T}, |{X[3]}|, v{T}
 	s_mov_b32 s86, {inv[0]:#x}
 	s_mov_b32 s87, {inv[1]:#x}
 	s_mov_b32 s88, {c0[0]:#x}
 	s_mov_b32 s89, {c0[1]:#x}
 	s_mov_b32 s90, {c2[0]:#x}
 	s_mov_b32 s91, {c2[1]:#x}
-	v_cmp_ngt_f32 vcc, s92, v{T}
-	v_mov_b32 v{SH}, {sh[0]:#x}
-	v_mov_b32 v{SH + 1}, {sh[1]:#x}
-	v_mov_b32 v{C1}, {c1[0]:#x}
-	v_mov_b32 v{C1 + 1}, {c1[1]:#x}
-	s_cbranch_vccnz {slow}""")
-    A, B, C, D, E = ([p + 2 * k for p in P] for k in range(5))
-    for j in range(4):
-        a(f"	v_cvt_f64_f32 {pair(A[j])}, {X[j]}")
-    for j in range(4):
+	v_mov_b32 v{vb}, {sh[0]:#x}
+	v_mov_b32 v{vb + 1}, {sh[1]:#x}
+	v_mov_b32 v{vb + 2}, {c1[0]:#x}
+	v_mov_b32 v{vb + 3}, {c1[1]:#x}""")
+
+
+def exp_special(a, vb, xs, slow):
+    """branches to `slow` when any of the samples xs is one of expf's special cases (|x| >= 88; after exp_consts; scratch v<vb+4>, vcc)"""
+    t = f"v{vb + 4}"
+    ab = [f"|{x}|" for x in xs]
+    if len(ab) == 2:
+        a(f"	v_max_f32_e64 {t}, {ab[0]}, {ab[1]}")
+    else:
+        a(f"	v_max3_f32 {t}, {ab[0]}, {ab[1]}, {ab[2]}")
+        k = 3
+        while len(ab) - k >= 2:
+            a(f"	v_max3_f32 {t}, {t}, {ab[k]}, {ab[k + 1]}")
+            k += 2
+        if k < len(ab):
+            a(f"	v_max_f32_e64 {t}, {ab[k]}, {t}")
+    a(f"	v_cmp_ngt_f32 vcc, s92, {t}\n	s_cbranch_vccnz {slow}")
+
+
+def exp_pair(a, vb, xin, xout):
+    """xout[j] = expf(xin[j]), j = 0, 1, for arguments that are not special (exp_special); window registers v<vb+4>..v<vb+21>, the
+    constants of exp_consts, the table registers of exp_table_init"""
+    pair = lambda r: f"v[{r}:{r + 1}]"
+    SH, C1 = vb, vb + 2
+    A, B, E, D = ([vb + 4 + 8 * j + 2 * k for j in range(2)] for k in range(4))     # per sample: xd / z, kd / r / y, kd - SHIFT / r2, the table value
+    K = [vb + 20, vb + 21]                                                          # ... and the low word of kd's bits
+    TLO, THI = f"v{vb + EXP_TAB}", f"v{vb + EXP_TAB + 1}"
+    R2 = range(2)
+    for j in R2:
+        a(f"	v_cvt_f64_f32 {pair(A[j])}, {xin[j]}")
+    for j in R2:
         a(f"	v_fma_f64 {pair(B[j])}, s[86:87], {pair(A[j])}, {pair(SH)}")                 # kd = InvLn2N x + SHIFT
-    for j in range(4):
+    for j in R2:
         a(f"	v_lshlrev_b32 v{D[j] + 1}, 2, v{B[j]}")
         a(f"	ds_bpermute_b32 v{D[j]}, v{D[j] + 1}, {TLO}")
         a(f"	ds_bpermute_b32 v{D[j] + 1}, v{D[j] + 1}, {THI}")
-    for j in range(4):
+    for j in R2:
         a(f"	v_add_f64 {pair(E[j])}, {pair(B[j])}, -{pair(SH)}")                           # kd - SHIFT
-    for j in range(4):
-        a(f"	v_fma_f64 {pair(C[j])}, s[86:87], {pair(A[j])}, -{pair(E[j])}")               # r = InvLn2N x - kd
-    for j in range(4):
-        a(f"	v_fma_f64 {pair(A[j])}, s[88:89], {pair(C[j])}, {pair(C1)}")                  # z = C0 r + C1
-        a(f"	v_mul_f64 {pair(E[j])}, {pair(C[j])}, {pair(C[j])}")                          # r2
-    for j in range(4):
-        a(f"	v_fma_f64 {pair(C[j])}, s[90:91], {pair(C[j])}, 1.0")                         # y = C2 r + 1
-    for j in range(4):
-        a(f"	v_fma_f64 {pair(C[j])}, {pair(A[j])}, {pair(E[j])}, {pair(C[j])}")            # y = z r2 + y
+        a(f"	v_mov_b32 v{K[j]}, v{B[j]}")
+    for j in R2:
+        a(f"	v_fma_f64 {pair(B[j])}, s[86:87], {pair(A[j])}, -{pair(E[j])}")               # r = InvLn2N x - kd
+    for j in R2:
+        a(f"	v_fma_f64 {pair(A[j])}, s[88:89], {pair(B[j])}, {pair(C1)}")                  # z = C0 r + C1
+        a(f"	v_mul_f64 {pair(E[j])}, {pair(B[j])}, {pair(B[j])}")                          # r2
+    for j in R2:
+        a(f"	v_fma_f64 {pair(B[j])}, s[90:91], {pair(B[j])}, 1.0")                         # y = C2 r + 1
+    for j in R2:
+        a(f"	v_fma_f64 {pair(B[j])}, {pair(A[j])}, {pair(E[j])}, {pair(B[j])}")            # y = z r2 + y
     a("	s_waitcnt lgkmcnt(0)")
-    for j in range(4):
-        a(f"	v_lshl_add_u32 v{D[j] + 1}, v{B[j]}, 15, v{D[j] + 1}")                        # s = T[ki % 32] + (ki << 47)
-    for j in range(4):
-        a(f"	v_mul_f64 {pair(C[j])}, {pair(C[j])}, {pair(D[j])}")
-    for j in range(4):
-        a(f"	v_cvt_f32_f64 {X[j]}, {pair(C[j])}")
-    a(f"	s_setpc_b64 s[96:97]")
-    a(f"{slow}:")
-    a(f"	v_writelane_b32 v{SAVE}, s96, 0")
-    a(f"	v_writelane_b32 v{SAVE}, s97, 1")
-    for j in range(4):
-        a(f"	v_mov_b32 v{KEEP + j}, {X[j]}")
-    for j in range(4):
-        here, ret = a.label("x4call"), a.label("x4ret")
-        a(f"""
-	v_mov_b32 v{vb}, v{KEEP + j}
-	s_getpc_b64 s[96:97]
-{here}:
-	s_add_u32 s96, s96, {ret} - {here}
-	s_addc_u32 s97, s97, 0
-	s_branch {prefix}exp
-{ret}:
-	v_mov_b32 v{KEEP + j}, v{vb}""")
-    for j in range(4):
-        a(f"	v_mov_b32 {X[j]}, v{KEEP + j}")
-    a(f"""
-	v_readlane_b32 s96, v{SAVE}, 0
-	v_readlane_b32 s97, v{SAVE}, 1
-	s_nop 3
-	s_setpc_b64 s[96:97]
-	.p2align 3
-{prefix}exp2_tab:""")
+    for j in R2:
+        a(f"	v_lshl_add_u32 v{D[j] + 1}, v{K[j]}, 15, v{D[j] + 1}")                        # s = T[ki % 32] + (ki << 47)
+    for j in R2:
+        a(f"	v_mul_f64 {pair(B[j])}, {pair(B[j])}, {pair(D[j])}")
+    for j in R2:
+        a(f"	v_cvt_f32_f64 {xout[j]}, {pair(B[j])}")
+
+
+def exp_table(a, prefix):
+    a(f"	.p2align 3\n{prefix}exp2_tab:")
     for v in exp2_table():
         a(f"	.quad {v:#x}")
 
@@ -223,7 +217,7 @@ def exp4_hand(a, prefix, vb):
 COPIES = []      # (prefix, v_base, routine names) of every embed(): the probe kernel (gen_interp.py gen_trans_probe) reaches each copy
 
 
-def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
+def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=None):
     """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
     window embeds its own copies: `s_branch` reaches 128 KB); s_map: the ten scalar registers s0..s9 go to (default s86..s95; pairs
     must stay even-aligned pairs), the return address always to s[96:97]; wide: also the four-sample routines FUNCS4, and a window of
@@ -231,12 +225,11 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False):
     txt = open(path).read()
     # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
     extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
-    COPIES.append((prefix, v_base, FUNCS + extra))
+    COPIES.append((prefix, v_base, FUNCS + extra + (["exp2"] if exp2 else [])))
+    if exp2:       # the kernel's handlers hold the two-sample expf written by hand (exp_pair): its table
+        exp_table(a, prefix)
     for f in FUNCS + extra:
-        if f == "exp4" and wide is True:      # written by hand (above); the compiled one stays the reference of tests/test_gpu_math.py's probe
-            exp4_hand(a, prefix, v_base)
-            continue
         m = re.search(rf"^fh_t_{f}:.*?\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M)
         assert m, f
         a(f"\t.p2align 6\n{prefix}{f}:")
-        a(_rename(m.group(1), f, v_base, prefix, s_map, WIDE_V if wide is True else MAX_V))
+        a(_rename(m.group(1), f, v_base, prefix, s_map, WIDE_V if wide is True else (EXP_TAB if exp2 else MAX_V)))

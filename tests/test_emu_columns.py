@@ -72,8 +72,8 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     ka = col_kernarg(a_st, in_kind, mat, size, column_mode, group_log2, a_tab=a_tab, layers=layers)
     trans = kernel == "fh_columns_t"
     gx, gy = ((nfp + 63) // 64 * 64, (layers + (1 << group_log2) - 1) >> group_log2) if column_mode else ((nfp + 3) // 4, layers)
-    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=256 if trans else 128,
-                     hooks=U.trans_hooks(U.program(), v_base=192, window=64) if trans else None)
+    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=248 if trans else 128,
+                     hooks=U.trans_hooks(U.program(), v_base=224, window=22) if trans else None)     # (window registers 22, 23: the hand-written expf's table)
     return zbuf, waves
 
 
@@ -385,7 +385,7 @@ def test_column_mode_in_the_transcendental_kernel():
 def _leaf_values(tape, n_regs, ik, mat, leaf=(0, 0, 0), kernel="fh_columns"):
     """run ONE leaf of an 8-voxel-per-lane class and return the tape's output for its 64 pixels x 8 voxels as the kernel left it in
     VT (v18 .. v25: the OUTPUT handler of the compact register map leaves it there; sample j = voxel z + 7 - j), next to numpy's"""
-    _, ws = run_columns(tape, n_regs, ik, mat, leaf)
+    _, ws = run_columns(tape, n_regs, ik, mat, leaf, kernel=kernel)
     w = max(ws, key=lambda w: w.counts.get("valu", 0))
     got = np.stack([np.asarray(w.v[18 + j]).view(F32) for j in range(8)], axis=1)       # [lane][sample]: VT, where the compact register map leaves the output
     lx, ly, lz = leaf
@@ -472,4 +472,33 @@ def test_generic_binary_ops_in_the_ten_register_file(mat):
                 got, want = _leaf_values(np.array(t, np.uint64), 10, ik, mat)
                 if not _same_bits(got, want):
                     bad.append((name, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad
+
+
+def test_hand_written_expf_in_the_transcendental_kernel():
+    """fh_columns_t's EXP handler holds expf itself (gen_trans.py exp_pair: glibc's operations in binary64 by hand, the 2^(i/32) table in
+    two VGPRs) - executed here instruction by instruction (the emulator's v_fma_f64 is exact rational arithmetic) against the host
+    libm, bit for bit: arguments of every size - fractions, tens, beyond +-88 (the special cases: the compiled routine, sample by
+    sample, for the whole op), infinities, NaNs, zeros of both signs, subnormals."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    bad = []
+    for scale in (0.37, 3.0, 41.0, 87.9, 95.0, 300.0, 1e30, 1e-40, 0.0, -0.0):
+        t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 2), P(OP["MUL_RR"], 0, 0, 1), P(OP["MUL_RI"], 0, 0, f(scale)), P(OP["EXP"], 2, 0, 0), P(OP["OUTPUT"], 0, 2, 0)]
+        got, want = _leaf_values(np.array(t, np.uint64), 3, ik, ROTATED, kernel="fh_columns_t")
+        if not _same_bits(got, want):
+            bad.append((scale, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    # ... and of NaN (sqrt of a negative number in some lanes) and of infinities of either sign (x / 0)
+    for sign in ("COPY_REG", "NEG"):
+        t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 1), P(OP["SUB_RI"], 1, 1, f(0.3)), P(OP["SQRT"], 1, 1, 0), P(OP["EXP"], 2, 1, 0),
+             P(OP["SUB_RR"], 3, 0, 0), P(OP["RECIP"], 3, 3, 0), P(OP["MUL_RR"], 3, 3, 0), P(OP[sign], 3, 3, 0), P(OP["EXP"], 4, 3, 0), P(OP["OUTPUT"], 0, 4, 0)]
+        got, want = _leaf_values(np.array(t, np.uint64), 5, ik, ROTATED, kernel="fh_columns_t")
+        assert (np.isinf(want).any() if sign == "NEG" else (want == 0).any())
+        if not _same_bits(got, want):
+            bad.append(("inf " + sign, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+        got, want = _leaf_values(np.array(t[:5] + [P(OP["OUTPUT"], 0, 2, 0)], np.uint64), 5, ik, ROTATED, kernel="fh_columns_t")
+        assert np.isnan(want).any() and np.isfinite(want).any()
+        if not _same_bits(got, want):
+            bad.append(("nan", int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
     assert not bad, bad

@@ -1181,6 +1181,11 @@ class Wave:
         x, y, z = self.fsrc(a, 0), self.fsrc(b, 1), self.fsrc(c, 2)
         self.vdst(d, self._fmin(self._fmin(x, y), z))
 
+    def i_v_max3_f32(self, i, d, a, b, c):
+        self.count("valu")
+        x, y, z = self.fsrc(a, 0), self.fsrc(b, 1), self.fsrc(c, 2)
+        self.vdst(d, self._fmax(self._fmax(x, y), z))
+
     def i_v_minimum3_f32(self, i, d, a, b, c):
         # gfx950: IEEE-754-2019 minimum - a NaN operand wins, -0 < +0 (measured over every pair of special values and 4 M random
         # pairs: tools/probe_minimum3.cpp, profiles/r06a/probe_minimum3.txt)
@@ -1336,6 +1341,66 @@ class Wave:
                 x, y = x.view(np.int32), y.view(np.int32)
             r = {"lt": x < y, "eq": x == y, "le": x <= y, "gt": x > y, "ne": x != y, "ge": x >= y}[op]
         self.sdst_mask(sd, r)
+
+    # -- binary64 (the hand-written expf of gen_trans.py) ------------------------------------------------
+    _F64_INLINE = {"0": 0.0, "0.5": 0.5, "-0.5": -0.5, "1.0": 1.0, "-1.0": -1.0, "2.0": 2.0, "-2.0": -2.0, "4.0": 4.0, "-4.0": -4.0}
+
+    def dsrc(self, name, which):
+        """a 64-bit float source: VGPR / SGPR pair with -, | | modifiers, or a float inline constant (the f64 value)"""
+        if name in self._F64_INLINE:
+            return np.full(LANES, self._F64_INLINE[name], dtype=np.float64)
+        vals, neg, ab = self.vsrc(name, which, 2)
+        bits = vals[0].astype(np.uint64) | (vals[1].astype(np.uint64) << np.uint64(32))
+        if ab:
+            bits = bits & np.uint64(0x7FFFFFFFFFFFFFFF)
+        if neg:
+            bits = bits ^ np.uint64(0x8000000000000000)
+        return bits.view(np.float64)
+
+    def ddst(self, name, x):
+        bits = np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
+        self.vdst(name, np.stack([(bits & np.uint64(0xFFFFFFFF)).astype(U32), (bits >> np.uint64(32)).astype(U32)]), 2)
+
+    @staticmethod
+    def fma64(a, b, c):
+        """exact fused multiply-add in f64, lane by lane in rational arithmetic (int / int division rounds to nearest even)"""
+        from fractions import Fraction
+        with np.errstate(all="ignore"):
+            r = a * b + c                   # infinities, NaNs, signed zeros: the unfused result's
+        for k in range(len(a)):
+            x, y, z = float(a[k]), float(b[k]), float(c[k])
+            if not (np.isfinite(x) and np.isfinite(y) and np.isfinite(z)):
+                continue
+            e = Fraction(x) * Fraction(y) + Fraction(z)
+            if e != 0:
+                try:
+                    r[k] = float(e)
+                except OverflowError:
+                    r[k] = np.inf if e > 0 else -np.inf
+        return r
+
+    def i_v_fma_f64(self, i, d, a, b, c):
+        self.count("valu")
+        self.ddst(d, self.fma64(self.dsrc(a, 0), self.dsrc(b, 1), self.dsrc(c, 2)))
+
+    def i_v_add_f64(self, i, d, a, b):
+        self.count("valu")
+        with np.errstate(all="ignore"):
+            self.ddst(d, self.dsrc(a, 0) + self.dsrc(b, 1))
+
+    def i_v_mul_f64(self, i, d, a, b):
+        self.count("valu")
+        with np.errstate(all="ignore"):
+            self.ddst(d, self.dsrc(a, 0) * self.dsrc(b, 1))
+
+    def i_v_cvt_f64_f32(self, i, d, a):
+        self.count("valu")
+        self.ddst(d, self.fsrc(a, 0).astype(np.float64))
+
+    def i_v_cvt_f32_f64(self, i, d, a):
+        self.count("valu")
+        with np.errstate(all="ignore"):
+            self.vdst(d, self.dsrc(a, 0).astype(F32))
 
     # -- packed f32 (VOP3P) ----------------------------------------------------------------------------
     def _pk(self, i, d, a, b, fn, c=None):
