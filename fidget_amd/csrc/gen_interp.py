@@ -605,16 +605,17 @@ class Interp:
                 self.idx_off()
                 if "no" + fn in EXP.split(","):       # experiment: what the routine costs (a copy in its place)
                     return self.write_out(VT)
-                if fn == "exp" and self.exp2:
+                if fn in ("exp", "ln") and self.exp2:      # expf / logf by hand, two samples at a time (gen_trans.exp_pair / ln_pair)
                     import gen_trans
-                    slow, join = a.label("exp_special"), a.label("exp_done")
-                    gen_trans.exp_consts(a, self.t_base)
-                    gen_trans.exp_special(a, self.t_base, VT[:self.zb], slow)
+                    slow, join = a.label(fn + "_special"), a.label(fn + "_done")
+                    consts, special, two = (gen_trans.exp_consts, gen_trans.exp_special, gen_trans.exp_pair) if fn == "exp" else (gen_trans.ln_consts, gen_trans.ln_special, gen_trans.ln_pair)
+                    consts(a, self.t_base)
+                    special(a, self.t_base, VT[:self.zb], slow)
                     for j0 in range(0, self.zb, 2):
-                        gen_trans.exp_pair(a, self.t_base, VT[j0:j0 + 2], VU[j0:j0 + 2])
+                        two(a, self.t_base, VT[j0:j0 + 2], VU[j0:j0 + 2])
                     a(f"{join}:")
                     self.write_out(VU)
-                    a(f"{slow}:")                   # some lane's |x| >= 88: glibc's special cases, by the compiled routine, sample by sample
+                    a(f"{slow}:")                   # some lane's argument is one of glibc's special cases: the compiled routine, sample by sample
                     for j in Z:
                         a(f"\tv_mov_b32 v{self.t_base}, {VT[j]}")
                         self.call(fn)
@@ -1901,13 +1902,15 @@ def gen_trans_probe(a):
             gen_trans.exp_table_init(a, vb, prefix, lane="v0")
         for fn in fns:
             skip = a.label("fn")
-            if fn == "exp2":        # the two-sample expf of the EXP handlers (gen_trans.exp_pair), as they hold it, under exp4's number
-                slow = a.label("probe_exp_special")
-                a(f"\ts_cmp_lg_u32 s8, {all_fns.index('exp4')}\n\ts_cbranch_scc1 {skip}")
-                gen_trans.exp_consts(a, vb)
-                gen_trans.exp_special(a, vb, [f"v{2 + k}" for k in range(4)], slow)
-                gen_trans.exp_pair(a, vb, ["v2", "v3"], ["v10", "v11"])
-                gen_trans.exp_pair(a, vb, ["v4", "v5"], ["v12", "v13"])
+            if fn in ("exp2", "ln2"):        # the two-sample expf / logf of the EXP / LN handlers (gen_trans.exp_pair, ln_pair), as they hold them, under exp4's / ln4's number
+                one = fn[:-1]
+                consts, special, two = (gen_trans.exp_consts, gen_trans.exp_special, gen_trans.exp_pair) if one == "exp" else (gen_trans.ln_consts, gen_trans.ln_special, gen_trans.ln_pair)
+                slow = a.label("probe_special")
+                a(f"\ts_cmp_lg_u32 s8, {all_fns.index(one + '4')}\n\ts_cbranch_scc1 {skip}")
+                consts(a, vb)
+                special(a, vb, [f"v{2 + k}" for k in range(4)], slow)
+                two(a, vb, ["v2", "v3"], ["v10", "v11"])
+                two(a, vb, ["v4", "v5"], ["v12", "v13"])
                 a(f"\ts_branch .Lfh_trans_probe_store\n{slow}:")
                 for k in range(4):
                     here, ret, h2 = a.label("call"), a.label("ret"), a.label("far")
@@ -1919,7 +1922,7 @@ def gen_trans_probe(a):
 	s_addc_u32 s97, s97, 0
 	s_getpc_b64 s[98:99]
 {h2}:
-	s_mov_b32 s100, {prefix}exp - {h2}
+	s_mov_b32 s100, {prefix}{one} - {h2}
 	s_ashr_i32 s101, s100, 31
 	s_add_u32 s98, s98, s100
 	s_addc_u32 s99, s99, s101

@@ -99,7 +99,6 @@ def _rename(body, name, V_BASE=V_BASE, prefix="fh_t_", s_map=None, MAX_V=MAX_V):
 # |x| >= 88 (glibc's special cases: overflow, underflow, infinities) in any lane of any sample of the op: the compiled one-sample
 # routine for each.  NaN arguments take the main path and come out NaN (the class is what is modelled, as everywhere).
 EXP_TAB = 22          # window registers v<base + 22>, v<base + 23>: the table's low / high words
-EXP2_WINDOW = 24
 
 
 def _f64(x):
@@ -119,7 +118,7 @@ def exp2_table():
 
 
 def exp_table_init(a, v_base, prefix="fh_t_", lane="v0"):
-    """loads the table registers of the hand-written exp2 (once per wave; clobbers s86..s89; `lane` = the lane's number)"""
+    """loads the table registers of the hand-written expf and logf (once per wave; clobbers s86..s89; `lane` = the lane's number)"""
     here = a.label("exptab")
     lo, hi = v_base + EXP_TAB, v_base + EXP_TAB + 1
     a(f"""
@@ -132,6 +131,9 @@ def exp_table_init(a, v_base, prefix="fh_t_", lane="v0"):
 	v_and_b32 v{lo}, 31, {lane}
 	v_lshlrev_b32 v{lo}, 3, v{lo}
 	global_load_dwordx2 v[{lo}:{hi}], v{lo}, s[86:87]
+	v_and_b32 v{v_base + LN_TAB}, 15, {lane}
+	v_lshlrev_b32 v{v_base + LN_TAB}, 4, v{v_base + LN_TAB}
+	global_load_dwordx4 v[{v_base + LN_TAB}:{v_base + LN_TAB + 3}], v{v_base + LN_TAB}, s[86:87] offset:256
 	s_waitcnt vmcnt(0)""")
 
 
@@ -212,6 +214,109 @@ def exp_table(a, prefix):
     a(f"	.p2align 3\n{prefix}exp2_tab:")
     for v in exp2_table():
         a(f"	.quad {v:#x}")
+    for invc, logc in ln_table():       # (256 bytes behind: logf's {1/c, log c})
+        a(f"	.quad {invc:#x}, {logc:#x}")
+
+
+# ---- logf for two samples at a time, by hand, inside the LN handlers (the compiled one-sample routine: 59 instructions and a call per
+# sample; bear.vm's 8 ln ops were a sixth of its leaf kernel's instructions) ------------------------------------------------------
+# trans_libm.hpp logf_main_ (glibc e_logf.c) operation for operation, 19 instructions per sample: the 16-entry table {1/c, log c} in
+# FOUR VGPRs of the wave (lane l: entry l % 16; LN_TAB, loaded once per wave by exp_table_init), an entry by four ds_bpermute_b32 whose
+# address is tmp >> 17 - bits 19..22 of tmp land on the lane-select bits; k, iz, z as the library computes them.  Special arguments
+# (x < 2^-126 - zero, negative, subnormal -, +inf, NaN: ix - 0x00800000 >= 0x7f000000) in any lane of any sample of the op: the compiled
+# routine, sample by sample.  x = 1 needs no case of its own here: the main path returns +0 for it in round-to-nearest.
+LN_TAB = 24           # window registers v<base + 24 .. 27>: 1/c low / high, log c low / high
+EXP2_WINDOW = 28
+
+
+def ln_table():
+    """MemTables::log_invc / log_logc of trans_libm.hpp (glibc's e_logf_data.c) as 16 x (invc, logc) bit patterns"""
+    import os, struct
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "trans_libm.hpp")).read()
+    out = []
+    for name in ("log_invc", "log_logc"):
+        m = re.search(name + r"\(uint32_t i\) \{\s*static const double T\[16\] = \{(.*?)\};", txt, re.S)
+        vals = [struct.unpack("<Q", struct.pack("<d", float.fromhex(v)))[0] for v in re.findall(r"-?0x[0-9a-fA-F.]+p[-+]?\d+", m.group(1))]
+        assert len(vals) == 16, (name, len(vals))
+        out.append(vals)
+    assert out[0][9] == 0x3ff0000000000000 and out[1][9] == 0
+    return list(zip(*out))
+
+
+def ln_consts(a, vb):
+    """the constants of ln_pair: s[86:87] Ln2, s[88:89] A1, s[90:91] A0, s92 / s93 the bounds of an ordinary argument; v[vb:vb+1] A2"""
+    ln2, a1, a0, a2 = _f64("0x1.62e42fefa39efp-1"), _f64("0x1.5575b0be00b6ap-2"), _f64("-0x1.00ea348b88334p-2"), _f64("-0x1.ffffef20a4123p-2")
+    a(f"""
+	s_mov_b32 s92, 0x00800000
+	s_mov_b32 s93, 0x7f800000
+	s_mov_b32 s86, {ln2[0]:#x}
+	s_mov_b32 s87, {ln2[1]:#x}
+	s_mov_b32 s88, {a1[0]:#x}
+	s_mov_b32 s89, {a1[1]:#x}
+	s_mov_b32 s90, {a0[0]:#x}
+	s_mov_b32 s91, {a0[1]:#x}
+	v_mov_b32 v{vb}, {a2[0]:#x}
+	v_mov_b32 v{vb + 1}, {a2[1]:#x}""")
+
+
+def ln_special(a, vb, xs, slow):
+    """branches to `slow` unless 2^-126 <= x < inf for every sample xs in every lane (their bit patterns as unsigned numbers; after
+    ln_consts; scratch v<vb+2>, v<vb+3>, vcc)"""
+    lo, hi = f"v{vb + 2}", f"v{vb + 3}"
+    if len(xs) == 2:
+        a(f"	v_min_u32 {lo}, {xs[0]}, {xs[1]}\n	v_max_u32 {hi}, {xs[0]}, {xs[1]}")
+    else:
+        a(f"	v_min3_u32 {lo}, {xs[0]}, {xs[1]}, {xs[2]}\n	v_max3_u32 {hi}, {xs[0]}, {xs[1]}, {xs[2]}")
+        k = 3
+        while len(xs) - k >= 2:
+            a(f"	v_min3_u32 {lo}, {lo}, {xs[k]}, {xs[k + 1]}\n	v_max3_u32 {hi}, {hi}, {xs[k]}, {xs[k + 1]}")
+            k += 2
+        if k < len(xs):
+            a(f"	v_min_u32 {lo}, {xs[k]}, {lo}\n	v_max_u32 {hi}, {xs[k]}, {hi}")
+    a(f"""
+	v_cmp_gt_u32 vcc, s92, {lo}
+	s_cbranch_vccnz {slow}
+	v_cmp_le_u32 vcc, s93, {hi}
+	s_cbranch_vccnz {slow}""")
+
+
+def ln_pair(a, vb, xin, xout):
+    """xout[j] = logf(xin[j]), j = 0, 1, for ordinary arguments (ln_special); window registers v<vb+2>..v<vb+21>, the constants of
+    ln_consts, the table registers of exp_table_init"""
+    pair = lambda r: f"v[{r}:{r + 1}]"
+    A2 = vb
+    base = [vb + 2 + 10 * j for j in range(2)]
+    P1, P2, P3, P4 = ([b + 2 * k for b in base] for k in range(4))     # 1/c, r2 | log c, y | k, y0, y0 + r | z, r
+    TMP, S = [b + 8 for b in base], [b + 9 for b in base]
+    T = [f"v{vb + LN_TAB + k}" for k in range(4)]
+    R2 = range(2)
+    for j in R2:
+        a(f"	v_add_u32 v{TMP[j]}, 0xc0cd0000, {xin[j]}")                                   # tmp = ix - 0x3f330000
+        a(f"	v_lshrrev_b32 v{S[j]}, 17, v{TMP[j]}")                                        # lane = (tmp >> 19) % 64 -> entry (tmp >> 19) % 16
+        a(f"	ds_bpermute_b32 v{P1[j]}, v{S[j]}, {T[0]}\n	ds_bpermute_b32 v{P1[j] + 1}, v{S[j]}, {T[1]}")
+        a(f"	ds_bpermute_b32 v{P2[j]}, v{S[j]}, {T[2]}\n	ds_bpermute_b32 v{P2[j] + 1}, v{S[j]}, {T[3]}")
+    for j in R2:
+        a(f"	v_ashrrev_i32 v{S[j]}, 23, v{TMP[j]}")                                        # k
+        a(f"	v_and_b32 v{TMP[j]}, 0xff800000, v{TMP[j]}")
+    for j in R2:
+        a(f"	v_cvt_f64_i32 {pair(P3[j])}, v{S[j]}")
+        a(f"	v_sub_u32 v{S[j]}, {xin[j]}, v{TMP[j]}")                                      # iz = ix - (tmp & 0xff800000)
+    for j in R2:
+        a(f"	v_cvt_f64_f32 {pair(P4[j])}, v{S[j]}")                                        # z
+    a("	s_waitcnt lgkmcnt(0)")
+    for j in R2:
+        a(f"	v_fma_f64 {pair(P4[j])}, {pair(P4[j])}, {pair(P1[j])}, -1.0")                 # r = z / c - 1
+        a(f"	v_fma_f64 {pair(P3[j])}, {pair(P3[j])}, s[86:87], {pair(P2[j])}")             # y0 = k Ln2 + log c
+    for j in R2:
+        a(f"	v_mul_f64 {pair(P1[j])}, {pair(P4[j])}, {pair(P4[j])}")                       # r2
+        a(f"	v_fma_f64 {pair(P2[j])}, s[88:89], {pair(P4[j])}, {pair(A2)}")                # y = A1 r + A2
+    for j in R2:
+        a(f"	v_fma_f64 {pair(P2[j])}, s[90:91], {pair(P1[j])}, {pair(P2[j])}")             # y = A0 r2 + y
+        a(f"	v_add_f64 {pair(P3[j])}, {pair(P3[j])}, {pair(P4[j])}")                       # y0 + r
+    for j in R2:
+        a(f"	v_fma_f64 {pair(P2[j])}, {pair(P2[j])}, {pair(P1[j])}, {pair(P3[j])}")        # y r2 + (y0 + r)
+    for j in R2:
+        a(f"	v_cvt_f32_f64 {xout[j]}, {pair(P2[j])}")
 
 
 COPIES = []      # (prefix, v_base, routine names) of every embed(): the probe kernel (gen_interp.py gen_trans_probe) reaches each copy
@@ -225,7 +330,7 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=N
     txt = open(path).read()
     # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
     extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
-    COPIES.append((prefix, v_base, FUNCS + extra + (["exp2"] if exp2 else [])))
+    COPIES.append((prefix, v_base, FUNCS + extra + (["exp2", "ln2"] if exp2 else [])))
     if exp2:       # the kernel's handlers hold the two-sample expf written by hand (exp_pair): its table
         exp_table(a, prefix)
     for f in FUNCS + extra:

@@ -72,7 +72,7 @@ def run_columns(tape, n_regs, in_kind, mat, leaf_xyz, size=16, zbuf_init=None, n
     ka = col_kernarg(a_st, in_kind, mat, size, column_mode, group_log2, a_tab=a_tab, layers=layers)
     trans = kernel == "fh_columns_t"
     gx, gy = ((nfp + 63) // 64 * 64, (layers + (1 << group_log2) - 1) >> group_log2) if column_mode else ((nfp + 3) // 4, layers)
-    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=248 if trans else 128,
+    waves = E.launch(U.program(), mem, kernel, ka.tobytes(), gx, grid_y=gy, lds_bytes=16, n_vgpr=256 if trans else 128,
                      hooks=U.trans_hooks(U.program(), v_base=224, window=22) if trans else None)     # (window registers 22, 23: the hand-written expf's table)
     return zbuf, waves
 
@@ -501,4 +501,26 @@ def test_hand_written_expf_in_the_transcendental_kernel():
         assert np.isnan(want).any() and np.isfinite(want).any()
         if not _same_bits(got, want):
             bad.append(("nan", int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad
+
+
+def test_hand_written_logf_in_the_transcendental_kernel():
+    """... and the LN handler's logf (gen_trans.py ln_pair: the {1/c, log c} table in four VGPRs), the same way: ordinary arguments of every
+    size, 1 exactly, and the special ones - zero, negative, subnormal, infinite, NaN - that send the whole op to the compiled routine."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    bad = []
+    for scale, shift in ((0.37, 1.3), (3.0, 5.0), (1e-20, 1e-19), (1e30, 2e30), (1e-38, 1.2e-38), (0.0, 1.0), (1.0, 0.0), (1e-42, 3e-42), (1e38, float("inf")), (-1.0, -3.0)):
+        t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 2), P(OP["MUL_RR"], 0, 0, 1), P(OP["MUL_RI"], 0, 0, f(scale)), P(OP["ADD_RI"], 0, 0, f(shift)), P(OP["LN"], 2, 0, 0),
+             P(OP["OUTPUT"], 0, 2, 0)]
+        got, want = _leaf_values(np.array(t, np.uint64), 3, ik, ROTATED, kernel="fh_columns_t")
+        if not _same_bits(got, want):
+            bad.append((scale, shift, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    # NaN arguments (sqrt of a negative number in some lanes)
+    t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 1), P(OP["SUB_RI"], 1, 1, f(0.3)), P(OP["SQRT"], 1, 1, 0), P(OP["LN"], 2, 1, 0), P(OP["OUTPUT"], 0, 2, 0)]
+    got, want = _leaf_values(np.array(t, np.uint64), 3, ik, ROTATED, kernel="fh_columns_t")
+    assert np.isnan(want).any() and np.isfinite(want).any()
+    if not _same_bits(got, want):
+        bad.append(("nan", int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
     assert not bad, bad

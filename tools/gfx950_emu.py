@@ -1397,6 +1397,10 @@ class Wave:
         self.count("valu")
         self.ddst(d, self.fsrc(a, 0).astype(np.float64))
 
+    def i_v_cvt_f64_i32(self, i, d, a):
+        self.count("valu")
+        self.ddst(d, self.usrc(a, 0).view(np.int32).astype(np.float64))
+
     def i_v_cvt_f32_f64(self, i, d, a):
         self.count("valu")
         with np.errstate(all="ignore"):
