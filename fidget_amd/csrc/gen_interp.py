@@ -440,6 +440,58 @@ class Interp:
 	v_div_fmas_f32 {d[0]}, {d[0]}, {d[1]}, {d[3]}
 	v_div_fixup_f32 {R[j]}, {d[0]}, {b}, {a}""")
 
+    def f_div_imm(self, A, B, R):
+        """R = A / immediate (B: the immediate in every sample, for the general sequence).  The division sequence of f_div with the work
+        that only the divisor needs - the reciprocal and its refinement - done once for the op, and the rest two samples per instruction:
+        when neither operand needs v_div_scale_f32's scaling (both within 2^-40 .. 2^40: the exponents differ by less than 96, no
+        denormal anywhere) the scaled operands are the operands and v_div_fmas_f32 is a plain fused multiply-add, so these are the same
+        operations with the same roundings; v_div_fixup_f32 ends both.  3.5 + 1 instructions per sample instead of 11; any sample
+        outside the range (zeros among them) in any lane: the general sequence for the op."""
+        a, d = self.a, VD
+        slow, done = a.label("div_general"), a.label("div_done")
+        n = self.zb
+        ab = [f"|{x}|" for x in A[:n]]
+        lo, hi, r, e = d[6], d[7], d[0], d[1]
+        a(f"""
+	s_bfe_u32 {S_T0}, {S_W1}, 0x80017
+	s_sub_u32 {S_T0}, {S_T0}, 87
+	s_cmp_gt_u32 {S_T0}, 80
+	s_cbranch_scc1 {slow}""")
+        if n == 2:
+            a(f"\tv_min_f32_e64 {lo}, {ab[0]}, {ab[1]}\n\tv_max_f32_e64 {hi}, {ab[0]}, {ab[1]}")
+        else:
+            a(f"\tv_min3_f32 {lo}, {ab[0]}, {ab[1]}, {ab[2]}\n\tv_max3_f32 {hi}, {ab[0]}, {ab[1]}, {ab[2]}")
+            k = 3
+            while n - k >= 2:
+                a(f"\tv_min3_f32 {lo}, {lo}, {ab[k]}, {ab[k + 1]}\n\tv_max3_f32 {hi}, {hi}, {ab[k]}, {ab[k + 1]}")
+                k += 2
+            if k < n:
+                a(f"\tv_min_f32_e64 {lo}, {ab[k]}, {lo}\n\tv_max_f32_e64 {hi}, {ab[k]}, {hi}")
+        a(f"""
+	v_rcp_f32 {r}, {S_W1}
+	v_cmp_gt_f32 vcc, 0x2b800000, {lo}
+	s_cbranch_vccnz {slow}
+	v_cmp_le_f32 vcc, 0x53800000, {hi}
+	s_cbranch_vccnz {slow}
+	v_fma_f32 {e}, -{S_W1}, {r}, 1.0
+	v_fmac_f32 {r}, {e}, {r}""")
+        # per pair: q0 = a r; e1 = a - c q0; q1 = q0 + e1 r; e2 = a - c q1; q = q1 + e2 r   (c: the high half of the op's SGPR pair)
+        tq, rr = [self.P(d, 1), self.P(d, 2)], self.P(d, 0)      # (r: the low half of its pair, selected for both samples)
+        for k in range(n // 2):
+            Ak, q = self.P(A, k), self.P(VU, k)
+            ee = tq[k % 2]
+            a(f"\tv_pk_mul_f32 {q}, {Ak}, {rr} op_sel_hi:[1,0]")
+            a(f"\tv_pk_fma_f32 {ee}, {S_CUR}, {q}, {Ak} op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+            a(f"\tv_pk_fma_f32 {q}, {ee}, {rr}, {q} op_sel_hi:[1,0,1]")
+            a(f"\tv_pk_fma_f32 {ee}, {S_CUR}, {q}, {Ak} op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+            a(f"\tv_pk_fma_f32 {q}, {ee}, {rr}, {q} op_sel_hi:[1,0,1]")
+        for j in range(n):
+            a(f"\tv_div_fixup_f32 {R[j]}, {VU[j]}, {S_W1}, {A[j]}")
+        a(f"\ts_branch {done}\n{slow}:")
+        self.imm_b(B)
+        self.f_div(A, B, R)
+        a(f"{done}:")
+
     def f_sqrt(self, A, R):
         # correctly rounded sqrtf: v_sqrt_f32 (1 ulp), then one ulp either way by the sign of the exact residuals.  Arguments
         # below 2^-96 (denormal results of the residuals), zeros and negative ones take the full sequence (scaled by 2^32, the
@@ -742,12 +794,15 @@ class Interp:
             if form == "RR":
                 self.read_b(VU)
             self.idx_off()
-            if form != "RR":
+            fast_div = base == "DIV" and form == "RI" and self.kind == "columns" and self.zb >= 2 and not (set(EXP.split(",")) & {"nofastdiv", "nodiv"})
+            if form != "RR" and not fast_div:      # (the division by an immediate fills VU itself, where it takes the general sequence)
                 self.imm_b(VU)
             A, B = (VT, VU) if form != "IR" else (VU, VT)
             if base == "DIV" and "nodiv" in EXP.split(","):      # experiment: what the division costs (a product in its place)
                 for k in PZ:
                     a(f"\tv_pk_mul_f32 {self.P(VW, k)}, {self.P(A, k)}, {self.P(B, k)}")
+            elif fast_div:
+                self.f_div_imm(A, B, VW)
             elif base == "DIV":
                 self.f_div(A, B, VW)
                 if "twicediv" in EXP.split(","):     # experiment: the division's cost once more, same results

@@ -524,3 +524,29 @@ def test_hand_written_logf_in_the_transcendental_kernel():
     if not _same_bits(got, want):
         bad.append(("nan", int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kernel", ["fh_columns", "fh_columns_t"])
+def test_division_by_an_immediate(kernel):
+    """DIV_RI's short sequence (gen_interp.py f_div_imm: the reciprocal's refinement once per op, the quotient's two samples per
+    instruction, no scaling when both operands lie within 2^-40 .. 2^40) against IEEE division, bit for bit: divisors of every kind -
+    not powers of two, negative, tiny, huge (those take the general sequence), numerators from 1e-13 to 1e13, and ops whose
+    numerators hold a zero, an infinity or a NaN in some lane (the general sequence for the whole op)."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    bad = []
+    for imm in (0.3, 3.0, -7.77, 1e-5, 123456.7, float.fromhex("0x1.fffffep+39"), 2.0 ** -40, 1.5 * 2.0 ** -41, 2.0 ** 41, 1e-30, 1e30, 1.0, -0.5):
+        for scale in (1.0, 1e-12, 1e11, 3e12, 1e-13):
+            t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 2), P(OP["MUL_RR"], 0, 0, 1), P(OP["ADD_RI"], 0, 0, f(0.013)), P(OP["MUL_RI"], 0, 0, f(scale)),
+                 P(OP["DIV_RI"], 2, 0, f(imm)), P(OP["OUTPUT"], 0, 2, 0)]
+            got, want = _leaf_values(np.array(t, np.uint64), 3, ik, ROTATED, kernel=kernel)
+            if not _same_bits(got, want):
+                bad.append((imm, scale, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    # zeros (x - x), infinities (1 / 0) and NaNs (sqrt of a negative number) among the numerators, in place as well
+    for pre in ([P(OP["SUB_RR"], 0, 0, 0)], [P(OP["SUB_RR"], 0, 0, 0), P(OP["RECIP"], 0, 0, 0)], [P(OP["SUB_RI"], 0, 0, f(0.3)), P(OP["SQRT"], 0, 0, 0)]):
+        t = [P(OP["INPUT"], 0, 0, 1)] + pre + [P(OP["DIV_RI"], 0, 0, f(0.7)), P(OP["OUTPUT"], 0, 0, 0)]
+        got, want = _leaf_values(np.array(t, np.uint64), 1, ik, ROTATED, kernel=kernel)
+        if not _same_bits(got, want):
+            bad.append(("special", len(pre), int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad
