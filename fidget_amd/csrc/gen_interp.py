@@ -657,10 +657,10 @@ class Interp:
                 self.idx_off()
                 if "no" + fn in EXP.split(","):       # experiment: what the routine costs (a copy in its place)
                     return self.write_out(VT)
-                if fn in ("exp", "ln") and self.exp2:      # expf / logf by hand, two samples at a time (gen_trans.exp_pair / ln_pair)
+                if fn in ("exp", "ln", "sin", "cos") and self.exp2:      # expf / logf / sinf / cosf by hand, two samples at a time (gen_trans.exp_pair ...)
                     import gen_trans
                     slow, join = a.label(fn + "_special"), a.label(fn + "_done")
-                    consts, special, two = (gen_trans.exp_consts, gen_trans.exp_special, gen_trans.exp_pair) if fn == "exp" else (gen_trans.ln_consts, gen_trans.ln_special, gen_trans.ln_pair)
+                    consts, special, two = gen_trans.hand(fn)
                     consts(a, self.t_base)
                     special(a, self.t_base, VT[:self.zb], slow)
                     for j0 in range(0, self.zb, 2):
@@ -1392,7 +1392,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
     its = [Interp(a, f"{kname}_{nr}x{zb}", nr, zb, "columns", off, trans=bool(trans)) for nr, zb in variants]
     for it in its:
         it.t_base = t_base
-        it.wide_trans = "sincos" if trans else False
+        it.wide_trans = False
         it.exp2 = bool(trans)
     inplace_mask = 0
     for k, op in enumerate(OPS):
@@ -1878,7 +1878,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
         a(f"\t.long {lut_bits(its[0], k)}")
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans, v_base=t_base, wide="sincos", exp2=True)
+        gen_trans.embed(a, trans, v_base=t_base, exp2=True)
     for it in its:
         it.emit()
     return kname, nvg
@@ -1957,9 +1957,9 @@ def gen_trans_probe(a):
             gen_trans.exp_table_init(a, vb, prefix, lane="v0")
         for fn in fns:
             skip = a.label("fn")
-            if fn in ("exp2", "ln2"):        # the two-sample expf / logf of the EXP / LN handlers (gen_trans.exp_pair, ln_pair), as they hold them, under exp4's / ln4's number
+            if fn in ("exp2", "ln2", "sin2", "cos2"):        # the two-sample routines written by hand that the EXP / LN / SIN / COS handlers hold (gen_trans.exp_pair ...), under the four-sample routines' numbers
                 one = fn[:-1]
-                consts, special, two = (gen_trans.exp_consts, gen_trans.exp_special, gen_trans.exp_pair) if one == "exp" else (gen_trans.ln_consts, gen_trans.ln_special, gen_trans.ln_pair)
+                consts, special, two = gen_trans.hand(one)
                 slow = a.label("probe_special")
                 a(f"\ts_cmp_lg_u32 s8, {all_fns.index(one + '4')}\n\ts_cbranch_scc1 {skip}")
                 consts(a, vb)

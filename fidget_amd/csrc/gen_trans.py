@@ -319,6 +319,133 @@ def ln_pair(a, vb, xin, xout):
         a(f"	v_cvt_f32_f64 {xout[j]}, {pair(P2[j])}")
 
 
+# ---- sinf / cosf for two samples at a time, by hand, inside the SIN / COS handlers (the compiled four-sample routines: 424 instructions
+# per call, 106 per sample - bear.vm's six such ops were a fifth of its leaf kernel's instructions) ------------------------------------
+# trans_libm.hpp sincosf_ (glibc s_sinf.c / s_cosf.c, the fast reduction |y| < 120) operation for operation, 32 instructions per sample:
+# n and x = y - n pi/2 in binary64, the sine polynomial's value, the cosine polynomial's value, the one the quadrant asks for, the
+# small-argument answer (y, 1) by a select.  |y| >= 120 or infinite in any lane of any sample of the op: the compiled routine, sample
+# by sample.  A NaN argument comes out NaN of the main path (n = 0, x = NaN).
+def sincos_consts(a, vb):
+    """s[86:87] 2^24 2/pi (sincos_pair puts the cosine's C4 there afterwards), s[88:89] pi/2, s[90:91] S1, s[92:93] S3, s[94:95] C1,
+    s[96:97] C2; v[vb:vb+1] S2, v[vb+2:vb+3] C3"""
+    c = {"s88": "0x1.921FB54442D18p0", "s90": "-0x1.555545995a603p-3", "s92": "-0x1.994eb3774cf24p-13", "s94": "-0x1.ffffffd0c621cp-2",
+         "s96": "0x1.55553e1068f19p-5"}
+    for r, v in c.items():
+        lo, hi = _f64(v)
+        n = int(r[1:])
+        a(f"	s_mov_b32 s{n}, {lo:#x}\n	s_mov_b32 s{n + 1}, {hi:#x}")
+    s2, c3 = _f64("0x1.1107605230bc4p-7"), _f64("-0x1.6c087e89a359dp-10")
+    a(f"""
+	v_mov_b32 v{vb}, {s2[0]:#x}
+	v_mov_b32 v{vb + 1}, {s2[1]:#x}
+	v_mov_b32 v{vb + 2}, {c3[0]:#x}
+	v_mov_b32 v{vb + 3}, {c3[1]:#x}""")
+
+
+def sincos_special(a, vb, xs, slow):
+    """branches to `slow` unless |y| < 120 for every sample in every lane (NaN: the main path's; scratch v<vb+4>, vcc)"""
+    t = f"v{vb + 4}"
+    ab = [f"|{x}|" for x in xs]
+    if len(ab) == 2:
+        a(f"	v_max_f32_e64 {t}, {ab[0]}, {ab[1]}")
+    else:
+        a(f"	v_max3_f32 {t}, {ab[0]}, {ab[1]}, {ab[2]}")
+        k = 3
+        while len(ab) - k >= 2:
+            a(f"	v_max3_f32 {t}, {t}, {ab[k]}, {ab[k + 1]}")
+            k += 2
+        if k < len(ab):
+            a(f"	v_max_f32_e64 {t}, {ab[k]}, {t}")
+    a(f"	v_cmp_ngt_f32 vcc, 0x42f00000, {t}\n	s_cbranch_vccnz {slow}")
+
+
+def sincos_pair(a, vb, xin, xout, is_cos):
+    """xout[j] = sinf / cosf(xin[j]), j = 0, 1, |xin| < 120 (sincos_special); window registers v<vb+4>..v<vb+21>, the constants of
+    sincos_consts; xout must not be xin (it holds the quadrant meanwhile)"""
+    pair = lambda r: f"v[{r}:{r + 1}]"
+    S2, C3 = vb, vb + 2
+    base = [vb + 4 + 9 * j for j in range(2)]
+    # (pairs at even registers: sample 0 takes v+4..v+12 with its single last, sample 1 its single first)
+    Pa, Pb, Pc, Pd = ([(b if j == 0 else b + 1) + 2 * k for j, b in enumerate(base)] for k in range(4))
+    Rs = [base[0] + 8, base[1]]
+    N = xout
+    R2 = range(2)
+    inv = _f64("0x1.45F306DC9C883p+23")
+    c4 = _f64("0x1.99343027bf8c3p-16")
+    a(f"	s_mov_b32 s86, {inv[0]:#x}\n	s_mov_b32 s87, {inv[1]:#x}")
+    for j in R2:
+        a(f"	v_cvt_f64_f32 {pair(Pa[j])}, {xin[j]}")
+    for j in R2:
+        a(f"	v_mul_f64 {pair(Pb[j])}, {pair(Pa[j])}, s[86:87]")
+    for j in R2:
+        a(f"	v_cvt_i32_f64 {N[j]}, {pair(Pb[j])}")
+    for j in R2:
+        a(f"	v_add_u32 {N[j]}, 0x800000, {N[j]}")
+    for j in R2:
+        a(f"	v_ashrrev_i32 {N[j]}, 24, {N[j]}")                                            # n = ((int32) r + 0x800000) >> 24
+    a(f"	s_mov_b32 s86, {c4[0]:#x}\n	s_mov_b32 s87, {c4[1]:#x}")
+    for j in R2:
+        a(f"	v_cvt_f64_i32 {pair(Pb[j])}, {N[j]}")
+    for j in R2:
+        a(f"	v_fma_f64 {pair(Pa[j])}, -{pair(Pb[j])}, s[88:89], {pair(Pa[j])}")            # x = y - n pi/2
+        a(f"	v_lshrrev_b32 v{Rs[j]}, 1, {N[j]}")
+    for j in R2:
+        a(f"	v_mul_f64 {pair(Pb[j])}, {pair(Pa[j])}, {pair(Pa[j])}")                       # x2 (before the sign: the same number)
+        a(f"	v_xor_b32 v{Rs[j]}, v{Rs[j]}, {N[j]}")
+    for j in R2:
+        a(f"	v_lshlrev_b32 v{Rs[j]}, 31, v{Rs[j]}")
+    for j in R2:
+        a(f"	v_xor_b32 v{Pa[j] + 1}, v{Pa[j] + 1}, v{Rs[j]}")                              # x * sign[n & 3], sign = 1 -1 -1 1
+    for j in R2:
+        a(f"	v_mul_f64 {pair(Pd[j])}, {pair(Pa[j])}, {pair(Pb[j])}")                       # x3
+        a(f"	v_fma_f64 {pair(Pc[j])}, {pair(Pb[j])}, s[92:93], {pair(S2)}")                # s1 = S2 + x2 S3
+    for j in R2:
+        a(f"	v_fma_f64 {pair(Pa[j])}, {pair(Pd[j])}, s[90:91], {pair(Pa[j])}")             # s = x + x3 S1
+        a(f"	v_mul_f64 {pair(Pd[j])}, {pair(Pd[j])}, {pair(Pb[j])}")                       # x7
+    for j in R2:
+        a(f"	v_fma_f64 {pair(Pa[j])}, {pair(Pd[j])}, {pair(Pc[j])}, {pair(Pa[j])}")        # the sine polynomial
+    for j in R2:
+        a(f"	v_cvt_f32_f64 v{Rs[j]}, {pair(Pa[j])}")
+        a(f"	v_mul_f64 {pair(Pa[j])}, {pair(Pb[j])}, {pair(Pb[j])}")                       # x4
+    for j in R2:
+        a(f"	v_fma_f64 {pair(Pc[j])}, {pair(Pb[j])}, s[86:87], {pair(C3)}")                # c2 = C3 + x2 C4
+        a(f"	v_fma_f64 {pair(Pd[j])}, {pair(Pb[j])}, s[94:95], 1.0")                       # c1 = 1 + x2 C1
+    for j in R2:
+        a(f"	v_mul_f64 {pair(Pb[j])}, {pair(Pa[j])}, {pair(Pb[j])}")                       # x6
+        a(f"	v_fma_f64 {pair(Pd[j])}, {pair(Pa[j])}, s[96:97], {pair(Pd[j])}")             # c = c1 + x4 C2
+    for j in R2:
+        a(f"	v_fma_f64 {pair(Pd[j])}, {pair(Pb[j])}, {pair(Pc[j])}, {pair(Pd[j])}")        # the cosine polynomial
+        a(f"	v_lshlrev_b32 v{Pa[j] + 1}, 30, {N[j]}")
+    for j in R2:
+        a(f"	v_cvt_f32_f64 v{Pa[j]}, {pair(Pd[j])}")
+        a(f"	v_and_b32 v{Pa[j] + 1}, 0x80000000, v{Pa[j] + 1}")                            # its sign: quadrants 2, 3
+    for j in R2:
+        a(f"	v_xor_b32 v{Pa[j]}, v{Pa[j]}, v{Pa[j] + 1}")
+        a(f"	v_lshlrev_b32 v{Pc[j]}, 31, {N[j]}")                                          # the quadrant's low bit as a sign
+    # sine: odd quadrant -> the cosine polynomial; cosine: even quadrant.  (Lane masks: vcc and s[86:87] - C4 is through; a mask written
+    # by a VALU instruction is read two instructions later at the earliest)
+    cmpop = "v_cmp_le_i32" if is_cos else "v_cmp_gt_i32"
+    a(f"	{cmpop} vcc, 0, v{Pc[0]}")
+    a(f"	{cmpop}_e64 s[86:87], 0, v{Pc[1]}")
+    for j in R2:
+        a(f"	v_and_b32 v{Pc[j]}, 0x7fffffff, {xin[j]}")
+    a(f"	v_cndmask_b32 {xout[0]}, v{Rs[0]}, v{Pa[0]}, vcc")
+    a(f"	v_cndmask_b32_e64 {xout[1]}, v{Rs[1]}, v{Pa[1]}, s[86:87]")
+    for j in R2:
+        a(f"	v_cmp_gt_u32 vcc, 0x39800000, v{Pc[j]}")                                      # |y| < 2^-12: y, 1
+        a(f"	s_nop 1")
+        a(f"	v_cndmask_b32 {xout[j]}, {xout[j]}, {'1.0' if is_cos else xin[j]}, vcc")
+
+
+def hand(fn):
+    """(constants, test for the special arguments, two samples) of the routine written by hand for the opcode fn"""
+    if fn == "exp":
+        return exp_consts, exp_special, exp_pair
+    if fn == "ln":
+        return ln_consts, ln_special, ln_pair
+    return sincos_consts, sincos_special, (lambda a, vb, xin, xout, c=(fn == "cos"): sincos_pair(a, vb, xin, xout, c))
+
+
 COPIES = []      # (prefix, v_base, routine names) of every embed(): the probe kernel (gen_interp.py gen_trans_probe) reaches each copy
 
 
@@ -330,7 +457,7 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=N
     txt = open(path).read()
     # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
     extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
-    COPIES.append((prefix, v_base, FUNCS + extra + (["exp2", "ln2"] if exp2 else [])))
+    COPIES.append((prefix, v_base, FUNCS + extra + (["sin2", "cos2", "exp2", "ln2"] if exp2 else [])))
     if exp2:       # the kernel's handlers hold the two-sample expf written by hand (exp_pair): its table
         exp_table(a, prefix)
     for f in FUNCS + extra:

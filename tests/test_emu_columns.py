@@ -550,3 +550,27 @@ def test_division_by_an_immediate(kernel):
         if not _same_bits(got, want):
             bad.append(("special", len(pre), int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("fn", ["SIN", "COS"])
+def test_hand_written_sinf_cosf_in_the_transcendental_kernel(fn):
+    """... and the SIN / COS handlers' sinf / cosf (gen_trans.py sincos_pair: glibc's fast reduction and both polynomials in binary64):
+    arguments in every quadrant and of every size below 120, tiny ones (|y| < 2^-12: y, 1), zeros of both signs, NaNs; 120 and
+    beyond, infinities: the compiled routine for the whole op."""
+    P, OP = U.pack, U.OPN
+    ik = [0, 1, 2] + [3] * 13
+    f = U.f2u
+    bad = []
+    for scale, shift in ((0.37, 0.0), (3.0, 0.5), (25.0, -7.0), (119.0, 0.0), (1e-4, 0.0), (1e-5, 2e-4), (0.0, 0.0), (-0.0, 0.0), (1e-30, 0.0), (130.0, 0.0), (1e6, 0.0), (1e30, 0.0),
+                         (1.0, 1.5707964), (1.0, 3.1415927), (0.001, 0.7853982)):
+        t = [P(OP["INPUT"], 0, 0, 0), P(OP["INPUT"], 1, 0, 2), P(OP["MUL_RR"], 0, 0, 1), P(OP["MUL_RI"], 0, 0, f(scale)), P(OP["ADD_RI"], 0, 0, f(shift)), P(OP[fn], 2, 0, 0),
+             P(OP["OUTPUT"], 0, 2, 0)]
+        got, want = _leaf_values(np.array(t, np.uint64), 3, ik, ROTATED, kernel="fh_columns_t")
+        if not _same_bits(got, want):
+            bad.append((scale, shift, int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    for pre in ([P(OP["SUB_RI"], 0, 0, f(0.3)), P(OP["SQRT"], 0, 0, 0)], [P(OP["SUB_RR"], 0, 0, 0), P(OP["RECIP"], 0, 0, 0)], [P(OP["SUB_RR"], 0, 0, 0), P(OP["NEG"], 0, 0, 0)]):
+        t = [P(OP["INPUT"], 0, 0, 1)] + pre + [P(OP[fn], 1, 0, 0), P(OP["OUTPUT"], 0, 1, 0)]       # NaN in some lanes; infinities; -0
+        got, want = _leaf_values(np.array(t, np.uint64), 2, ik, ROTATED, kernel="fh_columns_t")
+        if not _same_bits(got, want):
+            bad.append(("special", len(pre), int(((got.view(U32) != want.view(U32)) & ~(np.isnan(got) & np.isnan(want))).sum())))
+    assert not bad, bad

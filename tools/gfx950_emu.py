@@ -1397,6 +1397,13 @@ class Wave:
         self.count("valu")
         self.ddst(d, self.fsrc(a, 0).astype(np.float64))
 
+    def i_v_cvt_i32_f64(self, i, d, a):
+        self.count("valu")
+        x = self.dsrc(a, 0)
+        with np.errstate(all="ignore"):
+            y = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x), -2147483648.0, 2147483647.0))
+        self.vdst(d, y.astype(np.int64).astype(np.int32).view(U32))
+
     def i_v_cvt_f64_i32(self, i, d, a):
         self.count("valu")
         self.ddst(d, self.usrc(a, 0).view(np.int32).astype(np.float64))
