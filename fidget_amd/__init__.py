@@ -56,7 +56,7 @@ EXPORTS = [
     "fhip_profile_enable", "fhip_profile_read", "fhip_profile_read_kernels", "fhip_render_counters", "fhip_graph_new", "fhip_graph_free",
     "fhip_graph_len", "fhip_graph_var", "fhip_graph_constant", "fhip_graph_unary", "fhip_graph_binary",
     "fhip_graph_from_text", "fhip_tape_from_graph", "fhip_tape_axis_slot", "fhip_tape_var_slot",
-    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_tape_links", "fhip_debug_tape_chain", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_trans_probe", "fhip_debug_lane_frames", "fhip_debug_lane_tune", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
+    "fhip_screen_to_world", "fhip_debug_groups", "fhip_debug_ubench", "fhip_debug_math_sweep", "fhip_debug_stats", "fhip_debug_leaf_stats", "fhip_debug_tape_links", "fhip_debug_tape_chain", "fhip_debug_bench", "fhip_debug_leaves", "fhip_debug_arena", "fhip_debug_probe", "fhip_debug_trans_probe", "fhip_debug_lane_frames", "fhip_debug_rare_frames", "fhip_debug_lane_tune", "fhip_debug_walk_dual", "fhip_tape_group_count", "fhip_tape_group_op",
     "fhip_tape_group", "fhip_tape_term_plan", "fhip_tape_term_group", "fhip_tape_term_tree", "fhip_tape_term_choice_src",
 ]
 
@@ -188,6 +188,7 @@ def lib():
             "fhip_debug_math_sweep": (i32, [vp, i32, u32, u32, u64, vp, vp]),
             "fhip_debug_trans_probe": (i32, [vp, u32, u32, u32, u64, vp]),
             "fhip_debug_lane_frames": (u64, [vp]),
+            "fhip_debug_rare_frames": (u64, [vp]),
             "fhip_debug_lane_tune": (i32, [vp, vp, vp]),
             "fhip_graph_new": (vp, []), "fhip_graph_free": (None, [vp]), "fhip_graph_len": (u32, [vp]),
             "fhip_graph_var": (u32, [vp, i32, u64]), "fhip_graph_constant": (u32, [vp, f32]),
@@ -261,6 +262,11 @@ class HipContext:
     def lane_frames(self):
         """Frames of this context that went to a frame lane so far (fhip_debug_lane_frames)"""
         return int(lib().fhip_debug_lane_frames(self._h))
+
+    def rare_frames(self):
+        """3D frames of this context rendered in rare mode so far - the launches for tapes beyond the assembly kernels' register files folded
+        into the slab's other launches (fhip_debug_rare_frames; capi_render.hpp)"""
+        return int(lib().fhip_debug_rare_frames(self._h))
 
     def set_option(self, name, value=1):
         """A behaviour switch of this context (fhip_ctx_set_option: "no_column_inv", "frame_lanes", ...).  The environment

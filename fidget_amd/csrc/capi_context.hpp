@@ -112,6 +112,7 @@ fhip_status fhip_ctx_create(int device, void* stream, fhip_ctx** out) {
         void* hf = nullptr;
         if (hipHostMalloc(&hf, 64, hipHostMallocDefault) != hipSuccess) { delete c; return FHIP_ERR_HIP; }
         memset(hf, 0, 64);
+        ((uint32_t*)hf)[2] = 1;      // (no frame has finished yet: the kernels for the large tapes are launched on their own - capi_render.hpp rare mode)
         c->host_flags = (volatile uint32_t*)hf;
     }
     c->ev_tiles.resize(FH_MAX_SLABS); c->ev_leaves.resize(FH_MAX_SLABS); c->ev_aux.resize(FH_MAX_SLABS);

@@ -96,7 +96,7 @@ static void options_from_env(FhOptions& o) {
 // takes the set used longest ago, so that its coarse levels (which keep a few hundred waves busy for most of a millisecond)
 // run on a stream of their own beside the previous frames' slabs (frame pipelining; option no_pipeline turns all pipelining off).
 struct FrameBufs {
-    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch;
+    DevBuf state, arena, leaves, leaf_table, zbuf, normals, fp_lists, mind, squeue, slots[2], leaves_b, leaf_table_b, fp_lists_b, chw[2], tvals, topch, chwr, gscratch, rare_scratch;
     DevBuf queue[FH_MAX_LEVELS];
     uint32_t frame_stamp = 0;       // FhRenderState::frame_stamp of the last frame prepared
     uint64_t resident_serial = 0;   // the root (and group) tapes at the bottom of the arena belong to this tape
@@ -107,7 +107,7 @@ struct FrameBufs {
     bool ev_done_valid = false;
     void release_all() {
         DevBuf* bufs[] = {&state, &arena, &leaves, &leaf_table, &zbuf, &normals, &fp_lists, &mind, &squeue, &slots[0], &slots[1],
-                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr, &gscratch};
+                          &leaves_b, &leaf_table_b, &fp_lists_b, &chw[0], &chw[1], &tvals, &topch, &chwr, &gscratch, &rare_scratch};
         for (DevBuf* b : bufs) b->release();
         for (auto& q : queue) q.release();
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -190,6 +190,11 @@ struct fhip_ctx : FrameBufs {
     // frames of a queued sequence in turn when the frames' kernels are the 256-VGPR ones
     std::vector<fhip_ctx*> lanes;
     uint32_t lane_next = 0;
+    // Rare mode of a 3D frame (capi_render.hpp): the launches that exist for tapes too large for the assembly kernels' register files - three or
+    // four per slab, empty in nearly every frame - folded into launches the slab makes anyway; taken while the last finished frame met no such tape
+    bool rare_now = false;            // ... this frame
+    uint32_t rare_stride = 0;         // bytes of a rare block's register file in rare_scratch
+    uint64_t rare_frames = 0;         // frames rendered that way so far (fhip_debug_rare_frames)
     uint64_t lane_frames = 0;         // frames that went to a lane so far (fhip_debug_lane_frames)
     uint64_t lane_frames_wanted = 0;  // ... not counting the tuner's measuring windows
     hipEvent_t ev_last = nullptr;     // the end of the last 3D frame on the caller's stream ("is the frame before still under way?")

@@ -157,6 +157,13 @@ fhip_status fhip_debug_trans_probe(fhip_ctx* ctx, uint32_t copy, uint32_t fn, ui
     return FHIP_OK;
 }
 
+// Diagnostics: how many 3D frames of this context (its lanes included) were rendered in rare mode (capi_render.hpp render3d) so far
+uint64_t fhip_debug_rare_frames(const fhip_ctx* ctx) {
+    if (!ctx) return 0;
+    uint64_t n = ctx->rare_frames;
+    for (const fhip_ctx* l : ctx->lanes) n += l ? l->rare_frames : 0;
+    return n;
+}
 // Diagnostics: how many frames of this context went to a frame lane (capi_render.hpp run_on_lane) so far
 uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx) { return ctx ? ctx->lane_frames : 0; }
 // ... and what the arrangement tuner (capi_render.hpp lane_mode) knows about the kind of 3D frame queued last: its phase (0 / 1 / 2 measuring the

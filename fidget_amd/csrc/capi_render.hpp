@@ -613,12 +613,22 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         else FH_KLAUNCH((k_tiles<IS3D, FULL, BIG, 16>), dim3(grid), dim3(WAVE), lds, ctx->stream, dS, level);            \
     } while (0)
 // 3D tile stage of one level as three kernels (see kernels.hip "Split 3D tile stage")
+// Rare mode: blocks per folded launch, and where a slab context's blocks keep their register files (a slab context = one FhRenderState of the set)
+static const uint32_t FH_RARE_BLOCKS = 8;
+static char* rare_file(fhip_ctx* ctx, FhRenderState* dS) {
+    if (!ctx->rare_now) return nullptr;
+    return (char*)ctx->rare_scratch.p + (size_t)(dS - (FhRenderState*)ctx->state.p) * FH_RARE_BLOCKS * ctx->rare_stride;
+}
 static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderState* dS, int level, bool is3d) {
     // Persistent waves with a static round robin over the parents (one short workgroup per parent was measured slower in the
     // pipelined frame: the tile stage then takes more of the machine from the leaf kernel it overlaps with).
     const int gs = blocks_for(ctx, R.lds_tiles_small, 8);
     const int gb = blocks_big(ctx, R, R.lds_tiles_big, 8);
     const int gp = ctx->n_cu * 8;
+    // Rare mode (render3d): at a per-slab level the two launches for parents outside the small slot list are not made; the push kernel's last
+    // blocks evaluate such parents in C++ (none, nearly always)
+    const bool rare_level = ctx->rare_now && is3d && R.asm_tiles && !ctx->opt.no_tiles_v && level > 0 && R.S.pre_levels > 0 && (uint32_t)level >= R.S.pre_levels &&
+                            !(R.prune1 && (uint32_t)level < R.exp_levels);
     launch(ctx, FHIP_K_TILES, [&] {
         if (is3d) FH_KLAUNCH(k_tsetup3d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
         else FH_KLAUNCH(k_tsetup2d, dim3(gp), dim3(WAVE), 0, ctx->stream, dS, level);
@@ -714,6 +724,7 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             bool rest = true;   // anything left for the root-sized LDS layout?
             // (leaving the per-slab levels' big-list parents to the root-sized LDS launch alone - one launch less on the slab's tile
             // chain - was measured: 1.02 vs 1.04 ms per frame, within the noise; not done)
+            if (rare_level) return;      // (the parents outside the small list: the blocks behind k_tpush3d's)
             if (vk && level > 0) {
                 const int v64_waves = 8;
                 // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
@@ -773,7 +784,8 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
     const int gpush = (level + 1 == (int)R.S.P.n_levels) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
         // (above the leaf level: 16 more waves per parent for the fills of its interval-full children - kernels.hip tfill3d_body)
-        if (is3d) FH_KLAUNCH(k_tpush3d, dim3(gpush, (level + 1 == (int)R.S.P.n_levels) ? 1 : 17), dim3(WAVE), 0, ctx->stream, dS, level);
+        const uint32_t rb = rare_level ? FH_RARE_BLOCKS : 0u;
+        if (is3d) FH_KLAUNCH(k_tpush3d, dim3(gpush + rb, (level + 1 == (int)R.S.P.n_levels) ? 1 : 17), dim3(WAVE), 0, ctx->stream, dS, level, rb, rare_file(ctx, dS), ctx->rare_stride);
         else {
             if (!R.classify_only) FH_KLAUNCH(k_tpush2d, dim3(gpush), dim3(WAVE), 0, ctx->stream, dS, level);
             const uint32_t slots_max = R.S.qcap[level] * ((level == 0 && R.groups) ? R.S.n_tgroups : 1u);
@@ -1028,6 +1040,24 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // level 1 - the flags of its children, the frame mark, the fork of the slab contexts - goes to the stream the tile chains run on)
     // (only for frames whose tile chains will run on the tail stream - `tiles_first` below, the same conditions: a frame with heavy leaf
     // kernels keeps its tile chains on the side stream, and its fork must not queue behind the previous frame's tail work)
+    // Rare mode.  Four launches of a slab exist for tapes too large for the assembly kernels' register files - a leaf of more than 32
+    // registers (its points, then its normals, in the C++ kernels with an LDS file), a parent of a per-slab tile level outside the small
+    // slot list (fh_tiles_v64, then fh_tiles) - and find nothing to do in nearly every frame: prospero.vm 1024^3 0.138 -> 0.126 ms per
+    // frame without them.  While the last finished frame of this context met no such tape (k_finish3d: host_flags[2]) the slab does not
+    // make them: the last FH_RARE_BLOCKS blocks of k_classify3d, k_hits3d and k_tpush3d do their work - correct for any number of such
+    // tapes, slow for many (a wave per block, the register files in HBM), and the first frame that meets one puts the launches back.
+    {
+        const size_t need = std::max(std::max(R.lds_tiles_big, R.lds_points_big), R.lds_normals_big);
+        const size_t stride = (need + 255) / 256 * 256;
+        ctx->rare_now = R.split && R.asm_tiles && R.asm_points && R.asm_normals && !R.big_hbm && P.max_regs > 32 && ctx->host_flags && ctx->host_flags[2] == 0 &&
+                        stride * FH_RARE_BLOCKS * 4 <= ((size_t)256 << 20);
+        if (ctx->rare_now) {
+            HIP_TRY(ctx, ctx->rare_scratch.ensure(stride * FH_RARE_BLOCKS * 4));      // (a set's state buffer holds four slab contexts)
+            ctx->rare_stride = (uint32_t)stride;
+            ctx->rare_frames++;
+        }
+    }
+    const bool rare = ctx->rare_now;
     bool l1_only = false;
     if (l1_side && pre == 2 && ctx->stream3 && R.asm_points) {
         const bool pipe_plan = ctx->use_pipeline && !ctx->profiling && R.slab_hi - R.slab_lo > 1 && n_groups > 0 && !R.big_hbm;
@@ -1174,8 +1204,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         const bool tail = pipe && ctx->stream3 && tail_mode > 0 && R.asm_points && !on_main && !R.alt_pre;   // (the HIP leaf kernels walk the footprint lists)
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
-            launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_classify3d, dim3(class_blocks), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0); });
-            if (P.max_regs > 32)
+            launch(ctx, FHIP_K_OTHER, [&] {
+                FH_KLAUNCH(k_classify3d, dim3(class_blocks + (rare ? FH_RARE_BLOCKS : 0u)), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0, (uint32_t)class_blocks,
+                           rare_file(ctx, dS), ctx->rare_stride);
+            });
+            if (P.max_regs > 32 && !rare)      // (rare mode: in the blocks behind k_classify3d's)
                 launch(ctx, FHIP_K_POINTS, [&] {
                     const int g = blocks_big(ctx, R, R.lds_points_big, 16);
                     if (R.full) FH_KLAUNCH((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
@@ -1191,14 +1224,15 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 if (R.asm_normals) {
                     // (lists 0 and 1 of k_classify3d hold every footprint whose leaves need <= 32 registers - the assembly interpreter's file:
                     // k_hits3d turns them into the list of leaves that own a hit, the normals kernel takes one leaf per wave pass)
-                    FH_KLAUNCH(k_hits3d, dim3(std::min<uint32_t>((R.n_footprints + 3) / 4, (uint32_t)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, dS, z_lo, z_hi, R.hit_bucket_cap);
+                    const uint32_t hb = std::min<uint32_t>((R.n_footprints + 3) / 4, (uint32_t)ctx->n_cu * 16);
+                    FH_KLAUNCH(k_hits3d, dim3(hb + (rare ? FH_RARE_BLOCKS : 0u)), dim3(256), 0, ctx->stream, dS, z_lo, z_hi, R.hit_bucket_cap, hb, rare_file(ctx, dS), ctx->rare_stride);
                     // (wave w walks bucket w % 64 with a stride of n_waves / 64)
                     struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, bucket_cap, pad; } kn = {dS, std::max<uint32_t>((uint32_t)(ctx->n_cu * 8) / FH_HIT_BUCKETS, 1u) * FH_HIT_BUCKETS, R.col_slots, z_lo, z_hi, R.hit_bucket_cap, 0};
                     (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));
                 }
                 else if (R.full) FH_KLAUNCH((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 else FH_KLAUNCH((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
-                if (P.max_regs > 32) {
+                if (P.max_regs > 32 && !(rare && R.asm_normals)) {      // (rare mode: in the blocks behind k_hits3d's)
                     if (R.full) FH_KLAUNCH((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
                     else FH_KLAUNCH((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
                 }

@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > 32) { atomicAdd(&S->n_leaves_lds, 1u); S->rare_seen = 1u; }  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     S->leaf_table[(size_t)((cz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                         FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
@@ -604,7 +604,10 @@ FH_DEV void tsetup_body(FhRenderState* S, int level) {
     // unchanged: the lockstep prune's cost is the ops SOME child keeps, and neighbours keep much the same - and taken out)
     const uint32_t G = TG;      // slots per parent (tape groups at level 0)
     const uint32_t ns = min(S->count[level], S->slot_cap[0] / G), nb = min(S->count_big[level], S->slot_cap[1] / G);
-    if (blockIdx.x == 0 && lane == 0) { S->n_slots[0][level] = ns * G; S->n_slots[1][level] = nb * G; }
+    if (blockIdx.x == 0 && lane == 0) {
+        S->n_slots[0][level] = ns * G; S->n_slots[1][level] = nb * G;
+        if (IS3D && nb && S->pre_levels > 0 && (uint32_t)level >= S->pre_levels) S->rare_seen = 1u;      // (a per-slab level's parent outside the small list)
+    }
     // (root level with tape groups: a parent has one slot per group - 32 for prospero.vm - and a frame of few root tiles is a handful of
     // parents: the slots of a parent are shared out over `parts` waves, each repeating the little arithmetic and writing its slots)
     const uint32_t parts = TG > 1 ? max(1u, min(TG, gridDim.x / max(ns + nb, 1u))) : 1u;
@@ -947,21 +950,23 @@ __global__ void __launch_bounds__(WAVE) k_teval3d(FhRenderState* S, int level) {
 }
 
 // Step 3: fills of the decided children, queue / leaf entries for the ambiguous ones
+// which: 0 every slot, 1 the small list only, 2 the other list only (rare mode: k_tpush3d)
 template <bool IS3D>
-FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t stride) {
+FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t stride, int which = 0) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
     const uint32_t ntx = (P.width + T - 1) / T;
     const bool last_level = (level + 1 == (int)P.n_levels);
     const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    const uint32_t s_lo = which == 2 ? n0 : 0u, s_hi = which == 1 ? n0 : n0 + n1;
     // Leaves: ONE reservation per wave for all its parents (a first pass counts them).  One atomic per
     // parent on the same counter serialises in L2, ~15 ns each: with thousands of parents that was
     // nearly all of this kernel's time.
     uint32_t leaf_base = 0;
     if (last_level) {
         uint32_t mine = 0;
-        for (uint32_t si = first; si < n0 + n1; si += stride) {
+        for (uint32_t si = s_lo + first; si < s_hi; si += stride) {
             const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
             const uint64_t actm = sl.act;
             if (uni((uint32_t)(actm != 0)) == 0) continue;
@@ -971,7 +976,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         if (lane == 0 && mine) leaf_base = atomicAdd(&S->n_leaves, mine);
         leaf_base = uni(leaf_base);
     }
-    for (uint32_t si = first; si < n0 + n1; si += stride) {
+    for (uint32_t si = s_lo + first; si < s_hi; si += stride) {
         const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
         if (uni((uint32_t)(sl.act != 0)) == 0) continue;
         const bool act = (sl.act >> lane) & 1;
@@ -989,7 +994,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
         const uint64_t fullm = ballot(full);
         // (2D: k_tfill2d, one workgroup per decided tile - the root level's 128 x 128 fills by 16 waves took 1.9 ms; 3D above the leaf
         // level: the launch's fill waves, tfill3d_body - blockIdx.y > 0)
-        uint64_t fm = (IS3D && gridDim.y == 1) ? fullm : 0ull;
+        uint64_t fm = (IS3D && (gridDim.y == 1 || which == 2)) ? fullm : 0ull;
         while (fm) {  // interval-full tiles write fill_z = corner_z + T + 1 (voxel.rs:283, 310-317)
             const int c = __builtin_ctzll(fm);
             fm &= fm - 1;
@@ -1065,7 +1070,7 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                     FhLeaf lf;
                     lf.tape = child; lf.x = cx; lf.y = cy; lf.z = iz;
                     S->leaves[lb + slot] = lf;
-                    if (child.n_regs > 32) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
+                    if (child.n_regs > 32) { atomicAdd(&S->n_leaves_lds, 1u); S->rare_seen = 1u; }  // rare: lets k_leaves3d<2> return at once otherwise
                     if (IS3D)
                         S->leaf_table[(size_t)((iz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                             FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
@@ -1079,11 +1084,11 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
 // few dozen pre-pass parents full of them: bear.vm 512^3, 187 us of a 1 ms frame in ONE launch of 64 busy waves.  Here `parts` waves
 // share a parent's children, and a full child behind another full child of the same parent (same x, y, smaller z: its fill is the
 // smaller number of an atomic max) is skipped.
-FH_DEV void tfill3d_body(FhRenderState* S, int level, uint32_t first, uint32_t stride, uint32_t part, uint32_t parts) {
+FH_DEV void tfill3d_body(FhRenderState* S, int level, uint32_t first, uint32_t stride, uint32_t part, uint32_t parts, bool small_only) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const int lane = threadIdx.x;
     const uint32_t T = P.tiles[level];
-    const uint32_t n0 = S->n_slots[0][level], n1 = S->n_slots[1][level];
+    const uint32_t n0 = S->n_slots[0][level], n1 = small_only ? 0u : S->n_slots[1][level];
     for (uint32_t si = first; si < n0 + n1; si += stride) {
         const FhSlot& sl = si < n0 ? S->slots[0][si] : S->slots[1][si - n0];
         if (uni((uint32_t)(sl.act != 0)) == 0) continue;
@@ -1110,9 +1115,22 @@ FH_DEV void tfill3d_body(FhRenderState* S, int level, uint32_t first, uint32_t s
         }
     }
 }
-__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level) {
-    if (blockIdx.y == 0) tpush_body<true>(S, level, blockIdx.x, gridDim.x);
-    else tfill3d_body(S, level, blockIdx.x, gridDim.x, blockIdx.y - 1, gridDim.y - 1);
+// Rare mode (capi_render.hpp): the last `rare_blocks` blocks are the level's launches for the parents outside the small slot list - none,
+// nearly always: each evaluates and prunes its share of them in C++ (teval_slots, the interval file in HBM: `rare_stride` bytes per block from
+// `rare_file`) and pushes their children itself; the other blocks keep to the small list.
+__global__ void __launch_bounds__(WAVE) k_tpush3d(FhRenderState* S, int level, uint32_t rare_blocks, char* rare_file, uint32_t rare_stride) {
+    const uint32_t nb = gridDim.x - rare_blocks;
+    if (blockIdx.x >= nb) {
+        if (blockIdx.y) return;
+        const uint32_t e = blockIdx.x - nb;
+        if (S->n_slots[1][level] == 0) return;
+        teval_slots<true, true>(S, level, rare_file + (size_t)e * rare_stride, e, rare_blocks);
+        __threadfence_block();
+        tpush_body<true>(S, level, e, rare_blocks, 2);
+        return;
+    }
+    if (blockIdx.y == 0) tpush_body<true>(S, level, blockIdx.x, nb, rare_blocks ? 1 : 0);
+    else tfill3d_body(S, level, blockIdx.x, nb, blockIdx.y - 1, gridDim.y - 1, rare_blocks != 0);
 }
 __global__ void __launch_bounds__(WAVE) k_tpush2d(FhRenderState* S, int level) { tpush_body<false>(S, level, blockIdx.x, gridDim.x); }
 // 2D fills (pixel.rs:345-368, 225-229): a tile whose interval is decided becomes a NaN-boxed fill carrying the level it was
@@ -1278,7 +1296,15 @@ __global__ void __launch_bounds__(WAVE) k_pixels2d(FhRenderState* S) {
 // layers took 26 us at 1024^2, on the caller's stream of every frame since the tail stream carries root levels: 64 loads, eight in
 // flight.)
 #define FH_CLASSIFY_FP 32
-__global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge01) {
+template <int CLS, int NR, int ZB, bool FULL>
+FH_DEV void leaves3d_body(FhRenderState* S, char* file, uint32_t first, uint32_t stride);
+// (rare mode, capi_render.hpp: the blocks behind `class_blocks` are the slab's launch for leaves of more than 32 registers - none, nearly
+// always - with their register files in HBM, `rare_stride` bytes each from `rare_file`: a wave per block)
+__global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge01, uint32_t class_blocks, char* rare_file, uint32_t rare_stride) {
+    if (blockIdx.x >= class_blocks) {
+        if (threadIdx.x < WAVE) leaves3d_body<2, 0, 1, true>(S, rare_file + (size_t)(blockIdx.x - class_blocks) * rare_stride, blockIdx.x - class_blocks, gridDim.x - class_blocks);
+        return;
+    }
     __shared__ uint32_t mx_s[FH_CLASSIFY_FP], any_s[FH_CLASSIFY_FP];
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
@@ -1324,18 +1350,18 @@ __global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge0
 // to the z-buffer with a 64-bit atomic max (depth << 32 | leaf), so the order in which waves reach
 // the leaves of one column does not matter; a leaf whose pixels are all hit in front of it retires
 // after one load.  CLS: leaves of <= 16 registers, 17..32, more (LDS register file).
+// (file: the register file of class 2 - LDS, or a region of HBM; first, stride: this wave's leaves)
 template <int CLS, int NR, int ZB, bool FULL>
-__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+FH_DEV void leaves3d_body(FhRenderState* S, char* file, uint32_t first, uint32_t stride) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t T = P.tiles[P.n_levels - 1];  // T*T == 64 lanes
     Mat4 mat;
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     const uint32_t n_leaves = min(S->n_leaves, S->leaf_cap);
     if (CLS == 2 && S->n_leaves_lds == 0) return;
-    for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
+    for (uint32_t li = first; li < n_leaves; li += stride) {
         const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
         const uint32_t regs = lf.tape.n_regs;
         if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= 32)) continue;
@@ -1352,7 +1378,7 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
             float x[ZB], y[ZB], z[ZB], res[ZB];
             FOR_Z { xf_point(mat, (float)px, (float)py, (float)(lz + k - j), x[j], y[j], z[j]); res[j] = 0.0f; }
             if (NR) run_points<(NR ? NR : 1), ZB, FULL>(tape, len, P, x, y, z, res);
-            else res[0] = run_points_lds<FULL>(tape, len, P, (float*)big_file(S, smem), lane, x[0], y[0], z[0]);
+            else res[0] = run_points_lds<FULL>(tape, len, P, (float*)file, lane, x[0], y[0], z[0]);
             FOR_Z {
                 if (pending && res[j] < 0.0f) {  // first voxel inside, front to back
                     depth = lz + (uint32_t)(k - j) + 1;
@@ -1365,6 +1391,11 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
         if (hit) atomicMax((unsigned long long*)&S->zbuf[pix], ((unsigned long long)depth << 32) | (li + 1));
     }
 }
+template <int CLS, int NR, int ZB, bool FULL>
+__global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    leaves3d_body<CLS, NR, ZB, FULL>(S, CLS == 2 ? big_file(S, smem) : smem, blockIdx.x, gridDim.x);
+}
 
 // Normals for the hits of this slab: gradient of the winning leaf's tape at the voxel one
 // above the hit (voxel.rs:447-482).  Lanes of a footprint may have been hit in different
@@ -1374,20 +1405,19 @@ __global__ void __launch_bounds__(WAVE) k_leaves3d(FhRenderState* S) {
 // z_lo, z_hi: only hits of this slab (z_lo < depth <= z_hi) are this launch's - the leaf kernel of the slab behind may already
 // be running (its hits lie below z_lo and carry leaf numbers of the other slab context).
 template <bool FULL, bool BIG>
-__global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+FH_DEV void normals3d_body(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, char* file, uint32_t first, uint32_t stride) {
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T;
-    Regs<GR, WAVE> R{(GR*)(BIG ? big_file(S, smem) : smem), lane};
+    Regs<GR, WAVE> R{(GR*)file, lane};
     Mat4 mat;
 #pragma unroll
     for (int i = 0; i < 16; i++) mat.m[i] = P.mat[i];
     const uint32_t n_all = BIG ? S->fp_count[2] : S->fp_count[0] + S->fp_count[1];
     // static round robin: an atomic cursor per footprint would cost more than the work (most
     // footprints have no pending hit)
-    for (uint32_t wi = blockIdx.x; wi < n_all; wi += gridDim.x) {
+    for (uint32_t wi = first; wi < n_all; wi += stride) {
         uint32_t fi;
         if (BIG) fi = S->fp_list[2][wi];
         else if (wi < S->fp_count[0]) fi = S->fp_list[0][wi];
@@ -1428,6 +1458,11 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
         }
     }
 }
+template <bool FULL, bool BIG>
+__global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    normals3d_body<FULL, BIG>(S, z_lo, z_hi, BIG ? big_file(S, smem) : smem, blockIdx.x, gridDim.x);
+}
 
 // The work list of the assembly normals kernel (fh_normals, gen_normals.py): every leaf that owns a hit of this slab's depth range in the
 // finished z-buffer, once.  A wave per footprint of the classes the assembly kernel takes (lists 0 and 1 of k_classify3d) reads the 64
@@ -1437,12 +1472,18 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
 // The list is FH_HIT_BUCKETS lists (hit_list: the counters, 256 bytes apart, then the buckets of `bucket_cap` entries): footprint wi of the
 // class lists appends to bucket wi % 64, and wave w of the normals kernel walks bucket w % 64.  (One counter for all: 5.5 k atomics that
 // return a value on ONE address took 82 us on prospero.vm 1024^3 - 15 ns each, one after the other.)
-__global__ void __launch_bounds__(256) k_hits3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, uint32_t bucket_cap) {
+// (rare mode: the blocks behind `hit_blocks` are the slab's normals launch for the footprints with a leaf of more than 32 registers, as in
+// k_classify3d)
+__global__ void __launch_bounds__(256) k_hits3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, uint32_t bucket_cap, uint32_t hit_blocks, char* rare_file, uint32_t rare_stride) {
+    if (blockIdx.x >= hit_blocks) {
+        if (threadIdx.x < WAVE) normals3d_body<true, true>(S, z_lo, z_hi, rare_file + (size_t)(blockIdx.x - hit_blocks) * rare_stride, blockIdx.x - hit_blocks, gridDim.x - hit_blocks);
+        return;
+    }
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t n0 = S->fp_count[0], n_all = n0 + S->fp_count[1];
-    const uint32_t waves = gridDim.x * (256 / WAVE);
+    const uint32_t waves = hit_blocks * (256 / WAVE);
     for (uint32_t wi = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE; wi < n_all; wi += waves) {
         const uint32_t fi = uni(wi < n0 ? S->fp_list[0][wi] : S->fp_list[1][wi - n0]);
         const uint32_t px = (fi & 0xFFFFu) * T + (lane % T), py = (fi >> 16) * T + (lane / T);
@@ -1676,7 +1717,12 @@ __global__ void k_finish3d(FhRenderState* S, FhGeometryPixel* out, uint32_t n_ct
         uint32_t q = 0;
         for (uint32_t k = 0; k < n_ctx; k++) q |= S[k].queue_overflow;
         if (q) atomicOr(sticky, 1u);
-        if (host_flags) latch_arena(S, n_ctx, host_flags);
+        if (host_flags) {
+            latch_arena(S, n_ctx, host_flags);
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < n_ctx; k++) r |= S[k].rare_seen;
+            host_flags[2] = r;      // the frame met a large tape: the next frames launch the kernels for them on their own again (capi_render.hpp rare mode)
+        }
     }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t d = (uint32_t)(S->zbuf[i] >> 32);

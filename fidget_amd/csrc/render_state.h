@@ -127,6 +127,9 @@ struct FhRenderState {
     FhLeaf* leaves;
     uint32_t leaf_cap, n_leaves, leaf_cursor, leaf_cursor_big, normal_cursor, normal_cursor_big;
     uint32_t n_leaves_lds;  // 3D: leaves of this slab that need the LDS register file (> 32 registers)
+    // 3D: this frame met one of the rare large tapes - a leaf of more than 32 registers, or a parent of a per-slab tile level outside the
+    // small slot list - in this slab context (never reset by a slab; k_finish3d tells the host: capi_render.hpp rare mode)
+    uint32_t rare_seen;
     FhLeafRef* leaf_table;  // 3D: [layer][footprint] -> leaf id + 1 and what the leaf kernel needs of the leaf (layer = 8-voxel layer of the slab)
     uint32_t slab_z;        // 3D: z of the current slab's first voxel (a leaf's z = slab_z + 8 * layer)
     uint32_t frame_stamp;   // a number no other frame of this context has: what the linked prune signs the links it leaves in the arena with (prune2.hip)

@@ -28,6 +28,9 @@ fhip_status fhip_debug_probe(fhip_ctx* ctx, float* out);  /* ISA probe (gen_inte
 /* 3D frames of this context that went to a frame lane so far (option frame_lanes: whole frames of a queued sequence on child contexts;
  * the statistics the other debug calls return are then those of the last frame that did NOT) */
 uint64_t fhip_debug_lane_frames(const fhip_ctx* ctx);
+/* 3D frames of this context (its lanes included) rendered in rare mode so far: the launches that exist for tapes beyond the assembly kernels'
+ * register files folded into launches the slab makes anyway - taken while the last finished frame met no such tape */
+uint64_t fhip_debug_rare_frames(const fhip_ctx* ctx);
 /* the arrangement tuner's state for the kind of 3D frame (tape, image size) queued last: returns its phase (0 / 1 / 2 measuring the stage pipeline,
  * the lanes, the stage pipeline again; 3 waiting for the last window's end; 4 decided; -1 none); ms[0 .. 2] = ms per frame of the three windows,
  * *lanes = the decision */

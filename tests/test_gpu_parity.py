@@ -814,3 +814,42 @@ def test_render3d_front_slab_only_for_frames_without_z(dims):
                 assert same_bits_f32(got[..., :3].view(np.float32), ref["normal"]), no_zrep
                 gs = b.cpu().numpy().view(np.uint32)
                 assert (gs[..., 3] == small["depth"]).all() and same_bits_f32(gs[..., :3].view(np.float32), small["normal"]), no_zrep
+
+
+def test_rare_mode_takes_the_large_tapes_it_does_not_expect():
+    """Rare mode (capi_render.hpp): after a frame that met no tape too large for the assembly kernels' register files, a context's next 3D
+    frames fold the launches that exist for such tapes into three launches they make anyway.  A frame that then DOES have such tapes -
+    prospero.vm at 128^3: leaves of more than 32 registers, per-slab parents outside the small list - is rendered by those folded blocks
+    (C++, register files in HBM), bit for bit the oracle's; it tells the host, and the frames after it launch the kernels on their own
+    again - the same image."""
+    hip = F.HipContext(0)
+    hip.set_option("frame_lanes", 0)
+    big, big_o = F.Shape.from_vm(model_path("prospero.vm"), hip=hip), O.Shape.from_vm(model_path("prospero.vm"))
+    want = O.render3d(big_o, 128)[0]
+    a = F.render3d(big, 128)[0]             # (a new context: the launches on their own)
+    hip.sync()
+    assert hip.rare_frames() == 0
+    assert (a["depth"] == want["depth"]).all() and same_bits_f32(a["normal"], want["normal"])
+    for _ in range(2):                      # 1024^3 has no such tape: the second frame knows
+        F.render3d(big, 1024)
+        hip.sync()
+    n0 = hip.rare_frames()
+    assert n0 >= 1, "the frame after one without large tapes is not in rare mode"
+    b = F.render3d(big, 128)[0]             # ... and this one does not expect what it meets
+    hip.sync()
+    assert hip.rare_frames() == n0 + 1
+    assert (b["depth"] == want["depth"]).all(), f"{(b['depth'] != want['depth']).sum()} depths differ in rare mode"
+    assert same_bits_f32(b["normal"], want["normal"])
+    c = F.render3d(big, 128)[0]             # told: on their own again
+    hip.sync()
+    assert hip.rare_frames() == n0 + 1
+    assert (c["depth"] == want["depth"]).all() and same_bits_f32(c["normal"], want["normal"])
+    # the same with bear.vm's transcendental tapes at a size where its leaves are beyond 32 registers too
+    bear, bear_o = F.Shape.from_vm(model_path("bear.vm"), hip=hip), O.Shape.from_vm(model_path("bear.vm"))
+    for _ in range(2):
+        F.render3d(big, 1024)
+        hip.sync()
+    d = F.render3d(bear, 64)[0]
+    hip.sync()
+    w = O.render3d(bear_o, 64)[0]
+    assert (d["depth"] == w["depth"]).all()

@@ -14,7 +14,8 @@ general = (sys.argv[3] if len(sys.argv) > 3 else "general") == "general"
 want_stats = len(sys.argv) > 4 and sys.argv[4] == "stats"
 stream = torch.cuda.current_stream()
 hip = F.HipContext(0, stream.cuda_stream)
-hip.set_option("frame_lanes", 0)
+if not os.environ.get("VR_LANES"):       # (VR_LANES=1: the library's own arrangement of queued frames, as bench.py measures it)
+    hip.set_option("frame_lanes", 0)
 if general:
     hip.set_option("no_column_inv", 1)
 shape = F.Shape.from_vm(os.path.join(ROOT, "models", model), hip=hip)
@@ -37,8 +38,8 @@ for _ in range(4):
 hip.profile(False)
 res["kernel_ms_per_launch"] = {k: round(v[0] / v[1], 4) for k, v in kern.items()}
 res["kernel_launches_per_frame"] = {k: v[1] / 4 for k, v in kern.items()}
-K = 40
-for _ in range(5):
+K = 40 if not os.environ.get("VR_LANES") else 400
+for _ in range(5 if not os.environ.get("VR_LANES") else 150):      # (the arrangement tuner's windows first)
     F.render3d(shape, n, out=out)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
