@@ -8,6 +8,8 @@ static const uint32_t VM_TILES_3D[] = {128, 64, 32, 16, 8};  // fidget-core/src/
 // size, so that exactly the same voxels are covered (a root tile overhanging the image in z is
 // evaluated there by the reference too).
 
+static const uint32_t FH_LEAF_REGS = 40, FH_LEAF_REGS_T = 44;      // (gen_interp.py main(): fh_columns' 40 x 2 shape, fh_columns_t's 44 x 4)
+static const uint32_t FH_NORMAL_REGS = 40;                         // (gen_normals.py NR)
 struct RenderSetup {
     FhRenderState S;
     std::vector<FhGroup> roots;
@@ -236,8 +238,11 @@ static fhip_status prepare(fhip_ctx* ctx, const fhip_tape* tape, bool is3d, cons
     // assembly leaf kernels: supported opcodes only (any 4x4 screen-to-model matrix, projective ones included)
     R.asm_points = ctx->use_asm && is3d && (tape_asm_ok(t) || !ctx->opt.no_columns_t);
     R.asm_points_t = R.asm_points && !tape_asm_ok(t);   // transcendental / modulo / rng opcodes: the variant that calls the compiled routines
+    // (the most registers of a leaf the leaf kernel takes - gen_interp.py main(): the largest register-file shape of fh_columns / fh_columns_t)
+    R.S.leaf_asm_regs = !R.asm_points ? 32u : (R.asm_points_t ? FH_LEAF_REGS_T : FH_LEAF_REGS);
     // (fh_normals_t has the transcendental, rng and atan2 handlers; a modulo's gradient - div_euclid - keeps the C++ kernel)
     R.asm_normals = R.asm_points && !ctx->opt.no_asm_normals && (!R.asm_points_t || !tape_has_mod(t));
+    R.S.norm_asm_regs = R.asm_normals ? FH_NORMAL_REGS : 32u;
 
     // LDS budgets: BIG = bounded by the root tape (children never need more); SMALL = fixed
     R.lds_tiles_big = tiles_lds(P.max_regs, P.max_choices, TL);
@@ -1208,7 +1213,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 FH_KLAUNCH(k_classify3d, dim3(class_blocks + (rare ? FH_RARE_BLOCKS : 0u)), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0, (uint32_t)class_blocks,
                            rare_file(ctx, dS), ctx->rare_stride);
             });
-            if (P.max_regs > 32 && !rare)      // (rare mode: in the blocks behind k_classify3d's)
+            if (P.max_regs > R.S.leaf_asm_regs && !rare)      // (rare mode: in the blocks behind k_classify3d's)
                 launch(ctx, FHIP_K_POINTS, [&] {
                     const int g = blocks_big(ctx, R, R.lds_points_big, 16);
                     if (R.full) FH_KLAUNCH((k_leaves3d<2, 0, 1, true>), dim3(g), dim3(WAVE), R.lds_points_big, ctx->stream, dS);
@@ -1232,7 +1237,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 }
                 else if (R.full) FH_KLAUNCH((k_normals3d<true, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
                 else FH_KLAUNCH((k_normals3d<false, false>), dim3(gs), dim3(WAVE), R.lds_normals_small, ctx->stream, dS, z_lo, z_hi);
-                if (P.max_regs > 32 && !(rare && R.asm_normals)) {      // (rare mode: in the blocks behind k_hits3d's)
+                if (P.max_regs > R.S.norm_asm_regs && !(rare && R.asm_normals)) {      // (rare mode: in the blocks behind k_hits3d's)
                     if (R.full) FH_KLAUNCH((k_normals3d<true, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
                     else FH_KLAUNCH((k_normals3d<false, true>), dim3(gb), dim3(WAVE), R.lds_normals_big, ctx->stream, dS, z_lo, z_hi);
                 }

@@ -1589,7 +1589,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_lshr_b32 {S_RC}, {S_T0}, 24
 	s_and_b32 {S_FX}, {S_T1}, 0xffff
 	s_lshr_b32 {S_FY}, {S_T1}, 16
-	s_cmp_gt_u32 {S_RC}, 32                          ; needs the LDS register file: left to k_leaves3d<2> (never requested ahead)
+	s_cmp_gt_u32 {S_RC}, {its[-1].nr}                          ; needs the LDS register file: left to k_leaves3d<2> (never requested ahead)
 	s_cbranch_scc1 .Lfh_columns_leaf
 	s_lshl_b64 {S_TBASE}, {S_TBASE}, 3
 	s_add_u32 s84, s84, s30
@@ -1691,7 +1691,7 @@ def _gen_columns_body(a, variants, off, kname, trans):
 	s_nop 1
 	s_lshr_b32 {S_T0}, {S_T1}, 24
 	s_and_b32 {S_T1}, {S_T1}, 0xffffff
-	s_cmp_gt_u32 {S_T0}, 32
+	s_cmp_gt_u32 {S_T0}, {its[-1].nr}
 	s_cbranch_scc1 .Lfh_columns_noahead
 	s_cmp_gt_u32 {S_T1}, 64
 	s_cbranch_scc1 .Lfh_columns_noahead
@@ -2139,15 +2139,16 @@ def main():
     if len(sys.argv) > 3:
         import gen_trans
         gen_trans.tables(a, sys.argv[3])   # the compiled routines' constant tables, once for all the kernels that embed them
-    # (register-file shapes of the plain leaf kernel: 10 registers x 8 voxels, 20 x 4, 32 x 2 in the compact map's file of 80)
-    n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)) if EXP == "file64" else ((10, 8), (20, 4), (32, 2)), off)
+    # (register-file shapes of the plain leaf kernel: 10 registers x 8 voxels, 20 x 4, 40 x 2 in the compact map's file of 80 - capi_render.hpp
+    # FH_LEAF_REGS / FH_LEAF_REGS_T say what the largest shape takes: leaves beyond it are the C++ kernel's, one voxel per lane and pass)
+    n, nvg = gen_columns(a, ((8, 8), (16, 4), (32, 2)) if EXP == "file64" else ((10, 8), (20, 4), (40, 2)), off)
     ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     if len(sys.argv) > 3:   # ... and the variant with the transcendental / modulo / rng opcodes (calls the compiled routines)
         # (the compact map with a register file of 96 VGPRs - 12 registers x 8 voxels, 24 x 4, 32 x 2: the tapes that carry these opcodes
         # are smooth blends that prune little - bear.vm's leaves keep 350-430 ops in 17-23 registers -, and two passes of four voxels pay
         # the per-op dispatch half as often as four passes of two; with the routines' window of 24 registers 168 VGPRs, three waves
         # per SIMD - it was 64 + 128 + 64 = 256 and two)
-        n, nvg = gen_columns(a, ((22, 8), (32, 4), (32, 2)), off, trans=sys.argv[3])
+        n, nvg = gen_columns(a, ((22, 8), (44, 4)), off, trans=sys.argv[3])
         ks.append((n, 48, nvg, [(8, "global_buffer")] + [(4, "by_value")] * 6 + [(8, "global_buffer")] + [(4, "by_value")] * 2))
     for nr, zb, cls in ((16, 4, 0), (32, 2, 1)):
         n = gen_bulk(a, nr, zb, off)

@@ -26,7 +26,7 @@ from gen_interp import (Interp, OPS, FILE, S_KERNARG, S_STATE, S_MAT, S_SIGN, S_
                         S_M, S_RET, V_LANE, V_QNAN, V_SQRTC, VT, VU, VW, VD, SRC0, SRC1, DST, kernel_header, kernel_footer, common_consts,
                         handler_base, call_interp)
 
-NR = 32
+NR = 40      # registers of a leaf tape the kernel takes (4 VGPRs each: a file of 160 behind 64 fixed registers - two waves per SIMD as with 32; capi_render.hpp FH_NORMAL_REGS)
 T_BASE = FILE + NR * 4      # register window of the transcendental routines (fh_normals_t)
 S_SLOTX, S_SLOTY, S_SLOTZ = "s0", "s1", "s3"
 S_WI, S_NWG, S_NFP = "s6", "s7", "s40"

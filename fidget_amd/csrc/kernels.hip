@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
                 FhLeaf lf;
                 lf.tape = child; lf.x = cx; lf.y = cy; lf.z = cz;
                 S->leaves[lb + slot] = lf;
-                if (child.n_regs > 32) { atomicAdd(&S->n_leaves_lds, 1u); S->rare_seen = 1u; }  // rare: lets k_leaves3d<2> return at once otherwise
+                if (child.n_regs > S->norm_asm_regs) S->rare_seen = 1u;
+                if (child.n_regs > S->leaf_asm_regs) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                 if (IS3D) {
                     S->leaf_table[(size_t)((cz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                         FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
@@ -1070,7 +1071,8 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
                     FhLeaf lf;
                     lf.tape = child; lf.x = cx; lf.y = cy; lf.z = iz;
                     S->leaves[lb + slot] = lf;
-                    if (child.n_regs > 32) { atomicAdd(&S->n_leaves_lds, 1u); S->rare_seen = 1u; }  // rare: lets k_leaves3d<2> return at once otherwise
+                    if (child.n_regs > S->norm_asm_regs) S->rare_seen = 1u;
+                    if (child.n_regs > S->leaf_asm_regs) atomicAdd(&S->n_leaves_lds, 1u);  // rare: lets k_leaves3d<2> return at once otherwise
                     if (IS3D)
                         S->leaf_table[(size_t)((iz % P.slab) / T) * (ntx * ((P.height + T - 1) / T)) + (size_t)(cy / T) * ntx + cx / T] =
                             FhLeafRef{lb + slot + 1, child.off, child.len | (min((uint32_t)child.n_regs, 255u) << 24), cx | (cy << 16)};  // [layer][footprint]
@@ -1332,7 +1334,7 @@ __global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge0
     any = any_s[fl] != 0;
     // one atomic per block and class instead of one per footprint
     // merge01: the assembly leaf kernel picks the register-file shape per leaf, one list for <= 32 registers
-    const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= 32 ? (merge01 ? 0 : 1) : 2));
+    const int cls = !any ? -1 : (mx <= 16 ? 0 : (mx <= (merge01 ? S->norm_asm_regs : 32u) ? (merge01 ? 0 : 1) : 2));
     const int lane = threadIdx.x & (WAVE - 1);
     for (int c = 0; c < 3; c++) {
         const uint64_t m = ballot(cls == c);
@@ -1364,7 +1366,7 @@ FH_DEV void leaves3d_body(FhRenderState* S, char* file, uint32_t first, uint32_t
     for (uint32_t li = first; li < n_leaves; li += stride) {
         const AS4 FhLeaf& lf = *(const AS4 FhLeaf*)&S->leaves[li];
         const uint32_t regs = lf.tape.n_regs;
-        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= 32)) continue;
+        if (CLS == 0 ? regs > 16 : (CLS == 1 ? (regs <= 16 || regs > 32) : regs <= S->leaf_asm_regs)) continue;
         const uint32_t px = lf.x + (lane % T), py = lf.y + (lane / T), lz = lf.z;
         const bool inimg = px < P.width && py < P.height;
         const size_t pix = (size_t)py * P.width + px;

@@ -130,6 +130,8 @@ struct FhRenderState {
     // 3D: this frame met one of the rare large tapes - a leaf of more than 32 registers, or a parent of a per-slab tile level outside the
     // small slot list - in this slab context (never reset by a slab; k_finish3d tells the host: capi_render.hpp rare mode)
     uint32_t rare_seen;
+    uint32_t norm_asm_regs; // ... and to be the normals kernel's (32: the HIP kernel with the small LDS file; 40: fh_normals) - a footprint with a leaf beyond: list 2, k_normals3d<big>
+    uint32_t leaf_asm_regs; // 3D: the most registers a leaf may need to be the leaf kernel's (32: the HIP classes 0 and 1; the assembly kernels' largest shape) - beyond: k_leaves3d<2>
     FhLeafRef* leaf_table;  // 3D: [layer][footprint] -> leaf id + 1 and what the leaf kernel needs of the leaf (layer = 8-voxel layer of the slab)
     uint32_t slab_z;        // 3D: z of the current slab's first voxel (a leaf's z = slab_z + 8 * layer)
     uint32_t frame_stamp;   // a number no other frame of this context has: what the linked prune signs the links it leaves in the arena with (prune2.hip)

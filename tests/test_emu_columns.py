@@ -266,12 +266,13 @@ def test_block_of_leaves_with_tapes_requested_ahead():
                 hit = e != 0
                 want[hit] = (e[hit] & ~np.uint64(0xFFFFFFFF)) | np.uint64(i + 1)
             assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
-        # an LDS-class leaf (more than 32 registers) in the block is skipped, its neighbours are not disturbed
-        spec = [(t0, sh0.slot_count(), (0, 0, 0)), (t1, 40, (8, 0, 0)), (t1, sh1.slot_count(), (0, 8, 0)), (t0, sh0.slot_count(), (8, 8, 0))]
+        # an LDS-class leaf (more than 40 registers: beyond the kernel's largest shape, 40 x 2) in the block is skipped, its neighbours are not
+        # disturbed; a leaf that says it needs 40 is taken (the 40 x 2 shape: four passes of two voxels)
+        spec = [(t0, sh0.slot_count(), (0, 0, 0)), (t1, 41, (8, 0, 0)), (t1, 40, (0, 8, 0)), (t0, sh0.slot_count(), (8, 8, 0))]
         got = run_block(spec, ik, mat)
         want = np.zeros(256, np.uint64)
         for i, (t, r, xyz) in enumerate(spec):
-            if r > 32:
+            if r > 40:
                 continue
             e = expect(t, ik, mat, xyz, 16)
             hit = e != 0
@@ -279,24 +280,24 @@ def test_block_of_leaves_with_tapes_requested_ahead():
         assert (got == want).all()
 
 
-def wide_trans_shape():
+def wide_trans_shape(nt=18, trans=True):
     """a smooth blend in the manner of bear.vm - 18 exp(-k r_i^2) terms, each used twice (a sum of them over a sum of pairwise
     products), so that all are alive at once: 22 registers, fh_columns_t's 32 x 4 class (two passes of four voxels per lane)"""
     import fidget_amd as F
     c = F.Context()
     x, y, z = c.x(), c.y(), c.z()
-    nt, t = 18, []
+    t = []
     for i in range(nt):
         cx, cy, cz = 0.3 * np.cos(i), 0.3 * np.sin(2 * i), 0.2 * np.cos(3 * i + 1)
         r2 = c.add(c.add(c.square(c.sub(x, float(cx))), c.square(c.sub(y, float(cy)))), c.square(c.sub(z, float(cz))))
-        t.append(c.exp(c.mul(r2, -3.0 - 0.5 * i)))
+        t.append(c.exp(c.mul(r2, -3.0 - 0.5 * i)) if trans else c.div(1.0, c.add(c.mul(r2, 3.0 + 0.5 * i), 0.2)))
     A = t[0]
     for k in range(1, nt):
         A = c.add(A, t[k])
     B = c.mul(t[0], t[nt - 1])
     for k in range(1, nt - 1):
         B = c.add(B, c.mul(t[k], t[nt - 1 - k]))
-    n = c.sub(c.div(A, c.add(B, 0.1)), c.sqrt(c.add(c.ln(c.add(c.square(x), 1.5)), c.sin(y))))
+    n = c.sub(c.div(A, c.add(B, 0.1)), c.sqrt(c.add(c.ln(c.add(c.square(x), 1.5)), c.sin(y))) if trans else c.mul(c.sqrt(c.add(c.square(x), 0.3)), 9.0))
     sh = F.Shape(c, n)
     ik = [3] * 16
     for a in range(3):
@@ -317,6 +318,22 @@ def test_transcendental_leaf_kernel_32x4_class():
             assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
             hits += int((want != 0).sum()); misses += int((want == 0).sum())
     print("pixels hit", hits, "not hit", misses)
+    assert hits > 0
+
+
+@pytest.mark.parametrize("kernel,nt,lo,hi", [("fh_columns_t", 34, 32, 44), ("fh_columns", 34, 32, 40), ("fh_columns", 22, 20, 32)])
+def test_leaves_of_more_than_32_registers_in_the_largest_shapes(kernel, nt, lo, hi):
+    """the leaf kernels' largest register-file shapes (fh_columns 40 x 2: four passes of two voxels; fh_columns_t 44 x 4) take leaves the
+    C++ kernel with its LDS file had until round 6 (a 128^3 frame of prospero.vm: ten such leaves, 0.9 ms)"""
+    sh, tape, ik = wide_trans_shape(nt, trans=kernel.endswith("_t"))
+    assert lo < sh.slot_count() <= hi, sh.slot_count()
+    hits = 0
+    for mat in (AFFINE, ROTATED):
+        for leaf in ((0, 8, 0), (8, 0, 8)):
+            got, _ = run_columns(tape, sh.slot_count(), ik, mat, leaf, kernel=kernel)
+            want = expect(tape, ik, mat, leaf, 16)
+            assert (got == want).all(), f"{(got != want).sum()} z-buffer words differ"
+            hits += int((want != 0).sum())
     assert hits > 0
 
 

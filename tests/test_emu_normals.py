@@ -163,8 +163,8 @@ def run_normals(tapes, in_kind, mat, hits, size=16, z_lo=0, z_hi=1 << 20, kernel
     slots = sum((0xFF if slot[ax] < 0 else slot[ax]) << (8 * ax) for ax in range(3))
     ka = np.array([a_st & 0xFFFFFFFF, a_st >> 32, n_waves, slots, z_lo, z_hi, cap, 0], U32)
     trans = kernel == "fh_normals_t"
-    E.launch(U.program(), mem, kernel, ka.tobytes(), n_waves, lds_bytes=16, n_vgpr=218 if trans else 192, wg_y_sgpr=None,
-             hooks=U.trans_hooks(U.program(), "fh_tn_", 192) if trans else None)
+    E.launch(U.program(), mem, kernel, ka.tobytes(), n_waves, lds_bytes=16, n_vgpr=250 if trans else 224, wg_y_sgpr=None,
+             hooks=U.trans_hooks(U.program(), "fh_tn_", 224) if trans else None)
     return zbuf, normals.reshape(size * size, 3)
 
 
@@ -209,11 +209,11 @@ def same(a, b):
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 6])
 def test_normals_of_random_shapes(seed, mat):
     sh, tape, ik = shape_of(seed)
-    if sh.slot_count() > 32:
-        pytest.skip("more than 32 registers: the C++ kernel's")
+    if sh.slot_count() > 40:
+        pytest.skip("more than 40 registers: the C++ kernel's")
     sh2, tape2, ik2 = shape_of(seed + 1 if seed != 3 else 0)
     tapes = [(tape, sh.slot_count())]
-    if sh2.slot_count() <= 32 and ik2 == ik:
+    if sh2.slot_count() <= 40 and ik2 == ik:
         tapes.append((tape2, sh2.slot_count()))
     rng = np.random.default_rng(seed)
     hits = {}
