@@ -730,7 +730,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
             // (leaving the per-slab levels' big-list parents to the root-sized LDS launch alone - one launch less on the slab's tile
             // chain - was measured: 1.02 vs 1.04 ms per frame, within the noise; not done)
             if (rare_level) return;      // (the parents outside the small list: the blocks behind k_tpush3d's)
-            if (vk && level > 0) {
+            // (a ROOT tape that fits fh_tiles_v64 - 64 registers, 512 choices - and is not pruned through exported choices takes it too:
+            // bear.vm's 23 registers, 512^3: the root level 255 -> 160 us with the interval file in VGPRs instead of LDS)
+            const bool root_v64 = vk && level == 0 && is3d && !R.groups && R.S.P.max_regs <= V64_REGS && R.S.P.max_choices <= V64_CHOICES;
+            if (vk && (level > 0 || root_v64)) {
                 const int v64_waves = 8;
                 // (per-slab levels: the parents' tapes fit fh_tiles_v32 but for a rare one - an empty launch of 2048 waves of 176
                 // VGPRs each, queued behind the leaf kernel of the slab in front, was measured to hold the tile chain up for
@@ -785,7 +788,10 @@ static void launch_tiles_split(fhip_ctx* ctx, const RenderSetup& R, FhRenderStat
         else FH_KLAUNCH((k_teval3d<false, true>), dim3(gb), dim3(WAVE), R.lds_tiles_big, ctx->stream, dS, level);
     });
     // (last level: fewer waves, several parents each - one leaf reservation per wave)
-    const int push_mul = 2;
+#ifndef FH_PUSH_MUL
+#define FH_PUSH_MUL 2
+#endif
+    const int push_mul = FH_PUSH_MUL;
     const int gpush = (level + 1 == (int)R.S.P.n_levels) ? ctx->n_cu * push_mul : gp;
     launch(ctx, FHIP_K_TILES, [&] {
         // (above the leaf level: 16 more waves per parent for the fills of its interval-full children - kernels.hip tfill3d_body)
