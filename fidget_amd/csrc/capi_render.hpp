@@ -1079,12 +1079,12 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         for (uint32_t l = 0; l < pre; l++) {
             const bool flags_here = R.zrep && l > 0;
             if (l == 1 && l1_side) {
-                if (flags_here && l1_only) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+                if (flags_here && l1_only) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0, FhFork{}); });
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream_pre));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_l0, 0));
                 ctx->stream = ctx->stream2;
             }
-            if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0); });
+            if (flags_here && !(l == 1 && l1_only)) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 4), dim3(WAVE), 0, ctx->stream, dS, (int)l, R.col_depmask, 0, FhFork{}); });
             ctx->post_v64_stream = (l == 1 && l1_only) ? ctx->stream3 : nullptr;
             launch_tiles(ctx, R, dS, (int)l, true);
             ctx->post_v64_stream = nullptr;
@@ -1104,6 +1104,11 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     hipStream_t const side_stream = ctx->stream2;
     const uint32_t NC = pipe ? std::min<uint32_t>(ctx->slab_contexts, R.slab_hi - R.slab_lo) : 1;     // (no more contexts than slabs: each takes its share of the arena)
     ctx->forked = pipe ? NC : 0;
+    FhFork fork{};
+    fork.n = NC; fork.mark = (pre && n_groups) ? 1u : 0u;
+    fork.leaves = (FhLeaf*)ctx->leaves_b.p; fork.leaf_table = (FhLeafRef*)ctx->leaf_table_b.p; fork.fp_lists = (uint32_t*)ctx->fp_lists_b.p;
+    fork.leaf_cap = (size_t)R.S.leaf_cap; fork.n_footprints = (size_t)R.n_footprints; fork.hit_words = R.hit_words;
+    bool forked_here = false;
     if (pre && n_groups) {
         // (one coarse level - root tiles of 32^3 - in a pipelined frame: that level IS the frame's longest chain and the pre-pass stream the
         // pacemaker of the pipeline, so what follows its push - the flags of the parked parents, the frame mark, the fork of the slab
@@ -1113,13 +1118,15 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
             HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_l0, 0));
             ctx->stream = side_stream;
         }
-        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 8), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1); });
-        if (!pipe) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
+        if (R.zrep) launch(ctx, FHIP_K_OTHER, [&] {
+            // (the fork of a pipelined frame's slab contexts - or, with ONE context, the frame mark alone - in the same launch)
+            FH_KLAUNCH(k_tape_flags, dim3(ctx->n_cu * 8 + 1), dim3(WAVE), 0, ctx->stream, dS, (int)pre, R.col_depmask, 1, fork);
+            forked_here = true;
+        });
+        if (!pipe && !forked_here) launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_mark_frame, dim3(1), dim3(1), 0, ctx->stream, dS); });
     }
     if (pipe) {
-        FH_KLAUNCH(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, NC, (FhLeaf*)ctx->leaves_b.p,
-                           (FhLeafRef*)ctx->leaf_table_b.p, (uint32_t*)ctx->fp_lists_b.p, (size_t)R.S.leaf_cap, (size_t)R.n_footprints, R.hit_words,
-                           (pre && n_groups) ? 1u : 0u);
+        if (!forked_here) FH_KLAUNCH(k_fork_state, dim3(1), dim3(1), 0, ctx->stream, dS0, fork);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         if (ctx->stream != side_stream) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }

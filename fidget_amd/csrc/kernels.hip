@@ -553,14 +553,47 @@ __global__ void __launch_bounds__(WAVE) k_tiles(FhRenderState* S, int level) {
 // Which queued parents have a tape that reads no input changing along z (`depmask`: bit per input slot, from the camera
 // matrix - capi.hip)?  Their children repeat along z (tsetup_body / tpush_body).  One wave per queue entry, the tape scanned
 // 64 ops at a time; parked = 0: the queue of `level`; 1: the per-slab parking queues of the first per-slab level.
-__global__ void __launch_bounds__(WAVE) k_tape_flags(FhRenderState* S, int level, uint32_t depmask, int parked) {
+// Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
+// pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
+struct FhFork {
+    uint32_t n, mark;       // contexts (0: nothing to do); also k_mark_frame's work
+    FhLeaf* leaves; FhLeafRef* leaf_table; uint32_t* fp_lists;
+    size_t leaf_cap, n_footprints, hit_words;
+};
+FH_DEV void fork_state_body(FhRenderState* A, const FhFork& f) {
+    if (f.mark) A->arena_frame_end = min(A->arena_head, A->arena_cap);      // (k_mark_frame's work in the same launch: one kernel boundary less on the coarse chain)
+    // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
+    const uint32_t n = f.n;
+    const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
+    const uint32_t part = (A->arena_cap - lo) / n;
+    for (uint32_t k = 1; k < n; k++) {
+        FhRenderState* B = A + k;
+        *B = *A;
+        B->leaves = f.leaves + (k - 1) * f.leaf_cap; B->leaf_table = f.leaf_table + (k - 1) * f.leaf_cap;
+        uint32_t* fp = f.fp_lists + (k - 1) * (3 * f.n_footprints + f.hit_words);
+        B->fp_list[0] = fp; B->fp_list[1] = fp + f.n_footprints; B->fp_list[2] = fp + 2 * f.n_footprints; B->hit_list = fp + 3 * f.n_footprints;
+        B->arena_frame_end = lo + k * part; B->arena_root_end = lo + k * part;
+        B->arena_cap = lo + (k + 1) * part;
+    }
+    A->arena_cap = lo + part;
+}
+__global__ void k_fork_state(FhRenderState* A, FhFork f) { fork_state_body(A, f); }
+
+// (fork.n != 0: the launch's last block forks the slab contexts - k_fork_state's work, which touches nothing this kernel reads or writes: the
+// state's arena bounds and pointers against the queue entries' flags - one launch less on the frame's coarse chain)
+__global__ void __launch_bounds__(WAVE) k_tape_flags(FhRenderState* S, int level, uint32_t depmask, int parked, FhFork fork) {
+    const uint32_t n_blocks = gridDim.x - (fork.n ? 1u : 0u);
+    if (blockIdx.x >= n_blocks) {
+        if (threadIdx.x == 0) fork_state_body(S, fork);
+        return;
+    }
     const int lane = threadIdx.x;
     const uint32_t nq = parked ? S->n_slabs : 1u;
     for (uint32_t q = 0; q < nq; q++) {
         FhGroup* const base = parked ? S->squeue + (size_t)q * S->squeue_cap : S->queue[level];
         const uint32_t cap = parked ? S->squeue_cap : S->qcap[level];
         const uint32_t ns = parked ? S->scount[q] : S->count[level], nb = parked ? S->scount_big[q] : S->count_big[level];
-        for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += gridDim.x) {
+        for (uint32_t gi = blockIdx.x; gi < ns + nb; gi += n_blocks) {
             FhGroup& g = base[gi < ns ? gi : cap - 1 - (gi - ns)];
             const ctape_t tape = (ctape_t)(S->arena + g.tape.off);
             const uint32_t len = uni(g.tape.len);
@@ -1544,25 +1577,6 @@ FH_DEV void reset_slab_body(FhRenderState* S, uint32_t i, uint32_t stride, uint3
 }
 __global__ void k_reset_slab(FhRenderState* S, uint32_t table_words, uint32_t slab, uint32_t n_root_groups, uint32_t reset_root_mind) {
     reset_slab_body(S, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, table_words, slab, n_root_groups, reset_root_mind);
-}
-// Second slab context for the two-stream pipeline over the z-slabs: a copy of the state after the
-// pre-pass with its own leaves, leaf table and footprint lists and the upper half of the free arena
-__global__ void k_fork_state(FhRenderState* A, uint32_t n, FhLeaf* leaves, FhLeafRef* leaf_table, uint32_t* fp_lists,
-                             size_t leaf_cap, size_t n_footprints, size_t hit_words, uint32_t mark) {
-    if (mark) A->arena_frame_end = min(A->arena_head, A->arena_cap);      // (k_mark_frame's work in the same launch: one kernel boundary less on the coarse chain)
-    // contexts A[1] .. A[n-1]: copies of A[0] with their own leaves, leaf table, footprint lists and 1/n of the free arena
-    const uint32_t lo = min(A->pre_levels ? A->arena_frame_end : A->arena_root_end, A->arena_cap);
-    const uint32_t part = (A->arena_cap - lo) / n;
-    for (uint32_t k = 1; k < n; k++) {
-        FhRenderState* B = A + k;
-        *B = *A;
-        B->leaves = leaves + (k - 1) * leaf_cap; B->leaf_table = leaf_table + (k - 1) * leaf_cap;
-        uint32_t* fp = fp_lists + (k - 1) * (3 * n_footprints + hit_words);
-        B->fp_list[0] = fp; B->fp_list[1] = fp + n_footprints; B->fp_list[2] = fp + 2 * n_footprints; B->hit_list = fp + 3 * n_footprints;
-        B->arena_frame_end = lo + k * part; B->arena_root_end = lo + k * part;
-        B->arena_cap = lo + (k + 1) * part;
-    }
-    A->arena_cap = lo + part;
 }
 // End of the pre-pass: everything allocated so far lives for the whole frame
 // The head of a frame in ONE launch (it was five asynchronous copies / fills, each a launch of the runtime's own with its gap in front -
