@@ -1178,7 +1178,8 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 FH_KLAUNCH(k_slab_begin3, dim3(n1 + reset_blocks), dim3(256), 0, ctx->stream, dS, n1, R.table_words, (uint32_t)k, n_groups);
                 return;
             }
-            FH_KLAUNCH(k_reset_slab, dim3(reset_blocks), dim3(256), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
+            // (workgroups of one wave: they find room beside a leaf kernel that fills the machine - 73 us per launch on the general path with four)
+            FH_KLAUNCH(k_reset_slab, dim3(reset_blocks * 4), dim3(WAVE), 0, ctx->stream, dS, R.table_words, (uint32_t)k, n_groups,
                                (pyr3 && rebuild) ? 1u : 0u);
             if (rebuild && pyr3) {
                 const uint32_t n1 = ((P.width + 31) / 32) * ((P.height + 31) / 32);
@@ -1242,8 +1243,8 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
                 if (R.asm_normals) {
                     // (lists 0 and 1 of k_classify3d hold every footprint whose leaves need <= 32 registers - the assembly interpreter's file:
                     // k_hits3d turns them into the list of leaves that own a hit, the normals kernel takes one leaf per wave pass)
-                    const uint32_t hb = std::min<uint32_t>((R.n_footprints + 3) / 4, (uint32_t)ctx->n_cu * 16);
-                    FH_KLAUNCH(k_hits3d, dim3(hb + (rare ? FH_RARE_BLOCKS : 0u)), dim3(256), 0, ctx->stream, dS, z_lo, z_hi, R.hit_bucket_cap, hb, rare_file(ctx, dS), ctx->rare_stride);
+                    const uint32_t hb = std::min<uint32_t>(R.n_footprints, (uint32_t)ctx->n_cu * 64);
+                    FH_KLAUNCH(k_hits3d, dim3(hb + (rare ? FH_RARE_BLOCKS : 0u)), dim3(WAVE), 0, ctx->stream, dS, z_lo, z_hi, R.hit_bucket_cap, hb, rare_file(ctx, dS), ctx->rare_stride);
                     // (wave w walks bucket w % 64 with a stride of n_waves / 64)
                     struct { FhRenderState* S; uint32_t n_waves, slots, z_lo, z_hi, bucket_cap, pad; } kn = {dS, std::max<uint32_t>((uint32_t)(ctx->n_cu * 8) / FH_HIT_BUCKETS, 1u) * FH_HIT_BUCKETS, R.col_slots, z_lo, z_hi, R.hit_bucket_cap, 0};
                     (void)launch_asm(ctx, R.asm_points_t ? FH_ASM_NORMALS_T : FH_ASM_NORMALS, kn.n_waves, &kn, sizeof(kn));

@@ -1034,6 +1034,9 @@ FH_DEV void tpush_body(FhRenderState* S, int level, uint32_t first, uint32_t str
             fm &= fm - 1;
             const uint32_t ccx = __shfl(cx, c, WAVE), ccy = __shfl(cy, c, WAVE);
             if (IS3D) {
+                // (a full child behind another full child of this parent - same x, y, smaller z - fills with the smaller number of an
+                // atomic max: skipped.  A solid interior is stacks of four such children)
+                if (ballot(full && cx == ccx && cy == ccy && cz > __shfl(cz, c, WAVE))) continue;
                 // (of the instances stacked along z the nearest one's fill is the maximum)
                 const uint64_t v = (uint64_t)(__shfl(cz, c, WAVE) + (ninst - 1) * T + T + 1) << 32;
                 for (uint32_t p = lane; p < T * T; p += WAVE) {
@@ -1509,17 +1512,18 @@ __global__ void __launch_bounds__(WAVE) k_normals3d(FhRenderState* S, uint32_t z
 // return a value on ONE address took 82 us on prospero.vm 1024^3 - 15 ns each, one after the other.)
 // (rare mode: the blocks behind `hit_blocks` are the slab's normals launch for the footprints with a leaf of more than 32 registers, as in
 // k_classify3d)
-__global__ void __launch_bounds__(256) k_hits3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, uint32_t bucket_cap, uint32_t hit_blocks, char* rare_file, uint32_t rare_stride) {
+// (workgroups of ONE wave: beside a leaf kernel that fills the machine a workgroup of four waits for four free slots of one compute unit -
+// 195 us per launch on the general path against 4 alone)
+__global__ void __launch_bounds__(WAVE) k_hits3d(FhRenderState* S, uint32_t z_lo, uint32_t z_hi, uint32_t bucket_cap, uint32_t hit_blocks, char* rare_file, uint32_t rare_stride) {
     if (blockIdx.x >= hit_blocks) {
-        if (threadIdx.x < WAVE) normals3d_body<true, true>(S, z_lo, z_hi, rare_file + (size_t)(blockIdx.x - hit_blocks) * rare_stride, blockIdx.x - hit_blocks, gridDim.x - hit_blocks);
+        normals3d_body<true, true>(S, z_lo, z_hi, rare_file + (size_t)(blockIdx.x - hit_blocks) * rare_stride, blockIdx.x - hit_blocks, gridDim.x - hit_blocks);
         return;
     }
     const AS4 FhRender& P = *(const AS4 FhRender*)&S->P;
     const uint32_t T = P.tiles[P.n_levels - 1];
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t n0 = S->fp_count[0], n_all = n0 + S->fp_count[1];
-    const uint32_t waves = hit_blocks * (256 / WAVE);
-    for (uint32_t wi = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE; wi < n_all; wi += waves) {
+    for (uint32_t wi = blockIdx.x; wi < n_all; wi += hit_blocks) {
         const uint32_t fi = uni(wi < n0 ? S->fp_list[0][wi] : S->fp_list[1][wi - n0]);
         const uint32_t px = (fi & 0xFFFFu) * T + (lane % T), py = (fi >> 16) * T + (lane / T);
         const uint64_t zb = (px < P.width && py < P.height) ? S->zbuf[(size_t)py * P.width + px] : 0;
