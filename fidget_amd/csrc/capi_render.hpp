@@ -598,8 +598,8 @@ static fhip_status upload_frame(fhip_ctx* ctx, const fhip_tape* tape, RenderSetu
         fb.clear[k] = (uint32_t*)clear[k].p; fb.clear_words[k] = clear[k].bytes / 4; fb.fill[k] = clear[k].fill;
         if (clear[k].p) most = std::max(most, clear[k].bytes);
     }
-    const unsigned blocks = (unsigned)std::max<size_t>(2, std::min<size_t>((size_t)ctx->n_cu * 8, (most + 256 * 64 - 1) / (256 * 64)));
-    FH_KLAUNCH(k_frame_begin, dim3(blocks), dim3(256), 0, ctx->stream, fb);
+    const unsigned blocks = (unsigned)std::max<size_t>(8, std::min<size_t>((size_t)ctx->n_cu * 32, (most + 64 * 64 - 1) / (64 * 64)));
+    FH_KLAUNCH(k_frame_begin, dim3(blocks), dim3(WAVE), 0, ctx->stream, fb);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sg.ev, ctx->stream));
     sg.used = true;
@@ -1224,7 +1224,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         const uint32_t z_lo = (uint32_t)k * P.slab, z_hi = z_lo + P.slab;
         auto classify_work = [&] {
             launch(ctx, FHIP_K_OTHER, [&] {
-                FH_KLAUNCH(k_classify3d, dim3(class_blocks + (rare ? FH_RARE_BLOCKS : 0u)), dim3(256), 0, ctx->stream, dS, R.asm_points ? 1 : 0, (uint32_t)class_blocks,
+                FH_KLAUNCH(k_classify3d, dim3(class_blocks + (rare ? FH_RARE_BLOCKS : 0u)), dim3(P.slab / 8 > 16 ? 256 : WAVE), 0, ctx->stream, dS, R.asm_points ? 1 : 0, (uint32_t)class_blocks,
                            rare_file(ctx, dS), ctx->rare_stride);
             });
             if (P.max_regs > R.S.leaf_asm_regs && !rare)      // (rare mode: in the blocks behind k_classify3d's)
@@ -1331,7 +1331,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     }
     FH_SPAN(4);
     if (last_tail_idx >= 0) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_leaves[last_tail_idx], 0));   // the third stream is serial: the last slab's normals
-    launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_finish3d, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p, ctx->host_flags); });
+    launch(ctx, FHIP_K_OTHER, [&] { FH_KLAUNCH(k_finish3d, dim3(ctx->n_cu * 16), dim3(WAVE), 0, ctx->stream, dS0, d_out, std::max<uint32_t>(ctx->forked, 1u), (uint32_t*)ctx->sticky.p, ctx->host_flags); });
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->launch_failed) { ctx->launch_failed = false; return FHIP_ERR_HIP; }   // (message in fhip_last_error)
     ctx->async_pending = out_is_device != 0;

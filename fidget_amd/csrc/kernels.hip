@@ -1338,6 +1338,8 @@ template <int CLS, int NR, int ZB, bool FULL>
 FH_DEV void leaves3d_body(FhRenderState* S, char* file, uint32_t first, uint32_t stride);
 // (rare mode, capi_render.hpp: the blocks behind `class_blocks` are the slab's launch for leaves of more than 32 registers - none, nearly
 // always - with their register files in HBM, `rare_stride` bytes each from `rare_file`: a wave per block)
+// (workgroups of one wave - two layer groups per footprint - for slabs of up to 16 layers: beside a leaf kernel that fills the machine a workgroup
+// of four waves waits for four free slots of one compute unit; deep slabs - the 128 layers of a frame without z - keep eight layer groups)
 __global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge01, uint32_t class_blocks, char* rare_file, uint32_t rare_stride) {
     if (blockIdx.x >= class_blocks) {
         if (threadIdx.x < WAVE) leaves3d_body<2, 0, 1, true>(S, rare_file + (size_t)(blockIdx.x - class_blocks) * rare_stride, blockIdx.x - class_blocks, gridDim.x - class_blocks);
@@ -1348,7 +1350,7 @@ __global__ void __launch_bounds__(256) k_classify3d(FhRenderState* S, int merge0
     const uint32_t T = P.tiles[P.n_levels - 1];
     const uint32_t fw = (P.width + T - 1) / T, fh = (P.height + T - 1) / T;
     const uint32_t layers = P.slab / T;
-    const uint32_t fl = threadIdx.x % FH_CLASSIFY_FP, lg = threadIdx.x / FH_CLASSIFY_FP, n_lg = 256 / FH_CLASSIFY_FP;
+    const uint32_t fl = threadIdx.x % FH_CLASSIFY_FP, lg = threadIdx.x / FH_CLASSIFY_FP, n_lg = blockDim.x / FH_CLASSIFY_FP;
     const uint32_t fi = blockIdx.x * FH_CLASSIFY_FP + fl;
     if (threadIdx.x < FH_CLASSIFY_FP) { mx_s[threadIdx.x] = 0; any_s[threadIdx.x] = 0; }
     __syncthreads();
@@ -1591,11 +1593,13 @@ struct FhFrameBegin {
     uint32_t* roots_dst; const uint32_t* roots_src; uint32_t roots_words;
     uint32_t* clear[3]; unsigned long long clear_words[3]; uint32_t fill[3];
 };
-__global__ void __launch_bounds__(256) k_frame_begin(FhFrameBegin a) {
-    if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < a.state_words; i += blockDim.x) a.state_dst[i] = a.state_src[i];
-    } else if (blockIdx.x == 1) {
-        for (uint32_t i = threadIdx.x; i < a.roots_words; i += blockDim.x) a.roots_dst[i] = a.roots_src[i];
+// (workgroups of one wave - they find room beside another frame's leaf kernel where four waves together wait: 64 us against 11 -; the
+// first four copy the state, the next four the root groups: grid >= 8)
+__global__ void __launch_bounds__(WAVE) k_frame_begin(FhFrameBegin a) {
+    if (blockIdx.x < 4) {
+        for (uint32_t i = blockIdx.x * WAVE + threadIdx.x; i < a.state_words; i += 4 * WAVE) a.state_dst[i] = a.state_src[i];
+    } else if (blockIdx.x < 8) {
+        for (uint32_t i = (blockIdx.x - 4) * WAVE + threadIdx.x; i < a.roots_words; i += 4 * WAVE) a.roots_dst[i] = a.roots_src[i];
     }
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
     for (int k = 0; k < 3; k++) {
