@@ -670,7 +670,7 @@ def main():
         dist.destroy_process_group()
 
 
-TUNING_CAP = 50         # untimed frames beyond --warmup the library's arrangement tuner may take PER KIND of frame (3 windows of 12 queued frames + the verdict; `tuning_frames`
+TUNING_CAP = 64         # untimed frames beyond --warmup the library's arrangement tuner may take PER KIND of frame (windows of 12, 12 + 4 and 12 queued frames + the verdict; `tuning_frames`
                         # in the line is the sum over the kinds timed - default path, general path - and says how many it took)
 XGMI_LINK_GBS = 64.0        # one direction of one xGMI link as a collective sees it (7 links x ~153 GB/s both ways per GPU, MI355X_MICROARCH.md; ~85 % of 76)
 
