@@ -1060,7 +1060,8 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     {
         const size_t need = std::max(std::max(R.lds_tiles_big, R.lds_points_big), R.lds_normals_big);
         const size_t stride = (need + 255) / 256 * 256;
-        ctx->rare_now = R.split && R.asm_tiles && R.asm_points && R.asm_normals && !R.big_hbm && P.max_regs > 32 && ctx->host_flags && ctx->host_flags[2] == 0 &&
+        // (a root tape of <= 32 registers has no large leaves, but its per-slab levels still launch fh_tiles_v64 for the other slot list)
+        ctx->rare_now = R.split && R.asm_tiles && R.asm_points && R.asm_normals && !R.big_hbm && ctx->host_flags && ctx->host_flags[2] == 0 &&
                         stride * FH_RARE_BLOCKS * 4 <= ((size_t)256 << 20);
         if (ctx->rare_now) {
             HIP_TRY(ctx, ctx->rare_scratch.ensure(stride * FH_RARE_BLOCKS * 4));      // (a set's state buffer holds four slab contexts)
@@ -1454,11 +1455,12 @@ static fhip_status run_on_lane(fhip_ctx* ctx, uint32_t max_lanes, size_t bytes, 
 // window, so a queue of mixed frames never decides and keeps the prior: lanes for tapes with transcendental opcodes, the stage pipeline
 // otherwise.  Both arrangements give the same image, bit for bit (tests/test_gpu_parity.py).
 static constexpr uint32_t TUNE_SKIP = 4, TUNE_WIN = 8;       // (round 6: 40 frames to a verdict instead of 48)
-// The lanes' window is followed by TUNE_TAIL more frames on the lanes: K lanes finish their frames K at a time (heavy frames: every 5.5 ms four
+// The lanes' window is followed by more frames on the lanes: K lanes finish their frames K at a time (heavy frames: every 5.5 ms four
 // images of the general path of prospero.vm 1024^3), and a window whose last frame is the last frame ON the lanes ends with a group of one -
 // a lone frame that takes half the time: such a window read 1.07 ms per frame where the lanes run at 1.38 and the stage pipeline at 1.34
 // (profiles/r06b/experiments.txt 8).  With frames queued behind it the window's last group is a whole one.
-static constexpr uint32_t TUNE_TAIL = 4;
+// (with K lanes - option frame_lanes, 4 - the lanes' window is K frames of settling, 2 K frames timed, K frames behind them)
+static uint32_t tune_lanes(const fhip_ctx* ctx) { return (uint32_t)std::min(std::max(ctx->opt.frame_lanes, 2), 8); }
 static void lane_tune_release(fhip_ctx* ctx) {
     for (auto& t : ctx->lane_tune)
         for (hipEvent_t& e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -1504,7 +1506,7 @@ static bool lane_mode(fhip_ctx* ctx, const fhip_tape* tape, const fhip_render3d_
         for (int w = 0; w < 3; w++) {
             float t = 0.0f;
             ok = ok && hipEventElapsedTime(&t, T.ev[2 * w], T.ev[2 * w + 1]) == hipSuccess && t > 0.0f;
-            T.ms[w] = t / TUNE_WIN;
+            T.ms[w] = t / (w == 1 ? 2 * tune_lanes(ctx) : TUNE_WIN);
         }
         (void)hipGetLastError();
         T.lanes = ok ? T.ms[1] < 0.97f * std::min(T.ms[0], T.ms[2]) : prior;
@@ -1532,12 +1534,14 @@ static fhip_status frame_queued(fhip_ctx* ctx, int out_is_device) {      // (the
         fhip_ctx::LaneTune& T = ctx->lane_tune[(size_t)ctx->tune_cur];
         ctx->tune_cur = -1;
         T.n++;
-        if (T.n == TUNE_SKIP || T.n == TUNE_SKIP + TUNE_WIN) {
-            hipEvent_t& e = T.ev[2 * T.phase + (T.n == TUNE_SKIP ? 0 : 1)];
+        const uint32_t K = tune_lanes(ctx);
+        const uint32_t skip = T.phase == 1 ? K : TUNE_SKIP, win = T.phase == 1 ? 2 * K : TUNE_WIN, tail = T.phase == 1 ? K : 0u;
+        if (T.n == skip || T.n == skip + win) {
+            hipEvent_t& e = T.ev[2 * T.phase + (T.n == skip ? 0 : 1)];
             if (!e) HIP_TRY(ctx, hipEventCreate(&e));
             HIP_TRY(ctx, hipEventRecord(e, ctx->stream));
         }
-        if (T.n == TUNE_SKIP + TUNE_WIN + (T.phase == 1 ? TUNE_TAIL : 0u)) { T.phase++; T.n = 0; }
+        if (T.n == skip + win + tail) { T.phase++; T.n = 0; }
     }
     return FHIP_OK;
 }
