@@ -794,7 +794,7 @@ class Interp:
             if form == "RR":
                 self.read_b(VU)
             self.idx_off()
-            fast_div = base == "DIV" and form == "RI" and self.kind == "columns" and self.zb >= 2 and not (set(EXP.split(",")) & {"nofastdiv", "nodiv"})
+            fast_div = base == "DIV" and form == "RI" and self.kind in ("columns", "bulk") and self.zb >= 2 and not (set(EXP.split(",")) & {"nofastdiv", "nodiv"})
             if form != "RR" and not fast_div:      # (the division by an immediate fills VU itself, where it takes the general sequence)
                 self.imm_b(VU)
             A, B = (VT, VU) if form != "IR" else (VU, VT)

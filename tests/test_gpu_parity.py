@@ -853,3 +853,29 @@ def test_rare_mode_takes_the_large_tapes_it_does_not_expect():
     hip.sync()
     w = O.render3d(bear_o, 64)[0]
     assert (d["depth"] == w["depth"]).all()
+
+
+def test_bulk_division_by_an_immediate_bit_exact_over_the_float_range():
+    """The assembly interpreters' division by an immediate (gen_interp.py f_div_imm: the reciprocal's refinement once per op, the quotient
+    two samples per instruction, no v_div_scale_f32 while both operands lie within 2^-40 .. 2^40 - otherwise the general sequence for
+    the op) through fhip_float_eval on 4 M numerators covering every exponent, both signs, denormals, zeros, infinities and NaNs, for
+    divisors of every kind: IEEE division (numpy's), bit for bit."""
+    hip = F.default_context()
+    n = 1 << 22
+    rng = np.random.default_rng(12)
+    xs = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    xs[: 1 << 16] = (np.arange(1 << 16, dtype=np.uint32) << 16) | 0x8001
+    xs[1 << 16: (1 << 16) + 8] = [0, 0x80000000, 0x7F800000, 0xFF800000, 0x7FC00000, 1, 0x007FFFFF, 0x00800000]
+    xf = xs.view(np.float32)
+    # (mostly ordinary numerators too: a block of values within the short sequence's range, so that whole ops take it)
+    mid = (rng.standard_normal(n).astype(np.float32) * np.float32(1000.0))
+    zero = np.zeros(n, np.float32)
+    for c in (0.3, 3.0, -7.77, 1e-5, 123456.7, 2.0 ** -40, 1.5 * 2.0 ** -41, 2.0 ** 40, 2.0 ** 41, 1e-30, 1e30, 1.0, -0.5, float(np.float32(1.0000001))):
+        ctx = F.Context()
+        s = F.Shape(ctx, ctx.div(ctx.x(), float(np.float32(c))), hip=hip)
+        for name, arg in (("every exponent", xf), ("ordinary", mid)):
+            with np.errstate(all="ignore"):
+                want = (arg / np.float32(c)).astype(np.float32)
+            got = np.asarray(s.eval_float_slice(arg, zero, zero), np.float32)
+            ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), f"x / {c} ({name}): {(~ok).sum()} of {n} differ, first at input bits {hex(int(arg.view(np.uint32)[np.nonzero(~ok)[0][0]]))}"
