@@ -201,7 +201,8 @@ class Interp:
         self.trans = trans   # handlers for the transcendental / modulo / rng opcodes (they call the routines of gen_trans.py)
         self.t_base = 128    # ... whose register window starts here (behind the register file)
         self.wide_trans = False   # the four-sample routines are embedded too (window of gen_trans.WIDE_V registers)
-        self.exp2 = False         # EXP by the hand-written two-sample expf (gen_trans.exp_pair) inside the handler
+        self.exp2 = False         # EXP / LN / SIN / COS by the hand-written two-sample routines (gen_trans.exp_pair ...) inside the handlers
+        self.sincos2 = False      # ... SIN / COS alone (the bulk kernels: no table registers)
         self.t_prefix = "fh_t_"   # ... and whose labels start with this (every kernel embeds its own copies)
         self.lg = {2: 1, 4: 2, 8: 3}[zb]
         self.hl = HSTRIDE_LOG2
@@ -657,7 +658,7 @@ class Interp:
                 self.idx_off()
                 if "no" + fn in EXP.split(","):       # experiment: what the routine costs (a copy in its place)
                     return self.write_out(VT)
-                if fn in ("exp", "ln", "sin", "cos") and self.exp2:      # expf / logf / sinf / cosf by hand, two samples at a time (gen_trans.exp_pair ...)
+                if (fn in ("exp", "ln", "sin", "cos") and self.exp2) or (fn in ("sin", "cos") and self.sincos2):      # expf / logf / sinf / cosf by hand, two samples at a time (gen_trans.exp_pair ...)
                     import gen_trans
                     slow, join = a.label(fn + "_special"), a.label(fn + "_done")
                     consts, special, two = gen_trans.hand(fn)
@@ -1894,7 +1895,10 @@ def gen_bulk(a, nr, zb, off, trans=None):
     if trans:
         it.t_base = FILE + nr * zb
         it.t_prefix = f"fh_tb{nr}_"
-        it.wide_trans = "sincos"     # four samples per call for sin / cos (they fit the 26-register window: the mesher's gyroid is made of them)
+        # sinf / cosf written by hand inside the handlers (gen_trans.sincos_pair: the mesher's gyroid is made of them - the compiled four-sample
+        # routines were 424 instructions per call, these are 130 for four samples: the mesher's leaf stage at depth 10 0.214 -> 0.201 s)
+        it.sincos2 = EXP != "compiledsincos"      # (experiment: the compiled four-sample routines, as until round 6)
+        it.wide_trans = False if it.sincos2 else "sincos"
     kernel_header(a, name, 32, n_vgpr)
     a(f"""
 	s_load_dwordx2 {S_TAPE}, {S_KERNARG}, 0x0
@@ -1921,7 +1925,7 @@ def gen_bulk(a, nr, zb, off, trans=None):
     it.emit()
     if trans:
         import gen_trans
-        gen_trans.embed(a, trans, v_base=it.t_base, prefix=it.t_prefix, wide="sincos")
+        gen_trans.embed(a, trans, v_base=it.t_base, prefix=it.t_prefix, sincos2=it.sincos2, wide=False if it.sincos2 else "sincos")
     return name
 
 

@@ -449,7 +449,7 @@ def hand(fn):
 COPIES = []      # (prefix, v_base, routine names) of every embed(): the probe kernel (gen_interp.py gen_trans_probe) reaches each copy
 
 
-def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=None):
+def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=None, sincos2=False):
     """the routines as `<prefix><name>` with their vector registers in v[v_base .. v_base + 25] (a second kernel with another register
     window embeds its own copies: `s_branch` reaches 128 KB); s_map: the ten scalar registers s0..s9 go to (default s86..s95; pairs
     must stay even-aligned pairs), the return address always to s[96:97]; wide: also the four-sample routines FUNCS4, and a window of
@@ -457,7 +457,7 @@ def embed(a, path, v_base=V_BASE, prefix="fh_t_", s_map=None, wide=False, exp2=N
     txt = open(path).read()
     # wide = True: all of FUNCS4 in a window of WIDE_V registers; "sincos": sin4 / cos4 only, which fit the ordinary window of MAX_V
     extra = FUNCS4 if wide is True else (["sin4", "cos4"] if wide == "sincos" else [])
-    COPIES.append((prefix, v_base, FUNCS + extra + (["sin2", "cos2", "exp2", "ln2"] if exp2 else [])))
+    COPIES.append((prefix, v_base, FUNCS + extra + (["sin2", "cos2", "exp2", "ln2"] if exp2 else (["sin2", "cos2"] if sincos2 else []))))
     if exp2:       # the kernel's handlers hold the two-sample expf written by hand (exp_pair): its table
         exp_table(a, prefix)
     for f in FUNCS + extra:
