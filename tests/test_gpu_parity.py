@@ -824,6 +824,8 @@ def test_rare_mode_takes_the_large_tapes_it_does_not_expect():
     again - the same image."""
     hip = F.HipContext(0)
     hip.set_option("frame_lanes", 0)
+    for opt in ("no_asm", "no_split", "no_asm_tiles", "no_tiles_v", "no_asm_normals", "no_columns_t"):      # (rare mode is the assembly kernels' frames': whatever the environment says)
+        hip.set_option(opt, 0)
     big, big_o = F.Shape.from_vm(model_path("prospero.vm"), hip=hip), O.Shape.from_vm(model_path("prospero.vm"))
     want = O.render3d(big_o, 128)[0]
     a = F.render3d(big, 128)[0]             # (a new context: the launches on their own)
