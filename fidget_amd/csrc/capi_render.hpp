@@ -1003,6 +1003,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     const bool fpipe = ctx->frame_pipeline && ctx->use_pipeline && !ctx->profiling && out_is_device && !huge;
     struct StreamGuard { fhip_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     bool frames_queued = false;     // the frame before this one is still under way (the caller queues frames back to back)
+    bool lone = false;              // ... a pipelined context's frame with nothing under way before it
     if (fpipe) {
         // (rotate: the current set goes to the back of the ring, the set used longest ago comes forward)
         for (uint32_t i = 0; i < ctx->extra_sets; i++) std::swap(static_cast<FrameBufs&>(*ctx), ctx->others[i]);
@@ -1016,7 +1017,14 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         // serialises against it, measured in round 2), two frames' root levels in flight.
         R.alt_pre = ts.size() == 2 && R.xy_fixed && R.root_invariant && ctx->opt.no_zrep == 0 && ctx->stream3 &&
                     part.n_shards == 1 && part.nx * part.ny * part.nz == 1;
-        hipStream_t const pre_stream = R.alt_pre && (ctx->pre_turn++ & 1u) ? ctx->stream3 : ctx->stream_pre;
+        // A frame ALONE - nothing of the frame before it is under way - keeps its coarse levels on the caller's stream: there is nothing to run
+        // beside, and every change of stream is an event's latency (prospero.vm 1024^3, one frame alone: 0.388 -> 0.33 ms).  The frame queued
+        // behind it takes the pre-pass stream as before and overlaps with it.
+        lone = !frames_queued;
+#ifdef FH_EXP_NO_LONE      // experiment (tools/build_lib_variant.py): every frame's coarse levels on the pre-pass stream, as until round 6
+        lone = false;
+#endif
+        hipStream_t const pre_stream = lone ? main_stream : (R.alt_pre && (ctx->pre_turn++ & 1u) ? ctx->stream3 : ctx->stream_pre);
         ctx->stream = pre_stream;
         if (ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(pre_stream, ctx->ev_done, 0));   // the set's previous frame has left it
     }
@@ -1044,7 +1052,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
     // chains on the side stream.  The two coarse levels of a frame are one dependent chain of ~0.9 ms that, on one stream, set
     // the frame rate; split, the root level of frame n + 1 runs beside level 1 and the slabs of frame n, and the side stream
     // carries level 1 + the (now few) slab steps of its own frame.  (A frame alone sees no difference: the same chain.)
-    const bool l1_side = fpipe && pre > 1 && ctx->stream2 &&
+    const bool l1_side = fpipe && !lone && pre > 1 && ctx->stream2 &&
                          ctx->use_pipeline && R.slab_hi - R.slab_lo > 1 && n_groups > 0;
     // (option side_only_l1, on: the side stream - the busiest one of a pipelined frame, 0.43 ms of the 0.526 - carries level 1's evaluate + prune
     // launches and nothing else: the flags of level 1's tapes are set at the end of the root level on the pre-pass stream, and what follows
@@ -1114,7 +1122,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         // (one coarse level - root tiles of 32^3 - in a pipelined frame: that level IS the frame's longest chain and the pre-pass stream the
         // pacemaker of the pipeline, so what follows its push - the flags of the parked parents, the frame mark, the fork of the slab
         // contexts - goes to the head of the tile chains on the side stream, which has no level 1 to carry in such a frame)
-        if (fpipe && pipe && pre == 1 && side_stream && side_stream != ctx->stream) {
+        if (fpipe && !lone && pipe && pre == 1 && side_stream && side_stream != ctx->stream) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_l0, 0));
             ctx->stream = side_stream;
@@ -1131,7 +1139,7 @@ static fhip_status render3d_frame(fhip_ctx* ctx, const fhip_tape* tape, const fh
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         if (ctx->stream != side_stream) HIP_TRY(ctx, hipStreamWaitEvent(side_stream, ctx->ev_fork, 0));
     }
-    if (fpipe) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
+    if (fpipe && ctx->stream != main_stream) {      // the rest of the frame is the caller's stream's (and the side stream's, which waits for the fork above)
         // (one coarse level, its tail on the side stream, and tile chains to follow there: the caller's stream waits for the first tile
         // chain's event, which lies behind everything queued so far - no event of its own for that)
         const bool implied = pipe && pre == 1 && n_groups > 0 && side_stream && ctx->stream == side_stream;
